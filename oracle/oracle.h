@@ -1,0 +1,274 @@
+/*
+ * oracle.h -- CPU restatement ("oracle") of the BAD SLAM direct bundle-adjustment hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load liboracle.so.  The product path (badslam_amd/) never
+ * includes, links or calls anything in this directory.
+ *
+ * Parity pinning: the reference (ETH3D/badslam) ships no golden vectors, fixtures or
+ * known-answer files for this path and cannot be compiled here (CUDA + Eigen + Qt + ...).
+ * The oracle is pinned by (1) the reference's own closed-loop test criteria restated in
+ * tests/test_oracle_closed_loop.py (applications/badslam/src/badslam/test/ *.cc tolerances),
+ * (2) Jacobians checked against the reference's sympy derivation
+ * (applications/badslam/scripts/jacobians_derivation.py, fixtures in tests/golden/) and
+ * (3) central finite differences of the oracle's own residual functions.
+ *
+ * All arithmetic is IEEE binary32 unless stated (compiled with -ffp-contract=off); the small
+ * dense solves are done in binary64 exactly where the reference does so (Eigen LDLT on
+ * H.cast<double>()).
+ *
+ * Paths cited below are relative to /root/reference/; B/ = applications/badslam/src/badslam/.
+ */
+#ifndef BADSLAM_ORACLE_H_
+#define BADSLAM_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants: B/kernels.cuh:38-93, B/cost_function.cuh:44-52,105-109 ---- */
+#define ORC_INVALID_DEPTH_BIT 0x8000u
+#define ORC_UNKNOWN_DEPTH 65535u
+#define ORC_SURFEL_ACTIVE_FLAG 1u
+#define ORC_MERGE_BUFFER_COUNT 3
+#define ORC_INVALID_INDEX 4294967295u
+#define ORC_COS_NORMAL_COMPAT 0.76604f
+
+enum {
+  ORC_SURFEL_X = 0, ORC_SURFEL_Y = 1, ORC_SURFEL_Z = 2, ORC_SURFEL_NORMAL = 3,
+  ORC_SURFEL_RADIUS_SQ = 4, ORC_SURFEL_COLOR = 5, ORC_SURFEL_DESC1 = 6, ORC_SURFEL_DESC2 = 7,
+  ORC_SURFEL_ACCUM0 = 8, /* ... ACCUM8 = 16 */
+  ORC_SURFEL_DATA_ATTRS = 8, ORC_SURFEL_ATTRS = 17
+};
+
+enum { ORC_KF_ACTIVE = 0, ORC_KF_COVIS_ACTIVE = 1, ORC_KF_INACTIVE = 2 };
+
+/* PinholeCamera4f: fx, fy, cx, cy in the pixel-CORNER convention (libvis/src/libvis/camera.h:1740). */
+typedef struct {
+  float fx, fy, cx, cy;
+  int32_t width, height;
+} orc_camera;
+
+/* B/surfel_projection.cuh:129-149 (DepthParameters). cfactor is dense row-major,
+ * cf_height x cf_width = ((H-1)/cell+1) x ((W-1)/cell+1), indexed (py/cell, px/cell). */
+typedef struct {
+  float a;
+  float raw_to_float_depth;
+  float baseline_fx;
+  int32_t cell;
+  float* cfactor;
+  int32_t cf_width, cf_height;
+} orc_depth_params;
+
+/* SE3f stored like Sophus: unit quaternion (x,y,z,w) + translation. */
+typedef struct {
+  float q[4];
+  float t[3];
+} orc_se3;
+
+/* B/keyframe.h:50-237.  Images are dense row-major. color is RGBA u8 with A = luma. */
+typedef struct {
+  int32_t width, height;             /* depth image size */
+  int32_t color_width, color_height;
+  uint16_t* depth;
+  uint16_t* normals;
+  uint16_t* radius;
+  uint8_t* color;
+  orc_se3 global_T_frame;
+  float frame_T_global[12];          /* row-major 3x4, cached on every pose set */
+  float global_R_frame[9];           /* row-major 3x3 */
+  int32_t activation;
+  float min_depth, max_depth;
+  int32_t id;
+  int32_t last_active_in_ba_iteration;
+  int32_t last_covis_in_ba_iteration;
+} orc_keyframe;
+
+/* Surfel SoA: ORC_SURFEL_ATTRS rows of `capacity` floats; row r at data + r*capacity.
+ * B/direct_ba.cc:122, B/kernels.cuh:69-93. */
+typedef struct {
+  float* data;
+  uint8_t* active;
+  uint32_t capacity;
+  uint32_t surfels_size;
+  uint32_t surfel_count;
+} orc_surfels;
+
+/* ---- SE3 (libvis/third_party/sophus/sophus/se3.hpp:293-313,440-467; so3.hpp:282-320,421-465) ---- */
+void orc_se3_identity(orc_se3* T);
+void orc_se3_exp(const float tangent[6], orc_se3* out);
+void orc_se3_log(const orc_se3* T, float tangent[6]);
+void orc_se3_mul(const orc_se3* a, const orc_se3* b, orc_se3* out);
+void orc_se3_inverse(const orc_se3* a, orc_se3* out);
+void orc_se3_matrix3x4(const orc_se3* T, float m[12]);
+void orc_se3_rotation(const orc_se3* T, float r[9]);
+/* B/keyframe.h:160-172 */
+void orc_keyframe_set_global_T_frame(orc_keyframe* kf, const orc_se3* global_T_frame);
+
+/* ---- keyframe preprocessing (B/keyframe.cc:81-158) ---- */
+/* B/cuda_image_processing.cu:165-175 */
+void orc_compute_brightness(const uint8_t* rgb, int width, int height, uint8_t* rgba);
+/* B/cuda_depth_processing.cu:134-264 */
+void orc_compute_normals(const orc_camera* cam, const orc_depth_params* dp, const uint16_t* in_depth,
+                         uint16_t* out_depth, uint16_t* out_normals);
+/* B/cuda_depth_processing.cu:289-360 */
+void orc_compute_point_radii(const orc_camera* cam, float raw_to_float_depth, const uint16_t* depth,
+                             uint16_t* radius, uint16_t* out_depth);
+/* B/cuda_depth_processing.cu:391-465 */
+void orc_compute_min_max_depth(const uint16_t* depth, int width, int height, float raw_to_float_depth,
+                               float* min_depth, float* max_depth);
+/* Whole ctor #2: fills kf->depth/normals/radius/color (caller-allocated) from raw inputs. */
+void orc_keyframe_from_images(orc_keyframe* kf, const orc_camera* depth_cam, const orc_depth_params* dp,
+                              const uint16_t* depth_image, const uint8_t* rgb_image,
+                              const orc_se3* global_T_frame);
+
+/* ---- elementary pieces exposed for unit tests ---- */
+/* Software restatement of the clamp-addressed bilinear normalized-float sampler
+ * (B/keyframe.cc:67-73); returns luma in [0,1]. */
+float orc_sample_luma(const uint8_t* rgba, int width, int height, float x, float y);
+/* B/util.cuh:62-69 */
+float orc_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t raw);
+uint32_t orc_pack_normal10(float x, float y, float z);       /* B/util_nvcc_only.cuh:66-84 */
+void orc_unpack_normal10(uint32_t v, float n[3]);           /* B/util_nvcc_only.cuh:87-95 (renormalised) */
+uint16_t orc_pack_normal8(float x, float y);                /* B/util.cuh:121-135 */
+void orc_unpack_normal8(uint16_t v, float n[3]);            /* B/util.cuh:138-146 */
+uint16_t orc_float_to_half(float f);
+float orc_half_to_float(uint16_t h);
+
+/* Per (surfel, keyframe) evaluation used by tests for Jacobian checks: evaluates association
+ * and, if associated, the three raw residuals, weights and pose / surfel Jacobians.
+ * Returns 1 if associated. out layout documented in oracle_core.c. */
+typedef struct {
+  int32_t associated;
+  int32_t px, py;
+  int32_t color_valid;
+  float calibrated_depth;
+  float depth_residual, depth_weight, depth_inv_stddev;
+  float depth_jac_pose[6];
+  float depth_jac_surfel;
+  float desc_residual[2], desc_weight[2];
+  float desc_jac_pose[2][6];
+  float desc_jac_surfel[2];
+  float grad[4]; /* grad_x_1, grad_y_1, grad_x_2, grad_y_2 */
+} orc_pair_eval;
+int orc_evaluate_pair(const orc_camera* color_cam, const orc_camera* depth_cam, const orc_depth_params* dp,
+                      const orc_keyframe* kf, const float frame_T_global[12],
+                      const orc_surfels* s, uint32_t surfel_index, orc_pair_eval* out);
+
+/* ---- pose optimisation ---- */
+/* B/kernel_opt_pose.cc:39-97 + B/kernel_opt_pose.cu:251-383 + B/gauss_newton.cuh:46-93.
+ * H: 21 floats (row-major upper triangle), b: 6 floats.  Accumulation in surfel order
+ * (binary32 adds unless accumulate_double != 0). Returns number of depth-associated surfels. */
+uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camera* color_cam,
+                                    const orc_camera* depth_cam, const orc_depth_params* dp,
+                                    const orc_keyframe* kf, const float frame_T_global[12],
+                                    const orc_surfels* s, float H[21], float b[6],
+                                    float* residual_sum, int accumulate_double);
+/* B/direct_ba_alternating.cc:42-283.  Returns number of GN iterations done; *converged set. */
+int orc_estimate_frame_pose(int use_depth, int use_desc, const orc_camera* color_cam,
+                            const orc_camera* depth_cam, const orc_depth_params* dp,
+                            const orc_keyframe* kf, const orc_se3* global_T_frame_init,
+                            const orc_surfels* s, orc_se3* global_T_frame_out, int* converged);
+/* B/convergence_analysis.h:43-51 */
+int orc_is_scale1_pose_converged(const float x[6]);
+/* Solve H x = b like Eigen's H.cast<double>().selfadjointView<Upper>().ldlt().solve(b) for n<=8. */
+void orc_ldlt_solve(int n, const double* H_full_rowmajor, const double* b, double* x);
+
+/* ---- surfel activation, geometry ---- */
+/* B/kernel_surfel_activation.cc:39-67 */
+void orc_update_surfel_activation(const orc_camera* depth_cam, const orc_depth_params* dp,
+                                  orc_keyframe* const* kfs, int num_kfs, uint32_t surfels_size,
+                                  orc_surfels* s);
+/* B/kernel_opt_geometry.cc:39-77 */
+void orc_update_surfel_normals(const orc_camera* depth_cam, const orc_depth_params* dp,
+                               orc_keyframe* const* kfs, int num_kfs, orc_surfels* s);
+/* B/kernel_opt_geometry.cc:80-201 */
+void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_camera* color_cam,
+                                     const orc_camera* depth_cam, const orc_depth_params* dp,
+                                     orc_keyframe* const* kfs, int num_kfs, orc_surfels* s);
+
+/* ---- surfel lifecycle ---- */
+/* B/kernel_supporting_surfels.cc:40-165.  supporting: ORC_MERGE_BUFFER_COUNT planes of
+ * height*width u32 (full resolution allocation like the reference, indexed (py/cell, px/cell)).
+ * Deterministic restatement: surfels claim cells in ascending surfel index (the reference's
+ * atomicCAS winner is arbitrary). */
+void orc_determine_supporting_surfels(int merge, float merge_dist_factor, const orc_camera* depth_cam,
+                                      const orc_depth_params* dp, const orc_keyframe* kf,
+                                      orc_surfels* s, uint32_t* supporting);
+/* B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-183.  covis: indices into kfs of the
+ * keyframes co-visible with kf (only used when filter_new_surfels).  Deterministic: within a
+ * sparse cell the pixel with the lowest linear index wins.  Returns the number created. */
+uint32_t orc_create_surfels_for_keyframe(int filter_new_surfels, int min_observation_count,
+                                         const orc_camera* color_cam, const orc_camera* depth_cam,
+                                         const orc_depth_params* dp, const orc_keyframe* kf,
+                                         orc_keyframe* const* kfs, const int* covis, int n_covis,
+                                         orc_surfels* s, uint32_t* supporting);
+/* B/kernel_delete_surfels.cc:40-120 */
+void orc_delete_surfels_and_update_radii(int min_observation_count, const orc_camera* depth_cam,
+                                         const orc_depth_params* dp, orc_keyframe* const* kfs,
+                                         int num_kfs, orc_surfels* s);
+/* B/kernel_compact_surfels.cu:159-279 */
+void orc_compact_surfels(orc_surfels* s);
+
+/* ---- intrinsics (B/kernel_opt_intrinsics.cc:39-281) ---- */
+void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_intrinsics,
+                             orc_keyframe* const* kfs, int num_kfs, const orc_camera* color_cam,
+                             const orc_camera* depth_cam, orc_depth_params* dp, const orc_surfels* s,
+                             orc_camera* out_color_cam, orc_camera* out_depth_cam, float* out_a);
+
+/* ---- BA drivers ---- */
+typedef struct {
+  int use_depth_residuals, use_descriptor_residuals;
+  int optimize_depth_intrinsics, optimize_color_intrinsics;
+  int do_surfel_updates, optimize_poses, optimize_geometry;
+  int min_iterations, max_iterations;
+  int window_start, window_end;
+  int increase_ba_iteration_count;
+  int min_observation_count;
+  float surfel_merge_dist_factor;
+  int pcg_max_inner_iterations;
+  int pcg_gauge_keyframe;       /* -1: keyframe 0 (the reference uses rand() % K, B/direct_ba_pcg.cc:328) */
+} orc_ba_options;
+
+typedef struct {
+  int iterations_done;
+  int converged;
+  int pose_gn_steps_total;      /* sum over keyframes and iterations of GN steps in EstimateFramePose */
+  int pose_gn_rounds_max_sum;   /* sum over iterations of the max GN steps of any keyframe */
+  int pcg_inner_steps_total;
+} orc_ba_stats;
+
+/* B/direct_ba_alternating.cc:285-738 (alternating scheme).  covis_lists/covis_counts give the
+ * co-visibility list of each keyframe (may be NULL: treated as fully connected).
+ * ba_iteration_count / last_ba_iteration_count mirror DirectBA members. */
+typedef struct {
+  orc_camera color_cam, depth_cam;
+  orc_depth_params dp;
+  orc_keyframe** kfs;
+  int num_kfs;
+  const int* const* covis_lists;
+  const int* covis_counts;
+  orc_surfels* surfels;
+  uint32_t* supporting;     /* ORC_MERGE_BUFFER_COUNT * height * width */
+  int ba_iteration_count, last_ba_iteration_count;
+} orc_ba_state;
+
+void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* opt, orc_ba_stats* stats);
+/* B/direct_ba_pcg.cc:43-819 */
+void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_ba_stats* stats);
+
+/* Full cost evaluation (all residuals over all keyframe x surfel pairs, no Jacobians):
+ * the "CPU cost-evaluation path" timed as cpu_baseline.  Returns the summed robust cost. */
+double orc_evaluate_cost(int use_depth, int use_desc, const orc_camera* color_cam,
+                         const orc_camera* depth_cam, const orc_depth_params* dp,
+                         orc_keyframe* const* kfs, int num_kfs, const orc_surfels* s,
+                         uint64_t* num_residuals);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

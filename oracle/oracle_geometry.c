@@ -1,0 +1,181 @@
+/* oracle_geometry.c -- surfel activation and the per-surfel geometry step.
+ * Test infrastructure only (see oracle.h). */
+#include "oracle_internal.h"
+
+/* B/kernel_surfel_activation.cc:39-67, B/kernel_surfel_activation.cu:38-94 */
+void orc_update_surfel_activation(const orc_camera* depth_cam, const orc_depth_params* dp,
+                                  orc_keyframe* const* kfs, int num_kfs, uint32_t surfels_size,
+                                  orc_surfels* s) {
+  if (surfels_size == 0) return;
+  orc_surfels view = *s;
+  view.surfels_size = surfels_size;
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < surfels_size; ++i) {
+    uint8_t flag = s->active[i] & (uint8_t)~ORC_SURFEL_ACTIVE_FLAG;
+    for (int k = 0; k < num_kfs && !(flag & ORC_SURFEL_ACTIVE_FLAG); ++k) {
+      const orc_keyframe* kf = kfs[k];
+      if (!kf || kf->activation != ORC_KF_ACTIVE) continue;
+      proj_params p = make_proj_params(depth_cam, dp, &view, kf, kf->frame_T_global);
+      proj_result r;
+      if (orc_project_associate(&p, i, &r, NULL)) flag = ORC_SURFEL_ACTIVE_FLAG;
+    }
+    s->active[i] = flag;
+  }
+}
+
+/* Normals pass shared by B/kernel_opt_geometry.cc:39-77 and :108-134; kernels
+ * B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update). */
+void orc_update_surfel_normals(const orc_camera* depth_cam, const orc_depth_params* dp,
+                               orc_keyframe* const* kfs, int num_kfs, orc_surfels* s) {
+  if (s->surfels_size == 0) return;
+  float* a0 = srow(s, ORC_SURFEL_ACCUM0 + 0); float* a1 = srow(s, ORC_SURFEL_ACCUM0 + 1);
+  float* a2 = srow(s, ORC_SURFEL_ACCUM0 + 2); float* a3 = srow(s, ORC_SURFEL_ACCUM0 + 3);
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < s->surfels_size; ++i) {
+    if (!(s->active[i] & ORC_SURFEL_ACTIVE_FLAG)) continue;
+    a0[i] = a1[i] = a2[i] = a3[i] = 0;
+    for (int k = 0; k < num_kfs; ++k) {
+      const orc_keyframe* kf = kfs[k];
+      if (!kf || kf->activation == ORC_KF_INACTIVE) continue;
+      proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
+      proj_result r;
+      if (!orc_project_associate(&p, i, &r, NULL)) continue;
+      float m[3];
+      orc_unpack_normal8(kf->normals[(size_t)r.py * kf->width + r.px], m);
+      const v3 g = m33_mul(kf->global_R_frame, v3_make(m[0], m[1], m[2]));
+      a0[i] += g.x; a1[i] += g.y; a2[i] += g.z; a3[i] += 1.f;
+    }
+    const float count = a3[i];
+    if (count >= 1) surfel_set_normal(s, i, v3_scale(1.f / count, v3_make(a0[i], a1[i], a2[i])));
+  }
+}
+
+/* B/kernel_opt_geometry.cc:80-201 */
+void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_camera* color_cam,
+                                     const orc_camera* depth_cam, const orc_depth_params* dp,
+                                     orc_keyframe* const* kfs, int num_kfs, orc_surfels* s) {
+  if (s->surfels_size == 0) return;
+  orc_update_surfel_normals(depth_cam, dp, kfs, num_kfs, s);
+
+  const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
+  float* acc[9];
+  for (int k = 0; k < 9; ++k) acc[k] = srow(s, ORC_SURFEL_ACCUM0 + k);
+
+  if (!use_desc) {
+    /* depth only: B/kernel_opt_geometry.cu:381-399 (reset 0..1), :417-460, :487-508 */
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i < s->surfels_size; ++i) {
+      if (!(s->active[i] & ORC_SURFEL_ACTIVE_FLAG)) continue;
+      acc[0][i] = 0; acc[1][i] = 0;
+      for (int k = 0; k < num_kfs; ++k) {
+        const orc_keyframe* kf = kfs[k];
+        if (!kf || kf->activation == ORC_KF_INACTIVE) continue;
+        proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
+        proj_result r;
+        if (!orc_project_associate(&p, i, &r, NULL)) continue;
+        const v3 rn = m34_rotate(kf->frame_T_global, r.normal);
+        const float inv_std = depth_inv_stddev(unp_nx(&p.unp, (float)r.px), unp_ny(&p.unp, (float)r.py),
+                                               r.calibrated_depth, rn, dp->baseline_fx);
+        const float depth_jacobian = -inv_std;
+        const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
+        const float raw = inv_std * v3_dot(rn, v3_sub(u, r.local_position));
+        const float w = depth_residual_weight(raw);
+        const float weighted_jacobian = w * depth_jacobian;
+        acc[0][i] += weighted_jacobian * depth_jacobian;
+        acc[1][i] += weighted_jacobian * raw;
+      }
+      const float Hs = acc[0][i];
+      if (Hs > 1e-6f) {
+        const v3 gp = surfel_position(s, i);
+        const float t = -1.f * acc[1][i] / Hs;
+        const v3 n = surfel_normal(s, i);
+        surfel_set_position(s, i, v3_add(gp, v3_scale(t, n)));
+      }
+    }
+    return;
+  }
+
+  /* joint position + descriptors: B/kernel_opt_geometry.cu:41-63 (reset 0..8), :119-230, :273-353 */
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < s->surfels_size; ++i) {
+    if (!(s->active[i] & ORC_SURFEL_ACTIVE_FLAG)) continue;
+    for (int k = 0; k < 9; ++k) acc[k][i] = 0;
+    for (int k = 0; k < num_kfs; ++k) {
+      const orc_keyframe* kf = kfs[k];
+      if (!kf || kf->activation == ORC_KF_INACTIVE) continue;
+      proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
+      proj_result r;
+      if (!orc_project_associate(&p, i, &r, NULL)) continue;
+      const float* F = kf->frame_T_global;
+      const v3 rn = m34_rotate(F, r.normal);
+      if (use_depth) {
+        const float inv_std = depth_inv_stddev(unp_nx(&p.unp, (float)r.px), unp_ny(&p.unp, (float)r.py),
+                                               r.calibrated_depth, rn, dp->baseline_fx);
+        const float depth_jacobian = -inv_std;
+        const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
+        const float raw = inv_std * v3_dot(rn, v3_sub(u, r.local_position));
+        const float w = depth_residual_weight(raw);
+        acc[0][i] += w * depth_jacobian * depth_jacobian;
+        acc[6][i] += w * raw * depth_jacobian;
+      }
+      float c[2];
+      if (transform_depth_to_color(r.pxx, r.pxy, &d2c, &c[0], &c[1])) {
+        float t1[2], t2[2], raw1, raw2, g[4];
+        orc_tangent_projections(r.global_position, r.normal, srow(s, ORC_SURFEL_RADIUS_SQ)[i], F, color_cam, t1, t2);
+        orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &raw1, &raw2);
+        orc_descriptor_gradient(kf, c, t1, t2, g);
+        const v3 lp = r.local_position;
+        const float term1 = -color_cam->fx * (rn.x * lp.z - rn.z * lp.x);
+        const float term2 = -color_cam->fy * (rn.y * lp.z - rn.z * lp.y);
+        const float term3 = 1.f / (lp.z * lp.z);
+        const float jp1 = -(g[0] * term1 + g[1] * term2) * term3;
+        const float jp2 = -(g[2] * term1 + g[3] * term2) * term3;
+        const float jd = -1.f;
+        const float w1 = descriptor_residual_weight(raw1);
+        const float wr1 = w1 * raw1;
+        const float w2 = descriptor_residual_weight(raw2);
+        const float wr2 = w2 * raw2;
+        acc[0][i] += w1 * jp1 * jp1 + w2 * jp2 * jp2;
+        acc[1][i] += w1 * jp1 * jd;
+        acc[3][i] += w1 * jd * jd;
+        acc[6][i] += wr1 * jp1 + wr2 * jp2;
+        acc[7][i] += wr1 * jd;
+        acc[2][i] += w2 * jp2 * jd;
+        acc[5][i] += w2 * jd * jd;
+        acc[8][i] += wr2 * jd;
+      }
+    }
+    /* B/kernel_opt_geometry.cu:273-353 */
+    float H00 = acc[0][i], H01 = acc[1][i], H02 = acc[2][i], H11 = acc[3][i], H12 = acc[4][i], H22 = acc[5][i];
+    const float kEpsilon = 1e-6f;
+    H00 += kEpsilon; H11 += kEpsilon; H22 += kEpsilon;
+    H00 = sqrtf(H00);
+    H01 = H01 / H00;
+    H11 = sqrtf(H11 - H01 * H01);
+    H02 = H02 / H00;
+    H12 = (H12 - H02 * H01) / H11;
+    H22 = sqrtf(H22 - H02 * H02 - H12 * H12);
+    const float b0 = acc[6][i], b1 = acc[7][i], b2 = acc[8][i];
+    const float y0 = b0 / H00;
+    const float y1 = (b1 - H01 * y0) / H11;
+    const float y2 = (b2 - H02 * y0 - H12 * y1) / H22;
+    const float x2 = y2 / H22;
+    const float x1 = (y1 - H12 * x2) / H11;
+    const float x0 = (y0 - H02 * x2 - H01 * x1) / H00;
+    if (x0 != 0) {
+      const v3 gp = surfel_position(s, i);
+      const v3 n = surfel_normal(s, i);
+      surfel_set_position(s, i, v3_sub(gp, v3_scale(x0, n)));
+    }
+    if (x1 != 0) {
+      float d = srow(s, ORC_SURFEL_DESC1)[i];
+      d -= x1;
+      srow(s, ORC_SURFEL_DESC1)[i] = fmaxf(-180.f, fminf(180.f, d));
+    }
+    if (x2 != 0) {
+      float d = srow(s, ORC_SURFEL_DESC2)[i];
+      d -= x2;
+      srow(s, ORC_SURFEL_DESC2)[i] = fmaxf(-180.f, fminf(180.f, d));
+    }
+  }
+}

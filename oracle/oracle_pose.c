@@ -1,0 +1,168 @@
+/* oracle_pose.c -- pose normal equations and the per-frame Gauss-Newton loop.
+ * Test infrastructure only (see oracle.h). */
+#include "oracle_internal.h"
+
+/* One residual into (H, b): B/gauss_newton.cuh:59-92, row-major upper triangle. */
+static inline void add_residual_f(float* H, float* b, float raw, float w, const float* J) {
+  int k = 0;
+  for (int row = 0; row < 6; ++row)
+    for (int col = row; col < 6; ++col) H[k++] += w * J[row] * J[col];
+  const float wr = w * raw;
+  for (int i = 0; i < 6; ++i) b[i] += wr * J[i];
+}
+static inline void add_residual_d(double* H, double* b, float raw, float w, const float* J) {
+  int k = 0;
+  for (int row = 0; row < 6; ++row)
+    for (int col = row; col < 6; ++col) H[k++] += (double)(w * J[row] * J[col]);
+  const float wr = w * raw;
+  for (int i = 0; i < 6; ++i) b[i] += (double)(wr * J[i]);
+}
+
+/* B/kernel_opt_pose.cc:39-97, kernel B/kernel_opt_pose.cu:251-383. */
+uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camera* color_cam,
+                                    const orc_camera* depth_cam, const orc_depth_params* dp,
+                                    const orc_keyframe* kf, const float F[12], const orc_surfels* s,
+                                    float H[21], float b[6], float* residual_sum, int accumulate_double) {
+  proj_params p = make_proj_params(depth_cam, dp, s, kf, F);
+  const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
+  float Hf[21] = {0}, bf[6] = {0};
+  double Hd[21] = {0}, bd[6] = {0};
+  double cost = 0;
+  uint32_t count = 0;
+  for (uint32_t i = 0; i < s->surfels_size; ++i) {
+    proj_result r;
+    if (!orc_project_associate(&p, i, &r, NULL)) continue;
+    ++count;
+    float J[6], raw;
+    if (use_depth) {
+      const v3 nl = m34_rotate(F, r.normal);
+      const float inv_std = depth_inv_stddev(unp_nx(&p.unp, (float)r.px), unp_ny(&p.unp, (float)r.py),
+                                             r.calibrated_depth, nl, dp->baseline_fx);
+      const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
+      raw = inv_std * v3_dot(nl, v3_sub(u, r.local_position));
+      J[0] = inv_std * nl.x;
+      J[1] = inv_std * nl.y;
+      J[2] = inv_std * nl.z;
+      J[3] = inv_std * (-nl.y * u.z + nl.z * u.y);
+      J[4] = inv_std * (nl.x * u.z - nl.z * u.x);
+      J[5] = inv_std * (-nl.x * u.y + nl.y * u.x);
+      const float w = depth_residual_weight(raw);
+      if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else add_residual_f(Hf, bf, raw, w, J);
+      cost += weighted_depth_residual(raw);
+    }
+    if (use_desc) {
+      float c[2];
+      /* B/kernel_opt_pose.cu:303-353: if the colour-pixel transform fails, nothing is added. */
+      if (!transform_depth_to_color(r.pxx, r.pxy, &d2c, &c[0], &c[1])) continue;
+      float t1[2], t2[2], raw1, raw2, g[4];
+      orc_tangent_projections(r.global_position, r.normal, srow(s, ORC_SURFEL_RADIUS_SQ)[i], F, color_cam, t1, t2);
+      orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &raw1, &raw2);
+      orc_descriptor_gradient(kf, c, t1, t2, g);
+      const v3 ls = r.local_position;
+      const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
+      for (int k = 0; k < 2; ++k) {
+        const float gx = g[2 * k + 0] * color_cam->fx;
+        const float gy = g[2 * k + 1] * color_cam->fy;
+        J[0] = -gx * inv_z;
+        J[1] = -gy * inv_z;
+        J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
+        J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
+        J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
+        J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+        raw = k ? raw2 : raw1;
+        const float w = descriptor_residual_weight(raw);
+        if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else add_residual_f(Hf, bf, raw, w, J);
+      }
+      cost += weighted_descriptor_residual(raw1);
+    }
+  }
+  for (int k = 0; k < 21; ++k) H[k] = accumulate_double ? (float)Hd[k] : Hf[k];
+  for (int k = 0; k < 6; ++k) b[k] = accumulate_double ? (float)bd[k] : bf[k];
+  if (residual_sum) *residual_sum = (float)cost;
+  return count;
+}
+
+/* B/convergence_analysis.h:43-51 */
+int orc_is_scale1_pose_converged(const float x[6]) {
+  const float translation_threshold = 1e-06f;
+  const float rotation_threshold = 1e-07f;
+  float sq = 0.f;
+  for (int i = 0; i < 3; ++i) sq += x[i] * x[i];
+  const float f = translation_threshold / rotation_threshold;
+  for (int i = 3; i < 6; ++i) { const float v = x[i] * f; sq += v * v; }
+  return sq < translation_threshold;
+}
+
+/* Eigen::LDLT (symmetric diagonal pivoting, lower) + solve with the pseudo-inverse rule on D
+ * (Eigen/src/Cholesky/LDLT.h: |D_ii| <= numeric_limits<double>::min() -> 0).  n <= 8. */
+void orc_ldlt_solve(int n, const double* Hfull, const double* b, double* x) {
+  double A[64];
+  int perm[8];
+  for (int i = 0; i < n * n; ++i) A[i] = Hfull[i];
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  for (int k = 0; k < n; ++k) {
+    /* pivot: largest |diagonal| in the remaining block */
+    int piv = k; double best = fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i) if (fabs(A[i * n + i]) > best) { best = fabs(A[i * n + i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < n; ++j) { double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+      for (int j = 0; j < n; ++j) { double t = A[j * n + k]; A[j * n + k] = A[j * n + piv]; A[j * n + piv] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    const double d = A[k * n + k];
+    if (fabs(d) > 2.2250738585072014e-308) {
+      for (int i = k + 1; i < n; ++i) A[i * n + k] /= d;
+      for (int i = k + 1; i < n; ++i)
+        for (int j = k + 1; j <= i; ++j) {
+          A[i * n + j] -= A[i * n + k] * d * A[j * n + k];
+          A[j * n + i] = A[i * n + j];
+        }
+    } else {
+      for (int i = k + 1; i < n; ++i) A[i * n + k] = 0;
+    }
+  }
+  double y[8];
+  for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+  for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= A[i * n + j] * y[j];
+  for (int i = 0; i < n; ++i) { const double d = A[i * n + i]; y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0; }
+  for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] -= A[j * n + i] * y[j];
+  for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+}
+
+/* B/direct_ba_alternating.cc:42-283 */
+int orc_estimate_frame_pose(int use_depth, int use_desc, const orc_camera* color_cam,
+                            const orc_camera* depth_cam, const orc_depth_params* dp,
+                            const orc_keyframe* kf, const orc_se3* init, const orc_surfels* s,
+                            orc_se3* out, int* converged_out) {
+  orc_se3 est = *init;
+  int converged = 0, iteration;
+  for (iteration = 0; iteration < 30; ++iteration) {
+    orc_se3 inv;
+    orc_se3_inverse(&est, &inv);
+    float F[12];
+    orc_se3_matrix3x4(&inv, F);
+    float H21[21], b6[6];
+    if (s->surfels_size == 0) {
+      memset(H21, 0, sizeof(H21)); memset(b6, 0, sizeof(b6));
+    } else {
+      orc_accumulate_pose_coeffs(use_depth, use_desc, color_cam, depth_cam, dp, kf, F, s, H21, b6, NULL, 0);
+    }
+    double H[36], bd[6], xd[6];
+    int k = 0;
+    for (int row = 0; row < 6; ++row)
+      for (int col = row; col < 6; ++col) { H[row * 6 + col] = H21[k]; H[col * 6 + row] = H21[k]; ++k; }
+    for (int i = 0; i < 6; ++i) bd[i] = b6[i];
+    orc_ldlt_solve(6, H, bd, xd);
+    float x[6], mx[6];
+    for (int i = 0; i < 6; ++i) { x[i] = (float)xd[i]; mx[i] = -1.f * x[i]; }
+    orc_se3 upd, next;
+    orc_se3_exp(mx, &upd);
+    orc_se3_mul(&est, &upd, &next);
+    est = next;
+    converged = orc_is_scale1_pose_converged(x);
+    if (converged) { ++iteration; break; }
+  }
+  *out = est;
+  if (converged_out) *converged_out = converged;
+  return iteration;
+}
