@@ -1,0 +1,129 @@
+"""ctypes declarations for include/badslam_hip.h (the C ABI of the HIP backend).
+
+There is no CPU fallback: if libbadslam_hip.so is missing or cannot be loaded this module raises,
+and every entry point returns non-zero (-> BackendError) when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbadslam_hip.so")
+
+SURFEL_ATTRIBUTE_COUNT = 17
+MERGE_BUFFER_COUNT = 3
+KF_ACTIVE, KF_COVISIBLE_ACTIVE, KF_INACTIVE = 0, 1, 2
+
+# surfel rows, applications/badslam/src/badslam/kernels.cuh:69-88
+SURFEL_X, SURFEL_Y, SURFEL_Z, SURFEL_NORMAL, SURFEL_RADIUS_SQUARED, SURFEL_COLOR, SURFEL_DESCRIPTOR1, SURFEL_DESCRIPTOR2 = range(8)
+SURFEL_ACCUM0 = 8
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class DepthParams(C.Structure):
+    _fields_ = [("a", C.c_float), ("raw_to_float_depth", C.c_float), ("baseline_fx", C.c_float),
+                ("sparse_surfel_cell_size", C.c_int32), ("cfactor", C.c_void_p),
+                ("cfactor_pitch_bytes", C.c_uint32), ("cfactor_width", C.c_int32), ("cfactor_height", C.c_int32)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("depth_pitch_bytes", C.c_uint32),
+                ("normals", C.c_void_p), ("normals_pitch_bytes", C.c_uint32),
+                ("radius", C.c_void_p), ("radius_pitch_bytes", C.c_uint32),
+                ("color", C.c_void_p), ("color_pitch_bytes", C.c_uint32)]
+
+
+class Keyframe(C.Structure):
+    _fields_ = [("frame", Frame), ("global_T_frame", C.c_float * 7), ("activation", C.c_int32)]
+
+
+class Surfels(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("pitch_bytes", C.c_uint32), ("active", C.c_void_p),
+                ("surfels_size", C.c_uint32), ("capacity", C.c_uint32)]
+
+
+class PCGOptions(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("optimize_poses", "optimize_geometry", "optimize_depth_intrinsics",
+                                       "optimize_color_intrinsics", "use_depth_residuals", "use_descriptor_residuals",
+                                       "max_inner_iterations", "gauge_keyframe")]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# name -> (restype, argtypes); every symbol declared in include/badslam_hip.h
+SIGNATURES = {
+    "bahip_last_error": (C.c_char_p, []),
+    "bahip_device_count": (C.c_int, []),
+    "bahip_context_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    "bahip_context_destroy": (None, [C.c_void_p]),
+    "bahip_context_synchronize": (C.c_int, [C.c_void_p]),
+    "bahip_context_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "bahip_malloc_pitch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),
+    "bahip_free": (C.c_int, [C.c_void_p]),
+    "bahip_memcpy_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
+    "bahip_memset_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t]),
+    "bahip_compute_brightness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "bahip_compute_normals": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(DepthParams), C.c_void_p, C.c_uint32,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "bahip_compute_point_radii_and_remove_isolated_pixels": (
+        C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "bahip_compute_min_max_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float,
+                                              C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bahip_set_intrinsics": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Camera), C.POINTER(DepthParams)]),
+    "bahip_set_keyframes": (C.c_int, [C.c_void_p, C.POINTER(Keyframe), C.c_int]),
+    "bahip_get_keyframe_poses": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "bahip_update_surfel_activation": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.c_uint32]),
+    "bahip_update_surfel_normals": (C.c_int, [C.c_void_p, C.POINTER(Surfels)]),
+    "bahip_optimize_geometry_iteration": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels)]),
+    "bahip_accumulate_pose_estimation_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Frame), C.POINTER(C.c_float),
+                                                          C.POINTER(Surfels), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bahip_estimate_frame_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Frame), C.POINTER(C.c_float),
+                                            C.POINTER(Surfels), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bahip_estimate_keyframe_poses": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_float),
+                                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bahip_determine_supporting_surfels": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(Frame), C.POINTER(C.c_float),
+                                                     C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bahip_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                                    C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bahip_delete_surfels_and_update_radii": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_uint32)]),
+    "bahip_compact_surfels": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Surfels)]),
+    "bahip_optimize_intrinsics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.POINTER(Camera),
+                                            C.POINTER(Camera), C.POINTER(C.c_float)]),
+    "bahip_pcg_iteration": (C.c_int, [C.c_void_p, C.POINTER(PCGOptions), C.POINTER(Surfels), C.POINTER(Camera),
+                                      C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "bahip_debug_evaluate_pairs": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_float), C.POINTER(Surfels),
+                                             C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float)]),
+    "bahip_last_stage_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "bahip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP backend and attach prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BackendError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BackendError(load().bahip_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,349 @@
+// ba_device.h -- device-side arithmetic of the direct BA backend (gfx950, wave64).
+//
+// Restates, for HIP, the residual / association arithmetic defined by the reference's device
+// headers (B/ = applications/badslam/src/badslam/ in ETH3D/badslam):
+//   B/cuda_matrix.cuh:37-141, B/surfel_projection.cuh:40-207, B/util.cuh:62-153,
+//   B/util_nvcc_only.cuh:51-115, B/robust_weighting.cuh:39-86, B/cost_function.cuh:44-254,
+//   B/surfel_projection_nvcc_only.cuh:48-127,302-511.
+// gfx950 has no texture sampling path (tex2D is unavailable), so the bilinear, clamp-addressed,
+// normalised-float colour fetch of B/keyframe.cc:67-73 is done in software on the luma byte.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/badslam_hip.h"
+
+namespace bahip {
+
+constexpr uint16_t kInvalidDepthBit = 1 << 15;       // B/kernels.cuh:38
+constexpr uint16_t kUnknownDepth = 65535;            // B/kernels.cuh:41
+constexpr uint8_t kSurfelActiveFlag = 1;             // B/kernels.cuh:44
+constexpr uint32_t kInvalidIndex = 4294967295u;      // B/kernels.cuh:54
+constexpr float kCosNormalCompat = 0.76604f;         // B/kernels.cuh:58
+constexpr uint32_t kDeletedSurfelBits = 0x7fffffffu; // CUDART_NAN_F, B/kernel_delete_surfels.cu:145
+
+enum SurfelRow {  // B/kernels.cuh:69-88
+  kSurfelX = 0, kSurfelY = 1, kSurfelZ = 2, kSurfelNormal = 3, kSurfelRadiusSquared = 4,
+  kSurfelColor = 5, kSurfelDescriptor1 = 6, kSurfelDescriptor2 = 7, kSurfelAccum0 = 8
+};
+
+struct Vec3 { float x, y, z; };
+__device__ __forceinline__ Vec3 mk3(float x, float y, float z) { Vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ Vec3 operator+(Vec3 a, Vec3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ Vec3 operator*(float m, Vec3 b) { return mk3(m * b.x, m * b.y, m * b.z); }
+__device__ __forceinline__ float dot3(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float sqlen3(Vec3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ float norm3(Vec3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {
+  return mk3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
+}
+
+// Pose of one keyframe as the kernels consume it: frame_T_global (3x4 row-major) and
+// global_R_frame (3x3 row-major), both cached whenever the pose is set (B/keyframe.h:160-172).
+struct KfPose {
+  float F[12];
+  float GR[9];
+};
+
+// Device-side keyframe table entry.
+struct KfEntry {
+  const uint16_t* depth;
+  const uint16_t* normals;
+  const uint16_t* radius;
+  const uint8_t* color;
+  uint32_t depth_pitch, normals_pitch, radius_pitch, color_pitch;
+  KfPose pose;
+  float global_T_frame[7];   // Sophus layout: qx qy qz qw tx ty tz
+  int32_t activation;
+};
+
+// One frame whose pose is being estimated (batched Gauss-Newton, kernels_pose.hip).
+constexpr int kHbStride = 28;   // 21 H (row-major upper triangle) + 6 b + 1 pad
+struct PoseWork {
+  float F[12];        // frame_T_global at the current linearisation point
+  float T[7];         // global_T_frame estimate (Sophus layout)
+  int32_t kf_index;   // entry of the frame table providing the images
+  int32_t done;       // converged or iteration cap reached (or skipped)
+  int32_t iterations;
+  int32_t converged;
+};
+
+// Everything that is constant over a sweep; passed to kernels by value (kernarg -> SGPRs).
+struct Intrinsics {
+  // depth camera: corner-convention projector + centre-convention unprojector (B/surfel_projection.h:42-71)
+  float fx, fy, cx, cy;
+  float fx_inv, fy_inv, cx_inv, cy_inv;
+  int width, height;
+  // colour camera (PixelCornerProjector; PixelCenterProjector shares fx, fy)
+  float cfx, cfy, ccx, ccy;
+  int cwidth, cheight;
+  // DepthToColorPixelCorner (B/surfel_projection.h:105-124)
+  float d2c_fx, d2c_fy, d2c_cx, d2c_cy;
+  // DepthParameters
+  float a, raw_to_float_depth, baseline_fx;
+  int cell;
+  const float* cfactor;
+  uint32_t cfactor_pitch;
+  int cf_width, cf_height;
+};
+
+struct SurfelsView {
+  float* data;
+  uint32_t pitch;   // bytes
+  uint8_t* active;
+  uint32_t size;
+  __device__ __forceinline__ float* row(int r) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(data) + (size_t)r * pitch); }
+};
+
+template <typename T>
+__device__ __forceinline__ T pitched_load(const T* base, uint32_t pitch, int y, int x) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T));
+}
+template <typename T>
+__device__ __forceinline__ T* pitched_ptr(T* base, uint32_t pitch, int y, int x) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T));
+}
+
+// ---- packing (B/util.cuh:121-153, B/util_nvcc_only.cuh:66-95) ------------------------------------
+__device__ __forceinline__ float ten_bit_signed_to_float(uint32_t value) {
+  const int32_t s = (int32_t)(value << 22) >> 22;  // sign-extend the low 10 bits
+  return (float)s * (1.0f / 511.0f);
+}
+__device__ __forceinline__ Vec3 unpack_normal10(uint32_t v) {
+  Vec3 n = mk3(ten_bit_signed_to_float(v), ten_bit_signed_to_float(v >> 10), ten_bit_signed_to_float(v >> 20));
+  const float factor = 1.0f / norm3(n);
+  return factor * n;
+}
+__device__ __forceinline__ uint32_t float_to_ten_bit_signed(float value) {
+  const int16_t v = (int16_t)(value * 511.0f + ((value > 0) ? 0.5f : -0.5f));
+  return 0x03ffu & (uint16_t)v;
+}
+__device__ __forceinline__ uint32_t pack_normal10(Vec3 n) {
+  return float_to_ten_bit_signed(n.x) | (float_to_ten_bit_signed(n.y) << 10) | (float_to_ten_bit_signed(n.z) << 20);
+}
+__device__ __forceinline__ Vec3 unpack_normal8(uint16_t v) {
+  Vec3 r;
+  r.x = (float)(int8_t)(v & 0xff) * (1.0f / 127.0f);
+  r.y = (float)(int8_t)(v >> 8) * (1.0f / 127.0f);
+  const float z = 1 - r.x * r.x - r.y * r.y;
+  r.z = -sqrtf((z > 0.f) ? z : 0.f);
+  return r;
+}
+__device__ __forceinline__ uint16_t pack_normal8(float x, float y) {
+  const int8_t sx = (int8_t)(x * 127.0f + ((x > 0) ? 0.5f : -0.5f));
+  const int8_t sy = (int8_t)(y * 127.0f + ((y > 0) ? 0.5f : -0.5f));
+  return (uint16_t)((uint16_t)(uint8_t)sx | ((uint16_t)(uint8_t)sy << 8));
+}
+
+// ---- transforms ----------------------------------------------------------------------------------
+__device__ __forceinline__ Vec3 transform34(const float* F, Vec3 p) {
+  return mk3(F[0] * p.x + F[1] * p.y + F[2] * p.z + F[3],
+             F[4] * p.x + F[5] * p.y + F[6] * p.z + F[7],
+             F[8] * p.x + F[9] * p.y + F[10] * p.z + F[11]);
+}
+__device__ __forceinline__ Vec3 rotate34(const float* F, Vec3 p) {
+  return mk3(F[0] * p.x + F[1] * p.y + F[2] * p.z,
+             F[4] * p.x + F[5] * p.y + F[6] * p.z,
+             F[8] * p.x + F[9] * p.y + F[10] * p.z);
+}
+__device__ __forceinline__ Vec3 mul33(const float* R, Vec3 p) {
+  return mk3(R[0] * p.x + R[1] * p.y + R[2] * p.z,
+             R[3] * p.x + R[4] * p.y + R[5] * p.z,
+             R[6] * p.x + R[7] * p.y + R[8] * p.z);
+}
+
+// ---- depth ---------------------------------------------------------------------------------------
+// B/util.cuh:62-69
+__device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t raw) {
+  const float inv_depth = 1.0f / (raw_to_float_depth * raw);
+  return 1.f / (inv_depth + cfactor * expf(-a * inv_depth));
+}
+__device__ __forceinline__ float cfactor_at(const Intrinsics& in, int px, int py) {
+  return pitched_load(in.cfactor, in.cfactor_pitch, py / in.cell, px / in.cell);
+}
+__device__ __forceinline__ float unp_nx(const Intrinsics& in, float px) { return in.fx_inv * px + in.cx_inv; }
+__device__ __forceinline__ float unp_ny(const Intrinsics& in, float py) { return in.fy_inv * py + in.cy_inv; }
+__device__ __forceinline__ Vec3 unproject(const Intrinsics& in, int x, int y, float depth) {
+  return mk3(depth * (in.fx_inv * x + in.cx_inv), depth * (in.fy_inv * y + in.cy_inv), depth);
+}
+// B/cost_function.cuh:81-88
+__device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, Vec3 nl, float baseline_fx) {
+  return (0.1f * fabsf(nl.x * nx + nl.y * ny + nl.z) * (depth * depth)) / baseline_fx;
+}
+__device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float depth, Vec3 nl, float baseline_fx) {
+  return baseline_fx / (0.1f * fabsf(nl.x * nx + nl.y * ny + nl.z) * (depth * depth));
+}
+
+// ---- robust weights (B/robust_weighting.cuh:39-86; parameters B/cost_function.cuh:44-52,105-109) ---
+__device__ __forceinline__ float tukey_weight10(float r) {
+  if (fabsf(r) < 10.f) { const float q = r / 10.f; const float t = 1.f - q * q; return t * t; }
+  return 0.f;
+}
+__device__ __forceinline__ float huber_weight10(float r) {
+  const float a = fabsf(r);
+  return (a < 10.f) ? 1.f : (10.f / a);
+}
+__device__ __forceinline__ float depth_residual_weight(float r) { return 1.f * tukey_weight10(r); }
+__device__ __forceinline__ float descriptor_residual_weight(float r) { return 1.f * 1e-2f * huber_weight10(r); }
+
+// ---- association -----------------------------------------------------------------------------------
+struct Assoc {
+  Vec3 local;        // surfel position in the keyframe frame
+  Vec3 nl;           // surfel normal in the keyframe frame
+  float depth;       // calibrated depth of the associated pixel
+  int px, py;
+  float pxx, pxy;    // float pixel position, pixel-corner convention
+};
+
+// B/surfel_projection_nvcc_only.cuh:332-359 with IsAssociatedWithPixel :48-127; the order of the
+// rejection tests is the reference's.  A NaN position (deleted surfel) is rejected explicitly.
+// `gp`, `gn`: global position and (decoded, renormalised) global normal of the surfel.
+template <bool kFreeSpace>
+__device__ __forceinline__ bool project_associate(const Intrinsics& in, const float* F, const uint16_t* depth_img,
+                                                  uint32_t depth_pitch, const uint16_t* normals_img,
+                                                  uint32_t normals_pitch, Vec3 gp, Vec3 gn, Assoc* r,
+                                                  bool* free_space_violation) {
+  r->local.z = F[8] * gp.x + F[9] * gp.y + F[10] * gp.z + F[11];
+  if (!(r->local.z > 0.f)) return false;
+  r->local.x = F[0] * gp.x + F[1] * gp.y + F[2] * gp.z + F[3];
+  r->local.y = F[4] * gp.x + F[5] * gp.y + F[6] * gp.z + F[7];
+  r->pxx = in.fx * (r->local.x / r->local.z) + in.cx;
+  r->pxy = in.fy * (r->local.y / r->local.z) + in.cy;
+  if (!(r->pxx >= 0.f) || !(r->pxy >= 0.f) || !(r->pxx < (float)in.width) || !(r->pxy < (float)in.height)) return false;
+  r->px = (int)r->pxx;
+  r->py = (int)r->pxy;
+  if (r->px >= in.width || r->py >= in.height) return false;
+
+  const uint16_t measured = pitched_load(depth_img, depth_pitch, r->py, r->px);
+  if (measured & kInvalidDepthBit) return false;
+  r->depth = raw_to_calibrated_depth(in.a, cfactor_at(in, r->px, r->py), in.raw_to_float_depth, measured);
+  r->nl = rotate34(F, gn);
+  const float thr = 10.f * depth_stddev(unp_nx(in, (float)r->px), unp_ny(in, (float)r->py), r->depth, r->nl, in.baseline_fx);
+  if (kFreeSpace) {
+    const float diff = r->depth - r->local.z;
+    if (diff > thr) { *free_space_violation = true; return false; }
+    else if (diff < -thr) return false;
+  } else {
+    if (fabsf(r->local.z - r->depth) > thr) return false;
+  }
+  const float dist = norm3(r->local);
+  if ((1.0f / dist) * dot3(r->local, r->nl) > 0) return false;
+  const Vec3 m = unpack_normal8(pitched_load(normals_img, normals_pitch, r->py, r->px));
+  if (dot3(r->nl, m) < kCosNormalCompat) return false;
+  return true;
+}
+
+// ---- colour sampling -------------------------------------------------------------------------------
+__device__ __forceinline__ float luma_texel(const uint8_t* color, uint32_t pitch, int w, int h, int x, int y) {
+  x = max(0, min(x, w - 1));
+  y = max(0, min(y, h - 1));
+  return (float)color[(size_t)y * pitch + 4 * x + 3] * (1.0f / 255.0f);
+}
+// Bilinear luma at unnormalised coords, clamp addressing, texel centres at +0.5 (B/keyframe.cc:67-73).
+__device__ __forceinline__ float sample_luma(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y) {
+  float xb = x - 0.5f, yb = y - 0.5f;
+  if (!(xb >= -1.f)) xb = -1.f;
+  if (xb > (float)w) xb = (float)w;
+  if (!(yb >= -1.f)) yb = -1.f;
+  if (yb > (float)h) yb = (float)h;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = xb - fx, b = yb - fy;
+  const int ix = (int)fx, iy = (int)fy;
+  const float tl = luma_texel(color, pitch, w, h, ix, iy);
+  const float tr = luma_texel(color, pitch, w, h, ix + 1, iy);
+  const float bl = luma_texel(color, pitch, w, h, ix, iy + 1);
+  const float br = luma_texel(color, pitch, w, h, ix + 1, iy + 1);
+  const float top = tl + a * (tr - tl);
+  const float bot = bl + a * (br - bl);
+  return top + b * (bot - top);
+}
+// One sample point of DescriptorJacobianWrtProjectedPosition (B/cost_function.cuh:200-211).
+__device__ __forceinline__ void point_gradient(const uint8_t* color, uint32_t pitch, int w, int h, float qx, float qy,
+                                               float* dx, float* dy) {
+  float mx = fmaxf(0.f, qx - 0.5f), my = fmaxf(0.f, qy - 0.5f);
+  if (!(mx < (float)w)) mx = (float)w;
+  if (!(my < (float)h)) my = (float)h;
+  const int ix = (int)mx, iy = (int)my;
+  const float tx = fmaxf(0.f, fminf(1.f, qx - 0.5f - ix));
+  const float ty = fmaxf(0.f, fminf(1.f, qy - 0.5f - iy));
+  const float tl = luma_texel(color, pitch, w, h, ix, iy);
+  const float tr = luma_texel(color, pitch, w, h, ix + 1, iy);
+  const float bl = luma_texel(color, pitch, w, h, ix, iy + 1);
+  const float br = luma_texel(color, pitch, w, h, ix + 1, iy + 1);
+  *dx = (br - bl) * ty + (tr - tl) * (1 - ty);
+  *dy = (br - tr) * tx + (bl - tl) * (1 - tx);
+}
+
+// B/surfel_projection.cuh:194-207
+__device__ __forceinline__ bool depth_to_color_pixel(const Intrinsics& in, float pxx, float pxy, float* cx, float* cy) {
+  *cx = in.d2c_fx * pxx + in.d2c_cx;
+  *cy = in.d2c_fy * pxy + in.d2c_cy;
+  return *cx >= 0 && *cy >= 0 && (int)(*cx) < in.cwidth && (int)(*cy) < in.cheight;
+}
+
+// B/cost_function.cuh:115-136
+__device__ __forceinline__ void tangent_projections(const Intrinsics& in, const float* F, Vec3 gp, Vec3 gn, float radius_sq,
+                                                    float* t1x, float* t1y, float* t2x, float* t2y) {
+  Vec3 t1 = cross3(gn, (fabsf(gn.x) > 0.9f) ? mk3(0, 1, 0) : mk3(1, 0, 0));
+  t1 = (2.0f * sqrtf(radius_sq / fmaxf(1e-12f, sqlen3(t1)))) * t1;
+  const Vec3 l1 = transform34(F, gp + t1);
+  *t1x = in.cfx * (l1.x / l1.z) + in.ccx;
+  *t1y = in.cfy * (l1.y / l1.z) + in.ccy;
+  Vec3 t2 = cross3(gn, t1);
+  t2 = (2.0f * sqrtf(radius_sq / fmaxf(1e-12f, sqlen3(t2)))) * t2;
+  const Vec3 l2 = transform34(F, gp + t2);
+  *t2x = in.cfx * (l2.x / l2.z) + in.ccx;
+  *t2y = in.cfy * (l2.y / l2.z) + in.ccy;
+}
+
+// Descriptor residuals (B/cost_function.cuh:140-156) and gradients (:191-254) of one pair.
+struct DescEval {
+  float r1, r2;       // raw residuals
+  float gx1, gy1, gx2, gy2;
+};
+template <bool kWithGradient>
+__device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint8_t* color, uint32_t pitch, const float* F,
+                                                Vec3 gp, Vec3 gn, float radius_sq, float cx, float cy, float d1, float d2,
+                                                DescEval* e) {
+  float t1x, t1y, t2x, t2y;
+  tangent_projections(in, F, gp, gn, radius_sq, &t1x, &t1y, &t2x, &t2y);
+  const int w = in.cwidth, h = in.cheight;
+  const float i0 = sample_luma(color, pitch, w, h, cx, cy);
+  const float i1 = sample_luma(color, pitch, w, h, t1x, t1y);
+  const float i2 = sample_luma(color, pitch, w, h, t2x, t2y);
+  e->r1 = (180.f * (i1 - i0)) - d1;
+  e->r2 = (180.f * (i2 - i0)) - d2;
+  if (kWithGradient) {
+    float cdx, cdy, adx, ady, bdx, bdy;
+    point_gradient(color, pitch, w, h, cx, cy, &cdx, &cdy);
+    point_gradient(color, pitch, w, h, t1x, t1y, &adx, &ady);
+    point_gradient(color, pitch, w, h, t2x, t2y, &bdx, &bdy);
+    e->gx1 = 180.f * (adx - cdx);
+    e->gy1 = 180.f * (ady - cdy);
+    e->gx2 = 180.f * (bdx - cdx);
+    e->gy2 = 180.f * (bdy - cdy);
+  }
+}
+
+// ---- surfel loads ----------------------------------------------------------------------------------
+__device__ __forceinline__ Vec3 surfel_position(const SurfelsView& s, uint32_t i) {
+  return mk3(s.row(kSurfelX)[i], s.row(kSurfelY)[i], s.row(kSurfelZ)[i]);
+}
+__device__ __forceinline__ Vec3 surfel_normal(const SurfelsView& s, uint32_t i) {
+  return unpack_normal10(reinterpret_cast<const uint32_t*>(s.row(kSurfelNormal))[i]);
+}
+
+// ---- wave64 reductions -----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+
+}  // namespace bahip

@@ -1,0 +1,58 @@
+// ba_launch.h -- host-callable launch wrappers shared between the kernel translation units and
+// the C-ABI layer (capi.hip).
+#pragma once
+
+#include "ba_device.h"
+
+namespace bahip {
+
+struct SupportingView {
+  uint32_t* b[BAHIP_MERGE_BUFFER_COUNT];
+  uint32_t pitch;
+};
+
+// kernels_preprocess.hip
+void launch_brightness(hipStream_t stream, const uint8_t* rgb, uint32_t rgb_pitch, uint8_t* rgba, uint32_t rgba_pitch, int w, int h);
+void launch_normals_from_depth(hipStream_t stream, const Intrinsics& in, const uint16_t* in_depth, uint32_t in_pitch,
+                               uint16_t* out_depth, uint32_t out_pitch, uint16_t* out_normals, uint32_t normals_pitch);
+void launch_point_radii(hipStream_t stream, const Intrinsics& in, float raw_to_float_depth, const uint16_t* depth,
+                        uint32_t depth_pitch, uint16_t* radius, uint32_t radius_pitch, uint16_t* out_depth, uint32_t out_pitch);
+void launch_min_max_depth(hipStream_t stream, const uint16_t* depth, uint32_t depth_pitch, int w, int h,
+                          float raw_to_float_depth, int* result);
+
+// kernels_surfel.hip
+void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                       uint32_t surfels_size);
+void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
+void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
+                     int num_kfs, const SurfelsView& s);
+
+// kernels_pose.hip
+void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
+                            const void* work, int num_work, const SurfelsView& s, float* Hb);
+void launch_pose_solve(hipStream_t stream, void* work, int num_work, float* Hb, KfEntry* frames, int write_back,
+                       int* not_done_count);
+void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, float* Hb);
+
+void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
+                           const uint32_t* indices, int count, float* out);
+
+// kernels_lifecycle.hip
+void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, int h);
+void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup);
+void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count);
+void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags);
+void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,
+                          const float* covis_T_frame, int n_covis, int min_obs, uint8_t* flags);
+void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags,
+                          const uint32_t* indices, uint32_t surfels_size, const SurfelsView& s);
+void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                          int min_obs, uint32_t* deleted_count);
+size_t scan_temp_bytes(size_t n);
+hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint8_t* flags, uint32_t* out, int n);
+hipError_t scan_u32_exclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n);
+void launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invalid, uint32_t* free_rank, uint32_t* free_list,
+                    uint32_t surfel_count, void* temp, size_t temp_bytes);
+
+}  // namespace bahip

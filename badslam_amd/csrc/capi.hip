@@ -1,0 +1,649 @@
+// capi.hip -- the extern "C" boundary declared in include/badslam_hip.h.
+// Owns only scratch (device keyframe table, pose work items, scan temp, counters); every image
+// and the surfel buffer are borrowed from the caller.
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ba_launch.h"
+#include "se3_device.h"
+
+using namespace bahip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const char* what, const char* file, int line, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s failed at %s:%d: %s", what, file, line, hipGetErrorString(e));
+  else snprintf(buf, sizeof(buf), "%s (%s:%d)", what, file, line);
+  g_last_error = buf;
+  return 1;
+}
+
+#define HIP_TRY(expr)                                                  \
+  do {                                                                 \
+    hipError_t _e = (expr);                                            \
+    if (_e != hipSuccess) return fail(#expr, __FILE__, __LINE__, _e);  \
+  } while (0)
+#define REQUIRE(cond, msg)                                             \
+  do {                                                                 \
+    if (!(cond)) return fail(msg, __FILE__, __LINE__);                 \
+  } while (0)
+#define CHECK_LAUNCH() HIP_TRY(hipGetLastError())
+
+struct StageTimer {
+  std::vector<hipEvent_t> ev;   // pairs (start, stop)
+  int used = 0;                 // number of pairs used by the last call
+};
+
+}  // namespace
+
+struct bahip_context {
+  hipStream_t stream = nullptr;
+  bool have_intrinsics = false;
+  bahip_camera color_cam{}, depth_cam{};
+  bahip_depth_params dp{};
+  Intrinsics in{};
+
+  std::vector<KfEntry> host_kfs;
+  KfEntry* dev_kfs = nullptr;
+  int kfs_capacity = 0;
+  int num_kfs = 0;
+
+  PoseWork* dev_work = nullptr;
+  float* dev_Hb = nullptr;
+  int work_capacity = 0;
+  KfEntry* dev_frame1 = nullptr;   // single-frame table for EstimateFramePose / AccumulatePoseEstimationCoeffs
+  PoseWork* dev_work1 = nullptr;
+  float* dev_Hb1 = nullptr;
+
+  int* dev_counter = nullptr;      // [0] generic counter, [1..2] min/max depth bits
+  int* pinned_i = nullptr;         // 16 ints
+  float* pinned_f = nullptr;       // 64 floats
+
+  uint8_t* dev_flags = nullptr;    // W*H new-surfel flags
+  uint32_t* dev_indices = nullptr; // W*H scan output
+  size_t px_capacity = 0;
+  void* scan_temp = nullptr;
+  size_t scan_temp_bytes = 0;
+  int* dev_covis = nullptr;
+  float* dev_covis_T = nullptr;
+  int covis_capacity = 0;
+
+  bahip_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+
+  bool profiling = false;
+  StageTimer timers[4];
+};
+
+namespace {
+
+Intrinsics make_intrinsics(const bahip_camera& cc, const bahip_camera& dc, const bahip_depth_params& dp) {
+  Intrinsics in{};
+  in.fx = dc.fx; in.fy = dc.fy; in.cx = dc.cx; in.cy = dc.cy;
+  // B/surfel_projection.h:61-71
+  in.fx_inv = 1.0f / dc.fx;
+  in.fy_inv = 1.0f / dc.fy;
+  const float cx_pixel_center = dc.cx - 0.5f, cy_pixel_center = dc.cy - 0.5f;
+  in.cx_inv = -cx_pixel_center * in.fx_inv;
+  in.cy_inv = -cy_pixel_center * in.fy_inv;
+  in.width = dc.width; in.height = dc.height;
+  in.cfx = cc.fx; in.cfy = cc.fy; in.ccx = cc.cx; in.ccy = cc.cy;
+  in.cwidth = cc.width; in.cheight = cc.height;
+  // B/surfel_projection.h:105-124
+  in.d2c_fx = cc.fx / dc.fx;
+  in.d2c_cx = -1 * cc.fx * dc.cx / dc.fx + cc.cx;
+  in.d2c_fy = cc.fy / dc.fy;
+  in.d2c_cy = -1 * cc.fy * dc.cy / dc.fy + cc.cy;
+  in.a = dp.a; in.raw_to_float_depth = dp.raw_to_float_depth; in.baseline_fx = dp.baseline_fx;
+  in.cell = dp.sparse_surfel_cell_size;
+  in.cfactor = dp.cfactor; in.cfactor_pitch = dp.cfactor_pitch_bytes;
+  in.cf_width = dp.cfactor_width; in.cf_height = dp.cfactor_height;
+  return in;
+}
+
+void fill_pose(KfEntry* e, const float* global_T_frame) {
+  for (int c = 0; c < 7; ++c) e->global_T_frame[c] = global_T_frame[c];
+  float inv[7];
+  se3_inverse(global_T_frame, inv);
+  se3_matrix3x4(inv, e->pose.F);
+  se3_rotation(global_T_frame, e->pose.GR);
+}
+
+KfEntry make_entry(const bahip_frame& f) {
+  KfEntry e{};
+  e.depth = f.depth; e.normals = f.normals; e.radius = f.radius; e.color = f.color;
+  e.depth_pitch = f.depth_pitch_bytes; e.normals_pitch = f.normals_pitch_bytes;
+  e.radius_pitch = f.radius_pitch_bytes; e.color_pitch = f.color_pitch_bytes;
+  return e;
+}
+
+SurfelsView make_view(const bahip_surfels* s) {
+  SurfelsView v;
+  v.data = s->data; v.pitch = s->pitch_bytes; v.active = s->active; v.size = s->surfels_size;
+  return v;
+}
+
+int ensure_work(bahip_context* ctx, int n) {
+  if (n <= ctx->work_capacity) return 0;
+  if (ctx->dev_work) { hipFree(ctx->dev_work); hipFree(ctx->dev_Hb); }
+  const int cap = n + 64;
+  HIP_TRY(hipMalloc(&ctx->dev_work, sizeof(PoseWork) * cap));
+  HIP_TRY(hipMalloc(&ctx->dev_Hb, sizeof(float) * kHbStride * cap));
+  ctx->work_capacity = cap;
+  return 0;
+}
+
+int ensure_px(bahip_context* ctx, size_t px, size_t scan_n) {
+  if (px > ctx->px_capacity) {
+    if (ctx->dev_flags) { hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); }
+    HIP_TRY(hipMalloc(&ctx->dev_flags, px));
+    HIP_TRY(hipMalloc(&ctx->dev_indices, px * sizeof(uint32_t)));
+    ctx->px_capacity = px;
+  }
+  const size_t need = scan_temp_bytes(scan_n);
+  if (need > ctx->scan_temp_bytes) {
+    if (ctx->scan_temp) hipFree(ctx->scan_temp);
+    HIP_TRY(hipMalloc(&ctx->scan_temp, need));
+    ctx->scan_temp_bytes = need;
+  }
+  return 0;
+}
+
+void timer_begin(bahip_context* ctx, int stage, bool first) {
+  if (!ctx->profiling) return;
+  StageTimer& t = ctx->timers[stage];
+  if (first) t.used = 0;
+  if ((int)t.ev.size() < 2 * (t.used + 1)) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    t.ev.push_back(a); t.ev.push_back(b);
+  }
+  hipEventRecord(t.ev[2 * t.used], ctx->stream);
+}
+void timer_end(bahip_context* ctx, int stage) {
+  if (!ctx->profiling) return;
+  StageTimer& t = ctx->timers[stage];
+  hipEventRecord(t.ev[2 * t.used + 1], ctx->stream);
+  t.used += 1;
+}
+
+// Batched Gauss-Newton rounds over `num_work` work items already initialised on the device.
+int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
+                    PoseWork* dev_work, float* dev_Hb, int num_work, const SurfelsView& s, int write_back, int* rounds_out) {
+  int rounds = 0;
+  for (int round = 0; round < BAHIP_MAX_POSE_ITERATIONS; ++round) {
+    timer_begin(ctx, 2, round == 0);
+    launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb);
+    timer_end(ctx, 2);
+    CHECK_LAUNCH();
+    if (ctx->allreduce) {
+      if (ctx->allreduce(dev_Hb, (size_t)num_work * kHbStride, ctx->allreduce_user) != 0)
+        return fail("all-reduce hook failed", __FILE__, __LINE__);
+    }
+    timer_begin(ctx, 3, round == 0);
+    HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
+    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, ctx->dev_counter);
+    timer_end(ctx, 3);
+    CHECK_LAUNCH();
+    HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ++rounds;
+    if (ctx->pinned_i[0] == 0) break;
+  }
+  if (rounds_out) *rounds_out = rounds;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bahip_last_error(void) { return g_last_error.c_str(); }
+
+int bahip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int bahip_context_create(bahip_context** out, void* hip_stream) {
+  REQUIRE(out != nullptr, "bahip_context_create: out is NULL");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  REQUIRE(n > 0, "bahip_context_create: no HIP device (the HIP backend has no CPU fallback)");
+  bahip_context* ctx = new bahip_context();
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  HIP_TRY(hipMalloc(&ctx->dev_counter, 16 * sizeof(int)));
+  HIP_TRY(hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)));
+  HIP_TRY(hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)));
+  HIP_TRY(hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)));
+  HIP_TRY(hipMalloc(&ctx->dev_work1, sizeof(PoseWork)));
+  HIP_TRY(hipMalloc(&ctx->dev_Hb1, sizeof(float) * kHbStride));
+  *out = ctx;
+  return 0;
+}
+
+void bahip_context_destroy(bahip_context* ctx) {
+  if (!ctx) return;
+  hipStreamSynchronize(ctx->stream);
+  hipFree(ctx->dev_kfs); hipFree(ctx->dev_work); hipFree(ctx->dev_Hb);
+  hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1);
+  hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
+  hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
+  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
+  for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
+  delete ctx;
+}
+
+int bahip_context_synchronize(bahip_context* ctx) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user) {
+  ctx->allreduce = fn;
+  ctx->allreduce_user = user;
+  return 0;
+}
+
+int bahip_malloc_pitch(void** ptr, size_t* pitch_bytes, size_t width_bytes, size_t height) {
+  // Rows padded to 256 B (what hipMallocPitch would give), one plain allocation.
+  const size_t pitch = (width_bytes + 255) & ~size_t(255);
+  HIP_TRY(hipMalloc(ptr, pitch * (height ? height : 1)));
+  *pitch_bytes = pitch;
+  return 0;
+}
+
+int bahip_free(void* ptr) {
+  HIP_TRY(hipFree(ptr));
+  return 0;
+}
+
+int bahip_memcpy_2d(bahip_context* ctx, void* dst, size_t dst_pitch, const void* src, size_t src_pitch,
+                    size_t width_bytes, size_t height, int kind) {
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, k, ctx->stream));
+  if (kind != 3) HIP_TRY(hipStreamSynchronize(ctx->stream));  // pageable host memory: keep the call self-contained
+  return 0;
+}
+
+int bahip_memset_2d(bahip_context* ctx, void* dst, size_t pitch, int value, size_t width_bytes, size_t height) {
+  HIP_TRY(hipMemset2DAsync(dst, pitch, value, width_bytes, height, ctx->stream));
+  return 0;
+}
+
+// ---- preprocessing ---------------------------------------------------------------------------------
+int bahip_compute_brightness(bahip_context* ctx, const uint8_t* rgb, uint32_t rgb_pitch, uint8_t* rgba, uint32_t rgba_pitch,
+                             int width, int height) {
+  launch_brightness(ctx->stream, rgb, rgb_pitch, rgba, rgba_pitch, width, height);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_compute_normals(bahip_context* ctx, const bahip_camera* cam, const bahip_depth_params* dp, const uint16_t* in_depth,
+                          uint32_t in_pitch, uint16_t* out_depth, uint32_t out_pitch, uint16_t* out_normals,
+                          uint32_t normals_pitch) {
+  const Intrinsics in = make_intrinsics(*cam, *cam, *dp);
+  launch_normals_from_depth(ctx->stream, in, in_depth, in_pitch, out_depth, out_pitch, out_normals, normals_pitch);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_compute_point_radii_and_remove_isolated_pixels(bahip_context* ctx, const bahip_camera* cam, float raw_to_float_depth,
+                                                         const uint16_t* depth, uint32_t depth_pitch, uint16_t* radius,
+                                                         uint32_t radius_pitch, uint16_t* out_depth, uint32_t out_pitch) {
+  bahip_depth_params dp{};
+  dp.sparse_surfel_cell_size = 1;
+  const Intrinsics in = make_intrinsics(*cam, *cam, dp);
+  launch_point_radii(ctx->stream, in, raw_to_float_depth, depth, depth_pitch, radius, radius_pitch, out_depth, out_pitch);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_compute_min_max_depth(bahip_context* ctx, const uint16_t* depth, uint32_t depth_pitch, int width, int height,
+                                float raw_to_float_depth, float* min_depth, float* max_depth) {
+  // init: min = +inf, max = 0 (B/cuda_depth_processing.cu ComputeMinMaxDepthCUDA_InitializeBuffers)
+  const float init[2] = {__builtin_huge_valf(), 0.f};
+  memcpy(ctx->pinned_f, init, sizeof(init));
+  HIP_TRY(hipMemcpyAsync(ctx->dev_counter + 1, ctx->pinned_f, 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  launch_min_max_depth(ctx->stream, depth, depth_pitch, width, height, raw_to_float_depth, ctx->dev_counter + 1);
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_f, ctx->dev_counter + 1, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *min_depth = ctx->pinned_f[0];
+  *max_depth = ctx->pinned_f[1];
+  return 0;
+}
+
+// ---- scene binding -----------------------------------------------------------------------------------
+int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, const bahip_camera* depth_camera,
+                         const bahip_depth_params* dp) {
+  REQUIRE(dp->sparse_surfel_cell_size >= 1, "sparse_surfel_cell_size must be >= 1");
+  ctx->color_cam = *color_camera; ctx->depth_cam = *depth_camera; ctx->dp = *dp;
+  ctx->in = make_intrinsics(*color_camera, *depth_camera, *dp);
+  ctx->have_intrinsics = true;
+  return 0;
+}
+
+int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int num_keyframes) {
+  REQUIRE(num_keyframes >= 0, "negative keyframe count");
+  ctx->host_kfs.resize(num_keyframes);
+  for (int k = 0; k < num_keyframes; ++k) {
+    KfEntry e = make_entry(keyframes[k].frame);
+    fill_pose(&e, keyframes[k].global_T_frame);
+    e.activation = keyframes[k].activation;
+    ctx->host_kfs[k] = e;
+  }
+  if (num_keyframes > ctx->kfs_capacity) {
+    if (ctx->dev_kfs) hipFree(ctx->dev_kfs);
+    ctx->kfs_capacity = num_keyframes + 64;
+    HIP_TRY(hipMalloc(&ctx->dev_kfs, sizeof(KfEntry) * ctx->kfs_capacity));
+  }
+  ctx->num_kfs = num_keyframes;
+  if (num_keyframes > 0) {
+    HIP_TRY(hipMemcpyAsync(ctx->dev_kfs, ctx->host_kfs.data(), sizeof(KfEntry) * num_keyframes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // host_kfs is pageable
+  }
+  return 0;
+}
+
+int bahip_get_keyframe_poses(bahip_context* ctx, float* out, int num_keyframes) {
+  REQUIRE(num_keyframes <= ctx->num_kfs, "more poses requested than keyframes bound");
+  if (num_keyframes == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(ctx->host_kfs.data(), ctx->dev_kfs, sizeof(KfEntry) * ctx->num_kfs, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < num_keyframes; ++k) memcpy(out + 7 * k, ctx->host_kfs[k].global_T_frame, 7 * sizeof(float));
+  return 0;
+}
+
+// ---- stages ---------------------------------------------------------------------------------------------
+int bahip_update_surfel_activation(bahip_context* ctx, const bahip_surfels* surfels, uint32_t surfels_size) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(surfels->active != nullptr, "activation needs the active-surfel buffer");
+  timer_begin(ctx, 0, true);
+  launch_activation(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), surfels_size);
+  timer_end(ctx, 0);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_update_surfel_normals(bahip_context* ctx, const bahip_surfels* surfels) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(surfels->active != nullptr, "normals update needs the active-surfel buffer");
+  launch_normals(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");   // B/kernel_opt_geometry.cc:91
+  REQUIRE(surfels->active != nullptr, "geometry optimisation needs the active-surfel buffer");
+  timer_begin(ctx, 1, true);
+  launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
+  timer_end(ctx, 1);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, int use_desc, const bahip_frame* frame,
+                                            const float frame_T_global[12], const bahip_surfels* surfels, float* H, float* b) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");   // B/kernel_opt_pose.cc:58
+  REQUIRE(surfels->surfels_size > 0, "AccumulatePoseEstimationCoeffs is only intended for surfels_size > 0");  // :61
+  KfEntry e = make_entry(*frame);
+  PoseWork w{};
+  memcpy(w.F, frame_T_global, 12 * sizeof(float));
+  w.kf_index = 0;
+  HIP_TRY(hipMemcpyAsync(ctx->dev_frame1, &e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->dev_work1, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(float) * kHbStride, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  launch_pose_accumulate(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_frame1, ctx->dev_work1, 1,
+                         make_view(surfels), ctx->dev_Hb1);
+  CHECK_LAUNCH();
+  if (ctx->allreduce && ctx->allreduce(ctx->dev_Hb1, kHbStride, ctx->allreduce_user) != 0)
+    return fail("all-reduce hook failed", __FILE__, __LINE__);
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_f, ctx->dev_Hb1, sizeof(float) * kHbStride, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  memcpy(H, ctx->pinned_f, 21 * sizeof(float));
+  memcpy(b, ctx->pinned_f + 21, 6 * sizeof(float));
+  return 0;
+}
+
+int bahip_estimate_frame_pose(bahip_context* ctx, int use_depth, int use_desc, const bahip_frame* frame,
+                              const float init[7], const bahip_surfels* surfels, float out[7], int* iterations_done,
+                              int* converged) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");
+  KfEntry e = make_entry(*frame);
+  PoseWork w{};
+  memcpy(w.T, init, 7 * sizeof(float));
+  float inv[7];
+  se3_inverse(init, inv);
+  se3_matrix3x4(inv, w.F);
+  HIP_TRY(hipMemcpyAsync(ctx->dev_frame1, &e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->dev_work1, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(float) * kHbStride, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // surfels_size == 0: H = b = 0 -> x = 0 -> converged after one step (B/direct_ba_alternating.cc:148-151)
+  if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_frame1, ctx->dev_frame1, ctx->dev_work1, ctx->dev_Hb1, 1,
+                      make_view(surfels), /*write_back*/ 0, nullptr)) return 1;
+  HIP_TRY(hipMemcpy(&w, ctx->dev_work1, sizeof(w), hipMemcpyDeviceToHost));
+  memcpy(out, w.T, 7 * sizeof(float));
+  if (iterations_done) *iterations_done = w.iterations;
+  if (converged) *converged = w.converged;
+  return 0;
+}
+
+int bahip_estimate_keyframe_poses(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels,
+                                  float* global_T_frame_out, int* iterations_done, int* converged, int* rounds_out) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");
+  const int K = ctx->num_kfs;
+  if (rounds_out) *rounds_out = 0;
+  if (K == 0) return 0;
+  if (ensure_work(ctx, K)) return 1;
+  launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb);
+  CHECK_LAUNCH();
+  if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K,
+                      make_view(surfels), /*write_back*/ 1, rounds_out)) return 1;
+  std::vector<PoseWork> hw(K);
+  HIP_TRY(hipMemcpy(hw.data(), ctx->dev_work, sizeof(PoseWork) * K, hipMemcpyDeviceToHost));
+  for (int k = 0; k < K; ++k) {
+    if (hw[k].iterations > 0) fill_pose(&ctx->host_kfs[k], hw[k].T);
+    if (global_T_frame_out) memcpy(global_T_frame_out + 7 * k, ctx->host_kfs[k].global_T_frame, 7 * sizeof(float));
+    if (iterations_done) iterations_done[k] = hw[k].iterations;
+    if (converged) converged[k] = hw[k].converged;
+  }
+  return 0;
+}
+
+// ---- lifecycle ---------------------------------------------------------------------------------------------
+static int supporting_view(uint32_t* const* supporting, uint32_t pitch, SupportingView* v) {
+  for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) {
+    if (!supporting[b]) return 1;
+    v->b[b] = supporting[b];
+  }
+  v->pitch = pitch;
+  return 0;
+}
+
+static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_dist_factor, const KfEntry& e,
+                                     const bahip_surfels* surfels, const SupportingView& sup, uint32_t* merged_count_out) {
+  // The reference clears full-resolution planes (B/kernel_supporting_surfels.cc:58-60); only the
+  // sparse-cell region is ever addressed, so clearing that region is equivalent.
+  launch_supporting_fill(ctx->stream, sup, ctx->in.cf_width, ctx->in.cf_height);
+  CHECK_LAUNCH();
+  if (merged_count_out) *merged_count_out = 0;
+  if (surfels->surfels_size == 0) return 0;
+  const SurfelsView s = make_view(surfels);
+  launch_supporting_insert(ctx->stream, ctx->in, e, s, sup);
+  CHECK_LAUNCH();
+  if (merge) {
+    const float cell = (float)ctx->in.cell;
+    const float cell_merge_dist_sq = cell * cell * merge_dist_factor * merge_dist_factor;
+    HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
+    // per-surfel decision flags live in accum row 0 (scratch by contract, B/kernels.cuh:78-90)
+    uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
+    launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags,
+                 reinterpret_cast<uint32_t*>(ctx->dev_counter));
+    CHECK_LAUNCH();
+    HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (merged_count_out) *merged_count_out = (uint32_t)ctx->pinned_i[0];
+  }
+  return 0;
+}
+
+int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merge_dist_factor, const bahip_frame* frame,
+                                       const float frame_T_global[12], const bahip_surfels* surfels,
+                                       uint32_t* const* supporting, uint32_t supporting_pitch, uint32_t* merged_count_out) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  SupportingView sup;
+  REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
+  KfEntry e = make_entry(*frame);
+  memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
+  return determine_supporting_impl(ctx, merge, merge_dist_factor, e, surfels, sup, merged_count_out);
+}
+
+int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, int filter_new_surfels, int min_observation_count,
+                                      const int* covis, int n_covis, const bahip_surfels* surfels, uint32_t* const* supporting,
+                                      uint32_t supporting_pitch, uint32_t* new_surfel_count_out) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(keyframe_index >= 0 && keyframe_index < ctx->num_kfs, "keyframe index out of range");
+  SupportingView sup;
+  REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
+  const KfEntry& e = ctx->host_kfs[keyframe_index];
+  *new_surfel_count_out = 0;
+  if (determine_supporting_impl(ctx, 0, 0.f, e, surfels, sup, nullptr)) return 1;
+  const int W = ctx->in.width, H = ctx->in.height;
+  const size_t px = (size_t)W * H;
+  if (ensure_px(ctx, px, px > surfels->capacity ? px : surfels->capacity)) return 1;
+  launch_create_flag(ctx->stream, ctx->in, e, sup, ctx->dev_flags);
+  CHECK_LAUNCH();
+  if (filter_new_surfels && n_covis > 0) {
+    if (n_covis > ctx->covis_capacity) {
+      if (ctx->dev_covis) { hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); }
+      ctx->covis_capacity = n_covis + 64;
+      HIP_TRY(hipMalloc(&ctx->dev_covis, sizeof(int) * ctx->covis_capacity));
+      HIP_TRY(hipMalloc(&ctx->dev_covis_T, sizeof(float) * 12 * ctx->covis_capacity));
+    }
+    std::vector<float> rel(12 * (size_t)n_covis);
+    for (int c = 0; c < n_covis; ++c) {
+      REQUIRE(covis[c] >= 0 && covis[c] < ctx->num_kfs, "co-visibility index out of range");
+      // covis_T_frame = covis.frame_T_global * keyframe.global_T_frame (B/direct_ba.cc:359-365)
+      float cinv[7], prod[7];
+      se3_inverse(ctx->host_kfs[covis[c]].global_T_frame, cinv);
+      se3_mul(cinv, e.global_T_frame, prod);
+      se3_matrix3x4(prod, &rel[12 * c]);
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis, covis, sizeof(int) * n_covis, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis_T, rel.data(), sizeof(float) * 12 * n_covis, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    launch_create_filter(ctx->stream, ctx->in, e, ctx->dev_kfs, ctx->dev_covis, ctx->dev_covis_T, n_covis,
+                         min_observation_count, ctx->dev_flags);
+    CHECK_LAUNCH();
+  } else if (filter_new_surfels) {
+    // no co-visible keyframe: every candidate has exactly one observation
+    if (1 < min_observation_count) HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, ctx->stream));
+  }
+  HIP_TRY(scan_flags_inclusive(ctx->stream, ctx->scan_temp, ctx->scan_temp_bytes, ctx->dev_flags, ctx->dev_indices, (int)px));
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_indices + (px - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const uint32_t count = (uint32_t)ctx->pinned_i[0];
+  if (count == 0) return 0;
+  if ((uint64_t)surfels->surfels_size + count > surfels->capacity) {
+    g_last_error = "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";  // B/kernel_create_surfels.cc:162-165
+    return 0;  // soft failure in the reference: logs and returns without creating
+  }
+  launch_create_append(ctx->stream, ctx->in, e, ctx->dev_flags, ctx->dev_indices, surfels->surfels_size, make_view(surfels));
+  CHECK_LAUNCH();
+  *new_surfel_count_out = count;
+  return 0;
+}
+
+int bahip_delete_surfels_and_update_radii(bahip_context* ctx, int min_observation_count, const bahip_surfels* surfels,
+                                          uint32_t* deleted_count_out) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  *deleted_count_out = 0;
+  if (surfels->surfels_size == 0) return 0;
+  HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
+  launch_delete_update(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), min_observation_count,
+                       reinterpret_cast<uint32_t*>(ctx->dev_counter));
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *deleted_count_out = (uint32_t)ctx->pinned_i[0];
+  return 0;
+}
+
+int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip_surfels* surfels) {
+  if (surfels->surfels_size == surfel_count) return 0;
+  REQUIRE(surfel_count < surfels->surfels_size, "surfel_count larger than surfels_size");
+  if (ensure_px(ctx, 1, surfels->capacity)) return 1;
+  char* base = reinterpret_cast<char*>(surfels->data);
+  // scratch rows as in the reference: accum2 = invalid flags, accum0 = ranks, accum3 = free-spot list
+  uint32_t* invalid = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 2) * surfels->pitch_bytes);
+  uint32_t* free_rank = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 0) * surfels->pitch_bytes);
+  uint32_t* free_list = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 3) * surfels->pitch_bytes);
+  launch_compact(ctx->stream, make_view(surfels), invalid, free_rank, free_list, surfel_count, ctx->scan_temp, ctx->scan_temp_bytes);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- not yet implemented in this build ------------------------------------------------------------------------
+int bahip_optimize_intrinsics(bahip_context*, int, int, const bahip_surfels*, bahip_camera*, bahip_camera*, float*) {
+  return fail("bahip_optimize_intrinsics: not implemented yet", __FILE__, __LINE__);
+}
+int bahip_pcg_iteration(bahip_context*, const bahip_pcg_options*, const bahip_surfels*, bahip_camera*, bahip_camera*, float*, int*) {
+  return fail("bahip_pcg_iteration: not implemented yet", __FILE__, __LINE__);
+}
+
+// ---- test hook ------------------------------------------------------------------------------------------------------
+int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, const float frame_T_global[12],
+                               const bahip_surfels* surfels, const uint32_t* surfel_indices_host, int count, float* out_host) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  if (count <= 0) return 0;
+  KfEntry e = make_entry(*frame);
+  memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
+  uint32_t* d_idx = nullptr; float* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_idx, sizeof(uint32_t) * count));
+  HIP_TRY(hipMalloc(&d_out, sizeof(float) * 40 * count));
+  HIP_TRY(hipMemcpy(d_idx, surfel_indices_host, sizeof(uint32_t) * count, hipMemcpyHostToDevice));
+  launch_evaluate_pairs(ctx->stream, ctx->in, e, make_view(surfels), d_idx, count, d_out);
+  CHECK_LAUNCH();
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out_host, d_out, sizeof(float) * 40 * count, hipMemcpyDeviceToHost));
+  hipFree(d_idx); hipFree(d_out);
+  return 0;
+}
+
+// ---- instrumentation ------------------------------------------------------------------------------------------------
+int bahip_set_profiling(bahip_context* ctx, int enabled) {
+  ctx->profiling = enabled != 0;
+  return 0;
+}
+
+int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* launches_out) {
+  REQUIRE(stage >= 0 && stage < 4, "stage out of range");
+  StageTimer& t = ctx->timers[stage];
+  float total = 0.f;
+  for (int i = 0; i < t.used; ++i) {
+    HIP_TRY(hipEventSynchronize(t.ev[2 * i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]));
+    total += ms;
+  }
+  *ms_out = total;
+  if (launches_out) *launches_out = t.used;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,350 @@
+// kernels_lifecycle.hip -- surfel creation, supporting-surfel maps + merging, deletion + radius
+// update, compaction (B/ = applications/badslam/src/badslam/):
+//   B/kernel_supporting_surfels.{cc,cu}, B/kernel_create_surfels.{cc,cu},
+//   B/kernel_delete_surfels.{cc,cu}, B/kernel_compact_surfels.cu.
+//
+// The reference resolves ownership of a sparse cell with atomicCAS, so which pixel / surfel wins
+// is arbitrary and run-to-run different.  Here every choice is made deterministic and identical
+// to a sequential sweep in ascending index order: supporting slots hold the (up to) three
+// smallest associated surfel indices of a cell (atomicMin insertion chain), the merge decision
+// of a surfel is evaluated against exactly those, and a new surfel is created for the first
+// qualifying pixel of a cell in row-major order.
+#include <hip/hip_fp16.h>
+#include <hipcub/hipcub.hpp>
+
+#include "ba_device.h"
+#include "ba_launch.h"
+
+namespace bahip {
+
+constexpr int kLcBlock = 256;
+
+__device__ __forceinline__ bool is_deleted_bits(float x) { return __float_as_uint(x) == kDeletedSurfelBits; }
+
+// ---- supporting surfels ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLcBlock)
+supporting_fill_kernel(SupportingView sup, int width, int height) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= width || y >= height) return;
+#pragma unroll
+  for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) *pitched_ptr(sup.b[b], sup.pitch, y, x) = kInvalidIndex;
+}
+
+// Phase A: every associated surfel offers its index to the cell's slot chain.
+__global__ void __launch_bounds__(kLcBlock)
+supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if (i >= s.size) return;
+  Assoc r;
+  if (!project_associate<false>(in, frame.pose.F, frame.depth, frame.depth_pitch, frame.normals, frame.normals_pitch,
+                                surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
+  const int cx = r.px / in.cell, cy = r.py / in.cell;
+  uint32_t cur = i;
+#pragma unroll
+  for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) {
+    const uint32_t old = atomicMin(pitched_ptr(sup.b[b], sup.pitch, cy, cx), cur);
+    if (old == kInvalidIndex) break;     // an empty slot absorbed the value
+    if (old > cur) cur = old;            // displaced a larger index: push it down the chain
+  }
+}
+
+__device__ __forceinline__ bool merge_test(const SurfelsView& s, uint32_t a, uint32_t b, float cos_thr, float cell_merge_dist_sq) {
+  // B/kernel_supporting_surfels.cu:66-83
+  if (!(dot3(surfel_normal(s, b), surfel_normal(s, a)) > cos_thr)) return false;
+  const Vec3 pa = surfel_position(s, a), pb = surfel_position(s, b);
+  const float min_r = fminf(s.row(kSurfelRadiusSquared)[b], s.row(kSurfelRadiusSquared)[a]);
+  const Vec3 d = pb - pa;
+  return (d.x * d.x + d.y * d.y + d.z * d.z) < min_r * cell_merge_dist_sq;
+}
+
+// Phase B: decide (without modifying positions) which surfels a sequential ascending sweep would
+// merge away.  flags: one u32 per surfel.
+__global__ void __launch_bounds__(kLcBlock)
+merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, float cell_merge_dist_sq,
+                    float cos_thr, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if (i >= s.size) return;
+  flags[i] = 0;
+  Assoc r;
+  if (!project_associate<false>(in, frame.pose.F, frame.depth, frame.depth_pitch, frame.normals, frame.normals_pitch,
+                                surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
+  const int cx = r.px / in.cell, cy = r.py / in.cell;
+  const uint32_t s0 = *pitched_ptr(sup.b[0], sup.pitch, cy, cx);
+  const uint32_t s1 = *pitched_ptr(sup.b[1], sup.pitch, cy, cx);
+  const uint32_t s2 = *pitched_ptr(sup.b[2], sup.pitch, cy, cx);
+  if (i == s0) return;
+  // deletion state of the occupants of slots 1 and 2 at the time later surfels are tested
+  const bool d1 = (s1 != kInvalidIndex) && merge_test(s, s1, s0, cos_thr, cell_merge_dist_sq);
+  bool deleted;
+  if (i == s1) {
+    deleted = d1;
+  } else {
+    const bool d2 = (s2 != kInvalidIndex) &&
+                    (merge_test(s, s2, s0, cos_thr, cell_merge_dist_sq) || (!d1 && merge_test(s, s2, s1, cos_thr, cell_merge_dist_sq)));
+    if (i == s2) deleted = d2;
+    else deleted = merge_test(s, i, s0, cos_thr, cell_merge_dist_sq) ||
+                   (!d1 && merge_test(s, i, s1, cos_thr, cell_merge_dist_sq)) ||
+                   (!d2 && merge_test(s, i, s2, cos_thr, cell_merge_dist_sq));
+  }
+  flags[i] = deleted ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(kLcBlock)
+merge_apply_kernel(SurfelsView s, const uint32_t* __restrict__ flags, uint32_t* __restrict__ deleted_count) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  const bool del = (i < s.size) && flags[i];
+  if (del) s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits);
+  const unsigned long long m = __ballot(del);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(deleted_count, (uint32_t)__popcll(m));
+}
+
+// ---- creation ---------------------------------------------------------------------------------------
+// One thread per sparse cell: B/kernel_create_surfels.cu:41-75 with a deterministic winner.
+__global__ void __launch_bounds__(kLcBlock)
+create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __restrict__ flags /* W*H dense */) {
+  const int cxy = blockIdx.x * kLcBlock + threadIdx.x;
+  if (cxy >= in.cf_width * in.cf_height) return;
+  const int cy = cxy / in.cf_width, cx = cxy - cy * in.cf_width;
+  uint32_t* slot = pitched_ptr(sup.b[0], sup.pitch, cy, cx);
+  const bool free_cell = (*slot == kInvalidIndex);
+  bool claimed = false;
+  for (int dy = 0; dy < in.cell; ++dy) {
+    for (int dx = 0; dx < in.cell; ++dx) {
+      const int x = cx * in.cell + dx, y = cy * in.cell + dy;
+      if (x >= in.width || y >= in.height) continue;
+      bool flag = false;
+      if (free_cell && !claimed && x >= 1 && y >= 1 && x < in.width - 1 && y < in.height - 1 &&
+          !(pitched_load(frame.depth, frame.depth_pitch, y, x) & kInvalidDepthBit)) {
+        flag = true;
+        claimed = true;
+      }
+      flags[(size_t)y * in.width + x] = flag ? 1 : 0;
+    }
+  }
+  if (claimed) *slot = 0;
+}
+
+// B/kernel_create_surfels.cu:213-276 + :314-337: outlier filter for new surfels, one thread per pixel.
+__global__ void __launch_bounds__(kLcBlock)
+create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ kfs, const int* __restrict__ covis,
+                     const float* __restrict__ covis_T_frame /* 12 floats each */, int n_covis,
+                     int min_observation_count, uint8_t* __restrict__ flags) {
+  const int idx = blockIdx.x * kLcBlock + threadIdx.x;
+  if (idx >= in.width * in.height) return;
+  if (!flags[idx]) return;
+  const int y = idx / in.width, x = idx - y * in.width;
+  uint32_t observations = 1, violations = 0;
+  const float cd = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y), in.raw_to_float_depth, pitched_load(frame.depth, frame.depth_pitch, y, x));
+  const Vec3 input_pos = unproject(in, x, y, cd);
+  const Vec3 m = unpack_normal8(pitched_load(frame.normals, frame.normals_pitch, y, x));
+  for (int c = 0; c < n_covis; ++c) {
+    const KfEntry& ck = kfs[covis[c]];
+    const float* M = covis_T_frame + 12 * c;
+    Vec3 lp;
+    lp.z = M[8] * input_pos.x + M[9] * input_pos.y + M[10] * input_pos.z + M[11];
+    if (!(lp.z > 0.f)) continue;
+    lp.x = M[0] * input_pos.x + M[1] * input_pos.y + M[2] * input_pos.z + M[3];
+    lp.y = M[4] * input_pos.x + M[5] * input_pos.y + M[6] * input_pos.z + M[7];
+    const float pxx = in.fx * (lp.x / lp.z) + in.cx, pxy = in.fy * (lp.y / lp.z) + in.cy;
+    if (!(pxx >= 0.f) || !(pxy >= 0.f) || !(pxx < (float)in.width) || !(pxy < (float)in.height)) continue;
+    const int px = (int)pxx, py = (int)pxy;
+    // B/surfel_projection_nvcc_only.cuh:131-231
+    const uint16_t raw = pitched_load(ck.depth, ck.depth_pitch, py, px);
+    if (raw & kInvalidDepthBit) continue;
+    const Vec3 nl = rotate34(M, m);
+    const float d = raw_to_calibrated_depth(in.a, cfactor_at(in, px, py), in.raw_to_float_depth, raw);
+    const float thr = 10.f * depth_stddev(unp_nx(in, (float)px), unp_ny(in, (float)py), d, nl, in.baseline_fx);
+    const float diff = d - lp.z;
+    if (diff > thr) { violations += 1; continue; }
+    else if (diff < -thr) continue;
+    if ((1.0f / norm3(lp)) * dot3(lp, nl) > 0) continue;
+    if (dot3(nl, unpack_normal8(pitched_load(ck.normals, ck.normals_pitch, py, px))) < kCosNormalCompat) continue;
+    observations += 1;
+  }
+  if (observations < (uint32_t)min_observation_count || violations > observations) flags[idx] = 0;
+}
+
+// B/kernel_create_surfels.cu:91-160,357-390
+__global__ void __launch_bounds__(kLcBlock)
+create_append_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ indices,
+                     uint32_t surfels_size, SurfelsView s) {
+  const int idx = blockIdx.x * kLcBlock + threadIdx.x;
+  if (idx >= in.width * in.height) return;
+  if (flags[idx] != 1) return;
+  const int y = idx / in.width, x = idx - y * in.width;
+  const uint32_t si = surfels_size + indices[idx] - 1;   // inclusive scan
+  float G[12];
+  {
+    // global_T_frame as 3x4: rotation = transpose of frame_T_global's, translation from the pose
+    const float* q = frame.global_T_frame;
+    const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    const float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    G[0] = 1 - (tyy + tzz); G[1] = txy - twz;       G[2] = txz + twy;        G[3] = q[4];
+    G[4] = txy + twz;       G[5] = 1 - (txx + tzz); G[6] = tyz - twx;        G[7] = q[5];
+    G[8] = txz - twy;       G[9] = tyz + twx;       G[10] = 1 - (txx + tyy); G[11] = q[6];
+  }
+  const float cd = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y), in.raw_to_float_depth, pitched_load(frame.depth, frame.depth_pitch, y, x));
+  const Vec3 gp = transform34(G, unproject(in, x, y, cd));
+  s.row(kSurfelX)[si] = gp.x; s.row(kSurfelY)[si] = gp.y; s.row(kSurfelZ)[si] = gp.z;
+  const Vec3 gn = rotate34(G, unpack_normal8(pitched_load(frame.normals, frame.normals_pitch, y, x)));
+  reinterpret_cast<uint32_t*>(s.row(kSurfelNormal))[si] = pack_normal10(gn);
+  const float radius_sq = __half2float(__ushort_as_half(pitched_load(frame.radius, frame.radius_pitch, y, x)));
+  s.row(kSurfelRadiusSquared)[si] = radius_sq;
+  float cx, cy;
+  depth_to_color_pixel(in, x + 0.5f, y + 0.5f, &cx, &cy);
+  // colour: bilinear RGB sample, truncated to u8
+  {
+    float xb = cx - 0.5f, yb = cy - 0.5f;
+    const int w = in.cwidth, h = in.cheight;
+    if (!(xb >= -1.f)) xb = -1.f; if (xb > (float)w) xb = (float)w;
+    if (!(yb >= -1.f)) yb = -1.f; if (yb > (float)h) yb = (float)h;
+    const float fx = floorf(xb), fy = floorf(yb), a = xb - fx, b = yb - fy;
+    const int x0 = max(0, min((int)fx, w - 1)), x1 = max(0, min((int)fx + 1, w - 1));
+    const int y0 = max(0, min((int)fy, h - 1)), y1 = max(0, min((int)fy + 1, h - 1));
+    uint8_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float tl = frame.color[(size_t)y0 * frame.color_pitch + 4 * x0 + ch] * (1.0f / 255.0f);
+      const float tr = frame.color[(size_t)y0 * frame.color_pitch + 4 * x1 + ch] * (1.0f / 255.0f);
+      const float bl = frame.color[(size_t)y1 * frame.color_pitch + 4 * x0 + ch] * (1.0f / 255.0f);
+      const float br = frame.color[(size_t)y1 * frame.color_pitch + 4 * x1 + ch] * (1.0f / 255.0f);
+      const float top = tl + a * (tr - tl), bot = bl + a * (br - bl);
+      out[ch] = (uint8_t)(255.f * (top + b * (bot - top)));
+    }
+    reinterpret_cast<uchar4*>(s.row(kSurfelColor))[si] = make_uchar4(out[0], out[1], out[2], 0);
+  }
+  // descriptors are initialised so that both residuals are zero in the creating keyframe
+  const Vec3 gn_stored = gn;  // the reference uses the unquantised normal here (B/kernel_create_surfels.cu:133-140)
+  DescEval e;
+  eval_descriptor<false>(in, frame.color, frame.color_pitch, frame.pose.F, gp, gn_stored, radius_sq, cx, cy, 0.f, 0.f, &e);
+  s.row(kSurfelDescriptor1)[si] = e.r1;
+  s.row(kSurfelDescriptor2)[si] = e.r2;
+}
+
+// ---- deletion + radius update (B/kernel_delete_surfels.cu:42-176), one launch for all keyframes ------
+__global__ void __launch_bounds__(kLcBlock)
+delete_update_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
+                     int min_observation_count, uint32_t* __restrict__ deleted_count) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  bool newly_deleted = false;
+  if (i < s.size) {
+    const Vec3 gp = surfel_position(s, i);
+    const Vec3 gn = surfel_normal(s, i);
+    float obs = 0, viol = 0, min_r = __builtin_huge_valf();
+    for (int k = 0; k < num_kfs; ++k) {
+      Assoc r;
+      bool fsv = false;
+      if (project_associate<true>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
+                                  kfs[k].normals_pitch, gp, gn, &r, &fsv)) {
+        obs += 1.f;
+        min_r = fminf(min_r, __half2float(__ushort_as_half(pitched_load(kfs[k].radius, kfs[k].radius_pitch, r.py, r.px))));
+      } else if (fsv) {
+        viol += 1.f;
+      }
+    }
+    s.row(kSurfelAccum0 + 0)[i] = obs; s.row(kSurfelAccum0 + 1)[i] = viol; s.row(kSurfelAccum0 + 2)[i] = min_r;
+    if (obs < (float)min_observation_count || viol > obs) {
+      if (!is_deleted_bits(gp.x)) { s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits); newly_deleted = true; }
+    } else {
+      s.row(kSurfelRadiusSquared)[i] = min_r;
+    }
+  }
+  const unsigned long long m = __ballot(newly_deleted);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(deleted_count, (uint32_t)__popcll(m));
+}
+
+// ---- compaction (B/kernel_compact_surfels.cu:101-157) --------------------------------------------------
+__global__ void __launch_bounds__(kLcBlock)
+compact_flag_kernel(SurfelsView s, uint32_t* __restrict__ invalid) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if (i < s.size) invalid[i] = is_deleted_bits(s.row(kSurfelX)[i]) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(kLcBlock)
+compact_free_list_kernel(SurfelsView s, const uint32_t* __restrict__ invalid, const uint32_t* __restrict__ free_rank,
+                         uint32_t free_spot_count, uint32_t* __restrict__ free_list) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if (i < s.size && invalid[i] && free_rank[i] < free_spot_count) free_list[free_rank[i]] = i;
+}
+__global__ void __launch_bounds__(kLcBlock)
+compact_move_kernel(SurfelsView s, const uint32_t* __restrict__ invalid, const uint32_t* __restrict__ free_rank,
+                    const uint32_t* __restrict__ free_list, uint32_t free_spot_count, uint32_t surfel_count) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if (i >= s.size || invalid[i]) return;
+  // number of valid surfels with a larger index = reverse index of this surfel
+  const uint32_t valid_before = i - free_rank[i];
+  const uint32_t reverse_index = surfel_count - 1 - valid_before;
+  if (reverse_index >= free_spot_count) return;
+  const uint32_t dst = free_list[reverse_index];
+  if (dst < i) {
+#pragma unroll
+    for (int row = 0; row < 8; ++row) s.row(row)[dst] = s.row(row)[i];
+    if (s.active) s.active[dst] = s.active[i];
+  }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------
+static inline unsigned g1(uint32_t n) { return (n + kLcBlock - 1) / kLcBlock; }
+
+void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, int h) {
+  hipLaunchKernelGGL(supporting_fill_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(kLcBlock), 0, st, sup, w, h);
+}
+void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup) {
+  if (s.size) hipLaunchKernelGGL(supporting_insert_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup);
+}
+void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count) {
+  if (!s.size) return;
+  hipLaunchKernelGGL(merge_decide_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags);
+  hipLaunchKernelGGL(merge_apply_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, flags, deleted_count);
+}
+void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags) {
+  hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags);
+}
+void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,
+                          const float* covis_T_frame, int n_covis, int min_obs, uint8_t* flags) {
+  hipLaunchKernelGGL(create_filter_kernel, dim3(g1(in.width * in.height)), dim3(kLcBlock), 0, st, in, frame, kfs, covis,
+                     covis_T_frame, n_covis, min_obs, flags);
+}
+void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags,
+                          const uint32_t* indices, uint32_t surfels_size, const SurfelsView& s) {
+  hipLaunchKernelGGL(create_append_kernel, dim3(g1(in.width * in.height)), dim3(kLcBlock), 0, st, in, frame, flags, indices,
+                     surfels_size, s);
+}
+void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                          int min_obs, uint32_t* deleted_count) {
+  if (s.size) hipLaunchKernelGGL(delete_update_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, kfs, num_kfs, s, min_obs, deleted_count);
+}
+
+// Inclusive scan u8 -> u32 (new surfel indices) and exclusive scan u32 -> u32 (free ranks).
+size_t scan_temp_bytes(size_t n) {
+  size_t a = 0, b = 0;
+  hipcub::DeviceScan::InclusiveSum(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+  return a > b ? a : b;
+}
+struct U8ToU32 {
+  __host__ __device__ uint32_t operator()(const uint8_t& v) const { return (uint32_t)v; }
+};
+hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint8_t* flags, uint32_t* out, int n) {
+  hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t*> it(flags, U8ToU32());
+  return hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, it, out, n, st);
+}
+hipError_t scan_u32_exclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n) {
+  return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, n, st);
+}
+
+void launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invalid, uint32_t* free_rank, uint32_t* free_list,
+                    uint32_t surfel_count, void* temp, size_t temp_bytes) {
+  if (!s.size) return;
+  const uint32_t free_spot_count = s.size - surfel_count;
+  hipLaunchKernelGGL(compact_flag_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, invalid);
+  scan_u32_exclusive(st, temp, temp_bytes, invalid, free_rank, (int)s.size);
+  hipLaunchKernelGGL(compact_free_list_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, invalid, free_rank, free_spot_count, free_list);
+  hipLaunchKernelGGL(compact_move_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, invalid, free_rank, free_list,
+                     free_spot_count, surfel_count);
+}
+
+}  // namespace bahip

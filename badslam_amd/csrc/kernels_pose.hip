@@ -1,0 +1,301 @@
+// kernels_pose.hip -- pose normal equations and the batched Gauss-Newton pose solve.
+//
+// Reference (B/ = applications/badslam/src/badslam/): for every keyframe and every GN step the
+// host clears H/b with 2-4 tiny kernels, launches AccumulatePoseEstimationCoeffsCUDAKernel over
+// all surfels (B/kernel_opt_pose.cu:251-383; 81 serial CUB block reductions per block,
+// B/gauss_newton.cuh:46-93), copies 27 floats back, synchronises, and solves the 6x6 system with
+// Eigen on the host (B/kernel_opt_pose.cc:67-96, B/direct_ba_alternating.cc:126-244).
+//
+// Here one launch per GN *round* handles every keyframe that is still iterating: a thread owns a
+// surfel (position, normal, radius, descriptors in registers) and loops over the work items; the
+// three residuals of a (surfel, keyframe) pair are folded into one per-lane 27-vector which is
+// reduced across the wave64 with cross-lane adds and merged with one atomic per scalar per wave.
+// The 6x6 LDLT (binary64, like the reference), T <- T*exp(-x) and the convergence test run in a
+// second tiny kernel on the device, so a round costs two launches and one 4-byte read-back.
+#include "ba_device.h"
+#include "se3_device.h"
+
+namespace bahip {
+
+constexpr int kPoseBlock = 256;
+
+template <bool kUseDepth, bool kUseDesc>
+__global__ void __launch_bounds__(kPoseBlock)
+pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
+                       int num_work, SurfelsView s, float* __restrict__ Hb) {
+  const uint32_t i = blockIdx.x * kPoseBlock + threadIdx.x;
+  const bool in_range = i < s.size;
+  const uint32_t ii = in_range ? i : 0;
+  const Vec3 gp = surfel_position(s, ii);
+  const Vec3 gn = surfel_normal(s, ii);
+  float radius_sq = 0, d1 = 0, d2 = 0;
+  if (kUseDesc) {
+    radius_sq = s.row(kSurfelRadiusSquared)[ii];
+    d1 = s.row(kSurfelDescriptor1)[ii];
+    d2 = s.row(kSurfelDescriptor2)[ii];
+  }
+  const int lane = threadIdx.x & 63;
+
+  for (int w = 0; w < num_work; ++w) {
+    if (__builtin_amdgcn_readfirstlane(work[w].done)) continue;
+    const float* F = work[w].F;
+    const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
+    Assoc r;
+    const bool visible = in_range && project_associate<false>(in, F, kf.depth, kf.depth_pitch, kf.normals,
+                                                              kf.normals_pitch, gp, gn, &r, nullptr);
+    if (!__any(visible)) continue;
+
+    float acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0.f;
+
+    if (visible) {
+      float J[6];
+      if (kUseDepth) {
+        // B/kernel_opt_pose.cu:45-94
+        const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
+        const Vec3 u = unproject(in, r.px, r.py, r.depth);
+        const float raw = inv_std * dot3(r.nl, u - r.local);
+        J[0] = inv_std * r.nl.x;
+        J[1] = inv_std * r.nl.y;
+        J[2] = inv_std * r.nl.z;
+        J[3] = inv_std * (-r.nl.y * u.z + r.nl.z * u.y);
+        J[4] = inv_std * (r.nl.x * u.z - r.nl.z * u.x);
+        J[5] = inv_std * (-r.nl.x * u.y + r.nl.y * u.x);
+        const float wgt = depth_residual_weight(raw);
+        int q = 0;
+#pragma unroll
+        for (int row = 0; row < 6; ++row)
+#pragma unroll
+          for (int col = row; col < 6; ++col) acc[q++] += wgt * J[row] * J[col];
+        const float wr = wgt * raw;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[21 + c] += wr * J[c];
+      }
+      if (kUseDesc) {
+        float cx, cy;
+        // B/kernel_opt_pose.cu:303-353: nothing is added when the colour-pixel transform fails.
+        if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
+          DescEval e;
+          eval_descriptor<true>(in, kf.color, kf.color_pitch, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
+          // B/kernel_opt_pose.cu:96-142
+          const Vec3 ls = r.local;
+          const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float gx = (t ? e.gx2 : e.gx1) * in.cfx;
+            const float gy = (t ? e.gy2 : e.gy1) * in.cfy;
+            const float raw = t ? e.r2 : e.r1;
+            J[0] = -gx * inv_z;
+            J[1] = -gy * inv_z;
+            J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
+            J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
+            J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
+            J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+            const float wgt = descriptor_residual_weight(raw);
+            int q = 0;
+#pragma unroll
+            for (int row = 0; row < 6; ++row)
+#pragma unroll
+              for (int col = row; col < 6; ++col) acc[q++] += wgt * J[row] * J[col];
+            const float wr = wgt * raw;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[21 + c] += wr * J[c];
+          }
+        }
+      }
+    }
+
+    // wave64 reduction, then one atomic per scalar per wave
+    float mine = 0.f;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+      const float v = wave_sum(acc[q]);
+      if (lane == q) mine = v;
+    }
+    if (lane < 27) unsafeAtomicAdd(&Hb[(size_t)w * kHbStride + lane], mine);
+  }
+}
+
+// B/convergence_analysis.h:43-51
+__device__ __forceinline__ bool is_scale1_pose_converged(const float* x) {
+  float sq = 0.f;
+  for (int c = 0; c < 3; ++c) sq += x[c] * x[c];
+  for (int c = 3; c < 6; ++c) { const float v = x[c] * 10.f; sq += v * v; }
+  return sq < 1e-06f;
+}
+
+// LDLT with symmetric diagonal pivoting + pseudo-inverse rule on D, binary64 (what Eigen's
+// H.cast<double>().selfadjointView<Upper>().ldlt().solve(b) does, B/direct_ba_alternating.cc:206).
+template <int N>
+__device__ void ldlt_solve(double* A, const double* b, double* x) {
+  int perm[N];
+  for (int c = 0; c < N; ++c) perm[c] = c;
+  for (int k = 0; k < N; ++k) {
+    int piv = k; double best = fabs(A[k * N + k]);
+    for (int c = k + 1; c < N; ++c) if (fabs(A[c * N + c]) > best) { best = fabs(A[c * N + c]); piv = c; }
+    if (piv != k) {
+      for (int j = 0; j < N; ++j) { const double t = A[k * N + j]; A[k * N + j] = A[piv * N + j]; A[piv * N + j] = t; }
+      for (int j = 0; j < N; ++j) { const double t = A[j * N + k]; A[j * N + k] = A[j * N + piv]; A[j * N + piv] = t; }
+      const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    const double d = A[k * N + k];
+    if (fabs(d) > 2.2250738585072014e-308) {
+      for (int c = k + 1; c < N; ++c) A[c * N + k] /= d;
+      for (int c = k + 1; c < N; ++c)
+        for (int j = k + 1; j <= c; ++j) {
+          A[c * N + j] -= A[c * N + k] * d * A[j * N + k];
+          A[j * N + c] = A[c * N + j];
+        }
+    } else {
+      for (int c = k + 1; c < N; ++c) A[c * N + k] = 0;
+    }
+  }
+  double y[N];
+  for (int c = 0; c < N; ++c) y[c] = b[perm[c]];
+  for (int c = 0; c < N; ++c) for (int j = 0; j < c; ++j) y[c] -= A[c * N + j] * y[j];
+  for (int c = 0; c < N; ++c) { const double d = A[c * N + c]; y[c] = (fabs(d) > 2.2250738585072014e-308) ? y[c] / d : 0.0; }
+  for (int c = N - 1; c >= 0; --c) for (int j = c + 1; j < N; ++j) y[c] -= A[j * N + c] * y[j];
+  for (int c = 0; c < N; ++c) x[perm[c]] = y[c];
+}
+
+// One GN update per work item: B/direct_ba_alternating.cc:173-244.
+__global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, float* __restrict__ Hb,
+                                  KfEntry* __restrict__ frames, int write_back, int* __restrict__ not_done_count) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= num_work) return;
+  PoseWork& pw = work[w];
+  if (pw.done) return;
+  float* hb = Hb + (size_t)w * kHbStride;
+  double A[36], b[6], x[6];
+  int q = 0;
+  for (int row = 0; row < 6; ++row)
+    for (int col = row; col < 6; ++col) { A[row * 6 + col] = hb[q]; A[col * 6 + row] = hb[q]; ++q; }
+  for (int c = 0; c < 6; ++c) b[c] = hb[21 + c];
+  for (int c = 0; c < kHbStride; ++c) hb[c] = 0.f;
+  ldlt_solve<6>(A, b, x);
+  float xf[6], mx[6];
+  for (int c = 0; c < 6; ++c) { xf[c] = (float)x[c]; mx[c] = -1.f * xf[c]; }
+  float upd[7], next[7];
+  se3_exp(mx, upd);
+  se3_mul(pw.T, upd, next);
+  for (int c = 0; c < 7; ++c) pw.T[c] = next[c];
+  float inv[7];
+  se3_inverse(next, inv);
+  se3_matrix3x4(inv, pw.F);
+  pw.iterations += 1;
+  const bool conv = is_scale1_pose_converged(xf);
+  if (conv) pw.converged = 1;
+  if (conv || pw.iterations >= BAHIP_MAX_POSE_ITERATIONS) {
+    pw.done = 1;
+    if (write_back) {
+      KfEntry& kf = frames[pw.kf_index];
+      for (int c = 0; c < 7; ++c) kf.global_T_frame[c] = next[c];
+      for (int c = 0; c < 12; ++c) kf.pose.F[c] = pw.F[c];
+      se3_rotation(next, kf.pose.GR);
+    }
+  } else {
+    atomicAdd(not_done_count, 1);
+  }
+}
+
+// Builds one work item per bound keyframe (skipping kInactive ones), B/direct_ba_alternating.cc:547-553.
+__global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs, PoseWork* __restrict__ work,
+                                                float* __restrict__ Hb) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_kfs) return;
+  PoseWork& pw = work[k];
+  pw.kf_index = k;
+  pw.iterations = 0;
+  pw.converged = 0;
+  pw.done = (frames[k].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
+  for (int c = 0; c < 7; ++c) pw.T[c] = frames[k].global_T_frame[c];
+  for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
+  for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0.f;
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
+                            const void* work, int num_work, const SurfelsView& s, float* Hb) {
+  if (s.size == 0 || num_work == 0) return;
+  const dim3 grid((s.size + kPoseBlock - 1) / kPoseBlock), block(kPoseBlock);
+  const PoseWork* pw = static_cast<const PoseWork*>(work);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
+}
+
+void launch_pose_solve(hipStream_t stream, void* work, int num_work, float* Hb, KfEntry* frames, int write_back,
+                       int* not_done_count) {
+  if (num_work == 0) return;
+  hipLaunchKernelGGL(pose_solve_kernel, dim3((num_work + 63) / 64), dim3(64), 0, stream, static_cast<PoseWork*>(work),
+                     num_work, Hb, frames, write_back, not_done_count);
+}
+
+void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, float* Hb) {
+  if (num_kfs == 0) return;
+  hipLaunchKernelGGL(pose_init_from_keyframes_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs,
+                     static_cast<PoseWork*>(work), Hb);
+}
+
+
+
+
+}  // namespace bahip
+
+// ---- test hook: per-pair evaluation ------------------------------------------------------------------
+// Evaluates association, raw residuals, weights and pose Jacobians of individual (surfel, frame)
+// pairs with exactly the device functions the production kernels use; lets the parity tests
+// compare per-pair quantities against the oracle.  out: 40 floats per surfel index:
+// [0] associated, [1] px, [2] py, [3] colour-valid, [4] calibrated depth, [5] depth residual,
+// [6] depth weight, [7] inv stddev, [8..13] depth J, [14..15] desc residuals, [16..17] desc weights,
+// [18..23] desc J1, [24..29] desc J2, [30..33] gradients, [34..35] pxx, pxy.
+namespace bahip {
+__global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ indices,
+                                      int count, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  float* o = out + 40 * (size_t)t;
+  for (int c = 0; c < 40; ++c) o[c] = 0.f;
+  const uint32_t i = indices[t];
+  if (i >= s.size) return;
+  const float* F = frame.pose.F;
+  const Vec3 gp = surfel_position(s, i);
+  const Vec3 gn = surfel_normal(s, i);
+  Assoc r;
+  if (!project_associate<false>(in, F, frame.depth, frame.depth_pitch, frame.normals, frame.normals_pitch, gp, gn, &r, nullptr)) return;
+  o[0] = 1.f; o[1] = (float)r.px; o[2] = (float)r.py; o[4] = r.depth; o[34] = r.pxx; o[35] = r.pxy;
+  const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
+  const Vec3 u = unproject(in, r.px, r.py, r.depth);
+  const float raw = inv_std * dot3(r.nl, u - r.local);
+  o[5] = raw; o[6] = depth_residual_weight(raw); o[7] = inv_std;
+  o[8] = inv_std * r.nl.x; o[9] = inv_std * r.nl.y; o[10] = inv_std * r.nl.z;
+  o[11] = inv_std * (-r.nl.y * u.z + r.nl.z * u.y);
+  o[12] = inv_std * (r.nl.x * u.z - r.nl.z * u.x);
+  o[13] = inv_std * (-r.nl.x * u.y + r.nl.y * u.x);
+  float cx, cy;
+  if (!depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) return;
+  o[3] = 1.f;
+  DescEval e;
+  eval_descriptor<true>(in, frame.color, frame.color_pitch, F, gp, gn, s.row(kSurfelRadiusSquared)[i], cx, cy,
+                        s.row(kSurfelDescriptor1)[i], s.row(kSurfelDescriptor2)[i], &e);
+  o[14] = e.r1; o[15] = e.r2; o[16] = descriptor_residual_weight(e.r1); o[17] = descriptor_residual_weight(e.r2);
+  o[30] = e.gx1; o[31] = e.gy1; o[32] = e.gx2; o[33] = e.gy2;
+  const Vec3 ls = r.local;
+  const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
+  for (int q = 0; q < 2; ++q) {
+    const float gx = (q ? e.gx2 : e.gx1) * in.cfx, gy = (q ? e.gy2 : e.gy1) * in.cfy;
+    float* J = o + 18 + 6 * q;
+    J[0] = -gx * inv_z;
+    J[1] = -gy * inv_z;
+    J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
+    J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
+    J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
+    J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+  }
+}
+void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
+                           const uint32_t* indices, int count, float* out) {
+  if (count) hipLaunchKernelGGL(evaluate_pairs_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, in, frame, s, indices, count, out);
+}
+}  // namespace bahip

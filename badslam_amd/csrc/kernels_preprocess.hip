@@ -1,0 +1,154 @@
+// kernels_preprocess.hip -- what Keyframe's convenience constructor runs on its inputs
+// (B/keyframe.cc:96-144, B/ = applications/badslam/src/badslam/): luma, normals, point radii,
+// min/max depth.  Pixel kernels, 64x4 blocks (one wave64 per image row segment -> coalesced
+// 128-byte u16 rows).
+#include <hip/hip_fp16.h>
+
+#include "ba_device.h"
+
+namespace bahip {
+
+constexpr int kPxBlockX = 64, kPxBlockY = 4;
+
+// B/cuda_image_processing.cu:165-175
+__global__ void __launch_bounds__(kPxBlockX* kPxBlockY)
+brightness_kernel(const uint8_t* __restrict__ rgb, uint32_t rgb_pitch, uint8_t* __restrict__ rgba, uint32_t rgba_pitch,
+                  int width, int height) {
+  const int x = blockIdx.x * kPxBlockX + threadIdx.x, y = blockIdx.y * kPxBlockY + threadIdx.y;
+  if (x >= width || y >= height) return;
+  const uint8_t* p = rgb + (size_t)y * rgb_pitch + 3 * x;
+  const uint8_t r = p[0], g = p[1], b = p[2];
+  const uint8_t intensity = (uint8_t)(__builtin_fmaf(0.114f, (float)b, __builtin_fmaf(0.587f, (float)g, 0.299f * (float)r)) + 0.5f);
+  *reinterpret_cast<uchar4*>(rgba + (size_t)y * rgba_pitch + 4 * x) = make_uchar4(r, g, b, intensity);
+}
+
+// B/cuda_depth_processing.cu:134-264
+__global__ void __launch_bounds__(kPxBlockX* kPxBlockY)
+normals_from_depth_kernel(Intrinsics in, const uint16_t* __restrict__ in_depth, uint32_t in_pitch,
+                          uint16_t* __restrict__ out_depth, uint32_t out_pitch, uint16_t* __restrict__ out_normals,
+                          uint32_t normals_pitch) {
+  const int x = blockIdx.x * kPxBlockX + threadIdx.x, y = blockIdx.y * kPxBlockY + threadIdx.y;
+  const int W = in.width, H = in.height;
+  if (x >= W || y >= H) return;
+  uint16_t* od = pitched_ptr(out_depth, out_pitch, y, x);
+  uint16_t* on = pitched_ptr(out_normals, normals_pitch, y, x);
+  const uint16_t zero_normal = pack_normal8(0, 0);
+  if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) { *od = kUnknownDepth; *on = zero_normal; return; }
+  const uint16_t center_raw = pitched_load(in_depth, in_pitch, y, x);
+  if (center_raw & kInvalidDepthBit) { *od = kUnknownDepth; *on = zero_normal; return; }
+  const uint16_t right_raw = pitched_load(in_depth, in_pitch, y, x + 1);
+  const uint16_t left_raw = pitched_load(in_depth, in_pitch, y, x - 1);
+  const uint16_t bottom_raw = pitched_load(in_depth, in_pitch, y + 1, x);
+  const uint16_t top_raw = pitched_load(in_depth, in_pitch, y - 1, x);
+  if ((right_raw | left_raw | bottom_raw | top_raw) & kInvalidDepthBit) { *od = kUnknownDepth; *on = zero_normal; return; }
+
+  const float cd = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y), in.raw_to_float_depth, center_raw);
+  const float ld = raw_to_calibrated_depth(in.a, cfactor_at(in, x - 1, y), in.raw_to_float_depth, left_raw);
+  const float td = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y - 1), in.raw_to_float_depth, top_raw);
+  const float rd = raw_to_calibrated_depth(in.a, cfactor_at(in, x + 1, y), in.raw_to_float_depth, right_raw);
+  const float bd = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y + 1), in.raw_to_float_depth, bottom_raw);
+  const Vec3 lp = unproject(in, x - 1, y, ld), tp = unproject(in, x, y - 1, td), rp = unproject(in, x + 1, y, rd);
+  const Vec3 bp = unproject(in, x, y + 1, bd), cp = unproject(in, x, y, cd);
+
+  constexpr float kRatioThresholdSquared = 2.f * 2.f;
+  const float left_sq = sqlen3(lp - cp), right_sq = sqlen3(rp - cp);
+  const float lr_ratio = left_sq / right_sq;
+  Vec3 left_to_right;
+  if (lr_ratio < kRatioThresholdSquared && lr_ratio > 1.f / kRatioThresholdSquared) left_to_right = rp - lp;
+  else if (left_sq < right_sq) left_to_right = cp - lp;
+  else left_to_right = rp - cp;
+  const float bottom_sq = sqlen3(bp - cp), top_sq = sqlen3(tp - cp);
+  const float bt_ratio = bottom_sq / top_sq;
+  Vec3 bottom_to_top;
+  if (bt_ratio < kRatioThresholdSquared && bt_ratio > 1.f / kRatioThresholdSquared) bottom_to_top = tp - bp;
+  else if (bottom_sq < top_sq) bottom_to_top = cp - bp;
+  else bottom_to_top = tp - cp;
+
+  Vec3 normal = cross3(left_to_right, bottom_to_top);
+  const float length = norm3(normal);
+  if (!(length > 1e-6f)) {
+    normal = mk3(0, 0, -1);
+  } else {
+    const float inv_length = ((in.fy_inv < 0) ? -1.0f : 1.0f) / length;
+    normal.x *= inv_length;
+    normal.y *= inv_length;
+  }
+  *on = pack_normal8(normal.x, normal.y);
+  *od = center_raw;
+}
+
+// B/cuda_depth_processing.cu:289-360 with min_neighbors_for_radius_computation = 4
+__global__ void __launch_bounds__(kPxBlockX* kPxBlockY)
+point_radii_kernel(Intrinsics in, float raw_to_float_depth, const uint16_t* __restrict__ depth, uint32_t depth_pitch,
+                   uint16_t* __restrict__ radius, uint32_t radius_pitch, uint16_t* __restrict__ out_depth, uint32_t out_pitch) {
+  const int x = blockIdx.x * kPxBlockX + threadIdx.x, y = blockIdx.y * kPxBlockY + threadIdx.y;
+  const int W = in.width, H = in.height;
+  if (x >= W || y >= H) return;
+  const uint16_t d16 = pitched_load(depth, depth_pitch, y, x);
+  if (d16 & kInvalidDepthBit) { *pitched_ptr(out_depth, out_pitch, y, x) = kUnknownDepth; return; }
+  const float d = raw_to_float_depth * d16;
+  const Vec3 local = mk3(d * (in.fx_inv * x + in.cx_inv), d * (in.fy_inv * y + in.cy_inv), d);
+  int neighbor_count = 0;
+  float min_sq = __builtin_huge_valf();
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    // same visiting order as the reference's dy/dx double loop: top, left, right, bottom
+    const int dx = x + ((n == 1) ? -1 : (n == 2) ? 1 : 0);
+    const int dy = y + ((n == 0) ? -1 : (n == 3) ? 1 : 0);
+    if (dx < 0 || dy < 0 || dx >= W || dy >= H) continue;
+    const uint16_t nd16 = pitched_load(depth, depth_pitch, dy, dx);
+    if (nd16 & kInvalidDepthBit) continue;
+    ++neighbor_count;
+    const float nd = raw_to_float_depth * nd16;
+    const Vec3 other = mk3(nd * (in.fx_inv * dx + in.cx_inv), nd * (in.fy_inv * dy + in.cy_inv), nd);
+    const float dist_sq = sqlen3(other - local);
+    if (dist_sq < min_sq) min_sq = dist_sq;
+  }
+  const bool valid = neighbor_count >= 4;
+  *pitched_ptr(radius, radius_pitch, y, x) = __half_as_ushort(__float2half_rn(valid ? min_sq : 0.f));
+  *pitched_ptr(out_depth, out_pitch, y, x) = valid ? d16 : kUnknownDepth;
+}
+
+// B/cuda_depth_processing.cu:391-428: positive floats order like their bit patterns.
+__global__ void __launch_bounds__(kPxBlockX* kPxBlockY)
+min_max_depth_kernel(const uint16_t* __restrict__ depth, uint32_t depth_pitch, int width, int height,
+                     float raw_to_float_depth, int* __restrict__ result /* [0]=min bits, [1]=max bits */) {
+  const int x = blockIdx.x * kPxBlockX + threadIdx.x, y = blockIdx.y * kPxBlockY + threadIdx.y;
+  float mn = __builtin_huge_valf(), mx = 0.f;
+  if (x < width && y < height) {
+    const uint16_t d16 = pitched_load(depth, depth_pitch, y, x);
+    if (!(d16 & kInvalidDepthBit)) { mn = mx = raw_to_float_depth * d16; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off));
+    mx = fmaxf(mx, __shfl_xor(mx, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&result[0], __float_as_int(mn));
+    atomicMax(&result[1], __float_as_int(mx));
+  }
+}
+
+static inline dim3 px_grid(int w, int h) { return dim3((w + kPxBlockX - 1) / kPxBlockX, (h + kPxBlockY - 1) / kPxBlockY); }
+
+void launch_brightness(hipStream_t stream, const uint8_t* rgb, uint32_t rgb_pitch, uint8_t* rgba, uint32_t rgba_pitch, int w, int h) {
+  hipLaunchKernelGGL(brightness_kernel, px_grid(w, h), dim3(kPxBlockX, kPxBlockY), 0, stream, rgb, rgb_pitch, rgba, rgba_pitch, w, h);
+}
+void launch_normals_from_depth(hipStream_t stream, const Intrinsics& in, const uint16_t* in_depth, uint32_t in_pitch,
+                               uint16_t* out_depth, uint32_t out_pitch, uint16_t* out_normals, uint32_t normals_pitch) {
+  hipLaunchKernelGGL(normals_from_depth_kernel, px_grid(in.width, in.height), dim3(kPxBlockX, kPxBlockY), 0, stream, in,
+                     in_depth, in_pitch, out_depth, out_pitch, out_normals, normals_pitch);
+}
+void launch_point_radii(hipStream_t stream, const Intrinsics& in, float raw_to_float_depth, const uint16_t* depth,
+                        uint32_t depth_pitch, uint16_t* radius, uint32_t radius_pitch, uint16_t* out_depth, uint32_t out_pitch) {
+  hipLaunchKernelGGL(point_radii_kernel, px_grid(in.width, in.height), dim3(kPxBlockX, kPxBlockY), 0, stream, in,
+                     raw_to_float_depth, depth, depth_pitch, radius, radius_pitch, out_depth, out_pitch);
+}
+void launch_min_max_depth(hipStream_t stream, const uint16_t* depth, uint32_t depth_pitch, int w, int h,
+                          float raw_to_float_depth, int* result) {
+  hipLaunchKernelGGL(min_max_depth_kernel, px_grid(w, h), dim3(kPxBlockX, kPxBlockY), 0, stream, depth, depth_pitch, w, h,
+                     raw_to_float_depth, result);
+}
+
+}  // namespace bahip

@@ -1,0 +1,223 @@
+/*
+ * badslam_hip.h -- C ABI of the MI355X-native direct bundle-adjustment backend.
+ *
+ * This is the drop-in boundary for the BA hot path of ETH3D/badslam: every entry point below
+ * replaces one of the free functions that the reference's DirectBA class calls
+ * (applications/badslam/src/badslam/kernels.h:94-495, abbreviated B/kernels.h) or one of its
+ * keyframe preprocessing calls (B/keyframe.cc:96-144).  Plain pointers and sizes only, no C++
+ * types.  All device pointers are BORROWED: the caller owns every allocation (the reference's
+ * CUDABuffer objects own theirs, B/direct_ba.h:441-507); the library only owns the scratch held
+ * inside a bahip_context.
+ *
+ * Conventions
+ *   - return value 0 = success; non-zero = failure, message via bahip_last_error() (the C++ shim
+ *     turns non-zero into LOG(FATAL), matching the reference's CUDA_CHECK() semantics,
+ *     libvis/src/libvis/cuda/cuda_util.h:35-49).
+ *   - "stream" is the hipStream_t a bahip_context was created on; every call is asynchronous on
+ *     that stream unless documented as synchronising (those that return host values).
+ *   - images are pitched row-major: element (y, x) of type T at (char*)data + y*pitch_bytes + x*sizeof(T),
+ *     exactly libvis CUDABuffer_<T> (libvis/src/libvis/cuda/cuda_buffer.cuh:44-119).
+ *   - the surfel buffer is the reference's 17-row SoA (B/kernels.cuh:69-93): row r, surfel i at
+ *     (float*)((char*)data + r*pitch_bytes) + i.
+ *   - cameras are PinholeCamera4f parameter vectors in the pixel-corner convention.
+ *   - poses are SE3f stored like Sophus: unit quaternion (x, y, z, w) then translation = 7 floats.
+ */
+#ifndef BADSLAM_HIP_H_
+#define BADSLAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BAHIP_SURFEL_ATTRIBUTE_COUNT 17   /* B/kernels.cuh:93 */
+#define BAHIP_MERGE_BUFFER_COUNT 3        /* B/kernels.cuh:51 */
+#define BAHIP_MAX_POSE_ITERATIONS 30      /* B/direct_ba_alternating.cc:130 */
+
+enum { BAHIP_KF_ACTIVE = 0, BAHIP_KF_COVISIBLE_ACTIVE = 1, BAHIP_KF_INACTIVE = 2 };  /* B/keyframe.h:54-67 */
+
+typedef struct bahip_camera {       /* libvis PinholeCamera4f */
+  float fx, fy, cx, cy;
+  int32_t width, height;
+} bahip_camera;
+
+typedef struct bahip_depth_params { /* B/surfel_projection.cuh:129-149 */
+  float a;
+  float raw_to_float_depth;
+  float baseline_fx;
+  int32_t sparse_surfel_cell_size;
+  float* cfactor;                   /* device, ((H-1)/cell+1) x ((W-1)/cell+1) floats */
+  uint32_t cfactor_pitch_bytes;
+  int32_t cfactor_width, cfactor_height;
+} bahip_depth_params;
+
+typedef struct bahip_frame {        /* the four images a Keyframe owns, B/keyframe.h:227-231 */
+  uint16_t* depth;   uint32_t depth_pitch_bytes;
+  uint16_t* normals; uint32_t normals_pitch_bytes;
+  uint16_t* radius;  uint32_t radius_pitch_bytes;
+  uint8_t* color;    uint32_t color_pitch_bytes;   /* uchar4 (R, G, B, luma) */
+} bahip_frame;
+
+typedef struct bahip_keyframe {     /* one entry of the keyframe list handed to the *_CUDA functions */
+  bahip_frame frame;
+  float global_T_frame[7];          /* qx qy qz qw tx ty tz */
+  int32_t activation;               /* BAHIP_KF_*; a deleted (null) keyframe is simply left out */
+} bahip_keyframe;
+
+typedef struct bahip_surfels {      /* B/direct_ba.cc:122-123 */
+  float* data;
+  uint32_t pitch_bytes;
+  uint8_t* active;                  /* may be NULL where the reference passes none */
+  uint32_t surfels_size;
+  uint32_t capacity;
+} bahip_surfels;
+
+typedef struct bahip_context bahip_context;
+
+/* ---- library / context ---------------------------------------------------------------------- */
+const char* bahip_last_error(void);
+int bahip_device_count(void);
+/* hip_stream: a hipStream_t (NULL = the legacy default stream). */
+int bahip_context_create(bahip_context** out, void* hip_stream);
+void bahip_context_destroy(bahip_context* ctx);
+int bahip_context_synchronize(bahip_context* ctx);
+/* Optional all-reduce hook for multi-GPU surfel sharding: called on the context's stream with a
+ * device buffer of `count` floats that must be summed element-wise over all ranks in place.
+ * NULL (default) = single GPU.  The host side installs a torch.distributed / RCCL all_reduce. */
+typedef int (*bahip_allreduce_fn)(void* device_buffer, size_t count, void* user);
+int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user);
+
+/* Device memory helpers (what libvis CUDABuffer does with cudaMallocPitch / cudaMemcpy2DAsync,
+ * libvis/src/libvis/cuda/cuda_buffer_inl.h:36-186). */
+int bahip_malloc_pitch(void** ptr, size_t* pitch_bytes, size_t width_bytes, size_t height);
+int bahip_free(void* ptr);
+int bahip_memcpy_2d(bahip_context* ctx, void* dst, size_t dst_pitch, const void* src, size_t src_pitch,
+                    size_t width_bytes, size_t height, int kind /* 1 = H2D, 2 = D2H, 3 = D2D */);
+int bahip_memset_2d(bahip_context* ctx, void* dst, size_t pitch, int value, size_t width_bytes, size_t height);
+
+/* ---- keyframe preprocessing (Keyframe ctor #2, B/keyframe.cc:96-144) ------------------------- */
+/* B/cuda_image_processing.cu:165-193 ComputeBrightnessCUDA: uchar3 RGB -> uchar4 (R,G,B,luma). */
+int bahip_compute_brightness(bahip_context* ctx, const uint8_t* rgb, uint32_t rgb_pitch_bytes,
+                             uint8_t* rgba, uint32_t rgba_pitch_bytes, int width, int height);
+/* B/cuda_depth_processing.cu:134-287 ComputeNormalsCUDA. */
+int bahip_compute_normals(bahip_context* ctx, const bahip_camera* depth_camera, const bahip_depth_params* dp,
+                          const uint16_t* in_depth, uint32_t in_pitch, uint16_t* out_depth, uint32_t out_pitch,
+                          uint16_t* out_normals, uint32_t normals_pitch);
+/* B/cuda_depth_processing.cu:289-388 ComputePointRadiiAndRemoveIsolatedPixelsCUDA. */
+int bahip_compute_point_radii_and_remove_isolated_pixels(
+    bahip_context* ctx, const bahip_camera* depth_camera, float raw_to_float_depth,
+    const uint16_t* depth, uint32_t depth_pitch, uint16_t* radius, uint32_t radius_pitch,
+    uint16_t* out_depth, uint32_t out_pitch);
+/* B/cuda_depth_processing.cu:391-465 ComputeMinMaxDepthCUDA (synchronises; results on host). */
+int bahip_compute_min_max_depth(bahip_context* ctx, const uint16_t* depth, uint32_t depth_pitch, int width,
+                                int height, float raw_to_float_depth, float* min_depth, float* max_depth);
+
+/* ---- scene binding ----------------------------------------------------------------------------
+ * The reference passes cameras, DepthParameters and the keyframe vector to every *_CUDA call.
+ * Here they are bound once per BA call and kept in a device-side keyframe table so that one
+ * launch can sweep all keyframes (the per-keyframe launch granularity of B/kernel_*.cc is what
+ * this backend removes). */
+int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, const bahip_camera* depth_camera,
+                         const bahip_depth_params* dp);
+int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int num_keyframes);
+/* Read back the poses of the bound keyframes (7 floats each); synchronises. */
+int bahip_get_keyframe_poses(bahip_context* ctx, float* global_T_frame_out, int num_keyframes);
+
+/* ---- optimisation stages ---------------------------------------------------------------------- */
+/* B/kernels.h UpdateSurfelActivationCUDA (B/kernel_surfel_activation.cc:39-67): surfels
+ * [0, surfels_size) become active iff associated with >= 1 keyframe whose activation is kActive. */
+int bahip_update_surfel_activation(bahip_context* ctx, const bahip_surfels* surfels, uint32_t surfels_size);
+/* B/kernels.h UpdateSurfelNormalsCUDA (B/kernel_opt_geometry.cc:39-77). */
+int bahip_update_surfel_normals(bahip_context* ctx, const bahip_surfels* surfels);
+/* B/kernels.h OptimizeGeometryIterationCUDA (B/kernel_opt_geometry.cc:80-201). */
+int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth_residuals, int use_descriptor_residuals,
+                                      const bahip_surfels* surfels);
+/* B/kernels.h AccumulatePoseEstimationCoeffsCUDA (B/kernel_opt_pose.cc:39-97): one frame, one
+ * linearisation point.  H = 21 floats (row-major upper triangle), b = 6 floats, on the host;
+ * synchronises like the reference does (B/kernel_opt_pose.cc:94-96). */
+int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth_residuals,
+                                            int use_descriptor_residuals, const bahip_frame* frame,
+                                            const float frame_T_global[12], const bahip_surfels* surfels,
+                                            float* H, float* b);
+/* DirectBA::EstimateFramePose (B/direct_ba_alternating.cc:42-283) for an arbitrary frame:
+ * <= 30 Gauss-Newton steps, each = accumulate + double-precision LDLT + T <- T*exp(-x), entirely
+ * on the device; one read-back at the end.  Outputs on the host. */
+int bahip_estimate_frame_pose(bahip_context* ctx, int use_depth_residuals, int use_descriptor_residuals,
+                              const bahip_frame* frame, const float global_T_frame_initial[7],
+                              const bahip_surfels* surfels, float global_T_frame_out[7],
+                              int* iterations_done, int* converged);
+/* The pose phase of one alternating-BA iteration (B/direct_ba_alternating.cc:545-577): every
+ * bound keyframe that is not kInactive gets its own EstimateFramePose, all keyframes batched per
+ * Gauss-Newton round (they are mutually independent: surfels are frozen during this phase).
+ * Updated poses stay in the device keyframe table (fetch with bahip_get_keyframe_poses) and are
+ * also returned here.  iterations_done / converged: per keyframe (0 / 1 for skipped ones).
+ * rounds_out: number of batched rounds (= max iterations over keyframes). */
+int bahip_estimate_keyframe_poses(bahip_context* ctx, int use_depth_residuals, int use_descriptor_residuals,
+                                  const bahip_surfels* surfels, float* global_T_frame_out,
+                                  int* iterations_done, int* converged, int* rounds_out);
+
+/* ---- surfel lifecycle --------------------------------------------------------------------------- */
+/* B/kernels.h DetermineSupportingSurfelsCUDA / ...AndMergeSurfelsCUDA
+ * (B/kernel_supporting_surfels.cc:112-165).  supporting: BAHIP_MERGE_BUFFER_COUNT device planes
+ * of height x width u32 with the given pitch.  merged_count_out (host, may be NULL when
+ * merge == 0) receives the number of surfels deleted by merging; synchronises when merging.
+ * Deterministic: slots are claimed by the lowest surfel index (atomicMin), not by arrival. */
+int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merge_dist_factor,
+                                       const bahip_frame* frame, const float frame_T_global[12],
+                                       const bahip_surfels* surfels, uint32_t* const* supporting,
+                                       uint32_t supporting_pitch_bytes, uint32_t* merged_count_out);
+/* B/kernels.h CreateSurfelsForKeyframeCUDA (B/kernel_create_surfels.cc:40-183), including the
+ * DetermineSupportingSurfelsCUDA call that DirectBA::CreateSurfelsForKeyframe issues first
+ * (B/direct_ba.cc:345-355).  keyframe_index selects the bound keyframe; covis / n_covis: indices
+ * of bound keyframes used for the new-surfel outlier filter.  new_surfel_count_out on the host;
+ * synchronises.  Deterministic: the lowest linear pixel index wins a sparse cell. */
+int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, int filter_new_surfels,
+                                      int min_observation_count, const int* covis, int n_covis,
+                                      const bahip_surfels* surfels, uint32_t* const* supporting,
+                                      uint32_t supporting_pitch_bytes, uint32_t* new_surfel_count_out);
+/* B/kernels.h DeleteSurfelsAndUpdateRadiiCUDA (B/kernel_delete_surfels.cc:40-120); synchronises. */
+int bahip_delete_surfels_and_update_radii(bahip_context* ctx, int min_observation_count,
+                                          const bahip_surfels* surfels, uint32_t* deleted_count_out);
+/* B/kernels.h CompactSurfelsCUDA (B/kernel_compact_surfels.cu:159-279): surfel_count valid
+ * surfels end up in [0, surfel_count).  surfels->active may be NULL. */
+int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip_surfels* surfels);
+
+/* ---- intrinsics (B/kernels.h OptimizeIntrinsicsCUDA, B/kernel_opt_intrinsics.cc:39-281) --------- */
+int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth_intrinsics, int optimize_color_intrinsics,
+                              const bahip_surfels* surfels, bahip_camera* out_color_camera,
+                              bahip_camera* out_depth_camera, float* out_a);
+
+/* ---- PCG solver (B/direct_ba_pcg.cc:229-646 over B/kernels.h PCG*CUDA) -------------------------- */
+typedef struct bahip_pcg_options {
+  int optimize_poses, optimize_geometry, optimize_depth_intrinsics, optimize_color_intrinsics;
+  int use_depth_residuals, use_descriptor_residuals;
+  int max_inner_iterations;     /* 30 */
+  int gauge_keyframe;           /* index of the keyframe held fixed (reference: rand() % K) */
+} bahip_pcg_options;
+/* One outer Gauss-Newton iteration of the PCG scheme: builds and solves the full normal
+ * equations matrix-free, applies the update to poses (device table), surfels, intrinsics and
+ * cfactors.  Outputs new intrinsics on the host; inner_steps_out = PCG steps used. */
+int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const bahip_surfels* surfels,
+                        bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a,
+                        int* inner_steps_out);
+
+/* ---- test hook --------------------------------------------------------------------------------------
+ * Per-pair evaluation with the production device functions (association, the three raw residuals,
+ * weights, pose Jacobians, image gradients) for `count` surfel indices against one frame; 40 floats
+ * per index, layout documented in badslam_amd/csrc/kernels_pose.hip.  Host in / host out. */
+int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, const float frame_T_global[12],
+                               const bahip_surfels* surfels, const uint32_t* surfel_indices, int count, float* out);
+
+/* ---- instrumentation ---------------------------------------------------------------------------- */
+/* Time (ms, hipEvent on the context stream) and launch count of the kernels issued by the last
+ * call of each stage; used by bench.py for the roofline line.  stage: 0 activation, 1 geometry,
+ * 2 pose accumulate, 3 pose solve. */
+int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* launches_out);
+int bahip_set_profiling(bahip_context* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* BADSLAM_HIP_H_ */

@@ -6,7 +6,8 @@
 void orc_compute_brightness(const uint8_t* rgb, int width, int height, uint8_t* rgba) {
   for (size_t i = 0; i < (size_t)width * height; ++i) {
     const uint8_t r = rgb[3 * i + 0], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
-    const uint8_t intensity = (uint8_t)((0.299f * r + 0.587f * g + 0.114f * b) + 0.5f);
+    /* evaluated as the fused chain a CUDA/HIP compiler emits for this expression (fmad contraction) */
+    const uint8_t intensity = (uint8_t)(fmaf(0.114f, (float)b, fmaf(0.587f, (float)g, 0.299f * (float)r)) + 0.5f);
     rgba[4 * i + 0] = r; rgba[4 * i + 1] = g; rgba[4 * i + 2] = b; rgba[4 * i + 3] = intensity;
   }
 }
