@@ -35,8 +35,10 @@ class Scene:
     rgb: List[np.ndarray] = field(default_factory=list)          # (H, W, 3) uint8
 
 
-def random_planes(rng: np.random.Generator, count: int, offset: float = 2.5) -> np.ndarray:
-    n = rng.uniform(-1.0, 1.0, size=(count, 3))
+def random_planes(rng: np.random.Generator, count: int, offset: float = 2.5, slope: float = 1.0) -> np.ndarray:
+    """Planes n.x + offset = 0 with n = (slope*u1, slope*u2, -1)/|.|, u uniform in [-1, 1]
+    (slope 1 = the reference tests' Vec3f::Random() normals)."""
+    n = slope * rng.uniform(-1.0, 1.0, size=(count, 3))
     n[:, 2] = -1.0
     n /= np.linalg.norm(n, axis=1, keepdims=True)
     return np.concatenate([n, np.full((count, 1), offset)], axis=1)
