@@ -100,6 +100,7 @@ SIGNATURES = {
                                       C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bahip_debug_evaluate_pairs": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_float), C.POINTER(Surfels),
                                              C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float)]),
+    "bahip_debug_count_pairs": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.POINTER(C.c_uint64)]),
     "bahip_last_stage_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bahip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
 }

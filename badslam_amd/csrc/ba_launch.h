@@ -27,6 +27,9 @@ void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
                      int num_kfs, const SurfelsView& s);
 
+void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                        unsigned long long* counts);
+
 // kernels_pose.hip
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, float* Hb);
@@ -42,6 +45,7 @@ void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, in
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup);
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
                   float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count);
+size_t create_padded_count(const Intrinsics& in);   // length of the tile-major flag / index vectors
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags);
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,
                           const float* covis_T_frame, int n_covis, int min_obs, uint8_t* flags);

@@ -523,9 +523,9 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
   const KfEntry& e = ctx->host_kfs[keyframe_index];
   *new_surfel_count_out = 0;
   if (determine_supporting_impl(ctx, 0, 0.f, e, surfels, sup, nullptr)) return 1;
-  const int W = ctx->in.width, H = ctx->in.height;
-  const size_t px = (size_t)W * H;
+  const size_t px = create_padded_count(ctx->in);   // tile-major sequence, padded to whole tiles
   if (ensure_px(ctx, px, px > surfels->capacity ? px : surfels->capacity)) return 1;
+  HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, ctx->stream));
   launch_create_flag(ctx->stream, ctx->in, e, sup, ctx->dev_flags);
   CHECK_LAUNCH();
   if (filter_new_surfels && n_covis > 0) {
@@ -622,6 +622,19 @@ int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, con
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out_host, d_out, sizeof(float) * 40 * count, hipMemcpyDeviceToHost));
   hipFree(d_idx); hipFree(d_out);
+  return 0;
+}
+
+int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  launch_count_pairs(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), d);
+  CHECK_LAUNCH();
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(counts_out, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  hipFree(d);
   return 0;
 }
 

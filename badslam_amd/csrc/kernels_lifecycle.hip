@@ -99,9 +99,31 @@ merge_apply_kernel(SurfelsView s, const uint32_t* __restrict__ flags, uint32_t* 
 }
 
 // ---- creation ---------------------------------------------------------------------------------------
+// New surfels are numbered tile-major: tiles of 8x8 sparse cells (TP = 8*cell pixels per side),
+// row-major inside a tile, so that the 64 surfels of a wavefront form a compact patch that
+// wave_cull.h can bound tightly.  (The reference numbers them by a prefix sum over the row-major
+// pixel index, B/kernel_create_surfels.cu:357-390; the order is not observable in its results.)
+// The flag / index vectors are laid out in that sequence order, padded to whole tiles.
+__device__ __forceinline__ int tile_side(const Intrinsics& in) { return 8 * in.cell; }
+__device__ __forceinline__ int tiles_per_row(const Intrinsics& in) { return (in.width + tile_side(in) - 1) / tile_side(in); }
+__device__ __forceinline__ size_t tile_seq(const Intrinsics& in, int x, int y) {
+  const int tp = tile_side(in);
+  const int tx = x / tp, ty = y / tp, lx = x - tx * tp, ly = y - ty * tp;
+  return (((size_t)ty * tiles_per_row(in) + tx) * tp + ly) * tp + lx;
+}
+__device__ __forceinline__ bool tile_xy(const Intrinsics& in, size_t seq, int* x, int* y) {
+  const int tp = tile_side(in);
+  const int lx = (int)(seq % tp); seq /= tp;
+  const int ly = (int)(seq % tp); seq /= tp;
+  const int tpr = tiles_per_row(in);
+  const int tx = (int)(seq % tpr), ty = (int)(seq / tpr);
+  *x = tx * tp + lx; *y = ty * tp + ly;
+  return *x < in.width && *y < in.height;
+}
+
 // One thread per sparse cell: B/kernel_create_surfels.cu:41-75 with a deterministic winner.
 __global__ void __launch_bounds__(kLcBlock)
-create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __restrict__ flags /* W*H dense */) {
+create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __restrict__ flags /* tile-major, padded */) {
   const int cxy = blockIdx.x * kLcBlock + threadIdx.x;
   if (cxy >= in.cf_width * in.cf_height) return;
   const int cy = cxy / in.cf_width, cx = cxy - cy * in.cf_width;
@@ -118,7 +140,7 @@ create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __
         flag = true;
         claimed = true;
       }
-      flags[(size_t)y * in.width + x] = flag ? 1 : 0;
+      flags[tile_seq(in, x, y)] = flag ? 1 : 0;
     }
   }
   if (claimed) *slot = 0;
@@ -128,11 +150,12 @@ create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __
 __global__ void __launch_bounds__(kLcBlock)
 create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ kfs, const int* __restrict__ covis,
                      const float* __restrict__ covis_T_frame /* 12 floats each */, int n_covis,
-                     int min_observation_count, uint8_t* __restrict__ flags) {
+                     int min_observation_count, int padded_count, uint8_t* __restrict__ flags) {
   const int idx = blockIdx.x * kLcBlock + threadIdx.x;
-  if (idx >= in.width * in.height) return;
+  if (idx >= padded_count) return;
   if (!flags[idx]) return;
-  const int y = idx / in.width, x = idx - y * in.width;
+  int x, y;
+  if (!tile_xy(in, (size_t)idx, &x, &y)) return;
   uint32_t observations = 1, violations = 0;
   const float cd = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y), in.raw_to_float_depth, pitched_load(frame.depth, frame.depth_pitch, y, x));
   const Vec3 input_pos = unproject(in, x, y, cd);
@@ -167,11 +190,12 @@ create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ k
 // B/kernel_create_surfels.cu:91-160,357-390
 __global__ void __launch_bounds__(kLcBlock)
 create_append_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ indices,
-                     uint32_t surfels_size, SurfelsView s) {
+                     int padded_count, uint32_t surfels_size, SurfelsView s) {
   const int idx = blockIdx.x * kLcBlock + threadIdx.x;
-  if (idx >= in.width * in.height) return;
+  if (idx >= padded_count) return;
   if (flags[idx] != 1) return;
-  const int y = idx / in.width, x = idx - y * in.width;
+  int x, y;
+  if (!tile_xy(in, (size_t)idx, &x, &y)) return;
   const uint32_t si = surfels_size + indices[idx] - 1;   // inclusive scan
   float G[12];
   {
@@ -303,15 +327,21 @@ void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, co
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags) {
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags);
 }
+size_t create_padded_count(const Intrinsics& in) {
+  const size_t tp = 8 * (size_t)in.cell;
+  return ((in.width + tp - 1) / tp) * ((in.height + tp - 1) / tp) * tp * tp;
+}
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,
                           const float* covis_T_frame, int n_covis, int min_obs, uint8_t* flags) {
-  hipLaunchKernelGGL(create_filter_kernel, dim3(g1(in.width * in.height)), dim3(kLcBlock), 0, st, in, frame, kfs, covis,
-                     covis_T_frame, n_covis, min_obs, flags);
+  const int padded = (int)create_padded_count(in);
+  hipLaunchKernelGGL(create_filter_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, kfs, covis,
+                     covis_T_frame, n_covis, min_obs, padded, flags);
 }
 void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags,
                           const uint32_t* indices, uint32_t surfels_size, const SurfelsView& s) {
-  hipLaunchKernelGGL(create_append_kernel, dim3(g1(in.width * in.height)), dim3(kLcBlock), 0, st, in, frame, flags, indices,
-                     surfels_size, s);
+  const int padded = (int)create_padded_count(in);
+  hipLaunchKernelGGL(create_append_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, flags, indices,
+                     padded, surfels_size, s);
 }
 void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                           int min_obs, uint32_t* deleted_count) {

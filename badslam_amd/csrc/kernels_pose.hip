@@ -13,7 +13,9 @@
 // The 6x6 LDLT (binary64, like the reference), T <- T*exp(-x) and the convergence test run in a
 // second tiny kernel on the device, so a round costs two launches and one 4-byte read-back.
 #include "ba_device.h"
+#include "ba_launch.h"
 #include "se3_device.h"
+#include "wave_cull.h"
 
 namespace bahip {
 
@@ -36,14 +38,18 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
   }
   const int lane = threadIdx.x & 63;
 
-  for (int w = 0; w < num_work; ++w) {
-    if (__builtin_amdgcn_readfirstlane(work[w].done)) continue;
+  // Only the work items whose frustum can contain this wavefront's surfels are visited (wave_cull.h).
+  const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
+  for_each_candidate(
+      num_work,
+      [&](int w) { return !work[w].done && sphere_may_project(in, work[w].F, wb); },
+      [&](int w) {
     const float* F = work[w].F;
     const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
     Assoc r;
     const bool visible = in_range && project_associate<false>(in, F, kf.depth, kf.depth_pitch, kf.normals,
                                                               kf.normals_pitch, gp, gn, &r, nullptr);
-    if (!__any(visible)) continue;
+    if (!__any(visible)) return;
 
     float acc[27];
 #pragma unroll
@@ -114,7 +120,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
       if (lane == q) mine = v;
     }
     if (lane < 27) unsafeAtomicAdd(&Hb[(size_t)w * kHbStride + lane], mine);
-  }
+  });
 }
 
 // B/convergence_analysis.h:43-51

@@ -4,15 +4,19 @@
 // per stage, every launch streaming all N surfels and doing read-modify-write on the accumulator
 // rows of the surfel buffer (B/kernel_surfel_activation.cc:53-66, B/kernel_opt_geometry.cc:108-200).
 // Here each stage is ONE launch: a thread owns a surfel, keeps position / normal / accumulators in
-// registers and loops over the device-side keyframe table (wave-uniform -> scalar loads), so the
-// surfel array is read once and written once per stage and the K-fold RMW traffic disappears.
-// Accumulation over keyframes happens in keyframe order, i.e. in the same order as the
-// reference's sequence of launches.
+// registers and visits only the keyframes whose frustum can contain its wavefront's 64 surfels
+// (wave_cull.h), so the surfel array is read once and written once per stage and both the K-fold
+// RMW traffic and most of the K x N association tests disappear.  Keyframes are visited in
+// ascending order, i.e. accumulation order equals the reference's sequence of launches.
 #include "ba_device.h"
+#include "ba_launch.h"
+#include "wave_cull.h"
 
 namespace bahip {
 
 constexpr int kSurfelBlock = 256;
+
+__device__ __forceinline__ bool position_valid(Vec3 p) { return p.x == p.x; }   // deleted surfels carry NaN x
 
 // B/kernel_surfel_activation.cu:38-94
 __global__ void __launch_bounds__(kSurfelBlock)
@@ -22,38 +26,42 @@ activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, S
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
   const Vec3 gn = surfel_normal(s, ii);
+  const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
   bool active = false;
-  bool pending = in_range;
-  for (int k = 0; k < num_kfs; ++k) {
-    if (__builtin_amdgcn_readfirstlane(kfs[k].activation) != BAHIP_KF_ACTIVE) continue;
-    if (!__any(pending)) break;
-    if (pending) {
-      Assoc r;
-      if (project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
-                                   kfs[k].normals_pitch, gp, gn, &r, nullptr)) {
-        active = true;
-        pending = false;
-      }
-    }
-  }
+  for_each_candidate(
+      num_kfs,
+      [&](int k) { return kfs[k].activation == BAHIP_KF_ACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); },
+      [&](int k) {
+        if (in_range && !active) {
+          Assoc r;
+          if (project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
+                                       kfs[k].normals_pitch, gp, gn, &r, nullptr)) active = true;
+        }
+      });
   if (in_range) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (active ? kSurfelActiveFlag : 0);
 }
 
 // Normals pass: B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update).
+// `live` = this lane holds an active surfel; every lane of the wave must call this function.
 __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs,
-                                             SurfelsView& s, uint32_t i, Vec3 gp, Vec3* gn_inout) {
+                                             const WaveBounds& wb, SurfelsView& s, uint32_t i, bool live, Vec3 gp,
+                                             Vec3* gn_inout) {
   float sx = 0, sy = 0, sz = 0, count = 0;
   const Vec3 gn = *gn_inout;
-  for (int k = 0; k < num_kfs; ++k) {
-    if (__builtin_amdgcn_readfirstlane(kfs[k].activation) == BAHIP_KF_INACTIVE) continue;
-    Assoc r;
-    if (project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
-                                 kfs[k].normals_pitch, gp, gn, &r, nullptr)) {
-      const Vec3 m = unpack_normal8(pitched_load(kfs[k].normals, kfs[k].normals_pitch, r.py, r.px));
-      const Vec3 g = mul33(kfs[k].pose.GR, m);
-      sx += g.x; sy += g.y; sz += g.z; count += 1.f;
-    }
-  }
+  for_each_candidate(
+      num_kfs,
+      [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); },
+      [&](int k) {
+        if (!live) return;
+        Assoc r;
+        if (project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
+                                     kfs[k].normals_pitch, gp, gn, &r, nullptr)) {
+          const Vec3 m = unpack_normal8(pitched_load(kfs[k].normals, kfs[k].normals_pitch, r.py, r.px));
+          const Vec3 g = mul33(kfs[k].pose.GR, m);
+          sx += g.x; sy += g.y; sz += g.z; count += 1.f;
+        }
+      });
+  if (!live) return;
   // The reference leaves the sums in accum rows 0..3; keep that observable state.
   s.row(kSurfelAccum0 + 0)[i] = sx; s.row(kSurfelAccum0 + 1)[i] = sy;
   s.row(kSurfelAccum0 + 2)[i] = sz; s.row(kSurfelAccum0 + 3)[i] = count;
@@ -67,11 +75,13 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
 __global__ void __launch_bounds__(kSurfelBlock)
 normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
   const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
-  if (i >= s.size) return;
-  if (!(s.active[i] & kSurfelActiveFlag)) return;
-  Vec3 gp = surfel_position(s, i);
-  Vec3 gn = surfel_normal(s, i);
-  normals_pass(in, kfs, num_kfs, s, i, gp, &gn);
+  const bool in_range = i < s.size;
+  const uint32_t ii = in_range ? i : 0;
+  const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
+  const Vec3 gp = surfel_position(s, ii);
+  Vec3 gn = surfel_normal(s, ii);
+  const WaveBounds wb = wave_bounds(gp, live && position_valid(gp));
+  normals_pass(in, kfs, num_kfs, wb, s, ii, live, gp, &gn);
 }
 
 // Geometry step of one BA iteration for one surfel: normals, then either the depth-only 1x1 solve
@@ -80,19 +90,24 @@ template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(kSurfelBlock)
 geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
   const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
-  if (i >= s.size) return;
-  if (!(s.active[i] & kSurfelActiveFlag)) return;
-  const Vec3 gp = surfel_position(s, i);
-  Vec3 gn = surfel_normal(s, i);
-  normals_pass(in, kfs, num_kfs, s, i, gp, &gn);
+  const bool in_range = i < s.size;
+  const uint32_t ii = in_range ? i : 0;
+  const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
+  const Vec3 gp = surfel_position(s, ii);
+  Vec3 gn = surfel_normal(s, ii);
+  const WaveBounds wb = wave_bounds(gp, live && position_valid(gp));
+  if (wb.r < 0.f) return;   // wave-uniform: no active surfel in this wavefront
+  normals_pass(in, kfs, num_kfs, wb, s, ii, live, gp, &gn);
+
+  auto cand = [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); };
 
   if (!kUseDesc) {
     float H = 0, b = 0;
-    for (int k = 0; k < num_kfs; ++k) {
-      if (__builtin_amdgcn_readfirstlane(kfs[k].activation) == BAHIP_KF_INACTIVE) continue;
+    for_each_candidate(num_kfs, cand, [&](int k) {
+      if (!live) return;
       Assoc r;
       if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
-                                    kfs[k].normals_pitch, gp, gn, &r, nullptr)) continue;
+                                    kfs[k].normals_pitch, gp, gn, &r, nullptr)) return;
       const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
       const float jac = -inv_std;
       const Vec3 u = unproject(in, r.px, r.py, r.depth);
@@ -101,7 +116,8 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
       const float wj = w * jac;
       H += wj * jac;
       b += wj * raw;
-    }
+    });
+    if (!live) return;
     s.row(kSurfelAccum0 + 0)[i] = H;
     s.row(kSurfelAccum0 + 1)[i] = b;
     if (H > 1e-6f) {
@@ -112,16 +128,16 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
     return;
   }
 
-  const float radius_sq = s.row(kSurfelRadiusSquared)[i];
-  const float d1 = s.row(kSurfelDescriptor1)[i];
-  const float d2 = s.row(kSurfelDescriptor2)[i];
+  const float radius_sq = s.row(kSurfelRadiusSquared)[ii];
+  const float d1 = s.row(kSurfelDescriptor1)[ii];
+  const float d2 = s.row(kSurfelDescriptor2)[ii];
   float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-  for (int k = 0; k < num_kfs; ++k) {
-    if (__builtin_amdgcn_readfirstlane(kfs[k].activation) == BAHIP_KF_INACTIVE) continue;
+  for_each_candidate(num_kfs, cand, [&](int k) {
+    if (!live) return;
     const float* F = kfs[k].pose.F;
     Assoc r;
     if (!project_associate<false>(in, F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals, kfs[k].normals_pitch,
-                                  gp, gn, &r, nullptr)) continue;
+                                  gp, gn, &r, nullptr)) return;
     if (kUseDepth) {
       const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
       const float jac = -inv_std;
@@ -154,7 +170,8 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
       a5 += w2 * jd * jd;
       a8 += wr2 * jd;
     }
-  }
+  });
+  if (!live) return;
   s.row(kSurfelAccum0 + 0)[i] = a0; s.row(kSurfelAccum0 + 1)[i] = a1; s.row(kSurfelAccum0 + 2)[i] = a2;
   s.row(kSurfelAccum0 + 3)[i] = a3; s.row(kSurfelAccum0 + 4)[i] = 0;  s.row(kSurfelAccum0 + 5)[i] = a5;
   s.row(kSurfelAccum0 + 6)[i] = a6; s.row(kSurfelAccum0 + 7)[i] = a7; s.row(kSurfelAccum0 + 8)[i] = a8;
@@ -205,4 +222,39 @@ void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const In
   else hipLaunchKernelGGL((geometry_kernel<false, true>), grid, block, 0, stream, in, kfs, num_kfs, s);
 }
 
+}  // namespace bahip
+
+// ---- diagnostics: how much work does a sweep over all keyframes contain? ----------------------------
+// counts[0] = (wave, keyframe) candidates after frustum culling, [1] = of those with >= 1 associated
+// lane, [2] = associated (surfel, keyframe) pairs, [3] = pairs that passed the in-image test.
+namespace bahip {
+__global__ void __launch_bounds__(kSurfelBlock)
+count_pairs_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, unsigned long long* counts) {
+  const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
+  const bool in_range = i < s.size;
+  const uint32_t ii = in_range ? i : 0;
+  const Vec3 gp = surfel_position(s, ii);
+  const Vec3 gn = surfel_normal(s, ii);
+  const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
+  unsigned long long cand = 0, wave_hits = 0, lane_hits = 0, in_image = 0;
+  for_each_candidate(
+      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      [&](int k) {
+        Assoc r;
+        const bool hit = in_range && project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch,
+                                                              kfs[k].normals, kfs[k].normals_pitch, gp, gn, &r, nullptr);
+        const Vec3 l = transform34(kfs[k].pose.F, gp);
+        const float px = in.fx * (l.x / l.z) + in.cx, py = in.fy * (l.y / l.z) + in.cy;
+        const bool inside = in_range && l.z > 0 && px >= 0 && py >= 0 && px < in.width && py < in.height;
+        const unsigned long long m = __ballot(hit);
+        cand += 1; wave_hits += (m != 0); lane_hits += __popcll(m); in_image += __popcll(__ballot(inside));
+      });
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], cand); atomicAdd(&counts[1], wave_hits); atomicAdd(&counts[2], lane_hits); atomicAdd(&counts[3], in_image);
+  }
+}
+void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                        unsigned long long* counts) {
+  if (s.size) hipLaunchKernelGGL(count_pairs_kernel, dim3(grid_for(s.size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s, counts);
+}
 }  // namespace bahip

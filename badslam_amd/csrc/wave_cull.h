@@ -1,0 +1,87 @@
+// wave_cull.h -- wave64-level keyframe culling.
+//
+// The reference tests every surfel against every keyframe in every pass (K x N association
+// tests; B/kernel_opt_geometry.cc:114-117 etc.), although a keyframe sees only a few percent of
+// the surfels.  Here a wavefront owns 64 consecutive surfels (spatially compact because surfels
+// are created in 8x8-cell tile order), computes their bounding sphere with cross-lane min/max,
+// and tests that sphere against the frustum of 64 keyframes at a time (one keyframe per lane).
+// The surviving keyframes form a 64-bit ballot mask held in SGPRs; the per-surfel work then
+// loops over the set bits only, in ascending keyframe order (so floating-point accumulation
+// order -- and therefore every result bit -- is identical to the un-culled sweep).
+//
+// The test is conservative: a keyframe is skipped only if NO point of the (inflated) sphere can
+// project into its image with z > 0, which is a precondition of association
+// (B/surfel_projection_nvcc_only.cuh:332-345).  It never changes results.
+#pragma once
+
+#include "ba_device.h"
+
+namespace bahip {
+
+struct WaveBounds {
+  float cx, cy, cz;   // sphere centre (global frame)
+  float r;            // inflated radius; negative = no valid surfel in this wave
+};
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// Bounding sphere of the positions held by the lanes with valid == true (NaN positions -- deleted
+// surfels -- must be passed as valid == false).
+__device__ __forceinline__ WaveBounds wave_bounds(Vec3 p, bool valid) {
+  const float inf = __builtin_huge_valf();
+  const float minx = wave_min(valid ? p.x : inf), maxx = wave_max(valid ? p.x : -inf);
+  const float miny = wave_min(valid ? p.y : inf), maxy = wave_max(valid ? p.y : -inf);
+  const float minz = wave_min(valid ? p.z : inf), maxz = wave_max(valid ? p.z : -inf);
+  WaveBounds b;
+  if (!(maxx >= minx)) { b.cx = b.cy = b.cz = 0.f; b.r = -1.f; return b; }
+  b.cx = 0.5f * (minx + maxx); b.cy = 0.5f * (miny + maxy); b.cz = 0.5f * (minz + maxz);
+  const float dx = maxx - b.cx, dy = maxy - b.cy, dz = maxz - b.cz;
+  // half-diagonal of the box, inflated by 0.1 % + 1 cm to dominate every rounding error below
+  b.r = sqrtf(dx * dx + dy * dy + dz * dz) * 1.001f + 0.01f;
+  return b;
+}
+
+// Can any point within distance b.r of the centre project into the image of the frame with
+// frame_T_global = F?  Planes through the camera centre: px >= 0, px < W, py >= 0, py < H, z > 0.
+__device__ __forceinline__ bool sphere_may_project(const Intrinsics& in, const float* F, const WaveBounds& b) {
+  if (b.r < 0.f) return false;
+  const float lx = F[0] * b.cx + F[1] * b.cy + F[2] * b.cz + F[3];
+  const float ly = F[4] * b.cx + F[5] * b.cy + F[6] * b.cz + F[7];
+  const float lz = F[8] * b.cx + F[9] * b.cy + F[10] * b.cz + F[11];
+  if (lz + b.r <= 0.f) return false;
+  const float w = (float)in.width, h = (float)in.height;
+  // left:  fx*x + cx*z >= 0 ; right: fx*x + (cx - W)*z < 0   (z > 0)
+  if (in.fx * lx + in.cx * lz + b.r * sqrtf(in.fx * in.fx + in.cx * in.cx) < 0.f) return false;
+  if (in.fx * lx + (in.cx - w) * lz - b.r * sqrtf(in.fx * in.fx + (in.cx - w) * (in.cx - w)) > 0.f) return false;
+  if (in.fy * ly + in.cy * lz + b.r * sqrtf(in.fy * in.fy + in.cy * in.cy) < 0.f) return false;
+  if (in.fy * ly + (in.cy - h) * lz - b.r * sqrtf(in.fy * in.fy + (in.cy - h) * (in.cy - h)) > 0.f) return false;
+  return true;
+}
+
+// Calls body(k) (k wave-uniform, ascending) for every item k in [0, num_items) whose lane-level
+// predicate pred(k) holds.  The candidate set lives in a 64-bit scalar mask.
+template <typename Pred, typename Body>
+__device__ __forceinline__ void for_each_candidate(int num_items, Pred pred, Body body) {
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < num_items; base += 64) {
+    const int item = base + lane;
+    const bool cand = (item < num_items) && pred(item);
+    unsigned long long m = __ballot(cand);
+    while (m) {
+      const int k = base + __builtin_ctzll(m);
+      m &= m - 1;
+      body(k);
+    }
+  }
+}
+
+}  // namespace bahip

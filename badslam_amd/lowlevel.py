@@ -206,6 +206,13 @@ class Scene:
                                                           C.byref(rounds)))
         return (np.array(list(poses), dtype=np.float64).reshape(K, 7), np.array(list(its)), np.array(list(conv)), rounds.value)
 
+    def count_pairs(self):
+        """(wave-keyframe candidates, wave-keyframe hits, associated pairs, in-image pairs) of one sweep."""
+        out = (C.c_uint64 * 4)()
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_debug_count_pairs(self.ctx.handle, C.byref(s), out))
+        return [int(v) for v in out]
+
     def evaluate_pairs(self, i, surfel_indices, frame_T_global):
         idx = np.ascontiguousarray(surfel_indices, dtype=np.uint32)
         out = np.zeros((len(idx), 40), np.float32)

@@ -210,6 +210,11 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
 int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, const float frame_T_global[12],
                                const bahip_surfels* surfels, const uint32_t* surfel_indices, int count, float* out);
 
+/* Work census of one sweep of the bound keyframes over the surfels: counts[0] = (wavefront, keyframe)
+ * candidates left by frustum culling, [1] = of those with >= 1 association, [2] = associated
+ * (surfel, keyframe) pairs, [3] = pairs projecting into the image. */
+int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out);
+
 /* ---- instrumentation ---------------------------------------------------------------------------- */
 /* Time (ms, hipEvent on the context stream) and launch count of the kernels issued by the last
  * call of each stage; used by bench.py for the roofline line.  stage: 0 activation, 1 geometry,

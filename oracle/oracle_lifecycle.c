@@ -180,10 +180,21 @@ uint32_t orc_create_surfels_for_keyframe(int filter_new_surfels, int min_observa
   uint32_t count = 0;
   for (size_t i = 0; i < (size_t)W * H; ++i) count += flag[i];
   if (count == 0 || s->surfels_size + count > s->capacity) { free(flag); return 0; }
+  /* Append order.  The reference numbers new surfels by a prefix sum over the row-major pixel
+   * index (B/kernel_create_surfels.cu:357-390); the order is not observable in its results.  This
+   * backend numbers them tile-major -- tiles of 8x8 sparse cells, row-major inside a tile -- so that
+   * 64 consecutive surfels (one wavefront) form a compact patch ("surfel order"). */
   uint32_t next = s->surfels_size;
-  for (int y = 0; y < H; ++y)
-    for (int x = 0; x < W; ++x)
-      if (flag[(size_t)y * W + x]) create_new_surfel(x, y, next++, color_cam, depth_cam, dp, kf, s);
+  const int TP = 8 * dp->cell;
+  const int tiles_x = (W + TP - 1) / TP, tiles_y = (H + TP - 1) / TP;
+  for (int ty = 0; ty < tiles_y; ++ty)
+    for (int tx = 0; tx < tiles_x; ++tx)
+      for (int ly = 0; ly < TP; ++ly)
+        for (int lx = 0; lx < TP; ++lx) {
+          const int x = tx * TP + lx, y = ty * TP + ly;
+          if (x >= W || y >= H) continue;
+          if (flag[(size_t)y * W + x]) create_new_surfel(x, y, next++, color_cam, depth_cam, dp, kf, s);
+        }
   free(flag);
   s->surfels_size += count;
   s->surfel_count += count;
