@@ -97,9 +97,10 @@ SIGNATURES = {
     "bahip_optimize_intrinsics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.POINTER(Camera),
                                             C.POINTER(Camera), C.POINTER(C.c_float)]),
     "bahip_pcg_iteration": (C.c_int, [C.c_void_p, C.POINTER(PCGOptions), C.POINTER(Surfels), C.POINTER(Camera),
-                                      C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+                                      C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bahip_debug_evaluate_pairs": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_float), C.POINTER(Surfels),
                                              C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float)]),
+    "bahip_debug_read_pcg_vector": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
     "bahip_debug_count_pairs": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.POINTER(C.c_uint64)]),
     "bahip_last_stage_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bahip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

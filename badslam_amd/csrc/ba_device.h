@@ -70,6 +70,16 @@ struct PoseWork {
   int32_t converged;
 };
 
+// Unknown-vector layout of the PCG scheme (B/direct_ba_pcg.cc:232-307): [6 per non-gauge keyframe |
+// geom_stride per surfel | 5 + S depth intrinsics | 4 colour intrinsics].
+struct PcgLayout {
+  int optimize_poses, optimize_geometry, optimize_depth_intrinsics, optimize_color_intrinsics;
+  int use_depth, use_desc;
+  uint32_t surfel_start, depth_intr_start, a_index, color_intr_start, unknown_count;
+  int geom_stride;   // 3 with descriptor residuals, else 1
+  int gauge;         // keyframe whose pose is held fixed
+};
+
 // Everything that is constant over a sweep; passed to kernels by value (kernarg -> SGPRs).
 struct Intrinsics {
   // depth camera: corner-convention projector + centre-convention unprojector (B/surfel_projection.h:42-71)

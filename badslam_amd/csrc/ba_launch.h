@@ -40,6 +40,26 @@ void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, 
 void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
                            const uint32_t* indices, int count, float* out);
 
+// kernels_intrinsics.hip
+void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                                  const SurfelsView& s, float* glob, float* B, float* D, float* b2, float* obs, int S);
+void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* B, float* D, const float* b2);
+void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, const float* obs, const float* B, const float* D,
+                                   const float* x1, float* cfactor, uint32_t cfactor_pitch);
+
+// kernels_pcg.hip
+void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                     float* r, float* M);
+void launch_pcg_init2(hipStream_t st, const PcgLayout& L, float a, const float* r, const float* M, float* delta, float* g, float* p,
+                      float* alpha_n);
+void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                      const float* p, float* g, float* alpha_d);
+void launch_pcg_step2(hipStream_t st, const PcgLayout& L, float* r, const float* M, float* delta, float* g, const float* p,
+                      const float* alpha_n, const float* alpha_d, float* beta_n);
+void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n);
+void launch_pcg_update_surfels(hipStream_t st, const PcgLayout& L, const SurfelsView& s, const float* delta);
+void launch_pcg_update_cfactors(hipStream_t st, const Intrinsics& in, uint32_t start, const float* delta, float* cfactor, uint32_t pitch);
+
 // kernels_lifecycle.hip
 void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, int h);
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup);

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ba_launch.h"
+#include "ldlt.h"
 #include "se3_device.h"
 
 using namespace bahip;
@@ -73,6 +74,12 @@ struct bahip_context {
   int* dev_covis = nullptr;
   float* dev_covis_T = nullptr;
   int covis_capacity = 0;
+
+  float* intr_scratch = nullptr;   // intrinsics step: 64 + 8*S floats (glob | B | D | b2 | obs)
+  int intr_capacity = 0;
+
+  float* pcg_buf = nullptr;        // PCG vectors r, M, delta, g, p (5 * pcg_capacity floats) + 16 scalars
+  size_t pcg_capacity = 0;
 
   bahip_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -237,6 +244,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
+  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
   delete ctx;
 }
@@ -599,11 +607,207 @@ int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip
 }
 
 // ---- not yet implemented in this build ------------------------------------------------------------------------
-int bahip_optimize_intrinsics(bahip_context*, int, int, const bahip_surfels*, bahip_camera*, bahip_camera*, float*) {
-  return fail("bahip_optimize_intrinsics: not implemented yet", __FILE__, __LINE__);
+// B/kernel_opt_intrinsics.cc:39-281
+int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimize_color, const bahip_surfels* surfels,
+                              bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(optimize_depth || optimize_color, "at least one of depth / colour intrinsics must be optimised");  // :55
+  *out_color_camera = ctx->color_cam;
+  *out_depth_camera = ctx->depth_cam;
+  *out_a = ctx->dp.a;
+  if (surfels->surfels_size == 0) return 0;
+  const int S = ctx->in.cf_width * ctx->in.cf_height;
+  if (S > ctx->intr_capacity) {
+    if (ctx->intr_scratch) hipFree(ctx->intr_scratch);
+    ctx->intr_capacity = S + 1024;
+    HIP_TRY(hipMalloc(&ctx->intr_scratch, sizeof(float) * (64 + 8 * (size_t)ctx->intr_capacity)));
+  }
+  float* glob = ctx->intr_scratch;            // 34 sums + x1 at [40..44]
+  float* B = glob + 64;                       // 5 * S
+  float* D = B + 5 * (size_t)S;
+  float* b2 = D + S;
+  float* obs = b2 + S;                        // observation counts as floats (exact under a float SUM all-reduce)
+  HIP_TRY(hipMemsetAsync(glob, 0, sizeof(float) * (64 + 8 * (size_t)S), ctx->stream));
+  launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
+                               make_view(surfels), glob, B, D, b2, obs, S);
+  CHECK_LAUNCH();
+  if (ctx->allreduce && ctx->allreduce(glob, 64 + 8 * (size_t)S, ctx->allreduce_user) != 0)
+    return fail("all-reduce hook failed", __FILE__, __LINE__);
+  if (optimize_depth) {
+    launch_intrinsics_schur(ctx->stream, S, glob, B, D, b2);
+    CHECK_LAUNCH();
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_f, glob, 34 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const float* g = ctx->pinned_f;
+  if (optimize_depth) {
+    double M[25], rhs[5], x[5];
+    int q = 0;
+    for (int row = 0; row < 5; ++row)
+      for (int col = row; col < 5; ++col) { M[row * 5 + col] = g[q]; M[col * 5 + row] = g[q]; ++q; }
+    for (int c = 0; c < 5; ++c) rhs[c] = g[15 + c];
+    // weak prior pulling a towards zero (B/kernel_opt_intrinsics.cc:153-158); added in binary32 like the reference
+    constexpr float kAPriorWeight = 10;
+    M[24] = (double)((float)M[24] + kAPriorWeight * kAPriorWeight);
+    rhs[4] = (double)((float)rhs[4] + kAPriorWeight * kAPriorWeight * ctx->dp.a);
+    ldlt_solve_sym<5>(M, rhs, x);
+    float x1[5];
+    for (int c = 0; c < 5; ++c) x1[c] = (float)x[c];
+    const float new_fx = 1.0f / (ctx->in.fx_inv - x1[0]);
+    const float new_fy = 1.0f / (ctx->in.fy_inv - x1[1]);
+    out_depth_camera->fx = new_fx;
+    out_depth_camera->fy = new_fy;
+    out_depth_camera->cx = -(new_fx * (ctx->in.cx_inv - x1[2])) + 0.5f;
+    out_depth_camera->cy = -(new_fy * (ctx->in.cy_inv - x1[3])) + 0.5f;
+    *out_a = ctx->dp.a - x1[4];
+    memcpy(ctx->pinned_f + 40, x1, sizeof(x1));
+    HIP_TRY(hipMemcpyAsync(glob + 40, ctx->pinned_f + 40, sizeof(x1), hipMemcpyHostToDevice, ctx->stream));
+    launch_intrinsics_solve_cells(ctx->stream, ctx->in, S, obs, B, D, glob + 40, ctx->dp.cfactor, ctx->dp.cfactor_pitch_bytes);
+    CHECK_LAUNCH();
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (optimize_color) {
+    double M[16], rhs[4], x[4];
+    int q = 20;
+    for (int row = 0; row < 4; ++row)
+      for (int col = row; col < 4; ++col) { M[row * 4 + col] = g[q]; M[col * 4 + row] = g[q]; ++q; }
+    for (int c = 0; c < 4; ++c) rhs[c] = g[30 + c];
+    ldlt_solve_sym<4>(M, rhs, x);
+    out_color_camera->fx = ctx->color_cam.fx - (float)x[0];
+    out_color_camera->fy = ctx->color_cam.fy - (float)x[1];
+    out_color_camera->cx = ctx->color_cam.cx - (float)x[2];
+    out_color_camera->cy = ctx->color_cam.cy - (float)x[3];
+  }
+  return 0;
 }
-int bahip_pcg_iteration(bahip_context*, const bahip_pcg_options*, const bahip_surfels*, bahip_camera*, bahip_camera*, float*, int*) {
-  return fail("bahip_pcg_iteration: not implemented yet", __FILE__, __LINE__);
+// One outer Gauss-Newton iteration of the PCG scheme: B/direct_ba_pcg.cc:229-646.
+int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const bahip_surfels* surfels,
+                        bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a, int* inner_steps_out,
+                        int* num_converged_out) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(ctx->allreduce == nullptr, "the PCG scheme does not support surfel sharding yet (single GPU only)");
+  const int K = ctx->num_kfs;
+  REQUIRE(K >= 1, "PCG needs at least one keyframe");
+  const uint32_t N = surfels->surfels_size;
+  const int S = ctx->in.cf_width * ctx->in.cf_height;
+  PcgLayout L{};
+  L.use_depth = opt->use_depth_residuals; L.use_desc = opt->use_descriptor_residuals;
+  L.optimize_poses = opt->optimize_poses; L.optimize_geometry = opt->optimize_geometry;
+  L.optimize_depth_intrinsics = opt->optimize_depth_intrinsics; L.optimize_color_intrinsics = opt->optimize_color_intrinsics;
+  L.geom_stride = L.use_desc ? 3 : 1;
+  L.gauge = (opt->gauge_keyframe >= 0 && opt->gauge_keyframe < K) ? opt->gauge_keyframe : 0;
+  uint32_t cur = 0;
+  const uint32_t kInvalid = 0xffffffffu;
+  if (L.optimize_poses) cur += 6u * (uint32_t)(K - 1);
+  L.surfel_start = kInvalid;
+  if (L.optimize_geometry) { L.surfel_start = cur; cur += (uint32_t)L.geom_stride * N; }
+  L.depth_intr_start = kInvalid; L.a_index = kInvalid;
+  if (L.optimize_depth_intrinsics) { L.depth_intr_start = cur; cur += 5u + (uint32_t)S; L.a_index = L.depth_intr_start + 4; }
+  L.color_intr_start = kInvalid;
+  if (L.optimize_color_intrinsics) { L.color_intr_start = cur; cur += 4; }
+  L.unknown_count = cur;
+  const size_t U = cur;
+  *out_color_camera = ctx->color_cam; *out_depth_camera = ctx->depth_cam; *out_a = ctx->dp.a;
+  if (inner_steps_out) *inner_steps_out = 0;
+  if (num_converged_out) *num_converged_out = 0;
+
+  if (U > ctx->pcg_capacity) {   // lazy (re-)allocation like B/direct_ba_pcg.cc:255-268
+    if (ctx->pcg_buf) hipFree(ctx->pcg_buf);
+    ctx->pcg_capacity = U + U / 8 + 4096;
+    HIP_TRY(hipMalloc(&ctx->pcg_buf, sizeof(float) * (5 * ctx->pcg_capacity + 16)));
+  }
+  const size_t cap = ctx->pcg_capacity;
+  float* r_ = ctx->pcg_buf; float* M_ = r_ + cap; float* delta = M_ + cap; float* g_ = delta + cap; float* p_ = g_ + cap;
+  float* sc = p_ + cap;   // [0] alpha_n / beta_n (swapped), [1] alpha_d, [2] beta_n / alpha_n
+  int i_an = 0, i_bn = 2;
+  const SurfelsView sv = make_view(surfels);
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemsetAsync(r_, 0, sizeof(float) * U, st));
+  HIP_TRY(hipMemsetAsync(M_, 0, sizeof(float) * U, st));
+  HIP_TRY(hipMemsetAsync(sc, 0, sizeof(float) * 16, st));
+  launch_pcg_init(st, L, ctx->in, ctx->dev_kfs, K, sv, r_, M_);
+  CHECK_LAUNCH();
+  launch_pcg_init2(st, L, ctx->dp.a, r_, M_, delta, g_, p_, sc + i_an);
+  CHECK_LAUNCH();
+
+  float prev_r_norm = __builtin_huge_valf();
+  int no_improvement = 0, steps = 0;
+  for (int step = 0; step < opt->max_inner_iterations; ++step) {
+    ++steps;
+    HIP_TRY(hipMemsetAsync(sc + 1, 0, sizeof(float), st));
+    if (step > 0) {
+      const int t = i_an; i_an = i_bn; i_bn = t;
+      HIP_TRY(hipMemsetAsync(g_, 0, sizeof(float) * U, st));
+    }
+    launch_pcg_step1(st, L, ctx->in, ctx->dev_kfs, K, sv, p_, g_, sc + 1);
+    CHECK_LAUNCH();
+    HIP_TRY(hipMemsetAsync(sc + i_bn, 0, sizeof(float), st));
+    launch_pcg_step2(st, L, r_, M_, delta, g_, p_, sc + i_an, sc + 1, sc + i_bn);
+    CHECK_LAUNCH();
+    HIP_TRY(hipMemcpyAsync(ctx->pinned_f, sc + i_bn, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const float r_norm = sqrtf(ctx->pinned_f[0]);
+    if (r_norm < prev_r_norm - 1e-3f) no_improvement = 0;
+    else if (++no_improvement >= 3) break;
+    prev_r_norm = r_norm;
+    if (step < opt->max_inner_iterations - 1) {
+      launch_pcg_step3(st, L, g_, p_, sc + i_an, sc + i_bn);
+      CHECK_LAUNCH();
+    }
+  }
+  if (inner_steps_out) *inner_steps_out = steps;
+
+  // ---- apply the update (B/direct_ba_pcg.cc:551-642) ----
+  int num_converged = 0;
+  if (L.optimize_poses) {
+    std::vector<float> d(6 * (size_t)(K > 1 ? K - 1 : 1), 0.f);
+    if (K > 1) HIP_TRY(hipMemcpy(d.data(), delta, sizeof(float) * 6 * (K - 1), hipMemcpyDeviceToHost));
+    for (int k = 0; k < K; ++k) {
+      if (k == L.gauge) { ++num_converged; continue; }
+      const float* dk = &d[6 * (size_t)(k < L.gauge ? k : k - 1)];
+      float upd[7], next[7], lg[6];
+      se3_exp(dk, upd);
+      se3_mul(ctx->host_kfs[k].global_T_frame, upd, next);
+      fill_pose(&ctx->host_kfs[k], next);
+      se3_log(upd, lg);
+      float sq = 0.f;
+      for (int c = 0; c < 3; ++c) sq += lg[c] * lg[c];
+      for (int c = 3; c < 6; ++c) { const float v = lg[c] * 10.f; sq += v * v; }
+      if (sq < 1e-06f) ++num_converged;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->dev_kfs, ctx->host_kfs.data(), sizeof(KfEntry) * K, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (num_converged_out) *num_converged_out = num_converged;
+  if (L.optimize_geometry) {
+    launch_pcg_update_surfels(st, L, sv, delta);
+    CHECK_LAUNCH();
+  }
+  if (L.optimize_depth_intrinsics) {
+    float b[5];
+    HIP_TRY(hipMemcpy(b, delta + L.depth_intr_start, sizeof(b), hipMemcpyDeviceToHost));
+    const double old_fx_inv = 1. / ctx->depth_cam.fx, old_fy_inv = 1. / ctx->depth_cam.fy;
+    const double old_cx_pc = ctx->depth_cam.cx - 0.5, old_cy_pc = ctx->depth_cam.cy - 0.5;
+    const double old_cx_inv = -old_cx_pc * old_fx_inv, old_cy_inv = -old_cy_pc * old_fy_inv;
+    const double new_fx = 1. / (old_fx_inv + b[0]), new_fy = 1. / (old_fy_inv + b[1]);
+    out_depth_camera->fx = (float)new_fx;
+    out_depth_camera->fy = (float)new_fy;
+    out_depth_camera->cx = (float)(-(new_fx * (old_cx_inv + b[2])) + 0.5);
+    out_depth_camera->cy = (float)(-(new_fy * (old_cy_inv + b[3])) + 0.5);
+    *out_a = ctx->dp.a + b[4];
+    launch_pcg_update_cfactors(st, ctx->in, L.depth_intr_start + 5, delta, ctx->dp.cfactor, ctx->dp.cfactor_pitch_bytes);
+    CHECK_LAUNCH();
+  }
+  if (L.optimize_color_intrinsics) {
+    float b[4];
+    HIP_TRY(hipMemcpy(b, delta + L.color_intr_start, sizeof(b), hipMemcpyDeviceToHost));
+    out_color_camera->fx = (float)(ctx->color_cam.fx + b[0]);
+    out_color_camera->fy = (float)(ctx->color_cam.fy + b[1]);
+    out_color_camera->cx = (float)(ctx->color_cam.cx + b[2]);
+    out_color_camera->cy = (float)(ctx->color_cam.cy + b[3]);
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
 }
 
 // ---- test hook ------------------------------------------------------------------------------------------------------
@@ -622,6 +826,14 @@ int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, con
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out_host, d_out, sizeof(float) * 40 * count, hipMemcpyDeviceToHost));
   hipFree(d_idx); hipFree(d_out);
+  return 0;
+}
+
+int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, size_t count, float* out_host) {
+  REQUIRE(ctx->pcg_buf != nullptr, "no PCG iteration has run on this context");
+  REQUIRE(which >= 0 && which < 5 && offset + count <= ctx->pcg_capacity, "PCG vector range out of bounds");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out_host, ctx->pcg_buf + (size_t)which * ctx->pcg_capacity + offset, sizeof(float) * count, hipMemcpyDeviceToHost));
   return 0;
 }
 

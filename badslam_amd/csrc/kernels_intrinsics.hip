@@ -1,0 +1,199 @@
+// kernels_intrinsics.hip -- intrinsics + depth-deformation step of the alternating scheme.
+//
+// Reference (B/ = applications/badslam/src/badslam/): one launch of
+// AccumulateIntrinsicsCoefficientsCUDAKernel per keyframe over all surfels, each doing 20 + 28
+// serial CUB block reductions and per-pair atomics (B/kernel_opt_intrinsics.cu:47-263), then the
+// Schur complement kernel (:266-350), a 5x5 LDLT on the host (B/kernel_opt_intrinsics.cc:171) and
+// the per-cell back-substitution (:375-423).
+//
+// Here: ONE surfel-centric launch with wave64 frustum culling sweeps all keyframes.  The global
+// blocks A(15), b1(5), colour H(10), b(4) do not depend on the keyframe, so every lane keeps its
+// 34 partial sums in registers across the whole sweep and the wave reduces them once at the end;
+// only the per-cell terms B, D, b2, observation count go out as atomics per associated pair.
+#include "ba_device.h"
+#include "ba_launch.h"
+#include "wave_cull.h"
+
+namespace bahip {
+
+constexpr int kIntrBlock = 256;
+constexpr int kARows = 5;
+
+// Layout of the accumulation scratch (floats): [0..14] A, [15..19] b1, [20..29] colour H, [30..33] colour b.
+template <bool kDepth, bool kColor>
+__global__ void __launch_bounds__(kIntrBlock)
+intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
+                             float* __restrict__ glob /* 34 */, float* __restrict__ B, float* __restrict__ D,
+                             float* __restrict__ b2, float* __restrict__ obs /* counts kept as floats so that a
+                             float SUM all-reduce over ranks stays exact (< 2^24 per cell) */, int S) {
+  const uint32_t i = blockIdx.x * kIntrBlock + threadIdx.x;
+  const bool in_range = i < s.size;
+  const uint32_t ii = in_range ? i : 0;
+  const Vec3 gp = surfel_position(s, ii);
+  const Vec3 gn = surfel_normal(s, ii);
+  const float radius_sq = s.row(kSurfelRadiusSquared)[ii];
+  const float d1 = s.row(kSurfelDescriptor1)[ii], d2 = s.row(kSurfelDescriptor2)[ii];
+  const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
+  float acc[34];
+#pragma unroll
+  for (int q = 0; q < 34; ++q) acc[q] = 0.f;
+
+  for_each_candidate(
+      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      [&](int k) {
+        if (!in_range) return;
+        const float* F = kfs[k].pose.F;
+        Assoc r;
+        if (!project_associate<false>(in, F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals, kfs[k].normals_pitch,
+                                      gp, gn, &r, nullptr)) return;
+        const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
+        if (kDepth) {
+          // B/kernel_opt_intrinsics.cu:81-120
+          const int sparse_px = r.px / in.cell, sparse_py = r.py / in.cell;
+          const float cfactor = pitched_load(in.cfactor, in.cfactor_pitch, sparse_py, sparse_px);
+          const float raw_inv_depth = 1.0f / (in.raw_to_float_depth * pitched_load(kfs[k].depth, kfs[k].depth_pitch, r.py, r.px));
+          const float exp_inv_depth = expf(-in.a * raw_inv_depth);
+          const float corrected = cfactor * exp_inv_depth + raw_inv_depth;
+          if (fabsf(corrected) > 1e-4f) {
+            const float dot = dot3(mk3(nx, ny, 1), r.nl);
+            const float inv_std = depth_inv_stddev(nx, ny, r.depth, r.nl, in.baseline_fx);
+            const float jac_base = inv_std * dot * exp_inv_depth / (corrected * corrected);
+            float J[kARows + 1];
+            J[2] = inv_std * r.depth * dot3(gn, mk3(F[0], F[1], F[2]));
+            J[3] = inv_std * r.depth * dot3(gn, mk3(F[4], F[5], F[6]));
+            J[0] = r.px * J[2];
+            J[1] = r.py * J[3];
+            J[4] = cfactor * raw_inv_depth * jac_base;
+            J[5] = -jac_base;
+            const Vec3 u = mk3(r.depth * nx, r.depth * ny, r.depth);
+            const float raw = inv_std * dot3(r.nl, u - r.local);
+            const float w = depth_residual_weight(raw);
+            int q = 0;
+#pragma unroll
+            for (int row = 0; row < kARows; ++row)
+#pragma unroll
+              for (int col = row; col < kARows; ++col) acc[q++] += w * J[row] * J[col];
+            const float wr = w * raw;
+#pragma unroll
+            for (int c = 0; c < kARows; ++c) acc[15 + c] += wr * J[c];
+            const int cell = sparse_px + sparse_py * in.cf_width;
+#pragma unroll
+            for (int c = 0; c < kARows; ++c) unsafeAtomicAdd(&B[(size_t)c * S + cell], w * J[c] * J[kARows]);
+            unsafeAtomicAdd(&D[cell], w * J[kARows] * J[kARows]);
+            unsafeAtomicAdd(&b2[cell], w * raw * J[kARows]);
+            unsafeAtomicAdd(&obs[cell], 1.0f);
+          }
+        }
+        if (kColor) {
+          float cx, cy;
+          if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
+            DescEval e;
+            eval_descriptor<true>(in, kfs[k].color, kfs[k].color_pitch, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
+            // B/kernel_opt_intrinsics.cu:142-150,200-215: validity flag is "residual != 0"
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const float gx = t ? e.gx2 : e.gx1, gy = t ? e.gy2 : e.gy1, raw = t ? e.r2 : e.r1;
+              if (raw != 0) {
+                const float J[4] = {gx * nx, gy * ny, gx, gy};
+                const float w = descriptor_residual_weight(raw);
+                int q = 20;
+#pragma unroll
+                for (int row = 0; row < 4; ++row)
+#pragma unroll
+                  for (int col = row; col < 4; ++col) acc[q++] += w * J[row] * J[col];
+                const float wr = w * raw;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[30 + c] += wr * J[c];
+              }
+            }
+          }
+        }
+      });
+
+  const int lane = threadIdx.x & 63;
+  float mine = 0.f;
+#pragma unroll
+  for (int q = 0; q < 34; ++q) {
+    const float v = wave_sum(acc[q]);
+    if (lane == q) mine = v;
+  }
+  if (lane < 34 && mine != 0.f) unsafeAtomicAdd(&glob[lane], mine);
+}
+
+// Schur complement: B/kernel_opt_intrinsics.cu:266-350.  One thread per sparse cell.
+__global__ void __launch_bounds__(kIntrBlock)
+intrinsics_schur_kernel(int S, float* __restrict__ glob, float* __restrict__ B, float* __restrict__ D, const float* __restrict__ b2) {
+  const int cell = blockIdx.x * kIntrBlock + threadIdx.x;
+  float part[20];
+#pragma unroll
+  for (int q = 0; q < 20; ++q) part[q] = 0.f;
+  if (cell < S) {
+    const float D_inverse = 1.0f / D[cell];
+    if (!(D_inverse < 1e12f)) {
+      D[cell] = __builtin_nanf("");
+    } else {
+      const float D_inv_b2 = D_inverse * b2[cell];
+      D[cell] = D_inv_b2;
+      float Bc[kARows];
+#pragma unroll
+      for (int c = 0; c < kARows; ++c) Bc[c] = B[(size_t)c * S + cell];
+      int q = 0;
+#pragma unroll
+      for (int row = 0; row < kARows; ++row)
+#pragma unroll
+        for (int col = row; col < kARows; ++col) part[q++] = -1.f * (Bc[row] * D_inverse * Bc[col]);
+#pragma unroll
+      for (int c = 0; c < kARows; ++c) part[15 + c] = -1.f * (Bc[c] * D_inv_b2);
+#pragma unroll
+      for (int c = 0; c < kARows; ++c) B[(size_t)c * S + cell] = D_inverse * Bc[c];
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  float mine = 0.f;
+#pragma unroll
+  for (int q = 0; q < 20; ++q) {
+    const float v = wave_sum(part[q]);
+    if (lane == q) mine = v;
+  }
+  if (lane < 20 && mine != 0.f) unsafeAtomicAdd(&glob[lane], mine);
+}
+
+// Back-substitution: B/kernel_opt_intrinsics.cu:375-423
+__global__ void __launch_bounds__(kIntrBlock)
+intrinsics_solve_cells_kernel(Intrinsics in, int S, const float* __restrict__ obs, const float* __restrict__ B,
+                              const float* __restrict__ D, const float* __restrict__ x1 /* 5 */, float* cfactor,
+                              uint32_t cfactor_pitch) {
+  const int cell = blockIdx.x * kIntrBlock + threadIdx.x;
+  if (cell >= S) return;
+  float offset = D[cell];
+  if (offset != offset) {
+    offset = 0;
+  } else {
+#pragma unroll
+    for (int c = 0; c < kARows; ++c) offset -= B[(size_t)c * S + cell] * x1[c];
+  }
+  const int y = cell / in.cf_width, x = cell - y * in.cf_width;
+  float* p = pitched_ptr(cfactor, cfactor_pitch, y, x);
+  float value = *p - offset;
+  if (obs[cell] == 0.f) value = 0;
+  *p = value;
+}
+
+void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                                  const SurfelsView& s, float* glob, float* B, float* D, float* b2, float* obs, int S) {
+  if (!s.size) return;
+  const dim3 grid((s.size + kIntrBlock - 1) / kIntrBlock), block(kIntrBlock);
+  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, B, D, b2, obs, S);
+  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, B, D, b2, obs, S);
+  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, B, D, b2, obs, S);
+}
+void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* B, float* D, const float* b2) {
+  hipLaunchKernelGGL(intrinsics_schur_kernel, dim3((S + kIntrBlock - 1) / kIntrBlock), dim3(kIntrBlock), 0, st, S, glob, B, D, b2);
+}
+void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, const float* obs, const float* B, const float* D,
+                                   const float* x1, float* cfactor, uint32_t cfactor_pitch) {
+  hipLaunchKernelGGL(intrinsics_solve_cells_kernel, dim3((S + kIntrBlock - 1) / kIntrBlock), dim3(kIntrBlock), 0, st, in, S, obs, B,
+                     D, x1, cfactor, cfactor_pitch);
+}
+
+}  // namespace bahip

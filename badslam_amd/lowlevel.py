@@ -206,6 +206,59 @@ class Scene:
                                                           C.byref(rounds)))
         return (np.array(list(poses), dtype=np.float64).reshape(K, 7), np.array(list(its)), np.array(list(conv)), rounds.value)
 
+    def update_surfel_normals(self):
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_update_surfel_normals(self.ctx.handle, C.byref(s)))
+
+    def optimize_intrinsics(self, optimize_depth, optimize_color, apply=True):
+        """OptimizeIntrinsicsCUDA; with apply=True the new cameras / a are adopted like
+        B/direct_ba_alternating.cc:609-619 does."""
+        cc, dc, a = capi.Camera(), capi.Camera(), C.c_float()
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_optimize_intrinsics(self.ctx.handle, int(optimize_depth), int(optimize_color), C.byref(s),
+                                                      C.byref(cc), C.byref(dc), C.byref(a)))
+        if apply and self.surfels_size > 0:
+            if optimize_color:
+                self.color_cam = cc
+            if optimize_depth:
+                self.depth_cam = dc
+                self.dp.a = a.value
+            self.set_intrinsics()
+        return cc, dc, a.value
+
+    def pcg_iteration(self, optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=False,
+                      optimize_color_intrinsics=False, use_depth=True, use_desc=True, max_inner_iterations=30, gauge_keyframe=0):
+        """One outer iteration of the PCG scheme on the bound keyframes; adopts new poses / intrinsics."""
+        opt = capi.PCGOptions(int(optimize_poses), int(optimize_geometry), int(optimize_depth_intrinsics),
+                              int(optimize_color_intrinsics), int(use_depth), int(use_desc), int(max_inner_iterations),
+                              int(gauge_keyframe))
+        cc, dc, a = capi.Camera(), capi.Camera(), C.c_float()
+        steps, conv = C.c_int(), C.c_int()
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_pcg_iteration(self.ctx.handle, C.byref(opt), C.byref(s), C.byref(cc), C.byref(dc), C.byref(a),
+                                                C.byref(steps), C.byref(conv)))
+        K = len(self.keyframes)
+        if optimize_poses and K:
+            poses = (C.c_float * (7 * K))()
+            capi.check(self.lib.bahip_get_keyframe_poses(self.ctx.handle, poses, K))
+            arr = np.array(list(poses), dtype=np.float32).reshape(K, 7)
+            for k, kf in enumerate(self.keyframes):
+                kf["pose"] = arr[k].copy()
+        if optimize_color_intrinsics:
+            self.color_cam = cc
+        if optimize_depth_intrinsics:
+            self.depth_cam = dc
+            self.dp.a = a.value
+        if optimize_color_intrinsics or optimize_depth_intrinsics:
+            self.set_intrinsics()
+        return steps.value, conv.value
+
+    def read_pcg_vector(self, which, count, offset=0):
+        out = np.zeros(count, np.float32)
+        capi.check(self.lib.bahip_debug_read_pcg_vector(self.ctx.handle, int(which), int(offset), int(count),
+                                                        out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def count_pairs(self):
         """(wave-keyframe candidates, wave-keyframe hits, associated pairs, in-image pairs) of one sweep."""
         out = (C.c_uint64 * 4)()

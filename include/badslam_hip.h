@@ -201,7 +201,8 @@ typedef struct bahip_pcg_options {
  * cfactors.  Outputs new intrinsics on the host; inner_steps_out = PCG steps used. */
 int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const bahip_surfels* surfels,
                         bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a,
-                        int* inner_steps_out);
+                        int* inner_steps_out, int* num_converged_out /* keyframes whose pose update is below the
+                        convergence threshold, gauge keyframe included (B/direct_ba_pcg.cc:556-575) */);
 
 /* ---- test hook --------------------------------------------------------------------------------------
  * Per-pair evaluation with the production device functions (association, the three raw residuals,
@@ -209,6 +210,11 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
  * per index, layout documented in badslam_amd/csrc/kernels_pose.hip.  Host in / host out. */
 int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, const float frame_T_global[12],
                                const bahip_surfels* surfels, const uint32_t* surfel_indices, int count, float* out);
+
+/* Reads `count` entries of one of the PCG vectors left by the last bahip_pcg_iteration
+ * (which: 0 = r, 1 = M, 2 = delta, 3 = g, 4 = p).  With max_inner_iterations = 0 that call only
+ * assembles r = -J^T W F and M = diag(J^T W J) and applies no update. */
+int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, size_t count, float* out);
 
 /* Work census of one sweep of the bound keyframes over the surfels: counts[0] = (wavefront, keyframe)
  * candidates left by frustum culling, [1] = of those with >= 1 association, [2] = associated

@@ -287,12 +287,48 @@ class OracleBA:
                                                C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),
                                                C.byref(self.surfels))
 
+    def update_surfel_normals(self):
+        self.L.orc_update_surfel_normals(C.byref(self.depth_cam), C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),
+                                         C.byref(self.surfels))
+
+    def optimize_intrinsics(self, optimize_depth, optimize_color, apply=True):
+        cc, dc, a = Camera(), Camera(), C.c_float()
+        self.L.orc_optimize_intrinsics(int(optimize_depth), int(optimize_color), self._kf_ptr_array(), len(self.keyframes),
+                                       C.byref(self.color_cam), C.byref(self.depth_cam), C.byref(self.dp), C.byref(self.surfels),
+                                       C.byref(cc), C.byref(dc), C.byref(a))
+        if apply and self.surfels_size > 0:
+            if optimize_color:
+                self.color_cam = cc
+            if optimize_depth:
+                self.depth_cam = dc
+                self.dp.a = a.value
+        return cc, dc, a.value
+
     def evaluate_cost(self):
         n = C.c_uint64()
         c = self.L.orc_evaluate_cost(self.use_depth, self.use_desc, C.byref(self.color_cam), C.byref(self.depth_cam),
                                      C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes), C.byref(self.surfels),
                                      C.byref(n))
         return float(c), int(n.value)
+
+    def pcg_assemble(self, optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=False,
+                     optimize_color_intrinsics=False, gauge_keyframe=0):
+        """r = -J^T W F and M = diag(J^T W J) of the PCG scheme for the current state (test hook)."""
+        opt = BAOptions(self.use_depth, self.use_desc, int(optimize_depth_intrinsics), int(optimize_color_intrinsics), 0,
+                        int(optimize_poses), int(optimize_geometry), 1, 1, 0, len(self.keyframes) - 1, 0,
+                        int(self.min_observation_count), float(self.merge_factor), 30, int(gauge_keyframe))
+        kfs = self._kf_ptr_array()
+        st = BAState()
+        st.color_cam, st.depth_cam, st.dp = self.color_cam, self.depth_cam, self.dp
+        st.kfs, st.num_kfs = kfs, len(self.keyframes)
+        st.surfels = C.pointer(self.surfels)
+        st.supporting = _ptr(self.supporting, C.c_uint32)
+        cap = 6 * len(self.keyframes) + 3 * self.surfels_size + 5 + self.cf_w * self.cf_h + 4
+        r = np.zeros(cap, np.float32)
+        M = np.zeros(cap, np.float32)
+        self.L.orc_pcg_assemble.restype = C.c_uint32
+        U = self.L.orc_pcg_assemble(C.byref(st), C.byref(opt), _ptr(r, C.c_float), _ptr(M, C.c_float), C.c_uint32(cap))
+        return r[:U], M[:U]
 
     # -- BA --
     def bundle_adjustment(self, optimize_depth_intrinsics=False, optimize_color_intrinsics=False,

@@ -9,7 +9,8 @@ from oracle import binding as ob
 def build_oracle(scene, max_surfels, use_depth=True, use_desc=True, poses=None, create_from=None, filter_new=False,
                  min_observation_count=2):
     cam = ob.make_camera(scene.camera, scene.width, scene.height)
-    ba = ob.OracleBA(max_surfels, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, cam, cam,
+    cam2 = ob.make_camera(scene.camera, scene.width, scene.height)   # distinct objects: tests perturb them separately
+    ba = ob.OracleBA(max_surfels, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, cam, cam2,
                      use_depth_residuals=use_depth, use_descriptor_residuals=use_desc,
                      min_observation_count=min_observation_count)
     poses = scene.poses_gt if poses is None else poses
