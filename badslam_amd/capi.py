@@ -69,6 +69,14 @@ SIGNATURES = {
     "bahip_free": (C.c_int, [C.c_void_p]),
     "bahip_memcpy_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
     "bahip_memset_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t]),
+    "bahip_context_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bahip_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "bahip_stream_destroy": (C.c_int, [C.c_void_p]),
+    "bahip_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "bahip_memcpy_2d_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
+    "bahip_memcpy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "bahip_memset_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "bahip_fill_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int]),
     "bahip_compute_brightness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
     "bahip_compute_normals": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(DepthParams), C.c_void_p, C.c_uint32,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),

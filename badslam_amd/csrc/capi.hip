@@ -286,6 +286,64 @@ int bahip_memset_2d(bahip_context* ctx, void* dst, size_t pitch, int value, size
   return 0;
 }
 
+// ---- stream-level helpers for the host-side CUDABuffer<T> (no context needed) ------------------------
+int bahip_context_set_stream(bahip_context* ctx, void* hip_stream) {
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  return 0;
+}
+int bahip_stream_create(void** out) {
+  hipStream_t s;
+  HIP_TRY(hipStreamCreate(&s));
+  *out = s;
+  return 0;
+}
+int bahip_stream_destroy(void* s) {
+  HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(s)));
+  return 0;
+}
+int bahip_stream_synchronize(void* s) {
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(s)));
+  return 0;
+}
+int bahip_memcpy_2d_async(void* stream, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes,
+                          size_t height, int kind) {
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, k, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+int bahip_memcpy_async(void* stream, void* dst, const void* src, size_t bytes, int kind) {
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, k, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+int bahip_memset_async(void* stream, void* dst, int value, size_t bytes) {
+  HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+}  // extern "C"
+namespace {
+template <typename T>
+__global__ void fill_2d_kernel(T* data, uint32_t pitch, T value, int width, int height) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x < width && y < height) *reinterpret_cast<T*>(reinterpret_cast<char*>(data) + (size_t)y * pitch + (size_t)x * sizeof(T)) = value;
+}
+}  // namespace
+extern "C" {
+
+// CUDABuffer<T>::Clear(value, stream) (libvis/src/libvis/cuda/cuda_buffer.cu:41-60): every element := value.
+int bahip_fill_2d(void* stream, void* data, size_t pitch_bytes, int elem_bytes, uint32_t value_bits, int width, int height) {
+  if (width <= 0 || height <= 0) return 0;
+  const dim3 grid((width + 63) / 64, (height + 3) / 4), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (elem_bytes == 1) hipLaunchKernelGGL(fill_2d_kernel<uint8_t>, grid, block, 0, st, (uint8_t*)data, (uint32_t)pitch_bytes, (uint8_t)value_bits, width, height);
+  else if (elem_bytes == 2) hipLaunchKernelGGL(fill_2d_kernel<uint16_t>, grid, block, 0, st, (uint16_t*)data, (uint32_t)pitch_bytes, (uint16_t)value_bits, width, height);
+  else if (elem_bytes == 4) hipLaunchKernelGGL(fill_2d_kernel<uint32_t>, grid, block, 0, st, (uint32_t*)data, (uint32_t)pitch_bytes, value_bits, width, height);
+  else return fail("bahip_fill_2d: element size must be 1, 2 or 4 bytes", __FILE__, __LINE__);
+  CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- preprocessing ---------------------------------------------------------------------------------
 int bahip_compute_brightness(bahip_context* ctx, const uint8_t* rgb, uint32_t rgb_pitch, uint8_t* rgba, uint32_t rgba_pitch,
                              int width, int height) {

@@ -6,12 +6,17 @@
 // these (B/direct_ba_alternating.cc:214).
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <math.h>
 
-namespace bahip {
-
+// Usable from hipcc translation units (host + device) and from the plain-g++ host library.
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define BAHIP_HD __host__ __device__ inline
+#else
+#define BAHIP_HD inline
+#endif
+
+namespace bahip {
 
 constexpr float kSophusEpsilonF = 1e-5f;  // sophus/common.hpp:144-148
 

@@ -1,0 +1,560 @@
+// direct_ba.cc -- host driver of the MI355X direct-BA backend behind the reference's DirectBA surface.
+// Control flow follows B/direct_ba.cc, B/direct_ba_alternating.cc and B/direct_ba_pcg.cc
+// (B/ = applications/badslam/src/badslam/ of ETH3D/badslam); all device work goes through the C ABI
+// (include/badslam_hip.h).  Where the reference loops over keyframes and launches one kernel per
+// keyframe, this driver makes ONE call per stage.
+#include "direct_ba.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace vis {
+
+namespace {
+// B/convergence_analysis.h:43-51
+bool IsScale1PoseEstimationConverged(const float x[6]) {
+  float sq = 0.f;
+  for (int i = 0; i < 3; ++i) sq += x[i] * x[i];
+  for (int i = 3; i < 6; ++i) { const float v = x[i] * 10.f; sq += v * v; }
+  return sq < 1e-06f;
+}
+int ToBahipActivation(Keyframe::Activation a) { return static_cast<int>(a); }
+}  // namespace
+
+DirectBA::DirectBA(int max_surfel_count, float raw_to_float_depth, float baseline_fx, int sparse_surfel_cell_size,
+                   float surfel_merge_dist_factor, int min_observation_count_while_bootstrapping_1,
+                   int min_observation_count_while_bootstrapping_2, int min_observation_count,
+                   const PinholeCamera4f& color_camera_initial_estimate, const PinholeCamera4f& depth_camera_initial_estimate,
+                   int pyramid_level_for_color, bool use_depth_residuals, bool use_descriptor_residuals, void* render_window,
+                   const SE3f& global_T_anchor_frame)
+    : color_camera_(color_camera_initial_estimate), pyramid_level_for_color_(pyramid_level_for_color),
+      depth_camera_(depth_camera_initial_estimate), use_depth_residuals_(use_depth_residuals),
+      use_descriptor_residuals_(use_descriptor_residuals),
+      min_observation_count_while_bootstrapping_1_(min_observation_count_while_bootstrapping_1),
+      min_observation_count_while_bootstrapping_2_(min_observation_count_while_bootstrapping_2),
+      min_observation_count_(min_observation_count), surfel_merge_dist_factor_(surfel_merge_dist_factor),
+      global_T_anchor_frame_(global_T_anchor_frame) {
+  CHECK(render_window == nullptr) << "the render window is not part of the BA backend";
+  BAHIP_CHECKED_CALL(bahip_context_create(&ctx_, nullptr));
+  // B/direct_ba.cc:107-121
+  depth_params_.a = 0;
+  cfactor_buffer_.reset(new CUDABuffer<float>((depth_camera_.height() - 1) / sparse_surfel_cell_size + 1,
+                                              (depth_camera_.width() - 1) / sparse_surfel_cell_size + 1));
+  cfactor_buffer_->Clear(0, nullptr);
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(nullptr));
+  depth_params_.cfactor_buffer = cfactor_buffer_->ToCUDA();
+  depth_params_.raw_to_float_depth = raw_to_float_depth;
+  depth_params_.baseline_fx = baseline_fx;
+  depth_params_.sparse_surfel_cell_size = sparse_surfel_cell_size;
+  surfels_.reset(new CUDABuffer<float>(kSurfelAttributeCount, max_surfel_count));
+  active_surfels_.reset(new CUDABuffer<u8>(1, max_surfel_count));
+  for (int i = 0; i < kMergeBufferCount; ++i)
+    supporting_surfels_[i].reset(new CUDABuffer<u32>(depth_camera_.height(), depth_camera_.width()));
+}
+
+DirectBA::~DirectBA() { bahip_context_destroy(ctx_); }
+
+// ---- keyframe bookkeeping (B/direct_ba.cc:214-338,549-564,710-738) --------------------------------------------
+void DirectBA::AddKeyframe(const shared_ptr<Keyframe>& new_keyframe) {
+  new_keyframe->SetID(static_cast<int>(keyframes_.size()));
+  DetermineNewKeyframeCoVisibility(new_keyframe);
+  keyframes_.push_back(new_keyframe);
+}
+
+void DirectBA::DeleteKeyframe(int keyframe_index, void* /*loop_detector*/) {
+  shared_ptr<Keyframe> frame_to_delete = keyframes_[keyframe_index];
+  for (int covis_index : frame_to_delete->co_visibility_list()) {
+    auto& list = keyframes_[covis_index]->co_visibility_list();
+    auto it = std::find(list.begin(), list.end(), keyframe_index);
+    if (it != list.end()) list.erase(it);
+  }
+  keyframes_[keyframe_index].reset();
+}
+
+void DirectBA::DetermineNewKeyframeCoVisibility(const shared_ptr<Keyframe>& new_keyframe) {
+  CameraFrustum new_frustum(depth_camera_, new_keyframe->min_depth(), new_keyframe->max_depth(), new_keyframe->global_T_frame());
+  for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
+    if (!keyframe) continue;
+    CameraFrustum frustum(depth_camera_, keyframe->min_depth(), keyframe->max_depth(), keyframe->global_T_frame());
+    if (new_frustum.Intersects(frustum)) {
+      new_keyframe->co_visibility_list().push_back(keyframe->id());
+      keyframe->co_visibility_list().push_back(new_keyframe->id());
+      if (keyframe->activation() == Keyframe::Activation::kInactive) keyframe->SetActivation(Keyframe::Activation::kCovisibleActive);
+    }
+  }
+}
+
+void DirectBA::UpdateKeyframeCoVisibility(const shared_ptr<Keyframe>& keyframe) {
+  for (int covis_index : keyframe->co_visibility_list()) {
+    auto& list = keyframes_[covis_index]->co_visibility_list();
+    auto it = std::find(list.begin(), list.end(), keyframe->id());
+    if (it != list.end()) list.erase(it);
+  }
+  keyframe->co_visibility_list().clear();
+  CameraFrustum frustum(depth_camera_, keyframe->min_depth(), keyframe->max_depth(), keyframe->global_T_frame());
+  for (const shared_ptr<Keyframe>& other : keyframes_) {
+    if (!other) continue;
+    CameraFrustum other_frustum(depth_camera_, other->min_depth(), other->max_depth(), other->global_T_frame());
+    if (frustum.Intersects(other_frustum)) {
+      keyframe->co_visibility_list().push_back(other->id());
+      other->co_visibility_list().push_back(keyframe->id());
+    }
+  }
+}
+
+void DirectBA::DetermineCovisibleActiveKeyframes() {
+  for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
+    if (!keyframe || keyframe->activation() != Keyframe::Activation::kActive) continue;
+    for (int covisible_index : keyframe->co_visibility_list()) {
+      shared_ptr<Keyframe>& other = keyframes_[covisible_index];
+      if (other && other->activation() == Keyframe::Activation::kInactive) other->SetActivation(Keyframe::Activation::kCovisibleActive);
+    }
+  }
+}
+
+// B/direct_ba.cc:251-338: drops the keyframes that are closest to their neighbours (frees memory).
+void DirectBA::MergeKeyframes(hipStream_t /*stream*/, void* loop_detector, usize approx_merge_count) {
+  constexpr float kMaxAngleDifference = 0.5f * 1.57079632679f;
+  constexpr float kMaxEuclideanDistance = 0.3f;
+  if (keyframes_.size() <= 1) return;
+  struct Candidate { float distance; usize prev_id, id, next_id; };
+  vector<Candidate> distances;
+  float prev_half_distance = 0;
+  usize prev_keyframe_id = 0;
+  for (usize id = 0; id + 1 < keyframes_.size(); ++id) {
+    const shared_ptr<Keyframe>& keyframe = keyframes_[id];
+    if (!keyframe) continue;
+    const Keyframe* next = nullptr;
+    for (usize n = id + 1; n < keyframes_.size(); ++n) if (keyframes_[n]) { next = keyframes_[n].get(); break; }
+    if (!next) break;
+    float Ra[9], Rb[9];
+    keyframe->global_T_frame().rotationMatrix(Ra);
+    next->global_T_frame().rotationMatrix(Rb);
+    const float dot = Ra[2] * Rb[2] + Ra[5] * Rb[5] + Ra[8] * Rb[8];   // z axes
+    const float angle_difference = acosf(dot);
+    if (angle_difference > kMaxAngleDifference) continue;
+    const float* ta = keyframe->global_T_frame().translation();
+    const float* tb = next->global_T_frame().translation();
+    const float dist = sqrtf((ta[0] - tb[0]) * (ta[0] - tb[0]) + (ta[1] - tb[1]) * (ta[1] - tb[1]) + (ta[2] - tb[2]) * (ta[2] - tb[2]));
+    if (dist > kMaxEuclideanDistance) continue;
+    const float next_half_distance = dist + (0.5f / 1.57079632679f) * angle_difference;
+    if (id > 0) distances.push_back({prev_half_distance + next_half_distance, prev_keyframe_id, id, (usize)next->id()});
+    prev_half_distance = next_half_distance;
+    prev_keyframe_id = id;
+  }
+  const usize count = std::min(approx_merge_count, distances.size());
+  std::partial_sort(distances.begin(), distances.begin() + count, distances.end(),
+                    [](const Candidate& a, const Candidate& b) { return a.distance < b.distance; });
+  for (usize i = 0; i < count; ++i) {
+    const Candidate& m = distances[i];
+    if (!keyframes_[m.prev_id] || !keyframes_[m.id] || !keyframes_[m.next_id]) continue;
+    DeleteKeyframe((int)m.id, loop_detector);
+    LOG(WARNING) << "Deleted keyframe with ID " << m.id;
+  }
+}
+
+// ---- scene binding ---------------------------------------------------------------------------------------------
+bahip_surfels DirectBA::SurfelsStruct(bool with_active) const {
+  bahip_surfels s;
+  s.data = surfels_->ToCUDA().address();
+  s.pitch_bytes = (uint32_t)surfels_->ToCUDA().pitch();
+  s.active = with_active ? active_surfels_->ToCUDA().address() : nullptr;
+  s.surfels_size = surfels_size_;
+  s.capacity = (uint32_t)surfels_->width();
+  return s;
+}
+
+void DirectBA::BindScene(hipStream_t stream) {
+  BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
+  const bahip_camera cc = ToBahipCamera(color_camera_), dc = ToBahipCamera(depth_camera_);
+  const bahip_depth_params dp = ToBahipDepthParams(depth_params_);
+  BAHIP_CHECKED_CALL(bahip_set_intrinsics(ctx_, &cc, &dc, &dp));
+  vector<bahip_keyframe> list;
+  bound_ids_.clear();
+  id_to_bound_.assign(keyframes_.size(), -1);
+  for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
+    if (!keyframe) continue;
+    bahip_keyframe k;
+    k.frame = keyframe->ToBahipFrame();
+    memcpy(k.global_T_frame, keyframe->global_T_frame().data(), 7 * sizeof(float));
+    k.activation = ToBahipActivation(keyframe->activation());
+    id_to_bound_[keyframe->id()] = (int)list.size();
+    bound_ids_.push_back(keyframe->id());
+    list.push_back(k);
+  }
+  BAHIP_CHECKED_CALL(bahip_set_keyframes(ctx_, list.data(), (int)list.size()));
+}
+
+// ---- surfel creation (B/direct_ba.cc:340-405) ---------------------------------------------------------------------
+void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const shared_ptr<Keyframe>& keyframe) {
+  BindScene(stream);
+  vector<int> covis;
+  for (int id : keyframe->co_visibility_list())
+    if (id >= 0 && id < (int)id_to_bound_.size() && id_to_bound_[id] >= 0) covis.push_back(id_to_bound_[id]);
+  uint32_t* sup[kMergeBufferCount];
+  for (int i = 0; i < kMergeBufferCount; ++i) sup[i] = supporting_surfels_[i]->ToCUDA().address();
+  const bahip_surfels s = SurfelsStruct();
+  uint32_t new_surfel_count = 0;
+  BAHIP_CHECKED_CALL(bahip_create_surfels_for_keyframe(ctx_, id_to_bound_[keyframe->id()], filter_new_surfels ? 1 : 0,
+                                                       GetMinObservationCount(), covis.data(), (int)covis.size(), &s, sup,
+                                                       (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(), &new_surfel_count));
+  if (new_surfel_count == 0 && bahip_last_error()[0] == 'M') LOG(ERROR) << bahip_last_error();
+  Lock();
+  surfels_size_ += new_surfel_count;
+  surfel_count_ += new_surfel_count;
+  Unlock();
+}
+
+void DirectBA::MergeForKeyframe(const Keyframe& keyframe) {
+  uint32_t* sup[kMergeBufferCount];
+  for (int i = 0; i < kMergeBufferCount; ++i) sup[i] = supporting_surfels_[i]->ToCUDA().address();
+  const bahip_frame frame = keyframe.ToBahipFrame();
+  float F[12];
+  keyframe.frame_T_global().matrix3x4(F);
+  const bahip_surfels s = SurfelsStruct();
+  uint32_t merged = 0;
+  BAHIP_CHECKED_CALL(bahip_determine_supporting_surfels(ctx_, 1, surfel_merge_dist_factor_, &frame, F, &s, sup,
+                                                        (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(), &merged));
+  surfel_count_ -= merged;
+}
+
+// ---- single-frame pose estimation (B/direct_ba_alternating.cc:42-283) -----------------------------------------------
+void DirectBA::EstimateFramePose(hipStream_t stream, const SE3f& global_T_frame_initial_estimate, const CUDABuffer<u16>& depth_buffer,
+                                 const CUDABuffer<u16>& normals_buffer, hipTextureHandle_t color_texture,
+                                 SE3f* out_global_T_frame_estimate, bool /*called_within_ba*/) {
+  BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
+  const bahip_camera cc = ToBahipCamera(color_camera_), dc = ToBahipCamera(depth_camera_);
+  const bahip_depth_params dp = ToBahipDepthParams(depth_params_);
+  BAHIP_CHECKED_CALL(bahip_set_intrinsics(ctx_, &cc, &dc, &dp));
+  bahip_frame frame{};
+  frame.depth = depth_buffer.ToCUDA().address(); frame.depth_pitch_bytes = (uint32_t)depth_buffer.ToCUDA().pitch();
+  frame.normals = normals_buffer.ToCUDA().address(); frame.normals_pitch_bytes = (uint32_t)normals_buffer.ToCUDA().pitch();
+  frame.color = reinterpret_cast<uint8_t*>(color_texture->ToCUDA().address());
+  frame.color_pitch_bytes = (uint32_t)color_texture->ToCUDA().pitch();
+  const bahip_surfels s = SurfelsStruct();
+  int iterations = 0, converged = 0;
+  BAHIP_CHECKED_CALL(bahip_estimate_frame_pose(ctx_, use_depth_residuals_, use_descriptor_residuals_, &frame,
+                                               global_T_frame_initial_estimate.data(), &s, out_global_T_frame_estimate->data(),
+                                               &iterations, &converged));
+  if (!converged) LOG(WARNING) << "Pose estimation not converged";
+}
+
+// ---- dispatcher (B/direct_ba.cc:407-454) ---------------------------------------------------------------------------------
+void DirectBA::BundleAdjustment(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics,
+                                bool do_surfel_updates, bool optimize_poses, bool optimize_geometry, int min_iterations,
+                                int max_iterations, bool use_pcg, int active_keyframe_window_start,
+                                int active_keyframe_window_end, bool increase_ba_iteration_count, int* iterations_done,
+                                bool* converged, double time_limit, Timer* timer, int pcg_max_inner_iterations,
+                                int pcg_max_keyframes, std::function<bool(int)> progress_function) {
+  if (optimize_depth_intrinsics && !use_depth_residuals_) {
+    LOG(WARNING) << "optimize_depth_intrinsics set to true, but use_depth_residuals_ set to false. Depth intrinsics will not be optimized.";
+    optimize_depth_intrinsics = false;
+  }
+  if (optimize_color_intrinsics && !use_descriptor_residuals_) {
+    LOG(WARNING) << "optimize_color_intrinsics set to true, but use_descriptor_residuals_ set to false. Color intrinsics will not be optimized.";
+    optimize_color_intrinsics = false;
+  }
+  last_pose_rounds_ = last_pose_steps_ = last_pcg_inner_steps_ = 0;
+  if (use_pcg) {
+    BundleAdjustmentPCG(stream, optimize_depth_intrinsics, optimize_color_intrinsics, do_surfel_updates, optimize_poses,
+                        optimize_geometry, min_iterations, max_iterations, pcg_max_inner_iterations, pcg_max_keyframes,
+                        active_keyframe_window_start, active_keyframe_window_end, increase_ba_iteration_count, iterations_done,
+                        converged, time_limit, timer, progress_function);
+  } else {
+    BundleAdjustmentAlternating(stream, optimize_depth_intrinsics, optimize_color_intrinsics, do_surfel_updates, optimize_poses,
+                                optimize_geometry, min_iterations, max_iterations, active_keyframe_window_start,
+                                active_keyframe_window_end, increase_ba_iteration_count, iterations_done, converged, time_limit,
+                                timer, progress_function);
+  }
+}
+
+// ---- end-of-scheme tasks (B/direct_ba.cc:566-653) -----------------------------------------------------------------------
+void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates) {
+  BindScene(stream);
+  if (do_surfel_updates) {
+    for (shared_ptr<Keyframe>& keyframe : keyframes_) {
+      if (!keyframe) continue;
+      if (keyframe->last_active_in_ba_iteration() == ba_iteration_count_) MergeForKeyframe(*keyframe);
+    }
+  }
+  const bahip_surfels s = SurfelsStruct();
+  uint32_t deleted = 0;
+  BAHIP_CHECKED_CALL(bahip_delete_surfels_and_update_radii(ctx_, GetMinObservationCount(), &s, &deleted));
+  u32 surfel_count = surfel_count_ - deleted;
+  const bahip_surfels s2 = SurfelsStruct(/*with_active*/ false);   // B/direct_ba.cc:619: no active-flag buffer
+  BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count, &s2));
+  Lock();
+  surfels_size_ = surfel_count;
+  surfel_count_ = surfel_count;
+  Unlock();
+}
+
+// ---- alternating scheme (B/direct_ba_alternating.cc:285-738) ----------------------------------------------------------------
+void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics,
+                                           bool do_surfel_updates, bool optimize_poses, bool optimize_geometry, int min_iterations,
+                                           int max_iterations, int active_keyframe_window_start, int active_keyframe_window_end,
+                                           bool increase_ba_iteration_count, int* num_iterations_done, bool* converged,
+                                           double time_limit, Timer* timer, std::function<bool(int)> progress_function) {
+  if (converged) *converged = false;
+  if (num_iterations_done) *num_iterations_done = 0;
+  Lock();
+  const int fixed_ba_iteration_count = ba_iteration_count_;
+  Unlock();
+  if (!increase_ba_iteration_count && fixed_ba_iteration_count != last_ba_iteration_count_) {
+    last_ba_iteration_count_ = fixed_ba_iteration_count;
+    PerformBASchemeEndTasks(stream, do_surfel_updates);
+  }
+  vector<u32> keyframes_with_new_surfels;
+  const bool fixed_active_keyframe_set = active_keyframe_window_start > 0 || active_keyframe_window_end > 0;
+  const bool full_window = active_keyframe_window_start == 0 && active_keyframe_window_end == (int)keyframes_.size() - 1;
+  if (!full_window)
+    LOG(WARNING) << "Currently, only using all keyframes in every optimization iteration will work properly.";
+  BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address(), 0, surfels_size_));
+
+  for (int iteration = 0; iteration < max_iterations; ++iteration) {
+    if (progress_function && !progress_function(iteration)) break;
+    if (num_iterations_done) ++*num_iterations_done;
+    if (fixed_active_keyframe_set) {
+      Lock();
+      for (u32 i = 0; i < keyframes_.size(); ++i) {
+        if (!keyframes_[i]) continue;
+        keyframes_[i]->SetActivation(((int)i >= active_keyframe_window_start && (int)i <= active_keyframe_window_end)
+                                         ? Keyframe::Activation::kActive : Keyframe::Activation::kInactive);
+      }
+      DetermineCovisibleActiveKeyframes();
+      Unlock();
+    }
+
+    // --- surfel creation ---
+    keyframes_with_new_surfels.clear();
+    CHECK_EQ(surfels_size_, surfel_count_);
+    const usize old_surfels_size = surfels_size_;
+    if (optimize_geometry && do_surfel_updates) {
+      Lock();
+      for (shared_ptr<Keyframe>& keyframe : keyframes_) {
+        if (!keyframe) continue;
+        if (keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != fixed_ba_iteration_count) {
+          keyframe->SetLastActiveInBAIteration(fixed_ba_iteration_count);
+          keyframes_with_new_surfels.push_back(keyframe->id());
+        } else if (keyframe->activation() == Keyframe::Activation::kCovisibleActive &&
+                   keyframe->last_covis_in_ba_iteration() != fixed_ba_iteration_count) {
+          keyframe->SetLastCovisInBAIteration(fixed_ba_iteration_count);
+        }
+      }
+      Unlock();
+      for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
+    }
+
+    BindScene(stream);
+
+    // --- surfel activation ---
+    if (optimize_geometry && surfels_size_ > old_surfels_size)
+      BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address() + old_surfels_size, 1, surfels_size_ - old_surfels_size));
+    if (!full_window) {
+      BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address(), 1, old_surfels_size));
+    } else {
+      const bahip_surfels s = SurfelsStruct();
+      BAHIP_CHECKED_CALL(bahip_update_surfel_activation(ctx_, &s, (uint32_t)old_surfels_size));
+    }
+
+    // --- geometry ---
+    if (optimize_geometry) {
+      const bahip_surfels s = SurfelsStruct();
+      BAHIP_CHECKED_CALL(bahip_optimize_geometry_iteration(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s));
+    }
+
+    // --- surfel merge + compaction ---
+    if (do_surfel_updates) {
+      for (u32 keyframe_id : keyframes_with_new_surfels)
+        if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
+      if (!keyframes_with_new_surfels.empty()) {
+        const bahip_surfels s = SurfelsStruct();
+        BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count_, &s));
+        Lock();
+        surfels_size_ = surfel_count_;
+        Unlock();
+      }
+    }
+
+    // --- poses: every non-inactive keyframe, batched per Gauss-Newton round ---
+    usize num_converged = 0;
+    if (optimize_poses) {
+      const int K = (int)bound_ids_.size();
+      vector<float> poses(7 * (size_t)K);
+      vector<int> its(K), conv(K);
+      int rounds = 0;
+      const bahip_surfels s = SurfelsStruct();
+      BAHIP_CHECKED_CALL(bahip_estimate_keyframe_poses(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s, poses.data(),
+                                                       its.data(), conv.data(), &rounds));
+      last_pose_rounds_ += rounds;
+      for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
+        if (!keyframe || keyframe->activation() == Keyframe::Activation::kInactive) { ++num_converged; continue; }
+        const int b = id_to_bound_[keyframe->id()];
+        last_pose_steps_ += its[b];
+        if (!conv[b]) LOG(WARNING) << "Pose estimation not converged (keyframe " << keyframe->id() << ")";
+        const SE3f estimate(&poses[7 * (size_t)b]);
+        const SE3f pose_difference = keyframe->frame_T_global() * estimate;
+        float lg[6];
+        pose_difference.log(lg);
+        const bool frame_moved = !IsScale1PoseEstimationConverged(lg);
+        Lock();
+        keyframe->set_global_T_frame(estimate);
+        if (frame_moved) {
+          keyframe->SetActivation(Keyframe::Activation::kActive);
+        } else {
+          keyframe->SetActivation(Keyframe::Activation::kInactive);
+          ++num_converged;
+        }
+        Unlock();
+      }
+    }
+
+    // --- intrinsics ---
+    if (optimize_depth_intrinsics || optimize_color_intrinsics) {
+      bahip_camera out_color, out_depth;
+      float out_a = depth_params_.a;
+      const bahip_surfels s = SurfelsStruct();
+      BAHIP_CHECKED_CALL(bahip_optimize_intrinsics(ctx_, optimize_depth_intrinsics, optimize_color_intrinsics, &s, &out_color, &out_depth, &out_a));
+      if (surfels_size_ > 0) {
+        Lock();
+        if (optimize_color_intrinsics) color_camera_ = PinholeCamera4f(out_color.width, out_color.height, &out_color.fx);
+        if (optimize_depth_intrinsics) {
+          depth_camera_ = PinholeCamera4f(out_depth.width, out_depth.height, &out_depth.fx);
+          depth_params_.a = out_a;
+        }
+        Unlock();
+      }
+      if (intrinsics_updated_callback_) intrinsics_updated_callback_();
+    }
+
+    if (timings_stream_) {
+      *timings_stream_ << "BA_count " << fixed_ba_iteration_count << " inner_iteration " << iteration << " keyframe_count "
+                       << keyframes_.size() << " surfel_count " << surfel_count_ << std::endl;
+      static const char* keys[4] = {"BA_surfel_activation", "BA_geometry_optimization", "BA_pose_optimization", nullptr};
+      for (int stage = 0; stage < 3; ++stage) {
+        float ms = 0; int launches = 0;
+        if (bahip_last_stage_time_ms(ctx_, stage, &ms, &launches) == 0 && launches > 0) *timings_stream_ << keys[stage] << " " << ms << std::endl;
+      }
+    }
+
+    // --- convergence ---
+    if (iteration >= min_iterations - 1 && (num_converged == keyframes_.size() || !optimize_poses)) {
+      if (converged) *converged = true;
+      break;
+    }
+    if (timer && timer->GetTimeSinceStart() > time_limit) break;
+    Lock();
+    DetermineCovisibleActiveKeyframes();
+    Unlock();
+  }
+
+  if (increase_ba_iteration_count) {
+    PerformBASchemeEndTasks(stream, do_surfel_updates);
+    ++ba_iteration_count_;
+  }
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+}
+
+// ---- PCG scheme (B/direct_ba_pcg.cc:43-819) -----------------------------------------------------------------------------------
+void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics,
+                                   bool do_surfel_updates, bool optimize_poses, bool optimize_geometry, int min_iterations,
+                                   int max_iterations, int max_inner_iterations, int max_keyframe_count,
+                                   int active_keyframe_window_start, int active_keyframe_window_end, bool increase_ba_iteration_count,
+                                   int* num_iterations_done, bool* converged, double time_limit, Timer* timer,
+                                   std::function<bool(int)> progress_function) {
+  if ((active_keyframe_window_start != -1 || active_keyframe_window_end != -1) &&
+      (active_keyframe_window_start != 0 || active_keyframe_window_end != (int)keyframes_.size() - 1))
+    LOG(WARNING) << "The PCG-based solver implementation does not support an active window! These parameters will be ignored.";
+  if (num_iterations_done) *num_iterations_done = 0;
+  if (converged) *converged = false;
+  for (auto& keyframe : keyframes_) {
+    if (!keyframe) {
+      LOG(ERROR) << "The PCG-based solver implementation does not support having deleted keyframes yet! Aborting.";
+      return;
+    }
+  }
+  CHECK_LE((int)keyframes_.size(), max_keyframe_count);
+  if (!increase_ba_iteration_count && ba_iteration_count_ != last_ba_iteration_count_) {
+    last_ba_iteration_count_ = ba_iteration_count_;
+    PerformBASchemeEndTasks(stream, do_surfel_updates);
+  }
+  vector<u32> keyframes_with_new_surfels;
+  auto merge_and_compact = [&]() {
+    for (u32 keyframe_id : keyframes_with_new_surfels)
+      if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
+    if (!keyframes_with_new_surfels.empty()) {
+      const bahip_surfels s = SurfelsStruct();
+      BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count_, &s));
+      surfels_size_ = surfel_count_;
+    }
+  };
+
+  for (int iteration = 0; iteration < max_iterations; ++iteration) {
+    if (progress_function && !progress_function(iteration)) break;
+    if (num_iterations_done) ++*num_iterations_done;
+    keyframes_with_new_surfels.clear();
+    if (optimize_geometry && do_surfel_updates) {
+      for (shared_ptr<Keyframe>& keyframe : keyframes_) {
+        if (keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != ba_iteration_count_) {
+          keyframe->SetLastActiveInBAIteration(ba_iteration_count_);
+          CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframe);
+          keyframes_with_new_surfels.push_back(keyframe->id());
+        } else if (keyframe->activation() == Keyframe::Activation::kCovisibleActive &&
+                   keyframe->last_covis_in_ba_iteration() != ba_iteration_count_) {
+          keyframe->SetLastCovisInBAIteration(ba_iteration_count_);
+        }
+      }
+    }
+    BindScene(stream);
+    BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address(), 1, surfels_size_));
+    if (optimize_geometry) {
+      const bahip_surfels s = SurfelsStruct();
+      BAHIP_CHECKED_CALL(bahip_update_surfel_normals(ctx_, &s));
+    }
+
+    bahip_pcg_options opt;
+    opt.optimize_poses = optimize_poses; opt.optimize_geometry = optimize_geometry;
+    opt.optimize_depth_intrinsics = optimize_depth_intrinsics; opt.optimize_color_intrinsics = optimize_color_intrinsics;
+    opt.use_depth_residuals = use_depth_residuals_; opt.use_descriptor_residuals = use_descriptor_residuals_;
+    opt.max_inner_iterations = max_inner_iterations;
+    opt.gauge_keyframe = (pcg_gauge_keyframe_ >= 0) ? pcg_gauge_keyframe_ : (rand() % (int)keyframes_.size());   // B/direct_ba_pcg.cc:328
+    bahip_camera out_color, out_depth;
+    float out_a = depth_params_.a;
+    int inner_steps = 0, num_converged = 0;
+    const bahip_surfels s = SurfelsStruct();
+    BAHIP_CHECKED_CALL(bahip_pcg_iteration(ctx_, &opt, &s, &out_color, &out_depth, &out_a, &inner_steps, &num_converged));
+    last_pcg_inner_steps_ += inner_steps;
+    if (optimize_poses) {
+      vector<float> poses(7 * keyframes_.size());
+      BAHIP_CHECKED_CALL(bahip_get_keyframe_poses(ctx_, poses.data(), (int)keyframes_.size()));
+      for (usize k = 0; k < keyframes_.size(); ++k) keyframes_[k]->set_global_T_frame(SE3f(&poses[7 * k]));
+    }
+    if (optimize_color_intrinsics) color_camera_ = PinholeCamera4f(out_color.width, out_color.height, &out_color.fx);
+    if (optimize_depth_intrinsics) {
+      depth_camera_ = PinholeCamera4f(out_depth.width, out_depth.height, &out_depth.fx);
+      depth_params_.a = out_a;
+    }
+    if ((optimize_depth_intrinsics || optimize_color_intrinsics) && intrinsics_updated_callback_) intrinsics_updated_callback_();
+    if (do_surfel_updates) {
+      BindScene(stream);   // merges use the updated poses / intrinsics
+      merge_and_compact();
+    }
+
+    if (iteration >= min_iterations - 1 && ((usize)num_converged == keyframes_.size() || !optimize_poses)) {
+      if (converged) *converged = true;
+      break;
+    }
+    if (timer && timer->GetTimeSinceStart() > time_limit) break;
+  }
+
+  if (increase_ba_iteration_count) {
+    PerformBASchemeEndTasks(stream, do_surfel_updates);
+    ++ba_iteration_count_;
+  } else if (do_surfel_updates) {
+    BindScene(stream);
+    merge_and_compact();   // B/direct_ba_pcg.cc:775-812
+  }
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+}
+
+}  // namespace vis

@@ -1,0 +1,170 @@
+// direct_ba.h -- vis::DirectBA, the direct bundle-adjustment back-end of BAD SLAM, with the public
+// surface of the reference class (B/direct_ba.h:65-550; B/ = applications/badslam/src/badslam/):
+// same constructor arguments, same method names, argument meaning and defaults, same accessors.
+// Everything below the surface is new: the scene lives in HIP buffers, and every stage is one call
+// into the C ABI of the MI355X backend (include/badslam_hip.h) instead of a loop of per-keyframe
+// kernel launches.  Differences forced by the platform:
+//   - cudaStream_t -> hipStream_t (opaque), cudaTextureObject_t -> hipTextureHandle_t (gfx950 has
+//     no texture sampling; the handle names the colour buffer),
+//   - render window / OpenGL interop, loop-detector hooks and AssignColors are not part of the BA
+//     path (OUT) and are omitted,
+//   - SetRunParallel is declared but never defined in the reference (B/direct_ba.h:172): omitted.
+#pragma once
+
+#include "camera_frustum.h"
+#include "keyframe.h"
+
+namespace vis {
+
+constexpr int kMergeBufferCount = BAHIP_MERGE_BUFFER_COUNT;       // B/kernels.cuh:51
+constexpr int kSurfelAttributeCount = BAHIP_SURFEL_ATTRIBUTE_COUNT;
+constexpr int kSurfelX = 0, kSurfelY = 1, kSurfelZ = 2, kSurfelNormal = 3, kSurfelRadiusSquared = 4, kSurfelColor = 5,
+              kSurfelDescriptor1 = 6, kSurfelDescriptor2 = 7, kSurfelAccum0 = 8;   // B/kernels.cuh:69-88
+
+class DirectBA {
+ public:
+  DirectBA(int max_surfel_count, float raw_to_float_depth, float baseline_fx, int sparse_surfel_cell_size,
+           float surfel_merge_dist_factor, int min_observation_count_while_bootstrapping_1,
+           int min_observation_count_while_bootstrapping_2, int min_observation_count,
+           const PinholeCamera4f& color_camera_initial_estimate, const PinholeCamera4f& depth_camera_initial_estimate,
+           int pyramid_level_for_color, bool use_depth_residuals, bool use_descriptor_residuals,
+           void* render_window /* must be nullptr */, const SE3f& global_T_anchor_frame);
+  ~DirectBA();
+
+  void AddKeyframe(const shared_ptr<Keyframe>& new_keyframe);
+  void DeleteKeyframe(int keyframe_index, void* loop_detector = nullptr);
+  void MergeKeyframes(hipStream_t stream, void* loop_detector, usize approx_merge_count = 10);
+  void CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const shared_ptr<Keyframe>& keyframe);
+  void EstimateFramePose(hipStream_t stream, const SE3f& global_T_frame_initial_estimate, const CUDABuffer<u16>& depth_buffer,
+                         const CUDABuffer<u16>& normals_buffer, hipTextureHandle_t color_texture,
+                         SE3f* out_global_T_frame_estimate, bool called_within_ba);
+  void BundleAdjustment(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics, bool do_surfel_updates,
+                        bool optimize_poses, bool optimize_geometry, int min_iterations, int max_iterations, bool use_pcg,
+                        int active_keyframe_window_start, int active_keyframe_window_end, bool increase_ba_iteration_count,
+                        int* iterations_done = nullptr, bool* converged = nullptr, double time_limit = 0, Timer* timer = nullptr,
+                        int pcg_max_inner_iterations = 30, int pcg_max_keyframes = 2500,
+                        std::function<bool(int)> progress_function = nullptr);
+  void UpdateKeyframeCoVisibility(const shared_ptr<Keyframe>& keyframe);
+
+  void Lock() const { ba_thread_mutex_.lock(); }
+  void Unlock() const { ba_thread_mutex_.unlock(); }
+  std::mutex& Mutex() const { return ba_thread_mutex_; }
+
+  int GetMinObservationCount() const {
+    return (keyframes_.size() < 10) ? ((keyframes_.size() < 5) ? min_observation_count_while_bootstrapping_1_
+                                                                : min_observation_count_while_bootstrapping_2_)
+                                    : min_observation_count_;
+  }
+
+  // --- accessors (B/direct_ba.h:226-388) ---
+  const vector<shared_ptr<Keyframe>>& keyframes() const { return keyframes_; }
+  vector<shared_ptr<Keyframe>>* keyframes_mutable() { return &keyframes_; }
+  PinholeCamera4f color_camera() const { lock_guard<mutex> lock(ba_thread_mutex_); return color_camera_; }
+  PinholeCamera4f color_camera_no_lock() const { return color_camera_; }
+  void SetColorCamera(const PinholeCamera4f& camera) { lock_guard<mutex> lock(ba_thread_mutex_); color_camera_ = camera; }
+  int pyramid_level_for_color() const { return pyramid_level_for_color_; }
+  void SetPyramidLevelForColor(int level) { pyramid_level_for_color_ = level; }
+  PinholeCamera4f depth_camera() const { lock_guard<mutex> lock(ba_thread_mutex_); return depth_camera_; }
+  PinholeCamera4f depth_camera_no_lock() const { return depth_camera_; }
+  void SetDepthCamera(const PinholeCamera4f& camera) { lock_guard<mutex> lock(ba_thread_mutex_); depth_camera_ = camera; }
+  DepthParameters depth_params() const { lock_guard<mutex> lock(ba_thread_mutex_); return depth_params_; }
+  DepthParameters depth_params_no_lock() const { return depth_params_; }
+  void SetDepthParams(const DepthParameters& params) { lock_guard<mutex> lock(ba_thread_mutex_); depth_params_ = params; }
+  float& a() { return depth_params_.a; }
+  float a() const { return depth_params_.a; }
+  CUDABufferPtr<float> cfactor_buffer() { return cfactor_buffer_; }
+  CUDABufferConstPtr<float> cfactor_buffer() const { return cfactor_buffer_; }
+  void SetCFactorBuffer(const CUDABufferPtr<float>& cfactor_buffer) {
+    cfactor_buffer_ = cfactor_buffer;
+    depth_params_.cfactor_buffer = cfactor_buffer_->ToCUDA();
+  }
+  void IncreaseBAIterationCount() { lock_guard<mutex> lock(ba_thread_mutex_); ++ba_iteration_count_; }
+  bool use_depth_residuals() const { return use_depth_residuals_; }
+  void SetUseDepthResiduals(bool v) { use_depth_residuals_ = v; }
+  bool use_descriptor_residuals() const { return use_descriptor_residuals_; }
+  void SetUseDescriptorResiduals(bool v) { use_descriptor_residuals_ = v; }
+  int sparse_surfel_cell_size() const { return depth_params_.sparse_surfel_cell_size; }
+  void SetSparsificationSideFactor(int cell) { depth_params_.sparse_surfel_cell_size = cell; }
+  int min_observation_count_while_bootstrapping_1() const { return min_observation_count_while_bootstrapping_1_; }
+  void SetMinObservationCountWhileBootstrapping1(int c) { min_observation_count_while_bootstrapping_1_ = c; }
+  int min_observation_count_while_bootstrapping_2() const { return min_observation_count_while_bootstrapping_2_; }
+  void SetMinObservationCountWhileBootstrapping2(int c) { min_observation_count_while_bootstrapping_2_ = c; }
+  int min_observation_count() const { return min_observation_count_; }
+  void SetMinObservationCount(int c) { min_observation_count_ = c; }
+  void SetIntrinsicsUpdatedCallback(const std::function<void()>& callback) { intrinsics_updated_callback_ = callback; }
+  u32 surfel_count() const { lock_guard<mutex> lock(ba_thread_mutex_); return surfel_count_; }
+  u32 surfels_size() const { lock_guard<mutex> lock(ba_thread_mutex_); return surfels_size_; }
+  void SetSurfelCount(u32 surfel_count, u32 surfels_size) { surfel_count_ = surfel_count; surfels_size_ = surfels_size; }
+  CUDABufferConstPtr<float> surfels() const { return surfels_; }
+  CUDABufferPtr<float> surfels() { return surfels_; }
+  CUDABufferPtr<u8> active_surfels() { return active_surfels_; }
+  int ba_iteration_count() const { return ba_iteration_count_; }
+  void SetBAIterationCount(int count) { ba_iteration_count_ = count; }
+  int last_ba_iteration_count() const { return last_ba_iteration_count_; }
+  void SetLastBAIterationCount(int count) { last_ba_iteration_count_ = count; }
+  float surfel_merge_dist_factor() const { return surfel_merge_dist_factor_; }
+  void SetSurfelMergeDistFactor(float factor) { surfel_merge_dist_factor_ = factor; }
+  void SetSaveTimings(std::ostream* stream) { timings_stream_ = stream; }
+
+  // --- additions of this backend ---
+  // The gauge keyframe of the PCG scheme; the reference draws rand() % K per outer iteration
+  // (B/direct_ba_pcg.cc:328).  < 0 (default) = same rand() stream.
+  void SetPCGGaugeKeyframe(int keyframe_id) { pcg_gauge_keyframe_ = keyframe_id; }
+  // Multi-GPU surfel sharding: sums of the per-keyframe normal equations go through this hook
+  // (see include/badslam_hip.h, bahip_allreduce_fn).
+  void SetAllReduce(bahip_allreduce_fn fn, void* user) { BAHIP_CHECKED_CALL(bahip_context_set_allreduce(ctx_, fn, user)); }
+  bahip_context* backend_context() { return ctx_; }
+  // Statistics of the last BundleAdjustment() call: Gauss-Newton rounds (batched over keyframes)
+  // and total per-keyframe GN steps, PCG inner steps.
+  int last_pose_rounds() const { return last_pose_rounds_; }
+  int last_pose_steps() const { return last_pose_steps_; }
+  int last_pcg_inner_steps() const { return last_pcg_inner_steps_; }
+
+ private:
+  void BundleAdjustmentAlternating(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics,
+                                   bool do_surfel_updates, bool optimize_poses, bool optimize_geometry, int min_iterations,
+                                   int max_iterations, int active_keyframe_window_start, int active_keyframe_window_end,
+                                   bool increase_ba_iteration_count, int* num_iterations_done, bool* converged, double time_limit,
+                                   Timer* timer, std::function<bool(int)> progress_function);
+  void BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics, bool do_surfel_updates,
+                           bool optimize_poses, bool optimize_geometry, int min_iterations, int max_iterations,
+                           int max_inner_iterations, int max_keyframe_count, int active_keyframe_window_start,
+                           int active_keyframe_window_end, bool increase_ba_iteration_count, int* num_iterations_done,
+                           bool* converged, double time_limit, Timer* timer, std::function<bool(int)> progress_function);
+  void DetermineCovisibleActiveKeyframes();
+  void DetermineNewKeyframeCoVisibility(const shared_ptr<Keyframe>& new_keyframe);
+  void PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates);
+
+  // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
+  // keyframe ids and the dense bound list.
+  void BindScene(hipStream_t stream);
+  bahip_surfels SurfelsStruct(bool with_active = true) const;
+  void MergeForKeyframe(const Keyframe& keyframe);
+
+  PinholeCamera4f color_camera_;
+  int pyramid_level_for_color_;
+  PinholeCamera4f depth_camera_;
+  CUDABufferPtr<float> cfactor_buffer_;
+  DepthParameters depth_params_;
+  vector<shared_ptr<Keyframe>> keyframes_;
+  u32 surfel_count_ = 0, surfels_size_ = 0;
+  CUDABufferPtr<float> surfels_;
+  CUDABufferPtr<u8> active_surfels_;
+  int ba_iteration_count_ = 0, last_ba_iteration_count_ = -1;
+  bool use_depth_residuals_, use_descriptor_residuals_;
+  int min_observation_count_while_bootstrapping_1_, min_observation_count_while_bootstrapping_2_, min_observation_count_;
+  float surfel_merge_dist_factor_;
+  CUDABufferPtr<u32> supporting_surfels_[kMergeBufferCount];
+  mutable mutex ba_thread_mutex_;
+  std::ostream* timings_stream_ = nullptr;
+  std::function<void()> intrinsics_updated_callback_;
+  SE3f global_T_anchor_frame_;
+
+  bahip_context* ctx_ = nullptr;
+  vector<int> bound_ids_;        // bound list index -> keyframe id
+  vector<int> id_to_bound_;      // keyframe id -> bound list index (-1 for deleted keyframes)
+  int pcg_gauge_keyframe_ = -1;
+  int last_pose_rounds_ = 0, last_pose_steps_ = 0, last_pcg_inner_steps_ = 0;
+};
+
+}  // namespace vis

@@ -97,6 +97,20 @@ int bahip_memcpy_2d(bahip_context* ctx, void* dst, size_t dst_pitch, const void*
                     size_t width_bytes, size_t height, int kind /* 1 = H2D, 2 = D2H, 3 = D2D */);
 int bahip_memset_2d(bahip_context* ctx, void* dst, size_t pitch, int value, size_t width_bytes, size_t height);
 
+/* Stream-level helpers used by the host-side CUDABuffer<T> (libvis/src/libvis/cuda/cuda_buffer_inl.h:
+ * UploadAsync / DownloadAsync / UploadPartAsync / DownloadPartAsync / Clear / SetTo all take the
+ * stream per call).  kind: 1 = H2D, 2 = D2H, 3 = D2D.  All asynchronous on `hip_stream`. */
+int bahip_context_set_stream(bahip_context* ctx, void* hip_stream);
+int bahip_stream_create(void** hip_stream_out);
+int bahip_stream_destroy(void* hip_stream);
+int bahip_stream_synchronize(void* hip_stream);
+int bahip_memcpy_2d_async(void* hip_stream, void* dst, size_t dst_pitch, const void* src, size_t src_pitch,
+                          size_t width_bytes, size_t height, int kind);
+int bahip_memcpy_async(void* hip_stream, void* dst, const void* src, size_t bytes, int kind);
+int bahip_memset_async(void* hip_stream, void* dst, int value, size_t bytes);
+/* CUDABuffer<T>::Clear(value, stream) (libvis/src/libvis/cuda/cuda_buffer.cu:41-60) for 1/2/4-byte T. */
+int bahip_fill_2d(void* hip_stream, void* data, size_t pitch_bytes, int elem_bytes, uint32_t value_bits, int width, int height);
+
 /* ---- keyframe preprocessing (Keyframe ctor #2, B/keyframe.cc:96-144) ------------------------- */
 /* B/cuda_image_processing.cu:165-193 ComputeBrightnessCUDA: uchar3 RGB -> uchar4 (R,G,B,luma). */
 int bahip_compute_brightness(bahip_context* ctx, const uint8_t* rgb, uint32_t rgb_pitch_bytes,
