@@ -112,6 +112,7 @@ SIGNATURES = {
     "bahip_debug_count_pairs": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.POINTER(C.c_uint64)]),
     "bahip_last_stage_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bahip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "bahip_stage_work_units": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

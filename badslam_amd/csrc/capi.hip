@@ -38,7 +38,8 @@ int fail(const char* what, const char* file, int line, hipError_t e = hipSuccess
 
 struct StageTimer {
   std::vector<hipEvent_t> ev;   // pairs (start, stop)
-  int used = 0;                 // number of pairs used by the last call
+  int used = 0;                 // number of pairs used by the last call (mode 1) / since set_profiling (mode 2)
+  long long units = 0;          // work units of those launches (stage 2: keyframes still iterating)
 };
 
 }  // namespace
@@ -84,7 +85,7 @@ struct bahip_context {
   bahip_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
 
-  bool profiling = false;
+  int profiling = 0;               // 0 off, 1 last call of each stage, 2 cumulative since bahip_set_profiling
   StageTimer timers[4];
 };
 
@@ -162,10 +163,11 @@ int ensure_px(bahip_context* ctx, size_t px, size_t scan_n) {
   return 0;
 }
 
-void timer_begin(bahip_context* ctx, int stage, bool first) {
+void timer_begin(bahip_context* ctx, int stage, bool first, int units = 1) {
   if (!ctx->profiling) return;
   StageTimer& t = ctx->timers[stage];
-  if (first) t.used = 0;
+  if (first && ctx->profiling == 1) { t.used = 0; t.units = 0; }
+  t.units += units;
   if ((int)t.ev.size() < 2 * (t.used + 1)) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -184,8 +186,9 @@ void timer_end(bahip_context* ctx, int stage) {
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, float* dev_Hb, int num_work, const SurfelsView& s, int write_back, int* rounds_out) {
   int rounds = 0;
+  int iterating = num_work;
   for (int round = 0; round < BAHIP_MAX_POSE_ITERATIONS; ++round) {
-    timer_begin(ctx, 2, round == 0);
+    timer_begin(ctx, 2, round == 0, iterating);
     launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb);
     timer_end(ctx, 2);
     CHECK_LAUNCH();
@@ -201,7 +204,8 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ++rounds;
-    if (ctx->pinned_i[0] == 0) break;
+    iterating = ctx->pinned_i[0];
+    if (iterating == 0) break;
   }
   if (rounds_out) *rounds_out = rounds;
   return 0;
@@ -910,7 +914,8 @@ int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, ui
 
 // ---- instrumentation ------------------------------------------------------------------------------------------------
 int bahip_set_profiling(bahip_context* ctx, int enabled) {
-  ctx->profiling = enabled != 0;
+  ctx->profiling = enabled;
+  for (StageTimer& t : ctx->timers) { t.used = 0; t.units = 0; }
   return 0;
 }
 
@@ -926,6 +931,12 @@ int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* 
   }
   *ms_out = total;
   if (launches_out) *launches_out = t.used;
+  return 0;
+}
+
+int bahip_stage_work_units(bahip_context* ctx, int stage, long long* units_out) {
+  REQUIRE(stage >= 0 && stage < 4 && units_out != nullptr, "stage out of range");
+  *units_out = ctx->timers[stage].units;
   return 0;
 }
 

@@ -52,6 +52,7 @@ def _load():
         L.dba_download_cfactor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dba_clear_cfactor.argtypes = [C.c_void_p, C.c_void_p]
         L.dba_set_pcg_gauge_keyframe.argtypes = [C.c_void_p, C.c_int]
+        L.dba_set_ba_iteration_counts.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.dba_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.dba_backend_context.restype = C.c_void_p
         L.dba_backend_context.argtypes = [C.c_void_p]
@@ -199,6 +200,9 @@ class DirectBA:
         out = np.zeros((h.value, w.value), np.float32)
         self.L.dba_download_cfactor(self.h, self.stream, out.ctypes.data)
         return out
+
+    def set_ba_iteration_counts(self, ba_iteration_count, last_ba_iteration_count):
+        self.L.dba_set_ba_iteration_counts(self.h, int(ba_iteration_count), int(last_ba_iteration_count))
 
     def set_pcg_gauge_keyframe(self, k):
         self.L.dba_set_pcg_gauge_keyframe(self.h, int(k))

@@ -169,6 +169,11 @@ int dba_clear_cfactor(dba_handle* h, void* stream) {
   h->ba->cfactor_buffer()->Clear(0, stream);
   return 0;
 }
+int dba_set_ba_iteration_counts(dba_handle* h, int count, int last) {
+  h->ba->SetBAIterationCount(count);
+  h->ba->SetLastBAIterationCount(last);
+  return 0;
+}
 int dba_set_pcg_gauge_keyframe(dba_handle* h, int id) {
   h->ba->SetPCGGaugeKeyframe(id);
   return 0;

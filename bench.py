@@ -4,10 +4,14 @@
 One "step" = one iteration of the alternating scheme (B/direct_ba_alternating.cc:345-718 of the
 reference): surfel activation, geometry optimisation (normals + joint position/descriptor solve)
 and pose optimisation of every keyframe, geometric + photometric residuals, fixed surfel set,
-full keyframe window.  Workload at N=1: BASELINE.json configs[2] -- synthetic 640x480, 200
-keyframes, 3 M surfels.  With --gpus N the surfels are sharded over the ranks (keyframe images
-replicated) and the per-keyframe pose normal equations are all-reduced over RCCL (strong
-scaling: the same scene, the same result).
+full keyframe window.  The timed region is ONE call of the C++ host class
+`vis::DirectBA::BundleAdjustment(min_iterations = max_iterations = steps)` -- the same call the
+reference's BadSlam::RunBundleAdjustment makes (B/bad_slam.cc:780) -- through the flat C view
+include/badslam_directba.h; Python only prepares the synthetic scene and prints the result.
+
+Workload at N=1: BASELINE.json configs[2] -- synthetic 640x480, 200 keyframes, 3 M surfels.  With
+--gpus N the surfels are sharded over the ranks (keyframe images replicated) and the per-keyframe
+pose normal equations are all-reduced over RCCL (strong scaling: the same scene, the same result).
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,6 +29,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SURFEL_ROWS = 17        # BAHIP_SURFEL_ATTRIBUTE_COUNT
+STAGES = ("surfel_activation", "geometry_optimization", "pose_accumulate", "pose_solve")
 
 
 def parse_args():
@@ -38,14 +44,14 @@ def parse_args():
     p.add_argument("--height", type=int, default=480)
     p.add_argument("--seed", type=int, default=0)
     # Scene extent: ~20 gently sloped planes about 2.5 m in front of a camera rig that moves laterally.
-    # Sized so that, at cell 2, all keyframes together create ~3.0 M surfels and every surfel is seen
-    # by ~5 keyframes (each keyframe sees ~2.5 % of the surfels).
+    # Sized so that, at cell 2, all keyframes together create ~3.0 M surfels (DESIGN.md "bench scene").
     p.add_argument("--extent-x", type=float, default=17.3, help="keyframe x positions uniform in +-extent/2 [m]")
     p.add_argument("--extent-y", type=float, default=13.0)
     p.add_argument("--extent-z", type=float, default=0.6)
     p.add_argument("--rotation-range", type=float, default=0.6, help="rotation vector components uniform in +-range/2 [rad]")
     p.add_argument("--plane-slope", type=float, default=0.05)
     p.add_argument("--cell", type=int, default=2, help="sparse_surfel_cell_size")
+    p.add_argument("--pcg", action="store_true", help="time the PCG scheme instead of the alternating one (single GPU)")
     p.add_argument("--build-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
@@ -54,64 +60,48 @@ def parse_args():
 
 def build_scene(args, log):
     """Synthetic planes scene: K keyframes rendered on the host, preprocessed and
-    turned into surfels by the HIP path itself; poses and surfels perturbed before timing."""
-    from badslam_amd import lowlevel as ll, synthetic
+    turned into surfels by the HIP path itself (Keyframe ctor + DirectBA::CreateSurfelsForKeyframe);
+    poses and surfels perturbed before timing."""
+    from badslam_amd import se3, synthetic
+    from badslam_amd.directba import DirectBA
     t0 = time.time()
     rng = np.random.Generator(np.random.PCG64(args.seed))
     cam = synthetic.test_camera(args.width, args.height)
     planes = synthetic.random_planes(rng, 20, slope=args.plane_slope)
-    from badslam_amd import se3
     T0 = se3.exp([0.01, 0.02, 0.03, 0.004, 0.005, 0.006])
     ext = np.array([args.extent_x, args.extent_y, args.extent_z])
-    # small scenes (parity configs) shrink the extent with the keyframe count so coverage stays ~5x
+    # small scenes (parity configs) shrink the extent with the keyframe count so coverage stays the same
     ext[:2] *= np.sqrt(args.keyframes / 200.0 * (args.width * args.height) / (640.0 * 480.0))
-    ctx = ll.Context()
     cells = ((args.width - 1) // args.cell + 1) * ((args.height - 1) // args.cell + 1)
     cap = args.keyframes * cells + 1024   # worst case: no overlap between keyframes (288 GB of HBM: not a concern)
-    g = ll.Scene(ctx, cap, 1.0 / 5000, 40.0, args.cell, ll.make_camera(cam, args.width, args.height),
-                 ll.make_camera(cam, args.width, args.height))
+    ba = DirectBA(cap, 1.0 / 5000, 40.0, args.cell, args.width, args.height, cam, cam)
     poses_gt = []
     for k in range(args.keyframes):
         xi = np.concatenate([ext * (rng.random(3) - 0.5), args.rotation_range * (rng.random(3) - 0.5)])
         T = se3.mul(T0, se3.exp(xi))
         raw, rgb = synthetic.render_planes(T, planes, cam, args.width, args.height, 1.0 / 5000)
-        g.add_keyframe(raw, rgb, T)
+        ba.AddKeyframe(raw, rgb, T)
         poses_gt.append(T)
     log(f"rendered + preprocessed {args.keyframes} keyframes in {time.time() - t0:.1f}s")
     t1 = time.time()
-    # surfels from the keyframes (unfiltered creation, reference B/direct_ba.cc:340-405), cycling with
-    # decreasing sparsity until the target count is reached
-    per_kf = []
+    # surfels from the keyframes (unfiltered creation, reference B/direct_ba.cc:340-405)
+    per_kf, before = [], 0
     for k in range(args.keyframes):
-        per_kf.append(g.create_surfels_for_keyframe(k, filter_new_surfels=False))
-    created = g.surfels_size
-    if g.surfels_size > args.surfels:
-        g.surfels_size = g.surfel_count = args.surfels
+        ba.CreateSurfelsForKeyframe(k, filter_new_surfels=False)
+        per_kf.append(ba.surfels_size() - before)
+        before = ba.surfels_size()
+    created = ba.surfels_size()
+    if created > args.surfels:
+        ba.SetSurfelCount(args.surfels, args.surfels)
     log(f"created {created} surfels from {args.keyframes} keyframes (min/median/max per keyframe "
-        f"{min(per_kf)}/{int(np.median(per_kf))}/{max(per_kf)}) in {time.time() - t1:.1f}s; using {g.surfels_size}")
+        f"{min(per_kf)}/{int(np.median(per_kf))}/{max(per_kf)}) in {time.time() - t1:.1f}s; using {ba.surfels_size()}")
     # perturbation: poses * exp(N(0, 5 mm / 1 mrad)); surfels + U(0, 5 mm) along z (SURVEY 8d)
     prng = np.random.Generator(np.random.PCG64(args.seed + 1))
     for k in range(args.keyframes):
-        g.keyframes[k]["pose"] = np.asarray(synthetic.perturb_pose(prng, poses_gt[k]), np.float32)
-    data = g.download_surfels()
+        ba.set_keyframe_pose(k, synthetic.perturb_pose(prng, poses_gt[k]))
+    data = ba.download_surfels(rows=SURFEL_ROWS)
     data[2] += prng.uniform(0, 0.005, data.shape[1]).astype(np.float32)
-    return ctx, g, data, poses_gt
-
-
-def ba_iteration(g, stats):
-    """One alternating-scheme iteration on the bound scene (fixed keyframe window: every keyframe
-    is kActive at the start of each iteration, B/direct_ba_alternating.cc:354-372)."""
-    from badslam_amd import capi
-    for kf in g.keyframes:
-        kf["activation"] = capi.KF_ACTIVE
-    g.bind_keyframes()
-    g.update_surfel_activation()
-    g.optimize_geometry_iteration(True, True)
-    poses, its, conv, rounds = g.estimate_keyframe_poses(True, True)
-    for k, kf in enumerate(g.keyframes):
-        kf["pose"] = poses[k].astype(np.float32)
-    stats["rounds"].append(rounds)
-    stats["gn_steps"].append(int(its.sum()))
+    return ba, data, poses_gt
 
 
 def cpu_baseline(args, log):
@@ -153,38 +143,38 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    from badslam_amd import capi
-    ctx, g, data, poses_gt = build_scene(args, log)
+    from badslam_amd import capi, multigpu
+    ba, data, poses_gt = build_scene(args, log)
     N_total = data.shape[1]
     if args.build_only:
         return
     # surfel sharding: rank r owns a contiguous slice (keyframe images replicated on every rank)
-    lo, hi = (N_total * rank) // world, (N_total * (rank + 1)) // world
-    g.upload_surfels(data[:, lo:hi], np.zeros(hi - lo, np.uint8))
+    lo, hi = multigpu.shard_range(N_total, rank, world)
+    ba.upload_surfels(data[:, lo:hi])
+    ctx = ba.backend_context()
     hook_keepalive = None
     if world > 1:
-        from badslam_amd import multigpu
         hook_keepalive = multigpu.install_allreduce(ctx, dist)
-    capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 1))
+    K = args.keyframes
 
-    stats = dict(rounds=[], gn_steps=[])
-    for _ in range(args.warmup):
-        ba_iteration(g, stats)
+    def run(iterations):
+        # BA iteration counters equal -> BundleAdjustment skips PerformBASchemeEndTasks (fixed surfel set)
+        ba.set_ba_iteration_counts(1, 1)
+        done, _ = ba.BundleAdjustment(optimize_depth_intrinsics=False, optimize_color_intrinsics=False, do_surfel_updates=False,
+                                      optimize_poses=True, optimize_geometry=True, min_iterations=iterations,
+                                      max_iterations=iterations, use_pcg=args.pcg, active_keyframe_window_start=0,
+                                      active_keyframe_window_end=K - 1, increase_ba_iteration_count=False)
+        assert done == iterations, (done, iterations)
+
+    if args.warmup > 0:
+        run(args.warmup)
+    capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 2))   # cumulative hipEvent timing of every launch below
     ctx.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    stats = dict(rounds=[], gn_steps=[])
-    stage_ms = np.zeros(4)
-    stage_launches = np.zeros(4, dtype=np.int64)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ba_iteration(g, stats)
-        for s in range(4):
-            ms, n = C.c_float(), C.c_int()
-            capi.check(ctx.lib.bahip_last_stage_time_ms(ctx.handle, s, C.byref(ms), C.byref(n)))
-            stage_ms[s] += ms.value
-            stage_launches[s] += n.value
+    run(args.steps)
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -194,18 +184,19 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    stats = ba.last_stats()
+    stage_ms = np.zeros(4)
+    stage_launches = np.zeros(4, dtype=np.int64)
+    for s in range(4):
+        ms, n = C.c_float(), C.c_int()
+        capi.check(ctx.lib.bahip_last_stage_time_ms(ctx.handle, s, C.byref(ms), C.byref(n)))
+        stage_ms[s], stage_launches[s] = ms.value, n.value
+    units = C.c_longlong()
+    capi.check(ctx.lib.bahip_stage_work_units(ctx.handle, 2, C.byref(units)))
 
     if rank == 0:
-        K, W, H = args.keyframes, args.width, args.height
-        R = float(np.mean(stats["rounds"]))
-        Rbar = float(np.sum(stats["gn_steps"])) / (len(stats["gn_steps"]) * K)
-        # algorithmic bytes: per pose-accumulate launch = one GN round over all keyframes
-        # still iterating; charge the full K (upper bound on compulsory traffic per launch)
-        bytes_pose_launch = N_total / world * 28 + K * W * H * 5
-        launches = max(1, int(stage_launches[2]))
-        avg_ms = stage_ms[2] / launches
-        achieved = bytes_pose_launch / (avg_ms * 1e-3) / 1e9
-        b_alg_iter = N_total * (17 + 21 + 49 + 28 * R) + K * W * H * (4 + 4 + 5 + 5 * Rbar)
+        W, H = args.width, args.height
+        N_rank = hi - lo
         out = {
             "metric": "BA iterations/sec (and ms/iter) at N keyframes x M surfels, 640x480",
             "value": args.steps / elapsed,
@@ -219,26 +210,43 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"synthetic {W}x{H}, {K} keyframes, {N_total} surfels, geometry+photometric alternating BA "
-                                   f"(BASELINE configs[2])", "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
-                       "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU",
-                       "pose_gn_rounds_per_iteration": R, "pose_gn_steps_per_keyframe": Rbar},
-            "stage_ms_per_iteration": {"surfel_activation": stage_ms[0] / args.steps, "geometry_optimization": stage_ms[1] / args.steps,
-                                       "pose_accumulate": stage_ms[2] / args.steps, "pose_solve": stage_ms[3] / args.steps},
-            "algorithmic_bytes_per_iteration": b_alg_iter,
-            "iteration_fraction_of_hbm_roofline": b_alg_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
-            "roofline": {"bound": "hbm", "kernel": "pose_accumulate_kernel<true,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": bytes_pose_launch, "avg_launch_ms": avg_ms, "launches": launches},
+            "config": {"workload": f"synthetic {W}x{H}, {K} keyframes, {N_total} surfels, geometry+photometric "
+                                   f"{'PCG' if args.pcg else 'alternating'} BA (BASELINE configs[2])",
+                       "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
+                       "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
+                       "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU"},
+            "stage_ms_per_iteration": {STAGES[s]: stage_ms[s] / args.steps for s in range(4)},
         }
+        if not args.pcg:
+            R = stats["pose_rounds"] / args.steps
+            Rbar = stats["pose_steps"] / (args.steps * K)
+            launches = max(1, int(stage_launches[2]))
+            # algorithmic bytes of one pose-accumulate launch (DESIGN.md "pose_accumulate"): this rank's surfel
+            # positions / normals / descriptors once (28 B) + the depth, normal and luma texels (5 B/pixel) of the
+            # keyframes still iterating in that Gauss-Newton round, averaged over the timed launches
+            kf_per_launch = units.value / launches
+            bytes_pose_launch = N_rank * 28 + kf_per_launch * W * H * 5
+            avg_ms = stage_ms[2] / launches
+            achieved = bytes_pose_launch / (avg_ms * 1e-3) / 1e9
+            b_alg_iter = N_total * (17 + 21 + 49 + 28 * R) + K * W * H * (4 + 4 + 5 + 5 * Rbar)
+            out["config"].update({"pose_gn_rounds_per_iteration": R, "pose_gn_steps_per_keyframe": Rbar})
+            out["algorithmic_bytes_per_iteration"] = b_alg_iter
+            out["iteration_fraction_of_hbm_roofline"] = b_alg_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9)
+            out["roofline"] = {"bound": "hbm", "kernel": "pose_accumulate_kernel<true,true>", "achieved": achieved,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": bytes_pose_launch, "avg_launch_ms": avg_ms, "launches": launches,
+                               "keyframes_per_launch": kf_per_launch}
+        else:
+            out["config"]["pcg_inner_steps_per_iteration"] = stats["pcg_inner_steps"] / args.steps
         if not args.no_cpu_baseline:
             cb = cpu_baseline(args, log)
+            sweeps = 3 + (stats["pose_rounds"] / args.steps if not args.pcg else 3)
             out["cpu_baseline"] = {"value": cb["pairs_per_s"], "unit": "surfel-keyframe pairs/s (full cost evaluation)",
                                    "cores": cb["cores"], "kind": "port",
                                    "sample": f"oracle cost evaluation, {cb['K']} keyframes x {cb['N']} surfels {W}x{H}, "
                                              f"{cb['seconds_per_eval']:.2f} s per evaluation; one BA iteration at the bench "
-                                             f"size needs >= {(3 + R):.1f} such sweeps over {K}x{N_total} pairs",
-                                   "equivalent_ba_iterations_per_s": cb["pairs_per_s"] / ((3 + R) * K * N_total)}
+                                             f"size needs >= {sweeps:.1f} such sweeps over {K}x{N_total} pairs",
+                                   "equivalent_ba_iterations_per_s": cb["pairs_per_s"] / (sweeps * K * N_total)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
