@@ -94,6 +94,7 @@ struct Intrinsics {
   // DepthParameters
   float a, raw_to_float_depth, baseline_fx;
   int cell;
+  int cell_shift;   // log2(cell) if cell is a power of two, else -1 (host-side hint: shifts instead of integer division)
   const float* cfactor;
   uint32_t cfactor_pitch;
   int cf_width, cf_height;
@@ -171,6 +172,8 @@ __device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor,
   return 1.f / (inv_depth + cfactor * expf(-a * inv_depth));
 }
 __device__ __forceinline__ float cfactor_at(const Intrinsics& in, int px, int py) {
+  // px, py >= 0, so the shift is the same integer division
+  if (in.cell_shift >= 0) return pitched_load(in.cfactor, in.cfactor_pitch, py >> in.cell_shift, px >> in.cell_shift);
   return pitched_load(in.cfactor, in.cfactor_pitch, py / in.cell, px / in.cell);
 }
 __device__ __forceinline__ float unp_nx(const Intrinsics& in, float px) { return in.fx_inv * px + in.cx_inv; }
@@ -269,6 +272,44 @@ __device__ __forceinline__ float sample_luma(const uint8_t* color, uint32_t pitc
   const float bot = bl + a * (br - bl);
   return top + b * (bot - top);
 }
+// Bilinear luma AND the gradient sample of point_gradient at the same point.  Away from the image border both use
+// the same four texels (floor(x - 0.5) == trunc(max(0, x - 0.5))); they are fetched once and the arithmetic of
+// sample_luma / point_gradient is applied unchanged.  At the border the footprints differ and the gradient texels
+// are fetched separately, so the results are those of the two separate functions in every case.
+__device__ __forceinline__ void sample_luma_and_gradient(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y,
+                                                         float* value, float* dx, float* dy) {
+  float xb = x - 0.5f, yb = y - 0.5f;
+  if (!(xb >= -1.f)) xb = -1.f;
+  if (xb > (float)w) xb = (float)w;
+  if (!(yb >= -1.f)) yb = -1.f;
+  if (yb > (float)h) yb = (float)h;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = xb - fx, b = yb - fy;
+  const int ix = (int)fx, iy = (int)fy;
+  float tl = luma_texel(color, pitch, w, h, ix, iy);
+  float tr = luma_texel(color, pitch, w, h, ix + 1, iy);
+  float bl = luma_texel(color, pitch, w, h, ix, iy + 1);
+  float br = luma_texel(color, pitch, w, h, ix + 1, iy + 1);
+  const float top = tl + a * (tr - tl);
+  const float bot = bl + a * (br - bl);
+  *value = top + b * (bot - top);
+
+  float mx = fmaxf(0.f, x - 0.5f), my = fmaxf(0.f, y - 0.5f);
+  if (!(mx < (float)w)) mx = (float)w;
+  if (!(my < (float)h)) my = (float)h;
+  const int gx = (int)mx, gy = (int)my;
+  const float tx = fmaxf(0.f, fminf(1.f, x - 0.5f - gx));
+  const float ty = fmaxf(0.f, fminf(1.f, y - 0.5f - gy));
+  if (gx != ix || gy != iy) {
+    tl = luma_texel(color, pitch, w, h, gx, gy);
+    tr = luma_texel(color, pitch, w, h, gx + 1, gy);
+    bl = luma_texel(color, pitch, w, h, gx, gy + 1);
+    br = luma_texel(color, pitch, w, h, gx + 1, gy + 1);
+  }
+  *dx = (br - bl) * ty + (tr - tl) * (1 - ty);
+  *dy = (br - tr) * tx + (bl - tl) * (1 - tx);
+}
+
 // One sample point of DescriptorJacobianWrtProjectedPosition (B/cost_function.cuh:200-211).
 __device__ __forceinline__ void point_gradient(const uint8_t* color, uint32_t pitch, int w, int h, float qx, float qy,
                                                float* dx, float* dy) {
@@ -293,19 +334,31 @@ __device__ __forceinline__ bool depth_to_color_pixel(const Intrinsics& in, float
   return *cx >= 0 && *cy >= 0 && (int)(*cx) < in.cwidth && (int)(*cy) < in.cheight;
 }
 
-// B/cost_function.cuh:115-136
-__device__ __forceinline__ void tangent_projections(const Intrinsics& in, const float* F, Vec3 gp, Vec3 gn, float radius_sq,
-                                                    float* t1x, float* t1y, float* t2x, float* t2y) {
+// B/cost_function.cuh:115-136.  The two tangent sample points gp + t1, gp + t2 depend on the surfel only, so the hot
+// kernels compute them once per surfel (surfel_tangent_points) and project them per keyframe (project_tangents).
+struct TangentPoints { Vec3 q1, q2; };
+__device__ __forceinline__ TangentPoints surfel_tangent_points(Vec3 gp, Vec3 gn, float radius_sq) {
   Vec3 t1 = cross3(gn, (fabsf(gn.x) > 0.9f) ? mk3(0, 1, 0) : mk3(1, 0, 0));
   t1 = (2.0f * sqrtf(radius_sq / fmaxf(1e-12f, sqlen3(t1)))) * t1;
-  const Vec3 l1 = transform34(F, gp + t1);
-  *t1x = in.cfx * (l1.x / l1.z) + in.ccx;
-  *t1y = in.cfy * (l1.y / l1.z) + in.ccy;
   Vec3 t2 = cross3(gn, t1);
   t2 = (2.0f * sqrtf(radius_sq / fmaxf(1e-12f, sqlen3(t2)))) * t2;
-  const Vec3 l2 = transform34(F, gp + t2);
+  TangentPoints tp;
+  tp.q1 = gp + t1;
+  tp.q2 = gp + t2;
+  return tp;
+}
+__device__ __forceinline__ void project_tangents(const Intrinsics& in, const float* F, const TangentPoints& tp,
+                                                 float* t1x, float* t1y, float* t2x, float* t2y) {
+  const Vec3 l1 = transform34(F, tp.q1);
+  *t1x = in.cfx * (l1.x / l1.z) + in.ccx;
+  *t1y = in.cfy * (l1.y / l1.z) + in.ccy;
+  const Vec3 l2 = transform34(F, tp.q2);
   *t2x = in.cfx * (l2.x / l2.z) + in.ccx;
   *t2y = in.cfy * (l2.y / l2.z) + in.ccy;
+}
+__device__ __forceinline__ void tangent_projections(const Intrinsics& in, const float* F, Vec3 gp, Vec3 gn, float radius_sq,
+                                                    float* t1x, float* t1y, float* t2x, float* t2y) {
+  project_tangents(in, F, surfel_tangent_points(gp, gn, radius_sq), t1x, t1y, t2x, t2y);
 }
 
 // Descriptor residuals (B/cost_function.cuh:140-156) and gradients (:191-254) of one pair.
@@ -315,26 +368,34 @@ struct DescEval {
 };
 template <bool kWithGradient>
 __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint8_t* color, uint32_t pitch, const float* F,
-                                                Vec3 gp, Vec3 gn, float radius_sq, float cx, float cy, float d1, float d2,
-                                                DescEval* e) {
+                                                const TangentPoints& tp, float cx, float cy, float d1, float d2, DescEval* e) {
   float t1x, t1y, t2x, t2y;
-  tangent_projections(in, F, gp, gn, radius_sq, &t1x, &t1y, &t2x, &t2y);
+  project_tangents(in, F, tp, &t1x, &t1y, &t2x, &t2y);
   const int w = in.cwidth, h = in.cheight;
-  const float i0 = sample_luma(color, pitch, w, h, cx, cy);
-  const float i1 = sample_luma(color, pitch, w, h, t1x, t1y);
-  const float i2 = sample_luma(color, pitch, w, h, t2x, t2y);
-  e->r1 = (180.f * (i1 - i0)) - d1;
-  e->r2 = (180.f * (i2 - i0)) - d2;
   if (kWithGradient) {
-    float cdx, cdy, adx, ady, bdx, bdy;
-    point_gradient(color, pitch, w, h, cx, cy, &cdx, &cdy);
-    point_gradient(color, pitch, w, h, t1x, t1y, &adx, &ady);
-    point_gradient(color, pitch, w, h, t2x, t2y, &bdx, &bdy);
+    float i0, i1, i2, cdx, cdy, adx, ady, bdx, bdy;
+    sample_luma_and_gradient(color, pitch, w, h, cx, cy, &i0, &cdx, &cdy);
+    sample_luma_and_gradient(color, pitch, w, h, t1x, t1y, &i1, &adx, &ady);
+    sample_luma_and_gradient(color, pitch, w, h, t2x, t2y, &i2, &bdx, &bdy);
+    e->r1 = (180.f * (i1 - i0)) - d1;
+    e->r2 = (180.f * (i2 - i0)) - d2;
     e->gx1 = 180.f * (adx - cdx);
     e->gy1 = 180.f * (ady - cdy);
     e->gx2 = 180.f * (bdx - cdx);
     e->gy2 = 180.f * (bdy - cdy);
+  } else {
+    const float i0 = sample_luma(color, pitch, w, h, cx, cy);
+    const float i1 = sample_luma(color, pitch, w, h, t1x, t1y);
+    const float i2 = sample_luma(color, pitch, w, h, t2x, t2y);
+    e->r1 = (180.f * (i1 - i0)) - d1;
+    e->r2 = (180.f * (i2 - i0)) - d2;
   }
+}
+template <bool kWithGradient>
+__device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint8_t* color, uint32_t pitch, const float* F,
+                                                Vec3 gp, Vec3 gn, float radius_sq, float cx, float cy, float d1, float d2,
+                                                DescEval* e) {
+  eval_descriptor<kWithGradient>(in, color, pitch, F, surfel_tangent_points(gp, gn, radius_sq), cx, cy, d1, d2, e);
 }
 
 // ---- surfel loads ----------------------------------------------------------------------------------
@@ -345,15 +406,6 @@ __device__ __forceinline__ Vec3 surfel_normal(const SurfelsView& s, uint32_t i) 
   return unpack_normal10(reinterpret_cast<const uint32_t*>(s.row(kSurfelNormal))[i]);
 }
 
-// ---- wave64 reductions -----------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-  v += __shfl_xor(v, 32);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
-}
-
 }  // namespace bahip
+
+#include "wave_reduce.h"   // wave_sum, wave_reduce28

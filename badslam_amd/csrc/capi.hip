@@ -110,6 +110,8 @@ Intrinsics make_intrinsics(const bahip_camera& cc, const bahip_camera& dc, const
   in.d2c_cy = -1 * cc.fy * dc.cy / dc.fy + cc.cy;
   in.a = dp.a; in.raw_to_float_depth = dp.raw_to_float_depth; in.baseline_fx = dp.baseline_fx;
   in.cell = dp.sparse_surfel_cell_size;
+  in.cell_shift = -1;
+  if (in.cell > 0 && (in.cell & (in.cell - 1)) == 0) { in.cell_shift = 0; while ((1 << in.cell_shift) < in.cell) ++in.cell_shift; }
   in.cfactor = dp.cfactor; in.cfactor_pitch = dp.cfactor_pitch_bytes;
   in.cf_width = dp.cfactor_width; in.cf_height = dp.cfactor_height;
   return in;
@@ -896,6 +898,20 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
   REQUIRE(which >= 0 && which < 5 && offset + count <= ctx->pcg_capacity, "PCG vector range out of bounds");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out_host, ctx->pcg_buf + (size_t)which * ctx->pcg_capacity + offset, sizeof(float) * count, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56) {
+  float *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_in, 64 * 28 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out, 56 * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(d_in, in_64x28, 64 * 28 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(d_out, 0xff, 56 * sizeof(float), ctx->stream));
+  launch_wave_reduce_debug(ctx->stream, d_in, d_out);
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(out_56, d_out, 56 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  hipFree(d_in); hipFree(d_out);
   return 0;
 }
 

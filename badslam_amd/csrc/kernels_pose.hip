@@ -16,10 +16,26 @@
 #include "ba_launch.h"
 #include "se3_device.h"
 #include "wave_cull.h"
+#include "wave_reduce.h"
 
 namespace bahip {
 
 constexpr int kPoseBlock = 256;
+
+// acc += w * [upper(J J^T) | r J].  The totals are merged across wavefronts with float atomics in arbitrary order, so
+// nothing downstream depends on the rounding of these partial sums: fused multiply-adds are used.
+__device__ __forceinline__ void accumulate_jtj(float (&acc)[28], const float (&J)[6], float wgt, float raw) {
+  int q = 0;
+#pragma unroll
+  for (int row = 0; row < 6; ++row) {
+    const float wj = wgt * J[row];
+#pragma unroll
+    for (int col = row; col < 6; ++col, ++q) acc[q] = __builtin_fmaf(wj, J[col], acc[q]);
+  }
+  const float wr = wgt * raw;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) acc[21 + c] = __builtin_fmaf(wr, J[c], acc[21 + c]);
+}
 
 template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(kPoseBlock)
@@ -36,7 +52,9 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     d1 = s.row(kSurfelDescriptor1)[ii];
     d2 = s.row(kSurfelDescriptor2)[ii];
   }
+  const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);
   const int lane = threadIdx.x & 63;
+  const int slot = wave_reduce28_slot(lane);
 
   // Only the work items whose frustum can contain this wavefront's surfels are visited (wave_cull.h).
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
@@ -51,9 +69,9 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
                                                               kf.normals_pitch, gp, gn, &r, nullptr);
     if (!__any(visible)) return;
 
-    float acc[27];
+    float acc[28];   // 21 H + 6 b + 1 pad (kHbStride)
 #pragma unroll
-    for (int q = 0; q < 27; ++q) acc[q] = 0.f;
+    for (int q = 0; q < 28; ++q) acc[q] = 0.f;
 
     if (visible) {
       float J[6];
@@ -69,21 +87,14 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
         J[4] = inv_std * (r.nl.x * u.z - r.nl.z * u.x);
         J[5] = inv_std * (-r.nl.x * u.y + r.nl.y * u.x);
         const float wgt = depth_residual_weight(raw);
-        int q = 0;
-#pragma unroll
-        for (int row = 0; row < 6; ++row)
-#pragma unroll
-          for (int col = row; col < 6; ++col) acc[q++] += wgt * J[row] * J[col];
-        const float wr = wgt * raw;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) acc[21 + c] += wr * J[c];
+        accumulate_jtj(acc, J, wgt, raw);
       }
       if (kUseDesc) {
         float cx, cy;
         // B/kernel_opt_pose.cu:303-353: nothing is added when the colour-pixel transform fails.
         if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
           DescEval e;
-          eval_descriptor<true>(in, kf.color, kf.color_pitch, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
+          eval_descriptor<true>(in, kf.color, kf.color_pitch, F, tp, cx, cy, d1, d2, &e);
           // B/kernel_opt_pose.cu:96-142
           const Vec3 ls = r.local;
           const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
@@ -99,27 +110,15 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
             J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
             J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
             const float wgt = descriptor_residual_weight(raw);
-            int q = 0;
-#pragma unroll
-            for (int row = 0; row < 6; ++row)
-#pragma unroll
-              for (int col = row; col < 6; ++col) acc[q++] += wgt * J[row] * J[col];
-            const float wr = wgt * raw;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[21 + c] += wr * J[c];
+            accumulate_jtj(acc, J, wgt, raw);
           }
         }
       }
     }
 
-    // wave64 reduction, then one atomic per scalar per wave
-    float mine = 0.f;
-#pragma unroll
-    for (int q = 0; q < 27; ++q) {
-      const float v = wave_sum(acc[q]);
-      if (lane == q) mine = v;
-    }
-    if (lane < 27) unsafeAtomicAdd(&Hb[(size_t)w * kHbStride + lane], mine);
+    // wave64 halving reduction (wave_reduce.h), then one atomic per scalar per wave
+    const float mine = wave_reduce28(acc, lane);
+    if (slot >= 0 && slot < 27) unsafeAtomicAdd(&Hb[(size_t)w * kHbStride + slot], mine);
   });
 }
 
@@ -303,5 +302,24 @@ __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView 
 void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
                            const uint32_t* indices, int count, float* out) {
   if (count) hipLaunchKernelGGL(evaluate_pairs_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, in, frame, s, indices, count, out);
+}
+// Debug: one wave64; in = 64 x 28 floats (lane-major).  out[0..27] = wave_reduce28 totals scattered by slot,
+// out[28..55] = wave_sum of every column (what lane 17 receives; every lane holds the same value).
+__global__ void wave_reduce_debug_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float acc[28];
+#pragma unroll
+  for (int q = 0; q < 28; ++q) acc[q] = in[lane * 28 + q];
+  const float mine = wave_reduce28(acc, lane);
+  const int slot = wave_reduce28_slot(lane);
+  if (slot >= 0) out[slot] = mine;
+#pragma unroll
+  for (int q = 0; q < 28; ++q) {
+    const float v = wave_sum(acc[q]);
+    if (lane == 17) out[28 + q] = v;
+  }
+}
+void launch_wave_reduce_debug(hipStream_t stream, const float* in, float* out) {
+  hipLaunchKernelGGL(wave_reduce_debug_kernel, dim3(1), dim3(64), 0, stream, in, out);
 }
 }  // namespace bahip

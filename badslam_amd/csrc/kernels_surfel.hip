@@ -131,6 +131,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   const float radius_sq = s.row(kSurfelRadiusSquared)[ii];
   const float d1 = s.row(kSurfelDescriptor1)[ii];
   const float d2 = s.row(kSurfelDescriptor2)[ii];
+  const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);
   float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
   for_each_candidate(num_kfs, cand, [&](int k) {
     if (!live) return;
@@ -150,7 +151,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
     float cx, cy;
     if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
       DescEval e;
-      eval_descriptor<true>(in, kfs[k].color, kfs[k].color_pitch, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
+      eval_descriptor<true>(in, kfs[k].color, kfs[k].color_pitch, F, tp, cx, cy, d1, d2, &e);
       const float term1 = -in.cfx * (r.nl.x * r.local.z - r.nl.z * r.local.x);
       const float term2 = -in.cfy * (r.nl.y * r.local.z - r.nl.z * r.local.y);
       const float term3 = 1.f / (r.local.z * r.local.z);

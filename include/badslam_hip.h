@@ -233,6 +233,9 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
 /* Work census of one sweep of the bound keyframes over the surfels: counts[0] = (wavefront, keyframe)
  * candidates left by frustum culling, [1] = of those with >= 1 association, [2] = associated
  * (surfel, keyframe) pairs, [3] = pairs projecting into the image. */
+/* One wavefront: in = 64 lanes x 28 floats; out[0..27] = totals from the halving reduction used by the pose kernel
+ * (wave_reduce.h), out[28..55] = the same totals from the xor-butterfly wave_sum. */
+int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56);
 int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out);
 
 /* ---- instrumentation ---------------------------------------------------------------------------- */

@@ -129,3 +129,27 @@ def test_batched_pose_estimation_matches_oracle(scene):
         assert np.linalg.norm(gt_err[:3]) < 1e-3
         assert conv[k] == int(conv_ref)
     assert rounds == its.max()
+
+
+def test_wave_reductions():
+    """wave_reduce.h in isolation: the halving reduction (permlane swaps + DPP) returns the 28
+    column totals; the xor-butterfly wave_sum returns exactly the classic pairing's rounding."""
+    import ctypes as C
+    from badslam_amd import capi, lowlevel
+    ctx = lowlevel.Context()
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        # integers first (any summation order is exact), then floats
+        x = rng.integers(-1000, 1000, (64, 28)).astype(np.float32) if trial == 0 else rng.standard_normal((64, 28)).astype(np.float32)
+        out = np.zeros(56, np.float32)
+        capi.check(ctx.lib.bahip_debug_wave_reduce(ctx.handle, x.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   out.ctypes.data_as(C.POINTER(C.c_float))))
+        exact = x.astype(np.float64).sum(0)
+        if trial == 0:
+            assert np.array_equal(out[:28], exact) and np.array_equal(out[28:], exact)
+        else:
+            assert np.abs(out[:28] - exact).max() < 2e-5
+            v = x.copy()   # classic butterfly, binary32: xor 32, 16, 8, 4, 2, 1
+            for s in (32, 16, 8, 4, 2, 1):
+                v = v + v[np.arange(64) ^ s]
+            assert np.array_equal(out[28:], v[17])
