@@ -37,7 +37,8 @@ class Frame(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("depth_pitch_bytes", C.c_uint32),
                 ("normals", C.c_void_p), ("normals_pitch_bytes", C.c_uint32),
                 ("radius", C.c_void_p), ("radius_pitch_bytes", C.c_uint32),
-                ("color", C.c_void_p), ("color_pitch_bytes", C.c_uint32)]
+                ("color", C.c_void_p), ("color_pitch_bytes", C.c_uint32),
+                ("planes", C.c_void_p)]   # NULL: the library packs the BA planes itself
 
 
 class Keyframe(C.Structure):
@@ -113,6 +114,9 @@ SIGNATURES = {
     "bahip_debug_wave_reduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bahip_last_stage_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "bahip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "bahip_frame_planes_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bahip_frame_planes_update": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Frame)]),
+    "bahip_frame_planes_destroy": (None, [C.c_void_p]),
     "bahip_stage_work_units": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
 }
 

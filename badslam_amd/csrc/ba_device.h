@@ -7,6 +7,13 @@
 //   B/surfel_projection_nvcc_only.cuh:48-127,302-511.
 // gfx950 has no texture sampling path (tex2D is unavailable), so the bilinear, clamp-addressed,
 // normalised-float colour fetch of B/keyframe.cc:67-73 is done in software on the luma byte.
+//
+// The sweeps do not read the keyframe images in the reference's pitch-linear layout but two derived
+// "BA planes" per keyframe (kernels_preprocess.hip: pack_*_kernel), both made of 8x4-pixel tiles of
+// 32-bit words so that one 128-byte line holds a compact pixel block:
+//   geom   word(x, y) = raw depth u16 | packed normal u16 << 16            (one load per association test)
+//   lumafp word(ix+1, iy+1) = the 2x2 clamp-addressed luma footprint whose top-left texel is (ix, iy),
+//          ix in [-1, W], iy in [-1, H]: tl | tr << 8 | bl << 16 | br << 24 (one load per bilinear sample)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -53,6 +60,8 @@ struct KfEntry {
   const uint16_t* normals;
   const uint16_t* radius;
   const uint8_t* color;
+  const uint32_t* geom;      // tiled depth | normal words (BA plane)
+  const uint32_t* lumafp;    // tiled 2x2 luma footprints (BA plane)
   uint32_t depth_pitch, normals_pitch, radius_pitch, color_pitch;
   KfPose pose;
   float global_T_frame[7];   // Sophus layout: qx qy qz qw tx ty tz
@@ -95,6 +104,7 @@ struct Intrinsics {
   float a, raw_to_float_depth, baseline_fx;
   int cell;
   int cell_shift;   // log2(cell) if cell is a power of two, else -1 (host-side hint: shifts instead of integer division)
+  uint32_t geom_tpr, fp_tpr;   // tiles per row of the geom / lumafp planes
   const float* cfactor;
   uint32_t cfactor_pitch;
   int cf_width, cf_height;
@@ -115,6 +125,14 @@ __device__ __forceinline__ T pitched_load(const T* base, uint32_t pitch, int y, 
 template <typename T>
 __device__ __forceinline__ T* pitched_ptr(T* base, uint32_t pitch, int y, int x) {
   return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T));
+}
+
+// ---- BA planes: 8x4-pixel tiles of 32-bit words, one tile = one 128-byte line ------------------------------
+constexpr uint32_t kPlaneTileW = 8, kPlaneTileH = 4;
+__host__ __device__ __forceinline__ uint32_t plane_tiles_x(uint32_t width) { return (width + kPlaneTileW - 1) / kPlaneTileW; }
+__host__ __device__ __forceinline__ uint32_t plane_tiles_y(uint32_t height) { return (height + kPlaneTileH - 1) / kPlaneTileH; }
+__device__ __forceinline__ uint32_t plane_index(uint32_t x, uint32_t y, uint32_t tiles_per_row) {
+  return ((((y >> 2) * tiles_per_row) + (x >> 3)) << 5) | ((y & 3u) << 3) | (x & 7u);
 }
 
 // ---- packing (B/util.cuh:121-153, B/util_nvcc_only.cuh:66-95) ------------------------------------
@@ -214,10 +232,8 @@ struct Assoc {
 // rejection tests is the reference's.  A NaN position (deleted surfel) is rejected explicitly.
 // `gp`, `gn`: global position and (decoded, renormalised) global normal of the surfel.
 template <bool kFreeSpace>
-__device__ __forceinline__ bool project_associate(const Intrinsics& in, const float* F, const uint16_t* depth_img,
-                                                  uint32_t depth_pitch, const uint16_t* normals_img,
-                                                  uint32_t normals_pitch, Vec3 gp, Vec3 gn, Assoc* r,
-                                                  bool* free_space_violation) {
+__device__ __forceinline__ bool project_associate(const Intrinsics& in, const float* F, const uint32_t* __restrict__ geom,
+                                                  Vec3 gp, Vec3 gn, Assoc* r, bool* free_space_violation) {
   r->local.z = F[8] * gp.x + F[9] * gp.y + F[10] * gp.z + F[11];
   if (!(r->local.z > 0.f)) return false;
   r->local.x = F[0] * gp.x + F[1] * gp.y + F[2] * gp.z + F[3];
@@ -229,7 +245,8 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   r->py = (int)r->pxy;
   if (r->px >= in.width || r->py >= in.height) return false;
 
-  const uint16_t measured = pitched_load(depth_img, depth_pitch, r->py, r->px);
+  const uint32_t word = geom[plane_index((uint32_t)r->px, (uint32_t)r->py, in.geom_tpr)];
+  const uint16_t measured = (uint16_t)(word & 0xffffu);
   if (measured & kInvalidDepthBit) return false;
   r->depth = raw_to_calibrated_depth(in.a, cfactor_at(in, r->px, r->py), in.raw_to_float_depth, measured);
   r->nl = rotate34(F, gn);
@@ -243,19 +260,25 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   }
   const float dist = norm3(r->local);
   if ((1.0f / dist) * dot3(r->local, r->nl) > 0) return false;
-  const Vec3 m = unpack_normal8(pitched_load(normals_img, normals_pitch, r->py, r->px));
+  const Vec3 m = unpack_normal8((uint16_t)(word >> 16));
   if (dot3(r->nl, m) < kCosNormalCompat) return false;
   return true;
 }
 
 // ---- colour sampling -------------------------------------------------------------------------------
-__device__ __forceinline__ float luma_texel(const uint8_t* color, uint32_t pitch, int w, int h, int x, int y) {
-  x = max(0, min(x, w - 1));
-  y = max(0, min(y, h - 1));
-  return (float)color[(size_t)y * pitch + 4 * x + 3] * (1.0f / 255.0f);
+// 2x2 luma footprint with top-left texel (ix, iy), ix in [-1, w], iy in [-1, h] (clamp addressing baked in).
+struct Luma4 { float tl, tr, bl, br; };
+__device__ __forceinline__ Luma4 luma_footprint(const Intrinsics& in, const uint32_t* __restrict__ lumafp, int ix, int iy) {
+  const uint32_t word = lumafp[plane_index((uint32_t)(ix + 1), (uint32_t)(iy + 1), in.fp_tpr)];
+  Luma4 t;
+  t.tl = (float)(word & 0xffu) * (1.0f / 255.0f);
+  t.tr = (float)((word >> 8) & 0xffu) * (1.0f / 255.0f);
+  t.bl = (float)((word >> 16) & 0xffu) * (1.0f / 255.0f);
+  t.br = (float)(word >> 24) * (1.0f / 255.0f);
+  return t;
 }
 // Bilinear luma at unnormalised coords, clamp addressing, texel centres at +0.5 (B/keyframe.cc:67-73).
-__device__ __forceinline__ float sample_luma(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y) {
+__device__ __forceinline__ float sample_luma(const Intrinsics& in, const uint32_t* lumafp, int w, int h, float x, float y) {
   float xb = x - 0.5f, yb = y - 0.5f;
   if (!(xb >= -1.f)) xb = -1.f;
   if (xb > (float)w) xb = (float)w;
@@ -263,20 +286,16 @@ __device__ __forceinline__ float sample_luma(const uint8_t* color, uint32_t pitc
   if (yb > (float)h) yb = (float)h;
   const float fx = floorf(xb), fy = floorf(yb);
   const float a = xb - fx, b = yb - fy;
-  const int ix = (int)fx, iy = (int)fy;
-  const float tl = luma_texel(color, pitch, w, h, ix, iy);
-  const float tr = luma_texel(color, pitch, w, h, ix + 1, iy);
-  const float bl = luma_texel(color, pitch, w, h, ix, iy + 1);
-  const float br = luma_texel(color, pitch, w, h, ix + 1, iy + 1);
-  const float top = tl + a * (tr - tl);
-  const float bot = bl + a * (br - bl);
+  const Luma4 t = luma_footprint(in, lumafp, (int)fx, (int)fy);
+  const float top = t.tl + a * (t.tr - t.tl);
+  const float bot = t.bl + a * (t.br - t.bl);
   return top + b * (bot - top);
 }
-// Bilinear luma AND the gradient sample of point_gradient at the same point.  Away from the image border both use
-// the same four texels (floor(x - 0.5) == trunc(max(0, x - 0.5))); they are fetched once and the arithmetic of
-// sample_luma / point_gradient is applied unchanged.  At the border the footprints differ and the gradient texels
-// are fetched separately, so the results are those of the two separate functions in every case.
-__device__ __forceinline__ void sample_luma_and_gradient(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y,
+// Bilinear luma AND the gradient sample of DescriptorJacobianWrtProjectedPosition (B/cost_function.cuh:200-211) at the
+// same point.  Away from the image border both use the same footprint (floor(x - 0.5) == trunc(max(0, x - 0.5))), which
+// is fetched once; at the border the gradient's footprint is fetched separately, so the results are those of the
+// reference's two separate evaluations in every case.
+__device__ __forceinline__ void sample_luma_and_gradient(const Intrinsics& in, const uint32_t* lumafp, int w, int h, float x, float y,
                                                          float* value, float* dx, float* dy) {
   float xb = x - 0.5f, yb = y - 0.5f;
   if (!(xb >= -1.f)) xb = -1.f;
@@ -286,12 +305,9 @@ __device__ __forceinline__ void sample_luma_and_gradient(const uint8_t* color, u
   const float fx = floorf(xb), fy = floorf(yb);
   const float a = xb - fx, b = yb - fy;
   const int ix = (int)fx, iy = (int)fy;
-  float tl = luma_texel(color, pitch, w, h, ix, iy);
-  float tr = luma_texel(color, pitch, w, h, ix + 1, iy);
-  float bl = luma_texel(color, pitch, w, h, ix, iy + 1);
-  float br = luma_texel(color, pitch, w, h, ix + 1, iy + 1);
-  const float top = tl + a * (tr - tl);
-  const float bot = bl + a * (br - bl);
+  Luma4 t = luma_footprint(in, lumafp, ix, iy);
+  const float top = t.tl + a * (t.tr - t.tl);
+  const float bot = t.bl + a * (t.br - t.bl);
   *value = top + b * (bot - top);
 
   float mx = fmaxf(0.f, x - 0.5f), my = fmaxf(0.f, y - 0.5f);
@@ -300,31 +316,9 @@ __device__ __forceinline__ void sample_luma_and_gradient(const uint8_t* color, u
   const int gx = (int)mx, gy = (int)my;
   const float tx = fmaxf(0.f, fminf(1.f, x - 0.5f - gx));
   const float ty = fmaxf(0.f, fminf(1.f, y - 0.5f - gy));
-  if (gx != ix || gy != iy) {
-    tl = luma_texel(color, pitch, w, h, gx, gy);
-    tr = luma_texel(color, pitch, w, h, gx + 1, gy);
-    bl = luma_texel(color, pitch, w, h, gx, gy + 1);
-    br = luma_texel(color, pitch, w, h, gx + 1, gy + 1);
-  }
-  *dx = (br - bl) * ty + (tr - tl) * (1 - ty);
-  *dy = (br - tr) * tx + (bl - tl) * (1 - tx);
-}
-
-// One sample point of DescriptorJacobianWrtProjectedPosition (B/cost_function.cuh:200-211).
-__device__ __forceinline__ void point_gradient(const uint8_t* color, uint32_t pitch, int w, int h, float qx, float qy,
-                                               float* dx, float* dy) {
-  float mx = fmaxf(0.f, qx - 0.5f), my = fmaxf(0.f, qy - 0.5f);
-  if (!(mx < (float)w)) mx = (float)w;
-  if (!(my < (float)h)) my = (float)h;
-  const int ix = (int)mx, iy = (int)my;
-  const float tx = fmaxf(0.f, fminf(1.f, qx - 0.5f - ix));
-  const float ty = fmaxf(0.f, fminf(1.f, qy - 0.5f - iy));
-  const float tl = luma_texel(color, pitch, w, h, ix, iy);
-  const float tr = luma_texel(color, pitch, w, h, ix + 1, iy);
-  const float bl = luma_texel(color, pitch, w, h, ix, iy + 1);
-  const float br = luma_texel(color, pitch, w, h, ix + 1, iy + 1);
-  *dx = (br - bl) * ty + (tr - tl) * (1 - ty);
-  *dy = (br - tr) * tx + (bl - tl) * (1 - tx);
+  if (gx != ix || gy != iy) t = luma_footprint(in, lumafp, gx, gy);
+  *dx = (t.br - t.bl) * ty + (t.tr - t.tl) * (1 - ty);
+  *dy = (t.br - t.tr) * tx + (t.bl - t.tl) * (1 - tx);
 }
 
 // B/surfel_projection.cuh:194-207
@@ -367,16 +361,16 @@ struct DescEval {
   float gx1, gy1, gx2, gy2;
 };
 template <bool kWithGradient>
-__device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint8_t* color, uint32_t pitch, const float* F,
+__device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint32_t* lumafp, const float* F,
                                                 const TangentPoints& tp, float cx, float cy, float d1, float d2, DescEval* e) {
   float t1x, t1y, t2x, t2y;
   project_tangents(in, F, tp, &t1x, &t1y, &t2x, &t2y);
   const int w = in.cwidth, h = in.cheight;
   if (kWithGradient) {
     float i0, i1, i2, cdx, cdy, adx, ady, bdx, bdy;
-    sample_luma_and_gradient(color, pitch, w, h, cx, cy, &i0, &cdx, &cdy);
-    sample_luma_and_gradient(color, pitch, w, h, t1x, t1y, &i1, &adx, &ady);
-    sample_luma_and_gradient(color, pitch, w, h, t2x, t2y, &i2, &bdx, &bdy);
+    sample_luma_and_gradient(in, lumafp, w, h, cx, cy, &i0, &cdx, &cdy);
+    sample_luma_and_gradient(in, lumafp, w, h, t1x, t1y, &i1, &adx, &ady);
+    sample_luma_and_gradient(in, lumafp, w, h, t2x, t2y, &i2, &bdx, &bdy);
     e->r1 = (180.f * (i1 - i0)) - d1;
     e->r2 = (180.f * (i2 - i0)) - d2;
     e->gx1 = 180.f * (adx - cdx);
@@ -384,18 +378,18 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
     e->gx2 = 180.f * (bdx - cdx);
     e->gy2 = 180.f * (bdy - cdy);
   } else {
-    const float i0 = sample_luma(color, pitch, w, h, cx, cy);
-    const float i1 = sample_luma(color, pitch, w, h, t1x, t1y);
-    const float i2 = sample_luma(color, pitch, w, h, t2x, t2y);
+    const float i0 = sample_luma(in, lumafp, w, h, cx, cy);
+    const float i1 = sample_luma(in, lumafp, w, h, t1x, t1y);
+    const float i2 = sample_luma(in, lumafp, w, h, t2x, t2y);
     e->r1 = (180.f * (i1 - i0)) - d1;
     e->r2 = (180.f * (i2 - i0)) - d2;
   }
 }
 template <bool kWithGradient>
-__device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint8_t* color, uint32_t pitch, const float* F,
+__device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint32_t* lumafp, const float* F,
                                                 Vec3 gp, Vec3 gn, float radius_sq, float cx, float cy, float d1, float d2,
                                                 DescEval* e) {
-  eval_descriptor<kWithGradient>(in, color, pitch, F, surfel_tangent_points(gp, gn, radius_sq), cx, cy, d1, d2, e);
+  eval_descriptor<kWithGradient>(in, lumafp, F, surfel_tangent_points(gp, gn, radius_sq), cx, cy, d1, d2, e);
 }
 
 // ---- surfel loads ----------------------------------------------------------------------------------

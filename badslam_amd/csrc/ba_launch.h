@@ -19,6 +19,8 @@ void launch_point_radii(hipStream_t stream, const Intrinsics& in, float raw_to_f
                         uint32_t depth_pitch, uint16_t* radius, uint32_t radius_pitch, uint16_t* out_depth, uint32_t out_pitch);
 void launch_min_max_depth(hipStream_t stream, const uint16_t* depth, uint32_t depth_pitch, int w, int h,
                           float raw_to_float_depth, int* result);
+void launch_pack_planes(hipStream_t stream, const KfEntry& frame, int width, int height, int cwidth, int cheight, uint32_t* geom,
+                        uint32_t* lumafp);
 
 // kernels_surfel.hip
 void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,

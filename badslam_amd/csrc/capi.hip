@@ -44,6 +44,13 @@ struct StageTimer {
 
 }  // namespace
 
+// Tiled BA planes of one frame (ba_device.h).  Opaque to the C API.
+struct bahip_frame_planes {
+  uint32_t* geom = nullptr;
+  uint32_t* lumafp = nullptr;
+  int width = 0, height = 0, cwidth = 0, cheight = 0;
+};
+
 struct bahip_context {
   hipStream_t stream = nullptr;
   bool have_intrinsics = false;
@@ -82,6 +89,10 @@ struct bahip_context {
   float* pcg_buf = nullptr;        // PCG vectors r, M, delta, g, p (5 * pcg_capacity floats) + 16 scalars
   size_t pcg_capacity = 0;
 
+  // planes packed by the library itself for frames handed over without bahip_frame.planes:
+  // slot 0 = the single frame of the per-frame entry points, slot 1 + k = bound keyframe k
+  std::vector<bahip_frame_planes*> auto_planes;
+
   bahip_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
 
@@ -114,6 +125,8 @@ Intrinsics make_intrinsics(const bahip_camera& cc, const bahip_camera& dc, const
   if (in.cell > 0 && (in.cell & (in.cell - 1)) == 0) { in.cell_shift = 0; while ((1 << in.cell_shift) < in.cell) ++in.cell_shift; }
   in.cfactor = dp.cfactor; in.cfactor_pitch = dp.cfactor_pitch_bytes;
   in.cf_width = dp.cfactor_width; in.cf_height = dp.cfactor_height;
+  in.geom_tpr = plane_tiles_x(dc.width);
+  in.fp_tpr = plane_tiles_x(cc.width + 2);
   return in;
 }
 
@@ -125,12 +138,52 @@ void fill_pose(KfEntry* e, const float* global_T_frame) {
   se3_rotation(global_T_frame, e->pose.GR);
 }
 
-KfEntry make_entry(const bahip_frame& f) {
+int planes_alloc(int width, int height, int cwidth, int cheight, bahip_frame_planes** out) {
+  bahip_frame_planes* p = new bahip_frame_planes();
+  p->width = width; p->height = height; p->cwidth = cwidth; p->cheight = cheight;
+  const size_t gwords = (size_t)plane_tiles_x(width) * plane_tiles_y(height) * 32;
+  const size_t fwords = (size_t)plane_tiles_x(cwidth + 2) * plane_tiles_y(cheight + 2) * 32;
+  if (hipMalloc(&p->geom, gwords * sizeof(uint32_t)) != hipSuccess || hipMalloc(&p->lumafp, fwords * sizeof(uint32_t)) != hipSuccess) {
+    hipFree(p->geom); hipFree(p->lumafp); delete p;
+    return fail("hipMalloc of frame planes failed", __FILE__, __LINE__);
+  }
+  *out = p;
+  return 0;
+}
+void planes_free(bahip_frame_planes* p) {
+  if (!p) return;
+  hipFree(p->geom); hipFree(p->lumafp);
+  delete p;
+}
+
+KfEntry raw_entry(const bahip_frame& f) {
   KfEntry e{};
   e.depth = f.depth; e.normals = f.normals; e.radius = f.radius; e.color = f.color;
   e.depth_pitch = f.depth_pitch_bytes; e.normals_pitch = f.normals_pitch_bytes;
   e.radius_pitch = f.radius_pitch_bytes; e.color_pitch = f.color_pitch_bytes;
   return e;
+}
+
+// Frame table entry for `f`.  The sweeps read the tiled BA planes; a caller that maintains them (Keyframe does) passes
+// them in f.planes, otherwise they are packed here, on the context stream, into library-owned planes (`slot`).
+int make_entry(bahip_context* ctx, const bahip_frame& f, size_t slot, KfEntry* out) {
+  KfEntry e = raw_entry(f);
+  const bahip_frame_planes* p = f.planes;
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics must precede any call that takes frames");
+  const int w = ctx->in.width, h = ctx->in.height, cw = ctx->in.cwidth, ch = ctx->in.cheight;
+  if (!p) {
+    if (ctx->auto_planes.size() <= slot) ctx->auto_planes.resize(slot + 1, nullptr);
+    bahip_frame_planes*& mine = ctx->auto_planes[slot];
+    if (mine && (mine->width != w || mine->height != h || mine->cwidth != cw || mine->cheight != ch)) { planes_free(mine); mine = nullptr; }
+    if (!mine && planes_alloc(w, h, cw, ch, &mine)) return 1;
+    launch_pack_planes(ctx->stream, e, w, h, cw, ch, mine->geom, mine->lumafp);
+    CHECK_LAUNCH();
+    p = mine;
+  }
+  REQUIRE(p->width == w && p->height == h && p->cwidth == cw && p->cheight == ch, "frame planes do not match the camera image sizes");
+  e.geom = p->geom; e.lumafp = p->lumafp;
+  *out = e;
+  return 0;
 }
 
 SurfelsView make_view(const bahip_surfels* s) {
@@ -251,6 +304,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf);
+  for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
   delete ctx;
 }
@@ -403,11 +457,30 @@ int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, c
   return 0;
 }
 
+int bahip_frame_planes_create(bahip_context* ctx, int depth_width, int depth_height, int color_width, int color_height,
+                              bahip_frame_planes** out) {
+  REQUIRE(ctx != nullptr && out != nullptr, "bahip_frame_planes_create: NULL argument");
+  REQUIRE(depth_width > 0 && depth_height > 0 && color_width > 0 && color_height > 0, "image sizes must be positive");
+  return planes_alloc(depth_width, depth_height, color_width, color_height, out);
+}
+
+int bahip_frame_planes_update(bahip_context* ctx, bahip_frame_planes* planes, const bahip_frame* frame) {
+  REQUIRE(planes != nullptr && frame != nullptr, "bahip_frame_planes_update: NULL argument");
+  REQUIRE(frame->depth && frame->normals && frame->color, "bahip_frame_planes_update needs depth, normals and colour");
+  launch_pack_planes(ctx->stream, raw_entry(*frame), planes->width, planes->height, planes->cwidth, planes->cheight, planes->geom,
+                     planes->lumafp);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+void bahip_frame_planes_destroy(bahip_frame_planes* planes) { planes_free(planes); }
+
 int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int num_keyframes) {
   REQUIRE(num_keyframes >= 0, "negative keyframe count");
   ctx->host_kfs.resize(num_keyframes);
   for (int k = 0; k < num_keyframes; ++k) {
-    KfEntry e = make_entry(keyframes[k].frame);
+    KfEntry e;
+    if (make_entry(ctx, keyframes[k].frame, 1 + (size_t)k, &e)) return 1;
     fill_pose(&e, keyframes[k].global_T_frame);
     e.activation = keyframes[k].activation;
     ctx->host_kfs[k] = e;
@@ -469,7 +542,8 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");   // B/kernel_opt_pose.cc:58
   REQUIRE(surfels->surfels_size > 0, "AccumulatePoseEstimationCoeffs is only intended for surfels_size > 0");  // :61
-  KfEntry e = make_entry(*frame);
+  KfEntry e;
+  if (make_entry(ctx, *frame, 0, &e)) return 1;
   PoseWork w{};
   memcpy(w.F, frame_T_global, 12 * sizeof(float));
   w.kf_index = 0;
@@ -494,7 +568,8 @@ int bahip_estimate_frame_pose(bahip_context* ctx, int use_depth, int use_desc, c
                               int* converged) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");
-  KfEntry e = make_entry(*frame);
+  KfEntry e;
+  if (make_entry(ctx, *frame, 0, &e)) return 1;
   PoseWork w{};
   memcpy(w.T, init, 7 * sizeof(float));
   float inv[7];
@@ -580,7 +655,8 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   SupportingView sup;
   REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
-  KfEntry e = make_entry(*frame);
+  KfEntry e;
+  if (make_entry(ctx, *frame, 0, &e)) return 1;
   memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
   return determine_supporting_impl(ctx, merge, merge_dist_factor, e, surfels, sup, merged_count_out);
 }
@@ -879,7 +955,8 @@ int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, con
                                const bahip_surfels* surfels, const uint32_t* surfel_indices_host, int count, float* out_host) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   if (count <= 0) return 0;
-  KfEntry e = make_entry(*frame);
+  KfEntry e;
+  if (make_entry(ctx, *frame, 0, &e)) return 1;
   memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
   uint32_t* d_idx = nullptr; float* d_out = nullptr;
   HIP_TRY(hipMalloc(&d_idx, sizeof(uint32_t) * count));

@@ -44,8 +44,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
         if (!in_range) return;
         const float* F = kfs[k].pose.F;
         Assoc r;
-        if (!project_associate<false>(in, F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals, kfs[k].normals_pitch,
-                                      gp, gn, &r, nullptr)) return;
+        if (!project_associate<false>(in, F, kfs[k].geom, gp, gn, &r, nullptr)) return;
         const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
         if (kDepth) {
           // B/kernel_opt_intrinsics.cu:81-120
@@ -88,7 +87,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
           float cx, cy;
           if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
             DescEval e;
-            eval_descriptor<true>(in, kfs[k].color, kfs[k].color_pitch, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
+            eval_descriptor<true>(in, kfs[k].lumafp, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
             // B/kernel_opt_intrinsics.cu:142-150,200-215: validity flag is "residual != 0"
 #pragma unroll
             for (int t = 0; t < 2; ++t) {

@@ -36,8 +36,7 @@ supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, Supporting
   const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
   if (i >= s.size) return;
   Assoc r;
-  if (!project_associate<false>(in, frame.pose.F, frame.depth, frame.depth_pitch, frame.normals, frame.normals_pitch,
-                                surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
+  if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
   const int cx = r.px / in.cell, cy = r.py / in.cell;
   uint32_t cur = i;
 #pragma unroll
@@ -66,8 +65,7 @@ merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView 
   if (i >= s.size) return;
   flags[i] = 0;
   Assoc r;
-  if (!project_associate<false>(in, frame.pose.F, frame.depth, frame.depth_pitch, frame.normals, frame.normals_pitch,
-                                surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
+  if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
   const int cx = r.px / in.cell, cy = r.py / in.cell;
   const uint32_t s0 = *pitched_ptr(sup.b[0], sup.pitch, cy, cx);
   const uint32_t s1 = *pitched_ptr(sup.b[1], sup.pitch, cy, cx);
@@ -243,7 +241,7 @@ create_append_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ f
   // descriptors are initialised so that both residuals are zero in the creating keyframe
   const Vec3 gn_stored = gn;  // the reference uses the unquantised normal here (B/kernel_create_surfels.cu:133-140)
   DescEval e;
-  eval_descriptor<false>(in, frame.color, frame.color_pitch, frame.pose.F, gp, gn_stored, radius_sq, cx, cy, 0.f, 0.f, &e);
+  eval_descriptor<false>(in, frame.lumafp, frame.pose.F, gp, gn_stored, radius_sq, cx, cy, 0.f, 0.f, &e);
   s.row(kSurfelDescriptor1)[si] = e.r1;
   s.row(kSurfelDescriptor2)[si] = e.r2;
 }
@@ -261,8 +259,7 @@ delete_update_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs
     for (int k = 0; k < num_kfs; ++k) {
       Assoc r;
       bool fsv = false;
-      if (project_associate<true>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
-                                  kfs[k].normals_pitch, gp, gn, &r, &fsv)) {
+      if (project_associate<true>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, &fsv)) {
         obs += 1.f;
         min_r = fminf(min_r, __half2float(__ushort_as_half(pitched_load(kfs[k].radius, kfs[k].radius_pitch, r.py, r.px))));
       } else if (fsv) {

@@ -87,7 +87,7 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
     t->color_ok = depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy);
     if (t->color_ok) {
       DescEval e;
-      eval_descriptor<true>(in, kf.color, kf.color_pitch, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
+      eval_descriptor<true>(in, kf.lumafp, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
       t->raw1 = e.r1; t->raw2 = e.r2;
       const float gx1 = e.gx1 * in.cfx, gx2 = e.gx2 * in.cfx;
       const float gy1 = e.gy1 * in.cfy, gy2 = e.gy2 * in.cfy;
@@ -144,8 +144,7 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
       [&](int k) {
         const KfEntry& kf = kfs[k];
         Assoc a;
-        bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.depth, kf.depth_pitch, kf.normals, kf.normals_pitch,
-                                                            gp, gn, &a, nullptr);
+        bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.geom, gp, gn, &a, nullptr);
         if (!__any(visible)) return;
         const bool pose_kf = L.optimize_poses && (k != L.gauge);
         float pr[6] = {0, 0, 0, 0, 0, 0}, pM[6] = {0, 0, 0, 0, 0, 0};
@@ -294,8 +293,7 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
       [&](int k) {
         const KfEntry& kf = kfs[k];
         Assoc a;
-        const bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.depth, kf.depth_pitch, kf.normals,
-                                                                  kf.normals_pitch, gp, gn, &a, nullptr);
+        const bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.geom, gp, gn, &a, nullptr);
         if (!__any(visible)) return;
         const bool pose_kf = L.optimize_poses && (k != L.gauge);
         const uint32_t base = kf_pose_index(L, k);

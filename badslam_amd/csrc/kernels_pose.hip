@@ -65,8 +65,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     const float* F = work[w].F;
     const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
     Assoc r;
-    const bool visible = in_range && project_associate<false>(in, F, kf.depth, kf.depth_pitch, kf.normals,
-                                                              kf.normals_pitch, gp, gn, &r, nullptr);
+    const bool visible = in_range && project_associate<false>(in, F, kf.geom, gp, gn, &r, nullptr);
     if (!__any(visible)) return;
 
     float acc[28];   // 21 H + 6 b + 1 pad (kHbStride)
@@ -94,7 +93,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
         // B/kernel_opt_pose.cu:303-353: nothing is added when the colour-pixel transform fails.
         if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
           DescEval e;
-          eval_descriptor<true>(in, kf.color, kf.color_pitch, F, tp, cx, cy, d1, d2, &e);
+          eval_descriptor<true>(in, kf.lumafp, F, tp, cx, cy, d1, d2, &e);
           // B/kernel_opt_pose.cu:96-142
           const Vec3 ls = r.local;
           const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
@@ -268,7 +267,7 @@ __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView 
   const Vec3 gp = surfel_position(s, i);
   const Vec3 gn = surfel_normal(s, i);
   Assoc r;
-  if (!project_associate<false>(in, F, frame.depth, frame.depth_pitch, frame.normals, frame.normals_pitch, gp, gn, &r, nullptr)) return;
+  if (!project_associate<false>(in, F, frame.geom, gp, gn, &r, nullptr)) return;
   o[0] = 1.f; o[1] = (float)r.px; o[2] = (float)r.py; o[4] = r.depth; o[34] = r.pxx; o[35] = r.pxy;
   const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
   const Vec3 u = unproject(in, r.px, r.py, r.depth);
@@ -282,7 +281,7 @@ __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView 
   if (!depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) return;
   o[3] = 1.f;
   DescEval e;
-  eval_descriptor<true>(in, frame.color, frame.color_pitch, F, gp, gn, s.row(kSurfelRadiusSquared)[i], cx, cy,
+  eval_descriptor<true>(in, frame.lumafp, F, gp, gn, s.row(kSurfelRadiusSquared)[i], cx, cy,
                         s.row(kSurfelDescriptor1)[i], s.row(kSurfelDescriptor2)[i], &e);
   o[14] = e.r1; o[15] = e.r2; o[16] = descriptor_residual_weight(e.r1); o[17] = descriptor_residual_weight(e.r2);
   o[30] = e.gx1; o[31] = e.gy1; o[32] = e.gx2; o[33] = e.gy2;

@@ -34,8 +34,7 @@ activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, S
       [&](int k) {
         if (in_range && !active) {
           Assoc r;
-          if (project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
-                                       kfs[k].normals_pitch, gp, gn, &r, nullptr)) active = true;
+          if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) active = true;
         }
       });
   if (in_range) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (active ? kSurfelActiveFlag : 0);
@@ -54,8 +53,7 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
       [&](int k) {
         if (!live) return;
         Assoc r;
-        if (project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
-                                     kfs[k].normals_pitch, gp, gn, &r, nullptr)) {
+        if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) {
           const Vec3 m = unpack_normal8(pitched_load(kfs[k].normals, kfs[k].normals_pitch, r.py, r.px));
           const Vec3 g = mul33(kfs[k].pose.GR, m);
           sx += g.x; sy += g.y; sz += g.z; count += 1.f;
@@ -106,8 +104,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
     for_each_candidate(num_kfs, cand, [&](int k) {
       if (!live) return;
       Assoc r;
-      if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals,
-                                    kfs[k].normals_pitch, gp, gn, &r, nullptr)) return;
+      if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) return;
       const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
       const float jac = -inv_std;
       const Vec3 u = unproject(in, r.px, r.py, r.depth);
@@ -137,8 +134,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
     if (!live) return;
     const float* F = kfs[k].pose.F;
     Assoc r;
-    if (!project_associate<false>(in, F, kfs[k].depth, kfs[k].depth_pitch, kfs[k].normals, kfs[k].normals_pitch,
-                                  gp, gn, &r, nullptr)) return;
+    if (!project_associate<false>(in, F, kfs[k].geom, gp, gn, &r, nullptr)) return;
     if (kUseDepth) {
       const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
       const float jac = -inv_std;
@@ -151,7 +147,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
     float cx, cy;
     if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
       DescEval e;
-      eval_descriptor<true>(in, kfs[k].color, kfs[k].color_pitch, F, tp, cx, cy, d1, d2, &e);
+      eval_descriptor<true>(in, kfs[k].lumafp, F, tp, cx, cy, d1, d2, &e);
       const float term1 = -in.cfx * (r.nl.x * r.local.z - r.nl.z * r.local.x);
       const float term2 = -in.cfy * (r.nl.y * r.local.z - r.nl.z * r.local.y);
       const float term3 = 1.f / (r.local.z * r.local.z);
@@ -242,8 +238,7 @@ count_pairs_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, 
       num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
       [&](int k) {
         Assoc r;
-        const bool hit = in_range && project_associate<false>(in, kfs[k].pose.F, kfs[k].depth, kfs[k].depth_pitch,
-                                                              kfs[k].normals, kfs[k].normals_pitch, gp, gn, &r, nullptr);
+        const bool hit = in_range && project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr);
         const Vec3 l = transform34(kfs[k].pose.F, gp);
         const float px = in.fx * (l.x / l.z) + in.cx, py = in.fy * (l.y / l.z) + in.cy;
         const bool inside = in_range && l.z > 0 && px >= 0 && py >= 0 && px < in.width && py < in.height;

@@ -86,6 +86,7 @@ int dba_upload_keyframe_image(dba_handle* h, void* stream, int id, int which, co
     case 3: const_cast<CUDABuffer<uchar4>&>(kf->color_buffer()).UploadAsync(stream, static_cast<const uchar4*>(in)); break;
     default: return 1;
   }
+  kf->RefreshPlanes(static_cast<hipStream_t>(stream));
   return 0;
 }
 int dba_delete_keyframe(dba_handle* h, int id) {

@@ -4,7 +4,10 @@
 // co-visibility list and min/max depth.  The reference additionally creates a bilinear
 // cudaTextureObject_t over the colour buffer (B/keyframe.cc:67-73); gfx950 has no such sampling
 // path, so color_texture() returns a handle to the colour buffer itself and the BA kernels filter
-// in software.
+// in software.  Next to the four images the keyframe owns their tiled "BA planes"
+// (bahip_frame_planes, include/badslam_hip.h), derived in the constructors like normals / radii /
+// luma are; code that writes into the image buffers afterwards (the reference's tests do, through
+// const_cast) must call RefreshPlanes().
 #pragma once
 
 #include "cuda_buffer.h"
@@ -56,6 +59,7 @@ class Keyframe {
     color_buffer_.SetTo(color_buffer, stream);
     activation_ = Activation::kActive;
     set_global_T_frame(global_T_frame);
+    RefreshPlanes(stream);
   }
 
   // Convenience constructor from raw depth + RGB (B/keyframe.cc:81-158): luma, normals, radii +
@@ -87,9 +91,28 @@ class Keyframe {
         (uint32_t)depth_buffer_.ToCUDA().pitch()));
     BAHIP_CHECKED_CALL(bahip_compute_min_max_depth(ctx, depth_temp.ToCUDA().address(), (uint32_t)depth_temp.ToCUDA().pitch(), W, H,
                                                    depth_params.raw_to_float_depth, &min_depth_, &max_depth_));
+    BAHIP_CHECKED_CALL(bahip_frame_planes_create(ctx, W, H, color_image.width(), color_image.height(), &planes_));
+    const bahip_frame images = ToBahipFrame();
+    BAHIP_CHECKED_CALL(bahip_frame_planes_update(ctx, planes_, &images));
     bahip_context_destroy(ctx);
     set_global_T_frame(global_tr_frame);
     activation_ = Activation::kActive;
+  }
+
+  ~Keyframe() { bahip_frame_planes_destroy(planes_); }
+  Keyframe(const Keyframe&) = delete;
+  Keyframe& operator=(const Keyframe&) = delete;
+
+  // Re-derives the BA planes from the current contents of the image buffers.
+  void RefreshPlanes(hipStream_t stream) {
+    bahip_context* ctx = nullptr;
+    BAHIP_CHECKED_CALL(bahip_context_create(&ctx, stream));
+    if (!planes_)
+      BAHIP_CHECKED_CALL(bahip_frame_planes_create(ctx, depth_buffer_.width(), depth_buffer_.height(), color_buffer_.width(),
+                                                   color_buffer_.height(), &planes_));
+    const bahip_frame images = ToBahipFrame();
+    BAHIP_CHECKED_CALL(bahip_frame_planes_update(ctx, planes_, &images));
+    bahip_context_destroy(ctx);
   }
 
   void SetID(int id) { id_ = id; }
@@ -130,6 +153,7 @@ class Keyframe {
     f.normals = normals_buffer_.ToCUDA().address(); f.normals_pitch_bytes = (uint32_t)normals_buffer_.ToCUDA().pitch();
     f.radius = radius_buffer_.ToCUDA().address(); f.radius_pitch_bytes = (uint32_t)radius_buffer_.ToCUDA().pitch();
     f.color = reinterpret_cast<uint8_t*>(color_buffer_.ToCUDA().address()); f.color_pitch_bytes = (uint32_t)color_buffer_.ToCUDA().pitch();
+    f.planes = planes_;
     return f;
   }
 
@@ -146,6 +170,7 @@ class Keyframe {
   CUDABuffer<u16> normals_buffer_;
   CUDABuffer<u16> radius_buffer_;
   CUDABuffer<uchar4> color_buffer_;
+  bahip_frame_planes* planes_ = nullptr;
 };
 
 }  // namespace vis

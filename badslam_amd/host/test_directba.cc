@@ -167,11 +167,13 @@ int GeometryOptimizationWithGeometricResidual(bool use_pcg) {
       normals(x, y) = (u16)((u16)(u8)sx | ((u16)(u8)sy << 8));
     }
   const_cast<CUDABuffer<u16>*>(&kf->normals_buffer())->UploadAsync(nullptr, normals);
+  kf->RefreshPlanes(nullptr);   // the images were written behind the keyframe's back
   ba->AddKeyframe(kf);
   ba->CreateSurfelsForKeyframe(stream, false, kf);
   for (int y = 0; y < H; ++y)
     for (int x = 0; x < W; ++x) depth(x, y) = (u16)(depth(x, y) + (u16)((0.0001f * rng.below(50)) / s));
   const_cast<CUDABuffer<u16>*>(&kf->depth_buffer())->UploadAsync(stream, depth);
+  kf->RefreshPlanes(stream);
   for (int i = 0; i < 10; ++i)
     ba->BundleAdjustment(stream, false, false, false, false, true, 10, 10, use_pcg, 0, (int)ba->keyframes().size() - 1, true);
   const u32 n = ba->surfel_count();

@@ -53,11 +53,19 @@ typedef struct bahip_depth_params { /* B/surfel_projection.cuh:129-149 */
   int32_t cfactor_width, cfactor_height;
 } bahip_depth_params;
 
+/* Tiled copies ("BA planes") of a frame's depth+normals and of its luma, the layout the surfel sweeps
+ * read (DESIGN.md "HBM layout").  Opaque; owned by whoever owns the images (vis::Keyframe does). */
+typedef struct bahip_frame_planes bahip_frame_planes;
+
 typedef struct bahip_frame {        /* the four images a Keyframe owns, B/keyframe.h:227-231 */
   uint16_t* depth;   uint32_t depth_pitch_bytes;
   uint16_t* normals; uint32_t normals_pitch_bytes;
   uint16_t* radius;  uint32_t radius_pitch_bytes;
   uint8_t* color;    uint32_t color_pitch_bytes;   /* uchar4 (R, G, B, luma) */
+  /* Optional.  NULL: the library packs the planes itself on every call that receives this frame (correct, but a
+   * K-image repack per bahip_set_keyframes).  Non-NULL: must have been refreshed with bahip_frame_planes_update
+   * after the last change of depth / normals / color. */
+  const bahip_frame_planes* planes;
 } bahip_frame;
 
 typedef struct bahip_keyframe {     /* one entry of the keyframe list handed to the *_CUDA functions */
@@ -135,6 +143,14 @@ int bahip_compute_min_max_depth(bahip_context* ctx, const uint16_t* depth, uint3
  * this backend removes). */
 int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, const bahip_camera* depth_camera,
                          const bahip_depth_params* dp);
+/* BA planes of one frame: create for the given image sizes, refresh from the frame's images (on the context
+ * stream), destroy.  The Keyframe constructor (B/keyframe.cc:81-158) is where the reference derives normals, radii
+ * and luma from its inputs; the planes are one more derived product of the same step. */
+int bahip_frame_planes_create(bahip_context* ctx, int depth_width, int depth_height, int color_width, int color_height,
+                              bahip_frame_planes** out);
+int bahip_frame_planes_update(bahip_context* ctx, bahip_frame_planes* planes, const bahip_frame* frame);
+void bahip_frame_planes_destroy(bahip_frame_planes* planes);
+
 int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int num_keyframes);
 /* Read back the poses of the bound keyframes (7 floats each); synchronises. */
 int bahip_get_keyframe_poses(bahip_context* ctx, float* global_T_frame_out, int num_keyframes);
