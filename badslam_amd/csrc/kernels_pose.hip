@@ -20,7 +20,10 @@
 
 namespace bahip {
 
-constexpr int kPoseBlock = 256;
+#ifndef BAHIP_WAVES_ATTR
+#define BAHIP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))   // cap the allocation at 128 VGPRs: 4 waves per SIMD (5 spills: measured slower)
+#endif
+constexpr int kPoseBlock = 64;    // one wavefront per workgroup: no LDS, no barriers, and finished waves free their slot at once
 
 // acc += w * [upper(J J^T) | r J].  The totals are merged across wavefronts with float atomics in arbitrary order, so
 // nothing downstream depends on the rounding of these partial sums: fused multiply-adds are used.
@@ -38,7 +41,7 @@ __device__ __forceinline__ void accumulate_jtj(float (&acc)[28], const float (&J
 }
 
 template <bool kUseDepth, bool kUseDesc>
-__global__ void __launch_bounds__(kPoseBlock)
+__global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
 pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                        int num_work, SurfelsView s, float* __restrict__ Hb) {
   const uint32_t i = blockIdx.x * kPoseBlock + threadIdx.x;

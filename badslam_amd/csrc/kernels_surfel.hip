@@ -14,12 +14,15 @@
 
 namespace bahip {
 
-constexpr int kSurfelBlock = 256;
+#ifndef BAHIP_WAVES_ATTR
+#define BAHIP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))   // cap the allocation at 128 VGPRs: 4 waves per SIMD (5 spills: measured slower)
+#endif
+constexpr int kSurfelBlock = 64;   // one wavefront per workgroup (per-wave work varies with the keyframe candidates)
 
 __device__ __forceinline__ bool position_valid(Vec3 p) { return p.x == p.x; }   // deleted surfels carry NaN x
 
 // B/kernel_surfel_activation.cu:38-94
-__global__ void __launch_bounds__(kSurfelBlock)
+__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
 activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t surfels_size) {
   const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
   const bool in_range = i < surfels_size;
@@ -70,7 +73,7 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
   }
 }
 
-__global__ void __launch_bounds__(kSurfelBlock)
+__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
 normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
   const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
   const bool in_range = i < s.size;
@@ -85,7 +88,7 @@ normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Surf
 // Geometry step of one BA iteration for one surfel: normals, then either the depth-only 1x1 solve
 // (B/kernel_opt_geometry.cu:417-508) or the joint position + descriptor 3x3 solve (:119-353).
 template <bool kUseDepth, bool kUseDesc>
-__global__ void __launch_bounds__(kSurfelBlock)
+__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
 geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
   const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
   const bool in_range = i < s.size;
@@ -225,7 +228,7 @@ void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const In
 // counts[0] = (wave, keyframe) candidates after frustum culling, [1] = of those with >= 1 associated
 // lane, [2] = associated (surfel, keyframe) pairs, [3] = pairs that passed the in-image test.
 namespace bahip {
-__global__ void __launch_bounds__(kSurfelBlock)
+__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
 count_pairs_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, unsigned long long* counts) {
   const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
   const bool in_range = i < s.size;
