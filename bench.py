@@ -36,8 +36,8 @@ STAGES = ("surfel_activation", "geometry_optimization", "pose_accumulate", "pose
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)     # 20 timed iterations after 3 warm-up
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--keyframes", type=int, default=200)
     p.add_argument("--surfels", type=int, default=3000000)
     p.add_argument("--width", type=int, default=640)
@@ -102,6 +102,25 @@ def build_scene(args, log):
     data = ba.download_surfels(rows=SURFEL_ROWS)
     data[2] += prng.uniform(0, 0.005, data.shape[1]).astype(np.float32)
     return ba, data, poses_gt
+
+
+def pmc_traffic_bytes(kernel_prefix):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (scripts/profile_round.sh -> profiles/<round>_pmc_per_kernel.json; FETCH_SIZE and WRITE_SIZE are
+    collected in separate passes and are in KB).  gfx950 correction of MI355X_MICROARCH.md "HBM":
+    FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled.  Returns None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        pmc = json.load(f)
+    for name, counters in pmc.items():
+        if name.startswith(kernel_prefix) and "FETCH_SIZE" in counters:
+            fetch = counters["FETCH_SIZE"]["avg_per_launch"] * 1024.0 * 2.0
+            write = counters.get("WRITE_SIZE", {"avg_per_launch": 0.0})["avg_per_launch"] * 1024.0
+            return {"bytes": fetch + write, "source": os.path.relpath(files[-1], ROOT)}
+    return None
 
 
 def cpu_baseline(args, log):
@@ -232,8 +251,11 @@ def main():
             out["config"].update({"pose_gn_rounds_per_iteration": R, "pose_gn_steps_per_keyframe": Rbar})
             out["algorithmic_bytes_per_iteration"] = b_alg_iter
             out["iteration_fraction_of_hbm_roofline"] = b_alg_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9)
+            traffic = pmc_traffic_bytes("pose_accumulate_kernel<true, true>") if world == 1 else None
             out["roofline"] = {"bound": "hbm", "kernel": "pose_accumulate_kernel<true,true>", "achieved": achieved,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": traffic["bytes"] if traffic else None,
+                               "traffic_source": traffic["source"] if traffic else None,
                                "algorithmic_bytes_per_launch": bytes_pose_launch, "avg_launch_ms": avg_ms, "launches": launches,
                                "keyframes_per_launch": kf_per_launch}
         else:
