@@ -110,21 +110,33 @@ point_radii_kernel(Intrinsics in, float raw_to_float_depth, const uint16_t* __re
 }
 
 // B/cuda_depth_processing.cu:391-428: positive floats order like their bit patterns.
-__global__ void __launch_bounds__(kPxBlockX* kPxBlockY)
+// A fixed grid of 64 x 256 threads strides over the image (row segments of 64 pixels per wavefront), so only 256
+// wavefronts contend for the two result words.
+constexpr int kMinMaxBlocks = 64;
+__global__ void __launch_bounds__(256)
 min_max_depth_kernel(const uint16_t* __restrict__ depth, uint32_t depth_pitch, int width, int height,
                      float raw_to_float_depth, int* __restrict__ result /* [0]=min bits, [1]=max bits */) {
-  const int x = blockIdx.x * kPxBlockX + threadIdx.x, y = blockIdx.y * kPxBlockY + threadIdx.y;
   float mn = __builtin_huge_valf(), mx = 0.f;
-  if (x < width && y < height) {
-    const uint16_t d16 = pitched_load(depth, depth_pitch, y, x);
-    if (!(d16 & kInvalidDepthBit)) { mn = mx = raw_to_float_depth * d16; }
+  const int segs_per_row = (width + 63) / 64;
+  const int total_segs = segs_per_row * height;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, num_waves = kMinMaxBlocks * 4, lane = threadIdx.x & 63;
+  for (int seg = wave; seg < total_segs; seg += num_waves) {
+    const int y = seg / segs_per_row, x = (seg % segs_per_row) * 64 + lane;
+    if (x < width) {
+      const uint16_t d16 = pitched_load(depth, depth_pitch, y, x);
+      if (!(d16 & kInvalidDepthBit)) {
+        const float d = raw_to_float_depth * d16;
+        mn = fminf(mn, d);
+        mx = fmaxf(mx, d);
+      }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     mn = fminf(mn, __shfl_xor(mn, off));
     mx = fmaxf(mx, __shfl_xor(mx, off));
   }
-  if ((threadIdx.x & 63) == 0) {
+  if (lane == 0) {
     atomicMin(&result[0], __float_as_int(mn));
     atomicMax(&result[1], __float_as_int(mx));
   }
@@ -147,7 +159,7 @@ void launch_point_radii(hipStream_t stream, const Intrinsics& in, float raw_to_f
 }
 void launch_min_max_depth(hipStream_t stream, const uint16_t* depth, uint32_t depth_pitch, int w, int h,
                           float raw_to_float_depth, int* result) {
-  hipLaunchKernelGGL(min_max_depth_kernel, px_grid(w, h), dim3(kPxBlockX, kPxBlockY), 0, stream, depth, depth_pitch, w, h,
+  hipLaunchKernelGGL(min_max_depth_kernel, dim3(kMinMaxBlocks), dim3(256), 0, stream, depth, depth_pitch, w, h,
                      raw_to_float_depth, result);
 }
 
