@@ -226,6 +226,7 @@ struct Assoc {
   float depth;       // calibrated depth of the associated pixel
   int px, py;
   float pxx, pxy;    // float pixel position, pixel-corner convention
+  uint16_t normal_bits;   // packed measured normal of the associated pixel
 };
 
 // B/surfel_projection_nvcc_only.cuh:332-359 with IsAssociatedWithPixel :48-127; the order of the
@@ -260,7 +261,8 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   }
   const float dist = norm3(r->local);
   if ((1.0f / dist) * dot3(r->local, r->nl) > 0) return false;
-  const Vec3 m = unpack_normal8((uint16_t)(word >> 16));
+  r->normal_bits = (uint16_t)(word >> 16);
+  const Vec3 m = unpack_normal8(r->normal_bits);
   if (dot3(r->nl, m) < kCosNormalCompat) return false;
   return true;
 }

@@ -978,6 +978,14 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
   return 0;
 }
 
+int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts) {
+  REQUIRE(tile_waves == 0 || tile_waves == 1 || tile_waves == 4, "tile_waves must be 0 (automatic), 1 or 4");
+  REQUIRE(pose_parts == 0 || pose_parts == 1 || pose_parts == 2 || pose_parts == 4 || pose_parts == 8, "pose_parts must be 0, 1, 2, 4 or 8");
+  set_tile_waves(tile_waves);
+  set_pose_parts(pose_parts);
+  return 0;
+}
+
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56) {
   float *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, 64 * 28 * sizeof(float)));

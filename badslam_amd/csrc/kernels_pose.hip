@@ -12,6 +12,8 @@
 // reduced across the wave64 with cross-lane adds and merged with one atomic per scalar per wave.
 // The 6x6 LDLT (binary64, like the reference), T <- T*exp(-x) and the convergence test run in a
 // second tiny kernel on the device, so a round costs two launches and one 4-byte read-back.
+#include <stdlib.h>
+
 #include "ba_device.h"
 #include "ba_launch.h"
 #include "se3_device.h"
@@ -121,7 +123,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     // wave64 halving reduction (wave_reduce.h), then one atomic per scalar per wave
     const float mine = wave_reduce28(acc, lane);
     if (slot >= 0 && slot < 27) unsafeAtomicAdd(&Hb[(size_t)w * kHbStride + slot], mine);
-  });
+  }, gridDim.y, blockIdx.y);
 }
 
 // B/convergence_analysis.h:43-51
@@ -222,10 +224,20 @@ __global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ fram
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
+static int g_forced_pose_parts = [] { const char* e = getenv("BAHIP_POSE_PARTS"); return e ? atoi(e) : 0; }();
+void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
+
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, float* Hb) {
   if (s.size == 0 || num_work == 0) return;
-  const dim3 grid((s.size + kPoseBlock - 1) / kPoseBlock), block(kPoseBlock);
+  // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
+  // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
+  // (the sums are merged by atomics, so who visits a keyframe does not matter).
+  const unsigned tiles = (s.size + kPoseBlock - 1) / kPoseBlock;
+  const int forced = g_forced_pose_parts;
+  const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
+                         : tiles >= 32768 ? 2 : tiles >= 8192 ? 4 : 8;   // measured: 46.9 k tiles 2.01 / 1.79 / 1.80 ms with 1 / 2 / 4 parts
+  const dim3 grid(tiles, parts), block(kPoseBlock);
   const PoseWork* pw = static_cast<const PoseWork*>(work);
   if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
   else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);

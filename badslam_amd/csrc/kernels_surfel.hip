@@ -6,8 +6,19 @@
 // Here each stage is ONE launch: a thread owns a surfel, keeps position / normal / accumulators in
 // registers and visits only the keyframes whose frustum can contain its wavefront's 64 surfels
 // (wave_cull.h), so the surfel array is read once and written once per stage and both the K-fold
-// RMW traffic and most of the K x N association tests disappear.  Keyframes are visited in
-// ascending order, i.e. accumulation order equals the reference's sequence of launches.
+// RMW traffic and most of the K x N association tests disappear.
+//
+// Per-surfel sums over keyframes are DEFINED here as four interleaved partial sums: partial j adds the keyframes k
+// with k % 4 == j in ascending order, and the total is ((p0 + p1) + p2) + p3 (the oracle computes exactly that; the
+// reference adds the keyframes' contributions one launch after the other).  The definition lets the same bits come
+// out of two launch shapes (tile_sums):
+//   kWaves = 1  one wavefront per 64-surfel tile walks the four classes one after the other - least overhead, used
+//               when there are enough tiles to fill the chip (a single-GPU run);
+//   kWaves = 2, 4  a workgroup of two / four wavefronts per tile sharing the classes, partials combined through LDS -
+//               divides the longest wavefront, which is what bounds the launch once the surfel set is a shard of a
+//               multi-GPU run and no longer fills the chip.
+#include <stdlib.h>
+
 #include "ba_device.h"
 #include "ba_launch.h"
 #include "wave_cull.h"
@@ -18,6 +29,45 @@ namespace bahip {
 #define BAHIP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))   // cap the allocation at 128 VGPRs: 4 waves per SIMD (5 spills: measured slower)
 #endif
 constexpr int kSurfelBlock = 64;   // one wavefront per workgroup (per-wave work varies with the keyframe candidates)
+constexpr int kSumClasses = 4;     // interleaved partial sums per surfel (part of the numerical definition, not a tuning knob)
+
+// tot[q] = ((p0[q] + p1[q]) + p2[q]) + p3[q], p_c = what visit(acc, c) accumulates over the keyframes of class c.
+// kWaves > 1: the calling workgroup has kWaves wavefronts holding the same 64 surfels (wavefront w takes the classes
+// w, w + kWaves, ...); every thread must call.
+template <int kWaves, int kCount, typename Visit>
+__device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visit visit) {
+  static_assert(kWaves == 1 || kWaves == 2 || kWaves == kSumClasses, "1, 2 or 4 wavefronts per tile");
+  if (kWaves == 1) {
+#pragma unroll
+    for (int q = 0; q < kCount; ++q) tot[q] = 0.f;   // +0 + p0 == p0 bit for bit (the partials are never -0)
+#pragma nounroll
+    for (int c = 0; c < kSumClasses; ++c) {
+      float acc[kCount];
+#pragma unroll
+      for (int q = 0; q < kCount; ++q) acc[q] = 0.f;
+      visit(acc, c);
+#pragma unroll
+      for (int q = 0; q < kCount; ++q) tot[q] += acc[q];
+    }
+  } else {
+    const int part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma nounroll
+    for (int c = part; c < kSumClasses; c += kWaves) {
+      float acc[kCount];
+#pragma unroll
+      for (int q = 0; q < kCount; ++q) acc[q] = 0.f;
+      visit(acc, c);
+#pragma unroll
+      for (int q = 0; q < kCount; ++q) lds[(c * kCount + q) * 64 + lane] = acc[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kCount; ++q)
+      tot[q] = ((lds[(0 * kCount + q) * 64 + lane] + lds[(1 * kCount + q) * 64 + lane]) + lds[(2 * kCount + q) * 64 + lane]) +
+               lds[(3 * kCount + q) * 64 + lane];
+    __syncthreads();   // the buffer is reused by the next call
+  }
+}
 
 __device__ __forceinline__ bool position_valid(Vec3 p) { return p.x == p.x; }   // deleted surfels carry NaN x
 
@@ -44,80 +94,96 @@ activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, S
 }
 
 // Normals pass: B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update).
-// `live` = this lane holds an active surfel; every lane of the wave must call this function.
+// `live` = this lane holds an active surfel; every thread of the workgroup must call this function.
+template <int kWaves>
 __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs,
                                              const WaveBounds& wb, SurfelsView& s, uint32_t i, bool live, Vec3 gp,
-                                             Vec3* gn_inout) {
-  float sx = 0, sy = 0, sz = 0, count = 0;
+                                             Vec3* gn_inout, float* lds) {
+  const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
   const Vec3 gn = *gn_inout;
-  for_each_candidate(
-      num_kfs,
-      [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); },
-      [&](int k) {
-        if (!live) return;
-        Assoc r;
-        if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) {
-          const Vec3 m = unpack_normal8(pitched_load(kfs[k].normals, kfs[k].normals_pitch, r.py, r.px));
-          const Vec3 g = mul33(kfs[k].pose.GR, m);
-          sx += g.x; sy += g.y; sz += g.z; count += 1.f;
-        }
-      });
+  float sum[4];   // x, y, z, count
+  tile_sums<kWaves>(sum, lds, [&](float (&acc)[4], int cls) {
+    for_each_candidate(
+        num_kfs,
+        [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); },
+        [&](int k) {
+          if (!live) return;
+          Assoc r;
+          if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) {
+            const Vec3 g = mul33(kfs[k].pose.GR, unpack_normal8(r.normal_bits));
+            acc[0] += g.x; acc[1] += g.y; acc[2] += g.z; acc[3] += 1.f;
+          }
+        },
+        kSumClasses, cls);
+  });
   if (!live) return;
-  // The reference leaves the sums in accum rows 0..3; keep that observable state.
-  s.row(kSurfelAccum0 + 0)[i] = sx; s.row(kSurfelAccum0 + 1)[i] = sy;
-  s.row(kSurfelAccum0 + 2)[i] = sz; s.row(kSurfelAccum0 + 3)[i] = count;
+  const float sx = sum[0], sy = sum[1], sz = sum[2], count = sum[3];
+  if (writer) {
+    // The reference leaves the sums in accum rows 0..3; keep that observable state.
+    s.row(kSurfelAccum0 + 0)[i] = sx; s.row(kSurfelAccum0 + 1)[i] = sy;
+    s.row(kSurfelAccum0 + 2)[i] = sz; s.row(kSurfelAccum0 + 3)[i] = count;
+  }
   if (count >= 1) {
     const uint32_t packed = pack_normal10((1.f / count) * mk3(sx, sy, sz));
-    reinterpret_cast<uint32_t*>(s.row(kSurfelNormal))[i] = packed;
+    if (writer) reinterpret_cast<uint32_t*>(s.row(kSurfelNormal))[i] = packed;
     *gn_inout = unpack_normal10(packed);
   }
 }
 
-__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
+template <int kWaves>
+__global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
 normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
-  const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
+  __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 4 * 64];
+  const int lane = threadIdx.x & 63;
+  const uint32_t i = blockIdx.x * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
   const Vec3 gp = surfel_position(s, ii);
   Vec3 gn = surfel_normal(s, ii);
   const WaveBounds wb = wave_bounds(gp, live && position_valid(gp));
-  normals_pass(in, kfs, num_kfs, wb, s, ii, live, gp, &gn);
+  normals_pass<kWaves>(in, kfs, num_kfs, wb, s, ii, live, gp, &gn, lds);
 }
 
 // Geometry step of one BA iteration for one surfel: normals, then either the depth-only 1x1 solve
 // (B/kernel_opt_geometry.cu:417-508) or the joint position + descriptor 3x3 solve (:119-353).
-template <bool kUseDepth, bool kUseDesc>
-__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
+template <bool kUseDepth, bool kUseDesc, int kWaves>
+__global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
 geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
-  const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
+  __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
+  const int lane = threadIdx.x & 63;
+  const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
+  const uint32_t i = blockIdx.x * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
   const Vec3 gp = surfel_position(s, ii);
   Vec3 gn = surfel_normal(s, ii);
   const WaveBounds wb = wave_bounds(gp, live && position_valid(gp));
-  if (wb.r < 0.f) return;   // wave-uniform: no active surfel in this wavefront
-  normals_pass(in, kfs, num_kfs, wb, s, ii, live, gp, &gn);
+  if (wb.r < 0.f) return;   // workgroup-uniform (all wavefronts of the tile hold the same surfels): no active surfel here
+  normals_pass<kWaves>(in, kfs, num_kfs, wb, s, ii, live, gp, &gn, lds);
 
   auto cand = [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); };
 
   if (!kUseDesc) {
-    float H = 0, b = 0;
-    for_each_candidate(num_kfs, cand, [&](int k) {
-      if (!live) return;
-      Assoc r;
-      if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) return;
-      const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
-      const float jac = -inv_std;
-      const Vec3 u = unproject(in, r.px, r.py, r.depth);
-      const float raw = inv_std * dot3(r.nl, u - r.local);
-      const float w = depth_residual_weight(raw);
-      const float wj = w * jac;
-      H += wj * jac;
-      b += wj * raw;
+    float hb[2];
+    tile_sums<kWaves>(hb, lds, [&](float (&acc)[2], int cls) {
+      for_each_candidate(num_kfs, cand, [&](int k) {
+        if (!live) return;
+        Assoc r;
+        if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) return;
+        const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
+        const float jac = -inv_std;
+        const Vec3 u = unproject(in, r.px, r.py, r.depth);
+        const float raw = inv_std * dot3(r.nl, u - r.local);
+        const float w = depth_residual_weight(raw);
+        const float wj = w * jac;
+        acc[0] += wj * jac;
+        acc[1] += wj * raw;
+      }, kSumClasses, cls);
     });
-    if (!live) return;
+    if (!live || !writer) return;
+    const float H = hb[0], b = hb[1];
     s.row(kSurfelAccum0 + 0)[i] = H;
     s.row(kSurfelAccum0 + 1)[i] = b;
     if (H > 1e-6f) {
@@ -132,46 +198,50 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   const float d1 = s.row(kSurfelDescriptor1)[ii];
   const float d2 = s.row(kSurfelDescriptor2)[ii];
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);
-  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-  for_each_candidate(num_kfs, cand, [&](int k) {
-    if (!live) return;
-    const float* F = kfs[k].pose.F;
-    Assoc r;
-    if (!project_associate<false>(in, F, kfs[k].geom, gp, gn, &r, nullptr)) return;
-    if (kUseDepth) {
-      const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
-      const float jac = -inv_std;
-      const Vec3 u = unproject(in, r.px, r.py, r.depth);
-      const float raw = inv_std * dot3(r.nl, u - r.local);
-      const float w = depth_residual_weight(raw);
-      a0 += w * jac * jac;
-      a6 += w * raw * jac;
-    }
-    float cx, cy;
-    if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
-      DescEval e;
-      eval_descriptor<true>(in, kfs[k].lumafp, F, tp, cx, cy, d1, d2, &e);
-      const float term1 = -in.cfx * (r.nl.x * r.local.z - r.nl.z * r.local.x);
-      const float term2 = -in.cfy * (r.nl.y * r.local.z - r.nl.z * r.local.y);
-      const float term3 = 1.f / (r.local.z * r.local.z);
-      const float jp1 = -(e.gx1 * term1 + e.gy1 * term2) * term3;
-      const float jp2 = -(e.gx2 * term1 + e.gy2 * term2) * term3;
-      const float jd = -1.f;
-      const float w1 = descriptor_residual_weight(e.r1);
-      const float wr1 = w1 * e.r1;
-      const float w2 = descriptor_residual_weight(e.r2);
-      const float wr2 = w2 * e.r2;
-      a0 += w1 * jp1 * jp1 + w2 * jp2 * jp2;
-      a1 += w1 * jp1 * jd;
-      a3 += w1 * jd * jd;
-      a6 += wr1 * jp1 + wr2 * jp2;
-      a7 += wr1 * jd;
-      a2 += w2 * jp2 * jd;
-      a5 += w2 * jd * jd;
-      a8 += wr2 * jd;
-    }
+  float tot[8];   // a0 a1 a2 a3 a5 a6 a7 a8 of B/kernel_opt_geometry.cu:119-230 (a4 = H12 is exactly 0)
+  tile_sums<kWaves>(tot, lds, [&](float (&acc)[8], int cls) {
+    float &a0 = acc[0], &a1 = acc[1], &a2 = acc[2], &a3 = acc[3], &a5 = acc[4], &a6 = acc[5], &a7 = acc[6], &a8 = acc[7];
+    for_each_candidate(num_kfs, cand, [&](int k) {
+      if (!live) return;
+      const float* F = kfs[k].pose.F;
+      Assoc r;
+      if (!project_associate<false>(in, F, kfs[k].geom, gp, gn, &r, nullptr)) return;
+      if (kUseDepth) {
+        const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
+        const float jac = -inv_std;
+        const Vec3 u = unproject(in, r.px, r.py, r.depth);
+        const float raw = inv_std * dot3(r.nl, u - r.local);
+        const float w = depth_residual_weight(raw);
+        a0 += w * jac * jac;
+        a6 += w * raw * jac;
+      }
+      float cx, cy;
+      if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
+        DescEval e;
+        eval_descriptor<true>(in, kfs[k].lumafp, F, tp, cx, cy, d1, d2, &e);
+        const float term1 = -in.cfx * (r.nl.x * r.local.z - r.nl.z * r.local.x);
+        const float term2 = -in.cfy * (r.nl.y * r.local.z - r.nl.z * r.local.y);
+        const float term3 = 1.f / (r.local.z * r.local.z);
+        const float jp1 = -(e.gx1 * term1 + e.gy1 * term2) * term3;
+        const float jp2 = -(e.gx2 * term1 + e.gy2 * term2) * term3;
+        const float jd = -1.f;
+        const float w1 = descriptor_residual_weight(e.r1);
+        const float wr1 = w1 * e.r1;
+        const float w2 = descriptor_residual_weight(e.r2);
+        const float wr2 = w2 * e.r2;
+        a0 += w1 * jp1 * jp1 + w2 * jp2 * jp2;
+        a1 += w1 * jp1 * jd;
+        a3 += w1 * jd * jd;
+        a6 += wr1 * jp1 + wr2 * jp2;
+        a7 += wr1 * jd;
+        a2 += w2 * jp2 * jd;
+        a5 += w2 * jd * jd;
+        a8 += wr2 * jd;
+      }
+    }, kSumClasses, cls);
   });
-  if (!live) return;
+  if (!live || !writer) return;
+  const float a0 = tot[0], a1 = tot[1], a2 = tot[2], a3 = tot[3], a5 = tot[4], a6 = tot[5], a7 = tot[6], a8 = tot[7];
   s.row(kSurfelAccum0 + 0)[i] = a0; s.row(kSurfelAccum0 + 1)[i] = a1; s.row(kSurfelAccum0 + 2)[i] = a2;
   s.row(kSurfelAccum0 + 3)[i] = a3; s.row(kSurfelAccum0 + 4)[i] = 0;  s.row(kSurfelAccum0 + 5)[i] = a5;
   s.row(kSurfelAccum0 + 6)[i] = a6; s.row(kSurfelAccum0 + 7)[i] = a7; s.row(kSurfelAccum0 + 8)[i] = a8;
@@ -208,18 +278,44 @@ void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* 
                      surfels_size);
 }
 
+// Launch shape of the normals / geometry passes (see the header comment): one wavefront per tile when the tiles alone
+// fill the chip several times over, else four.  Results do not depend on it; BAHIP_TILE_WAVES=1|4 or
+// bahip_debug_set_launch_shapes force one (tests run both).
+static int g_forced_tile_waves = [] { const char* e = getenv("BAHIP_TILE_WAVES"); return e ? atoi(e) : 0; }();
+void set_tile_waves(int waves) { g_forced_tile_waves = waves; }
+static int tile_waves(uint32_t surfels) {
+  const int forced = g_forced_tile_waves;
+  if (forced == 1 || forced == 4) return forced;
+  // measured on MI355X (geometry pass, ms): 11.7 k tiles: 0.90 with one wavefront per tile, 0.95 with four;
+  // 5.9 k tiles: 0.65 vs 0.51
+  return grid_for(surfels) >= 8192 ? 1 : 4;
+}
+
 void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s) {
   if (s.size == 0) return;
-  hipLaunchKernelGGL(normals_kernel, dim3(grid_for(s.size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s);
+  const dim3 grid(grid_for(s.size));
+  switch (tile_waves(s.size)) {
+    case 1: hipLaunchKernelGGL(normals_kernel<1>, grid, dim3(64), 0, stream, in, kfs, num_kfs, s); break;
+    default: hipLaunchKernelGGL(normals_kernel<4>, grid, dim3(256), 0, stream, in, kfs, num_kfs, s); break;
+  }
+}
+
+template <int kWaves>
+static void launch_geometry_shape(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
+                                  int num_kfs, const SurfelsView& s) {
+  const dim3 grid(grid_for(s.size)), block(64 * kWaves);
+  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false, kWaves>), grid, block, 0, stream, in, kfs, num_kfs, s);
+  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true, kWaves>), grid, block, 0, stream, in, kfs, num_kfs, s);
+  else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves>), grid, block, 0, stream, in, kfs, num_kfs, s);
 }
 
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
                      int num_kfs, const SurfelsView& s) {
   if (s.size == 0) return;
-  const dim3 grid(grid_for(s.size)), block(kSurfelBlock);
-  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false>), grid, block, 0, stream, in, kfs, num_kfs, s);
-  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true>), grid, block, 0, stream, in, kfs, num_kfs, s);
-  else hipLaunchKernelGGL((geometry_kernel<false, true>), grid, block, 0, stream, in, kfs, num_kfs, s);
+  switch (tile_waves(s.size)) {
+    case 1: launch_geometry_shape<1>(stream, use_depth, use_desc, in, kfs, num_kfs, s); break;
+    default: launch_geometry_shape<4>(stream, use_depth, use_desc, in, kfs, num_kfs, s); break;
+  }
 }
 
 }  // namespace bahip

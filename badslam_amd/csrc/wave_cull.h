@@ -23,16 +23,25 @@ struct WaveBounds {
   float r;            // inflated radius; negative = no valid surfel in this wave
 };
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+// All-lanes min / max with the cross-lane primitives of wave_reduce.h (no LDS traffic).
+template <typename Op>
+__device__ __forceinline__ float wave_all(float v, Op op) {
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  v = op(v, dpp::mov<dpp::kRowRor8>(v));
+  v = op(v, __uint_as_float(__builtin_amdgcn_ds_swizzle(__float_as_uint(v), 0x101F)));
+  v = op(v, dpp::mov<dpp::kQuadXor2>(v));
+  v = op(v, dpp::mov<dpp::kQuadXor1>(v));
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
-}
+__device__ __forceinline__ float wave_min(float v) { return wave_all(v, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_all(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // Bounding sphere of the positions held by the lanes with valid == true (NaN positions -- deleted
 // surfels -- must be passed as valid == false).
@@ -67,17 +76,19 @@ __device__ __forceinline__ bool sphere_may_project(const Intrinsics& in, const f
   return true;
 }
 
-// Calls body(k) (k wave-uniform, ascending) for every item k in [0, num_items) whose lane-level
-// predicate pred(k) holds.  The candidate set lives in a 64-bit scalar mask.
+// Calls body(k) (k wave-uniform, ascending) for every item k in [0, num_items) with k % parts == part whose
+// lane-level predicate pred(k) holds.  The candidate set lives in a 64-bit scalar mask (one item per lane).
+// parts > 1 splits the items of one surfel tile over several wavefronts: the per-keyframe pose sums are merged
+// by atomics (any split is fine), the per-surfel sums are defined as four interleaved partial sums (kernels_surfel.hip).
 template <typename Pred, typename Body>
-__device__ __forceinline__ void for_each_candidate(int num_items, Pred pred, Body body) {
+__device__ __forceinline__ void for_each_candidate(int num_items, Pred pred, Body body, int parts = 1, int part = 0) {
   const int lane = threadIdx.x & 63;
-  for (int base = 0; base < num_items; base += 64) {
-    const int item = base + lane;
+  for (int base = part; base < num_items; base += 64 * parts) {
+    const int item = base + lane * parts;
     const bool cand = (item < num_items) && pred(item);
     unsigned long long m = __ballot(cand);
     while (m) {
-      const int k = base + __builtin_ctzll(m);
+      const int k = base + __builtin_ctzll(m) * parts;
       m &= m - 1;
       body(k);
     }

@@ -24,6 +24,20 @@ def shard_range(total, rank, world):
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+def shard_chunks(total, rank, world, chunk=4096):
+    """Chunk-cyclic surfel partition: rank r owns chunks r, r + world, r + 2 world, ... of `chunk` consecutive
+    surfels.  Consecutive surfels are spatial neighbours (tile-major creation order), and the work per surfel varies
+    over the scene with the number of keyframes that see it; dealing chunks round-robin keeps every rank's share
+    of each region - and so its kernel time - the same, while a chunk (64 wavefronts) keeps its locality.
+    Returns the index array (ascending) of the surfels owned by `rank`."""
+    import numpy as np
+    starts = np.arange(rank * chunk, total, world * chunk, dtype=np.int64)
+    if starts.size == 0:
+        return np.zeros(0, np.int64)
+    idx = (starts[:, None] + np.arange(chunk, dtype=np.int64)[None, :]).ravel()
+    return idx[idx < total]
+
+
 def make_allreduce_callback(all_reduce_tensor):
     """Wraps `all_reduce_tensor(torch_tensor)` as a bahip_allreduce_fn."""
     import torch

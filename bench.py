@@ -52,6 +52,13 @@ def parse_args():
     p.add_argument("--plane-slope", type=float, default=0.05)
     p.add_argument("--cell", type=int, default=2, help="sparse_surfel_cell_size")
     p.add_argument("--pcg", action="store_true", help="time the PCG scheme instead of the alternating one (single GPU)")
+    p.add_argument("--force-allreduce", action="store_true",
+                   help="install the RCCL all-reduce hook even with one rank (measures the cost of the exchange path)")
+    p.add_argument("--emulate-world", type=int, default=0,
+                   help="single process: time rank 0's share of an N-rank run (with --force-allreduce: plus the exchange path); "
+                        "a planning aid, the JSON line then describes that share, not the whole job")
+    p.add_argument("--emulate-rank", type=int, default=0)
+    p.add_argument("--shard-chunk", type=int, default=4096, help="surfels per chunk of the chunk-cyclic partition; 0 = contiguous")
     p.add_argument("--build-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
@@ -146,15 +153,22 @@ def cpu_baseline(args, log):
 
 def main():
     args = parse_args()
+    # stdout carries exactly one JSON line: anything a library prints to fd 1 (RCCL prints a version banner there)
+    # is sent to stderr instead, and the result is written to the original stdout at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_allreduce:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
 
@@ -167,12 +181,18 @@ def main():
     N_total = data.shape[1]
     if args.build_only:
         return
-    # surfel sharding: rank r owns a contiguous slice (keyframe images replicated on every rank)
-    lo, hi = multigpu.shard_range(N_total, rank, world)
-    ba.upload_surfels(data[:, lo:hi])
+    # surfel sharding: rank r owns every world-th chunk of 4096 surfels (keyframe images replicated on every rank)
+    shard_world = args.emulate_world if (args.emulate_world > 0 and world == 1) else world
+    shard_rank = args.emulate_rank if shard_world != world else rank
+    if args.shard_chunk > 0:
+        mine = multigpu.shard_chunks(N_total, shard_rank, shard_world, args.shard_chunk)
+    else:
+        lo, hi = multigpu.shard_range(N_total, shard_rank, shard_world)
+        mine = np.arange(lo, hi, dtype=np.int64)
+    ba.upload_surfels(np.ascontiguousarray(data[:, mine]) if shard_world > 1 else data)
     ctx = ba.backend_context()
     hook_keepalive = None
-    if world > 1:
+    if dist is not None:
         hook_keepalive = multigpu.install_allreduce(ctx, dist)
     K = args.keyframes
 
@@ -215,7 +235,7 @@ def main():
 
     if rank == 0:
         W, H = args.width, args.height
-        N_rank = hi - lo
+        N_rank = int(mine.size)
         out = {
             "metric": "BA iterations/sec (and ms/iter) at N keyframes x M surfels, 640x480",
             "value": args.steps / elapsed,
@@ -234,6 +254,7 @@ def main():
                        "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
                        "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
                        "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU"},
+            **({"emulated_share_of_world": shard_world} if shard_world != world else {}),
             "stage_ms_per_iteration": {STAGES[s]: stage_ms[s] / args.steps for s in range(4)},
         }
         if not args.pcg:
@@ -269,7 +290,7 @@ def main():
                                              f"{cb['seconds_per_eval']:.2f} s per evaluation; one BA iteration at the bench "
                                              f"size needs >= {sweeps:.1f} such sweeps over {K}x{N_total} pairs",
                                    "equivalent_ba_iterations_per_s": cb["pairs_per_s"] / (sweeps * K * N_total)}
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

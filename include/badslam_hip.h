@@ -249,6 +249,11 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
 /* Work census of one sweep of the bound keyframes over the surfels: counts[0] = (wavefront, keyframe)
  * candidates left by frustum culling, [1] = of those with >= 1 association, [2] = associated
  * (surfel, keyframe) pairs, [3] = pairs projecting into the image. */
+/* Launch shapes of the surfel sweeps, process-wide; 0 = chosen from the surfel count (default).  tile_waves (1 | 4):
+ * wavefronts per 64-surfel tile in the normals / geometry passes - results are bit-identical for both (the per-surfel
+ * sums are defined as four interleaved partial sums).  pose_parts (1 | 2 | 4 | 8): wavefronts sharing a
+ * tile's keyframes in the pose kernel (sums merged by float atomics in any case). */
+int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
 /* One wavefront: in = 64 lanes x 28 floats; out[0..27] = totals from the halving reduction used by the pose kernel
  * (wave_reduce.h), out[28..55] = the same totals from the xor-butterfly wave_sum. */
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56);

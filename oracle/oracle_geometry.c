@@ -23,6 +23,14 @@ void orc_update_surfel_activation(const orc_camera* depth_cam, const orc_depth_p
   }
 }
 
+/* Per-surfel sums over keyframes.  The reference adds the keyframes' contributions in keyframe order (one kernel launch
+ * per keyframe).  The HIP path defines the sums as four interleaved partial sums - partial j takes the keyframes whose
+ * index among the non-deleted keyframes is congruent to j modulo 4, in ascending order - combined as
+ * ((p0 + p1) + p2) + p3 (kernels_surfel.hip: tile_sums).  The oracle follows that definition so
+ * that the comparison can be bit-exact; in exact arithmetic it is the reference's sum. */
+#define ORC_SPLIT 4
+static inline float combine4(const float p[ORC_SPLIT]) { return ((p[0] + p[1]) + p[2]) + p[3]; }
+
 /* Normals pass shared by B/kernel_opt_geometry.cc:39-77 and :108-134; kernels
  * B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update). */
 void orc_update_surfel_normals(const orc_camera* depth_cam, const orc_depth_params* dp,
@@ -33,18 +41,23 @@ void orc_update_surfel_normals(const orc_camera* depth_cam, const orc_depth_para
 #pragma omp parallel for schedule(static)
   for (uint32_t i = 0; i < s->surfels_size; ++i) {
     if (!(s->active[i] & ORC_SURFEL_ACTIVE_FLAG)) continue;
-    a0[i] = a1[i] = a2[i] = a3[i] = 0;
+    float part[4][ORC_SPLIT] = {{0}};
+    int bound_index = -1;   /* index among the non-deleted keyframes = index in the HIP keyframe table */
     for (int k = 0; k < num_kfs; ++k) {
       const orc_keyframe* kf = kfs[k];
-      if (!kf || kf->activation == ORC_KF_INACTIVE) continue;
+      if (!kf) continue;
+      ++bound_index;
+      if (kf->activation == ORC_KF_INACTIVE) continue;
       proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
       proj_result r;
       if (!orc_project_associate(&p, i, &r, NULL)) continue;
       float m[3];
       orc_unpack_normal8(kf->normals[(size_t)r.py * kf->width + r.px], m);
       const v3 g = m33_mul(kf->global_R_frame, v3_make(m[0], m[1], m[2]));
-      a0[i] += g.x; a1[i] += g.y; a2[i] += g.z; a3[i] += 1.f;
+      const int j = bound_index % ORC_SPLIT;
+      part[0][j] += g.x; part[1][j] += g.y; part[2][j] += g.z; part[3][j] += 1.f;
     }
+    a0[i] = combine4(part[0]); a1[i] = combine4(part[1]); a2[i] = combine4(part[2]); a3[i] = combine4(part[3]);
     const float count = a3[i];
     if (count >= 1) surfel_set_normal(s, i, v3_scale(1.f / count, v3_make(a0[i], a1[i], a2[i])));
   }
@@ -66,10 +79,14 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
 #pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < s->surfels_size; ++i) {
       if (!(s->active[i] & ORC_SURFEL_ACTIVE_FLAG)) continue;
-      acc[0][i] = 0; acc[1][i] = 0;
+      float part[2][ORC_SPLIT] = {{0}};
+      int bound_index = -1;
       for (int k = 0; k < num_kfs; ++k) {
         const orc_keyframe* kf = kfs[k];
-        if (!kf || kf->activation == ORC_KF_INACTIVE) continue;
+        if (!kf) continue;
+        ++bound_index;
+        if (kf->activation == ORC_KF_INACTIVE) continue;
+        const int j = bound_index % ORC_SPLIT;
         proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
         proj_result r;
         if (!orc_project_associate(&p, i, &r, NULL)) continue;
@@ -81,9 +98,10 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         const float raw = inv_std * v3_dot(rn, v3_sub(u, r.local_position));
         const float w = depth_residual_weight(raw);
         const float weighted_jacobian = w * depth_jacobian;
-        acc[0][i] += weighted_jacobian * depth_jacobian;
-        acc[1][i] += weighted_jacobian * raw;
+        part[0][j] += weighted_jacobian * depth_jacobian;
+        part[1][j] += weighted_jacobian * raw;
       }
+      acc[0][i] = combine4(part[0]); acc[1][i] = combine4(part[1]);
       const float Hs = acc[0][i];
       if (Hs > 1e-6f) {
         const v3 gp = surfel_position(s, i);
@@ -99,10 +117,14 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
 #pragma omp parallel for schedule(static)
   for (uint32_t i = 0; i < s->surfels_size; ++i) {
     if (!(s->active[i] & ORC_SURFEL_ACTIVE_FLAG)) continue;
-    for (int k = 0; k < 9; ++k) acc[k][i] = 0;
+    float part[9][ORC_SPLIT] = {{0}};
+    int bound_index = -1;
     for (int k = 0; k < num_kfs; ++k) {
       const orc_keyframe* kf = kfs[k];
-      if (!kf || kf->activation == ORC_KF_INACTIVE) continue;
+      if (!kf) continue;
+      ++bound_index;
+      if (kf->activation == ORC_KF_INACTIVE) continue;
+      const int j = bound_index % ORC_SPLIT;
       proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
       proj_result r;
       if (!orc_project_associate(&p, i, &r, NULL)) continue;
@@ -115,8 +137,8 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
         const float raw = inv_std * v3_dot(rn, v3_sub(u, r.local_position));
         const float w = depth_residual_weight(raw);
-        acc[0][i] += w * depth_jacobian * depth_jacobian;
-        acc[6][i] += w * raw * depth_jacobian;
+        part[0][j] += w * depth_jacobian * depth_jacobian;
+        part[6][j] += w * raw * depth_jacobian;
       }
       float c[2];
       if (transform_depth_to_color(r.pxx, r.pxy, &d2c, &c[0], &c[1])) {
@@ -135,16 +157,17 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         const float wr1 = w1 * raw1;
         const float w2 = descriptor_residual_weight(raw2);
         const float wr2 = w2 * raw2;
-        acc[0][i] += w1 * jp1 * jp1 + w2 * jp2 * jp2;
-        acc[1][i] += w1 * jp1 * jd;
-        acc[3][i] += w1 * jd * jd;
-        acc[6][i] += wr1 * jp1 + wr2 * jp2;
-        acc[7][i] += wr1 * jd;
-        acc[2][i] += w2 * jp2 * jd;
-        acc[5][i] += w2 * jd * jd;
-        acc[8][i] += wr2 * jd;
+        part[0][j] += w1 * jp1 * jp1 + w2 * jp2 * jp2;
+        part[1][j] += w1 * jp1 * jd;
+        part[3][j] += w1 * jd * jd;
+        part[6][j] += wr1 * jp1 + wr2 * jp2;
+        part[7][j] += wr1 * jd;
+        part[2][j] += w2 * jp2 * jd;
+        part[5][j] += w2 * jd * jd;
+        part[8][j] += wr2 * jd;
       }
     }
+    for (int q = 0; q < 9; ++q) acc[q][i] = combine4(part[q]);
     /* B/kernel_opt_geometry.cu:273-353 */
     float H00 = acc[0][i], H01 = acc[1][i], H02 = acc[2][i], H11 = acc[3][i], H12 = acc[4][i], H22 = acc[5][i];
     const float kEpsilon = 1e-6f;

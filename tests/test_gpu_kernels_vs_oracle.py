@@ -63,9 +63,17 @@ def _full(H21):
     return M + np.triu(M, 1).T
 
 
-@pytest.mark.parametrize("use_depth,use_desc", [(True, False), (False, True), (True, True)])
-def test_pose_coefficients(synced, use_depth, use_desc):
+def _launch_shapes(g, tile_waves, pose_parts):
+    from badslam_amd import capi
+    capi.check(g.ctx.lib.bahip_debug_set_launch_shapes(tile_waves, pose_parts))
+
+
+@pytest.mark.parametrize("use_depth,use_desc,pose_parts", [(True, False, 0), (False, True, 0), (True, True, 0), (True, True, 1),
+                                                            (True, True, 8)])
+def test_pose_coefficients(synced, use_depth, use_desc, pose_parts, request):
     ba, g = synced
+    _launch_shapes(g, 0, pose_parts)   # how many wavefronts share a tile's keyframes: any split gives the same sums
+    request.addfinalizer(lambda: _launch_shapes(g, 0, 0))
     ba.use_depth, ba.use_desc = int(use_depth), int(use_desc)
     for k in range(len(ba.keyframes)):
         F = np.array(list(ba.keyframes[k].frame_T_global), np.float32)
@@ -80,8 +88,13 @@ def test_pose_coefficients(synced, use_depth, use_desc):
         assert np.abs(x - x_ref).max() < 1e-6   # "one GN pose step 1e-6 on the tangent" 
 
 
-def test_activation_and_geometry_step(scene, synced):
+@pytest.mark.parametrize("tile_waves", [1, 4])
+def test_activation_and_geometry_step(scene, synced, tile_waves, request):
+    """Both launch shapes of the normals / geometry passes (one or four wavefronts per surfel tile) must give the
+    oracle's bits: the per-surfel sums are defined as four interleaved partial sums on both sides."""
     ba, g = synced
+    _launch_shapes(g, tile_waves, 0)
+    request.addfinalizer(lambda: _launch_shapes(g, 0, 0))
     ba.use_depth, ba.use_desc = 1, 1
     # perturb the surfels identically on both sides: move along +z and detune descriptors
     data, active = common.oracle_surfels(ba)
@@ -101,7 +114,7 @@ def test_activation_and_geometry_step(scene, synced):
     ba.optimize_geometry_iteration()
     got = g.download_surfels()
     ref = ba.surfel_data[:, :data.shape[1]]
-    # accumulation over keyframes runs in keyframe order on both sides -> bit-exact surfels
+    # same association decisions, same per-pair terms, same summation order -> bit-exact surfels
     assert np.array_equal(got[:8].view(np.uint32), ref[:8].view(np.uint32))
     # the step must actually have moved the surfels back towards the surface
     assert np.abs(ref[2] - data[2]).mean() > 1e-4
