@@ -203,6 +203,78 @@ int GeometryOptimizationWithGeometricResidual(bool use_pcg) {
   return failures;
 }
 
+// test_geometry_optimization_photometric_residual.cc:126-285 (checks :45-117)
+int GeometryOptimizationWithPhotometricResidual(bool use_pcg) {
+  int failures = 0;
+  Rng rng(4);
+  PinholeCamera4f camera(W, H, kCam);
+  const SE3f global_tr_frame_0 = Exp(0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f);
+  hipStream_t stream = nullptr;
+  BAHIP_CHECKED_CALL(bahip_stream_create(&stream));
+  constexpr float s = 1.f / 5000;
+  std::unique_ptr<DirectBA> ba(MakeBA(camera, s, 1, /*depth*/ false, /*desc*/ true, /*min_obs*/ 1));
+  constexpr int kFrameOffsetPx = 100;
+  constexpr float kDepth = 2.f;
+  Image<u16> depth(W, H);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      depth(x, y) = (x < kFrameOffsetPx || y == 0 || x == W - 1 || y == H - 1) ? 65535 : (u16)((kDepth / s) + 0.5f);
+  Image<Vec3u8> color(W, H);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const u8 i = (u8)((255 / 2.f) * (1.f + std::sin(0.15f * x + 0.5f * std::sin(0.25f * y))));
+      color(x, y) = Vec3u8(i, i, i);
+    }
+  shared_ptr<Keyframe> kf0(new Keyframe(stream, 0, ba->depth_params(), ba->depth_camera(), depth, color, global_tr_frame_0));
+  Image<u16> normals(W, H);   // fronto-parallel: ImageSpaceNormalToU16(0, 0) = 0
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) normals(x, y) = 0;
+  const_cast<CUDABuffer<u16>*>(&kf0->normals_buffer())->UploadAsync(nullptr, normals);
+  kf0->RefreshPlanes(nullptr);
+  ba->AddKeyframe(kf0);
+  // the second keyframe sees the same plane shifted by kFrameOffsetPx pixels, with depth noise (:223-234)
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      if (x == 0 || y == 0 || x >= W - kFrameOffsetPx || y == H - 1) {
+        depth(x, y) = 65535;
+      } else {
+        depth(x, y) = (u16)(depth(x + kFrameOffsetPx, y) + 0.0001f * rng.below(100) / s);
+        color(x, y) = color(x + kFrameOffsetPx, y);
+      }
+    }
+  const float offset_x = kDepth * kFrameOffsetPx / kCam[0];
+  const SE3f global_tr_frame_1 = global_tr_frame_0 * Exp(offset_x, 0, 0, 0, 0, 0);
+  shared_ptr<Keyframe> kf1(new Keyframe(stream, 1, ba->depth_params(), ba->depth_camera(), depth, color, global_tr_frame_1));
+  const_cast<CUDABuffer<u16>*>(&kf1->normals_buffer())->UploadAsync(nullptr, normals);
+  kf1->RefreshPlanes(nullptr);
+  ba->AddKeyframe(kf1);
+  ba->CreateSurfelsForKeyframe(stream, false, kf1);
+  ba->BundleAdjustment(stream, false, false, false, false, true, 60, 60, use_pcg, 0, (int)ba->keyframes().size() - 1, true);
+  const u32 n = ba->surfel_count();
+  vector<float> sx(n), sy(n), sz(n);
+  ba->surfels()->DownloadPartAsync(kSurfelX * ba->surfels()->ToCUDA().pitch(), n * sizeof(float), stream, sx.data());
+  ba->surfels()->DownloadPartAsync(kSurfelY * ba->surfels()->ToCUDA().pitch(), n * sizeof(float), stream, sy.data());
+  ba->surfels()->DownloadPartAsync(kSurfelZ * ba->surfels()->ToCUDA().pitch(), n * sizeof(float), stream, sz.data());
+  float F[12];
+  global_tr_frame_1.inverse().matrix3x4(F);
+  int num_fails = 0, num_correct = 0;
+  for (u32 i = 0; i < n; ++i) {
+    const float cx = F[0] * sx[i] + F[1] * sy[i] + F[2] * sz[i] + F[3];
+    const float cy = F[4] * sx[i] + F[5] * sy[i] + F[6] * sz[i] + F[7];
+    const float cz = F[8] * sx[i] + F[9] * sy[i] + F[10] * sz[i] + F[11];
+    if (!(cz > 0)) continue;
+    const float px = kCam[0] * cx / cz + kCam[2], py = kCam[1] * cy / cz + kCam[3];
+    if (px < 0 || py < 0 || px >= W || py >= H) continue;
+    if (std::fabs(kDepth - cz) > 1e-3f) ++num_fails; else ++num_correct;
+  }
+  EXPECT_TRUE(num_correct >= 100000, "only %d surfels within 1e-3 of the plane", num_correct);
+  EXPECT_TRUE(num_fails <= 75000, "%d surfels further than 1e-3 from the plane", num_fails);
+  printf("    %u surfels: %d within 1e-3 of the plane (>= 100000 required), %d not (<= 75000 allowed)\n", n, num_correct, num_fails);
+  ba.reset(); kf0.reset(); kf1.reset();
+  bahip_stream_destroy(stream);
+  return failures;
+}
+
 struct TestCase { const char* name; std::function<int()> fn; };
 
 }  // namespace
@@ -213,6 +285,8 @@ int main(int argc, char** argv) {
       {"PoseOptimizationColorOnlyCues", PoseOptimizationColorOnlyCues},
       {"AlternatingGeometryOptimizationWithGeometricResidual", [] { return GeometryOptimizationWithGeometricResidual(false); }},
       {"PCGGeometryOptimizationWithGeometricResidual", [] { return GeometryOptimizationWithGeometricResidual(true); }},
+      {"AlternatingGeometryOptimizationWithPhotometricResidual", [] { return GeometryOptimizationWithPhotometricResidual(false); }},
+      {"PCGGeometryOptimizationWithPhotometricResidual", [] { return GeometryOptimizationWithPhotometricResidual(true); }},
   };
   if (bahip_device_count() <= 0) { printf("no HIP device: these tests need an MI355X\n"); return 99; }
   for (const TestCase& t : tests) {
