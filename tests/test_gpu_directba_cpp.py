@@ -14,7 +14,13 @@ BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
                                   "AlternatingGeometryOptimizationWithGeometricResidual",
                                   "PCGGeometryOptimizationWithGeometricResidual",
                                   "AlternatingGeometryOptimizationWithPhotometricResidual",
-                                  "PCGGeometryOptimizationWithPhotometricResidual"])
+                                  "PCGGeometryOptimizationWithPhotometricResidual",
+                                  "AlternatingIntrinsicsOptimizationWithPhotometricResidual",
+                                  "PCGIntrinsicsOptimizationWithPhotometricResidual",
+                                  "AlternatingDepthDeformationOptimizationWithGeometricResidual",
+                                  "PCGDepthDeformationOptimizationWithGeometricResidual",
+                                  "AlternatingIntrinsicsOptimizationWithGeometricResidual",
+                                  "PCGIntrinsicsOptimizationWithGeometricResidual"])
 def test_reference_closed_loop(name):
     assert os.path.exists(BIN), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     proc = subprocess.run([BIN, name], capture_output=True, text=True, timeout=600)
