@@ -87,6 +87,11 @@ struct PcgLayout {
   uint32_t surfel_start, depth_intr_start, a_index, color_intr_start, unknown_count;
   int geom_stride;   // 3 with descriptor residuals, else 1
   int gauge;         // keyframe whose pose is held fixed
+  // Surfel sharding: the surfel block [surfel_start, surfel_end) is local to a rank, everything else (the "dense head":
+  // poses and intrinsics) is replicated after an all-reduce.  Dot products are formed as head * head_scale + local and
+  // summed over the ranks, head_scale = 1 / world (1 on a single GPU: the product is then exact and changes nothing).
+  uint32_t surfel_end;
+  float head_scale;
 };
 
 // Everything that is constant over a sweep; passed to kernels by value (kernarg -> SGPRs).

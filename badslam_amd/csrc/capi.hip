@@ -88,6 +88,9 @@ struct bahip_context {
 
   float* pcg_buf = nullptr;        // PCG vectors r, M, delta, g, p (5 * pcg_capacity floats) + 16 scalars
   size_t pcg_capacity = 0;
+  float* pcg_stage = nullptr;      // sharded PCG: staging buffer for the all-reduce of the dense head
+  size_t pcg_stage_capacity = 0;
+  int world = 0;                   // number of ranks behind the all-reduce hook (0 = not probed yet)
 
   // planes packed by the library itself for frames handed over without bahip_frame.planes:
   // slot 0 = the single frame of the per-frame entry points, slot 1 + k = bound keyframe k
@@ -266,6 +269,58 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
   return 0;
 }
 
+// Number of ranks behind the all-reduce hook: the sum of a 1 from every rank.
+int probe_world(bahip_context* ctx) {
+  if (!ctx->allreduce) { ctx->world = 1; return 0; }
+  if (ctx->world > 0) return 0;
+  const float one = 1.f;
+  HIP_TRY(hipMemcpyAsync(ctx->dev_Hb1, &one, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->allreduce(ctx->dev_Hb1, 1, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
+  float sum = 0.f;
+  HIP_TRY(hipMemcpy(&sum, ctx->dev_Hb1, sizeof(float), hipMemcpyDeviceToHost));
+  ctx->world = (int)(sum + 0.5f);
+  if (ctx->world < 1) return fail("all-reduce hook returned a rank count < 1", __FILE__, __LINE__);
+  return 0;
+}
+
+// Sharded PCG: sums the dense head (everything outside the local surfel block) of up to two vectors plus `num_scalars`
+// scalars over the ranks with ONE hook call, through a contiguous staging buffer.
+int allreduce_head(bahip_context* ctx, const PcgLayout& L, float* a, float* b, float* scalars, int num_scalars) {
+  const size_t U = L.unknown_count;
+  const size_t lo = L.optimize_geometry ? L.surfel_start : U;          // head = [0, lo) + [hi, U)
+  const size_t hi = L.optimize_geometry ? L.surfel_end : U;
+  const size_t head = lo + (U - hi);
+  const size_t total = head * (b ? 2 : 1) + (size_t)num_scalars;
+  if (total == 0) return 0;
+  if (total > ctx->pcg_stage_capacity) {
+    if (ctx->pcg_stage) hipFree(ctx->pcg_stage);
+    ctx->pcg_stage_capacity = total + 1024;
+    HIP_TRY(hipMalloc(&ctx->pcg_stage, sizeof(float) * ctx->pcg_stage_capacity));
+  }
+  hipStream_t st = ctx->stream;
+  float* stage = ctx->pcg_stage;
+  size_t at = 0;
+  float* vecs[2] = {a, b};
+  for (float* v : vecs) {
+    if (!v) continue;
+    if (lo) HIP_TRY(hipMemcpyAsync(stage + at, v, sizeof(float) * lo, hipMemcpyDeviceToDevice, st));
+    if (U > hi) HIP_TRY(hipMemcpyAsync(stage + at + lo, v + hi, sizeof(float) * (U - hi), hipMemcpyDeviceToDevice, st));
+    at += head;
+  }
+  if (num_scalars) HIP_TRY(hipMemcpyAsync(stage + at, scalars, sizeof(float) * num_scalars, hipMemcpyDeviceToDevice, st));
+  if (ctx->allreduce(stage, total, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
+  at = 0;
+  for (float* v : vecs) {
+    if (!v) continue;
+    if (lo) HIP_TRY(hipMemcpyAsync(v, stage + at, sizeof(float) * lo, hipMemcpyDeviceToDevice, st));
+    if (U > hi) HIP_TRY(hipMemcpyAsync(v + hi, stage + at + lo, sizeof(float) * (U - hi), hipMemcpyDeviceToDevice, st));
+    at += head;
+  }
+  if (num_scalars) HIP_TRY(hipMemcpyAsync(scalars, stage + at, sizeof(float) * num_scalars, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -303,7 +358,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
-  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf);
+  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
   delete ctx;
@@ -317,6 +372,7 @@ int bahip_context_synchronize(bahip_context* ctx) {
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user) {
   ctx->allreduce = fn;
   ctx->allreduce_user = user;
+  ctx->world = 0;   // probed on first use (probe_world)
   return 0;
 }
 
@@ -755,7 +811,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   *out_color_camera = ctx->color_cam;
   *out_depth_camera = ctx->depth_cam;
   *out_a = ctx->dp.a;
-  if (surfels->surfels_size == 0) return 0;
+  if (surfels->surfels_size == 0 && !ctx->allreduce) return 0;   // a rank with an empty shard still takes part in the exchange
   const int S = ctx->in.cf_width * ctx->in.cf_height;
   if (S > ctx->intr_capacity) {
     if (ctx->intr_scratch) hipFree(ctx->intr_scratch);
@@ -825,7 +881,8 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
                         bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a, int* inner_steps_out,
                         int* num_converged_out) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
-  REQUIRE(ctx->allreduce == nullptr, "the PCG scheme does not support surfel sharding yet (single GPU only)");
+  const bool sharded = ctx->allreduce != nullptr;
+  if (probe_world(ctx)) return 1;
   const int K = ctx->num_kfs;
   REQUIRE(K >= 1, "PCG needs at least one keyframe");
   const uint32_t N = surfels->surfels_size;
@@ -846,6 +903,8 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   L.color_intr_start = kInvalid;
   if (L.optimize_color_intrinsics) { L.color_intr_start = cur; cur += 4; }
   L.unknown_count = cur;
+  L.surfel_end = L.optimize_geometry ? L.surfel_start + (uint32_t)L.geom_stride * N : kInvalid;
+  L.head_scale = 1.f / (float)ctx->world;
   const size_t U = cur;
   *out_color_camera = ctx->color_cam; *out_depth_camera = ctx->depth_cam; *out_a = ctx->dp.a;
   if (inner_steps_out) *inner_steps_out = 0;
@@ -867,8 +926,10 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   HIP_TRY(hipMemsetAsync(sc, 0, sizeof(float) * 16, st));
   launch_pcg_init(st, L, ctx->in, ctx->dev_kfs, K, sv, r_, M_);
   CHECK_LAUNCH();
+  if (sharded && allreduce_head(ctx, L, r_, M_, nullptr, 0)) return 1;
   launch_pcg_init2(st, L, ctx->dp.a, r_, M_, delta, g_, p_, sc + i_an);
   CHECK_LAUNCH();
+  if (sharded && ctx->allreduce(sc + i_an, 1, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
 
   float prev_r_norm = __builtin_huge_valf();
   int no_improvement = 0, steps = 0;
@@ -881,9 +942,11 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
     }
     launch_pcg_step1(st, L, ctx->in, ctx->dev_kfs, K, sv, p_, g_, sc + 1);
     CHECK_LAUNCH();
+    if (sharded && allreduce_head(ctx, L, g_, nullptr, sc + 1, 1)) return 1;     // g head and alpha_d in one exchange
     HIP_TRY(hipMemsetAsync(sc + i_bn, 0, sizeof(float), st));
     launch_pcg_step2(st, L, r_, M_, delta, g_, p_, sc + i_an, sc + 1, sc + i_bn);
     CHECK_LAUNCH();
+    if (sharded && ctx->allreduce(sc + i_bn, 1, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
     HIP_TRY(hipMemcpyAsync(ctx->pinned_f, sc + i_bn, sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const float r_norm = sqrtf(ctx->pinned_f[0]);

@@ -27,6 +27,11 @@ __device__ __forceinline__ uint32_t kf_pose_index(const PcgLayout& L, int k) {
   if (k == L.gauge) return 0xffffffffu;
   return (k < L.gauge) ? 6u * (uint32_t)k : 6u * (uint32_t)(k - 1);
 }
+// Weight of unknown u in a dot product that is summed over the ranks (PcgLayout::head_scale).
+__device__ __forceinline__ float dot_weight(const PcgLayout& L, uint32_t u) {
+  const bool local = L.optimize_geometry && u >= L.surfel_start && u < L.surfel_end;
+  return local ? 1.f : L.head_scale;
+}
 __device__ __forceinline__ float prior_at(const PcgLayout& L, uint32_t u) {
   return (u == L.a_index) ? (kAPriorWeight * kAPriorWeight) : 0.f;
 }
@@ -254,7 +259,7 @@ pcg_init2_kernel(PcgLayout L, float a, const float* __restrict__ r_, const float
     const float p_value = r_value / (M_[u] + kDiagEpsilon + prior_at(L, u));
     p_[u] = p_value;
     delta[u] = 0;
-    term = r_value * p_value;
+    term = dot_weight(L, u) * (r_value * p_value);
   }
   block_atomic_sum(alpha_n, term);
 }
@@ -402,7 +407,7 @@ __global__ void __launch_bounds__(kPcgBlock)
 pcg_eps_terms_kernel(PcgLayout L, const float* __restrict__ p_, float repeat, float* alpha_d) {
   const uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x;
   float term = 0.f;
-  if (u < L.unknown_count) { const float pv = p_[u]; term = (kDiagEpsilon + prior_at(L, u)) * pv * pv; }
+  if (u < L.unknown_count) { const float pv = p_[u]; term = dot_weight(L, u) * ((kDiagEpsilon + prior_at(L, u)) * pv * pv); }
   block_atomic_sum(alpha_d, repeat * term);
 }
 
@@ -422,7 +427,7 @@ pcg_step2_kernel(PcgLayout L, float* __restrict__ r_, const float* __restrict__ 
     r_[u] = r_value;
     const float z_value = r_value / (M_[u] + kDiagEpsilon + prior_at(L, u));
     g_[u] = z_value;
-    term = z_value * r_value;
+    term = dot_weight(L, u) * (z_value * r_value);
   }
   block_atomic_sum(beta_n, term);
 }

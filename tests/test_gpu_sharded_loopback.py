@@ -1,0 +1,169 @@
+"""The multi-GPU decomposition exercised end to end on ONE GPU: two "ranks" (threads, one backend context each)
+hold complementary chunk-cyclic surfel shards of the same scene and run the alternating scheme in lockstep; the
+all-reduce hook of the C ABI is served by an in-process loopback that sums the two ranks' device buffers (what RCCL
+does between GPUs - RCCL itself refuses two ranks on one device).  The sharded run must reproduce the unsharded one:
+surfels are local to their shard, poses come from the summed normal equations."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+WORLD = 2
+ITERATIONS = 3
+
+
+def _ba_iteration(g, use_depth=True, use_desc=True):
+    from badslam_amd import capi
+    for kf in g.keyframes:
+        kf["activation"] = capi.KF_ACTIVE
+    g.bind_keyframes()
+    g.update_surfel_activation()
+    g.optimize_geometry_iteration(use_depth, use_desc)
+    poses, its, conv, rounds = g.estimate_keyframe_poses(use_depth, use_desc)
+    for k, kf in enumerate(g.keyframes):
+        kf["pose"] = poses[k].astype(np.float32)
+    return rounds
+
+
+class _Loopback:
+    """Sum-all-reduce between WORLD host threads that share one device."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.ptrs = [None] * world
+        self.calls = 0
+
+    def hook_for(self, rank):
+        import torch
+        from badslam_amd import capi, multigpu
+
+        def _hook(device_ptr, count, _user):
+            try:
+                self.ptrs[rank] = (device_ptr, count)
+                self.barrier.wait(timeout=60)
+                if rank == 0:
+                    views = [torch.as_tensor(multigpu._DevicePtrView(p, n), device="cuda") for p, n in self.ptrs]
+                    total = views[0].clone()
+                    for v in views[1:]:       # fixed rank order
+                        total += v
+                    for v in views:
+                        v.copy_(total)
+                    torch.cuda.synchronize()
+                    self.calls += 1
+                self.barrier.wait(timeout=60)
+                return 0
+            except Exception as e:   # surfaces as a bahip error in the calling thread
+                print("loopback all-reduce failed:", e, flush=True)
+                self.barrier.abort()
+                return 1
+
+        return capi.ALLREDUCE_FN(_hook)
+
+
+def _run_sharded_and_unsharded(step, seed=9):
+    """Runs ITERATIONS x step(scene) on the whole cloud and on WORLD complementary shards in lockstep.
+    Returns (reference dict, per-rank dicts, loopback, number of surfels)."""
+    import torch
+    from badslam_amd import capi, multigpu
+    torch.cuda.set_device(0)
+    scene = common.small_scene(num_keyframes=5, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(2))
+    start_poses = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+
+    # unsharded reference run (surfels created at the ground-truth poses, then displaced)
+    g = common.build_gpu(scene, 500000)
+    data = g.download_surfels()
+    data[2] += rng.uniform(0, 0.004, data.shape[1]).astype(np.float32)
+    N = data.shape[1]
+    g.upload_surfels(data, np.ones(N, np.uint8))
+    for k, T in enumerate(start_poses):
+        g.keyframes[k]["pose"] = np.asarray(T, np.float32)
+    ref = dict(out=[step(g) for _ in range(ITERATIONS)], surfels=g.download_surfels(), poses=[kf["pose"].copy() for kf in g.keyframes],
+               scene=g)
+
+    loop = _Loopback(WORLD)
+    results, errors = [None] * WORLD, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            gr = common.build_gpu(scene, 500000, create_from=[])
+            mine = multigpu.shard_chunks(N, rank, WORLD, chunk=1024)
+            gr.upload_surfels(np.ascontiguousarray(data[:, mine]), np.ones(mine.size, np.uint8))
+            for k, T in enumerate(start_poses):
+                gr.keyframes[k]["pose"] = np.asarray(T, np.float32)
+            hook = loop.hook_for(rank)
+            capi.check(gr.ctx.lib.bahip_context_set_allreduce(gr.ctx.handle, hook, None))
+            out = [step(gr) for _ in range(ITERATIONS)]
+            results[rank] = dict(mine=mine, surfels=gr.download_surfels(), poses=[kf["pose"].copy() for kf in gr.keyframes],
+                                 out=out, keep=hook, scene=gr)
+        except Exception as e:
+            errors.append((rank, repr(e)))
+            loop.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    return ref, results, loop, N
+
+
+def test_two_shards_reproduce_the_unsharded_run():
+    ref, results, loop, N = _run_sharded_and_unsharded(_ba_iteration)
+    rounds_ref, ref_poses, ref_surfels = ref["out"], ref["poses"], ref["surfels"]
+    for r in results:
+        r["rounds"] = r["out"]
+    assert loop.calls == sum(rounds_ref)                      # one exchange per Gauss-Newton round, nothing else
+    # every rank took the same number of rounds and ended at the same poses (they see the same summed equations)
+    assert results[0]["rounds"] == results[1]["rounds"] == rounds_ref
+    for k in range(len(ref_poses)):
+        assert np.array_equal(results[0]["poses"][k], results[1]["poses"][k])
+        err = common.pose_error(ref_poses[k], results[0]["poses"][k])
+        assert np.abs(err).max() < 1e-6, (k, err)             # float sums in a different order, nothing more
+    # the union of the shards is the unsharded cloud
+    merged = np.zeros_like(ref_surfels)
+    for r in results:
+        merged[:, r["mine"]] = r["surfels"]
+    # per-surfel work is local and deterministic; only the 1e-7 pose differences of later iterations can move a result
+    same_normal = merged[3].view(np.uint32) == ref_surfels[3].view(np.uint32)
+    assert same_normal.mean() > 0.999
+    close = np.abs(merged[:3] - ref_surfels[:3]).max(axis=0) < 1e-5
+    assert close.mean() > 0.999, close.mean()
+    assert np.median(np.abs(merged[6:8] - ref_surfels[6:8])) < 1e-3                            # descriptors (range +-180)
+
+
+def test_sharded_pcg_and_intrinsics_follow_the_unsharded_run():
+    """PCG scheme (dense head of r / M / g and the three scalars of every inner step summed over the ranks) and the
+    alternating intrinsics step (Schur accumulators summed over the ranks) on two shards."""
+    def step(g):
+        g.bind_keyframes()
+        g.update_surfel_normals()
+        steps, _ = g.pcg_iteration(optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=True,
+                                   optimize_color_intrinsics=True, max_inner_iterations=10)
+        g.bind_keyframes()
+        g.optimize_intrinsics(True, True)
+        return steps
+
+    ref, results, loop, N = _run_sharded_and_unsharded(step, seed=10)
+    assert results[0]["out"] == results[1]["out"]                       # same number of inner steps on every rank
+    for k in range(len(ref["poses"])):
+        assert np.array_equal(results[0]["poses"][k], results[1]["poses"][k])
+        err = common.pose_error(ref["poses"][k], results[0]["poses"][k])
+        assert np.abs(err).max() < 2e-4, (k, err)                       # float CG: same tolerance as PCG vs the oracle
+    for which in ("color_cam", "depth_cam"):
+        a, b, c = (getattr(x["scene"], which) for x in (results[0], results[1], ref))
+        assert (a.fx, a.fy, a.cx, a.cy) == (b.fx, b.fy, b.cx, b.cy)
+        assert max(abs(a.fx - c.fx), abs(a.fy - c.fy), abs(a.cx - c.cx), abs(a.cy - c.cy)) < 2e-2
+    merged = np.zeros_like(ref["surfels"])
+    for r in results:
+        merged[:, r["mine"]] = r["surfels"]
+    assert np.median(np.abs(merged[:3] - ref["surfels"][:3])) < 1e-5
