@@ -48,7 +48,8 @@ void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEnt
 // kernels_intrinsics.hip
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
                                   const SurfelsView& s, float* glob, float* B, float* D, float* b2, float* obs, int S);
-void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* B, float* D, const float* b2);
+size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_schur needs
+void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* B, float* D, const float* b2, float* partials);
 void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, const float* obs, const float* B, const float* D,
                                    const float* x1, float* cfactor, uint32_t cfactor_pitch);
 

@@ -816,7 +816,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   if (S > ctx->intr_capacity) {
     if (ctx->intr_scratch) hipFree(ctx->intr_scratch);
     ctx->intr_capacity = S + 1024;
-    HIP_TRY(hipMalloc(&ctx->intr_scratch, sizeof(float) * (64 + 8 * (size_t)ctx->intr_capacity)));
+    HIP_TRY(hipMalloc(&ctx->intr_scratch, sizeof(float) * (64 + 8 * (size_t)ctx->intr_capacity + intrinsics_schur_partials(ctx->intr_capacity))));
   }
   float* glob = ctx->intr_scratch;            // 34 sums + x1 at [40..44]
   float* B = glob + 64;                       // 5 * S
@@ -830,7 +830,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   if (ctx->allreduce && ctx->allreduce(glob, 64 + 8 * (size_t)S, ctx->allreduce_user) != 0)
     return fail("all-reduce hook failed", __FILE__, __LINE__);
   if (optimize_depth) {
-    launch_intrinsics_schur(ctx->stream, S, glob, B, D, b2);
+    launch_intrinsics_schur(ctx->stream, S, glob, B, D, b2, obs + ctx->intr_capacity /* past the all-reduced block */);
     CHECK_LAUNCH();
   }
   HIP_TRY(hipMemcpyAsync(ctx->pinned_f, glob, 34 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

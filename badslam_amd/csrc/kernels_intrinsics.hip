@@ -119,9 +119,13 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
   if (lane < 34 && mine != 0.f) unsafeAtomicAdd(&glob[lane], mine);
 }
 
-// Schur complement: B/kernel_opt_intrinsics.cu:266-350.  One thread per sparse cell.
+// Schur complement: B/kernel_opt_intrinsics.cu:266-350.  One thread per sparse cell.  This runs AFTER the multi-GPU
+// all-reduce of the accumulators, on every rank, so it must give every rank the same bits: the 20 sums over the cells are
+// formed without atomics - a fixed cross-lane tree per wavefront (wave_sum), one partial per wavefront, then
+// intrinsics_schur_finish_kernel adds the partials in wavefront order.
 __global__ void __launch_bounds__(kIntrBlock)
-intrinsics_schur_kernel(int S, float* __restrict__ glob, float* __restrict__ B, float* __restrict__ D, const float* __restrict__ b2) {
+intrinsics_schur_kernel(int S, float* __restrict__ partials /* [wavefronts][20] */, float* __restrict__ B, float* __restrict__ D,
+                        const float* __restrict__ b2) {
   const int cell = blockIdx.x * kIntrBlock + threadIdx.x;
   float part[20];
 #pragma unroll
@@ -154,7 +158,16 @@ intrinsics_schur_kernel(int S, float* __restrict__ glob, float* __restrict__ B, 
     const float v = wave_sum(part[q]);
     if (lane == q) mine = v;
   }
-  if (lane < 20 && mine != 0.f) unsafeAtomicAdd(&glob[lane], mine);
+  const int wave = (blockIdx.x * kIntrBlock + threadIdx.x) >> 6;
+  if (lane < 20) partials[(size_t)wave * 20 + lane] = mine;
+}
+__global__ void __launch_bounds__(64)
+intrinsics_schur_finish_kernel(int num_waves, const float* __restrict__ partials, float* __restrict__ glob) {
+  const int q = threadIdx.x;
+  if (q >= 20) return;
+  float total = 0.f;
+  for (int w = 0; w < num_waves; ++w) total += partials[(size_t)w * 20 + q];
+  glob[q] += total;
 }
 
 // Back-substitution: B/kernel_opt_intrinsics.cu:375-423
@@ -186,8 +199,11 @@ void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const 
   else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, B, D, b2, obs, S);
   else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, B, D, b2, obs, S);
 }
-void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* B, float* D, const float* b2) {
-  hipLaunchKernelGGL(intrinsics_schur_kernel, dim3((S + kIntrBlock - 1) / kIntrBlock), dim3(kIntrBlock), 0, st, S, glob, B, D, b2);
+size_t intrinsics_schur_partials(int S) { return 20 * (size_t)((S + kIntrBlock - 1) / kIntrBlock) * (kIntrBlock / 64); }
+void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* B, float* D, const float* b2, float* partials) {
+  const int blocks = (S + kIntrBlock - 1) / kIntrBlock;
+  hipLaunchKernelGGL(intrinsics_schur_kernel, dim3(blocks), dim3(kIntrBlock), 0, st, S, partials, B, D, b2);
+  hipLaunchKernelGGL(intrinsics_schur_finish_kernel, dim3(1), dim3(64), 0, st, blocks * (kIntrBlock / 64), partials, glob);
 }
 void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, const float* obs, const float* B, const float* D,
                                    const float* x1, float* cfactor, uint32_t cfactor_pitch) {

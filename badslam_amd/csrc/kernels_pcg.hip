@@ -18,7 +18,9 @@
 
 namespace bahip {
 
-constexpr int kPcgBlock = 256;
+constexpr int kPcgBlock = 256;     // per-unknown vector kernels
+constexpr int kPcgSweepBlock = 64; // surfel sweeps (init, step 1): one wavefront per workgroup, like kernels_surfel.hip
+#define BAHIP_PCG_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(4)))   // 128-VGPR cap: 4 waves per SIMD
 constexpr float kDiagEpsilon = 1e-8f;   // B/kernel_pcg.cu:44
 constexpr float kAPriorWeight = 10.f;   // B/kernel_pcg.cu:48
 
@@ -127,10 +129,10 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
 
 // ---- PCGInit: r -= J^T W F, M += diag(J^T W J)  (B/kernel_pcg.cu:179-541) -----------------------------
 template <bool kDepthIntr, bool kColorIntr>
-__global__ void __launch_bounds__(kPcgBlock)
+__global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
 pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
                 float* __restrict__ r_, float* __restrict__ M_) {
-  const uint32_t i = blockIdx.x * kPcgBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -266,10 +268,10 @@ pcg_init2_kernel(PcgLayout L, float a, const float* __restrict__ r_, const float
 
 // ---- PCGStep1: g += J^T W J p, alpha_d += p^T J^T W J p  (B/kernel_pcg.cu:646-1026) -------------------
 template <bool kDepthIntr, bool kColorIntr>
-__global__ void __launch_bounds__(kPcgBlock)
+__global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
 pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
                  const float* __restrict__ p_, float* __restrict__ g_, float* alpha_d) {
-  const uint32_t i = blockIdx.x * kPcgBlock + threadIdx.x;
+  const uint32_t i = blockIdx.x * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -474,10 +476,12 @@ pcg_update_cfactors_kernel(Intrinsics in, uint32_t start, const float* __restric
 // ---- launchers -----------------------------------------------------------------------------------------------
 static inline unsigned gU(uint32_t n) { return (n + kPcgBlock - 1) / kPcgBlock; }
 
+static inline unsigned gS(uint32_t n) { return (n + kPcgSweepBlock - 1) / kPcgSweepBlock; }
+
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                      float* r, float* M) {
   if (!s.size) return;
-  const dim3 grid(gU(s.size)), block(kPcgBlock);
+  const dim3 grid(gS(s.size)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
   if (di && ci) hipLaunchKernelGGL((pcg_init_kernel<true, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, r, M);
   else if (di) hipLaunchKernelGGL((pcg_init_kernel<true, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, r, M);
@@ -491,7 +495,7 @@ void launch_pcg_init2(hipStream_t st, const PcgLayout& L, float a, const float* 
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                       const float* p, float* g, float* alpha_d) {
   if (!s.size) return;
-  const dim3 grid(gU(s.size)), block(kPcgBlock);
+  const dim3 grid(gS(s.size)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
   if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
   else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
