@@ -78,6 +78,8 @@ SIGNATURES = {
     "bahip_memcpy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "bahip_memset_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "bahip_fill_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int]),
+    "bahip_bilateral_filtering_and_depth_cutoff": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint16, C.c_float,
+                                                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
     "bahip_compute_brightness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
     "bahip_compute_normals": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(DepthParams), C.c_void_p, C.c_uint32,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),

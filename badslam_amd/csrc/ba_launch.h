@@ -12,6 +12,8 @@ struct SupportingView {
 };
 
 // kernels_preprocess.hip
+int launch_bilateral_filter(hipStream_t stream, float sigma_xy, float sigma_value, float radius_factor, uint16_t max_depth,
+                            float raw_to_float_depth, const uint16_t* in, uint32_t in_pitch, uint16_t* out, uint32_t out_pitch, int w, int h);
 void launch_brightness(hipStream_t stream, const uint8_t* rgb, uint32_t rgb_pitch, uint8_t* rgba, uint32_t rgba_pitch, int w, int h);
 void launch_normals_from_depth(hipStream_t stream, const Intrinsics& in, const uint16_t* in_depth, uint32_t in_pitch,
                                uint16_t* out_depth, uint32_t out_pitch, uint16_t* out_normals, uint32_t normals_pitch);

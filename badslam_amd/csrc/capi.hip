@@ -461,6 +461,17 @@ int bahip_fill_2d(void* stream, void* data, size_t pitch_bytes, int elem_bytes, 
 }
 
 // ---- preprocessing ---------------------------------------------------------------------------------
+int bahip_bilateral_filtering_and_depth_cutoff(bahip_context* ctx, float sigma_xy, float sigma_value, float radius_factor,
+                                               uint16_t max_depth, float raw_to_float_depth, const uint16_t* in_depth, uint32_t in_pitch,
+                                               uint16_t* out_depth, uint32_t out_pitch, int width, int height) {
+  REQUIRE(in_depth != out_depth, "bilateral filtering cannot run in place");
+  REQUIRE(launch_bilateral_filter(ctx->stream, sigma_xy, sigma_value, radius_factor, max_depth, raw_to_float_depth, in_depth, in_pitch,
+                                  out_depth, out_pitch, width, height) == 0,
+          "bilateral filter radius (radius_factor * sigma_xy) must be in [0, 8] pixels");
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int bahip_compute_brightness(bahip_context* ctx, const uint8_t* rgb, uint32_t rgb_pitch, uint8_t* rgba, uint32_t rgba_pitch,
                              int width, int height) {
   launch_brightness(ctx->stream, rgb, rgb_pitch, rgba, rgba_pitch, width, height);

@@ -22,6 +22,46 @@ brightness_kernel(const uint8_t* __restrict__ rgb, uint32_t rgb_pitch, uint8_t* 
   *reinterpret_cast<uchar4*>(rgba + (size_t)y * rgba_pitch + 4 * x) = make_uchar4(r, g, b, intensity);
 }
 
+// B/cuda_depth_processing.cu:42-128 (BadSlam::PreprocessFrame runs it on every incoming depth image, B/bad_slam.cc:697-706).
+// A 64x4 block stages its (64 + 2r) x (4 + 2r) neighbourhood in LDS once; every pixel then reads its (2r+1)^2 window
+// from there instead of issuing up to 49 global halfword loads.
+constexpr int kBilateralMaxRadius = 8;
+__global__ void __launch_bounds__(kPxBlockX* kPxBlockY)
+bilateral_filter_kernel(float denom_xy, float denom_value, int radius, int radius_squared, uint16_t max_depth, float raw_to_float_depth,
+                        const uint16_t* __restrict__ in, uint32_t in_pitch, uint16_t* __restrict__ out, uint32_t out_pitch, int width,
+                        int height) {
+  __shared__ uint16_t tile[(kPxBlockY + 2 * kBilateralMaxRadius) * (kPxBlockX + 2 * kBilateralMaxRadius)];
+  const int tw = kPxBlockX + 2 * radius, th = kPxBlockY + 2 * radius;
+  const int x0 = blockIdx.x * kPxBlockX - radius, y0 = blockIdx.y * kPxBlockY - radius;
+  for (int t = threadIdx.y * kPxBlockX + threadIdx.x; t < tw * th; t += kPxBlockX * kPxBlockY) {
+    const int tx = t % tw, ty = t / tw, gx = x0 + tx, gy = y0 + ty;
+    tile[t] = (gx >= 0 && gy >= 0 && gx < width && gy < height) ? pitched_load(in, in_pitch, gy, gx) : (uint16_t)0;   // 0 = "no sample"
+  }
+  __syncthreads();
+  const int x = blockIdx.x * kPxBlockX + threadIdx.x, y = blockIdx.y * kPxBlockY + threadIdx.y;
+  if (x >= width || y >= height) return;
+  uint16_t* o = pitched_ptr(out, out_pitch, y, x);
+  const uint16_t center_value = tile[(threadIdx.y + radius) * tw + threadIdx.x + radius];
+  if (center_value == 0 || center_value > max_depth) { *o = kUnknownDepth; return; }
+  const float inv_center_value = 1.0f / (raw_to_float_depth * center_value);
+  float sum = 0, weight = 0;
+  // the reference clips the window to the image; outside pixels are zeros in the tile and are skipped like missing samples
+  for (int dy = -radius; dy <= radius; ++dy)
+    for (int dx = -radius; dx <= radius; ++dx) {
+      const int grid_distance_squared = dx * dx + dy * dy;
+      if (grid_distance_squared > radius_squared) continue;
+      const uint16_t sample = tile[(threadIdx.y + radius + dy) * tw + threadIdx.x + radius + dx];
+      if (sample == 0) continue;
+      const float inv_sample = 1.0f / (raw_to_float_depth * sample);
+      float value_distance_squared = inv_center_value - inv_sample;
+      value_distance_squared *= value_distance_squared;
+      const float w = expf(-grid_distance_squared / denom_xy + -value_distance_squared / denom_value);
+      sum += w * inv_sample;
+      weight += w;
+    }
+  *o = (weight == 0) ? kUnknownDepth : (uint16_t)(1.0f / (raw_to_float_depth * sum / weight));
+}
+
 // B/cuda_depth_processing.cu:134-264
 __global__ void __launch_bounds__(kPxBlockX* kPxBlockY)
 normals_from_depth_kernel(Intrinsics in, const uint16_t* __restrict__ in_depth, uint32_t in_pitch,
@@ -144,6 +184,14 @@ min_max_depth_kernel(const uint16_t* __restrict__ depth, uint32_t depth_pitch, i
 
 static inline dim3 px_grid(int w, int h) { return dim3((w + kPxBlockX - 1) / kPxBlockX, (h + kPxBlockY - 1) / kPxBlockY); }
 
+int launch_bilateral_filter(hipStream_t stream, float sigma_xy, float sigma_value, float radius_factor, uint16_t max_depth,
+                            float raw_to_float_depth, const uint16_t* in, uint32_t in_pitch, uint16_t* out, uint32_t out_pitch, int w, int h) {
+  const int radius = (int)(radius_factor * sigma_xy + 0.5f);
+  if (radius < 0 || radius > kBilateralMaxRadius) return 1;
+  hipLaunchKernelGGL(bilateral_filter_kernel, px_grid(w, h), dim3(kPxBlockX, kPxBlockY), 0, stream, 2.0f * sigma_xy * sigma_xy,
+                     2.0f * sigma_value * sigma_value, radius, radius * radius, max_depth, raw_to_float_depth, in, in_pitch, out, out_pitch, w, h);
+  return 0;
+}
 void launch_brightness(hipStream_t stream, const uint8_t* rgb, uint32_t rgb_pitch, uint8_t* rgba, uint32_t rgba_pitch, int w, int h) {
   hipLaunchKernelGGL(brightness_kernel, px_grid(w, h), dim3(kPxBlockX, kPxBlockY), 0, stream, rgb, rgb_pitch, rgba, rgba_pitch, w, h);
 }

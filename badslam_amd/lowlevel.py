@@ -67,6 +67,18 @@ class Context:
             self.handle = None
 
 
+def bilateral_filtering_and_depth_cutoff(ctx, depth_u16, sigma_xy, sigma_value, radius_factor, max_depth, raw_to_float_depth):
+    """BadSlam::PreprocessFrame's depth filter on a host image (upload, filter on the GPU, download)."""
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    src = DeviceBuffer2D(ctx, d.shape[0], d.shape[1], np.uint16)
+    dst = DeviceBuffer2D(ctx, d.shape[0], d.shape[1], np.uint16)
+    src.upload(d)
+    capi.check(ctx.lib.bahip_bilateral_filtering_and_depth_cutoff(ctx.handle, sigma_xy, sigma_value, radius_factor, int(max_depth),
+                                                                  raw_to_float_depth, src.ptr, src.pitch, dst.ptr, dst.pitch,
+                                                                  d.shape[1], d.shape[0]))
+    return dst.download()
+
+
 def make_camera(params, width, height):
     p = np.asarray(params, dtype=np.float32)
     return capi.Camera(float(p[0]), float(p[1]), float(p[2]), float(p[3]), int(width), int(height))

@@ -119,6 +119,15 @@ int bahip_memset_async(void* hip_stream, void* dst, int value, size_t bytes);
 /* CUDABuffer<T>::Clear(value, stream) (libvis/src/libvis/cuda/cuda_buffer.cu:41-60) for 1/2/4-byte T. */
 int bahip_fill_2d(void* hip_stream, void* data, size_t pitch_bytes, int elem_bytes, uint32_t value_bits, int width, int height);
 
+/* ---- frame preprocessing (BadSlam::PreprocessFrame, B/bad_slam.cc:643-765) --------------------- */
+/* B/cuda_depth_processing.cu:42-128 BilateralFilteringAndDepthCutoffCUDA: raw depth 0 or > max_depth -> 65535 (unknown),
+ * else the bilateral filter in inverse depth over a disc of radius int(radius_factor * sigma_xy + 0.5) <= 8 pixels.
+ * Not in place. */
+int bahip_bilateral_filtering_and_depth_cutoff(bahip_context* ctx, float sigma_xy, float sigma_value, float radius_factor,
+                                               uint16_t max_depth, float raw_to_float_depth, const uint16_t* in_depth,
+                                               uint32_t in_pitch_bytes, uint16_t* out_depth, uint32_t out_pitch_bytes, int width,
+                                               int height);
+
 /* ---- keyframe preprocessing (Keyframe ctor #2, B/keyframe.cc:96-144) ------------------------- */
 /* B/cuda_image_processing.cu:165-193 ComputeBrightnessCUDA: uchar3 RGB -> uchar4 (R,G,B,luma). */
 int bahip_compute_brightness(bahip_context* ctx, const uint8_t* rgb, uint32_t rgb_pitch_bytes,

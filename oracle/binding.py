@@ -109,6 +109,9 @@ def lib():
         build()
         L = C.CDLL(_LIB_PATH)
         L.orc_sample_luma.restype = C.c_float
+        L.orc_bilateral_filter_and_depth_cutoff.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint16, C.c_float, C.c_void_p,
+                                                            C.c_int, C.c_int, C.c_void_p]
+        L.orc_bilateral_filter_and_depth_cutoff.restype = None
         L.orc_sample_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         L.orc_raw_to_calibrated_depth.restype = C.c_float
         L.orc_raw_to_calibrated_depth.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint16]
@@ -133,6 +136,15 @@ def lib():
 
 def _ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def bilateral_filter_and_depth_cutoff(depth_u16, sigma_xy, sigma_value, radius_factor, max_depth, raw_to_float_depth):
+    import numpy as np
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    out = np.empty_like(d)
+    lib().orc_bilateral_filter_and_depth_cutoff(sigma_xy, sigma_value, radius_factor, int(max_depth), raw_to_float_depth, d.ctypes.data,
+                                                d.shape[1], d.shape[0], out.ctypes.data)
+    return out
 
 
 def make_camera(params, width, height):

@@ -107,6 +107,12 @@ void orc_se3_rotation(const orc_se3* T, float r[9]);
 /* B/keyframe.h:160-172 */
 void orc_keyframe_set_global_T_frame(orc_keyframe* kf, const orc_se3* global_T_frame);
 
+/* ---- frame preprocessing ahead of the keyframe (BadSlam::PreprocessFrame, B/bad_slam.cc:697-706) ---- */
+/* B/cuda_depth_processing.cu:42-128 BilateralFilteringAndDepthCutoffCUDA (radius = int(radius_factor * sigma_xy + 0.5)) */
+void orc_bilateral_filter_and_depth_cutoff(float sigma_xy, float sigma_value, float radius_factor, uint16_t max_depth,
+                                           float raw_to_float_depth, const uint16_t* in_depth, int width, int height,
+                                           uint16_t* out_depth);
+
 /* ---- keyframe preprocessing (B/keyframe.cc:81-158) ---- */
 /* B/cuda_image_processing.cu:165-175 */
 void orc_compute_brightness(const uint8_t* rgb, int width, int height, uint8_t* rgba);

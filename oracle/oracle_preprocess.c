@@ -12,6 +12,42 @@ void orc_compute_brightness(const uint8_t* rgb, int width, int height, uint8_t* 
   }
 }
 
+/* B/cuda_depth_processing.cu:42-128 */
+void orc_bilateral_filter_and_depth_cutoff(float sigma_xy, float sigma_value, float radius_factor, uint16_t max_depth,
+                                           float raw_to_float_depth, const uint16_t* in_depth, int width, int height,
+                                           uint16_t* out_depth) {
+  const float denom_xy = 2.0f * sigma_xy * sigma_xy, denom_value = 2.0f * sigma_value * sigma_value;
+  const int radius = (int)(radius_factor * sigma_xy + 0.5f);
+  const int radius_squared = radius * radius;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      const uint16_t center_value = in_depth[(size_t)y * width + x];
+      if (center_value == 0 || center_value > max_depth) { out_depth[(size_t)y * width + x] = ORC_UNKNOWN_DEPTH; continue; }
+      const float inv_center_value = 1.0f / (raw_to_float_depth * center_value);
+      float sum = 0, weight = 0;
+      const int min_y = y - radius > 0 ? y - radius : 0, max_y = y + radius < height - 1 ? y + radius : height - 1;
+      const int min_x = x - radius > 0 ? x - radius : 0, max_x = x + radius < width - 1 ? x + radius : width - 1;
+      for (int sy = min_y; sy <= max_y; ++sy) {
+        const int dy = sy - y;
+        for (int sx = min_x; sx <= max_x; ++sx) {
+          const int dx = sx - x;
+          const int grid_distance_squared = dx * dx + dy * dy;
+          if (grid_distance_squared > radius_squared) continue;
+          const uint16_t sample = in_depth[(size_t)sy * width + sx];
+          if (sample == 0) continue;
+          const float inv_sample = 1.0f / (raw_to_float_depth * sample);
+          float value_distance_squared = inv_center_value - inv_sample;
+          value_distance_squared *= value_distance_squared;
+          const float w = expf(-grid_distance_squared / denom_xy + -value_distance_squared / denom_value);
+          sum += w * inv_sample;
+          weight += w;
+        }
+      }
+      out_depth[(size_t)y * width + x] = (weight == 0) ? ORC_UNKNOWN_DEPTH : (uint16_t)(1.0f / (raw_to_float_depth * sum / weight));
+    }
+}
+
 static inline float calib_at(const orc_depth_params* dp, int x, int y, uint16_t raw) {
   return orc_raw_to_calibrated_depth(dp->a, cfactor_at(dp, x, y), dp->raw_to_float_depth, raw);
 }

@@ -207,3 +207,28 @@ def test_descriptor_surfel_jacobian_is_gradient_times_projection_jacobian():
             # the reference's sign convention: position update is p -= x0 * n with J = -(g . dpi/dt)... verify magnitude + sign
             worst = max(worst, abs(g @ dpi - ref) / max(1.0, abs(ref)))
     assert worst < 2e-3, worst
+
+
+def test_bilateral_filter_and_depth_cutoff_properties():
+    """B/cuda_depth_processing.cu:42-128 restated: cutoff, holes, constancy, edge preservation."""
+    rng = np.random.default_rng(3)
+    s = 1.0 / 5000
+    H, W = 48, 64
+    depth = np.full((H, W), 10000, np.uint16)          # 2 m everywhere
+    depth[5, 7] = 0                                     # hole
+    depth[20:, 40:] = 20000                             # 4 m: beyond the 3 m cutoff
+    depth[30, 10] = 10050                               # 1 cm bump
+    out = ob.bilateral_filter_and_depth_cutoff(depth, 1.5, 0.005, 2.0, int(3.0 / s), s)
+    assert out[5, 7] == 65535 and (out[20:, 40:] == 65535).all()           # unknown-depth marker
+    far = out[:15, 12:30]                                                   # away from the hole and the cutoff region
+    assert np.abs(far.astype(int) - 10000).max() <= 1                       # a constant stays constant (float round trip)
+    assert 10000 <= out[30, 10] < 10050                                     # the bump is smoothed towards its neighbours
+    # a step much larger than sigma_value in inverse depth survives: 1 m next to 2 m
+    step = np.full((H, W), 10000, np.uint16)
+    step[:, :32] = 5000
+    out = ob.bilateral_filter_and_depth_cutoff(step, 1.5, 0.005, 2.0, 15000, s)
+    assert np.abs(out[:, 31].astype(int) - 5000).max() <= 1 and np.abs(out[:, 32].astype(int) - 10000).max() <= 1
+    # noise is reduced
+    noisy = (10000 + rng.integers(-20, 21, (H, W))).astype(np.uint16)
+    out = ob.bilateral_filter_and_depth_cutoff(noisy, 1.5, 0.005, 2.0, 15000, s)
+    assert out[4:-4, 4:-4].astype(float).std() < 0.5 * noisy[4:-4, 4:-4].astype(float).std()

@@ -166,3 +166,25 @@ def test_wave_reductions():
             for s in (32, 16, 8, 4, 2, 1):
                 v = v + v[np.arange(64) ^ s]
             assert np.array_equal(out[28:], v[17])
+
+
+def test_bilateral_filter_matches_oracle(scene):
+    """Frame preprocessing ahead of the keyframe (BadSlam::PreprocessFrame): same raw depth through the HIP filter and the
+    oracle.  Both evaluate the same binary32 expressions except expf (device library vs glibc, each within 1 ulp), so a
+    filtered depth may differ by one raw unit where the float result sits on a truncation boundary."""
+    from badslam_amd import lowlevel
+    from oracle import binding as ob
+    ctx = lowlevel.Context()
+    rng = np.random.default_rng(8)
+    raw = scene.depth[0].copy()
+    raw[raw == 65535] = 0                                         # a sensor reports 0 for "no measurement"
+    raw = np.where(raw > 0, raw + rng.integers(-15, 16, raw.shape), 0).astype(np.uint16)
+    s = scene.raw_to_float_depth
+    for sigma_xy, radius_factor, max_depth_m in ((1.5, 2.0, 3.0), (3.0, 2.5, 2.6)):
+        ref = ob.bilateral_filter_and_depth_cutoff(raw, sigma_xy, 0.005, radius_factor, int(max_depth_m / s), s)
+        got = lowlevel.bilateral_filtering_and_depth_cutoff(ctx, raw, sigma_xy, 0.005, radius_factor, int(max_depth_m / s), s)
+        assert np.array_equal(got == 65535, ref == 65535)        # cutoff and holes: exact
+        diff = np.abs(got.astype(np.int64) - ref.astype(np.int64))
+        assert diff.max() <= 1
+        assert (diff != 0).mean() < 1e-3
+        assert (ref != 65535).sum() > 10000
