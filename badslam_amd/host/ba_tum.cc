@@ -1,0 +1,111 @@
+// ba_tum.cc -- direct bundle adjustment of a TUM-format RGB-D sequence with given initial poses.
+//
+// What BadSlam does around DirectBA for every keyframe (B/bad_slam.cc: PreprocessFrame, CreateKeyframe, AddKeyframe,
+// RunBundleAdjustment), without the odometry front-end: the initial keyframe poses come from a trajectory file of the
+// dataset (as with the reference's --import_poses).  Reads <dataset>/{calibration.txt, associated.txt, <trajectory>},
+// makes every <interval>-th frame a keyframe, runs <iterations> BA calls of up to 10 iterations each with surfel
+// updates, and writes <out>.poses.txt (TUM trajectory lines of the keyframes), <out>.*_intrinsics.txt,
+// <out>.deformation.txt and <out>.ply.
+//
+//   ba_tum <dataset_dir> <trajectory_file> <out_prefix> [--interval N] [--iterations N] [--cell N] [--max_depth M]
+//          [--raw_to_float_depth S] [--pcg] [--intrinsics]
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "rgbd_io.h"
+
+using namespace vis;
+
+// ba_tum --check-dataset <dataset_dir> <trajectory_file>: parse and decode only (no GPU): prints what was read.
+static int CheckDataset(const char* dataset, const char* trajectory) {
+  RGBDVideo<Vec3u8, u16> video;
+  if (!ReadTUMRGBDDatasetAssociatedAndCalibrated(dataset, (trajectory && *trajectory) ? trajectory : nullptr, &video)) return 1;
+  const float* c = video.depth_camera()->parameters();
+  printf("frames %zu width %d height %d camera %.9g %.9g %.9g %.9g\n", (size_t)video.frame_count(), video.depth_camera()->width(),
+         video.depth_camera()->height(), c[0], c[1], c[2], c[3]);
+  for (usize f = 0; f < video.frame_count(); ++f) {
+    shared_ptr<Image<u16>> depth = video.depth_frame_mutable(f)->GetImage();
+    shared_ptr<Image<Vec3u8>> color = video.color_frame_mutable(f)->GetImage();
+    if (!depth || !color) return 1;
+    unsigned long long depth_sum = 0, color_sum = 0;
+    for (usize i = 0; i < (usize)depth->width() * depth->height(); ++i) depth_sum += depth->data()[i];
+    for (usize i = 0; i < (usize)color->width() * color->height(); ++i) color_sum += color->data()[i].v[0] + 2 * color->data()[i].v[1] + 3 * color->data()[i].v[2];
+    const float* v = video.depth_frame(f)->global_T_frame().data();
+    printf("frame %zu %s %s depth_sum %llu color_sum %llu pose %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", (size_t)f,
+           video.color_frame(f)->timestamp_string().c_str(), video.depth_frame(f)->timestamp_string().c_str(), depth_sum, color_sum, v[0], v[1],
+           v[2], v[3], v[4], v[5], v[6]);
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 3 && !strcmp(argv[1], "--check-dataset")) return CheckDataset(argv[2], argc > 3 ? argv[3] : nullptr);
+  if (argc < 4) {
+    fprintf(stderr, "usage: ba_tum <dataset_dir> <trajectory_file> <out_prefix> [--interval N] [--iterations N] [--cell N] [--max_depth M]"
+                    " [--raw_to_float_depth S] [--pcg] [--intrinsics]\n");
+    return 2;
+  }
+  const std::string dataset = argv[1], trajectory = argv[2], out = argv[3];
+  int interval = 1, iterations = 10, cell = 4;
+  float raw_to_float_depth = 1.0f / 5000;   // TUM RGB-D depth PNGs: 5000 units per metre
+  bool use_pcg = false, intrinsics = false;
+  PreprocessConfig config;
+  for (int i = 4; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--interval" && i + 1 < argc) interval = atoi(argv[++i]);
+    else if (a == "--iterations" && i + 1 < argc) iterations = atoi(argv[++i]);
+    else if (a == "--cell" && i + 1 < argc) cell = atoi(argv[++i]);
+    else if (a == "--max_depth" && i + 1 < argc) config.max_depth = (float)atof(argv[++i]);
+    else if (a == "--raw_to_float_depth" && i + 1 < argc) raw_to_float_depth = (float)atof(argv[++i]);
+    else if (a == "--pcg") use_pcg = true;
+    else if (a == "--intrinsics") intrinsics = true;
+    else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+  }
+  if (bahip_device_count() <= 0) { fprintf(stderr, "no HIP device (there is no CPU fallback)\n"); return 99; }
+
+  RGBDVideo<Vec3u8, u16> video;
+  if (!ReadTUMRGBDDatasetAssociatedAndCalibrated(dataset.c_str(), trajectory.c_str(), &video)) return 1;
+  printf("read %zu frames, %d x %d\n", (size_t)video.frame_count(), video.depth_camera()->width(), video.depth_camera()->height());
+  if (video.frame_count() == 0) return 1;
+
+  hipStream_t stream = nullptr;
+  BAHIP_CHECKED_CALL(bahip_stream_create(&stream));
+  {
+    // B/bad_slam.cc:125-142 with the defaults of B/bad_slam_config.h
+    DirectBA ba(/*max_surfel_count*/ 25 * 1000 * 1000, raw_to_float_depth, /*baseline_fx*/ 40, cell, /*surfel_merge_dist_factor*/ 0.8f,
+                /*min_observation_count_while_bootstrapping_1*/ 1, /*min_observation_count_while_bootstrapping_2*/ 2, /*min_observation_count*/ 2,
+                *video.color_camera(), *video.depth_camera(), /*pyramid_level_for_color*/ 0, /*use_depth_residuals*/ true,
+                /*use_descriptor_residuals*/ true, nullptr, SE3f());
+    vector<int> keyframe_frames;
+    for (usize f = 0; f < video.frame_count(); f += interval) {
+      shared_ptr<Keyframe> kf = CreateKeyframeFromFrame(stream, config, ba, video, (int)f);
+      ba.AddKeyframe(kf);
+      keyframe_frames.push_back((int)f);
+    }
+    printf("%zu keyframes\n", keyframe_frames.size());
+    for (int i = 0; i < iterations; ++i) {
+      int done = 0;
+      bool converged = false;
+      ba.BundleAdjustment(stream, /*optimize_depth_intrinsics*/ intrinsics, /*optimize_color_intrinsics*/ intrinsics, /*do_surfel_updates*/ true,
+                          /*optimize_poses*/ true, /*optimize_geometry*/ true, /*min_iterations*/ 1, /*max_iterations*/ 10, use_pcg, 0,
+                          (int)ba.keyframes().size() - 1, /*increase_ba_iteration_count*/ true, &done, &converged);
+      printf("BA call %d: %d iteration(s)%s, %u surfels\n", i + 1, done, converged ? ", converged" : "", ba.surfel_count());
+    }
+    // keyframe poses back into the video (the reference shares the pose object between keyframe and video frame)
+    RGBDVideo<Vec3u8, u16> keyframe_video;
+    for (usize k = 0; k < keyframe_frames.size(); ++k) {
+      const int f = keyframe_frames[k];
+      video.depth_frame_mutable(f)->SetGlobalTFrame(ba.keyframes()[k]->global_T_frame());
+      video.color_frame_mutable(f)->SetGlobalTFrame(ba.keyframes()[k]->global_T_frame());
+      keyframe_video.depth_frames_mutable()->push_back(video.depth_frame(f));
+      keyframe_video.color_frames_mutable()->push_back(video.color_frame(f));
+    }
+    if (!SavePoses(keyframe_video, /*use_depth_timestamps*/ true, /*start_frame*/ 0, out + ".poses.txt")) return 1;
+    if (!SaveCalibration(stream, ba, out)) return 1;
+    if (!SavePointCloudAsPLY(stream, ba, out + ".ply")) return 1;
+    printf("wrote %s.{poses.txt,depth_intrinsics.txt,color_intrinsics.txt,deformation.txt,ply}\n", out.c_str());
+  }
+  bahip_stream_destroy(stream);
+  return 0;
+}

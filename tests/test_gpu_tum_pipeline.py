@@ -1,0 +1,75 @@
+"""TUM-format input end to end on the GPU: a synthetic sequence written as PNGs + associated.txt +
+calibration.txt + an initial trajectory -> `ba_tum` (reader, PNG decoder, PreprocessFrame chain incl. the bilateral
+filter, Keyframe from buffers, BundleAdjustment with surfel updates, SavePoses / SaveCalibration / PLY export) ->
+the written trajectory is compared with the ground truth."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from badslam_amd import se3
+from tests import common, tum_writer
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "badslam_amd", "lib", "ba_tum")
+
+
+def _read_trajectory(path):
+    out = []
+    for line in open(path):
+        if line.startswith("#") or not line.strip():
+            continue
+        t = line.split()
+        v = [float(x) for x in t[1:]]
+        out.append((t[0], np.array([v[3], v[4], v[5], v[6], v[0], v[1], v[2]])))   # -> Sophus order
+    return out
+
+
+def _relative(poses):
+    inv0 = se3.inverse(np.asarray(poses[0], np.float64))
+    return [se3.mul(inv0, np.asarray(p, np.float64)) for p in poses]
+
+
+@pytest.mark.parametrize("use_pcg", [False, True])
+def test_ba_on_a_tum_format_sequence(tmp_path, use_pcg):
+    assert os.path.exists(BIN), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    scene = common.small_scene(num_keyframes=6, width=320, height=240, seed=4)
+    rng = np.random.Generator(np.random.PCG64(6))
+    initial = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    stamps = tum_writer.write_dataset(str(tmp_path), scene, {"groundtruth.txt": scene.poses_gt, "initial.txt": initial})
+    out = str(tmp_path / "result")
+    cmd = [BIN, str(tmp_path), "initial.txt", out, "--cell", "2", "--iterations", "6", "--max_depth", "8"] + (["--pcg"] if use_pcg else [])
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    print(proc.stdout[-3000:])
+    print(proc.stderr[-3000:])
+    assert proc.returncode == 0
+
+    result = _read_trajectory(out + ".poses.txt")
+    assert [t for t, _ in result] == stamps
+    est = [p for _, p in result]                      # already relative to the first keyframe (B/io.cc:542,551)
+    gt_rel, init_rel = _relative(scene.poses_gt), _relative(initial)
+    err_after = np.array([np.linalg.norm(common.pose_error(g, e)[:3]) for g, e in zip(gt_rel[1:], est[1:])])
+    err_before = np.array([np.linalg.norm(common.pose_error(g, e)[:3]) for g, e in zip(gt_rel[1:], init_rel[1:])])
+    print("relative translation error before", err_before, "after", err_after)
+    assert np.allclose(est[0][[3, 4, 5, 6]], [1, 0, 0, 0], atol=1e-6)          # first pose is the identity by construction
+    assert err_before.mean() > 3e-3                                              # the 5 mm / 1 mrad perturbation
+    assert err_after.mean() < 0.25 * err_before.mean()
+    assert err_after.max() < 2.5e-3
+
+    # calibration files: cx, cy are written in the pixel-centre convention (B/io.cc:583-586)
+    fx, fy, cx, cy = [float(v) for v in open(out + ".depth_intrinsics.txt").read().split()]
+    assert np.allclose([fx, fy, cx + 0.5, cy + 0.5], scene.camera, rtol=1e-5)
+    dims = open(out + ".deformation.txt").readline().split()
+    assert [int(d) for d in dims] == [(320 - 1) // 2 + 1, (240 - 1) // 2 + 1]
+
+    # binary PLY: header + 27 bytes per vertex, points near the planes of the scene (z about 2.5 m in front of the rig)
+    blob = open(out + ".ply", "rb").read()
+    header_end = blob.index(b"end_header\n") + len(b"end_header\n")
+    header = blob[:header_end].decode()
+    n = int([l for l in header.splitlines() if l.startswith("element vertex")][0].split()[-1])
+    assert n > 20000 and len(blob) == header_end + 27 * n
+    first = struct.unpack_from("<3f3B3f", blob, header_end)
+    assert np.isfinite(first[:3]).all() and abs(np.linalg.norm(first[6:9]) - 1) < 1e-3
