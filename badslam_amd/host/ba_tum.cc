@@ -4,7 +4,8 @@
 // RunBundleAdjustment), without the odometry front-end: the initial keyframe poses come from a trajectory file of the
 // dataset (as with the reference's --import_poses).  Reads <dataset>/{calibration.txt, associated.txt, <trajectory>},
 // makes every <interval>-th frame a keyframe, runs <iterations> BA calls of up to 10 iterations each with surfel
-// updates, and writes <out>.poses.txt (TUM trajectory lines of the keyframes), <out>.*_intrinsics.txt,
+// updates, lets the frames in between follow their keyframes (trajectory deformation) and writes <out>.poses.txt (TUM
+// trajectory lines of all frames, relative to the first), <out>.*_intrinsics.txt,
 // <out>.deformation.txt and <out>.ply.
 //
 //   ba_tum <dataset_dir> <trajectory_file> <out_prefix> [--interval N] [--iterations N] [--cell N] [--max_depth M]
@@ -84,6 +85,8 @@ int main(int argc, char** argv) {
       keyframe_frames.push_back((int)f);
     }
     printf("%zu keyframes\n", keyframe_frames.size());
+    vector<SE3f> original_keyframe_T_global;
+    RememberKeyframePoses(&ba, &original_keyframe_T_global);   // B/bad_slam.cc:1230 (before the BA that moves them)
     for (int i = 0; i < iterations; ++i) {
       int done = 0;
       bool converged = false;
@@ -92,16 +95,15 @@ int main(int argc, char** argv) {
                           (int)ba.keyframes().size() - 1, /*increase_ba_iteration_count*/ true, &done, &converged);
       printf("BA call %d: %d iteration(s)%s, %u surfels\n", i + 1, done, converged ? ", converged" : "", ba.surfel_count());
     }
-    // keyframe poses back into the video (the reference shares the pose object between keyframe and video frame)
-    RGBDVideo<Vec3u8, u16> keyframe_video;
+    // keyframe poses back into the video (the reference shares the pose object between keyframe and video frame), then the
+    // frames in between follow their keyframes (B/bad_slam.cc:1259-1269)
     for (usize k = 0; k < keyframe_frames.size(); ++k) {
       const int f = keyframe_frames[k];
       video.depth_frame_mutable(f)->SetGlobalTFrame(ba.keyframes()[k]->global_T_frame());
       video.color_frame_mutable(f)->SetGlobalTFrame(ba.keyframes()[k]->global_T_frame());
-      keyframe_video.depth_frames_mutable()->push_back(video.depth_frame(f));
-      keyframe_video.color_frames_mutable()->push_back(video.color_frame(f));
     }
-    if (!SavePoses(keyframe_video, /*use_depth_timestamps*/ true, /*start_frame*/ 0, out + ".poses.txt")) return 1;
+    ExtrapolateAndInterpolateKeyframePoseChanges(0, (u32)video.frame_count() - 1, &ba, original_keyframe_T_global, &video);
+    if (!SavePoses(video, /*use_depth_timestamps*/ true, /*start_frame*/ 0, out + ".poses.txt")) return 1;
     if (!SaveCalibration(stream, ba, out)) return 1;
     if (!SavePointCloudAsPLY(stream, ba, out + ".ply")) return 1;
     printf("wrote %s.{poses.txt,depth_intrinsics.txt,color_intrinsics.txt,deformation.txt,ply}\n", out.c_str());

@@ -356,6 +356,48 @@ bool SavePointCloudAsPLY(hipStream_t stream, DirectBA& direct_ba, const std::str
   return true;
 }
 
+// ---- trajectory deformation ----------------------------------------------------------------------------------------------
+void RememberKeyframePoses(DirectBA* dense_ba, vector<SE3f>* original_keyframe_T_global) {
+  original_keyframe_T_global->resize(dense_ba->keyframes().size());
+  for (usize keyframe_index = 0; keyframe_index < dense_ba->keyframes().size(); ++keyframe_index)
+    if (dense_ba->keyframes()[keyframe_index]) original_keyframe_T_global->at(keyframe_index) = dense_ba->keyframes()[keyframe_index]->frame_T_global();
+}
+
+void ExtrapolateAndInterpolateKeyframePoseChanges(u32 start_frame, u32 end_frame, DirectBA* dense_ba,
+                                                  const vector<SE3f>& original_keyframe_T_global, RGBDVideo<Vec3u8, u16>* rgbd_video) {
+  end_frame = std::min<int>(end_frame, (int)rgbd_video->frame_count() - 1);
+  const auto& keyframes = dense_ba->keyframes();
+  usize prev_keyframe_index = 0, next_keyframe_index = 0;
+  for (usize other_frame_index = start_frame; other_frame_index <= end_frame; ++other_frame_index) {
+    while (next_keyframe_index < keyframes.size() && keyframes[next_keyframe_index]->frame_index() <= other_frame_index) {
+      prev_keyframe_index = next_keyframe_index;
+      ++next_keyframe_index;
+      while (next_keyframe_index < keyframes.size() && !keyframes[next_keyframe_index]) ++next_keyframe_index;
+    }
+    Keyframe* prev_keyframe = keyframes[prev_keyframe_index].get();
+    Keyframe* next_keyframe = (next_keyframe_index < keyframes.size()) ? keyframes[next_keyframe_index].get() : nullptr;
+    if (prev_keyframe->frame_index() == other_frame_index) continue;   // a keyframe: nothing to do
+    const SE3f old_global_T_other = rgbd_video->depth_frame_mutable(other_frame_index)->global_T_frame();
+    const SE3f old_other_T_global = rgbd_video->depth_frame_mutable(other_frame_index)->frame_T_global();
+    SE3f new_global_T_other_frame;
+    if (next_keyframe == nullptr || prev_keyframe->frame_index() > other_frame_index) {   // extrapolate at the end / at the start
+      const SE3f old_kf_T_other_frame = original_keyframe_T_global[prev_keyframe_index] * old_global_T_other;
+      new_global_T_other_frame = prev_keyframe->global_T_frame() * old_kf_T_other_frame;
+    } else {
+      const SE3f from_prev = old_other_T_global * (prev_keyframe->global_T_frame() * (original_keyframe_T_global[prev_keyframe_index] * old_global_T_other));
+      const SE3f from_next = old_other_T_global * (next_keyframe->global_T_frame() * (original_keyframe_T_global[next_keyframe_index] * old_global_T_other));
+      const u32 prev_frame = prev_keyframe->frame_index(), next_frame = next_keyframe->frame_index();
+      const float factor = (other_frame_index - prev_frame) * 1.0f / (next_frame - prev_frame);
+      float v[7];
+      Slerp(from_prev.data(), from_next.data(), factor, v);
+      for (int c = 0; c < 3; ++c) v[4 + c] = (1 - factor) * from_prev.translation()[c] + factor * from_next.translation()[c];
+      new_global_T_other_frame = old_global_T_other * SE3f(v);
+    }
+    rgbd_video->depth_frame_mutable(other_frame_index)->SetGlobalTFrame(new_global_T_other_frame);
+    rgbd_video->color_frame_mutable(other_frame_index)->SetGlobalTFrame(new_global_T_other_frame);
+  }
+}
+
 // ---- frame -> keyframe --------------------------------------------------------------------------------------------------
 shared_ptr<Keyframe> CreateKeyframeFromFrame(hipStream_t stream, const PreprocessConfig& config, DirectBA& direct_ba,
                                              RGBDVideo<Vec3u8, u16>& rgbd_video, int frame_index) {

@@ -6,6 +6,7 @@
 //   * PNG decoding (8-bit RGB / RGBA / grey, 16-bit grey; the reference links libpng, here zlib + the PNG filters)
 //   * SavePoses / LoadPoses (TUM trajectory lines), SaveCalibration / LoadCalibration, ExportToPointCloud +
 //     SavePointCloudAsPLY                                        B/io.cc:537-703, B/direct_ba.cc:461-547
+//   * trajectory deformation of the non-keyframes after BA          B/trajectory_deformation.cc:33-130
 //   * PreprocessFrame + CreateKeyframe: raw depth + RGB of a video frame -> bilateral filter, normals, radii, luma,
 //     min / max depth -> vis::Keyframe                            B/bad_slam.cc:643-765, 957-1001
 #pragma once
@@ -100,6 +101,14 @@ struct Point3fC3u8Nf { float position[3]; u8 color[3]; float normal[3]; };   // 
 void ExportToPointCloud(hipStream_t stream, DirectBA& direct_ba, vector<Point3fC3u8Nf>* cloud);
 // B/io.cc:694-703 + L/point_cloud.h:493-533 (binary little-endian PLY: x y z, red green blue, nx ny nz)
 bool SavePointCloudAsPLY(hipStream_t stream, DirectBA& direct_ba, const std::string& export_path);
+
+// ---- trajectory deformation (B/trajectory_deformation.cc:33-130) -----------------------------------------------------------
+// After BA moved the keyframes, the frames between them follow: RememberKeyframePoses before BA, then every
+// non-keyframe in [start_frame, end_frame] gets the pose change of its neighbouring keyframes, interpolated (translation
+// linearly, rotation by slerp) by frame index, or extrapolated from the nearest keyframe at the ends.
+void RememberKeyframePoses(DirectBA* dense_ba, vector<SE3f>* original_keyframe_T_global);
+void ExtrapolateAndInterpolateKeyframePoseChanges(u32 start_frame, u32 end_frame, DirectBA* dense_ba,
+                                                  const vector<SE3f>& original_keyframe_T_global, RGBDVideo<Vec3u8, u16>* rgbd_video);
 
 // ---- frame -> keyframe (B/bad_slam.cc:643-765, 957-1001) -----------------------------------------------------------------
 struct PreprocessConfig {            // defaults of B/bad_slam_config.h:96-122

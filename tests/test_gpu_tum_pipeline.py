@@ -73,3 +73,30 @@ def test_ba_on_a_tum_format_sequence(tmp_path, use_pcg):
     assert n > 20000 and len(blob) == header_end + 27 * n
     first = struct.unpack_from("<3f3B3f", blob, header_end)
     assert np.isfinite(first[:3]).all() and abs(np.linalg.norm(first[6:9]) - 1) < 1e-3
+
+
+def test_non_keyframes_follow_their_keyframes(tmp_path):
+    """Every second frame is a keyframe; the initial trajectory has a smooth drift.  BA corrects the keyframes and the
+    trajectory deformation (B/trajectory_deformation.cc:45-130) carries the correction to the frames in between."""
+    scene = common.small_scene(num_keyframes=7, width=320, height=240, seed=5)
+    drift = np.array([0.004, -0.003, 0.002, 0.0008, -0.0006, 0.0005])
+    initial = [se3.mul(np.asarray(T, np.float64), se3.exp(k * drift)) for k, T in enumerate(scene.poses_gt)]
+    stamps = tum_writer.write_dataset(str(tmp_path), scene, {"initial.txt": initial})
+    out = str(tmp_path / "result")
+    proc = subprocess.run([BIN, str(tmp_path), "initial.txt", out, "--cell", "2", "--iterations", "6", "--max_depth", "8", "--interval", "2"],
+                          capture_output=True, text=True, timeout=600)
+    print(proc.stdout[-2000:])
+    print(proc.stderr[-2000:])
+    assert proc.returncode == 0
+    result = _read_trajectory(out + ".poses.txt")
+    assert [t for t, _ in result] == stamps                      # all 7 frames are written, 4 of them keyframes
+    est = [p for _, p in result]
+    gt_rel, init_rel = _relative(scene.poses_gt), _relative(initial)
+    err_after = np.array([np.linalg.norm(common.pose_error(g, e)[:3]) for g, e in zip(gt_rel, est)])
+    err_before = np.array([np.linalg.norm(common.pose_error(g, e)[:3]) for g, e in zip(gt_rel, init_rel)])
+    print("before", [round(float(v), 5) for v in err_before], "after", [round(float(v), 5) for v in err_after])
+    keyframes, others = [2, 4, 6], [1, 3, 5]
+    assert err_after[keyframes].max() < 1e-3
+    # the in-between frames inherit the interpolated correction: most of their drift is gone too (the synthetic frames are
+    # far apart in pose, so interpolating the correction by frame index is only approximately right)
+    assert (err_after[others] < 0.5 * err_before[others]).all()
