@@ -921,7 +921,11 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   if (inner_steps_out) *inner_steps_out = 0;
   if (num_converged_out) *num_converged_out = 0;
 
-  if (U > ctx->pcg_capacity) {   // lazy (re-)allocation like B/direct_ba_pcg.cc:255-268
+  if (U == 0 && !sharded) {   // nothing to solve for (e.g. one keyframe = the gauge, no surfels): every pose counts as converged
+    if (num_converged_out) *num_converged_out = K;
+    return 0;
+  }
+  if (U > ctx->pcg_capacity || ctx->pcg_buf == nullptr) {   // lazy (re-)allocation like B/direct_ba_pcg.cc:255-268
     if (ctx->pcg_buf) hipFree(ctx->pcg_buf);
     ctx->pcg_capacity = U + U / 8 + 4096;
     HIP_TRY(hipMalloc(&ctx->pcg_buf, sizeof(float) * (5 * ctx->pcg_capacity + 16)));

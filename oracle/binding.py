@@ -242,8 +242,12 @@ class OracleBA:
     def _kf_ptr_array(self):
         arr = (C.POINTER(Keyframe) * len(self.keyframes))()
         for i, kf in enumerate(self.keyframes):
-            arr[i] = C.pointer(kf)
+            if i not in getattr(self, "deleted", ()):      # a deleted keyframe is a NULL entry of the list (B/direct_ba.cc:251-283)
+                arr[i] = C.pointer(kf)
         return arr
+
+    def delete_keyframe(self, i):
+        self.deleted = set(getattr(self, "deleted", ())) | {int(i)}
 
     # -- surfels --
     @property

@@ -1,0 +1,114 @@
+"""Edge cases of the path on the GPU: ragged image sizes (plane tiles and wavefronts with padding), a deleted keyframe in
+the middle of the list, empty surfel sets, an all-invalid depth image, a single keyframe, capacity exceeded."""
+import numpy as np
+import pytest
+
+from badslam_amd import synthetic
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ragged_image_size_matches_oracle():
+    """330 x 243: neither a multiple of the 8x4 plane tile, nor of the 64x4 pixel blocks, nor of the 8-cell creation tile."""
+    scene = common.small_scene(num_keyframes=3, width=330, height=243, seed=21)
+    ba = common.build_oracle(scene, 300000)
+    g = common.build_gpu(scene, 300000)
+    for k in range(3):
+        arrs, kf = ba.kf_arrays(k), g.keyframes[k]
+        for name in ("depth", "normals", "color"):
+            assert np.array_equal(kf[name].download(), arrs[name]), (k, name)
+    ref, active = common.oracle_surfels(ba)
+    got = g.download_surfels()
+    assert got.shape[1] == ref.shape[1] > 5000
+    assert np.array_equal(got[:8].view(np.uint32), ref[:8].view(np.uint32))
+    # one geometry step from a displaced cloud, both launch shapes
+    rng = np.random.Generator(np.random.PCG64(3))
+    data = ref.copy()
+    data[2] += rng.uniform(0, 0.004, data.shape[1]).astype(np.float32)
+    from badslam_amd import capi
+    for tile_waves in (1, 4):
+        capi.check(g.ctx.lib.bahip_debug_set_launch_shapes(tile_waves, 0))
+        ba.surfel_data[:, :data.shape[1]] = data
+        g.upload_surfels(data, active * 0)
+        g.bind_keyframes()
+        g.update_surfel_activation()
+        ba.update_surfel_activation()
+        g.optimize_geometry_iteration(True, True)
+        ba.optimize_geometry_iteration()
+        assert np.array_equal(g.download_surfels()[:8].view(np.uint32), ba.surfel_data[:8, :data.shape[1]].view(np.uint32))
+    capi.check(g.ctx.lib.bahip_debug_set_launch_shapes(0, 0))
+
+
+def test_deleted_keyframe_in_the_middle():
+    """A deleted keyframe is a NULL entry of the reference's keyframe list and is left out of the bound table; the
+    four-class sums count positions among the remaining keyframes on both sides."""
+    scene = common.small_scene(num_keyframes=6, seed=23)
+    ba = common.build_oracle(scene, 500000)
+    g = common.build_gpu(scene, 500000)
+    data, active = common.oracle_surfels(ba)
+    rng = np.random.Generator(np.random.PCG64(4))
+    data[2] += rng.uniform(0, 0.004, data.shape[1]).astype(np.float32)
+    ba.surfel_data[:, :data.shape[1]] = data
+    ba.delete_keyframe(2)
+    del g.keyframes[2]
+    g.upload_surfels(data, active * 0)
+    g.bind_keyframes()
+    g.update_surfel_activation()
+    ba.update_surfel_activation()
+    assert np.array_equal(g.active_buf.download()[0, :data.shape[1]], ba.active[:data.shape[1]])
+    g.optimize_geometry_iteration(True, True)
+    ba.optimize_geometry_iteration()
+    assert np.array_equal(g.download_surfels()[:8].view(np.uint32), ba.surfel_data[:8, :data.shape[1]].view(np.uint32))
+
+
+def _directba(scene, cap, **kw):
+    from badslam_amd.directba import DirectBA
+    return DirectBA(cap, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, scene.width, scene.height, scene.camera, scene.camera, **kw)
+
+
+def test_bundle_adjustment_without_surfels_and_with_one_keyframe():
+    scene = common.small_scene(num_keyframes=2, width=160, height=120, seed=25)
+    # min_observation_count 1: with the default 2, the end-of-scheme tasks delete every surfel of a single keyframe
+    ba = _directba(scene, 100000, min_observation_count=1, min_observation_count_while_bootstrapping_1=1,
+                   min_observation_count_while_bootstrapping_2=1)
+    ba.AddKeyframe(scene.depth[0], scene.rgb[0], scene.poses_gt[0])
+    # one keyframe, no surfels: H = b = 0, the pose stays (B/direct_ba_alternating.cc:148-151), nothing crashes
+    for use_pcg in (False, True):
+        done, _ = ba.BundleAdjustment(optimize_poses=True, optimize_geometry=True, min_iterations=2, max_iterations=2, use_pcg=use_pcg)
+        assert done == 2 and ba.surfel_count() == 0
+        assert np.allclose(ba.keyframe_pose(0), np.asarray(scene.poses_gt[0], np.float64), atol=1e-6)
+    # surfels from the only keyframe, then BA with surfel updates: every surfel has a single observation
+    ba.CreateSurfelsForKeyframe(0, filter_new_surfels=False)
+    n = ba.surfel_count()
+    assert n > 1000
+    before = ba.download_surfels(3)
+    ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=2, max_iterations=2)
+    after = ba.download_surfels(3)
+    assert after.shape == before.shape and np.isfinite(after).all()
+    assert np.abs(after - before).max() < 1e-4          # consistent input: nothing to correct
+
+
+def test_all_invalid_depth_creates_no_surfels():
+    scene = common.small_scene(num_keyframes=1, width=160, height=120, seed=26)
+    ba = _directba(scene, 100000)
+    ba.AddKeyframe(np.full_like(scene.depth[0], 65535), scene.rgb[0], scene.poses_gt[0])
+    ba.CreateSurfelsForKeyframe(0, filter_new_surfels=False)
+    assert ba.surfel_count() == 0 and ba.surfels_size() == 0
+    assert (ba.keyframe_image(0, "depth") & 0x8000).all()
+
+
+def test_capacity_exceeded_is_a_soft_failure():
+    """B/kernel_create_surfels.cc:162-165: not enough room -> an error is logged, no surfels are created, no crash."""
+    scene = common.small_scene(num_keyframes=2, width=160, height=120, seed=27)
+    probe = _directba(scene, 100000)
+    probe.AddKeyframe(scene.depth[0], scene.rgb[0], scene.poses_gt[0])
+    probe.CreateSurfelsForKeyframe(0)
+    need = probe.surfel_count()
+    assert need > 1000
+    ba = _directba(scene, need // 2)
+    ba.AddKeyframe(scene.depth[0], scene.rgb[0], scene.poses_gt[0])
+    ba.CreateSurfelsForKeyframe(0)
+    assert ba.surfel_count() == 0
+    done, _ = ba.BundleAdjustment(min_iterations=1, max_iterations=1)
+    assert done == 1
