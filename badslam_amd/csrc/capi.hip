@@ -221,8 +221,11 @@ int ensure_px(bahip_context* ctx, size_t px, size_t scan_n) {
   return 0;
 }
 
+// profiling == 3: like 2 (cumulative), but only stage 2 (the pose-accumulate launches) is timed
+inline bool timer_on(const bahip_context* ctx, int stage) { return ctx->profiling && (ctx->profiling != 3 || stage == 2); }
+
 void timer_begin(bahip_context* ctx, int stage, bool first, int units = 1) {
-  if (!ctx->profiling) return;
+  if (!timer_on(ctx, stage)) return;
   StageTimer& t = ctx->timers[stage];
   if (first && ctx->profiling == 1) { t.used = 0; t.units = 0; }
   t.units += units;
@@ -234,7 +237,7 @@ void timer_begin(bahip_context* ctx, int stage, bool first, int units = 1) {
   hipEventRecord(t.ev[2 * t.used], ctx->stream);
 }
 void timer_end(bahip_context* ctx, int stage) {
-  if (!ctx->profiling) return;
+  if (!timer_on(ctx, stage)) return;
   StageTimer& t = ctx->timers[stage];
   hipEventRecord(t.ev[2 * t.used + 1], ctx->stream);
   t.used += 1;

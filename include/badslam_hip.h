@@ -273,7 +273,8 @@ int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, ui
  * call of each stage; used by bench.py for the roofline line.  stage: 0 activation, 1 geometry,
  * 2 pose accumulate, 3 pose solve. */
 int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* launches_out);
-/* enabled: 0 off; 1 = the counters cover the last call of each stage; 2 = cumulative since this call. */
+/* enabled: 0 off; 1 = the counters cover the last call of each stage; 2 = cumulative since this call; 3 = cumulative,
+ * stage 2 only (two event records per pose round instead of ten per BA iteration). */
 int bahip_set_profiling(bahip_context* ctx, int enabled);
 /* Work units of the launches counted above (stage 2: sum over launches of the keyframes still
  * iterating in that Gauss-Newton round; other stages: launches). */
