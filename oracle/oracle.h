@@ -8,9 +8,11 @@
  * Parity pinning: the reference (ETH3D/badslam) ships no golden vectors, fixtures or
  * known-answer files for this path and cannot be compiled here (CUDA + Eigen + Qt + ...).
  * The oracle is pinned by (1) the reference's own closed-loop test criteria restated in
- * tests/test_oracle_closed_loop.py (applications/badslam/src/badslam/test/ *.cc tolerances),
- * (2) Jacobians checked against the reference's sympy derivation
- * (applications/badslam/scripts/jacobians_derivation.py, fixtures in tests/golden/) and
+ * tests/test_oracle_*_closed_loop.py (applications/badslam/src/badslam/test/ *.cc tolerances; all
+ * twelve of them also run against the HIP path, badslam_amd/host/test_directba.cc),
+ * (2) its residual Jacobians checked against golden vectors generated HERE by importing the
+ * reference's own derivation script (applications/badslam/scripts/jacobians_derivation.py ->
+ * scripts/make_golden_jacobians.py -> tests/golden/jacobians.json) and
  * (3) central finite differences of the oracle's own residual functions.
  *
  * All arithmetic is IEEE binary32 unless stated (compiled with -ffp-contract=off); the small
@@ -129,6 +131,14 @@ void orc_compute_min_max_depth(const uint16_t* depth, int width, int height, flo
 void orc_keyframe_from_images(orc_keyframe* kf, const orc_camera* depth_cam, const orc_depth_params* dp,
                               const uint16_t* depth_image, const uint8_t* rgb_image,
                               const orc_se3* global_T_frame);
+
+/* ---- residual Jacobians in isolation (oracle_internal.h: jac_*), checked against tests/golden/jacobians.json ---- */
+void orc_jac_depth_pose(const float nl[3], const float u[3], float inv_std, float J[6]);                    /* B/kernel_opt_pose.cu:88-93 */
+void orc_jac_descriptor_pose(const float ls[3], float gx, float gy, float J[6]);                            /* B/kernel_opt_pose.cu:126-141 */
+float orc_jac_descriptor_surfel(const float rn[3], const float lp[3], float gx, float gy, float cfx, float cfy);   /* B/kernel_opt_geometry.cu:170-190 */
+void orc_jac_depth_intrinsics(int px, int py, float depth, float inv_std, float n_dot_Frow0, float n_dot_Frow1, float dot, float cfactor,
+                              float raw_inv_depth, float exp_inv_depth, float corrected_inv_depth, float J[6]);      /* B/kernel_opt_intrinsics.cu:107-140 */
+void orc_jac_descriptor_color_intrinsics(float gx, float gy, float nx, float ny, float J[4]);              /* B/kernel_opt_intrinsics.cu:176-199 */
 
 /* ---- elementary pieces exposed for unit tests ---- */
 /* Software restatement of the clamp-addressed bilinear normalized-float sampler

@@ -147,11 +147,8 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &raw1, &raw2);
         orc_descriptor_gradient(kf, c, t1, t2, g);
         const v3 lp = r.local_position;
-        const float term1 = -color_cam->fx * (rn.x * lp.z - rn.z * lp.x);
-        const float term2 = -color_cam->fy * (rn.y * lp.z - rn.z * lp.y);
-        const float term3 = 1.f / (lp.z * lp.z);
-        const float jp1 = -(g[0] * term1 + g[1] * term2) * term3;
-        const float jp2 = -(g[2] * term1 + g[3] * term2) * term3;
+        const float jp1 = jac_descriptor_surfel(rn, lp, g[0], g[1], color_cam->fx, color_cam->fy);
+        const float jp2 = jac_descriptor_surfel(rn, lp, g[2], g[3], color_cam->fx, color_cam->fy);
         const float jd = -1.f;
         const float w1 = descriptor_residual_weight(raw1);
         const float wr1 = w1 * raw1;

@@ -50,14 +50,10 @@ void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_i
           const v3 nl = m34_rotate(F, r.normal);
           const float dot = v3_dot(v3_make(nx, ny, 1), nl);
           const float inv_std = depth_inv_stddev(nx, ny, r.calibrated_depth, nl, dp->baseline_fx);
-          const float jac_base = inv_std * dot * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
           float J[K_A_ROWS + 1];
-          J[2] = inv_std * r.calibrated_depth * v3_dot(r.normal, v3_make(F[0], F[1], F[2]));
-          J[3] = inv_std * r.calibrated_depth * v3_dot(r.normal, v3_make(F[4], F[5], F[6]));
-          J[0] = r.px * J[2];
-          J[1] = r.py * J[3];
-          J[4] = cfactor * raw_inv_depth * jac_base;
-          J[5] = -jac_base;
+          jac_depth_intrinsics(r.px, r.py, r.calibrated_depth, inv_std, v3_dot(r.normal, v3_make(F[0], F[1], F[2])),
+                               v3_dot(r.normal, v3_make(F[4], F[5], F[6])), dot, cfactor, raw_inv_depth, exp_inv_depth,
+                               corrected_inv_depth, J);
           const v3 u = v3_make(r.calibrated_depth * nx, r.calibrated_depth * ny, r.calibrated_depth);
           const float raw = inv_std * v3_dot(nl, v3_sub(u, r.local_position));
           const float w = depth_residual_weight(raw);
@@ -76,8 +72,9 @@ void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_i
           orc_tangent_projections(r.global_position, r.normal, srow(s, ORC_SURFEL_RADIUS_SQ)[i], F, color_cam, t1, t2);
           orc_descriptor_gradient(kf, c, t1, t2, g);
           orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &raw1, &raw2);
-          const float J1[4] = {g[0] * nx, g[1] * ny, g[0], g[1]};
-          const float J2[4] = {g[2] * nx, g[3] * ny, g[2], g[3]};
+          float J1[4], J2[4];
+          jac_descriptor_color_intrinsics(g[0], g[1], nx, ny, J1);
+          jac_descriptor_color_intrinsics(g[2], g[3], nx, ny, J2);
           /* validity flag is "residual != 0" (B/kernel_opt_intrinsics.cu:200-215) */
           if (raw1 != 0) add_h_b(4, color_H, color_b, raw1, descriptor_residual_weight(raw1), J1);
           if (raw2 != 0) add_h_b(4, color_H, color_b, raw2, descriptor_residual_weight(raw2), J2);

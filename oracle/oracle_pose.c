@@ -40,12 +40,7 @@ uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camer
                                              r.calibrated_depth, nl, dp->baseline_fx);
       const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
       raw = inv_std * v3_dot(nl, v3_sub(u, r.local_position));
-      J[0] = inv_std * nl.x;
-      J[1] = inv_std * nl.y;
-      J[2] = inv_std * nl.z;
-      J[3] = inv_std * (-nl.y * u.z + nl.z * u.y);
-      J[4] = inv_std * (nl.x * u.z - nl.z * u.x);
-      J[5] = inv_std * (-nl.x * u.y + nl.y * u.x);
+      jac_depth_pose(nl, u, inv_std, J);
       const float w = depth_residual_weight(raw);
       if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else add_residual_f(Hf, bf, raw, w, J);
       cost += weighted_depth_residual(raw);
@@ -59,16 +54,10 @@ uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camer
       orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &raw1, &raw2);
       orc_descriptor_gradient(kf, c, t1, t2, g);
       const v3 ls = r.local_position;
-      const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
       for (int k = 0; k < 2; ++k) {
         const float gx = g[2 * k + 0] * color_cam->fx;
         const float gy = g[2 * k + 1] * color_cam->fy;
-        J[0] = -gx * inv_z;
-        J[1] = -gy * inv_z;
-        J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
-        J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
-        J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
-        J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+        jac_descriptor_pose(ls, gx, gy, J);
         raw = k ? raw2 : raw1;
         const float w = descriptor_residual_weight(raw);
         if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else add_residual_f(Hf, bf, raw, w, J);
@@ -165,4 +154,22 @@ int orc_estimate_frame_pose(int use_depth, int use_desc, const orc_camera* color
   *out = est;
   if (converged_out) *converged_out = converged;
   return iteration;
+}
+
+/* ---- the Jacobian helpers of oracle_internal.h, exported for tests/test_cpu_golden_jacobians.py ---- */
+void orc_jac_depth_pose(const float nl[3], const float u[3], float inv_std, float J[6]) {
+  jac_depth_pose(v3_make(nl[0], nl[1], nl[2]), v3_make(u[0], u[1], u[2]), inv_std, J);
+}
+void orc_jac_descriptor_pose(const float ls[3], float gx, float gy, float J[6]) {
+  jac_descriptor_pose(v3_make(ls[0], ls[1], ls[2]), gx, gy, J);
+}
+float orc_jac_descriptor_surfel(const float rn[3], const float lp[3], float gx, float gy, float cfx, float cfy) {
+  return jac_descriptor_surfel(v3_make(rn[0], rn[1], rn[2]), v3_make(lp[0], lp[1], lp[2]), gx, gy, cfx, cfy);
+}
+void orc_jac_depth_intrinsics(int px, int py, float depth, float inv_std, float n_dot_Frow0, float n_dot_Frow1, float dot, float cfactor,
+                              float raw_inv_depth, float exp_inv_depth, float corrected_inv_depth, float J[6]) {
+  jac_depth_intrinsics(px, py, depth, inv_std, n_dot_Frow0, n_dot_Frow1, dot, cfactor, raw_inv_depth, exp_inv_depth, corrected_inv_depth, J);
+}
+void orc_jac_descriptor_color_intrinsics(float gx, float gy, float nx, float ny, float J[4]) {
+  jac_descriptor_color_intrinsics(gx, gy, nx, ny, J);
 }
