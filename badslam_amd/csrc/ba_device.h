@@ -399,6 +399,51 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
   eval_descriptor<kWithGradient>(in, lumafp, F, surfel_tangent_points(gp, gn, radius_sq), cx, cy, d1, d2, e);
 }
 
+// ---- residual Jacobians (the same functions the oracle has, oracle_internal.h: jac_*; checked in isolation against golden
+// vectors generated from the reference's derivation script, tests/golden/jacobians.json) ---------------------------------
+// B/kernel_opt_pose.cu:88-93: nl = surfel normal, u = unprojected measurement, both in the keyframe frame.
+__device__ __forceinline__ void jac_depth_pose(Vec3 nl, Vec3 u, float inv_std, float (&J)[6]) {
+  J[0] = inv_std * nl.x;
+  J[1] = inv_std * nl.y;
+  J[2] = inv_std * nl.z;
+  J[3] = inv_std * (-nl.y * u.z + nl.z * u.y);
+  J[4] = inv_std * (nl.x * u.z - nl.z * u.x);
+  J[5] = inv_std * (-nl.x * u.y + nl.y * u.x);
+}
+// B/kernel_opt_pose.cu:126-141: ls = surfel position in the keyframe frame, gx, gy = image gradient of the residual times fx, fy.
+__device__ __forceinline__ void jac_descriptor_pose(Vec3 ls, float gx, float gy, float (&J)[6]) {
+  const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
+  J[0] = -gx * inv_z;
+  J[1] = -gy * inv_z;
+  J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
+  J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
+  J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
+  J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+}
+// B/kernel_opt_geometry.cu:170-190: rn = surfel normal, lp = surfel position in the keyframe frame, g = gradient per pixel.
+__device__ __forceinline__ float jac_descriptor_surfel(Vec3 rn, Vec3 lp, float gx, float gy, float cfx, float cfy) {
+  const float term1 = -cfx * (rn.x * lp.z - rn.z * lp.x);
+  const float term2 = -cfy * (rn.y * lp.z - rn.z * lp.y);
+  const float term3 = 1.f / (lp.z * lp.z);
+  return -(gx * term1 + gy * term2) * term3;
+}
+// B/kernel_opt_intrinsics.cu:107-140: rows fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor.
+__device__ __forceinline__ void jac_depth_intrinsics(int px, int py, float depth, float inv_std, float n_dot_Frow0, float n_dot_Frow1,
+                                                     float dot, float cfactor, float raw_inv_depth, float exp_inv_depth,
+                                                     float corrected_inv_depth, float (&J)[6]) {
+  const float jac_base = inv_std * dot * exp_inv_depth / (corrected_inv_depth * corrected_inv_depth);
+  J[2] = inv_std * depth * n_dot_Frow0;
+  J[3] = inv_std * depth * n_dot_Frow1;
+  J[0] = px * J[2];
+  J[1] = py * J[3];
+  J[4] = cfactor * raw_inv_depth * jac_base;
+  J[5] = -jac_base;
+}
+// B/kernel_opt_intrinsics.cu:176-199: rows fx, fy, cx, cy of the colour camera.
+__device__ __forceinline__ void jac_descriptor_color_intrinsics(float gx, float gy, float nx, float ny, float (&J)[4]) {
+  J[0] = gx * nx; J[1] = gy * ny; J[2] = gx; J[3] = gy;
+}
+
 // ---- surfel loads ----------------------------------------------------------------------------------
 __device__ __forceinline__ Vec3 surfel_position(const SurfelsView& s, uint32_t i) {
   return mk3(s.row(kSurfelX)[i], s.row(kSurfelY)[i], s.row(kSurfelZ)[i]);

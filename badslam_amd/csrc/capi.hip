@@ -1067,6 +1067,20 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts) {
   return 0;
 }
 
+int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in, float* out, int n_out) {
+  REQUIRE(kind >= 0 && kind <= 4 && n_in > 0 && n_in <= 16 && n_out > 0 && n_out <= 8, "bahip_debug_jacobian: bad arguments");
+  float *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_in, 16 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out, 8 * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(d_in, in, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  launch_jacobian_debug(ctx->stream, kind, d_in, d_out);
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  hipFree(d_in); hipFree(d_out);
+  return 0;
+}
+
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56) {
   float *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, 64 * 28 * sizeof(float)));

@@ -56,14 +56,9 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
           if (fabsf(corrected) > 1e-4f) {
             const float dot = dot3(mk3(nx, ny, 1), r.nl);
             const float inv_std = depth_inv_stddev(nx, ny, r.depth, r.nl, in.baseline_fx);
-            const float jac_base = inv_std * dot * exp_inv_depth / (corrected * corrected);
             float J[kARows + 1];
-            J[2] = inv_std * r.depth * dot3(gn, mk3(F[0], F[1], F[2]));
-            J[3] = inv_std * r.depth * dot3(gn, mk3(F[4], F[5], F[6]));
-            J[0] = r.px * J[2];
-            J[1] = r.py * J[3];
-            J[4] = cfactor * raw_inv_depth * jac_base;
-            J[5] = -jac_base;
+            jac_depth_intrinsics(r.px, r.py, r.depth, inv_std, dot3(gn, mk3(F[0], F[1], F[2])), dot3(gn, mk3(F[4], F[5], F[6])), dot, cfactor,
+                                 raw_inv_depth, exp_inv_depth, corrected, J);
             const Vec3 u = mk3(r.depth * nx, r.depth * ny, r.depth);
             const float raw = inv_std * dot3(r.nl, u - r.local);
             const float w = depth_residual_weight(raw);
@@ -93,7 +88,8 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
             for (int t = 0; t < 2; ++t) {
               const float gx = t ? e.gx2 : e.gx1, gy = t ? e.gy2 : e.gy1, raw = t ? e.r2 : e.r1;
               if (raw != 0) {
-                const float J[4] = {gx * nx, gy * ny, gx, gy};
+                float J[4];
+                jac_descriptor_color_intrinsics(gx, gy, nx, ny, J);
                 const float w = descriptor_residual_weight(raw);
                 int q = 20;
 #pragma unroll

@@ -84,12 +84,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
         const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
         const Vec3 u = unproject(in, r.px, r.py, r.depth);
         const float raw = inv_std * dot3(r.nl, u - r.local);
-        J[0] = inv_std * r.nl.x;
-        J[1] = inv_std * r.nl.y;
-        J[2] = inv_std * r.nl.z;
-        J[3] = inv_std * (-r.nl.y * u.z + r.nl.z * u.y);
-        J[4] = inv_std * (r.nl.x * u.z - r.nl.z * u.x);
-        J[5] = inv_std * (-r.nl.x * u.y + r.nl.y * u.x);
+        jac_depth_pose(r.nl, u, inv_std, J);
         const float wgt = depth_residual_weight(raw);
         accumulate_jtj(acc, J, wgt, raw);
       }
@@ -101,18 +96,12 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
           eval_descriptor<true>(in, kf.lumafp, F, tp, cx, cy, d1, d2, &e);
           // B/kernel_opt_pose.cu:96-142
           const Vec3 ls = r.local;
-          const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const float gx = (t ? e.gx2 : e.gx1) * in.cfx;
             const float gy = (t ? e.gy2 : e.gy1) * in.cfy;
             const float raw = t ? e.r2 : e.r1;
-            J[0] = -gx * inv_z;
-            J[1] = -gy * inv_z;
-            J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
-            J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
-            J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
-            J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+            jac_descriptor_pose(ls, gx, gy, J);
             const float wgt = descriptor_residual_weight(raw);
             accumulate_jtj(acc, J, wgt, raw);
           }
@@ -288,10 +277,7 @@ __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView 
   const Vec3 u = unproject(in, r.px, r.py, r.depth);
   const float raw = inv_std * dot3(r.nl, u - r.local);
   o[5] = raw; o[6] = depth_residual_weight(raw); o[7] = inv_std;
-  o[8] = inv_std * r.nl.x; o[9] = inv_std * r.nl.y; o[10] = inv_std * r.nl.z;
-  o[11] = inv_std * (-r.nl.y * u.z + r.nl.z * u.y);
-  o[12] = inv_std * (r.nl.x * u.z - r.nl.z * u.x);
-  o[13] = inv_std * (-r.nl.x * u.y + r.nl.y * u.x);
+  { float Jd[6]; jac_depth_pose(r.nl, u, inv_std, Jd); for (int c = 0; c < 6; ++c) o[8 + c] = Jd[c]; }
   float cx, cy;
   if (!depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) return;
   o[3] = 1.f;
@@ -300,17 +286,11 @@ __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView 
                         s.row(kSurfelDescriptor1)[i], s.row(kSurfelDescriptor2)[i], &e);
   o[14] = e.r1; o[15] = e.r2; o[16] = descriptor_residual_weight(e.r1); o[17] = descriptor_residual_weight(e.r2);
   o[30] = e.gx1; o[31] = e.gy1; o[32] = e.gx2; o[33] = e.gy2;
-  const Vec3 ls = r.local;
-  const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
   for (int q = 0; q < 2; ++q) {
     const float gx = (q ? e.gx2 : e.gx1) * in.cfx, gy = (q ? e.gy2 : e.gy1) * in.cfy;
-    float* J = o + 18 + 6 * q;
-    J[0] = -gx * inv_z;
-    J[1] = -gy * inv_z;
-    J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
-    J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
-    J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
-    J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+    float Jq[6];
+    jac_descriptor_pose(r.local, gx, gy, Jq);
+    for (int c = 0; c < 6; ++c) o[18 + 6 * q + c] = Jq[c];
   }
 }
 void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
@@ -335,5 +315,22 @@ __global__ void wave_reduce_debug_kernel(const float* __restrict__ in, float* __
 }
 void launch_wave_reduce_debug(hipStream_t stream, const float* in, float* out) {
   hipLaunchKernelGGL(wave_reduce_debug_kernel, dim3(1), dim3(64), 0, stream, in, out);
+}
+// Debug: the Jacobian functions of ba_device.h on explicit inputs (one thread).  Layout of `in` / `out` per kind:
+//   0 depth/pose          in nl[3] u[3] inv_std                                        out J[6]
+//   1 descriptor/pose     in ls[3] gx gy                                               out J[6]
+//   2 descriptor/surfel   in rn[3] lp[3] gx gy cfx cfy                                 out J[1]
+//   3 depth/intrinsics    in px py depth inv_std ndF0 ndF1 dot cfactor raw_inv exp_inv corrected   out J[6]
+//   4 descriptor/colour   in gx gy nx ny                                               out J[4]
+__global__ void jacobian_debug_kernel(int kind, const float* __restrict__ in, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  if (kind == 0) { float J[6]; jac_depth_pose(mk3(in[0], in[1], in[2]), mk3(in[3], in[4], in[5]), in[6], J); for (int c = 0; c < 6; ++c) out[c] = J[c]; }
+  else if (kind == 1) { float J[6]; jac_descriptor_pose(mk3(in[0], in[1], in[2]), in[3], in[4], J); for (int c = 0; c < 6; ++c) out[c] = J[c]; }
+  else if (kind == 2) { out[0] = jac_descriptor_surfel(mk3(in[0], in[1], in[2]), mk3(in[3], in[4], in[5]), in[6], in[7], in[8], in[9]); }
+  else if (kind == 3) { float J[6]; jac_depth_intrinsics((int)in[0], (int)in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], in[9], in[10], J); for (int c = 0; c < 6; ++c) out[c] = J[c]; }
+  else if (kind == 4) { float J[4]; jac_descriptor_color_intrinsics(in[0], in[1], in[2], in[3], J); for (int c = 0; c < 4; ++c) out[c] = J[c]; }
+}
+void launch_jacobian_debug(hipStream_t stream, int kind, const float* in, float* out) {
+  hipLaunchKernelGGL(jacobian_debug_kernel, dim3(1), dim3(64), 0, stream, kind, in, out);
 }
 }  // namespace bahip

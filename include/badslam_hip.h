@@ -263,6 +263,11 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
  * sums are defined as four interleaved partial sums).  pose_parts (1 | 2 | 4 | 8): wavefronts sharing a
  * tile's keyframes in the pose kernel (sums merged by float atomics in any case). */
 int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
+/* The residual Jacobian functions of the kernels (ba_device.h: jac_*) on explicit inputs, for the golden vectors of
+ * tests/golden/jacobians.json.  kind: 0 depth/pose (in: nl[3] u[3] inv_std; out 6), 1 descriptor/pose (ls[3] gx gy; 6),
+ * 2 descriptor/surfel (rn[3] lp[3] gx gy cfx cfy; 1), 3 depth/intrinsics (px py depth inv_std n.Frow0 n.Frow1 dot cfactor
+ * raw_inv_depth exp_inv_depth corrected_inv_depth; 6), 4 descriptor/colour intrinsics (gx gy nx ny; 4). */
+int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in, float* out, int n_out);
 /* One wavefront: in = 64 lanes x 28 floats; out[0..27] = totals from the halving reduction used by the pose kernel
  * (wave_reduce.h), out[28..55] = the same totals from the xor-butterfly wave_sum. */
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56);
