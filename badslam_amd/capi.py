@@ -104,6 +104,7 @@ SIGNATURES = {
     "bahip_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
                                                     C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_delete_surfels_and_update_radii": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_uint32)]),
+    "bahip_sort_surfels_spatially": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.c_float]),
     "bahip_compact_surfels": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Surfels)]),
     "bahip_optimize_intrinsics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.POINTER(Camera),
                                             C.POINTER(Camera), C.POINTER(C.c_float)]),

@@ -82,6 +82,7 @@ void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& f
                           const uint32_t* indices, uint32_t surfels_size, const SurfelsView& s);
 void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                           int min_obs, uint32_t* deleted_count);
+hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float inv_cell);
 size_t scan_temp_bytes(size_t n);
 hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint8_t* flags, uint32_t* out, int n);
 hipError_t scan_u32_exclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n);

@@ -816,7 +816,13 @@ int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip
   return 0;
 }
 
-// ---- not yet implemented in this build ------------------------------------------------------------------------
+int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfels, float grid_cell_size) {
+  REQUIRE(grid_cell_size > 0.f, "grid_cell_size must be positive");
+  const float inv_cell = 1.0f / grid_cell_size;
+  HIP_TRY(sort_surfels_spatially(ctx->stream, make_view(surfels), inv_cell));
+  return 0;
+}
+
 // B/kernel_opt_intrinsics.cc:39-281
 int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimize_color, const bahip_surfels* surfels,
                               bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a) {

@@ -145,6 +145,10 @@ class DirectBA:
     def surfels_size(self):
         return int(self.L.dba_surfels_size(self.h))
 
+    def SortSurfelsSpatially(self, grid_cell_size=0.02):
+        self.L.dba_sort_surfels_spatially.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        assert self.L.dba_sort_surfels_spatially(self.h, self.stream, float(grid_cell_size)) == 0
+
     def SetSurfelCount(self, surfel_count, surfels_size):
         self.L.dba_set_surfel_count(self.h, int(surfel_count), int(surfels_size))
 

@@ -131,6 +131,11 @@ int dba_set_surfel_count(dba_handle* h, uint32_t surfel_count, uint32_t surfels_
   return 0;
 }
 
+int dba_sort_surfels_spatially(dba_handle* h, void* stream, float grid_cell_size) {
+  h->ba->SortSurfelsSpatially(stream, grid_cell_size);
+  return 0;
+}
+
 int dba_download_surfels(dba_handle* h, void* stream, int rows, uint32_t count, float* out) {
   auto s = h->ba->surfels();
   for (int r = 0; r < rows; ++r)

@@ -289,6 +289,12 @@ void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_update
   Unlock();
 }
 
+void DirectBA::SortSurfelsSpatially(hipStream_t stream, float grid_cell_size) {
+  BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
+  const bahip_surfels s = SurfelsStruct();
+  BAHIP_CHECKED_CALL(bahip_sort_surfels_spatially(ctx_, &s, grid_cell_size));
+}
+
 // ---- alternating scheme (B/direct_ba_alternating.cc:285-738) ----------------------------------------------------------------
 void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics,
                                            bool do_surfel_updates, bool optimize_poses, bool optimize_geometry, int min_iterations,

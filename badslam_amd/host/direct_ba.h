@@ -95,6 +95,10 @@ class DirectBA {
   u32 surfel_count() const { lock_guard<mutex> lock(ba_thread_mutex_); return surfel_count_; }
   u32 surfels_size() const { lock_guard<mutex> lock(ba_thread_mutex_); return surfels_size_; }
   void SetSurfelCount(u32 surfel_count, u32 surfels_size) { surfel_count_ = surfel_count; surfels_size_ = surfels_size; }
+  // Not in the reference.  Reorders the surfel buffer along a Morton curve over a world grid (bahip_sort_surfels_spatially):
+  // surfels that an image region shows become neighbours in the buffer, which the sweeps' cache behaviour wants.  No
+  // result depends on the order; call it when the surfel set has grown (after adding keyframes), not per iteration.
+  void SortSurfelsSpatially(hipStream_t stream, float grid_cell_size = 0.02f);
   CUDABufferConstPtr<float> surfels() const { return surfels_; }
   CUDABufferPtr<float> surfels() { return surfels_; }
   CUDABufferPtr<u8> active_surfels() { return active_surfels_; }

@@ -222,6 +222,10 @@ class Scene:
         s = self.surfels_struct()
         capi.check(self.lib.bahip_update_surfel_normals(self.ctx.handle, C.byref(s)))
 
+    def sort_surfels_spatially(self, grid_cell_size=0.02):
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_sort_surfels_spatially(self.ctx.handle, C.byref(s), float(grid_cell_size)))
+
     def optimize_intrinsics(self, optimize_depth, optimize_color, apply=True):
         """OptimizeIntrinsicsCUDA; with apply=True the new cameras / a are adopted like
         B/direct_ba_alternating.cc:609-619 does."""

@@ -59,6 +59,7 @@ def parse_args():
                         "a planning aid, the JSON line then describes that share, not the whole job")
     p.add_argument("--emulate-rank", type=int, default=0)
     p.add_argument("--shard-chunk", type=int, default=4096, help="surfels per chunk of the chunk-cyclic partition; 0 = contiguous")
+    p.add_argument("--no-spatial-sort", action="store_true", help="leave the surfels in creation order")
     p.add_argument("--build-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
@@ -100,6 +101,10 @@ def build_scene(args, log):
     created = ba.surfels_size()
     if created > args.surfels:
         ba.SetSurfelCount(args.surfels, args.surfels)
+    if not args.no_spatial_sort:
+        # maintenance step of the backend (DirectBA::SortSurfelsSpatially, not per iteration): surfels that an image
+        # region shows become neighbours in the buffer.  Part of scene construction here, outside the timed region.
+        ba.SortSurfelsSpatially()
     log(f"created {created} surfels from {args.keyframes} keyframes (min/median/max per keyframe "
         f"{min(per_kf)}/{int(np.median(per_kf))}/{max(per_kf)}) in {time.time() - t1:.1f}s; using {ba.surfels_size()}")
     # perturbation: poses * exp(N(0, 5 mm / 1 mrad)); surfels + U(0, 5 mm) along z
@@ -264,6 +269,7 @@ def main():
                                    f"{'PCG' if args.pcg else 'alternating'} BA (BASELINE configs[2])",
                        "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
                        "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
+                       "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, 2 cm grid)",
                        "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU"},
             **({"emulated_share_of_world": shard_world} if shard_world != world else {}),
             "stage_ms_per_iteration": {STAGES[s]: breakdown_ms[s] / BREAKDOWN_STEPS for s in range(4)},

@@ -56,6 +56,8 @@ int dba_bundle_adjustment(dba_handle* h, void* hip_stream, int optimize_depth_in
 uint32_t dba_surfel_count(dba_handle* h);
 uint32_t dba_surfels_size(dba_handle* h);
 int dba_set_surfel_count(dba_handle* h, uint32_t surfel_count, uint32_t surfels_size);
+/* DirectBA::SortSurfelsSpatially (ours: Morton order of the surfel buffer over a world grid of grid_cell_size metres) */
+int dba_sort_surfels_spatially(dba_handle* h, void* hip_stream, float grid_cell_size);
 /* surfels()->Download/UploadPartAsync of `rows` attribute rows x `count` surfels starting at row 0 */
 int dba_download_surfels(dba_handle* h, void* hip_stream, int rows, uint32_t count, float* out);
 int dba_upload_surfels(dba_handle* h, void* hip_stream, int rows, uint32_t count, const float* in);

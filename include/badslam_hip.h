@@ -152,6 +152,12 @@ int bahip_compute_min_max_depth(bahip_context* ctx, const uint16_t* depth, uint3
  * this backend removes). */
 int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, const bahip_camera* depth_camera,
                          const bahip_depth_params* dp);
+/* Maintenance, like compaction: reorders surfels [0, surfels_size) along a Morton curve over a world grid of
+ * `grid_cell_size` metres (stable; deleted surfels last).  Moves the 8 data rows and the active flags.  Surfels that
+ * one image region shows become neighbours in the buffer, which is what the sweeps' L2 behaviour wants;
+ * no result depends on the order.  Not part of the reference: call it when convenient (after keyframes were added). */
+int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfels, float grid_cell_size);
+
 /* BA planes of one frame: create for the given image sizes, refresh from the frame's images (on the context
  * stream), destroy.  The Keyframe constructor (B/keyframe.cc:81-158) is where the reference derives normals, radii
  * and luma from its inputs; the planes are one more derived product of the same step. */

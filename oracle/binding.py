@@ -303,6 +303,11 @@ class OracleBA:
                                                C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),
                                                C.byref(self.surfels))
 
+    def sort_surfels_spatially(self, grid_cell_size=0.02):
+        self.L.orc_sort_surfels_spatially.argtypes = [C.c_void_p, C.c_float]
+        self.L.orc_sort_surfels_spatially.restype = None
+        self.L.orc_sort_surfels_spatially(C.byref(self.surfels), float(grid_cell_size))
+
     def update_surfel_normals(self):
         self.L.orc_update_surfel_normals(C.byref(self.depth_cam), C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),
                                          C.byref(self.surfels))

@@ -227,6 +227,8 @@ void orc_delete_surfels_and_update_radii(int min_observation_count, const orc_ca
                                          int num_kfs, orc_surfels* s);
 /* B/kernel_compact_surfels.cu:159-279 */
 void orc_compact_surfels(orc_surfels* s);
+/* kernels_lifecycle.hip: sort_surfels_spatially (ours, not the reference's): stable Morton order over a world grid */
+void orc_sort_surfels_spatially(orc_surfels* s, float grid_cell_size);
 
 /* ---- intrinsics (B/kernel_opt_intrinsics.cc:39-281) ---- */
 void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_intrinsics,

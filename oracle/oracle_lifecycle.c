@@ -265,3 +265,55 @@ void orc_compact_surfels(orc_surfels* s) {
   free(invalid);
   s->surfels_size = s->surfel_count;
 }
+
+/* ---- spatial order (no counterpart in the reference; mirrors kernels_lifecycle.hip: sort_surfels_spatially) ---- */
+static inline uint64_t spread21(uint64_t v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+typedef struct { uint64_t key; uint32_t idx; } sort_item;
+static int cmp_sort_item(const void* a, const void* b) {
+  const sort_item* x = (const sort_item*)a; const sort_item* y = (const sort_item*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);   /* ties keep their order: a stable sort */
+}
+void orc_sort_surfels_spatially(orc_surfels* s, float grid_cell_size) {
+  const uint32_t n = s->surfels_size;
+  if (n < 2) return;
+  const float inv_cell = 1.0f / grid_cell_size;
+  sort_item* items = (sort_item*)malloc(sizeof(sort_item) * n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const v3 p = surfel_position(s, i);
+    uint64_t key = ~0ull;
+    if (p.x == p.x) {
+      const float c[3] = {p.x, p.y, p.z};
+      uint64_t q[3];
+      for (int a = 0; a < 3; ++a) {
+        float g = floorf(c[a] * inv_cell) + 1048576.f;
+        g = fminf(fmaxf(g, 0.f), 2097151.f);
+        q[a] = (uint64_t)g;
+      }
+      key = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+    }
+    items[i].key = key; items[i].idx = i;
+  }
+  qsort(items, n, sizeof(sort_item), cmp_sort_item);
+  float* tmp = (float*)malloc(sizeof(float) * n);
+  for (int row = 0; row < ORC_SURFEL_DATA_ATTRS; ++row) {
+    float* r = srow(s, row);
+    for (uint32_t i = 0; i < n; ++i) tmp[i] = r[items[i].idx];
+    memcpy(r, tmp, sizeof(float) * n);
+  }
+  if (s->active) {
+    uint8_t* t8 = (uint8_t*)tmp;
+    for (uint32_t i = 0; i < n; ++i) t8[i] = s->active[items[i].idx];
+    memcpy(s->active, t8, n);
+  }
+  free(tmp);
+  free(items);
+}

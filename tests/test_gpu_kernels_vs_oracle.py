@@ -188,3 +188,38 @@ def test_bilateral_filter_matches_oracle(scene):
         assert diff.max() <= 1
         assert (diff != 0).mean() < 1e-3
         assert (ref != 65535).sum() > 10000
+
+
+def test_spatial_sort_matches_oracle_and_changes_no_result(scene, synced):
+    """bahip_sort_surfels_spatially: the same stable Morton order as the oracle's restatement, bit for bit; and a geometry
+    step on the sorted cloud gives every surfel the bits it gets in the unsorted cloud (results do not depend on the order)."""
+    ba, g = synced
+    ba.use_depth, ba.use_desc = 1, 1
+    data, active = common.oracle_surfels(ba)
+    n = data.shape[1]
+    rng = np.random.Generator(np.random.PCG64(12))
+    data[2] += rng.uniform(0, 0.004, n).astype(np.float32)
+    data[5] = np.arange(n, dtype=np.uint32).view(np.float32)          # tag every surfel with its original index (colour row)
+
+    def geometry_step(order_then_sort):
+        ba.surfel_data[:, :n] = data
+        g.upload_surfels(data, active * 0)
+        if order_then_sort:
+            g.sort_surfels_spatially(0.02)
+            ba.sort_surfels_spatially(0.02)
+            assert np.array_equal(g.download_surfels()[:8].view(np.uint32), ba.surfel_data[:8, :n].view(np.uint32))
+        g.bind_keyframes()
+        g.update_surfel_activation()
+        g.optimize_geometry_iteration(True, True)
+        return g.download_surfels()[:8].view(np.uint32)
+
+    plain = geometry_step(False)
+    sorted_ = geometry_step(True)
+    tags = sorted_[5]
+    assert not np.array_equal(tags, np.arange(n, dtype=np.uint32))     # the sort did reorder
+    assert np.array_equal(np.sort(tags), np.arange(n, dtype=np.uint32))   # a permutation
+    assert np.array_equal(sorted_, plain[:, tags])                      # same bits per surfel, wherever it sits
+    # neighbours in the buffer are neighbours in space now: mean distance between consecutive surfels shrinks
+    pos_plain, pos_sorted = plain[:3].view(np.float32), sorted_[:3].view(np.float32)
+    step = lambda p: np.linalg.norm(np.diff(p, axis=1), axis=0).mean()
+    assert step(pos_sorted) < 0.8 * step(pos_plain)
