@@ -46,7 +46,7 @@ template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
 pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                        int num_work, SurfelsView s, float* __restrict__ Hb) {
-  const uint32_t i = blockIdx.x * kPoseBlock + threadIdx.x;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPoseBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -222,7 +222,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
   // (the sums are merged by atomics, so who visits a keyframe does not matter).
-  const unsigned tiles = (s.size + kPoseBlock - 1) / kPoseBlock;
+  const unsigned tiles = ((s.size + kPoseBlock - 1) / kPoseBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk);   // whole XCD chunks
   const int forced = g_forced_pose_parts;
   const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
                          : tiles >= 32768 ? 2 : tiles >= 8192 ? 4 : 8;   // measured: 46.9 k tiles 2.01 / 1.79 / 1.80 ms with 1 / 2 / 4 parts

@@ -74,7 +74,7 @@ __device__ __forceinline__ bool position_valid(Vec3 p) { return p.x == p.x; }   
 // B/kernel_surfel_activation.cu:38-94
 __global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
 activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t surfels_size) {
-  const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + threadIdx.x;
   const bool in_range = i < surfels_size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
 normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
   __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 4 * 64];
   const int lane = threadIdx.x & 63;
-  const uint32_t i = blockIdx.x * kSurfelBlock + lane;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
@@ -153,7 +153,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
   const int lane = threadIdx.x & 63;
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
-  const uint32_t i = blockIdx.x * kSurfelBlock + lane;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
@@ -266,7 +266,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
-static inline unsigned grid_for(uint32_t n) { return (n + kSurfelBlock - 1) / kSurfelBlock; }
+static inline unsigned grid_for(uint32_t n) { return ((n + kSurfelBlock - 1) / kSurfelBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk); }   // whole XCD chunks
 
 void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                        uint32_t surfels_size) {
@@ -323,7 +323,7 @@ void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const In
 namespace bahip {
 __global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
 count_pairs_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, unsigned long long* counts) {
-  const uint32_t i = blockIdx.x * kSurfelBlock + threadIdx.x;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);

@@ -18,6 +18,16 @@
 
 namespace bahip {
 
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  With the surfel
+// buffer in spatial order, neighbouring tiles read the same image lines; giving every XCD runs of kXcdChunk consecutive
+// tiles (instead of every 8th tile) lets those lines be shared in one L2, while the chunks still interleave over the XCDs
+// for balance.  Returns the tile that workgroup `block` of a grid of `num_blocks` (a multiple of 8 * kXcdChunk) owns.
+constexpr uint32_t kXcdChunk = 32;
+__device__ __forceinline__ uint32_t xcd_chunked_tile(uint32_t block) {
+  const uint32_t xcd = block & 7u, j = block >> 3;
+  return ((j / kXcdChunk) * 8u + xcd) * kXcdChunk + (j % kXcdChunk);
+}
+
 struct WaveBounds {
   float cx, cy, cz;   // sphere centre (global frame)
   float r;            // inflated radius; negative = no valid surfel in this wave
