@@ -81,7 +81,9 @@ activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, S
   const Vec3 gn = surfel_normal(s, ii);
   const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
   bool active = false;
-  for_each_candidate(
+  // the reference stops testing a surfel once it is active (B/kernel_surfel_activation.cu:69-72); here the wavefront stops
+  // visiting keyframes once every one of its surfels is
+  for_each_candidate_until(
       num_kfs,
       [&](int k) { return kfs[k].activation == BAHIP_KF_ACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); },
       [&](int k) {
@@ -89,6 +91,7 @@ activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, S
           Assoc r;
           if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) active = true;
         }
+        return __all(active || !in_range) != 0;
       });
   if (in_range) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (active ? kSurfelActiveFlag : 0);
 }

@@ -105,4 +105,21 @@ __device__ __forceinline__ void for_each_candidate(int num_items, Pred pred, Bod
   }
 }
 
+// Like for_each_candidate (one part), but stops as soon as body(k) returns true for the whole wavefront
+// (wave-uniform return value), e.g. "every lane has found what it was looking for".
+template <typename Pred, typename Body>
+__device__ __forceinline__ void for_each_candidate_until(int num_items, Pred pred, Body body) {
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < num_items; base += 64) {
+    const int item = base + lane;
+    const bool cand = (item < num_items) && pred(item);
+    unsigned long long m = __ballot(cand);
+    while (m) {
+      const int k = base + __builtin_ctzll(m);
+      m &= m - 1;
+      if (body(k)) return;
+    }
+  }
+}
+
 }  // namespace bahip
