@@ -170,10 +170,17 @@ def main():
     dist = None
     if world > 1 or args.force_allreduce:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a device (plumbing test on a 1-GPU box: RCCL
+        # refuses two ranks on one device, gloo stages the all-reduce through the host)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+        torch.cuda.set_device(device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
 
