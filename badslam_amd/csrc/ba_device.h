@@ -328,6 +328,26 @@ __device__ __forceinline__ void sample_luma_and_gradient(const Intrinsics& in, c
   *dy = (t.br - t.tr) * tx + (t.bl - t.tl) * (1 - tx);
 }
 
+// The same for a point whose footprint lies inside the image (0 <= x - 0.5 < w, 0 <= y - 0.5 < h): none of the clamps
+// above changes a value then (xb = x - 0.5, trunc(max(0, xb)) == floor(xb), and x - 0.5 - gx is the fraction a in [0, 1)),
+// so they are not evaluated.  Same operations in the same order on the values that matter: identical results.
+__device__ __forceinline__ bool luma_sample_is_interior(int w, int h, float x, float y) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  return xb >= 0.f && xb < (float)w && yb >= 0.f && yb < (float)h;
+}
+__device__ __forceinline__ void sample_luma_and_gradient_interior(const Intrinsics& in, const uint32_t* lumafp, float x, float y,
+                                                                  float* value, float* dx, float* dy) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = xb - fx, b = yb - fy;
+  const Luma4 t = luma_footprint(in, lumafp, (int)fx, (int)fy);
+  const float top = t.tl + a * (t.tr - t.tl);
+  const float bot = t.bl + a * (t.br - t.bl);
+  *value = top + b * (bot - top);
+  *dx = (t.br - t.bl) * b + (t.tr - t.tl) * (1 - b);
+  *dy = (t.br - t.tr) * a + (t.bl - t.tl) * (1 - a);
+}
+
 // B/surfel_projection.cuh:194-207
 __device__ __forceinline__ bool depth_to_color_pixel(const Intrinsics& in, float pxx, float pxy, float* cx, float* cy) {
   *cx = in.d2c_fx * pxx + in.d2c_cx;
@@ -375,9 +395,15 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
   const int w = in.cwidth, h = in.cheight;
   if (kWithGradient) {
     float i0, i1, i2, cdx, cdy, adx, ady, bdx, bdy;
-    sample_luma_and_gradient(in, lumafp, w, h, cx, cy, &i0, &cdx, &cdy);
-    sample_luma_and_gradient(in, lumafp, w, h, t1x, t1y, &i1, &adx, &ady);
-    sample_luma_and_gradient(in, lumafp, w, h, t2x, t2y, &i2, &bdx, &bdy);
+    if (luma_sample_is_interior(w, h, cx, cy) && luma_sample_is_interior(w, h, t1x, t1y) && luma_sample_is_interior(w, h, t2x, t2y)) {
+      sample_luma_and_gradient_interior(in, lumafp, cx, cy, &i0, &cdx, &cdy);
+      sample_luma_and_gradient_interior(in, lumafp, t1x, t1y, &i1, &adx, &ady);
+      sample_luma_and_gradient_interior(in, lumafp, t2x, t2y, &i2, &bdx, &bdy);
+    } else {
+      sample_luma_and_gradient(in, lumafp, w, h, cx, cy, &i0, &cdx, &cdy);
+      sample_luma_and_gradient(in, lumafp, w, h, t1x, t1y, &i1, &adx, &ady);
+      sample_luma_and_gradient(in, lumafp, w, h, t2x, t2y, &i2, &bdx, &bdy);
+    }
     e->r1 = (180.f * (i1 - i0)) - d1;
     e->r2 = (180.f * (i2 - i0)) - d2;
     e->gx1 = 180.f * (adx - cdx);
