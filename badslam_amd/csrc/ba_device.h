@@ -264,8 +264,8 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   } else {
     if (fabsf(r->local.z - r->depth) > thr) return false;
   }
-  const float dist = norm3(r->local);
-  if ((1.0f / dist) * dot3(r->local, r->nl) > 0) return false;
+  // the reference tests (1 / |p|) * dot(p, n) > 0; |p| > 0 here, so the sign test needs no normalisation (oracle: same)
+  if (dot3(r->local, r->nl) > 0) return false;
   r->normal_bits = (uint16_t)(word >> 16);
   const Vec3 m = unpack_normal8(r->normal_bits);
   if (dot3(r->nl, m) < kCosNormalCompat) return false;

@@ -178,7 +178,7 @@ create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ k
     const float diff = d - lp.z;
     if (diff > thr) { violations += 1; continue; }
     else if (diff < -thr) continue;
-    if ((1.0f / norm3(lp)) * dot3(lp, nl) > 0) continue;
+    if (dot3(lp, nl) > 0) continue;   // sign of (1 / |p|) * dot(p, n), see project_associate
     if (dot3(nl, unpack_normal8(pitched_load(ck.normals, ck.normals_pitch, py, px))) < kCosNormalCompat) continue;
     observations += 1;
   }

@@ -391,9 +391,10 @@ int orc_project_associate(const proj_params* p, uint32_t i, proj_result* r, int*
     if (fabsf(r->local_position.z - calibrated_depth) > thr) return 0;
   }
 
-  const float surfel_distance = v3_norm(r->local_position);
-  const float dot_angle = (1.0f / surfel_distance) * v3_dot(r->local_position, nl);
-  if (dot_angle > 0) return 0;
+  /* The reference tests (1 / |p|) * dot(p, n) > 0 (B/surfel_projection_nvcc_only.cuh:107-111).  |p| > 0 here (z > 0), so the
+   * sign is that of the dot product; the normalisation (a square root and a division per test) is left out on both sides,
+   * oracle and kernels. */
+  if (v3_dot(r->local_position, nl) > 0) return 0;
 
   float m[3];
   orc_unpack_normal8(p->normals[(size_t)r->py * p->width + r->px], m);

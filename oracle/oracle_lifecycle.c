@@ -115,8 +115,7 @@ static int pixel_surfel_associated(v3 lp, v3 nl, const orc_keyframe* covis, cons
   const float diff = d - lp.z;
   if (diff > thr) { *fsv = 1; return 0; }
   else if (diff < -thr) return 0;
-  const float dist = v3_norm(lp);
-  if ((1.0f / dist) * v3_dot(lp, nl) > 0) return 0;
+  if (v3_dot(lp, nl) > 0) return 0;   /* sign of (1 / |p|) * dot(p, n), B/surfel_projection_nvcc_only.cuh:216-220; see orc_project_associate */
   float m[3];
   orc_unpack_normal8(covis->normals[idx], m);
   if (v3_dot(nl, v3_make(m[0], m[1], m[2])) < ORC_COS_NORMAL_COMPAT) return 0;
