@@ -40,9 +40,13 @@ __device__ __forceinline__ Vec3 mk3(float x, float y, float z) { Vec3 r; r.x = x
 __device__ __forceinline__ Vec3 operator+(Vec3 a, Vec3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ Vec3 operator*(float m, Vec3 b) { return mk3(m * b.x, m * b.y, m * b.z); }
-__device__ __forceinline__ float dot3(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float sqlen3(Vec3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-__device__ __forceinline__ float norm3(Vec3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// Sums of products are written as explicit fused multiply-add chains, the same chains as the oracle's helpers
+// (oracle_internal.h): -ffp-contract=off keeps the compiler from fusing anything else, so both sides round alike, and the
+// kernels (VALU-issue bound) spend one instruction per term.  (The reference's nvcc build fuses at its own discretion.)
+__device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float dot3(Vec3 a, Vec3 b) { return mad(a.z, b.z, mad(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float sqlen3(Vec3 a) { return mad(a.z, a.z, mad(a.y, a.y, a.x * a.x)); }
+__device__ __forceinline__ float norm3(Vec3 a) { return sqrtf(sqlen3(a)); }
 __device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {
   return mk3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
 }
@@ -173,43 +177,43 @@ __device__ __forceinline__ uint16_t pack_normal8(float x, float y) {
 
 // ---- transforms ----------------------------------------------------------------------------------
 __device__ __forceinline__ Vec3 transform34(const float* F, Vec3 p) {
-  return mk3(F[0] * p.x + F[1] * p.y + F[2] * p.z + F[3],
-             F[4] * p.x + F[5] * p.y + F[6] * p.z + F[7],
-             F[8] * p.x + F[9] * p.y + F[10] * p.z + F[11]);
+  return mk3(mad(F[2], p.z, mad(F[1], p.y, mad(F[0], p.x, F[3]))),
+             mad(F[6], p.z, mad(F[5], p.y, mad(F[4], p.x, F[7]))),
+             mad(F[10], p.z, mad(F[9], p.y, mad(F[8], p.x, F[11]))));
 }
 __device__ __forceinline__ Vec3 rotate34(const float* F, Vec3 p) {
-  return mk3(F[0] * p.x + F[1] * p.y + F[2] * p.z,
-             F[4] * p.x + F[5] * p.y + F[6] * p.z,
-             F[8] * p.x + F[9] * p.y + F[10] * p.z);
+  return mk3(mad(F[2], p.z, mad(F[1], p.y, F[0] * p.x)),
+             mad(F[6], p.z, mad(F[5], p.y, F[4] * p.x)),
+             mad(F[10], p.z, mad(F[9], p.y, F[8] * p.x)));
 }
 __device__ __forceinline__ Vec3 mul33(const float* R, Vec3 p) {
-  return mk3(R[0] * p.x + R[1] * p.y + R[2] * p.z,
-             R[3] * p.x + R[4] * p.y + R[5] * p.z,
-             R[6] * p.x + R[7] * p.y + R[8] * p.z);
+  return mk3(mad(R[2], p.z, mad(R[1], p.y, R[0] * p.x)),
+             mad(R[5], p.z, mad(R[4], p.y, R[3] * p.x)),
+             mad(R[8], p.z, mad(R[7], p.y, R[6] * p.x)));
 }
 
 // ---- depth ---------------------------------------------------------------------------------------
 // B/util.cuh:62-69
 __device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t raw) {
   const float inv_depth = 1.0f / (raw_to_float_depth * raw);
-  return 1.f / (inv_depth + cfactor * expf(-a * inv_depth));
+  return 1.f / mad(cfactor, expf(-a * inv_depth), inv_depth);
 }
 __device__ __forceinline__ float cfactor_at(const Intrinsics& in, int px, int py) {
   // px, py >= 0, so the shift is the same integer division
   if (in.cell_shift >= 0) return pitched_load(in.cfactor, in.cfactor_pitch, py >> in.cell_shift, px >> in.cell_shift);
   return pitched_load(in.cfactor, in.cfactor_pitch, py / in.cell, px / in.cell);
 }
-__device__ __forceinline__ float unp_nx(const Intrinsics& in, float px) { return in.fx_inv * px + in.cx_inv; }
-__device__ __forceinline__ float unp_ny(const Intrinsics& in, float py) { return in.fy_inv * py + in.cy_inv; }
+__device__ __forceinline__ float unp_nx(const Intrinsics& in, float px) { return mad(in.fx_inv, px, in.cx_inv); }
+__device__ __forceinline__ float unp_ny(const Intrinsics& in, float py) { return mad(in.fy_inv, py, in.cy_inv); }
 __device__ __forceinline__ Vec3 unproject(const Intrinsics& in, int x, int y, float depth) {
-  return mk3(depth * (in.fx_inv * x + in.cx_inv), depth * (in.fy_inv * y + in.cy_inv), depth);
+  return mk3(depth * mad(in.fx_inv, (float)x, in.cx_inv), depth * mad(in.fy_inv, (float)y, in.cy_inv), depth);
 }
 // B/cost_function.cuh:81-88
 __device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, Vec3 nl, float baseline_fx) {
-  return (0.1f * fabsf(nl.x * nx + nl.y * ny + nl.z) * (depth * depth)) / baseline_fx;
+  return (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth)) / baseline_fx;
 }
 __device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float depth, Vec3 nl, float baseline_fx) {
-  return baseline_fx / (0.1f * fabsf(nl.x * nx + nl.y * ny + nl.z) * (depth * depth));
+  return baseline_fx / (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth));
 }
 
 // ---- robust weights (B/robust_weighting.cuh:39-86; parameters B/cost_function.cuh:44-52,105-109) ---
@@ -240,12 +244,12 @@ struct Assoc {
 template <bool kFreeSpace>
 __device__ __forceinline__ bool project_associate(const Intrinsics& in, const float* F, const uint32_t* __restrict__ geom,
                                                   Vec3 gp, Vec3 gn, Assoc* r, bool* free_space_violation) {
-  r->local.z = F[8] * gp.x + F[9] * gp.y + F[10] * gp.z + F[11];
+  r->local.z = mad(F[10], gp.z, mad(F[9], gp.y, mad(F[8], gp.x, F[11])));
   if (!(r->local.z > 0.f)) return false;
-  r->local.x = F[0] * gp.x + F[1] * gp.y + F[2] * gp.z + F[3];
-  r->local.y = F[4] * gp.x + F[5] * gp.y + F[6] * gp.z + F[7];
-  r->pxx = in.fx * (r->local.x / r->local.z) + in.cx;
-  r->pxy = in.fy * (r->local.y / r->local.z) + in.cy;
+  r->local.x = mad(F[2], gp.z, mad(F[1], gp.y, mad(F[0], gp.x, F[3])));
+  r->local.y = mad(F[6], gp.z, mad(F[5], gp.y, mad(F[4], gp.x, F[7])));
+  r->pxx = mad(in.fx, r->local.x / r->local.z, in.cx);
+  r->pxy = mad(in.fy, r->local.y / r->local.z, in.cy);
   if (!(r->pxx >= 0.f) || !(r->pxy >= 0.f) || !(r->pxx < (float)in.width) || !(r->pxy < (float)in.height)) return false;
   r->px = (int)r->pxx;
   r->py = (int)r->pxy;
@@ -294,9 +298,9 @@ __device__ __forceinline__ float sample_luma(const Intrinsics& in, const uint32_
   const float fx = floorf(xb), fy = floorf(yb);
   const float a = xb - fx, b = yb - fy;
   const Luma4 t = luma_footprint(in, lumafp, (int)fx, (int)fy);
-  const float top = t.tl + a * (t.tr - t.tl);
-  const float bot = t.bl + a * (t.br - t.bl);
-  return top + b * (bot - top);
+  const float top = mad(a, t.tr - t.tl, t.tl);
+  const float bot = mad(a, t.br - t.bl, t.bl);
+  return mad(b, bot - top, top);
 }
 // Bilinear luma AND the gradient sample of DescriptorJacobianWrtProjectedPosition (B/cost_function.cuh:200-211) at the
 // same point.  Away from the image border both use the same footprint (floor(x - 0.5) == trunc(max(0, x - 0.5))), which
@@ -313,9 +317,9 @@ __device__ __forceinline__ void sample_luma_and_gradient(const Intrinsics& in, c
   const float a = xb - fx, b = yb - fy;
   const int ix = (int)fx, iy = (int)fy;
   Luma4 t = luma_footprint(in, lumafp, ix, iy);
-  const float top = t.tl + a * (t.tr - t.tl);
-  const float bot = t.bl + a * (t.br - t.bl);
-  *value = top + b * (bot - top);
+  const float top = mad(a, t.tr - t.tl, t.tl);
+  const float bot = mad(a, t.br - t.bl, t.bl);
+  *value = mad(b, bot - top, top);
 
   float mx = fmaxf(0.f, x - 0.5f), my = fmaxf(0.f, y - 0.5f);
   if (!(mx < (float)w)) mx = (float)w;
@@ -324,8 +328,8 @@ __device__ __forceinline__ void sample_luma_and_gradient(const Intrinsics& in, c
   const float tx = fmaxf(0.f, fminf(1.f, x - 0.5f - gx));
   const float ty = fmaxf(0.f, fminf(1.f, y - 0.5f - gy));
   if (gx != ix || gy != iy) t = luma_footprint(in, lumafp, gx, gy);
-  *dx = (t.br - t.bl) * ty + (t.tr - t.tl) * (1 - ty);
-  *dy = (t.br - t.tr) * tx + (t.bl - t.tl) * (1 - tx);
+  *dx = mad(t.br - t.bl, ty, (t.tr - t.tl) * (1 - ty));
+  *dy = mad(t.br - t.tr, tx, (t.bl - t.tl) * (1 - tx));
 }
 
 // The same for a point whose footprint lies inside the image (0 <= x - 0.5 < w, 0 <= y - 0.5 < h): none of the clamps
@@ -341,17 +345,17 @@ __device__ __forceinline__ void sample_luma_and_gradient_interior(const Intrinsi
   const float fx = floorf(xb), fy = floorf(yb);
   const float a = xb - fx, b = yb - fy;
   const Luma4 t = luma_footprint(in, lumafp, (int)fx, (int)fy);
-  const float top = t.tl + a * (t.tr - t.tl);
-  const float bot = t.bl + a * (t.br - t.bl);
-  *value = top + b * (bot - top);
-  *dx = (t.br - t.bl) * b + (t.tr - t.tl) * (1 - b);
-  *dy = (t.br - t.tr) * a + (t.bl - t.tl) * (1 - a);
+  const float top = mad(a, t.tr - t.tl, t.tl);
+  const float bot = mad(a, t.br - t.bl, t.bl);
+  *value = mad(b, bot - top, top);
+  *dx = mad(t.br - t.bl, b, (t.tr - t.tl) * (1 - b));
+  *dy = mad(t.br - t.tr, a, (t.bl - t.tl) * (1 - a));
 }
 
 // B/surfel_projection.cuh:194-207
 __device__ __forceinline__ bool depth_to_color_pixel(const Intrinsics& in, float pxx, float pxy, float* cx, float* cy) {
-  *cx = in.d2c_fx * pxx + in.d2c_cx;
-  *cy = in.d2c_fy * pxy + in.d2c_cy;
+  *cx = mad(in.d2c_fx, pxx, in.d2c_cx);
+  *cy = mad(in.d2c_fy, pxy, in.d2c_cy);
   return *cx >= 0 && *cy >= 0 && (int)(*cx) < in.cwidth && (int)(*cy) < in.cheight;
 }
 
@@ -371,11 +375,11 @@ __device__ __forceinline__ TangentPoints surfel_tangent_points(Vec3 gp, Vec3 gn,
 __device__ __forceinline__ void project_tangents(const Intrinsics& in, const float* F, const TangentPoints& tp,
                                                  float* t1x, float* t1y, float* t2x, float* t2y) {
   const Vec3 l1 = transform34(F, tp.q1);
-  *t1x = in.cfx * (l1.x / l1.z) + in.ccx;
-  *t1y = in.cfy * (l1.y / l1.z) + in.ccy;
+  *t1x = mad(in.cfx, l1.x / l1.z, in.ccx);
+  *t1y = mad(in.cfy, l1.y / l1.z, in.ccy);
   const Vec3 l2 = transform34(F, tp.q2);
-  *t2x = in.cfx * (l2.x / l2.z) + in.ccx;
-  *t2y = in.cfy * (l2.y / l2.z) + in.ccy;
+  *t2x = mad(in.cfx, l2.x / l2.z, in.ccx);
+  *t2y = mad(in.cfy, l2.y / l2.z, in.ccy);
 }
 __device__ __forceinline__ void tangent_projections(const Intrinsics& in, const float* F, Vec3 gp, Vec3 gn, float radius_sq,
                                                     float* t1x, float* t1y, float* t2x, float* t2y) {
@@ -404,8 +408,8 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
       sample_luma_and_gradient(in, lumafp, w, h, t1x, t1y, &i1, &adx, &ady);
       sample_luma_and_gradient(in, lumafp, w, h, t2x, t2y, &i2, &bdx, &bdy);
     }
-    e->r1 = (180.f * (i1 - i0)) - d1;
-    e->r2 = (180.f * (i2 - i0)) - d2;
+    e->r1 = mad(180.f, i1 - i0, -d1);
+    e->r2 = mad(180.f, i2 - i0, -d2);
     e->gx1 = 180.f * (adx - cdx);
     e->gy1 = 180.f * (ady - cdy);
     e->gx2 = 180.f * (bdx - cdx);
@@ -414,8 +418,8 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
     const float i0 = sample_luma(in, lumafp, w, h, cx, cy);
     const float i1 = sample_luma(in, lumafp, w, h, t1x, t1y);
     const float i2 = sample_luma(in, lumafp, w, h, t2x, t2y);
-    e->r1 = (180.f * (i1 - i0)) - d1;
-    e->r2 = (180.f * (i2 - i0)) - d2;
+    e->r1 = mad(180.f, i1 - i0, -d1);
+    e->r2 = mad(180.f, i2 - i0, -d2);
   }
 }
 template <bool kWithGradient>
@@ -432,26 +436,26 @@ __device__ __forceinline__ void jac_depth_pose(Vec3 nl, Vec3 u, float inv_std, f
   J[0] = inv_std * nl.x;
   J[1] = inv_std * nl.y;
   J[2] = inv_std * nl.z;
-  J[3] = inv_std * (-nl.y * u.z + nl.z * u.y);
-  J[4] = inv_std * (nl.x * u.z - nl.z * u.x);
-  J[5] = inv_std * (-nl.x * u.y + nl.y * u.x);
+  J[3] = inv_std * mad(nl.z, u.y, -(nl.y * u.z));
+  J[4] = inv_std * mad(nl.x, u.z, -(nl.z * u.x));
+  J[5] = inv_std * mad(nl.y, u.x, -(nl.x * u.y));
 }
 // B/kernel_opt_pose.cu:126-141: ls = surfel position in the keyframe frame, gx, gy = image gradient of the residual times fx, fy.
 __device__ __forceinline__ void jac_descriptor_pose(Vec3 ls, float gx, float gy, float (&J)[6]) {
   const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
   J[0] = -gx * inv_z;
   J[1] = -gy * inv_z;
-  J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
-  J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
-  J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
-  J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+  J[2] = mad(ls.y, gy, ls.x * gx) * inv_z_sq;
+  J[3] = mad(mad(ls.y, ls.y, z_sq), gy, xy * gx) * inv_z_sq;
+  J[4] = -mad(mad(ls.x, ls.x, z_sq), gx, xy * gy) * inv_z_sq;
+  J[5] = -mad(ls.x, gy, -(ls.y * gx)) * inv_z;
 }
 // B/kernel_opt_geometry.cu:170-190: rn = surfel normal, lp = surfel position in the keyframe frame, g = gradient per pixel.
 __device__ __forceinline__ float jac_descriptor_surfel(Vec3 rn, Vec3 lp, float gx, float gy, float cfx, float cfy) {
-  const float term1 = -cfx * (rn.x * lp.z - rn.z * lp.x);
-  const float term2 = -cfy * (rn.y * lp.z - rn.z * lp.y);
+  const float term1 = -cfx * mad(rn.x, lp.z, -(rn.z * lp.x));
+  const float term2 = -cfy * mad(rn.y, lp.z, -(rn.z * lp.y));
   const float term3 = 1.f / (lp.z * lp.z);
-  return -(gx * term1 + gy * term2) * term3;
+  return -mad(gy, term2, gx * term1) * term3;
 }
 // B/kernel_opt_intrinsics.cu:107-140: rows fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor.
 __device__ __forceinline__ void jac_depth_intrinsics(int px, int py, float depth, float inv_std, float n_dot_Frow0, float n_dot_Frow1,

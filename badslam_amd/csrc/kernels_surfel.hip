@@ -181,8 +181,8 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
         const float raw = inv_std * dot3(r.nl, u - r.local);
         const float w = depth_residual_weight(raw);
         const float wj = w * jac;
-        acc[0] += wj * jac;
-        acc[1] += wj * raw;
+        acc[0] = mad(wj, jac, acc[0]);
+        acc[1] = mad(wj, raw, acc[1]);
       }, kSumClasses, cls);
     });
     if (!live || !writer) return;
@@ -215,8 +215,8 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
         const Vec3 u = unproject(in, r.px, r.py, r.depth);
         const float raw = inv_std * dot3(r.nl, u - r.local);
         const float w = depth_residual_weight(raw);
-        a0 += w * jac * jac;
-        a6 += w * raw * jac;
+        a0 = mad(w * jac, jac, a0);
+        a6 = mad(w * raw, jac, a6);
       }
       float cx, cy;
       if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
@@ -229,10 +229,10 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
         const float wr1 = w1 * e.r1;
         const float w2 = descriptor_residual_weight(e.r2);
         const float wr2 = w2 * e.r2;
-        a0 += w1 * jp1 * jp1 + w2 * jp2 * jp2;
+        a0 = mad(w2 * jp2, jp2, mad(w1 * jp1, jp1, a0));
         a1 += w1 * jp1 * jd;
         a3 += w1 * jd * jd;
-        a6 += wr1 * jp1 + wr2 * jp2;
+        a6 = mad(wr2, jp2, mad(wr1, jp1, a6));
         a7 += wr1 * jd;
         a2 += w2 * jp2 * jd;
         a5 += w2 * jd * jd;
@@ -339,7 +339,7 @@ count_pairs_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, 
         Assoc r;
         const bool hit = in_range && project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr);
         const Vec3 l = transform34(kfs[k].pose.F, gp);
-        const float px = in.fx * (l.x / l.z) + in.cx, py = in.fy * (l.y / l.z) + in.cy;
+        const float px = mad(in.fx, l.x / l.z, in.cx), py = mad(in.fy, l.y / l.z, in.cy);
         const bool inside = in_range && l.z > 0 && px >= 0 && py >= 0 && px < in.width && py < in.height;
         const unsigned long long m = __ballot(hit);
         cand += 1; wave_hits += (m != 0); lane_hits += __popcll(m); in_image += __popcll(__ballot(inside));

@@ -255,7 +255,7 @@ float orc_half_to_float(uint16_t h) {
 /* B/util.cuh:62-69 */
 float orc_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t measured_depth) {
   const float inv_depth = 1.0f / (raw_to_float_depth * measured_depth);
-  return 1.f / (inv_depth + cfactor * expf(-a * inv_depth));
+  return 1.f / mad(cfactor, expf(-a * inv_depth), inv_depth);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -284,9 +284,9 @@ float orc_sample_luma(const uint8_t* rgba, int width, int height, float x, float
   const float tr = luma_texel(rgba, width, height, ix + 1, iy);
   const float bl = luma_texel(rgba, width, height, ix, iy + 1);
   const float br = luma_texel(rgba, width, height, ix + 1, iy + 1);
-  const float top = tl + a * (tr - tl);
-  const float bot = bl + a * (br - bl);
-  return top + b * (bot - top);
+  const float top = mad(a, tr - tl, tl);
+  const float bot = mad(a, br - bl, bl);
+  return mad(b, bot - top, top);
 }
 
 /* B/cost_function.cuh:115-136 */
@@ -296,13 +296,13 @@ void orc_tangent_projections(v3 gp, v3 gn, float radius_sq, const float* F, cons
   v3 t1 = v3_cross(gn, (fabsf(gn.x) > 0.9f) ? v3_make(0, 1, 0) : v3_make(1, 0, 0));
   t1 = v3_scale(kTangentScaling * sqrtf(radius_sq / fmaxf(1e-12f, v3_sqlen(t1))), t1);
   v3 l1 = m34_mul(F, v3_add(gp, t1));
-  t1_pxy[0] = color_cam->fx * (l1.x / l1.z) + color_cam->cx;
-  t1_pxy[1] = color_cam->fy * (l1.y / l1.z) + color_cam->cy;
+  t1_pxy[0] = mad(color_cam->fx, l1.x / l1.z, color_cam->cx);
+  t1_pxy[1] = mad(color_cam->fy, l1.y / l1.z, color_cam->cy);
   v3 t2 = v3_cross(gn, t1);
   t2 = v3_scale(kTangentScaling * sqrtf(radius_sq / fmaxf(1e-12f, v3_sqlen(t2))), t2);
   v3 l2 = m34_mul(F, v3_add(gp, t2));
-  t2_pxy[0] = color_cam->fx * (l2.x / l2.z) + color_cam->cx;
-  t2_pxy[1] = color_cam->fy * (l2.y / l2.z) + color_cam->cy;
+  t2_pxy[0] = mad(color_cam->fx, l2.x / l2.z, color_cam->cx);
+  t2_pxy[1] = mad(color_cam->fy, l2.y / l2.z, color_cam->cy);
 }
 
 /* B/cost_function.cuh:140-156 */
@@ -311,8 +311,8 @@ void orc_raw_descriptor_residual(const orc_keyframe* kf, const float c[2], const
   const float intensity = orc_sample_luma(kf->color, kf->color_width, kf->color_height, c[0], c[1]);
   const float t1_intensity = orc_sample_luma(kf->color, kf->color_width, kf->color_height, t1[0], t1[1]);
   const float t2_intensity = orc_sample_luma(kf->color, kf->color_width, kf->color_height, t2[0], t2[1]);
-  *r1 = (180.f * (t1_intensity - intensity)) - d1;
-  *r2 = (180.f * (t2_intensity - intensity)) - d2;
+  *r1 = mad(180.f, t1_intensity - intensity, -d1);
+  *r2 = mad(180.f, t2_intensity - intensity, -d2);
 }
 
 /* One sample point of B/cost_function.cuh:200-211.  The four taps sit exactly on texel centres,
@@ -329,8 +329,8 @@ static void point_gradient(const orc_keyframe* kf, float qx, float qy, float* dx
   const float top_right = luma_texel(kf->color, w, h, ix + 1, iy);
   const float bottom_left = luma_texel(kf->color, w, h, ix, iy + 1);
   const float bottom_right = luma_texel(kf->color, w, h, ix + 1, iy + 1);
-  *dx = (bottom_right - bottom_left) * ty + (top_right - top_left) * (1 - ty);
-  *dy = (bottom_right - top_right) * tx + (bottom_left - top_left) * (1 - tx);
+  *dx = mad(bottom_right - bottom_left, ty, (top_right - top_left) * (1 - ty));
+  *dy = mad(bottom_right - top_right, tx, (bottom_left - top_left) * (1 - tx));
 }
 
 /* B/cost_function.cuh:191-254 */
@@ -358,13 +358,13 @@ int orc_project_associate(const proj_params* p, uint32_t i, proj_result* r, int*
   r->global_position = surfel_position(p->s, i);
   const float* F = p->F;
   const v3 g = r->global_position;
-  r->local_position.z = F[8] * g.x + F[9] * g.y + F[10] * g.z + F[11];
+  r->local_position.z = mad(F[10], g.z, mad(F[9], g.y, mad(F[8], g.x, F[11])));
   if (!(r->local_position.z > 0.f)) return 0;
-  r->local_position.x = F[0] * g.x + F[1] * g.y + F[2] * g.z + F[3];
-  r->local_position.y = F[4] * g.x + F[5] * g.y + F[6] * g.z + F[7];
+  r->local_position.x = mad(F[2], g.z, mad(F[1], g.y, mad(F[0], g.x, F[3])));
+  r->local_position.y = mad(F[6], g.z, mad(F[5], g.y, mad(F[4], g.x, F[7])));
 
-  r->pxx = p->fx * (r->local_position.x / r->local_position.z) + p->cx;
-  r->pxy = p->fy * (r->local_position.y / r->local_position.z) + p->cy;
+  r->pxx = mad(p->fx, r->local_position.x / r->local_position.z, p->cx);
+  r->pxy = mad(p->fy, r->local_position.y / r->local_position.z, p->cy);
   if (!(r->pxx >= 0.f) || !(r->pxy >= 0.f) || !(r->pxx < (float)p->width) || !(r->pxy < (float)p->height)) return 0;
   r->px = (int)r->pxx;
   r->py = (int)r->pxy;
@@ -422,12 +422,7 @@ int orc_evaluate_pair(const orc_camera* color_cam, const orc_camera* depth_cam, 
   o->depth_inv_stddev = inv_std;
   o->depth_residual = raw;
   o->depth_weight = depth_residual_weight(raw);
-  o->depth_jac_pose[0] = inv_std * nl.x;
-  o->depth_jac_pose[1] = inv_std * nl.y;
-  o->depth_jac_pose[2] = inv_std * nl.z;
-  o->depth_jac_pose[3] = inv_std * (-nl.y * u.z + nl.z * u.y);
-  o->depth_jac_pose[4] = inv_std * (nl.x * u.z - nl.z * u.x);
-  o->depth_jac_pose[5] = inv_std * (-nl.x * u.y + nl.y * u.x);
+  jac_depth_pose(nl, u, inv_std, o->depth_jac_pose);
   o->depth_jac_surfel = -inv_std;
 
   depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
@@ -443,23 +438,10 @@ int orc_evaluate_pair(const orc_camera* color_cam, const orc_camera* depth_cam, 
     orc_descriptor_gradient(kf, c, t1, t2, o->grad);
     const v3 ls = r.local_position;
     /* PixelCenterProjector fx, fy == camera fx, fy (B/surfel_projection.h:53-59) */
-    const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
     for (int k = 0; k < 2; ++k) {
-      const float gx = o->grad[2 * k + 0] * color_cam->fx;
-      const float gy = o->grad[2 * k + 1] * color_cam->fy;
-      float* J = o->desc_jac_pose[k];
-      J[0] = -gx * inv_z;
-      J[1] = -gy * inv_z;
-      J[2] = (ls.x * gx + ls.y * gy) * inv_z_sq;
-      J[3] = ((ls.y * ls.y + z_sq) * gy + xy * gx) * inv_z_sq;
-      J[4] = -((ls.x * ls.x + z_sq) * gx + xy * gy) * inv_z_sq;
-      J[5] = -(ls.x * gy - ls.y * gx) * inv_z;
+      jac_descriptor_pose(ls, o->grad[2 * k + 0] * color_cam->fx, o->grad[2 * k + 1] * color_cam->fy, o->desc_jac_pose[k]);
+      o->desc_jac_surfel[k] = jac_descriptor_surfel(nl, ls, o->grad[2 * k + 0], o->grad[2 * k + 1], color_cam->fx, color_cam->fy);
     }
-    const float term1 = -color_cam->fx * (nl.x * ls.z - nl.z * ls.x);
-    const float term2 = -color_cam->fy * (nl.y * ls.z - nl.z * ls.y);
-    const float term3 = 1.f / (ls.z * ls.z);
-    o->desc_jac_surfel[0] = -(o->grad[0] * term1 + o->grad[1] * term2) * term3;
-    o->desc_jac_surfel[1] = -(o->grad[2] * term1 + o->grad[3] * term2) * term3;
   }
   return 1;
 }

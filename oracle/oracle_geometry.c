@@ -98,8 +98,8 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         const float raw = inv_std * v3_dot(rn, v3_sub(u, r.local_position));
         const float w = depth_residual_weight(raw);
         const float weighted_jacobian = w * depth_jacobian;
-        part[0][j] += weighted_jacobian * depth_jacobian;
-        part[1][j] += weighted_jacobian * raw;
+        part[0][j] = mad(weighted_jacobian, depth_jacobian, part[0][j]);
+        part[1][j] = mad(weighted_jacobian, raw, part[1][j]);
       }
       acc[0][i] = combine4(part[0]); acc[1][i] = combine4(part[1]);
       const float Hs = acc[0][i];
@@ -137,8 +137,8 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
         const float raw = inv_std * v3_dot(rn, v3_sub(u, r.local_position));
         const float w = depth_residual_weight(raw);
-        part[0][j] += w * depth_jacobian * depth_jacobian;
-        part[6][j] += w * raw * depth_jacobian;
+        part[0][j] = mad(w * depth_jacobian, depth_jacobian, part[0][j]);
+        part[6][j] = mad(w * raw, depth_jacobian, part[6][j]);
       }
       float c[2];
       if (transform_depth_to_color(r.pxx, r.pxy, &d2c, &c[0], &c[1])) {
@@ -154,10 +154,10 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         const float wr1 = w1 * raw1;
         const float w2 = descriptor_residual_weight(raw2);
         const float wr2 = w2 * raw2;
-        part[0][j] += w1 * jp1 * jp1 + w2 * jp2 * jp2;
+        part[0][j] = mad(w2 * jp2, jp2, mad(w1 * jp1, jp1, part[0][j]));
         part[1][j] += w1 * jp1 * jd;
         part[3][j] += w1 * jd * jd;
-        part[6][j] += wr1 * jp1 + wr2 * jp2;
+        part[6][j] = mad(wr2, jp2, mad(wr1, jp1, part[6][j]));
         part[7][j] += wr1 * jd;
         part[2][j] += w2 * jp2 * jd;
         part[5][j] += w2 * jd * jd;
