@@ -210,7 +210,7 @@ __device__ __forceinline__ Vec3 unproject(const Intrinsics& in, int x, int y, fl
 }
 // B/cost_function.cuh:81-88
 __device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, Vec3 nl, float baseline_fx) {
-  return (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth)) / baseline_fx;
+  return (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth)) * (1.f / baseline_fx);
 }
 __device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float depth, Vec3 nl, float baseline_fx) {
   return baseline_fx / (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth));
@@ -218,11 +218,12 @@ __device__ __forceinline__ float depth_inv_stddev(float nx, float ny, float dept
 
 // ---- robust weights (B/robust_weighting.cuh:39-86; parameters B/cost_function.cuh:44-52,105-109) ---
 __device__ __forceinline__ float tukey_weight10(float r) {
-  if (fabsf(r) < 10.f) { const float q = r / 10.f; const float t = 1.f - q * q; return t * t; }
+  if (fabsf(r) < 10.f) { const float q = r * 0.1f; const float t = 1.f - q * q; return t * t; }
   return 0.f;
 }
 __device__ __forceinline__ float huber_weight10(float r) {
   const float a = fabsf(r);
+  if (!__any(a >= 10.f)) return 1.f;   // no outlier in the wave: skip the division (same values either way)
   return (a < 10.f) ? 1.f : (10.f / a);
 }
 __device__ __forceinline__ float depth_residual_weight(float r) { return 1.f * tukey_weight10(r); }
@@ -248,8 +249,9 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   if (!(r->local.z > 0.f)) return false;
   r->local.x = mad(F[2], gp.z, mad(F[1], gp.y, mad(F[0], gp.x, F[3])));
   r->local.y = mad(F[6], gp.z, mad(F[5], gp.y, mad(F[4], gp.x, F[7])));
-  r->pxx = mad(in.fx, r->local.x / r->local.z, in.cx);
-  r->pxy = mad(in.fy, r->local.y / r->local.z, in.cy);
+  const float inv_z = 1.f / r->local.z;   // one reciprocal shared by both coordinates (and by the Jacobians), as in the oracle
+  r->pxx = mad(in.fx, r->local.x * inv_z, in.cx);
+  r->pxy = mad(in.fy, r->local.y * inv_z, in.cy);
   if (!(r->pxx >= 0.f) || !(r->pxy >= 0.f) || !(r->pxx < (float)in.width) || !(r->pxy < (float)in.height)) return false;
   r->px = (int)r->pxx;
   r->py = (int)r->pxy;
@@ -375,11 +377,13 @@ __device__ __forceinline__ TangentPoints surfel_tangent_points(Vec3 gp, Vec3 gn,
 __device__ __forceinline__ void project_tangents(const Intrinsics& in, const float* F, const TangentPoints& tp,
                                                  float* t1x, float* t1y, float* t2x, float* t2y) {
   const Vec3 l1 = transform34(F, tp.q1);
-  *t1x = mad(in.cfx, l1.x / l1.z, in.ccx);
-  *t1y = mad(in.cfy, l1.y / l1.z, in.ccy);
+  const float inv_z1 = 1.f / l1.z;
+  *t1x = mad(in.cfx, l1.x * inv_z1, in.ccx);
+  *t1y = mad(in.cfy, l1.y * inv_z1, in.ccy);
   const Vec3 l2 = transform34(F, tp.q2);
-  *t2x = mad(in.cfx, l2.x / l2.z, in.ccx);
-  *t2y = mad(in.cfy, l2.y / l2.z, in.ccy);
+  const float inv_z2 = 1.f / l2.z;
+  *t2x = mad(in.cfx, l2.x * inv_z2, in.ccx);
+  *t2y = mad(in.cfy, l2.y * inv_z2, in.ccy);
 }
 __device__ __forceinline__ void tangent_projections(const Intrinsics& in, const float* F, Vec3 gp, Vec3 gn, float radius_sq,
                                                     float* t1x, float* t1y, float* t2x, float* t2y) {
@@ -454,7 +458,7 @@ __device__ __forceinline__ void jac_descriptor_pose(Vec3 ls, float gx, float gy,
 __device__ __forceinline__ float jac_descriptor_surfel(Vec3 rn, Vec3 lp, float gx, float gy, float cfx, float cfy) {
   const float term1 = -cfx * mad(rn.x, lp.z, -(rn.z * lp.x));
   const float term2 = -cfy * mad(rn.y, lp.z, -(rn.z * lp.y));
-  const float term3 = 1.f / (lp.z * lp.z);
+  const float inv_z = 1.f / lp.z, term3 = inv_z * inv_z;
   return -mad(gy, term2, gx * term1) * term3;
 }
 // B/kernel_opt_intrinsics.cu:107-140: rows fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor.

@@ -339,7 +339,7 @@ count_pairs_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, 
         Assoc r;
         const bool hit = in_range && project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr);
         const Vec3 l = transform34(kfs[k].pose.F, gp);
-        const float px = mad(in.fx, l.x / l.z, in.cx), py = mad(in.fy, l.y / l.z, in.cy);
+        const float px = mad(in.fx, l.x * (1.f / l.z), in.cx), py = mad(in.fy, l.y * (1.f / l.z), in.cy);
         const bool inside = in_range && l.z > 0 && px >= 0 && py >= 0 && px < in.width && py < in.height;
         const unsigned long long m = __ballot(hit);
         cand += 1; wave_hits += (m != 0); lane_hits += __popcll(m); in_image += __popcll(__ballot(inside));

@@ -296,13 +296,15 @@ void orc_tangent_projections(v3 gp, v3 gn, float radius_sq, const float* F, cons
   v3 t1 = v3_cross(gn, (fabsf(gn.x) > 0.9f) ? v3_make(0, 1, 0) : v3_make(1, 0, 0));
   t1 = v3_scale(kTangentScaling * sqrtf(radius_sq / fmaxf(1e-12f, v3_sqlen(t1))), t1);
   v3 l1 = m34_mul(F, v3_add(gp, t1));
-  t1_pxy[0] = mad(color_cam->fx, l1.x / l1.z, color_cam->cx);
-  t1_pxy[1] = mad(color_cam->fy, l1.y / l1.z, color_cam->cy);
+  const float inv_z1 = 1.f / l1.z;
+  t1_pxy[0] = mad(color_cam->fx, l1.x * inv_z1, color_cam->cx);
+  t1_pxy[1] = mad(color_cam->fy, l1.y * inv_z1, color_cam->cy);
   v3 t2 = v3_cross(gn, t1);
   t2 = v3_scale(kTangentScaling * sqrtf(radius_sq / fmaxf(1e-12f, v3_sqlen(t2))), t2);
   v3 l2 = m34_mul(F, v3_add(gp, t2));
-  t2_pxy[0] = mad(color_cam->fx, l2.x / l2.z, color_cam->cx);
-  t2_pxy[1] = mad(color_cam->fy, l2.y / l2.z, color_cam->cy);
+  const float inv_z2 = 1.f / l2.z;
+  t2_pxy[0] = mad(color_cam->fx, l2.x * inv_z2, color_cam->cx);
+  t2_pxy[1] = mad(color_cam->fy, l2.y * inv_z2, color_cam->cy);
 }
 
 /* B/cost_function.cuh:140-156 */
@@ -363,8 +365,10 @@ int orc_project_associate(const proj_params* p, uint32_t i, proj_result* r, int*
   r->local_position.x = mad(F[2], g.z, mad(F[1], g.y, mad(F[0], g.x, F[3])));
   r->local_position.y = mad(F[6], g.z, mad(F[5], g.y, mad(F[4], g.x, F[7])));
 
-  r->pxx = mad(p->fx, r->local_position.x / r->local_position.z, p->cx);
-  r->pxy = mad(p->fy, r->local_position.y / r->local_position.z, p->cy);
+  /* one reciprocal shared by both coordinates (x * (1/z) instead of x / z; kernels: same) */
+  const float inv_z = 1.f / r->local_position.z;
+  r->pxx = mad(p->fx, r->local_position.x * inv_z, p->cx);
+  r->pxy = mad(p->fy, r->local_position.y * inv_z, p->cy);
   if (!(r->pxx >= 0.f) || !(r->pxy >= 0.f) || !(r->pxx < (float)p->width) || !(r->pxy < (float)p->height)) return 0;
   r->px = (int)r->pxx;
   r->py = (int)r->pxy;

@@ -133,11 +133,11 @@ int orc_project_associate(const proj_params* p, uint32_t surfel_index, proj_resu
 
 /* Robust weights, B/robust_weighting.cuh:39-86; B/cost_function.cuh:44-52,95-98,105-109,177-185 */
 static inline float tukey_weight(float r, float k) {
-  if (fabsf(r) < k) { const float q = r / k; const float t = 1.f - q * q; return t * t; }
+  if (fabsf(r) < k) { const float q = r * (1.f / k); const float t = 1.f - q * q; return t * t; }
   return 0.f;
 }
 static inline float tukey_residual(float r, float k) {
-  if (fabsf(r) < k) { const float q = r / k; const float t = 1.f - q * q; return (1 / 6.f) * k * k * (1 - t * t * t); }
+  if (fabsf(r) < k) { const float q = r * (1.f / k); const float t = 1.f - q * q; return (1 / 6.f) * k * k * (1 - t * t * t); }
   return (1 / 6.f) * k * k;
 }
 static inline float huber_weight(float r, float k) { const float a = fabsf(r); return (a < k) ? 1.f : (k / a); }
@@ -151,7 +151,7 @@ static inline float weighted_descriptor_residual(float r) { return 1.f * 1e-2f *
 
 /* B/cost_function.cuh:81-88 */
 static inline float depth_stddev(float nx, float ny, float depth, v3 nl, float baseline_fx) {
-  return (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth)) / baseline_fx;
+  return (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth)) * (1.f / baseline_fx);
 }
 static inline float depth_inv_stddev(float nx, float ny, float depth, v3 nl, float baseline_fx) {
   return baseline_fx / (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth));
@@ -196,7 +196,7 @@ static inline void jac_descriptor_pose(v3 ls, float gx, float gy, float J[6]) {
 static inline float jac_descriptor_surfel(v3 rn, v3 lp, float gx, float gy, float cfx, float cfy) {
   const float term1 = -cfx * mad(rn.x, lp.z, -(rn.z * lp.x));
   const float term2 = -cfy * mad(rn.y, lp.z, -(rn.z * lp.y));
-  const float term3 = 1.f / (lp.z * lp.z);
+  const float inv_z = 1.f / lp.z, term3 = inv_z * inv_z;
   return -mad(gy, term2, gx * term1) * term3;
 }
 /* B/kernel_opt_intrinsics.cu:107-140: d(depth residual)/d(fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor).  n_dot_Frow0/1 = global
