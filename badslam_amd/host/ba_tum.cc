@@ -9,11 +9,18 @@
 // <out>.deformation.txt and <out>.ply.
 //
 //   ba_tum <dataset_dir> <trajectory_file> <out_prefix> [--interval N] [--iterations N] [--cell N] [--max_depth M]
-//          [--raw_to_float_depth S] [--pcg] [--intrinsics]
+//          [--raw_to_float_depth S] [--pcg] [--intrinsics] [--incremental | --parallel_ba] [--save_state F] [--load_state F]
+//
+// --incremental / --parallel_ba feed the keyframes one at a time through vis::BAScheduler (ba_scheduler.h), the way
+// BadSlam::ProcessFrame does: each keyframe arrives with its pose relative to the previous keyframe (taken from the
+// trajectory file), plans max_num_ba_iterations_per_keyframe iterations, and these run either right away (sequential) or
+// on the BA thread while the next keyframe is being prepared.  --save_state writes the backend state after BA;
+// --load_state starts from such a file instead of creating keyframes and surfels (checkpoint / resume, rgbd_io.h).
 #include <cstdio>
 #include <cstring>
 #include <string>
 
+#include "ba_scheduler.h"
 #include "rgbd_io.h"
 
 using namespace vis;
@@ -50,7 +57,8 @@ int main(int argc, char** argv) {
   const std::string dataset = argv[1], trajectory = argv[2], out = argv[3];
   int interval = 1, iterations = 10, cell = 4;
   float raw_to_float_depth = 1.0f / 5000;   // TUM RGB-D depth PNGs: 5000 units per metre
-  bool use_pcg = false, intrinsics = false;
+  bool use_pcg = false, intrinsics = false, incremental = false, parallel_ba = false;
+  std::string save_state, load_state;
   PreprocessConfig config;
   for (int i = 4; i < argc; ++i) {
     const std::string a = argv[i];
@@ -61,6 +69,10 @@ int main(int argc, char** argv) {
     else if (a == "--raw_to_float_depth" && i + 1 < argc) raw_to_float_depth = (float)atof(argv[++i]);
     else if (a == "--pcg") use_pcg = true;
     else if (a == "--intrinsics") intrinsics = true;
+    else if (a == "--incremental") incremental = true;
+    else if (a == "--parallel_ba") incremental = parallel_ba = true;
+    else if (a == "--save_state" && i + 1 < argc) save_state = argv[++i];
+    else if (a == "--load_state" && i + 1 < argc) load_state = argv[++i];
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
   if (bahip_device_count() <= 0) { fprintf(stderr, "no HIP device (there is no CPU fallback)\n"); return 99; }
@@ -78,31 +90,61 @@ int main(int argc, char** argv) {
                 /*min_observation_count_while_bootstrapping_1*/ 1, /*min_observation_count_while_bootstrapping_2*/ 2, /*min_observation_count*/ 2,
                 *video.color_camera(), *video.depth_camera(), /*pyramid_level_for_color*/ 0, /*use_depth_residuals*/ true,
                 /*use_descriptor_residuals*/ true, nullptr, SE3f());
-    vector<int> keyframe_frames;
-    for (usize f = 0; f < video.frame_count(); f += interval) {
-      shared_ptr<Keyframe> kf = CreateKeyframeFromFrame(stream, config, ba, video, (int)f);
-      ba.AddKeyframe(kf);
-      keyframe_frames.push_back((int)f);
-    }
-    printf("%zu keyframes\n", keyframe_frames.size());
     vector<SE3f> original_keyframe_T_global;
-    RememberKeyframePoses(&ba, &original_keyframe_T_global);   // B/bad_slam.cc:1230 (before the BA that moves them)
-    for (int i = 0; i < iterations; ++i) {
-      int done = 0;
-      bool converged = false;
-      ba.BundleAdjustment(stream, /*optimize_depth_intrinsics*/ intrinsics, /*optimize_color_intrinsics*/ intrinsics, /*do_surfel_updates*/ true,
-                          /*optimize_poses*/ true, /*optimize_geometry*/ true, /*min_iterations*/ 1, /*max_iterations*/ 10, use_pcg, 0,
-                          (int)ba.keyframes().size() - 1, /*increase_ba_iteration_count*/ true, &done, &converged);
-      printf("BA call %d: %d iteration(s)%s, %u surfels\n", i + 1, done, converged ? ", converged" : "", ba.surfel_count());
+    if (incremental) {
+      BASchedulerConfig scheduler_config;
+      scheduler_config.parallel_ba = parallel_ba;
+      scheduler_config.use_pcg = use_pcg;
+      scheduler_config.optimize_intrinsics = intrinsics;
+      scheduler_config.max_num_ba_iterations_per_keyframe = iterations;
+      BAScheduler scheduler(scheduler_config, &ba, &video, stream);
+      SE3f previous_keyframe_pose;
+      for (usize f = 0; f < video.frame_count(); f += interval) {
+        // what an odometry front-end would hand over: the pose relative to the previous keyframe
+        const SE3f initial_pose = video.depth_frame(f)->global_T_frame();
+        const SE3f last_kf_tr_this_kf = (f == 0) ? SE3f() : previous_keyframe_pose.inverse() * initial_pose;
+        previous_keyframe_pose = initial_pose;
+        shared_ptr<Keyframe> kf = CreateKeyframeFromFrame(stream, config, ba, video, (int)f);
+        const u32 newest_frame = (u32)std::min<usize>(f + interval - 1, video.frame_count() - 1);
+        scheduler.SetLastFrameIndex((int)newest_frame);
+        scheduler.AddKeyframe(kf, last_kf_tr_this_kf);
+        scheduler.RunPlannedIterations(newest_frame);
+      }
+      scheduler.WaitForQueuedWork();
+      scheduler.StopBAThreadAndWaitForIt();
+      printf("%zu keyframes through the scheduler (%s), %d parallel iteration(s), %u surfels\n", ba.keyframes().size(),
+             parallel_ba ? "BA thread" : "sequential", scheduler.parallel_iterations_done(), ba.surfel_count());
+    } else {
+      if (!load_state.empty()) {
+        if (!LoadState(stream, config, &video, &ba, load_state)) { fprintf(stderr, "cannot load state %s\n", load_state.c_str()); return 1; }
+        printf("loaded %s: %zu keyframes, %u surfels, BA iteration count %d\n", load_state.c_str(), ba.keyframes().size(), ba.surfel_count(),
+               ba.ba_iteration_count());
+      } else {
+        for (usize f = 0; f < video.frame_count(); f += interval) ba.AddKeyframe(CreateKeyframeFromFrame(stream, config, ba, video, (int)f));
+      }
+      printf("%zu keyframes\n", ba.keyframes().size());
+      RememberKeyframePoses(&ba, &original_keyframe_T_global);   // B/bad_slam.cc:1230 (before the BA that moves them)
+      for (int i = 0; i < iterations; ++i) {
+        int done = 0;
+        bool converged = false;
+        ba.BundleAdjustment(stream, /*optimize_depth_intrinsics*/ intrinsics, /*optimize_color_intrinsics*/ intrinsics, /*do_surfel_updates*/ true,
+                            /*optimize_poses*/ true, /*optimize_geometry*/ true, /*min_iterations*/ 1, /*max_iterations*/ 10, use_pcg, 0,
+                            (int)ba.keyframes().size() - 1, /*increase_ba_iteration_count*/ true, &done, &converged);
+        printf("BA call %d: %d iteration(s)%s, %u surfels\n", i + 1, done, converged ? ", converged" : "", ba.surfel_count());
+      }
     }
     // keyframe poses back into the video (the reference shares the pose object between keyframe and video frame), then the
-    // frames in between follow their keyframes (B/bad_slam.cc:1259-1269)
-    for (usize k = 0; k < keyframe_frames.size(); ++k) {
-      const int f = keyframe_frames[k];
-      video.depth_frame_mutable(f)->SetGlobalTFrame(ba.keyframes()[k]->global_T_frame());
-      video.color_frame_mutable(f)->SetGlobalTFrame(ba.keyframes()[k]->global_T_frame());
+    // frames in between follow their keyframes (B/bad_slam.cc:1259-1269; the scheduler has done that after every BA)
+    for (const shared_ptr<Keyframe>& kf : ba.keyframes()) {
+      if (!kf) continue;
+      video.depth_frame_mutable(kf->frame_index())->SetGlobalTFrame(kf->global_T_frame());
+      video.color_frame_mutable(kf->frame_index())->SetGlobalTFrame(kf->global_T_frame());
     }
-    ExtrapolateAndInterpolateKeyframePoseChanges(0, (u32)video.frame_count() - 1, &ba, original_keyframe_T_global, &video);
+    if (!incremental) ExtrapolateAndInterpolateKeyframePoseChanges(0, (u32)video.frame_count() - 1, &ba, original_keyframe_T_global, &video);
+    if (!save_state.empty()) {
+      if (!SaveState(stream, video, ba, save_state)) { fprintf(stderr, "cannot write state %s\n", save_state.c_str()); return 1; }
+      printf("wrote %s\n", save_state.c_str());
+    }
     if (!SavePoses(video, /*use_depth_timestamps*/ true, /*start_frame*/ 0, out + ".poses.txt")) return 1;
     if (!SaveCalibration(stream, ba, out)) return 1;
     if (!SavePointCloudAsPLY(stream, ba, out + ".ply")) return 1;

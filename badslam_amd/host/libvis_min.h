@@ -26,6 +26,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef int8_t i8;
 typedef int16_t i16;
+typedef int32_t i32;
 typedef size_t usize;
 using std::shared_ptr;
 using std::vector;

@@ -446,4 +446,251 @@ shared_ptr<Keyframe> CreateKeyframeFromFrame(hipStream_t stream, const Preproces
   return keyframe;
 }
 
+// ---- binary state -------------------------------------------------------------------------------------------------------
+namespace {
+constexpr u8 kStateVersion = 101;              // the reference writes 1 (B/io.cc:66); see rgbd_io.h
+constexpr int kSurfelDataAttributeCount = 8;   // B/kernels.cuh:90: the rows that are state; the accumulators are not
+constexpr int kPinholeCamera4fTypeInt = 1;     // L/camera.h:289
+
+struct StateWriter {
+  FILE* file;
+  bool ok = true;
+  void Bytes(const void* data, size_t size) { if (size && fwrite(data, 1, size, file) != size) ok = false; }
+  void Int32(int value) { const i32 v = value; Bytes(&v, sizeof(v)); }
+  void U32(u32 value) { Bytes(&value, sizeof(value)); }
+  void Float(float value) { Bytes(&value, sizeof(value)); }
+  void Bool(bool value) { const u8 v = value ? 1 : 0; Bytes(&v, 1); }
+  void Pose(const SE3f& value) { Bytes(value.data(), 7 * sizeof(float)); }
+};
+struct StateReader {
+  FILE* file;
+  bool ok = true;
+  void Bytes(void* data, size_t size) { if (size && fread(data, 1, size, file) != size) { ok = false; memset(data, 0, size); } }
+  int Int32() { i32 v; Bytes(&v, sizeof(v)); return v; }
+  u32 U32() { u32 v; Bytes(&v, sizeof(v)); return v; }
+  float Float() { float v; Bytes(&v, sizeof(v)); return v; }
+  bool Bool() { u8 v; Bytes(&v, 1); return v != 0; }
+  SE3f Pose() { float v[7]; Bytes(v, sizeof(v)); SE3f pose; memcpy(pose.data(), v, sizeof(v)); return pose; }
+};
+struct FileCloser {
+  FILE* file;
+  ~FileCloser() { if (file) fclose(file); }
+};
+}  // namespace
+
+bool SaveState(hipStream_t stream, const RGBDVideo<Vec3u8, u16>& rgbd_video, DirectBA& direct_ba, const std::string& path) {
+  FILE* file = fopen(path.c_str(), "wb");
+  if (!file) return false;
+  FileCloser closer{file};
+  StateWriter w{file};
+  w.Bytes("BADSLAM", 7);
+  w.Bytes(&kStateVersion, 1);
+
+  // RGBDVideo (frame poses), B/io.cc:112-117.  The reference shares one pose object between a keyframe and its video
+  // frame; here the keyframe owns its pose, and it is the one that counts.
+  vector<const Keyframe*> keyframe_of_frame(rgbd_video.frame_count(), nullptr);
+  for (const shared_ptr<Keyframe>& keyframe : direct_ba.keyframes())
+    if (keyframe && keyframe->frame_index() < keyframe_of_frame.size()) keyframe_of_frame[keyframe->frame_index()] = keyframe.get();
+  w.U32((u32)rgbd_video.frame_count());
+  for (usize i = 0; i < rgbd_video.frame_count(); ++i)
+    w.Pose(keyframe_of_frame[i] ? keyframe_of_frame[i]->global_T_frame() : rgbd_video.depth_frame(i)->global_T_frame());
+
+  // Direct BA, B/io.cc:120-180
+  const PinholeCamera4f color_camera = direct_ba.color_camera(), depth_camera = direct_ba.depth_camera();
+  w.Int32(kPinholeCamera4fTypeInt); w.Int32(color_camera.width()); w.Int32(color_camera.height()); w.Int32(4);
+  w.Bytes(color_camera.parameters(), 4 * sizeof(float));
+  w.Int32(direct_ba.pyramid_level_for_color());
+  w.Int32(kPinholeCamera4fTypeInt); w.Int32(depth_camera.width()); w.Int32(depth_camera.height()); w.Int32(4);
+  w.Bytes(depth_camera.parameters(), 4 * sizeof(float));
+
+  CUDABufferPtr<float> cfactor_buffer = direct_ba.cfactor_buffer();
+  Image<float> cfactor_cpu(cfactor_buffer->width(), cfactor_buffer->height());
+  cfactor_buffer->DownloadAsync(stream, &cfactor_cpu);
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+  w.Int32(cfactor_cpu.width()); w.Int32(cfactor_cpu.height()); w.Int32(cfactor_cpu.stride());
+  w.Bytes(cfactor_cpu.data(), (size_t)cfactor_cpu.height() * cfactor_cpu.stride());
+
+  const DepthParameters depth_params = direct_ba.depth_params();
+  w.Float(depth_params.a); w.Float(depth_params.raw_to_float_depth); w.Float(depth_params.baseline_fx);
+  w.Int32(depth_params.sparse_surfel_cell_size);
+
+  w.Int32((int)direct_ba.keyframes().size());
+  for (const shared_ptr<Keyframe>& keyframe : direct_ba.keyframes()) {
+    w.Int32(keyframe ? keyframe->id() : -1);
+    if (!keyframe) continue;
+    w.Int32((int)keyframe->frame_index());
+    w.Int32(static_cast<int>(keyframe->activation()));
+    w.Int32(keyframe->last_active_in_ba_iteration());
+    w.Int32(keyframe->last_covis_in_ba_iteration());
+  }
+
+  const u32 surfels_size = direct_ba.surfels_size();
+  w.Int32((int)direct_ba.surfel_count());
+  w.Int32((int)surfels_size);
+  CUDABufferConstPtr<float> surfels = direct_ba.surfels();
+  vector<float> surfel_data(surfels_size);
+  for (int row = 0; row < kSurfelDataAttributeCount; ++row) {
+    if (surfels_size) {
+      surfels->DownloadPartAsync((size_t)row * surfels->ToCUDA().pitch(), surfels_size * sizeof(float), stream, surfel_data.data());
+      BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    }
+    w.Bytes(surfel_data.data(), surfels_size * sizeof(float));
+  }
+
+  w.Int32(direct_ba.ba_iteration_count());
+  w.Int32(direct_ba.last_ba_iteration_count());
+  w.Bool(direct_ba.use_depth_residuals());
+  w.Bool(direct_ba.use_descriptor_residuals());
+  w.Int32(direct_ba.min_observation_count_while_bootstrapping_1());
+  w.Int32(direct_ba.min_observation_count_while_bootstrapping_2());
+  w.Int32(direct_ba.min_observation_count());
+  w.Float(direct_ba.surfel_merge_dist_factor());
+  return w.ok;
+}
+
+bool LoadState(hipStream_t stream, const PreprocessConfig& config, RGBDVideo<Vec3u8, u16>* rgbd_video, DirectBA* direct_ba,
+               const std::string& path, std::function<bool(int, int)> progress_function) {
+  FILE* file = fopen(path.c_str(), "rb");
+  if (!file) return false;
+  FileCloser closer{file};
+  StateReader r{file};
+  char identifier[7];
+  u8 version = 0;
+  r.Bytes(identifier, 7);
+  r.Bytes(&version, 1);
+  if (!r.ok || memcmp(identifier, "BADSLAM", 7) != 0) { LOG(ERROR) << "File identifier does not match."; return false; }
+  if (version != kStateVersion) { LOG(ERROR) << "Unknown file format version."; return false; }
+
+  // Everything that can be checked is checked before the objects are touched (the reference's TODO, B/io.cc:189-190):
+  // the file is parsed into host memory first.
+  const u32 frame_count = r.U32();
+  if (!r.ok || frame_count != rgbd_video->frame_count()) {
+    LOG(ERROR) << "Loaded frame count does not match the existing frame count in the dataset.";
+    return false;
+  }
+  vector<SE3f> frame_poses(frame_count);
+  for (u32 i = 0; i < frame_count; ++i) frame_poses[i] = r.Pose();
+
+  struct CameraRecord { int type_int, width, height, parameter_count; float parameters[4]; } cameras[2];
+  int pyramid_level_for_color = 0;
+  for (int which = 0; which < 2; ++which) {   // colour camera, pyramid level, depth camera
+    CameraRecord& c = cameras[which];
+    c.type_int = r.Int32(); c.width = r.Int32(); c.height = r.Int32(); c.parameter_count = r.Int32();
+    if (!r.ok || c.type_int != kPinholeCamera4fTypeInt || c.parameter_count != 4) {
+      LOG(ERROR) << "Unexpected " << (which == 0 ? "color" : "depth") << " camera type or parameter count.";
+      return false;
+    }
+    r.Bytes(c.parameters, sizeof(c.parameters));
+    if (which == 0) pyramid_level_for_color = r.Int32();
+  }
+
+  const int cfactor_width = r.Int32(), cfactor_height = r.Int32(), cfactor_stride = r.Int32();
+  CUDABufferPtr<float> cfactor_buffer = direct_ba->cfactor_buffer();
+  if (!r.ok || cfactor_width != cfactor_buffer->width() || cfactor_height != cfactor_buffer->height()) {
+    LOG(ERROR) << "cfactor_buffer size does not match.";
+    return false;
+  }
+  if (cfactor_stride < cfactor_width * (int)sizeof(float) || cfactor_stride > 100000 * (int)sizeof(float)) {
+    LOG(ERROR) << "Implausible cfactor_buffer stride, refusing to load.";
+    return false;
+  }
+  vector<u8> cfactor_bytes((size_t)cfactor_height * cfactor_stride);
+  r.Bytes(cfactor_bytes.data(), cfactor_bytes.size());
+  Image<float> cfactor_cpu(cfactor_width, cfactor_height);
+  for (int y = 0; y < cfactor_height; ++y) memcpy(cfactor_cpu.row(y), cfactor_bytes.data() + (size_t)y * cfactor_stride, cfactor_width * sizeof(float));
+
+  DepthParameters depth_params = direct_ba->depth_params();
+  depth_params.a = r.Float();
+  depth_params.raw_to_float_depth = r.Float();
+  depth_params.baseline_fx = r.Float();
+  depth_params.sparse_surfel_cell_size = r.Int32();
+
+  struct KeyframeRecord { int id, frame_index, activation, last_active_in_ba_iteration, last_covis_in_ba_iteration; };
+  const int keyframe_count = r.Int32();
+  if (!r.ok || keyframe_count < 0 || (usize)keyframe_count > rgbd_video->frame_count()) {
+    LOG(ERROR) << "More keyframes than frames in the video.";
+    return false;
+  }
+  vector<KeyframeRecord> keyframe_records(keyframe_count);
+  for (int i = 0; i < keyframe_count; ++i) {
+    KeyframeRecord& k = keyframe_records[i];
+    k.id = r.Int32();
+    if (k.id < 0) continue;
+    if (k.id != i) { LOG(ERROR) << "Unexpected keyframe id."; return false; }
+    k.frame_index = r.Int32(); k.activation = r.Int32(); k.last_active_in_ba_iteration = r.Int32(); k.last_covis_in_ba_iteration = r.Int32();
+    if (!r.ok || k.frame_index < 0 || (usize)k.frame_index >= rgbd_video->frame_count() || k.activation < 0 || k.activation > 2) {
+      LOG(ERROR) << "Invalid keyframe record.";
+      return false;
+    }
+  }
+
+  const int surfel_count = r.Int32(), surfels_size = r.Int32();
+  CUDABufferPtr<float> surfels = direct_ba->surfels();
+  if (!r.ok || surfel_count < 0 || surfels_size < surfel_count || surfels_size > surfels->width()) {
+    LOG(ERROR) << "Invalid surfel count (or more surfels than this DirectBA was allocated for).";
+    return false;
+  }
+  vector<vector<float>> surfel_rows(kSurfelDataAttributeCount, vector<float>(surfels_size));
+  for (int row = 0; row < kSurfelDataAttributeCount; ++row) r.Bytes(surfel_rows[row].data(), (size_t)surfels_size * sizeof(float));
+
+  const int ba_iteration_count = r.Int32(), last_ba_iteration_count = r.Int32();
+  const bool use_depth_residuals = r.Bool(), use_descriptor_residuals = r.Bool();
+  const int min_obs_bootstrapping_1 = r.Int32(), min_obs_bootstrapping_2 = r.Int32(), min_obs = r.Int32();
+  const float surfel_merge_dist_factor = r.Float();
+  if (!r.ok) { LOG(ERROR) << "Unexpected end of file."; return false; }
+
+  // ---- apply ----
+  for (u32 i = 0; i < frame_count; ++i) {
+    rgbd_video->color_frame_mutable(i)->SetGlobalTFrame(frame_poses[i]);
+    rgbd_video->depth_frame_mutable(i)->SetGlobalTFrame(frame_poses[i]);
+  }
+  direct_ba->keyframes_mutable()->clear();
+  direct_ba->SetColorCamera(PinholeCamera4f(cameras[0].width, cameras[0].height, cameras[0].parameters));
+  direct_ba->SetPyramidLevelForColor(pyramid_level_for_color);
+  direct_ba->SetDepthCamera(PinholeCamera4f(cameras[1].width, cameras[1].height, cameras[1].parameters));
+  cfactor_buffer->UploadAsync(stream, cfactor_cpu);
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+  direct_ba->SetDepthParams(depth_params);
+  direct_ba->SetCFactorBuffer(cfactor_buffer);   // SetDepthParams overwrote the device view kept inside depth_params
+
+  // Keyframes are rebuilt from their video frames with the loaded calibration and poses (B/io.cc:405-445).
+  for (int i = 0; i < keyframe_count; ++i) {
+    if (progress_function && !progress_function(i, keyframe_count)) {
+      direct_ba->keyframes_mutable()->clear();
+      return false;
+    }
+    const KeyframeRecord& k = keyframe_records[i];
+    if (k.id < 0) { direct_ba->keyframes_mutable()->push_back(nullptr); continue; }
+    shared_ptr<Keyframe> keyframe = CreateKeyframeFromFrame(stream, config, *direct_ba, *rgbd_video, k.frame_index);
+    direct_ba->AddKeyframe(keyframe);
+    CHECK_EQ(keyframe->id(), k.id);
+  }
+  // The stored activation states are applied once all keyframes are in: AddKeyframe wakes up inactive keyframes that are
+  // co-visible with the one being added, so applying them keyframe by keyframe (B/io.cc:437-440) would not reproduce the
+  // saved state.
+  for (int i = 0; i < keyframe_count; ++i) {
+    const KeyframeRecord& k = keyframe_records[i];
+    if (k.id < 0) continue;
+    Keyframe* keyframe = (*direct_ba->keyframes_mutable())[i].get();
+    keyframe->SetActivation(static_cast<Keyframe::Activation>(k.activation));
+    keyframe->SetLastActiveInBAIteration(k.last_active_in_ba_iteration);
+    keyframe->SetLastCovisInBAIteration(k.last_covis_in_ba_iteration);
+  }
+
+  direct_ba->SetSurfelCount(surfel_count, surfels_size);
+  for (int row = 0; row < kSurfelDataAttributeCount && surfels_size; ++row)
+    surfels->UploadPartAsync((size_t)row * surfels->ToCUDA().pitch(), (size_t)surfels_size * sizeof(float), stream, surfel_rows[row].data());
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+
+  direct_ba->SetBAIterationCount(ba_iteration_count);
+  direct_ba->SetLastBAIterationCount(last_ba_iteration_count);
+  direct_ba->SetUseDepthResiduals(use_depth_residuals);
+  direct_ba->SetUseDescriptorResiduals(use_descriptor_residuals);
+  direct_ba->SetMinObservationCountWhileBootstrapping1(min_obs_bootstrapping_1);
+  direct_ba->SetMinObservationCountWhileBootstrapping2(min_obs_bootstrapping_2);
+  direct_ba->SetMinObservationCount(min_obs);
+  direct_ba->SetSurfelMergeDistFactor(surfel_merge_dist_factor);
+  return true;
+}
+
 }  // namespace vis

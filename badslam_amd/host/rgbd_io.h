@@ -122,4 +122,17 @@ struct PreprocessConfig {            // defaults of B/bad_slam_config.h:96-122
 shared_ptr<Keyframe> CreateKeyframeFromFrame(hipStream_t stream, const PreprocessConfig& config, DirectBA& direct_ba,
                                              RGBDVideo<Vec3u8, u16>& rgbd_video, int frame_index);
 
+// ---- binary state (B/io.cc:38-183 SaveState, :185-535 LoadState): checkpoint / resume of the BA backend -------------------
+// The sections of the reference's state file that belong to the backend, with the reference's field order and types:
+// "RGBDVideo (frame poses)" (B/io.cc:112-117) and "Direct BA" (:120-180: cameras, cfactor image, depth parameters,
+// keyframe table, the kSurfelDataAttributeCount = 8 surfel rows, iteration counters, residual switches, observation
+// thresholds, merge factor).  The front-end sections (motion model, queued keyframes, BadSlamConfig) have no counterpart
+// here and are not written, so the container announces itself as "BADSLAM" with version 101: a reference build refuses it
+// ("Unknown file format version") instead of misreading it.  Keyframe images are not stored (as in the reference): on
+// loading, every keyframe is rebuilt from its video frame by CreateKeyframeFromFrame, with the loaded pose.
+bool SaveState(hipStream_t stream, const RGBDVideo<Vec3u8, u16>& rgbd_video, DirectBA& direct_ba, const std::string& path);
+// progress_function(keyframes_done, keyframe_count) may return false to abort (B/io.cc:396-403).
+bool LoadState(hipStream_t stream, const PreprocessConfig& config, RGBDVideo<Vec3u8, u16>* rgbd_video, DirectBA* direct_ba,
+               const std::string& path, std::function<bool(int, int)> progress_function = nullptr);
+
 }  // namespace vis

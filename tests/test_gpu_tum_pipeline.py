@@ -75,6 +75,85 @@ def test_ba_on_a_tum_format_sequence(tmp_path, use_pcg):
     assert np.isfinite(first[:3]).all() and abs(np.linalg.norm(first[6:9]) - 1) < 1e-3
 
 
+def _run(cmd, timeout=600):
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    print(proc.stdout[-3000:])
+    print(proc.stderr[-3000:])
+    assert proc.returncode == 0
+    return proc.stdout
+
+
+def _translation_errors(scene, est):
+    gt_rel = _relative(scene.poses_gt)
+    return np.array([np.linalg.norm(common.pose_error(g, e)[:3]) for g, e in zip(gt_rel, est)])
+
+
+@pytest.mark.parametrize("mode", ["--incremental", "--parallel_ba"])
+def test_keyframes_fed_one_at_a_time_through_the_scheduler(tmp_path, mode):
+    """BAScheduler (B/bad_slam.cc AddKeyframe / RunBundleAdjustment / StartParallelIterations /
+    BAThreadMain).  Every keyframe arrives with its pose relative to the previous keyframe; with --parallel_ba the
+    iterations run on the BA thread while the main thread prepares the next keyframe (mutex protocol of the reference),
+    and a queued keyframe's absolute pose is formed from the previous keyframe's pose *after* BA."""
+    scene = common.small_scene(num_keyframes=6, width=320, height=240, seed=4)
+    rng = np.random.Generator(np.random.PCG64(6))
+    initial = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    stamps = tum_writer.write_dataset(str(tmp_path), scene, {"initial.txt": initial})
+    out = str(tmp_path / "result")
+    log = _run([BIN, str(tmp_path), "initial.txt", out, "--cell", "2", "--iterations", "10", "--max_depth", "8", mode])
+    assert "6 keyframes through the scheduler" in log
+    if mode == "--parallel_ba":
+        done = int(log.split("keyframes through the scheduler (BA thread), ")[1].split(" parallel")[0])
+        assert 5 <= done <= 50                       # at most max_num_ba_iterations_per_keyframe queued per keyframe
+    result = _read_trajectory(out + ".poses.txt")
+    assert [t for t, _ in result] == stamps
+    err_after = _translation_errors(scene, [p for _, p in result])
+    err_before = _translation_errors(scene, _relative(initial))
+    print("before", err_before, "after", err_after)
+    assert err_before[1:].mean() > 3e-3
+    assert err_after[1:].mean() < 0.3 * err_before[1:].mean()
+    assert err_after.max() < 3e-3
+
+
+def test_state_file_round_trip_and_resume(tmp_path):
+    """SURVEY 8f row 3 (binary state, B/io.cc:38-535): run A does 2 BA calls and saves; run B loads the state (keyframes are
+    rebuilt from the video frames, surfels / poses / counters come from the file), saves again and continues.  The second
+    state file must equal the first one bit for bit, and the resumed run must end where an uninterrupted run ends."""
+    scene = common.small_scene(num_keyframes=5, width=320, height=240, seed=7)
+    rng = np.random.Generator(np.random.PCG64(8))
+    initial = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    tum_writer.write_dataset(str(tmp_path), scene, {"initial.txt": initial})
+    base = [BIN, str(tmp_path), "initial.txt"]
+    opts = ["--cell", "2", "--max_depth", "8"]
+    state_a, state_b = str(tmp_path / "a.state"), str(tmp_path / "b.state")
+    _run(base + [str(tmp_path / "a")] + opts + ["--iterations", "2", "--save_state", state_a])
+    log = _run(base + [str(tmp_path / "b")] + opts + ["--iterations", "0", "--load_state", state_a, "--save_state", state_b])
+    assert "loaded" in log and "5 keyframes" in log
+    blob_a, blob_b = open(state_a, "rb").read(), open(state_b, "rb").read()
+    assert blob_a[:7] == b"BADSLAM" and blob_a[7] == 101
+    assert len(blob_a) > 8 * 4 * 20000                      # eight rows of at least 20 k surfels
+    assert blob_a == blob_b
+    # the poses written after loading are the poses written before saving
+    pa, pb = _read_trajectory(str(tmp_path / "a") + ".poses.txt"), _read_trajectory(str(tmp_path / "b") + ".poses.txt")
+    assert np.allclose(np.array([p for _, p in pa]), np.array([p for _, p in pb]), atol=1e-6)
+
+    # resume: 2 + 3 calls end at the same accuracy as 5 calls in one go (not bit-equal: the pose sums use float atomics)
+    _run(base + [str(tmp_path / "c")] + opts + ["--iterations", "3", "--load_state", state_a])
+    _run(base + [str(tmp_path / "d")] + opts + ["--iterations", "5"])
+    pc, pd = _read_trajectory(str(tmp_path / "c") + ".poses.txt"), _read_trajectory(str(tmp_path / "d") + ".poses.txt")
+    err_c, err_d = _translation_errors(scene, [p for _, p in pc]), _translation_errors(scene, [p for _, p in pd])
+    print("resumed", err_c, "uninterrupted", err_d)
+    assert err_c.max() < 2.5e-3 and err_d.max() < 2.5e-3
+    assert np.abs(np.array([p for _, p in pc]) - np.array([p for _, p in pd])).max() < 1e-3
+
+    # a truncated file and a file of the reference's own version are refused without touching anything
+    open(str(tmp_path / "short.state"), "wb").write(blob_a[:len(blob_a) // 2])
+    open(str(tmp_path / "v1.state"), "wb").write(blob_a[:7] + bytes([1]) + blob_a[8:])
+    for bad in ("short.state", "v1.state"):
+        proc = subprocess.run(base + [str(tmp_path / "e")] + opts + ["--iterations", "0", "--load_state", str(tmp_path / bad)],
+                              capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 1 and "cannot load state" in proc.stderr
+
+
 def test_non_keyframes_follow_their_keyframes(tmp_path):
     """Every second frame is a keyframe; the initial trajectory has a smooth drift.  BA corrects the keyframes and the
     trajectory deformation (B/trajectory_deformation.cc:45-130) carries the correction to the frames in between."""
