@@ -52,6 +52,8 @@ def parse_args():
     p.add_argument("--plane-slope", type=float, default=0.05)
     p.add_argument("--cell", type=int, default=2, help="sparse_surfel_cell_size")
     p.add_argument("--pcg", action="store_true", help="time the PCG scheme instead of the alternating one (single GPU)")
+    p.add_argument("--intrinsics", action="store_true",
+                   help="also optimise the depth and colour intrinsics in every iteration (BASELINE configs[4]: joint BA)")
     p.add_argument("--force-allreduce", action="store_true",
                    help="install the RCCL all-reduce hook even with one rank (measures the cost of the exchange path)")
     p.add_argument("--emulate-world", type=int, default=0,
@@ -211,7 +213,8 @@ def main():
     def run(iterations):
         # BA iteration counters equal -> BundleAdjustment skips PerformBASchemeEndTasks (fixed surfel set)
         ba.set_ba_iteration_counts(1, 1)
-        done, _ = ba.BundleAdjustment(optimize_depth_intrinsics=False, optimize_color_intrinsics=False, do_surfel_updates=False,
+        done, _ = ba.BundleAdjustment(optimize_depth_intrinsics=args.intrinsics, optimize_color_intrinsics=args.intrinsics,
+                                      do_surfel_updates=False,
                                       optimize_poses=True, optimize_geometry=True, min_iterations=iterations,
                                       max_iterations=iterations, use_pcg=args.pcg, active_keyframe_window_start=0,
                                       active_keyframe_window_end=K - 1, increase_ba_iteration_count=False)
@@ -273,7 +276,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic {W}x{H}, {K} keyframes, {N_total} surfels, geometry+photometric "
-                                   f"{'PCG' if args.pcg else 'alternating'} BA (BASELINE configs[2])",
+                                   f"{'PCG' if args.pcg else 'alternating'} BA"
+                                   f"{' with intrinsics' if args.intrinsics else ''}"
+                                   f"{' (BASELINE configs[2])' if (W, H, K, args.surfels, args.intrinsics) == (640, 480, 200, 3000000, False) else ''}",
                        "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
                        "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
                        "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, 2 cm grid)",
