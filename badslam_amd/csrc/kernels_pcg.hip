@@ -53,7 +53,7 @@ struct PairTerms {
 
 template <bool kDepthIntr, bool kColorIntr>
 __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrinsics& in, const KfEntry& kf, const Assoc& r,
-                                                Vec3 gp, Vec3 gn, float radius_sq, float d1, float d2, PairTerms* t) {
+                                                Vec3 gn, const TangentPoints& tp, float d1, float d2, PairTerms* t) {
   const float* F = kf.pose.F;
   const Vec3 rn = r.nl;
   const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
@@ -94,7 +94,7 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
     t->color_ok = depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy);
     if (t->color_ok) {
       DescEval e;
-      eval_descriptor<true>(in, kf.lumafp, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
+      eval_descriptor<true>(in, kf.lumafp, F, tp, cx, cy, d1, d2, &e);
       t->raw1 = e.r1; t->raw2 = e.r2;
       const float gx1 = e.gx1 * in.cfx, gx2 = e.gx2 * in.cfx;
       const float gy1 = e.gy1 * in.cfy, gy2 = e.gy2 * in.cfy;
@@ -132,13 +132,14 @@ template <bool kDepthIntr, bool kColorIntr>
 __global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
 pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
                 float* __restrict__ r_, float* __restrict__ M_) {
-  const uint32_t i = blockIdx.x * kPcgSweepBlock + threadIdx.x;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
   const Vec3 gn = surfel_normal(s, ii);
   const float radius_sq = s.row(kSurfelRadiusSquared)[ii];
   const float d1 = s.row(kSurfelDescriptor1)[ii], d2 = s.row(kSurfelDescriptor2)[ii];
+  const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);   // per surfel, not per pair
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
   const int lane = threadIdx.x & 63;
   float gr[3] = {0, 0, 0}, gM[3] = {0, 0, 0};     // surfel entries
@@ -157,7 +158,7 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
         float pr[6] = {0, 0, 0, 0, 0, 0}, pM[6] = {0, 0, 0, 0, 0, 0};
         if (visible) {
           PairTerms t;
-          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, a, gp, gn, radius_sq, d1, d2, &t);
+          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, a, gn, tp, d1, d2, &t);
           if (L.use_depth) {
             if (L.optimize_geometry) {
               gr[0] -= t.Jgeom * t.w * t.raw;
@@ -207,15 +208,11 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
         }
         if (pose_kf) {
           const uint32_t base = kf_pose_index(L, k);
-          float mine = 0.f;
-#pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const float vr = wave_sum(pr[c]), vm = wave_sum(pM[c]);
-            if (lane == c) mine = vr;
-            if (lane == 6 + c) mine = vm;
-          }
-          if (lane < 6) unsafeAtomicAdd(&r_[base + lane], mine);
-          else if (lane < 12) unsafeAtomicAdd(&M_[base + lane - 6], mine);
+          // 12 totals with one halving butterfly (wave_reduce.h): lane 4 j holds total j
+          const float v[16] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pM[0], pM[1], pM[2], pM[3], pM[4], pM[5], 0.f, 0.f, 0.f, 0.f};
+          const float mine = wave_reduce_small<16>(v, lane);
+          const int slot = lane >> 2;
+          if ((lane & 3) == 0 && slot < 12) unsafeAtomicAdd(slot < 6 ? &r_[base + slot] : &M_[base + slot - 6], mine);
         }
       });
 
@@ -244,24 +241,33 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
 }
 
 // ---- block-level scalar reduction helper ------------------------------------------------------------------
+// One atomic per workgroup of kPcgBlock threads.  The vector kernels below run a grid-stride loop over at most
+// kPcgReduceBlocks workgroups: a dot product over 9 M unknowns then ends in 1024 atomics on its scalar instead of one per
+// wavefront (141 k atomics on ONE address serialise at 12.6 ns each -- 1.79 ms for a kernel that moves 0.2 GB).
+constexpr unsigned kPcgReduceBlocks = 1024;
 __device__ __forceinline__ void block_atomic_sum(float* dest, float value) {
+  __shared__ float partial[kPcgBlock / 64];
   const float v = wave_sum(value);
-  if ((threadIdx.x & 63) == 0 && v != 0.f) unsafeAtomicAdd(dest, v);
+  if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float total = ((partial[0] + partial[1]) + partial[2]) + partial[3];
+    if (total != 0.f) unsafeAtomicAdd(dest, total);
+  }
 }
 
 // PCGInit2 (B/kernel_pcg.cu:565-600)
 __global__ void __launch_bounds__(kPcgBlock)
 pcg_init2_kernel(PcgLayout L, float a, const float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta,
                  float* __restrict__ g_, float* __restrict__ p_, float* alpha_n) {
-  const uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x;
   float term = 0.f;
-  if (u < L.unknown_count) {
+  for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
     g_[u] = 0;
     const float r_value = r_[u] + ((u == L.a_index) ? (-kAPriorWeight * kAPriorWeight * a) : 0);
     const float p_value = r_value / (M_[u] + kDiagEpsilon + prior_at(L, u));
     p_[u] = p_value;
     delta[u] = 0;
-    term = dot_weight(L, u) * (r_value * p_value);
+    term += dot_weight(L, u) * (r_value * p_value);
   }
   block_atomic_sum(alpha_n, term);
 }
@@ -271,13 +277,14 @@ template <bool kDepthIntr, bool kColorIntr>
 __global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
 pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
                  const float* __restrict__ p_, float* __restrict__ g_, float* alpha_d) {
-  const uint32_t i = blockIdx.x * kPcgSweepBlock + threadIdx.x;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
   const Vec3 gn = surfel_normal(s, ii);
   const float radius_sq = s.row(kSurfelRadiusSquared)[ii];
   const float d1 = s.row(kSurfelDescriptor1)[ii], d2 = s.row(kSurfelDescriptor2)[ii];
+  const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);   // per surfel, not per pair
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
   const int lane = threadIdx.x & 63;
   const uint32_t gi = L.optimize_geometry ? (L.surfel_start + (uint32_t)L.geom_stride * ii) : 0u;
@@ -309,7 +316,7 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
         float gpose[6] = {0, 0, 0, 0, 0, 0};
         if (visible) {
           PairTerms t;
-          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, a, gp, gn, radius_sq, d1, d2, &t);
+          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, a, gn, tp, d1, d2, &t);
           if (L.use_depth) {
             float sum = 0;
             if (L.optimize_geometry) sum += t.Jgeom * ps[0];
@@ -374,13 +381,9 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
           }
         }
         if (pose_kf) {
-          float mine = 0.f;
-#pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const float v = wave_sum(gpose[c]);
-            if (lane == c) mine = v;
-          }
-          if (lane < 6) unsafeAtomicAdd(&g_[base + lane], mine);
+          const float v[8] = {gpose[0], gpose[1], gpose[2], gpose[3], gpose[4], gpose[5], 0.f, 0.f};
+          const float mine = wave_reduce_small<8>(v, lane);   // lane 8 j holds total j
+          if ((lane & 7) == 0 && lane < 48) unsafeAtomicAdd(&g_[base + (lane >> 3)], mine);
         }
       });
 
@@ -407,9 +410,11 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
 // (B/kernel_pcg.cu:1102-1112), i.e. the term enters alpha_d `repeat` times -- reproduced.
 __global__ void __launch_bounds__(kPcgBlock)
 pcg_eps_terms_kernel(PcgLayout L, const float* __restrict__ p_, float repeat, float* alpha_d) {
-  const uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x;
   float term = 0.f;
-  if (u < L.unknown_count) { const float pv = p_[u]; term = dot_weight(L, u) * ((kDiagEpsilon + prior_at(L, u)) * pv * pv); }
+  for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
+    const float pv = p_[u];
+    term += dot_weight(L, u) * ((kDiagEpsilon + prior_at(L, u)) * pv * pv);
+  }
   block_atomic_sum(alpha_d, repeat * term);
 }
 
@@ -417,11 +422,10 @@ pcg_eps_terms_kernel(PcgLayout L, const float* __restrict__ p_, float repeat, fl
 __global__ void __launch_bounds__(kPcgBlock)
 pcg_step2_kernel(PcgLayout L, float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta, float* __restrict__ g_,
                  const float* __restrict__ p_, const float* alpha_n, const float* alpha_d, float* beta_n) {
-  const uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x;
   float term = 0.f;
-  if (u < L.unknown_count) {
-    const float ad = *alpha_d;
-    const float alpha = (ad >= 1e-35f) ? (*alpha_n / ad) : 0;
+  const float ad = *alpha_d;
+  const float alpha = (ad >= 1e-35f) ? (*alpha_n / ad) : 0;
+  for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
     const float p_value = p_[u];
     delta[u] += alpha * p_value;
     float r_value = r_[u];
@@ -429,7 +433,7 @@ pcg_step2_kernel(PcgLayout L, float* __restrict__ r_, const float* __restrict__ 
     r_[u] = r_value;
     const float z_value = r_value / (M_[u] + kDiagEpsilon + prior_at(L, u));
     g_[u] = z_value;
-    term = dot_weight(L, u) * (z_value * r_value);
+    term += dot_weight(L, u) * (z_value * r_value);
   }
   block_atomic_sum(beta_n, term);
 }
@@ -475,8 +479,10 @@ pcg_update_cfactors_kernel(Intrinsics in, uint32_t start, const float* __restric
 
 // ---- launchers -----------------------------------------------------------------------------------------------
 static inline unsigned gU(uint32_t n) { return (n + kPcgBlock - 1) / kPcgBlock; }
+static inline unsigned gR(uint32_t n) { return gU(n) < kPcgReduceBlocks ? gU(n) : kPcgReduceBlocks; }   // grid-stride reductions
 
-static inline unsigned gS(uint32_t n) { return (n + kPcgSweepBlock - 1) / kPcgSweepBlock; }
+// whole XCD chunks, as in kernels_surfel.hip (xcd_chunked_tile)
+static inline unsigned gS(uint32_t n) { return ((n + kPcgSweepBlock - 1) / kPcgSweepBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk); }
 
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                      float* r, float* M) {
@@ -490,7 +496,7 @@ void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, c
 }
 void launch_pcg_init2(hipStream_t st, const PcgLayout& L, float a, const float* r, const float* M, float* delta, float* g, float* p,
                       float* alpha_n) {
-  if (L.unknown_count) hipLaunchKernelGGL(pcg_init2_kernel, dim3(gU(L.unknown_count)), dim3(kPcgBlock), 0, st, L, a, r, M, delta, g, p, alpha_n);
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_init2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, a, r, M, delta, g, p, alpha_n);
 }
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                       const float* p, float* g, float* alpha_d) {
@@ -501,11 +507,11 @@ void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, 
   else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
   else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
   else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
-  hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gU(L.unknown_count)), dim3(kPcgBlock), 0, st, L, p, (float)num_kfs, alpha_d);
+  hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, p, (float)num_kfs, alpha_d);
 }
 void launch_pcg_step2(hipStream_t st, const PcgLayout& L, float* r, const float* M, float* delta, float* g, const float* p,
                       const float* alpha_n, const float* alpha_d, float* beta_n) {
-  if (L.unknown_count) hipLaunchKernelGGL(pcg_step2_kernel, dim3(gU(L.unknown_count)), dim3(kPcgBlock), 0, st, L, r, M, delta, g, p, alpha_n, alpha_d, beta_n);
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_step2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, r, M, delta, g, p, alpha_n, alpha_d, beta_n);
 }
 void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n) {
   if (L.unknown_count) hipLaunchKernelGGL(pcg_step3_kernel, dim3(gU(L.unknown_count)), dim3(kPcgBlock), 0, st, L, g, p, alpha_n, beta_n);

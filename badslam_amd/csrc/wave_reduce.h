@@ -86,4 +86,23 @@ __device__ __forceinline__ float wave_reduce28(const float (&acc)[28], int lane)
   return r5 + dpp::mov<dpp::kQuadXor1>(r5);
 }
 
+// kCount = 8 or 16 per-lane values -> their wave totals with the same halving butterfly: lane (64 / kCount) * j receives
+// the total of v[j] (every lane of that group of 64 / kCount lanes does).  10 / 17 cross-lane adds instead of 6 per value.
+template <int kCount>
+__device__ __forceinline__ float wave_reduce_small(const float (&v)[kCount], int lane) {
+  static_assert(kCount == 8 || kCount == 16, "8 or 16 values");
+  float r1[kCount / 2], r2[kCount / 4], r3[kCount / 8];
+#pragma unroll
+  for (int p = 0; p < kCount / 2; ++p) r1[p] = halve32(v[p], v[p + kCount / 2]);
+#pragma unroll
+  for (int p = 0; p < kCount / 4; ++p) r2[p] = halve16(r1[p], r1[p + kCount / 4]);
+#pragma unroll
+  for (int p = 0; p < kCount / 8; ++p) r3[p] = halve_dpp<dpp::kRowRor8>(r2[p], r2[p + kCount / 8], (lane & 8) != 0);
+  float r4;
+  if (kCount == 16) r4 = halve_dpp<dpp::kRowHalfMirror>(r3[0], r3[kCount / 8 - 1], (lane & 4) != 0);
+  else r4 = r3[0] + dpp::mov<dpp::kRowHalfMirror>(r3[0]);
+  r4 += dpp::mov<dpp::kQuadXor2>(r4);
+  return r4 + dpp::mov<dpp::kQuadXor1>(r4);
+}
+
 }  // namespace bahip
