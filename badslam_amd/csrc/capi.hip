@@ -1087,15 +1087,15 @@ int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in
   return 0;
 }
 
-int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56) {
+int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_80) {
   float *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, 64 * 28 * sizeof(float)));
-  HIP_TRY(hipMalloc(&d_out, 56 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out, 80 * sizeof(float)));
   HIP_TRY(hipMemcpyAsync(d_in, in_64x28, 64 * 28 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemsetAsync(d_out, 0xff, 56 * sizeof(float), ctx->stream));
+  HIP_TRY(hipMemsetAsync(d_out, 0xff, 80 * sizeof(float), ctx->stream));
   launch_wave_reduce_debug(ctx->stream, d_in, d_out);
   CHECK_LAUNCH();
-  HIP_TRY(hipMemcpyAsync(out_56, d_out, 56 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out_80, d_out, 80 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   hipFree(d_in); hipFree(d_out);
   return 0;

@@ -312,6 +312,14 @@ __global__ void wave_reduce_debug_kernel(const float* __restrict__ in, float* __
     const float v = wave_sum(acc[q]);
     if (lane == 17) out[28 + q] = v;
   }
+  float v8[8], v16[16];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v8[q] = acc[q];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v16[q] = acc[q];
+  const float t8 = wave_reduce_small<8>(v8, lane), t16 = wave_reduce_small<16>(v16, lane);
+  if ((lane & 7) == 0) out[56 + (lane >> 3)] = t8;
+  if ((lane & 3) == 0) out[64 + (lane >> 2)] = t16;
 }
 void launch_wave_reduce_debug(hipStream_t stream, const float* in, float* out) {
   hipLaunchKernelGGL(wave_reduce_debug_kernel, dim3(1), dim3(64), 0, stream, in, out);

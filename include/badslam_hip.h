@@ -275,8 +275,9 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
  * raw_inv_depth exp_inv_depth corrected_inv_depth; 6), 4 descriptor/colour intrinsics (gx gy nx ny; 4). */
 int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in, float* out, int n_out);
 /* One wavefront: in = 64 lanes x 28 floats; out[0..27] = totals from the halving reduction used by the pose kernel
- * (wave_reduce.h), out[28..55] = the same totals from the xor-butterfly wave_sum. */
-int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_56);
+ * (wave_reduce.h), out[28..55] = the same totals from the xor-butterfly wave_sum, out[56..63] / out[64..79] = totals of the
+ * first 8 / 16 columns from the small halving reductions the PCG sweeps use (wave_reduce_small<8>, <16>). */
+int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_80);
 int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out);
 
 /* ---- instrumentation ---------------------------------------------------------------------------- */

@@ -154,18 +154,20 @@ def test_wave_reductions():
     for trial in range(3):
         # integers first (any summation order is exact), then floats
         x = rng.integers(-1000, 1000, (64, 28)).astype(np.float32) if trial == 0 else rng.standard_normal((64, 28)).astype(np.float32)
-        out = np.zeros(56, np.float32)
+        out = np.zeros(80, np.float32)
         capi.check(ctx.lib.bahip_debug_wave_reduce(ctx.handle, x.ctypes.data_as(C.POINTER(C.c_float)),
                                                    out.ctypes.data_as(C.POINTER(C.c_float))))
         exact = x.astype(np.float64).sum(0)
         if trial == 0:
-            assert np.array_equal(out[:28], exact) and np.array_equal(out[28:], exact)
+            assert np.array_equal(out[:28], exact) and np.array_equal(out[28:56], exact)
+            assert np.array_equal(out[56:64], exact[:8]) and np.array_equal(out[64:80], exact[:16])   # wave_reduce_small<8>, <16>
         else:
             assert np.abs(out[:28] - exact).max() < 2e-5
+            assert np.abs(out[56:64] - exact[:8]).max() < 2e-5 and np.abs(out[64:80] - exact[:16]).max() < 2e-5
             v = x.copy()   # classic butterfly, binary32: xor 32, 16, 8, 4, 2, 1
             for s in (32, 16, 8, 4, 2, 1):
                 v = v + v[np.arange(64) ^ s]
-            assert np.array_equal(out[28:], v[17])
+            assert np.array_equal(out[28:56], v[17])
 
 
 def test_bilateral_filter_matches_oracle(scene):
