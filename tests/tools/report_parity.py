@@ -1,6 +1,6 @@
 """Prints how close the HIP path is to the oracle on a small scene (used to set test thresholds)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import common
 

@@ -1,6 +1,6 @@
 """BASELINE.json configs[0]: 10 synthetic 320x240 keyframes, ~50 k surfels, 5 BA iterations on the CPU oracle (plumbing)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import common
 from oracle import binding as ob
