@@ -51,12 +51,13 @@ def test_no_cpu_fallback():
 
 def test_product_package_does_not_import_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
-    pkg = os.path.join(ROOT, "badslam_amd")
     offenders = []
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cc", ".c")) or f == "Makefile":
-                text = open(os.path.join(dirpath, f), errors="ignore").read()
-                if re.search(r"(from\s+oracle|import\s+oracle|oracle/|liboracle)", text):
-                    offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    for top in ("badslam_amd", "scripts", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".h", ".hip", ".cc", ".c")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"(from\s+oracle|import\s+oracle|liboracle|build_oracle|oracle\.binding)", text) or \
+                       (top != "scripts" and "oracle/" in text):
+                        offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
     assert not offenders, offenders
