@@ -88,3 +88,95 @@ def test_shard_range_partitions():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- sharded PCG: the exchange protocol of capi.hip (allreduce_head, PcgLayout::head_scale) on a model problem ------------
+def _pcg_model_problem(seed=3, head=13, surfels=600, rows_per_surfel=5):
+    """Residuals that each touch the dense head (poses / intrinsics) and ONE surfel unknown -- the arrowhead structure of
+    the BA normal equations.  Returns (J_head [R, head], J_surfel [R], surfel index [R], residual [R])."""
+    rng = np.random.default_rng(seed)
+    R = surfels * rows_per_surfel
+    idx = np.repeat(np.arange(surfels), rows_per_surfel)
+    return rng.standard_normal((R, head)), rng.standard_normal(R) + 2.0, idx, rng.standard_normal(R)
+
+
+def _pcg_sharded(Jh, Js, idx, res, owned, allreduce, world, steps=40, eps=1e-8):
+    """One rank's view: rows of its own surfels only; the head of every vector is replicated, the surfel block local.
+    Mirrors the sequence init -> init2 -> (step1, step2, step3)* and the three exchanges per DESIGN.md section 4."""
+    H, S = Jh.shape[1], int(idx.max()) + 1
+    rows = np.isin(idx, owned)
+    Jh, Js, idx, res = Jh[rows], Js[rows], idx[rows], res[rows]
+    local = np.zeros(S, bool); local[owned] = True
+    head_scale = 1.0 / world                                  # dot_weight of a head entry (replicated on every rank)
+
+    def JtJ(ph, ps):                                          # (J^T J p) from the local rows
+        jp = Jh @ ph + Js * ps[idx]
+        return Jh.T @ jp, np.bincount(idx, weights=Js * jp, minlength=S), float(jp @ jp)
+
+    def dot(ah, as_, bh, bs):
+        return head_scale * float(ah @ bh) + float(as_[local] @ bs[local])
+
+    rh, rs = -(Jh.T @ res), -np.bincount(idx, weights=Js * res, minlength=S)
+    Mh, Ms = (Jh * Jh).sum(0), np.bincount(idx, weights=Js * Js, minlength=S)
+    rh, Mh = np.split(allreduce(np.concatenate([rh, Mh])), 2)                                  # exchange 0: head of r and M
+    ph, ps = rh / (Mh + eps), np.where(local, rs / (Ms + eps), 0.0)
+    dh, ds = np.zeros(H), np.zeros(S)
+    alpha_n = allreduce(np.array([dot(rh, rs, ph, ps)]))[0]
+    for _ in range(steps):
+        gh, gs, alpha_d = JtJ(ph, ps)
+        alpha_d += eps * dot(ph, ps, ph, ps)
+        packed = allreduce(np.concatenate([gh, [alpha_d]]))                                    # exchange 1: head of g + alpha_d
+        gh, alpha_d = packed[:H], packed[H]
+        alpha = alpha_n / alpha_d if alpha_d >= 1e-35 else 0.0
+        dh, ds = dh + alpha * ph, ds + alpha * ps
+        rh, rs = rh - alpha * (gh + eps * ph), rs - alpha * (gs + eps * ps)
+        zh, zs = rh / (Mh + eps), np.where(local, rs / (Ms + eps), 0.0)
+        beta_n = allreduce(np.array([dot(zh, zs, rh, rs)]))[0]                                 # exchange 2: beta_n
+        beta = beta_n / alpha_n if alpha_n >= 1e-35 else 0.0
+        ph, ps = zh + beta * ph, zs + beta * ps
+        alpha_n = beta_n
+    return dh, ds
+
+
+def _pcg_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from badslam_amd import multigpu
+    Jh, Js, idx, res = _pcg_model_problem()
+    owned = multigpu.shard_chunks(int(idx.max()) + 1, rank, world, chunk=64)
+
+    def allreduce(v):
+        t = torch.from_numpy(np.ascontiguousarray(v, np.float64))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    dh, ds = _pcg_sharded(Jh, Js, idx, res, owned, allreduce, world)
+    np.save(os.path.join(out_dir, f"pcg_head_{rank}.npy"), dh)
+    np.save(os.path.join(out_dir, f"pcg_surfels_{rank}.npy"), ds)
+    np.save(os.path.join(out_dir, f"pcg_owned_{rank}.npy"), owned)
+    dist.destroy_process_group()
+
+
+def test_sharded_pcg_exchange_protocol(tmp_path):
+    """Dense head replicated and summed, surfel block local, dot products formed as head / world + local: two ranks
+    following the protocol reach the solution of the unsharded normal equations, and agree on the head bit for bit."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_pcg_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    Jh, Js, idx, res = _pcg_model_problem()
+    S = int(idx.max()) + 1
+    J = np.zeros((len(res), Jh.shape[1] + S))
+    J[:, :Jh.shape[1]] = Jh
+    J[np.arange(len(res)), Jh.shape[1] + idx] = Js
+    exact = np.linalg.lstsq(J, -res, rcond=None)[0]
+    single_h, single_s = _pcg_sharded(Jh, Js, idx, res, np.arange(S), lambda v: v, 1)     # the same code on one rank
+    assert np.abs(np.concatenate([single_h, single_s]) - exact).max() < 1e-8
+    h0, h1 = np.load(tmp_path / "pcg_head_0.npy"), np.load(tmp_path / "pcg_head_1.npy")
+    assert np.array_equal(h0, h1)
+    surfels = np.zeros(S)
+    for r in range(world):
+        owned = np.load(tmp_path / f"pcg_owned_{r}.npy")
+        surfels[owned] = np.load(tmp_path / f"pcg_surfels_{r}.npy")[owned]
+    assert np.abs(np.concatenate([h0, surfels]) - exact).max() < 1e-8
