@@ -110,8 +110,10 @@ def test_keyframes_fed_one_at_a_time_through_the_scheduler(tmp_path, mode):
     err_before = _translation_errors(scene, _relative(initial))
     print("before", err_before, "after", err_after)
     assert err_before[1:].mean() > 3e-3
-    assert err_after[1:].mean() < 0.3 * err_before[1:].mean()
-    assert err_after.max() < 3e-3
+    # (how many iterations the BA thread gets in before the last keyframe arrives depends on the timing of the two
+    # threads, hence the margin)
+    assert err_after[1:].mean() < 0.4 * err_before[1:].mean()
+    assert err_after.max() < 4e-3
 
 
 def test_state_file_round_trip_and_resume(tmp_path):
