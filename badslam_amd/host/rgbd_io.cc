@@ -60,6 +60,10 @@ bool DecodePNG(const std::string& path, PngRaw* out) {
   if (out->bit_depth != 8 && out->bit_depth != 16) return false;
   const size_t bpp = (size_t)out->channels * out->bit_depth / 8;   // bytes per pixel = filter distance
   const size_t row_bytes = (size_t)out->width * bpp;
+  // A header may announce any size up to 2^31 squared; deflate expands by at most 1032:1, so more scanline bytes than
+  // that cannot be in this file (and are not allocated for).
+  const size_t max_raw = compressed.size() * 1032 + 64;
+  if (row_bytes + 1 > max_raw / out->height) return false;
   std::vector<u8> raw((row_bytes + 1) * out->height);
   uLongf raw_size = (uLongf)raw.size();
   if (uncompress(raw.data(), &raw_size, compressed.data(), (uLong)compressed.size()) != Z_OK || raw_size != raw.size()) return false;
@@ -406,8 +410,15 @@ shared_ptr<Keyframe> CreateKeyframeFromFrame(hipStream_t stream, const Preproces
   CHECK(depth_image && rgb_image) << "cannot load the images of frame " << frame_index;
   const int W = depth_image->width(), H = depth_image->height();
   const PinholeCamera4f depth_camera = direct_ba.depth_camera();
+  const PinholeCamera4f color_camera = direct_ba.color_camera();
   const DepthParameters depth_params = direct_ba.depth_params();
   const float raw_to_float_depth = depth_params.raw_to_float_depth;
+  // the kernels address the images with the cameras' dimensions
+  CHECK(W == depth_camera.width() && H == depth_camera.height())
+      << "frame " << frame_index << ": depth image is " << W << " x " << H << ", the depth camera " << depth_camera.width() << " x " << depth_camera.height();
+  CHECK((int)rgb_image->width() == color_camera.width() && (int)rgb_image->height() == color_camera.height())
+      << "frame " << frame_index << ": colour image is " << rgb_image->width() << " x " << rgb_image->height() << ", the colour camera "
+      << color_camera.width() << " x " << color_camera.height();
 
   bahip_context* ctx = nullptr;
   BAHIP_CHECKED_CALL(bahip_context_create(&ctx, stream));

@@ -35,3 +35,62 @@ def test_tum_reader_and_png_decoder(tmp_path):
         if pose[3] * gt[3] < 0:
             pose[:4] = -pose[:4]
         assert np.abs(pose - gt).max() < 1e-6
+
+
+def test_png_decoder_refuses_malformed_files_without_crashing(tmp_path):
+    """The decoder is written from the PNG specification (the reference links libpng), so it gets the hostile cases too:
+    headers announcing absurd sizes, truncated or over-long data, unknown filters, unsupported formats, a zlib bomb, plus
+    random truncations / byte flips of valid files.  Every one must end in a clean refusal (exit code 1) or -- where the
+    corruption happens to leave a valid PNG -- a normal run, never in a signal."""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    def png(w, h, bit_depth, color_type, raw, interlace=0):
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bit_depth, color_type, 0, 0, interlace)) +
+                chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+    scene = common.small_scene(num_keyframes=2, width=64, height=48, seed=1)
+    tum_writer.write_dataset(str(tmp_path), scene, {"t.txt": scene.poses_gt})
+    rgb = os.path.join(tmp_path, "rgb", sorted(os.listdir(tmp_path / "rgb"))[0])
+    depth = os.path.join(tmp_path, "depth", sorted(os.listdir(tmp_path / "depth"))[0])
+    original = {f: open(f, "rb").read() for f in (rgb, depth)}
+
+    def run():
+        return subprocess.run([BIN, "--check-dataset", str(tmp_path), "t.txt"], capture_output=True, timeout=120).returncode
+
+    assert run() == 0
+    row = lambda n: b"\x00" + bytes(n)   # noqa: E731
+    refused = {
+        "header announces 2^31 x 2^31": (rgb, png(0x7fffffff, 0x7fffffff, 8, 2, b"")),
+        "zero size": (rgb, png(0, 0, 8, 2, b"")),
+        "too few scanlines": (rgb, png(64, 48, 8, 2, row(64 * 3) * 10)),
+        "too many scanlines": (rgb, png(64, 48, 8, 2, row(64 * 3) * 100)),
+        "unknown filter type": (rgb, png(64, 48, 8, 2, (b"\x09" + bytes(64 * 3)) * 48)),
+        "interlaced": (rgb, png(64, 48, 8, 2, row(64 * 3) * 48, interlace=1)),
+        "palette": (rgb, png(64, 48, 8, 3, row(64) * 48)),
+        "1 bit per sample": (rgb, png(64, 48, 1, 0, row(8) * 48)),
+        "colour where depth is expected": (depth, png(64, 48, 8, 2, row(64 * 3) * 48)),
+        "huge depth header": (depth, png(70000, 70000, 16, 0, b"")),
+        "zlib bomb": (rgb, png(64, 48, 8, 2, bytes(50_000_000))),
+    }
+    for name, (path, blob) in refused.items():
+        open(path, "wb").write(blob)
+        assert run() == 1, name
+        open(path, "wb").write(original[path])
+
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        path = (rgb, depth)[trial % 2]
+        blob = bytearray(original[path])
+        if trial % 3 == 0:
+            blob = blob[:rng.integers(0, len(blob))]
+        else:
+            for _ in range(int(rng.integers(1, 8))):
+                blob[rng.integers(0, len(blob))] = rng.integers(0, 256)
+        open(path, "wb").write(bytes(blob))
+        assert run() in (0, 1), trial
+        open(path, "wb").write(original[path])
+    assert run() == 0
