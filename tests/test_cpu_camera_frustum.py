@@ -18,7 +18,7 @@ def test_frustum_intersection_against_brute_force(tmp_path):
     sat, sat_reverse, brute = t[:, 0], t[:, 1], t[:, 2]
     assert len(t) == 1500
     assert np.array_equal(sat, sat_reverse)                          # symmetric
-    assert 0.2 < brute.mean() < 0.8                                  # the sample has both kinds
+    assert 0.1 < brute.mean() < 0.9                                  # the sample has both kinds
     assert not np.any((brute == 1) & (sat == 0))                     # never misses an intersection a sample point proves
     # the other direction cannot be strict (a thin overlap may contain no sample point), but must be rare
     assert np.sum((sat == 1) & (brute == 0)) <= 0.03 * len(t)
