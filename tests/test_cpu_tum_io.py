@@ -94,3 +94,44 @@ def test_png_decoder_refuses_malformed_files_without_crashing(tmp_path):
         assert run() in (0, 1), trial
         open(path, "wb").write(original[path])
     assert run() == 0
+
+
+def test_trajectory_poses_are_interpolated_between_samples(tmp_path):
+    """L/rgbd_video_io_tum_dataset.h:42-72: a frame whose timestamp falls between two trajectory samples gets the
+    translation interpolated linearly and the rotation by slerp; before the first / after the last sample the nearest one."""
+    scene = common.small_scene(num_keyframes=6, width=64, height=48, seed=3)
+    stamps = tum_writer.write_dataset(str(tmp_path), scene, {})
+    t = np.array([float(s) for s in stamps])
+    # three samples: 40 % of the way into the second frame interval, between frames 3 and 4, and just before the last frame
+    sample_times = np.array([t[1] + 0.4 * (t[2] - t[1]), t[3] + 0.5 * (t[4] - t[3]), t[5] - 0.25 * (t[5] - t[4])])
+    sample_poses = [np.asarray(scene.poses_gt[k], np.float64) for k in (1, 3, 5)]
+    tum_writer.write_trajectory(str(tmp_path / "sparse.txt"), ["%.6f" % v for v in sample_times], sample_poses)
+    out = subprocess.run([BIN, "--check-dataset", str(tmp_path), "sparse.txt"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = [np.array([float(v) for v in line.split()[9:16]]) for line in out.stdout.strip().splitlines()[1:]]
+    sample_times = np.array([float("%.6f" % v) for v in sample_times])          # as written to the file
+
+    def slerp(qa, qb, f):
+        d = float(qa @ qb)
+        if d < 0:
+            qb, d = -qb, -d
+        if d > 1 - 1e-12:
+            return (1 - f) * qa + f * qb
+        theta = np.arccos(d)
+        return (np.sin((1 - f) * theta) * qa + np.sin(f * theta) * qb) / np.sin(theta)
+
+    for k in range(6):
+        if t[k] <= sample_times[0]:
+            want = sample_poses[0]
+        elif t[k] >= sample_times[-1]:
+            want = sample_poses[-1]
+        else:
+            i = int(np.searchsorted(sample_times, t[k])) - 1
+            f = (t[k] - sample_times[i]) / (sample_times[i + 1] - sample_times[i])
+            a, b = sample_poses[i], sample_poses[i + 1]
+            want = np.concatenate([slerp(a[:4], b[:4], f), a[4:] + f * (b[4:] - a[4:])])
+        pose = got[k].copy()
+        if pose[:4] @ want[:4] < 0:
+            pose[:4] = -pose[:4]
+        assert np.abs(pose - want).max() < 2e-6, (k, pose, want)
+        assert abs(np.linalg.norm(pose[:4]) - 1) < 1e-6
