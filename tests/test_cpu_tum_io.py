@@ -135,3 +135,32 @@ def test_trajectory_poses_are_interpolated_between_samples(tmp_path):
             pose[:4] = -pose[:4]
         assert np.abs(pose - want).max() < 2e-6, (k, pose, want)
         assert abs(np.linalg.norm(pose[:4]) - 1) < 1e-6
+
+
+def test_save_poses_writes_the_trajectory_relative_to_the_start_frame(tmp_path):
+    """B/io.cc:537-568: one `timestamp tx ty tz qx qy qz qw` line per frame, every pose pre-multiplied by the inverse of the
+    start frame's pose (so the start frame is written as the identity)."""
+    from badslam_amd import se3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "badslam_amd", "lib")
+    exe = str(tmp_path / "save_poses_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "badslam_amd", "host"), "-I", os.path.join(root, "include"),
+                    "-o", exe, os.path.join(root, "tests", "cpp", "save_poses_check.cc"), "-L", lib, "-lbadslam_host", "-lbadslam_hip",
+                    "-Wl,-rpath," + lib], check=True, timeout=300)
+    scene = common.small_scene(num_keyframes=5, width=64, height=48, seed=6)
+    stamps = tum_writer.write_dataset(str(tmp_path), scene, {"gt.txt": scene.poses_gt})
+    for start_frame in (0, 2):
+        out = str(tmp_path / f"poses_{start_frame}.txt")
+        assert subprocess.run([exe, str(tmp_path), "gt.txt", out, str(start_frame)], timeout=120).returncode == 0
+        lines = [l for l in open(out).read().splitlines() if not l.startswith("#")]
+        assert [l.split()[0] for l in lines] == stamps
+        inv = se3.inverse(np.asarray(scene.poses_gt[start_frame], np.float64))
+        for k, line in enumerate(lines):
+            v = [float(x) for x in line.split()[1:]]
+            pose = np.array([v[3], v[4], v[5], v[6], v[0], v[1], v[2]])
+            want = se3.mul(inv, np.asarray(scene.poses_gt[k], np.float64))
+            if pose[:4] @ want[:4] < 0:
+                pose[:4] = -pose[:4]
+            assert np.abs(pose - want).max() < 2e-6
+        ident = [float(x) for x in lines[start_frame].split()[1:]]
+        assert np.allclose(ident[:3], 0, atol=1e-6) and np.allclose(np.abs(ident[6]), 1, atol=1e-6)
