@@ -91,6 +91,7 @@ SIGNATURES = {
     "bahip_set_keyframes": (C.c_int, [C.c_void_p, C.POINTER(Keyframe), C.c_int]),
     "bahip_get_keyframe_poses": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "bahip_update_surfel_activation": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.c_uint32]),
+    "bahip_assign_colors": (C.c_int, [C.c_void_p, C.POINTER(Surfels)]),
     "bahip_update_surfel_normals": (C.c_int, [C.c_void_p, C.POINTER(Surfels)]),
     "bahip_optimize_geometry_iteration": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels)]),
     "bahip_accumulate_pose_estimation_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Frame), C.POINTER(C.c_float),

@@ -27,6 +27,7 @@ void launch_pack_planes(hipStream_t stream, const KfEntry& frame, int width, int
 // kernels_surfel.hip
 void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                        uint32_t surfels_size);
+void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
 void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
                      int num_kfs, const SurfelsView& s);

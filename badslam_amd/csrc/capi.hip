@@ -588,6 +588,13 @@ int bahip_update_surfel_activation(bahip_context* ctx, const bahip_surfels* surf
   return 0;
 }
 
+int bahip_assign_colors(bahip_context* ctx, const bahip_surfels* surfels) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  launch_assign_colors(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int bahip_update_surfel_normals(bahip_context* ctx, const bahip_surfels* surfels) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(surfels->active != nullptr, "normals update needs the active-surfel buffer");

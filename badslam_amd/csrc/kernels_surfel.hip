@@ -96,6 +96,70 @@ activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, S
   if (in_range) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (active ? kSurfelActiveFlag : 0);
 }
 
+// ---- DirectBA::AssignColors (B/kernel_assign_colors.cu:41-125, B/kernel_assign_colors.cc:39-80) --------------------------
+// Bilinear RGBA sample at unnormalised coordinates, clamp addressing, texel centres at +0.5 (the tex2D<float4> of the
+// reference on the keyframe's pitch-linear uchar4 image); per channel the arithmetic of sample_luma (oracle: orc_sample_rgba).
+__device__ __forceinline__ void sample_rgba(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y, float (&out)[4]) {
+  float xb = x - 0.5f, yb = y - 0.5f;
+  if (!(xb >= -1.f)) xb = -1.f;
+  if (xb > (float)w) xb = (float)w;
+  if (!(yb >= -1.f)) yb = -1.f;
+  if (yb > (float)h) yb = (float)h;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = xb - fx, b = yb - fy;
+  const int x0 = min(max((int)fx, 0), w - 1), x1 = min(max((int)fx + 1, 0), w - 1);
+  const int y0 = min(max((int)fy, 0), h - 1), y1 = min(max((int)fy + 1, 0), h - 1);
+  const uchar4* image = reinterpret_cast<const uchar4*>(color);
+  const uchar4 tl = pitched_load(image, pitch, y0, x0), tr = pitched_load(image, pitch, y0, x1);
+  const uchar4 bl = pitched_load(image, pitch, y1, x0), br = pitched_load(image, pitch, y1, x1);
+  const uint8_t ctl[4] = {tl.x, tl.y, tl.z, tl.w}, ctr[4] = {tr.x, tr.y, tr.z, tr.w};
+  const uint8_t cbl[4] = {bl.x, bl.y, bl.z, bl.w}, cbr[4] = {br.x, br.y, br.z, br.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float vtl = (float)ctl[c] * (1.0f / 255.0f), vtr = (float)ctr[c] * (1.0f / 255.0f);
+    const float vbl = (float)cbl[c] * (1.0f / 255.0f), vbr = (float)cbr[c] * (1.0f / 255.0f);
+    const float top = mad(a, vtr - vtl, vtl);
+    const float bot = mad(a, vbr - vbl, vbl);
+    out[c] = mad(b, bot - top, top);
+  }
+}
+
+// Every keyframe a surfel is associated with (whatever its activation) contributes the RGBA sample at the surfel's colour
+// pixel, in keyframe order; the mean, rounded, becomes the surfel colour.  Surfels no keyframe sees keep theirs.  The
+// reference parks count and sums in accumulator rows 0-4 between its K + 2 launches; here they live in registers.
+__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
+assign_colors_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + threadIdx.x;
+  const bool in_range = i < s.size;
+  const uint32_t ii = in_range ? i : 0;
+  const Vec3 gp = surfel_position(s, ii);
+  const Vec3 gn = surfel_normal(s, ii);
+  const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
+  float count = 0.f, sum[4] = {0.f, 0.f, 0.f, 0.f};
+  for_each_candidate(
+      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      [&](int k) {
+        if (!in_range) return;
+        Assoc r;
+        if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) return;
+        float cx, cy;
+        if (!depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) return;
+        float c[4];
+        sample_rgba(kfs[k].color, kfs[k].color_pitch, in.cwidth, in.cheight, cx, cy, c);
+        count += 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum[q] += c[q];
+      });
+  if (in_range && count > 0.f) {
+    uchar4 out;
+    out.x = (uint8_t)(255.f * sum[0] / count + 0.5f);
+    out.y = (uint8_t)(255.f * sum[1] / count + 0.5f);
+    out.z = (uint8_t)(255.f * sum[2] / count + 0.5f);
+    out.w = (uint8_t)(255.f * sum[3] / count + 0.5f);
+    reinterpret_cast<uchar4*>(s.row(kSurfelColor))[i] = out;
+  }
+}
+
 // Normals pass: B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update).
 // `live` = this lane holds an active surfel; every thread of the workgroup must call this function.
 template <int kWaves>
@@ -276,6 +340,11 @@ void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* 
   if (surfels_size == 0) return;
   hipLaunchKernelGGL(activation_kernel, dim3(grid_for(surfels_size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s,
                      surfels_size);
+}
+
+void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s) {
+  if (s.size == 0) return;
+  hipLaunchKernelGGL(assign_colors_kernel, dim3(grid_for(s.size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s);
 }
 
 // Launch shape of the normals / geometry passes (see the header comment): one wavefront per tile when the tiles alone

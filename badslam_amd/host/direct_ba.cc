@@ -84,6 +84,12 @@ void DirectBA::DetermineNewKeyframeCoVisibility(const shared_ptr<Keyframe>& new_
   }
 }
 
+void DirectBA::AssignColors(hipStream_t stream) {
+  BindScene(stream);
+  const bahip_surfels s = SurfelsStruct(/*with_active*/ false);
+  BAHIP_CHECKED_CALL(bahip_assign_colors(ctx_, &s));
+}
+
 void DirectBA::UpdateKeyframeCoVisibility(const shared_ptr<Keyframe>& keyframe) {
   for (int covis_index : keyframe->co_visibility_list()) {
     auto& list = keyframes_[covis_index]->co_visibility_list();

@@ -45,6 +45,8 @@ class DirectBA {
                         int pcg_max_inner_iterations = 30, int pcg_max_keyframes = 2500,
                         std::function<bool(int)> progress_function = nullptr);
   void UpdateKeyframeCoVisibility(const shared_ptr<Keyframe>& keyframe);
+  // B/direct_ba.h:167, B/direct_ba.cc:456-459: surfel colours := mean of their observations in all keyframes (before an export).
+  void AssignColors(hipStream_t stream);
 
   void Lock() const { ba_thread_mutex_.lock(); }
   void Unlock() const { ba_thread_mutex_.unlock(); }

@@ -204,6 +204,10 @@ class Scene:
         s = self.surfels_struct()
         capi.check(self.lib.bahip_update_surfel_activation(self.ctx.handle, C.byref(s), self.surfels_size))
 
+    def assign_colors(self):
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_assign_colors(self.ctx.handle, C.byref(s)))
+
     def optimize_geometry_iteration(self, use_depth, use_desc):
         s = self.surfels_struct()
         capi.check(self.lib.bahip_optimize_geometry_iteration(self.ctx.handle, int(use_depth), int(use_desc), C.byref(s)))

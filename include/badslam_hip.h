@@ -174,6 +174,10 @@ int bahip_get_keyframe_poses(bahip_context* ctx, float* global_T_frame_out, int 
 /* B/kernels.h UpdateSurfelActivationCUDA (B/kernel_surfel_activation.cc:39-67): surfels
  * [0, surfels_size) become active iff associated with >= 1 keyframe whose activation is kActive. */
 int bahip_update_surfel_activation(bahip_context* ctx, const bahip_surfels* surfels, uint32_t surfels_size);
+/* B/kernels.h:301-308 AssignColorsCUDA (B/kernel_assign_colors.cc:39-80), behind DirectBA::AssignColors
+ * (B/direct_ba.cc:456-459): the colour of every surfel becomes the mean of the bilinear RGBA samples at its colour pixel
+ * in all bound keyframes it is associated with (any activation); surfels seen by none keep their colour. */
+int bahip_assign_colors(bahip_context* ctx, const bahip_surfels* surfels);
 /* B/kernels.h UpdateSurfelNormalsCUDA (B/kernel_opt_geometry.cc:39-77). */
 int bahip_update_surfel_normals(bahip_context* ctx, const bahip_surfels* surfels);
 /* B/kernels.h OptimizeGeometryIterationCUDA (B/kernel_opt_geometry.cc:80-201). */

@@ -298,6 +298,11 @@ class OracleBA:
         self.L.orc_update_surfel_activation(C.byref(self.depth_cam), C.byref(self.dp), self._kf_ptr_array(),
                                             len(self.keyframes), C.c_uint32(self.surfels_size), C.byref(self.surfels))
 
+    def assign_colors(self):
+        self.L.orc_assign_colors.restype = None
+        self.L.orc_assign_colors(C.byref(self.color_cam), C.byref(self.depth_cam), C.byref(self.dp), self._kf_ptr_array(),
+                                 len(self.keyframes), C.byref(self.surfels))
+
     def optimize_geometry_iteration(self):
         self.L.orc_optimize_geometry_iteration(self.use_depth, self.use_desc, C.byref(self.color_cam), C.byref(self.depth_cam),
                                                C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),

@@ -193,6 +193,9 @@ int orc_is_scale1_pose_converged(const float x[6]);
 void orc_ldlt_solve(int n, const double* H_full_rowmajor, const double* b, double* x);
 
 /* ---- surfel activation, geometry ---- */
+/* DirectBA::AssignColors (B/direct_ba.cc:456-459, B/kernel_assign_colors.cc:39-80) */
+void orc_assign_colors(const orc_camera* color_cam, const orc_camera* depth_cam, const orc_depth_params* dp,
+                       orc_keyframe* const* kfs, int num_kfs, orc_surfels* s);
 /* B/kernel_surfel_activation.cc:39-67 */
 void orc_update_surfel_activation(const orc_camera* depth_cam, const orc_depth_params* dp,
                                   orc_keyframe* const* kfs, int num_kfs, uint32_t surfels_size,

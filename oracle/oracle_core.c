@@ -289,6 +289,35 @@ float orc_sample_luma(const uint8_t* rgba, int width, int height, float x, float
   return mad(b, bot - top, top);
 }
 
+/* The same sampler on all four channels (tex2D<float4> of B/kernel_assign_colors.cu:80). */
+void orc_sample_rgba(const uint8_t* rgba, int width, int height, float x, float y, float out[4]) {
+  float xb = x - 0.5f, yb = y - 0.5f;
+  if (!(xb >= -1.f)) xb = -1.f;
+  if (xb > (float)width) xb = (float)width;
+  if (!(yb >= -1.f)) yb = -1.f;
+  if (yb > (float)height) yb = (float)height;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = xb - fx, b = yb - fy;
+  int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 = 0;
+  if (x0 > width - 1) x0 = width - 1;
+  if (x1 < 0) x1 = 0;
+  if (x1 > width - 1) x1 = width - 1;
+  if (y0 < 0) y0 = 0;
+  if (y0 > height - 1) y0 = height - 1;
+  if (y1 < 0) y1 = 0;
+  if (y1 > height - 1) y1 = height - 1;
+  for (int c = 0; c < 4; ++c) {
+    const float tl = (float)rgba[4 * ((size_t)y0 * width + x0) + c] * (1.0f / 255.0f);
+    const float tr = (float)rgba[4 * ((size_t)y0 * width + x1) + c] * (1.0f / 255.0f);
+    const float bl = (float)rgba[4 * ((size_t)y1 * width + x0) + c] * (1.0f / 255.0f);
+    const float br = (float)rgba[4 * ((size_t)y1 * width + x1) + c] * (1.0f / 255.0f);
+    const float top = mad(a, tr - tl, tl);
+    const float bot = mad(a, br - bl, bl);
+    out[c] = mad(b, bot - top, top);
+  }
+}
+
 /* B/cost_function.cuh:115-136 */
 void orc_tangent_projections(v3 gp, v3 gn, float radius_sq, const float* F, const orc_camera* color_cam,
                              float t1_pxy[2], float t2_pxy[2]) {

@@ -23,6 +23,36 @@ void orc_update_surfel_activation(const orc_camera* depth_cam, const orc_depth_p
   }
 }
 
+/* DirectBA::AssignColors: B/kernel_assign_colors.cc:39-80, B/kernel_assign_colors.cu:41-125.  Every keyframe a surfel is
+ * associated with (active or not) contributes the bilinear RGBA sample at the surfel's colour pixel, in keyframe order; the
+ * mean becomes the surfel colour (rounded to nearest by + 0.5 and truncation).  Surfels seen by no keyframe keep theirs.  The
+ * reference parks count and sums in accumulator rows 0-4 (scratch by contract); they stay untouched here. */
+void orc_assign_colors(const orc_camera* color_cam, const orc_camera* depth_cam, const orc_depth_params* dp,
+                       orc_keyframe* const* kfs, int num_kfs, orc_surfels* s) {
+  const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
+#pragma omp parallel for schedule(static)
+  for (uint32_t i = 0; i < s->surfels_size; ++i) {
+    float count = 0.f, sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < num_kfs; ++k) {
+      const orc_keyframe* kf = kfs[k];
+      if (!kf) continue;
+      proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
+      proj_result r;
+      if (!orc_project_associate(&p, i, &r, NULL)) continue;
+      float cx, cy;
+      if (!transform_depth_to_color(r.pxx, r.pxy, &d2c, &cx, &cy)) continue;
+      float c[4];
+      orc_sample_rgba(kf->color, kf->color_width, kf->color_height, cx, cy, c);
+      count += 1.f;
+      for (int q = 0; q < 4; ++q) sum[q] += c[q];
+    }
+    if (count > 0) {
+      uint8_t* out = (uint8_t*)&srow(s, ORC_SURFEL_COLOR)[i];
+      for (int q = 0; q < 4; ++q) out[q] = (uint8_t)(255.f * sum[q] / count + 0.5f);
+    }
+  }
+}
+
 /* Per-surfel sums over keyframes.  The reference adds the keyframes' contributions in keyframe order (one kernel launch
  * per keyframe).  The HIP path defines the sums as four interleaved partial sums - partial j takes the keyframes whose
  * index among the non-deleted keyframes is congruent to j modulo 4, in ascending order - combined as

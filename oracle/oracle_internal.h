@@ -163,6 +163,7 @@ void orc_tangent_projections(v3 gp, v3 gn, float radius_sq, const float* F, cons
 /* B/cost_function.cuh:140-156 */
 void orc_raw_descriptor_residual(const orc_keyframe* kf, const float c[2], const float t1[2], const float t2[2],
                                  float d1, float d2, float* r1, float* r2);
+void orc_sample_rgba(const uint8_t* rgba, int width, int height, float x, float y, float out[4]);
 /* B/cost_function.cuh:191-254 */
 void orc_descriptor_gradient(const orc_keyframe* kf, const float c[2], const float t1[2], const float t2[2],
                              float g[4]);

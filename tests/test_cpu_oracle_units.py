@@ -232,3 +232,51 @@ def test_bilateral_filter_and_depth_cutoff_properties():
     noisy = (10000 + rng.integers(-20, 21, (H, W))).astype(np.uint16)
     out = ob.bilateral_filter_and_depth_cutoff(noisy, 1.5, 0.005, 2.0, 15000, s)
     assert out[4:-4, 4:-4].astype(float).std() < 0.5 * noisy[4:-4, 4:-4].astype(float).std()
+
+
+def test_assign_colors_is_the_mean_of_the_bilinear_samples():
+    """orc_assign_colors (B/kernel_assign_colors.cu:41-125): on images of constant colour the mean of the bilinear samples is
+    that colour exactly; with keyframes of different constant colours it lies between them and depends on which keyframes see
+    the surfel; surfels no keyframe sees keep their colour; the luma channel of the RGBA sampler is the luma sampler."""
+    import ctypes as C
+    from oracle import binding as ob
+    scene = common.small_scene(num_keyframes=3, width=160, height=120, seed=9)
+    ba = common.build_oracle(scene, 60000)
+    n = ba.surfels_size
+    colors = ba.surfel_data[ob.SURFEL_COLOR if hasattr(ob, "SURFEL_COLOR") else 5, :n].view(np.uint8).reshape(n, 4)
+
+    # (1) RGBA sampler, channel 3 == luma sampler, bit for bit
+    L = ob.lib()
+    L.orc_sample_luma.restype = C.c_float
+    rgba = ba.kf_arrays(0)["color"]
+    h, w = rgba.shape[:2]
+    rng = np.random.default_rng(0)
+    for x, y in rng.uniform(-2, max(w, h) + 2, (200, 2)):
+        out = (C.c_float * 4)()
+        L.orc_sample_rgba(rgba.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, C.c_float(x), C.c_float(y), out)
+        luma = L.orc_sample_luma(rgba.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, C.c_float(x), C.c_float(y))
+        assert np.float32(out[3]) == np.float32(luma)
+        assert all(0.0 <= out[c] <= 1.0 for c in range(4))
+
+    # (2) the same constant colour in every keyframe
+    for k in range(3):
+        ba.kf_arrays(k)["color"][:] = (10, 200, 77, 131)
+    colors[:] = (1, 2, 3, 4)
+    ba.assign_colors()
+    seen = ~np.all(colors == (1, 2, 3, 4), axis=1)
+    assert seen.mean() > 0.9
+    assert np.all(colors[seen] == (10, 200, 77, 131))
+    before = colors.copy()
+    ba.assign_colors()
+    assert np.array_equal(colors, before)                       # idempotent
+
+    # (3) a different constant per keyframe: the result is a mean of a subset of them
+    consts = np.array([(0, 30, 60, 90), (100, 130, 160, 190), (250, 240, 230, 220)], np.float64)
+    for k in range(3):
+        ba.kf_arrays(k)["color"][:] = consts[k].astype(np.uint8)
+    ba.assign_colors()
+    subsets = [[0], [1], [2], [0, 1], [0, 2], [1, 2], [0, 1, 2]]
+    means = np.array([np.floor(consts[sub].mean(0) + 0.5) for sub in subsets])
+    dist = np.abs(colors[seen].astype(np.float64)[:, None, :] - means[None]).max(2).min(1)
+    assert dist.max() <= 1                                      # float rounding of the mean may differ by one level
+    assert len(np.unique(colors[seen], axis=0)) >= 3            # several visibility patterns occur

@@ -225,3 +225,31 @@ def test_spatial_sort_matches_oracle_and_changes_no_result(scene, synced):
     pos_plain, pos_sorted = plain[:3].view(np.float32), sorted_[:3].view(np.float32)
     step = lambda p: np.linalg.norm(np.diff(p, axis=1), axis=0).mean()
     assert step(pos_sorted) < 0.8 * step(pos_plain)
+
+
+@pytest.mark.xfail(strict=False, reason="DirectBA::AssignColors was added after round 1's GPU budget was spent: the kernel "
+                   "compiles for gfx950 and the oracle side is tested on the CPU (tests/test_cpu_oracle_units.py), but this "
+                   "comparison has not run on an MI355X yet; the marker goes once it has")
+def test_assign_colors_matches_oracle():
+    """DirectBA::AssignColors (B/kernel_assign_colors.cu:41-125): mean bilinear RGBA observation per surfel over all
+    keyframes it is associated with, bit for bit against the oracle (own scene objects: the colour row is rewritten)."""
+    scene = common.small_scene(num_keyframes=4, width=320, height=240, seed=12)
+    ba = common.build_oracle(scene, 200000)
+    g = common.build_gpu(scene, 200000, create_from=[])
+    data, active = common.oracle_surfels(ba)
+    n = data.shape[1]
+    rng = np.random.Generator(np.random.PCG64(13))
+    data[5] = rng.integers(0, 2 ** 32, n, dtype=np.uint32).view(np.float32)      # arbitrary colours to start from
+    data[0, :50] += 100.0                                                          # 50 surfels no keyframe sees
+    ba.surfel_data[:, :n] = data
+    g.upload_surfels(data, active)
+    g.bind_keyframes()
+    g.assign_colors()
+    ba.assign_colors()
+    got = g.download_surfels()
+    ref = ba.surfel_data[:, :n]
+    assert np.array_equal(got[5].view(np.uint32), ref[5].view(np.uint32))
+    assert np.array_equal(got[5, :50].view(np.uint32), data[5, :50].view(np.uint32))             # unseen: untouched
+    assert (got[5, 50:].view(np.uint32) != data[5, 50:].view(np.uint32)).mean() > 0.95           # seen: reassigned
+    for row in (0, 1, 2, 3, 4, 6, 7):                                                              # nothing else written
+        assert np.array_equal(got[row].view(np.uint32), data[row].view(np.uint32))
