@@ -227,9 +227,6 @@ def test_spatial_sort_matches_oracle_and_changes_no_result(scene, synced):
     assert step(pos_sorted) < 0.8 * step(pos_plain)
 
 
-@pytest.mark.xfail(strict=False, reason="DirectBA::AssignColors was added after round 1's GPU budget was spent: the kernel "
-                   "compiles for gfx950 and the oracle side is tested on the CPU (tests/test_cpu_oracle_units.py), but this "
-                   "comparison has not run on an MI355X yet; the marker goes once it has")
 def test_assign_colors_matches_oracle():
     """DirectBA::AssignColors (B/kernel_assign_colors.cu:41-125): mean bilinear RGBA observation per surfel over all
     keyframes it is associated with, bit for bit against the oracle (own scene objects: the colour row is rewritten)."""
