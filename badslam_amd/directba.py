@@ -56,6 +56,10 @@ def _load():
         L.dba_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.dba_backend_context.restype = C.c_void_p
         L.dba_backend_context.argtypes = [C.c_void_p]
+        L.dba_keyframe_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(capi.Frame)]
+        L.dba_surfels_struct.argtypes = [C.c_void_p, C.POINTER(capi.Surfels)]
+        L.dba_bind_scene.argtypes = [C.c_void_p, C.c_void_p]
+        L.dba_keyframe_covisibility.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         _lib = L
     return _lib
 
@@ -101,6 +105,27 @@ class DirectBA:
 
     def backend_context(self):
         return _BackendContext(self.L.dba_backend_context(self.h))
+
+    # borrowed views for driving single bahip_* stages on this scene (stage-level parity tests)
+    def keyframe_frame(self, k):
+        f = capi.Frame()
+        assert self.L.dba_keyframe_frame(self.h, int(k), C.byref(f)) == 0
+        return f
+
+    def surfels_struct(self):
+        s = capi.Surfels()
+        assert self.L.dba_surfels_struct(self.h, C.byref(s)) == 0
+        return s
+
+    def keyframe_covisibility(self, k):
+        cap = max(1, self.keyframe_count())
+        out = (C.c_int * cap)()
+        n = self.L.dba_keyframe_covisibility(self.h, int(k), out, cap)
+        assert 0 <= n <= cap
+        return [int(out[i]) for i in range(n)]
+
+    def BindScene(self):
+        assert self.L.dba_bind_scene(self.h, self.stream) == 0
 
     # -- keyframes --
     def AddKeyframe(self, depth_u16, rgb_u8, global_T_frame):

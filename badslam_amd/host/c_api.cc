@@ -191,5 +191,27 @@ int dba_last_stats(dba_handle* h, int* pose_rounds, int* pose_steps, int* pcg_in
   return 0;
 }
 bahip_context* dba_backend_context(dba_handle* h) { return h->ba->backend_context(); }
+int dba_keyframe_frame(dba_handle* h, int id, bahip_frame* out) {
+  Keyframe* kf = get_kf(h, id);
+  if (!kf || !out) return 1;
+  *out = kf->ToBahipFrame();
+  return 0;
+}
+int dba_surfels_struct(dba_handle* h, bahip_surfels* out) {
+  if (!out) return 1;
+  *out = h->ba->SurfelsStruct(true);
+  return 0;
+}
+int dba_keyframe_covisibility(dba_handle* h, int id, int* out, int capacity) {
+  Keyframe* kf = get_kf(h, id);
+  if (!kf) return -1;
+  const auto& list = kf->co_visibility_list();
+  for (int i = 0; i < (int)list.size() && i < capacity; ++i) out[i] = list[i];
+  return (int)list.size();
+}
+int dba_bind_scene(dba_handle* h, void* stream) {
+  h->ba->BindScene(static_cast<hipStream_t>(stream));
+  return 0;
+}
 
 }  // extern "C"

@@ -6,8 +6,8 @@
 // kernel launches.  Differences forced by the platform:
 //   - cudaStream_t -> hipStream_t (opaque), cudaTextureObject_t -> hipTextureHandle_t (gfx950 has
 //     no texture sampling; the handle names the colour buffer),
-//   - render window / OpenGL interop, loop-detector hooks and AssignColors are not part of the BA
-//     path (OUT) and are omitted,
+//   - render window / OpenGL interop and loop-detector hooks are not part of the BA path
+//     (OUT) and are omitted,
 //   - SetRunParallel is declared but never defined in the reference (B/direct_ba.h:172): omitted.
 #pragma once
 
@@ -120,6 +120,11 @@ class DirectBA {
   // (see include/badslam_hip.h, bahip_allreduce_fn).
   void SetAllReduce(bahip_allreduce_fn fn, void* user) { BAHIP_CHECKED_CALL(bahip_context_set_allreduce(ctx_, fn, user)); }
   bahip_context* backend_context() { return ctx_; }
+  // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
+  // keyframe ids and the dense bound list.  Public so that a caller can drive single bahip_* stages
+  // on this scene (the stage-level parity tests do).
+  void BindScene(hipStream_t stream);
+  bahip_surfels SurfelsStruct(bool with_active = true) const;
   // Statistics of the last BundleAdjustment() call: Gauss-Newton rounds (batched over keyframes)
   // and total per-keyframe GN steps, PCG inner steps.
   int last_pose_rounds() const { return last_pose_rounds_; }
@@ -141,10 +146,6 @@ class DirectBA {
   void DetermineNewKeyframeCoVisibility(const shared_ptr<Keyframe>& new_keyframe);
   void PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates);
 
-  // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
-  // keyframe ids and the dense bound list.
-  void BindScene(hipStream_t stream);
-  bahip_surfels SurfelsStruct(bool with_active = true) const;
   void MergeForKeyframe(const Keyframe& keyframe);
 
   PinholeCamera4f color_camera_;

@@ -168,6 +168,34 @@ class Scene:
         self.surfel_count += n.value
         return n.value
 
+    def determine_supporting_surfels(self, i, frame_T_global, merge=False, merge_dist_factor=0.8):
+        """DetermineSupportingSurfels[AndMergeSurfels]CUDA for keyframe i; returns (the three supporting planes restricted to
+        the sparse-cell grid, number of surfels deleted by merging)."""
+        F = (C.c_float * 12)(*[float(v) for v in frame_T_global])
+        merged = C.c_uint32()
+        fr, s = self.frame_struct(i), self.surfels_struct()
+        capi.check(self.lib.bahip_determine_supporting_surfels(self.ctx.handle, int(merge), float(merge_dist_factor), C.byref(fr), F,
+                                                               C.byref(s), self._supporting_ptrs(), self.supporting[0].pitch,
+                                                               C.byref(merged)))
+        self.ctx.synchronize()
+        self.surfel_count -= merged.value
+        planes = np.stack([b.download()[:self.cf_h, :self.cf_w] for b in self.supporting])
+        return planes, merged.value
+
+    def delete_surfels_and_update_radii(self, min_observation_count):
+        deleted = C.c_uint32()
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_delete_surfels_and_update_radii(self.ctx.handle, int(min_observation_count), C.byref(s), C.byref(deleted)))
+        self.surfel_count -= deleted.value
+        return deleted.value
+
+    def compact_surfels(self, with_active=True):
+        s = self.surfels_struct()
+        if not with_active:
+            s.active = None
+        capi.check(self.lib.bahip_compact_surfels(self.ctx.handle, self.surfel_count, C.byref(s)))
+        self.surfels_size = self.surfel_count
+
     def download_surfels(self):
         self.ctx.synchronize()
         return self.surfel_buf.download()[:, :self.surfels_size]

@@ -72,6 +72,14 @@ int dba_set_ba_iteration_counts(dba_handle* h, int ba_iteration_count, int last_
 int dba_last_stats(dba_handle* h, int* pose_rounds, int* pose_steps, int* pcg_inner_steps);
 /* backend context of this DirectBA (for bahip_context_set_allreduce, bahip_set_profiling, ...) */
 bahip_context* dba_backend_context(dba_handle* h);
+/* Borrowed views for callers that drive individual bahip_* stages on a DirectBA-owned scene (the stage-level parity
+ * tests): the images (and BA planes) of one keyframe, the surfel buffer, and DirectBA::BindScene (cameras, depth
+ * parameters and the keyframe list as the backend sees them; bound index = position among the non-deleted keyframes). */
+int dba_keyframe_frame(dba_handle* h, int keyframe_id, bahip_frame* out);
+int dba_surfels_struct(dba_handle* h, bahip_surfels* out);
+int dba_bind_scene(dba_handle* h, void* hip_stream);
+/* Keyframe::co_visibility_list() (keyframe ids); returns the list length (entries beyond `capacity` are not written), -1 for a bad id. */
+int dba_keyframe_covisibility(dba_handle* h, int keyframe_id, int* out, int capacity);
 
 #ifdef __cplusplus
 }

@@ -229,6 +229,28 @@ class OracleBA:
         self._kf_arrays.append(arrs)
         return kf
 
+    def add_preprocessed_keyframe(self, depth, normals, radius, color_rgba, global_T_frame, min_depth=0.0, max_depth=0.0):
+        """A keyframe from already preprocessed images (what Keyframe ctor #1, B/keyframe.cc:35-79, takes): used to hand the
+        oracle the very images the HIP path works on (preprocessing parity has its own tests)."""
+        W, H = self.depth_cam.width, self.depth_cam.height
+        arrs = dict(depth=np.ascontiguousarray(depth, np.uint16).reshape(H, W), normals=np.ascontiguousarray(normals, np.uint16).reshape(H, W),
+                    radius=np.ascontiguousarray(radius, np.uint16).reshape(H, W),
+                    color=np.ascontiguousarray(color_rgba, np.uint8).reshape(self.color_cam.height, self.color_cam.width, 4))
+        kf = Keyframe()
+        kf.width, kf.height = W, H
+        kf.color_width, kf.color_height = self.color_cam.width, self.color_cam.height
+        kf.depth, kf.normals = _ptr(arrs["depth"], C.c_uint16), _ptr(arrs["normals"], C.c_uint16)
+        kf.radius, kf.color = _ptr(arrs["radius"], C.c_uint16), _ptr(arrs["color"], C.c_uint8)
+        kf.activation = KF_ACTIVE
+        kf.min_depth, kf.max_depth = float(min_depth), float(max_depth)
+        kf.last_active_in_ba_iteration = kf.last_covis_in_ba_iteration = -1
+        T = global_T_frame if isinstance(global_T_frame, SE3) else SE3.from_array(global_T_frame)
+        self.L.orc_keyframe_set_global_T_frame(C.byref(kf), C.byref(T))
+        kf.id = len(self.keyframes)
+        self.keyframes.append(kf)
+        self._kf_arrays.append(arrs)
+        return kf
+
     def kf_arrays(self, i):
         return self._kf_arrays[i]
 
@@ -264,6 +286,27 @@ class OracleBA:
             C.byref(self.dp), C.byref(self.keyframes[i]), kfs, cv, len(covis), C.byref(self.surfels),
             _ptr(self.supporting, C.c_uint32)))
 
+    def determine_supporting_surfels(self, i, merge=False):
+        """orc_determine_supporting_surfels for keyframe i at its current pose; returns the three planes restricted to the
+        sparse-cell grid.  With merge=True surfels are deleted (NaN x) and surfel_count drops."""
+        self.L.orc_determine_supporting_surfels.restype = None
+        self.L.orc_determine_supporting_surfels(int(merge), C.c_float(self.merge_factor), C.byref(self.depth_cam), C.byref(self.dp),
+                                                C.byref(self.keyframes[i]), C.byref(self.surfels), _ptr(self.supporting, C.c_uint32))
+        W, H = self.depth_cam.width, self.depth_cam.height
+        return self.supporting.reshape(3, H, W)[:, :self.cf_h, :self.cf_w].copy()
+
+    def delete_surfels_and_update_radii(self, min_observation_count=None):
+        self.L.orc_delete_surfels_and_update_radii.restype = None
+        before = int(self.surfels.surfel_count)
+        self.L.orc_delete_surfels_and_update_radii(int(self.min_observation_count if min_observation_count is None else min_observation_count),
+                                                   C.byref(self.depth_cam), C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),
+                                                   C.byref(self.surfels))
+        return before - int(self.surfels.surfel_count)
+
+    def compact_surfels(self):
+        self.L.orc_compact_surfels.restype = None
+        self.L.orc_compact_surfels(C.byref(self.surfels))
+
     # -- pose --
     def accumulate_pose_coeffs(self, i, frame_T_global=None, accumulate_double=False):
         kf = self.keyframes[i]
@@ -292,6 +335,25 @@ class OracleBA:
         ok = self.L.orc_evaluate_pair(C.byref(self.color_cam), C.byref(self.depth_cam), C.byref(self.dp), C.byref(kf), F,
                                       C.byref(self.surfels), C.c_uint32(surfel_index), C.byref(out))
         return bool(ok), out
+
+    # word offsets of orc_pair_eval (37 four-byte words, no padding)
+    PAIR_WORDS = 37
+    PAIR_FIELDS = dict(associated=(0, 1), px=(1, 1), py=(2, 1), color_valid=(3, 1), calibrated_depth=(4, 1), depth_residual=(5, 1),
+                       depth_weight=(6, 1), depth_inv_stddev=(7, 1), depth_jac_pose=(8, 6), depth_jac_surfel=(14, 1),
+                       desc_residual=(15, 2), desc_weight=(17, 2), desc_jac_pose=(19, 12), desc_jac_surfel=(31, 2), grad=(33, 4))
+
+    def evaluate_pairs(self, i, surfel_indices, frame_T_global=None):
+        """orc_evaluate_pair for many surfel indices against keyframe i; returns a (count, 37) uint32 array of raw
+        orc_pair_eval words (view as float32 where the field is a float; PAIR_FIELDS gives (offset, length))."""
+        assert C.sizeof(PairEval) == 4 * self.PAIR_WORDS
+        kf = self.keyframes[i]
+        F = (C.c_float * 12)(*(list(kf.frame_T_global) if frame_T_global is None else [float(v) for v in frame_T_global]))
+        idx = np.ascontiguousarray(surfel_indices, dtype=np.uint32)
+        out = np.zeros((len(idx), self.PAIR_WORDS), np.uint32)
+        self.L.orc_evaluate_pairs.restype = None
+        self.L.orc_evaluate_pairs(C.byref(self.color_cam), C.byref(self.depth_cam), C.byref(self.dp), C.byref(kf), F,
+                                  C.byref(self.surfels), _ptr(idx, C.c_uint32), C.c_int(len(idx)), out.ctypes.data_as(C.c_void_p))
+        return out
 
     # -- geometry / activation --
     def update_surfel_activation(self):

@@ -172,6 +172,9 @@ typedef struct {
 int orc_evaluate_pair(const orc_camera* color_cam, const orc_camera* depth_cam, const orc_depth_params* dp,
                       const orc_keyframe* kf, const float frame_T_global[12],
                       const orc_surfels* s, uint32_t surfel_index, orc_pair_eval* out);
+void orc_evaluate_pairs(const orc_camera* color_cam, const orc_camera* depth_cam, const orc_depth_params* dp,
+                        const orc_keyframe* kf, const float frame_T_global[12], const orc_surfels* s,
+                        const uint32_t* surfel_indices, int count, orc_pair_eval* out);
 
 /* ---- pose optimisation ---- */
 /* B/kernel_opt_pose.cc:39-97 + B/kernel_opt_pose.cu:251-383 + B/gauss_newton.cuh:46-93.

@@ -122,13 +122,24 @@ void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* o
     /* --- poses --- */
     int num_converged = 0;
     if (opt->optimize_poses) {
+      /* Every keyframe is estimated against the same (frozen) surfels, so the estimates are independent: they are
+       * computed in parallel (one thread per keyframe, each summing in surfel order as before) and applied in
+       * keyframe order. */
       int max_steps = 0;
+      orc_se3* ests = (orc_se3*)malloc(sizeof(orc_se3) * (st->num_kfs ? st->num_kfs : 1));
+      int* steps_of = (int*)calloc(st->num_kfs ? st->num_kfs : 1, sizeof(int));
+#pragma omp parallel for schedule(dynamic, 1)
+      for (int k = 0; k < st->num_kfs; ++k) {
+        orc_keyframe* kf = st->kfs[k];
+        if (!kf || kf->activation == ORC_KF_INACTIVE) continue;
+        steps_of[k] = orc_estimate_frame_pose(use_depth, use_desc, &st->color_cam, &st->depth_cam, &st->dp, kf,
+                                              &kf->global_T_frame, s, &ests[k], NULL);
+      }
       for (int k = 0; k < st->num_kfs; ++k) {
         orc_keyframe* kf = st->kfs[k];
         if (!kf || kf->activation == ORC_KF_INACTIVE) { ++num_converged; continue; }
-        orc_se3 est;
-        const int steps = orc_estimate_frame_pose(use_depth, use_desc, &st->color_cam, &st->depth_cam, &st->dp, kf,
-                                                  &kf->global_T_frame, s, &est, NULL);
+        const orc_se3 est = ests[k];
+        const int steps = steps_of[k];
         stats->pose_gn_steps_total += steps;
         if (steps > max_steps) max_steps = steps;
         /* pose_difference = frame_T_global(old) * global_T_frame(new) */
@@ -142,6 +153,7 @@ void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* o
         if (frame_moved) kf->activation = ORC_KF_ACTIVE;
         else { kf->activation = ORC_KF_INACTIVE; ++num_converged; }
       }
+      free(ests); free(steps_of);
       stats->pose_gn_rounds_max_sum += max_steps;
     }
 

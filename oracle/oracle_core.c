@@ -478,3 +478,15 @@ int orc_evaluate_pair(const orc_camera* color_cam, const orc_camera* depth_cam, 
   }
   return 1;
 }
+
+/* orc_evaluate_pair for `count` surfel indices against one keyframe (OpenMP over the pairs); used by the sampled
+ * per-pair parity test at full size. */
+void orc_evaluate_pairs(const orc_camera* color_cam, const orc_camera* depth_cam, const orc_depth_params* dp,
+                        const orc_keyframe* kf, const float F[12], const orc_surfels* s, const uint32_t* indices,
+                        int count, orc_pair_eval* out) {
+#pragma omp parallel for schedule(static)
+  for (int t = 0; t < count; ++t) {
+    if (indices[t] >= s->surfels_size) { memset(&out[t], 0, sizeof(out[t])); continue; }
+    orc_evaluate_pair(color_cam, depth_cam, dp, kf, F, s, indices[t], &out[t]);
+  }
+}

@@ -142,6 +142,15 @@ uint32_t orc_create_surfels_for_keyframe(int filter_new_surfels, int min_observa
   }
   if (filter_new_surfels) {
     const unprojector unp = make_unprojector(depth_cam);
+    /* covis_T_frame = covis.frame_T_global * kf.global_T_frame (B/direct_ba.cc:359-365); one per co-visible keyframe */
+    float* rel_M = (float*)malloc(sizeof(float) * 12 * (n_covis ? n_covis : 1));
+    for (int c = 0; c < n_covis; ++c) {
+      orc_se3 cinv, rel;
+      orc_se3_inverse(&kfs[covis[c]]->global_T_frame, &cinv);
+      orc_se3_mul(&cinv, &kf->global_T_frame, &rel);
+      orc_se3_matrix3x4(&rel, rel_M + 12 * c);
+    }
+#pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < H; ++y) {
       for (int x = 0; x < W; ++x) {
         const size_t idx = (size_t)y * W + x;
@@ -153,12 +162,7 @@ uint32_t orc_create_surfels_for_keyframe(int filter_new_surfels, int min_observa
         orc_unpack_normal8(kf->normals[idx], m);
         for (int c = 0; c < n_covis; ++c) {
           const orc_keyframe* ck = kfs[covis[c]];
-          /* covis_T_frame = covis.frame_T_global * kf.global_T_frame (B/direct_ba.cc:359-365) */
-          orc_se3 cinv, rel;
-          orc_se3_inverse(&ck->global_T_frame, &cinv);
-          orc_se3_mul(&cinv, &kf->global_T_frame, &rel);
-          float M[12];
-          orc_se3_matrix3x4(&rel, M);
+          const float* M = rel_M + 12 * c;
           v3 lp;
           lp.z = M[8] * input_pos.x + M[9] * input_pos.y + M[10] * input_pos.z + M[11];
           if (!(lp.z > 0.f)) continue;
@@ -175,6 +179,7 @@ uint32_t orc_create_surfels_for_keyframe(int filter_new_surfels, int min_observa
         if (observations < (uint32_t)min_observation_count || violations > observations) flag[idx] = 0;
       }
     }
+    free(rel_M);
   }
   uint32_t count = 0;
   for (size_t i = 0; i < (size_t)W * H; ++i) count += flag[i];
@@ -208,6 +213,7 @@ void orc_delete_surfels_and_update_radii(int min_observation_count, const orc_ca
   float* a0 = srow(s, ORC_SURFEL_ACCUM0 + 0); float* a1 = srow(s, ORC_SURFEL_ACCUM0 + 1);
   float* a2 = srow(s, ORC_SURFEL_ACCUM0 + 2);
   uint32_t deleted = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : deleted)
   for (uint32_t i = 0; i < s->surfels_size; ++i) {
     a0[i] = 0; a1[i] = 0; a2[i] = INFINITY;
     for (int k = 0; k < num_kfs; ++k) {

@@ -101,10 +101,13 @@ def test_bundle_adjustment_with_surfel_updates(scene):
     for k, T in enumerate(perturbed):
         orc.set_pose(k, T)
         ba.set_keyframe_pose(k, T)
+    orc.covis = [ba.keyframe_covisibility(k) for k in range(len(perturbed))]     # the host's frustum-based lists
     for call in range(2):
         done, _ = ba.BundleAdjustment(do_surfel_updates=True, min_iterations=2, max_iterations=2, increase_ba_iteration_count=True)
         orc.bundle_adjustment(do_surfel_updates=True, min_iterations=2, max_iterations=2, increase_ba_iteration_count=True)
-        assert abs(ba.surfel_count() - orc.surfels_size) <= 2e-3 * max(1, orc.surfels_size), (call, ba.surfel_count(), orc.surfels_size)
+        # every lifecycle stage is bit-exact against the oracle (test_gpu_lifecycle_stages.py) and the geometry step is
+        # too, so the same surfels survive: exact counts
+        assert ba.surfel_count() == orc.surfels_size, (call, ba.surfel_count(), orc.surfels_size)
     assert orc.surfels_size > 10000
     K = len(perturbed)
     got_poses = [ba.keyframe_pose(k) for k in range(K)]

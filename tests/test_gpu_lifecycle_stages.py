@@ -1,0 +1,144 @@
+"""Stage-level parity of the surfel lifecycle ("next round" item 2): every C-ABI entry point of
+B/kernel_supporting_surfels.cu:45, B/kernel_create_surfels.cu:213-356, B/kernel_delete_surfels.cu:84-133 and
+B/kernel_compact_surfels.cu:101-279 against the oracle's restatement of the same function, bit for bit -- not only the
+survivor counts of a whole BundleAdjustment call."""
+import numpy as np
+import pytest
+
+from badslam_amd import synthetic
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+NAN_BITS = 0x7fffffff     # deleted-surfel marker, B/kernel_delete_surfels.cu:145
+
+
+@pytest.fixture()
+def world():
+    """Four keyframes; surfels created (unfiltered) from the first three on both sides."""
+    scene = common.small_scene(num_keyframes=4, seed=23)
+    orc = common.build_oracle(scene, 500000, create_from=[0, 1, 2])
+    g = common.build_gpu(scene, 500000, create_from=[0, 1, 2])
+    ref, _ = common.oracle_surfels(orc)
+    assert np.array_equal(g.download_surfels()[:8].view(np.uint32), ref[:8].view(np.uint32))
+    return scene, orc, g
+
+
+def _sync(orc, g, data, count=None):
+    n = data.shape[1]
+    orc.surfel_data[:, :n] = data
+    orc.surfels.surfels_size = n
+    orc.surfels.surfel_count = n if count is None else count
+    g.upload_surfels(data, np.zeros(n, np.uint8))
+    g.surfel_count = n if count is None else count
+
+
+def _rows(a):
+    return np.ascontiguousarray(a[:8]).view(np.uint32)
+
+
+def test_supporting_surfels_lists_bit_exact(world):
+    scene, orc, g = world
+    for k in (3, 0):        # a keyframe that created no surfels yet, and one that did
+        F = np.array(list(orc.keyframes[k].frame_T_global), np.float32)
+        planes, merged = g.determine_supporting_surfels(k, F, merge=False)
+        ref = orc.determine_supporting_surfels(k, merge=False)
+        assert merged == 0
+        assert np.array_equal(planes, ref), k
+        filled = (ref != 0xffffffff).sum(axis=(1, 2))
+        assert filled[0] > 5000 and filled[1] > 100, filled           # second slots are in use: cells seen by several surfels
+
+
+def test_merge_bit_exact(world):
+    scene, orc, g = world
+    data, _ = common.oracle_surfels(orc)
+    n = data.shape[1]
+    # near-duplicates of a third of the cloud (1 mm away, same normal): candidates for merging, appended after the originals
+    rng = np.random.Generator(np.random.PCG64(3))
+    pick = np.sort(rng.choice(n, n // 3, replace=False))
+    dup = data[:, pick].copy()
+    dup[:3] += rng.normal(0, 0.001, (3, len(pick))).astype(np.float32)
+    both = np.concatenate([data, dup], axis=1)
+    _sync(orc, g, both)
+    total_merged = 0
+    for k in (0, 1, 3):
+        F = np.array(list(orc.keyframes[k].frame_T_global), np.float32)
+        before = int(orc.surfels.surfel_count)
+        planes, merged = g.determine_supporting_surfels(k, F, merge=True, merge_dist_factor=orc.merge_factor)
+        ref = orc.determine_supporting_surfels(k, merge=True)
+        assert merged == before - int(orc.surfels.surfel_count), k
+        assert np.array_equal(planes, ref), k
+        got = g.surfel_buf.download()[:, :both.shape[1]]
+        assert np.array_equal(_rows(got), _rows(orc.surfel_data[:, :both.shape[1]])), k     # the same surfels carry the NaN marker
+        total_merged += merged
+    assert total_merged > 1000, total_merged
+    assert g.surfel_count == int(orc.surfels.surfel_count)
+    # compaction after merging (what the BA loop does next, B/direct_ba_alternating.cc:505-520), with the active flags
+    act = (np.arange(both.shape[1]) % 3 == 0).astype(np.uint8)
+    orc.active[:both.shape[1]] = act
+    a = np.zeros((1, g.capacity), np.uint8); a[0, :both.shape[1]] = act
+    g.active_buf.upload(a)
+    g.compact_surfels(with_active=True)
+    orc.compact_surfels()
+    m = orc.surfels_size
+    assert g.surfels_size == m == both.shape[1] - total_merged
+    assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :m]))
+    assert np.array_equal(g.active_buf.download()[0, :m], orc.active[:m])
+    assert not np.any(_rows(orc.surfel_data[:, :m])[0] == NAN_BITS)
+
+
+@pytest.mark.parametrize("min_obs", [1, 2, 3])
+def test_filtered_creation_bit_exact(min_obs):
+    """CreateSurfelsForKeyframe with filter_new_surfels: observation / free-space-violation counting over the co-visible
+    keyframes (B/kernel_create_surfels.cu:213-356), for complete and partial co-visibility lists."""
+    scene = common.small_scene(num_keyframes=5, seed=29)
+    rng = np.random.Generator(np.random.PCG64(7))
+    # slightly wrong poses for two keyframes: some new surfels then violate free space in the others and are filtered
+    poses = [T if k in (0, 2, 4) else synthetic.perturb_pose(rng, T, 0.03, 0.01) for k, T in enumerate(scene.poses_gt)]
+    orc = common.build_oracle(scene, 600000, poses=poses, create_from=[], min_observation_count=min_obs)
+    g = common.build_gpu(scene, 600000, poses=poses, create_from=[])
+    plan = [(0, [1, 2, 3, 4]), (1, [0, 2]), (2, [4]), (3, [0, 1, 2, 4]), (4, [])]
+    created = []
+    for k, covis in plan:
+        n_ref = orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis)
+        n_got = g.create_surfels_for_keyframe(k, filter_new_surfels=True, min_observation_count=min_obs, covis=covis)
+        assert n_got == n_ref, (k, n_got, n_ref)
+        created.append(n_ref)
+        assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :orc.surfels_size])), k
+    unfiltered = common.build_oracle(scene, 600000, poses=poses, create_from=[0]).surfels_size
+    if min_obs >= 2:
+        assert 0 < created[0] < unfiltered            # the filter removed something and kept something
+        assert created[4] == 0                        # no co-visible keyframe: a single observation is not enough
+    else:
+        assert sum(created) > 10000
+
+
+def test_delete_and_update_radii_then_compact_bit_exact(world):
+    scene, orc, g = world
+    data, _ = common.oracle_surfels(orc)
+    n = data.shape[1]
+    rng = np.random.Generator(np.random.PCG64(5))
+    data = data.copy()
+    far = rng.choice(n, n // 10, replace=False)
+    data[2, far] += 0.6                                   # behind the surface: unobserved or free-space violating -> deleted
+    near = rng.choice(n, n // 10, replace=False)
+    data[2, near] -= 0.5                                  # in front of the surface: free-space violations in other keyframes
+    data[4] *= 4.0                                        # inflated radii: the update takes the smallest observed radius
+    for min_obs in (1, 2):
+        _sync(orc, g, data)
+        g.bind_keyframes()
+        deleted = g.delete_surfels_and_update_radii(min_obs)
+        ref_deleted = orc.delete_surfels_and_update_radii(min_obs)
+        assert deleted == ref_deleted, (min_obs, deleted, ref_deleted)
+        assert n // 20 < deleted < n // 2, deleted
+        got = g.surfel_buf.download()[:, :n]
+        assert np.array_equal(_rows(got), _rows(orc.surfel_data[:, :n])), min_obs
+        assert np.count_nonzero(got[4] != data[4]) > n // 2                   # radii were updated
+        g.compact_surfels(with_active=False)                                  # B/direct_ba.cc:619: no active-flag buffer here
+        active = orc.surfels.active
+        orc.surfels.active = None
+        orc.compact_surfels()
+        orc.surfels.active = active
+        m = orc.surfels_size
+        assert g.surfels_size == m == n - deleted
+        assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :m]))

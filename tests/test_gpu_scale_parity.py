@@ -1,0 +1,308 @@
+"""Oracle parity at the scale of BASELINE.json's configs ("next round" item 1).
+
+(a) K = 200 keyframes (160x120): the first place where the wave-level keyframe culling (wave_cull.h: for_each_candidate)
+    walks several 64-keyframe chunks and splits them over `parts` wavefronts against a checker: creation, activation
+    flags and the geometry step bit for bit (both launch shapes), batched pose estimation with pose_parts 1 / 2 / 8.
+(b) One full iteration of BASELINE configs[2] (200 keyframes x 3 M surfels x 640x480, bench.build_scene) through the
+    oracle's BundleAdjustment restatement and through vis::DirectBA: surfels bit for bit, poses <= 1e-5 m RMSE.
+(c) Sampled per-pair parity at that size: bahip_debug_evaluate_pairs vs orc_evaluate_pairs on 10^6 random
+    (surfel, keyframe) pairs -- association decision, pixel, calibrated depth, the three residuals, weights, pose
+    Jacobians and image gradients, every bit.
+(d) BASELINE configs[1]'s size (50 keyframes, ~500 k surfels, 640x480; synthetic stand-in for TUM fr1/desk) end to end:
+    alternating BA with the surfel lifecycle inside the loop (filtered creation with the host's co-visibility lists,
+    merge, delete + radii, compaction) against the oracle.
+The oracle gets the very images the HIP path works on (downloaded preprocessed keyframes); preprocessing parity has its
+own tests (test_gpu_kernels_vs_oracle.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from badslam_amd import capi, synthetic
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _shapes(lib, tile_waves, pose_parts):
+    capi.check(lib.bahip_debug_set_launch_shapes(tile_waves, pose_parts))
+
+
+# ---- (a) many keyframes ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def many():
+    scene = synthetic.make_scene(200, 160, 120, seed=21, cell=2, translation_range=5.0, rotation_range=0.9)
+    orc = common.build_oracle(scene, 900000)
+    g = common.build_gpu(scene, 900000)           # the GPU creates its own surfels from all 200 keyframes
+    return scene, orc, g
+
+
+def test_many_keyframes_creation_bit_exact(many):
+    scene, orc, g = many
+    ref, _ = common.oracle_surfels(orc)
+    got = g.download_surfels()
+    assert got.shape[1] == ref.shape[1] > 100000, (got.shape, ref.shape)
+    assert np.array_equal(got[:8].view(np.uint32), ref[:8].view(np.uint32))
+
+
+def _set_activations(orc, g, pattern):
+    for k in range(len(orc.keyframes)):
+        orc.keyframes[k].activation = int(pattern[k])
+        g.keyframes[k]["activation"] = int(pattern[k])
+
+
+@pytest.mark.parametrize("tile_waves", [1, 4])
+def test_many_keyframes_activation_and_geometry_bit_exact(many, tile_waves, request):
+    scene, orc, g = many
+    K = len(orc.keyframes)
+    _shapes(g.ctx.lib, tile_waves, 0)
+    request.addfinalizer(lambda: _shapes(g.ctx.lib, 0, 0))
+    orc.use_depth, orc.use_desc = 1, 1
+    data, active = common.oracle_surfels(orc)
+    n = data.shape[1]
+    rng = np.random.Generator(np.random.PCG64(31))
+    moved = data.copy()
+    moved[2] += rng.uniform(0, 0.004, n).astype(np.float32)
+    moved[6] += 2.0
+    # a third of the keyframes active, a third co-visible active, a third inactive: activation looks at the active ones
+    # only, the geometry passes skip the inactive ones (predicates of wave_cull.h candidates differ per pass)
+    _set_activations(orc, g, np.arange(K) % 3)
+    try:
+        orc.surfel_data[:, :n] = moved
+        g.upload_surfels(moved, active * 0)
+        g.bind_keyframes()
+        g.update_surfel_activation()
+        orc.update_surfel_activation()
+        act = g.active_buf.download()[0, :n]
+        assert np.array_equal(act, orc.active[:n])
+        assert 0.3 * n < act.sum() < n                 # some surfels are seen by no active keyframe
+        g.optimize_geometry_iteration(True, True)
+        orc.optimize_geometry_iteration()
+        got = g.download_surfels()
+        ref = orc.surfel_data[:, :n]
+        assert np.array_equal(got[:8].view(np.uint32), ref[:8].view(np.uint32))
+        assert np.abs(ref[2] - moved[2])[act == 1].mean() > 1e-4
+    finally:
+        _set_activations(orc, g, np.zeros(K, int))
+        orc.surfel_data[:, :n] = data
+
+
+_ORACLE_POSES = {}
+
+
+def _oracle_pose_estimates(orc, perturbed, pattern):
+    """orc_estimate_frame_pose of every non-inactive keyframe (independent of each other; ctypes releases the GIL)."""
+    if not _ORACLE_POSES:
+        from concurrent.futures import ThreadPoolExecutor
+        ks = [k for k in range(len(perturbed)) if pattern[k] != capi.KF_INACTIVE]
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as pool:
+            for k, res in zip(ks, pool.map(lambda k: orc.estimate_frame_pose(k, perturbed[k]), ks)):
+                _ORACLE_POSES[k] = res
+    return _ORACLE_POSES
+
+
+@pytest.mark.parametrize("pose_parts", [1, 2, 8])
+def test_many_keyframes_batched_pose_estimation(many, pose_parts, request):
+    scene, orc, g = many
+    K = len(orc.keyframes)
+    _shapes(g.ctx.lib, 0, pose_parts)
+    request.addfinalizer(lambda: _shapes(g.ctx.lib, 0, 0))
+    orc.use_depth, orc.use_desc = 1, 1
+    data, active = common.oracle_surfels(orc)
+    g.upload_surfels(data, active)
+    rng = np.random.Generator(np.random.PCG64(41))
+    perturbed = [synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    pattern = np.where(np.arange(K) % 7 == 3, capi.KF_INACTIVE, np.arange(K) % 2)     # inactive keyframes are skipped
+    _set_activations(orc, g, pattern)
+    try:
+        for k, T in enumerate(perturbed):
+            orc.set_pose(k, T)
+            g.keyframes[k]["pose"] = np.asarray(T, np.float32)
+        g.bind_keyframes()
+        poses, its, conv, rounds = g.estimate_keyframe_poses(True, True)
+        reference = _oracle_pose_estimates(orc, perturbed, pattern)
+        mismatched_steps = 0
+        for k in range(K):
+            if pattern[k] == capi.KF_INACTIVE:
+                assert its[k] == 0
+                assert np.array_equal(poses[k].astype(np.float32), np.asarray(perturbed[k], np.float32))
+                continue
+            est, its_ref, conv_ref = reference[k]
+            if its[k] != its_ref:          # a convergence test decided differently at its threshold (summation order)
+                mismatched_steps += 1
+                continue
+            err = common.pose_error(est.to_array(), poses[k])
+            assert np.abs(err).max() < 2e-6, (k, err)
+            assert conv[k] == int(conv_ref)
+        assert mismatched_steps <= 2, mismatched_steps
+        assert rounds == its.max() >= 2
+    finally:
+        _set_activations(orc, g, np.zeros(K, int))
+        for k, T in enumerate(scene.poses_gt):
+            orc.set_pose(k, T)
+            g.keyframes[k]["pose"] = np.asarray(T, np.float32)
+
+
+# ---- (b), (c): BASELINE configs[2] at full size -------------------------------------------------------------------------
+def _bench_scene(**overrides):
+    sys.path.insert(0, ROOT)
+    import bench
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        args = bench.parse_args()
+    finally:
+        sys.argv = argv
+    for k, v in overrides.items():
+        setattr(args, k, v)
+    ba, data, poses_gt = bench.build_scene(args, lambda m: None)
+    return ba, data, poses_gt, args
+
+
+def _oracle_from_directba(ba, args, data, keyframe_ids=None):
+    """Oracle scene holding the preprocessed images of `keyframe_ids` (default: all) and the surfel rows `data`."""
+    cam = synthetic.test_camera(args.width, args.height)
+    from oracle import binding as ob
+    orc = ob.OracleBA(data.shape[1] + 1024, 1.0 / 5000, 40.0, args.cell, ob.make_camera(cam, args.width, args.height),
+                      ob.make_camera(cam, args.width, args.height))
+    ids = range(ba.keyframe_count()) if keyframe_ids is None else keyframe_ids
+    for k in ids:
+        orc.add_preprocessed_keyframe(ba.keyframe_image(k, "depth"), ba.keyframe_image(k, "normals"), ba.keyframe_image(k, "radius"),
+                                      ba.keyframe_image(k, "color"), ba.keyframe_pose(k))
+    n = data.shape[1]
+    orc.surfel_data[:data.shape[0], :n] = data
+    orc.surfels.surfels_size = orc.surfels.surfel_count = n
+    return orc
+
+
+@pytest.fixture(scope="module")
+def c3():
+    ba, data, poses_gt, args = _bench_scene()
+    ba.upload_surfels(data)
+    return ba, data, poses_gt, args
+
+
+def test_c3_sampled_pairs_bit_exact(c3):
+    ba, data, poses_gt, args = c3
+    ba.upload_surfels(data)
+    N, K = data.shape[1], ba.keyframe_count()
+    assert (N, K) == (3000000, 200)
+    rng = np.random.Generator(np.random.PCG64(77))
+    kf_ids = sorted(rng.choice(K, 25, replace=False).tolist())
+    orc = _oracle_from_directba(ba, args, data, kf_ids)
+    ctx = ba.backend_context()
+    ba.BindScene()                                     # cameras + depth parameters into the backend context
+    surfels = ba.surfels_struct()
+    F_PAIR = orc.PAIR_FIELDS
+    total = associated = with_colour = 0
+    for j, k in enumerate(kf_ids):
+        idx = rng.integers(0, N, 40000).astype(np.uint32)
+        F = np.array(list(orc.keyframes[j].frame_T_global), np.float32)
+        ref = orc.evaluate_pairs(j, idx)
+        out = np.zeros((len(idx), 40), np.float32)
+        frame = ba.keyframe_frame(k)
+        capi.check(ctx.lib.bahip_debug_evaluate_pairs(ctx.handle, C.byref(frame), F.ctypes.data_as(C.POINTER(C.c_float)),
+                                                      C.byref(surfels), idx.ctypes.data_as(C.POINTER(C.c_uint32)), len(idx),
+                                                      out.ctypes.data_as(C.POINTER(C.c_float))))
+        got = out.view(np.uint32)
+        refi = ref.view(np.int32)
+        assoc = refi[:, 0] == 1
+        assert np.array_equal(out[:, 0] == 1.0, assoc), k                              # the association decision of every pair
+        a = np.flatnonzero(assoc)
+        assert np.array_equal(out[a, 1].astype(np.int32), refi[a, 1]) and np.array_equal(out[a, 2].astype(np.int32), refi[a, 2])
+        assert np.array_equal(out[a, 3] == 1.0, refi[a, 3] == 1)
+
+        def same(gpu_cols, field, rows):
+            o, n = F_PAIR[field]
+            assert np.array_equal(got[rows][:, gpu_cols], ref[rows][:, o:o + n]), (k, field)
+
+        same([4], "calibrated_depth", a)
+        same([5], "depth_residual", a)
+        same([6], "depth_weight", a)
+        same([7], "depth_inv_stddev", a)
+        same(list(range(8, 14)), "depth_jac_pose", a)
+        c = a[refi[a, 3] == 1]
+        same([14, 15], "desc_residual", c)
+        same([16, 17], "desc_weight", c)
+        same(list(range(18, 30)), "desc_jac_pose", c)
+        same(list(range(30, 34)), "grad", c)
+        total += len(idx); associated += len(a); with_colour += len(c)
+    assert total == 1000000
+    assert associated > 50000 and with_colour > 0.9 * associated, (associated, with_colour)
+    print(f"{total} pairs, {associated} associated, {with_colour} with a colour pixel: every compared field bit-identical")
+
+
+def test_c3_one_iteration_matches_oracle(c3):
+    ba, data, poses_gt, args = c3
+    K = ba.keyframe_count()
+    ba.upload_surfels(data)
+    start = [ba.keyframe_pose(k) for k in range(K)]
+    orc = _oracle_from_directba(ba, args, data)
+    try:
+        ba.set_ba_iteration_counts(1, 1)               # equal counters: no end-of-scheme tasks (fixed surfel set)
+        done, _ = ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=1,
+                                      max_iterations=1, active_keyframe_window_start=0, active_keyframe_window_end=K - 1,
+                                      increase_ba_iteration_count=False)
+        orc.ba_iteration_count, orc.last_ba_iteration_count = 1, 1
+        stats = orc.bundle_adjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=1,
+                                      max_iterations=1, increase_ba_iteration_count=False)
+        assert done == stats.iterations_done == 1
+        n = data.shape[1]
+        got = ba.download_surfels(8)
+        ref = orc.surfel_data[:8, :n]
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))              # geometry step at full size: every bit
+        assert np.abs(ref[2] - data[2]).mean() > 1e-4
+        got_poses = np.array([ba.keyframe_pose(k) for k in range(K)])
+        ref_poses = np.array([orc.pose(k) for k in range(K)])
+        moved = np.linalg.norm(got_poses[:, 4:] - np.array(start)[:, 4:], axis=1)
+        assert np.median(moved) > 1e-3                                               # the 5 mm perturbation was worked on
+        rmse = float(np.sqrt(np.mean(np.sum((got_poses[:, 4:] - ref_poses[:, 4:]) ** 2, axis=1))))
+        worst = max(np.abs(common.pose_error(ref_poses[k], got_poses[k])).max() for k in range(K))
+        print(f"config 3, one iteration: pose RMSE vs oracle {rmse:.2e} m, worst tangent component {worst:.2e}, "
+              f"{stats.pose_gn_steps_total} GN steps in the oracle")
+        assert rmse <= 1e-5, rmse
+        assert abs(ba.last_stats()["pose_steps"] - stats.pose_gn_steps_total) <= 2
+    finally:
+        for k in range(K):
+            ba.set_keyframe_pose(k, start[k])
+
+
+# ---- (d): BASELINE configs[1]'s size, end to end with the surfel lifecycle ------------------------------------------------
+def test_c2_size_end_to_end_with_surfel_updates():
+    ba, data, poses_gt, args = _bench_scene(keyframes=50, surfels=10 ** 9, no_spatial_sort=True)
+    K = ba.keyframe_count()
+    # start from an empty cloud: BundleAdjustment creates the surfels itself (filtered, co-visibility lists of the host)
+    ba.SetSurfelCount(0, 0)
+    cam = synthetic.test_camera(args.width, args.height)
+    from oracle import binding as ob
+    cap = data.shape[1] * 2 + 1024
+    orc = ob.OracleBA(cap, 1.0 / 5000, 40.0, args.cell, ob.make_camera(cam, args.width, args.height),
+                      ob.make_camera(cam, args.width, args.height), min_observation_count=2)
+    for k in range(K):
+        orc.add_preprocessed_keyframe(ba.keyframe_image(k, "depth"), ba.keyframe_image(k, "normals"), ba.keyframe_image(k, "radius"),
+                                      ba.keyframe_image(k, "color"), ba.keyframe_pose(k))
+    orc.covis = [ba.keyframe_covisibility(k) for k in range(K)]
+    assert min(len(l) for l in orc.covis) >= 1 and max(len(l) for l in orc.covis) < K - 1      # a real co-visibility structure
+    for call in range(2):
+        done, _ = ba.BundleAdjustment(do_surfel_updates=True, optimize_poses=True, optimize_geometry=True, min_iterations=2,
+                                      max_iterations=2, increase_ba_iteration_count=True)
+        stats = orc.bundle_adjustment(do_surfel_updates=True, optimize_poses=True, optimize_geometry=True, min_iterations=2,
+                                      max_iterations=2, increase_ba_iteration_count=True)
+        assert done == stats.iterations_done == 2
+        assert ba.surfel_count() == orc.surfels_size, (call, ba.surfel_count(), orc.surfels_size)
+    n = orc.surfels_size
+    assert 300000 < n < 900000, n
+    got_poses = np.array([ba.keyframe_pose(k) for k in range(K)])
+    ref_poses = np.array([orc.pose(k) for k in range(K)])
+    rmse = float(np.sqrt(np.mean(np.sum((got_poses[:, 4:] - ref_poses[:, 4:]) ** 2, axis=1))))
+    got = ba.download_surfels(8)
+    ref = orc.surfel_data[:8, :n]
+    dpos = np.abs(got[:3] - ref[:3]).max(axis=0)
+    flips = int(np.count_nonzero(~(dpos <= 1e-5)))
+    print(f"config-2 size: {n} surfels, pose RMSE vs oracle {rmse:.2e} m, {flips} surfels beyond 1e-5 m, "
+          f"bit-identical rows: {np.array_equal(got.view(np.uint32), ref.view(np.uint32))}")
+    assert rmse <= 1e-5, rmse
+    assert flips <= 1e-3 * n, flips
