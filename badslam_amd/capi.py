@@ -56,7 +56,10 @@ class PCGOptions(C.Structure):
                                        "max_inner_iterations", "gauge_keyframe")]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+SUM_F32, SUM_I64 = 0, 1
+RCCL_UNIQUE_ID_BYTES = 128
+# int fn(void* device_buffer, size_t count, int dtype, void* hip_stream, void* user)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol declared in include/badslam_hip.h
 SIGNATURES = {
@@ -66,6 +69,8 @@ SIGNATURES = {
     "bahip_context_destroy": (None, [C.c_void_p]),
     "bahip_context_synchronize": (C.c_int, [C.c_void_p]),
     "bahip_context_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "bahip_rccl_get_unique_id": (C.c_int, [C.c_char_p]),
+    "bahip_context_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "bahip_malloc_pitch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),
     "bahip_free": (C.c_int, [C.c_void_p]),
     "bahip_memcpy_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),

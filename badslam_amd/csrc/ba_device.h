@@ -74,6 +74,17 @@ struct KfEntry {
 
 // One frame whose pose is being estimated (batched Gauss-Newton, kernels_pose.hip).
 constexpr int kHbStride = 28;   // 21 H (row-major upper triangle) + 6 b + 1 pad
+// The pose normal equations are summed in FIXED POINT: the 27 binary32 totals of one (64-surfel tile, keyframe) pair -- the
+// result of the fixed halving tree of wave_reduce.h -- are converted to 48.16 fixed point (round to nearest even) and added
+// as 64-bit integers.  Integer addition is associative, so the sums do not depend on the order of the atomics, on the launch
+// shape (pose_parts), on how tiles are grouped, or on how the surfels are sharded over GPUs (an integer all-reduce is exact):
+// H and b are deterministic, and the oracle computes the same bits (oracle_pose.c).  The reference merges float atomics in
+// arbitrary order (B/gauss_newton.cuh:71,89; SURVEY appendix B marks this FIX).  Resolution 2^-16 = 1.5e-5 is below the
+// binary32 ulp of any tile total that matters (a tile's H entries are 1e2 ... 1e8); range +-1.4e14.
+typedef long long HbFixed;
+constexpr double kHbFixedScale = 65536.0;
+__host__ __device__ __forceinline__ HbFixed hb_to_fixed(float v) { return (HbFixed)__builtin_rint((double)v * kHbFixedScale); }
+__host__ __device__ __forceinline__ double hb_from_fixed(HbFixed q) { return (double)q * (1.0 / kHbFixedScale); }
 struct PoseWork {
   float F[12];        // frame_T_global at the current linearisation point
   float T[7];         // global_T_frame estimate (Sophus layout)

@@ -37,10 +37,10 @@ void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry*
 
 // kernels_pose.hip
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
-                            const void* work, int num_work, const SurfelsView& s, float* Hb);
-void launch_pose_solve(hipStream_t stream, void* work, int num_work, float* Hb, KfEntry* frames, int write_back,
+                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb);
+void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int* not_done_count);
-void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, float* Hb);
+void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
 void set_pose_parts(int parts);   // 0 = automatic; 1 | 2 | 4 | 8 wavefronts share a tile's keyframes in the pose kernel

@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary declared in include/badslam_hip.h.
 // Owns only scratch (device keyframe table, pose work items, scan temp, counters); every image
 // and the surfel buffer are borrowed from the caller.
+#include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -64,11 +65,11 @@ struct bahip_context {
   int num_kfs = 0;
 
   PoseWork* dev_work = nullptr;
-  float* dev_Hb = nullptr;
+  HbFixed* dev_Hb = nullptr;      // pose normal equations in fixed point (ba_device.h: HbFixed)
   int work_capacity = 0;
   KfEntry* dev_frame1 = nullptr;   // single-frame table for EstimateFramePose / AccumulatePoseEstimationCoeffs
   PoseWork* dev_work1 = nullptr;
-  float* dev_Hb1 = nullptr;
+  HbFixed* dev_Hb1 = nullptr;
 
   int* dev_counter = nullptr;      // [0] generic counter, [1..2] min/max depth bits
   int* pinned_i = nullptr;         // 16 ints
@@ -98,6 +99,7 @@ struct bahip_context {
 
   bahip_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  void* rccl_comm = nullptr;       // ncclComm_t created by bahip_context_init_rccl (native all-reduce on ctx->stream)
 
   int profiling = 0;               // 0 off, 1 last call of each stage, 2 cumulative since bahip_set_profiling
   StageTimer timers[4];
@@ -200,7 +202,7 @@ int ensure_work(bahip_context* ctx, int n) {
   if (ctx->dev_work) { hipFree(ctx->dev_work); hipFree(ctx->dev_Hb); }
   const int cap = n + 64;
   HIP_TRY(hipMalloc(&ctx->dev_work, sizeof(PoseWork) * cap));
-  HIP_TRY(hipMalloc(&ctx->dev_Hb, sizeof(float) * kHbStride * cap));
+  HIP_TRY(hipMalloc(&ctx->dev_Hb, sizeof(HbFixed) * kHbStride * cap));
   ctx->work_capacity = cap;
   return 0;
 }
@@ -243,9 +245,11 @@ void timer_end(bahip_context* ctx, int stage) {
   t.used += 1;
 }
 
+int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype);
+
 // Batched Gauss-Newton rounds over `num_work` work items already initialised on the device.
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
-                    PoseWork* dev_work, float* dev_Hb, int num_work, const SurfelsView& s, int write_back, int* rounds_out) {
+                    PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int* rounds_out) {
   int rounds = 0;
   int iterating = num_work;
   for (int round = 0; round < BAHIP_MAX_POSE_ITERATIONS; ++round) {
@@ -253,10 +257,8 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb);
     timer_end(ctx, 2);
     CHECK_LAUNCH();
-    if (ctx->allreduce) {
-      if (ctx->allreduce(dev_Hb, (size_t)num_work * kHbStride, ctx->allreduce_user) != 0)
-        return fail("all-reduce hook failed", __FILE__, __LINE__);
-    }
+    // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
+    if (reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
     timer_begin(ctx, 3, round == 0);
     HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
     launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, ctx->dev_counter);
@@ -272,17 +274,70 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
   return 0;
 }
 
+// ---- RCCL, loaded on first use ---------------------------------------------------------------------------------------
+// The prototypes below restate the four RCCL entry points used (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllReduce,
+// ncclCommDestroy, ncclGetErrorString); ncclFloat = 7, ncclInt64 = 4, ncclSum = 0 in every NCCL / RCCL release.
+struct RcclId { char internal[BAHIP_RCCL_UNIQUE_ID_BYTES]; };
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId /* ncclUniqueId, by value */, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int load_rccl() {
+  if (g_rccl.handle) return 0;
+  void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail("librccl.so could not be loaded (multi-GPU needs RCCL)", __FILE__, __LINE__);
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    return fail("librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy", __FILE__, __LINE__);
+  g_rccl.handle = h;
+  return 0;
+}
+int rccl_fail(const char* what, int rc) {
+  char buf[256];
+  snprintf(buf, sizeof(buf), "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+  g_last_error = buf;
+  return 1;
+}
+int rccl_allreduce(bahip_context* ctx, void* buffer, size_t count, int dtype) {
+  const int nccl_type = dtype == BAHIP_SUM_I64 ? 4 /* ncclInt64 */ : 7 /* ncclFloat */;
+  const int rc = g_rccl.AllReduce(buffer, buffer, count, nccl_type, 0 /* ncclSum */, ctx->rccl_comm, ctx->stream);
+  return rc == 0 ? 0 : rccl_fail("ncclAllReduce", rc);
+}
+
+// Element-wise sum of a device buffer over all ranks, in place, ordered on the context's stream: the native RCCL path
+// (bahip_context_init_rccl) if a communicator exists, else the caller's hook, else nothing (single GPU).
+int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype) {
+  if (count == 0) return 0;
+  if (ctx->rccl_comm) return rccl_allreduce(ctx, buffer, count, dtype);
+  if (ctx->allreduce && ctx->allreduce(buffer, count, dtype, ctx->stream, ctx->allreduce_user) != 0)
+    return fail("all-reduce hook failed", __FILE__, __LINE__);
+  return 0;
+}
+inline bool is_sharded(const bahip_context* ctx) { return ctx->allreduce != nullptr || ctx->rccl_comm != nullptr; }
+
 // Number of ranks behind the all-reduce hook: the sum of a 1 from every rank.
 int probe_world(bahip_context* ctx) {
-  if (!ctx->allreduce) { ctx->world = 1; return 0; }
+  if (!is_sharded(ctx)) { ctx->world = 1; return 0; }
   if (ctx->world > 0) return 0;
-  const float one = 1.f;
-  HIP_TRY(hipMemcpyAsync(ctx->dev_Hb1, &one, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  const HbFixed one = 1;
+  HIP_TRY(hipMemcpyAsync(ctx->dev_Hb1, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (ctx->allreduce(ctx->dev_Hb1, 1, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
-  float sum = 0.f;
-  HIP_TRY(hipMemcpy(&sum, ctx->dev_Hb1, sizeof(float), hipMemcpyDeviceToHost));
-  ctx->world = (int)(sum + 0.5f);
+  if (reduce_over_ranks(ctx, ctx->dev_Hb1, 1, BAHIP_SUM_I64)) return 1;
+  HbFixed sum = 0;
+  HIP_TRY(hipMemcpyAsync(&sum, ctx->dev_Hb1, sizeof(sum), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->world = (int)sum;
   if (ctx->world < 1) return fail("all-reduce hook returned a rank count < 1", __FILE__, __LINE__);
   return 0;
 }
@@ -312,7 +367,7 @@ int allreduce_head(bahip_context* ctx, const PcgLayout& L, float* a, float* b, f
     at += head;
   }
   if (num_scalars) HIP_TRY(hipMemcpyAsync(stage + at, scalars, sizeof(float) * num_scalars, hipMemcpyDeviceToDevice, st));
-  if (ctx->allreduce(stage, total, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
+  if (reduce_over_ranks(ctx, stage, total, BAHIP_SUM_F32)) return 1;
   at = 0;
   for (float* v : vecs) {
     if (!v) continue;
@@ -348,7 +403,7 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   HIP_TRY(hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)));
   HIP_TRY(hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)));
   HIP_TRY(hipMalloc(&ctx->dev_work1, sizeof(PoseWork)));
-  HIP_TRY(hipMalloc(&ctx->dev_Hb1, sizeof(float) * kHbStride));
+  HIP_TRY(hipMalloc(&ctx->dev_Hb1, sizeof(HbFixed) * kHbStride));
   *out = ctx;
   return 0;
 }
@@ -362,6 +417,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
+  if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
   delete ctx;
@@ -376,6 +432,31 @@ int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void*
   ctx->allreduce = fn;
   ctx->allreduce_user = user;
   ctx->world = 0;   // probed on first use (probe_world)
+  return 0;
+}
+
+int bahip_rccl_get_unique_id(char unique_id_out[BAHIP_RCCL_UNIQUE_ID_BYTES]) {
+  REQUIRE(unique_id_out != nullptr, "bahip_rccl_get_unique_id: NULL argument");
+  if (load_rccl()) return 1;
+  RcclId id;
+  const int rc = g_rccl.GetUniqueId(&id);
+  if (rc != 0) return rccl_fail("ncclGetUniqueId", rc);
+  memcpy(unique_id_out, id.internal, BAHIP_RCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+int bahip_context_init_rccl(bahip_context* ctx, const char unique_id[BAHIP_RCCL_UNIQUE_ID_BYTES], int rank, int world_size) {
+  REQUIRE(ctx != nullptr && unique_id != nullptr, "bahip_context_init_rccl: NULL argument");
+  REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "bahip_context_init_rccl: rank / world_size out of range");
+  if (load_rccl()) return 1;
+  if (ctx->rccl_comm) { g_rccl.CommDestroy(ctx->rccl_comm); ctx->rccl_comm = nullptr; }
+  RcclId id;
+  memcpy(id.internal, unique_id, BAHIP_RCCL_UNIQUE_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = g_rccl.CommInitRank(&comm, world_size, id, rank);
+  if (rc != 0) return rccl_fail("ncclCommInitRank", rc);
+  ctx->rccl_comm = comm;
+  ctx->world = world_size;
   return 0;
 }
 
@@ -626,17 +707,17 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
   w.kf_index = 0;
   HIP_TRY(hipMemcpyAsync(ctx->dev_frame1, &e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->dev_work1, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(float) * kHbStride, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(HbFixed) * kHbStride, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   launch_pose_accumulate(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_frame1, ctx->dev_work1, 1,
                          make_view(surfels), ctx->dev_Hb1);
   CHECK_LAUNCH();
-  if (ctx->allreduce && ctx->allreduce(ctx->dev_Hb1, kHbStride, ctx->allreduce_user) != 0)
-    return fail("all-reduce hook failed", __FILE__, __LINE__);
-  HIP_TRY(hipMemcpyAsync(ctx->pinned_f, ctx->dev_Hb1, sizeof(float) * kHbStride, hipMemcpyDeviceToHost, ctx->stream));
+  if (reduce_over_ranks(ctx, ctx->dev_Hb1, kHbStride, BAHIP_SUM_I64)) return 1;
+  HbFixed* fixed = reinterpret_cast<HbFixed*>(ctx->pinned_f);   // 28 x 8 bytes of the 64-float pinned buffer
+  HIP_TRY(hipMemcpyAsync(fixed, ctx->dev_Hb1, sizeof(HbFixed) * kHbStride, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  memcpy(H, ctx->pinned_f, 21 * sizeof(float));
-  memcpy(b, ctx->pinned_f + 21, 6 * sizeof(float));
+  for (int c = 0; c < 21; ++c) H[c] = (float)hb_from_fixed(fixed[c]);
+  for (int c = 0; c < 6; ++c) b[c] = (float)hb_from_fixed(fixed[21 + c]);
   return 0;
 }
 
@@ -654,7 +735,7 @@ int bahip_estimate_frame_pose(bahip_context* ctx, int use_depth, int use_desc, c
   se3_matrix3x4(inv, w.F);
   HIP_TRY(hipMemcpyAsync(ctx->dev_frame1, &e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->dev_work1, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(float) * kHbStride, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(HbFixed) * kHbStride, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   // surfels_size == 0: H = b = 0 -> x = 0 -> converged after one step (B/direct_ba_alternating.cc:148-151)
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_frame1, ctx->dev_frame1, ctx->dev_work1, ctx->dev_Hb1, 1,
@@ -838,7 +919,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   *out_color_camera = ctx->color_cam;
   *out_depth_camera = ctx->depth_cam;
   *out_a = ctx->dp.a;
-  if (surfels->surfels_size == 0 && !ctx->allreduce) return 0;   // a rank with an empty shard still takes part in the exchange
+  if (surfels->surfels_size == 0 && !is_sharded(ctx)) return 0;   // a rank with an empty shard still takes part in the exchange
   const int S = ctx->in.cf_width * ctx->in.cf_height;
   if (S > ctx->intr_capacity) {
     if (ctx->intr_scratch) hipFree(ctx->intr_scratch);
@@ -854,8 +935,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
                                make_view(surfels), glob, B, D, b2, obs, S);
   CHECK_LAUNCH();
-  if (ctx->allreduce && ctx->allreduce(glob, 64 + 8 * (size_t)S, ctx->allreduce_user) != 0)
-    return fail("all-reduce hook failed", __FILE__, __LINE__);
+  if (reduce_over_ranks(ctx, glob, 64 + 8 * (size_t)S, BAHIP_SUM_F32)) return 1;
   if (optimize_depth) {
     launch_intrinsics_schur(ctx->stream, S, glob, B, D, b2, obs + ctx->intr_capacity /* past the all-reduced block */);
     CHECK_LAUNCH();
@@ -908,7 +988,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
                         bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a, int* inner_steps_out,
                         int* num_converged_out) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
-  const bool sharded = ctx->allreduce != nullptr;
+  const bool sharded = is_sharded(ctx);
   if (probe_world(ctx)) return 1;
   const int K = ctx->num_kfs;
   REQUIRE(K >= 1, "PCG needs at least one keyframe");
@@ -960,7 +1040,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   if (sharded && allreduce_head(ctx, L, r_, M_, nullptr, 0)) return 1;
   launch_pcg_init2(st, L, ctx->dp.a, r_, M_, delta, g_, p_, sc + i_an);
   CHECK_LAUNCH();
-  if (sharded && ctx->allreduce(sc + i_an, 1, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
+  if (sharded && reduce_over_ranks(ctx, sc + i_an, 1, BAHIP_SUM_F32)) return 1;
 
   float prev_r_norm = __builtin_huge_valf();
   int no_improvement = 0, steps = 0;
@@ -977,7 +1057,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
     HIP_TRY(hipMemsetAsync(sc + i_bn, 0, sizeof(float), st));
     launch_pcg_step2(st, L, r_, M_, delta, g_, p_, sc + i_an, sc + 1, sc + i_bn);
     CHECK_LAUNCH();
-    if (sharded && ctx->allreduce(sc + i_bn, 1, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
+    if (sharded && reduce_over_ranks(ctx, sc + i_bn, 1, BAHIP_SUM_F32)) return 1;
     HIP_TRY(hipMemcpyAsync(ctx->pinned_f, sc + i_bn, sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const float r_norm = sqrtf(ctx->pinned_f[0]);

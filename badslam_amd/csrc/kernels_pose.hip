@@ -27,8 +27,8 @@ namespace bahip {
 #endif
 constexpr int kPoseBlock = 64;    // one wavefront per workgroup: no LDS, no barriers, and finished waves free their slot at once
 
-// acc += w * [upper(J J^T) | r J].  The totals are merged across wavefronts with float atomics in arbitrary order, so
-// nothing downstream depends on the rounding of these partial sums: fused multiply-adds are used.
+// acc += w * [upper(J J^T) | r J], as fused multiply-add chains (the oracle's orc_accumulate_pose_coeffs spells the same chain:
+// the per-lane sums, the wave tree and the fixed-point totals are part of the numerical definition, ba_device.h: HbFixed).
 __device__ __forceinline__ void accumulate_jtj(float (&acc)[28], const float (&J)[6], float wgt, float raw) {
   int q = 0;
 #pragma unroll
@@ -45,7 +45,7 @@ __device__ __forceinline__ void accumulate_jtj(float (&acc)[28], const float (&J
 template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
 pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
-                       int num_work, SurfelsView s, float* __restrict__ Hb) {
+                       int num_work, SurfelsView s, HbFixed* __restrict__ Hb) {
   const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPoseBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
@@ -109,9 +109,11 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
       }
     }
 
-    // wave64 halving reduction (wave_reduce.h), then one atomic per scalar per wave
+    // wave64 halving reduction (wave_reduce.h: a fixed tree over the 64 lanes), then one 64-bit integer atomic per scalar
+    // per wave on the fixed-point value: order-free, hence deterministic
     const float mine = wave_reduce28(acc, lane);
-    if (slot >= 0 && slot < 27) unsafeAtomicAdd(&Hb[(size_t)w * kHbStride + slot], mine);
+    if (slot >= 0 && slot < 27)
+      atomicAdd(reinterpret_cast<unsigned long long*>(&Hb[(size_t)w * kHbStride + slot]), (unsigned long long)hb_to_fixed(mine));
   }, gridDim.y, blockIdx.y);
 }
 
@@ -158,19 +160,21 @@ __device__ void ldlt_solve(double* A, const double* b, double* x) {
 }
 
 // One GN update per work item: B/direct_ba_alternating.cc:173-244.
-__global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, float* __restrict__ Hb,
+__global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
                                   KfEntry* __restrict__ frames, int write_back, int* __restrict__ not_done_count) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= num_work) return;
   PoseWork& pw = work[w];
   if (pw.done) return;
-  float* hb = Hb + (size_t)w * kHbStride;
+  HbFixed* hb = Hb + (size_t)w * kHbStride;
   double A[36], b[6], x[6];
   int q = 0;
+  // the reference hands binary32 H, b to the binary64 solve (H.cast<double>(), B/direct_ba_alternating.cc:206): the
+  // fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
   for (int row = 0; row < 6; ++row)
-    for (int col = row; col < 6; ++col) { A[row * 6 + col] = hb[q]; A[col * 6 + row] = hb[q]; ++q; }
-  for (int c = 0; c < 6; ++c) b[c] = hb[21 + c];
-  for (int c = 0; c < kHbStride; ++c) hb[c] = 0.f;
+    for (int col = row; col < 6; ++col) { const double v = (double)(float)hb_from_fixed(hb[q]); A[row * 6 + col] = v; A[col * 6 + row] = v; ++q; }
+  for (int c = 0; c < 6; ++c) b[c] = (double)(float)hb_from_fixed(hb[21 + c]);
+  for (int c = 0; c < kHbStride; ++c) hb[c] = 0;
   ldlt_solve<6>(A, b, x);
   float xf[6], mx[6];
   for (int c = 0; c < 6; ++c) { xf[c] = (float)x[c]; mx[c] = -1.f * xf[c]; }
@@ -199,7 +203,7 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, flo
 
 // Builds one work item per bound keyframe (skipping kInactive ones), B/direct_ba_alternating.cc:547-553.
 __global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs, PoseWork* __restrict__ work,
-                                                float* __restrict__ Hb) {
+                                                HbFixed* __restrict__ Hb) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num_kfs) return;
   PoseWork& pw = work[k];
@@ -209,7 +213,7 @@ __global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ fram
   pw.done = (frames[k].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
   for (int c = 0; c < 7; ++c) pw.T[c] = frames[k].global_T_frame[c];
   for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
-  for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0.f;
+  for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -217,11 +221,11 @@ static int g_forced_pose_parts = [] { const char* e = getenv("BAHIP_POSE_PARTS")
 void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
 
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
-                            const void* work, int num_work, const SurfelsView& s, float* Hb) {
+                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb) {
   if (s.size == 0 || num_work == 0) return;
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
-  // (the sums are merged by atomics, so who visits a keyframe does not matter).
+  // (the sums are merged by integer atomics, so who visits a keyframe does not matter: same bits for every split).
   const unsigned tiles = ((s.size + kPoseBlock - 1) / kPoseBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk);   // whole XCD chunks
   const int forced = g_forced_pose_parts;
   const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
@@ -233,14 +237,14 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
 }
 
-void launch_pose_solve(hipStream_t stream, void* work, int num_work, float* Hb, KfEntry* frames, int write_back,
+void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int* not_done_count) {
   if (num_work == 0) return;
   hipLaunchKernelGGL(pose_solve_kernel, dim3((num_work + 63) / 64), dim3(64), 0, stream, static_cast<PoseWork*>(work),
                      num_work, Hb, frames, write_back, not_done_count);
 }
 
-void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, float* Hb) {
+void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb) {
   if (num_kfs == 0) return;
   hipLaunchKernelGGL(pose_init_from_keyframes_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs,
                      static_cast<PoseWork*>(work), Hb);

@@ -20,6 +20,39 @@ namespace bahip {
 
 constexpr float kSophusEpsilonF = 1e-5f;  // sophus/common.hpp:144-148
 
+// sin and cos of a binary32 angle, defined by explicit binary64 operations (Cody-Waite reduction by pi/2, Taylor
+// polynomials on |r| <= pi/4 evaluated with fused multiply-adds, result rounded to binary32): the exponential map runs on
+// the device (pose_solve_kernel) and on the host, and math-library sinf / cosf differ between the two in the last bit.
+// Defined this way every pose update is the same bits wherever it is computed (the oracle restates the same operations),
+// which is what lets whole bundle-adjustment runs be compared bit for bit.  Error < 1 ulp of binary32 for |x| < 1e5.
+BAHIP_HD void sincos_det(float xf, float* sin_out, float* cos_out) {
+  const double x = (double)xf;
+  const double k = __builtin_rint(x * 0.63661977236758134308);                 // nearest multiple of pi/2
+  double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+  r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+  const double r2 = r * r;
+  double sp = 1.0 / 6227020800.0;
+  sp = __builtin_fma(sp, r2, -1.0 / 39916800.0);
+  sp = __builtin_fma(sp, r2, 1.0 / 362880.0);
+  sp = __builtin_fma(sp, r2, -1.0 / 5040.0);
+  sp = __builtin_fma(sp, r2, 1.0 / 120.0);
+  sp = __builtin_fma(sp, r2, -1.0 / 6.0);
+  sp = __builtin_fma(sp * r2, r, r);
+  double cp = -1.0 / 87178291200.0;
+  cp = __builtin_fma(cp, r2, 1.0 / 479001600.0);
+  cp = __builtin_fma(cp, r2, -1.0 / 3628800.0);
+  cp = __builtin_fma(cp, r2, 1.0 / 40320.0);
+  cp = __builtin_fma(cp, r2, -1.0 / 720.0);
+  cp = __builtin_fma(cp, r2, 1.0 / 24.0);
+  cp = __builtin_fma(cp, r2, -0.5);
+  cp = __builtin_fma(cp, r2, 1.0);
+  const int quadrant = (int)((long long)k & 3);
+  const double sv = (quadrant == 0) ? sp : (quadrant == 1) ? cp : (quadrant == 2) ? -sp : -cp;
+  const double cv = (quadrant == 0) ? cp : (quadrant == 1) ? -sp : (quadrant == 2) ? -cp : sp;
+  *sin_out = (float)sv;
+  *cos_out = (float)cv;
+}
+
 BAHIP_HD void quat_mul(const float* a, const float* b, float* o) {
   const float ax = a[0], ay = a[1], az = a[2], aw = a[3];
   const float bx = b[0], by = b[1], bz = b[2], bw = b[3];
@@ -97,8 +130,10 @@ BAHIP_HD void se3_exp(const float* a, float* o) {
     imag_factor = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
     real_factor = 1.f - 0.5f * theta_sq + (float)(1.0 / 384.0) * theta_po4;
   } else {
-    imag_factor = sinf(half_theta) / theta;
-    real_factor = cosf(half_theta);
+    float sin_half, cos_half;
+    sincos_det(half_theta, &sin_half, &cos_half);
+    imag_factor = sin_half / theta;
+    real_factor = cos_half;
   }
   o[3] = real_factor; o[0] = imag_factor * ox; o[1] = imag_factor * oy; o[2] = imag_factor * oz;
   const float Om[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
@@ -107,8 +142,10 @@ BAHIP_HD void se3_exp(const float* a, float* o) {
   if (theta < kSophusEpsilonF) {
     se3_rotation(o, V);
   } else {
-    const float c1 = (1.f - cosf(theta)) / theta_sq;
-    const float c2 = (theta - sinf(theta)) / (theta_sq * theta);
+    float sin_theta, cos_theta;
+    sincos_det(theta, &sin_theta, &cos_theta);
+    const float c1 = (1.f - cos_theta) / theta_sq;
+    const float c2 = (theta - sin_theta) / (theta_sq * theta);
     for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + c1 * Om[i] + c2 * Om2[i];
   }
   o[4] = V[0] * a[0] + V[1] * a[1] + V[2] * a[2];
@@ -139,7 +176,9 @@ BAHIP_HD void se3_log(const float* T, float* out) {
     c = (float)(1. / 12.);
   } else {
     const float half_theta = 0.5f * theta;
-    c = (1.f - theta * cosf(half_theta) / (2.f * sinf(half_theta))) / (theta * theta);
+    float sin_half, cos_half;
+    sincos_det(half_theta, &sin_half, &cos_half);
+    c = (1.f - theta * cos_half / (2.f * sin_half)) / (theta * theta);
   }
   float Vinv[9];
   for (int i = 0; i < 9; ++i) Vinv[i] = ((i % 4 == 0) ? 1.f : 0.f) - 0.5f * Om[i] + c * Om2[i];

@@ -91,11 +91,24 @@ int bahip_device_count(void);
 int bahip_context_create(bahip_context** out, void* hip_stream);
 void bahip_context_destroy(bahip_context* ctx);
 int bahip_context_synchronize(bahip_context* ctx);
-/* Optional all-reduce hook for multi-GPU surfel sharding: called on the context's stream with a
- * device buffer of `count` floats that must be summed element-wise over all ranks in place.
- * NULL (default) = single GPU.  The host side installs a torch.distributed / RCCL all_reduce. */
-typedef int (*bahip_allreduce_fn)(void* device_buffer, size_t count, void* user);
+/* Multi-GPU surfel sharding (one process per GPU, DESIGN.md "Multi-GPU"): the per-keyframe pose normal equations, the
+ * intrinsics accumulators and the dense head of the PCG vectors are summed element-wise over all ranks, in place.
+ *
+ * Native path: bahip_context_init_rccl creates an RCCL communicator for this context (rank 0 obtains the 128-byte id with
+ * bahip_rccl_get_unique_id and distributes it by any means, e.g. a torch.distributed broadcast) and every sum becomes one
+ * ncclAllReduce on the context's stream: no host round trip, ordered with the kernels around it.  librccl.so is loaded
+ * on first use (dlopen), so a single-GPU process never touches it.
+ *
+ * Hook path: any other transport.  The hook receives the stream the producers of `device_buffer` were queued on and must
+ * order the reduction after them and before later work on that stream (e.g. torch.cuda.ExternalStream(stream) around
+ * dist.all_reduce).  dtype: BAHIP_SUM_F32 (count floats) or BAHIP_SUM_I64 (count int64_t: the pose normal equations are
+ * summed in fixed point, which makes a sharded run bit-identical to the unsharded one).  NULL (default) = single GPU. */
+enum { BAHIP_SUM_F32 = 0, BAHIP_SUM_I64 = 1 };
+typedef int (*bahip_allreduce_fn)(void* device_buffer, size_t count, int dtype, void* hip_stream, void* user);
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user);
+#define BAHIP_RCCL_UNIQUE_ID_BYTES 128
+int bahip_rccl_get_unique_id(char unique_id_out[BAHIP_RCCL_UNIQUE_ID_BYTES]);
+int bahip_context_init_rccl(bahip_context* ctx, const char unique_id[BAHIP_RCCL_UNIQUE_ID_BYTES], int rank, int world_size);
 
 /* Device memory helpers (what libvis CUDABuffer does with cudaMallocPitch / cudaMemcpy2DAsync,
  * libvis/src/libvis/cuda/cuda_buffer_inl.h:36-186). */

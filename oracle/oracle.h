@@ -100,6 +100,8 @@ typedef struct {
 
 /* ---- SE3 (libvis/third_party/sophus/sophus/se3.hpp:293-313,440-467; so3.hpp:282-320,421-465) ---- */
 void orc_se3_identity(orc_se3* T);
+/* sin / cos as the backend defines them (binary64 polynomial evaluation, se3_device.h: sincos_det) */
+void orc_sincos(float x, float* sin_out, float* cos_out);
 void orc_se3_exp(const float tangent[6], orc_se3* out);
 void orc_se3_log(const orc_se3* T, float tangent[6]);
 void orc_se3_mul(const orc_se3* a, const orc_se3* b, orc_se3* out);
@@ -178,8 +180,10 @@ void orc_evaluate_pairs(const orc_camera* color_cam, const orc_camera* depth_cam
 
 /* ---- pose optimisation ---- */
 /* B/kernel_opt_pose.cc:39-97 + B/kernel_opt_pose.cu:251-383 + B/gauss_newton.cuh:46-93.
- * H: 21 floats (row-major upper triangle), b: 6 floats.  Accumulation in surfel order
- * (binary32 adds unless accumulate_double != 0). Returns number of depth-associated surfels. */
+ * H: 21 floats (row-major upper triangle), b: 6 floats.  accumulate_double == 0: the backend's definition of the sum
+ * (per-surfel fma chains, fixed 64-surfel tile tree, 48.16 fixed-point integer total; oracle_pose.c), which is what
+ * orc_estimate_frame_pose uses; != 0: plain binary64 running sum in surfel order.  Returns the number of associated surfels. */
+float orc_tile_tree_sum(const float lane_values[64]);
 uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camera* color_cam,
                                     const orc_camera* depth_cam, const orc_depth_params* dp,
                                     const orc_keyframe* kf, const float frame_T_global[12],

@@ -94,6 +94,37 @@ static void mat3_mul(const float* a, const float* b, float* o) {
       o[3 * i + j] = a[3 * i + 0] * b[0 + j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
 }
 
+/* sin / cos of a binary32 angle by explicit binary64 operations: the backend defines them this way (se3_device.h:
+ * sincos_det) because device and host math libraries differ in the last bit of sinf / cosf; restated here operation by
+ * operation (pi/2 split in two parts, Taylor polynomials on |r| <= pi/4, fused multiply-adds, one final rounding). */
+void orc_sincos(float xf, float* sin_out, float* cos_out) {
+  const double x = (double)xf;
+  const double k = rint(x * 0.63661977236758134308);
+  double r = fma(-k, 1.57079632679489655800e+00, x);
+  r = fma(-k, 6.12323399573676603587e-17, r);
+  const double r2 = r * r;
+  double sp = 1.0 / 6227020800.0;
+  sp = fma(sp, r2, -1.0 / 39916800.0);
+  sp = fma(sp, r2, 1.0 / 362880.0);
+  sp = fma(sp, r2, -1.0 / 5040.0);
+  sp = fma(sp, r2, 1.0 / 120.0);
+  sp = fma(sp, r2, -1.0 / 6.0);
+  sp = fma(sp * r2, r, r);
+  double cp = -1.0 / 87178291200.0;
+  cp = fma(cp, r2, 1.0 / 479001600.0);
+  cp = fma(cp, r2, -1.0 / 3628800.0);
+  cp = fma(cp, r2, 1.0 / 40320.0);
+  cp = fma(cp, r2, -1.0 / 720.0);
+  cp = fma(cp, r2, 1.0 / 24.0);
+  cp = fma(cp, r2, -0.5);
+  cp = fma(cp, r2, 1.0);
+  const int quadrant = (int)((long long)k & 3);
+  const double sv = (quadrant == 0) ? sp : (quadrant == 1) ? cp : (quadrant == 2) ? -sp : -cp;
+  const double cv = (quadrant == 0) ? cp : (quadrant == 1) ? -sp : (quadrant == 2) ? -cp : sp;
+  *sin_out = (float)sv;
+  *cos_out = (float)cv;
+}
+
 /* se3.hpp:293-313, so3.hpp:282-320 */
 void orc_se3_exp(const float a[6], orc_se3* out) {
   const float ox = a[3], oy = a[4], oz = a[5];
@@ -106,9 +137,10 @@ void orc_se3_exp(const float a[6], orc_se3* out) {
     imag_factor = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
     real_factor = 1.f - 0.5f * theta_sq + (float)(1.0 / 384.0) * theta_po4;
   } else {
-    const float sin_half_theta = sinf(half_theta);
+    float sin_half_theta, cos_half_theta;
+    orc_sincos(half_theta, &sin_half_theta, &cos_half_theta);
     imag_factor = sin_half_theta / theta;
-    real_factor = cosf(half_theta);
+    real_factor = cos_half_theta;
   }
   orc_se3 r;
   r.q[3] = real_factor; r.q[0] = imag_factor * ox; r.q[1] = imag_factor * oy; r.q[2] = imag_factor * oz;
@@ -120,8 +152,10 @@ void orc_se3_exp(const float a[6], orc_se3* out) {
   if (theta < SOPHUS_EPS_F) {
     orc_se3_rotation(&r, V);
   } else {
-    const float c1 = (1.f - cosf(theta)) / theta_sq;
-    const float c2 = (theta - sinf(theta)) / (theta_sq * theta);
+    float sin_theta, cos_theta;
+    orc_sincos(theta, &sin_theta, &cos_theta);
+    const float c1 = (1.f - cos_theta) / theta_sq;
+    const float c2 = (theta - sin_theta) / (theta_sq * theta);
     for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + c1 * Om[i] + c2 * Om2[i];
   }
   v3 t = m33_mul(V, v3_make(a[0], a[1], a[2]));
@@ -154,7 +188,9 @@ void orc_se3_log(const orc_se3* T, float out[6]) {
     c = (float)(1. / 12.);
   } else {
     const float half_theta = 0.5f * theta;
-    c = (1.f - theta * cosf(half_theta) / (2.f * sinf(half_theta))) / (theta * theta);
+    float sin_half_theta, cos_half_theta;
+    orc_sincos(half_theta, &sin_half_theta, &cos_half_theta);
+    c = (1.f - theta * cos_half_theta / (2.f * sin_half_theta)) / (theta * theta);
   }
   for (int i = 0; i < 9; ++i) Vinv[i] = ((i % 4 == 0) ? 1.f : 0.f) - 0.5f * Om[i] + c * Om2[i];
   v3 u = m33_mul(Vinv, v3_make(T->t[0], T->t[1], T->t[2]));

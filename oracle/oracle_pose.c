@@ -2,13 +2,28 @@
  * Test infrastructure only (see oracle.h). */
 #include "oracle_internal.h"
 
-/* One residual into (H, b): B/gauss_newton.cuh:59-92, row-major upper triangle. */
-static inline void add_residual_f(float* H, float* b, float raw, float w, const float* J) {
+/* One residual into (H, b): B/gauss_newton.cuh:59-92, row-major upper triangle.
+ *
+ * Definition of the sum (accumulate_double == 0).  The reference merges block partials with float atomics in arbitrary
+ * order (B/gauss_newton.cuh:71,89), so its H, b are not reproducible run to run; SURVEY appendix B marks that FIX.  The
+ * backend defines the sum so that it is reproducible AND independent of launch shape and multi-GPU sharding, and this
+ * function restates exactly that definition:
+ *   1. every surfel i accumulates its (up to three) residuals into 27 binary32 values with fused multiply-adds, depth
+ *      residual first, then the two descriptor residuals (acc_residual below);
+ *   2. the 64 surfels [64 t, 64 t + 64) of tile t are summed by a fixed binary tree (tile_tree: lane pairs at distance
+ *      32, 16, 8, then 7 - i inside groups of 8, then distance 2, 1 -- the halving butterfly of wave_reduce.h);
+ *   3. each of the 27 tile totals is converted to 48.16 fixed point (round to nearest even) and the tiles are added as
+ *      64-bit integers -- associative, hence order-free;
+ *   4. H, b = the integer totals scaled back and rounded to binary32.
+ * accumulate_double != 0 is the plain binary64 running sum in surfel order (an independent check of 1.-4.). */
+static inline void acc_residual(float* acc, float raw, float w, const float* J) {
   int k = 0;
-  for (int row = 0; row < 6; ++row)
-    for (int col = row; col < 6; ++col) H[k++] += w * J[row] * J[col];
+  for (int row = 0; row < 6; ++row) {
+    const float wj = w * J[row];
+    for (int col = row; col < 6; ++col, ++k) acc[k] = fmaf(wj, J[col], acc[k]);
+  }
   const float wr = w * raw;
-  for (int i = 0; i < 6; ++i) b[i] += wr * J[i];
+  for (int i = 0; i < 6; ++i) acc[21 + i] = fmaf(wr, J[i], acc[21 + i]);
 }
 static inline void add_residual_d(double* H, double* b, float raw, float w, const float* J) {
   int k = 0;
@@ -17,6 +32,18 @@ static inline void add_residual_d(double* H, double* b, float raw, float w, cons
   const float wr = w * raw;
   for (int i = 0; i < 6; ++i) b[i] += (double)(wr * J[i]);
 }
+/* Sum of 64 lane values in the order of the backend's wave64 reduction (wave_reduce.h: wave_reduce28). */
+float orc_tile_tree_sum(const float x[64]) {
+  float A[8];
+  for (int c = 0; c < 8; ++c) {
+    const float* v = x + c;   /* lanes c + 8 m, m = 0..7: v[8 m] */
+    const float s04 = v[0] + v[32], s26 = v[16] + v[48], s15 = v[8] + v[40], s37 = v[24] + v[56];
+    A[c] = (s04 + s26) + (s15 + s37);
+  }
+  const float B0 = A[0] + A[7], B1 = A[1] + A[6], B2 = A[2] + A[5], B3 = A[3] + A[4];
+  return (B0 + B2) + (B1 + B3);
+}
+#define ORC_HB_FIXED_SCALE 65536.0
 
 /* B/kernel_opt_pose.cc:39-97, kernel B/kernel_opt_pose.cu:251-383. */
 uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camera* color_cam,
@@ -25,48 +52,58 @@ uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camer
                                     float H[21], float b[6], float* residual_sum, int accumulate_double) {
   proj_params p = make_proj_params(depth_cam, dp, s, kf, F);
   const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
-  float Hf[21] = {0}, bf[6] = {0};
+  long long fixed[27] = {0};
   double Hd[21] = {0}, bd[6] = {0};
   double cost = 0;
   uint32_t count = 0;
-  for (uint32_t i = 0; i < s->surfels_size; ++i) {
-    proj_result r;
-    if (!orc_project_associate(&p, i, &r, NULL)) continue;
-    ++count;
-    float J[6], raw;
-    if (use_depth) {
-      const v3 nl = m34_rotate(F, r.normal);
-      const float inv_std = depth_inv_stddev(unp_nx(&p.unp, (float)r.px), unp_ny(&p.unp, (float)r.py),
-                                             r.calibrated_depth, nl, dp->baseline_fx);
-      const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
-      raw = inv_std * v3_dot(nl, v3_sub(u, r.local_position));
-      jac_depth_pose(nl, u, inv_std, J);
-      const float w = depth_residual_weight(raw);
-      if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else add_residual_f(Hf, bf, raw, w, J);
-      cost += weighted_depth_residual(raw);
-    }
-    if (use_desc) {
+  for (uint32_t tile = 0; tile < s->surfels_size; tile += 64) {
+    float lanes[27][64];
+    int any = 0;
+    memset(lanes, 0, sizeof(lanes));
+    for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
+      const uint32_t i = tile + lane;
+      proj_result r;
+      if (!orc_project_associate(&p, i, &r, NULL)) continue;
+      ++count;
+      any = 1;
+      float acc[27] = {0};
+      float J[6], raw;
+      if (use_depth) {
+        const v3 nl = m34_rotate(F, r.normal);
+        const float inv_std = depth_inv_stddev(unp_nx(&p.unp, (float)r.px), unp_ny(&p.unp, (float)r.py),
+                                               r.calibrated_depth, nl, dp->baseline_fx);
+        const v3 u = unp_point(&p.unp, r.px, r.py, r.calibrated_depth);
+        raw = inv_std * v3_dot(nl, v3_sub(u, r.local_position));
+        jac_depth_pose(nl, u, inv_std, J);
+        const float w = depth_residual_weight(raw);
+        if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else acc_residual(acc, raw, w, J);
+        cost += weighted_depth_residual(raw);
+      }
       float c[2];
       /* B/kernel_opt_pose.cu:303-353: if the colour-pixel transform fails, nothing is added. */
-      if (!transform_depth_to_color(r.pxx, r.pxy, &d2c, &c[0], &c[1])) continue;
-      float t1[2], t2[2], raw1, raw2, g[4];
-      orc_tangent_projections(r.global_position, r.normal, srow(s, ORC_SURFEL_RADIUS_SQ)[i], F, color_cam, t1, t2);
-      orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &raw1, &raw2);
-      orc_descriptor_gradient(kf, c, t1, t2, g);
-      const v3 ls = r.local_position;
-      for (int k = 0; k < 2; ++k) {
-        const float gx = g[2 * k + 0] * color_cam->fx;
-        const float gy = g[2 * k + 1] * color_cam->fy;
-        jac_descriptor_pose(ls, gx, gy, J);
-        raw = k ? raw2 : raw1;
-        const float w = descriptor_residual_weight(raw);
-        if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else add_residual_f(Hf, bf, raw, w, J);
+      if (use_desc && transform_depth_to_color(r.pxx, r.pxy, &d2c, &c[0], &c[1])) {
+        float t1[2], t2[2], raw1, raw2, g[4];
+        orc_tangent_projections(r.global_position, r.normal, srow(s, ORC_SURFEL_RADIUS_SQ)[i], F, color_cam, t1, t2);
+        orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &raw1, &raw2);
+        orc_descriptor_gradient(kf, c, t1, t2, g);
+        const v3 ls = r.local_position;
+        for (int k = 0; k < 2; ++k) {
+          const float gx = g[2 * k + 0] * color_cam->fx;
+          const float gy = g[2 * k + 1] * color_cam->fy;
+          jac_descriptor_pose(ls, gx, gy, J);
+          raw = k ? raw2 : raw1;
+          const float w = descriptor_residual_weight(raw);
+          if (accumulate_double) add_residual_d(Hd, bd, raw, w, J); else acc_residual(acc, raw, w, J);
+        }
+        cost += weighted_descriptor_residual(raw1);
       }
-      cost += weighted_descriptor_residual(raw1);
+      for (int q = 0; q < 27; ++q) lanes[q][lane] = acc[q];
     }
+    if (any && !accumulate_double)
+      for (int q = 0; q < 27; ++q) fixed[q] += llrint((double)orc_tile_tree_sum(lanes[q]) * ORC_HB_FIXED_SCALE);
   }
-  for (int k = 0; k < 21; ++k) H[k] = accumulate_double ? (float)Hd[k] : Hf[k];
-  for (int k = 0; k < 6; ++k) b[k] = accumulate_double ? (float)bd[k] : bf[k];
+  for (int k = 0; k < 21; ++k) H[k] = accumulate_double ? (float)Hd[k] : (float)((double)fixed[k] * (1.0 / ORC_HB_FIXED_SCALE));
+  for (int k = 0; k < 6; ++k) b[k] = accumulate_double ? (float)bd[k] : (float)((double)fixed[21 + k] * (1.0 / ORC_HB_FIXED_SCALE));
   if (residual_sum) *residual_sum = (float)cost;
   return count;
 }

@@ -83,6 +83,11 @@ def test_bundle_adjustment_fixed_surfels(scene, use_pcg):
         dpos = np.abs(got[:3] - ref[:3]).max(axis=0)
         flips = np.count_nonzero(dpos > 1e-5)
         assert flips <= 1e-3 * ref.shape[1], (flips, np.quantile(dpos, [0.5, 0.99, 1.0]))
+        # those are the north-star gates; every stage of the alternating scheme is a defined computation on both sides
+        # (geometry: four-class sums; poses: tile tree + fixed point, binary64 solve, defined sin / cos), so five
+        # iterations plus the end-of-scheme tasks end in the same bits
+        assert np.array_equal(np.asarray(got_poses, np.float32), np.asarray(ref_poses, np.float32))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     else:
         # PCG: binary32 conjugate gradients are chaotic with respect to summation order (the reference is
         # run-to-run non-deterministic for the same reason) and the joint system has near-gauge modes, so
@@ -112,4 +117,7 @@ def test_bundle_adjustment_with_surfel_updates(scene):
     K = len(perturbed)
     got_poses = [ba.keyframe_pose(k) for k in range(K)]
     ref_poses = [orc.pose(k) for k in range(K)]
-    assert _translation_rmse(got_poses, ref_poses) <= 2e-5
+    assert _translation_rmse(got_poses, ref_poses) <= 1e-5
+    assert np.array_equal(np.asarray(got_poses, np.float32), np.asarray(ref_poses, np.float32))
+    got, ref = ba.download_surfels(8), orc.surfel_data[:8, :orc.surfels_size]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

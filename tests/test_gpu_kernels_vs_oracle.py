@@ -78,11 +78,15 @@ def test_pose_coefficients(synced, use_depth, use_desc, pose_parts, request):
     for k in range(len(ba.keyframes)):
         F = np.array(list(ba.keyframes[k].frame_T_global), np.float32)
         H_ref, b_ref, n, _ = ba.accumulate_pose_coeffs(k, accumulate_double=True)
+        H_def, b_def, _, _ = ba.accumulate_pose_coeffs(k, accumulate_double=False)
         H, b = g.accumulate_pose_coeffs(k, use_depth, use_desc, F)
         assert n > 1000
-        # per-pair terms are bit-identical to the oracle's; only the summation order differs
-        # (binary32 wave/atomic tree vs the oracle's binary64 running sum)
-        assert np.allclose(H, H_ref, rtol=0, atol=2e-6 * np.abs(H_ref).max())
+        # the sum is DEFINED (per-surfel fma chains, 64-surfel tile tree, fixed-point total; ba_device.h HbFixed, oracle_pose.c):
+        # the same bits on both sides, for every launch shape
+        assert np.array_equal(np.asarray(H, np.float32), np.asarray(H_def, np.float32)), np.abs(H - H_def).max()
+        assert np.array_equal(np.asarray(b, np.float32), np.asarray(b_def, np.float32)), np.abs(b - b_def).max()
+        # and it is the sum: the oracle's plain binary64 running sum agrees to binary32 precision
+        assert np.allclose(H, H_ref, rtol=0, atol=2e-7 * np.abs(H_ref).max())
         x_ref = np.linalg.solve(_full(H_ref), b_ref)
         x = np.linalg.solve(_full(H), b)
         assert np.abs(x - x_ref).max() < 1e-6   # "one GN pose step 1e-6 on the tangent" 
@@ -134,8 +138,8 @@ def test_batched_pose_estimation_matches_oracle(scene):
     poses, its, conv, rounds = g.estimate_keyframe_poses(True, True)
     for k in range(len(perturbed)):
         est, its_ref, conv_ref = ba.estimate_frame_pose(k, perturbed[k])
-        err = common.pose_error(est.to_array(), poses[k])
-        assert np.abs(err).max() < 1e-6, (k, err)
+        # defined normal-equation sums + binary64 solve + defined sin / cos: the same pose, bit for bit
+        assert np.array_equal(poses[k].astype(np.float32), est.to_array().astype(np.float32)), (k, common.pose_error(est.to_array(), poses[k]))
         assert its[k] == its_ref
         # and both recover the ground truth to well below the 5 mm perturbation
         gt_err = common.pose_error(scene.poses_gt[k], poses[k])
@@ -149,6 +153,7 @@ def test_wave_reductions():
     column totals; the xor-butterfly wave_sum returns exactly the classic pairing's rounding."""
     import ctypes as C
     from badslam_amd import capi, lowlevel
+    from oracle import binding as ob
     ctx = lowlevel.Context()
     rng = np.random.default_rng(5)
     for trial in range(3):
@@ -162,6 +167,12 @@ def test_wave_reductions():
             assert np.array_equal(out[:28], exact) and np.array_equal(out[28:56], exact)
             assert np.array_equal(out[56:64], exact[:8]) and np.array_equal(out[64:80], exact[:16])   # wave_reduce_small<8>, <16>
         else:
+            # the halving reduction is a fixed tree over the lanes: distance 32, 16, 8, then i <-> 7 - i inside groups of 8,
+            # then distance 2, 1 (the oracle's orc_tile_tree_sum restates it; the pose sums are defined by it)
+            L = ob.lib()
+            L.orc_tile_tree_sum.restype = C.c_float
+            tree = np.array([L.orc_tile_tree_sum(np.ascontiguousarray(x[:, q]).ctypes.data_as(C.POINTER(C.c_float))) for q in range(28)], np.float32)
+            assert np.array_equal(out[:28], tree)
             assert np.abs(out[:28] - exact).max() < 2e-5
             assert np.abs(out[56:64] - exact[:8]).max() < 2e-5 and np.abs(out[64:80] - exact[:16]).max() < 2e-5
             v = x.copy()   # classic butterfly, binary32: xor 32, 16, 8, 4, 2, 1
