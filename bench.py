@@ -207,7 +207,11 @@ def main():
     ctx = ba.backend_context()
     hook_keepalive = None
     if dist is not None:
-        hook_keepalive = multigpu.install_allreduce(ctx, dist)
+        if dist.get_backend() == "nccl" and not os.environ.get("BENCH_ALLREDUCE_HOOK"):
+            # native path: the backend owns an RCCL communicator and issues ncclAllReduce on its own stream
+            multigpu.init_rccl(ctx, dist)
+        else:
+            hook_keepalive = multigpu.install_allreduce(ctx, dist)
     K = args.keyframes
 
     def run(iterations):

@@ -73,5 +73,6 @@ def test_reductions_use_the_gfx950_cross_lane_instructions(listings):
     body = next(v[0] for k, v in kernels.items() if "pose_accumulate_kernelILb1ELb1" in k)
     assert "v_permlane32_swap" in body and "v_permlane16_swap" in body and "dpp" in body
     assert "ds_bpermute" not in body                                             # no LDS round trips in the reduction
-    assert "global_atomic_add_f32" in body                                       # -munsafe-fp-atomics: hardware float atomics
-    assert "global_atomic_cmpswap" not in body                                   # ... not a compare-and-swap loop
+    assert "global_atomic_add_x2" in body                                        # 64-bit integer atomics on the fixed-point totals
+    assert "global_atomic_add_f32" not in body                                   # ... no float atomics (order-dependent sums)
+    assert "global_atomic_cmpswap" not in body                                   # ... and no compare-and-swap loop
