@@ -207,6 +207,10 @@ __device__ __forceinline__ Vec3 mul33(const float* R, Vec3 p) {
 // B/util.cuh:62-69
 __device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t raw) {
   const float inv_depth = 1.0f / (raw_to_float_depth * raw);
+  // a == 0 (wave-uniform: a kernel argument; the value of every run that has not optimised the depth intrinsics):
+  // exp(-0 * inv_depth) is exactly 1 for every finite inv_depth, so the exponential is skipped -- the same bits; raw == 0
+  // (inv_depth = inf, -0 * inf = NaN) keeps its NaN.
+  if (a == 0.f) return 1.f / mad(cfactor, (raw == 0) ? __builtin_nanf("") : 1.f, inv_depth);
   return 1.f / mad(cfactor, expf(-a * inv_depth), inv_depth);
 }
 __device__ __forceinline__ float cfactor_at(const Intrinsics& in, int px, int py) {
@@ -243,6 +247,7 @@ __device__ __forceinline__ float descriptor_residual_weight(float r) { return 1.
 // ---- association -----------------------------------------------------------------------------------
 struct Assoc {
   Vec3 local;        // surfel position in the keyframe frame
+  float inv_z;       // 1 / local.z (IEEE), shared by the projection and the descriptor Jacobians
   Vec3 nl;           // surfel normal in the keyframe frame
   float depth;       // calibrated depth of the associated pixel
   int px, py;
@@ -261,6 +266,7 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   r->local.x = mad(F[2], gp.z, mad(F[1], gp.y, mad(F[0], gp.x, F[3])));
   r->local.y = mad(F[6], gp.z, mad(F[5], gp.y, mad(F[4], gp.x, F[7])));
   const float inv_z = 1.f / r->local.z;   // one reciprocal shared by both coordinates (and by the Jacobians), as in the oracle
+  r->inv_z = inv_z;
   r->pxx = mad(in.fx, r->local.x * inv_z, in.cx);
   r->pxy = mad(in.fy, r->local.y * inv_z, in.cy);
   if (!(r->pxx >= 0.f) || !(r->pxy >= 0.f) || !(r->pxx < (float)in.width) || !(r->pxy < (float)in.height)) return false;
@@ -456,8 +462,9 @@ __device__ __forceinline__ void jac_depth_pose(Vec3 nl, Vec3 u, float inv_std, f
   J[5] = inv_std * mad(nl.y, u.x, -(nl.x * u.y));
 }
 // B/kernel_opt_pose.cu:126-141: ls = surfel position in the keyframe frame, gx, gy = image gradient of the residual times fx, fy.
-__device__ __forceinline__ void jac_descriptor_pose(Vec3 ls, float gx, float gy, float (&J)[6]) {
-  const float inv_z = 1.f / ls.z, z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
+// inv_z = 1.f / ls.z: the hot kernels pass the reciprocal the projection already computed (Assoc::inv_z, the same value).
+__device__ __forceinline__ void jac_descriptor_pose(Vec3 ls, float inv_z, float gx, float gy, float (&J)[6]) {
+  const float z_sq = ls.z * ls.z, inv_z_sq = inv_z * inv_z, xy = ls.x * ls.y;
   J[0] = -gx * inv_z;
   J[1] = -gy * inv_z;
   J[2] = mad(ls.y, gy, ls.x * gx) * inv_z_sq;
@@ -465,12 +472,18 @@ __device__ __forceinline__ void jac_descriptor_pose(Vec3 ls, float gx, float gy,
   J[4] = -mad(mad(ls.x, ls.x, z_sq), gx, xy * gy) * inv_z_sq;
   J[5] = -mad(ls.x, gy, -(ls.y * gx)) * inv_z;
 }
+__device__ __forceinline__ void jac_descriptor_pose(Vec3 ls, float gx, float gy, float (&J)[6]) {
+  jac_descriptor_pose(ls, 1.f / ls.z, gx, gy, J);
+}
 // B/kernel_opt_geometry.cu:170-190: rn = surfel normal, lp = surfel position in the keyframe frame, g = gradient per pixel.
-__device__ __forceinline__ float jac_descriptor_surfel(Vec3 rn, Vec3 lp, float gx, float gy, float cfx, float cfy) {
+__device__ __forceinline__ float jac_descriptor_surfel(Vec3 rn, Vec3 lp, float inv_z, float gx, float gy, float cfx, float cfy) {
   const float term1 = -cfx * mad(rn.x, lp.z, -(rn.z * lp.x));
   const float term2 = -cfy * mad(rn.y, lp.z, -(rn.z * lp.y));
-  const float inv_z = 1.f / lp.z, term3 = inv_z * inv_z;
+  const float term3 = inv_z * inv_z;
   return -mad(gy, term2, gx * term1) * term3;
+}
+__device__ __forceinline__ float jac_descriptor_surfel(Vec3 rn, Vec3 lp, float gx, float gy, float cfx, float cfy) {
+  return jac_descriptor_surfel(rn, lp, 1.f / lp.z, gx, gy, cfx, cfy);
 }
 // B/kernel_opt_intrinsics.cu:107-140: rows fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor.
 __device__ __forceinline__ void jac_depth_intrinsics(int px, int py, float depth, float inv_std, float n_dot_Frow0, float n_dot_Frow1,

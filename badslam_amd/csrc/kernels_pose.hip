@@ -101,7 +101,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
             const float gx = (t ? e.gx2 : e.gx1) * in.cfx;
             const float gy = (t ? e.gy2 : e.gy1) * in.cfy;
             const float raw = t ? e.r2 : e.r1;
-            jac_descriptor_pose(ls, gx, gy, J);
+            jac_descriptor_pose(ls, r.inv_z, gx, gy, J);
             const float wgt = descriptor_residual_weight(raw);
             accumulate_jtj(acc, J, wgt, raw);
           }

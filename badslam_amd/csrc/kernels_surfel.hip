@@ -286,8 +286,8 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
       if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
         DescEval e;
         eval_descriptor<true>(in, kfs[k].lumafp, F, tp, cx, cy, d1, d2, &e);
-        const float jp1 = jac_descriptor_surfel(r.nl, r.local, e.gx1, e.gy1, in.cfx, in.cfy);
-        const float jp2 = jac_descriptor_surfel(r.nl, r.local, e.gx2, e.gy2, in.cfx, in.cfy);
+        const float jp1 = jac_descriptor_surfel(r.nl, r.local, r.inv_z, e.gx1, e.gy1, in.cfx, in.cfy);
+        const float jp2 = jac_descriptor_surfel(r.nl, r.local, r.inv_z, e.gx2, e.gy2, in.cfx, in.cfy);
         const float jd = -1.f;
         const float w1 = descriptor_residual_weight(e.r1);
         const float wr1 = w1 * e.r1;
