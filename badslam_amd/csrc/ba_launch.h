@@ -45,6 +45,7 @@ void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
 void set_pose_parts(int parts);   // 0 = automatic; 1 | 2 | 4 | 8 wavefronts share a tile's keyframes in the pose kernel
 void launch_jacobian_debug(hipStream_t stream, int kind, const float* in, float* out);
+void launch_pose_step_debug(hipStream_t stream, const float* in, float* out);
 void launch_wave_reduce_debug(hipStream_t stream, const float* in, float* out);
 void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
                            const uint32_t* indices, int count, float* out);

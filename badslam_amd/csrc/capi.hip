@@ -1174,6 +1174,22 @@ int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in
   return 0;
 }
 
+int bahip_debug_pose_step(bahip_context* ctx, const float* H21_b6, const float* global_T_frame, float* out_25) {
+  float *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_in, 34 * sizeof(float)));
+  if (hipMalloc(&d_out, 25 * sizeof(float)) != hipSuccess) { hipFree(d_in); return fail("hipMalloc failed", __FILE__, __LINE__); }
+  float in[34];
+  memcpy(in, H21_b6, 27 * sizeof(float));
+  memcpy(in + 27, global_T_frame, 7 * sizeof(float));
+  hipError_t e = hipMemcpyAsync(d_in, in, sizeof(in), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) { launch_pose_step_debug(ctx->stream, d_in, d_out); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_25, d_out, 25 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_in); hipFree(d_out);
+  if (e != hipSuccess) return fail("bahip_debug_pose_step", __FILE__, __LINE__, e);
+  return 0;
+}
+
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_80) {
   float *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, 64 * 28 * sizeof(float)));

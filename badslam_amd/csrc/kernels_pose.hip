@@ -159,28 +159,36 @@ __device__ void ldlt_solve(double* A, const double* b, double* x) {
   for (int c = 0; c < N; ++c) x[perm[c]] = y[c];
 }
 
-// One GN update per work item: B/direct_ba_alternating.cc:173-244.
+// One Gauss-Newton update of a pose: B/direct_ba_alternating.cc:173-244.  hb = H (21, row-major upper triangle) and b (6) in
+// binary32 (what the reference hands to Eigen: H.cast<double>()...ldlt().solve(b.cast<double>())); x = the binary32 step,
+// T_next = T * exp(-x).
+__device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* T_next) {
+  double A[36], b[6], x[6];
+  int q = 0;
+  for (int row = 0; row < 6; ++row)
+    for (int col = row; col < 6; ++col) { const double v = (double)hb[q]; A[row * 6 + col] = v; A[col * 6 + row] = v; ++q; }
+  for (int c = 0; c < 6; ++c) b[c] = (double)hb[21 + c];
+  ldlt_solve<6>(A, b, x);
+  float mx[6];
+  for (int c = 0; c < 6; ++c) { xf[c] = (float)x[c]; mx[c] = -1.f * xf[c]; }
+  float upd[7];
+  se3_exp(mx, upd);
+  se3_mul(T, upd, T_next);
+}
+
 __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
                                   KfEntry* __restrict__ frames, int write_back, int* __restrict__ not_done_count) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= num_work) return;
   PoseWork& pw = work[w];
   if (pw.done) return;
-  HbFixed* hb = Hb + (size_t)w * kHbStride;
-  double A[36], b[6], x[6];
-  int q = 0;
-  // the reference hands binary32 H, b to the binary64 solve (H.cast<double>(), B/direct_ba_alternating.cc:206): the
-  // fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
-  for (int row = 0; row < 6; ++row)
-    for (int col = row; col < 6; ++col) { const double v = (double)(float)hb_from_fixed(hb[q]); A[row * 6 + col] = v; A[col * 6 + row] = v; ++q; }
-  for (int c = 0; c < 6; ++c) b[c] = (double)(float)hb_from_fixed(hb[21 + c]);
-  for (int c = 0; c < kHbStride; ++c) hb[c] = 0;
-  ldlt_solve<6>(A, b, x);
-  float xf[6], mx[6];
-  for (int c = 0; c < 6; ++c) { xf[c] = (float)x[c]; mx[c] = -1.f * xf[c]; }
-  float upd[7], next[7];
-  se3_exp(mx, upd);
-  se3_mul(pw.T, upd, next);
+  HbFixed* fixed = Hb + (size_t)w * kHbStride;
+  float hb[27];
+  // the fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
+  for (int c = 0; c < 27; ++c) hb[c] = (float)hb_from_fixed(fixed[c]);
+  for (int c = 0; c < kHbStride; ++c) fixed[c] = 0;
+  float xf[6], next[7];
+  pose_gn_step(hb, pw.T, xf, next);
   for (int c = 0; c < 7; ++c) pw.T[c] = next[c];
   float inv[7];
   se3_inverse(next, inv);
@@ -199,6 +207,23 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
   } else {
     atomicAdd(not_done_count, 1);
   }
+}
+
+// Test hook: pose_gn_step on explicit inputs.  in = hb[27] | T[7]; out = x[6] | T_next[7] | frame_T_global of T_next [12].
+__global__ void pose_step_debug_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float hb[27], T[7], xf[6], next[7], inv[7], F[12];
+  for (int c = 0; c < 27; ++c) hb[c] = in[c];
+  for (int c = 0; c < 7; ++c) T[c] = in[27 + c];
+  pose_gn_step(hb, T, xf, next);
+  se3_inverse(next, inv);
+  se3_matrix3x4(inv, F);
+  for (int c = 0; c < 6; ++c) out[c] = xf[c];
+  for (int c = 0; c < 7; ++c) out[6 + c] = next[c];
+  for (int c = 0; c < 12; ++c) out[13 + c] = F[c];
+}
+void launch_pose_step_debug(hipStream_t stream, const float* in, float* out) {
+  hipLaunchKernelGGL(pose_step_debug_kernel, dim3(1), dim3(64), 0, stream, in, out);
 }
 
 // Builds one work item per bound keyframe (skipping kInactive ones), B/direct_ba_alternating.cc:547-553.

@@ -295,6 +295,9 @@ int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in
  * (wave_reduce.h), out[28..55] = the same totals from the xor-butterfly wave_sum, out[56..63] / out[64..79] = totals of the
  * first 8 / 16 columns from the small halving reductions the PCG sweeps use (wave_reduce_small<8>, <16>). */
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_80);
+/* One Gauss-Newton pose update with the device code of the pose solve (binary64 LDLT of the binary32 H (21) | b (6), x as
+ * binary32, T <- T * exp(-x) with the defined sin / cos): out = x[6] | T_next[7] | frame_T_global(T_next)[12]. */
+int bahip_debug_pose_step(bahip_context* ctx, const float* H21_b6, const float* global_T_frame, float* out_25);
 int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out);
 
 /* ---- instrumentation ---------------------------------------------------------------------------- */

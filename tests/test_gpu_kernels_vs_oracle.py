@@ -261,3 +261,51 @@ def test_assign_colors_matches_oracle():
     assert (got[5, 50:].view(np.uint32) != data[5, 50:].view(np.uint32)).mean() > 0.95           # seen: reassigned
     for row in (0, 1, 2, 3, 4, 6, 7):                                                              # nothing else written
         assert np.array_equal(got[row].view(np.uint32), data[row].view(np.uint32))
+
+
+def _oracle_gn_step(hb, T):
+    """The oracle's restatement of one pose update (oracle_pose.c: orc_estimate_frame_pose's loop body)."""
+    import ctypes as C
+    from oracle import binding as ob
+    L = ob.lib()
+    H = np.zeros((6, 6))
+    H[np.triu_indices(6)] = np.asarray(hb[:21], np.float32).astype(np.float64)
+    H = H + np.triu(H, 1).T
+    b = np.asarray(hb[21:27], np.float32).astype(np.float64)
+    x = np.zeros(6)
+    L.orc_ldlt_solve(6, np.ascontiguousarray(H).ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
+                     x.ctypes.data_as(C.POINTER(C.c_double)))
+    xf = x.astype(np.float32)
+    mx = (np.float32(-1.0) * xf).astype(np.float32)
+    nxt = ob.se3_mul(ob.SE3.from_array(T), ob.se3_exp(mx))
+    F = ob.se3_matrix3x4(ob.se3_inverse(nxt))
+    return xf, nxt.to_array().astype(np.float32), F
+
+
+def test_pose_update_step_bit_exact():
+    """The device code of the pose solve (binary64 LDLT with Eigen's pivoting and pseudo-inverse rule, x -> binary32,
+    T * exp(-x) with the defined sin / cos, the inverse and its 3x4 matrix) against the oracle, on explicit inputs: realistic
+    normal equations, tiny and large steps (both branches of the exponential map), rank-deficient systems."""
+    import ctypes as C
+    from badslam_amd import capi, lowlevel
+    ctx = lowlevel.Context()
+    rng = np.random.default_rng(17)
+    cases = 0
+    for trial in range(400):
+        J = rng.standard_normal((40, 6)) * rng.choice([1.0, 30.0, 1e3]) * np.array([1, 1, 1, 3, 3, 3])
+        if trial % 10 == 7:
+            J[:, rng.integers(0, 6)] = 0.0                      # a direction without any constraint: zero pivot
+        H = (J.T @ J).astype(np.float32)
+        step = rng.standard_normal(6) * rng.choice([1e-7, 1e-5, 1e-3, 0.05, 1.0])
+        b = (H.astype(np.float64) @ step).astype(np.float32)
+        hb = np.concatenate([H[np.triu_indices(6)], b]).astype(np.float32)
+        T = se3.exp(rng.standard_normal(6) * np.array([1, 1, 1, 0.5, 0.5, 0.5])).astype(np.float32)
+        out = np.zeros(25, np.float32)
+        capi.check(ctx.lib.bahip_debug_pose_step(ctx.handle, hb.ctypes.data_as(C.POINTER(C.c_float)), T.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 out.ctypes.data_as(C.POINTER(C.c_float))))
+        xf, nxt, F = _oracle_gn_step(hb, T)
+        assert np.array_equal(out[:6].view(np.uint32), xf.view(np.uint32)), (trial, out[:6], xf)
+        assert np.array_equal(out[6:13].view(np.uint32), nxt.view(np.uint32)), (trial, out[6:13], nxt)
+        assert np.array_equal(out[13:25].view(np.uint32), np.asarray(F, np.float32).view(np.uint32)), (trial, out[13:25], F)
+        cases += 1
+    assert cases == 400
