@@ -158,8 +158,11 @@ void orc_se3_exp(const float a[6], orc_se3* out) {
     const float c2 = (theta - sin_theta) / (theta_sq * theta);
     for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + c1 * Om[i] + c2 * Om2[i];
   }
-  v3 t = m33_mul(V, v3_make(a[0], a[1], a[2]));
-  r.t[0] = t.x; r.t[1] = t.y; r.t[2] = t.z;
+  /* V * upsilon as a plain (unfused) matrix-vector product, like the rest of this SE(3) arithmetic (host-side Eigen /
+   * Sophus code in the reference); m33_mul of oracle_internal.h is the fused chain of the device kernels and is NOT used here */
+  r.t[0] = V[0] * a[0] + V[1] * a[1] + V[2] * a[2];
+  r.t[1] = V[3] * a[0] + V[4] * a[1] + V[5] * a[2];
+  r.t[2] = V[6] * a[0] + V[7] * a[1] + V[8] * a[2];
   *out = r;
 }
 
@@ -193,8 +196,10 @@ void orc_se3_log(const orc_se3* T, float out[6]) {
     c = (1.f - theta * cos_half_theta / (2.f * sin_half_theta)) / (theta * theta);
   }
   for (int i = 0; i < 9; ++i) Vinv[i] = ((i % 4 == 0) ? 1.f : 0.f) - 0.5f * Om[i] + c * Om2[i];
-  v3 u = m33_mul(Vinv, v3_make(T->t[0], T->t[1], T->t[2]));
-  out[0] = u.x; out[1] = u.y; out[2] = u.z; out[3] = ox; out[4] = oy; out[5] = oz;
+  out[0] = Vinv[0] * T->t[0] + Vinv[1] * T->t[1] + Vinv[2] * T->t[2];
+  out[1] = Vinv[3] * T->t[0] + Vinv[4] * T->t[1] + Vinv[5] * T->t[2];
+  out[2] = Vinv[6] * T->t[0] + Vinv[7] * T->t[1] + Vinv[8] * T->t[2];
+  out[3] = ox; out[4] = oy; out[5] = oz;
 }
 
 /* B/keyframe.h:160-165 with libvis/src/libvis/image_frame.h:84-94 (both directions cached) */
