@@ -51,6 +51,32 @@ __device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {
   return mk3(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
 }
 
+// ---- exact reciprocal and square root in few instructions ----------------------------------------------------------
+// The sweeps are VALU-issue bound, and the compiler's IEEE sequences for 1.f / x (11 instructions: two v_div_scale, v_rcp,
+// five fused multiply-adds, v_div_fmas, v_div_fixup) and sqrtf (16) spend most of them on operands that cannot occur here
+// (denormal inputs / results, 2^-126 scalings).  On normal operands the hardware approximation (<= 1 ulp) followed by one
+// fused Newton step IS the correctly rounded result (Markstein's theorem for the reciprocal; the sqrt keeps the compiler's
+// own residual test over s - 1 ulp, s, s + 1 ulp).  tests/test_gpu_exact_math.py checks both against IEEE division / sqrtf
+// for EVERY binary32 significand (2^23 values per binade) on the device, so parity with the oracle's `1.f / x` and
+// `sqrtf(x)` stays bit for bit.  Domain: |x| and 1 / |x| normal (2^-126 < |x| < 2^126), or 0 / inf / NaN, which get the
+// hardware's IEEE result.
+__device__ __forceinline__ float rcp_exact(float x) {
+  const float y0 = __builtin_amdgcn_rcpf(x);
+  const float e = __builtin_fmaf(-x, y0, 1.f);
+  const float y1 = __builtin_fmaf(e, y0, y0);
+  return (e == e) ? y1 : y0;            // x = 0, inf, NaN: e is NaN and v_rcp_f32 already returned inf, 0, NaN
+}
+// x in [2^-96, 2^127) or 0 (the range in which the compiler's sequence does not rescale).
+__device__ __forceinline__ float sqrt_exact(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_dn = __builtin_fmaf(-dn, s, x);
+  const float r_up = __builtin_fmaf(-up, s, x);
+  float t = (0.f >= r_dn) ? dn : s;
+  t = (0.f < r_up) ? up : t;
+  return (x == 0.f) ? x : t;
+}
+
 // Pose of one keyframe as the kernels consume it: frame_T_global (3x4 row-major) and
 // global_R_frame (3x3 row-major), both cached whenever the pose is set (B/keyframe.h:160-172).
 struct KfPose {
@@ -177,7 +203,7 @@ __device__ __forceinline__ Vec3 unpack_normal8(uint16_t v) {
   r.x = (float)(int8_t)(v & 0xff) * (1.0f / 127.0f);
   r.y = (float)(int8_t)(v >> 8) * (1.0f / 127.0f);
   const float z = 1 - r.x * r.x - r.y * r.y;
-  r.z = -sqrtf((z > 0.f) ? z : 0.f);
+  r.z = -sqrt_exact((z > 0.f) ? z : 0.f);   // z is 0 or >= 2^-24 (x, y are multiples of 1 / 127): inside sqrt_exact's range
   return r;
 }
 __device__ __forceinline__ uint16_t pack_normal8(float x, float y) {
@@ -206,12 +232,12 @@ __device__ __forceinline__ Vec3 mul33(const float* R, Vec3 p) {
 // ---- depth ---------------------------------------------------------------------------------------
 // B/util.cuh:62-69
 __device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t raw) {
-  const float inv_depth = 1.0f / (raw_to_float_depth * raw);
+  const float inv_depth = rcp_exact(raw_to_float_depth * raw);
   // a == 0 (wave-uniform: a kernel argument; the value of every run that has not optimised the depth intrinsics):
   // exp(-0 * inv_depth) is exactly 1 for every finite inv_depth, so the exponential is skipped -- the same bits; raw == 0
   // (inv_depth = inf, -0 * inf = NaN) keeps its NaN.
-  if (a == 0.f) return 1.f / mad(cfactor, (raw == 0) ? __builtin_nanf("") : 1.f, inv_depth);
-  return 1.f / mad(cfactor, expf(-a * inv_depth), inv_depth);
+  if (a == 0.f) return rcp_exact(mad(cfactor, (raw == 0) ? __builtin_nanf("") : 1.f, inv_depth));
+  return rcp_exact(mad(cfactor, expf(-a * inv_depth), inv_depth));
 }
 __device__ __forceinline__ float cfactor_at(const Intrinsics& in, int px, int py) {
   // px, py >= 0, so the shift is the same integer division
@@ -265,7 +291,7 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   if (!(r->local.z > 0.f)) return false;
   r->local.x = mad(F[2], gp.z, mad(F[1], gp.y, mad(F[0], gp.x, F[3])));
   r->local.y = mad(F[6], gp.z, mad(F[5], gp.y, mad(F[4], gp.x, F[7])));
-  const float inv_z = 1.f / r->local.z;   // one reciprocal shared by both coordinates (and by the Jacobians), as in the oracle
+  const float inv_z = rcp_exact(r->local.z);   // == 1.f / z; one reciprocal shared by both coordinates (and by the Jacobians), as in the oracle
   r->inv_z = inv_z;
   r->pxx = mad(in.fx, r->local.x * inv_z, in.cx);
   r->pxy = mad(in.fy, r->local.y * inv_z, in.cy);
@@ -394,11 +420,11 @@ __device__ __forceinline__ TangentPoints surfel_tangent_points(Vec3 gp, Vec3 gn,
 __device__ __forceinline__ void project_tangents(const Intrinsics& in, const float* F, const TangentPoints& tp,
                                                  float* t1x, float* t1y, float* t2x, float* t2y) {
   const Vec3 l1 = transform34(F, tp.q1);
-  const float inv_z1 = 1.f / l1.z;
+  const float inv_z1 = rcp_exact(l1.z);
   *t1x = mad(in.cfx, l1.x * inv_z1, in.ccx);
   *t1y = mad(in.cfy, l1.y * inv_z1, in.ccy);
   const Vec3 l2 = transform34(F, tp.q2);
-  const float inv_z2 = 1.f / l2.z;
+  const float inv_z2 = rcp_exact(l2.z);
   *t2x = mad(in.cfx, l2.x * inv_z2, in.ccx);
   *t2y = mad(in.cfy, l2.y * inv_z2, in.ccy);
 }

@@ -46,6 +46,7 @@ void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel 
 void set_pose_parts(int parts);   // 0 = automatic; 1 | 2 | 4 | 8 wavefronts share a tile's keyframes in the pose kernel
 void launch_jacobian_debug(hipStream_t stream, int kind, const float* in, float* out);
 void launch_pose_step_debug(hipStream_t stream, const float* in, float* out);
+void launch_exact_math_debug(hipStream_t stream, int kind, const float* in, float* out, size_t n);
 void launch_wave_reduce_debug(hipStream_t stream, const float* in, float* out);
 void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
                            const uint32_t* indices, int count, float* out);

@@ -1174,6 +1174,21 @@ int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in
   return 0;
 }
 
+int bahip_debug_exact_math(bahip_context* ctx, int kind, const float* in, float* out, size_t n) {
+  REQUIRE(kind == 0 || kind == 1, "bahip_debug_exact_math: kind must be 0 (reciprocal) or 1 (square root)");
+  if (n == 0) return 0;
+  float *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_in, n * sizeof(float)));
+  if (hipMalloc(&d_out, n * sizeof(float)) != hipSuccess) { hipFree(d_in); return fail("hipMalloc failed", __FILE__, __LINE__); }
+  hipError_t e = hipMemcpyAsync(d_in, in, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) { launch_exact_math_debug(ctx->stream, kind, d_in, d_out, n); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_in); hipFree(d_out);
+  if (e != hipSuccess) return fail("bahip_debug_exact_math", __FILE__, __LINE__, e);
+  return 0;
+}
+
 int bahip_debug_pose_step(bahip_context* ctx, const float* H21_b6, const float* global_T_frame, float* out_25) {
   float *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, 34 * sizeof(float)));

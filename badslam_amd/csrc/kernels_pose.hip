@@ -367,6 +367,15 @@ __global__ void jacobian_debug_kernel(int kind, const float* __restrict__ in, fl
   else if (kind == 3) { float J[6]; jac_depth_intrinsics((int)in[0], (int)in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], in[9], in[10], J); for (int c = 0; c < 6; ++c) out[c] = J[c]; }
   else if (kind == 4) { float J[4]; jac_descriptor_color_intrinsics(in[0], in[1], in[2], in[3], J); for (int c = 0; c < 4; ++c) out[c] = J[c]; }
 }
+// Debug: rcp_exact / sqrt_exact (ba_device.h) on n explicit inputs; kind 0 = reciprocal, 1 = square root.
+__global__ void exact_math_debug_kernel(int kind, const float* __restrict__ in, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = kind == 0 ? rcp_exact(in[i]) : sqrt_exact(in[i]);
+}
+void launch_exact_math_debug(hipStream_t stream, int kind, const float* in, float* out, size_t n) {
+  if (n) hipLaunchKernelGGL(exact_math_debug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, in, out, n);
+}
 void launch_jacobian_debug(hipStream_t stream, int kind, const float* in, float* out) {
   hipLaunchKernelGGL(jacobian_debug_kernel, dim3(1), dim3(64), 0, stream, kind, in, out);
 }

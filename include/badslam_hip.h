@@ -297,6 +297,9 @@ int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_80);
 /* One Gauss-Newton pose update with the device code of the pose solve (binary64 LDLT of the binary32 H (21) | b (6), x as
  * binary32, T <- T * exp(-x) with the defined sin / cos): out = x[6] | T_next[7] | frame_T_global(T_next)[12]. */
+/* rcp_exact (kind 0) / sqrt_exact (kind 1) of the device code on n host values (ba_device.h: the few-instruction exact
+ * reciprocal and square root the sweeps use instead of the compiler's IEEE sequences); checked exhaustively by the tests. */
+int bahip_debug_exact_math(bahip_context* ctx, int kind, const float* in, float* out, size_t n);
 int bahip_debug_pose_step(bahip_context* ctx, const float* H21_b6, const float* global_T_frame, float* out_25);
 int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out);
 

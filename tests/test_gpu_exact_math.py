@@ -1,0 +1,66 @@
+"""rcp_exact / sqrt_exact of ba_device.h (hardware approximation + one fused correction step, 5 and 8 instructions instead
+of the compiler's 11 and 16) must equal IEEE `1.f / x` and `sqrtf(x)` -- what the oracle computes -- for EVERY binary32
+significand: exhaustive over all 2^23 significands in several binades, plus the special values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, kind, x):
+    from badslam_amd import capi
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    capi.check(ctx.lib.bahip_debug_exact_math(ctx.handle, kind, x.ctypes.data_as(C.POINTER(C.c_float)),
+                                              out.ctypes.data_as(C.POINTER(C.c_float)), x.size))
+    return out
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from badslam_amd import lowlevel
+    return lowlevel.Context()
+
+
+@pytest.mark.parametrize("exponent", [-20, -3, -1, 0, 1, 2, 13, 40, -60, 100])
+def test_reciprocal_is_correctly_rounded_for_every_significand(ctx, exponent):
+    bits = (np.arange(1 << 23, dtype=np.uint32) | np.uint32((127 + exponent) << 23))
+    for sign in (0, 0x80000000):
+        x = (bits | np.uint32(sign)).view(np.float32)
+        got = _run(ctx, 0, x)
+        ref = (np.float32(1.0) / x).astype(np.float32)
+        bad = np.flatnonzero(got.view(np.uint32) != ref.view(np.uint32))
+        assert bad.size == 0, (exponent, sign, bad.size, x[bad[:5]], got[bad[:5]], ref[bad[:5]])
+
+
+def test_reciprocal_special_values(ctx):
+    x = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 1e-30, 1e30], np.float32)
+    got = _run(ctx, 0, x)
+    with np.errstate(divide="ignore"):
+        ref = (np.float32(1.0) / x).astype(np.float32)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok].view(np.uint32), ref[ok].view(np.uint32))
+
+
+@pytest.mark.parametrize("exponent", [-60, -24, -23, -2, -1, 0, 1, 2, 3, 30])
+def test_square_root_is_correctly_rounded_for_every_significand(ctx, exponent):
+    x = (np.arange(1 << 23, dtype=np.uint32) | np.uint32((127 + exponent) << 23)).view(np.float32)
+    got = _run(ctx, 1, x)
+    ref = np.sqrt(x).astype(np.float32)
+    bad = np.flatnonzero(got.view(np.uint32) != ref.view(np.uint32))
+    assert bad.size == 0, (exponent, bad.size, x[bad[:5]], got[bad[:5]], ref[bad[:5]])
+
+
+def test_square_root_of_every_packed_normal(ctx):
+    """The only hot-loop use: z = -sqrt(max(0, 1 - x^2 - y^2)) of the 2 x s8 packed measurement normals (all 65536 codes)."""
+    i, j = np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij")
+    x = (i.astype(np.float32) * np.float32(1.0 / 127.0)).astype(np.float32)
+    y = (j.astype(np.float32) * np.float32(1.0 / 127.0)).astype(np.float32)
+    z = (np.float32(1) - x * x - y * y).astype(np.float32)
+    z = np.where(z > 0, z, np.float32(0)).astype(np.float32).ravel()
+    got = _run(ctx, 1, z)
+    assert np.array_equal(got.view(np.uint32), np.sqrt(z).astype(np.float32).view(np.uint32))
+    assert got[z == 0].size > 0 and np.all(got[z == 0] == 0)
