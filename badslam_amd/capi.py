@@ -99,6 +99,7 @@ SIGNATURES = {
     "bahip_assign_colors": (C.c_int, [C.c_void_p, C.POINTER(Surfels)]),
     "bahip_update_surfel_normals": (C.c_int, [C.c_void_p, C.POINTER(Surfels)]),
     "bahip_optimize_geometry_iteration": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels)]),
+    "bahip_update_activation_and_optimize_geometry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.c_uint32]),
     "bahip_accumulate_pose_estimation_coeffs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Frame), C.POINTER(C.c_float),
                                                           C.POINTER(Surfels), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bahip_estimate_frame_pose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Frame), C.POINTER(C.c_float),

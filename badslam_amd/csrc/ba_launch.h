@@ -30,7 +30,7 @@ void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* 
 void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
 void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                     int num_kfs, const SurfelsView& s);
+                     int num_kfs, const SurfelsView& s, long long activate_count = -1);
 
 void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                         unsigned long long* counts);

@@ -695,6 +695,20 @@ int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth, int use
   return 0;
 }
 
+int bahip_update_activation_and_optimize_geometry(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels,
+                                                  uint32_t activation_surfels_size) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");   // B/kernel_opt_geometry.cc:91
+  REQUIRE(surfels->active != nullptr, "geometry optimisation needs the active-surfel buffer");
+  REQUIRE(activation_surfels_size <= surfels->surfels_size, "activation range exceeds surfels_size");
+  timer_begin(ctx, 1, true);
+  launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels),
+                  (long long)activation_surfels_size);
+  timer_end(ctx, 1);
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, int use_desc, const bahip_frame* frame,
                                             const float frame_T_global[12], const bahip_surfels* surfels, float* H, float* b) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");

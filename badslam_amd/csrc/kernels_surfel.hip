@@ -162,14 +162,21 @@ assign_colors_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs
 
 // Normals pass: B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update).
 // `live` = this lane holds an active surfel; every thread of the workgroup must call this function.
-template <int kWaves>
+// kActivate: the surfel activation of B/kernel_surfel_activation.cu:38-94 is decided here instead of in a sweep of its
+// own -- a surfel is active iff it is associated with >= 1 keyframe whose activation is kActive, and this pass tests
+// exactly those associations (same position, same old normal) on its way over the non-inactive keyframes.  Lanes with
+// `decide` set enter as live candidates, count their associations with kActive keyframes (a fifth sum), get their flag
+// written and stay live only if that count is >= 1; what an inactive surfel accumulated is dropped.
+template <int kWaves, bool kActivate>
 __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs,
-                                             const WaveBounds& wb, SurfelsView& s, uint32_t i, bool live, Vec3 gp,
-                                             Vec3* gn_inout, float* lds) {
+                                             const WaveBounds& wb, SurfelsView& s, uint32_t i, bool* live_inout, bool decide,
+                                             Vec3 gp, Vec3* gn_inout, float* lds) {
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
   const Vec3 gn = *gn_inout;
-  float sum[4];   // x, y, z, count
-  tile_sums<kWaves>(sum, lds, [&](float (&acc)[4], int cls) {
+  bool live = *live_inout;
+  constexpr int kCount = kActivate ? 5 : 4;
+  float sum[kCount];   // x, y, z, count [, count over kActive keyframes]
+  tile_sums<kWaves>(sum, lds, [&](float (&acc)[kCount], int cls) {
     for_each_candidate(
         num_kfs,
         [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); },
@@ -179,10 +186,17 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
           if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) {
             const Vec3 g = mul33(kfs[k].pose.GR, unpack_normal8(r.normal_bits));
             acc[0] += g.x; acc[1] += g.y; acc[2] += g.z; acc[3] += 1.f;
+            if (kActivate) acc[kCount - 1] += (kfs[k].activation == BAHIP_KF_ACTIVE) ? 1.f : 0.f;
           }
         },
         kSumClasses, cls);
   });
+  if (kActivate && decide) {
+    const bool active = live && sum[kCount - 1] >= 1.f;
+    if (writer) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (active ? kSurfelActiveFlag : 0);
+    live = active;
+    *live_inout = active;
+  }
   if (!live) return;
   const float sx = sum[0], sy = sum[1], sz = sum[2], count = sum[3];
   if (writer) {
@@ -205,30 +219,38 @@ normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Surf
   const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
-  const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
+  bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
   const Vec3 gp = surfel_position(s, ii);
   Vec3 gn = surfel_normal(s, ii);
   const WaveBounds wb = wave_bounds(gp, live && position_valid(gp));
-  normals_pass<kWaves>(in, kfs, num_kfs, wb, s, ii, live, gp, &gn, lds);
+  normals_pass<kWaves, false>(in, kfs, num_kfs, wb, s, ii, &live, false, gp, &gn, lds);
 }
 
 // Geometry step of one BA iteration for one surfel: normals, then either the depth-only 1x1 solve
 // (B/kernel_opt_geometry.cu:417-508) or the joint position + descriptor 3x3 solve (:119-353).
-template <bool kUseDepth, bool kUseDesc, int kWaves>
+// kActivate: surfels [0, activate_count) get their activation flag decided inside the normals pass (see normals_pass) --
+// UpdateSurfelActivationCUDA and OptimizeGeometryIterationCUDA of one BA iteration in one sweep; surfels beyond
+// activate_count keep the flag they have (the reference flags newly created surfels active without a test,
+// B/direct_ba_alternating.cc:448-452).
+template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate>
 __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
-geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
+geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count) {
   __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
   const int lane = threadIdx.x & 63;
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
   const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
-  const bool live = in_range && (s.active[ii] & kSurfelActiveFlag);
+  const bool decide = kActivate && in_range && i < activate_count;
+  bool live = in_range && (decide || (s.active[ii] & kSurfelActiveFlag));
   const Vec3 gp = surfel_position(s, ii);
   Vec3 gn = surfel_normal(s, ii);
   const WaveBounds wb = wave_bounds(gp, live && position_valid(gp));
-  if (wb.r < 0.f) return;   // workgroup-uniform (all wavefronts of the tile hold the same surfels): no active surfel here
-  normals_pass<kWaves>(in, kfs, num_kfs, wb, s, ii, live, gp, &gn, lds);
+  if (wb.r < 0.f) {   // workgroup-uniform (all wavefronts of the tile hold the same surfels): nothing a keyframe could see
+    if (decide && writer) s.active[ii] = s.active[ii] & (uint8_t)~kSurfelActiveFlag;   // (deleted surfels: never active)
+    return;
+  }
+  normals_pass<kWaves, kActivate>(in, kfs, num_kfs, wb, s, ii, &live, decide, gp, &gn, lds);
 
   auto cand = [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); };
 
@@ -369,21 +391,26 @@ void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs
   }
 }
 
-template <int kWaves>
+template <int kWaves, bool kActivate>
 static void launch_geometry_shape(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                                  int num_kfs, const SurfelsView& s) {
+                                  int num_kfs, const SurfelsView& s, uint32_t activate_count) {
   const dim3 grid(grid_for(s.size)), block(64 * kWaves);
-  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false, kWaves>), grid, block, 0, stream, in, kfs, num_kfs, s);
-  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true, kWaves>), grid, block, 0, stream, in, kfs, num_kfs, s);
-  else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves>), grid, block, 0, stream, in, kfs, num_kfs, s);
+  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count);
+  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count);
+  else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count);
 }
 
+// activate_count < 0: the activation flags are taken as they are; >= 0: surfels [0, activate_count) are (re)activated first.
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                     int num_kfs, const SurfelsView& s) {
+                     int num_kfs, const SurfelsView& s, long long activate_count) {
   if (s.size == 0) return;
-  switch (tile_waves(s.size)) {
-    case 1: launch_geometry_shape<1>(stream, use_depth, use_desc, in, kfs, num_kfs, s); break;
-    default: launch_geometry_shape<4>(stream, use_depth, use_desc, in, kfs, num_kfs, s); break;
+  const uint32_t n = activate_count < 0 ? 0u : (uint32_t)activate_count;
+  if (tile_waves(s.size) == 1) {
+    if (activate_count < 0) launch_geometry_shape<1, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
+    else launch_geometry_shape<1, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
+  } else {
+    if (activate_count < 0) launch_geometry_shape<4, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
+    else launch_geometry_shape<4, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
   }
 }
 

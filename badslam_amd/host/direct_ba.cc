@@ -359,20 +359,24 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
 
     BindScene(stream);
 
-    // --- surfel activation ---
+    // --- surfel activation + geometry ---
     if (optimize_geometry && surfels_size_ > old_surfels_size)
       BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address() + old_surfels_size, 1, surfels_size_ - old_surfels_size));
     if (!full_window) {
       BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address(), 1, old_surfels_size));
-    } else {
+    } else if (!optimize_geometry) {
       const bahip_surfels s = SurfelsStruct();
       BAHIP_CHECKED_CALL(bahip_update_surfel_activation(ctx_, &s, (uint32_t)old_surfels_size));
     }
-
-    // --- geometry ---
     if (optimize_geometry) {
       const bahip_surfels s = SurfelsStruct();
-      BAHIP_CHECKED_CALL(bahip_optimize_geometry_iteration(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s));
+      if (full_window) {
+        // UpdateSurfelActivationCUDA + OptimizeGeometryIterationCUDA (B/direct_ba_alternating.cc:441-487) as one sweep
+        BAHIP_CHECKED_CALL(bahip_update_activation_and_optimize_geometry(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s,
+                                                                         (uint32_t)old_surfels_size));
+      } else {
+        BAHIP_CHECKED_CALL(bahip_optimize_geometry_iteration(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s));
+      }
     }
 
     // --- surfel merge + compaction ---

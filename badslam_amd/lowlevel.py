@@ -240,6 +240,11 @@ class Scene:
         s = self.surfels_struct()
         capi.check(self.lib.bahip_optimize_geometry_iteration(self.ctx.handle, int(use_depth), int(use_desc), C.byref(s)))
 
+    def update_activation_and_optimize_geometry(self, use_depth, use_desc, activation_surfels_size=None):
+        s = self.surfels_struct()
+        n = self.surfels_size if activation_surfels_size is None else int(activation_surfels_size)
+        capi.check(self.lib.bahip_update_activation_and_optimize_geometry(self.ctx.handle, int(use_depth), int(use_desc), C.byref(s), n))
+
     def estimate_keyframe_poses(self, use_depth, use_desc):
         K = len(self.keyframes)
         poses = (C.c_float * (7 * K))()

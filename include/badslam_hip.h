@@ -196,6 +196,12 @@ int bahip_update_surfel_normals(bahip_context* ctx, const bahip_surfels* surfels
 /* B/kernels.h OptimizeGeometryIterationCUDA (B/kernel_opt_geometry.cc:80-201). */
 int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth_residuals, int use_descriptor_residuals,
                                       const bahip_surfels* surfels);
+/* UpdateSurfelActivationCUDA for surfels [0, activation_surfels_size) followed by OptimizeGeometryIterationCUDA, as ONE
+ * sweep: a surfel is active iff it is associated with a kActive keyframe, and the normals pass of the geometry step tests
+ * exactly those associations anyway (B/direct_ba_alternating.cc:441-487 calls the two back to back).  Same flags and the same
+ * surfels, bit for bit, as the two separate calls. */
+int bahip_update_activation_and_optimize_geometry(bahip_context* ctx, int use_depth_residuals, int use_descriptor_residuals,
+                                                  const bahip_surfels* surfels, uint32_t activation_surfels_size);
 /* B/kernels.h AccumulatePoseEstimationCoeffsCUDA (B/kernel_opt_pose.cc:39-97): one frame, one
  * linearisation point.  H = 21 floats (row-major upper triangle), b = 6 floats, on the host;
  * synchronises like the reference does (B/kernel_opt_pose.cc:94-96). */

@@ -92,10 +92,11 @@ def test_pose_coefficients(synced, use_depth, use_desc, pose_parts, request):
         assert np.abs(x - x_ref).max() < 1e-6   # "one GN pose step 1e-6 on the tangent" 
 
 
-@pytest.mark.parametrize("tile_waves", [1, 4])
-def test_activation_and_geometry_step(scene, synced, tile_waves, request):
+@pytest.mark.parametrize("tile_waves,fused", [(1, False), (4, False), (1, True), (4, True)])
+def test_activation_and_geometry_step(scene, synced, tile_waves, fused, request):
     """Both launch shapes of the normals / geometry passes (one or four wavefronts per surfel tile) must give the
-    oracle's bits: the per-surfel sums are defined as four interleaved partial sums on both sides."""
+    oracle's bits: the per-surfel sums are defined as four interleaved partial sums on both sides.  fused: activation and
+    geometry step as one sweep (bahip_update_activation_and_optimize_geometry) instead of two calls: same flags, same bits."""
     ba, g = synced
     _launch_shapes(g, tile_waves, 0)
     request.addfinalizer(lambda: _launch_shapes(g, 0, 0))
@@ -108,13 +109,16 @@ def test_activation_and_geometry_step(scene, synced, tile_waves, request):
     ba.surfel_data[:, :data.shape[1]] = data
     g.upload_surfels(data, active * 0)
     g.bind_keyframes()
-    g.update_surfel_activation()
     ba.update_surfel_activation()
+    if fused:
+        g.update_activation_and_optimize_geometry(True, True)
+    else:
+        g.update_surfel_activation()
     act = g.active_buf.download()[0, :data.shape[1]]
     assert np.array_equal(act, ba.active[:data.shape[1]])
     assert act.sum() > 0.9 * data.shape[1]
-
-    g.optimize_geometry_iteration(True, True)
+    if not fused:
+        g.optimize_geometry_iteration(True, True)
     ba.optimize_geometry_iteration()
     got = g.download_surfels()
     ref = ba.surfel_data[:, :data.shape[1]]

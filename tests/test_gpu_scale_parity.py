@@ -55,8 +55,8 @@ def _set_activations(orc, g, pattern):
         g.keyframes[k]["activation"] = int(pattern[k])
 
 
-@pytest.mark.parametrize("tile_waves", [1, 4])
-def test_many_keyframes_activation_and_geometry_bit_exact(many, tile_waves, request):
+@pytest.mark.parametrize("tile_waves,fused", [(1, False), (4, False), (1, True), (4, True)])
+def test_many_keyframes_activation_and_geometry_bit_exact(many, tile_waves, fused, request):
     scene, orc, g = many
     K = len(orc.keyframes)
     _shapes(g.ctx.lib, tile_waves, 0)
@@ -75,12 +75,16 @@ def test_many_keyframes_activation_and_geometry_bit_exact(many, tile_waves, requ
         orc.surfel_data[:, :n] = moved
         g.upload_surfels(moved, active * 0)
         g.bind_keyframes()
-        g.update_surfel_activation()
         orc.update_surfel_activation()
+        if fused:          # activation decided inside the normals pass of the geometry sweep (one launch instead of two)
+            g.update_activation_and_optimize_geometry(True, True)
+        else:
+            g.update_surfel_activation()
         act = g.active_buf.download()[0, :n]
         assert np.array_equal(act, orc.active[:n])
         assert 0.3 * n < act.sum() < n                 # some surfels are seen by no active keyframe
-        g.optimize_geometry_iteration(True, True)
+        if not fused:
+            g.optimize_geometry_iteration(True, True)
         orc.optimize_geometry_iteration()
         got = g.download_surfels()
         ref = orc.surfel_data[:, :n]
