@@ -106,6 +106,11 @@ SIGNATURES = {
                                             C.POINTER(Surfels), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bahip_estimate_keyframe_poses": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_float),
                                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bahip_estimate_keyframe_poses_and_update_activation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_float),
+                                                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bahip_set_covisibility": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "bahip_propagate_covisible_activation": (C.c_int, [C.c_void_p]),
     "bahip_determine_supporting_surfels": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(Frame), C.POINTER(C.c_float),
                                                      C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,

@@ -114,6 +114,7 @@ __host__ __device__ __forceinline__ double hb_from_fixed(HbFixed q) { return (do
 struct PoseWork {
   float F[12];        // frame_T_global at the current linearisation point
   float T[7];         // global_T_frame estimate (Sophus layout)
+  float T0[7];        // global_T_frame when the Gauss-Newton rounds began (decides afterwards whether the keyframe "moved")
   int32_t kf_index;   // entry of the frame table providing the images
   int32_t done;       // converged or iteration cap reached (or skipped)
   int32_t iterations;

@@ -42,6 +42,9 @@ void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb
                        int* not_done_count);
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb);
 
+void launch_pose_finalize(hipStream_t stream, const void* work, int num_kfs, KfEntry* frames, int* moved_out, int* num_converged);
+void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices);
+
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
 void set_pose_parts(int parts);   // 0 = automatic; 1 | 2 | 4 | 8 wavefronts share a tile's keyframes in the pose kernel
 void launch_jacobian_debug(hipStream_t stream, int kind, const float* in, float* out);

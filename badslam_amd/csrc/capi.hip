@@ -83,6 +83,14 @@ struct bahip_context {
   int* dev_covis = nullptr;
   float* dev_covis_T = nullptr;
   int covis_capacity = 0;
+  // co-visibility lists of the bound keyframes (CSR over bound indices), for the device-side activation state machine
+  std::vector<int> covis_offsets, covis_indices;
+  int* dev_covis_csr = nullptr;    // offsets (K + 1) followed by the indices
+  size_t covis_csr_capacity = 0;
+  bool have_covisibility = false;
+  int* dev_moved = nullptr;        // per bound keyframe: pose moved in the last pose phase (work_capacity ints) + [cap] = count
+  char* pinned_work = nullptr;     // read-back of the pose work items + moved flags + counter (page-locked)
+  size_t pinned_work_bytes = 0;
 
   float* intr_scratch = nullptr;   // intrinsics step: 64 + 8*S floats (glob | B | D | b2 | obs)
   int intr_capacity = 0;
@@ -199,10 +207,18 @@ SurfelsView make_view(const bahip_surfels* s) {
 
 int ensure_work(bahip_context* ctx, int n) {
   if (n <= ctx->work_capacity) return 0;
-  if (ctx->dev_work) { hipFree(ctx->dev_work); hipFree(ctx->dev_Hb); }
   const int cap = n + 64;
-  HIP_TRY(hipMalloc(&ctx->dev_work, sizeof(PoseWork) * cap));
-  HIP_TRY(hipMalloc(&ctx->dev_Hb, sizeof(HbFixed) * kHbStride * cap));
+  // allocate first, swap on success: a failed grow leaves the context as it was
+  PoseWork* work = nullptr; HbFixed* hb = nullptr; int* moved = nullptr; char* pinned = nullptr;
+  const size_t pinned_bytes = sizeof(PoseWork) * cap + sizeof(int) * (cap + 4);
+  if (hipMalloc(&work, sizeof(PoseWork) * cap) != hipSuccess || hipMalloc(&hb, sizeof(HbFixed) * kHbStride * cap) != hipSuccess ||
+      hipMalloc(&moved, sizeof(int) * (cap + 4)) != hipSuccess || hipHostMalloc(&pinned, pinned_bytes) != hipSuccess) {
+    hipFree(work); hipFree(hb); hipFree(moved); if (pinned) hipHostFree(pinned);
+    return fail("allocation of the pose work items failed", __FILE__, __LINE__);
+  }
+  hipFree(ctx->dev_work); hipFree(ctx->dev_Hb); hipFree(ctx->dev_moved);
+  if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
+  ctx->dev_work = work; ctx->dev_Hb = hb; ctx->dev_moved = moved; ctx->pinned_work = pinned; ctx->pinned_work_bytes = pinned_bytes;
   ctx->work_capacity = cap;
   return 0;
 }
@@ -415,7 +431,8 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1);
   hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
-  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
+  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_moved);
+  if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
@@ -642,6 +659,7 @@ int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int
     HIP_TRY(hipMalloc(&ctx->dev_kfs, sizeof(KfEntry) * ctx->kfs_capacity));
   }
   ctx->num_kfs = num_keyframes;
+  ctx->have_covisibility = false;   // lists refer to the previous binding
   if (num_keyframes > 0) {
     HIP_TRY(hipMemcpyAsync(ctx->dev_kfs, ctx->host_kfs.data(), sizeof(KfEntry) * num_keyframes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // host_kfs is pageable
@@ -761,25 +779,95 @@ int bahip_estimate_frame_pose(bahip_context* ctx, int use_depth, int use_desc, c
   return 0;
 }
 
-int bahip_estimate_keyframe_poses(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels,
-                                  float* global_T_frame_out, int* iterations_done, int* converged, int* rounds_out) {
+static int estimate_keyframe_poses_impl(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels,
+                                       float* global_T_frame_out, int* iterations_done, int* converged, int* rounds_out,
+                                       bool update_activation, int* moved_out, int* num_converged_out) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");
   const int K = ctx->num_kfs;
   if (rounds_out) *rounds_out = 0;
+  if (num_converged_out) *num_converged_out = 0;
   if (K == 0) return 0;
   if (ensure_work(ctx, K)) return 1;
   launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb);
   CHECK_LAUNCH();
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K,
                       make_view(surfels), /*write_back*/ 1, rounds_out)) return 1;
-  std::vector<PoseWork> hw(K);
-  HIP_TRY(hipMemcpy(hw.data(), ctx->dev_work, sizeof(PoseWork) * K, hipMemcpyDeviceToHost));
+  const int cap = ctx->work_capacity;
+  int* dev_count = ctx->dev_moved + cap;
+  if (update_activation) {
+    HIP_TRY(hipMemsetAsync(dev_count, 0, sizeof(int), ctx->stream));
+    launch_pose_finalize(ctx->stream, ctx->dev_work, K, ctx->dev_kfs, ctx->dev_moved, dev_count);
+    CHECK_LAUNCH();
+  }
+  // one read-back into page-locked memory: work items | moved flags | converged count
+  PoseWork* hw = reinterpret_cast<PoseWork*>(ctx->pinned_work);
+  int* hmoved = reinterpret_cast<int*>(ctx->pinned_work + sizeof(PoseWork) * cap);
+  HIP_TRY(hipMemcpyAsync(hw, ctx->dev_work, sizeof(PoseWork) * K, hipMemcpyDeviceToHost, ctx->stream));
+  if (update_activation) HIP_TRY(hipMemcpyAsync(hmoved, ctx->dev_moved, sizeof(int) * (cap + 1), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < K; ++k) {
     if (hw[k].iterations > 0) fill_pose(&ctx->host_kfs[k], hw[k].T);
+    if (update_activation && ctx->host_kfs[k].activation != BAHIP_KF_INACTIVE)
+      ctx->host_kfs[k].activation = hmoved[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;       // mirror of pose_finalize_kernel
     if (global_T_frame_out) memcpy(global_T_frame_out + 7 * k, ctx->host_kfs[k].global_T_frame, 7 * sizeof(float));
     if (iterations_done) iterations_done[k] = hw[k].iterations;
     if (converged) converged[k] = hw[k].converged;
+    if (moved_out) moved_out[k] = update_activation ? hmoved[k] : 0;
+  }
+  if (update_activation && num_converged_out) *num_converged_out = hmoved[cap];
+  return 0;
+}
+
+int bahip_estimate_keyframe_poses(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels,
+                                  float* global_T_frame_out, int* iterations_done, int* converged, int* rounds_out) {
+  return estimate_keyframe_poses_impl(ctx, use_depth, use_desc, surfels, global_T_frame_out, iterations_done, converged, rounds_out,
+                                      false, nullptr, nullptr);
+}
+
+int bahip_estimate_keyframe_poses_and_update_activation(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels,
+                                                        float* global_T_frame_out, int* iterations_done, int* converged, int* moved,
+                                                        int* rounds_out, int* num_converged_out) {
+  return estimate_keyframe_poses_impl(ctx, use_depth, use_desc, surfels, global_T_frame_out, iterations_done, converged, rounds_out,
+                                      true, moved, num_converged_out);
+}
+
+int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* indices, int num_keyframes) {
+  REQUIRE(num_keyframes == ctx->num_kfs, "bahip_set_covisibility: list count differs from the bound keyframes");
+  REQUIRE(offsets != nullptr && offsets[0] == 0, "bahip_set_covisibility: offsets must start at 0");
+  const int K = num_keyframes, total = offsets[K];
+  REQUIRE(total >= 0 && (total == 0 || indices != nullptr), "bahip_set_covisibility: bad lists");
+  for (int k = 0; k < K; ++k) REQUIRE(offsets[k + 1] >= offsets[k], "bahip_set_covisibility: offsets must be non-decreasing");
+  for (int j = 0; j < total; ++j) REQUIRE(indices[j] >= 0 && indices[j] < K, "bahip_set_covisibility: keyframe index out of range");
+  ctx->covis_offsets.assign(offsets, offsets + K + 1);
+  ctx->covis_indices.assign(indices, indices + total);
+  const size_t need = (size_t)K + 1 + (size_t)total;
+  if (need > ctx->covis_csr_capacity) {
+    int* grown = nullptr;
+    HIP_TRY(hipMalloc(&grown, sizeof(int) * (need + 1024)));
+    hipFree(ctx->dev_covis_csr);
+    ctx->dev_covis_csr = grown;
+    ctx->covis_csr_capacity = need + 1024;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->dev_covis_csr, ctx->covis_offsets.data(), sizeof(int) * (K + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (total) HIP_TRY(hipMemcpyAsync(ctx->dev_covis_csr + K + 1, ctx->covis_indices.data(), sizeof(int) * total, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));   // the vectors are pageable
+  ctx->have_covisibility = true;
+  return 0;
+}
+
+int bahip_propagate_covisible_activation(bahip_context* ctx) {
+  REQUIRE(ctx->have_covisibility && (int)ctx->covis_offsets.size() == ctx->num_kfs + 1,
+          "bahip_set_covisibility must follow bahip_set_keyframes before the activation can be propagated");
+  const int K = ctx->num_kfs;
+  launch_propagate_covisible(ctx->stream, ctx->dev_kfs, K, ctx->dev_covis_csr, ctx->dev_covis_csr + K + 1);
+  CHECK_LAUNCH();
+  for (int k = 0; k < K; ++k) {   // the host mirror of the table
+    if (ctx->host_kfs[k].activation != BAHIP_KF_ACTIVE) continue;
+    for (int j = ctx->covis_offsets[k]; j < ctx->covis_offsets[k + 1]; ++j) {
+      KfEntry& other = ctx->host_kfs[ctx->covis_indices[j]];
+      if (other.activation == BAHIP_KF_INACTIVE) other.activation = BAHIP_KF_COVISIBLE_ACTIVE;
+    }
   }
   return 0;
 }

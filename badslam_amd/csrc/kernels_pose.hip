@@ -236,12 +236,54 @@ __global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ fram
   pw.iterations = 0;
   pw.converged = 0;
   pw.done = (frames[k].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
-  for (int c = 0; c < 7; ++c) pw.T[c] = frames[k].global_T_frame[c];
+  for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
   for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
   for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
 }
 
+// After the Gauss-Newton rounds of one BA iteration, B/direct_ba_alternating.cc:556-577: a keyframe whose pose moved (the
+// logarithm of old^-1 * new fails the convergence test) becomes kActive, one that did not becomes kInactive and counts as
+// converged, as do the keyframes that were kInactive (not optimised).  The reference does this on the host between the
+// iterations; here the device keyframe table stays authoritative during the BA loop, so the next iteration's sweeps can be
+// queued while the host is still copying the results into its Keyframe objects.
+__global__ void pose_finalize_kernel(const PoseWork* __restrict__ work, int num_kfs, KfEntry* __restrict__ frames,
+                                     int* __restrict__ moved_out, int* __restrict__ num_converged) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_kfs) return;
+  if (frames[k].activation == BAHIP_KF_INACTIVE) { moved_out[k] = 0; atomicAdd(num_converged, 1); return; }
+  const PoseWork& pw = work[k];
+  float inv0[7], diff[7], lg[6];
+  se3_inverse(pw.T0, inv0);        // Keyframe::frame_T_global() of the old pose
+  se3_mul(inv0, pw.T, diff);
+  se3_log(diff, lg);
+  const bool moved = !is_scale1_pose_converged(lg);
+  frames[k].activation = moved ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+  moved_out[k] = moved ? 1 : 0;
+  if (!moved) atomicAdd(num_converged, 1);
+}
+
+// DirectBA::DetermineCovisibleActiveKeyframes (B/direct_ba.cc:549-564) on the device table: every kInactive keyframe that is
+// co-visible with a kActive one becomes kCovisibleActive.  Lists in CSR form over bound keyframe indices.  Order-free: a
+// write only turns kInactive into kCovisibleActive and only kActive entries are sources.
+__global__ void propagate_covisible_kernel(KfEntry* __restrict__ frames, int num_kfs, const int* __restrict__ offsets,
+                                           const int* __restrict__ indices) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_kfs || frames[k].activation != BAHIP_KF_ACTIVE) return;
+  for (int j = offsets[k]; j < offsets[k + 1]; ++j) {
+    const int other = indices[j];
+    if (frames[other].activation == BAHIP_KF_INACTIVE) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
+  }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
+void launch_pose_finalize(hipStream_t stream, const void* work, int num_kfs, KfEntry* frames, int* moved_out, int* num_converged) {
+  if (num_kfs) hipLaunchKernelGGL(pose_finalize_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, static_cast<const PoseWork*>(work),
+                                  num_kfs, frames, moved_out, num_converged);
+}
+void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices) {
+  if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices);
+}
+
 static int g_forced_pose_parts = [] { const char* e = getenv("BAHIP_POSE_PARTS"); return e ? atoi(e) : 0; }();
 void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
 

@@ -11,13 +11,6 @@
 namespace vis {
 
 namespace {
-// B/convergence_analysis.h:43-51
-bool IsScale1PoseEstimationConverged(const float x[6]) {
-  float sq = 0.f;
-  for (int i = 0; i < 3; ++i) sq += x[i] * x[i];
-  for (int i = 3; i < 6; ++i) { const float v = x[i] * 10.f; sq += v * v; }
-  return sq < 1e-06f;
-}
 int ToBahipActivation(Keyframe::Activation a) { return static_cast<int>(a); }
 }  // namespace
 
@@ -189,6 +182,14 @@ void DirectBA::BindScene(hipStream_t stream) {
     list.push_back(k);
   }
   BAHIP_CHECKED_CALL(bahip_set_keyframes(ctx_, list.data(), (int)list.size()));
+  // co-visibility lists over bound indices: the activation state machine of the alternating scheme runs on the device table
+  vector<int> offsets(1, 0), indices;
+  for (int id : bound_ids_) {
+    for (int other : keyframes_[id]->co_visibility_list())
+      if (other >= 0 && other < (int)id_to_bound_.size() && id_to_bound_[other] >= 0) indices.push_back(id_to_bound_[other]);
+    offsets.push_back((int)indices.size());
+  }
+  BAHIP_CHECKED_CALL(bahip_set_covisibility(ctx_, offsets.data(), indices.data(), (int)bound_ids_.size()));
 }
 
 // ---- surfel creation (B/direct_ba.cc:340-405) ---------------------------------------------------------------------
@@ -323,10 +324,38 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     LOG(WARNING) << "Currently, only using all keyframes in every optimization iteration will work properly.";
   BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address(), 0, surfels_size_));
 
+  // During the loop the device keyframe table is authoritative: the pose phase updates poses AND activations there
+  // (bahip_estimate_keyframe_poses_and_update_activation, bahip_propagate_covisible_activation), so the next iteration's sweeps
+  // can be queued at once, and the results are copied into the Keyframe objects ("pending") while the GPU already works on
+  // them.  Anything that reads the Keyframe objects applies the pending results first.
+  struct PendingPoseResults {
+    bool valid = false, propagate = false;
+    vector<float> poses;
+    vector<int> moved;
+  } pending;
+  auto apply_pending = [&]() {
+    if (!pending.valid) return;
+    Lock();
+    for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
+      if (!keyframe || keyframe->activation() == Keyframe::Activation::kInactive) continue;
+      const int b = id_to_bound_[keyframe->id()];
+      keyframe->set_global_T_frame(SE3f(&pending.poses[7 * (size_t)b]));
+      keyframe->SetActivation(pending.moved[b] ? Keyframe::Activation::kActive : Keyframe::Activation::kInactive);
+    }
+    if (pending.propagate) DetermineCovisibleActiveKeyframes();
+    Unlock();
+    pending.valid = false;
+  };
+  bool scene_bound = false;   // does the backend context hold the current keyframes / poses / activations / intrinsics?
+
   for (int iteration = 0; iteration < max_iterations; ++iteration) {
-    if (progress_function && !progress_function(iteration)) break;
+    if (progress_function) {
+      apply_pending();   // the callback may look at the keyframes
+      if (!progress_function(iteration)) break;
+    }
     if (num_iterations_done) ++*num_iterations_done;
     if (fixed_active_keyframe_set) {
+      apply_pending();
       Lock();
       for (u32 i = 0; i < keyframes_.size(); ++i) {
         if (!keyframes_[i]) continue;
@@ -335,6 +364,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       }
       DetermineCovisibleActiveKeyframes();
       Unlock();
+      scene_bound = false;
     }
 
     // --- surfel creation ---
@@ -342,6 +372,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     CHECK_EQ(surfels_size_, surfel_count_);
     const usize old_surfels_size = surfels_size_;
     if (optimize_geometry && do_surfel_updates) {
+      apply_pending();
       Lock();
       for (shared_ptr<Keyframe>& keyframe : keyframes_) {
         if (!keyframe) continue;
@@ -355,9 +386,14 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       }
       Unlock();
       for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
+      if (!keyframes_with_new_surfels.empty()) scene_bound = true;   // CreateSurfelsForKeyframe bound the current scene
     }
 
-    BindScene(stream);
+    if (!scene_bound) {
+      apply_pending();
+      BindScene(stream);
+      scene_bound = true;
+    }
 
     // --- surfel activation + geometry ---
     if (optimize_geometry && surfels_size_ > old_surfels_size)
@@ -378,6 +414,8 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         BAHIP_CHECKED_CALL(bahip_optimize_geometry_iteration(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s));
       }
     }
+    // the previous iteration's pose results go into the Keyframe objects while the GPU runs the sweep queued above
+    apply_pending();
 
     // --- surfel merge + compaction ---
     if (do_surfel_updates) {
@@ -392,36 +430,27 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       }
     }
 
-    // --- poses: every non-inactive keyframe, batched per Gauss-Newton round ---
+    // --- poses: every non-inactive keyframe, batched per Gauss-Newton round; activations updated on the device ---
     usize num_converged = 0;
     if (optimize_poses) {
       const int K = (int)bound_ids_.size();
-      vector<float> poses(7 * (size_t)K);
+      pending.poses.assign(7 * (size_t)K, 0.f);
+      pending.moved.assign(K, 0);
       vector<int> its(K), conv(K);
-      int rounds = 0;
+      int rounds = 0, converged_bound = 0;
       const bahip_surfels s = SurfelsStruct();
-      BAHIP_CHECKED_CALL(bahip_estimate_keyframe_poses(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s, poses.data(),
-                                                       its.data(), conv.data(), &rounds));
+      BAHIP_CHECKED_CALL(bahip_estimate_keyframe_poses_and_update_activation(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s,
+                                                                             pending.poses.data(), its.data(), conv.data(),
+                                                                             pending.moved.data(), &rounds, &converged_bound));
+      pending.valid = true;
+      pending.propagate = false;
       last_pose_rounds_ += rounds;
+      num_converged = (usize)converged_bound + (keyframes_.size() - (usize)K);   // deleted keyframes count as converged
       for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
-        if (!keyframe || keyframe->activation() == Keyframe::Activation::kInactive) { ++num_converged; continue; }
+        if (!keyframe || keyframe->activation() == Keyframe::Activation::kInactive) continue;
         const int b = id_to_bound_[keyframe->id()];
         last_pose_steps_ += its[b];
         if (!conv[b]) LOG(WARNING) << "Pose estimation not converged (keyframe " << keyframe->id() << ")";
-        const SE3f estimate(&poses[7 * (size_t)b]);
-        const SE3f pose_difference = keyframe->frame_T_global() * estimate;
-        float lg[6];
-        pose_difference.log(lg);
-        const bool frame_moved = !IsScale1PoseEstimationConverged(lg);
-        Lock();
-        keyframe->set_global_T_frame(estimate);
-        if (frame_moved) {
-          keyframe->SetActivation(Keyframe::Activation::kActive);
-        } else {
-          keyframe->SetActivation(Keyframe::Activation::kInactive);
-          ++num_converged;
-        }
-        Unlock();
       }
     }
 
@@ -439,8 +468,12 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
           depth_params_.a = out_a;
         }
         Unlock();
+        // the backend context takes over the new cameras / depth parameters (the keyframe table is unaffected)
+        const bahip_camera cc = ToBahipCamera(color_camera_), dc = ToBahipCamera(depth_camera_);
+        const bahip_depth_params dp = ToBahipDepthParams(depth_params_);
+        BAHIP_CHECKED_CALL(bahip_set_intrinsics(ctx_, &cc, &dc, &dp));
       }
-      if (intrinsics_updated_callback_) intrinsics_updated_callback_();
+      if (intrinsics_updated_callback_) { apply_pending(); intrinsics_updated_callback_(); }
     }
 
     if (timings_stream_) {
@@ -459,10 +492,17 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       break;
     }
     if (timer && timer->GetTimeSinceStart() > time_limit) break;
-    Lock();
-    DetermineCovisibleActiveKeyframes();
-    Unlock();
+    // DetermineCovisibleActiveKeyframes: on the device table now, on the Keyframe objects when the pending results are applied
+    BAHIP_CHECKED_CALL(bahip_propagate_covisible_activation(ctx_));
+    if (pending.valid) {
+      pending.propagate = true;
+    } else {
+      Lock();
+      DetermineCovisibleActiveKeyframes();
+      Unlock();
+    }
   }
+  apply_pending();
 
   if (increase_ba_iteration_count) {
     PerformBASchemeEndTasks(stream, do_surfel_updates);

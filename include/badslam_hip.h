@@ -226,6 +226,22 @@ int bahip_estimate_keyframe_poses(bahip_context* ctx, int use_depth_residuals, i
                                   const bahip_surfels* surfels, float* global_T_frame_out,
                                   int* iterations_done, int* converged, int* rounds_out);
 
+/* The same pose phase, followed on the device by the activation update of B/direct_ba_alternating.cc:556-577: a keyframe
+ * whose pose moved (log(old^-1 * new) fails the convergence test of B/convergence_analysis.h:43-51) becomes kActive, one
+ * that did not becomes kInactive.  The device keyframe table (and its host mirror inside the context) then carries the new
+ * poses AND activations, so the next iteration's sweeps need no bahip_set_keyframes.  moved: per bound keyframe 1 / 0 (0 for
+ * keyframes that were kInactive); num_converged_out: keyframes that were kInactive or did not move. */
+int bahip_estimate_keyframe_poses_and_update_activation(bahip_context* ctx, int use_depth_residuals, int use_descriptor_residuals,
+                                                        const bahip_surfels* surfels, float* global_T_frame_out,
+                                                        int* iterations_done, int* converged, int* moved, int* rounds_out,
+                                                        int* num_converged_out);
+/* Co-visibility lists of the bound keyframes in CSR form over bound indices (offsets: num_keyframes + 1 entries); call after
+ * bahip_set_keyframes.  bahip_propagate_covisible_activation is DirectBA::DetermineCovisibleActiveKeyframes
+ * (B/direct_ba.cc:549-564) on the device table: kInactive keyframes co-visible with a kActive one become kCovisibleActive.
+ * Asynchronous on the context stream. */
+int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* indices, int num_keyframes);
+int bahip_propagate_covisible_activation(bahip_context* ctx);
+
 /* ---- surfel lifecycle --------------------------------------------------------------------------- */
 /* B/kernels.h DetermineSupportingSurfelsCUDA / ...AndMergeSurfelsCUDA
  * (B/kernel_supporting_surfels.cc:112-165).  supporting: BAHIP_MERGE_BUFFER_COUNT device planes

@@ -102,6 +102,7 @@ typedef struct {
 void orc_se3_identity(orc_se3* T);
 /* sin / cos as the backend defines them (binary64 polynomial evaluation, se3_device.h: sincos_det) */
 void orc_sincos(float x, float* sin_out, float* cos_out);
+float orc_atan(float x);
 void orc_se3_exp(const float tangent[6], orc_se3* out);
 void orc_se3_log(const orc_se3* T, float tangent[6]);
 void orc_se3_mul(const orc_se3* a, const orc_se3* b, orc_se3* out);

@@ -125,6 +125,36 @@ void orc_sincos(float xf, float* sin_out, float* cos_out) {
   *cos_out = (float)cv;
 }
 
+/* atan as the backend defines it (se3_device.h: atan_det), operation by operation in binary64. */
+float orc_atan(float xf) {
+  double x = (double)xf;
+  const int negative = x < 0.0;
+  if (negative) x = -x;
+  const int inverted = x > 1.0;
+  if (inverted) x = 1.0 / x;
+  const int shifted = x > 0.41421356237309503;
+  if (shifted) x = (x - 1.0) / (x + 1.0);
+  const double x2 = x * x;
+  double p = 1.0 / 27.0;
+  p = fma(p, -x2, 1.0 / 25.0);
+  p = fma(p, -x2, 1.0 / 23.0);
+  p = fma(p, -x2, 1.0 / 21.0);
+  p = fma(p, -x2, 1.0 / 19.0);
+  p = fma(p, -x2, 1.0 / 17.0);
+  p = fma(p, -x2, 1.0 / 15.0);
+  p = fma(p, -x2, 1.0 / 13.0);
+  p = fma(p, -x2, 1.0 / 11.0);
+  p = fma(p, -x2, 1.0 / 9.0);
+  p = fma(p, -x2, 1.0 / 7.0);
+  p = fma(p, -x2, 1.0 / 5.0);
+  p = fma(p, -x2, 1.0 / 3.0);
+  p = fma(p, -x2, 1.0);
+  double r = p * x;
+  if (shifted) r = 0.78539816339744830962 + r;
+  if (inverted) r = 1.57079632679489661923 - r;
+  return (float)(negative ? -r : r);
+}
+
 /* se3.hpp:293-313, so3.hpp:282-320 */
 void orc_se3_exp(const float a[6], orc_se3* out) {
   const float ox = a[3], oy = a[4], oz = a[5];
@@ -178,7 +208,7 @@ void orc_se3_log(const orc_se3* T, float out[6]) {
   } else if (fabsf(w) < SOPHUS_EPS_F) {
     two_atan_nbyw_by_n = (w > 0.f) ? ((float)M_PI / n) : (-(float)M_PI / n);
   } else {
-    two_atan_nbyw_by_n = 2.f * atanf(n / w) / n;
+    two_atan_nbyw_by_n = 2.f * orc_atan(n / w) / n;
   }
   const float theta = two_atan_nbyw_by_n * n;
   const float ox = two_atan_nbyw_by_n * qx, oy = two_atan_nbyw_by_n * qy, oz = two_atan_nbyw_by_n * qz;
