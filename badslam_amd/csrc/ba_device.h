@@ -119,7 +119,15 @@ struct PoseWork {
   int32_t done;       // converged or iteration cap reached (or skipped)
   int32_t iterations;
   int32_t converged;
+  int32_t moved;      // set when done (batched keyframe phase): log(T0^-1 * T) fails the convergence test
+  int32_t pad;
 };
+static_assert(sizeof(PoseWork) == 128, "PoseWork is read back as 32-word records");
+// The two records after the last work item hold counters (as int32): [round] = work items still iterating after that
+// Gauss-Newton round (round < BAHIP_MAX_POSE_ITERATIONS = 30), [kPoseCounterConverged] = keyframes that count as converged
+// in the BA loop (inactive ones + those that did not move).  One device-to-host copy per round brings work items and counters.
+constexpr int kPoseCounterConverged = 32;
+constexpr int kPoseTailRecords = 2;
 
 // Unknown-vector layout of the PCG scheme (B/direct_ba_pcg.cc:232-307): [6 per non-gauge keyframe |
 // geom_stride per surfel | 5 + S depth intrinsics | 4 colour intrinsics].

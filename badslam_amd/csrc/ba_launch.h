@@ -39,10 +39,9 @@ void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry*
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb);
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
-                       int* not_done_count);
+                       int update_activation, int round);
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb);
 
-void launch_pose_finalize(hipStream_t stream, const void* work, int num_kfs, KfEntry* frames, int* moved_out, int* num_converged);
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes

@@ -69,6 +69,7 @@ struct bahip_context {
   int work_capacity = 0;
   KfEntry* dev_frame1 = nullptr;   // single-frame table for EstimateFramePose / AccumulatePoseEstimationCoeffs
   PoseWork* dev_work1 = nullptr;
+  PoseWork* pinned_work1 = nullptr;
   HbFixed* dev_Hb1 = nullptr;
 
   int* dev_counter = nullptr;      // [0] generic counter, [1..2] min/max depth bits
@@ -88,9 +89,7 @@ struct bahip_context {
   int* dev_covis_csr = nullptr;    // offsets (K + 1) followed by the indices
   size_t covis_csr_capacity = 0;
   bool have_covisibility = false;
-  int* dev_moved = nullptr;        // per bound keyframe: pose moved in the last pose phase (work_capacity ints) + [cap] = count
-  char* pinned_work = nullptr;     // read-back of the pose work items + moved flags + counter (page-locked)
-  size_t pinned_work_bytes = 0;
+  PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
 
   float* intr_scratch = nullptr;   // intrinsics step: 64 + 8*S floats (glob | B | D | b2 | obs)
   int intr_capacity = 0;
@@ -209,16 +208,16 @@ int ensure_work(bahip_context* ctx, int n) {
   if (n <= ctx->work_capacity) return 0;
   const int cap = n + 64;
   // allocate first, swap on success: a failed grow leaves the context as it was
-  PoseWork* work = nullptr; HbFixed* hb = nullptr; int* moved = nullptr; char* pinned = nullptr;
-  const size_t pinned_bytes = sizeof(PoseWork) * cap + sizeof(int) * (cap + 4);
-  if (hipMalloc(&work, sizeof(PoseWork) * cap) != hipSuccess || hipMalloc(&hb, sizeof(HbFixed) * kHbStride * cap) != hipSuccess ||
-      hipMalloc(&moved, sizeof(int) * (cap + 4)) != hipSuccess || hipHostMalloc(&pinned, pinned_bytes) != hipSuccess) {
-    hipFree(work); hipFree(hb); hipFree(moved); if (pinned) hipHostFree(pinned);
+  PoseWork* work = nullptr; HbFixed* hb = nullptr; PoseWork* pinned = nullptr;
+  const size_t records = (size_t)cap + kPoseTailRecords;
+  if (hipMalloc(&work, sizeof(PoseWork) * records) != hipSuccess || hipMalloc(&hb, sizeof(HbFixed) * kHbStride * cap) != hipSuccess ||
+      hipHostMalloc(&pinned, sizeof(PoseWork) * records) != hipSuccess) {
+    hipFree(work); hipFree(hb); if (pinned) hipHostFree(pinned);
     return fail("allocation of the pose work items failed", __FILE__, __LINE__);
   }
-  hipFree(ctx->dev_work); hipFree(ctx->dev_Hb); hipFree(ctx->dev_moved);
+  hipFree(ctx->dev_work); hipFree(ctx->dev_Hb);
   if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
-  ctx->dev_work = work; ctx->dev_Hb = hb; ctx->dev_moved = moved; ctx->pinned_work = pinned; ctx->pinned_work_bytes = pinned_bytes;
+  ctx->dev_work = work; ctx->dev_Hb = hb; ctx->pinned_work = pinned;
   ctx->work_capacity = cap;
   return 0;
 }
@@ -265,9 +264,11 @@ int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype)
 
 // Batched Gauss-Newton rounds over `num_work` work items already initialised on the device.
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
-                    PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int* rounds_out) {
+                    PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
+                    PoseWork* host_work /* page-locked, num_work + kPoseTailRecords records */, int* rounds_out) {
   int rounds = 0;
   int iterating = num_work;
+  const int* counters = reinterpret_cast<const int*>(host_work + num_work);
   for (int round = 0; round < BAHIP_MAX_POSE_ITERATIONS; ++round) {
     timer_begin(ctx, 2, round == 0, iterating);
     launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb);
@@ -276,14 +277,14 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
     if (reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
     timer_begin(ctx, 3, round == 0);
-    HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
-    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, ctx->dev_counter);
+    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, round);
     timer_end(ctx, 3);
     CHECK_LAUNCH();
-    HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // one read-back per round: the work items (final after the last round) and the counters behind them
+    HIP_TRY(hipMemcpyAsync(host_work, dev_work, sizeof(PoseWork) * ((size_t)num_work + kPoseTailRecords), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ++rounds;
-    iterating = ctx->pinned_i[0];
+    iterating = counters[round];
     if (iterating == 0) break;
   }
   if (rounds_out) *rounds_out = rounds;
@@ -418,7 +419,8 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   HIP_TRY(hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)));
   HIP_TRY(hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)));
   HIP_TRY(hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)));
-  HIP_TRY(hipMalloc(&ctx->dev_work1, sizeof(PoseWork)));
+  HIP_TRY(hipMalloc(&ctx->dev_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)));
+  HIP_TRY(hipHostMalloc(&ctx->pinned_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)));
   HIP_TRY(hipMalloc(&ctx->dev_Hb1, sizeof(HbFixed) * kHbStride));
   *out = ctx;
   return 0;
@@ -430,8 +432,9 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_kfs); hipFree(ctx->dev_work); hipFree(ctx->dev_Hb);
   hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1);
   hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
+  if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
-  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_moved);
+  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr);
   if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
@@ -760,22 +763,23 @@ int bahip_estimate_frame_pose(bahip_context* ctx, int use_depth, int use_desc, c
   REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");
   KfEntry e;
   if (make_entry(ctx, *frame, 0, &e)) return 1;
-  PoseWork w{};
-  memcpy(w.T, init, 7 * sizeof(float));
+  PoseWork w[1 + kPoseTailRecords] = {};   // the work item and its (zeroed) counter records
+  memcpy(w[0].T, init, 7 * sizeof(float));
+  memcpy(w[0].T0, init, 7 * sizeof(float));
   float inv[7];
   se3_inverse(init, inv);
-  se3_matrix3x4(inv, w.F);
+  se3_matrix3x4(inv, w[0].F);
   HIP_TRY(hipMemcpyAsync(ctx->dev_frame1, &e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->dev_work1, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->dev_work1, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(HbFixed) * kHbStride, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   // surfels_size == 0: H = b = 0 -> x = 0 -> converged after one step (B/direct_ba_alternating.cc:148-151)
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_frame1, ctx->dev_frame1, ctx->dev_work1, ctx->dev_Hb1, 1,
-                      make_view(surfels), /*write_back*/ 0, nullptr)) return 1;
-  HIP_TRY(hipMemcpy(&w, ctx->dev_work1, sizeof(w), hipMemcpyDeviceToHost));
-  memcpy(out, w.T, 7 * sizeof(float));
-  if (iterations_done) *iterations_done = w.iterations;
-  if (converged) *converged = w.converged;
+                      make_view(surfels), /*write_back*/ 0, /*update_activation*/ 0, ctx->pinned_work1, nullptr)) return 1;
+  const PoseWork& result = ctx->pinned_work1[0];
+  memcpy(out, result.T, 7 * sizeof(float));
+  if (iterations_done) *iterations_done = result.iterations;
+  if (converged) *converged = result.converged;
   return 0;
 }
 
@@ -792,30 +796,19 @@ static int estimate_keyframe_poses_impl(bahip_context* ctx, int use_depth, int u
   launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb);
   CHECK_LAUNCH();
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K,
-                      make_view(surfels), /*write_back*/ 1, rounds_out)) return 1;
-  const int cap = ctx->work_capacity;
-  int* dev_count = ctx->dev_moved + cap;
-  if (update_activation) {
-    HIP_TRY(hipMemsetAsync(dev_count, 0, sizeof(int), ctx->stream));
-    launch_pose_finalize(ctx->stream, ctx->dev_work, K, ctx->dev_kfs, ctx->dev_moved, dev_count);
-    CHECK_LAUNCH();
-  }
-  // one read-back into page-locked memory: work items | moved flags | converged count
-  PoseWork* hw = reinterpret_cast<PoseWork*>(ctx->pinned_work);
-  int* hmoved = reinterpret_cast<int*>(ctx->pinned_work + sizeof(PoseWork) * cap);
-  HIP_TRY(hipMemcpyAsync(hw, ctx->dev_work, sizeof(PoseWork) * K, hipMemcpyDeviceToHost, ctx->stream));
-  if (update_activation) HIP_TRY(hipMemcpyAsync(hmoved, ctx->dev_moved, sizeof(int) * (cap + 1), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+                      make_view(surfels), /*write_back*/ 1, update_activation ? 1 : 0, ctx->pinned_work, rounds_out)) return 1;
+  const PoseWork* hw = ctx->pinned_work;
+  const int* counters = reinterpret_cast<const int*>(hw + K);
   for (int k = 0; k < K; ++k) {
     if (hw[k].iterations > 0) fill_pose(&ctx->host_kfs[k], hw[k].T);
     if (update_activation && ctx->host_kfs[k].activation != BAHIP_KF_INACTIVE)
-      ctx->host_kfs[k].activation = hmoved[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;       // mirror of pose_finalize_kernel
+      ctx->host_kfs[k].activation = hw[k].moved ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;       // mirror of pose_solve_kernel
     if (global_T_frame_out) memcpy(global_T_frame_out + 7 * k, ctx->host_kfs[k].global_T_frame, 7 * sizeof(float));
     if (iterations_done) iterations_done[k] = hw[k].iterations;
     if (converged) converged[k] = hw[k].converged;
-    if (moved_out) moved_out[k] = update_activation ? hmoved[k] : 0;
+    if (moved_out) moved_out[k] = update_activation ? hw[k].moved : 0;
   }
-  if (update_activation && num_converged_out) *num_converged_out = hmoved[cap];
+  if (update_activation && num_converged_out) *num_converged_out = counters[kPoseCounterConverged];
   return 0;
 }
 

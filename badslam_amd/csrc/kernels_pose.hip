@@ -176,12 +176,18 @@ __device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* 
   se3_mul(T, upd, T_next);
 }
 
+// `round`: the Gauss-Newton round this launch closes (its not-done count goes to counter [round]).  update_activation: when
+// a work item is done, the activation update of B/direct_ba_alternating.cc:556-577 is applied to its keyframe right here:
+// moved (the logarithm of old^-1 * new fails the convergence test) -> kActive, else kInactive and one more converged keyframe.
+// The reference does that on the host between the iterations; with the device table authoritative during the BA loop the
+// next iteration's sweeps can be queued while the host is still copying the results into its Keyframe objects.
 __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
-                                  KfEntry* __restrict__ frames, int write_back, int* __restrict__ not_done_count) {
+                                  KfEntry* __restrict__ frames, int write_back, int update_activation, int round) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= num_work) return;
   PoseWork& pw = work[w];
   if (pw.done) return;
+  int* counters = reinterpret_cast<int*>(work + num_work);
   HbFixed* fixed = Hb + (size_t)w * kHbStride;
   float hb[27];
   // the fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
@@ -203,9 +209,19 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
       for (int c = 0; c < 7; ++c) kf.global_T_frame[c] = next[c];
       for (int c = 0; c < 12; ++c) kf.pose.F[c] = pw.F[c];
       se3_rotation(next, kf.pose.GR);
+      if (update_activation) {
+        float inv0[7], diff[7], lg[6];
+        se3_inverse(pw.T0, inv0);        // Keyframe::frame_T_global() of the old pose
+        se3_mul(inv0, next, diff);
+        se3_log(diff, lg);
+        const bool moved = !is_scale1_pose_converged(lg);
+        kf.activation = moved ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+        pw.moved = moved ? 1 : 0;
+        if (!moved) atomicAdd(&counters[kPoseCounterConverged], 1);
+      }
     }
   } else {
-    atomicAdd(not_done_count, 1);
+    atomicAdd(&counters[round], 1);
   }
 }
 
@@ -236,30 +252,16 @@ __global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ fram
   pw.iterations = 0;
   pw.converged = 0;
   pw.done = (frames[k].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
+  pw.moved = 0;
   for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
   for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
   for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
-}
-
-// After the Gauss-Newton rounds of one BA iteration, B/direct_ba_alternating.cc:556-577: a keyframe whose pose moved (the
-// logarithm of old^-1 * new fails the convergence test) becomes kActive, one that did not becomes kInactive and counts as
-// converged, as do the keyframes that were kInactive (not optimised).  The reference does this on the host between the
-// iterations; here the device keyframe table stays authoritative during the BA loop, so the next iteration's sweeps can be
-// queued while the host is still copying the results into its Keyframe objects.
-__global__ void pose_finalize_kernel(const PoseWork* __restrict__ work, int num_kfs, KfEntry* __restrict__ frames,
-                                     int* __restrict__ moved_out, int* __restrict__ num_converged) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= num_kfs) return;
-  if (frames[k].activation == BAHIP_KF_INACTIVE) { moved_out[k] = 0; atomicAdd(num_converged, 1); return; }
-  const PoseWork& pw = work[k];
-  float inv0[7], diff[7], lg[6];
-  se3_inverse(pw.T0, inv0);        // Keyframe::frame_T_global() of the old pose
-  se3_mul(inv0, pw.T, diff);
-  se3_log(diff, lg);
-  const bool moved = !is_scale1_pose_converged(lg);
-  frames[k].activation = moved ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
-  moved_out[k] = moved ? 1 : 0;
-  if (!moved) atomicAdd(num_converged, 1);
+  if (k == 0) {   // the counters behind the work items: per-round not-done counts = 0, converged = the inactive keyframes
+    int* counters = reinterpret_cast<int*>(work + num_kfs);
+    int inactive = 0;
+    for (int j = 0; j < num_kfs; ++j) inactive += (frames[j].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
+    for (int c = 0; c < kPoseTailRecords * 32; ++c) counters[c] = (c == kPoseCounterConverged) ? inactive : 0;
+  }
 }
 
 // DirectBA::DetermineCovisibleActiveKeyframes (B/direct_ba.cc:549-564) on the device table: every kInactive keyframe that is
@@ -276,10 +278,6 @@ __global__ void propagate_covisible_kernel(KfEntry* __restrict__ frames, int num
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
-void launch_pose_finalize(hipStream_t stream, const void* work, int num_kfs, KfEntry* frames, int* moved_out, int* num_converged) {
-  if (num_kfs) hipLaunchKernelGGL(pose_finalize_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, static_cast<const PoseWork*>(work),
-                                  num_kfs, frames, moved_out, num_converged);
-}
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices) {
   if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices);
 }
@@ -305,10 +303,10 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
 }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
-                       int* not_done_count) {
+                       int update_activation, int round) {
   if (num_work == 0) return;
   hipLaunchKernelGGL(pose_solve_kernel, dim3((num_work + 63) / 64), dim3(64), 0, stream, static_cast<PoseWork*>(work),
-                     num_work, Hb, frames, write_back, not_done_count);
+                     num_work, Hb, frames, write_back, update_activation, round);
 }
 
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb) {
