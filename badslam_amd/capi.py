@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbadslam_hip.so")
+# BADSLAM_LIB_DIR: load the backend from another build directory (A/B timing of two builds on one GPU box)
+LIB_PATH = os.path.join(os.environ.get("BADSLAM_LIB_DIR") or os.path.join(_HERE, "lib"), "libbadslam_hip.so")
 
 SURFEL_ATTRIBUTE_COUNT = 17
 MERGE_BUFFER_COUNT = 3

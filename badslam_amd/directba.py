@@ -10,7 +10,8 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_HERE, "lib", "libbadslam_host.so")
+# BADSLAM_LIB_DIR: load the backend from another build directory (A/B timing of two builds on one GPU box)
+HOST_LIB_PATH = os.path.join(os.environ.get("BADSLAM_LIB_DIR") or os.path.join(_HERE, "lib"), "libbadslam_host.so")
 
 _F7 = C.c_float * 7
 _F4 = C.c_float * 4
