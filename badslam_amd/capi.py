@@ -153,6 +153,8 @@ def load():
                 "There is no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
+            if os.environ.get("BADSLAM_LIB_DIR") and not hasattr(lib, name):
+                continue              # an older build under A/B timing (scripts/ab_bench.sh) may lack newer entry points
             fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
