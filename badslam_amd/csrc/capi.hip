@@ -3,7 +3,10 @@
 // and the surfel buffer are borrowed from the caller.
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include <string>
 #include <vector>
@@ -90,6 +93,8 @@ struct bahip_context {
   size_t covis_csr_capacity = 0;
   bool have_covisibility = false;
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
+  void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
+  size_t tile_bounds_bytes = 0;
 
   float* intr_scratch = nullptr;   // intrinsics step: 64 + 8*S floats (glob | B | D | b2 | obs)
   int intr_capacity = 0;
@@ -262,6 +267,17 @@ void timer_end(bahip_context* ctx, int stage) {
 
 int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype);
 
+int ensure_tile_bounds(bahip_context* ctx, uint32_t surfels) {
+  const size_t need = pose_tile_bounds_bytes(surfels);
+  if (need <= ctx->tile_bounds_bytes) return 0;
+  void* grown = nullptr;
+  HIP_TRY(hipMalloc(&grown, need + need / 4));
+  hipFree(ctx->dev_tile_bounds);
+  ctx->dev_tile_bounds = grown;
+  ctx->tile_bounds_bytes = need + need / 4;
+  return 0;
+}
+
 // Batched Gauss-Newton rounds over `num_work` work items already initialised on the device.
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
@@ -269,9 +285,15 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
   int rounds = 0;
   int iterating = num_work;
   const int* counters = reinterpret_cast<const int*>(host_work + num_work);
+  if (ensure_tile_bounds(ctx, s.size)) return 1;
+  static const bool host_timing = getenv("BADSLAM_HOST_TIMING") != nullptr;   // diagnostics: where a pose round's wall time goes
+  static double t_launch = 0, t_wait = 0; static long n_rounds = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int round = 0; round < BAHIP_MAX_POSE_ITERATIONS; ++round) {
+    const double t0 = host_timing ? now() : 0;
     timer_begin(ctx, 2, round == 0, iterating);
-    launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb);
+    launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb, ctx->dev_tile_bounds,
+                           /*stored_bounds*/ round > 0);
     timer_end(ctx, 2);
     CHECK_LAUNCH();
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
@@ -282,7 +304,12 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     CHECK_LAUNCH();
     // one read-back per round: the work items (final after the last round) and the counters behind them
     HIP_TRY(hipMemcpyAsync(host_work, dev_work, sizeof(PoseWork) * ((size_t)num_work + kPoseTailRecords), hipMemcpyDeviceToHost, ctx->stream));
+    const double t1 = host_timing ? now() : 0;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (host_timing) {
+      t_launch += t1 - t0; t_wait += now() - t1;
+      if (++n_rounds % 30 == 0) fprintf(stderr, "[pose rounds, us per round] enqueue %.1f | wait %.1f\n", t_launch / n_rounds, t_wait / n_rounds);
+    }
     ++rounds;
     iterating = counters[round];
     if (iterating == 0) break;
@@ -434,7 +461,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
-  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr);
+  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds);
   if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
@@ -744,8 +771,9 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
   HIP_TRY(hipMemcpyAsync(ctx->dev_work1, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(HbFixed) * kHbStride, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ensure_tile_bounds(ctx, surfels->surfels_size)) return 1;
   launch_pose_accumulate(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_frame1, ctx->dev_work1, 1,
-                         make_view(surfels), ctx->dev_Hb1);
+                         make_view(surfels), ctx->dev_Hb1, ctx->dev_tile_bounds, /*stored_bounds*/ false);
   CHECK_LAUNCH();
   if (reduce_over_ranks(ctx, ctx->dev_Hb1, kHbStride, BAHIP_SUM_I64)) return 1;
   HbFixed* fixed = reinterpret_cast<HbFixed*>(ctx->pinned_f);   // 28 x 8 bytes of the 64-float pinned buffer
@@ -838,7 +866,7 @@ int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* in
   if (need > ctx->covis_csr_capacity) {
     int* grown = nullptr;
     HIP_TRY(hipMalloc(&grown, sizeof(int) * (need + 1024)));
-    hipFree(ctx->dev_covis_csr);
+    hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds);
     ctx->dev_covis_csr = grown;
     ctx->covis_csr_capacity = need + 1024;
   }

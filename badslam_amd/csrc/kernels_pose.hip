@@ -42,11 +42,29 @@ __device__ __forceinline__ void accumulate_jtj(float (&acc)[28], const float (&J
   for (int c = 0; c < 6; ++c) acc[21 + c] = __builtin_fmaf(wr, J[c], acc[21 + c]);
 }
 
+// tile_bounds: one bounding sphere per 64-surfel tile.  The first Gauss-Newton round of a pose phase (stored_bounds == 0)
+// computes them from the positions and stores them; the later rounds -- which iterate only the few keyframes that have not
+// converged, yet launch one wavefront (or several) per tile all the same -- read the sphere back (one scalar load), test it
+// against the remaining work items and return at once if none can see the tile, before any surfel is loaded.  Positions do
+// not change between the rounds of a phase, so the stored sphere is the one that would be recomputed.
 template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
 pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
-                       int num_work, SurfelsView s, HbFixed* __restrict__ Hb) {
-  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPoseBlock + threadIdx.x;
+                       int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds) {
+  const uint32_t tile = xcd_chunked_tile(blockIdx.x);
+  const int lane = threadIdx.x & 63;
+  WaveBounds wb;
+  if (stored_bounds) {
+    wb = tile_bounds[tile];     // wave-uniform address: scalar loads
+    if (wb.r < 0.f) return;
+    bool any = false;
+    for (int base = blockIdx.y; base < num_work && !any; base += 64 * gridDim.y) {
+      const int item = base + lane * gridDim.y;
+      any = __any(item < num_work && !work[item].done && sphere_may_project(in, work[item].F, wb)) != 0;
+    }
+    if (!any) return;
+  }
+  const uint32_t i = tile * kPoseBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -58,11 +76,13 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     d2 = s.row(kSurfelDescriptor2)[ii];
   }
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);
-  const int lane = threadIdx.x & 63;
   const int slot = wave_reduce28_slot(lane);
 
   // Only the work items whose frustum can contain this wavefront's surfels are visited (wave_cull.h).
-  const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
+  if (!stored_bounds) {
+    wb = wave_bounds(gp, in_range && (gp.x == gp.x));
+    if (blockIdx.y == 0 && lane == 0) tile_bounds[tile] = wb;
+  }
   for_each_candidate(
       num_work,
       [&](int w) { return !work[w].done && sphere_may_project(in, work[w].F, wb); },
@@ -285,8 +305,13 @@ void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs
 static int g_forced_pose_parts = [] { const char* e = getenv("BAHIP_POSE_PARTS"); return e ? atoi(e) : 0; }();
 void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
 
+size_t pose_tile_bounds_bytes(uint32_t surfels) {
+  const size_t tiles = ((size_t)(surfels + kPoseBlock - 1) / kPoseBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk);
+  return tiles * sizeof(WaveBounds);
+}
+
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
-                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb) {
+                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds) {
   if (s.size == 0 || num_work == 0) return;
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
@@ -297,9 +322,11 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
                          : tiles >= 32768 ? 2 : tiles >= 8192 ? 4 : 8;   // measured: 46.9 k tiles 2.01 / 1.79 / 1.80 ms with 1 / 2 / 4 parts
   const dim3 grid(tiles, parts), block(kPoseBlock);
   const PoseWork* pw = static_cast<const PoseWork*>(work);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb);
+  WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);
+  const int sb = stored_bounds ? 1 : 0;
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb);
 }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,

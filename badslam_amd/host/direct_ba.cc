@@ -6,7 +6,9 @@
 #include "direct_ba.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 namespace vis {
 
@@ -347,6 +349,12 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     pending.valid = false;
   };
   bool scene_bound = false;   // does the backend context hold the current keyframes / poses / activations / intrinsics?
+  // BADSLAM_HOST_TIMING=1: wall time the host spends in each part of an iteration (printed once per call; diagnostics)
+  const bool host_timing = getenv("BADSLAM_HOST_TIMING") != nullptr;
+  double t_phase[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](int phase) { if (host_timing) { const double t = now(); t_phase[phase] += t - t_mark; t_mark = t; } };
 
   for (int iteration = 0; iteration < max_iterations; ++iteration) {
     if (progress_function) {
@@ -389,11 +397,13 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       if (!keyframes_with_new_surfels.empty()) scene_bound = true;   // CreateSurfelsForKeyframe bound the current scene
     }
 
+    lap(0);
     if (!scene_bound) {
       apply_pending();
       BindScene(stream);
       scene_bound = true;
     }
+    lap(1);
 
     // --- surfel activation + geometry ---
     if (optimize_geometry && surfels_size_ > old_surfels_size)
@@ -414,8 +424,10 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         BAHIP_CHECKED_CALL(bahip_optimize_geometry_iteration(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s));
       }
     }
+    lap(2);
     // the previous iteration's pose results go into the Keyframe objects while the GPU runs the sweep queued above
     apply_pending();
+    lap(3);
 
     // --- surfel merge + compaction ---
     if (do_surfel_updates) {
@@ -444,6 +456,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
                                                                              pending.moved.data(), &rounds, &converged_bound));
       pending.valid = true;
       pending.propagate = false;
+      lap(4);
       last_pose_rounds_ += rounds;
       num_converged = (usize)converged_bound + (keyframes_.size() - (usize)K);   // deleted keyframes count as converged
       for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
@@ -503,6 +516,10 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     }
   }
   apply_pending();
+  lap(5);
+  if (host_timing)
+    fprintf(stderr, "[DirectBA host timing, us] loop top %.0f | bind %.0f | geometry launch %.0f | apply pending %.0f | pose phase %.0f | rest %.0f\n",
+            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
 
   if (increase_ba_iteration_count) {
     PerformBASchemeEndTasks(stream, do_surfel_updates);
