@@ -112,6 +112,8 @@ SIGNATURES = {
                                                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bahip_set_covisibility": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "bahip_propagate_covisible_activation": (C.c_int, [C.c_void_p]),
+    "bahip_set_activation_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]),
+    "bahip_apply_activation_window": (C.c_int, [C.c_void_p]),
     "bahip_determine_supporting_surfels": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(Frame), C.POINTER(C.c_float),
                                                      C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,

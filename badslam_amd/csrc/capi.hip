@@ -92,6 +92,9 @@ struct bahip_context {
   int* dev_covis_csr = nullptr;    // offsets (K + 1) followed by the indices
   size_t covis_csr_capacity = 0;
   bool have_covisibility = false;
+  std::vector<uint8_t> window;     // per bound keyframe: inside the fixed active window (bahip_set_activation_window)
+  uint8_t* dev_window = nullptr;
+  size_t window_capacity = 0;
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
@@ -461,7 +464,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
-  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds);
+  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
   if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
@@ -690,6 +693,7 @@ int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int
   }
   ctx->num_kfs = num_keyframes;
   ctx->have_covisibility = false;   // lists refer to the previous binding
+  ctx->window.clear();
   if (num_keyframes > 0) {
     HIP_TRY(hipMemcpyAsync(ctx->dev_kfs, ctx->host_kfs.data(), sizeof(KfEntry) * num_keyframes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // host_kfs is pageable
@@ -866,7 +870,7 @@ int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* in
   if (need > ctx->covis_csr_capacity) {
     int* grown = nullptr;
     HIP_TRY(hipMalloc(&grown, sizeof(int) * (need + 1024)));
-    hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds);
+    hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
     ctx->dev_covis_csr = grown;
     ctx->covis_csr_capacity = need + 1024;
   }
@@ -875,6 +879,32 @@ int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* in
   HIP_TRY(hipStreamSynchronize(ctx->stream));   // the vectors are pageable
   ctx->have_covisibility = true;
   return 0;
+}
+
+int bahip_set_activation_window(bahip_context* ctx, const uint8_t* in_window, int num_keyframes) {
+  REQUIRE(num_keyframes == ctx->num_kfs && in_window != nullptr, "bahip_set_activation_window: one flag per bound keyframe");
+  ctx->window.assign(in_window, in_window + num_keyframes);
+  if ((size_t)num_keyframes > ctx->window_capacity) {
+    uint8_t* grown = nullptr;
+    HIP_TRY(hipMalloc(&grown, (size_t)num_keyframes + 256));
+    hipFree(ctx->dev_window);
+    ctx->dev_window = grown;
+    ctx->window_capacity = (size_t)num_keyframes + 256;
+  }
+  if (num_keyframes) {
+    HIP_TRY(hipMemcpyAsync(ctx->dev_window, ctx->window.data(), num_keyframes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return 0;
+}
+
+int bahip_apply_activation_window(bahip_context* ctx) {
+  REQUIRE((int)ctx->window.size() == ctx->num_kfs, "bahip_set_activation_window must follow bahip_set_keyframes");
+  const int K = ctx->num_kfs;
+  launch_window_activation(ctx->stream, ctx->dev_kfs, K, ctx->dev_window);
+  CHECK_LAUNCH();
+  for (int k = 0; k < K; ++k) ctx->host_kfs[k].activation = ctx->window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+  return bahip_propagate_covisible_activation(ctx);
 }
 
 int bahip_propagate_covisible_activation(bahip_context* ctx) {

@@ -297,7 +297,17 @@ __global__ void propagate_covisible_kernel(KfEntry* __restrict__ frames, int num
   }
 }
 
+// Top of an alternating iteration with a fixed active window (B/direct_ba_alternating.cc:353-371): keyframes inside the window
+// become kActive, all others kInactive (the co-visible ones are then raised by propagate_covisible_kernel).
+__global__ void window_activation_kernel(KfEntry* __restrict__ frames, int num_kfs, const uint8_t* __restrict__ in_window) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < num_kfs) frames[k].activation = in_window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
+void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window) {
+  if (num_kfs) hipLaunchKernelGGL(window_activation_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, in_window);
+}
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices) {
   if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices);
 }

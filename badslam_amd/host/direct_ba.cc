@@ -166,6 +166,9 @@ bahip_surfels DirectBA::SurfelsStruct(bool with_active) const {
 }
 
 void DirectBA::BindScene(hipStream_t stream) {
+  static const bool host_timing = getenv("BADSLAM_HOST_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = host_timing ? now() : 0;
   BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
   const bahip_camera cc = ToBahipCamera(color_camera_), dc = ToBahipCamera(depth_camera_);
   const bahip_depth_params dp = ToBahipDepthParams(depth_params_);
@@ -183,7 +186,9 @@ void DirectBA::BindScene(hipStream_t stream) {
     bound_ids_.push_back(keyframe->id());
     list.push_back(k);
   }
+  const double t1 = host_timing ? now() : 0;
   BAHIP_CHECKED_CALL(bahip_set_keyframes(ctx_, list.data(), (int)list.size()));
+  const double t2 = host_timing ? now() : 0;
   // co-visibility lists over bound indices: the activation state machine of the alternating scheme runs on the device table
   vector<int> offsets(1, 0), indices;
   for (int id : bound_ids_) {
@@ -191,7 +196,11 @@ void DirectBA::BindScene(hipStream_t stream) {
       if (other >= 0 && other < (int)id_to_bound_.size() && id_to_bound_[other] >= 0) indices.push_back(id_to_bound_[other]);
     offsets.push_back((int)indices.size());
   }
+  const double t3 = host_timing ? now() : 0;
   BAHIP_CHECKED_CALL(bahip_set_covisibility(ctx_, offsets.data(), indices.data(), (int)bound_ids_.size()));
+  if (host_timing)
+    fprintf(stderr, "[BindScene, us] list %.0f | set_keyframes %.0f | covisibility lists (%zu entries) %.0f | set_covisibility %.0f\n", t1 - t0,
+            t2 - t1, indices.size(), t3 - t2, now() - t3);
 }
 
 // ---- surfel creation (B/direct_ba.cc:340-405) ---------------------------------------------------------------------
@@ -330,23 +339,23 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
   // (bahip_estimate_keyframe_poses_and_update_activation, bahip_propagate_covisible_activation), so the next iteration's sweeps
   // can be queued at once, and the results are copied into the Keyframe objects ("pending") while the GPU already works on
   // them.  Anything that reads the Keyframe objects applies the pending results first.
-  struct PendingPoseResults {
-    bool valid = false, propagate = false;
-    vector<float> poses;
-    vector<int> moved;
-  } pending;
+  // Deferred host bookkeeping: operations on the Keyframe objects that mirror what the device table already went through,
+  // run in order under the lock.
+  vector<std::function<void()>> pending;
   auto apply_pending = [&]() {
-    if (!pending.valid) return;
+    if (pending.empty()) return;
     Lock();
-    for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
-      if (!keyframe || keyframe->activation() == Keyframe::Activation::kInactive) continue;
-      const int b = id_to_bound_[keyframe->id()];
-      keyframe->set_global_T_frame(SE3f(&pending.poses[7 * (size_t)b]));
-      keyframe->SetActivation(pending.moved[b] ? Keyframe::Activation::kActive : Keyframe::Activation::kInactive);
-    }
-    if (pending.propagate) DetermineCovisibleActiveKeyframes();
+    for (auto& op : pending) op();
     Unlock();
-    pending.valid = false;
+    pending.clear();
+  };
+  auto set_window_activation = [this, active_keyframe_window_start, active_keyframe_window_end]() {
+    for (u32 i = 0; i < keyframes_.size(); ++i) {
+      if (!keyframes_[i]) continue;
+      keyframes_[i]->SetActivation(((int)i >= active_keyframe_window_start && (int)i <= active_keyframe_window_end)
+                                       ? Keyframe::Activation::kActive : Keyframe::Activation::kInactive);
+    }
+    DetermineCovisibleActiveKeyframes();
   };
   bool scene_bound = false;   // does the backend context hold the current keyframes / poses / activations / intrinsics?
   // BADSLAM_HOST_TIMING=1: wall time the host spends in each part of an iteration (printed once per call; diagnostics)
@@ -363,16 +372,16 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     }
     if (num_iterations_done) ++*num_iterations_done;
     if (fixed_active_keyframe_set) {
-      apply_pending();
-      Lock();
-      for (u32 i = 0; i < keyframes_.size(); ++i) {
-        if (!keyframes_[i]) continue;
-        keyframes_[i]->SetActivation(((int)i >= active_keyframe_window_start && (int)i <= active_keyframe_window_end)
-                                         ? Keyframe::Activation::kActive : Keyframe::Activation::kInactive);
+      if (scene_bound) {
+        // the device table takes the window activation itself; the Keyframe objects follow when the pending work is applied
+        BAHIP_CHECKED_CALL(bahip_apply_activation_window(ctx_));
+        pending.push_back(set_window_activation);
+      } else {
+        apply_pending();
+        Lock();
+        set_window_activation();
+        Unlock();
       }
-      DetermineCovisibleActiveKeyframes();
-      Unlock();
-      scene_bound = false;
     }
 
     // --- surfel creation ---
@@ -401,6 +410,12 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     if (!scene_bound) {
       apply_pending();
       BindScene(stream);
+      if (fixed_active_keyframe_set) {
+        vector<uint8_t> in_window(bound_ids_.size());
+        for (usize b = 0; b < bound_ids_.size(); ++b)
+          in_window[b] = (bound_ids_[b] >= active_keyframe_window_start && bound_ids_[b] <= active_keyframe_window_end) ? 1 : 0;
+        BAHIP_CHECKED_CALL(bahip_set_activation_window(ctx_, in_window.data(), (int)in_window.size()));
+      }
       scene_bound = true;
     }
     lap(1);
@@ -446,16 +461,22 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     usize num_converged = 0;
     if (optimize_poses) {
       const int K = (int)bound_ids_.size();
-      pending.poses.assign(7 * (size_t)K, 0.f);
-      pending.moved.assign(K, 0);
+      auto poses = std::make_shared<vector<float>>(7 * (size_t)K, 0.f);
+      auto moved = std::make_shared<vector<int>>(K, 0);
       vector<int> its(K), conv(K);
       int rounds = 0, converged_bound = 0;
       const bahip_surfels s = SurfelsStruct();
       BAHIP_CHECKED_CALL(bahip_estimate_keyframe_poses_and_update_activation(ctx_, use_depth_residuals_, use_descriptor_residuals_, &s,
-                                                                             pending.poses.data(), its.data(), conv.data(),
-                                                                             pending.moved.data(), &rounds, &converged_bound));
-      pending.valid = true;
-      pending.propagate = false;
+                                                                             poses->data(), its.data(), conv.data(), moved->data(),
+                                                                             &rounds, &converged_bound));
+      pending.push_back([this, poses, moved]() {
+        for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
+          if (!keyframe || keyframe->activation() == Keyframe::Activation::kInactive) continue;
+          const int b = id_to_bound_[keyframe->id()];
+          keyframe->set_global_T_frame(SE3f(&(*poses)[7 * (size_t)b]));
+          keyframe->SetActivation((*moved)[b] ? Keyframe::Activation::kActive : Keyframe::Activation::kInactive);
+        }
+      });
       lap(4);
       last_pose_rounds_ += rounds;
       num_converged = (usize)converged_bound + (keyframes_.size() - (usize)K);   // deleted keyframes count as converged
@@ -507,13 +528,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     if (timer && timer->GetTimeSinceStart() > time_limit) break;
     // DetermineCovisibleActiveKeyframes: on the device table now, on the Keyframe objects when the pending results are applied
     BAHIP_CHECKED_CALL(bahip_propagate_covisible_activation(ctx_));
-    if (pending.valid) {
-      pending.propagate = true;
-    } else {
-      Lock();
-      DetermineCovisibleActiveKeyframes();
-      Unlock();
-    }
+    pending.push_back([this]() { DetermineCovisibleActiveKeyframes(); });
   }
   apply_pending();
   lap(5);

@@ -241,6 +241,11 @@ int bahip_estimate_keyframe_poses_and_update_activation(bahip_context* ctx, int 
  * Asynchronous on the context stream. */
 int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* indices, int num_keyframes);
 int bahip_propagate_covisible_activation(bahip_context* ctx);
+/* Fixed active window of the alternating scheme (B/direct_ba_alternating.cc:353-371): in_window[k] != 0 for the bound
+ * keyframes inside it.  bahip_apply_activation_window sets those kActive, all others kInactive, and then propagates the
+ * co-visible activation -- the top of every iteration, on the device table; asynchronous. */
+int bahip_set_activation_window(bahip_context* ctx, const uint8_t* in_window, int num_keyframes);
+int bahip_apply_activation_window(bahip_context* ctx);
 
 /* ---- surfel lifecycle --------------------------------------------------------------------------- */
 /* B/kernels.h DetermineSupportingSurfelsCUDA / ...AndMergeSurfelsCUDA
