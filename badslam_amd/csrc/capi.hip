@@ -833,8 +833,6 @@ static int estimate_keyframe_poses_impl(bahip_context* ctx, int use_depth, int u
   const int* counters = reinterpret_cast<const int*>(hw + K);
   for (int k = 0; k < K; ++k) {
     if (hw[k].iterations > 0) fill_pose(&ctx->host_kfs[k], hw[k].T);
-    if (update_activation && ctx->host_kfs[k].activation != BAHIP_KF_INACTIVE)
-      ctx->host_kfs[k].activation = hw[k].moved ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;       // mirror of pose_solve_kernel
     if (global_T_frame_out) memcpy(global_T_frame_out + 7 * k, ctx->host_kfs[k].global_T_frame, 7 * sizeof(float));
     if (iterations_done) iterations_done[k] = hw[k].iterations;
     if (converged) converged[k] = hw[k].converged;
@@ -882,8 +880,8 @@ int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* in
 }
 
 int bahip_set_activation_window(bahip_context* ctx, const uint8_t* in_window, int num_keyframes) {
-  REQUIRE(num_keyframes == ctx->num_kfs && in_window != nullptr, "bahip_set_activation_window: one flag per bound keyframe");
-  ctx->window.assign(in_window, in_window + num_keyframes);
+  REQUIRE(num_keyframes == ctx->num_kfs && (in_window != nullptr || num_keyframes == 0), "bahip_set_activation_window: one flag per bound keyframe");
+  ctx->window.assign(in_window, in_window + (in_window ? num_keyframes : 0));
   if ((size_t)num_keyframes > ctx->window_capacity) {
     uint8_t* grown = nullptr;
     HIP_TRY(hipMalloc(&grown, (size_t)num_keyframes + 256));
@@ -903,7 +901,6 @@ int bahip_apply_activation_window(bahip_context* ctx) {
   const int K = ctx->num_kfs;
   launch_window_activation(ctx->stream, ctx->dev_kfs, K, ctx->dev_window);
   CHECK_LAUNCH();
-  for (int k = 0; k < K; ++k) ctx->host_kfs[k].activation = ctx->window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
   return bahip_propagate_covisible_activation(ctx);
 }
 
@@ -911,15 +908,9 @@ int bahip_propagate_covisible_activation(bahip_context* ctx) {
   REQUIRE(ctx->have_covisibility && (int)ctx->covis_offsets.size() == ctx->num_kfs + 1,
           "bahip_set_covisibility must follow bahip_set_keyframes before the activation can be propagated");
   const int K = ctx->num_kfs;
+  // (the activation field of the host-side copy of the table is "as bound": only the device table follows the state machine)
   launch_propagate_covisible(ctx->stream, ctx->dev_kfs, K, ctx->dev_covis_csr, ctx->dev_covis_csr + K + 1);
   CHECK_LAUNCH();
-  for (int k = 0; k < K; ++k) {   // the host mirror of the table
-    if (ctx->host_kfs[k].activation != BAHIP_KF_ACTIVE) continue;
-    for (int j = ctx->covis_offsets[k]; j < ctx->covis_offsets[k + 1]; ++j) {
-      KfEntry& other = ctx->host_kfs[ctx->covis_indices[j]];
-      if (other.activation == BAHIP_KF_INACTIVE) other.activation = BAHIP_KF_COVISIBLE_ACTIVE;
-    }
-  }
   return 0;
 }
 
@@ -1242,6 +1233,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
       for (int c = 3; c < 6; ++c) { const float v = lg[c] * 10.f; sq += v * v; }
       if (sq < 1e-06f) ++num_converged;
     }
+    // (re-uploads the table "as bound" apart from the poses: nothing in the PCG scheme reads the activation field)
     HIP_TRY(hipMemcpyAsync(ctx->dev_kfs, ctx->host_kfs.data(), sizeof(KfEntry) * K, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
