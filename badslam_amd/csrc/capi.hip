@@ -302,11 +302,11 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
     if (reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
     timer_begin(ctx, 3, round == 0);
-    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, round);
+    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, round, host_work);
     timer_end(ctx, 3);
     CHECK_LAUNCH();
-    // one read-back per round: the work items (final after the last round) and the counters behind them
-    HIP_TRY(hipMemcpyAsync(host_work, dev_work, sizeof(PoseWork) * ((size_t)num_work + kPoseTailRecords), hipMemcpyDeviceToHost, ctx->stream));
+    // per round only the counters are copied (256 bytes); finished work items were written to host_work by the kernel itself
+    HIP_TRY(hipMemcpyAsync(host_work + num_work, dev_work + num_work, sizeof(PoseWork) * kPoseTailRecords, hipMemcpyDeviceToHost, ctx->stream));
     const double t1 = host_timing ? now() : 0;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (host_timing) {
@@ -825,7 +825,7 @@ static int estimate_keyframe_poses_impl(bahip_context* ctx, int use_depth, int u
   if (num_converged_out) *num_converged_out = 0;
   if (K == 0) return 0;
   if (ensure_work(ctx, K)) return 1;
-  launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb);
+  launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work);
   CHECK_LAUNCH();
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K,
                       make_view(surfels), /*write_back*/ 1, update_activation ? 1 : 0, ctx->pinned_work, rounds_out)) return 1;

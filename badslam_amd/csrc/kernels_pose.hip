@@ -201,8 +201,11 @@ __device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* 
 // moved (the logarithm of old^-1 * new fails the convergence test) -> kActive, else kInactive and one more converged keyframe.
 // The reference does that on the host between the iterations; with the device table authoritative during the BA loop the
 // next iteration's sweeps can be queued while the host is still copying the results into its Keyframe objects.
+// host_out: page-locked host memory mapped into the device (zero-copy): a work item that is done writes its final record there,
+// so the host needs no copy of the work array, only the 256 bytes of counters per round.
 __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
-                                  KfEntry* __restrict__ frames, int write_back, int update_activation, int round) {
+                                  KfEntry* __restrict__ frames, int write_back, int update_activation, int round,
+                                  PoseWork* __restrict__ host_out) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= num_work) return;
   PoseWork& pw = work[w];
@@ -240,6 +243,7 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
         if (!moved) atomicAdd(&counters[kPoseCounterConverged], 1);
       }
     }
+    host_out[w] = pw;
   } else {
     atomicAdd(&counters[round], 1);
   }
@@ -264,7 +268,7 @@ void launch_pose_step_debug(hipStream_t stream, const float* in, float* out) {
 
 // Builds one work item per bound keyframe (skipping kInactive ones), B/direct_ba_alternating.cc:547-553.
 __global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs, PoseWork* __restrict__ work,
-                                                HbFixed* __restrict__ Hb) {
+                                                HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num_kfs) return;
   PoseWork& pw = work[k];
@@ -276,6 +280,7 @@ __global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ fram
   for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
   for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
   for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
+  if (pw.done) host_out[k] = pw;   // skipped keyframes: their (unchanged) record
   if (k == 0) {   // the counters behind the work items: per-round not-done counts = 0, converged = the inactive keyframes
     int* counters = reinterpret_cast<int*>(work + num_kfs);
     int inactive = 0;
@@ -340,16 +345,16 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
 }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
-                       int update_activation, int round) {
+                       int update_activation, int round, void* host_out) {
   if (num_work == 0) return;
   hipLaunchKernelGGL(pose_solve_kernel, dim3((num_work + 63) / 64), dim3(64), 0, stream, static_cast<PoseWork*>(work),
-                     num_work, Hb, frames, write_back, update_activation, round);
+                     num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out));
 }
 
-void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb) {
+void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out) {
   if (num_kfs == 0) return;
   hipLaunchKernelGGL(pose_init_from_keyframes_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs,
-                     static_cast<PoseWork*>(work), Hb);
+                     static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out));
 }
 
 
