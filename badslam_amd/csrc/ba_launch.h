@@ -43,7 +43,8 @@ void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb
                        int update_activation, int round, void* host_out);
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out);
 
-void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window);
+void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window, const int* offsets,
+                              const int* indices);   // window activation + co-visible propagation
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes

@@ -899,9 +899,10 @@ int bahip_set_activation_window(bahip_context* ctx, const uint8_t* in_window, in
 int bahip_apply_activation_window(bahip_context* ctx) {
   REQUIRE((int)ctx->window.size() == ctx->num_kfs, "bahip_set_activation_window must follow bahip_set_keyframes");
   const int K = ctx->num_kfs;
-  launch_window_activation(ctx->stream, ctx->dev_kfs, K, ctx->dev_window);
+  REQUIRE(ctx->have_covisibility && (int)ctx->covis_offsets.size() == K + 1, "bahip_set_covisibility must follow bahip_set_keyframes");
+  launch_window_activation(ctx->stream, ctx->dev_kfs, K, ctx->dev_window, ctx->dev_covis_csr, ctx->dev_covis_csr + K + 1);
   CHECK_LAUNCH();
-  return bahip_propagate_covisible_activation(ctx);
+  return 0;
 }
 
 int bahip_propagate_covisible_activation(bahip_context* ctx) {

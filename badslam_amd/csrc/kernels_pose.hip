@@ -309,9 +309,30 @@ __global__ void window_activation_kernel(KfEntry* __restrict__ frames, int num_k
   if (k < num_kfs) frames[k].activation = in_window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
 }
 
+// Both steps in one workgroup (num_kfs <= 1024): one launch at the top of an iteration instead of two.
+__global__ void __launch_bounds__(1024) window_and_propagate_kernel(KfEntry* __restrict__ frames, int num_kfs,
+                                                                    const uint8_t* __restrict__ in_window,
+                                                                    const int* __restrict__ offsets, const int* __restrict__ indices) {
+  const int k = threadIdx.x;
+  if (k < num_kfs) frames[k].activation = in_window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+  __syncthreads();
+  if (k < num_kfs && in_window[k])
+    for (int j = offsets[k]; j < offsets[k + 1]; ++j) {
+      const int other = indices[j];
+      if (!in_window[other]) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
+    }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
-void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window) {
-  if (num_kfs) hipLaunchKernelGGL(window_activation_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, in_window);
+void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window, const int* offsets,
+                              const int* indices) {
+  if (num_kfs == 0) return;
+  if (num_kfs <= 1024) {
+    hipLaunchKernelGGL(window_and_propagate_kernel, dim3(1), dim3(1024), 0, stream, frames, num_kfs, in_window, offsets, indices);
+  } else {
+    hipLaunchKernelGGL(window_activation_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, in_window);
+    hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices);
+  }
 }
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices) {
   if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices);

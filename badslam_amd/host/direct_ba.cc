@@ -403,7 +403,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       }
       Unlock();
       for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
-      if (!keyframes_with_new_surfels.empty()) scene_bound = true;   // CreateSurfelsForKeyframe bound the current scene
+      if (!keyframes_with_new_surfels.empty()) scene_bound = false;   // CreateSurfelsForKeyframe re-bound the keyframes: lists and window go again
     }
 
     lap(0);
@@ -527,7 +527,9 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     }
     if (timer && timer->GetTimeSinceStart() > time_limit) break;
     // DetermineCovisibleActiveKeyframes: on the device table now, on the Keyframe objects when the pending results are applied
-    BAHIP_CHECKED_CALL(bahip_propagate_covisible_activation(ctx_));
+    // (with a fixed window the next iteration overwrites every activation on the device first thing, so only the Keyframe objects
+    // need this step there)
+    if (!fixed_active_keyframe_set) BAHIP_CHECKED_CALL(bahip_propagate_covisible_activation(ctx_));
     pending.push_back([this]() { DetermineCovisibleActiveKeyframes(); });
   }
   apply_pending();
