@@ -131,6 +131,7 @@ SIGNATURES = {
     "bahip_debug_count_pairs": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.POINTER(C.c_uint64)]),
     "bahip_debug_set_launch_shapes": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "bahip_debug_read_pattern": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "bahip_debug_exact_math": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t]),
     "bahip_debug_pose_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bahip_debug_wave_reduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -24,6 +24,8 @@ void launch_min_max_depth(hipStream_t stream, const uint16_t* depth, uint32_t de
 void launch_pack_planes(hipStream_t stream, const KfEntry& frame, int width, int height, int cwidth, int cheight, uint32_t* geom,
                         uint32_t* lumafp);
 
+void launch_read_pattern(hipStream_t stream, const uint32_t* data, size_t words, int pattern, uint32_t* sink);
+
 // kernels_surfel.hip
 void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                        uint32_t surfels_size);

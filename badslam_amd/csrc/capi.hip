@@ -117,7 +117,7 @@ struct bahip_context {
   void* rccl_comm = nullptr;       // ncclComm_t created by bahip_context_init_rccl (native all-reduce on ctx->stream)
 
   int profiling = 0;               // 0 off, 1 last call of each stage, 2 cumulative since bahip_set_profiling
-  StageTimer timers[4];
+  StageTimer timers[6];              // 0 activation, 1 geometry, 2 pose accumulate, 3 pose solve, 4 intrinsics, 5 PCG iteration
 };
 
 namespace {
@@ -1076,6 +1076,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   float* D = B + 5 * (size_t)S;
   float* b2 = D + S;
   float* obs = b2 + S;                        // observation counts as floats (exact under a float SUM all-reduce)
+  timer_begin(ctx, 4, true);
   HIP_TRY(hipMemsetAsync(glob, 0, sizeof(float) * (64 + 8 * (size_t)S), ctx->stream));
   launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
                                make_view(surfels), glob, B, D, b2, obs, S);
@@ -1085,6 +1086,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
     launch_intrinsics_schur(ctx->stream, S, glob, B, D, b2, obs + ctx->intr_capacity /* past the all-reduced block */);
     CHECK_LAUNCH();
   }
+  timer_end(ctx, 4);   // the sweep and the Schur complement; the 5x5 / 4x4 solves and the cfactor update that follow are tiny
   HIP_TRY(hipMemcpyAsync(ctx->pinned_f, glob, 34 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const float* g = ctx->pinned_f;
@@ -1320,6 +1322,21 @@ int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in
   return 0;
 }
 
+int bahip_debug_read_pattern(bahip_context* ctx, size_t bytes, int pattern, int repeats) {
+  REQUIRE(bytes >= 4096 && (pattern == 0 || pattern == 1) && repeats >= 1, "bahip_debug_read_pattern: bad arguments");
+  uint32_t* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, bytes + 4));
+  hipError_t e = hipMemsetAsync(buf, 0, bytes + 4, ctx->stream);
+  for (int r = 0; r < repeats && e == hipSuccess; ++r) {
+    launch_read_pattern(ctx->stream, buf, bytes / 4, pattern, buf + bytes / 4);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(buf);
+  if (e != hipSuccess) return fail("bahip_debug_read_pattern", __FILE__, __LINE__, e);
+  return 0;
+}
+
 int bahip_debug_exact_math(bahip_context* ctx, int kind, const float* in, float* out, size_t n) {
   REQUIRE(kind == 0 || kind == 1, "bahip_debug_exact_math: kind must be 0 (reciprocal) or 1 (square root)");
   if (n == 0) return 0;
@@ -1386,7 +1403,7 @@ int bahip_set_profiling(bahip_context* ctx, int enabled) {
 }
 
 int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* launches_out) {
-  REQUIRE(stage >= 0 && stage < 4, "stage out of range");
+  REQUIRE(stage >= 0 && stage < 6, "stage out of range");
   StageTimer& t = ctx->timers[stage];
   float total = 0.f;
   for (int i = 0; i < t.used; ++i) {
@@ -1401,7 +1418,7 @@ int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* 
 }
 
 int bahip_stage_work_units(bahip_context* ctx, int stage, long long* units_out) {
-  REQUIRE(stage >= 0 && stage < 4 && units_out != nullptr, "stage out of range");
+  REQUIRE(stage >= 0 && stage < 6 && units_out != nullptr, "stage out of range");
   *units_out = ctx->timers[stage].units;
   return 0;
 }

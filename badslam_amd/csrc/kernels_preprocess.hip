@@ -257,4 +257,24 @@ void launch_pack_planes(hipStream_t stream, const KfEntry& frame, int width, int
                      cwidth, cheight, ftpr, fwords, lumafp);
 }
 
+// ---- counter calibration (tooling) -------------------------------------------------------------------------------------
+// Reads of KNOWN size with the instruction width the sweeps gather with (global_load_dword, 4 bytes per lane), so that the
+// FETCH_SIZE counter of rocprofv3 can be calibrated on this access width (MI355X_MICROARCH.md calibrates its x2 correction
+// for wide coalesced reads only).  pattern 0: every dword of the buffer once, consecutive lanes on consecutive dwords;
+// pattern 1: one dword per 128-byte line (a gather that uses 4 of every 128 bytes).
+__global__ void read_pattern_kernel(const uint32_t* __restrict__ data, size_t words, int pattern, uint32_t* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  uint32_t acc = 0;
+  if (pattern == 0) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) acc += data[i];
+  } else {
+    const size_t lines = words / 32;
+    for (size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x; l < lines; l += stride) acc += data[l * 32 + (l & 31)];
+  }
+  if (acc == 0x12345678u) *sink = acc;   // never true for a zero-filled buffer: keeps the loads alive
+}
+void launch_read_pattern(hipStream_t stream, const uint32_t* data, size_t words, int pattern, uint32_t* sink) {
+  hipLaunchKernelGGL(read_pattern_kernel, dim3(8192), dim3(256), 0, stream, data, words, pattern, sink);
+}
+
 }  // namespace bahip

@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SURFEL_ROWS = 17        # BAHIP_SURFEL_ATTRIBUTE_COUNT
-STAGES = ("surfel_activation", "geometry_optimization", "pose_accumulate", "pose_solve")
+STAGES = ("surfel_activation", "geometry_optimization", "pose_accumulate", "pose_solve", "intrinsics_optimization")
 
 
 def parse_args():
@@ -64,7 +64,8 @@ def parse_args():
     p.add_argument("--no-spatial-sort", action="store_true", help="leave the surfels in creation order")
     p.add_argument("--build-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the untimed extra measurements after the timed region (intrinsics stage, PCG scheme)")
     return p.parse_args()
 
 
@@ -118,44 +119,62 @@ def build_scene(args, log):
     return ba, data, poses_gt
 
 
-def pmc_traffic_bytes(kernel_prefix):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (scripts/profile_round.sh -> profiles/<round>_pmc_per_kernel.json; FETCH_SIZE and WRITE_SIZE are
-    collected in separate passes and are in KB).  gfx950 correction of MI355X_MICROARCH.md "HBM":
-    FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled.  Returns None if no profile is committed."""
+def committed_profile(args):
+    """The newest committed PMC summary (scripts/profile_round.sh -> profiles/<tag>_pmc_per_kernel.json) whose recorded
+    config is THIS run's workload -- counters of another scene are not this run's traffic.  None if there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")))
-    if not files:
+    want = {"keyframes": args.keyframes, "surfels": args.surfels, "width": args.width, "height": args.height,
+            "intrinsics": bool(args.intrinsics), "pcg": bool(args.pcg)}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")), reverse=True):
+        with open(path) as f:
+            pmc = json.load(f)
+        if pmc.get("config") == want:
+            return pmc, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def pmc_kernel_entry(pmc, source, kernel_prefix):
+    """HBM-side bytes per launch of one kernel from the PMC passes (FETCH_SIZE and WRITE_SIZE, collected in separate passes,
+    in KB).  FETCH_SIZE counts fabric read requests; MI355X_MICROARCH.md "HBM" calibrates it for wide coalesced reads
+    (128-byte requests tallied at 64 bytes -> x2).  These sweeps issue 4-byte gathers, so the factor used here is the one
+    measured on THIS access pattern by the calibration kernel of the same profile run (pmc["fetch_calibration"]: a gather of
+    known size, bytes actually requested / bytes FETCH_SIZE reported), not the guide's 2.0; without it the entry is None."""
+    if pmc is None:
         return None
-    with open(files[-1]) as f:
-        pmc = json.load(f)
-    for name, counters in pmc.items():
-        if name.startswith(kernel_prefix) and "FETCH_SIZE" in counters:
-            fetch = counters["FETCH_SIZE"]["avg_per_launch"] * 1024.0 * 2.0
+    cal = pmc.get("fetch_calibration")
+    for name, counters in pmc.get("kernels", {}).items():
+        if name.startswith(kernel_prefix) and "FETCH_SIZE" in counters and cal:
+            fetch = counters["FETCH_SIZE"]["avg_per_launch"] * 1024.0 * cal["factor"]
             write = counters.get("WRITE_SIZE", {"avg_per_launch": 0.0})["avg_per_launch"] * 1024.0
-            return {"bytes": fetch + write, "source": os.path.relpath(files[-1], ROOT)}
+            out = {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "fetch_factor": cal["factor"], "source": source}
+            if "valu_issue_fraction" in counters:
+                out["valu_issue_fraction"] = counters["valu_issue_fraction"]
+            return out
     return None
 
 
-def cpu_baseline(args, log):
-    """Times the oracle's full cost evaluation (the reference has no CPU BA path)
-    on a bounded sample of the same kind of scene, on this box's host cores."""
-    from tests import common
+def cpu_baseline(args, ba, data, log):
+    """One full cost evaluation -- every residual of every (surfel, keyframe) pair, no Jacobians: the reference has no CPU BA
+    path, its only CPU-side notion of the cost is this sum -- of THE BENCH SCENE by the oracle's
+    OpenMP restatement on this box's host cores: the very keyframe images the GPU path worked on (downloaded) and the same
+    surfels.  Nothing is extrapolated."""
+    from badslam_amd import synthetic
     from oracle import binding as ob
-    K, W, H = 8, args.width, args.height
-    scene = common.synthetic.make_scene(K, W, H, seed=args.seed, cell=2)
-    ba = common.build_oracle(scene, 2000000)
-    n = ba.surfels_size
-    ba.evaluate_cost()  # warm
-    reps, t0 = 0, time.time()
-    while True:
-        cost, nres = ba.evaluate_cost()
-        reps += 1
-        if time.time() - t0 > args.cpu_baseline_seconds:
-            break
-    dt = (time.time() - t0) / reps
-    pairs_per_s = K * n / dt
-    return dict(pairs_per_s=pairs_per_s, seconds_per_eval=dt, K=K, N=n, cores=ob.lib().orc_num_threads(), nres=nres)
+    t0 = time.time()
+    cam = synthetic.test_camera(args.width, args.height)
+    K, N = ba.keyframe_count(), data.shape[1]
+    orc = ob.OracleBA(N + 64, 1.0 / 5000, 40.0, args.cell, ob.make_camera(cam, args.width, args.height),
+                      ob.make_camera(cam, args.width, args.height))
+    for k in range(K):
+        orc.add_preprocessed_keyframe(ba.keyframe_image(k, "depth"), ba.keyframe_image(k, "normals"), ba.keyframe_image(k, "radius"),
+                                      ba.keyframe_image(k, "color"), ba.keyframe_pose(k))
+    orc.surfel_data[:data.shape[0], :N] = data
+    orc.surfels.surfels_size = orc.surfels.surfel_count = N
+    log(f"cpu baseline: scene handed to the oracle in {time.time() - t0:.1f}s ({K} keyframes, {N} surfels)")
+    t1 = time.time()
+    cost, nres = orc.evaluate_cost()
+    dt = time.time() - t1
+    return dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=ob.lib().orc_num_threads(), nres=nres, cost=cost)
 
 
 def main():
@@ -214,13 +233,13 @@ def main():
             hook_keepalive = multigpu.install_allreduce(ctx, dist)
     K = args.keyframes
 
-    def run(iterations):
+    def run(iterations, intrinsics=args.intrinsics, pcg=args.pcg):
         # BA iteration counters equal -> BundleAdjustment skips PerformBASchemeEndTasks (fixed surfel set)
         ba.set_ba_iteration_counts(1, 1)
-        done, _ = ba.BundleAdjustment(optimize_depth_intrinsics=args.intrinsics, optimize_color_intrinsics=args.intrinsics,
+        done, _ = ba.BundleAdjustment(optimize_depth_intrinsics=intrinsics, optimize_color_intrinsics=intrinsics,
                                       do_surfel_updates=False,
                                       optimize_poses=True, optimize_geometry=True, min_iterations=iterations,
-                                      max_iterations=iterations, use_pcg=args.pcg, active_keyframe_window_start=0,
+                                      max_iterations=iterations, use_pcg=pcg, active_keyframe_window_start=0,
                                       active_keyframe_window_end=K - 1, increase_ba_iteration_count=False)
         assert done == iterations, (done, iterations)
 
@@ -247,8 +266,8 @@ def main():
     stats = ba.last_stats()
 
     def read_stage_timers():
-        out_ms, out_n = np.zeros(4), np.zeros(4, dtype=np.int64)
-        for s in range(4):
+        out_ms, out_n = np.zeros(5), np.zeros(5, dtype=np.int64)
+        for s in range(5):
             ms, n = C.c_float(), C.c_int()
             capi.check(ctx.lib.bahip_last_stage_time_ms(ctx.handle, s, C.byref(ms), C.byref(n)))
             out_ms[s], out_n[s] = ms.value, n.value
@@ -262,6 +281,33 @@ def main():
     run(BREAKDOWN_STEPS)
     ctx.synchronize()
     breakdown_ms, _ = read_stage_timers()
+
+    # Untimed extras, so that the driver's default run also sees the other two stages of SURVEY 8d: the intrinsics step of the
+    # alternating scheme (reference timing key BA_intrinsics_optimization, B/direct_ba_alternating.cc:687) and the PCG scheme.
+    extras = {}
+    if not args.no_extras and not args.pcg and shard_world == 1 and world == 1:
+        EXTRA_STEPS = 3
+        if not args.intrinsics:
+            capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 2))
+            run(EXTRA_STEPS, intrinsics=True)
+            ctx.synchronize()
+            ms, _ = read_stage_timers()
+            extras["intrinsics"] = {"BA_intrinsics_optimization_ms_per_iteration": ms[4] / EXTRA_STEPS, "iterations": EXTRA_STEPS,
+                                    "note": "alternating iterations with depth + colour intrinsics optimisation after the timed region"}
+            cc, dc, _a = ba.cameras()
+            ba.set_cameras(cc, dc, 0.0)        # back to a = 0 for what follows (the cfactor image keeps its update)
+        capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
+        run(1, intrinsics=False, pcg=True)     # warm: allocates the PCG vectors
+        ctx.synchronize()
+        t_pcg = time.perf_counter()
+        run(EXTRA_STEPS, intrinsics=False, pcg=True)
+        ctx.synchronize()
+        dt_pcg = time.perf_counter() - t_pcg
+        inner = ba.last_stats()["pcg_inner_steps"] / EXTRA_STEPS
+        extras["pcg"] = {"outer_iterations_per_s": EXTRA_STEPS / dt_pcg, "ms_per_outer_iteration": 1e3 * dt_pcg / EXTRA_STEPS,
+                         "inner_steps_per_outer_iteration": inner, "inner_steps_per_s": inner * EXTRA_STEPS / dt_pcg,
+                         "max_inner_iterations": 30, "iterations": EXTRA_STEPS,
+                         "note": "PCG scheme (poses + geometry) on the same scene after the timed region"}
 
     if rank == 0:
         W, H = args.width, args.height
@@ -288,8 +334,10 @@ def main():
                        "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, 2 cm grid)",
                        "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU"},
             **({"emulated_share_of_world": shard_world} if shard_world != world else {}),
-            "stage_ms_per_iteration": {STAGES[s]: breakdown_ms[s] / BREAKDOWN_STEPS for s in range(4)},
-            "stage_ms_note": f"{BREAKDOWN_STEPS} further iterations after the timed region, all stages timed",
+            "stage_ms_per_iteration": {STAGES[s]: breakdown_ms[s] / BREAKDOWN_STEPS for s in range(5 if args.intrinsics else 4)},
+            "stage_ms_note": f"{BREAKDOWN_STEPS} further iterations after the timed region, all stages timed; the surfel activation "
+                             "is decided inside the normals pass of the geometry sweep (one launch), hence 0",
+            **extras,
         }
         if not args.pcg:
             R = stats["pose_rounds"] / args.steps
@@ -306,24 +354,42 @@ def main():
             out["config"].update({"pose_gn_rounds_per_iteration": R, "pose_gn_steps_per_keyframe": Rbar})
             out["algorithmic_bytes_per_iteration"] = b_alg_iter
             out["iteration_fraction_of_hbm_roofline"] = b_alg_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9)
-            traffic = pmc_traffic_bytes("pose_accumulate_kernel<true, true>") if world == 1 else None
+            pmc, pmc_source = committed_profile(args) if (world == 1 and shard_world == 1) else (None, None)
+            traffic = pmc_kernel_entry(pmc, pmc_source, "pose_accumulate_kernel<true, true>")
             out["roofline"] = {"bound": "hbm", "kernel": "pose_accumulate_kernel<true,true>", "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": traffic["bytes"] if traffic else None,
                                "traffic_source": traffic["source"] if traffic else None,
+                               "traffic_fetch_factor": traffic["fetch_factor"] if traffic else None,
                                "algorithmic_bytes_per_launch": bytes_pose_launch, "avg_launch_ms": avg_ms, "launches": launches,
-                               "keyframes_per_launch": kf_per_launch}
+                               "keyframes_per_launch": kf_per_launch,
+                               "limiter": "VALU issue, not HBM: the sweep evaluates ~120 instructions of association per visited "
+                                          "(surfel tile, keyframe) candidate before any byte of Jacobian work (DESIGN.md section 5)",
+                               "valu_issue_fraction": traffic.get("valu_issue_fraction") if traffic else None}
+            # the other sweep of an iteration: activation + normals + position/descriptor step in one launch
+            geo_ms = breakdown_ms[1] / BREAKDOWN_STEPS
+            bytes_geo = N_rank * (17 + 21 + 49) + K * W * H * (4 + 5)
+            geo_traffic = pmc_kernel_entry(pmc, pmc_source, "geometry_kernel<true, true")
+            out["roofline_geometry"] = {"bound": "hbm", "kernel": "geometry_kernel<true,true> (activation + normals + position step)",
+                                        "achieved": bytes_geo / (geo_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": bytes_geo / (geo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "traffic": geo_traffic["bytes"] if geo_traffic else None,
+                                        "algorithmic_bytes_per_launch": bytes_geo, "avg_launch_ms": geo_ms,
+                                        "valu_issue_fraction": geo_traffic.get("valu_issue_fraction") if geo_traffic else None}
         else:
             out["config"]["pcg_inner_steps_per_iteration"] = stats["pcg_inner_steps"] / args.steps
-        if not args.no_cpu_baseline:
-            cb = cpu_baseline(args, log)
+        if not args.no_cpu_baseline and world == 1:
+            cb = cpu_baseline(args, ba, data, log)
             sweeps = 3 + (stats["pose_rounds"] / args.steps if not args.pcg else 3)
             out["cpu_baseline"] = {"value": cb["pairs_per_s"], "unit": "surfel-keyframe pairs/s (full cost evaluation)",
                                    "cores": cb["cores"], "kind": "port",
-                                   "sample": f"oracle cost evaluation, {cb['K']} keyframes x {cb['N']} surfels {W}x{H}, "
-                                             f"{cb['seconds_per_eval']:.2f} s per evaluation; one BA iteration at the bench "
-                                             f"size needs >= {sweeps:.1f} such sweeps over {K}x{N_total} pairs",
-                                   "equivalent_ba_iterations_per_s": cb["pairs_per_s"] / (sweeps * K * N_total)}
+                                   "sample": f"ONE full cost evaluation of the bench scene itself by the oracle (OpenMP): {cb['K']} keyframes x "
+                                             f"{cb['N']} surfels {W}x{H} = {cb['K'] * cb['N']:.3g} pairs, {cb['nres']} residuals, "
+                                             f"{cb['seconds_per_eval']:.2f} s; nothing extrapolated",
+                                   "seconds_per_cost_evaluation": cb["seconds_per_eval"],
+                                   "ba_iteration_lower_bound_note": f"one BA iteration makes >= {sweeps:.1f} such sweeps (activation, normals, "
+                                                                    "position step, pose rounds) plus the Jacobians",
+                                   "equivalent_ba_iterations_per_s": 1.0 / (sweeps * cb["seconds_per_eval"])}
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()

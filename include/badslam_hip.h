@@ -324,6 +324,11 @@ int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_80);
 /* One Gauss-Newton pose update with the device code of the pose solve (binary64 LDLT of the binary32 H (21) | b (6), x as
  * binary32, T <- T * exp(-x) with the defined sin / cos): out = x[6] | T_next[7] | frame_T_global(T_next)[12]. */
+/* Counter calibration (tooling): reads a zero-filled device buffer of `bytes` with 4-byte loads, `repeats` launches of
+ * read_pattern_kernel.  pattern 0: every dword once, coalesced; 1: one dword per 128-byte line.  Run under
+ * `rocprofv3 --pmc FETCH_SIZE` to learn what the counter reports for a known amount of data at this access width
+ * (scripts/profile_round.sh). */
+int bahip_debug_read_pattern(bahip_context* ctx, size_t bytes, int pattern, int repeats);
 /* rcp_exact (kind 0) / sqrt_exact (kind 1) of the device code on n host values (ba_device.h: the few-instruction exact
  * reciprocal and square root the sweeps use instead of the compiler's IEEE sequences); checked exhaustively by the tests. */
 int bahip_debug_exact_math(bahip_context* ctx, int kind, const float* in, float* out, size_t n);
@@ -333,7 +338,7 @@ int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, ui
 /* ---- instrumentation ---------------------------------------------------------------------------- */
 /* Time (ms, hipEvent on the context stream) and launch count of the kernels issued by the last
  * call of each stage; used by bench.py for the roofline line.  stage: 0 activation, 1 geometry,
- * 2 pose accumulate, 3 pose solve. */
+ * 2 pose accumulate, 3 pose solve, 4 intrinsics (accumulation sweep + Schur complement), 5 reserved. */
 int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* launches_out);
 /* enabled: 0 off; 1 = the counters cover the last call of each stage; 2 = cumulative since this call; 3 = cumulative,
  * stage 2 only (two event records per pose round instead of ten per BA iteration). */

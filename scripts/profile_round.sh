@@ -1,23 +1,28 @@
 #!/bin/bash
-# Profiles `python bench.py` on the GPU box (run through gpurun) and leaves the summaries under
-# gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/.
+# Profiles `python bench.py` on the GPU box (run through gpurun) and leaves the summaries under gpurun_out/prof_<tag>/ ;
+# copy what should be judged into profiles/ (scripts/summarize_profile.py prints the cp line).
 #   scripts/profile_round.sh <tag> [bench args...]
-# Pass 1: rocprofv3 --kernel-trace --stats (per-kernel time).  Passes 2,3: PMC counters alone
-# (FETCH_SIZE and WRITE_SIZE need separate passes: TCC slots), no trace domains besides kernel-trace.
+# Pass 1: rocprofv3 --kernel-trace --stats (per-kernel time; the bench line of the same command is kept).
+# Passes 2-4: PMC counters alone, one pass each (FETCH_SIZE and WRITE_SIZE share TCC slots), --kernel-trace only as the pool
+# requires: FETCH_SIZE, WRITE_SIZE, and the issue-side counters behind "VALU-issue bound".
+# Pass 5: FETCH_SIZE over reads of known size (scripts/fetch_calibration.py): what the counter reports per byte at the
+# 4-byte access width of the sweeps.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.log"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > /dev/null 2> "$OUT/pmc_fetch.log"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > /dev/null 2> "$OUT/pmc_write.log"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_fetch.log"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_write.log"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_sq.log"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_cal" -- python $REPO/scripts/fetch_calibration.py > "$OUT/cal_bytes.txt" 2> "$OUT/pmc_cal.log"
 cd "$REPO"
-python scripts/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+python scripts/summarize_profile.py "$OUT" "$TAG" $* > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep only the small files (kernel trace CSVs are large)
 find "$OUT" -name '*kernel_trace.csv' -size +2M -delete
