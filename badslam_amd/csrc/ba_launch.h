@@ -71,11 +71,15 @@ void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, c
                      float* r, float* M);
 void launch_pcg_init2(hipStream_t st, const PcgLayout& L, float a, const float* r, const float* M, float* delta, float* g, float* p,
                       float* alpha_n);
+// ctl: device-side inner-loop control block (pcg_control_bytes(); stopping rule of B/direct_ba_pcg.cc:427-456 evaluated on the device)
+size_t pcg_control_bytes();
+void launch_pcg_control_init(hipStream_t st, void* ctl);
+void launch_pcg_control(hipStream_t st, void* ctl, const float* beta_n);
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
-                      const float* p, float* g, float* alpha_d);
+                      const float* p, float* g, float* alpha_d, const void* ctl);
 void launch_pcg_step2(hipStream_t st, const PcgLayout& L, float* r, const float* M, float* delta, float* g, const float* p,
-                      const float* alpha_n, const float* alpha_d, float* beta_n);
-void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n);
+                      const float* alpha_n, const float* alpha_d, float* beta_n, const void* ctl);
+void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n, const void* ctl);
 void launch_pcg_update_surfels(hipStream_t st, const PcgLayout& L, const SurfelsView& s, const float* delta);
 void launch_pcg_update_cfactors(hipStream_t st, const Intrinsics& in, uint32_t start, const float* delta, float* cfactor, uint32_t pitch);
 

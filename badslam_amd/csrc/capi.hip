@@ -1189,31 +1189,41 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   CHECK_LAUNCH();
   if (sharded && reduce_over_ranks(ctx, sc + i_an, 1, BAHIP_SUM_F32)) return 1;
 
-  float prev_r_norm = __builtin_huge_valf();
-  int no_improvement = 0, steps = 0;
+  // Inner loop: the stopping rule runs on the device (pcg_control_kernel), so steps are queued in groups without a host
+  // round trip per step; kernels queued after the stop return at once.  The host only looks at `stop` between groups.
+  void* ctl = sc + 8;   // PcgControl lives in the scalar block (16 floats)
+  static_assert(sizeof(float) * 8 >= 16, "room for PcgControl behind the scalars");
+  launch_pcg_control_init(st, ctl);
+  CHECK_LAUNCH();
+  const size_t head_lo = L.optimize_geometry ? L.surfel_start : U, head_hi = L.optimize_geometry ? L.surfel_end : U;
+  constexpr int kStepsPerGroup = 6;
+  int steps = 0;
   for (int step = 0; step < opt->max_inner_iterations; ++step) {
-    ++steps;
     HIP_TRY(hipMemsetAsync(sc + 1, 0, sizeof(float), st));
     if (step > 0) {
       const int t = i_an; i_an = i_bn; i_bn = t;
-      HIP_TRY(hipMemsetAsync(g_, 0, sizeof(float) * U, st));
+      // g: the surfel block is overwritten by the sweep, only the dense head accumulates
+      if (head_lo) HIP_TRY(hipMemsetAsync(g_, 0, sizeof(float) * head_lo, st));
+      if (U > head_hi) HIP_TRY(hipMemsetAsync(g_ + head_hi, 0, sizeof(float) * (U - head_hi), st));
     }
-    launch_pcg_step1(st, L, ctx->in, ctx->dev_kfs, K, sv, p_, g_, sc + 1);
+    launch_pcg_step1(st, L, ctx->in, ctx->dev_kfs, K, sv, p_, g_, sc + 1, ctl);
     CHECK_LAUNCH();
     if (sharded && allreduce_head(ctx, L, g_, nullptr, sc + 1, 1)) return 1;     // g head and alpha_d in one exchange
     HIP_TRY(hipMemsetAsync(sc + i_bn, 0, sizeof(float), st));
-    launch_pcg_step2(st, L, r_, M_, delta, g_, p_, sc + i_an, sc + 1, sc + i_bn);
+    launch_pcg_step2(st, L, r_, M_, delta, g_, p_, sc + i_an, sc + 1, sc + i_bn, ctl);
     CHECK_LAUNCH();
     if (sharded && reduce_over_ranks(ctx, sc + i_bn, 1, BAHIP_SUM_F32)) return 1;
-    HIP_TRY(hipMemcpyAsync(ctx->pinned_f, sc + i_bn, sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const float r_norm = sqrtf(ctx->pinned_f[0]);
-    if (r_norm < prev_r_norm - 1e-3f) no_improvement = 0;
-    else if (++no_improvement >= 3) break;
-    prev_r_norm = r_norm;
+    launch_pcg_control(st, ctl, sc + i_bn);
+    CHECK_LAUNCH();
     if (step < opt->max_inner_iterations - 1) {
-      launch_pcg_step3(st, L, g_, p_, sc + i_an, sc + i_bn);
+      launch_pcg_step3(st, L, g_, p_, sc + i_an, sc + i_bn, ctl);
       CHECK_LAUNCH();
+    }
+    if ((step + 1) % kStepsPerGroup == 0 || step == opt->max_inner_iterations - 1) {
+      HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctl, 16, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      steps = ctx->pinned_i[3];
+      if (ctx->pinned_i[2]) break;   // stop
     }
   }
   if (inner_steps_out) *inner_steps_out = steps;

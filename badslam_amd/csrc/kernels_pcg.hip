@@ -59,18 +59,15 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
   const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
   t->di_valid = false;
   t->color_ok = false;
+  // All Jacobians come from the jac_* functions of ba_device.h -- the ones the alternating sweeps use and the ones checked
+  // against the golden vectors derived from the reference's own script (tests/golden/jacobians.json).
   if (L.use_depth) {
     const float inv_std = depth_inv_stddev(nx, ny, r.depth, rn, in.baseline_fx);
     const Vec3 u = unproject(in, r.px, r.py, r.depth);
     t->raw = inv_std * dot3(rn, u - r.local);
     t->w = depth_residual_weight(t->raw);
     t->Jgeom = -inv_std;
-    t->Jpose[0] = inv_std * rn.x;
-    t->Jpose[1] = inv_std * rn.y;
-    t->Jpose[2] = inv_std * rn.z;
-    t->Jpose[3] = inv_std * (-rn.y * u.z + rn.z * u.y);
-    t->Jpose[4] = inv_std * (rn.x * u.z - rn.z * u.x);
-    t->Jpose[5] = inv_std * (-rn.x * u.y + rn.y * u.x);
+    jac_depth_pose(rn, u, inv_std, t->Jpose);
     if (kDepthIntr) {
       const int sparse_px = r.px / in.cell, sparse_py = r.py / in.cell;
       const float cfactor = pitched_load(in.cfactor, in.cfactor_pitch, sparse_py, sparse_px);
@@ -79,13 +76,12 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
       const float corrected = cfactor * exp_inv_depth + raw_inv_depth;
       t->di_valid = !(fabsf(corrected) < 1e-4f);
       const float dot = dot3(mk3(nx, ny, 1), rn);
-      const float jac_base = inv_std * dot * exp_inv_depth / (corrected * corrected);
-      t->Jdi[2] = inv_std * r.depth * dot3(gn, mk3(F[0], F[1], F[2]));
-      t->Jdi[3] = inv_std * r.depth * dot3(gn, mk3(F[4], F[5], F[6]));
-      t->Jdi[0] = r.px * t->Jdi[2];
-      t->Jdi[1] = r.py * t->Jdi[3];
-      t->Jdi[4] = cfactor * raw_inv_depth * jac_base;
-      t->Jcf = -jac_base;
+      float Jdi[6];   // fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor (B/kernel_opt_intrinsics.cu:107-140 = B/kernel_pcg.cu:258-303)
+      jac_depth_intrinsics(r.px, r.py, r.depth, inv_std, dot3(gn, mk3(F[0], F[1], F[2])), dot3(gn, mk3(F[4], F[5], F[6])), dot, cfactor,
+                           raw_inv_depth, exp_inv_depth, corrected, Jdi);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) t->Jdi[c] = Jdi[c];
+      t->Jcf = Jdi[5];
       t->cf_index = L.depth_intr_start + 5 + sparse_px + sparse_py * in.cf_width;
     }
   }
@@ -96,32 +92,15 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
       DescEval e;
       eval_descriptor<true>(in, kf.lumafp, F, tp, cx, cy, d1, d2, &e);
       t->raw1 = e.r1; t->raw2 = e.r2;
-      const float gx1 = e.gx1 * in.cfx, gx2 = e.gx2 * in.cfx;
-      const float gy1 = e.gy1 * in.cfy, gy2 = e.gy2 * in.cfy;
       t->w1 = descriptor_residual_weight(e.r1);
       t->w2 = descriptor_residual_weight(e.r2);
-      const Vec3 lp = r.local;
-      {
-        const float term1 = -(rn.x * lp.z - rn.z * lp.x);
-        const float term2 = -(rn.y * lp.z - rn.z * lp.y);
-        const float term3 = 1.f / (lp.z * lp.z);
-        t->Jg1 = -(gx1 * term1 + gy1 * term2) * term3;
-        t->Jg2 = -(gx2 * term1 + gy2 * term2) * term3;
-      }
-      {
-        const float inv_z = 1.f / lp.z, z_sq = lp.z * lp.z, inv_z_sq = inv_z * inv_z, xy = lp.x * lp.y;
-        const float term1 = lp.y * lp.y + z_sq, term2 = lp.x * lp.x + z_sq;
-        t->Jp1[0] = -gx1 * inv_z;                          t->Jp2[0] = -gx2 * inv_z;
-        t->Jp1[1] = -gy1 * inv_z;                          t->Jp2[1] = -gy2 * inv_z;
-        t->Jp1[2] = (lp.x * gx1 + lp.y * gy1) * inv_z_sq;  t->Jp2[2] = (lp.x * gx2 + lp.y * gy2) * inv_z_sq;
-        t->Jp1[3] = (term1 * gy1 + xy * gx1) * inv_z_sq;   t->Jp2[3] = (term1 * gy2 + xy * gx2) * inv_z_sq;
-        t->Jp1[4] = -(term2 * gx1 + xy * gy1) * inv_z_sq;  t->Jp2[4] = -(term2 * gx2 + xy * gy2) * inv_z_sq;
-        t->Jp1[5] = -(lp.x * gy1 - lp.y * gx1) * inv_z;    t->Jp2[5] = -(lp.x * gy2 - lp.y * gx2) * inv_z;
-      }
+      t->Jg1 = jac_descriptor_surfel(rn, r.local, r.inv_z, e.gx1, e.gy1, in.cfx, in.cfy);
+      t->Jg2 = jac_descriptor_surfel(rn, r.local, r.inv_z, e.gx2, e.gy2, in.cfx, in.cfy);
+      jac_descriptor_pose(r.local, r.inv_z, e.gx1 * in.cfx, e.gy1 * in.cfy, t->Jp1);
+      jac_descriptor_pose(r.local, r.inv_z, e.gx2 * in.cfx, e.gy2 * in.cfy, t->Jp2);
       if (kColorIntr) {
-        const float x1 = gx1 / in.cfx, y1 = gy1 / in.cfy, x2 = gx2 / in.cfx, y2 = gy2 / in.cfy;
-        t->Jci1[0] = x1 * nx; t->Jci1[1] = y1 * ny; t->Jci1[2] = x1; t->Jci1[3] = y1;
-        t->Jci2[0] = x2 * nx; t->Jci2[1] = y2 * ny; t->Jci2[2] = x2; t->Jci2[3] = y2;
+        jac_descriptor_color_intrinsics(e.gx1, e.gy1, nx, ny, t->Jci1);
+        jac_descriptor_color_intrinsics(e.gx2, e.gy2, nx, ny, t->Jci2);
       }
     }
   }
@@ -240,6 +219,29 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
   }
 }
 
+// ---- inner-loop control on the device -------------------------------------------------------------------------------------
+// The reference reads beta_n back after every inner step and decides on the host whether the residual norm still improves
+// (B/direct_ba_pcg.cc:427-456: stop after three steps without an improvement of 1e-3).  Here a one-thread kernel takes that
+// decision after step 2; once `stop` is set the sweeps and vector kernels queued behind it return at once, so the host can
+// queue several inner steps without waiting for any of them.
+struct PcgControl {
+  float prev_r_norm;
+  int no_improvement;
+  int stop;
+  int steps;
+};
+__global__ void pcg_control_kernel(PcgControl* ctl, const float* beta_n) {
+  if (ctl->stop) return;
+  ctl->steps += 1;
+  const float r_norm = sqrtf(*beta_n);
+  if (r_norm < ctl->prev_r_norm - 1e-3f) ctl->no_improvement = 0;
+  else if (++ctl->no_improvement >= 3) ctl->stop = 1;
+  ctl->prev_r_norm = r_norm;
+}
+__global__ void pcg_control_init_kernel(PcgControl* ctl) {
+  ctl->prev_r_norm = __builtin_huge_valf(); ctl->no_improvement = 0; ctl->stop = 0; ctl->steps = 0;
+}
+
 // ---- block-level scalar reduction helper ------------------------------------------------------------------
 // One atomic per workgroup of kPcgBlock threads.  The vector kernels below run a grid-stride loop over at most
 // kPcgReduceBlocks workgroups: a dot product over 9 M unknowns then ends in 1024 atomics on its scalar instead of one per
@@ -276,7 +278,8 @@ pcg_init2_kernel(PcgLayout L, float a, const float* __restrict__ r_, const float
 template <bool kDepthIntr, bool kColorIntr>
 __global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
 pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                 const float* __restrict__ p_, float* __restrict__ g_, float* alpha_d) {
+                 const float* __restrict__ p_, float* __restrict__ g_, float* alpha_d, const PcgControl* ctl) {
+  if (ctl->stop) return;
   const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
@@ -409,7 +412,8 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
 // AddAlphaDEpsilonTerms (B/kernel_pcg.cu:1028-1050); the reference launches it once per keyframe
 // (B/kernel_pcg.cu:1102-1112), i.e. the term enters alpha_d `repeat` times -- reproduced.
 __global__ void __launch_bounds__(kPcgBlock)
-pcg_eps_terms_kernel(PcgLayout L, const float* __restrict__ p_, float repeat, float* alpha_d) {
+pcg_eps_terms_kernel(PcgLayout L, const float* __restrict__ p_, float repeat, float* alpha_d, const PcgControl* ctl) {
+  if (ctl->stop) return;
   float term = 0.f;
   for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
     const float pv = p_[u];
@@ -421,7 +425,8 @@ pcg_eps_terms_kernel(PcgLayout L, const float* __restrict__ p_, float repeat, fl
 // PCGStep2 (B/kernel_pcg.cu:1117-1158)
 __global__ void __launch_bounds__(kPcgBlock)
 pcg_step2_kernel(PcgLayout L, float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta, float* __restrict__ g_,
-                 const float* __restrict__ p_, const float* alpha_n, const float* alpha_d, float* beta_n) {
+                 const float* __restrict__ p_, const float* alpha_n, const float* alpha_d, float* beta_n, const PcgControl* ctl) {
+  if (ctl->stop) return;
   float term = 0.f;
   const float ad = *alpha_d;
   const float alpha = (ad >= 1e-35f) ? (*alpha_n / ad) : 0;
@@ -440,8 +445,10 @@ pcg_step2_kernel(PcgLayout L, float* __restrict__ r_, const float* __restrict__ 
 
 // PCGStep3 (B/kernel_pcg.cu:1212-1226)
 __global__ void __launch_bounds__(kPcgBlock)
-pcg_step3_kernel(PcgLayout L, const float* __restrict__ g_, float* __restrict__ p_, const float* alpha_n, const float* beta_n) {
+pcg_step3_kernel(PcgLayout L, const float* __restrict__ g_, float* __restrict__ p_, const float* alpha_n, const float* beta_n,
+                 const PcgControl* ctl) {
   const uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x;
+  if (ctl->stop) return;
   if (u < L.unknown_count) {
     const float an = *alpha_n;
     const float beta = (an >= 1e-35f) ? (*beta_n / an) : 0;
@@ -498,23 +505,32 @@ void launch_pcg_init2(hipStream_t st, const PcgLayout& L, float a, const float* 
                       float* alpha_n) {
   if (L.unknown_count) hipLaunchKernelGGL(pcg_init2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, a, r, M, delta, g, p, alpha_n);
 }
+void launch_pcg_control_init(hipStream_t st, void* ctl) { hipLaunchKernelGGL(pcg_control_init_kernel, dim3(1), dim3(1), 0, st, static_cast<PcgControl*>(ctl)); }
+void launch_pcg_control(hipStream_t st, void* ctl, const float* beta_n) {
+  hipLaunchKernelGGL(pcg_control_kernel, dim3(1), dim3(1), 0, st, static_cast<PcgControl*>(ctl), beta_n);
+}
+size_t pcg_control_bytes() { return sizeof(PcgControl); }
+
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
-                      const float* p, float* g, float* alpha_d) {
+                      const float* p, float* g, float* alpha_d, const void* ctl_) {
+  const PcgControl* ctl = static_cast<const PcgControl*>(ctl_);
   if (!s.size) return;
   const dim3 grid(gS(s.size)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
-  if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
-  else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
-  else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
-  else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d);
-  hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, p, (float)num_kfs, alpha_d);
+  if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
+  else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
+  else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
+  else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
+  hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, p, (float)num_kfs, alpha_d, ctl);
 }
 void launch_pcg_step2(hipStream_t st, const PcgLayout& L, float* r, const float* M, float* delta, float* g, const float* p,
-                      const float* alpha_n, const float* alpha_d, float* beta_n) {
-  if (L.unknown_count) hipLaunchKernelGGL(pcg_step2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, r, M, delta, g, p, alpha_n, alpha_d, beta_n);
+                      const float* alpha_n, const float* alpha_d, float* beta_n, const void* ctl) {
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_step2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, r, M, delta, g, p, alpha_n, alpha_d, beta_n,
+                                          static_cast<const PcgControl*>(ctl));
 }
-void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n) {
-  if (L.unknown_count) hipLaunchKernelGGL(pcg_step3_kernel, dim3(gU(L.unknown_count)), dim3(kPcgBlock), 0, st, L, g, p, alpha_n, beta_n);
+void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n, const void* ctl) {
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_step3_kernel, dim3(gU(L.unknown_count)), dim3(kPcgBlock), 0, st, L, g, p, alpha_n, beta_n,
+                                          static_cast<const PcgControl*>(ctl));
 }
 void launch_pcg_update_surfels(hipStream_t st, const PcgLayout& L, const SurfelsView& s, const float* delta) {
   if (s.size) hipLaunchKernelGGL(pcg_update_surfels_kernel, dim3(gU(s.size)), dim3(kPcgBlock), 0, st, L, s, delta);

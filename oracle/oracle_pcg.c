@@ -42,6 +42,7 @@ static void eval_pair_terms(const pcg_layout* L, const orc_camera* color_cam, co
   const float* F = kf->frame_T_global;
   const v3 rn = m34_rotate(F, r->normal);
   memset(t, 0, sizeof(*t));
+  /* All Jacobians through the jac_* helpers of oracle_internal.h (the golden-vector-tested ones), like the backend. */
   if (L->use_depth) {
     const float nx = unp_nx(&p->unp, (float)r->px), ny = unp_ny(&p->unp, (float)r->py);
     t->inv_std = depth_inv_stddev(nx, ny, r->calibrated_depth, rn, dp->baseline_fx);
@@ -49,12 +50,7 @@ static void eval_pair_terms(const pcg_layout* L, const orc_camera* color_cam, co
     t->raw = t->inv_std * v3_dot(rn, v3_sub(u, r->local_position));
     t->w = depth_residual_weight(t->raw);
     t->Jgeom = -t->inv_std;
-    t->Jpose[0] = t->inv_std * rn.x;
-    t->Jpose[1] = t->inv_std * rn.y;
-    t->Jpose[2] = t->inv_std * rn.z;
-    t->Jpose[3] = t->inv_std * (-rn.y * u.z + rn.z * u.y);
-    t->Jpose[4] = t->inv_std * (rn.x * u.z - rn.z * u.x);
-    t->Jpose[5] = t->inv_std * (-rn.x * u.y + rn.y * u.x);
+    jac_depth_pose(rn, u, t->inv_std, t->Jpose);
     if (L->optimize_depth_intrinsics) {
       const int sparse_px = r->px / dp->cell, sparse_py = r->py / dp->cell;
       const float cfactor = dp->cfactor[(size_t)sparse_py * dp->cf_width + sparse_px];
@@ -64,13 +60,11 @@ static void eval_pair_terms(const pcg_layout* L, const orc_camera* color_cam, co
       t->corrected_inv_depth = corrected;
       t->di_valid = !(fabsf(corrected) < 1e-4f);
       const float dot = v3_dot(v3_make(nx, ny, 1), rn);
-      const float jac_base = t->inv_std * dot * exp_inv_depth / (corrected * corrected);
-      t->Jdi[2] = t->inv_std * r->calibrated_depth * v3_dot(r->normal, v3_make(F[0], F[1], F[2]));
-      t->Jdi[3] = t->inv_std * r->calibrated_depth * v3_dot(r->normal, v3_make(F[4], F[5], F[6]));
-      t->Jdi[0] = r->px * t->Jdi[2];
-      t->Jdi[1] = r->py * t->Jdi[3];
-      t->Jdi[4] = cfactor * raw_inv_depth * jac_base;
-      t->Jcf = -jac_base;
+      float Jdi[6];   /* fx_inv, fy_inv, cx_inv, cy_inv, a, cfactor: B/kernel_pcg.cu:258-303 */
+      jac_depth_intrinsics(r->px, r->py, r->calibrated_depth, t->inv_std, v3_dot(r->normal, v3_make(F[0], F[1], F[2])),
+                           v3_dot(r->normal, v3_make(F[4], F[5], F[6])), dot, cfactor, raw_inv_depth, exp_inv_depth, corrected, Jdi);
+      for (int c = 0; c < 5; ++c) t->Jdi[c] = Jdi[c];
+      t->Jcf = Jdi[5];
       t->cf_index = L->depth_intr_start + 5 + sparse_px + sparse_py * dp->cf_width;
     }
   }
@@ -82,34 +76,18 @@ static void eval_pair_terms(const pcg_layout* L, const orc_camera* color_cam, co
       orc_tangent_projections(r->global_position, r->normal, srow(s, ORC_SURFEL_RADIUS_SQ)[i], F, color_cam, t1, t2);
       orc_raw_descriptor_residual(kf, c, t1, t2, srow(s, ORC_SURFEL_DESC1)[i], srow(s, ORC_SURFEL_DESC2)[i], &t->raw1, &t->raw2);
       orc_descriptor_gradient(kf, c, t1, t2, g);
-      /* B/kernel_pcg.cu:366-369: gradients pre-multiplied with the colour focal lengths */
-      const float gx1 = g[0] * color_cam->fx, gx2 = g[2] * color_cam->fx;
-      const float gy1 = g[1] * color_cam->fy, gy2 = g[3] * color_cam->fy;
       t->w1 = descriptor_residual_weight(t->raw1);
       t->w2 = descriptor_residual_weight(t->raw2);
       const v3 lp = r->local_position;
-      {
-        const float term1 = -(rn.x * lp.z - rn.z * lp.x);
-        const float term2 = -(rn.y * lp.z - rn.z * lp.y);
-        const float term3 = 1.f / (lp.z * lp.z);
-        t->Jg1 = -(gx1 * term1 + gy1 * term2) * term3;
-        t->Jg2 = -(gx2 * term1 + gy2 * term2) * term3;
-      }
-      {
-        const float inv_z = 1.f / lp.z, z_sq = lp.z * lp.z, inv_z_sq = inv_z * inv_z, xy = lp.x * lp.y;
-        const float term1 = lp.y * lp.y + z_sq, term2 = lp.x * lp.x + z_sq;
-        t->Jp1[0] = -gx1 * inv_z;                          t->Jp2[0] = -gx2 * inv_z;
-        t->Jp1[1] = -gy1 * inv_z;                          t->Jp2[1] = -gy2 * inv_z;
-        t->Jp1[2] = (lp.x * gx1 + lp.y * gy1) * inv_z_sq;  t->Jp2[2] = (lp.x * gx2 + lp.y * gy2) * inv_z_sq;
-        t->Jp1[3] = (term1 * gy1 + xy * gx1) * inv_z_sq;   t->Jp2[3] = (term1 * gy2 + xy * gx2) * inv_z_sq;
-        t->Jp1[4] = -(term2 * gx1 + xy * gy1) * inv_z_sq;  t->Jp2[4] = -(term2 * gx2 + xy * gy2) * inv_z_sq;
-        t->Jp1[5] = -(lp.x * gy1 - lp.y * gx1) * inv_z;    t->Jp2[5] = -(lp.x * gy2 - lp.y * gx2) * inv_z;
-      }
+      t->Jg1 = jac_descriptor_surfel(rn, lp, g[0], g[1], color_cam->fx, color_cam->fy);
+      t->Jg2 = jac_descriptor_surfel(rn, lp, g[2], g[3], color_cam->fx, color_cam->fy);
+      /* B/kernel_pcg.cu:366-369: gradients pre-multiplied with the colour focal lengths */
+      jac_descriptor_pose(lp, g[0] * color_cam->fx, g[1] * color_cam->fy, t->Jp1);
+      jac_descriptor_pose(lp, g[2] * color_cam->fx, g[3] * color_cam->fy, t->Jp2);
       if (L->optimize_color_intrinsics) {
         const float nx = unp_nx(&p->unp, (float)r->px), ny = unp_ny(&p->unp, (float)r->py);
-        const float x1 = gx1 / color_cam->fx, y1 = gy1 / color_cam->fy, x2 = gx2 / color_cam->fx, y2 = gy2 / color_cam->fy;
-        t->Jci1[0] = x1 * nx; t->Jci1[1] = y1 * ny; t->Jci1[2] = x1; t->Jci1[3] = y1;
-        t->Jci2[0] = x2 * nx; t->Jci2[1] = y2 * ny; t->Jci2[2] = x2; t->Jci2[3] = y2;
+        jac_descriptor_color_intrinsics(g[0], g[1], nx, ny, t->Jci1);
+        jac_descriptor_color_intrinsics(g[2], g[3], nx, ny, t->Jci2);
       }
     }
   }
