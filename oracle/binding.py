@@ -319,6 +319,16 @@ class OracleBA:
                                               int(accumulate_double))
         return np.array(list(H)), np.array(list(b)), int(n), float(cost.value)
 
+    def accumulate_pose_coeffs_fixed(self, i, frame_T_global=None):
+        """The 27 fixed-point (48.16) totals of the defined pose sum, as int64."""
+        kf = self.keyframes[i]
+        F = (C.c_float * 12)(*(list(kf.frame_T_global) if frame_T_global is None else [float(v) for v in frame_T_global]))
+        fixed = (C.c_longlong * 27)()
+        self.L.orc_accumulate_pose_coeffs_fixed.restype = C.c_uint32
+        self.L.orc_accumulate_pose_coeffs_fixed(self.use_depth, self.use_desc, C.byref(self.color_cam), C.byref(self.depth_cam),
+                                                C.byref(self.dp), C.byref(kf), F, C.byref(self.surfels), fixed)
+        return np.array(list(fixed), dtype=np.int64)
+
     def estimate_frame_pose(self, i, init):
         T = init if isinstance(init, SE3) else SE3.from_array(init)
         out = SE3()

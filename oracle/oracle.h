@@ -190,6 +190,10 @@ uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camer
                                     const orc_keyframe* kf, const float frame_T_global[12],
                                     const orc_surfels* s, float H[21], float b[6],
                                     float* residual_sum, int accumulate_double);
+uint32_t orc_accumulate_pose_coeffs_fixed(int use_depth, int use_desc, const orc_camera* color_cam,
+                                          const orc_camera* depth_cam, const orc_depth_params* dp,
+                                          const orc_keyframe* kf, const float frame_T_global[12],
+                                          const orc_surfels* s, long long fixed_out[27]);
 /* B/direct_ba_alternating.cc:42-283.  Returns number of GN iterations done; *converged set. */
 int orc_estimate_frame_pose(int use_depth, int use_desc, const orc_camera* color_cam,
                             const orc_camera* depth_cam, const orc_depth_params* dp,

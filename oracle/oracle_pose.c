@@ -46,10 +46,10 @@ float orc_tile_tree_sum(const float x[64]) {
 #define ORC_HB_FIXED_SCALE 65536.0
 
 /* B/kernel_opt_pose.cc:39-97, kernel B/kernel_opt_pose.cu:251-383. */
-uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camera* color_cam,
-                                    const orc_camera* depth_cam, const orc_depth_params* dp,
-                                    const orc_keyframe* kf, const float F[12], const orc_surfels* s,
-                                    float H[21], float b[6], float* residual_sum, int accumulate_double) {
+static uint32_t accumulate_pose_coeffs_impl(int use_depth, int use_desc, const orc_camera* color_cam,
+                                            const orc_camera* depth_cam, const orc_depth_params* dp,
+                                            const orc_keyframe* kf, const float F[12], const orc_surfels* s,
+                                            float H[21], float b[6], float* residual_sum, int accumulate_double, long long* fixed_out) {
   proj_params p = make_proj_params(depth_cam, dp, s, kf, F);
   const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
   long long fixed[27] = {0};
@@ -105,7 +105,24 @@ uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camer
   for (int k = 0; k < 21; ++k) H[k] = accumulate_double ? (float)Hd[k] : (float)((double)fixed[k] * (1.0 / ORC_HB_FIXED_SCALE));
   for (int k = 0; k < 6; ++k) b[k] = accumulate_double ? (float)bd[k] : (float)((double)fixed[21 + k] * (1.0 / ORC_HB_FIXED_SCALE));
   if (residual_sum) *residual_sum = (float)cost;
+  if (fixed_out) memcpy(fixed_out, fixed, sizeof(fixed));
   return count;
+}
+
+uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camera* color_cam,
+                                    const orc_camera* depth_cam, const orc_depth_params* dp,
+                                    const orc_keyframe* kf, const float F[12], const orc_surfels* s,
+                                    float H[21], float b[6], float* residual_sum, int accumulate_double) {
+  return accumulate_pose_coeffs_impl(use_depth, use_desc, color_cam, depth_cam, dp, kf, F, s, H, b, residual_sum, accumulate_double, NULL);
+}
+
+/* The 48.16 fixed-point totals themselves (what the ranks of a surfel-sharded run exchange: an integer sum over shards
+ * made of whole 64-surfel tiles IS the unsharded total). */
+uint32_t orc_accumulate_pose_coeffs_fixed(int use_depth, int use_desc, const orc_camera* color_cam,
+                                          const orc_camera* depth_cam, const orc_depth_params* dp,
+                                          const orc_keyframe* kf, const float F[12], const orc_surfels* s, long long fixed[27]) {
+  float H[21], b[6];
+  return accumulate_pose_coeffs_impl(use_depth, use_desc, color_cam, depth_cam, dp, kf, F, s, H, b, NULL, 0, fixed);
 }
 
 /* B/convergence_analysis.h:43-51 */

@@ -1,9 +1,9 @@
 """world_size-2 test of the multi-GPU decomposition on CPU (gloo): surfels are sharded over the
 ranks, keyframes replicated; each rank builds the pose normal equations of every keyframe from its
-shard, the K x 28 block is all-reduced (SUM) and every rank solves the same 6x6 systems.  The
-per-shard partial sums come from the oracle here (no GPU in this container); the partition rule
-(badslam_amd.multigpu.shard_chunks), the reduction and the equality with the unsharded result are
-what is under test."""
+shard as 48.16 fixed-point integers (the backend's definition of the sum), the K x 28 int64 block is
+all-reduced (SUM) and every rank solves the same 6x6 systems.  The per-shard partial sums come from the
+oracle here (no GPU in this container); the partition rule (badslam_amd.multigpu.shard_chunks), the
+integer reduction and the EXACT equality with the unsharded result are what is under test."""
 import os
 import sys
 
@@ -32,12 +32,11 @@ def _worker(rank, world, port, out_dir):
     ba.surfel_data[:, :mine.size] = data[:, mine]
     ba.surfels.surfels_size = mine.size
     K = len(ba.keyframes)
-    Hb = np.zeros((K, 28), np.float32)
+    Hb = np.zeros((K, 28), np.int64)
     for k in range(K):
-        H, b, _, _ = ba.accumulate_pose_coeffs(k, accumulate_double=True)
-        Hb[k, :21], Hb[k, 21:27] = H, b
+        Hb[k, :27] = ba.accumulate_pose_coeffs_fixed(k)
     t = torch.from_numpy(Hb)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)       # what the hook does on the device buffer over RCCL
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)       # what ncclAllReduce(ncclInt64) / the hook does on the device buffer
     np.save(os.path.join(out_dir, f"hb_{rank}.npy"), t.numpy())
     np.save(os.path.join(out_dir, f"owned_{rank}.npy"), mine)
     dist.destroy_process_group()
@@ -51,19 +50,21 @@ def test_surfel_sharded_pose_normal_equations_match_unsharded(tmp_path):
     from tests import common
     scene = common.small_scene(num_keyframes=3, seed=4, width=160, height=120)
     ba = common.build_oracle(scene, 60000)
-    ref = np.zeros((3, 28), np.float32)
+    ref = np.zeros((3, 28), np.int64)
     for k in range(3):
-        H, b, _, _ = ba.accumulate_pose_coeffs(k, accumulate_double=True)
-        ref[k, :21], ref[k, 21:27] = H, b
+        ref[k, :27] = ba.accumulate_pose_coeffs_fixed(k)
     owned = np.concatenate([np.load(tmp_path / "owned_0.npy"), np.load(tmp_path / "owned_1.npy")])
     assert np.array_equal(np.sort(owned), np.arange(ba.surfels_size))                # complete, disjoint
     hb0, hb1 = np.load(tmp_path / "hb_0.npy"), np.load(tmp_path / "hb_1.npy")
     assert np.array_equal(hb0, hb1)                                                  # every rank holds the same sums
-    assert np.allclose(hb0, ref, rtol=0, atol=3e-6 * np.abs(ref).max())
-    for k in range(3):   # and therefore takes the same Gauss-Newton step
-        M = np.zeros((6, 6)); M[np.triu_indices(6)] = ref[k, :21]; M = M + np.triu(M, 1).T
-        M2 = np.zeros((6, 6)); M2[np.triu_indices(6)] = hb0[k, :21]; M2 = M2 + np.triu(M2, 1).T
-        assert np.abs(np.linalg.solve(M, ref[k, 21:27]) - np.linalg.solve(M2, hb0[k, 21:27])).max() < 1e-7
+    # shards are whole 64-surfel tiles of the unsharded cloud (chunks of 1024) and integer addition is associative: the
+    # sharded sums ARE the unsharded sums, bit for bit -- every rank takes exactly the single-GPU Gauss-Newton step
+    assert np.array_equal(hb0, ref)
+    assert np.abs(ref[:, :21]).max() > 2 ** 30                                       # real magnitudes (H ~ 1e5 ... 1e8 in 48.16)
+    for k in range(3):   # and the binary32 H, b agree with a plain binary64 running sum to binary32 precision
+        H, b, _, _ = ba.accumulate_pose_coeffs(k, accumulate_double=True)
+        Hf = (ref[k, :21].astype(np.float64) / 65536.0).astype(np.float32)
+        assert np.allclose(Hf, H, rtol=0, atol=2e-7 * np.abs(H).max())
 
 
 def test_shard_chunks_partition():
