@@ -342,6 +342,17 @@ __device__ __forceinline__ Luma4 luma_footprint(const Intrinsics& in, const uint
   t.br = (float)(word >> 24) * (1.0f / 255.0f);
   return t;
 }
+// -DBAHIP_QUANTIZED_BILINEAR_WEIGHTS (experiment build only, tests/tools/seed_study.sh): the two interpolation weights of a
+// bilinear VALUE sample are rounded to 8 fractional bits, as CUDA's tex2D does in hardware (the reference's sampler; this
+// backend and the oracle use exact binary32 weights).  The gradient taps are point samples lerped in float in
+// the reference too and are not affected.
+__device__ __forceinline__ float bilinear_weight(float w) {
+#ifdef BAHIP_QUANTIZED_BILINEAR_WEIGHTS
+  return floorf(w * 256.f + 0.5f) * (1.f / 256.f);
+#else
+  return w;
+#endif
+}
 // Bilinear luma at unnormalised coords, clamp addressing, texel centres at +0.5 (B/keyframe.cc:67-73).
 __device__ __forceinline__ float sample_luma(const Intrinsics& in, const uint32_t* lumafp, int w, int h, float x, float y) {
   float xb = x - 0.5f, yb = y - 0.5f;
@@ -350,7 +361,7 @@ __device__ __forceinline__ float sample_luma(const Intrinsics& in, const uint32_
   if (!(yb >= -1.f)) yb = -1.f;
   if (yb > (float)h) yb = (float)h;
   const float fx = floorf(xb), fy = floorf(yb);
-  const float a = xb - fx, b = yb - fy;
+  const float a = bilinear_weight(xb - fx), b = bilinear_weight(yb - fy);
   const Luma4 t = luma_footprint(in, lumafp, (int)fx, (int)fy);
   const float top = mad(a, t.tr - t.tl, t.tl);
   const float bot = mad(a, t.br - t.bl, t.bl);
@@ -371,9 +382,12 @@ __device__ __forceinline__ void sample_luma_and_gradient(const Intrinsics& in, c
   const float a = xb - fx, b = yb - fy;
   const int ix = (int)fx, iy = (int)fy;
   Luma4 t = luma_footprint(in, lumafp, ix, iy);
-  const float top = mad(a, t.tr - t.tl, t.tl);
-  const float bot = mad(a, t.br - t.bl, t.bl);
-  *value = mad(b, bot - top, top);
+  {
+    const float qa = bilinear_weight(a), qb = bilinear_weight(b);
+    const float top = mad(qa, t.tr - t.tl, t.tl);
+    const float bot = mad(qa, t.br - t.bl, t.bl);
+    *value = mad(qb, bot - top, top);
+  }
 
   float mx = fmaxf(0.f, x - 0.5f), my = fmaxf(0.f, y - 0.5f);
   if (!(mx < (float)w)) mx = (float)w;
@@ -399,9 +413,12 @@ __device__ __forceinline__ void sample_luma_and_gradient_interior(const Intrinsi
   const float fx = floorf(xb), fy = floorf(yb);
   const float a = xb - fx, b = yb - fy;
   const Luma4 t = luma_footprint(in, lumafp, (int)fx, (int)fy);
-  const float top = mad(a, t.tr - t.tl, t.tl);
-  const float bot = mad(a, t.br - t.bl, t.bl);
-  *value = mad(b, bot - top, top);
+  {
+    const float qa = bilinear_weight(a), qb = bilinear_weight(b);
+    const float top = mad(qa, t.tr - t.tl, t.tl);
+    const float bot = mad(qa, t.br - t.bl, t.bl);
+    *value = mad(qb, bot - top, top);
+  }
   *dx = mad(t.br - t.bl, b, (t.tr - t.tl) * (1 - b));
   *dy = mad(t.br - t.tr, a, (t.bl - t.tl) * (1 - a));
 }

@@ -1,0 +1,224 @@
+// kernels_hip.cc -- Route B of INTEGRATION.md: the free functions of the reference's B/kernels.h (the *CUDA entry points
+// DirectBA calls) implemented on top of the C ABI of the MI355X backend (include/badslam_hip.h).  A maintainer of the
+// reference who keeps their own DirectBA host code drops this file in place of kernel_*.cc / kernel_*.cu.  Every function
+// does the same three things: describe the caller's buffers as bahip_* structs (pointers are borrowed), bind cameras / depth
+// parameters / keyframes, call the one bahip_* function that replaces the reference function, and turn a failure into
+// LOG(FATAL) like the reference's CUDA_CHECK().  One backend context per host thread, re-pointed at the caller's stream.
+#include "badslam/kernels.h"
+
+namespace vis {
+namespace {
+
+bahip_context* Ctx(cudaStream_t stream) {
+  static thread_local bahip_context* ctx = nullptr;
+  if (!ctx) BAHIP_CHECKED_CALL(bahip_context_create(&ctx, stream));
+  BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx, stream));
+  return ctx;
+}
+
+bahip_surfels Surfels(const CUDABuffer<float>& surfels, const CUDABuffer<u8>* active, u32 surfels_size) {
+  bahip_surfels s;
+  s.data = surfels.ToCUDA().address();
+  s.pitch_bytes = (uint32_t)surfels.ToCUDA().pitch();
+  s.active = active ? active->ToCUDA().address() : nullptr;
+  s.surfels_size = surfels_size;
+  s.capacity = (uint32_t)surfels.width();
+  return s;
+}
+
+void BindIntrinsics(bahip_context* ctx, const PinholeCamera4f& color_camera, const PinholeCamera4f& depth_camera,
+                    const DepthParameters& depth_params) {
+  const bahip_camera cc = ToBahipCamera(color_camera), dc = ToBahipCamera(depth_camera);
+  const bahip_depth_params dp = ToBahipDepthParams(depth_params);
+  BAHIP_CHECKED_CALL(bahip_set_intrinsics(ctx, &cc, &dc, &dp));
+}
+
+// The keyframe vector of the reference (deleted keyframes are null entries) -> the dense bound list; returns the bound
+// index of `keyframe_id` (or -1).
+int BindKeyframes(bahip_context* ctx, const vector<shared_ptr<Keyframe>>& keyframes, int keyframe_id = -1) {
+  vector<bahip_keyframe> table;
+  int bound_of_id = -1;
+  for (const shared_ptr<Keyframe>& kf : keyframes) {
+    if (!kf) continue;
+    bahip_keyframe e;
+    e.frame = kf->ToBahipFrame();
+    memcpy(e.global_T_frame, kf->global_T_frame().data(), 7 * sizeof(float));
+    e.activation = (int)kf->activation();
+    if (kf->id() == keyframe_id) bound_of_id = (int)table.size();
+    table.push_back(e);
+  }
+  BAHIP_CHECKED_CALL(bahip_set_keyframes(ctx, table.data(), (int)table.size()));
+  return bound_of_id;
+}
+
+bahip_frame Frame(const CUDABuffer<u16>& depth, const CUDABuffer<u16>& normals, const CUDABuffer<u16>* radius,
+                  const CUDABuffer<uchar4>* color) {
+  bahip_frame f{};
+  f.depth = depth.ToCUDA().address(); f.depth_pitch_bytes = (uint32_t)depth.ToCUDA().pitch();
+  f.normals = normals.ToCUDA().address(); f.normals_pitch_bytes = (uint32_t)normals.ToCUDA().pitch();
+  if (radius) { f.radius = radius->ToCUDA().address(); f.radius_pitch_bytes = (uint32_t)radius->ToCUDA().pitch(); }
+  if (color) { f.color = reinterpret_cast<uint8_t*>(color->ToCUDA().address()); f.color_pitch_bytes = (uint32_t)color->ToCUDA().pitch(); }
+  f.planes = nullptr;   // the library packs its tiled planes itself (a caller that keeps bahip_frame_planes passes them)
+  return f;
+}
+
+void SupportingPointers(CUDABuffer<u32>** supporting_surfels, uint32_t* out[BAHIP_MERGE_BUFFER_COUNT], uint32_t* pitch) {
+  for (int i = 0; i < BAHIP_MERGE_BUFFER_COUNT; ++i) out[i] = supporting_surfels[i]->ToCUDA().address();
+  *pitch = (uint32_t)supporting_surfels[0]->ToCUDA().pitch();
+}
+
+}  // namespace
+
+void DetermineSupportingSurfelsCUDA(cudaStream_t stream, const PinholeCamera4f& camera, const CUDAMatrix3x4& frame_T_global,
+                                    const DepthParameters& depth_params, const CUDABuffer<u16>& depth_buffer,
+                                    const CUDABuffer<u16>& normals_buffer, u32 surfels_size, CUDABuffer<float>* surfels,
+                                    CUDABuffer<u32>** supporting_surfels) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, camera, camera, depth_params);
+  const bahip_frame frame = Frame(depth_buffer, normals_buffer, nullptr, nullptr);
+  const bahip_surfels s = Surfels(*surfels, nullptr, surfels_size);
+  uint32_t* sup[BAHIP_MERGE_BUFFER_COUNT]; uint32_t pitch;
+  SupportingPointers(supporting_surfels, sup, &pitch);
+  BAHIP_CHECKED_CALL(bahip_determine_supporting_surfels(ctx, 0, 0.f, &frame, &frame_T_global.row0.x, &s, sup, pitch, nullptr));
+}
+
+void DetermineSupportingSurfelsAndMergeSurfelsCUDA(cudaStream_t stream, float merge_dist_factor, const PinholeCamera4f& camera,
+                                                   const CUDAMatrix3x4& frame_T_global, const DepthParameters& depth_params,
+                                                   const CUDABuffer<u16>& depth_buffer, const CUDABuffer<u16>& normals_buffer,
+                                                   u32 surfels_size, CUDABuffer<float>* surfels, CUDABuffer<u32>** supporting_surfels,
+                                                   u32* surfel_count, CUDABufferPtr<u32>* /*deleted_count_buffer*/) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, camera, camera, depth_params);
+  const bahip_frame frame = Frame(depth_buffer, normals_buffer, nullptr, nullptr);
+  const bahip_surfels s = Surfels(*surfels, nullptr, surfels_size);
+  uint32_t* sup[BAHIP_MERGE_BUFFER_COUNT]; uint32_t pitch;
+  SupportingPointers(supporting_surfels, sup, &pitch);
+  uint32_t merged = 0;
+  BAHIP_CHECKED_CALL(bahip_determine_supporting_surfels(ctx, 1, merge_dist_factor, &frame, &frame_T_global.row0.x, &s, sup, pitch, &merged));
+  *surfel_count -= merged;
+}
+
+void CreateSurfelsForKeyframeCUDA(cudaStream_t stream, int /*sparse_surfel_cell_size: part of depth_params*/, bool filter_new_surfels,
+                                  int min_observation_count, int keyframe_id, const vector<shared_ptr<Keyframe>>& keyframes,
+                                  const PinholeCamera4f& color_camera, const PinholeCamera4f& depth_camera,
+                                  const CUDAMatrix3x4& /*global_T_frame*/, const CUDAMatrix3x4& /*frame_T_global*/,
+                                  const vector<CUDAMatrix3x4>& /*covis_T_frame: recomputed from the bound poses*/,
+                                  const DepthParameters& depth_params, const CUDABuffer<u16>&, const CUDABuffer<u16>&,
+                                  const CUDABuffer<u16>&, const CUDABuffer<uchar4>&, cudaTextureObject_t,
+                                  CUDABuffer<u32>** supporting_surfels, void**, usize*, CUDABuffer<u8>*, CUDABuffer<u32>*,
+                                  u32 surfels_size, u32 /*surfel_count*/, u32* new_surfel_count, CUDABuffer<float>* surfels) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, color_camera, depth_camera, depth_params);
+  const int bound = BindKeyframes(ctx, keyframes, keyframe_id);
+  CHECK(bound >= 0) << "keyframe " << keyframe_id << " is not in the keyframe list";
+  // co-visible keyframes: ids -> bound indices (the reference passes their relative transforms; the backend derives them)
+  vector<int> id_to_bound(keyframes.size(), -1), covis;
+  { int b = 0; for (const auto& kf : keyframes) if (kf) id_to_bound[kf->id()] = b++; }
+  for (int id : keyframes[keyframe_id]->co_visibility_list())
+    if (id >= 0 && id < (int)id_to_bound.size() && id_to_bound[id] >= 0) covis.push_back(id_to_bound[id]);
+  const bahip_surfels s = Surfels(*surfels, nullptr, surfels_size);
+  uint32_t* sup[BAHIP_MERGE_BUFFER_COUNT]; uint32_t pitch;
+  SupportingPointers(supporting_surfels, sup, &pitch);
+  uint32_t created = 0;
+  BAHIP_CHECKED_CALL(bahip_create_surfels_for_keyframe(ctx, bound, filter_new_surfels ? 1 : 0, min_observation_count, covis.data(),
+                                                       (int)covis.size(), &s, sup, pitch, &created));
+  *new_surfel_count = created;
+}
+
+void AccumulatePoseEstimationCoeffsCUDA(cudaStream_t stream, bool use_depth_residuals, bool use_descriptor_residuals,
+                                        const PinholeCamera4f& color_camera, const PinholeCamera4f& depth_camera,
+                                        const DepthParameters& depth_params, const CUDABuffer<u16>& depth_buffer,
+                                        const CUDABuffer<u16>& normals_buffer, cudaTextureObject_t color_texture,
+                                        const CUDAMatrix3x4& frame_T_global_estimate, u32 surfels_size,
+                                        const CUDABuffer<float>& surfels, bool /*debug*/, u32* /*residual_count*/,
+                                        float* /*residual_sum*/, float* H, float* b, PoseEstimationHelperBuffers*) {
+  CHECK(use_depth_residuals || use_descriptor_residuals);   // B/kernel_opt_pose.cc:58
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, color_camera, depth_camera, depth_params);
+  const bahip_frame frame = Frame(depth_buffer, normals_buffer, nullptr, color_texture);   // the handle IS the colour buffer
+  const bahip_surfels s = Surfels(surfels, nullptr, surfels_size);
+  BAHIP_CHECKED_CALL(bahip_accumulate_pose_estimation_coeffs(ctx, use_depth_residuals, use_descriptor_residuals, &frame,
+                                                             &frame_T_global_estimate.row0.x, &s, H, b));
+}
+
+void UpdateSurfelNormalsCUDA(cudaStream_t stream, const PinholeCamera4f& depth_camera, const DepthParameters& depth_params,
+                             const vector<shared_ptr<Keyframe>>& keyframes, u32 surfels_size, const CUDABuffer<float>& surfels,
+                             const CUDABuffer<u8>& active_surfels) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, depth_camera, depth_camera, depth_params);
+  BindKeyframes(ctx, keyframes);
+  const bahip_surfels s = Surfels(surfels, &active_surfels, surfels_size);
+  BAHIP_CHECKED_CALL(bahip_update_surfel_normals(ctx, &s));
+}
+
+void OptimizeGeometryIterationCUDA(cudaStream_t stream, bool use_depth_residuals, bool use_descriptor_residuals,
+                                   const PinholeCamera4f& color_camera, const PinholeCamera4f& depth_camera,
+                                   const DepthParameters& depth_params, const vector<shared_ptr<Keyframe>>& keyframes,
+                                   u32 surfels_size, const CUDABuffer<float>& surfels, const CUDABuffer<u8>& active_surfels) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, color_camera, depth_camera, depth_params);
+  BindKeyframes(ctx, keyframes);
+  const bahip_surfels s = Surfels(surfels, &active_surfels, surfels_size);
+  BAHIP_CHECKED_CALL(bahip_optimize_geometry_iteration(ctx, use_depth_residuals, use_descriptor_residuals, &s));
+}
+
+void OptimizeIntrinsicsCUDA(cudaStream_t stream, bool optimize_depth_intrinsics, bool optimize_color_intrinsics,
+                            const vector<shared_ptr<Keyframe>>& keyframes, const PinholeCamera4f& color_camera,
+                            const PinholeCamera4f& depth_camera, const DepthParameters& depth_params, u32 surfels_size,
+                            const CUDABuffer<float>& surfels, PinholeCamera4f* out_color_camera, PinholeCamera4f* out_depth_camera,
+                            float* a, CUDABufferPtr<float>* /*cfactor_buffer: updated in place through depth_params*/,
+                            IntrinsicsOptimizationHelperBuffers*) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, color_camera, depth_camera, depth_params);
+  BindKeyframes(ctx, keyframes);
+  const bahip_surfels s = Surfels(surfels, nullptr, surfels_size);
+  bahip_camera cc, dc;
+  BAHIP_CHECKED_CALL(bahip_optimize_intrinsics(ctx, optimize_depth_intrinsics, optimize_color_intrinsics, &s, &cc, &dc, a));
+  *out_color_camera = PinholeCamera4f(cc.width, cc.height, &cc.fx);
+  *out_depth_camera = PinholeCamera4f(dc.width, dc.height, &dc.fx);
+}
+
+void UpdateSurfelActivationCUDA(cudaStream_t stream, const PinholeCamera4f& camera, const DepthParameters& depth_params,
+                                const vector<shared_ptr<Keyframe>>& keyframes, u32 surfels_size, CUDABuffer<float>* surfels,
+                                CUDABuffer<u8>* active_surfels) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, camera, camera, depth_params);
+  BindKeyframes(ctx, keyframes);
+  const bahip_surfels s = Surfels(*surfels, active_surfels, surfels_size);
+  BAHIP_CHECKED_CALL(bahip_update_surfel_activation(ctx, &s, surfels_size));
+}
+
+void DeleteSurfelsAndUpdateRadiiCUDA(cudaStream_t stream, int min_observation_count, const PinholeCamera4f& camera,
+                                     const DepthParameters& depth_params, const vector<shared_ptr<Keyframe>>& keyframes,
+                                     u32* surfel_count, u32 surfels_size, CUDABuffer<float>* surfels, CUDABufferPtr<u32>*) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, camera, camera, depth_params);
+  BindKeyframes(ctx, keyframes);
+  const bahip_surfels s = Surfels(*surfels, nullptr, surfels_size);
+  uint32_t deleted = 0;
+  BAHIP_CHECKED_CALL(bahip_delete_surfels_and_update_radii(ctx, min_observation_count, &s, &deleted));
+  *surfel_count -= deleted;
+}
+
+void CompactSurfelsCUDA(cudaStream_t stream, void**, usize*, u32 surfel_count, u32* surfels_size, CUDABuffer_<float>* surfels,
+                        CUDABuffer_<u8>* active_surfels) {
+  bahip_context* ctx = Ctx(stream);
+  bahip_surfels s;
+  s.data = surfels->address(); s.pitch_bytes = (uint32_t)surfels->pitch();
+  s.active = active_surfels ? active_surfels->address() : nullptr;
+  s.surfels_size = *surfels_size; s.capacity = (uint32_t)surfels->width();
+  BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx, surfel_count, &s));
+  *surfels_size = surfel_count;
+}
+
+void AssignColorsCUDA(cudaStream_t stream, const PinholeCamera4f& color_camera, const PinholeCamera4f& depth_camera,
+                      const DepthParameters& depth_params, const vector<shared_ptr<Keyframe>>& keyframes, u32 surfels_size,
+                      CUDABuffer<float>* surfels) {
+  bahip_context* ctx = Ctx(stream);
+  BindIntrinsics(ctx, color_camera, depth_camera, depth_params);
+  BindKeyframes(ctx, keyframes);
+  const bahip_surfels s = Surfels(*surfels, nullptr, surfels_size);
+  BAHIP_CHECKED_CALL(bahip_assign_colors(ctx, &s));
+}
+
+}  // namespace vis

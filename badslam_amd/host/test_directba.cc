@@ -353,7 +353,10 @@ int IntrinsicsOptimizationWithPhotometricResidual(bool use_pcg) {
   }
   for (auto& kf : ba->keyframes()) ba->CreateSurfelsForKeyframe(stream, true, kf);
   ba->SetColorCamera(distorted_color_camera);
-  for (int i = 0; i < 10; ++i) {
+  // TEST_CALLS_FACTOR (default 1): multiplies the prescribed number of BundleAdjustment calls (the seed study of DESIGN.md:
+  // does a seed that misses the bound after the prescribed calls reach it with more, or does it settle elsewhere?)
+  const int calls_factor = getenv("TEST_CALLS_FACTOR") ? atoi(getenv("TEST_CALLS_FACTOR")) : 1;
+  for (int i = 0; i < 10 * calls_factor; ++i) {
     ba->BundleAdjustment(stream, /*depth intr*/ false, /*color intr*/ true, /*surfel updates*/ true, /*poses*/ false, /*geometry*/ false,
                          1, 10, use_pcg, 0, (int)ba->keyframes().size() - 1, /*increase_ba_iteration_count*/ i != 0);
     const PinholeCamera4f e = ba->color_camera();
@@ -451,7 +454,7 @@ int DepthDeformationOptimizationWithGeometricResidual(bool use_pcg) {
   }
   constexpr int kCFactorTestX = 50, kCFactorTestY = 50;
   Image<float> cfactor_image(ba->cfactor_buffer()->width(), ba->cfactor_buffer()->height());
-  const int calls = use_pcg ? 20 : 400;
+  const int calls = (use_pcg ? 20 : 400) * (getenv("TEST_CALLS_FACTOR") ? atoi(getenv("TEST_CALLS_FACTOR")) : 1);
   for (int i = 0; i < calls; ++i) {
     ba->BundleAdjustment(stream, /*depth intr*/ i != 0, /*color intr*/ false, /*surfel updates*/ true, /*poses*/ false, /*geometry*/ true,
                          1, 10, use_pcg, 0, (int)ba->keyframes().size() - 1, /*increase_ba_iteration_count*/ i != 0);

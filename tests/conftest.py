@@ -17,7 +17,7 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The libraries are build products (not in git).  If a checkout is tested before __graft_entry__.build() ran and a
     compiler is at hand (the build container), build them; on a box without hipcc the tests fail with their own messages."""
-    needed = [os.path.join(ROOT, "badslam_amd", "lib", n) for n in ("libbadslam_hip.so", "libbadslam_host.so", "test_directba", "ba_tum")]
+    needed = [os.path.join(ROOT, "badslam_amd", "lib", n) for n in ("libbadslam_hip.so", "libbadslam_host.so", "test_directba", "ba_tum", "test_route_b")]
     needed.append(os.path.join(ROOT, "oracle", "liboracle.so"))
     if all(os.path.exists(p) for p in needed):
         return

@@ -27,3 +27,16 @@ def test_reference_closed_loop(name):
     print(proc.stdout)
     print(proc.stderr)
     assert proc.returncode == 0, proc.stdout[-2000:]
+
+
+def test_route_b_shim_matches_route_a():
+    """INTEGRATION.md Route B: badslam_amd/host/route_b/kernels_hip.cc implements the reference's *CUDA free functions
+    (B/kernels.h:94-311, signatures restated in route_b/badslam/kernels.h) on the bahip_* C ABI.  The test program drives them
+    in the reference's call order and compares with Route A (vis::DirectBA): created surfels and one geometry iteration
+    bit-identical, pose normal equations sane."""
+    binary = os.path.join(os.path.dirname(BIN), "test_route_b")
+    assert os.path.exists(binary), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    proc = subprocess.run([binary], capture_output=True, text=True, timeout=600)
+    print(proc.stdout)
+    print(proc.stderr)
+    assert proc.returncode == 0 and "ROUTE_B_OK" in proc.stdout, (proc.stdout[-2000:], proc.stderr[-2000:])
