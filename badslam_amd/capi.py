@@ -69,6 +69,8 @@ SIGNATURES = {
     "bahip_context_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     "bahip_context_destroy": (None, [C.c_void_p]),
     "bahip_context_synchronize": (C.c_int, [C.c_void_p]),
+    "bahip_context_take_capacity_exceeded": (C.c_int, [C.c_void_p]),
+    "bahip_context_is_sharded": (C.c_int, [C.c_void_p]),
     "bahip_context_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "bahip_rccl_get_unique_id": (C.c_int, [C.c_char_p]),
     "bahip_context_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),

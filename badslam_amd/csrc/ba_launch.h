@@ -100,7 +100,7 @@ hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float in
 size_t scan_temp_bytes(size_t n);
 hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint8_t* flags, uint32_t* out, int n);
 hipError_t scan_u32_exclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n);
-void launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invalid, uint32_t* free_rank, uint32_t* free_list,
-                    uint32_t surfel_count, void* temp, size_t temp_bytes);
+hipError_t launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invalid, uint32_t* free_rank, uint32_t* free_list,
+                          uint32_t surfel_count, void* temp, size_t temp_bytes);
 
 }  // namespace bahip

@@ -40,6 +40,13 @@ int fail(const char* what, const char* file, int line, hipError_t e = hipSuccess
   } while (0)
 #define CHECK_LAUNCH() HIP_TRY(hipGetLastError())
 
+// Scratch of the test hooks: freed on every return path.
+struct DevMem {
+  void* p = nullptr;
+  ~DevMem() { if (p) hipFree(p); }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct StageTimer {
   std::vector<hipEvent_t> ev;   // pairs (start, stop)
   int used = 0;                 // number of pairs used by the last call (mode 1) / since set_profiling (mode 2)
@@ -91,6 +98,7 @@ struct bahip_context {
   std::vector<int> covis_offsets, covis_indices;
   int* dev_covis_csr = nullptr;    // offsets (K + 1) followed by the indices
   size_t covis_csr_capacity = 0;
+  bool capacity_exceeded = false;  // last bahip_create_surfels_for_keyframe did not fit (bahip_context_take_capacity_exceeded)
   bool have_covisibility = false;
   std::vector<uint8_t> window;     // per bound keyframe: inside the fixed active window (bahip_set_activation_window)
   uint8_t* dev_window = nullptr;
@@ -212,6 +220,25 @@ SurfelsView make_view(const bahip_surfels* s) {
   return v;
 }
 
+// Grow-on-demand for library-owned scratch: the new block is allocated FIRST and swapped in on success, so a failed grow
+// leaves pointer and capacity as they were (no dangling pointer behind an unchanged capacity, no double free at destroy).
+template <typename T>
+int grow_device(T** ptr, size_t* capacity, size_t need, size_t slack, const char* what) {
+  if (need <= *capacity && *ptr) return 0;
+  T* grown = nullptr;
+  const size_t cap = need + slack;
+  if (hipMalloc(&grown, sizeof(T) * cap) != hipSuccess) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "hipMalloc of %zu bytes for %s failed", sizeof(T) * cap, what);
+    g_last_error = buf;
+    return 1;
+  }
+  hipFree(*ptr);
+  *ptr = grown;
+  *capacity = cap;
+  return 0;
+}
+
 int ensure_work(bahip_context* ctx, int n) {
   if (n <= ctx->work_capacity) return 0;
   const int cap = n + 64;
@@ -232,15 +259,21 @@ int ensure_work(bahip_context* ctx, int n) {
 
 int ensure_px(bahip_context* ctx, size_t px, size_t scan_n) {
   if (px > ctx->px_capacity) {
-    if (ctx->dev_flags) { hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); }
-    HIP_TRY(hipMalloc(&ctx->dev_flags, px));
-    HIP_TRY(hipMalloc(&ctx->dev_indices, px * sizeof(uint32_t)));
+    uint8_t* flags = nullptr; uint32_t* indices = nullptr;
+    if (hipMalloc(&flags, px) != hipSuccess || hipMalloc(&indices, px * sizeof(uint32_t)) != hipSuccess) {
+      hipFree(flags); hipFree(indices);
+      return fail("allocation of the new-surfel flag / index vectors failed", __FILE__, __LINE__);
+    }
+    hipFree(ctx->dev_flags); hipFree(ctx->dev_indices);
+    ctx->dev_flags = flags; ctx->dev_indices = indices;
     ctx->px_capacity = px;
   }
   const size_t need = scan_temp_bytes(scan_n);
   if (need > ctx->scan_temp_bytes) {
-    if (ctx->scan_temp) hipFree(ctx->scan_temp);
-    HIP_TRY(hipMalloc(&ctx->scan_temp, need));
+    void* temp = nullptr;
+    if (hipMalloc(&temp, need) != hipSuccess) return fail("allocation of the scan scratch failed", __FILE__, __LINE__);
+    hipFree(ctx->scan_temp);
+    ctx->scan_temp = temp;
     ctx->scan_temp_bytes = need;
   }
   return 0;
@@ -398,11 +431,7 @@ int allreduce_head(bahip_context* ctx, const PcgLayout& L, float* a, float* b, f
   const size_t head = lo + (U - hi);
   const size_t total = head * (b ? 2 : 1) + (size_t)num_scalars;
   if (total == 0) return 0;
-  if (total > ctx->pcg_stage_capacity) {
-    if (ctx->pcg_stage) hipFree(ctx->pcg_stage);
-    ctx->pcg_stage_capacity = total + 1024;
-    HIP_TRY(hipMalloc(&ctx->pcg_stage, sizeof(float) * ctx->pcg_stage_capacity));
-  }
+  if (grow_device(&ctx->pcg_stage, &ctx->pcg_stage_capacity, total, 1024, "the all-reduce staging buffer")) return 1;
   hipStream_t st = ctx->stream;
   float* stage = ctx->pcg_stage;
   size_t at = 0;
@@ -445,13 +474,17 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   REQUIRE(n > 0, "bahip_context_create: no HIP device (the HIP backend has no CPU fallback)");
   bahip_context* ctx = new bahip_context();
   ctx->stream = static_cast<hipStream_t>(hip_stream);
-  HIP_TRY(hipMalloc(&ctx->dev_counter, 16 * sizeof(int)));
-  HIP_TRY(hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)));
-  HIP_TRY(hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)));
-  HIP_TRY(hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)));
-  HIP_TRY(hipMalloc(&ctx->dev_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)));
-  HIP_TRY(hipHostMalloc(&ctx->pinned_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)));
-  HIP_TRY(hipMalloc(&ctx->dev_Hb1, sizeof(HbFixed) * kHbStride));
+  const bool ok = hipMalloc(&ctx->dev_counter, 16 * sizeof(int)) == hipSuccess &&
+                  hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)) == hipSuccess &&
+                  hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)) == hipSuccess &&
+                  hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)) == hipSuccess &&
+                  hipMalloc(&ctx->dev_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)) == hipSuccess &&
+                  hipHostMalloc(&ctx->pinned_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)) == hipSuccess &&
+                  hipMalloc(&ctx->dev_Hb1, sizeof(HbFixed) * kHbStride) == hipSuccess;
+  if (!ok) {
+    bahip_context_destroy(ctx);   // frees whatever was allocated (hipFree(nullptr) is a no-op)
+    return fail("bahip_context_create: allocation of the context scratch failed", __FILE__, __LINE__);
+  }
   *out = ctx;
   return 0;
 }
@@ -459,13 +492,15 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
 void bahip_context_destroy(bahip_context* ctx) {
   if (!ctx) return;
   hipStreamSynchronize(ctx->stream);
+  if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->dev_kfs); hipFree(ctx->dev_work); hipFree(ctx->dev_Hb);
   hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1);
-  hipFree(ctx->dev_counter); hipHostFree(ctx->pinned_i); hipHostFree(ctx->pinned_f);
+  hipFree(ctx->dev_counter);
+  if (ctx->pinned_i) hipHostFree(ctx->pinned_i);
+  if (ctx->pinned_f) hipHostFree(ctx->pinned_f);
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
-  if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
@@ -477,6 +512,14 @@ int bahip_context_synchronize(bahip_context* ctx) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return 0;
 }
+
+int bahip_context_take_capacity_exceeded(bahip_context* ctx) {
+  const int flag = ctx->capacity_exceeded ? 1 : 0;
+  ctx->capacity_exceeded = false;
+  return flag;
+}
+
+int bahip_context_is_sharded(bahip_context* ctx) { return (ctx->allreduce != nullptr || ctx->rccl_comm != nullptr) ? 1 : 0; }
 
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user) {
   ctx->allreduce = fn;
@@ -687,9 +730,9 @@ int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int
     ctx->host_kfs[k] = e;
   }
   if (num_keyframes > ctx->kfs_capacity) {
-    if (ctx->dev_kfs) hipFree(ctx->dev_kfs);
-    ctx->kfs_capacity = num_keyframes + 64;
-    HIP_TRY(hipMalloc(&ctx->dev_kfs, sizeof(KfEntry) * ctx->kfs_capacity));
+    size_t cap = (size_t)ctx->kfs_capacity;
+    if (grow_device(&ctx->dev_kfs, &cap, (size_t)num_keyframes, 64, "the keyframe table")) return 1;
+    ctx->kfs_capacity = (int)cap;
   }
   ctx->num_kfs = num_keyframes;
   ctx->have_covisibility = false;   // lists refer to the previous binding
@@ -981,10 +1024,15 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
   CHECK_LAUNCH();
   if (filter_new_surfels && n_covis > 0) {
     if (n_covis > ctx->covis_capacity) {
-      if (ctx->dev_covis) { hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); }
-      ctx->covis_capacity = n_covis + 64;
-      HIP_TRY(hipMalloc(&ctx->dev_covis, sizeof(int) * ctx->covis_capacity));
-      HIP_TRY(hipMalloc(&ctx->dev_covis_T, sizeof(float) * 12 * ctx->covis_capacity));
+      int* idx = nullptr; float* T = nullptr;
+      const int cap = n_covis + 64;
+      if (hipMalloc(&idx, sizeof(int) * cap) != hipSuccess || hipMalloc(&T, sizeof(float) * 12 * cap) != hipSuccess) {
+        hipFree(idx); hipFree(T);
+        return fail("allocation of the co-visibility scratch failed", __FILE__, __LINE__);
+      }
+      hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
+      ctx->dev_covis = idx; ctx->dev_covis_T = T;
+      ctx->covis_capacity = cap;
     }
     std::vector<float> rel(12 * (size_t)n_covis);
     for (int c = 0; c < n_covis; ++c) {
@@ -1011,8 +1059,11 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
   const uint32_t count = (uint32_t)ctx->pinned_i[0];
   if (count == 0) return 0;
   if ((uint64_t)surfels->surfels_size + count > surfels->capacity) {
-    g_last_error = "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";  // B/kernel_create_surfels.cc:162-165
-    return 0;  // soft failure in the reference: logs and returns without creating
+    // soft failure in the reference: logs and returns without creating (B/kernel_create_surfels.cc:162-165); the caller asks
+    // bahip_context_take_capacity_exceeded() to tell this from "no new surfels"
+    g_last_error = "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";
+    ctx->capacity_exceeded = true;
+    return 0;
   }
   launch_create_append(ctx->stream, ctx->in, e, ctx->dev_flags, ctx->dev_indices, surfels->surfels_size, make_view(surfels));
   CHECK_LAUNCH();
@@ -1044,8 +1095,7 @@ int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip
   uint32_t* invalid = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 2) * surfels->pitch_bytes);
   uint32_t* free_rank = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 0) * surfels->pitch_bytes);
   uint32_t* free_list = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 3) * surfels->pitch_bytes);
-  launch_compact(ctx->stream, make_view(surfels), invalid, free_rank, free_list, surfel_count, ctx->scan_temp, ctx->scan_temp_bytes);
-  CHECK_LAUNCH();
+  HIP_TRY(launch_compact(ctx->stream, make_view(surfels), invalid, free_rank, free_list, surfel_count, ctx->scan_temp, ctx->scan_temp_bytes));
   return 0;
 }
 
@@ -1067,9 +1117,12 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   if (surfels->surfels_size == 0 && !is_sharded(ctx)) return 0;   // a rank with an empty shard still takes part in the exchange
   const int S = ctx->in.cf_width * ctx->in.cf_height;
   if (S > ctx->intr_capacity) {
-    if (ctx->intr_scratch) hipFree(ctx->intr_scratch);
-    ctx->intr_capacity = S + 1024;
-    HIP_TRY(hipMalloc(&ctx->intr_scratch, sizeof(float) * (64 + 8 * (size_t)ctx->intr_capacity + intrinsics_schur_partials(ctx->intr_capacity))));
+    const int cap = S + 1024;
+    float* grown = nullptr;
+    HIP_TRY(hipMalloc(&grown, sizeof(float) * (64 + 8 * (size_t)cap + intrinsics_schur_partials(cap))));
+    hipFree(ctx->intr_scratch);
+    ctx->intr_scratch = grown;
+    ctx->intr_capacity = cap;
   }
   float* glob = ctx->intr_scratch;            // 34 sums + x1 at [40..44]
   float* B = glob + 64;                       // 5 * S
@@ -1169,9 +1222,12 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
     return 0;
   }
   if (U > ctx->pcg_capacity || ctx->pcg_buf == nullptr) {   // lazy (re-)allocation like B/direct_ba_pcg.cc:255-268
-    if (ctx->pcg_buf) hipFree(ctx->pcg_buf);
-    ctx->pcg_capacity = U + U / 8 + 4096;
-    HIP_TRY(hipMalloc(&ctx->pcg_buf, sizeof(float) * (5 * ctx->pcg_capacity + 16)));
+    const size_t cap = U + U / 8 + 4096;
+    float* grown = nullptr;
+    HIP_TRY(hipMalloc(&grown, sizeof(float) * (5 * cap + 16)));
+    hipFree(ctx->pcg_buf);
+    ctx->pcg_buf = grown;
+    ctx->pcg_capacity = cap;
   }
   const size_t cap = ctx->pcg_capacity;
   float* r_ = ctx->pcg_buf; float* M_ = r_ + cap; float* delta = M_ + cap; float* g_ = delta + cap; float* p_ = g_ + cap;
@@ -1290,15 +1346,14 @@ int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, con
   KfEntry e;
   if (make_entry(ctx, *frame, 0, &e)) return 1;
   memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
-  uint32_t* d_idx = nullptr; float* d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_idx, sizeof(uint32_t) * count));
-  HIP_TRY(hipMalloc(&d_out, sizeof(float) * 40 * count));
-  HIP_TRY(hipMemcpy(d_idx, surfel_indices_host, sizeof(uint32_t) * count, hipMemcpyHostToDevice));
-  launch_evaluate_pairs(ctx->stream, ctx->in, e, make_view(surfels), d_idx, count, d_out);
+  DevMem idx, out;
+  HIP_TRY(hipMalloc(&idx.p, sizeof(uint32_t) * count));
+  HIP_TRY(hipMalloc(&out.p, sizeof(float) * 40 * count));
+  HIP_TRY(hipMemcpy(idx.p, surfel_indices_host, sizeof(uint32_t) * count, hipMemcpyHostToDevice));
+  launch_evaluate_pairs(ctx->stream, ctx->in, e, make_view(surfels), idx.as<uint32_t>(), count, out.as<float>());
   CHECK_LAUNCH();
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipMemcpy(out_host, d_out, sizeof(float) * 40 * count, hipMemcpyDeviceToHost));
-  hipFree(d_idx); hipFree(d_out);
+  HIP_TRY(hipMemcpy(out_host, out.p, sizeof(float) * 40 * count, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1320,15 +1375,14 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts) {
 
 int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in, float* out, int n_out) {
   REQUIRE(kind >= 0 && kind <= 4 && n_in > 0 && n_in <= 16 && n_out > 0 && n_out <= 8, "bahip_debug_jacobian: bad arguments");
-  float *d_in = nullptr, *d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_in, 16 * sizeof(float)));
-  HIP_TRY(hipMalloc(&d_out, 8 * sizeof(float)));
-  HIP_TRY(hipMemcpyAsync(d_in, in, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  launch_jacobian_debug(ctx->stream, kind, d_in, d_out);
+  DevMem d_in, d_out;
+  HIP_TRY(hipMalloc(&d_in.p, 16 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out.p, 8 * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(d_in.p, in, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  launch_jacobian_debug(ctx->stream, kind, d_in.as<float>(), d_out.as<float>());
   CHECK_LAUNCH();
-  HIP_TRY(hipMemcpyAsync(out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out, d_out.p, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  hipFree(d_in); hipFree(d_out);
   return 0;
 }
 
@@ -1379,29 +1433,27 @@ int bahip_debug_pose_step(bahip_context* ctx, const float* H21_b6, const float* 
 }
 
 int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* out_80) {
-  float *d_in = nullptr, *d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_in, 64 * 28 * sizeof(float)));
-  HIP_TRY(hipMalloc(&d_out, 80 * sizeof(float)));
-  HIP_TRY(hipMemcpyAsync(d_in, in_64x28, 64 * 28 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemsetAsync(d_out, 0xff, 80 * sizeof(float), ctx->stream));
-  launch_wave_reduce_debug(ctx->stream, d_in, d_out);
+  DevMem d_in, d_out;
+  HIP_TRY(hipMalloc(&d_in.p, 64 * 28 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_out.p, 80 * sizeof(float)));
+  HIP_TRY(hipMemcpyAsync(d_in.p, in_64x28, 64 * 28 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(d_out.p, 0xff, 80 * sizeof(float), ctx->stream));
+  launch_wave_reduce_debug(ctx->stream, d_in.as<float>(), d_out.as<float>());
   CHECK_LAUNCH();
-  HIP_TRY(hipMemcpyAsync(out_80, d_out, 80 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out_80, d_out.p, 80 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  hipFree(d_in); hipFree(d_out);
   return 0;
 }
 
 int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
-  unsigned long long* d = nullptr;
-  HIP_TRY(hipMalloc(&d, 4 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), ctx->stream));
-  launch_count_pairs(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), d);
+  DevMem d;
+  HIP_TRY(hipMalloc(&d.p, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  launch_count_pairs(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), d.as<unsigned long long>());
   CHECK_LAUNCH();
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipMemcpy(counts_out, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  hipFree(d);
+  HIP_TRY(hipMemcpy(counts_out, d.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
 }
 

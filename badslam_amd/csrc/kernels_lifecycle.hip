@@ -363,15 +363,17 @@ hipError_t scan_u32_exclusive(hipStream_t st, void* temp, size_t temp_bytes, con
   return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, n, st);
 }
 
-void launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invalid, uint32_t* free_rank, uint32_t* free_list,
-                    uint32_t surfel_count, void* temp, size_t temp_bytes) {
-  if (!s.size) return;
+hipError_t launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invalid, uint32_t* free_rank, uint32_t* free_list,
+                          uint32_t surfel_count, void* temp, size_t temp_bytes) {
+  if (!s.size) return hipSuccess;
   const uint32_t free_spot_count = s.size - surfel_count;
   hipLaunchKernelGGL(compact_flag_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, invalid);
-  scan_u32_exclusive(st, temp, temp_bytes, invalid, free_rank, (int)s.size);
+  const hipError_t scan = scan_u32_exclusive(st, temp, temp_bytes, invalid, free_rank, (int)s.size);
+  if (scan != hipSuccess) return scan;   // nothing has been moved yet
   hipLaunchKernelGGL(compact_free_list_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, invalid, free_rank, free_spot_count, free_list);
   hipLaunchKernelGGL(compact_move_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, invalid, free_rank, free_list,
                      free_spot_count, surfel_count);
+  return hipGetLastError();
 }
 
 // ---- spatial order of the surfel buffer ---------------------------------------------------------------------------------

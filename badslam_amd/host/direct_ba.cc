@@ -216,7 +216,7 @@ void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surf
   BAHIP_CHECKED_CALL(bahip_create_surfels_for_keyframe(ctx_, id_to_bound_[keyframe->id()], filter_new_surfels ? 1 : 0,
                                                        GetMinObservationCount(), covis.data(), (int)covis.size(), &s, sup,
                                                        (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(), &new_surfel_count));
-  if (new_surfel_count == 0 && bahip_last_error()[0] == 'M') LOG(ERROR) << bahip_last_error();
+  if (bahip_context_take_capacity_exceeded(ctx_)) LOG(ERROR) << "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";
   Lock();
   surfels_size_ += new_surfel_count;
   surfel_count_ += new_surfel_count;
@@ -494,7 +494,9 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       float out_a = depth_params_.a;
       const bahip_surfels s = SurfelsStruct();
       BAHIP_CHECKED_CALL(bahip_optimize_intrinsics(ctx_, optimize_depth_intrinsics, optimize_color_intrinsics, &s, &out_color, &out_depth, &out_a));
-      if (surfels_size_ > 0) {
+      // under surfel sharding every rank takes the globally solved cameras, also one whose own shard is empty (else the ranks
+      // would bind different intrinsics from here on and disagree on convergence tests, i.e. on the number of collectives)
+      if (surfels_size_ > 0 || bahip_context_is_sharded(ctx_)) {
         Lock();
         if (optimize_color_intrinsics) color_camera_ = PinholeCamera4f(out_color.width, out_color.height, &out_color.fx);
         if (optimize_depth_intrinsics) {

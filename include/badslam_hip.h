@@ -103,6 +103,8 @@ int bahip_context_synchronize(bahip_context* ctx);
  * order the reduction after them and before later work on that stream (e.g. torch.cuda.ExternalStream(stream) around
  * dist.all_reduce).  dtype: BAHIP_SUM_F32 (count floats) or BAHIP_SUM_I64 (count int64_t: the pose normal equations are
  * summed in fixed point, which makes a sharded run bit-identical to the unsharded one).  NULL (default) = single GPU. */
+/* 1 if sums go over several ranks (a hook or an RCCL communicator is installed), else 0. */
+int bahip_context_is_sharded(bahip_context* ctx);
 enum { BAHIP_SUM_F32 = 0, BAHIP_SUM_I64 = 1 };
 typedef int (*bahip_allreduce_fn)(void* device_buffer, size_t count, int dtype, void* hip_stream, void* user);
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user);
@@ -266,6 +268,9 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
                                       int min_observation_count, const int* covis, int n_covis,
                                       const bahip_surfels* surfels, uint32_t* const* supporting,
                                       uint32_t supporting_pitch_bytes, uint32_t* new_surfel_count_out);
+/* 1 if the last bahip_create_surfels_for_keyframe on this context created nothing because the surfels would not have fit
+ * into `capacity` (the reference's soft failure, B/kernel_create_surfels.cc:162-165); reading clears the flag. */
+int bahip_context_take_capacity_exceeded(bahip_context* ctx);
 /* B/kernels.h DeleteSurfelsAndUpdateRadiiCUDA (B/kernel_delete_surfels.cc:40-120); synchronises. */
 int bahip_delete_surfels_and_update_radii(bahip_context* ctx, int min_observation_count,
                                           const bahip_surfels* surfels, uint32_t* deleted_count_out);
