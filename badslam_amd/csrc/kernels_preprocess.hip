@@ -252,6 +252,9 @@ void launch_pack_planes(hipStream_t stream, const KfEntry& frame, int width, int
   const uint32_t gtpr = plane_tiles_x(width), gwords = gtpr * plane_tiles_y(height) * 32;
   hipLaunchKernelGGL(pack_geom_kernel, dim3((gwords + 255) / 256), dim3(256), 0, stream, frame.depth, frame.depth_pitch, frame.normals,
                      frame.normals_pitch, width, height, gtpr, gwords, geom);
+  // a frame handed over without a colour image (the supporting-surfel entry point of B/kernels.h:94-119 gets depth and
+  // normals only) has no luma plane to pack; the calls that take such a frame never sample colour
+  if (frame.color == nullptr) return;
   const uint32_t ftpr = plane_tiles_x(cwidth + 2), fwords = ftpr * plane_tiles_y(cheight + 2) * 32;
   hipLaunchKernelGGL(pack_luma_footprint_kernel, dim3((fwords + 255) / 256), dim3(256), 0, stream, frame.color, frame.color_pitch,
                      cwidth, cheight, ftpr, fwords, lumafp);
