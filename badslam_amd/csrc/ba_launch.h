@@ -59,12 +59,13 @@ void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEnt
                            const uint32_t* indices, int count, float* out);
 
 // kernels_intrinsics.hip
+// cells: S records of 8 floats {B0..B4, D, b2, observation count} (kernels_intrinsics.hip)
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, float* glob, float* B, float* D, float* b2, float* obs, int S);
+                                  const SurfelsView& s, float* glob, float* cells);
 size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_schur needs
-void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* B, float* D, const float* b2, float* partials);
-void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, const float* obs, const float* B, const float* D,
-                                   const float* x1, float* cfactor, uint32_t cfactor_pitch);
+void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* cells, float* partials);
+void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, float* cells, const float* x1, float* cfactor,
+                                   uint32_t cfactor_pitch);
 
 // kernels_pcg.hip
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,

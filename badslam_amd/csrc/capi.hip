@@ -107,7 +107,7 @@ struct bahip_context {
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
 
-  float* intr_scratch = nullptr;   // intrinsics step: 64 + 8*S floats (glob | B | D | b2 | obs)
+  float* intr_scratch = nullptr;   // intrinsics step: 64 + 8*S floats (glob | S cell records of 8)
   int intr_capacity = 0;
 
   float* pcg_buf = nullptr;        // PCG vectors r, M, delta, g, p (5 * pcg_capacity floats) + 16 scalars
@@ -1125,18 +1125,15 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
     ctx->intr_capacity = cap;
   }
   float* glob = ctx->intr_scratch;            // 34 sums + x1 at [40..44]
-  float* B = glob + 64;                       // 5 * S
-  float* D = B + 5 * (size_t)S;
-  float* b2 = D + S;
-  float* obs = b2 + S;                        // observation counts as floats (exact under a float SUM all-reduce)
+  float* cells = glob + 64;                   // S records {B0..B4, D, b2, observation count (a float: exact under a float SUM)}
   timer_begin(ctx, 4, true);
   HIP_TRY(hipMemsetAsync(glob, 0, sizeof(float) * (64 + 8 * (size_t)S), ctx->stream));
   launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
-                               make_view(surfels), glob, B, D, b2, obs, S);
+                               make_view(surfels), glob, cells);
   CHECK_LAUNCH();
   if (reduce_over_ranks(ctx, glob, 64 + 8 * (size_t)S, BAHIP_SUM_F32)) return 1;
   if (optimize_depth) {
-    launch_intrinsics_schur(ctx->stream, S, glob, B, D, b2, obs + ctx->intr_capacity /* past the all-reduced block */);
+    launch_intrinsics_schur(ctx->stream, S, glob, cells, cells + 8 * (size_t)ctx->intr_capacity /* past the all-reduced block */);
     CHECK_LAUNCH();
   }
   timer_end(ctx, 4);   // the sweep and the Schur complement; the 5x5 / 4x4 solves and the cfactor update that follow are tiny
@@ -1165,7 +1162,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
     *out_a = ctx->dp.a - x1[4];
     memcpy(ctx->pinned_f + 40, x1, sizeof(x1));
     HIP_TRY(hipMemcpyAsync(glob + 40, ctx->pinned_f + 40, sizeof(x1), hipMemcpyHostToDevice, ctx->stream));
-    launch_intrinsics_solve_cells(ctx->stream, ctx->in, S, obs, B, D, glob + 40, ctx->dp.cfactor, ctx->dp.cfactor_pitch_bytes);
+    launch_intrinsics_solve_cells(ctx->stream, ctx->in, S, cells, glob + 40, ctx->dp.cfactor, ctx->dp.cfactor_pitch_bytes);
     CHECK_LAUNCH();
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
