@@ -173,9 +173,17 @@ struct SurfelsView {
   __device__ __forceinline__ float* row(int r) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(data) + (size_t)r * pitch); }
 };
 
+// A pointer read from a device table (KfEntry::geom, ...) is a generic pointer to the compiler, which then emits flat_load
+// (checked against the LDS / scratch apertures, counted on vmcnt AND lgkmcnt).  Every such pointer here is a hipMalloc
+// allocation: say so, and the gathers are global_load.
+template <typename T>
+__device__ __forceinline__ T load_global(const T* p) {
+  if constexpr (__is_scalar(T)) return *(const __attribute__((address_space(1))) T*)(p);
+  else return *p;   // class types (uchar4): no address-space-qualified copy constructor; not on a hot path
+}
 template <typename T>
 __device__ __forceinline__ T pitched_load(const T* base, uint32_t pitch, int y, int x) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T));
+  return load_global(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T)));
 }
 template <typename T>
 __device__ __forceinline__ T* pitched_ptr(T* base, uint32_t pitch, int y, int x) {
@@ -293,26 +301,56 @@ struct Assoc {
 // B/surfel_projection_nvcc_only.cuh:332-359 with IsAssociatedWithPixel :48-127; the order of the
 // rejection tests is the reference's.  A NaN position (deleted surfel) is rejected explicitly.
 // `gp`, `gn`: global position and (decoded, renormalised) global normal of the surfel.
+//
+// The test is written in three phases so that a sweep can put every gather of a (surfel, keyframe) pair in flight at once:
+//   project_surfel        arithmetic only: the position in the keyframe frame, the pixel, "projects into the image";
+//   load_pixel_words      the packed depth + normal word of that pixel and the cfactor of its cell, from CLAMPED coordinates
+//                         (always a valid address, so the loads are unconditional and sit in straight-line code; for a lane
+//                         that projects into the image the clamp is the identity);
+//   associate_from_words  the remaining tests on the loaded values.
+// A wavefront spends most of its time waiting for gathers (61 % of the wave-cycles of the geometry sweep, PMC SQ_WAIT_ANY,
+// profiles/r2_c_stall.txt): pixel word -> cfactor -> luma footprints used to be three dependent round trips per pair; issued
+// together they are one.  project_associate() is the three phases in sequence (every other caller).
+struct Projected {
+  Vec3 local;        // surfel position in the keyframe frame
+  float inv_z;       // 1 / local.z (IEEE)
+  float pxx, pxy;    // float pixel position, pixel-corner convention
+  int px, py;
+  bool ok;           // z > 0 and the pixel lies in the image
+};
+__device__ __forceinline__ Projected project_surfel(const Intrinsics& in, const float* F, Vec3 gp) {
+  Projected p;
+  p.local.z = mad(F[10], gp.z, mad(F[9], gp.y, mad(F[8], gp.x, F[11])));
+  p.local.x = mad(F[2], gp.z, mad(F[1], gp.y, mad(F[0], gp.x, F[3])));
+  p.local.y = mad(F[6], gp.z, mad(F[5], gp.y, mad(F[4], gp.x, F[7])));
+  p.inv_z = rcp_exact(p.local.z);   // == 1.f / z; one reciprocal shared by both coordinates (and by the Jacobians), as in the oracle
+  p.pxx = mad(in.fx, p.local.x * p.inv_z, in.cx);
+  p.pxy = mad(in.fy, p.local.y * p.inv_z, in.cy);
+  p.px = (int)p.pxx;
+  p.py = (int)p.pxy;
+  p.ok = (p.local.z > 0.f) && (p.pxx >= 0.f) && (p.pxy >= 0.f) && (p.pxx < (float)in.width) && (p.pxy < (float)in.height) &&
+         p.px < in.width && p.py < in.height;
+  return p;
+}
+struct PixelWords {
+  uint32_t geom;     // measured depth (low half) and packed measured normal (high half)
+  float cfactor;
+};
+__device__ __forceinline__ PixelWords load_pixel_words(const Intrinsics& in, const uint32_t* __restrict__ geom, const Projected& p) {
+  const int cx = min(max(p.px, 0), in.width - 1), cy = min(max(p.py, 0), in.height - 1);
+  PixelWords w;
+  w.geom = load_global(geom + plane_index((uint32_t)cx, (uint32_t)cy, in.geom_tpr));
+  w.cfactor = cfactor_at(in, cx, cy);
+  return w;
+}
 template <bool kFreeSpace>
-__device__ __forceinline__ bool project_associate(const Intrinsics& in, const float* F, const uint32_t* __restrict__ geom,
-                                                  Vec3 gp, Vec3 gn, Assoc* r, bool* free_space_violation) {
-  r->local.z = mad(F[10], gp.z, mad(F[9], gp.y, mad(F[8], gp.x, F[11])));
-  if (!(r->local.z > 0.f)) return false;
-  r->local.x = mad(F[2], gp.z, mad(F[1], gp.y, mad(F[0], gp.x, F[3])));
-  r->local.y = mad(F[6], gp.z, mad(F[5], gp.y, mad(F[4], gp.x, F[7])));
-  const float inv_z = rcp_exact(r->local.z);   // == 1.f / z; one reciprocal shared by both coordinates (and by the Jacobians), as in the oracle
-  r->inv_z = inv_z;
-  r->pxx = mad(in.fx, r->local.x * inv_z, in.cx);
-  r->pxy = mad(in.fy, r->local.y * inv_z, in.cy);
-  if (!(r->pxx >= 0.f) || !(r->pxy >= 0.f) || !(r->pxx < (float)in.width) || !(r->pxy < (float)in.height)) return false;
-  r->px = (int)r->pxx;
-  r->py = (int)r->pxy;
-  if (r->px >= in.width || r->py >= in.height) return false;
-
-  const uint32_t word = geom[plane_index((uint32_t)r->px, (uint32_t)r->py, in.geom_tpr)];
-  const uint16_t measured = (uint16_t)(word & 0xffffu);
+__device__ __forceinline__ bool associate_from_words(const Intrinsics& in, const float* F, Vec3 gn, const Projected& p,
+                                                     const PixelWords& w, Assoc* r, bool* free_space_violation) {
+  if (!p.ok) return false;
+  r->local = p.local; r->inv_z = p.inv_z; r->pxx = p.pxx; r->pxy = p.pxy; r->px = p.px; r->py = p.py;
+  const uint16_t measured = (uint16_t)(w.geom & 0xffffu);
   if (measured & kInvalidDepthBit) return false;
-  r->depth = raw_to_calibrated_depth(in.a, cfactor_at(in, r->px, r->py), in.raw_to_float_depth, measured);
+  r->depth = raw_to_calibrated_depth(in.a, w.cfactor, in.raw_to_float_depth, measured);
   r->nl = rotate34(F, gn);
   const float thr = 10.f * depth_stddev(unp_nx(in, (float)r->px), unp_ny(in, (float)r->py), r->depth, r->nl, in.baseline_fx);
   if (kFreeSpace) {
@@ -324,17 +362,36 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   }
   // the reference tests (1 / |p|) * dot(p, n) > 0; |p| > 0 here, so the sign test needs no normalisation (oracle: same)
   if (dot3(r->local, r->nl) > 0) return false;
-  r->normal_bits = (uint16_t)(word >> 16);
+  r->normal_bits = (uint16_t)(w.geom >> 16);
   const Vec3 m = unpack_normal8(r->normal_bits);
   if (dot3(r->nl, m) < kCosNormalCompat) return false;
   return true;
+}
+template <bool kFreeSpace>
+__device__ __forceinline__ bool project_associate(const Intrinsics& in, const float* F, const uint32_t* __restrict__ geom,
+                                                  Vec3 gp, Vec3 gn, Assoc* r, bool* free_space_violation) {
+  const Projected p = project_surfel(in, F, gp);
+  if (!p.ok) return false;
+  const PixelWords w = load_pixel_words(in, geom, p);
+  return associate_from_words<kFreeSpace>(in, F, gn, p, w, r, free_space_violation);
 }
 
 // ---- colour sampling -------------------------------------------------------------------------------
 // 2x2 luma footprint with top-left texel (ix, iy), ix in [-1, w], iy in [-1, h] (clamp addressing baked in).
 struct Luma4 { float tl, tr, bl, br; };
+__device__ __forceinline__ uint32_t luma_footprint_word(const Intrinsics& in, const uint32_t* __restrict__ lumafp, int ix, int iy) {
+  return load_global(lumafp + plane_index((uint32_t)(ix + 1), (uint32_t)(iy + 1), in.fp_tpr));
+}
+__device__ __forceinline__ Luma4 unpack_luma_footprint(uint32_t word) {
+  Luma4 t;
+  t.tl = (float)(word & 0xffu) * (1.0f / 255.0f);
+  t.tr = (float)((word >> 8) & 0xffu) * (1.0f / 255.0f);
+  t.bl = (float)((word >> 16) & 0xffu) * (1.0f / 255.0f);
+  t.br = (float)(word >> 24) * (1.0f / 255.0f);
+  return t;
+}
 __device__ __forceinline__ Luma4 luma_footprint(const Intrinsics& in, const uint32_t* __restrict__ lumafp, int ix, int iy) {
-  const uint32_t word = lumafp[plane_index((uint32_t)(ix + 1), (uint32_t)(iy + 1), in.fp_tpr)];
+  const uint32_t word = luma_footprint_word(in, lumafp, ix, iy);
   Luma4 t;
   t.tl = (float)(word & 0xffu) * (1.0f / 255.0f);
   t.tr = (float)((word >> 8) & 0xffu) * (1.0f / 255.0f);
@@ -407,12 +464,18 @@ __device__ __forceinline__ bool luma_sample_is_interior(int w, int h, float x, f
   const float xb = x - 0.5f, yb = y - 0.5f;
   return xb >= 0.f && xb < (float)w && yb >= 0.f && yb < (float)h;
 }
-__device__ __forceinline__ void sample_luma_and_gradient_interior(const Intrinsics& in, const uint32_t* lumafp, float x, float y,
-                                                                  float* value, float* dx, float* dy) {
+// The footprint word of the sample at (x, y), from coordinates clamped into the plane: the word the interior sampler uses
+// when the point is interior, some valid word otherwise (the caller then does not use it).  NaN coordinates clamp too.
+__device__ __forceinline__ uint32_t luma_word_clamped(const Intrinsics& in, const uint32_t* __restrict__ lumafp, float x, float y) {
+  const float fx = fminf(fmaxf(floorf(x - 0.5f), -1.f), (float)in.cwidth);
+  const float fy = fminf(fmaxf(floorf(y - 0.5f), -1.f), (float)in.cheight);
+  return luma_footprint_word(in, lumafp, (int)fx, (int)fy);
+}
+__device__ __forceinline__ void sample_luma_and_gradient_interior(uint32_t word, float x, float y, float* value, float* dx, float* dy) {
   const float xb = x - 0.5f, yb = y - 0.5f;
   const float fx = floorf(xb), fy = floorf(yb);
   const float a = xb - fx, b = yb - fy;
-  const Luma4 t = luma_footprint(in, lumafp, (int)fx, (int)fy);
+  const Luma4 t = unpack_luma_footprint(word);
   {
     const float qa = bilinear_weight(a), qb = bilinear_weight(b);
     const float top = mad(qa, t.tr - t.tl, t.tl);
@@ -473,9 +536,9 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
   if (kWithGradient) {
     float i0, i1, i2, cdx, cdy, adx, ady, bdx, bdy;
     if (luma_sample_is_interior(w, h, cx, cy) && luma_sample_is_interior(w, h, t1x, t1y) && luma_sample_is_interior(w, h, t2x, t2y)) {
-      sample_luma_and_gradient_interior(in, lumafp, cx, cy, &i0, &cdx, &cdy);
-      sample_luma_and_gradient_interior(in, lumafp, t1x, t1y, &i1, &adx, &ady);
-      sample_luma_and_gradient_interior(in, lumafp, t2x, t2y, &i2, &bdx, &bdy);
+      sample_luma_and_gradient_interior(luma_word_clamped(in, lumafp, cx, cy), cx, cy, &i0, &cdx, &cdy);
+      sample_luma_and_gradient_interior(luma_word_clamped(in, lumafp, t1x, t1y), t1x, t1y, &i1, &adx, &ady);
+      sample_luma_and_gradient_interior(luma_word_clamped(in, lumafp, t2x, t2y), t2x, t2y, &i2, &bdx, &bdy);
     } else {
       sample_luma_and_gradient(in, lumafp, w, h, cx, cy, &i0, &cdx, &cdy);
       sample_luma_and_gradient(in, lumafp, w, h, t1x, t1y, &i1, &adx, &ady);
@@ -494,6 +557,48 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
     e->r1 = mad(180.f, i1 - i0, -d1);
     e->r2 = mad(180.f, i2 - i0, -d2);
   }
+}
+// Split-phase form for the sweeps (see project_surfel): load_descriptor_words() needs only the projection, so its three
+// gathers are in flight together with the pixel word; eval_descriptor_from_words() is eval_descriptor<true> on the loaded
+// words (samples near the image border take the general sampler, which loads its footprints itself).
+struct DescWords {
+  float cx, cy, t1x, t1y, t2x, t2y;
+  uint32_t w0, w1, w2;
+  bool color_ok;     // depth_to_color_pixel succeeded (B/kernel_opt_pose.cu:303-353: nothing is added otherwise)
+  bool interior;     // all three footprints lie inside the image
+};
+__device__ __forceinline__ DescWords load_descriptor_words(const Intrinsics& in, const uint32_t* __restrict__ lumafp, const float* F,
+                                                           const TangentPoints& tp, const Projected& p) {
+  DescWords d;
+  d.color_ok = depth_to_color_pixel(in, p.pxx, p.pxy, &d.cx, &d.cy);
+  project_tangents(in, F, tp, &d.t1x, &d.t1y, &d.t2x, &d.t2y);
+  const int w = in.cwidth, h = in.cheight;
+  d.interior = luma_sample_is_interior(w, h, d.cx, d.cy) && luma_sample_is_interior(w, h, d.t1x, d.t1y) &&
+               luma_sample_is_interior(w, h, d.t2x, d.t2y);
+  d.w0 = luma_word_clamped(in, lumafp, d.cx, d.cy);
+  d.w1 = luma_word_clamped(in, lumafp, d.t1x, d.t1y);
+  d.w2 = luma_word_clamped(in, lumafp, d.t2x, d.t2y);
+  return d;
+}
+__device__ __forceinline__ void eval_descriptor_from_words(const Intrinsics& in, const uint32_t* lumafp, const DescWords& d, float d1,
+                                                           float d2, DescEval* e) {
+  const int w = in.cwidth, h = in.cheight;
+  float i0, i1, i2, cdx, cdy, adx, ady, bdx, bdy;
+  if (d.interior) {
+    sample_luma_and_gradient_interior(d.w0, d.cx, d.cy, &i0, &cdx, &cdy);
+    sample_luma_and_gradient_interior(d.w1, d.t1x, d.t1y, &i1, &adx, &ady);
+    sample_luma_and_gradient_interior(d.w2, d.t2x, d.t2y, &i2, &bdx, &bdy);
+  } else {
+    sample_luma_and_gradient(in, lumafp, w, h, d.cx, d.cy, &i0, &cdx, &cdy);
+    sample_luma_and_gradient(in, lumafp, w, h, d.t1x, d.t1y, &i1, &adx, &ady);
+    sample_luma_and_gradient(in, lumafp, w, h, d.t2x, d.t2y, &i2, &bdx, &bdy);
+  }
+  e->r1 = mad(180.f, i1 - i0, -d1);
+  e->r2 = mad(180.f, i2 - i0, -d2);
+  e->gx1 = 180.f * (adx - cdx);
+  e->gy1 = 180.f * (ady - cdy);
+  e->gx2 = 180.f * (bdx - cdx);
+  e->gy2 = 180.f * (bdy - cdy);
 }
 template <bool kWithGradient>
 __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint32_t* lumafp, const float* F,

@@ -67,6 +67,9 @@ void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* cells, f
 void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, float* cells, const float* x1, float* cfactor,
                                    uint32_t cfactor_pitch);
 
+#ifdef BAHIP_COUNT_CANDIDATES
+void pose_counters_dump();   // experiment build only (kernels_pose.hip)
+#endif
 // kernels_pcg.hip
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                      float* r, float* M);

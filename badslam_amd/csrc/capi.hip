@@ -492,6 +492,9 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
 void bahip_context_destroy(bahip_context* ctx) {
   if (!ctx) return;
   hipStreamSynchronize(ctx->stream);
+#ifdef BAHIP_COUNT_CANDIDATES
+  bahip::pose_counters_dump();
+#endif
   if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->dev_kfs); hipFree(ctx->dev_work); hipFree(ctx->dev_Hb);
   hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1);

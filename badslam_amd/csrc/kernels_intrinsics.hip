@@ -52,7 +52,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
   for (int q = 0; q < 34; ++q) acc[q] = 0.f;
 
   for_each_candidate(
-      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         const float* F = kfs[k].pose.F;
         Assoc r;

@@ -127,7 +127,7 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
   for (int q = 0; q < 9; ++q) { ir[q] = 0.f; iM[q] = 0.f; }
 
   for_each_candidate(
-      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         const KfEntry& kf = kfs[k];
         Assoc a;
@@ -306,7 +306,7 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
   float ad = 0.f;
 
   for_each_candidate(
-      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         const KfEntry& kf = kfs[k];
         Assoc a;

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "ba_device.h"
+#include <cstdio>
 #include "ba_launch.h"
 #include "se3_device.h"
 #include "wave_cull.h"
@@ -47,6 +48,15 @@ __device__ __forceinline__ void accumulate_jtj(float (&acc)[28], const float (&J
 // converged, yet launch one wavefront (or several) per tile all the same -- read the sphere back (one scalar load), test it
 // against the remaining work items and return at once if none can see the tile, before any surfel is loaded.  Positions do
 // not change between the rounds of a phase, so the stored sphere is the one that would be recomputed.
+#ifdef BAHIP_COUNT_CANDIDATES
+// experiment build only: (surfel tile, keyframe) candidates the cull lets through / with at least one associated lane / lanes
+__device__ unsigned long long g_candidate_counters[4];
+void pose_counters_dump() {
+  unsigned long long c[4];
+  if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_candidate_counters), sizeof(c)) == hipSuccess)
+    fprintf(stderr, "candidates %llu  with-any-association %llu  associated lanes %llu\n", c[0], c[1], c[2]);
+}
+#endif
 template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
 pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
@@ -83,14 +93,57 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     wb = wave_bounds(gp, in_range && (gp.x == gp.x));
     if (blockIdx.y == 0 && lane == 0) tile_bounds[tile] = wb;
   }
+  // The 27 atomics of a candidate are issued one candidate late, behind the next candidate's gathers: vmcnt counts loads,
+  // stores and atomics alike and retires them in order, so a wavefront that issues its atomics and then the next gathers
+  // cannot use the gathered words before the atomics have been acknowledged by the memory side - two round trips per
+  // candidate.  Held back (one VGPR: every lane holds the tile total of one slot), the acknowledgement has a whole
+  // candidate's arithmetic to arrive in.
+  float pending = 0.f;
+  int pending_w = -1;   // wave-uniform
+  auto flush_pending = [&]() {
+    if (pending_w >= 0 && slot >= 0 && slot < 27) {
+      // as an asm statement: the compiler's waitcnt pass otherwise waits for the (non-returning) atomic at the top of the
+      // next candidate.  Not tracking it is safe: vmcnt retires in order, so an untracked older operation can only make a
+      // later s_waitcnt vmcnt(N) wait for more than the compiler intended, never for less.
+      HbFixed* target = &Hb[(size_t)pending_w * kHbStride + slot];
+      const HbFixed value = hb_to_fixed(pending);
+      asm volatile("global_atomic_add_x2 %0, %1, off" ::"v"(target), "v"(value) : "memory");
+    }
+    pending_w = -1;
+  };
   for_each_candidate(
       num_work,
-      [&](int w) { return !work[w].done && sphere_may_project(in, work[w].F, wb); },
+      [&](int w) {
+        float f[12];
+        int32_t done;
+        load_candidate(work[w].F, &work[w].done, f, &done);
+        return !done && sphere_may_project(in, f, wb);
+      },
       [&](int w) {
     const float* F = work[w].F;
     const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
+    // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
+    const Projected p = project_surfel(in, F, gp);
+    const PixelWords pix = load_pixel_words(in, kf.geom, p);
+    DescWords dw;
+    if (kUseDesc) dw = load_descriptor_words(in, kf.lumafp, F, tp, p);
     Assoc r;
-    const bool visible = in_range && project_associate<false>(in, F, kf.geom, gp, gn, &r, nullptr);
+    const bool visible = in_range && associate_from_words<false>(in, F, gn, p, pix, &r, nullptr);
+    // every gather has arrived from here on, on every path (a load still pending at the loop's back edge would make the
+    // compiler wait for it - and, vmcnt being in-order, for the atomics behind it - at the top of the next candidate)
+    asm volatile("" ::"v"(pix.geom), "v"(pix.cfactor));
+    if (kUseDesc) asm volatile("" ::"v"(dw.w0), "v"(dw.w1), "v"(dw.w2));
+    flush_pending();
+#ifdef BAHIP_COUNT_CANDIDATES
+    {
+      const unsigned long long associated_lanes = __ballot(visible);
+      if (!stored_bounds && lane == 0) {
+        atomicAdd(&g_candidate_counters[0], 1ull);
+        atomicAdd(&g_candidate_counters[1], associated_lanes ? 1ull : 0ull);
+        atomicAdd(&g_candidate_counters[2], (unsigned long long)__popcll(associated_lanes));
+      }
+    }
+#endif
     if (!__any(visible)) return;
 
     float acc[28];   // 21 H + 6 b + 1 pad (kHbStride)
@@ -109,11 +162,10 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
         accumulate_jtj(acc, J, wgt, raw);
       }
       if (kUseDesc) {
-        float cx, cy;
         // B/kernel_opt_pose.cu:303-353: nothing is added when the colour-pixel transform fails.
-        if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
+        if (dw.color_ok) {
           DescEval e;
-          eval_descriptor<true>(in, kf.lumafp, F, tp, cx, cy, d1, d2, &e);
+          eval_descriptor_from_words(in, kf.lumafp, dw, d1, d2, &e);
           // B/kernel_opt_pose.cu:96-142
           const Vec3 ls = r.local;
 #pragma unroll
@@ -131,10 +183,10 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
 
     // wave64 halving reduction (wave_reduce.h: a fixed tree over the 64 lanes), then one 64-bit integer atomic per scalar
     // per wave on the fixed-point value: order-free, hence deterministic
-    const float mine = wave_reduce28(acc, lane);
-    if (slot >= 0 && slot < 27)
-      atomicAdd(reinterpret_cast<unsigned long long*>(&Hb[(size_t)w * kHbStride + slot]), (unsigned long long)hb_to_fixed(mine));
+    pending = wave_reduce28(acc, lane);
+    pending_w = w;
   }, gridDim.y, blockIdx.y);
+  flush_pending();
 }
 
 // B/convergence_analysis.h:43-51

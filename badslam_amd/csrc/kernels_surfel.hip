@@ -137,7 +137,7 @@ assign_colors_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs
   const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
   float count = 0.f, sum[4] = {0.f, 0.f, 0.f, 0.f};
   for_each_candidate(
-      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         if (!in_range) return;
         Assoc r;
@@ -179,11 +179,17 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
   tile_sums<kWaves>(sum, lds, [&](float (&acc)[kCount], int cls) {
     for_each_candidate(
         num_kfs,
-        [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); },
         [&](int k) {
-          if (!live) return;
+          float f[12];
+          int32_t activation;
+          load_candidate(kfs[k].pose.F, &kfs[k].activation, f, &activation);
+          return activation != BAHIP_KF_INACTIVE && sphere_may_project(in, f, wb);
+        },
+        [&](int k) {
+          const Projected p = project_surfel(in, kfs[k].pose.F, gp);
+          const PixelWords pix = load_pixel_words(in, kfs[k].geom, p);   // both gathers in flight at once (ba_device.h)
           Assoc r;
-          if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) {
+          if (live && associate_from_words<false>(in, kfs[k].pose.F, gn, p, pix, &r, nullptr)) {
             const Vec3 g = mul33(kfs[k].pose.GR, unpack_normal8(r.normal_bits));
             acc[0] += g.x; acc[1] += g.y; acc[2] += g.z; acc[3] += 1.f;
             if (kActivate) acc[kCount - 1] += (kfs[k].activation == BAHIP_KF_ACTIVE) ? 1.f : 0.f;
@@ -252,15 +258,21 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   }
   normals_pass<kWaves, kActivate>(in, kfs, num_kfs, wb, s, ii, &live, decide, gp, &gn, lds);
 
-  auto cand = [&](int k) { return kfs[k].activation != BAHIP_KF_INACTIVE && sphere_may_project(in, kfs[k].pose.F, wb); };
+  auto cand = [&](int k) {
+    float f[12];
+    int32_t activation;
+    load_candidate(kfs[k].pose.F, &kfs[k].activation, f, &activation);
+    return activation != BAHIP_KF_INACTIVE && sphere_may_project(in, f, wb);
+  };
 
   if (!kUseDesc) {
     float hb[2];
     tile_sums<kWaves>(hb, lds, [&](float (&acc)[2], int cls) {
       for_each_candidate(num_kfs, cand, [&](int k) {
-        if (!live) return;
+        const Projected p = project_surfel(in, kfs[k].pose.F, gp);
+        const PixelWords pix = load_pixel_words(in, kfs[k].geom, p);
         Assoc r;
-        if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) return;
+        if (!live || !associate_from_words<false>(in, kfs[k].pose.F, gn, p, pix, &r, nullptr)) return;
         const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
         const float jac = -inv_std;
         const Vec3 u = unproject(in, r.px, r.py, r.depth);
@@ -291,10 +303,13 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   tile_sums<kWaves>(tot, lds, [&](float (&acc)[8], int cls) {
     float &a0 = acc[0], &a1 = acc[1], &a2 = acc[2], &a3 = acc[3], &a5 = acc[4], &a6 = acc[5], &a7 = acc[6], &a8 = acc[7];
     for_each_candidate(num_kfs, cand, [&](int k) {
-      if (!live) return;
       const float* F = kfs[k].pose.F;
+      // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
+      const Projected p = project_surfel(in, F, gp);
+      const PixelWords pix = load_pixel_words(in, kfs[k].geom, p);
+      const DescWords dw = load_descriptor_words(in, kfs[k].lumafp, F, tp, p);
       Assoc r;
-      if (!project_associate<false>(in, F, kfs[k].geom, gp, gn, &r, nullptr)) return;
+      if (!live || !associate_from_words<false>(in, F, gn, p, pix, &r, nullptr)) return;
       if (kUseDepth) {
         const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
         const float jac = -inv_std;
@@ -304,10 +319,9 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
         a0 = mad(w * jac, jac, a0);
         a6 = mad(w * raw, jac, a6);
       }
-      float cx, cy;
-      if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
+      if (dw.color_ok) {
         DescEval e;
-        eval_descriptor<true>(in, kfs[k].lumafp, F, tp, cx, cy, d1, d2, &e);
+        eval_descriptor_from_words(in, kfs[k].lumafp, dw, d1, d2, &e);
         const float jp1 = jac_descriptor_surfel(r.nl, r.local, r.inv_z, e.gx1, e.gy1, in.cfx, in.cfy);
         const float jp2 = jac_descriptor_surfel(r.nl, r.local, r.inv_z, e.gx2, e.gy2, in.cfx, in.cfy);
         const float jd = -1.f;
@@ -430,7 +444,7 @@ count_pairs_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, 
   const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
   unsigned long long cand = 0, wave_hits = 0, lane_hits = 0, in_image = 0;
   for_each_candidate(
-      num_kfs, [&](int k) { return sphere_may_project(in, kfs[k].pose.F, wb); },
+      num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         Assoc r;
         const bool hit = in_range && project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr);

@@ -86,6 +86,25 @@ __device__ __forceinline__ bool sphere_may_project(const Intrinsics& in, const f
   return true;
 }
 
+// The lane's own candidate item for the test above: the 12 coefficients of F and (optionally) a flag word of the same record,
+// all loads in flight at once and ALL ARRIVED on return.  (With the loads left to the short-circuit tests, a lane that
+// fails an early test leaves later loads pending; the compiler then has to put an s_waitcnt vmcnt(0) at the top of the
+// candidate loop that follows, where it is executed per candidate and also waits for the previous candidate's atomics.)
+__device__ __forceinline__ void load_candidate(const float* __restrict__ F, const int32_t* __restrict__ flag_ptr, float (&f)[12], int32_t* flag) {
+#pragma unroll
+  for (int c = 0; c < 12; ++c) f[c] = load_global(F + c);
+  int32_t v = 0;
+  if (flag_ptr) v = load_global(flag_ptr);
+  asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]), "v"(f[8]), "v"(f[9]),
+               "v"(f[10]), "v"(f[11]), "v"(v));
+  if (flag) *flag = v;
+}
+__device__ __forceinline__ bool sphere_may_project_item(const Intrinsics& in, const float* __restrict__ F, const WaveBounds& b) {
+  float f[12];
+  load_candidate(F, nullptr, f, nullptr);
+  return sphere_may_project(in, f, b);
+}
+
 // Calls body(k) (k wave-uniform, ascending) for every item k in [0, num_items) with k % parts == part whose
 // lane-level predicate pred(k) holds.  The candidate set lives in a 64-bit scalar mask (one item per lane).
 // parts > 1 splits the items of one surfel tile over several wavefronts: the per-keyframe pose sums are merged
