@@ -600,6 +600,14 @@ __device__ __forceinline__ void eval_descriptor_from_words(const Intrinsics& in,
   e->gx2 = 180.f * (bdx - cdx);
   e->gy2 = 180.f * (bdy - cdy);
 }
+// "Every gather of this pair has arrived", placed after the association tests of a sweep.  An empty asm statement that reads
+// the loaded words on every path: it keeps the compiler from sinking a gather into the branch that uses it (which would put
+// the round trips back in series), and no load is pending at the loop's back edge (a pending one costs an s_waitcnt vmcnt(0)
+// at the top of every following candidate).
+__device__ __forceinline__ void gathers_arrived(const PixelWords& pix) { asm volatile("" ::"v"(pix.geom), "v"(pix.cfactor)); }
+__device__ __forceinline__ void gathers_arrived(const PixelWords& pix, const DescWords& d) {
+  asm volatile("" ::"v"(pix.geom), "v"(pix.cfactor), "v"(d.w0), "v"(d.w1), "v"(d.w2));
+}
 template <bool kWithGradient>
 __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint32_t* lumafp, const float* F,
                                                 Vec3 gp, Vec3 gn, float radius_sq, float cx, float cy, float d1, float d2,

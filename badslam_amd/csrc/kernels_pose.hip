@@ -126,13 +126,13 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     const Projected p = project_surfel(in, F, gp);
     const PixelWords pix = load_pixel_words(in, kf.geom, p);
     DescWords dw;
-    if (kUseDesc) dw = load_descriptor_words(in, kf.lumafp, F, tp, p);
+    if (kUseDesc) dw = load_descriptor_words(in, kf.lumafp, F, tp, p);   // (issued after the association instead: pose sweep +7 %)
     Assoc r;
     const bool visible = in_range && associate_from_words<false>(in, F, gn, p, pix, &r, nullptr);
     // every gather has arrived from here on, on every path (a load still pending at the loop's back edge would make the
     // compiler wait for it - and, vmcnt being in-order, for the atomics behind it - at the top of the next candidate)
-    asm volatile("" ::"v"(pix.geom), "v"(pix.cfactor));
-    if (kUseDesc) asm volatile("" ::"v"(dw.w0), "v"(dw.w1), "v"(dw.w2));
+    if (kUseDesc) gathers_arrived(pix, dw);
+    else gathers_arrived(pix);
     flush_pending();
 #ifdef BAHIP_COUNT_CANDIDATES
     {

@@ -21,6 +21,21 @@ __global__ void __launch_bounds__(64) fma_kernel(float* out, float a, float b) {
   }
   out[blockIdx.x * 64 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
+// one dependent chain: every instruction needs the previous result
+template <int kIters>
+__global__ void __launch_bounds__(64) dep_fma_kernel(float* out, float a, float b) {
+  float x0 = threadIdx.x;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                   "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                   : "+v"(x0) : "v"(a), "v"(b));
+    }
+  }
+  out[blockIdx.x * 64 + threadIdx.x] = x0;
+}
 template <int kIters>
 __global__ void __launch_bounds__(64) pk_fma_kernel(float* out, float a, float b) {
   float2v x0 = {(float)threadIdx.x, 1.f}, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f, x4 = x0 + 4.f, x5 = x0 + 5.f, x6 = x0 + 6.f, x7 = x0 + 7.f;
@@ -49,13 +64,14 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   printf("%s: %d CUs, %.0f MHz\n", p.gcnArchName, cus, clock_hz / 1e6);
-  for (int packed = 0; packed < 2; ++packed)
-    for (int waves_per_simd = 1; waves_per_simd <= 8; waves_per_simd *= 2) {
+  for (int packed = 0; packed < 3; ++packed)
+    for (int waves_per_simd = 1; waves_per_simd <= 8; waves_per_simd = (waves_per_simd < 4 ? waves_per_simd + 1 : waves_per_simd * 2)) {
       const int blocks = cus * 4 * waves_per_simd;
       float ms = 0, best = 1e30f;
       for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        if (packed) hipLaunchKernelGGL(pk_fma_kernel<kIters>, dim3(blocks), dim3(64), 0, 0, out, 1.0001f, 0.5f);
+        if (packed == 2) hipLaunchKernelGGL(dep_fma_kernel<kIters>, dim3(blocks), dim3(64), 0, 0, out, 1.0001f, 0.5f);
+        else if (packed) hipLaunchKernelGGL(pk_fma_kernel<kIters>, dim3(blocks), dim3(64), 0, 0, out, 1.0001f, 0.5f);
         else hipLaunchKernelGGL(fma_kernel<kIters>, dim3(blocks), dim3(64), 0, 0, out, 1.0001f, 0.5f);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
@@ -64,8 +80,8 @@ int main() {
       }
       const double instr_per_simd = (double)kIters * 64 * waves_per_simd;
       const double cycles = best * 1e-3 * clock_hz;
-      printf("%-13s %d waves/SIMD: %.3f ms, %.2f cycles per wave64 instruction per SIMD, %.1f TFLOP/s\n", packed ? "v_pk_fma_f32" : "v_fma_f32",
-             waves_per_simd, best, cycles / instr_per_simd, instr_per_simd * cus * 4 * 64 * (packed ? 4 : 2) / (best * 1e-3) / 1e12);
+      printf("%-13s %d waves/SIMD: %.3f ms, %.2f cycles per wave64 instruction per SIMD, %.1f TFLOP/s\n", packed == 2 ? "dependent fma" : packed ? "v_pk_fma_f32" : "v_fma_f32",
+             waves_per_simd, best, cycles / instr_per_simd, instr_per_simd * cus * 4 * 64 * (packed == 1 ? 4 : 2) / (best * 1e-3) / 1e12);
     }
   return 0;
 }
