@@ -361,18 +361,23 @@ __global__ void window_activation_kernel(KfEntry* __restrict__ frames, int num_k
   if (k < num_kfs) frames[k].activation = in_window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
 }
 
-// Both steps in one workgroup (num_kfs <= 1024): one launch at the top of an iteration instead of two.
+// Both steps in one workgroup (num_kfs <= 1024): one launch at the top of an iteration instead of two.  The rows of the
+// co-visibility CSR are dealt to the 16 wavefronts, the entries of a row to the lanes (a thread per row walking its row
+// alone took 43 us at 200 keyframes: 200 dependent loads).
 __global__ void __launch_bounds__(1024) window_and_propagate_kernel(KfEntry* __restrict__ frames, int num_kfs,
                                                                     const uint8_t* __restrict__ in_window,
                                                                     const int* __restrict__ offsets, const int* __restrict__ indices) {
   const int k = threadIdx.x;
   if (k < num_kfs) frames[k].activation = in_window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
   __syncthreads();
-  if (k < num_kfs && in_window[k])
-    for (int j = offsets[k]; j < offsets[k + 1]; ++j) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int row = wave; row < num_kfs; row += 16) {
+    if (!in_window[row]) continue;   // wave-uniform
+    for (int j = offsets[row] + lane; j < offsets[row + 1]; j += 64) {
       const int other = indices[j];
       if (!in_window[other]) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
     }
+  }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -407,7 +412,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   const unsigned tiles = ((s.size + kPoseBlock - 1) / kPoseBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk);   // whole XCD chunks
   const int forced = g_forced_pose_parts;
   const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
-                         : tiles >= 32768 ? 2 : tiles >= 8192 ? 4 : 8;   // measured: 46.9 k tiles 2.01 / 1.79 / 1.80 ms with 1 / 2 / 4 parts
+                         : tiles >= 32768 ? 1 : tiles >= 8192 ? 4 : 8;   // measured (r2, full launch): 46.9 k tiles 1.03 / 1.08 / 1.30 ms with 1 / 2 / 4 parts
   const dim3 grid(tiles, parts), block(kPoseBlock);
   const PoseWork* pw = static_cast<const PoseWork*>(work);
   WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);

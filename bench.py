@@ -62,6 +62,7 @@ def parse_args():
     p.add_argument("--emulate-rank", type=int, default=0)
     p.add_argument("--shard-chunk", type=int, default=4096, help="surfels per chunk of the chunk-cyclic partition; 0 = contiguous")
     p.add_argument("--no-spatial-sort", action="store_true", help="leave the surfels in creation order")
+    p.add_argument("--launch-shapes", default="", help="experiment: 'tile_waves,pose_parts' forced through bahip_debug_set_launch_shapes (0 = heuristic)")
     p.add_argument("--build-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",
@@ -85,6 +86,10 @@ def build_scene(args, log):
     ext[:2] *= np.sqrt(args.keyframes / 200.0 * (args.width * args.height) / (640.0 * 480.0))
     cells = ((args.width - 1) // args.cell + 1) * ((args.height - 1) // args.cell + 1)
     cap = args.keyframes * cells + 1024   # worst case: no overlap between keyframes (288 GB of HBM: not a concern)
+    if args.launch_shapes:
+        from badslam_amd import capi
+        tile_waves, pose_parts = (int(v) for v in args.launch_shapes.split(","))
+        capi.load().bahip_debug_set_launch_shapes(tile_waves, pose_parts)
     ba = DirectBA(cap, 1.0 / 5000, 40.0, args.cell, args.width, args.height, cam, cam)
     poses_gt = []
     for k in range(args.keyframes):
