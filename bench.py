@@ -152,8 +152,9 @@ def pmc_kernel_entry(pmc, source, kernel_prefix):
             fetch = counters["FETCH_SIZE"]["avg_per_launch"] * 1024.0 * cal["factor"]
             write = counters.get("WRITE_SIZE", {"avg_per_launch": 0.0})["avg_per_launch"] * 1024.0
             out = {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "fetch_factor": cal["factor"], "source": source}
-            if "valu_issue_fraction" in counters:
-                out["valu_issue_fraction"] = counters["valu_issue_fraction"]
+            for key in ("valu_issue_fraction", "valu_cycles_per_instruction"):
+                if key in counters:
+                    out[key] = counters[key]
             return out
     return None
 
@@ -368,9 +369,11 @@ def main():
                                "traffic_fetch_factor": traffic["fetch_factor"] if traffic else None,
                                "algorithmic_bytes_per_launch": bytes_pose_launch, "avg_launch_ms": avg_ms, "launches": launches,
                                "keyframes_per_launch": kf_per_launch,
-                               "limiter": "VALU issue, not HBM: the sweep evaluates ~120 instructions of association per visited "
-                                          "(surfel tile, keyframe) candidate before any byte of Jacobian work (DESIGN.md section 5)",
-                               "valu_issue_fraction": traffic.get("valu_issue_fraction") if traffic else None}
+                               "limiter": "instruction issue, not HBM: ~700 VALU + ~150 scalar instructions per visited (surfel tile, "
+                                          "keyframe) candidate at 4 wavefronts per SIMD (125 VGPRs); measured ceiling 2.7 cycles per "
+                                          "VALU instruction per SIMD (scripts/microbench/valu_rate.hip), DESIGN.md section 5",
+                               "valu_issue_fraction": traffic.get("valu_issue_fraction") if traffic else None,
+                               "valu_cycles_per_instruction": traffic.get("valu_cycles_per_instruction") if traffic else None}
             # the other sweep of an iteration: activation + normals + position/descriptor step in one launch
             geo_ms = breakdown_ms[1] / BREAKDOWN_STEPS
             bytes_geo = N_rank * (17 + 21 + 49) + K * W * H * (4 + 5)

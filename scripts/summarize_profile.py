@@ -56,9 +56,12 @@ def main():
             kernels.setdefault(k, {}).update(cs)
     for k, cs in kernels.items():
         if "SQ_INSTS_VALU" in cs and "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"]["avg_per_launch"] > 0:
-            # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
+            # 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs.  Issue ceiling: scripts/microbench/valu_rate.hip measures
+            # 2.7 cycles per wave64 binary32 VALU instruction per SIMD with 4 resident wavefronts (independent or dependent
+            # v_fma_f32 alike; 2.54 with 8), i.e. the SIMD issues one every ~2.7 cycles at best -- not every 4 as r1 assumed.
             cycles = cs["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8.0
-            cs["valu_issue_fraction"] = cs["SQ_INSTS_VALU"]["avg_per_launch"] * 4.0 / (1024.0 * cycles)
+            cs["valu_cycles_per_instruction"] = 1024.0 * cycles / cs["SQ_INSTS_VALU"]["avg_per_launch"]
+            cs["valu_issue_fraction"] = 2.7 / cs["valu_cycles_per_instruction"]
 
     cal = None
     cal_counters = counters_of(d, "pmc_cal").get("read_pattern_kernel")
