@@ -183,7 +183,8 @@ __device__ __forceinline__ T load_global(const T* p) {
 }
 template <typename T>
 __device__ __forceinline__ T pitched_load(const T* base, uint32_t pitch, int y, int x) {
-  return load_global(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch + (size_t)x * sizeof(T)));
+  // 32-bit offset, 24-bit multiply (full rate; v_mul_lo_u32 is quarter rate): rows < 2^24, pitch < 2^24, images < 4 GiB
+  return load_global(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (__umul24((uint32_t)y, pitch) + (uint32_t)x * (uint32_t)sizeof(T))));
 }
 template <typename T>
 __device__ __forceinline__ T* pitched_ptr(T* base, uint32_t pitch, int y, int x) {
@@ -195,7 +196,7 @@ constexpr uint32_t kPlaneTileW = 8, kPlaneTileH = 4;
 __host__ __device__ __forceinline__ uint32_t plane_tiles_x(uint32_t width) { return (width + kPlaneTileW - 1) / kPlaneTileW; }
 __host__ __device__ __forceinline__ uint32_t plane_tiles_y(uint32_t height) { return (height + kPlaneTileH - 1) / kPlaneTileH; }
 __device__ __forceinline__ uint32_t plane_index(uint32_t x, uint32_t y, uint32_t tiles_per_row) {
-  return ((((y >> 2) * tiles_per_row) + (x >> 3)) << 5) | ((y & 3u) << 3) | (x & 7u);
+  return ((__umul24(y >> 2, tiles_per_row) + (x >> 3)) << 5) | ((y & 3u) << 3) | (x & 7u);   // 24-bit multiply: full rate
 }
 
 // ---- packing (B/util.cuh:121-153, B/util_nvcc_only.cuh:66-95) ------------------------------------
@@ -467,8 +468,9 @@ __device__ __forceinline__ bool luma_sample_is_interior(int w, int h, float x, f
 // The footprint word of the sample at (x, y), from coordinates clamped into the plane: the word the interior sampler uses
 // when the point is interior, some valid word otherwise (the caller then does not use it).  NaN coordinates clamp too.
 __device__ __forceinline__ uint32_t luma_word_clamped(const Intrinsics& in, const uint32_t* __restrict__ lumafp, float x, float y) {
-  const float fx = fminf(fmaxf(floorf(x - 0.5f), -1.f), (float)in.cwidth);
-  const float fy = fminf(fmaxf(floorf(y - 0.5f), -1.f), (float)in.cheight);
+  // v_med3_f32: one instruction, and none to quiet a NaN first (a NaN coordinate gives the minimum of the bounds: valid)
+  const float fx = __builtin_amdgcn_fmed3f(floorf(x - 0.5f), -1.f, (float)in.cwidth);
+  const float fy = __builtin_amdgcn_fmed3f(floorf(y - 0.5f), -1.f, (float)in.cheight);
   return luma_footprint_word(in, lumafp, (int)fx, (int)fy);
 }
 __device__ __forceinline__ void sample_luma_and_gradient_interior(uint32_t word, float x, float y, float* value, float* dx, float* dy) {
