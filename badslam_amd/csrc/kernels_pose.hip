@@ -412,7 +412,9 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   const unsigned tiles = ((s.size + kPoseBlock - 1) / kPoseBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk);   // whole XCD chunks
   const int forced = g_forced_pose_parts;
   const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
-                         : tiles >= 32768 ? 1 : tiles >= 8192 ? 4 : 8;   // measured (r2, full launch): 46.9 k tiles 1.03 / 1.08 / 1.30 ms with 1 / 2 / 4 parts
+                         : tiles >= 32768 ? 1 : tiles >= 8192 ? 2 : 4;
+  // measured (r2, pose stage per iteration, ms): 46.9 k tiles 1.03 / 1.08 / 1.30 with 1 / 2 / 4 parts; 23.4 k tiles 0.578 / 0.557 / 0.618
+  // with 1 / 2 / 4; 11.7 k tiles 0.29 / 0.30 with 2 / 4; 5.9 k tiles 0.155 / 0.172 with 4 / 8
   const dim3 grid(tiles, parts), block(kPoseBlock);
   const PoseWork* pw = static_cast<const PoseWork*>(work);
   WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);
