@@ -40,6 +40,20 @@ inline bahip_depth_params ToBahipDepthParams(const DepthParameters& p) {
   return r;
 }
 
+// A backend context for work that is not tied to a DirectBA (keyframe preprocessing, plane packing): one per (thread, stream),
+// created on first use and kept -- a context is six allocations and a synchronisation, too much to pay per keyframe.
+// Never destroyed (a few KB per thread and stream; tearing contexts down from thread-exit destructors would race the HIP
+// runtime's own shutdown).
+inline bahip_context* UtilityContext(hipStream_t stream) {
+  thread_local std::vector<std::pair<hipStream_t, bahip_context*>> cache;
+  for (const auto& entry : cache)
+    if (entry.first == stream) return entry.second;
+  bahip_context* ctx = nullptr;
+  BAHIP_CHECKED_CALL(bahip_context_create(&ctx, stream));
+  cache.emplace_back(stream, ctx);
+  return ctx;
+}
+
 class Keyframe {
  public:
   enum class Activation { kActive = 0, kCovisibleActive = 1, kInactive = 2 };
@@ -69,8 +83,7 @@ class Keyframe {
       : frame_index_(frame_index), last_active_in_ba_iteration_(-1), last_covis_in_ba_iteration_(-1),
         depth_buffer_(depth_image.height(), depth_image.width()), normals_buffer_(depth_image.height(), depth_image.width()),
         radius_buffer_(depth_image.height(), depth_image.width()), color_buffer_(color_image.height(), color_image.width()) {
-    bahip_context* ctx = nullptr;
-    BAHIP_CHECKED_CALL(bahip_context_create(&ctx, stream));
+    bahip_context* ctx = UtilityContext(stream);
     const int W = depth_image.width(), H = depth_image.height();
     CUDABuffer<u8> rgb_buffer(color_image.height(), color_image.width() * 3);
     rgb_buffer.UploadAsync(stream, reinterpret_cast<const u8*>(color_image.data()));
@@ -94,7 +107,6 @@ class Keyframe {
     BAHIP_CHECKED_CALL(bahip_frame_planes_create(ctx, W, H, color_image.width(), color_image.height(), &planes_));
     const bahip_frame images = ToBahipFrame();
     BAHIP_CHECKED_CALL(bahip_frame_planes_update(ctx, planes_, &images));
-    bahip_context_destroy(ctx);
     set_global_T_frame(global_tr_frame);
     activation_ = Activation::kActive;
   }
@@ -105,14 +117,12 @@ class Keyframe {
 
   // Re-derives the BA planes from the current contents of the image buffers.
   void RefreshPlanes(hipStream_t stream) {
-    bahip_context* ctx = nullptr;
-    BAHIP_CHECKED_CALL(bahip_context_create(&ctx, stream));
+    bahip_context* ctx = UtilityContext(stream);
     if (!planes_)
       BAHIP_CHECKED_CALL(bahip_frame_planes_create(ctx, depth_buffer_.width(), depth_buffer_.height(), color_buffer_.width(),
                                                    color_buffer_.height(), &planes_));
     const bahip_frame images = ToBahipFrame();
     BAHIP_CHECKED_CALL(bahip_frame_planes_update(ctx, planes_, &images));
-    bahip_context_destroy(ctx);
   }
 
   void SetID(int id) { id_ = id; }

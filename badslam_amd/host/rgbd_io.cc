@@ -420,8 +420,7 @@ shared_ptr<Keyframe> CreateKeyframeFromFrame(hipStream_t stream, const Preproces
       << "frame " << frame_index << ": colour image is " << rgb_image->width() << " x " << rgb_image->height() << ", the colour camera "
       << color_camera.width() << " x " << color_camera.height();
 
-  bahip_context* ctx = nullptr;
-  BAHIP_CHECKED_CALL(bahip_context_create(&ctx, stream));
+  bahip_context* ctx = UtilityContext(stream);
   CUDABuffer<u16> depth_buffer(H, W), filtered_A(H, W), filtered_B(H, W), normals_buffer(H, W), radius_buffer(H, W);
   CUDABuffer<u8> rgb_buffer(rgb_image->height(), rgb_image->width() * 3);
   CUDABuffer<uchar4> color_buffer(rgb_image->height(), rgb_image->width());
@@ -449,7 +448,6 @@ shared_ptr<Keyframe> CreateKeyframeFromFrame(hipStream_t stream, const Preproces
   float keyframe_min_depth = 0, keyframe_max_depth = 0;
   BAHIP_CHECKED_CALL(bahip_compute_min_max_depth(ctx, filtered_A.ToCUDA().address(), (uint32_t)filtered_A.ToCUDA().pitch(), W, H, raw_to_float_depth,
                                                  &keyframe_min_depth, &keyframe_max_depth));
-  bahip_context_destroy(ctx);
   shared_ptr<Keyframe> keyframe(new Keyframe(stream, frame_index, keyframe_min_depth, keyframe_max_depth, filtered_A, normals_buffer,
                                              radius_buffer, color_buffer, rgbd_video.depth_frame(frame_index)->global_T_frame()));
   rgbd_video.depth_frame_mutable(frame_index)->ClearImageAndDerivedData();
@@ -593,6 +591,16 @@ bool LoadState(hipStream_t stream, const PreprocessConfig& config, RGBDVideo<Vec
     }
     r.Bytes(c.parameters, sizeof(c.parameters));
     if (which == 0) pyramid_level_for_color = r.Int32();
+    // The images on disk and the buffers of this DirectBA have the live cameras' size: a state with other dimensions cannot
+    // be applied (it would abort later, in the keyframe constructor), and parameters that are not finite are not a camera.
+    const PinholeCamera4f live = which == 0 ? direct_ba->color_camera() : direct_ba->depth_camera();
+    if (!r.ok || c.width != (int)live.width() || c.height != (int)live.height()) {
+      LOG(ERROR) << "Stored " << (which == 0 ? "color" : "depth") << " camera size does not match the existing camera.";
+      return false;
+    }
+    for (float v : c.parameters)
+      if (!std::isfinite(v)) { LOG(ERROR) << "Non-finite camera parameter."; return false; }
+    if (!(c.parameters[0] > 0.f) || !(c.parameters[1] > 0.f)) { LOG(ERROR) << "Non-positive focal length."; return false; }
   }
 
   const int cfactor_width = r.Int32(), cfactor_height = r.Int32(), cfactor_stride = r.Int32();
@@ -615,6 +623,16 @@ bool LoadState(hipStream_t stream, const PreprocessConfig& config, RGBDVideo<Vec
   depth_params.raw_to_float_depth = r.Float();
   depth_params.baseline_fx = r.Float();
   depth_params.sparse_surfel_cell_size = r.Int32();
+  // The surfel grid and the cfactor image are laid out for this DirectBA's cell size; depth scales must be usable numbers.
+  if (!r.ok || depth_params.sparse_surfel_cell_size != direct_ba->depth_params().sparse_surfel_cell_size) {
+    LOG(ERROR) << "sparse_surfel_cell_size does not match.";
+    return false;
+  }
+  if (!std::isfinite(depth_params.a) || !std::isfinite(depth_params.raw_to_float_depth) || !(depth_params.raw_to_float_depth > 0.f) ||
+      !std::isfinite(depth_params.baseline_fx) || !(depth_params.baseline_fx > 0.f)) {
+    LOG(ERROR) << "Invalid depth parameters.";
+    return false;
+  }
 
   struct KeyframeRecord { int id, frame_index, activation, last_active_in_ba_iteration, last_covis_in_ba_iteration; };
   const int keyframe_count = r.Int32();
@@ -650,7 +668,39 @@ bool LoadState(hipStream_t stream, const PreprocessConfig& config, RGBDVideo<Vec
   const float surfel_merge_dist_factor = r.Float();
   if (!r.ok) { LOG(ERROR) << "Unexpected end of file."; return false; }
 
-  // ---- apply ----
+  // ---- apply ----  All or nothing: what the keyframe rebuild below needs to be in place already (poses, calibration) is
+  // remembered first and put back if the rebuild is cancelled.
+  struct Snapshot {
+    vector<SE3f> color_poses, depth_poses;
+    vector<shared_ptr<Keyframe>> keyframes;
+    PinholeCamera4f color_camera, depth_camera;
+    int pyramid_level;
+    DepthParameters depth_params;
+    Image<float> cfactor;
+  } old{{}, {}, *direct_ba->keyframes_mutable(), direct_ba->color_camera(), direct_ba->depth_camera(), direct_ba->pyramid_level_for_color(),
+        direct_ba->depth_params(), Image<float>(cfactor_width, cfactor_height)};
+  old.color_poses.reserve(frame_count);
+  old.depth_poses.reserve(frame_count);
+  for (u32 i = 0; i < frame_count; ++i) {
+    old.color_poses.push_back(rgbd_video->color_frame_mutable(i)->global_T_frame());
+    old.depth_poses.push_back(rgbd_video->depth_frame_mutable(i)->global_T_frame());
+  }
+  cfactor_buffer->DownloadAsync(stream, &old.cfactor);
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+  auto roll_back = [&]() {
+    for (u32 i = 0; i < frame_count; ++i) {
+      rgbd_video->color_frame_mutable(i)->SetGlobalTFrame(old.color_poses[i]);
+      rgbd_video->depth_frame_mutable(i)->SetGlobalTFrame(old.depth_poses[i]);
+    }
+    *direct_ba->keyframes_mutable() = old.keyframes;
+    direct_ba->SetColorCamera(old.color_camera);
+    direct_ba->SetPyramidLevelForColor(old.pyramid_level);
+    direct_ba->SetDepthCamera(old.depth_camera);
+    cfactor_buffer->UploadAsync(stream, old.cfactor);
+    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    direct_ba->SetDepthParams(old.depth_params);
+    direct_ba->SetCFactorBuffer(cfactor_buffer);
+  };
   for (u32 i = 0; i < frame_count; ++i) {
     rgbd_video->color_frame_mutable(i)->SetGlobalTFrame(frame_poses[i]);
     rgbd_video->depth_frame_mutable(i)->SetGlobalTFrame(frame_poses[i]);
@@ -667,7 +717,7 @@ bool LoadState(hipStream_t stream, const PreprocessConfig& config, RGBDVideo<Vec
   // Keyframes are rebuilt from their video frames with the loaded calibration and poses (B/io.cc:405-445).
   for (int i = 0; i < keyframe_count; ++i) {
     if (progress_function && !progress_function(i, keyframe_count)) {
-      direct_ba->keyframes_mutable()->clear();
+      roll_back();   // cancelled: the objects are as they were before the call
       return false;
     }
     const KeyframeRecord& k = keyframe_records[i];

@@ -147,10 +147,32 @@ def test_state_file_round_trip_and_resume(tmp_path):
     assert err_c.max() < 2.5e-3 and err_d.max() < 2.5e-3
     assert np.abs(np.array([p for _, p in pc]) - np.array([p for _, p in pd])).max() < 1e-3
 
-    # a truncated file and a file of the reference's own version are refused without touching anything
+    # a truncated file and a file of the reference's own version are refused without touching anything; so are files whose
+    # calibration cannot belong to this run: another image size, another surfel cell size, a depth scale of zero
+    import struct
     open(str(tmp_path / "short.state"), "wb").write(blob_a[:len(blob_a) // 2])
     open(str(tmp_path / "v1.state"), "wb").write(blob_a[:7] + bytes([1]) + blob_a[8:])
-    for bad in ("short.state", "v1.state"):
+    frames = struct.unpack_from("<I", blob_a, 8)[0]
+    color_camera = 12 + 28 * frames                       # type, width, height, parameter count, 4 floats, pyramid level
+    depth_camera = color_camera + 36
+    cfactor = depth_camera + 32                           # width, height, stride, rows
+    cf_h, cf_stride = struct.unpack_from("<ii", blob_a, cfactor + 4)
+    depth_params = cfactor + 12 + cf_h * cf_stride        # a, raw_to_float_depth, baseline_fx, cell
+    assert struct.unpack_from("<i", blob_a, color_camera + 4)[0] == 320 and struct.unpack_from("<i", blob_a, depth_params + 12)[0] == 2
+
+    def patched(name, offset, fmt, value):
+        blob = bytearray(blob_a)
+        struct.pack_into(fmt, blob, offset, value)
+        open(str(tmp_path / name), "wb").write(bytes(blob))
+        return name
+
+    hostile = ["short.state", "v1.state",
+               patched("width.state", color_camera + 4, "<i", 321),
+               patched("cell.state", depth_params + 12, "<i", 4),
+               patched("cell0.state", depth_params + 12, "<i", 0),
+               patched("scale.state", depth_params + 4, "<f", 0.0),
+               patched("focal.state", depth_camera + 16, "<f", float("nan"))]
+    for bad in hostile:
         proc = subprocess.run(base + [str(tmp_path / "e")] + opts + ["--iterations", "0", "--load_state", str(tmp_path / bad)],
                               capture_output=True, text=True, timeout=600)
         assert proc.returncode == 1 and "cannot load state" in proc.stderr
