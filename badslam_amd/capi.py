@@ -57,7 +57,7 @@ class PCGOptions(C.Structure):
                                        "max_inner_iterations", "gauge_keyframe")]
 
 
-SUM_F32, SUM_I64 = 0, 1
+SUM_F32, SUM_I64, SUM_F64 = 0, 1, 2
 RCCL_UNIQUE_ID_BYTES = 128
 # int fn(void* device_buffer, size_t count, int dtype, void* hip_stream, void* user)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)

@@ -59,12 +59,15 @@ void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEnt
                            const uint32_t* indices, int count, float* out);
 
 // kernels_intrinsics.hip
-// cells: S records of 8 floats {B0..B4, D, b2, observation count} (kernels_intrinsics.hip)
+// Intrinsics step (kernels_intrinsics.hip).  glob_d / cells_d: binary64 accumulators (34 sums; S records of 8: B0..B4, D, b2,
+// observation count) -- what a multi-GPU run sums over the ranks; glob_f / cells_f: their binary32 roundings after the
+// Schur complement (glob_f also carries x1 at [40..44] for the back-substitution).
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, float* glob, float* cells);
-size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_schur needs
-void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* cells, float* partials);
-void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, float* cells, const float* x1, float* cfactor,
+                                  const SurfelsView& s, double* glob_d, double* cells_d);
+size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_finish needs
+void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* glob_d, const double* cells_d, float* glob_f, float* cells_f,
+                              float* partials);
+void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, float* cells_f, const float* x1, float* cfactor,
                                    uint32_t cfactor_pitch);
 
 #ifdef BAHIP_COUNT_CANDIDATES

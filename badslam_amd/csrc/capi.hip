@@ -107,7 +107,7 @@ struct bahip_context {
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
 
-  float* intr_scratch = nullptr;   // intrinsics step: 64 + 8*S floats (glob | S cell records of 8)
+  float* intr_scratch = nullptr;   // intrinsics step: (64 + 8 S) doubles, then (64 + 8 S) floats + Schur partials
   int intr_capacity = 0;
 
   float* pcg_buf = nullptr;        // PCG vectors r, M, delta, g, p (5 * pcg_capacity floats) + 16 scalars
@@ -390,7 +390,7 @@ int rccl_fail(const char* what, int rc) {
   return 1;
 }
 int rccl_allreduce(bahip_context* ctx, void* buffer, size_t count, int dtype) {
-  const int nccl_type = dtype == BAHIP_SUM_I64 ? 4 /* ncclInt64 */ : 7 /* ncclFloat */;
+  const int nccl_type = dtype == BAHIP_SUM_I64 ? 4 /* ncclInt64 */ : dtype == BAHIP_SUM_F64 ? 8 /* ncclDouble */ : 7 /* ncclFloat */;
   const int rc = g_rccl.AllReduce(buffer, buffer, count, nccl_type, 0 /* ncclSum */, ctx->rccl_comm, ctx->stream);
   return rc == 0 ? 0 : rccl_fail("ncclAllReduce", rc);
 }
@@ -1122,23 +1122,25 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   if (S > ctx->intr_capacity) {
     const int cap = S + 1024;
     float* grown = nullptr;
-    HIP_TRY(hipMalloc(&grown, sizeof(float) * (64 + 8 * (size_t)cap + intrinsics_schur_partials(cap))));
+    // doubles first (8-byte aligned): glob_d[64] | cells_d[8 cap] | then floats: glob_f[64] | cells_f[8 cap] | Schur partials
+    HIP_TRY(hipMalloc(&grown, sizeof(double) * (64 + 8 * (size_t)cap) + sizeof(float) * (64 + 8 * (size_t)cap + intrinsics_schur_partials(cap))));
     hipFree(ctx->intr_scratch);
     ctx->intr_scratch = grown;
     ctx->intr_capacity = cap;
   }
-  float* glob = ctx->intr_scratch;            // 34 sums + x1 at [40..44]
-  float* cells = glob + 64;                   // S records {B0..B4, D, b2, observation count (a float: exact under a float SUM)}
+  double* glob_d = reinterpret_cast<double*>(ctx->intr_scratch);   // 34 sums
+  double* cells_d = glob_d + 64;                                   // S records {B0..B4, D, b2, observation count}
+  float* glob = reinterpret_cast<float*>(cells_d + 8 * (size_t)ctx->intr_capacity);   // the 34 sums rounded (+ Schur); x1 at [40..44]
+  float* cells = glob + 64;
+  float* partials = cells + 8 * (size_t)ctx->intr_capacity;
   timer_begin(ctx, 4, true);
-  HIP_TRY(hipMemsetAsync(glob, 0, sizeof(float) * (64 + 8 * (size_t)S), ctx->stream));
+  HIP_TRY(hipMemsetAsync(glob_d, 0, sizeof(double) * (64 + 8 * (size_t)S), ctx->stream));
   launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
-                               make_view(surfels), glob, cells);
+                               make_view(surfels), glob_d, cells_d);
   CHECK_LAUNCH();
-  if (reduce_over_ranks(ctx, glob, 64 + 8 * (size_t)S, BAHIP_SUM_F32)) return 1;
-  if (optimize_depth) {
-    launch_intrinsics_schur(ctx->stream, S, glob, cells, cells + 8 * (size_t)ctx->intr_capacity /* past the all-reduced block */);
-    CHECK_LAUNCH();
-  }
+  if (reduce_over_ranks(ctx, glob_d, 64 + 8 * (size_t)S, BAHIP_SUM_F64)) return 1;
+  launch_intrinsics_finish(ctx->stream, optimize_depth != 0, S, glob_d, cells_d, glob, cells, partials);
+  CHECK_LAUNCH();
   timer_end(ctx, 4);   // the sweep and the Schur complement; the 5x5 / 4x4 solves and the cfactor update that follow are tiny
   HIP_TRY(hipMemcpyAsync(ctx->pinned_f, glob, 34 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -11,11 +11,19 @@
 // 34 partial sums in registers across the whole sweep and the wave reduces them once at the end;
 // only the per-cell terms B, D, b2, observation count go out as atomics per associated pair.
 //
-// Per-cell accumulators: ONE record of 8 floats per sparse cell, {B0..B4, D, b2, observation count} (32 bytes), instead of
-// eight arrays.  A memory-side float atomic costs a request per cache line it touches, whatever the number of lanes in it:
-// eight scattered atomics per associated pair (52 M pairs x 8 at the bench size) took 12.9 ms.  The wavefront therefore
-// transposes its 64 x 8 contributions through LDS and issues 8 instructions in which 8 consecutive lanes carry the 8
-// values of one surfel - one 32-byte request per surfel instead of eight 4-byte requests to eight lines.
+// Per-cell accumulators: ONE record of 8 values per sparse cell, {B0..B4, D, b2, observation count}, instead of eight arrays.
+// A memory-side atomic costs a request per cache line it touches, whatever the number of lanes in it: eight scattered
+// atomics per associated pair (52 M pairs x 8 at the bench size) took 12.9 ms.  The wavefront therefore transposes its
+// 64 x 8 contributions through LDS and issues 8 instructions in which 8 consecutive lanes carry the 8 values of one
+// surfel - one request per surfel instead of eight requests to eight lines.
+//
+// DEFINITION of the sums (the oracle restates it, oracle_intrinsics.c).  The terms are binary32, exactly the reference's
+// expressions; they are ADDED IN BINARY64: the 34 global sums as per-surfel binary32 chains over the keyframes in ascending
+// order, then the xor butterfly over the 64 surfels of a tile (wave_sum), then binary64 over the tiles; the per-cell sums in
+// binary64 pair by pair.  A binary64 sum of binary32 terms depends on the order of the additions only in bits that the
+// final rounding to binary32 discards (a tie aside), so the atomics' order, the launch shape and a multi-GPU exchange
+// (BAHIP_SUM_F64) do not show in the result, and kernels and oracle agree to the last bit (the reference adds binary32
+// atomics in arbitrary order, B/kernel_opt_intrinsics.cu:217-262).
 #include "ba_device.h"
 #include "ba_launch.h"
 #include "wave_cull.h"
@@ -35,8 +43,7 @@ __device__ __forceinline__ float& cell_obs(float* cells, int cell) { return cell
 template <bool kDepth, bool kColor>
 __global__ void __launch_bounds__(kIntrSweepBlock)
 intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                             float* __restrict__ glob /* 34 */, float* __restrict__ cells /* S records of kCellFloats; the
-                             observation counts are floats so that a float SUM all-reduce over ranks stays exact (< 2^24) */) {
+                             double* __restrict__ glob /* 34 */, double* __restrict__ cells /* S records of kCellFloats */) {
   __shared__ float xpose[64 * (kCellFloats + 1)];   // lane-major: 8 values + the cell index, stride 9 (conflict-free both ways)
   const uint32_t i = blockIdx.x * kIntrSweepBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -136,7 +143,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
               if (!((contributing >> (8 * j)) & 0xffull)) continue;   // wave-uniform
               const float* src = xpose + (8 * j + (lane >> 3)) * (kCellFloats + 1);
               const int c = __float_as_int(src[kCellFloats]);
-              if (c >= 0) unsafeAtomicAdd(&cells[(size_t)c * kCellFloats + (lane & 7)], src[lane & 7]);
+              if (c >= 0) unsafeAtomicAdd(&cells[(size_t)c * kCellFloats + (lane & 7)], (double)src[lane & 7]);
             }
             __builtin_amdgcn_wave_barrier();   // the next candidate overwrites the buffer
           }
@@ -149,20 +156,24 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
     const float v = wave_sum(acc[q]);
     if (lane == q) mine = v;
   }
-  if (lane < 34 && mine != 0.f) unsafeAtomicAdd(&glob[lane], mine);
+  if (lane < 34 && mine != 0.f) unsafeAtomicAdd(&glob[lane], (double)mine);
 }
 
 // Schur complement: B/kernel_opt_intrinsics.cu:266-350.  One thread per sparse cell.  This runs AFTER the multi-GPU
-// all-reduce of the accumulators, on every rank, so it must give every rank the same bits: the 20 sums over the cells are
-// formed without atomics - a fixed cross-lane tree per wavefront (wave_sum), one partial per wavefront, then
-// intrinsics_schur_finish_kernel adds the partials in wavefront order.
+// all-reduce of the accumulators, on every rank.  The binary64 accumulators are rounded to binary32 here (cells_f: what the
+// reference holds at this point); the 20 sums over the cells are formed without atomics - the xor butterfly per wavefront
+// of 64 cells (wave_sum), one partial per wavefront, then intrinsics_finish_kernel adds the partials in wavefront order
+// (binary32, starting from 0) and adds that total to the rounded global sum: defined, and restated by the oracle.
 __global__ void __launch_bounds__(kIntrBlock)
-intrinsics_schur_kernel(int S, float* __restrict__ partials /* [wavefronts][20] */, float* __restrict__ cells) {
+intrinsics_schur_kernel(int S, float* __restrict__ partials /* [wavefronts][20] */, const double* __restrict__ cells_d,
+                        float* __restrict__ cells) {
   const int cell = blockIdx.x * kIntrBlock + threadIdx.x;
   float part[20];
 #pragma unroll
   for (int q = 0; q < 20; ++q) part[q] = 0.f;
   if (cell < S) {
+#pragma unroll
+    for (int c = 0; c < kCellFloats; ++c) cells[(size_t)cell * kCellFloats + c] = (float)cells_d[(size_t)cell * kCellFloats + c];
     const float D_inverse = 1.0f / cell_D(cells, cell);
     if (!(D_inverse < 1e12f)) {
       cell_D(cells, cell) = __builtin_nanf("");
@@ -193,13 +204,18 @@ intrinsics_schur_kernel(int S, float* __restrict__ partials /* [wavefronts][20] 
   const int wave = (blockIdx.x * kIntrBlock + threadIdx.x) >> 6;
   if (lane < 20) partials[(size_t)wave * 20 + lane] = mine;
 }
+// glob_f[q] = (float)glob_d[q] for the 34 global sums [+ the Schur total of sum q < 20 when num_waves > 0]
 __global__ void __launch_bounds__(64)
-intrinsics_schur_finish_kernel(int num_waves, const float* __restrict__ partials, float* __restrict__ glob) {
+intrinsics_finish_kernel(int num_waves, const float* __restrict__ partials, const double* __restrict__ glob_d, float* __restrict__ glob_f) {
   const int q = threadIdx.x;
-  if (q >= 20) return;
-  float total = 0.f;
-  for (int w = 0; w < num_waves; ++w) total += partials[(size_t)w * 20 + q];
-  glob[q] += total;
+  if (q >= 34) return;
+  float value = (float)glob_d[q];
+  if (q < 20 && num_waves > 0) {
+    float total = 0.f;
+    for (int w = 0; w < num_waves; ++w) total += partials[(size_t)w * 20 + q];
+    value += total;
+  }
+  glob_f[q] = value;
 }
 
 // Back-substitution: B/kernel_opt_intrinsics.cu:375-423
@@ -223,7 +239,7 @@ intrinsics_solve_cells_kernel(Intrinsics in, int S, float* __restrict__ cells, c
 }
 
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, float* glob, float* cells) {
+                                  const SurfelsView& s, double* glob, double* cells) {
   if (!s.size) return;
   const dim3 grid((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock), block(kIntrSweepBlock);
   if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells);
@@ -231,10 +247,15 @@ void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const 
   else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells);
 }
 size_t intrinsics_schur_partials(int S) { return 20 * (size_t)((S + kIntrBlock - 1) / kIntrBlock) * (kIntrBlock / 64); }
-void launch_intrinsics_schur(hipStream_t st, int S, float* glob, float* cells, float* partials) {
-  const int blocks = (S + kIntrBlock - 1) / kIntrBlock;
-  hipLaunchKernelGGL(intrinsics_schur_kernel, dim3(blocks), dim3(kIntrBlock), 0, st, S, partials, cells);
-  hipLaunchKernelGGL(intrinsics_schur_finish_kernel, dim3(1), dim3(64), 0, st, blocks * (kIntrBlock / 64), partials, glob);
+void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* glob_d, const double* cells_d, float* glob_f, float* cells_f,
+                              float* partials) {
+  int waves = 0;
+  if (schur) {
+    const int blocks = (S + kIntrBlock - 1) / kIntrBlock;
+    hipLaunchKernelGGL(intrinsics_schur_kernel, dim3(blocks), dim3(kIntrBlock), 0, st, S, partials, cells_d, cells_f);
+    waves = blocks * (kIntrBlock / 64);
+  }
+  hipLaunchKernelGGL(intrinsics_finish_kernel, dim3(1), dim3(64), 0, st, waves, partials, glob_d, glob_f);
 }
 void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, float* cells, const float* x1, float* cfactor,
                                    uint32_t cfactor_pitch) {

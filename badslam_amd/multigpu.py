@@ -20,7 +20,7 @@ class _DevicePtrView:
     """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it."""
 
     def __init__(self, ptr, count, dtype=0):
-        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i8" if dtype == capi.SUM_I64 else "<f4",
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": {capi.SUM_I64: "<i8", capi.SUM_F64: "<f8"}.get(dtype, "<f4"),
                                          "data": (int(ptr), False), "version": 2}
 
 

@@ -101,11 +101,12 @@ int bahip_context_synchronize(bahip_context* ctx);
  *
  * Hook path: any other transport.  The hook receives the stream the producers of `device_buffer` were queued on and must
  * order the reduction after them and before later work on that stream (e.g. torch.cuda.ExternalStream(stream) around
- * dist.all_reduce).  dtype: BAHIP_SUM_F32 (count floats) or BAHIP_SUM_I64 (count int64_t: the pose normal equations are
- * summed in fixed point, which makes a sharded run bit-identical to the unsharded one).  NULL (default) = single GPU. */
+ * dist.all_reduce).  dtype: BAHIP_SUM_F32 (count floats), BAHIP_SUM_I64 (count int64_t: the pose normal equations are
+ * summed in fixed point, which makes a sharded run bit-identical to the unsharded one) or BAHIP_SUM_F64 (count doubles: the
+ * accumulators of the intrinsics step).  NULL (default) = single GPU. */
 /* 1 if sums go over several ranks (a hook or an RCCL communicator is installed), else 0. */
 int bahip_context_is_sharded(bahip_context* ctx);
-enum { BAHIP_SUM_F32 = 0, BAHIP_SUM_I64 = 1 };
+enum { BAHIP_SUM_F32 = 0, BAHIP_SUM_I64 = 1, BAHIP_SUM_F64 = 2 };
 typedef int (*bahip_allreduce_fn)(void* device_buffer, size_t count, int dtype, void* hip_stream, void* user);
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user);
 #define BAHIP_RCCL_UNIQUE_ID_BYTES 128

@@ -458,7 +458,9 @@ class OracleBA:
         st.supporting = _ptr(self.supporting, C.c_uint32)
         st.ba_iteration_count, st.last_ba_iteration_count = self.ba_iteration_count, self.last_ba_iteration_count
         stats = BAStats()
-        fn = self.L.orc_bundle_adjustment_pcg if use_pcg else self.L.orc_bundle_adjustment_alternating
+        # use_pcg = "f64": the PCG scheme with binary64 vectors and scalars (oracle_pcg.c compiled with -DORC_PCG_DOUBLE)
+        fn = (self.L.orc_bundle_adjustment_pcg_f64 if use_pcg == "f64" else self.L.orc_bundle_adjustment_pcg) if use_pcg \
+            else self.L.orc_bundle_adjustment_alternating
         fn(C.byref(st), C.byref(opt), C.byref(stats))
         self.color_cam, self.depth_cam = st.color_cam, st.depth_cam
         self.dp.a = st.dp.a

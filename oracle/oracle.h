@@ -185,6 +185,8 @@ void orc_evaluate_pairs(const orc_camera* color_cam, const orc_camera* depth_cam
  * (per-surfel fma chains, fixed 64-surfel tile tree, 48.16 fixed-point integer total; oracle_pose.c), which is what
  * orc_estimate_frame_pose uses; != 0: plain binary64 running sum in surfel order.  Returns the number of associated surfels. */
 float orc_tile_tree_sum(const float lane_values[64]);
+/* the classic xor butterfly (32, 16, 8, 4, 2, 1) in binary32: the backend's wave_sum */
+float orc_wave_xor_sum(const float lane_values[64]);
 uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camera* color_cam,
                                     const orc_camera* depth_cam, const orc_depth_params* dp,
                                     const orc_keyframe* kf, const float frame_T_global[12],

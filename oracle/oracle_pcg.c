@@ -5,6 +5,22 @@
  * atomics are formed here sequentially in (keyframe, surfel) order. */
 #include "oracle_internal.h"
 
+/* The file is compiled twice (oracle/Makefile): as is -- PCGScalar = float, the reference's -- and with -DORC_PCG_DOUBLE,
+ * which keeps the per-pair terms in binary32 but holds the vectors r, M, g, p, delta and every scalar of the conjugate
+ * gradient recurrence in binary64 (entry points orc_bundle_adjustment_pcg_f64 / orc_pcg_assemble_f64).  The binary64
+ * flavour is what the binary32 solvers -- this one and the backend's -- are measured against in
+ * tests/test_gpu_directba_vs_oracle.py: it shows how far a binary32 conjugate gradient is from the solution of its own
+ * linear system, i.e. how close two correct binary32 implementations can be expected to agree. */
+#ifdef ORC_PCG_DOUBLE
+typedef double pcg_real;
+#define PCG_SQRT(x) sqrt(x)
+#define orc_bundle_adjustment_pcg orc_bundle_adjustment_pcg_f64
+#define orc_pcg_assemble orc_pcg_assemble_f64
+#else
+typedef float pcg_real;
+#define PCG_SQRT(x) sqrtf(x)
+#endif
+
 static const float kDiagEpsilon = 1e-8f;     /* B/kernel_pcg.cu:44 */
 static const float kAPriorWeight = 10.f;     /* B/kernel_pcg.cu:48 */
 #define INVALID_UNKNOWN 0xffffffffu
@@ -93,13 +109,13 @@ static void eval_pair_terms(const pcg_layout* L, const orc_camera* color_cam, co
   }
 }
 
-static inline void sum_r_m(float* r, float* M, uint32_t idx, float J, float w, float raw) {
-  const float wj = w * J;
+static inline void sum_r_m(pcg_real* r, pcg_real* M, uint32_t idx, float J, float w, float raw) {
+  const pcg_real wj = (pcg_real)w * J;
   r[idx] += -1 * wj * raw;
   M[idx] += J * wj;
 }
-static inline void sum_r_m2(float* r, float* M, uint32_t idx, float J1, float w1, float raw1, float J2, float w2, float raw2) {
-  const float wj1 = w1 * J1, wj2 = w2 * J2;
+static inline void sum_r_m2(pcg_real* r, pcg_real* M, uint32_t idx, float J1, float w1, float raw1, float J2, float w2, float raw2) {
+  const pcg_real wj1 = (pcg_real)w1 * J1, wj2 = (pcg_real)w2 * J2;
   r[idx] += -1 * wj1 * raw1 + -1 * wj2 * raw2;
   M[idx] += J1 * wj1 + J2 * wj2;
 }
@@ -107,7 +123,7 @@ static inline void sum_r_m2(float* r, float* M, uint32_t idx, float J1, float w1
 /* B/kernel_pcg.cu:179-541, one keyframe */
 static void pcg_init_kf(const pcg_layout* L, uint32_t pose_index, int optimize_pose_of_kf, const orc_camera* color_cam,
                         const orc_camera* depth_cam, const orc_depth_params* dp, const orc_keyframe* kf,
-                        const orc_surfels* s, float* r_, float* M_) {
+                        const orc_surfels* s, pcg_real* r_, pcg_real* M_) {
   proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
   const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
   for (uint32_t i = 0; i < s->surfels_size; ++i) {
@@ -157,7 +173,7 @@ static void pcg_init_kf(const pcg_layout* L, uint32_t pose_index, int optimize_p
 /* B/kernel_pcg.cu:646-1026, one keyframe: g += J^T W J p, alpha_d += p^T J^T W J p */
 static void pcg_step1_kf(const pcg_layout* L, uint32_t pose_index, int optimize_pose_of_kf, const orc_camera* color_cam,
                          const orc_camera* depth_cam, const orc_depth_params* dp, const orc_keyframe* kf,
-                         const orc_surfels* s, const float* p_, float* g_, float* alpha_d) {
+                         const orc_surfels* s, const pcg_real* p_, pcg_real* g_, pcg_real* alpha_d) {
   proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
   const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
   for (uint32_t i = 0; i < s->surfels_size; ++i) {
@@ -167,7 +183,7 @@ static void pcg_step1_kf(const pcg_layout* L, uint32_t pose_index, int optimize_
     eval_pair_terms(L, color_cam, depth_cam, dp, kf, &p, &d2c, s, i, &pr, &t);
     const uint32_t gi = L->surfel_start + (uint32_t)L->geom_stride * i;
     if (L->use_depth) {
-      float sum = 0;
+      pcg_real sum = 0;
       if (L->optimize_geometry) sum += t.Jgeom * p_[gi];
       if (optimize_pose_of_kf) for (int c = 0; c < 6; ++c) sum += t.Jpose[c] * p_[pose_index + c];
       const int di = L->optimize_depth_intrinsics && t.di_valid;
@@ -190,17 +206,17 @@ static void pcg_step1_kf(const pcg_layout* L, uint32_t pose_index, int optimize_
     }
     if (L->use_desc) {
       if (!t.color_ok) continue;
-      float sum1 = 0, sum2 = 0;
+      pcg_real sum1 = 0, sum2 = 0;
       if (L->optimize_geometry) {
-        float pv = p_[gi + 0];
+        pcg_real pv = p_[gi + 0];
         sum1 += t.Jg1 * pv; sum2 += t.Jg2 * pv;
         pv = p_[gi + 1]; sum1 += -1.f * pv;
         pv = p_[gi + 2]; sum2 += -1.f * pv;
       }
       if (optimize_pose_of_kf)
-        for (int c = 0; c < 6; ++c) { const float pv = p_[pose_index + c]; sum1 += t.Jp1[c] * pv; sum2 += t.Jp2[c] * pv; }
+        for (int c = 0; c < 6; ++c) { const pcg_real pv = p_[pose_index + c]; sum1 += t.Jp1[c] * pv; sum2 += t.Jp2[c] * pv; }
       if (L->optimize_color_intrinsics)
-        for (int c = 0; c < 4; ++c) { const float pv = p_[L->color_intr_start + c]; sum1 += t.Jci1[c] * pv; sum2 += t.Jci2[c] * pv; }
+        for (int c = 0; c < 4; ++c) { const pcg_real pv = p_[L->color_intr_start + c]; sum1 += t.Jci1[c] * pv; sum2 += t.Jci2[c] * pv; }
       *alpha_d += sum1 * t.w1 * sum1 + sum2 * t.w2 * sum2;
       sum1 *= t.w1; sum2 *= t.w2;
       if (L->optimize_geometry) {
@@ -241,16 +257,15 @@ uint32_t orc_pcg_assemble(orc_ba_state* st, const orc_ba_options* opt, float* r_
   L.color_intr_start = INVALID_UNKNOWN;
   if (L.optimize_color_intrinsics) { L.color_intr_start = cur; cur += 4; }
   L.unknown_count = cur;
-  float* r_ = (float*)calloc(cur ? cur : 1, sizeof(float));
-  float* M_ = (float*)calloc(cur ? cur : 1, sizeof(float));
+  pcg_real* r_ = (pcg_real*)calloc(cur ? cur : 1, sizeof(pcg_real));
+  pcg_real* M_ = (pcg_real*)calloc(cur ? cur : 1, sizeof(pcg_real));
   const int gauge = (opt->pcg_gauge_keyframe >= 0 && opt->pcg_gauge_keyframe < K) ? opt->pcg_gauge_keyframe : 0;
   for (int k = 0; k < K; ++k) {
     const uint32_t pi = (k == gauge) ? INVALID_UNKNOWN : ((k < gauge) ? 6u * (uint32_t)k : 6u * (uint32_t)(k - 1));
     pcg_init_kf(&L, pi, (k == gauge) ? 0 : L.optimize_poses, &st->color_cam, &st->depth_cam, &st->dp, st->kfs[k], s, r_, M_);
   }
   const uint32_t n = cur < capacity ? cur : capacity;
-  memcpy(r_out, r_, sizeof(float) * n);
-  memcpy(M_out, M_, sizeof(float) * n);
+  for (uint32_t u = 0; u < n; ++u) { r_out[u] = (float)r_[u]; M_out[u] = (float)M_[u]; }
   free(r_); free(M_);
   return cur;
 }
@@ -277,7 +292,7 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     orc_bundle_adjustment_alternating(st, &o2, &tmp);
   }
 
-  float *r_ = NULL, *M_ = NULL, *delta = NULL, *g_ = NULL, *p_ = NULL;
+  pcg_real *r_ = NULL, *M_ = NULL, *delta = NULL, *g_ = NULL, *p_ = NULL;
   size_t allocated = 0;
   int n_new = 0;
   int* new_kfs = (int*)malloc(sizeof(int) * (K ? K : 1));
@@ -325,11 +340,11 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     if (U > allocated) {
       free(r_); free(M_); free(delta); free(g_); free(p_);
       allocated = U + 1024;
-      r_ = (float*)malloc(sizeof(float) * allocated); M_ = (float*)malloc(sizeof(float) * allocated);
-      delta = (float*)malloc(sizeof(float) * allocated); g_ = (float*)malloc(sizeof(float) * allocated);
-      p_ = (float*)malloc(sizeof(float) * allocated);
+      r_ = (pcg_real*)malloc(sizeof(pcg_real) * allocated); M_ = (pcg_real*)malloc(sizeof(pcg_real) * allocated);
+      delta = (pcg_real*)malloc(sizeof(pcg_real) * allocated); g_ = (pcg_real*)malloc(sizeof(pcg_real) * allocated);
+      p_ = (pcg_real*)malloc(sizeof(pcg_real) * allocated);
     }
-    memset(r_, 0, sizeof(float) * U); memset(M_, 0, sizeof(float) * U);
+    memset(r_, 0, sizeof(pcg_real) * U); memset(M_, 0, sizeof(pcg_real) * U);
 
     const int gauge = (opt->pcg_gauge_keyframe >= 0 && opt->pcg_gauge_keyframe < K) ? opt->pcg_gauge_keyframe : 0;
 #define KF_POSE_INDEX(id) ((id) == gauge ? INVALID_UNKNOWN : ((id) < gauge ? 6u * (uint32_t)(id) : 6u * (uint32_t)((id) - 1)))
@@ -339,24 +354,24 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
                   st->kfs[k], s, r_, M_);
 
     /* PCGInit2, B/kernel_pcg.cu:565-600 */
-    float alpha_n = 0, alpha_d = 0, beta_n = 0;
+    pcg_real alpha_n = 0, alpha_d = 0, beta_n = 0;
     for (uint32_t u = 0; u < U; ++u) {
       g_[u] = 0;
-      const float r_value = r_[u] + ((u == L.a_index) ? (-kAPriorWeight * kAPriorWeight * st->dp.a) : 0);
-      const float p_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
+      const pcg_real r_value = r_[u] + ((u == L.a_index) ? (-kAPriorWeight * kAPriorWeight * st->dp.a) : 0);
+      const pcg_real p_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
       p_[u] = p_value;
       delta[u] = 0;
       alpha_n += r_value * p_value;
     }
 
-    float prev_r_norm = INFINITY;
+    pcg_real prev_r_norm = INFINITY;
     int no_improvement = 0;
     for (int step = 0; step < opt->pcg_max_inner_iterations; ++step) {
       stats->pcg_inner_steps_total += 1;
       alpha_d = 0;
       if (step > 0) {
-        const float tmp = alpha_n; alpha_n = beta_n; beta_n = tmp;
-        memset(g_, 0, sizeof(float) * U);
+        const pcg_real tmp = alpha_n; alpha_n = beta_n; beta_n = tmp;
+        memset(g_, 0, sizeof(pcg_real) * U);
       }
       for (int k = 0; k < K; ++k) {
         pcg_step1_kf(&L, KF_POSE_INDEX(k), (k == gauge) ? 0 : L.optimize_poses, &st->color_cam, &st->depth_cam, &st->dp,
@@ -367,24 +382,24 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
       }
       /* PCGStep2, B/kernel_pcg.cu:1117-1158 */
       beta_n = 0;
-      const float alpha = (alpha_d >= 1e-35f) ? (alpha_n / alpha_d) : 0;
+      const pcg_real alpha = (alpha_d >= 1e-35f) ? (alpha_n / alpha_d) : 0;
       for (uint32_t u = 0; u < U; ++u) {
-        const float p_value = p_[u];
+        const pcg_real p_value = p_[u];
         delta[u] += alpha * p_value;
-        float r_value = r_[u];
+        pcg_real r_value = r_[u];
         r_value -= alpha * (g_[u] + (kDiagEpsilon + prior_at(&L, u)) * p_value);
         r_[u] = r_value;
-        const float z_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
+        const pcg_real z_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
         g_[u] = z_value;
         beta_n += z_value * r_value;
       }
-      const float r_norm = sqrtf(beta_n);
+      const pcg_real r_norm = PCG_SQRT(beta_n);
       if (r_norm < prev_r_norm - 1e-3f) no_improvement = 0;
       else if (++no_improvement >= 3) break;
       prev_r_norm = r_norm;
       if (step < opt->pcg_max_inner_iterations - 1) {
         /* PCGStep3, B/kernel_pcg.cu:1212-1226 */
-        const float beta = (alpha_n >= 1e-35f) ? (beta_n / alpha_n) : 0;
+        const pcg_real beta = (alpha_n >= 1e-35f) ? (beta_n / alpha_n) : 0;
         for (uint32_t u = 0; u < U; ++u) p_[u] = g_[u] + beta * p_[u];
       }
     }
@@ -395,7 +410,9 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
       for (int k = 0; k < K; ++k) {
         if (k == gauge) { ++num_converged; continue; }
         orc_se3 d, next;
-        orc_se3_exp(&delta[KF_POSE_INDEX(k)], &d);
+        float step6[6];
+        for (int c = 0; c < 6; ++c) step6[c] = (float)delta[KF_POSE_INDEX(k) + c];
+        orc_se3_exp(step6, &d);
         orc_se3_mul(&st->kfs[k]->global_T_frame, &d, &next);
         orc_keyframe_set_global_T_frame(st->kfs[k], &next);
         float lg[6];
@@ -406,18 +423,18 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     if (L.optimize_geometry) {
       for (uint32_t i = 0; i < s->surfels_size; ++i) {
         const uint32_t gi = L.surfel_start + (uint32_t)L.geom_stride * i;
-        const float tt = delta[gi];
+        const float tt = (float)delta[gi];
         if (tt != 0) surfel_set_position(s, i, v3_add(surfel_position(s, i), v3_scale(tt, surfel_normal(s, i))));
         if (L.use_desc) {
-          float d1 = srow(s, ORC_SURFEL_DESC1)[i]; d1 += delta[gi + 1];
+          float d1 = srow(s, ORC_SURFEL_DESC1)[i]; d1 += (float)delta[gi + 1];
           srow(s, ORC_SURFEL_DESC1)[i] = fmaxf(-180.f, fminf(180.f, d1));
-          float d2 = srow(s, ORC_SURFEL_DESC2)[i]; d2 += delta[gi + 2];
+          float d2 = srow(s, ORC_SURFEL_DESC2)[i]; d2 += (float)delta[gi + 2];
           srow(s, ORC_SURFEL_DESC2)[i] = fmaxf(-180.f, fminf(180.f, d2));
         }
       }
     }
     if (L.optimize_depth_intrinsics) {
-      const float* b = &delta[L.depth_intr_start];
+      const pcg_real* b = &delta[L.depth_intr_start];
       const double old_fx_inv = 1. / st->depth_cam.fx, old_fy_inv = 1. / st->depth_cam.fy;
       const double old_cx_pc = st->depth_cam.cx - 0.5, old_cy_pc = st->depth_cam.cy - 0.5;
       const double old_cx_inv = -old_cx_pc * old_fx_inv, old_cy_inv = -old_cy_pc * old_fy_inv;
@@ -425,11 +442,11 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
       const double new_cx = -(new_fx * (old_cx_inv + b[2])) + 0.5, new_cy = -(new_fy * (old_cy_inv + b[3])) + 0.5;
       st->depth_cam.fx = (float)new_fx; st->depth_cam.fy = (float)new_fy;
       st->depth_cam.cx = (float)new_cx; st->depth_cam.cy = (float)new_cy;
-      st->dp.a += b[4];
-      for (int c = 0; c < S; ++c) st->dp.cfactor[c] += delta[L.depth_intr_start + 5 + c];
+      st->dp.a += (float)b[4];
+      for (int c = 0; c < S; ++c) st->dp.cfactor[c] += (float)delta[L.depth_intr_start + 5 + c];
     }
     if (L.optimize_color_intrinsics) {
-      const float* b = &delta[L.color_intr_start];
+      const pcg_real* b = &delta[L.color_intr_start];
       st->color_cam.fx = (float)(st->color_cam.fx + b[0]); st->color_cam.fy = (float)(st->color_cam.fy + b[1]);
       st->color_cam.cx = (float)(st->color_cam.cx + b[2]); st->color_cam.cy = (float)(st->color_cam.cy + b[3]);
     }

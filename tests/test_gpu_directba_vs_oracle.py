@@ -89,11 +89,28 @@ def test_bundle_adjustment_fixed_surfels(scene, use_pcg):
         assert np.array_equal(np.asarray(got_poses, np.float32), np.asarray(ref_poses, np.float32))
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     else:
-        # PCG: binary32 conjugate gradients are chaotic with respect to summation order (the reference is
-        # run-to-run non-deterministic for the same reason) and the joint system has near-gauge modes, so
-        # iterates agree to the scale of the convergence threshold, not to 1e-5; equivalence of the cost
-        # decrease per iteration is asserted in test_gpu_intrinsics_pcg_vs_oracle.py::test_pcg_iteration.
-        assert _translation_rmse(got_poses, ref_poses) <= 1e-3, _translation_rmse(got_poses, ref_poses)
+        # PCG.  The iterates of a binary32 conjugate gradient depend on the summation order in every dot product (the
+        # reference is run-to-run non-deterministic for the same reason), so two correct binary32 implementations cannot be
+        # expected to agree more closely than each of them agrees with the solution of its own linear systems.  That
+        # distance is measured here instead of assumed: the same three iterations are run a third time by the oracle's
+        # PCG with binary64 vectors and scalars (oracle_pcg.c, ORC_PCG_DOUBLE; the per-pair terms stay binary32).
+        orc64 = common.build_oracle(scene, 600000)
+        orc64.surfel_data[:, :data.shape[1]] = data
+        for k, T in enumerate(perturbed):
+            orc64.set_pose(k, T)
+        stats64 = orc64.bundle_adjustment(min_iterations=iters, max_iterations=iters, use_pcg="f64", increase_ba_iteration_count=True,
+                                          optimize_poses=True, optimize_geometry=True, pcg_gauge_keyframe=0)
+        assert stats64.iterations_done == iters
+        poses64 = [orc64.pose(k) for k in range(K)]
+        d_gpu_ref, d_gpu_64, d_ref_64 = (_translation_rmse(a, b) for a, b in ((got_poses, ref_poses), (got_poses, poses64), (ref_poses, poses64)))
+        print("PCG end to end, translation RMSE [m]: backend vs binary32 oracle %.3g, backend vs binary64 CG %.3g, binary32 oracle vs binary64 CG %.3g"
+              % (d_gpu_ref, d_gpu_64, d_ref_64))
+        # the backend is as close to the binary64 solution as the binary32 restatement of the reference is (factor 3: the two
+        # binary32 runs are two samples of the same rounding noise), and the two binary32 runs are no further apart than the
+        # sum of their distances to it
+        assert d_gpu_64 <= 3.0 * d_ref_64 + 1e-5, (d_gpu_64, d_ref_64)
+        assert d_gpu_ref <= d_gpu_64 + d_ref_64 + 1e-5
+        assert d_gpu_ref <= 1e-3
         assert abs(ba.surfel_count() - orc.surfels_size) <= 5e-3 * orc.surfels_size
 
 

@@ -40,24 +40,37 @@ def _perturbed_pair(scene, depth_cam_offset=(0.5, -0.6, 1.23, -2.17), color_cam_
     return ba, g
 
 
+def _bits(values):
+    return np.asarray(values, np.float32).view(np.uint32)
+
+
 def test_depth_intrinsics_step(scene):
+    """One depth-intrinsics + deformation step (Schur complement over the sparse cfactor cells).  The accumulation is DEFINED
+    (binary32 terms, per-surfel chains, xor butterfly per tile, binary64 across tiles and per cell, xor butterfly + ordered
+    partials in the Schur complement: kernels_intrinsics.hip / oracle_intrinsics.c), so kernels and oracle agree to the last
+    bit although the kernels merge with atomics.  (a = 0 here, so expf -- device library vs glibc, 1 ulp apart at times -- is
+    exactly 1 on both sides; the step after this one is compared with a tolerance below.)"""
     ba, g = _perturbed_pair(scene)
     ba.use_depth, ba.use_desc = 1, 1
     before = _cam_tuple(ba.depth_cam)
     cc_r, dc_r, a_r = ba.optimize_intrinsics(True, False)
     cc_g, dc_g, a_g = g.optimize_intrinsics(True, False)
     true_cam = np.asarray(scene.camera, np.float64)
-    step = np.abs(_cam_tuple(dc_r) - before)
     # one step removes most of the 0.5 .. 2.2 px perturbation (this also pins the oracle's Schur solve)
     assert np.abs(_cam_tuple(dc_r) - true_cam).max() < 0.1
-    # The 5x5 Schur system is a difference of nearly equal binary32 sums; summation order moves the
-    # solution by a few 1e-3 px (the reference's own acceptance for converged intrinsics is 1e-3 px
-    # after 100 BA calls, test_intrinsics_optimization_geometric_residual.cc:538-542).
-    assert np.abs(_cam_tuple(dc_g) - _cam_tuple(dc_r)).max() < 1e-2 * max(1.0, step.max())
-    assert a_g == pytest.approx(a_r, abs=2e-4)
+    assert np.array_equal(_bits(_cam_tuple(dc_g)), _bits(_cam_tuple(dc_r))), (_cam_tuple(dc_g), _cam_tuple(dc_r))
+    assert np.array_equal(_bits([a_g]), _bits([a_r])), (a_g, a_r)
     cf_r, cf_g = ba.cfactor, g.cfactor.download()
-    assert np.abs(cf_g - cf_r).max() < 0.05 * np.abs(cf_r).max()
     assert np.count_nonzero(cf_r) > 0.5 * cf_r.size
+    assert np.array_equal(_bits(cf_g), _bits(cf_r)), np.abs(cf_g - cf_r).max()
+
+    # second step, from the updated calibration both sides adopted (a != 0 now: expf enters, and the device library and glibc
+    # are one ulp apart at times)
+    _, dc_r2, a_r2 = ba.optimize_intrinsics(True, False)
+    _, dc_g2, a_g2 = g.optimize_intrinsics(True, False)
+    step2 = np.abs(_cam_tuple(dc_r2) - _cam_tuple(dc_r)).max()
+    assert np.abs(_cam_tuple(dc_g2) - _cam_tuple(dc_r2)).max() <= 1e-4 * max(1.0, step2), (_cam_tuple(dc_g2), _cam_tuple(dc_r2))
+    assert a_g2 == pytest.approx(a_r2, abs=1e-6)
 
 
 def test_color_intrinsics_step(scene):
@@ -65,7 +78,7 @@ def test_color_intrinsics_step(scene):
     ba.use_depth, ba.use_desc = 1, 1
     cc_r, _, _ = ba.optimize_intrinsics(False, True)
     cc_g, _, _ = g.optimize_intrinsics(False, True)
-    assert np.allclose(_cam_tuple(cc_g), _cam_tuple(cc_r), rtol=0, atol=2e-3)
+    assert np.array_equal(_bits(_cam_tuple(cc_g)), _bits(_cam_tuple(cc_r))), (_cam_tuple(cc_g), _cam_tuple(cc_r))
 
 
 def _pcg_setup(scene, mode):

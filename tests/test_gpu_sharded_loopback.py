@@ -168,3 +168,23 @@ def test_sharded_pcg_and_intrinsics_follow_the_unsharded_run():
     for r in results:
         merged[:, r["mine"]] = r["surfels"]
     assert np.median(np.abs(merged[:3] - ref["surfels"][:3])) < 1e-5
+
+
+def test_sharded_intrinsics_step_is_the_unsharded_step():
+    """The alternating scheme's intrinsics step alone (depth camera, deformation parameter, cfactor cells, colour camera) on
+    two shards: its accumulators are binary64 sums of per-tile / per-pair binary32 terms (kernels_intrinsics.hip), exchanged
+    as BAHIP_SUM_F64, and the shards consist of whole 64-surfel tiles, so every rank ends with the bits of the unsharded run."""
+    def step(g):
+        g.bind_keyframes()
+        g.optimize_intrinsics(True, True)
+        return 0
+
+    ref, results, loop, N = _run_sharded_and_unsharded(step, seed=12)
+    assert loop.calls == ITERATIONS                                   # one exchange per step
+    for which in ("color_cam", "depth_cam"):
+        a, b, c = (getattr(x["scene"], which) for x in (results[0], results[1], ref))
+        assert (a.fx, a.fy, a.cx, a.cy) == (b.fx, b.fy, b.cx, b.cy) == (c.fx, c.fy, c.cx, c.cy), which
+    assert results[0]["scene"].dp.a == results[1]["scene"].dp.a == ref["scene"].dp.a
+    cf = [x["scene"].cfactor.download() for x in (results[0], results[1], ref)]
+    assert np.array_equal(cf[0].view(np.uint32), cf[2].view(np.uint32)) and np.array_equal(cf[1].view(np.uint32), cf[2].view(np.uint32))
+    assert np.count_nonzero(cf[2]) > 0.5 * cf[2].size
