@@ -105,12 +105,18 @@ def test_bundle_adjustment_fixed_surfels(scene, use_pcg):
         d_gpu_ref, d_gpu_64, d_ref_64 = (_translation_rmse(a, b) for a, b in ((got_poses, ref_poses), (got_poses, poses64), (ref_poses, poses64)))
         print("PCG end to end, translation RMSE [m]: backend vs binary32 oracle %.3g, backend vs binary64 CG %.3g, binary32 oracle vs binary64 CG %.3g"
               % (d_gpu_ref, d_gpu_64, d_ref_64))
-        # the backend is as close to the binary64 solution as the binary32 restatement of the reference is (factor 3: the two
-        # binary32 runs are two samples of the same rounding noise), and the two binary32 runs are no further apart than the
-        # sum of their distances to it
-        assert d_gpu_64 <= 3.0 * d_ref_64 + 1e-5, (d_gpu_64, d_ref_64)
+        # Measured on the MI355X: backend vs binary64 CG 3.6e-7 m, binary32 oracle vs binary64 CG 9.4e-5 m, backend vs binary32
+        # oracle 9.4e-5 m -- the backend (tree-shaped sums, fixed-point pose blocks) sits on the binary64 solution; it is the
+        # oracle's sequential binary32 sums over 1e5 terms that wander.  So the north-star gate (1e-5 m) is asserted against the
+        # binary64 conjugate gradient, and the binary32 oracle only has to be as close to the backend as it is to that.
+        assert d_gpu_64 <= 1e-5, (d_gpu_64, d_ref_64)
         assert d_gpu_ref <= d_gpu_64 + d_ref_64 + 1e-5
         assert d_gpu_ref <= 1e-3
+        got64 = orc64.surfel_data[:3, :orc64.surfels_size]
+        if ba.surfel_count() == orc64.surfels_size:
+            dpos = np.abs(ba.download_surfels(8)[:3] - got64).max(axis=0)
+            print("PCG end to end, surfel positions vs binary64 CG: median %.3g, 99.9 %% %.3g, max %.3g m" % tuple(np.quantile(dpos, [0.5, 0.999, 1.0])))
+            assert np.count_nonzero(dpos > 1e-5) <= 1e-3 * dpos.size
         assert abs(ba.surfel_count() - orc.surfels_size) <= 5e-3 * orc.surfels_size
 
 
