@@ -533,7 +533,14 @@ __global__ void jacobian_debug_kernel(int kind, const float* __restrict__ in, fl
 __global__ void exact_math_debug_kernel(int kind, const float* __restrict__ in, float* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[i] = kind == 0 ? rcp_exact(in[i]) : sqrt_exact(in[i]);
+  if (kind == 0) out[i] = rcp_exact(in[i]);
+  else if (kind == 1) out[i] = sqrt_exact(in[i]);
+  else if (kind == 4) out[i] = atan_det(in[i]);
+  else {   // 2: sin, 3: cos (se3_device.h: sincos_det)
+    float sn, cs;
+    sincos_det(in[i], &sn, &cs);
+    out[i] = kind == 2 ? sn : cs;
+  }
 }
 void launch_exact_math_debug(hipStream_t stream, int kind, const float* in, float* out, size_t n) {
   if (n) hipLaunchKernelGGL(exact_math_debug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, in, out, n);

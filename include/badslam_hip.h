@@ -336,7 +336,8 @@ int bahip_debug_wave_reduce(bahip_context* ctx, const float* in_64x28, float* ou
  * (scripts/profile_round.sh). */
 int bahip_debug_read_pattern(bahip_context* ctx, size_t bytes, int pattern, int repeats);
 /* rcp_exact (kind 0) / sqrt_exact (kind 1) of the device code on n host values (ba_device.h: the few-instruction exact
- * reciprocal and square root the sweeps use instead of the compiler's IEEE sequences); checked exhaustively by the tests. */
+ * reciprocal and square root the sweeps use instead of the compiler's IEEE sequences); checked exhaustively by the tests.
+ * kind 2 / 3 / 4: the defined sin / cos / atan of the SE(3) exponential and logarithm (se3_device.h). */
 int bahip_debug_exact_math(bahip_context* ctx, int kind, const float* in, float* out, size_t n);
 int bahip_debug_pose_step(bahip_context* ctx, const float* H21_b6, const float* global_T_frame, float* out_25);
 int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, uint64_t* counts_out);

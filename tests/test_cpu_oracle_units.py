@@ -280,3 +280,30 @@ def test_assign_colors_is_the_mean_of_the_bilinear_samples():
     dist = np.abs(colors[seen].astype(np.float64)[:, None, :] - means[None]).max(2).min(1)
     assert dist.max() <= 1                                      # float rounding of the mean may differ by one level
     assert len(np.unique(colors[seen], axis=0)) >= 3            # several visibility patterns occur
+
+
+def test_defined_sin_cos_atan_are_correctly_rounded_almost_everywhere():
+    """orc_sincos / orc_atan (binary64 range reduction + polynomial, rounded to binary32): the SE(3) exponential and logarithm
+    of both the oracle and the kernels use them instead of libm / the device library, so that pose updates are bit-identical.
+    They must be as good as libm: within 1 ulp of the correctly rounded value, and equal to it but for rare ties."""
+    import ctypes as C
+    from oracle import binding as ob
+    L = ob.lib()
+    L.orc_atan.restype = C.c_float
+    L.orc_atan.argtypes = [C.c_float]
+    L.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-3.2, 3.2, 12000), rng.uniform(-1e-3, 1e-3, 3000), rng.uniform(-40, 40, 3000),
+                        np.array([0.0, 1e-30, np.pi, -np.pi, np.pi / 2, np.pi / 4])]).astype(np.float32)
+    sn, cs = C.c_float(), C.c_float()
+    got = np.empty((3, x.size), np.float32)
+    for i, v in enumerate(x):
+        L.orc_sincos(float(v), C.byref(sn), C.byref(cs))
+        got[:, i] = sn.value, cs.value, L.orc_atan(float(v))
+    x64 = x.astype(np.float64)
+    for row, exact in zip(got, (np.sin(x64), np.cos(x64), np.arctan(x64))):
+        rounded = exact.astype(np.float32)
+        a, b = row.view(np.int32).astype(np.int64), rounded.view(np.int32).astype(np.int64)
+        a, b = np.where(a < 0, -(a & 0x7fffffff), a), np.where(b < 0, -(b & 0x7fffffff), b)
+        ulps = np.abs(a - b)
+        assert ulps.max() <= 1 and np.count_nonzero(ulps) <= 1e-3 * x.size, (int(ulps.max()), int(np.count_nonzero(ulps)))
