@@ -410,8 +410,9 @@ class OracleBA:
         return float(c), int(n.value)
 
     def pcg_assemble(self, optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=False,
-                     optimize_color_intrinsics=False, gauge_keyframe=0):
-        """r = -J^T W F and M = diag(J^T W J) of the PCG scheme for the current state (test hook)."""
+                     optimize_color_intrinsics=False, gauge_keyframe=0, binary64=False):
+        """r = -J^T W F and M = diag(J^T W J) of the PCG scheme for the current state (test hook).  binary64: the same binary32
+        terms accumulated in binary64 (oracle_pcg.c compiled with -DORC_PCG_DOUBLE), rounded to binary32 at the end."""
         opt = BAOptions(self.use_depth, self.use_desc, int(optimize_depth_intrinsics), int(optimize_color_intrinsics), 0,
                         int(optimize_poses), int(optimize_geometry), 1, 1, 0, len(self.keyframes) - 1, 0,
                         int(self.min_observation_count), float(self.merge_factor), 30, int(gauge_keyframe))
@@ -424,8 +425,9 @@ class OracleBA:
         cap = 6 * len(self.keyframes) + 3 * self.surfels_size + 5 + self.cf_w * self.cf_h + 4
         r = np.zeros(cap, np.float32)
         M = np.zeros(cap, np.float32)
-        self.L.orc_pcg_assemble.restype = C.c_uint32
-        U = self.L.orc_pcg_assemble(C.byref(st), C.byref(opt), _ptr(r, C.c_float), _ptr(M, C.c_float), C.c_uint32(cap))
+        fn = self.L.orc_pcg_assemble_f64 if binary64 else self.L.orc_pcg_assemble
+        fn.restype = C.c_uint32
+        U = fn(C.byref(st), C.byref(opt), _ptr(r, C.c_float), _ptr(M, C.c_float), C.c_uint32(cap))
         return r[:U], M[:U]
 
     # -- BA --

@@ -148,6 +148,90 @@ def test_many_keyframes_batched_pose_estimation(many, pose_parts, request):
             g.keyframes[k]["pose"] = np.asarray(T, np.float32)
 
 
+def test_many_keyframes_intrinsics_step_bit_exact(many):
+    """The intrinsics sweep (kernels_intrinsics.hip) over 200 keyframes -- several 64-keyframe chunks in its candidate loop --
+    with perturbed cameras: depth camera, deformation parameter, every cfactor cell and the colour camera come out with the
+    oracle's bits (the sums are defined: DESIGN.md section 3)."""
+    scene, orc, g = many
+    K = len(orc.keyframes)
+    orc.use_depth, orc.use_desc = 1, 1
+    data, active = common.oracle_surfels(orc)
+    g.upload_surfels(data, np.ones_like(active))
+    orc.active[:data.shape[1]] = 1
+    _set_activations(orc, g, np.zeros(K, np.int64))
+    for k, T in enumerate(scene.poses_gt):
+        orc.set_pose(k, T)
+        g.keyframes[k]["pose"] = np.asarray(T, np.float32)
+    saved = [(obj, name, tuple(getattr(getattr(obj, name), f) for f in ("fx", "fy", "cx", "cy"))) for obj in (orc, g)
+             for name in ("depth_cam", "color_cam")]
+    cf_saved, a_saved = orc.cfactor.copy(), orc.dp.a
+    try:
+        for obj in (orc, g):
+            obj.depth_cam.fx += 0.5; obj.depth_cam.fy -= 0.6; obj.depth_cam.cx += 1.23; obj.depth_cam.cy -= 1.17
+            obj.color_cam.fx += 0.4; obj.color_cam.fy -= 0.3; obj.color_cam.cx += 0.8; obj.color_cam.cy -= 0.6
+        g.set_intrinsics()
+        g.bind_keyframes()
+        cc_r, dc_r, a_r = orc.optimize_intrinsics(True, True, apply=False)
+        cc_g, dc_g, a_g = g.optimize_intrinsics(True, True, apply=False)
+        for got, ref in ((dc_g, dc_r), (cc_g, cc_r)):
+            assert (got.fx, got.fy, got.cx, got.cy) == (ref.fx, ref.fy, ref.cx, ref.cy), ((got.fx, got.fy, got.cx, got.cy), (ref.fx, ref.fy, ref.cx, ref.cy))
+        assert np.float32(a_g) == np.float32(a_r)
+        cf_g = g.cfactor.download()
+        assert np.count_nonzero(orc.cfactor) > 0.5 * orc.cfactor.size
+        assert np.array_equal(cf_g.view(np.uint32), orc.cfactor.view(np.uint32))
+    finally:
+        for obj, name, values in saved:
+            cam = getattr(obj, name)
+            cam.fx, cam.fy, cam.cx, cam.cy = values
+        orc.cfactor[:] = cf_saved
+        orc.dp.a = a_saved
+        g.dp.a = a_saved
+        g.cfactor.upload(cf_saved)
+        g.set_intrinsics()
+
+
+def test_many_keyframes_pcg_assembly(many):
+    """PCGInit over 200 keyframes: the surfel block of r = -J^T W F and M = diag(J^T W J) bit for bit (per-surfel sums in
+    keyframe order), the 6 x 199 pose block to the summation noise of binary32 atomics."""
+    scene, orc, g = many
+    K = len(orc.keyframes)
+    orc.use_depth, orc.use_desc = 1, 1
+    data, active = common.oracle_surfels(orc)
+    g.upload_surfels(data, np.ones_like(active))
+    orc.active[:data.shape[1]] = 1
+    _set_activations(orc, g, np.zeros(K, np.int64))
+    rng = np.random.Generator(np.random.PCG64(43))
+    perturbed = [synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    for k, T in enumerate(perturbed):
+        orc.set_pose(k, T)
+        g.keyframes[k]["pose"] = np.asarray(T, np.float32)
+    g.bind_keyframes()
+    g.update_surfel_normals()
+    orc.update_surfel_normals()
+    r_ref, M_ref = orc.pcg_assemble(True, True, False, False, gauge_keyframe=1)
+    g.pcg_iteration(optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=False, optimize_color_intrinsics=False,
+                    max_inner_iterations=0, gauge_keyframe=1)
+    U = len(r_ref)
+    r, M = g.read_pcg_vector(0, U), g.read_pcg_vector(1, U)
+    N = data.shape[1]
+    ps = 6 * (K - 1)
+    assert U == ps + 3 * N
+    assert np.array_equal(r[ps:].view(np.uint32), r_ref[ps:].view(np.uint32))
+    assert np.array_equal(M[ps:].view(np.uint32), M_ref[ps:].view(np.uint32))
+    # The pose block is a sum over ~1e5 signed terms per entry.  The oracle's binary32 running sums are the noisy side here
+    # (5e-2 of sqrt(M) at this size), so the block is held against the same terms accumulated in binary64: by Cauchy-Schwarz
+    # |sum w J r| <= sqrt(M) * sqrt(cost), so the summation noise is measured in units of sqrt(M).
+    r64, M64 = orc.pcg_assemble(True, True, False, False, gauge_keyframe=1, binary64=True)
+    scale = np.sqrt(np.maximum(M64[:ps], 1e-30)) + 1e-30
+    noise_gpu, noise_oracle32 = np.abs((r[:ps] - r64[:ps]) / scale).max(), np.abs((r_ref[:ps] - r64[:ps]) / scale).max()
+    print("pose block of r, worst deviation from the binary64 sum in units of sqrt(M): backend %.3g, binary32 oracle %.3g" % (noise_gpu, noise_oracle32))
+    assert np.abs(M[:ps] - M64[:ps]).max() <= 1e-5 * np.abs(M64[:ps]).max()
+    assert noise_gpu < 2e-3
+    for k, T in enumerate(scene.poses_gt):     # leave the shared fixture as it was
+        orc.set_pose(k, T)
+        g.keyframes[k]["pose"] = np.asarray(T, np.float32)
+
+
 # ---- (b), (c): BASELINE configs[2] at full size -------------------------------------------------------------------------
 def _bench_scene(**overrides):
     sys.path.insert(0, ROOT)
