@@ -128,6 +128,10 @@ static_assert(sizeof(PoseWork) == 128, "PoseWork is read back as 32-word records
 // in the BA loop (inactive ones + those that did not move).  One device-to-host copy per round brings work items and counters.
 constexpr int kPoseCounterConverged = 32;
 constexpr int kPoseTailRecords = 2;
+// Behind the counter records (device only): the indices of the work items still iterating after the latest Gauss-Newton
+// round, in arbitrary order (pose_solve_kernel appends with the same atomic that counts them).  The later rounds of a phase
+// sweep over this list instead of over all work items (a handful of entries instead of K).
+__host__ __device__ constexpr size_t pose_work_records(size_t work_items) { return work_items + kPoseTailRecords + (work_items + 31) / 32; }
 
 // Unknown-vector layout of the PCG scheme (B/direct_ba_pcg.cc:232-307): [6 per non-gauge keyframe |
 // geom_stride per surfel | 5 + S depth intrinsics | 4 colour intrinsics].

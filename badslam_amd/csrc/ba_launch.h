@@ -40,7 +40,8 @@ void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry*
 // kernels_pose.hip
 size_t pose_tile_bounds_bytes(uint32_t surfels);   // size of the per-tile bounding-sphere buffer launch_pose_accumulate needs
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
-                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds);
+                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
+                            int num_listed /* stored_bounds: entries of the list of work items still iterating */);
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out);
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out);

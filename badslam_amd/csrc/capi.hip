@@ -244,7 +244,7 @@ int ensure_work(bahip_context* ctx, int n) {
   const int cap = n + 64;
   // allocate first, swap on success: a failed grow leaves the context as it was
   PoseWork* work = nullptr; HbFixed* hb = nullptr; PoseWork* pinned = nullptr;
-  const size_t records = (size_t)cap + kPoseTailRecords;
+  const size_t records = pose_work_records((size_t)cap);
   if (hipMalloc(&work, sizeof(PoseWork) * records) != hipSuccess || hipMalloc(&hb, sizeof(HbFixed) * kHbStride * cap) != hipSuccess ||
       hipHostMalloc(&pinned, sizeof(PoseWork) * records) != hipSuccess) {
     hipFree(work); hipFree(hb); if (pinned) hipHostFree(pinned);
@@ -329,7 +329,7 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     const double t0 = host_timing ? now() : 0;
     timer_begin(ctx, 2, round == 0, iterating);
     launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb, ctx->dev_tile_bounds,
-                           /*stored_bounds*/ round > 0);
+                           /*stored_bounds*/ round > 0, /*num_listed*/ iterating);
     timer_end(ctx, 2);
     CHECK_LAUNCH();
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
@@ -478,7 +478,7 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
                   hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)) == hipSuccess &&
                   hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)) == hipSuccess &&
-                  hipMalloc(&ctx->dev_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)) == hipSuccess &&
+                  hipMalloc(&ctx->dev_work1, sizeof(PoseWork) * pose_work_records(1)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)) == hipSuccess &&
                   hipMalloc(&ctx->dev_Hb1, sizeof(HbFixed) * kHbStride) == hipSuccess;
   if (!ok) {
@@ -823,7 +823,7 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ensure_tile_bounds(ctx, surfels->surfels_size)) return 1;
   launch_pose_accumulate(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_frame1, ctx->dev_work1, 1,
-                         make_view(surfels), ctx->dev_Hb1, ctx->dev_tile_bounds, /*stored_bounds*/ false);
+                         make_view(surfels), ctx->dev_Hb1, ctx->dev_tile_bounds, /*stored_bounds*/ false, /*num_listed*/ 0);
   CHECK_LAUNCH();
   if (reduce_over_ranks(ctx, ctx->dev_Hb1, kHbStride, BAHIP_SUM_I64)) return 1;
   HbFixed* fixed = reinterpret_cast<HbFixed*>(ctx->pinned_f);   // 28 x 8 bytes of the 64-float pinned buffer

@@ -60,17 +60,29 @@ void pose_counters_dump() {
 template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
 pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
-                       int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds) {
+                       int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
+                       int num_listed) {
   const uint32_t tile = xcd_chunked_tile(blockIdx.x);
   const int lane = threadIdx.x & 63;
+  // Later rounds (stored_bounds): the items are the num_listed entries of the list behind the counter records -- the work
+  // items still iterating -- instead of all num_work work items.
+  const int* __restrict__ listed = reinterpret_cast<const int*>(work + num_work + kPoseTailRecords);
+  const int num_items = stored_bounds ? num_listed : num_work;
+  auto work_item_of = [&](int item) { return stored_bounds ? load_global(listed + item) : item; };
   WaveBounds wb;
   if (stored_bounds) {
     wb = tile_bounds[tile];     // wave-uniform address: scalar loads
     if (wb.r < 0.f) return;
     bool any = false;
-    for (int base = blockIdx.y; base < num_work && !any; base += 64 * gridDim.y) {
+    for (int base = blockIdx.y; base < num_items && !any; base += 64 * gridDim.y) {
       const int item = base + lane * gridDim.y;
-      any = __any(item < num_work && !work[item].done && sphere_may_project(in, work[item].F, wb)) != 0;
+      bool sees = false;
+      if (item < num_items) {
+        float f[12];
+        load_candidate(work[work_item_of(item)].F, nullptr, f, nullptr);
+        sees = sphere_may_project(in, f, wb);
+      }
+      any = __any(sees) != 0;
     }
     if (!any) return;
   }
@@ -112,14 +124,16 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     pending_w = -1;
   };
   for_each_candidate(
-      num_work,
-      [&](int w) {
+      num_items,
+      [&](int item) {
+        const int w = work_item_of(item);
         float f[12];
         int32_t done;
         load_candidate(work[w].F, &work[w].done, f, &done);
         return !done && sphere_may_project(in, f, wb);
       },
-      [&](int w) {
+      [&](int item) {
+    const int w = __builtin_amdgcn_readfirstlane(work_item_of(item));
     const float* F = work[w].F;
     const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
     // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
@@ -297,7 +311,8 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
     }
     host_out[w] = pw;
   } else {
-    atomicAdd(&counters[round], 1);
+    const int slot = atomicAdd(&counters[round], 1);
+    counters[kPoseTailRecords * 32 + slot] = w;   // the list of work items still iterating (ba_device.h: pose_work_records)
   }
 }
 
@@ -318,26 +333,37 @@ void launch_pose_step_debug(hipStream_t stream, const float* in, float* out) {
   hipLaunchKernelGGL(pose_step_debug_kernel, dim3(1), dim3(64), 0, stream, in, out);
 }
 
-// Builds one work item per bound keyframe (skipping kInactive ones), B/direct_ba_alternating.cc:547-553.
-__global__ void pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs, PoseWork* __restrict__ work,
-                                                HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out) {
+// Builds one work item per bound keyframe (skipping kInactive ones), B/direct_ba_alternating.cc:547-553.  One workgroup
+// (kSingleBlock): the count of inactive keyframes is a __syncthreads_count instead of one thread walking the table (200
+// dependent loads took 10 us); larger tables take the multi-block form, whose thread 0 counts.
+template <bool kSingleBlock>
+__global__ void __launch_bounds__(kSingleBlock ? 1024 : 64)
+pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs, PoseWork* __restrict__ work,
+                                HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= num_kfs) return;
-  PoseWork& pw = work[k];
-  pw.kf_index = k;
-  pw.iterations = 0;
-  pw.converged = 0;
-  pw.done = (frames[k].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
-  pw.moved = 0;
-  for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
-  for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
-  for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
-  if (pw.done) host_out[k] = pw;   // skipped keyframes: their (unchanged) record
-  if (k == 0) {   // the counters behind the work items: per-round not-done counts = 0, converged = the inactive keyframes
-    int* counters = reinterpret_cast<int*>(work + num_kfs);
-    int inactive = 0;
-    for (int j = 0; j < num_kfs; ++j) inactive += (frames[j].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
-    for (int c = 0; c < kPoseTailRecords * 32; ++c) counters[c] = (c == kPoseCounterConverged) ? inactive : 0;
+  const bool in_range = k < num_kfs;
+  const bool inactive = in_range && frames[k].activation == BAHIP_KF_INACTIVE;
+  if (in_range) {
+    PoseWork& pw = work[k];
+    pw.kf_index = k;
+    pw.iterations = 0;
+    pw.converged = 0;
+    pw.done = inactive ? 1 : 0;
+    pw.moved = 0;
+    for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
+    for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
+    for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
+    if (pw.done) host_out[k] = pw;   // skipped keyframes: their (unchanged) record
+  }
+  // the counters behind the work items: per-round not-done counts = 0, converged = the inactive keyframes
+  int* counters = reinterpret_cast<int*>(work + num_kfs);
+  if (kSingleBlock) {
+    const int num_inactive = __syncthreads_count(inactive ? 1 : 0);
+    if (threadIdx.x < kPoseTailRecords * 32) counters[threadIdx.x] = (threadIdx.x == kPoseCounterConverged) ? num_inactive : 0;
+  } else if (k == 0) {
+    int num_inactive = 0;
+    for (int j = 0; j < num_kfs; ++j) num_inactive += (frames[j].activation == BAHIP_KF_INACTIVE) ? 1 : 0;
+    for (int c = 0; c < kPoseTailRecords * 32; ++c) counters[c] = (c == kPoseCounterConverged) ? num_inactive : 0;
   }
 }
 
@@ -368,8 +394,10 @@ __global__ void __launch_bounds__(1024) window_and_propagate_kernel(KfEntry* __r
                                                                     const uint8_t* __restrict__ in_window,
                                                                     const int* __restrict__ offsets, const int* __restrict__ indices) {
   const int k = threadIdx.x;
-  if (k < num_kfs) frames[k].activation = in_window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
-  __syncthreads();
+  const bool inside = k < num_kfs && in_window[k];
+  if (k < num_kfs) frames[k].activation = inside ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+  // (also the barrier between the two steps) a window that holds every keyframe leaves nothing to wake up
+  if (__syncthreads_count(inside ? 1 : 0) == num_kfs) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int row = wave; row < num_kfs; row += 16) {
     if (!in_window[row]) continue;   // wave-uniform
@@ -404,7 +432,8 @@ size_t pose_tile_bounds_bytes(uint32_t surfels) {
 }
 
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
-                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds) {
+                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
+                            int num_listed) {
   if (s.size == 0 || num_work == 0) return;
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
@@ -419,9 +448,9 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   const PoseWork* pw = static_cast<const PoseWork*>(work);
   WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);
   const int sb = stored_bounds ? 1 : 0;
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed);
 }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
@@ -433,8 +462,12 @@ void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb
 
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out) {
   if (num_kfs == 0) return;
-  hipLaunchKernelGGL(pose_init_from_keyframes_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs,
-                     static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out));
+  if (num_kfs <= 1024)
+    hipLaunchKernelGGL(pose_init_from_keyframes_kernel<true>, dim3(1), dim3(1024), 0, stream, frames, num_kfs,
+                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out));
+  else
+    hipLaunchKernelGGL(pose_init_from_keyframes_kernel<false>, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs,
+                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out));
 }
 
 
