@@ -127,6 +127,11 @@ static_assert(sizeof(PoseWork) == 128, "PoseWork is read back as 32-word records
 // Gauss-Newton round (round < BAHIP_MAX_POSE_ITERATIONS = 30), [kPoseCounterConverged] = keyframes that count as converged
 // in the BA loop (inactive ones + those that did not move).  One device-to-host copy per round brings work items and counters.
 constexpr int kPoseCounterConverged = 32;
+// [kPoseCounterTicket]: workgroups of pose_solve_kernel that have finished (the last one publishes the counters to the host);
+// [kPoseCounterSequence] (host copy only): the sequence number of the launch whose counters the host copy holds -- the host
+// polls it instead of synchronising the stream and copying 256 bytes (capi.hip: run_pose_rounds).
+constexpr int kPoseCounterTicket = 33;
+constexpr int kPoseCounterSequence = 34;
 constexpr int kPoseTailRecords = 2;
 // Behind the counter records (device only): the indices of the work items still iterating after the latest Gauss-Newton
 // round, in arbitrary order (pose_solve_kernel appends with the same atomic that counts them).  The later rounds of a phase

@@ -43,7 +43,8 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
                             int num_listed /* stored_bounds: entries of the list of work items still iterating */);
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
-                       int update_activation, int round, void* host_out);
+                       int update_activation, int round, void* host_out,
+                       int sequence /* published to the host copy of the counters when the launch is complete */);
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out);
 
 void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window, const int* offsets,

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 
 #include <string>
@@ -104,6 +105,7 @@ struct bahip_context {
   uint8_t* dev_window = nullptr;
   size_t window_capacity = 0;
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
+  bool poll_disabled = false;        // the host copy of the pose counters is not updated by the kernel on this system: synchronise instead
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
 
@@ -246,7 +248,7 @@ int ensure_work(bahip_context* ctx, int n) {
   PoseWork* work = nullptr; HbFixed* hb = nullptr; PoseWork* pinned = nullptr;
   const size_t records = pose_work_records((size_t)cap);
   if (hipMalloc(&work, sizeof(PoseWork) * records) != hipSuccess || hipMalloc(&hb, sizeof(HbFixed) * kHbStride * cap) != hipSuccess ||
-      hipHostMalloc(&pinned, sizeof(PoseWork) * records) != hipSuccess) {
+      hipHostMalloc(&pinned, sizeof(PoseWork) * records, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     hipFree(work); hipFree(hb); if (pinned) hipHostFree(pinned);
     return fail("allocation of the pose work items failed", __FILE__, __LINE__);
   }
@@ -314,6 +316,26 @@ int ensure_tile_bounds(bahip_context* ctx, uint32_t surfels) {
   return 0;
 }
 
+// Waits until pose_solve_kernel has published `sequence` in the host copy of the counter records.  Polling a word of mapped
+// host memory costs a microsecond where hipStreamSynchronize + a 256-byte copy cost 25.  If the word does not show up within
+// two seconds (a runtime that does not map the allocation coherently), fall back to synchronising and copying.
+int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_tail, const PoseWork* dev_tail, int sequence) {
+  volatile int* published = reinterpret_cast<volatile int*>(host_tail) + kPoseCounterSequence;
+  if (!ctx->poll_disabled) {
+    const auto start = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+      if (*published == sequence) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+      if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - start > std::chrono::seconds(2)) break;
+    }
+    ctx->poll_disabled = true;
+    fprintf(stderr, "badslam_hip: the pose counters were not published to host memory; falling back to stream synchronisation\n");
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (*published == sequence) return 0;
+  HIP_TRY(hipMemcpy(host_tail, dev_tail, sizeof(PoseWork) * kPoseTailRecords, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // Batched Gauss-Newton rounds over `num_work` work items already initialised on the device.
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
@@ -335,13 +357,17 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
     if (reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
     timer_begin(ctx, 3, round == 0);
-    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, round, host_work);
+    // process-wide and increasing: page-locked memory is recycled between contexts, and a word left behind by an earlier
+    // context must never equal a sequence number somebody is going to wait for
+    static std::atomic<int> g_pose_sequence{0};
+    const int sequence = ++g_pose_sequence;
+    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, round, host_work, sequence);
     timer_end(ctx, 3);
     CHECK_LAUNCH();
-    // per round only the counters are copied (256 bytes); finished work items were written to host_work by the kernel itself
-    HIP_TRY(hipMemcpyAsync(host_work + num_work, dev_work + num_work, sizeof(PoseWork) * kPoseTailRecords, hipMemcpyDeviceToHost, ctx->stream));
+    // No stream synchronisation and no copy per round: the solve kernel writes finished work items and, last, the counters and
+    // this launch's sequence number into host_work (mapped, coherent host memory); the host polls the sequence number.
     const double t1 = host_timing ? now() : 0;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (wait_for_pose_sequence(ctx, host_work + num_work, dev_work + num_work, sequence)) return 1;
     if (host_timing) {
       t_launch += t1 - t0; t_wait += now() - t1;
       if (++n_rounds % 30 == 0) fprintf(stderr, "[pose rounds, us per round] enqueue %.1f | wait %.1f\n", t_launch / n_rounds, t_wait / n_rounds);
@@ -479,7 +505,7 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
                   hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)) == hipSuccess &&
                   hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)) == hipSuccess &&
                   hipMalloc(&ctx->dev_work1, sizeof(PoseWork) * pose_work_records(1)) == hipSuccess &&
-                  hipHostMalloc(&ctx->pinned_work1, sizeof(PoseWork) * (1 + kPoseTailRecords)) == hipSuccess &&
+                  hipHostMalloc(&ctx->pinned_work1, sizeof(PoseWork) * (1 + kPoseTailRecords), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
                   hipMalloc(&ctx->dev_Hb1, sizeof(HbFixed) * kHbStride) == hipSuccess;
   if (!ok) {
     bahip_context_destroy(ctx);   // frees whatever was allocated (hipFree(nullptr) is a no-op)

@@ -271,48 +271,64 @@ __device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* 
 // so the host needs no copy of the work array, only the 256 bytes of counters per round.
 __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
                                   KfEntry* __restrict__ frames, int write_back, int update_activation, int round,
-                                  PoseWork* __restrict__ host_out) {
+                                  PoseWork* __restrict__ host_out, int sequence) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= num_work) return;
-  PoseWork& pw = work[w];
-  if (pw.done) return;
   int* counters = reinterpret_cast<int*>(work + num_work);
-  HbFixed* fixed = Hb + (size_t)w * kHbStride;
-  float hb[27];
-  // the fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
-  for (int c = 0; c < 27; ++c) hb[c] = (float)hb_from_fixed(fixed[c]);
-  for (int c = 0; c < kHbStride; ++c) fixed[c] = 0;
-  float xf[6], next[7];
-  pose_gn_step(hb, pw.T, xf, next);
-  for (int c = 0; c < 7; ++c) pw.T[c] = next[c];
-  float inv[7];
-  se3_inverse(next, inv);
-  se3_matrix3x4(inv, pw.F);
-  pw.iterations += 1;
-  const bool conv = is_scale1_pose_converged(xf);
-  if (conv) pw.converged = 1;
-  if (conv || pw.iterations >= BAHIP_MAX_POSE_ITERATIONS) {
-    pw.done = 1;
-    if (write_back) {
-      KfEntry& kf = frames[pw.kf_index];
-      for (int c = 0; c < 7; ++c) kf.global_T_frame[c] = next[c];
-      for (int c = 0; c < 12; ++c) kf.pose.F[c] = pw.F[c];
-      se3_rotation(next, kf.pose.GR);
-      if (update_activation) {
-        float inv0[7], diff[7], lg[6];
-        se3_inverse(pw.T0, inv0);        // Keyframe::frame_T_global() of the old pose
-        se3_mul(inv0, next, diff);
-        se3_log(diff, lg);
-        const bool moved = !is_scale1_pose_converged(lg);
-        kf.activation = moved ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
-        pw.moved = moved ? 1 : 0;
-        if (!moved) atomicAdd(&counters[kPoseCounterConverged], 1);
+  if (w < num_work && !work[w].done) {
+    PoseWork& pw = work[w];
+    HbFixed* fixed = Hb + (size_t)w * kHbStride;
+    float hb[27];
+    // the fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
+    for (int c = 0; c < 27; ++c) hb[c] = (float)hb_from_fixed(fixed[c]);
+    for (int c = 0; c < kHbStride; ++c) fixed[c] = 0;
+    float xf[6], next[7];
+    pose_gn_step(hb, pw.T, xf, next);
+    for (int c = 0; c < 7; ++c) pw.T[c] = next[c];
+    float inv[7];
+    se3_inverse(next, inv);
+    se3_matrix3x4(inv, pw.F);
+    pw.iterations += 1;
+    const bool conv = is_scale1_pose_converged(xf);
+    if (conv) pw.converged = 1;
+    if (conv || pw.iterations >= BAHIP_MAX_POSE_ITERATIONS) {
+      pw.done = 1;
+      if (write_back) {
+        KfEntry& kf = frames[pw.kf_index];
+        for (int c = 0; c < 7; ++c) kf.global_T_frame[c] = next[c];
+        for (int c = 0; c < 12; ++c) kf.pose.F[c] = pw.F[c];
+        se3_rotation(next, kf.pose.GR);
+        if (update_activation) {
+          float inv0[7], diff[7], lg[6];
+          se3_inverse(pw.T0, inv0);        // Keyframe::frame_T_global() of the old pose
+          se3_mul(inv0, next, diff);
+          se3_log(diff, lg);
+          const bool moved = !is_scale1_pose_converged(lg);
+          kf.activation = moved ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+          pw.moved = moved ? 1 : 0;
+          if (!moved) atomicAdd(&counters[kPoseCounterConverged], 1);
+        }
       }
+      host_out[w] = pw;
+    } else {
+      const int slot = atomicAdd(&counters[round], 1);
+      counters[kPoseTailRecords * 32 + slot] = w;   // the list of work items still iterating (ba_device.h: pose_work_records)
     }
-    host_out[w] = pw;
-  } else {
-    const int slot = atomicAdd(&counters[round], 1);
-    counters[kPoseTailRecords * 32 + slot] = w;   // the list of work items still iterating (ba_device.h: pose_work_records)
+  }
+  // The last workgroup to finish publishes the counters to the host copy and then the launch's sequence number, which the
+  // host polls: the records written to host_out above (mapped, coherent host memory) are fenced before it.
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(&counters[kPoseCounterTicket], 1);
+    if (ticket == (int)gridDim.x - 1) {
+      counters[kPoseCounterTicket] = 0;
+      int* host_counters = reinterpret_cast<int*>(host_out + num_work);
+      for (int c = 0; c < kPoseTailRecords * 32; ++c)
+        if (c != kPoseCounterTicket && c != kPoseCounterSequence)
+          host_counters[c] = __hip_atomic_load(&counters[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(&host_counters[kPoseCounterSequence], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -454,10 +470,10 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
 }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
-                       int update_activation, int round, void* host_out) {
+                       int update_activation, int round, void* host_out, int sequence) {
   if (num_work == 0) return;
   hipLaunchKernelGGL(pose_solve_kernel, dim3((num_work + 63) / 64), dim3(64), 0, stream, static_cast<PoseWork*>(work),
-                     num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out));
+                     num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out), sequence);
 }
 
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out) {
