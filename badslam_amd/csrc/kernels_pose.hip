@@ -318,15 +318,18 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
   // host polls: the records written to host_out above (mapped, coherent host memory) are fenced before it.
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int ticket = atomicAdd(&counters[kPoseCounterTicket], 1);
-    if (ticket == (int)gridDim.x - 1) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) is_last = atomicAdd(&counters[kPoseCounterTicket], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (is_last) {   // workgroup-uniform; 64 threads = the 64 counter words
+    int* host_counters = reinterpret_cast<int*>(host_out + num_work);
+    const int c = threadIdx.x;
+    if (c < kPoseTailRecords * 32 && c != kPoseCounterTicket && c != kPoseCounterSequence)
+      host_counters[c] = __hip_atomic_load(&counters[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
       counters[kPoseCounterTicket] = 0;
-      int* host_counters = reinterpret_cast<int*>(host_out + num_work);
-      for (int c = 0; c < kPoseTailRecords * 32; ++c)
-        if (c != kPoseCounterTicket && c != kPoseCounterSequence)
-          host_counters[c] = __hip_atomic_load(&counters[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
       __hip_atomic_store(&host_counters[kPoseCounterSequence], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
