@@ -389,6 +389,16 @@ class OracleBA:
         self.L.orc_update_surfel_normals(C.byref(self.depth_cam), C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),
                                          C.byref(self.surfels))
 
+    def intrinsics_accumulators(self, optimize_depth=True, optimize_color=True):
+        """The binary64 accumulators of the intrinsics step for the current surfel set: (glob[34], cells[S, 8])."""
+        S = self.cf_w * self.cf_h
+        glob, cells = np.zeros(34, np.float64), np.zeros((S, 8), np.float64)
+        self.L.orc_intrinsics_accumulate.restype = None
+        self.L.orc_intrinsics_accumulate(int(optimize_depth), int(optimize_color), self._kf_ptr_array(), len(self.keyframes),
+                                         C.byref(self.color_cam), C.byref(self.depth_cam), C.byref(self.dp), C.byref(self.surfels),
+                                         _ptr(glob, C.c_double), _ptr(cells, C.c_double))
+        return glob, cells
+
     def optimize_intrinsics(self, optimize_depth, optimize_color, apply=True):
         cc, dc, a = Camera(), Camera(), C.c_float()
         self.L.orc_optimize_intrinsics(int(optimize_depth), int(optimize_color), self._kf_ptr_array(), len(self.keyframes),

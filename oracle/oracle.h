@@ -248,6 +248,12 @@ void orc_compact_surfels(orc_surfels* s);
 void orc_sort_surfels_spatially(orc_surfels* s, float grid_cell_size);
 
 /* ---- intrinsics (B/kernel_opt_intrinsics.cc:39-281) ---- */
+/* The accumulators of the intrinsics step alone, binary64, ADDED to glob[34] / cells[8 * cf_width * cf_height] (per sparse
+ * cell: B0..B4, D, b2, observation count): what a surfel-sharded run sums over its ranks. */
+void orc_intrinsics_accumulate(int optimize_depth_intrinsics, int optimize_color_intrinsics,
+                               orc_keyframe* const* kfs, int num_kfs, const orc_camera* color_cam,
+                               const orc_camera* depth_cam, const orc_depth_params* dp, const orc_surfels* s,
+                               double glob[34], double* cells);
 void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_intrinsics,
                              orc_keyframe* const* kfs, int num_kfs, const orc_camera* color_cam,
                              const orc_camera* depth_cam, orc_depth_params* dp, const orc_surfels* s,

@@ -30,21 +30,15 @@ float orc_wave_xor_sum(const float x[64]) {
  * butterfly over the 64 surfels of a tile, then binary64 over the tiles; the per-cell sums are binary64, pair by pair; both
  * are rounded to binary32 before the Schur complement.  (The reference adds binary32 atomics in arbitrary order,
  * B/kernel_opt_intrinsics.cu:217-262.) */
-void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_intrinsics,
-                             orc_keyframe* const* kfs, int num_kfs, const orc_camera* color_cam,
-                             const orc_camera* depth_cam, orc_depth_params* dp, const orc_surfels* s,
-                             orc_camera* out_color_cam, orc_camera* out_depth_cam, float* out_a) {
-  *out_color_cam = *color_cam;
-  *out_depth_cam = *depth_cam;
-  *out_a = dp->a;
-  if (s->surfels_size == 0) return;
+/* The accumulation alone: glob[34] (slots 0..14 A, 15..19 b1, 20..29 colour H, 30..33 colour b) and cells[8 S] (per sparse
+ * cell: B0..B4, D, b2, observation count), both binary64, ADDED to what the arrays hold.  This is what a surfel-sharded run
+ * sums over its ranks (BAHIP_SUM_F64) before the Schur complement. */
+void orc_intrinsics_accumulate(int optimize_depth_intrinsics, int optimize_color_intrinsics,
+                               orc_keyframe* const* kfs, int num_kfs, const orc_camera* color_cam,
+                               const orc_camera* depth_cam, const orc_depth_params* dp, const orc_surfels* s,
+                               double glob[34], double* cells) {
   const unprojector unp = make_unprojector(depth_cam);
   const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
-  const int S = dp->cf_width * dp->cf_height;
-
-  /* slots 0..14 A, 15..19 b1, 20..29 colour H, 30..33 colour b */
-  double glob[34] = {0};
-  double* cells = (double*)calloc((size_t)8 * S, sizeof(double));   /* per cell: B0..B4, D, b2, observation count */
   proj_params* pp = (proj_params*)calloc((size_t)(num_kfs > 0 ? num_kfs : 1), sizeof(proj_params));
   for (int k = 0; k < num_kfs; ++k)
     if (kfs[k]) pp[k] = make_proj_params(depth_cam, dp, s, kfs[k], kfs[k]->frame_T_global);
@@ -109,6 +103,21 @@ void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_i
     for (int q = 0; q < 34; ++q) glob[q] += (double)orc_wave_xor_sum(lanes[q]);
   }
   free(pp);
+}
+
+void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_intrinsics,
+                             orc_keyframe* const* kfs, int num_kfs, const orc_camera* color_cam,
+                             const orc_camera* depth_cam, orc_depth_params* dp, const orc_surfels* s,
+                             orc_camera* out_color_cam, orc_camera* out_depth_cam, float* out_a) {
+  *out_color_cam = *color_cam;
+  *out_depth_cam = *depth_cam;
+  *out_a = dp->a;
+  if (s->surfels_size == 0) return;
+  const unprojector unp = make_unprojector(depth_cam);
+  const int S = dp->cf_width * dp->cf_height;
+  double glob[34] = {0};
+  double* cells = (double*)calloc((size_t)8 * S, sizeof(double));
+  orc_intrinsics_accumulate(optimize_depth_intrinsics, optimize_color_intrinsics, kfs, num_kfs, color_cam, depth_cam, dp, s, glob, cells);
 
   float A[15], b1[K_A_ROWS], color_H[10], color_b[4];
   for (int q = 0; q < 15; ++q) A[q] = (float)glob[q];

@@ -181,3 +181,52 @@ def test_sharded_pcg_exchange_protocol(tmp_path):
         owned = np.load(tmp_path / f"pcg_owned_{r}.npy")
         surfels[owned] = np.load(tmp_path / f"pcg_surfels_{r}.npy")[owned]
     assert np.abs(np.concatenate([h0, surfels]) - exact).max() < 1e-8
+
+
+
+# ---- the intrinsics step's exchange: binary64 accumulators (BAHIP_SUM_F64) ---------------------------------------------------
+def _intrinsics_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from badslam_amd import multigpu
+    from tests import common
+    scene = common.small_scene(num_keyframes=3, seed=6, width=160, height=120)
+    ba = common.build_oracle(scene, 60000)
+    ba.depth_cam.fx += 0.5; ba.depth_cam.cy -= 0.7; ba.color_cam.fy += 0.3      # something to correct
+    N = ba.surfels_size
+    data = ba.surfel_data[:, :N].copy()
+    mine = multigpu.shard_chunks(N, rank, world, chunk=1024)
+    ba.surfel_data[:, :mine.size] = data[:, mine]
+    ba.surfels.surfels_size = mine.size
+    glob, cells = ba.intrinsics_accumulators()
+    t = torch.from_numpy(np.concatenate([glob, cells.ravel()]))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)       # ncclAllReduce(ncclDouble) / the hook with BAHIP_SUM_F64
+    np.save(os.path.join(out_dir, f"intr_{rank}.npy"), t.numpy())
+    dist.destroy_process_group()
+
+
+def test_surfel_sharded_intrinsics_accumulators_round_to_the_unsharded_ones(tmp_path):
+    """The accumulators of the intrinsics step are binary64 sums of binary32 terms (per-tile totals, per-pair cell terms).
+    Summed shard by shard and exchanged, they differ from the unsharded sums in the last bits of the binary64 value at most,
+    so their binary32 roundings -- what the Schur complement works on -- are those of the unsharded run."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_intrinsics_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from tests import common
+    scene = common.small_scene(num_keyframes=3, seed=6, width=160, height=120)
+    ba = common.build_oracle(scene, 60000)
+    ba.depth_cam.fx += 0.5; ba.depth_cam.cy -= 0.7; ba.color_cam.fy += 0.3
+    glob, cells = ba.intrinsics_accumulators()
+    ref = np.concatenate([glob, cells.ravel()])
+    got0, got1 = np.load(tmp_path / "intr_0.npy"), np.load(tmp_path / "intr_1.npy")
+    assert np.array_equal(got0, got1)
+    # (entries of the `a` row are zero while cfactor is, and the colour sums may be empty: zero residuals are skipped)
+    assert np.count_nonzero(ref) > 1000 and np.count_nonzero(ref[:20]) >= 12
+    assert np.array_equal(got0.astype(np.float32).view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    # and the binary64 values themselves agree to a few units in the last place
+    assert np.abs(got0 - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.all(np.abs(got0 - ref) <= 8 * np.spacing(np.abs(ref)) + 0)
+    assert np.array_equal(got0.reshape(-1)[34:].reshape(-1, 8)[:, 7], ref[34:].reshape(-1, 8)[:, 7])   # observation counts: exact
