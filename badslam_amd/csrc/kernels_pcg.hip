@@ -489,7 +489,7 @@ static inline unsigned gU(uint32_t n) { return (n + kPcgBlock - 1) / kPcgBlock; 
 static inline unsigned gR(uint32_t n) { return gU(n) < kPcgReduceBlocks ? gU(n) : kPcgReduceBlocks; }   // grid-stride reductions
 
 // whole XCD chunks, as in kernels_surfel.hip (xcd_chunked_tile)
-static inline unsigned gS(uint32_t n) { return ((n + kPcgSweepBlock - 1) / kPcgSweepBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk); }
+static inline unsigned gS(uint32_t n) { return xcd_padded_tiles((n + kPcgSweepBlock - 1) / kPcgSweepBlock); }
 
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                      float* r, float* M) {

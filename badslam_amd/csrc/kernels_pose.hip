@@ -446,7 +446,7 @@ static int g_forced_pose_parts = [] { const char* e = getenv("BAHIP_POSE_PARTS")
 void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
 
 size_t pose_tile_bounds_bytes(uint32_t surfels) {
-  const size_t tiles = ((size_t)(surfels + kPoseBlock - 1) / kPoseBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk);
+  const size_t tiles = xcd_padded_tiles((surfels + kPoseBlock - 1) / kPoseBlock);
   return tiles * sizeof(WaveBounds);
 }
 
@@ -457,7 +457,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
   // (the sums are merged by integer atomics, so who visits a keyframe does not matter: same bits for every split).
-  const unsigned tiles = ((s.size + kPoseBlock - 1) / kPoseBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk);   // whole XCD chunks
+  const unsigned tiles = xcd_padded_tiles((s.size + kPoseBlock - 1) / kPoseBlock);   // whole XCD runs
   const int forced = g_forced_pose_parts;
   const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
                          : tiles >= 32768 ? 1 : tiles >= 8192 ? 2 : 4;

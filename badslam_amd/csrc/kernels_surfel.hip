@@ -377,7 +377,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
-static inline unsigned grid_for(uint32_t n) { return ((n + kSurfelBlock - 1) / kSurfelBlock + 8 * kXcdChunk - 1) / (8 * kXcdChunk) * (8 * kXcdChunk); }   // whole XCD chunks
+static inline unsigned grid_for(uint32_t n) { return xcd_padded_tiles((n + kSurfelBlock - 1) / kSurfelBlock); }   // whole XCD runs
 
 void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                        uint32_t surfels_size) {

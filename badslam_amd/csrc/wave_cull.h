@@ -19,13 +19,23 @@
 namespace bahip {
 
 // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  With the surfel
-// buffer in spatial order, neighbouring tiles read the same image lines; giving every XCD runs of kXcdChunk consecutive
-// tiles (instead of every 8th tile) lets those lines be shared in one L2, while the chunks still interleave over the XCDs
-// for balance.  Returns the tile that workgroup `block` of a grid of `num_blocks` (a multiple of 8 * kXcdChunk) owns.
-constexpr uint32_t kXcdChunk = 32;
+// buffer in spatial order, neighbouring tiles read the same image lines; giving every XCD runs of consecutive tiles
+// (instead of every 8th tile) lets those lines be shared in one L2, while the runs still interleave over the XCDs for
+// balance.  Run length: 128 tiles for a grid that fills the chip many times over (measured at 46.9 k tiles, it/s: 32 -> 474,
+// 64 -> 469, 96 -> 470, 128 -> 487, 192 -> 473, 256 -> 479, 512 -> 468), 32 for smaller grids (a shard of a multi-GPU run:
+// 5.9 k tiles are 5.7 runs of 128 per XCD, i.e. 20 % imbalance).  The grid is padded to whole runs on all 8 XCDs
+// (xcd_padded_tiles); the kernel derives the run length from the padded grid size.
+constexpr uint32_t kXcdLargeGrid = 32768;
+__host__ __device__ __forceinline__ uint32_t xcd_padded_tiles(uint32_t tiles) {
+  uint32_t padded = (tiles + 255u) / 256u * 256u;                          // 8 XCDs x runs of 32
+  if (padded >= kXcdLargeGrid) padded = (tiles + 1023u) / 1024u * 1024u;   // 8 XCDs x runs of 128
+  return padded;
+}
+// The tile that workgroup `block` of a grid of xcd_padded_tiles(...) workgroups owns.
 __device__ __forceinline__ uint32_t xcd_chunked_tile(uint32_t block) {
+  const uint32_t shift = gridDim.x >= kXcdLargeGrid ? 7u : 5u;   // wave-uniform
   const uint32_t xcd = block & 7u, j = block >> 3;
-  return ((j / kXcdChunk) * 8u + xcd) * kXcdChunk + (j % kXcdChunk);
+  return ((((j >> shift) << 3) + xcd) << shift) + (j & ((1u << shift) - 1u));
 }
 
 struct WaveBounds {
