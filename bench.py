@@ -62,6 +62,7 @@ def parse_args():
     p.add_argument("--emulate-rank", type=int, default=0)
     p.add_argument("--shard-chunk", type=int, default=4096, help="surfels per chunk of the chunk-cyclic partition; 0 = contiguous")
     p.add_argument("--no-spatial-sort", action="store_true", help="leave the surfels in creation order")
+    p.add_argument("--sort-cell", type=float, default=0.02, help="grid cell of DirectBA::SortSurfelsSpatially [m] (its default: 0.02)")
     p.add_argument("--launch-shapes", default="", help="experiment: 'tile_waves,pose_parts' forced through bahip_debug_set_launch_shapes (0 = heuristic)")
     p.add_argument("--build-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,7 +113,7 @@ def build_scene(args, log):
     if not args.no_spatial_sort:
         # maintenance step of the backend (DirectBA::SortSurfelsSpatially, not per iteration): surfels that an image
         # region shows become neighbours in the buffer.  Part of scene construction here, outside the timed region.
-        ba.SortSurfelsSpatially()
+        ba.SortSurfelsSpatially(args.sort_cell)
     log(f"created {created} surfels from {args.keyframes} keyframes (min/median/max per keyframe "
         f"{min(per_kf)}/{int(np.median(per_kf))}/{max(per_kf)}) in {time.time() - t1:.1f}s; using {ba.surfels_size()}")
     # perturbation: poses * exp(N(0, 5 mm / 1 mrad)); surfels + U(0, 5 mm) along z
@@ -337,7 +338,7 @@ def main():
                                    f"{' (BASELINE configs[2])' if (W, H, K, args.surfels, args.intrinsics) == (640, 480, 200, 3000000, False) else ''}",
                        "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
                        "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
-                       "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, 2 cm grid)",
+                       "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, %g cm grid)" % (100 * args.sort_cell),
                        "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU"},
             **({"emulated_share_of_world": shard_world} if shard_world != world else {}),
             "stage_ms_per_iteration": {STAGES[s]: breakdown_ms[s] / BREAKDOWN_STEPS for s in range(5 if args.intrinsics else 4)},
