@@ -327,11 +327,16 @@ int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_tail, const PoseWo
       if (*published == sequence) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
       if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - start > std::chrono::seconds(2)) break;
     }
+  }
+  // not seen within two seconds (or polling is off): wait for the stream.  If the word is there afterwards the launch was
+  // merely slow and polling stays on; if it is not, this system does not show the kernel's stores to the host: copy, and
+  // stop polling for this context.
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (*published == sequence) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+  if (!ctx->poll_disabled) {
     ctx->poll_disabled = true;
     fprintf(stderr, "badslam_hip: the pose counters were not published to host memory; falling back to stream synchronisation\n");
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (*published == sequence) return 0;
   HIP_TRY(hipMemcpy(host_tail, dev_tail, sizeof(PoseWork) * kPoseTailRecords, hipMemcpyDeviceToHost));
   return 0;
 }
