@@ -426,13 +426,16 @@ int rccl_allreduce(bahip_context* ctx, void* buffer, size_t count, int dtype) {
   return rc == 0 ? 0 : rccl_fail("ncclAllReduce", rc);
 }
 
-// Element-wise sum of a device buffer over all ranks, in place, ordered on the context's stream: the native RCCL path
-// (bahip_context_init_rccl) if a communicator exists, else the caller's hook, else nothing (single GPU).
+// Element-wise sum of a device buffer over all ranks, in place, ordered on the context's stream: the caller's hook if one is
+// installed (it overrides: a caller that installs a hook after bahip_context_init_rccl wants the hook), else the native RCCL
+// path if a communicator exists, else nothing (single GPU).
 int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype) {
   if (count == 0) return 0;
+  if (ctx->allreduce) {
+    if (ctx->allreduce(buffer, count, dtype, ctx->stream, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
+    return 0;
+  }
   if (ctx->rccl_comm) return rccl_allreduce(ctx, buffer, count, dtype);
-  if (ctx->allreduce && ctx->allreduce(buffer, count, dtype, ctx->stream, ctx->allreduce_user) != 0)
-    return fail("all-reduce hook failed", __FILE__, __LINE__);
   return 0;
 }
 inline bool is_sharded(const bahip_context* ctx) { return ctx->allreduce != nullptr || ctx->rccl_comm != nullptr; }

@@ -234,8 +234,19 @@ def main():
     hook_keepalive = None
     if dist is not None:
         if dist.get_backend() == "nccl" and not os.environ.get("BENCH_ALLREDUCE_HOOK"):
-            # native path: the backend owns an RCCL communicator and issues ncclAllReduce on its own stream
-            multigpu.init_rccl(ctx, dist)
+            # native path: the backend owns an RCCL communicator and issues ncclAllReduce on its own stream.  Should the
+            # communicator not come up on some system (all ranks must agree, hence the vote), the hook over torch.distributed
+            # carries the same sums.
+            try:
+                multigpu.init_rccl(ctx, dist)
+                native_ok = 1
+            except Exception as e:   # noqa: BLE001 -- whatever it is, the run should still be measured
+                log(f"native RCCL path unavailable ({e}); using the torch.distributed hook")
+                native_ok = 0
+            vote = torch.tensor([native_ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+            if int(vote.item()) == 0:
+                hook_keepalive = multigpu.install_allreduce(ctx, dist)
         else:
             hook_keepalive = multigpu.install_allreduce(ctx, dist)
     K = args.keyframes

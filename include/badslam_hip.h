@@ -99,7 +99,7 @@ int bahip_context_synchronize(bahip_context* ctx);
  * ncclAllReduce on the context's stream: no host round trip, ordered with the kernels around it.  librccl.so is loaded
  * on first use (dlopen), so a single-GPU process never touches it.
  *
- * Hook path: any other transport.  The hook receives the stream the producers of `device_buffer` were queued on and must
+ * Hook path: any other transport (a hook, when installed, takes precedence over the communicator).  The hook receives the stream the producers of `device_buffer` were queued on and must
  * order the reduction after them and before later work on that stream (e.g. torch.cuda.ExternalStream(stream) around
  * dist.all_reduce).  dtype: BAHIP_SUM_F32 (count floats), BAHIP_SUM_I64 (count int64_t: the pose normal equations are
  * summed in fixed point, which makes a sharded run bit-identical to the unsharded one) or BAHIP_SUM_F64 (count doubles: the
