@@ -9,9 +9,11 @@
 // Here one launch per GN *round* handles every keyframe that is still iterating: a thread owns a
 // surfel (position, normal, radius, descriptors in registers) and loops over the work items; the
 // three residuals of a (surfel, keyframe) pair are folded into one per-lane 27-vector which is
-// reduced across the wave64 with cross-lane adds and merged with one atomic per scalar per wave.
-// The 6x6 LDLT (binary64, like the reference), T <- T*exp(-x) and the convergence test run in a
-// second tiny kernel on the device, so a round costs two launches and one 4-byte read-back.
+// reduced across the wave64 in a fixed tree with cross-lane adds, converted to fixed point and merged
+// with one 64-bit integer atomic per scalar per wave (a DEFINED, order-free sum: ba_device.h, HbFixed).
+// The 6x6 LDLT (binary64, like the reference), T <- T*exp(-x), the convergence test and the activation
+// update of the BA loop run in a second tiny kernel on the device, which publishes its counters to
+// mapped host memory: a round costs two launches and no stream synchronisation.
 #include <stdlib.h>
 
 #include "ba_device.h"
