@@ -76,3 +76,46 @@ def test_reductions_use_the_gfx950_cross_lane_instructions(listings):
     assert "global_atomic_add_x2" in body                                        # 64-bit integer atomics on the fixed-point totals
     assert "global_atomic_add_f32" not in body                                   # ... no float atomics (order-dependent sums)
     assert "global_atomic_cmpswap" not in body                                   # ... and no compare-and-swap loop
+
+
+def _innermost_loop(body):
+    """Lines of the deepest loop of a kernel listing (the per-candidate body of a sweep), from its header label on."""
+    lines = body.split("\n")
+    depth = max((int(m.group(1)) for m in re.finditer(r"Depth=(\d+)", body)), default=0)
+    idx = [i for i, l in enumerate(lines) if f"Depth={depth}" in l]
+    return lines[min(idx):max(idx) + 200] if idx else []
+
+
+def test_pose_sweep_puts_all_five_gathers_in_flight_before_the_first_wait(listings):
+    """DESIGN.md section 3, "every gather of a pair in flight at once": in the per-candidate body of the pose sweep the pixel
+    word, the cfactor and the three luma footprints are issued (global_load, not flat_load) before the first s_waitcnt on
+    vmcnt, and that first wait is a counted one (it lets the later loads stay in flight).  A compiler that sinks one of the
+    loads back into the branch that uses it puts the round trips in series again (-7 % measured)."""
+    kernels = _kernels(listings["kernels_pose"])
+    body = next(v[0] for k, v in kernels.items() if "pose_accumulate_kernelILb1ELb1" in k)
+    assert "flat_load" not in body
+    loop = _innermost_loop(body)
+    assert loop
+    loads_before_wait, first_wait = 0, None
+    for line in loop:
+        s = line.strip()
+        if s.startswith("global_load_dword "):
+            loads_before_wait += 1
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", s)
+        if m and loads_before_wait:
+            first_wait = int(m.group(1))
+            break
+    assert loads_before_wait == 5, loads_before_wait
+    assert first_wait is not None and first_wait >= 3, first_wait
+    # the atomics of a candidate are issued one candidate late: one atomic instruction in the loop, one more after it
+    assert body.count("global_atomic_add_x2") == 2
+
+
+def test_sweeps_gather_through_global_loads(listings):
+    """Pointers read from the keyframe table are generic to the compiler; load_global() (ba_device.h) says they are global
+    memory, so the gathers are global_load (flat_load checks the LDS / scratch apertures and counts on lgkmcnt too)."""
+    for unit, prefixes in (("kernels_surfel", ("geometry_kernelILb1ELb1ELi1", "normals_kernel")), ("kernels_pcg", ("pcg_step1_kernel",))):
+        for name, (body, *_rest) in _kernels(listings[unit]).items():
+            if any(p in name for p in prefixes):
+                loop = "\n".join(_innermost_loop(body))
+                assert "flat_load" not in loop, name
