@@ -149,6 +149,8 @@ void orc_jac_descriptor_color_intrinsics(float gx, float gy, float nx, float ny,
 float orc_sample_luma(const uint8_t* rgba, int width, int height, float x, float y);
 /* B/util.cuh:62-69 */
 float orc_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t raw);
+/* test hook: pixel-centre unprojection of pixel (x, y) at `depth` (B/surfel_projection.cuh:88-126) */
+void orc_unproject(const orc_camera* cam, int x, int y, float depth, float out[3]);
 uint32_t orc_pack_normal10(float x, float y, float z);       /* B/util_nvcc_only.cuh:66-84 */
 void orc_unpack_normal10(uint32_t v, float n[3]);           /* B/util_nvcc_only.cuh:87-95 (renormalised) */
 uint16_t orc_pack_normal8(float x, float y);                /* B/util.cuh:121-135 */

@@ -323,6 +323,13 @@ float orc_half_to_float(uint16_t h) {
   return f;
 }
 
+/* Test hook: PixelCenterUnprojector::UnprojectPoint (B/surfel_projection.cuh:88-126) of pixel (x, y) at `depth`. */
+void orc_unproject(const orc_camera* cam, int x, int y, float depth, float out[3]) {
+  const unprojector u = make_unprojector(cam);
+  const v3 p = unp_point(&u, x, y, depth);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
 /* B/util.cuh:62-69 */
 float orc_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t measured_depth) {
   const float inv_depth = 1.0f / (raw_to_float_depth * measured_depth);
