@@ -12,8 +12,13 @@
  * twelve of them also run against the HIP path, badslam_amd/host/test_directba.cc),
  * (2) its residual Jacobians checked against golden vectors generated HERE by importing the
  * reference's own derivation script (applications/badslam/scripts/jacobians_derivation.py ->
- * scripts/make_golden_jacobians.py -> tests/golden/jacobians.json) and
- * (3) central finite differences of the oracle's own residual functions.
+ * scripts/make_golden_jacobians.py -> tests/golden/jacobians.json), (3) golden VALUES of the
+ * building blocks the same script defines -- depth calibration, projection, unprojection, bilinear
+ * weights, the rotation of the exponential map -- (scripts/make_golden_functions.py ->
+ * tests/golden/functions.json) and (4) central finite differences of the oracle's own residual
+ * functions.  Where the arithmetic is DEFINED here rather than taken from the reference (summation
+ * orders, fixed point, defined sin / cos / atan: DESIGN.md section 3), the definitions are shared with
+ * the kernels, and the closed-loop criteria of (1) are what ties them to the reference.
  *
  * All arithmetic is IEEE binary32 unless stated (compiled with -ffp-contract=off); the small
  * dense solves are done in binary64 exactly where the reference does so (Eigen LDLT on
