@@ -27,7 +27,9 @@ def golden():
 
 @pytest.fixture(scope="module")
 def L():
-    return ob.lib()
+    """A handle of its own: the prototypes set below must not leak into the cached handle the other tests share."""
+    ob.lib()                                   # builds the library if it is not there yet
+    return C.CDLL(ob._LIB_PATH)
 
 
 def _close(got, expected, rel=2e-6, floor=0.0):

@@ -288,7 +288,8 @@ def test_defined_sin_cos_atan_are_correctly_rounded_almost_everywhere():
     They must be as good as libm: within 1 ulp of the correctly rounded value, and equal to it but for rare ties."""
     import ctypes as C
     from oracle import binding as ob
-    L = ob.lib()
+    ob.lib()
+    L = C.CDLL(ob._LIB_PATH)                   # a handle of its own: prototypes set here stay here
     L.orc_atan.restype = C.c_float
     L.orc_atan.argtypes = [C.c_float]
     L.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]

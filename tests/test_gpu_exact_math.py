@@ -86,7 +86,8 @@ def test_defined_trigonometry_equals_the_oracle_and_is_correctly_rounded(ctx):
     libm rounded to binary32), almost always equal to it."""
     import ctypes as C
     from oracle import binding as ob
-    L = ob.lib()
+    ob.lib()
+    L = C.CDLL(ob._LIB_PATH)                   # a handle of its own: prototypes set here stay here
     L.orc_atan.restype = C.c_float
     L.orc_atan.argtypes = [C.c_float]
     L.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
