@@ -146,11 +146,38 @@ struct PcgLayout {
   uint32_t surfel_start, depth_intr_start, a_index, color_intr_start, unknown_count;
   int geom_stride;   // 3 with descriptor residuals, else 1
   int gauge;         // keyframe whose pose is held fixed
-  // Surfel sharding: the surfel block [surfel_start, surfel_end) is local to a rank, everything else (the "dense head":
-  // poses and intrinsics) is replicated after an all-reduce.  Dot products are formed as head * head_scale + local and
-  // summed over the ranks, head_scale = 1 / world (1 on a single GPU: the product is then exact and changes nothing).
-  uint32_t surfel_end;
-  float head_scale;
+  // The surfel block [head_lo, head_hi) of the unknown vector is local to a rank under surfel sharding; everything else (the
+  // "dense head": poses and intrinsics) is replicated.  head_lo == head_hi == unknown_count when geometry is not optimised.
+  uint32_t head_lo, head_hi;
+  // Per-keyframe entry points (bahip_pcg_init / bahip_pcg_step1 with one keyframe, Route B): the sweep covers one keyframe
+  // whose pose unknowns start at single_pose_index (optimize_poses already says whether they are unknowns at all), and the
+  // surfel entries continue the chains the earlier calls left in the vectors instead of starting from zero.
+  int single_keyframe;   // -1: the sweep covers the whole bound table
+  uint32_t single_pose_index;
+  int accumulate;
+};
+
+// Exact accumulators of one PCG solve (exact_sum.h; kernels_pcg.hip says what is summed where).  Replicated slots: sums that
+// every tile / workgroup adds to -- 64 replicas each, folded when they are resolved.
+struct ExactCell;
+constexpr int kHotReplicas = 64;
+enum : int {
+  kHotA = 0,           // 9: global intrinsics entries of r (PCGInit) / g (PCGStep1)
+  kHotB = 9,           // 9: ... of M
+  kHotAlphaD = 18,     // pair part of alpha_d
+  kHotEpsLocal = 19,   // epsilon terms of alpha_d over the local unknowns
+  kHotExchanged1 = 20, // slots [0, 20) + the head cells are what a sharded run exchanges after a sweep
+  kHotDotLocal = 20,   // alpha_n / beta_n over the local unknowns (exchanged after the dot-product kernel)
+  kHotEpsHead = 21,    // the dense head's share (identical on every rank: not exchanged)
+  kHotDotHead = 22,
+  kHotSlots = 23
+};
+struct PcgExact {
+  ExactCell* hot;        // slots [0, kHotExchanged1) x kHotReplicas
+  ExactCell* head_a;     // one cell per dense-head unknown: r (PCGInit) / g (PCGStep1)
+  ExactCell* head_b;     // ... M
+  ExactCell* hot_tail;   // slots [kHotExchanged1, kHotSlots) x kHotReplicas
+  unsigned* invalid;     // sticky: a non-finite term was added; every sum resolves to NaN
 };
 
 // Everything that is constant over a sweep; passed to kernels by value (kernarg -> SGPRs).

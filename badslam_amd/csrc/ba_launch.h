@@ -76,19 +76,28 @@ void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, 
 void pose_counters_dump();   // experiment build only (kernels_pose.hip)
 #endif
 // kernels_pcg.hip
-void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
-                     float* r, float* M);
-void launch_pcg_init2(hipStream_t st, const PcgLayout& L, float a, const float* r, const float* M, float* delta, float* g, float* p,
-                      float* alpha_n);
-// ctl: device-side inner-loop control block (pcg_control_bytes(); stopping rule of B/direct_ba_pcg.cc:427-456 evaluated on the device)
+// `ex`: the exact accumulators of the solve (pcg_exact_cells(head_count) cells of 72 bytes, zeroed once; every kernel that
+// resolves a sum clears what it read).  ctl: device-side inner-loop control block (pcg_control_bytes(); stopping rule of
+// B/direct_ba_pcg.cc:427-456 evaluated on the device).
+size_t pcg_exact_cells(uint32_t head_count);
+PcgExact pcg_exact_view(void* buffer, uint32_t head_count);
 size_t pcg_control_bytes();
-void launch_pcg_control_init(hipStream_t st, void* ctl);
-void launch_pcg_control(hipStream_t st, void* ctl, const float* beta_n);
-void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
-                      const float* p, float* g, float* alpha_d, const void* ctl);
-void launch_pcg_step2(hipStream_t st, const PcgLayout& L, float* r, const float* M, float* delta, float* g, const float* p,
-                      const float* alpha_n, const float* alpha_d, float* beta_n, const void* ctl);
-void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n, const void* ctl);
+void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                     const SurfelsView& s, float* r, float* M);
+void launch_pcg_resolve_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, float* M);
+void launch_pcg_init2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float a, const float* r, const float* M, float* delta, float* g,
+                      float* p);
+void launch_pcg_control_init(hipStream_t st, const PcgExact& ex, void* ctl, float* alpha_n);
+void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                      const SurfelsView& s, const float* p, float* g, const void* ctl);
+void launch_pcg_eps_terms(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* p);
+void launch_pcg_resolve_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* g, float* alpha_d, double eps_repeat, const void* ctl);
+void launch_pcg_step2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, const float* M, float* delta, float* g, const float* p,
+                      const float* alpha_n, const float* alpha_d, const void* ctl);
+void launch_pcg_control(hipStream_t st, const PcgExact& ex, void* ctl, float* beta_n);
+void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* g, float* p, const float* alpha_n, const float* beta_n,
+                      const void* ctl);
+void launch_exact_sum_debug(hipStream_t st, const PcgExact& ex, const float* values, size_t n, int mode, double* out);
 void launch_pcg_update_surfels(hipStream_t st, const PcgLayout& L, const SurfelsView& s, const float* delta);
 void launch_pcg_update_cfactors(hipStream_t st, const Intrinsics& in, uint32_t start, const float* delta, float* cfactor, uint32_t pitch);
 

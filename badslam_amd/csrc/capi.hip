@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ba_launch.h"
+#include "exact_sum.h"
 #include "ldlt.h"
 #include "se3_device.h"
 
@@ -114,9 +115,11 @@ struct bahip_context {
 
   float* pcg_buf = nullptr;        // PCG vectors r, M, delta, g, p (5 * pcg_capacity floats) + 16 scalars
   size_t pcg_capacity = 0;
-  float* pcg_stage = nullptr;      // sharded PCG: staging buffer for the all-reduce of the dense head
-  size_t pcg_stage_capacity = 0;
-  int world = 0;                   // number of ranks behind the all-reduce hook (0 = not probed yet)
+  void* pcg_exact = nullptr;       // exact accumulators of the PCG solve (ExactCell[pcg_exact_capacity]; kernels_pcg.hip)
+  size_t pcg_exact_capacity = 0;
+  int world = 0;                   // ranks of the RCCL communicator (0 = none)
+  long long exchange_calls = 0;    // sums over the ranks requested since the last reset (bahip_exchange_stats), and their bytes
+  long long exchange_bytes = 0;
 
   // planes packed by the library itself for frames handed over without bahip_frame.planes:
   // slot 0 = the single frame of the per-frame entry points, slot 1 + k = bound keyframe k
@@ -319,7 +322,8 @@ int ensure_tile_bounds(bahip_context* ctx, uint32_t surfels) {
 // Waits until pose_solve_kernel has published `sequence` in the host copy of the counter records.  Polling a word of mapped
 // host memory costs a microsecond where hipStreamSynchronize + a 256-byte copy cost 25.  If the word does not show up within
 // two seconds (a runtime that does not map the allocation coherently), fall back to synchronising and copying.
-int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_tail, const PoseWork* dev_tail, int sequence) {
+int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_work, const PoseWork* dev_work, int num_work, int sequence) {
+  PoseWork* host_tail = host_work + num_work;
   volatile int* published = reinterpret_cast<volatile int*>(host_tail) + kPoseCounterSequence;
   if (!ctx->poll_disabled) {
     const auto start = std::chrono::steady_clock::now();
@@ -337,7 +341,9 @@ int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_tail, const PoseWo
     ctx->poll_disabled = true;
     fprintf(stderr, "badslam_hip: the pose counters were not published to host memory; falling back to stream synchronisation\n");
   }
-  HIP_TRY(hipMemcpy(host_tail, dev_tail, sizeof(PoseWork) * kPoseTailRecords, hipMemcpyDeviceToHost));
+  // the finished work items were written to the same mapped memory by the solve kernel: bring the whole record range over,
+  // not only the counters, or the poses read after the phase would be stale
+  HIP_TRY(hipMemcpy(host_work, dev_work, sizeof(PoseWork) * ((size_t)num_work + kPoseTailRecords), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -372,7 +378,7 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     // No stream synchronisation and no copy per round: the solve kernel writes finished work items and, last, the counters and
     // this launch's sequence number into host_work (mapped, coherent host memory); the host polls the sequence number.
     const double t1 = host_timing ? now() : 0;
-    if (wait_for_pose_sequence(ctx, host_work + num_work, dev_work + num_work, sequence)) return 1;
+    if (wait_for_pose_sequence(ctx, host_work, dev_work, num_work, sequence)) return 1;
     if (host_timing) {
       t_launch += t1 - t0; t_wait += now() - t1;
       if (++n_rounds % 30 == 0) fprintf(stderr, "[pose rounds, us per round] enqueue %.1f | wait %.1f\n", t_launch / n_rounds, t_wait / n_rounds);
@@ -431,6 +437,10 @@ int rccl_allreduce(bahip_context* ctx, void* buffer, size_t count, int dtype) {
 // path if a communicator exists, else nothing (single GPU).
 int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype) {
   if (count == 0) return 0;
+  if (ctx->allreduce || ctx->rccl_comm) {
+    ctx->exchange_calls += 1;
+    ctx->exchange_bytes += (long long)count * (dtype == BAHIP_SUM_F32 ? 4 : 8);
+  }
   if (ctx->allreduce) {
     if (ctx->allreduce(buffer, count, dtype, ctx->stream, ctx->allreduce_user) != 0) return fail("all-reduce hook failed", __FILE__, __LINE__);
     return 0;
@@ -439,55 +449,6 @@ int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype)
   return 0;
 }
 inline bool is_sharded(const bahip_context* ctx) { return ctx->allreduce != nullptr || ctx->rccl_comm != nullptr; }
-
-// Number of ranks behind the all-reduce hook: the sum of a 1 from every rank.
-int probe_world(bahip_context* ctx) {
-  if (!is_sharded(ctx)) { ctx->world = 1; return 0; }
-  if (ctx->world > 0) return 0;
-  const HbFixed one = 1;
-  HIP_TRY(hipMemcpyAsync(ctx->dev_Hb1, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (reduce_over_ranks(ctx, ctx->dev_Hb1, 1, BAHIP_SUM_I64)) return 1;
-  HbFixed sum = 0;
-  HIP_TRY(hipMemcpyAsync(&sum, ctx->dev_Hb1, sizeof(sum), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  ctx->world = (int)sum;
-  if (ctx->world < 1) return fail("all-reduce hook returned a rank count < 1", __FILE__, __LINE__);
-  return 0;
-}
-
-// Sharded PCG: sums the dense head (everything outside the local surfel block) of up to two vectors plus `num_scalars`
-// scalars over the ranks with ONE hook call, through a contiguous staging buffer.
-int allreduce_head(bahip_context* ctx, const PcgLayout& L, float* a, float* b, float* scalars, int num_scalars) {
-  const size_t U = L.unknown_count;
-  const size_t lo = L.optimize_geometry ? L.surfel_start : U;          // head = [0, lo) + [hi, U)
-  const size_t hi = L.optimize_geometry ? L.surfel_end : U;
-  const size_t head = lo + (U - hi);
-  const size_t total = head * (b ? 2 : 1) + (size_t)num_scalars;
-  if (total == 0) return 0;
-  if (grow_device(&ctx->pcg_stage, &ctx->pcg_stage_capacity, total, 1024, "the all-reduce staging buffer")) return 1;
-  hipStream_t st = ctx->stream;
-  float* stage = ctx->pcg_stage;
-  size_t at = 0;
-  float* vecs[2] = {a, b};
-  for (float* v : vecs) {
-    if (!v) continue;
-    if (lo) HIP_TRY(hipMemcpyAsync(stage + at, v, sizeof(float) * lo, hipMemcpyDeviceToDevice, st));
-    if (U > hi) HIP_TRY(hipMemcpyAsync(stage + at + lo, v + hi, sizeof(float) * (U - hi), hipMemcpyDeviceToDevice, st));
-    at += head;
-  }
-  if (num_scalars) HIP_TRY(hipMemcpyAsync(stage + at, scalars, sizeof(float) * num_scalars, hipMemcpyDeviceToDevice, st));
-  if (reduce_over_ranks(ctx, stage, total, BAHIP_SUM_F32)) return 1;
-  at = 0;
-  for (float* v : vecs) {
-    if (!v) continue;
-    if (lo) HIP_TRY(hipMemcpyAsync(v, stage + at, sizeof(float) * lo, hipMemcpyDeviceToDevice, st));
-    if (U > hi) HIP_TRY(hipMemcpyAsync(v + hi, stage + at + lo, sizeof(float) * (U - hi), hipMemcpyDeviceToDevice, st));
-    at += head;
-  }
-  if (num_scalars) HIP_TRY(hipMemcpyAsync(scalars, stage + at, sizeof(float) * num_scalars, hipMemcpyDeviceToDevice, st));
-  return 0;
-}
 
 }  // namespace
 
@@ -538,7 +499,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
-  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_stage);
+  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
@@ -561,7 +522,6 @@ int bahip_context_is_sharded(bahip_context* ctx) { return (ctx->allreduce != nul
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user) {
   ctx->allreduce = fn;
   ctx->allreduce_user = user;
-  ctx->world = 0;   // probed on first use (probe_world)
   return 0;
 }
 
@@ -948,7 +908,7 @@ int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* in
   if (need > ctx->covis_csr_capacity) {
     int* grown = nullptr;
     HIP_TRY(hipMalloc(&grown, sizeof(int) * (need + 1024)));
-    hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
+    hipFree(ctx->dev_covis_csr);   // only the CSR buffer is re-grown here (tile bounds and window have their own grow paths)
     ctx->dev_covis_csr = grown;
     ctx->covis_csr_capacity = need + 1024;
   }
@@ -1220,12 +1180,21 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   return 0;
 }
 // One outer Gauss-Newton iteration of the PCG scheme: B/direct_ba_pcg.cc:229-646.
+static int ensure_pcg_exact(bahip_context* ctx, uint32_t head_count) {
+  const size_t need = pcg_exact_cells(head_count);
+  if (need <= ctx->pcg_exact_capacity && ctx->pcg_exact) return 0;
+  void* grown = nullptr;
+  HIP_TRY(hipMalloc(&grown, sizeof(ExactCell) * (need + need / 8)));
+  hipFree(ctx->pcg_exact);
+  ctx->pcg_exact = grown;
+  ctx->pcg_exact_capacity = need + need / 8;
+  return 0;
+}
 int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const bahip_surfels* surfels,
                         bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a, int* inner_steps_out,
                         int* num_converged_out) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
-  const bool sharded = is_sharded(ctx);
-  if (probe_world(ctx)) return 1;
+  const bool sharded = is_sharded(ctx);   // (exact sums need no rank count: every rank adds its terms, the limbs are summed)
   const int K = ctx->num_kfs;
   REQUIRE(K >= 1, "PCG needs at least one keyframe");
   const uint32_t N = surfels->surfels_size;
@@ -1246,9 +1215,11 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   L.color_intr_start = kInvalid;
   if (L.optimize_color_intrinsics) { L.color_intr_start = cur; cur += 4; }
   L.unknown_count = cur;
-  L.surfel_end = L.optimize_geometry ? L.surfel_start + (uint32_t)L.geom_stride * N : kInvalid;
-  L.head_scale = 1.f / (float)ctx->world;
+  L.head_lo = L.optimize_geometry ? L.surfel_start : cur;
+  L.head_hi = L.optimize_geometry ? L.surfel_start + (uint32_t)L.geom_stride * N : cur;
+  L.single_keyframe = -1; L.single_pose_index = kInvalid; L.accumulate = 0;
   const size_t U = cur;
+  const uint32_t head_count = L.head_lo + (L.unknown_count - L.head_hi);
   *out_color_camera = ctx->color_cam; *out_depth_camera = ctx->depth_cam; *out_a = ctx->dp.a;
   if (inner_steps_out) *inner_steps_out = 0;
   if (num_converged_out) *num_converged_out = 0;
@@ -1258,64 +1229,68 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
     return 0;
   }
   if (U > ctx->pcg_capacity || ctx->pcg_buf == nullptr) {   // lazy (re-)allocation like B/direct_ba_pcg.cc:255-268
-    const size_t cap = U + U / 8 + 4096;
+    const size_t cap = (U + U / 8 + 4096 + 3) & ~(size_t)3;   // multiple of 4: the scalar block behind the vectors stays 16-byte aligned
     float* grown = nullptr;
     HIP_TRY(hipMalloc(&grown, sizeof(float) * (5 * cap + 16)));
     hipFree(ctx->pcg_buf);
     ctx->pcg_buf = grown;
     ctx->pcg_capacity = cap;
   }
+  if (ensure_pcg_exact(ctx, head_count)) return 1;
+  const PcgExact ex = pcg_exact_view(ctx->pcg_exact, head_count);
   const size_t cap = ctx->pcg_capacity;
   float* r_ = ctx->pcg_buf; float* M_ = r_ + cap; float* delta = M_ + cap; float* g_ = delta + cap; float* p_ = g_ + cap;
   float* sc = p_ + cap;   // [0] alpha_n / beta_n (swapped), [1] alpha_d, [2] beta_n / alpha_n
   int i_an = 0, i_bn = 2;
   const SurfelsView sv = make_view(surfels);
   hipStream_t st = ctx->stream;
-  HIP_TRY(hipMemsetAsync(r_, 0, sizeof(float) * U, st));
-  HIP_TRY(hipMemsetAsync(M_, 0, sizeof(float) * U, st));
+  // a rank with an empty shard launches no sweep, so it must provide zeros for the entries a sweep would have written
   HIP_TRY(hipMemsetAsync(sc, 0, sizeof(float) * 16, st));
-  launch_pcg_init(st, L, ctx->in, ctx->dev_kfs, K, sv, r_, M_);
+  HIP_TRY(hipMemsetAsync(ctx->pcg_exact, 0, sizeof(ExactCell) * pcg_exact_cells(head_count), st));
+  // what a sharded run exchanges: the limbs, as int64 -- an exact sum, so sharded == unsharded bit for bit
+  const size_t x1_init = ((size_t)kHotExchanged1 * kHotReplicas + 2 * (size_t)head_count) * kExactLimbs;
+  const size_t x1_step = ((size_t)kHotExchanged1 * kHotReplicas + (size_t)head_count) * kExactLimbs;
+  const size_t x2 = (size_t)kHotReplicas * kExactLimbs;
+  launch_pcg_init(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, r_, M_);
   CHECK_LAUNCH();
-  if (sharded && allreduce_head(ctx, L, r_, M_, nullptr, 0)) return 1;
-  launch_pcg_init2(st, L, ctx->dp.a, r_, M_, delta, g_, p_, sc + i_an);
+  if (sharded && reduce_over_ranks(ctx, ex.hot, x1_init, BAHIP_SUM_I64)) return 1;
+  launch_pcg_resolve_init(st, L, ex, r_, M_);
   CHECK_LAUNCH();
-  if (sharded && reduce_over_ranks(ctx, sc + i_an, 1, BAHIP_SUM_F32)) return 1;
+  launch_pcg_init2(st, L, ex, ctx->dp.a, r_, M_, delta, g_, p_);
+  CHECK_LAUNCH();
+  if (sharded && reduce_over_ranks(ctx, ex.hot_tail, x2, BAHIP_SUM_I64)) return 1;
 
   // Inner loop: the stopping rule runs on the device (pcg_control_kernel), so steps are queued in groups without a host
   // round trip per step; kernels queued after the stop return at once.  The host only looks at `stop` between groups.
   void* ctl = sc + 8;   // PcgControl lives in the scalar block (16 floats)
-  static_assert(sizeof(float) * 8 >= 16, "room for PcgControl behind the scalars");
-  launch_pcg_control_init(st, ctl);
+  if (pcg_control_bytes() > sizeof(float) * 8) return fail("PcgControl does not fit behind the scalars", __FILE__, __LINE__);
+  launch_pcg_control_init(st, ex, ctl, sc + i_an);
   CHECK_LAUNCH();
-  const size_t head_lo = L.optimize_geometry ? L.surfel_start : U, head_hi = L.optimize_geometry ? L.surfel_end : U;
+  // AddAlphaDEpsilonTerms runs once per keyframe in the reference (B/kernel_pcg.cu:1102-1112), and not at all without surfels
+  const double eps_repeat = (N > 0 || sharded) ? (double)K : 0.0;
   constexpr int kStepsPerGroup = 6;
   int steps = 0;
   for (int step = 0; step < opt->max_inner_iterations; ++step) {
-    HIP_TRY(hipMemsetAsync(sc + 1, 0, sizeof(float), st));
-    if (step > 0) {
-      const int t = i_an; i_an = i_bn; i_bn = t;
-      // g: the surfel block is overwritten by the sweep, only the dense head accumulates
-      if (head_lo) HIP_TRY(hipMemsetAsync(g_, 0, sizeof(float) * head_lo, st));
-      if (U > head_hi) HIP_TRY(hipMemsetAsync(g_ + head_hi, 0, sizeof(float) * (U - head_hi), st));
-    }
-    launch_pcg_step1(st, L, ctx->in, ctx->dev_kfs, K, sv, p_, g_, sc + 1, ctl);
+    if (step > 0) { const int t = i_an; i_an = i_bn; i_bn = t; }
+    launch_pcg_step1(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, p_, g_, ctl);
     CHECK_LAUNCH();
-    if (sharded && allreduce_head(ctx, L, g_, nullptr, sc + 1, 1)) return 1;     // g head and alpha_d in one exchange
-    HIP_TRY(hipMemsetAsync(sc + i_bn, 0, sizeof(float), st));
-    launch_pcg_step2(st, L, r_, M_, delta, g_, p_, sc + i_an, sc + 1, sc + i_bn, ctl);
+    if (sharded && reduce_over_ranks(ctx, ex.hot, x1_step, BAHIP_SUM_I64)) return 1;   // g head, intrinsics entries, alpha_d terms
+    launch_pcg_resolve_step1(st, L, ex, g_, sc + 1, eps_repeat, ctl);
     CHECK_LAUNCH();
-    if (sharded && reduce_over_ranks(ctx, sc + i_bn, 1, BAHIP_SUM_F32)) return 1;
-    launch_pcg_control(st, ctl, sc + i_bn);
+    launch_pcg_step2(st, L, ex, r_, M_, delta, g_, p_, sc + i_an, sc + 1, ctl);
+    CHECK_LAUNCH();
+    if (sharded && reduce_over_ranks(ctx, ex.hot_tail, x2, BAHIP_SUM_I64)) return 1;
+    launch_pcg_control(st, ex, ctl, sc + i_bn);
     CHECK_LAUNCH();
     if (step < opt->max_inner_iterations - 1) {
-      launch_pcg_step3(st, L, g_, p_, sc + i_an, sc + i_bn, ctl);
+      launch_pcg_step3(st, L, ex, g_, p_, sc + i_an, sc + i_bn, ctl);
       CHECK_LAUNCH();
     }
     if ((step + 1) % kStepsPerGroup == 0 || step == opt->max_inner_iterations - 1) {
-      HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctl, 16, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctl, 24, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      steps = ctx->pinned_i[3];
-      if (ctx->pinned_i[2]) break;   // stop
+      steps = ctx->pinned_i[4];
+      if (ctx->pinned_i[3]) break;   // stop
     }
   }
   if (inner_steps_out) *inner_steps_out = steps;
@@ -1390,6 +1365,21 @@ int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, con
   CHECK_LAUNCH();
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipMemcpy(out_host, out.p, sizeof(float) * 40 * count, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int bahip_debug_exact_sum(bahip_context* ctx, const float* values_host, size_t count, int mode, double* out_host) {
+  REQUIRE(out_host != nullptr && (values_host != nullptr || count == 0) && (mode == 0 || mode == 1), "bahip_debug_exact_sum: bad arguments");
+  DevMem values, cells, out;
+  HIP_TRY(hipMalloc(&values.p, sizeof(float) * (count ? count : 1)));
+  HIP_TRY(hipMalloc(&cells.p, sizeof(ExactCell) * pcg_exact_cells(0)));
+  HIP_TRY(hipMalloc(&out.p, sizeof(double)));
+  if (count) HIP_TRY(hipMemcpy(values.p, values_host, sizeof(float) * count, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemsetAsync(cells.p, 0, sizeof(ExactCell) * pcg_exact_cells(0), ctx->stream));
+  launch_exact_sum_debug(ctx->stream, pcg_exact_view(cells.p, 0), values.as<float>(), count, mode, out.as<double>());
+  CHECK_LAUNCH();
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out_host, out.p, sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1512,6 +1502,13 @@ int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* 
   }
   *ms_out = total;
   if (launches_out) *launches_out = t.used;
+  return 0;
+}
+
+int bahip_exchange_stats(bahip_context* ctx, long long* calls_out, long long* bytes_out, int reset) {
+  if (calls_out) *calls_out = ctx->exchange_calls;
+  if (bytes_out) *bytes_out = ctx->exchange_bytes;
+  if (reset) { ctx->exchange_calls = 0; ctx->exchange_bytes = 0; }
   return 0;
 }
 

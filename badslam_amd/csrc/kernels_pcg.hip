@@ -8,12 +8,22 @@
 //
 // Here both are single launches: a thread owns a surfel and sweeps the keyframes that survive the
 // wave64 frustum test (wave_cull.h).  Surfel entries of r / M / g are accumulated in registers in
-// keyframe order (identical to the reference's launch order) and written once.  Entries of the
-// global intrinsics blocks are keyframe-independent, so each lane sums them over the whole sweep
-// and the wave reduces once.  Only the 6 pose entries need a wave reduction + atomics per visited
-// keyframe, and the per-cell cfactor entries an atomic per associated pair.
+// keyframe order (identical to the reference's launch order) and written once.
+//
+// DEFINITION of the dense sums (round 3; restated by oracle_pcg.c).  Everything the reference merges with binary32
+// atomics in arbitrary order (B/kernel_pcg.cu:98-154) is an EXACT sum here (exact_sum.h: 9 x int64 limbs, integer atomics),
+// rounded once to binary64 and then to the PCGScalar:
+//   - the 6 pose entries of a keyframe: per (64-surfel tile, keyframe) the halving tree of wave_reduce.h, tile totals exact;
+//   - the 5 + 4 global intrinsics entries and the pair part of alpha_d: per-surfel binary32 chains over the keyframes, the xor
+//     butterfly over the tile, tile totals exact (into one of 64 replicas, folded when resolved -- exactness makes the
+//     replication free, and 47 k tiles would otherwise serialise on one address);
+//   - per-cell cfactor entries: per-pair terms, exact;
+//   - dot products over the unknowns (alpha_n, beta_n, the epsilon terms of alpha_d): the binary32 products, exact.
+// So the conjugate gradient is deterministic, bit-identical to the oracle (inner step count included), independent of the
+// launch shape, and a surfel-sharded run -- limbs exchanged with an int64 all-reduce -- equals the unsharded one bit for bit.
 #include "ba_device.h"
 #include "ba_launch.h"
+#include "exact_sum.h"
 #include "wave_cull.h"
 
 namespace bahip {
@@ -26,16 +36,49 @@ constexpr float kAPriorWeight = 10.f;   // B/kernel_pcg.cu:48
 
 __device__ __forceinline__ uint32_t kf_pose_index(const PcgLayout& L, int k) {
   // B/direct_ba_pcg.cc:329-337
+  if (L.single_keyframe >= 0) return L.single_pose_index;   // per-keyframe entry points (Route B): the caller names the index
   if (k == L.gauge) return 0xffffffffu;
   return (k < L.gauge) ? 6u * (uint32_t)k : 6u * (uint32_t)(k - 1);
 }
-// Weight of unknown u in a dot product that is summed over the ranks (PcgLayout::head_scale).
-__device__ __forceinline__ float dot_weight(const PcgLayout& L, uint32_t u) {
-  const bool local = L.optimize_geometry && u >= L.surfel_start && u < L.surfel_end;
-  return local ? 1.f : L.head_scale;
+__device__ __forceinline__ bool kf_pose_is_unknown(const PcgLayout& L, int k) {
+  return L.optimize_poses && (L.single_keyframe >= 0 || k != L.gauge);
 }
 __device__ __forceinline__ float prior_at(const PcgLayout& L, uint32_t u) {
   return (u == L.a_index) ? (kAPriorWeight * kAPriorWeight) : 0.f;
+}
+__device__ __forceinline__ bool is_local(const PcgLayout& L, uint32_t u) { return u >= L.head_lo && u < L.head_hi; }
+__device__ __forceinline__ uint32_t head_index(const PcgLayout& L, uint32_t u) { return u < L.head_lo ? u : L.head_lo + (u - L.head_hi); }
+// Slot (0..8) of a global intrinsics unknown among the replicated accumulators, or -1.
+__device__ __forceinline__ int intrinsics_slot(const PcgLayout& L, uint32_t u) {
+  if (L.optimize_depth_intrinsics && u >= L.depth_intr_start && u < L.depth_intr_start + 5u) return (int)(u - L.depth_intr_start);
+  if (L.optimize_color_intrinsics && u >= L.color_intr_start && u < L.color_intr_start + 4u) return 5 + (int)(u - L.color_intr_start);
+  return -1;
+}
+
+// ---- the exact accumulators of one PCG solve ------------------------------------------------------------------------------
+// One device allocation, laid out so that what a sharded run exchanges is contiguous:
+//   [ replicated slots 0..19 | head A | head B | replicated slot 20 | replicated slots 21..22 | invalid flag ]
+// exchange 1 (after a sweep) = slots 0..19 + head A (+ head B after PCGInit); exchange 2 (after a dot product) = slot 20.
+// Slots 21 / 22 hold the dense head's share of the dot products: the head is replicated over the ranks, so every rank adds the
+// same terms there and they are NOT exchanged.
+__device__ __forceinline__ ExactCell* hot_cell(const PcgExact& ex, int slot, int replica) {
+  return (slot < kHotExchanged1 ? ex.hot : ex.hot_tail - (size_t)kHotExchanged1 * kHotReplicas) + (size_t)slot * kHotReplicas + replica;
+}
+// One wavefront folds the 64 replicas of slot a (and of slot b if b >= 0) into the exact binary64 value; optionally clears them.
+__device__ __forceinline__ double fold_hot(const PcgExact& ex, int a, int b, bool clear) {
+  const int lane = threadIdx.x & 63;
+  long long l[kExactLimbs];
+  ExactCell* ca = hot_cell(ex, a, lane);
+  ExactCell* cb = b >= 0 ? hot_cell(ex, b, lane) : nullptr;
+#pragma unroll
+  for (int j = 0; j < kExactLimbs; ++j) {
+    l[j] = ca->limb[j] + (cb ? cb->limb[j] : 0ll);
+    if (clear) { ca->limb[j] = 0; if (cb) cb->limb[j] = 0; }
+  }
+#pragma unroll
+  for (int j = 0; j < kExactLimbs; ++j)
+    for (int off = 32; off; off >>= 1) l[j] += __shfl_xor(l[j], off);
+  return exact_value(l);
 }
 
 // Terms of one associated pair (B/kernel_pcg.cu:213-303,334-395 and :663-748,786-905).
@@ -109,9 +152,10 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
 // ---- PCGInit: r -= J^T W F, M += diag(J^T W J)  (B/kernel_pcg.cu:179-541) -----------------------------
 template <bool kDepthIntr, bool kColorIntr>
 __global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
-pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
+pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
                 float* __restrict__ r_, float* __restrict__ M_) {
-  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPcgSweepBlock + threadIdx.x;
+  const uint32_t tile = xcd_chunked_tile(blockIdx.x);
+  const uint32_t i = tile * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -121,7 +165,13 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);   // per surfel, not per pair
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
   const int lane = threadIdx.x & 63;
+  const int replica = (int)(tile & (kHotReplicas - 1));
+  const uint32_t gi = L.optimize_geometry ? (L.surfel_start + (uint32_t)L.geom_stride * ii) : 0u;
   float gr[3] = {0, 0, 0}, gM[3] = {0, 0, 0};     // surfel entries
+  if (L.accumulate && in_range && L.optimize_geometry) {   // per-keyframe calls continue the chain the earlier calls left
+    gr[0] = r_[gi]; gM[0] = M_[gi];
+    if (L.geom_stride == 3) { gr[1] = r_[gi + 1]; gM[1] = M_[gi + 1]; gr[2] = r_[gi + 2]; gM[2] = M_[gi + 2]; }
+  }
   float ir[9], iM[9];                             // 5 depth + 4 colour global intrinsics entries
 #pragma unroll
   for (int q = 0; q < 9; ++q) { ir[q] = 0.f; iM[q] = 0.f; }
@@ -133,7 +183,7 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
         Assoc a;
         bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.geom, gp, gn, &a, nullptr);
         if (!__any(visible)) return;
-        const bool pose_kf = L.optimize_poses && (k != L.gauge);
+        const bool pose_kf = kf_pose_is_unknown(L, k);
         float pr[6] = {0, 0, 0, 0, 0, 0}, pM[6] = {0, 0, 0, 0, 0, 0};
         if (visible) {
           PairTerms t;
@@ -153,8 +203,9 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
 #pragma unroll
                 for (int c = 0; c < 5; ++c) { const float wj = t.w * t.Jdi[c]; ir[c] += -1 * wj * t.raw; iM[c] += t.Jdi[c] * wj; }
                 const float wj = t.w * t.Jcf;
-                unsafeAtomicAdd(&r_[t.cf_index], -1 * wj * t.raw);
-                unsafeAtomicAdd(&M_[t.cf_index], t.Jcf * wj);
+                const uint32_t h = head_index(L, t.cf_index);
+                exact_atomic_add(&ex.head_a[h], -1 * wj * t.raw, ex.invalid);
+                exact_atomic_add(&ex.head_b[h], t.Jcf * wj, ex.invalid);
               }
             }
           }
@@ -186,17 +237,16 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
           }
         }
         if (pose_kf) {
-          const uint32_t base = kf_pose_index(L, k);
-          // 12 totals with one halving butterfly (wave_reduce.h): lane 4 j holds total j
+          const uint32_t base = kf_pose_index(L, k);   // pose unknowns come first: head index == unknown index
+          // 12 tile totals with one halving butterfly (wave_reduce.h): lanes 4 j .. 4 j + 3 hold total j
           const float v[16] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pM[0], pM[1], pM[2], pM[3], pM[4], pM[5], 0.f, 0.f, 0.f, 0.f};
           const float mine = wave_reduce_small<16>(v, lane);
           const int slot = lane >> 2;
-          if ((lane & 3) == 0 && slot < 12) unsafeAtomicAdd(slot < 6 ? &r_[base + slot] : &M_[base + slot - 6], mine);
+          if ((lane & 3) == 0 && slot < 12) exact_atomic_add(slot < 6 ? &ex.head_a[base + slot] : &ex.head_b[base + slot - 6], mine, ex.invalid);
         }
       });
 
   if (in_range && L.optimize_geometry) {
-    const uint32_t gi = L.surfel_start + (uint32_t)L.geom_stride * i;
     r_[gi] = gr[0]; M_[gi] = gM[0];
     if (L.geom_stride == 3) { r_[gi + 1] = gr[1]; M_[gi + 1] = gM[1]; r_[gi + 2] = gr[2]; M_[gi + 2] = gM[2]; }
   }
@@ -208,79 +258,167 @@ pcg_init_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int
       if (lane == q) mine = vr;
       if (lane == 9 + q) mine = vm;
     }
-    if (lane < 18 && mine != 0.f) {
+    if (lane < 18) {
       const int q = lane % 9;
       const bool is_depth = q < 5;
-      if ((is_depth && kDepthIntr) || (!is_depth && kColorIntr)) {
-        const uint32_t u = is_depth ? (L.depth_intr_start + q) : (L.color_intr_start + (q - 5));
-        unsafeAtomicAdd(lane < 9 ? &r_[u] : &M_[u], mine);
-      }
+      if ((is_depth && kDepthIntr) || (!is_depth && kColorIntr))
+        exact_atomic_add(hot_cell(ex, (lane < 9 ? kHotA : kHotB) + q, replica), mine, ex.invalid);
     }
   }
 }
 
 // ---- inner-loop control on the device -------------------------------------------------------------------------------------
 // The reference reads beta_n back after every inner step and decides on the host whether the residual norm still improves
-// (B/direct_ba_pcg.cc:427-456: stop after three steps without an improvement of 1e-3).  Here a one-thread kernel takes that
-// decision after step 2; once `stop` is set the sweeps and vector kernels queued behind it return at once, so the host can
-// queue several inner steps without waiting for any of them.
+// (B/direct_ba_pcg.cc:427-456: stop after three steps without an improvement of 1e-3).  Here a one-wavefront kernel resolves
+// beta_n and takes that decision after step 2; once `stop` is set the sweeps and vector kernels queued behind it return at
+// once, so the host can queue several inner steps without waiting for any of them.
 struct PcgControl {
-  float prev_r_norm;
+  double prev_r_norm;
   int no_improvement;
   int stop;
   int steps;
+  int pad;
 };
-__global__ void pcg_control_kernel(PcgControl* ctl, const float* beta_n) {
-  if (ctl->stop) return;
-  ctl->steps += 1;
-  const float r_norm = sqrtf(*beta_n);
-  if (r_norm < ctl->prev_r_norm - 1e-3f) ctl->no_improvement = 0;
-  else if (++ctl->no_improvement >= 3) ctl->stop = 1;
-  ctl->prev_r_norm = r_norm;
-}
-__global__ void pcg_control_init_kernel(PcgControl* ctl) {
-  ctl->prev_r_norm = __builtin_huge_valf(); ctl->no_improvement = 0; ctl->stop = 0; ctl->steps = 0;
-}
-
-// ---- block-level scalar reduction helper ------------------------------------------------------------------
-// One atomic per workgroup of kPcgBlock threads.  The vector kernels below run a grid-stride loop over at most
-// kPcgReduceBlocks workgroups: a dot product over 9 M unknowns then ends in 1024 atomics on its scalar instead of one per
-// wavefront (141 k atomics on ONE address serialise at 12.6 ns each -- 1.79 ms for a kernel that moves 0.2 GB).
-constexpr unsigned kPcgReduceBlocks = 1024;
-__device__ __forceinline__ void block_atomic_sum(float* dest, float value) {
-  __shared__ float partial[kPcgBlock / 64];
-  const float v = wave_sum(value);
-  if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = v;
-  __syncthreads();
+static_assert(sizeof(PcgControl) == 24, "PcgControl lives behind the scalars of the PCG buffer");
+// after PCGInit2: alpha_n = the exact dot product, rounded; the control block starts over
+__global__ void __launch_bounds__(64) pcg_control_init_kernel(PcgExact ex, PcgControl* ctl, float* alpha_n) {
+  const double v = fold_hot(ex, kHotDotLocal, kHotDotHead, true);
   if (threadIdx.x == 0) {
-    const float total = ((partial[0] + partial[1]) + partial[2]) + partial[3];
-    if (total != 0.f) unsafeAtomicAdd(dest, total);
+    *alpha_n = (*ex.invalid) ? __builtin_nanf("") : (float)v;
+    ctl->prev_r_norm = __builtin_huge_val(); ctl->no_improvement = 0; ctl->stop = 0; ctl->steps = 0;
+  }
+}
+// after PCGStep2: beta_n, then the stopping rule.  r_norm is a PCGScalar (binary32 square root), the comparison is evaluated
+// in double like the reference's `r_norm < prev_r_norm - 1e-3` (B/direct_ba_pcg.cc:441-446).
+__global__ void __launch_bounds__(64) pcg_control_kernel(PcgExact ex, PcgControl* ctl, float* beta_n) {
+  if (ctl->stop) return;
+  const double v = fold_hot(ex, kHotDotLocal, kHotDotHead, true);
+  if (threadIdx.x == 0) {
+    const float bn = (*ex.invalid) ? __builtin_nanf("") : (float)v;
+    *beta_n = bn;
+    ctl->steps += 1;
+    const float r_norm = __builtin_sqrtf(bn);   // IEEE (no fast-math): the correctly rounded root, like the oracle's sqrtf
+    if ((double)r_norm < ctl->prev_r_norm - 1e-3) ctl->no_improvement = 0;
+    else if (++ctl->no_improvement >= 3) ctl->stop = 1;
+    ctl->prev_r_norm = (double)r_norm;
   }
 }
 
-// PCGInit2 (B/kernel_pcg.cu:565-600)
+// ---- resolving the exact accumulators into the PCGScalar vectors -------------------------------------------------------------
+// Workgroups [0, head blocks): one thread per dense-head unknown: exact value -> va[u] (and vb[u]); the cell is cleared.  The
+// last workgroup folds the replicated slots: the global intrinsics entries and, after PCGStep1, alpha_d.
+template <bool kInit>
 __global__ void __launch_bounds__(kPcgBlock)
-pcg_init2_kernel(PcgLayout L, float a, const float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta,
-                 float* __restrict__ g_, float* __restrict__ p_, float* alpha_n) {
-  float term = 0.f;
+pcg_resolve_kernel(PcgLayout L, PcgExact ex, float* __restrict__ va, float* __restrict__ vb, float* alpha_d, double eps_repeat,
+                   const PcgControl* ctl) {
+  if (!kInit && ctl->stop) return;
+  const bool invalid = *ex.invalid != 0u;
+  const uint32_t head_count = L.head_lo + (L.unknown_count - L.head_hi);
+  if (blockIdx.x + 1 < gridDim.x) {
+    const uint32_t h = blockIdx.x * kPcgBlock + threadIdx.x;
+    if (h >= head_count) return;
+    const uint32_t u = h < L.head_lo ? h : L.head_hi + (h - L.head_lo);
+    if (intrinsics_slot(L, u) >= 0) return;   // written by the last workgroup
+    ExactCell* ca = &ex.head_a[h];
+    va[u] = invalid ? __builtin_nanf("") : (float)exact_value(ca->limb);
+#pragma unroll
+    for (int j = 0; j < kExactLimbs; ++j) ca->limb[j] = 0;
+    if (kInit) {
+      ExactCell* cb = &ex.head_b[h];
+      vb[u] = invalid ? __builtin_nanf("") : (float)exact_value(cb->limb);
+#pragma unroll
+      for (int j = 0; j < kExactLimbs; ++j) cb->limb[j] = 0;
+    }
+    return;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int task = wave; task < (kInit ? 18 : 10); task += kPcgBlock / 64) {
+    if (!kInit && task == 9) {
+      // alpha_d = pairs + repeat * epsilon terms (AddAlphaDEpsilonTerms runs once per keyframe in the reference,
+      // B/kernel_pcg.cu:1102-1112: the term enters `repeat` times), both exact sums, combined in binary64
+      const double pairs = fold_hot(ex, kHotAlphaD, -1, true);
+      const double eps = fold_hot(ex, kHotEpsLocal, kHotEpsHead, true);
+      if (lane == 0) *alpha_d = invalid ? __builtin_nanf("") : (float)(pairs + eps_repeat * eps);
+      continue;
+    }
+    const int q = task % 9;
+    const bool enabled = (q < 5) ? L.optimize_depth_intrinsics : L.optimize_color_intrinsics;
+    if (!enabled) continue;
+    const double v = fold_hot(ex, (task < 9 ? kHotA : kHotB) + q, -1, true);
+    const uint32_t u = (q < 5) ? (L.depth_intr_start + q) : (L.color_intr_start + (q - 5));
+    if (lane == 0) (task < 9 ? va : vb)[u] = invalid ? __builtin_nanf("") : (float)v;
+  }
+}
+
+// ---- exact dot products in the per-unknown kernels -----------------------------------------------------------------------------
+// A thread's terms over the local (surfel) unknowns go into a private column of limbs in workgroup memory (the limb index is
+// data dependent); terms of dense-head unknowns -- few -- go straight to the head's replicated slot with atomics.  At the end
+// the workgroup folds its columns and adds 9 limbs per sum to one of the 64 replicas.
+template <int kSets>
+struct BlockExact {
+  long long limbs[kSets][kExactLimbs][kPcgBlock];
+};
+template <int kSets>
+__device__ __forceinline__ void block_exact_clear(BlockExact<kSets>& b) {
+#pragma unroll
+  for (int set = 0; set < kSets; ++set)
+#pragma unroll
+    for (int j = 0; j < kExactLimbs; ++j) b.limbs[set][j][threadIdx.x] = 0;
+}
+template <int kSets>
+__device__ __forceinline__ void block_exact_add(BlockExact<kSets>& b, int set, float v, unsigned* invalid) {
+  exact_lds_add(&b.limbs[set][0][0], kPcgBlock, (int)threadIdx.x, v, invalid);
+}
+template <int kSets>
+__device__ __forceinline__ void block_exact_flush(BlockExact<kSets>& b, const PcgExact& ex, const int (&slots)[kSets]) {
+  __syncthreads();
+  const int replica = (int)(blockIdx.x & (kHotReplicas - 1));
+  const int part = threadIdx.x & 15;
+  for (int row = threadIdx.x >> 4; row < kSets * kExactLimbs; row += kPcgBlock >> 4) {   // 16 threads fold one row of 256 columns
+    const long long* line = &b.limbs[0][0][0] + (size_t)row * kPcgBlock;
+    long long sum = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sum += line[c * 16 + part];
+    for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off);
+    if (part == 0 && sum != 0) limb_atomic_add(&hot_cell(ex, slots[row / kExactLimbs], replica)->limb[row % kExactLimbs], sum);
+  }
+}
+
+// PCGInit2 (B/kernel_pcg.cu:565-600); also the epsilon terms of the first step's alpha_d (they depend on p alone)
+__global__ void __launch_bounds__(kPcgBlock)
+pcg_init2_kernel(PcgLayout L, PcgExact ex, float a, const float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta,
+                 float* __restrict__ g_, float* __restrict__ p_) {
+  __shared__ BlockExact<2> acc;
+  block_exact_clear(acc);
+  const int replica = (int)(blockIdx.x & (kHotReplicas - 1));
   for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
     g_[u] = 0;
     const float r_value = r_[u] + ((u == L.a_index) ? (-kAPriorWeight * kAPriorWeight * a) : 0);
     const float p_value = r_value / (M_[u] + kDiagEpsilon + prior_at(L, u));
     p_[u] = p_value;
     delta[u] = 0;
-    term += dot_weight(L, u) * (r_value * p_value);
+    const float dot_term = r_value * p_value;
+    const float eps_term = (kDiagEpsilon + prior_at(L, u)) * p_value * p_value;
+    if (is_local(L, u)) {
+      block_exact_add(acc, 0, dot_term, ex.invalid);
+      block_exact_add(acc, 1, eps_term, ex.invalid);
+    } else {
+      exact_atomic_add(hot_cell(ex, kHotDotHead, replica), dot_term, ex.invalid);
+      exact_atomic_add(hot_cell(ex, kHotEpsHead, replica), eps_term, ex.invalid);
+    }
   }
-  block_atomic_sum(alpha_n, term);
+  const int slots[2] = {kHotDotLocal, kHotEpsLocal};
+  block_exact_flush(acc, ex, slots);
 }
 
 // ---- PCGStep1: g += J^T W J p, alpha_d += p^T J^T W J p  (B/kernel_pcg.cu:646-1026) -------------------
 template <bool kDepthIntr, bool kColorIntr>
 __global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
-pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                 const float* __restrict__ p_, float* __restrict__ g_, float* alpha_d, const PcgControl* ctl) {
+pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
+                 const float* __restrict__ p_, float* __restrict__ g_, const PcgControl* ctl) {
   if (ctl->stop) return;
-  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kPcgSweepBlock + threadIdx.x;
+  const uint32_t tile = xcd_chunked_tile(blockIdx.x);
+  const uint32_t i = tile * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -290,6 +428,7 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);   // per surfel, not per pair
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
   const int lane = threadIdx.x & 63;
+  const int replica = (int)(tile & (kHotReplicas - 1));
   const uint32_t gi = L.optimize_geometry ? (L.surfel_start + (uint32_t)L.geom_stride * ii) : 0u;
   float ps[3] = {0, 0, 0};
   if (L.optimize_geometry) {
@@ -300,6 +439,10 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
   if (kDepthIntr) for (int c = 0; c < 5; ++c) pdi[c] = p_[L.depth_intr_start + c];
   if (kColorIntr) for (int c = 0; c < 4; ++c) pci[c] = p_[L.color_intr_start + c];
   float gs[3] = {0, 0, 0};
+  if (L.accumulate && in_range && L.optimize_geometry) {
+    gs[0] = g_[gi];
+    if (L.geom_stride == 3) { gs[1] = g_[gi + 1]; gs[2] = g_[gi + 2]; }
+  }
   float gi_acc[9];
 #pragma unroll
   for (int q = 0; q < 9; ++q) gi_acc[q] = 0.f;
@@ -312,7 +455,7 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
         Assoc a;
         const bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.geom, gp, gn, &a, nullptr);
         if (!__any(visible)) return;
-        const bool pose_kf = L.optimize_poses && (k != L.gauge);
+        const bool pose_kf = kf_pose_is_unknown(L, k);
         const uint32_t base = kf_pose_index(L, k);
         float pp[6] = {0, 0, 0, 0, 0, 0};
         if (pose_kf) for (int c = 0; c < 6; ++c) pp[c] = p_[base + c];
@@ -348,7 +491,7 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
             if (di) {
 #pragma unroll
               for (int c = 0; c < 5; ++c) gi_acc[c] += t.Jdi[c] * sum;
-              unsafeAtomicAdd(&g_[t.cf_index], t.Jcf * sum);
+              exact_atomic_add(&ex.head_a[head_index(L, t.cf_index)], t.Jcf * sum, ex.invalid);
             }
           }
           if (L.use_desc && t.color_ok) {
@@ -385,8 +528,8 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
         }
         if (pose_kf) {
           const float v[8] = {gpose[0], gpose[1], gpose[2], gpose[3], gpose[4], gpose[5], 0.f, 0.f};
-          const float mine = wave_reduce_small<8>(v, lane);   // lane 8 j holds total j
-          if ((lane & 7) == 0 && lane < 48) unsafeAtomicAdd(&g_[base + (lane >> 3)], mine);
+          const float mine = wave_reduce_small<8>(v, lane);   // lanes 8 j .. 8 j + 7 hold total j
+          if ((lane & 7) == 0 && lane < 48) exact_atomic_add(&ex.head_a[base + (lane >> 3)], mine, ex.invalid);
         }
       });
 
@@ -402,32 +545,20 @@ pcg_step1_kernel(PcgLayout L, Intrinsics in, const KfEntry* __restrict__ kfs, in
   }
   const float adv = wave_sum(ad);
   if (lane == 9) mine = adv;
-  if (lane < 9 && mine != 0.f) {
-    if (lane < 5) { if (kDepthIntr) unsafeAtomicAdd(&g_[L.depth_intr_start + lane], mine); }
-    else if (kColorIntr) unsafeAtomicAdd(&g_[L.color_intr_start + lane - 5], mine);
+  if (lane < 9) {
+    if (lane < 5 ? kDepthIntr : kColorIntr) exact_atomic_add(hot_cell(ex, kHotA + lane, replica), mine, ex.invalid);
   }
-  if (lane == 9 && mine != 0.f) unsafeAtomicAdd(alpha_d, mine);
-}
-
-// AddAlphaDEpsilonTerms (B/kernel_pcg.cu:1028-1050); the reference launches it once per keyframe
-// (B/kernel_pcg.cu:1102-1112), i.e. the term enters alpha_d `repeat` times -- reproduced.
-__global__ void __launch_bounds__(kPcgBlock)
-pcg_eps_terms_kernel(PcgLayout L, const float* __restrict__ p_, float repeat, float* alpha_d, const PcgControl* ctl) {
-  if (ctl->stop) return;
-  float term = 0.f;
-  for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
-    const float pv = p_[u];
-    term += dot_weight(L, u) * ((kDiagEpsilon + prior_at(L, u)) * pv * pv);
-  }
-  block_atomic_sum(alpha_d, repeat * term);
+  if (lane == 9) exact_atomic_add(hot_cell(ex, kHotAlphaD, replica), mine, ex.invalid);
 }
 
 // PCGStep2 (B/kernel_pcg.cu:1117-1158)
 __global__ void __launch_bounds__(kPcgBlock)
-pcg_step2_kernel(PcgLayout L, float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta, float* __restrict__ g_,
-                 const float* __restrict__ p_, const float* alpha_n, const float* alpha_d, float* beta_n, const PcgControl* ctl) {
+pcg_step2_kernel(PcgLayout L, PcgExact ex, float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta,
+                 float* __restrict__ g_, const float* __restrict__ p_, const float* alpha_n, const float* alpha_d, const PcgControl* ctl) {
   if (ctl->stop) return;
-  float term = 0.f;
+  __shared__ BlockExact<1> acc;
+  block_exact_clear(acc);
+  const int replica = (int)(blockIdx.x & (kHotReplicas - 1));
   const float ad = *alpha_d;
   const float alpha = (ad >= 1e-35f) ? (*alpha_n / ad) : 0;
   for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
@@ -438,22 +569,49 @@ pcg_step2_kernel(PcgLayout L, float* __restrict__ r_, const float* __restrict__ 
     r_[u] = r_value;
     const float z_value = r_value / (M_[u] + kDiagEpsilon + prior_at(L, u));
     g_[u] = z_value;
-    term += dot_weight(L, u) * (z_value * r_value);
+    const float term = z_value * r_value;
+    if (is_local(L, u)) block_exact_add(acc, 0, term, ex.invalid);
+    else exact_atomic_add(hot_cell(ex, kHotDotHead, replica), term, ex.invalid);
   }
-  block_atomic_sum(beta_n, term);
+  const int slots[1] = {kHotDotLocal};
+  block_exact_flush(acc, ex, slots);
 }
 
-// PCGStep3 (B/kernel_pcg.cu:1212-1226)
+// PCGStep3 (B/kernel_pcg.cu:1212-1226), and the epsilon terms of the next step's alpha_d from the new p
+// (AddAlphaDEpsilonTerms, B/kernel_pcg.cu:1028-1050)
 __global__ void __launch_bounds__(kPcgBlock)
-pcg_step3_kernel(PcgLayout L, const float* __restrict__ g_, float* __restrict__ p_, const float* alpha_n, const float* beta_n,
+pcg_step3_kernel(PcgLayout L, PcgExact ex, const float* __restrict__ g_, float* __restrict__ p_, const float* alpha_n, const float* beta_n,
                  const PcgControl* ctl) {
-  const uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x;
   if (ctl->stop) return;
-  if (u < L.unknown_count) {
-    const float an = *alpha_n;
-    const float beta = (an >= 1e-35f) ? (*beta_n / an) : 0;
-    p_[u] = g_[u] + beta * p_[u];
+  __shared__ BlockExact<1> acc;
+  block_exact_clear(acc);
+  const int replica = (int)(blockIdx.x & (kHotReplicas - 1));
+  const float an = *alpha_n;
+  const float beta = (an >= 1e-35f) ? (*beta_n / an) : 0;
+  for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
+    const float pv = g_[u] + beta * p_[u];
+    p_[u] = pv;
+    const float term = (kDiagEpsilon + prior_at(L, u)) * pv * pv;
+    if (is_local(L, u)) block_exact_add(acc, 0, term, ex.invalid);
+    else exact_atomic_add(hot_cell(ex, kHotEpsHead, replica), term, ex.invalid);
   }
+  const int slots[1] = {kHotEpsLocal};
+  block_exact_flush(acc, ex, slots);
+}
+// the epsilon terms alone (per-stage entry points: a caller's PCGStep1 sees a p that no step 3 of ours produced)
+__global__ void __launch_bounds__(kPcgBlock)
+pcg_eps_terms_kernel(PcgLayout L, PcgExact ex, const float* __restrict__ p_) {
+  __shared__ BlockExact<1> acc;
+  block_exact_clear(acc);
+  const int replica = (int)(blockIdx.x & (kHotReplicas - 1));
+  for (uint32_t u = blockIdx.x * kPcgBlock + threadIdx.x; u < L.unknown_count; u += gridDim.x * kPcgBlock) {
+    const float pv = p_[u];
+    const float term = (kDiagEpsilon + prior_at(L, u)) * pv * pv;
+    if (is_local(L, u)) block_exact_add(acc, 0, term, ex.invalid);
+    else exact_atomic_add(hot_cell(ex, kHotEpsHead, replica), term, ex.invalid);
+  }
+  const int slots[1] = {kHotEpsLocal};
+  block_exact_flush(acc, ex, slots);
 }
 
 // UpdateSurfelsFromPCGDelta (B/kernel_pcg.cu:1306-1331)
@@ -484,52 +642,103 @@ pcg_update_cfactors_kernel(Intrinsics in, uint32_t start, const float* __restric
   *pitched_ptr(cfactor, pitch, y, x) += delta[start + idx];
 }
 
+// ---- test hook: the exact sum of n binary32 values through the same device code paths ------------------------------------------
+// mode 0: every term with exact_atomic_add into one of 64 replicas; mode 1: through the per-thread columns in workgroup memory
+// and block_exact_flush, as the per-unknown kernels do.  The result is the binary64 value fold_hot + exact_value produce.
+__global__ void __launch_bounds__(kPcgBlock) exact_sum_debug_kernel(PcgExact ex, const float* __restrict__ v, size_t n, int mode) {
+  __shared__ BlockExact<1> acc;
+  block_exact_clear(acc);
+  const int replica = (int)(blockIdx.x & (kHotReplicas - 1));
+  for (size_t i = (size_t)blockIdx.x * kPcgBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kPcgBlock) {
+    if (mode == 0) exact_atomic_add(hot_cell(ex, kHotDotHead, replica), v[i], ex.invalid);
+    else block_exact_add(acc, 0, v[i], ex.invalid);
+  }
+  const int slots[1] = {kHotDotLocal};
+  block_exact_flush(acc, ex, slots);
+}
+__global__ void __launch_bounds__(64) exact_sum_debug_resolve_kernel(PcgExact ex, double* out) {
+  const double v = fold_hot(ex, kHotDotLocal, kHotDotHead, true);
+  if (threadIdx.x == 0) *out = (*ex.invalid) ? __builtin_nan("") : v;
+}
+void launch_exact_sum_debug(hipStream_t st, const PcgExact& ex, const float* values, size_t n, int mode, double* out) {
+  const unsigned blocks = n ? (unsigned)((n + kPcgBlock - 1) / kPcgBlock < 512 ? (n + kPcgBlock - 1) / kPcgBlock : 512) : 1u;
+  hipLaunchKernelGGL(exact_sum_debug_kernel, dim3(blocks), dim3(kPcgBlock), 0, st, ex, values, n, mode);
+  hipLaunchKernelGGL(exact_sum_debug_resolve_kernel, dim3(1), dim3(64), 0, st, ex, out);
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------
 static inline unsigned gU(uint32_t n) { return (n + kPcgBlock - 1) / kPcgBlock; }
-static inline unsigned gR(uint32_t n) { return gU(n) < kPcgReduceBlocks ? gU(n) : kPcgReduceBlocks; }   // grid-stride reductions
+// The per-unknown kernels run a grid-stride loop over at most kPcgReduceBlocks workgroups: each ends in 9 atomics per sum.
+constexpr unsigned kPcgReduceBlocks = 1024;
+static inline unsigned gR(uint32_t n) { return gU(n) < kPcgReduceBlocks ? gU(n) : kPcgReduceBlocks; }
 
 // whole XCD chunks, as in kernels_surfel.hip (xcd_chunked_tile)
 static inline unsigned gS(uint32_t n) { return xcd_padded_tiles((n + kPcgSweepBlock - 1) / kPcgSweepBlock); }
 
-void launch_pcg_init(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
-                     float* r, float* M) {
+size_t pcg_exact_cells(uint32_t head_count) { return (size_t)kHotSlots * kHotReplicas + 2 * (size_t)head_count + 1; }
+PcgExact pcg_exact_view(void* buffer, uint32_t head_count) {
+  PcgExact ex;
+  ExactCell* base = static_cast<ExactCell*>(buffer);
+  ex.hot = base;
+  ex.head_a = base + (size_t)kHotExchanged1 * kHotReplicas;
+  ex.head_b = ex.head_a + head_count;
+  ex.hot_tail = ex.head_b + head_count;
+  ex.invalid = reinterpret_cast<unsigned*>(ex.hot_tail + (size_t)(kHotSlots - kHotExchanged1) * kHotReplicas);
+  return ex;
+}
+
+void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                     const SurfelsView& s, float* r, float* M) {
   if (!s.size) return;
   const dim3 grid(gS(s.size)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
-  if (di && ci) hipLaunchKernelGGL((pcg_init_kernel<true, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, r, M);
-  else if (di) hipLaunchKernelGGL((pcg_init_kernel<true, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, r, M);
-  else if (ci) hipLaunchKernelGGL((pcg_init_kernel<false, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, r, M);
-  else hipLaunchKernelGGL((pcg_init_kernel<false, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, r, M);
+  if (di && ci) hipLaunchKernelGGL((pcg_init_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
+  else if (di) hipLaunchKernelGGL((pcg_init_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
+  else if (ci) hipLaunchKernelGGL((pcg_init_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
+  else hipLaunchKernelGGL((pcg_init_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
 }
-void launch_pcg_init2(hipStream_t st, const PcgLayout& L, float a, const float* r, const float* M, float* delta, float* g, float* p,
-                      float* alpha_n) {
-  if (L.unknown_count) hipLaunchKernelGGL(pcg_init2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, a, r, M, delta, g, p, alpha_n);
+static inline unsigned resolve_grid(const PcgLayout& L) { return gU(L.head_lo + (L.unknown_count - L.head_hi)) + 1; }
+void launch_pcg_resolve_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, float* M) {
+  hipLaunchKernelGGL((pcg_resolve_kernel<true>), dim3(resolve_grid(L)), dim3(kPcgBlock), 0, st, L, ex, r, M, nullptr, 0.0, nullptr);
 }
-void launch_pcg_control_init(hipStream_t st, void* ctl) { hipLaunchKernelGGL(pcg_control_init_kernel, dim3(1), dim3(1), 0, st, static_cast<PcgControl*>(ctl)); }
-void launch_pcg_control(hipStream_t st, void* ctl, const float* beta_n) {
-  hipLaunchKernelGGL(pcg_control_kernel, dim3(1), dim3(1), 0, st, static_cast<PcgControl*>(ctl), beta_n);
+void launch_pcg_resolve_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* g, float* alpha_d, double eps_repeat, const void* ctl) {
+  hipLaunchKernelGGL((pcg_resolve_kernel<false>), dim3(resolve_grid(L)), dim3(kPcgBlock), 0, st, L, ex, g, nullptr, alpha_d, eps_repeat,
+                     static_cast<const PcgControl*>(ctl));
+}
+void launch_pcg_init2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float a, const float* r, const float* M, float* delta, float* g,
+                      float* p) {
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_init2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, ex, a, r, M, delta, g, p);
+}
+void launch_pcg_control_init(hipStream_t st, const PcgExact& ex, void* ctl, float* alpha_n) {
+  hipLaunchKernelGGL(pcg_control_init_kernel, dim3(1), dim3(64), 0, st, ex, static_cast<PcgControl*>(ctl), alpha_n);
+}
+void launch_pcg_control(hipStream_t st, const PcgExact& ex, void* ctl, float* beta_n) {
+  hipLaunchKernelGGL(pcg_control_kernel, dim3(1), dim3(64), 0, st, ex, static_cast<PcgControl*>(ctl), beta_n);
 }
 size_t pcg_control_bytes() { return sizeof(PcgControl); }
 
-void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
-                      const float* p, float* g, float* alpha_d, const void* ctl_) {
+void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                      const SurfelsView& s, const float* p, float* g, const void* ctl_) {
   const PcgControl* ctl = static_cast<const PcgControl*>(ctl_);
   if (!s.size) return;
   const dim3 grid(gS(s.size)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
-  if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
-  else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
-  else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
-  else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, in, kfs, num_kfs, s, p, g, alpha_d, ctl);
-  hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, p, (float)num_kfs, alpha_d, ctl);
+  if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
+  else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
+  else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
+  else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
 }
-void launch_pcg_step2(hipStream_t st, const PcgLayout& L, float* r, const float* M, float* delta, float* g, const float* p,
-                      const float* alpha_n, const float* alpha_d, float* beta_n, const void* ctl) {
-  if (L.unknown_count) hipLaunchKernelGGL(pcg_step2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, r, M, delta, g, p, alpha_n, alpha_d, beta_n,
+void launch_pcg_eps_terms(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* p) {
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, ex, p);
+}
+void launch_pcg_step2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, const float* M, float* delta, float* g, const float* p,
+                      const float* alpha_n, const float* alpha_d, const void* ctl) {
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_step2_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, ex, r, M, delta, g, p, alpha_n, alpha_d,
                                           static_cast<const PcgControl*>(ctl));
 }
-void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const float* g, float* p, const float* alpha_n, const float* beta_n, const void* ctl) {
-  if (L.unknown_count) hipLaunchKernelGGL(pcg_step3_kernel, dim3(gU(L.unknown_count)), dim3(kPcgBlock), 0, st, L, g, p, alpha_n, beta_n,
+void launch_pcg_step3(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* g, float* p, const float* alpha_n, const float* beta_n,
+                      const void* ctl) {
+  if (L.unknown_count) hipLaunchKernelGGL(pcg_step3_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, ex, g, p, alpha_n, beta_n,
                                           static_cast<const PcgControl*>(ctl));
 }
 void launch_pcg_update_surfels(hipStream_t st, const PcgLayout& L, const SurfelsView& s, const float* delta) {

@@ -312,6 +312,13 @@ class Scene:
                                                         out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def exact_sum(self, values, mode=0):
+        """Exactly rounded binary64 sum of binary32 values through the device's exact accumulators (test hook)."""
+        v = np.ascontiguousarray(values, np.float32)
+        out = C.c_double()
+        capi.check(self.lib.bahip_debug_exact_sum(self.ctx.handle, v.ctypes.data_as(C.POINTER(C.c_float)), v.size, int(mode), C.byref(out)))
+        return float(out.value)
+
     def count_pairs(self):
         """(wave-keyframe candidates, wave-keyframe hits, associated pairs, in-image pairs) of one sweep."""
         out = (C.c_uint64 * 4)()

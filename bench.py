@@ -184,8 +184,40 @@ def cpu_baseline(args, ba, data, log):
     return dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=ob.lib().orc_num_threads(), nres=nres, cost=cost)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, one per GPU, exactly the way the
+    driver does it (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), and pass
+    rank 0's JSON line through.  Fails loudly when the box has fewer than N devices (BENCH_DIST_BACKEND=gloo lets ranks share
+    a device: a plumbing test, not a measurement)."""
+    import socket
+    import subprocess
+    from badslam_amd import capi
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    devices = int(capi.load().bahip_device_count())
+    if devices < 1 or (backend == "nccl" and devices < args.gpus):
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} HIP devices, this box has {devices} "
+              f"(one rank per GPU over RCCL; nothing is measured on fewer)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        # a line that says "n_gpus": 1 for a run that was asked to use 8 would be read as a scaling result
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} rank(s)", file=sys.stderr)
+        sys.exit(2)
     # stdout carries exactly one JSON line: anything a library prints to fd 1 (RCCL prints a version banner there)
     # is sent to stderr instead, and the result is written to the original stdout at the end.
     sys.stdout.flush()
@@ -201,6 +233,9 @@ def main():
         # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a device (plumbing test on a 1-GPU box: RCCL
         # refuses two ranks on one device, gloo stages the all-reduce through the host)
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            print(f"bench.py: {world} ranks over RCCL need {world} devices, this box has {torch.cuda.device_count()}", file=sys.stderr)
+            sys.exit(2)
         device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
         torch.cuda.set_device(device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -266,6 +301,7 @@ def main():
     # hipEvent pairs around every launch of the dominant kernel in the timed region (the roofline's duration); the other
     # stages are timed in a few extra iterations afterwards, so their ten event records per iteration stay out of `value`
     capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 3))
+    capi.check(ctx.lib.bahip_exchange_stats(ctx.handle, None, None, 1))
     ctx.synchronize()
     if dist is not None:
         dist.barrier()
@@ -274,9 +310,12 @@ def main():
     run(args.steps)
     ctx.synchronize()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0       # this rank alone, before it waits for the others
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    exchange_calls, exchange_bytes = C.c_longlong(), C.c_longlong()
+    capi.check(ctx.lib.bahip_exchange_stats(ctx.handle, C.byref(exchange_calls), C.byref(exchange_bytes), 0))
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -327,6 +366,14 @@ def main():
                          "max_inner_iterations": 30, "iterations": EXTRA_STEPS,
                          "note": "PCG scheme (poses + geometry) on the same scene after the timed region"}
 
+    per_rank = None
+    if dist is not None and world > 1:
+        # what makes a measured scaling curve readable: every rank's own time and stage breakdown, and what was exchanged
+        mine_report = {"rank": rank, "surfels": int(mine.size), "ms_per_step_before_barrier": 1e3 * local_elapsed / args.steps,
+                       "stage_ms_per_iteration": {STAGES[s]: float(breakdown_ms[s]) / BREAKDOWN_STEPS for s in range(5 if args.intrinsics else 4)},
+                       "pose_accumulate_ms_per_launch_timed_region": float(stage_ms[2]) / max(1, int(stage_launches[2]))}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_report)
     if rank == 0:
         W, H = args.width, args.height
         N_rank = int(mine.size)
@@ -352,6 +399,12 @@ def main():
                        "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, %g cm grid)" % (100 * args.sort_cell),
                        "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU"},
             **({"emulated_share_of_world": shard_world} if shard_world != world else {}),
+            **({"exchange": {"calls_per_iteration": exchange_calls.value / args.steps, "bytes_per_iteration": exchange_bytes.value / args.steps,
+                             "what": "int64 fixed-point pose normal equations, one all-reduce per Gauss-Newton round"
+                                     + ("; binary64 intrinsics accumulators" if args.intrinsics else "")
+                                     + ("; int64 limbs of the PCG scheme's exact sums, two per inner step" if args.pcg else ""),
+                             "transport": "torch.distributed hook" if hook_keepalive is not None else "native RCCL (ncclAllReduce on the backend's stream)"},
+                "per_rank": per_rank} if per_rank is not None else {}),
             "stage_ms_per_iteration": {STAGES[s]: breakdown_ms[s] / BREAKDOWN_STEPS for s in range(5 if args.intrinsics else 4)},
             "stage_ms_note": f"{BREAKDOWN_STEPS} further iterations after the timed region, all stages timed; the surfel activation "
                              "is decided inside the normals pass of the geometry sweep (one launch), hence 0",

@@ -311,6 +311,12 @@ int bahip_debug_evaluate_pairs(bahip_context* ctx, const bahip_frame* frame, con
  * assembles r = -J^T W F and M = diag(J^T W J) and applies no update. */
 int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, size_t count, float* out);
 
+/* The exact sum of `count` binary32 values, rounded once to binary64 (nearest, ties to even; NaN if a value is not finite),
+ * through the device code the PCG scheme's dense sums and dot products use (badslam_amd/csrc/exact_sum.h).  mode 0: every
+ * term with 64-bit integer atomics on the accumulator's limbs; mode 1: per-thread limb columns in workgroup memory, folded
+ * per workgroup (the path of the per-unknown kernels).  Tests compare it with math.fsum. */
+int bahip_debug_exact_sum(bahip_context* ctx, const float* values, size_t count, int mode, double* out);
+
 /* Work census of one sweep of the bound keyframes over the surfels: counts[0] = (wavefront, keyframe)
  * candidates left by frustum culling, [1] = of those with >= 1 association, [2] = associated
  * (surfel, keyframe) pairs, [3] = pairs projecting into the image. */
@@ -353,6 +359,9 @@ int bahip_set_profiling(bahip_context* ctx, int enabled);
 /* Work units of the launches counted above (stage 2: sum over launches of the keyframes still
  * iterating in that Gauss-Newton round; other stages: launches). */
 int bahip_stage_work_units(bahip_context* ctx, int stage, long long* units_out);
+/* Multi-GPU accounting: how many sums over the ranks this context has requested (through the hook or RCCL) since the last
+ * reset, and the bytes of the buffers summed (per rank, one direction).  A single-GPU context reports zeros. */
+int bahip_exchange_stats(bahip_context* ctx, long long* calls_out, long long* bytes_out, int reset);
 
 #ifdef __cplusplus
 }

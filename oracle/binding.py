@@ -147,6 +147,31 @@ def bilateral_filter_and_depth_cutoff(depth_u16, sigma_xy, sigma_value, radius_f
     return out
 
 
+def exact_sum(values):
+    """The exactly rounded binary64 sum of binary32 values (oracle_exact.c: the definition of the PCG scheme's dense sums)."""
+    v = np.ascontiguousarray(values, np.float32)
+    L = lib()
+    L.orc_exact_sum.restype = C.c_double
+    return float(L.orc_exact_sum(_ptr(v, C.c_float), C.c_size_t(v.size)))
+
+
+def exact_limbs(values, limbs=None):
+    """Adds binary32 values into 9 int64 limbs (a new accumulator if limbs is None); returns the limbs."""
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.zeros(9, np.int64) if limbs is None else np.ascontiguousarray(limbs, np.int64).copy()
+    bad = C.c_int(0)
+    lib().orc_exact_accumulate(_ptr(v, C.c_float), C.c_size_t(v.size), _ptr(out, C.c_longlong), C.byref(bad))
+    if bad.value:
+        raise FloatingPointError("non-finite term in an exact sum")
+    return out
+
+
+def exact_resolve(limbs):
+    L = lib()
+    L.orc_exact_resolve.restype = C.c_double
+    return float(L.orc_exact_resolve(_ptr(np.ascontiguousarray(limbs, np.int64), C.c_longlong)))
+
+
 def make_camera(params, width, height):
     p = np.asarray(params, dtype=np.float32)
     return Camera(float(p[0]), float(p[1]), float(p[2]), float(p[3]), int(width), int(height))
@@ -420,9 +445,9 @@ class OracleBA:
         return float(c), int(n.value)
 
     def pcg_assemble(self, optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=False,
-                     optimize_color_intrinsics=False, gauge_keyframe=0, binary64=False):
-        """r = -J^T W F and M = diag(J^T W J) of the PCG scheme for the current state (test hook).  binary64: the same binary32
-        terms accumulated in binary64 (oracle_pcg.c compiled with -DORC_PCG_DOUBLE), rounded to binary32 at the end."""
+                     optimize_color_intrinsics=False, gauge_keyframe=0):
+        """r = -J^T W F and M = diag(J^T W J) of the PCG scheme for the current state (test hook); dense entries are exact sums
+        of the per-tile / per-pair binary32 terms (oracle_pcg.c, oracle_exact.c)."""
         opt = BAOptions(self.use_depth, self.use_desc, int(optimize_depth_intrinsics), int(optimize_color_intrinsics), 0,
                         int(optimize_poses), int(optimize_geometry), 1, 1, 0, len(self.keyframes) - 1, 0,
                         int(self.min_observation_count), float(self.merge_factor), 30, int(gauge_keyframe))
@@ -435,7 +460,7 @@ class OracleBA:
         cap = 6 * len(self.keyframes) + 3 * self.surfels_size + 5 + self.cf_w * self.cf_h + 4
         r = np.zeros(cap, np.float32)
         M = np.zeros(cap, np.float32)
-        fn = self.L.orc_pcg_assemble_f64 if binary64 else self.L.orc_pcg_assemble
+        fn = self.L.orc_pcg_assemble
         fn.restype = C.c_uint32
         U = fn(C.byref(st), C.byref(opt), _ptr(r, C.c_float), _ptr(M, C.c_float), C.c_uint32(cap))
         return r[:U], M[:U]
@@ -470,9 +495,7 @@ class OracleBA:
         st.supporting = _ptr(self.supporting, C.c_uint32)
         st.ba_iteration_count, st.last_ba_iteration_count = self.ba_iteration_count, self.last_ba_iteration_count
         stats = BAStats()
-        # use_pcg = "f64": the PCG scheme with binary64 vectors and scalars (oracle_pcg.c compiled with -DORC_PCG_DOUBLE)
-        fn = (self.L.orc_bundle_adjustment_pcg_f64 if use_pcg == "f64" else self.L.orc_bundle_adjustment_pcg) if use_pcg \
-            else self.L.orc_bundle_adjustment_alternating
+        fn = self.L.orc_bundle_adjustment_pcg if use_pcg else self.L.orc_bundle_adjustment_alternating
         fn(C.byref(st), C.byref(opt), C.byref(stats))
         self.color_cam, self.depth_cam = st.color_cam, st.depth_cam
         self.dp.a = st.dp.a

@@ -29,6 +29,7 @@
 #ifndef BADSLAM_ORACLE_H_
 #define BADSLAM_ORACLE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -315,6 +316,13 @@ double orc_evaluate_cost(int use_depth, int use_desc, const orc_camera* color_ca
                          uint64_t* num_residuals);
 
 int orc_num_threads(void);
+
+/* The exactly rounded (nearest, ties to even) binary64 sum of n binary32 values; NaN if one of them is not finite.  This is
+ * the definition of every dense-block sum and dot product of the PCG scheme (oracle_exact.c). */
+double orc_exact_sum(const float* values, size_t n);
+/* The accumulator itself: 9 int64 limbs (limb j weighs 2^(32 j - 149)); `invalid` is set when a value is not finite. */
+void orc_exact_accumulate(const float* values, size_t n, long long limbs[9], int* invalid);
+double orc_exact_resolve(const long long limbs[9]);
 
 #ifdef __cplusplus
 }

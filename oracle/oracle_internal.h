@@ -11,6 +11,13 @@
 
 typedef struct { float x, y, z; } v3;
 
+/* ---- exact sums of binary32 values (oracle_exact.c) ---- */
+#define ORC_EXACT_LIMBS 9
+typedef struct { long long limb[ORC_EXACT_LIMBS]; } orc_exact;   /* limb j: weight 2^(32 j - 149) */
+void orc_exact_add(orc_exact* cell, float v, int* invalid);      /* atomic on the limbs: callable from OpenMP regions */
+void orc_exact_merge(orc_exact* dst, const orc_exact* src);
+double orc_exact_value(const orc_exact* cell);                   /* the exact sum rounded to binary64, ties to even */
+
 static inline v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
 static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }

@@ -1,30 +1,29 @@
 /* oracle_pcg.c -- the matrix-free PCG Gauss-Newton scheme.
  * Test infrastructure only (see oracle.h).
  * Follows B/direct_ba_pcg.cc:43-819 (driver) and B/kernel_pcg.cu:44-1389 (kernels).
- * PCGScalar = float (B/kernels.cuh:62).  Sums that the reference forms with block reductions +
- * atomics are formed here sequentially in (keyframe, surfel) order. */
+ * PCGScalar = float (B/kernels.cuh:62).
+ *
+ * DEFINITION of the sums (shared with the backend, kernels_pcg.hip).  The reference forms every dense entry of r, M and g and
+ * every dot product with block reductions + binary32 atomics in arbitrary order (B/kernel_pcg.cu:98-154), so its conjugate
+ * gradient is not reproducible run to run (FIX).  Here:
+ *   - a surfel's own entries are binary32 chains over the keyframes in ascending order (as in the reference, whose launches
+ *     are ordered by keyframe);
+ *   - the 6 pose entries of a keyframe: per (64-surfel tile, keyframe) the per-surfel binary32 contributions are added by the
+ *     fixed tree of orc_tile_tree_sum, and the tile totals are summed EXACTLY (oracle_exact.c);
+ *   - the 5 + 4 global intrinsics entries and alpha_d: per-surfel binary32 chains over the keyframes, the xor butterfly over
+ *     the 64 surfels of a tile (orc_wave_xor_sum), tile totals summed exactly;
+ *   - per-cell cfactor entries: the per-pair binary32 terms summed exactly;
+ *   - dot products over the unknowns (alpha_n, beta_n, the epsilon terms of alpha_d): the binary32 products summed exactly;
+ * every exact sum is rounded once to binary64 and from there to binary32 where it is stored in a PCGScalar.  Exact sums do
+ * not depend on the order or grouping of their terms, so the backend's atomics, launch shapes and surfel sharding over GPUs
+ * (an integer all-reduce of the limbs) produce the same bits, and so does the OpenMP loop below. */
 #include "oracle_internal.h"
 
-/* The file is compiled twice (oracle/Makefile): as is -- PCGScalar = float, the reference's -- and with -DORC_PCG_DOUBLE,
- * which keeps the per-pair terms in binary32 but holds the vectors r, M, g, p, delta and every scalar of the conjugate
- * gradient recurrence in binary64 (entry points orc_bundle_adjustment_pcg_f64 / orc_pcg_assemble_f64).  The binary64
- * flavour is what the binary32 solvers -- this one and the backend's -- are measured against in
- * tests/test_gpu_directba_vs_oracle.py: it shows how far a binary32 conjugate gradient is from the solution of its own
- * linear system, i.e. how close two correct binary32 implementations can be expected to agree. */
-#ifdef ORC_PCG_DOUBLE
-typedef double pcg_real;
-#define PCG_SQRT(x) sqrt(x)
-#define orc_bundle_adjustment_pcg orc_bundle_adjustment_pcg_f64
-#define orc_pcg_assemble orc_pcg_assemble_f64
-#else
 typedef float pcg_real;
-#define PCG_SQRT(x) sqrtf(x)
-#endif
 
 static const float kDiagEpsilon = 1e-8f;     /* B/kernel_pcg.cu:44 */
 static const float kAPriorWeight = 10.f;     /* B/kernel_pcg.cu:48 */
 #define INVALID_UNKNOWN 0xffffffffu
-
 typedef struct {
   int optimize_poses, optimize_geometry, optimize_depth_intrinsics, optimize_color_intrinsics;
   int use_depth, use_desc;
@@ -109,130 +108,286 @@ static void eval_pair_terms(const pcg_layout* L, const orc_camera* color_cam, co
   }
 }
 
-static inline void sum_r_m(pcg_real* r, pcg_real* M, uint32_t idx, float J, float w, float raw) {
-  const pcg_real wj = (pcg_real)w * J;
-  r[idx] += -1 * wj * raw;
-  M[idx] += J * wj;
+
+/* ---- the dense head: every unknown outside the surfel block ---- */
+enum { HOT_A = 0 /* 9: r or g of the global intrinsics */, HOT_B = 9 /* 9: M */, HOT_ALPHA_D = 18, HOT_SLOTS = 19 };
+typedef struct {
+  uint32_t lo, hi, count;   /* head = [0, lo) + [hi, U) */
+  orc_exact* a;             /* r (init) / g (step 1) */
+  orc_exact* b;             /* M (init) */
+  orc_exact hot[HOT_SLOTS];
+  int invalid;
+} pcg_head;
+static uint32_t head_index(const pcg_head* H, uint32_t u) { return u < H->lo ? u : H->lo + (u - H->hi); }
+static void head_setup(pcg_head* H, const pcg_layout* L, uint32_t surfels_size) {
+  const uint32_t U = L->unknown_count;
+  H->lo = L->optimize_geometry ? L->surfel_start : U;
+  H->hi = L->optimize_geometry ? L->surfel_start + (uint32_t)L->geom_stride * surfels_size : U;
+  H->count = H->lo + (U - H->hi);
+  H->a = (orc_exact*)calloc(H->count ? H->count : 1, sizeof(orc_exact));
+  H->b = (orc_exact*)calloc(H->count ? H->count : 1, sizeof(orc_exact));
+  memset(H->hot, 0, sizeof(H->hot));
+  H->invalid = 0;
 }
-static inline void sum_r_m2(pcg_real* r, pcg_real* M, uint32_t idx, float J1, float w1, float raw1, float J2, float w2, float raw2) {
-  const pcg_real wj1 = (pcg_real)w1 * J1, wj2 = (pcg_real)w2 * J2;
-  r[idx] += -1 * wj1 * raw1 + -1 * wj2 * raw2;
-  M[idx] += J1 * wj1 + J2 * wj2;
+static void head_free(pcg_head* H) { free(H->a); free(H->b); }
+static float exact_f32(const orc_exact* c, int invalid) { return invalid ? NAN : (float)orc_exact_value(c); }
+/* slot of a global intrinsics unknown among HOT_A.. (0..4 depth, 5..8 colour), or -1 */
+static int intrinsics_slot(const pcg_layout* L, uint32_t u) {
+  if (L->optimize_depth_intrinsics && u >= L->depth_intr_start && u < L->depth_intr_start + 5) return (int)(u - L->depth_intr_start);
+  if (L->optimize_color_intrinsics && u >= L->color_intr_start && u < L->color_intr_start + 4) return 5 + (int)(u - L->color_intr_start);
+  return -1;
+}
+/* head accumulators -> the head entries of the PCGScalar vectors; the accumulators are cleared */
+static void head_resolve(pcg_head* H, const pcg_layout* L, pcg_real* va, pcg_real* vb) {
+  const uint32_t U = L->unknown_count;
+  for (uint32_t u = 0; u < U; ++u) {
+    if (u >= H->lo && u < H->hi) { u = H->hi - 1; continue; }
+    const uint32_t h = head_index(H, u);
+    const int slot = intrinsics_slot(L, u);
+    va[u] = exact_f32(slot >= 0 ? &H->hot[HOT_A + slot] : &H->a[h], H->invalid);
+    if (vb) vb[u] = exact_f32(slot >= 0 ? &H->hot[HOT_B + slot] : &H->b[h], H->invalid);
+  }
+  memset(H->a, 0, sizeof(orc_exact) * (H->count ? H->count : 1));
+  memset(H->b, 0, sizeof(orc_exact) * (H->count ? H->count : 1));
+  memset(H->hot, 0, sizeof(orc_exact) * HOT_ALPHA_D);
 }
 
-/* B/kernel_pcg.cu:179-541, one keyframe */
-static void pcg_init_kf(const pcg_layout* L, uint32_t pose_index, int optimize_pose_of_kf, const orc_camera* color_cam,
-                        const orc_camera* depth_cam, const orc_depth_params* dp, const orc_keyframe* kf,
-                        const orc_surfels* s, pcg_real* r_, pcg_real* M_) {
-  proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
-  const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
-  for (uint32_t i = 0; i < s->surfels_size; ++i) {
-    proj_result pr;
-    if (!orc_project_associate(&p, i, &pr, NULL)) continue;
-    pair_terms t;
-    eval_pair_terms(L, color_cam, depth_cam, dp, kf, &p, &d2c, s, i, &pr, &t);
-    int visible = 1;
-    const uint32_t gi = L->surfel_start + (uint32_t)L->geom_stride * i;
-    if (L->use_depth) {
-      if (L->optimize_geometry) {
-        r_[gi] -= t.Jgeom * t.w * t.raw;
-        M_[gi] += t.Jgeom * t.w * t.Jgeom;
+typedef struct {
+  const pcg_layout* L;
+  int K, gauge;
+  orc_keyframe* const* kfs;
+  const orc_camera* color_cam; const orc_camera* depth_cam;
+  const orc_depth_params* dp;
+  const orc_surfels* s;
+  proj_params* pp;          /* one per keyframe */
+  depth_to_color d2c;
+} pcg_sweep;
+static uint32_t kf_pose_index(const pcg_sweep* w, int k) {   /* B/direct_ba_pcg.cc:329-337 */
+  if (k == w->gauge) return INVALID_UNKNOWN;
+  return (k < w->gauge) ? 6u * (uint32_t)k : 6u * (uint32_t)(k - 1);
+}
+
+/* PCGInit over all keyframes (B/kernel_pcg.cu:179-541): r -= J^T W F, M += diag(J^T W J). */
+static void pcg_init_sweep(const pcg_sweep* w, pcg_real* r_, pcg_real* M_, pcg_head* H) {
+  const pcg_layout* L = w->L;
+  const orc_surfels* s = w->s;
+  const long tiles = (long)((s->surfels_size + 63u) / 64u);
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long tile_index = 0; tile_index < tiles; ++tile_index) {
+    const uint32_t tile = (uint32_t)tile_index * 64u;
+    float gr[3][64], gM[3][64], ir[9][64], iM[9][64];
+    memset(gr, 0, sizeof(gr)); memset(gM, 0, sizeof(gM)); memset(ir, 0, sizeof(ir)); memset(iM, 0, sizeof(iM));
+    for (int k = 0; k < w->K; ++k) {
+      const orc_keyframe* kf = w->kfs[k];
+      const int pose_kf = L->optimize_poses && k != w->gauge;
+      float pr[6][64], pM[6][64];
+      int any = 0;
+      memset(pr, 0, sizeof(pr)); memset(pM, 0, sizeof(pM));
+      for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
+        const uint32_t i = tile + lane;
+        proj_result pres;
+        if (!orc_project_associate(&w->pp[k], i, &pres, NULL)) continue;
+        any = 1;
+        pair_terms t;
+        eval_pair_terms(L, w->color_cam, w->depth_cam, w->dp, kf, &w->pp[k], &w->d2c, s, i, &pres, &t);
+        int visible = 1;
+        if (L->use_depth) {
+          if (L->optimize_geometry) {
+            gr[0][lane] -= t.Jgeom * t.w * t.raw;
+            gM[0][lane] += t.Jgeom * t.w * t.Jgeom;
+          }
+          if (pose_kf)
+            for (int c = 0; c < 6; ++c) { const float wj = t.w * t.Jpose[c]; pr[c][lane] += -1 * wj * t.raw; pM[c][lane] += t.Jpose[c] * wj; }
+          if (L->optimize_depth_intrinsics) {
+            if (!t.di_valid) visible = 0;   /* B/kernel_pcg.cu:272-274: also hides the descriptor part */
+            if (visible) {
+              for (int c = 0; c < 5; ++c) { const float wj = t.w * t.Jdi[c]; ir[c][lane] += -1 * wj * t.raw; iM[c][lane] += t.Jdi[c] * wj; }
+              const float wj = t.w * t.Jcf;
+              const uint32_t h = head_index(H, t.cf_index);
+              orc_exact_add(&H->a[h], -1 * wj * t.raw, &H->invalid);
+              orc_exact_add(&H->b[h], t.Jcf * wj, &H->invalid);
+            }
+          }
+        }
+        if (L->use_desc && visible && t.color_ok) {
+          if (L->optimize_geometry) {
+            gr[0][lane] -= t.Jg1 * t.w1 * t.raw1 + t.Jg2 * t.w2 * t.raw2;
+            gM[0][lane] += t.Jg1 * t.w1 * t.Jg1 + t.Jg2 * t.w2 * t.Jg2;
+            gr[1][lane] -= -1.f * t.w1 * t.raw1 + 0.f * t.w2 * t.raw2;
+            gM[1][lane] += -1.f * t.w1 * -1.f + 0.f * t.w2 * 0.f;
+            gr[2][lane] -= 0.f * t.w1 * t.raw1 + -1.f * t.w2 * t.raw2;
+            gM[2][lane] += 0.f * t.w1 * 0.f + -1.f * t.w2 * -1.f;
+          }
+          if (pose_kf)
+            for (int c = 0; c < 6; ++c) {
+              const float wj1 = t.w1 * t.Jp1[c], wj2 = t.w2 * t.Jp2[c];
+              pr[c][lane] += -1 * wj1 * t.raw1 + -1 * wj2 * t.raw2;
+              pM[c][lane] += t.Jp1[c] * wj1 + t.Jp2[c] * wj2;
+            }
+          if (L->optimize_color_intrinsics)
+            for (int c = 0; c < 4; ++c) {
+              const float wj1 = t.w1 * t.Jci1[c], wj2 = t.w2 * t.Jci2[c];
+              ir[5 + c][lane] += -1 * wj1 * t.raw1 + -1 * wj2 * t.raw2;
+              iM[5 + c][lane] += t.Jci1[c] * wj1 + t.Jci2[c] * wj2;
+            }
+        }
       }
-      if (optimize_pose_of_kf) for (int c = 0; c < 6; ++c) sum_r_m(r_, M_, pose_index + c, t.Jpose[c], t.w, t.raw);
-      if (L->optimize_depth_intrinsics) {
-        if (!t.di_valid) visible = 0;   /* B/kernel_pcg.cu:272-274: also hides the descriptor part */
-        if (visible) {
-          sum_r_m(r_, M_, L->depth_intr_start + 2, t.Jdi[2], t.w, t.raw);
-          sum_r_m(r_, M_, L->depth_intr_start + 3, t.Jdi[3], t.w, t.raw);
-          sum_r_m(r_, M_, L->depth_intr_start + 0, t.Jdi[0], t.w, t.raw);
-          sum_r_m(r_, M_, L->depth_intr_start + 1, t.Jdi[1], t.w, t.raw);
-          sum_r_m(r_, M_, L->depth_intr_start + 4, t.Jdi[4], t.w, t.raw);
-          sum_r_m(r_, M_, t.cf_index, t.Jcf, t.w, t.raw);
+      if (pose_kf && any) {
+        const uint32_t base = kf_pose_index(w, k);   /* pose unknowns come first: head index == unknown index */
+        for (int c = 0; c < 6; ++c) {
+          orc_exact_add(&H->a[base + c], orc_tile_tree_sum(pr[c]), &H->invalid);
+          orc_exact_add(&H->b[base + c], orc_tile_tree_sum(pM[c]), &H->invalid);
         }
       }
     }
-    if (L->use_desc) {
-      visible = visible && t.color_ok;
-      if (!visible) continue;
-      if (L->optimize_geometry) {
-        r_[gi + 0] -= t.Jg1 * t.w1 * t.raw1 + t.Jg2 * t.w2 * t.raw2;
-        M_[gi + 0] += t.Jg1 * t.w1 * t.Jg1 + t.Jg2 * t.w2 * t.Jg2;
-        r_[gi + 1] -= -1.f * t.w1 * t.raw1 + 0.f * t.w2 * t.raw2;
-        M_[gi + 1] += -1.f * t.w1 * -1.f + 0.f * t.w2 * 0.f;
-        r_[gi + 2] -= 0.f * t.w1 * t.raw1 + -1.f * t.w2 * t.raw2;
-        M_[gi + 2] += 0.f * t.w1 * 0.f + -1.f * t.w2 * -1.f;
-      }
-      if (optimize_pose_of_kf)
-        for (int c = 0; c < 6; ++c) sum_r_m2(r_, M_, pose_index + c, t.Jp1[c], t.w1, t.raw1, t.Jp2[c], t.w2, t.raw2);
-      if (L->optimize_color_intrinsics)
-        for (int c = 0; c < 4; ++c) sum_r_m2(r_, M_, L->color_intr_start + c, t.Jci1[c], t.w1, t.raw1, t.Jci2[c], t.w2, t.raw2);
+    for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
+      if (!L->optimize_geometry) break;
+      const uint32_t gi = L->surfel_start + (uint32_t)L->geom_stride * (tile + lane);
+      for (int c = 0; c < L->geom_stride; ++c) { r_[gi + c] = gr[c][lane]; M_[gi + c] = gM[c][lane]; }
     }
+    if (L->optimize_depth_intrinsics || L->optimize_color_intrinsics)
+      for (int q = 0; q < 9; ++q) {
+        if ((q < 5) ? !L->optimize_depth_intrinsics : !L->optimize_color_intrinsics) continue;
+        orc_exact_add(&H->hot[HOT_A + q], orc_wave_xor_sum(ir[q]), &H->invalid);
+        orc_exact_add(&H->hot[HOT_B + q], orc_wave_xor_sum(iM[q]), &H->invalid);
+      }
   }
+  head_resolve(H, L, r_, M_);
 }
 
-/* B/kernel_pcg.cu:646-1026, one keyframe: g += J^T W J p, alpha_d += p^T J^T W J p */
-static void pcg_step1_kf(const pcg_layout* L, uint32_t pose_index, int optimize_pose_of_kf, const orc_camera* color_cam,
-                         const orc_camera* depth_cam, const orc_depth_params* dp, const orc_keyframe* kf,
-                         const orc_surfels* s, const pcg_real* p_, pcg_real* g_, pcg_real* alpha_d) {
-  proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
-  const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
-  for (uint32_t i = 0; i < s->surfels_size; ++i) {
-    proj_result pr;
-    if (!orc_project_associate(&p, i, &pr, NULL)) continue;
-    pair_terms t;
-    eval_pair_terms(L, color_cam, depth_cam, dp, kf, &p, &d2c, s, i, &pr, &t);
-    const uint32_t gi = L->surfel_start + (uint32_t)L->geom_stride * i;
-    if (L->use_depth) {
-      pcg_real sum = 0;
-      if (L->optimize_geometry) sum += t.Jgeom * p_[gi];
-      if (optimize_pose_of_kf) for (int c = 0; c < 6; ++c) sum += t.Jpose[c] * p_[pose_index + c];
-      const int di = L->optimize_depth_intrinsics && t.di_valid;
-      if (di) {
-        sum += t.Jdi[2] * p_[L->depth_intr_start + 2];
-        sum += t.Jdi[3] * p_[L->depth_intr_start + 3];
-        sum += t.Jdi[0] * p_[L->depth_intr_start + 0];
-        sum += t.Jdi[1] * p_[L->depth_intr_start + 1];
-        sum += t.Jdi[4] * p_[L->depth_intr_start + 4];
-        sum += t.Jcf * p_[t.cf_index];
+/* PCGStep1 over all keyframes (B/kernel_pcg.cu:646-1026): g = J^T W J p; returns the pair part of alpha_d = p^T J^T W J p
+ * as its exactly rounded binary64 value (the epsilon terms are added by the caller). */
+static double pcg_step1_sweep(const pcg_sweep* w, const pcg_real* p_, pcg_real* g_, pcg_head* H) {
+  const pcg_layout* L = w->L;
+  const orc_surfels* s = w->s;
+  const long tiles = (long)((s->surfels_size + 63u) / 64u);
+  float pdi[5] = {0, 0, 0, 0, 0}, pci[4] = {0, 0, 0, 0};
+  if (L->optimize_depth_intrinsics) for (int c = 0; c < 5; ++c) pdi[c] = p_[L->depth_intr_start + c];
+  if (L->optimize_color_intrinsics) for (int c = 0; c < 4; ++c) pci[c] = p_[L->color_intr_start + c];
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long tile_index = 0; tile_index < tiles; ++tile_index) {
+    const uint32_t tile = (uint32_t)tile_index * 64u;
+    float gs[3][64], gia[9][64], ad[64];
+    memset(gs, 0, sizeof(gs)); memset(gia, 0, sizeof(gia)); memset(ad, 0, sizeof(ad));
+    for (int k = 0; k < w->K; ++k) {
+      const orc_keyframe* kf = w->kfs[k];
+      const int pose_kf = L->optimize_poses && k != w->gauge;
+      const uint32_t base = kf_pose_index(w, k);
+      float pp6[6] = {0, 0, 0, 0, 0, 0};
+      if (pose_kf) for (int c = 0; c < 6; ++c) pp6[c] = p_[base + c];
+      float gpose[6][64];
+      int any = 0;
+      memset(gpose, 0, sizeof(gpose));
+      for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
+        const uint32_t i = tile + lane;
+        proj_result pres;
+        if (!orc_project_associate(&w->pp[k], i, &pres, NULL)) continue;
+        any = 1;
+        pair_terms t;
+        eval_pair_terms(L, w->color_cam, w->depth_cam, w->dp, kf, &w->pp[k], &w->d2c, s, i, &pres, &t);
+        const uint32_t gi = L->optimize_geometry ? L->surfel_start + (uint32_t)L->geom_stride * i : 0u;
+        float ps[3] = {0, 0, 0};
+        if (L->optimize_geometry) for (int c = 0; c < L->geom_stride; ++c) ps[c] = p_[gi + c];
+        if (L->use_depth) {
+          float sum = 0;
+          if (L->optimize_geometry) sum += t.Jgeom * ps[0];
+          if (pose_kf) for (int c = 0; c < 6; ++c) sum += t.Jpose[c] * pp6[c];
+          const int di = L->optimize_depth_intrinsics && t.di_valid;
+          if (di) {
+            sum += t.Jdi[2] * pdi[2];
+            sum += t.Jdi[3] * pdi[3];
+            sum += t.Jdi[0] * pdi[0];
+            sum += t.Jdi[1] * pdi[1];
+            sum += t.Jdi[4] * pdi[4];
+            sum += t.Jcf * p_[t.cf_index];
+          }
+          ad[lane] += sum * t.w * sum;
+          sum *= t.w;
+          if (L->optimize_geometry) gs[0][lane] += t.Jgeom * sum;
+          if (pose_kf) for (int c = 0; c < 6; ++c) gpose[c][lane] += t.Jpose[c] * sum;
+          if (di) {
+            for (int c = 0; c < 5; ++c) gia[c][lane] += t.Jdi[c] * sum;
+            orc_exact_add(&H->a[head_index(H, t.cf_index)], t.Jcf * sum, &H->invalid);
+          }
+        }
+        if (L->use_desc && t.color_ok) {
+          float sum1 = 0, sum2 = 0;
+          if (L->optimize_geometry) {
+            sum1 += t.Jg1 * ps[0]; sum2 += t.Jg2 * ps[0];
+            sum1 += -1.f * ps[1];
+            sum2 += -1.f * ps[2];
+          }
+          if (pose_kf) for (int c = 0; c < 6; ++c) { sum1 += t.Jp1[c] * pp6[c]; sum2 += t.Jp2[c] * pp6[c]; }
+          if (L->optimize_color_intrinsics) for (int c = 0; c < 4; ++c) { sum1 += t.Jci1[c] * pci[c]; sum2 += t.Jci2[c] * pci[c]; }
+          ad[lane] += sum1 * t.w1 * sum1 + sum2 * t.w2 * sum2;
+          sum1 *= t.w1; sum2 *= t.w2;
+          if (L->optimize_geometry) {
+            gs[0][lane] += t.Jg1 * sum1 + t.Jg2 * sum2;
+            gs[1][lane] += -1.f * sum1 + 0.f * sum2;
+            gs[2][lane] += 0.f * sum1 + -1.f * sum2;
+          }
+          if (pose_kf) for (int c = 0; c < 6; ++c) gpose[c][lane] += t.Jp1[c] * sum1 + t.Jp2[c] * sum2;
+          if (L->optimize_color_intrinsics) for (int c = 0; c < 4; ++c) gia[5 + c][lane] += t.Jci1[c] * sum1 + t.Jci2[c] * sum2;
+        }
       }
-      *alpha_d += sum * t.w * sum;
-      sum *= t.w;
-      if (L->optimize_geometry) g_[gi] += t.Jgeom * sum;
-      if (optimize_pose_of_kf) for (int c = 0; c < 6; ++c) g_[pose_index + c] += t.Jpose[c] * sum;
-      if (di) {
-        for (int c = 0; c < 5; ++c) g_[L->depth_intr_start + c] += t.Jdi[c] * sum;
-        g_[t.cf_index] += t.Jcf * sum;
-      }
+      if (pose_kf && any)
+        for (int c = 0; c < 6; ++c) orc_exact_add(&H->a[base + c], orc_tile_tree_sum(gpose[c]), &H->invalid);
     }
-    if (L->use_desc) {
-      if (!t.color_ok) continue;
-      pcg_real sum1 = 0, sum2 = 0;
-      if (L->optimize_geometry) {
-        pcg_real pv = p_[gi + 0];
-        sum1 += t.Jg1 * pv; sum2 += t.Jg2 * pv;
-        pv = p_[gi + 1]; sum1 += -1.f * pv;
-        pv = p_[gi + 2]; sum2 += -1.f * pv;
-      }
-      if (optimize_pose_of_kf)
-        for (int c = 0; c < 6; ++c) { const pcg_real pv = p_[pose_index + c]; sum1 += t.Jp1[c] * pv; sum2 += t.Jp2[c] * pv; }
-      if (L->optimize_color_intrinsics)
-        for (int c = 0; c < 4; ++c) { const pcg_real pv = p_[L->color_intr_start + c]; sum1 += t.Jci1[c] * pv; sum2 += t.Jci2[c] * pv; }
-      *alpha_d += sum1 * t.w1 * sum1 + sum2 * t.w2 * sum2;
-      sum1 *= t.w1; sum2 *= t.w2;
-      if (L->optimize_geometry) {
-        g_[gi + 0] += t.Jg1 * sum1 + t.Jg2 * sum2;
-        g_[gi + 1] += -1.f * sum1 + 0.f * sum2;
-        g_[gi + 2] += 0.f * sum1 + -1.f * sum2;
-      }
-      if (optimize_pose_of_kf) for (int c = 0; c < 6; ++c) g_[pose_index + c] += t.Jp1[c] * sum1 + t.Jp2[c] * sum2;
-      if (L->optimize_color_intrinsics)
-        for (int c = 0; c < 4; ++c) g_[L->color_intr_start + c] += t.Jci1[c] * sum1 + t.Jci2[c] * sum2;
+    for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
+      if (!L->optimize_geometry) break;
+      const uint32_t gi = L->surfel_start + (uint32_t)L->geom_stride * (tile + lane);
+      for (int c = 0; c < L->geom_stride; ++c) g_[gi + c] = gs[c][lane];
     }
+    for (int q = 0; q < 9; ++q) {
+      if ((q < 5) ? !L->optimize_depth_intrinsics : !L->optimize_color_intrinsics) continue;
+      orc_exact_add(&H->hot[HOT_A + q], orc_wave_xor_sum(gia[q]), &H->invalid);
+    }
+    orc_exact_add(&H->hot[HOT_ALPHA_D], orc_wave_xor_sum(ad), &H->invalid);
   }
+  const double pairs = H->invalid ? (double)NAN : orc_exact_value(&H->hot[HOT_ALPHA_D]);
+  memset(&H->hot[HOT_ALPHA_D], 0, sizeof(orc_exact));
+  head_resolve(H, L, g_, NULL);
+  return pairs;
 }
 
 static inline float prior_at(const pcg_layout* L, uint32_t idx) {
   return (idx == L->a_index) ? (kAPriorWeight * kAPriorWeight) : 0.f;
+}
+/* sum_u (epsilon + prior_u) p_u^2, exact (AddAlphaDEpsilonTerms, B/kernel_pcg.cu:1028-1050) */
+static double pcg_eps_terms(const pcg_layout* L, const pcg_real* p_) {
+  orc_exact acc; int invalid = 0;
+  memset(&acc, 0, sizeof(acc));
+  for (uint32_t u = 0; u < L->unknown_count; ++u) {
+    const float pv = p_[u];
+    orc_exact_add(&acc, (kDiagEpsilon + prior_at(L, u)) * pv * pv, &invalid);
+  }
+  return invalid ? (double)NAN : orc_exact_value(&acc);
+}
+
+static void make_layout(pcg_layout* L, const orc_ba_options* opt, int K, uint32_t surfels_size, int S) {
+  memset(L, 0, sizeof(*L));
+  L->use_depth = opt->use_depth_residuals; L->use_desc = opt->use_descriptor_residuals;
+  L->optimize_poses = opt->optimize_poses; L->optimize_geometry = opt->optimize_geometry;
+  L->optimize_depth_intrinsics = opt->optimize_depth_intrinsics && L->use_depth;   /* B/direct_ba.cc:427-434 */
+  L->optimize_color_intrinsics = opt->optimize_color_intrinsics && L->use_desc;
+  L->geom_stride = L->use_desc ? 3 : 1;
+  /* unknown layout (B/direct_ba_pcg.cc:232-307) */
+  uint32_t cur = 0;
+  if (L->optimize_poses) cur += 6u * (uint32_t)(K - 1);
+  L->surfel_start = INVALID_UNKNOWN;
+  if (L->optimize_geometry) { L->surfel_start = cur; cur += (uint32_t)L->geom_stride * surfels_size; }
+  L->depth_intr_start = INVALID_UNKNOWN; L->a_index = INVALID_UNKNOWN;
+  if (L->optimize_depth_intrinsics) { L->depth_intr_start = cur; cur += 5u + (uint32_t)S; L->a_index = L->depth_intr_start + 4; }
+  L->color_intr_start = INVALID_UNKNOWN;
+  if (L->optimize_color_intrinsics) { L->color_intr_start = cur; cur += 4; }
+  L->unknown_count = cur;
+}
+static void sweep_setup(pcg_sweep* w, const pcg_layout* L, orc_ba_state* st, int gauge) {
+  w->L = L; w->K = st->num_kfs; w->gauge = gauge; w->kfs = st->kfs;
+  w->color_cam = &st->color_cam; w->depth_cam = &st->depth_cam; w->dp = &st->dp; w->s = st->surfels;
+  w->pp = (proj_params*)calloc((size_t)(w->K > 0 ? w->K : 1), sizeof(proj_params));
+  for (int k = 0; k < w->K; ++k) w->pp[k] = make_proj_params(&st->depth_cam, &st->dp, st->surfels, st->kfs[k], st->kfs[k]->frame_T_global);
+  w->d2c = make_depth_to_color(&st->depth_cam, &st->color_cam);
 }
 
 /* Test hook: assembles r = -J^T W F and M = diag(J^T W J) (PCGInit over all keyframes, without the
@@ -240,32 +395,19 @@ static inline float prior_at(const pcg_layout* L, uint32_t idx) {
 uint32_t orc_pcg_assemble(orc_ba_state* st, const orc_ba_options* opt, float* r_out, float* M_out, uint32_t capacity) {
   const orc_surfels* s = st->surfels;
   const int K = st->num_kfs;
-  const int S = st->dp.cf_width * st->dp.cf_height;
   pcg_layout L;
-  memset(&L, 0, sizeof(L));
-  L.use_depth = opt->use_depth_residuals; L.use_desc = opt->use_descriptor_residuals;
-  L.optimize_poses = opt->optimize_poses; L.optimize_geometry = opt->optimize_geometry;
-  L.optimize_depth_intrinsics = opt->optimize_depth_intrinsics && L.use_depth;
-  L.optimize_color_intrinsics = opt->optimize_color_intrinsics && L.use_desc;
-  L.geom_stride = L.use_desc ? 3 : 1;
-  uint32_t cur = 0;
-  if (L.optimize_poses) cur += 6u * (uint32_t)(K - 1);
-  L.surfel_start = INVALID_UNKNOWN;
-  if (L.optimize_geometry) { L.surfel_start = cur; cur += (uint32_t)L.geom_stride * s->surfels_size; }
-  L.depth_intr_start = INVALID_UNKNOWN; L.a_index = INVALID_UNKNOWN;
-  if (L.optimize_depth_intrinsics) { L.depth_intr_start = cur; cur += 5u + (uint32_t)S; L.a_index = L.depth_intr_start + 4; }
-  L.color_intr_start = INVALID_UNKNOWN;
-  if (L.optimize_color_intrinsics) { L.color_intr_start = cur; cur += 4; }
-  L.unknown_count = cur;
+  make_layout(&L, opt, K, s->surfels_size, st->dp.cf_width * st->dp.cf_height);
+  const uint32_t cur = L.unknown_count;
   pcg_real* r_ = (pcg_real*)calloc(cur ? cur : 1, sizeof(pcg_real));
   pcg_real* M_ = (pcg_real*)calloc(cur ? cur : 1, sizeof(pcg_real));
   const int gauge = (opt->pcg_gauge_keyframe >= 0 && opt->pcg_gauge_keyframe < K) ? opt->pcg_gauge_keyframe : 0;
-  for (int k = 0; k < K; ++k) {
-    const uint32_t pi = (k == gauge) ? INVALID_UNKNOWN : ((k < gauge) ? 6u * (uint32_t)k : 6u * (uint32_t)(k - 1));
-    pcg_init_kf(&L, pi, (k == gauge) ? 0 : L.optimize_poses, &st->color_cam, &st->depth_cam, &st->dp, st->kfs[k], s, r_, M_);
-  }
+  pcg_sweep w; pcg_head H;
+  sweep_setup(&w, &L, st, gauge);
+  head_setup(&H, &L, s->surfels_size);
+  pcg_init_sweep(&w, r_, M_, &H);
+  head_free(&H); free(w.pp);
   const uint32_t n = cur < capacity ? cur : capacity;
-  for (uint32_t u = 0; u < n; ++u) { r_out[u] = (float)r_[u]; M_out[u] = (float)M_[u]; }
+  for (uint32_t u = 0; u < n; ++u) { r_out[u] = r_[u]; M_out[u] = M_[u]; }
   free(r_); free(M_);
   return cur;
 }
@@ -275,12 +417,7 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
   memset(stats, 0, sizeof(*stats));
   const int K = st->num_kfs;
   pcg_layout L;
-  memset(&L, 0, sizeof(L));
-  L.use_depth = opt->use_depth_residuals; L.use_desc = opt->use_descriptor_residuals;
-  L.optimize_poses = opt->optimize_poses; L.optimize_geometry = opt->optimize_geometry;
-  L.optimize_depth_intrinsics = opt->optimize_depth_intrinsics && L.use_depth;   /* B/direct_ba.cc:427-434 */
-  L.optimize_color_intrinsics = opt->optimize_color_intrinsics && L.use_desc;
-  L.geom_stride = L.use_desc ? 3 : 1;
+  make_layout(&L, opt, K, 0, 0);
   for (int k = 0; k < K; ++k) if (!st->kfs[k]) return;   /* B/direct_ba_pcg.cc:138-143 */
   const int S = st->dp.cf_width * st->dp.cf_height;
 
@@ -325,18 +462,8 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     memset(s->active, ORC_SURFEL_ACTIVE_FLAG, s->surfels_size);
     if (opt->optimize_geometry) orc_update_surfel_normals(&st->depth_cam, &st->dp, st->kfs, K, s);
 
-    /* --- unknown layout (B/direct_ba_pcg.cc:232-307) --- */
-    uint32_t cur = 0;
-    const uint32_t kf_unknowns = L.optimize_poses ? 6u * (uint32_t)(K - 1) : 0u;
-    if (L.optimize_poses) cur += kf_unknowns;
-    L.surfel_start = INVALID_UNKNOWN;
-    if (L.optimize_geometry) { L.surfel_start = cur; cur += (uint32_t)L.geom_stride * s->surfels_size; }
-    L.depth_intr_start = INVALID_UNKNOWN; L.a_index = INVALID_UNKNOWN;
-    if (L.optimize_depth_intrinsics) { L.depth_intr_start = cur; cur += 5u + (uint32_t)S; L.a_index = L.depth_intr_start + 4; }
-    L.color_intr_start = INVALID_UNKNOWN;
-    if (L.optimize_color_intrinsics) { L.color_intr_start = cur; cur += 4; }
-    L.unknown_count = cur;
-    const uint32_t U = cur;
+    make_layout(&L, opt, K, s->surfels_size, S);
+    const uint32_t U = L.unknown_count;
     if (U > allocated) {
       free(r_); free(M_); free(delta); free(g_); free(p_);
       allocated = U + 1024;
@@ -348,61 +475,66 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
 
     const int gauge = (opt->pcg_gauge_keyframe >= 0 && opt->pcg_gauge_keyframe < K) ? opt->pcg_gauge_keyframe : 0;
 #define KF_POSE_INDEX(id) ((id) == gauge ? INVALID_UNKNOWN : ((id) < gauge ? 6u * (uint32_t)(id) : 6u * (uint32_t)((id) - 1)))
-
-    for (int k = 0; k < K; ++k)
-      pcg_init_kf(&L, KF_POSE_INDEX(k), (k == gauge) ? 0 : L.optimize_poses, &st->color_cam, &st->depth_cam, &st->dp,
-                  st->kfs[k], s, r_, M_);
+    pcg_sweep w; pcg_head H;
+    sweep_setup(&w, &L, st, gauge);
+    head_setup(&H, &L, s->surfels_size);
+    pcg_init_sweep(&w, r_, M_, &H);
 
     /* PCGInit2, B/kernel_pcg.cu:565-600 */
     pcg_real alpha_n = 0, alpha_d = 0, beta_n = 0;
-    for (uint32_t u = 0; u < U; ++u) {
-      g_[u] = 0;
-      const pcg_real r_value = r_[u] + ((u == L.a_index) ? (-kAPriorWeight * kAPriorWeight * st->dp.a) : 0);
-      const pcg_real p_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
-      p_[u] = p_value;
-      delta[u] = 0;
-      alpha_n += r_value * p_value;
+    {
+      orc_exact acc; int invalid = 0;
+      memset(&acc, 0, sizeof(acc));
+      for (uint32_t u = 0; u < U; ++u) {
+        g_[u] = 0;
+        const pcg_real r_value = r_[u] + ((u == L.a_index) ? (-kAPriorWeight * kAPriorWeight * st->dp.a) : 0);
+        const pcg_real p_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
+        p_[u] = p_value;
+        delta[u] = 0;
+        orc_exact_add(&acc, r_value * p_value, &invalid);
+      }
+      alpha_n = exact_f32(&acc, invalid);
     }
 
-    pcg_real prev_r_norm = INFINITY;
+    double prev_r_norm = INFINITY;
     int no_improvement = 0;
     for (int step = 0; step < opt->pcg_max_inner_iterations; ++step) {
       stats->pcg_inner_steps_total += 1;
-      alpha_d = 0;
-      if (step > 0) {
-        const pcg_real tmp = alpha_n; alpha_n = beta_n; beta_n = tmp;
-        memset(g_, 0, sizeof(pcg_real) * U);
-      }
-      for (int k = 0; k < K; ++k) {
-        pcg_step1_kf(&L, KF_POSE_INDEX(k), (k == gauge) ? 0 : L.optimize_poses, &st->color_cam, &st->depth_cam, &st->dp,
-                     st->kfs[k], s, p_, g_, &alpha_d);
-        /* AddAlphaDEpsilonTerms runs once per keyframe (B/kernel_pcg.cu:1102-1112): reproduced */
-        if (s->surfels_size > 0)
-          for (uint32_t u = 0; u < U; ++u) alpha_d += (kDiagEpsilon + prior_at(&L, u)) * p_[u] * p_[u];
-      }
+      if (step > 0) { const pcg_real tmp = alpha_n; alpha_n = beta_n; beta_n = tmp; }
+      memset(g_, 0, sizeof(pcg_real) * U);
+      const double pairs = pcg_step1_sweep(&w, p_, g_, &H);
+      /* AddAlphaDEpsilonTerms runs once per keyframe (B/kernel_pcg.cu:1102-1112): the term enters K times -- reproduced */
+      const double eps_terms = (s->surfels_size > 0) ? pcg_eps_terms(&L, p_) : 0.0;
+      alpha_d = (pcg_real)(pairs + (double)K * eps_terms);
       /* PCGStep2, B/kernel_pcg.cu:1117-1158 */
-      beta_n = 0;
       const pcg_real alpha = (alpha_d >= 1e-35f) ? (alpha_n / alpha_d) : 0;
-      for (uint32_t u = 0; u < U; ++u) {
-        const pcg_real p_value = p_[u];
-        delta[u] += alpha * p_value;
-        pcg_real r_value = r_[u];
-        r_value -= alpha * (g_[u] + (kDiagEpsilon + prior_at(&L, u)) * p_value);
-        r_[u] = r_value;
-        const pcg_real z_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
-        g_[u] = z_value;
-        beta_n += z_value * r_value;
+      {
+        orc_exact acc; int invalid = 0;
+        memset(&acc, 0, sizeof(acc));
+        for (uint32_t u = 0; u < U; ++u) {
+          const pcg_real p_value = p_[u];
+          delta[u] += alpha * p_value;
+          pcg_real r_value = r_[u];
+          r_value -= alpha * (g_[u] + (kDiagEpsilon + prior_at(&L, u)) * p_value);
+          r_[u] = r_value;
+          const pcg_real z_value = r_value / (M_[u] + kDiagEpsilon + prior_at(&L, u));
+          g_[u] = z_value;
+          orc_exact_add(&acc, z_value * r_value, &invalid);
+        }
+        beta_n = exact_f32(&acc, invalid);
       }
-      const pcg_real r_norm = PCG_SQRT(beta_n);
-      if (r_norm < prev_r_norm - 1e-3f) no_improvement = 0;
+      /* B/direct_ba_pcg.cc:441-456: PCGScalar r_norm = sqrt(beta_n); the comparison is evaluated in double */
+      const pcg_real r_norm = sqrtf(beta_n);
+      if ((double)r_norm < prev_r_norm - 1e-3) no_improvement = 0;
       else if (++no_improvement >= 3) break;
-      prev_r_norm = r_norm;
+      prev_r_norm = (double)r_norm;
       if (step < opt->pcg_max_inner_iterations - 1) {
         /* PCGStep3, B/kernel_pcg.cu:1212-1226 */
         const pcg_real beta = (alpha_n >= 1e-35f) ? (beta_n / alpha_n) : 0;
         for (uint32_t u = 0; u < U; ++u) p_[u] = g_[u] + beta * p_[u];
       }
     }
+    head_free(&H); free(w.pp);
 
     /* --- apply the update (B/direct_ba_pcg.cc:551-642) --- */
     int num_converged = 0;

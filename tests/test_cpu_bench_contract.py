@@ -65,3 +65,21 @@ def test_bench_parses_its_arguments_without_a_gpu():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def _bench(*flags, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+
+
+def test_gpus_flag_is_honoured_or_fails_loudly():
+    """`bench.py --gpus N` launches N ranks itself when no launcher did.  Without N devices it must refuse -- a run that
+    silently uses one GPU and prints "n_gpus": 1 would be read as a scaling result (VERDICT r2 missing 2).  This box has no
+    HIP device at all, so both the self-launch path and a mismatching launcher must end non-zero with a message and no line."""
+    out = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert out.returncode != 0 and "needs 2 HIP devices" in out.stderr and out.stdout.strip() == ""
+    out = _bench("--gpus", "8", "--steps", "1", "--warmup", "0", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and out.stdout.strip() == ""
+    out = _bench("--gpus", "0")
+    assert out.returncode != 0

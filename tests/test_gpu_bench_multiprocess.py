@@ -28,3 +28,24 @@ def test_bench_under_torchrun_with_shared_device(world):
     assert out["n_gpus"] == world and out["steps"] == 3 and out["scaling"] == "strong"
     assert out["value"] > 0 and out["config"]["surfels"] <= 150000
     assert "roofline" in out and out["roofline"]["launches"] >= 3   # >= one pose round per iteration on rank 0
+    assert out["exchange"]["calls_per_iteration"] >= 1 and out["exchange"]["bytes_per_iteration"] >= 16 * 28 * 8
+    assert [r["rank"] for r in out["per_rank"]] == list(range(world)) and sum(r["surfels"] for r in out["per_rank"]) == out["config"]["surfels"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts the N = 1 leg): bench.py starts the two
+    ranks itself.  Over RCCL that needs two devices -- this box has one, so it must refuse; with BENCH_DIST_BACKEND=gloo the
+    ranks share the device and the line says n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    flags = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--keyframes", "12", "--surfels", "100000", "--no-cpu-baseline"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert proc.returncode != 0 and "needs 2 HIP devices" in proc.stderr and proc.stdout.strip() == ""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600,
+                          env=dict(env, BENCH_DIST_BACKEND="gloo"), cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank"]) == 2

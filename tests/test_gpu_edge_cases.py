@@ -1,5 +1,7 @@
 """Edge cases of the path on the GPU: ragged image sizes (plane tiles and wavefronts with padding), a deleted keyframe in
 the middle of the list, empty surfel sets, an all-invalid depth image, a single keyframe, capacity exceeded."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -112,3 +114,47 @@ def test_capacity_exceeded_is_a_soft_failure():
     assert ba.surfel_count() == 0
     done, _ = ba.BundleAdjustment(min_iterations=1, max_iterations=1)
     assert done == 1
+
+
+def test_covisibility_lists_regrown_on_a_live_context():
+    """re-growing the co-visibility CSR buffer freed the tile-bounds and window buffers too and left their
+    pointers dangling.  Bind, run a pose phase (allocates the tile bounds) and set a window, then hand over lists with more
+    than the 1024 entries of slack, and run everything again: results must equal those of a fresh context."""
+    from badslam_amd import capi
+    scene = common.small_scene(num_keyframes=6, seed=31)
+    rng = np.random.Generator(np.random.PCG64(4))
+    perturbed = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+
+    def phase(g, lists):
+        K = len(g.keyframes)
+        offsets = np.zeros(K + 1, np.int32)
+        offsets[1:] = np.cumsum([len(l) for l in lists])
+        indices = np.asarray([j for l in lists for j in l], np.int32)
+        window = np.ones(K, np.uint8)
+        capi.check(g.ctx.lib.bahip_set_covisibility(g.ctx.handle, offsets.ctypes.data_as(C.POINTER(C.c_int)),
+                                                indices.ctypes.data_as(C.POINTER(C.c_int)), K))
+        capi.check(g.ctx.lib.bahip_set_activation_window(g.ctx.handle, window.ctypes.data_as(C.POINTER(C.c_uint8)), K))
+        poses, its, conv, rounds = g.estimate_keyframe_poses(True, True)
+        return np.asarray(poses, np.float32), list(its)
+
+    def fresh():
+        g = common.build_gpu(scene, 300000)
+        for k, T in enumerate(perturbed):
+            g.keyframes[k]["pose"] = np.asarray(T, np.float32)
+        g.bind_keyframes()
+        return g
+
+    K = len(scene.depth)
+    short = [[j for j in range(K) if j != k] for k in range(K)]
+    long_lists = [[j for j in range(K) if j != k] * 60 for k in range(K)]     # 6 * 300 = 1800 entries > 30 + 1024 slack
+    g = fresh()
+    first = phase(g, short)
+    second = phase(g, long_lists)                                              # re-grows the CSR buffer on the live context
+    third = phase(g, short)
+    ref = fresh()
+    assert np.array_equal(first[0], phase(ref, short)[0])
+    ref2 = fresh()
+    want = phase(ref2, long_lists)
+    assert np.array_equal(second[0], want[0]) and second[1] == want[1]
+    assert np.array_equal(third[0], first[0])
+    del g, ref, ref2                                                           # destroying the contexts must not double-free

@@ -1,12 +1,9 @@
 """GPU parity: intrinsics step (Schur complement) and the PCG scheme vs the CPU oracle.
 
-Per-pair terms are bit-identical on both sides (test_gpu_kernels_vs_oracle.py); what differs is the
-order in which many binary32 terms are summed (wave / atomic trees vs the oracle's running sums).
-For quantities that are plain sums (normal-equation blocks, r and M of the PCG system) the
-tolerance is a small multiple of binary32 epsilon relative to the largest entry.  The PCG
-iterates themselves are chaotic in binary32 (the reference is run-to-run non-deterministic for the
-same reason), so the solver is compared through what it is for: the cost
-decrease of one outer iteration and agreement of the resulting state to well below the update."""
+Per-pair terms are bit-identical on both sides (test_gpu_kernels_vs_oracle.py), and every sum over many of them is a DEFINED
+sum on both sides: binary32 chains per surfel, fixed trees per 64-surfel tile, and then binary64 accumulation (intrinsics step)
+or exact accumulation (PCG: exact_sum.h / oracle_exact.c) over the tiles.  So the kernels -- which merge with atomics in
+arbitrary order -- and the oracle agree to the last bit, the number of inner conjugate-gradient steps included."""
 import numpy as np
 import pytest
 
@@ -102,7 +99,7 @@ def _pcg_setup(scene, mode):
 
 @pytest.mark.parametrize("mode", ["poses+geometry", "all"])
 def test_pcg_system_assembly(scene, mode):
-    """r = -J^T W F and M = diag(J^T W J) (PCGInit over all keyframes)."""
+    """r = -J^T W F and M = diag(J^T W J) (PCGInit over all keyframes): every entry, bit for bit."""
     ba, g, data, _ = _pcg_setup(scene, mode)
     di = ci = (mode == "all")
     r_ref, M_ref = ba.pcg_assemble(True, True, di, ci, gauge_keyframe=1)
@@ -112,22 +109,24 @@ def test_pcg_system_assembly(scene, mode):
     r, M = g.read_pcg_vector(0, U), g.read_pcg_vector(1, U)
     K, N = len(ba.keyframes), data.shape[1]
     ps = 6 * (K - 1)
-    # surfel block: per-surfel sums over keyframes in keyframe order on both sides -> bit-exact
-    assert np.array_equal(r[ps:ps + 3 * N].view(np.uint32), r_ref[ps:ps + 3 * N].view(np.uint32))
-    assert np.array_equal(M[ps:ps + 3 * N].view(np.uint32), M_ref[ps:ps + 3 * N].view(np.uint32))
-    # dense head / tail: sums over ~1e4..1e5 terms in a different order
-    for lo, hi in ((0, ps), (ps + 3 * N, U)):
-        if hi > lo:
-            # (the oracle's binary32 running sum over ~3e4 terms drifts by up to ~n*eps/2 relative)
-            assert np.abs(M[lo:hi] - M_ref[lo:hi]).max() <= 1e-4 * np.abs(M_ref[lo:hi]).max()
-            # r entries are signed sums with cancellation; by Cauchy-Schwarz |sum w J r| <= sqrt(M) * sqrt(cost),
-            # so the summation noise is measured in units of sqrt(M)
-            scale = np.sqrt(np.maximum(M_ref[lo:hi], 1e-30)) + 1e-30
-            assert np.abs((r[lo:hi] - r_ref[lo:hi]) / scale).max() < 1e-2
+    assert U == ps + 3 * N + ((5 + ba.cf_w * ba.cf_h + 4) if di else 0)
+    assert np.count_nonzero(M_ref[:ps]) == ps and np.count_nonzero(r_ref[:ps]) == ps
+    if di:
+        assert np.count_nonzero(M_ref[ps + 3 * N:]) > 0.5 * (U - ps - 3 * N)
+    # surfel block: per-surfel chains over the keyframes; dense head (poses, intrinsics, cfactor cells): exact sums of tile /
+    # pair terms -- the same bits although the kernel adds them with atomics in arbitrary order
+    assert np.array_equal(_bits(r), _bits(r_ref)), np.flatnonzero(_bits(r) != _bits(r_ref))[:10]
+    assert np.array_equal(_bits(M), _bits(M_ref)), np.flatnonzero(_bits(M) != _bits(M_ref))[:10]
+    # and run to run (the reference's PCG is not reproducible: float atomics)
+    g.pcg_iteration(optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=di, optimize_color_intrinsics=ci,
+                    max_inner_iterations=0, gauge_keyframe=1)
+    assert np.array_equal(_bits(g.read_pcg_vector(0, U)), _bits(r))
 
 
 @pytest.mark.parametrize("mode", ["poses+geometry", "geometry-only", "all"])
 def test_pcg_iteration(scene, mode):
+    """One outer iteration of the PCG scheme: the same number of inner steps, the same surfels, poses and calibration, bit for
+    bit (a = 0 going in, so expf -- device library vs glibc -- is exactly 1 on both sides)."""
     ba, g, data, perturbed = _pcg_setup(scene, mode)
     poses_on = mode != "geometry-only"
     di = ci = (mode == "all")
@@ -139,43 +138,18 @@ def test_pcg_iteration(scene, mode):
     g.update_surfel_normals()
     steps, conv = g.pcg_iteration(optimize_poses=poses_on, optimize_geometry=True, optimize_depth_intrinsics=di,
                                   optimize_color_intrinsics=ci, gauge_keyframe=0)
-    assert 3 <= steps <= 30 and 3 <= stats.pcg_inner_steps_total <= 30
+    assert 3 <= stats.pcg_inner_steps_total <= 30
+    assert steps == stats.pcg_inner_steps_total, (steps, stats.pcg_inner_steps_total)
     got = g.download_surfels()
     ref = ba.surfel_data[:, :got.shape[1]].copy()
-    assert np.array_equal(got[3].view(np.uint32), ref[3].view(np.uint32))          # normals pass is exact
     moved = np.abs(ref[:3] - data[:3]).max(axis=0)
     assert np.median(moved) > 1e-4                                                  # a real update happened
     cost_ref, _ = ba.evaluate_cost()
     assert cost_ref < 0.7 * cost_before
-
-    # cost reached by the GPU's update, evaluated by the oracle on the GPU's resulting state
-    ref_poses = [ba.pose(k) for k in range(len(perturbed))]
-    ba.surfel_data[:, :got.shape[1]] = got
+    assert np.array_equal(got[:8].view(np.uint32), ref[:8].view(np.uint32)), np.abs(got[:3] - ref[:3]).max()
     for k in range(len(perturbed)):
-        ba.set_pose(k, g.keyframes[k]["pose"])
-    saved = (ba.depth_cam, ba.color_cam, ba.dp.a, ba.cfactor.copy())
-    ba.depth_cam, ba.color_cam = common.ob.make_camera(_cam_tuple(g.depth_cam), scene.width, scene.height), \
-        common.ob.make_camera(_cam_tuple(g.color_cam), scene.width, scene.height)
-    ba.dp.a = g.dp.a
-    ba.cfactor[:] = g.cfactor.download()
-    cost_gpu, _ = ba.evaluate_cost()
-    assert abs(cost_gpu - cost_ref) <= 0.02 * (cost_before - cost_ref), (cost_before, cost_ref, cost_gpu)
-
-    if mode != "all":
-        # well-conditioned blocks: the states themselves agree far below the update size
-        dpos = np.abs(got[:3] - ref[:3]).max(axis=0)
-        assert np.quantile(dpos, 0.999) < 0.05 * np.median(moved), np.quantile(dpos, [0.5, 0.99, 0.999, 1.0])
-        if poses_on:
-            for k in range(len(perturbed)):
-                err = common.pose_error(ref_poses[k], g.keyframes[k]["pose"])
-                assert np.abs(err).max() < 2e-5, (k, err)
-            # the same outer iteration by the oracle's binary64 conjugate gradient (same binary32 pair terms): the backend's
-            # poses are closer to it than the binary32 oracle's, whose running sums carry more noise (the backend's own
-            # noise -- binary32 atomics in the dense head -- moves this figure between 8e-7 and 3.5e-6 from run to run)
-            ba64, _, _, _ = _pcg_setup(scene, mode)
-            ba64.bundle_adjustment(optimize_poses=True, optimize_geometry=True, min_iterations=1, max_iterations=1, use_pcg="f64",
-                                   increase_ba_iteration_count=False, pcg_gauge_keyframe=0)
-            worst = max(np.abs(common.pose_error(ba64.pose(k), g.keyframes[k]["pose"])).max() for k in range(len(perturbed)))
-            worst32 = max(np.abs(common.pose_error(ba64.pose(k), ref_poses[k])).max() for k in range(len(perturbed)))
-            print("one PCG iteration, worst pose component vs the binary64 CG: backend %.3g, binary32 oracle %.3g" % (worst, worst32))
-            assert worst < 1e-5, (worst, worst32)
+        assert np.array_equal(np.asarray(g.keyframes[k]["pose"], np.float32), np.asarray(ba.pose(k), np.float32)), k
+    assert np.array_equal(_bits(_cam_tuple(g.depth_cam)), _bits(_cam_tuple(ba.depth_cam)))
+    assert np.array_equal(_bits(_cam_tuple(g.color_cam)), _bits(_cam_tuple(ba.color_cam)))
+    assert np.array_equal(_bits([g.dp.a]), _bits([ba.dp.a]))
+    assert np.array_equal(_bits(g.cfactor.download()), _bits(ba.cfactor))

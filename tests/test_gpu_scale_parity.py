@@ -192,7 +192,7 @@ def test_many_keyframes_intrinsics_step_bit_exact(many):
 
 def test_many_keyframes_pcg_assembly(many):
     """PCGInit over 200 keyframes: the surfel block of r = -J^T W F and M = diag(J^T W J) bit for bit (per-surfel sums in
-    keyframe order), the 6 x 199 pose block to the summation noise of binary32 atomics."""
+    keyframe order) and the 6 x 199 pose block (exact sums): bit for bit."""
     scene, orc, g = many
     K = len(orc.keyframes)
     orc.use_depth, orc.use_desc = 1, 1
@@ -216,17 +216,11 @@ def test_many_keyframes_pcg_assembly(many):
     N = data.shape[1]
     ps = 6 * (K - 1)
     assert U == ps + 3 * N
-    assert np.array_equal(r[ps:].view(np.uint32), r_ref[ps:].view(np.uint32))
-    assert np.array_equal(M[ps:].view(np.uint32), M_ref[ps:].view(np.uint32))
-    # The pose block is a sum over ~1e5 signed terms per entry.  The oracle's binary32 running sums are the noisy side here
-    # (5e-2 of sqrt(M) at this size), so the block is held against the same terms accumulated in binary64: by Cauchy-Schwarz
-    # |sum w J r| <= sqrt(M) * sqrt(cost), so the summation noise is measured in units of sqrt(M).
-    r64, M64 = orc.pcg_assemble(True, True, False, False, gauge_keyframe=1, binary64=True)
-    scale = np.sqrt(np.maximum(M64[:ps], 1e-30)) + 1e-30
-    noise_gpu, noise_oracle32 = np.abs((r[:ps] - r64[:ps]) / scale).max(), np.abs((r_ref[:ps] - r64[:ps]) / scale).max()
-    print("pose block of r, worst deviation from the binary64 sum in units of sqrt(M): backend %.3g, binary32 oracle %.3g" % (noise_gpu, noise_oracle32))
-    assert np.abs(M[:ps] - M64[:ps]).max() <= 1e-5 * np.abs(M64[:ps]).max()
-    assert noise_gpu < 5e-3      # (5.6e-4 measured; the order of the backend's binary32 atomics varies from run to run)
+    # every entry, the 6 x 199 pose block (exact sums of ~1e3 tile totals per entry, added with atomics in arbitrary order by
+    # the kernel) included
+    assert np.array_equal(r.view(np.uint32), r_ref.view(np.uint32)), np.flatnonzero(r.view(np.uint32) != r_ref.view(np.uint32))[:10]
+    assert np.array_equal(M.view(np.uint32), M_ref.view(np.uint32)), np.flatnonzero(M.view(np.uint32) != M_ref.view(np.uint32))[:10]
+    assert np.count_nonzero(M_ref[:ps]) == ps
     for k, T in enumerate(scene.poses_gt):     # leave the shared fixture as it was
         orc.set_pose(k, T)
         g.keyframes[k]["pose"] = np.asarray(T, np.float32)
