@@ -56,6 +56,25 @@ __device__ __forceinline__ void exact_atomic_add(ExactCell* cell, float v, unsig
   }
 }
 
+// One part of cell += v from each of two neighbouring lanes that hold the same v (part 0: the low addend, part 1: the rest):
+// one atomic instruction per value pair instead of two, issued as an asm statement the compiler's waitcnt pass does not track
+// -- the sweeps issue these one candidate keyframe late, behind the next candidate's gathers (kernels_pose.hip says why: vmcnt
+// retires in order, and an atomic in front of the gathers would put a second memory round trip into every candidate).
+// Validated on gfx950 (the mnemonic is the gfx9 family's; later families call it global_atomic_add_u64).
+__device__ __forceinline__ void exact_atomic_add_part_untracked(ExactCell* cell, float v, int part, unsigned* invalid) {
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "exact_atomic_add_part_untracked: inline asm validated for the gfx9 family only"
+#endif
+  const ExactSplit s = exact_split(v);
+  if (s.limb >= 0) {
+    const long long addend = part ? s.hi : s.lo;
+    long long* target = &cell->limb[s.limb + part];
+    if (addend != 0) asm volatile("global_atomic_add_x2 %0, %1, off" ::"v"(target), "v"(addend) : "memory");
+  } else if (s.limb == -2 && part == 0) {
+    atomicOr(invalid, 1u);
+  }
+}
+
 // The same into workgroup memory.  `limbs` is laid out [kExactLimbs][stride] with one column per thread, so the threads of a
 // wavefront touch consecutive 8-byte words: a private accumulator per thread whose limb index is data dependent (registers
 // cannot be indexed that way).

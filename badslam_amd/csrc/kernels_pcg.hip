@@ -96,7 +96,7 @@ struct PairTerms {
 
 template <bool kDepthIntr, bool kColorIntr>
 __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrinsics& in, const KfEntry& kf, const Assoc& r,
-                                                Vec3 gn, const TangentPoints& tp, float d1, float d2, PairTerms* t) {
+                                                const PixelWords& pix, const DescWords& dw, Vec3 gn, float d1, float d2, PairTerms* t) {
   const float* F = kf.pose.F;
   const Vec3 rn = r.nl;
   const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
@@ -112,9 +112,11 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
     t->Jgeom = -inv_std;
     jac_depth_pose(rn, u, inv_std, t->Jpose);
     if (kDepthIntr) {
+      // cfactor of the pixel's cell and the raw depth: the words the association already loaded (the geometry plane's low
+      // half is the keyframe's depth image)
       const int sparse_px = r.px / in.cell, sparse_py = r.py / in.cell;
-      const float cfactor = pitched_load(in.cfactor, in.cfactor_pitch, sparse_py, sparse_px);
-      const float raw_inv_depth = 1.0f / (in.raw_to_float_depth * pitched_load(kf.depth, kf.depth_pitch, r.py, r.px));
+      const float cfactor = pix.cfactor;
+      const float raw_inv_depth = 1.0f / (in.raw_to_float_depth * (uint16_t)(pix.geom & 0xffffu));
       const float exp_inv_depth = expf(-in.a * raw_inv_depth);
       const float corrected = cfactor * exp_inv_depth + raw_inv_depth;
       t->di_valid = !(fabsf(corrected) < 1e-4f);
@@ -129,11 +131,10 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
     }
   }
   if (L.use_desc) {
-    float cx, cy;
-    t->color_ok = depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy);
+    t->color_ok = dw.color_ok;
     if (t->color_ok) {
       DescEval e;
-      eval_descriptor<true>(in, kf.lumafp, F, tp, cx, cy, d1, d2, &e);
+      eval_descriptor_from_words(in, kf.lumafp, dw, d1, d2, &e);
       t->raw1 = e.r1; t->raw2 = e.r2;
       t->w1 = descriptor_residual_weight(e.r1);
       t->w2 = descriptor_residual_weight(e.r2);
@@ -147,6 +148,25 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
       }
     }
   }
+}
+
+// The gathers of one (surfel, keyframe) pair, all in flight before the first is waited for (ba_device.h: project_surfel), and
+// the association on the loaded words.
+struct PairGather {
+  PixelWords pix;
+  DescWords dw;
+  Assoc a;
+};
+__device__ __forceinline__ bool gather_and_associate(const PcgLayout& L, const Intrinsics& in, const KfEntry& kf, Vec3 gp, Vec3 gn,
+                                                     const TangentPoints& tp, bool in_range, PairGather* g) {
+  const float* F = kf.pose.F;
+  const Projected p = project_surfel(in, F, gp);
+  g->pix = load_pixel_words(in, kf.geom, p);
+  if (L.use_desc) g->dw = load_descriptor_words(in, kf.lumafp, F, tp, p);
+  const bool visible = in_range && associate_from_words<false>(in, F, gn, p, g->pix, &g->a, nullptr);
+  if (L.use_desc) gathers_arrived(g->pix, g->dw);
+  else gathers_arrived(g->pix);
+  return visible;
 }
 
 // ---- PCGInit: r -= J^T W F, M += diag(J^T W J)  (B/kernel_pcg.cu:179-541) -----------------------------
@@ -176,18 +196,44 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
 #pragma unroll
   for (int q = 0; q < 9; ++q) { ir[q] = 0.f; iM[q] = 0.f; }
 
+  // The exact atomics of a candidate keyframe are issued one candidate late, behind the next candidate's gathers
+  // (exact_sum.h: exact_atomic_add_part_untracked): the tile totals of the pose entries wait in `pending`, the per-cell
+  // cfactor terms of a lane in pending_cf*.
+  float pending = 0.f;
+  uint32_t pending_base = 0xffffffffu;    // wave-uniform
+  uint32_t pending_cf = 0xffffffffu;      // per lane: head index of the cell
+  float pending_cf_r = 0.f, pending_cf_M = 0.f;
+  auto flush_pending = [&]() {
+    if (pending_base != 0xffffffffu) {
+      const int slot = lane >> 2, part = lane & 3;   // lanes 4 j .. 4 j + 3 hold tile total j: two of them add its two parts
+      if (slot < 12 && part < 2)
+        exact_atomic_add_part_untracked(slot < 6 ? &ex.head_a[pending_base + slot] : &ex.head_b[pending_base + slot - 6], pending, part, ex.invalid);
+      pending_base = 0xffffffffu;
+    }
+    if (kDepthIntr) {
+      if (pending_cf != 0xffffffffu) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          exact_atomic_add_part_untracked(&ex.head_a[pending_cf], pending_cf_r, part, ex.invalid);
+          exact_atomic_add_part_untracked(&ex.head_b[pending_cf], pending_cf_M, part, ex.invalid);
+        }
+      }
+      pending_cf = 0xffffffffu;
+    }
+  };
   for_each_candidate(
       num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         const KfEntry& kf = kfs[k];
-        Assoc a;
-        bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.geom, gp, gn, &a, nullptr);
+        PairGather pg;
+        bool visible = gather_and_associate(L, in, kf, gp, gn, tp, in_range, &pg);
+        flush_pending();
         if (!__any(visible)) return;
         const bool pose_kf = kf_pose_is_unknown(L, k);
         float pr[6] = {0, 0, 0, 0, 0, 0}, pM[6] = {0, 0, 0, 0, 0, 0};
         if (visible) {
           PairTerms t;
-          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, a, gn, tp, d1, d2, &t);
+          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, pg.a, pg.pix, pg.dw, gn, d1, d2, &t);
           if (L.use_depth) {
             if (L.optimize_geometry) {
               gr[0] -= t.Jgeom * t.w * t.raw;
@@ -203,9 +249,9 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
 #pragma unroll
                 for (int c = 0; c < 5; ++c) { const float wj = t.w * t.Jdi[c]; ir[c] += -1 * wj * t.raw; iM[c] += t.Jdi[c] * wj; }
                 const float wj = t.w * t.Jcf;
-                const uint32_t h = head_index(L, t.cf_index);
-                exact_atomic_add(&ex.head_a[h], -1 * wj * t.raw, ex.invalid);
-                exact_atomic_add(&ex.head_b[h], t.Jcf * wj, ex.invalid);
+                pending_cf = head_index(L, t.cf_index);
+                pending_cf_r = -1 * wj * t.raw;
+                pending_cf_M = t.Jcf * wj;
               }
             }
           }
@@ -240,11 +286,11 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
           const uint32_t base = kf_pose_index(L, k);   // pose unknowns come first: head index == unknown index
           // 12 tile totals with one halving butterfly (wave_reduce.h): lanes 4 j .. 4 j + 3 hold total j
           const float v[16] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pM[0], pM[1], pM[2], pM[3], pM[4], pM[5], 0.f, 0.f, 0.f, 0.f};
-          const float mine = wave_reduce_small<16>(v, lane);
-          const int slot = lane >> 2;
-          if ((lane & 3) == 0 && slot < 12) exact_atomic_add(slot < 6 ? &ex.head_a[base + slot] : &ex.head_b[base + slot - 6], mine, ex.invalid);
+          pending = wave_reduce_small<16>(v, lane);
+          pending_base = base;
         }
       });
+  flush_pending();
 
   if (in_range && L.optimize_geometry) {
     r_[gi] = gr[0]; M_[gi] = gM[0];
@@ -448,21 +494,41 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
   for (int q = 0; q < 9; ++q) gi_acc[q] = 0.f;
   float ad = 0.f;
 
+  // exact atomics one candidate late, as in pcg_init_kernel
+  float pending = 0.f;
+  uint32_t pending_base = 0xffffffffu;    // wave-uniform
+  uint32_t pending_cf = 0xffffffffu;      // per lane
+  float pending_cf_g = 0.f;
+  auto flush_pending = [&]() {
+    if (pending_base != 0xffffffffu) {
+      const int slot = lane >> 3, part = lane & 7;   // lanes 8 j .. 8 j + 7 hold tile total j
+      if (slot < 6 && part < 2) exact_atomic_add_part_untracked(&ex.head_a[pending_base + slot], pending, part, ex.invalid);
+      pending_base = 0xffffffffu;
+    }
+    if (kDepthIntr) {
+      if (pending_cf != 0xffffffffu) {
+        exact_atomic_add_part_untracked(&ex.head_a[pending_cf], pending_cf_g, 0, ex.invalid);
+        exact_atomic_add_part_untracked(&ex.head_a[pending_cf], pending_cf_g, 1, ex.invalid);
+      }
+      pending_cf = 0xffffffffu;
+    }
+  };
   for_each_candidate(
       num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         const KfEntry& kf = kfs[k];
-        Assoc a;
-        const bool visible = in_range && project_associate<false>(in, kf.pose.F, kf.geom, gp, gn, &a, nullptr);
-        if (!__any(visible)) return;
+        PairGather pg;
+        const bool visible = gather_and_associate(L, in, kf, gp, gn, tp, in_range, &pg);
         const bool pose_kf = kf_pose_is_unknown(L, k);
         const uint32_t base = kf_pose_index(L, k);
         float pp[6] = {0, 0, 0, 0, 0, 0};
-        if (pose_kf) for (int c = 0; c < 6; ++c) pp[c] = p_[base + c];
+        if (pose_kf) for (int c = 0; c < 6; ++c) pp[c] = p_[base + c];   // (wave-uniform address: scalar loads)
+        flush_pending();
+        if (!__any(visible)) return;
         float gpose[6] = {0, 0, 0, 0, 0, 0};
         if (visible) {
           PairTerms t;
-          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, a, gn, tp, d1, d2, &t);
+          eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, pg.a, pg.pix, pg.dw, gn, d1, d2, &t);
           if (L.use_depth) {
             float sum = 0;
             if (L.optimize_geometry) sum += t.Jgeom * ps[0];
@@ -491,7 +557,8 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
             if (di) {
 #pragma unroll
               for (int c = 0; c < 5; ++c) gi_acc[c] += t.Jdi[c] * sum;
-              exact_atomic_add(&ex.head_a[head_index(L, t.cf_index)], t.Jcf * sum, ex.invalid);
+              pending_cf = head_index(L, t.cf_index);
+              pending_cf_g = t.Jcf * sum;
             }
           }
           if (L.use_desc && t.color_ok) {
@@ -528,10 +595,11 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
         }
         if (pose_kf) {
           const float v[8] = {gpose[0], gpose[1], gpose[2], gpose[3], gpose[4], gpose[5], 0.f, 0.f};
-          const float mine = wave_reduce_small<8>(v, lane);   // lanes 8 j .. 8 j + 7 hold total j
-          if ((lane & 7) == 0 && lane < 48) exact_atomic_add(&ex.head_a[base + (lane >> 3)], mine, ex.invalid);
+          pending = wave_reduce_small<8>(v, lane);   // lanes 8 j .. 8 j + 7 hold total j
+          pending_base = base;
         }
       });
+  flush_pending();
 
   if (in_range && L.optimize_geometry) {
     g_[gi] = gs[0];

@@ -9,6 +9,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so, ROCm 7.0); the backend library resolves libamdhip64 through the
+# system's (/opt/rocm, 7.2).  Whichever is loaded first serves the whole process, and torch does not find its GPUs on the
+# system's copy ("No HIP GPUs are available") -- so a process that uses both (the loopback and gloo tests, bench.py) imports
+# torch FIRST.  A full run did that by accident (collection imports tests/test_cpu_multigpu_gloo.py); a partial run did not.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: CPU test taking more than ~20 s")

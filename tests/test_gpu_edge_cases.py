@@ -127,6 +127,7 @@ def test_covisibility_lists_regrown_on_a_live_context():
 
     def phase(g, lists):
         K = len(g.keyframes)
+        g.bind_keyframes()           # (the pose phase leaves its result in the device table: start every phase from the same poses)
         offsets = np.zeros(K + 1, np.int32)
         offsets[1:] = np.cumsum([len(l) for l in lists])
         indices = np.asarray([j for l in lists for j in l], np.int32)

