@@ -162,9 +162,10 @@ def pmc_kernel_entry(pmc, source, kernel_prefix):
 
 def cpu_baseline(args, ba, data, log):
     """One full cost evaluation -- every residual of every (surfel, keyframe) pair, no Jacobians: the reference has no CPU BA
-    path, its only CPU-side notion of the cost is this sum -- of THE BENCH SCENE by the oracle's
-    OpenMP restatement on this box's host cores: the very keyframe images the GPU path worked on (downloaded) and the same
-    surfels.  Nothing is extrapolated."""
+    path, its only CPU-side notion of the cost is this sum -- of THE BENCH SCENE on this box's host
+    cores: the very keyframe images the GPU path worked on (downloaded) and the same surfels, evaluated by the reference's own
+    functions (oracle/_ref, kind "reference") or, where that library is absent, by the oracle's restatement (kind "port").
+    Nothing is extrapolated."""
     from badslam_amd import synthetic
     from oracle import binding as ob
     t0 = time.time()
@@ -178,10 +179,22 @@ def cpu_baseline(args, ba, data, log):
     orc.surfel_data[:data.shape[0], :N] = data
     orc.surfels.surfels_size = orc.surfels.surfel_count = N
     log(f"cpu baseline: scene handed to the oracle in {time.time() - t0:.1f}s ({K} keyframes, {N} surfels)")
+    cores = ob.lib().orc_num_threads()
+    from oracle import ref_binding as rb
+    if os.path.exists(rb.LIB_PATH) and not os.environ.get("BENCH_CPU_BASELINE_PORT"):
+        # the REFERENCE's own functions (its device-math headers compiled for the host: oracle/_ref, built in the build container
+        # from /root/reference and shipped prebuilt), OpenMP over the surfels, one keyframe per call
+        t1 = time.time()
+        cost, nres = rb.evaluate_cost(orc)
+        dt = time.time() - t1
+        return dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=cores, nres=nres, cost=cost, kind="reference",
+                    who="the reference's own association / residual / robust-cost functions (oracle/_ref: B/surfel_projection_nvcc_only.cuh, "
+                        "B/cost_function.cuh, B/robust_weighting.cuh compiled for the host, OpenMP over the surfels)")
     t1 = time.time()
     cost, nres = orc.evaluate_cost()
     dt = time.time() - t1
-    return dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=ob.lib().orc_num_threads(), nres=nres, cost=cost)
+    return dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=cores, nres=nres, cost=cost, kind="port",
+                who="the oracle's restatement (OpenMP)")
 
 
 def launch_ranks(args):
@@ -455,8 +468,8 @@ def main():
             cb = cpu_baseline(args, ba, data, log)
             sweeps = 3 + (stats["pose_rounds"] / args.steps if not args.pcg else 3)
             out["cpu_baseline"] = {"value": cb["pairs_per_s"], "unit": "surfel-keyframe pairs/s (full cost evaluation)",
-                                   "cores": cb["cores"], "kind": "port",
-                                   "sample": f"ONE full cost evaluation of the bench scene itself by the oracle (OpenMP): {cb['K']} keyframes x "
+                                   "cores": cb["cores"], "kind": cb["kind"],
+                                   "sample": f"ONE full cost evaluation of the bench scene itself by {cb['who']}: {cb['K']} keyframes x "
                                              f"{cb['N']} surfels {W}x{H} = {cb['K'] * cb['N']:.3g} pairs, {cb['nres']} residuals, "
                                              f"{cb['seconds_per_eval']:.2f} s; nothing extrapolated",
                                    "seconds_per_cost_evaluation": cb["seconds_per_eval"],

@@ -1,0 +1,95 @@
+"""ctypes binding of oracle/_ref/libbadslam_ref.so: the REFERENCE's own device-math headers compiled for the host
+(oracle/Makefile, oracle/ref_shim/).  Test infrastructure only (see oracle.h): tests/ use it to measure how far the oracle's
+restatement is from the reference's code, pair by pair."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ref", "libbadslam_ref.so")
+REFERENCE_HEADERS = "/root/reference/applications/badslam/src/badslam/cost_function.cuh"
+_lib = None
+
+
+class RefScene(C.Structure):
+    _fields_ = [("depth_cam", C.c_float * 4), ("color_cam", C.c_float * 4), ("width", C.c_int), ("height", C.c_int),
+                ("color_width", C.c_int), ("color_height", C.c_int), ("a", C.c_float), ("raw_to_float_depth", C.c_float),
+                ("baseline_fx", C.c_float), ("cell", C.c_int), ("cfactor", C.POINTER(C.c_float)), ("cf_width", C.c_int),
+                ("cf_height", C.c_int), ("depth", C.POINTER(C.c_uint16)), ("normals", C.POINTER(C.c_uint16)),
+                ("rgba", C.POINTER(C.c_uint8)), ("frame_T_global", C.c_float * 12), ("surfel_rows", C.POINTER(C.c_float)),
+                ("capacity", C.c_uint32), ("surfels_size", C.c_uint32), ("quantize_texture_weights", C.c_int)]
+
+
+def available():
+    return os.path.exists(LIB_PATH) or os.path.exists(REFERENCE_HEADERS)
+
+
+def lib():
+    """Loads the library; builds it first where the reference's sources are present (the build container)."""
+    global _lib
+    if _lib is None:
+        if os.path.exists(REFERENCE_HEADERS):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "_ref/libbadslam_ref.so"])
+        L = C.CDLL(LIB_PATH)
+        for name in ("ref_raw_to_calibrated_depth", "ref_tukey_weight", "ref_tukey_residual", "ref_huber_weight", "ref_huber_residual", "ref_sample_luma"):
+            getattr(L, name).restype = C.c_float
+        L.ref_raw_to_calibrated_depth.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint16]
+        for name in ("ref_tukey_weight", "ref_tukey_residual", "ref_huber_weight", "ref_huber_residual"):
+            getattr(L, name).argtypes = [C.c_float, C.c_float]
+        L.ref_sample_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.ref_image_space_normal_to_u16.restype = C.c_uint16
+        L.ref_image_space_normal_to_u16.argtypes = [C.c_float, C.c_float]
+        L.ref_u16_to_image_space_normal.argtypes = [C.c_uint16, C.POINTER(C.c_float)]
+        L.ref_pack_surfel_normal.restype = C.c_uint32
+        L.ref_pack_surfel_normal.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.ref_unpack_surfel_normal.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L.ref_evaluate_pairs.restype = None
+        _lib = L
+    return _lib
+
+
+def _scene(orc, keyframe_index, quantize_texture_weights):
+    from oracle import binding as ob
+    arrs = orc.kf_arrays(keyframe_index)
+    kf = orc.keyframes[keyframe_index]
+    sc = RefScene()
+    for name, cam in (("depth_cam", orc.depth_cam), ("color_cam", orc.color_cam)):
+        getattr(sc, name)[:] = [cam.fx, cam.fy, cam.cx, cam.cy]
+    sc.width, sc.height = orc.depth_cam.width, orc.depth_cam.height
+    sc.color_width, sc.color_height = orc.color_cam.width, orc.color_cam.height
+    sc.a, sc.raw_to_float_depth, sc.baseline_fx, sc.cell = orc.dp.a, orc.dp.raw_to_float_depth, orc.dp.baseline_fx, orc.dp.cell
+    sc.cfactor, sc.cf_width, sc.cf_height = ob._ptr(orc.cfactor, C.c_float), orc.cf_w, orc.cf_h
+    sc.depth, sc.normals = ob._ptr(arrs["depth"], C.c_uint16), ob._ptr(arrs["normals"], C.c_uint16)
+    sc.rgba = ob._ptr(arrs["color"], C.c_uint8)
+    sc.frame_T_global[:] = list(kf.frame_T_global)
+    sc.surfel_rows, sc.capacity, sc.surfels_size = ob._ptr(orc.surfel_data, C.c_float), orc.surfel_data.shape[1], orc.surfels_size
+    sc.quantize_texture_weights = int(quantize_texture_weights)
+    return sc
+
+
+def evaluate_pairs(orc, keyframe_index, surfel_indices, quantize_texture_weights=False):
+    """ref_evaluate_pairs on the scene an oracle.binding.OracleBA holds: the same keyframe images, cfactor image, cameras and
+    surfel rows go to the reference's functions.  Returns a (count, 37) uint32 array laid out like OracleBA.evaluate_pairs."""
+    from oracle import binding as ob
+    L = lib()
+    sc = _scene(orc, keyframe_index, quantize_texture_weights)
+    idx = np.ascontiguousarray(surfel_indices, dtype=np.uint32)
+    out = np.zeros((len(idx), ob.OracleBA.PAIR_WORDS), np.uint32)
+    L.ref_evaluate_pairs(C.byref(sc), ob._ptr(idx, C.c_uint32), C.c_int(len(idx)), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def evaluate_cost(orc, keyframe_indices=None, quantize_texture_weights=False):
+    """Sum of the robust costs of every associated (surfel, keyframe) pair by the reference's functions (ref_evaluate_cost,
+    OpenMP over the surfels, one keyframe per call).  Returns (cost, number of residuals)."""
+    L = lib()
+    L.ref_evaluate_cost.restype = C.c_double
+    total, count = 0.0, 0
+    for k in (range(len(orc.keyframes)) if keyframe_indices is None else keyframe_indices):
+        sc = _scene(orc, k, quantize_texture_weights)
+        n = C.c_ulonglong()
+        total += float(L.ref_evaluate_cost(C.byref(sc), C.byref(n), int(orc.use_depth), int(orc.use_desc)))
+        count += int(n.value)
+    return total, count

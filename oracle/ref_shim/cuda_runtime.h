@@ -1,0 +1,90 @@
+// cuda_runtime.h -- a HOST stand-in for the CUDA runtime header, just large enough to compile the reference's device-math
+// headers (applications/badslam/src/badslam/*.cuh) with g++.  TEST INFRASTRUCTURE (see oracle/oracle.h): it exists so that
+// oracle/_ref/libbadslam_ref.so can be built from the reference's own sources, read where they lie under /root/reference at
+// build time -- nothing of the reference is copied into this repository.
+//
+// What is modelled:
+//   * the vector PODs and make_* constructors the headers use;
+//   * __device__ / __host__ / __forceinline__ as nothing / inline;  __CUDA_ARCH__ defined, so Norm() takes its sqrtf branch
+//     (B/cuda_util.cuh:78-85);
+//   * tex2D<float4> on a uchar4 image: the reference's colour texture is created with clamp addressing, linear filtering,
+//     cudaReadModeNormalizedFloat, unnormalised coordinates (B/keyframe.cc:67-73).  CUDA's linear filter (programming guide,
+//     "Linear Filtering"): xB = x - 0.5, i = floor(xB), alpha = frac(xB) kept in 9-bit fixed point with 8 fractional bits;
+//     result = (1-a)(1-b) T[i,j] + a (1-b) T[i+1,j] + (1-a) b T[i,j+1] + a b T[i+1,j+1].  `quantize_weights` selects the
+//     hardware's 8-bit weights (round to nearest) or exact binary32 weights (what oracle and kernels use);
+//   * __syncthreads_or(x) == x for the single "thread" that runs here.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#ifndef __CUDA_ARCH__
+#define __CUDA_ARCH__ 600
+#endif
+
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct uint2 { unsigned int x, y; };
+struct uchar4 { unsigned char x, y, z, w; };
+struct uchar3 { unsigned char x, y, z; };
+inline float2 make_float2(float x, float y) { float2 r = {x, y}; return r; }
+inline float3 make_float3(float x, float y, float z) { float3 r = {x, y, z}; return r; }
+inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
+inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
+inline uint2 make_uint2(unsigned int x, unsigned int y) { uint2 r = {x, y}; return r; }
+inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { uchar4 r = {x, y, z, w}; return r; }
+
+// the headers call ::min / ::max (CUDA's global overloads)
+inline float max(float a, float b) { return a > b ? a : b; }
+inline float min(float a, float b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline unsigned int max(unsigned int a, unsigned int b) { return a > b ? a : b; }
+inline unsigned int min(unsigned int a, unsigned int b) { return a < b ? a : b; }
+
+typedef void* cudaStream_t;
+typedef unsigned long long cudaTextureObject_t;   // here: the address of a RefTexture
+
+struct RefTexture {
+  const uchar4* texels;   // pitch-linear RGBA, w = luma (B/cuda_image_processing.cu:165-193)
+  int width, height;
+  size_t pitch_bytes;
+  int quantize_weights;   // 1: 8 fractional bits like the texture unit; 0: exact binary32 weights
+};
+
+template <typename T> T tex2D(cudaTextureObject_t tex, float x, float y);
+
+inline float ref_filter_weight(float frac, int quantize) {
+  return quantize ? std::floor(frac * 256.f + 0.5f) * (1.f / 256.f) : frac;
+}
+template <> inline float4 tex2D<float4>(cudaTextureObject_t handle, float x, float y) {
+  const RefTexture& t = *reinterpret_cast<const RefTexture*>(handle);
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = std::floor(xb), fy = std::floor(yb);
+  const float a = ref_filter_weight(xb - fx, t.quantize_weights), b = ref_filter_weight(yb - fy, t.quantize_weights);
+  const int i = (int)fx, j = (int)fy;
+  auto at = [&](int u, int v) {
+    u = u < 0 ? 0 : (u >= t.width ? t.width - 1 : u);     // cudaAddressModeClamp
+    v = v < 0 ? 0 : (v >= t.height ? t.height - 1 : v);
+    const uchar4 c = *reinterpret_cast<const uchar4*>(reinterpret_cast<const char*>(t.texels) + (size_t)v * t.pitch_bytes + (size_t)u * 4);
+    return make_float4(c.x * (1.f / 255.f), c.y * (1.f / 255.f), c.z * (1.f / 255.f), c.w * (1.f / 255.f));   // cudaReadModeNormalizedFloat
+  };
+  const float4 t00 = at(i, j), t10 = at(i + 1, j), t01 = at(i, j + 1), t11 = at(i + 1, j + 1);
+  const float w00 = (1 - a) * (1 - b), w10 = a * (1 - b), w01 = (1 - a) * b, w11 = a * b;
+  return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x, w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+                     w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z, w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
+}
+// single-channel float textures (the *WithFloatTexture variants of the headers; not exercised here, but they must compile)
+template <> inline float tex2D<float>(cudaTextureObject_t handle, float x, float y) { return tex2D<float4>(handle, x, y).w; }
+
+inline int __syncthreads_or(int predicate) { return predicate; }
+inline int __all(int predicate) { return predicate; }
