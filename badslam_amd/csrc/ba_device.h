@@ -99,18 +99,58 @@ struct KfEntry {
 };
 
 // One frame whose pose is being estimated (batched Gauss-Newton, kernels_pose.hip).
-constexpr int kHbStride = 28;   // 21 H (row-major upper triangle) + 6 b + 1 pad
-// The pose normal equations are summed in FIXED POINT: the 27 binary32 totals of one (64-surfel tile, keyframe) pair -- the
-// result of the fixed halving tree of wave_reduce.h -- are converted to 48.16 fixed point (round to nearest even) and added
-// as 64-bit integers.  Integer addition is associative, so the sums do not depend on the order of the atomics, on the launch
-// shape (pose_parts), on how tiles are grouped, or on how the surfels are sharded over GPUs (an integer all-reduce is exact):
-// H and b are deterministic, and the oracle computes the same bits (oracle_pose.c).  The reference merges float atomics in
-// arbitrary order (B/gauss_newton.cuh:71,89; SURVEY appendix B marks this FIX).  Resolution 2^-16 = 1.5e-5 is below the
-// binary32 ulp of any tile total that matters (a tile's H entries are 1e2 ... 1e8); range +-1.4e14.
-typedef long long HbFixed;
-constexpr double kHbFixedScale = 65536.0;
-__host__ __device__ __forceinline__ HbFixed hb_to_fixed(float v) { return (HbFixed)__builtin_rint((double)v * kHbFixedScale); }
-__host__ __device__ __forceinline__ double hb_from_fixed(HbFixed q) { return (double)q * (1.0 / kHbFixedScale); }
+constexpr int kHbCoefficients = 28;   // 21 H (row-major upper triangle) + 6 b + 1 pad
+// The pose normal equations are summed in FIXED POINT, order-free.  The 27 binary32 totals of one (64-surfel tile, keyframe)
+// pair -- the result of the fixed halving tree of wave_reduce.h -- are converted to multiples of 2^-32 (round to nearest even;
+// exact for every total of magnitude >= 2^-9) and added as two 64-bit integer limbs: the low 32 bits of that integer into limb
+// 0 (weight 2^-32), the rest into limb 1 (weight 1).  Integer addition is associative, so the sums do not depend on the order
+// of the atomics, on the launch shape (workgroup tables in LDS or global atomics, pose_parts), on how tiles are grouped, or on
+// how the surfels are sharded over GPUs (an integer all-reduce is exact): H and b are deterministic, and the oracle computes
+// the same bits (oracle_pose.c).  The reference merges float atomics in arbitrary order (B/gauss_newton.cuh:71,89; SURVEY
+// appendix B marks this FIX).  Round 2 used one limb of weight 2^-16 (range 1.4e14, and a quantum above the binary32 ulp of a
+// total below 128); with two limbs the quantum is 2.3e-10 and the range of a sum 9.2e18.  A tile total that is not finite or
+// not below 2^40 = 1.1e12 in magnitude (so that 2^23 tiles cannot overflow limb 1) is NOT added: it raises a sticky flag in the
+// counter record of the phase and the pose estimation fails with an error (the reference would carry a NaN into the solve).
+typedef long long HbFixed;            // one limb
+constexpr int kHbLimbs = 2;
+constexpr int kHbStride = kHbCoefficients * kHbLimbs;   // int64 words per work item: [coefficient][limb]
+struct HbSplit {
+  long long lo, hi;
+  bool valid;
+};
+__host__ __device__ __forceinline__ HbSplit hb_split(float v) {
+  unsigned int bits;
+  __builtin_memcpy(&bits, &v, sizeof(bits));
+  unsigned int e = (bits >> 23) & 0xffu;
+  unsigned int m = bits & 0x7fffffu;
+  HbSplit r;
+  r.lo = 0; r.hi = 0; r.valid = true;
+  if (e) m |= 0x800000u; else e = 1u;
+  // |v| = m * 2^(e - 150) = m * 2^s in units of 2^-32, s = e - 118; |v| < 2^40 <=> e - 127 < 40 <=> s <= 48
+  const int s = (int)e - 118;
+  if (s > 48) { r.valid = false; return r; }        // too large, infinite or NaN (e = 255)
+  if (s >= 32) {
+    r.hi = (long long)((unsigned long long)m << (s - 32));
+  } else if (s >= 0) {
+    const unsigned long long w = (unsigned long long)m << s;
+    r.lo = (long long)(w & 0xffffffffull);
+    r.hi = (long long)(w >> 32);
+  } else if (s >= -25) {                            // below the quantum: round to nearest, ties to even
+    const int sh = -s;
+    unsigned int q = m >> sh;
+    const unsigned int rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    r.lo = (long long)q;
+  }
+  if (bits >> 31) { r.lo = -r.lo; r.hi = -r.hi; }
+  return r;
+}
+// The value of a limb pair (carry-normalised first): binary64; H and b are its rounding to binary32.
+__host__ __device__ __forceinline__ double hb_value(long long lo, long long hi) {
+  hi += lo >> 32;                 // arithmetic shift: floor
+  lo &= 0xffffffffll;
+  return (double)hi + (double)lo * 2.3283064365386963e-10;   // 2^-32
+}
 struct PoseWork {
   float F[12];        // frame_T_global at the current linearisation point
   float T[7];         // global_T_frame estimate (Sophus layout)
@@ -132,6 +172,9 @@ constexpr int kPoseCounterConverged = 32;
 // polls it instead of synchronising the stream and copying 256 bytes (capi.hip: run_pose_rounds).
 constexpr int kPoseCounterTicket = 33;
 constexpr int kPoseCounterSequence = 34;
+// [kPoseCounterInvalid]: sticky, raised by the accumulate kernel when a tile total could not be added (not finite, or 2^40 and
+// beyond: hb_split); the host turns it into an error when the round's counters arrive.
+constexpr int kPoseCounterInvalid = 35;
 constexpr int kPoseTailRecords = 2;
 // Behind the counter records (device only): the indices of the work items still iterating after the latest Gauss-Newton
 // round, in arbitrary order (pose_solve_kernel appends with the same atomic that counts them).  The later rounds of a phase

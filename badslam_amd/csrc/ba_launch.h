@@ -41,7 +41,9 @@ void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry*
 size_t pose_tile_bounds_bytes(uint32_t surfels);   // size of the per-tile bounding-sphere buffer launch_pose_accumulate needs
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
-                            int num_listed /* stored_bounds: entries of the list of work items still iterating */);
+                            int num_listed /* stored_bounds: entries of the list of work items still iterating */,
+                            uint32_t* tile_counters /* 16 words, zero before the first launch; NULL: never the persistent LDS form */,
+                            int* parity_inout /* which half of tile_counters the next persistent launch draws from */);
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out,
                        int sequence /* published to the host copy of the counters when the launch is complete */);
@@ -52,10 +54,12 @@ void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, 
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
+void set_pose_form(int form);     // 0 = automatic; 1 = one tile per wavefront + global atomics; 2 = persistent workgroups with the normal equations in LDS
 void set_pose_parts(int parts);   // 0 = automatic; 1 | 2 | 4 | 8 wavefronts share a tile's keyframes in the pose kernel
 void launch_jacobian_debug(hipStream_t stream, int kind, const float* in, float* out);
 void launch_pose_step_debug(hipStream_t stream, const float* in, float* out);
 void launch_exact_math_debug(hipStream_t stream, int kind, const float* in, float* out, size_t n);
+void launch_pose_limbs_debug(hipStream_t stream, const float* in, long long* out, size_t n);
 void launch_wave_reduce_debug(hipStream_t stream, const float* in, float* out);
 void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
                            const uint32_t* indices, int count, float* out);

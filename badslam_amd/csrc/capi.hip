@@ -83,10 +83,12 @@ struct bahip_context {
   PoseWork* dev_work1 = nullptr;
   PoseWork* pinned_work1 = nullptr;
   HbFixed* dev_Hb1 = nullptr;
+  uint32_t* dev_tile_counters = nullptr;   // persistent pose sweep: two sets of 8 tile counters (kernels_pose.hip)
+  int pose_parity = 0;                     // the set the next persistent launch draws from
 
   int* dev_counter = nullptr;      // [0] generic counter, [1..2] min/max depth bits
   int* pinned_i = nullptr;         // 16 ints
-  float* pinned_f = nullptr;       // 64 floats
+  float* pinned_f = nullptr;       // 128 floats
 
   uint8_t* dev_flags = nullptr;    // W*H new-surfel flags
   uint32_t* dev_indices = nullptr; // W*H scan output
@@ -362,7 +364,7 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     const double t0 = host_timing ? now() : 0;
     timer_begin(ctx, 2, round == 0, iterating);
     launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb, ctx->dev_tile_bounds,
-                           /*stored_bounds*/ round > 0, /*num_listed*/ iterating);
+                           /*stored_bounds*/ round > 0, /*num_listed*/ iterating, ctx->dev_tile_counters, &ctx->pose_parity);
     timer_end(ctx, 2);
     CHECK_LAUNCH();
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
@@ -379,6 +381,9 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     // this launch's sequence number into host_work (mapped, coherent host memory); the host polls the sequence number.
     const double t1 = host_timing ? now() : 0;
     if (wait_for_pose_sequence(ctx, host_work, dev_work, num_work, sequence)) return 1;
+    if (counters[kPoseCounterInvalid])
+      return fail("pose normal equations: a tile total was not finite or reached 2^40 (hb_split); the surfels or images hold non-finite "
+                  "values or the scene is out of the fixed-point range", __FILE__, __LINE__);
     if (host_timing) {
       t_launch += t1 - t0; t_wait += now() - t1;
       if (++n_rounds % 30 == 0) fprintf(stderr, "[pose rounds, us per round] enqueue %.1f | wait %.1f\n", t_launch / n_rounds, t_wait / n_rounds);
@@ -471,7 +476,9 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   ctx->stream = static_cast<hipStream_t>(hip_stream);
   const bool ok = hipMalloc(&ctx->dev_counter, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)) == hipSuccess &&
-                  hipHostMalloc(&ctx->pinned_f, 64 * sizeof(float)) == hipSuccess &&
+                  hipHostMalloc(&ctx->pinned_f, 128 * sizeof(float)) == hipSuccess &&
+                  hipMalloc(&ctx->dev_tile_counters, 16 * sizeof(uint32_t)) == hipSuccess &&
+                  hipMemset(ctx->dev_tile_counters, 0, 16 * sizeof(uint32_t)) == hipSuccess &&
                   hipMalloc(&ctx->dev_frame1, sizeof(KfEntry)) == hipSuccess &&
                   hipMalloc(&ctx->dev_work1, sizeof(PoseWork) * pose_work_records(1)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_work1, sizeof(PoseWork) * (1 + kPoseTailRecords), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
@@ -492,7 +499,7 @@ void bahip_context_destroy(bahip_context* ctx) {
 #endif
   if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->dev_kfs); hipFree(ctx->dev_work); hipFree(ctx->dev_Hb);
-  hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1);
+  hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1); hipFree(ctx->dev_tile_counters);
   hipFree(ctx->dev_counter);
   if (ctx->pinned_i) hipHostFree(ctx->pinned_i);
   if (ctx->pinned_f) hipHostFree(ctx->pinned_f);
@@ -808,23 +815,27 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
   REQUIRE(surfels->surfels_size > 0, "AccumulatePoseEstimationCoeffs is only intended for surfels_size > 0");  // :61
   KfEntry e;
   if (make_entry(ctx, *frame, 0, &e)) return 1;
-  PoseWork w{};
-  memcpy(w.F, frame_T_global, 12 * sizeof(float));
-  w.kf_index = 0;
+  PoseWork w[1 + kPoseTailRecords] = {};   // the work item and its (zeroed) counter records
+  memcpy(w[0].F, frame_T_global, 12 * sizeof(float));
+  w[0].kf_index = 0;
   HIP_TRY(hipMemcpyAsync(ctx->dev_frame1, &e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->dev_work1, &w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->dev_work1, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->dev_Hb1, 0, sizeof(HbFixed) * kHbStride, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ensure_tile_bounds(ctx, surfels->surfels_size)) return 1;
   launch_pose_accumulate(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_frame1, ctx->dev_work1, 1,
-                         make_view(surfels), ctx->dev_Hb1, ctx->dev_tile_bounds, /*stored_bounds*/ false, /*num_listed*/ 0);
+                         make_view(surfels), ctx->dev_Hb1, ctx->dev_tile_bounds, /*stored_bounds*/ false, /*num_listed*/ 0,
+                         ctx->dev_tile_counters, &ctx->pose_parity);
   CHECK_LAUNCH();
   if (reduce_over_ranks(ctx, ctx->dev_Hb1, kHbStride, BAHIP_SUM_I64)) return 1;
-  HbFixed* fixed = reinterpret_cast<HbFixed*>(ctx->pinned_f);   // 28 x 8 bytes of the 64-float pinned buffer
+  HbFixed* fixed = reinterpret_cast<HbFixed*>(ctx->pinned_f);   // 56 x 8 bytes of the 128-float pinned buffer
   HIP_TRY(hipMemcpyAsync(fixed, ctx->dev_Hb1, sizeof(HbFixed) * kHbStride, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, reinterpret_cast<const int*>(ctx->dev_work1 + 1) + kPoseCounterInvalid, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  for (int c = 0; c < 21; ++c) H[c] = (float)hb_from_fixed(fixed[c]);
-  for (int c = 0; c < 6; ++c) b[c] = (float)hb_from_fixed(fixed[21 + c]);
+  if (ctx->pinned_i[0])
+    return fail("pose normal equations: a tile total was not finite or reached 2^40 (hb_split)", __FILE__, __LINE__);
+  for (int c = 0; c < 21; ++c) H[c] = (float)hb_value(fixed[c * kHbLimbs], fixed[c * kHbLimbs + 1]);
+  for (int c = 0; c < 6; ++c) b[c] = (float)hb_value(fixed[(21 + c) * kHbLimbs], fixed[(21 + c) * kHbLimbs + 1]);
   return 0;
 }
 
@@ -1391,6 +1402,12 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
   return 0;
 }
 
+int bahip_debug_set_pose_form(int form) {
+  REQUIRE(form == 0 || form == 1 || form == 2, "pose form must be 0 (automatic), 1 (one tile per wavefront, global atomics) or 2 (persistent, LDS table)");
+  set_pose_form(form);
+  return 0;
+}
+
 int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts) {
   REQUIRE(tile_waves == 0 || tile_waves == 1 || tile_waves == 4, "tile_waves must be 0 (automatic), 1 or 4");
   REQUIRE(pose_parts == 0 || pose_parts == 1 || pose_parts == 2 || pose_parts == 4 || pose_parts == 8, "pose_parts must be 0, 1, 2, 4 or 8");
@@ -1439,6 +1456,19 @@ int bahip_debug_exact_math(bahip_context* ctx, int kind, const float* in, float*
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   hipFree(d_in); hipFree(d_out);
   if (e != hipSuccess) return fail("bahip_debug_exact_math", __FILE__, __LINE__, e);
+  return 0;
+}
+
+int bahip_debug_pose_limbs(bahip_context* ctx, const float* values_host, size_t count, long long* out_host) {
+  if (count == 0) return 0;
+  DevMem in, out;
+  HIP_TRY(hipMalloc(&in.p, sizeof(float) * count));
+  HIP_TRY(hipMalloc(&out.p, sizeof(long long) * 3 * count));
+  HIP_TRY(hipMemcpy(in.p, values_host, sizeof(float) * count, hipMemcpyHostToDevice));
+  launch_pose_limbs_debug(ctx->stream, in.as<float>(), out.as<long long>(), count);
+  CHECK_LAUNCH();
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out_host, out.p, sizeof(long long) * 3 * count, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -59,12 +59,74 @@ void pose_counters_dump() {
     fprintf(stderr, "candidates %llu  with-any-association %llu  associated lanes %llu\n", c[0], c[1], c[2]);
 }
 #endif
-template <bool kUseDepth, bool kUseDesc>
-__global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
-pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
-                       int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
-                       int num_listed) {
-  const uint32_t tile = xcd_chunked_tile(blockIdx.x);
+// Where the 27 tile totals of a (tile, work item) pair go.
+//
+// GlobalSink: two 64-bit integer atomics per total on the Hb buffer.  They are issued one candidate late, behind the next
+// candidate's gathers: vmcnt counts loads, stores and atomics alike and retires them in order, so a wavefront that issues its
+// atomics and then the next gathers cannot use the gathered words before the atomics have been acknowledged by the memory
+// side -- two round trips per candidate.  Held back (one VGPR: every lane holds the tile total of one slot), the
+// acknowledgement has a whole candidate's arithmetic to arrive in.  As asm statements: the compiler's waitcnt pass otherwise
+// waits for the (non-returning) atomics at the top of the next candidate.  Not tracking them is safe: vmcnt retires in order,
+// so an untracked older operation can only make a later s_waitcnt vmcnt(N) wait for more than the compiler intended, never
+// for less.  (Mnemonic of the gfx9 family, validated on gfx950; later families call it global_atomic_add_u64.)
+struct GlobalSink {
+  HbFixed* Hb;
+  int* invalid;
+  float pending;
+  int pending_w;     // wave-uniform
+  int slot_offset;   // byte offset of this lane's coefficient in a work item's row, or -1 (lane holds no total)
+  __device__ __forceinline__ void flush() {
+    if (pending_w >= 0 && slot_offset >= 0) {
+      const HbSplit v = hb_split(pending);
+      const HbFixed* row = Hb + (size_t)pending_w * kHbStride;   // wave-uniform: a scalar base, the lane adds its 32-bit offset
+      if (v.valid) {
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__)
+        if (v.lo) asm volatile("global_atomic_add_x2 %0, %1, %2" ::"v"(slot_offset), "v"(v.lo), "s"(row) : "memory");
+        if (v.hi) asm volatile("global_atomic_add_x2 %0, %1, %2 offset:8" ::"v"(slot_offset), "v"(v.hi), "s"(row) : "memory");
+#else
+        HbFixed* target = const_cast<HbFixed*>(row) + slot_offset / (int)sizeof(HbFixed);
+        if (v.lo) __hip_atomic_fetch_add(target, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v.hi) __hip_atomic_fetch_add(target + 1, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      } else {
+        atomicOr(invalid, 1);
+      }
+    }
+    pending_w = -1;
+  }
+  __device__ __forceinline__ void gathers_done() { flush(); }
+  __device__ __forceinline__ void add(int /*item*/, int w, float total) { pending = total; pending_w = w; }
+  __device__ __forceinline__ void finish() { flush(); }
+};
+// LdsSink: the workgroup's own table of limb pairs in LDS, one row per work item; ds_add_u64 costs no memory round trip and
+// does not take part in vmcnt, so the totals are added at once.  The workgroup flushes the table to Hb when it runs out of
+// tiles (pose_accumulate_lds_kernel): per launch 256 workgroups x K x 27 x 2 global atomics instead of 2 per total of every
+// (tile, work item) pair -- 25 M memory-side atomics and 97 MB of write traffic per launch at the bench size (profiles/r2_e).
+struct LdsSink {
+  HbFixed* table;   // [num_items][kHbCoefficients][kHbLimbs]
+  int* invalid;
+  int slot;
+  __device__ __forceinline__ void gathers_done() {}
+  __device__ __forceinline__ void add(int item, int /*w*/, float total) {
+    if (slot >= 0 && slot < 27) {
+      const HbSplit v = hb_split(total);
+      HbFixed* target = &table[(size_t)item * kHbStride + slot * kHbLimbs];
+      if (v.valid) {
+        if (v.lo) __hip_atomic_fetch_add(target, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v.hi) __hip_atomic_fetch_add(target + 1, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        atomicOr(invalid, 1);
+      }
+    }
+  }
+  __device__ __forceinline__ void finish() {}
+};
+
+// One 64-surfel tile against the work items still iterating (every `parts`-th of them, starting at `part`).
+template <bool kUseDepth, bool kUseDesc, typename Sink>
+__device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
+                                          int num_work, const SurfelsView& s, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
+                                          int num_listed, uint32_t tile, int parts, int part, Sink& sink) {
   const int lane = threadIdx.x & 63;
   // Later rounds (stored_bounds): the items are the num_listed entries of the list behind the counter records -- the work
   // items still iterating -- instead of all num_work work items.
@@ -76,8 +138,8 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     wb = tile_bounds[tile];     // wave-uniform address: scalar loads
     if (wb.r < 0.f) return;
     bool any = false;
-    for (int base = blockIdx.y; base < num_items && !any; base += 64 * gridDim.y) {
-      const int item = base + lane * gridDim.y;
+    for (int base = part; base < num_items && !any; base += 64 * parts) {
+      const int item = base + lane * parts;
       bool sees = false;
       if (item < num_items) {
         float f[12];
@@ -88,7 +150,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     }
     if (!any) return;
   }
-  const uint32_t i = tile * kPoseBlock + threadIdx.x;
+  const uint32_t i = tile * kPoseBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -100,42 +162,27 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     d2 = s.row(kSurfelDescriptor2)[ii];
   }
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);
-  const int slot = wave_reduce28_slot(lane);
 
   // Only the work items whose frustum can contain this wavefront's surfels are visited (wave_cull.h).
   if (!stored_bounds) {
     wb = wave_bounds(gp, in_range && (gp.x == gp.x));
-    if (blockIdx.y == 0 && lane == 0) tile_bounds[tile] = wb;
+    if (part == 0 && lane == 0) tile_bounds[tile] = wb;
   }
-  // The 27 atomics of a candidate are issued one candidate late, behind the next candidate's gathers: vmcnt counts loads,
-  // stores and atomics alike and retires them in order, so a wavefront that issues its atomics and then the next gathers
-  // cannot use the gathered words before the atomics have been acknowledged by the memory side - two round trips per
-  // candidate.  Held back (one VGPR: every lane holds the tile total of one slot), the acknowledgement has a whole
-  // candidate's arithmetic to arrive in.
-  float pending = 0.f;
-  int pending_w = -1;   // wave-uniform
-  auto flush_pending = [&]() {
-    if (pending_w >= 0 && slot >= 0 && slot < 27) {
-      // as an asm statement: the compiler's waitcnt pass otherwise waits for the (non-returning) atomic at the top of the
-      // next candidate.  Not tracking it is safe: vmcnt retires in order, so an untracked older operation can only make a
-      // later s_waitcnt vmcnt(N) wait for more than the compiler intended, never for less.
-      HbFixed* target = &Hb[(size_t)pending_w * kHbStride + slot];
-      const HbFixed value = hb_to_fixed(pending);
-      asm volatile("global_atomic_add_x2 %0, %1, off" ::"v"(target), "v"(value) : "memory");
-    }
-    pending_w = -1;
-  };
+  int my_w = 0;   // the work item of this lane's candidate item in the current chunk of 64 (read back by lane in the body)
   for_each_candidate(
       num_items,
       [&](int item) {
         const int w = work_item_of(item);
+        my_w = w;
         float f[12];
         int32_t done;
         load_candidate(work[w].F, &work[w].done, f, &done);
         return !done && sphere_may_project(in, f, wb);
       },
       [&](int item) {
-    const int w = __builtin_amdgcn_readfirstlane(work_item_of(item));
+    // item = base + lane' * parts for the lane' that tested it: its w comes from that lane's register, not from memory
+    // (a list lookup here was a dependent load and a wait at the top of every candidate of the later rounds)
+    const int w = __builtin_amdgcn_readfirstlane(stored_bounds ? __builtin_amdgcn_readlane(my_w, ((item - part) / parts) & 63) : item);
     const float* F = work[w].F;
     const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
     // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
@@ -149,7 +196,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
     // compiler wait for it - and, vmcnt being in-order, for the atomics behind it - at the top of the next candidate)
     if (kUseDesc) gathers_arrived(pix, dw);
     else gathers_arrived(pix);
-    flush_pending();
+    sink.gathers_done();
 #ifdef BAHIP_COUNT_CANDIDATES
     {
       const unsigned long long associated_lanes = __ballot(visible);
@@ -162,7 +209,7 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
 #endif
     if (!__any(visible)) return;
 
-    float acc[28];   // 21 H + 6 b + 1 pad (kHbStride)
+    float acc[28];   // 21 H + 6 b + 1 pad (kHbCoefficients)
 #pragma unroll
     for (int q = 0; q < 28; ++q) acc[q] = 0.f;
 
@@ -197,12 +244,85 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
       }
     }
 
-    // wave64 halving reduction (wave_reduce.h: a fixed tree over the 64 lanes), then one 64-bit integer atomic per scalar
-    // per wave on the fixed-point value: order-free, hence deterministic
-    pending = wave_reduce28(acc, lane);
-    pending_w = w;
-  }, gridDim.y, blockIdx.y);
-  flush_pending();
+    // wave64 halving reduction (wave_reduce.h: a fixed tree over the 64 lanes), then two 64-bit integer adds per scalar
+    // per wave on the fixed-point limbs: order-free, hence deterministic
+    sink.add(item, w, wave_reduce28(acc, lane));
+  }, parts, part);
+  sink.finish();
+}
+
+// One wavefront per workgroup and tile; gridDim.y wavefronts share a tile's work items (shards of a multi-GPU run, and work
+// item tables too large for the LDS form below).
+template <bool kUseDepth, bool kUseDesc>
+__global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
+pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
+                       int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
+                       int num_listed, int* __restrict__ invalid /* counter word kPoseCounterInvalid; its own argument so that `work`
+                       stays read-only to the compiler: the per-candidate pose rows are then scalar loads */) {
+  const int lane = threadIdx.x & 63;
+  const int slot = wave_reduce28_slot(lane);
+  GlobalSink sink{Hb, invalid, 0.f, -1, (slot >= 0 && slot < 27) ? slot * kHbLimbs * (int)sizeof(HbFixed) : -1};
+  pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, xcd_chunked_tile(blockIdx.x),
+                                 (int)gridDim.y, (int)blockIdx.y, sink);
+}
+
+// Persistent form: one workgroup of 16 wavefronts per compute unit keeps the normal equations of every work item in LDS
+// (K x 28 x 2 limbs: 90 KB at 200 keyframes; gfx950 has 160 KB per CU).  Its wavefronts draw tiles instead of owning one
+// each, so a wavefront with many candidate keyframes does not hold the others back (one tile per wavefront of a multi-wave
+// workgroup did: -8 %, round 1).  Two levels: the workgroup takes batches of kPoseBatch tiles from a counter in global memory
+// -- one per XCD, in the order of xcd_chunked_tile, so the spatial runs still meet in one L2 -- and its wavefronts take single
+// tiles of the batch from a word in LDS (wave-level draws from the global counters were tried first: 5 860 returning atomics
+// per address per launch serialise, 0.5 ms for a round with three work items left).  `tile_counters`: two sets of 8; a
+// launch draws from set `parity` and clears the other for the next launch.
+constexpr int kPoseLdsWaves = 16;
+constexpr uint32_t kPoseBatch = 32;
+template <bool kUseDepth, bool kUseDesc>
+__global__ void __launch_bounds__(64 * kPoseLdsWaves) BAHIP_WAVES_ATTR
+pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
+                           int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
+                           int num_listed, int* __restrict__ invalid, uint32_t padded_tiles, uint32_t* __restrict__ tile_counters, int parity) {
+  extern __shared__ HbFixed table[];
+  __shared__ unsigned long long batch_state;   // (first tile of the current batch << 32) | tiles of it already taken
+  const int lane = threadIdx.x & 63;
+  const int num_items = stored_bounds ? num_listed : num_work;
+  const uint32_t xcd = blockIdx.x & 7u, per_xcd = padded_tiles >> 3;
+  uint32_t* counter = tile_counters + parity * 8 + xcd;
+  for (int e = threadIdx.x; e < num_items * kHbStride; e += 64 * kPoseLdsWaves) table[e] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 8) tile_counters[(parity ^ 1) * 8 + threadIdx.x] = 0;
+  if (threadIdx.x == 0) batch_state = (unsigned long long)atomicAdd(counter, kPoseBatch) << 32;
+  __syncthreads();
+  const int slot = wave_reduce28_slot(lane);
+  LdsSink sink{table, invalid, slot};
+  for (;;) {
+    unsigned long long taken = 0;
+    if (lane == 0) taken = atomicAdd(&batch_state, 1ull);
+    const uint32_t first = __builtin_amdgcn_readfirstlane((uint32_t)(taken >> 32));
+    const uint32_t index = __builtin_amdgcn_readfirstlane((uint32_t)taken);
+    if (first >= per_xcd) break;                         // the XCD's tiles are used up
+    if (index < kPoseBatch) {
+      if (first + index < per_xcd)
+        pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed,
+                                       xcd_chunked_tile_of((first + index) * 8u + xcd, padded_tiles), 1, 0, sink);
+    } else if (index == kPoseBatch) {                    // this wavefront took the batch's last-plus-one: it fetches the next batch
+      if (lane == 0) {
+        const uint32_t next = atomicAdd(counter, kPoseBatch);
+        __hip_atomic_store(&batch_state, (unsigned long long)next << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {                                             // the others wait for it (a few microseconds per kPoseBatch tiles)
+      while ((uint32_t)(__hip_atomic_load(&batch_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == first)
+        __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  const int* __restrict__ listed = reinterpret_cast<const int*>(work + num_work + kPoseTailRecords);
+  for (int e = threadIdx.x; e < num_items * kHbStride; e += 64 * kPoseLdsWaves) {
+    const HbFixed v = table[e];
+    if (v != 0) {
+      const int item = e / kHbStride;
+      const int w = stored_bounds ? listed[item] : item;
+      __hip_atomic_fetch_add(&Hb[(size_t)w * kHbStride + (e - item * kHbStride)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // B/convergence_analysis.h:43-51
@@ -281,7 +401,7 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
     HbFixed* fixed = Hb + (size_t)w * kHbStride;
     float hb[27];
     // the fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
-    for (int c = 0; c < 27; ++c) hb[c] = (float)hb_from_fixed(fixed[c]);
+    for (int c = 0; c < 27; ++c) hb[c] = (float)hb_value(fixed[c * kHbLimbs], fixed[c * kHbLimbs + 1]);
     for (int c = 0; c < kHbStride; ++c) fixed[c] = 0;
     float xf[6], next[7];
     pose_gn_step(hb, pw.T, xf, next);
@@ -452,9 +572,34 @@ size_t pose_tile_bounds_bytes(uint32_t surfels) {
   return tiles * sizeof(WaveBounds);
 }
 
+// 0 = chosen from the sizes (default), 1 = always the one-tile-per-wavefront form with global atomics, 2 = the persistent LDS
+// form whenever the table fits (tests run both: same bits)
+static int g_forced_pose_form = [] { const char* e = getenv("BAHIP_POSE_FORM"); return e ? atoi(e) : 0; }();
+void set_pose_form(int form) { g_forced_pose_form = form; }
+constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a compute unit
+
+template <bool kUseDepth, bool kUseDesc>
+static void launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
+                            const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
+                            uint32_t* tile_counters, int parity) {
+  int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
+  static int compute_units = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }();
+  static bool raised = [] {   // dynamic LDS beyond 64 KB needs the opt-in
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_accumulate_lds_kernel<kUseDepth, kUseDesc>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsTableLimit) == hipSuccess;
+  }();
+  (void)raised;
+  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc>), dim3(compute_units), dim3(64 * kPoseLdsWaves), table_bytes, stream, in, frames,
+                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity);
+}
+
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
-                            int num_listed) {
+                            int num_listed, uint32_t* tile_counters, int* parity_inout) {
   if (s.size == 0 || num_work == 0) return;
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
@@ -465,13 +610,27 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
                          : tiles >= 32768 ? 1 : tiles >= 8192 ? 2 : 4;
   // measured (r2, pose stage per iteration, ms): 46.9 k tiles 1.03 / 1.08 / 1.30 with 1 / 2 / 4 parts; 23.4 k tiles 0.578 / 0.557 / 0.618
   // with 1 / 2 / 4; 11.7 k tiles 0.29 / 0.30 with 2 / 4; 5.9 k tiles 0.155 / 0.172 with 4 / 8
-  const dim3 grid(tiles, parts), block(kPoseBlock);
   const PoseWork* pw = static_cast<const PoseWork*>(work);
   WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);
   const int sb = stored_bounds ? 1 : 0;
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed);
+  // The persistent LDS form when the grid fills the chip on its own (no splitting of a tile's work items) and the table of the
+  // work items in this launch fits.
+  const size_t table_bytes = sizeof(HbFixed) * kHbStride * (size_t)(stored_bounds ? num_listed : num_work);
+  const bool lds_form = tile_counters != nullptr && table_bytes <= kPoseLdsTableLimit &&
+                        (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && parts == 1 && forced == 0));
+  if (lds_form) {
+    const int parity = *parity_inout;
+    *parity_inout = parity ^ 1;
+    if (use_depth && use_desc) launch_pose_lds<true, true>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity);
+    else if (use_depth) launch_pose_lds<true, false>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity);
+    else launch_pose_lds<false, true>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity);
+    return;
+  }
+  const dim3 grid(tiles, parts), block(kPoseBlock);
+  int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid);
 }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
@@ -595,6 +754,16 @@ __global__ void exact_math_debug_kernel(int kind, const float* __restrict__ in, 
     sincos_det(in[i], &sn, &cs);
     out[i] = kind == 2 ? sn : cs;
   }
+}
+// Test hook: hb_split on explicit values.  out: [lo, hi, valid] per value.
+__global__ void pose_limbs_debug_kernel(const float* __restrict__ in, long long* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const HbSplit v = hb_split(in[i]);
+  out[3 * i] = v.lo; out[3 * i + 1] = v.hi; out[3 * i + 2] = v.valid ? 1 : 0;
+}
+void launch_pose_limbs_debug(hipStream_t stream, const float* in, long long* out, size_t n) {
+  if (n) hipLaunchKernelGGL(pose_limbs_debug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);
 }
 void launch_exact_math_debug(hipStream_t stream, int kind, const float* in, float* out, size_t n) {
   if (n) hipLaunchKernelGGL(exact_math_debug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, in, out, n);

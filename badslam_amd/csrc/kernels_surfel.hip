@@ -207,11 +207,9 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
   }
   if (!live) return;
   const float sx = sum[0], sy = sum[1], sz = sum[2], count = sum[3];
-  if (writer) {
-    // The reference leaves the sums in accum rows 0..3; keep that observable state.
-    s.row(kSurfelAccum0 + 0)[i] = sx; s.row(kSurfelAccum0 + 1)[i] = sy;
-    s.row(kSurfelAccum0 + 2)[i] = sz; s.row(kSurfelAccum0 + 3)[i] = count;
-  }
+  // (The reference parks these sums in accum rows 0..3 between its kernels, B/kernel_opt_geometry.cu:527-597; here they live
+  // in registers and are not stored: rows 8..16 are scratch, nothing reads them after the step, and until round 3 writing
+  // them -- with the nine sums of the position pass -- tripled the sweep's write traffic: 77 instead of 25 bytes per surfel.)
   if (count >= 1) {
     const uint32_t packed = pack_normal10((1.f / count) * mk3(sx, sy, sz));
     if (writer) reinterpret_cast<uint32_t*>(s.row(kSurfelNormal))[i] = packed;
@@ -289,8 +287,6 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
     });
     if (!live || !writer) return;
     const float H = hb[0], b = hb[1];
-    s.row(kSurfelAccum0 + 0)[i] = H;
-    s.row(kSurfelAccum0 + 1)[i] = b;
     if (H > 1e-6f) {
       const float t = -1.f * b / H;
       const Vec3 np = gp + t * gn;
@@ -350,9 +346,6 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   });
   if (!live || !writer) return;
   const float a0 = tot[0], a1 = tot[1], a2 = tot[2], a3 = tot[3], a5 = tot[4], a6 = tot[5], a7 = tot[6], a8 = tot[7];
-  s.row(kSurfelAccum0 + 0)[i] = a0; s.row(kSurfelAccum0 + 1)[i] = a1; s.row(kSurfelAccum0 + 2)[i] = a2;
-  s.row(kSurfelAccum0 + 3)[i] = a3; s.row(kSurfelAccum0 + 4)[i] = 0;  s.row(kSurfelAccum0 + 5)[i] = a5;
-  s.row(kSurfelAccum0 + 6)[i] = a6; s.row(kSurfelAccum0 + 7)[i] = a7; s.row(kSurfelAccum0 + 8)[i] = a8;
 
   // B/kernel_opt_geometry.cu:273-353: in-place Cholesky of the 3x3 system (H12 is exactly 0).
   float H00 = a0 + 1e-6f, H01 = a1, H02 = a2, H11 = a3 + 1e-6f, H12 = 0.f, H22 = a5 + 1e-6f;

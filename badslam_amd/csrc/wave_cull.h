@@ -38,6 +38,13 @@ __device__ __forceinline__ uint32_t xcd_chunked_tile(uint32_t block) {
   return ((((j >> shift) << 3) + xcd) << shift) + (j & ((1u << shift) - 1u));
 }
 
+// The same for a persistent grid: the tile that position `block` of a grid of `padded_tiles` one-tile workgroups would own.
+__device__ __forceinline__ uint32_t xcd_chunked_tile_of(uint32_t block, uint32_t padded_tiles) {
+  const uint32_t shift = padded_tiles >= kXcdLargeGrid ? 7u : 5u;
+  const uint32_t xcd = block & 7u, j = block >> 3;
+  return ((((j >> shift) << 3) + xcd) << shift) + (j & ((1u << shift) - 1u));
+}
+
 struct WaveBounds {
   float cx, cy, cz;   // sphere centre (global frame)
   float r;            // inflated radius; negative = no valid surfel in this wave

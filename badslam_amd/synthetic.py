@@ -85,13 +85,13 @@ def render_planes(pose, planes, camera, width, height, raw_to_float_depth, textu
 def make_scene(num_keyframes: int, width: int = 640, height: int = 480, seed: int = 0,
                num_planes: int = 20, raw_to_float_depth: float = 1.0 / 5000, baseline_fx: float = 40.0,
                cell: int = 2, translation_range: float = 3.0, rotation_range: float = 1.4,
-               textured: bool = True) -> Scene:
+               textured: bool = True, plane_distance: float = 2.5) -> Scene:
     """K keyframes scattered around a first pose: T_k = T_0 * exp(xi_k), xi translation uniform in
     +-translation_range/2 and rotation uniform in +-rotation_range/2 (reference:
     test_intrinsics_optimization_geometric_residual.cc:285-297 uses 3.0 m and 1.4 rad)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     cam = test_camera(width, height)
-    scene = Scene(width, height, cam, raw_to_float_depth, baseline_fx, cell, random_planes(rng, num_planes))
+    scene = Scene(width, height, cam, raw_to_float_depth, baseline_fx, cell, random_planes(rng, num_planes, offset=plane_distance))
     T0 = se3.exp([0.01, 0.02, 0.03, 0.004, 0.005, 0.006])
     for _ in range(num_keyframes):
         xi = np.concatenate([translation_range * (rng.random(3) - 0.5), rotation_range * (rng.random(3) - 0.5)])

@@ -325,6 +325,15 @@ int bahip_debug_exact_sum(bahip_context* ctx, const float* values, size_t count,
  * sums are defined as four interleaved partial sums).  pose_parts (1 | 2 | 4 | 8): wavefronts sharing a
  * tile's keyframes in the pose kernel (sums merged by float atomics in any case). */
 int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
+/* Form of the pose sweep, process-wide; results are bit-identical for all of them.  0 = chosen from the sizes (default);
+ * 1 = one wavefront per surfel tile, tile totals added to the normal equations with global 64-bit integer atomics (the only form
+ * for shards and for more work items than fit the table); 2 = persistent workgroups, one per compute unit, that keep the normal
+ * equations of every work item in LDS and flush them once (whenever the table fits 128 KB: up to 292 work items). */
+int bahip_debug_set_pose_form(int form);
+/* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):
+ * out[3 i .. 3 i + 2] = limb 0 (weight 2^-32), limb 1 (weight 1), valid (0: not finite or 2^40 and beyond -- such a total is
+ * not added and fails the pose estimation). */
+int bahip_debug_pose_limbs(bahip_context* ctx, const float* values, size_t count, long long* out);
 /* The residual Jacobian functions of the kernels (ba_device.h: jac_*) on explicit inputs, for the golden vectors of
  * tests/golden/jacobians.json.  kind: 0 depth/pose (in: nl[3] u[3] inv_std; out 6), 1 descriptor/pose (ls[3] gx gy; 6),
  * 2 descriptor/surfel (rn[3] lp[3] gx gy cfx cfy; 1), 3 depth/intrinsics (px py depth inv_std n.Frow0 n.Frow1 dot cfactor

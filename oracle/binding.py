@@ -345,14 +345,25 @@ class OracleBA:
         return np.array(list(H)), np.array(list(b)), int(n), float(cost.value)
 
     def accumulate_pose_coeffs_fixed(self, i, frame_T_global=None):
-        """The 27 fixed-point (48.16) totals of the defined pose sum, as int64."""
+        """The 27 fixed-point totals of the defined pose sum as (27, 2) int64 limb pairs: limb 0 weighs 2^-32, limb 1 weighs 1."""
         kf = self.keyframes[i]
         F = (C.c_float * 12)(*(list(kf.frame_T_global) if frame_T_global is None else [float(v) for v in frame_T_global]))
-        fixed = (C.c_longlong * 27)()
+        fixed = (C.c_longlong * 54)()
         self.L.orc_accumulate_pose_coeffs_fixed.restype = C.c_uint32
         self.L.orc_accumulate_pose_coeffs_fixed(self.use_depth, self.use_desc, C.byref(self.color_cam), C.byref(self.depth_cam),
                                                 C.byref(self.dp), C.byref(kf), F, C.byref(self.surfels), fixed)
-        return np.array(list(fixed), dtype=np.int64)
+        return np.array(list(fixed), dtype=np.int64).reshape(27, 2)
+
+    @staticmethod
+    def pose_limbs_value(limbs):
+        """Binary64 value of (..., 2) limb pairs (carry-normalised): what H and b are rounded from."""
+        L = lib()
+        L.orc_pose_limbs_value.restype = C.c_double
+        flat = np.asarray(limbs, np.int64).reshape(-1, 2)
+        return np.array([L.orc_pose_limbs_value(C.c_longlong(int(lo)), C.c_longlong(int(hi))) for lo, hi in flat]).reshape(np.shape(limbs)[:-1])
+
+    def pose_sum_invalid(self, reset=True):
+        return bool(self.L.orc_pose_sum_invalid(int(reset)))
 
     def estimate_frame_pose(self, i, init):
         T = init if isinstance(init, SE3) else SE3.from_array(init)

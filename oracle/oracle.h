@@ -190,7 +190,7 @@ void orc_evaluate_pairs(const orc_camera* color_cam, const orc_camera* depth_cam
 /* ---- pose optimisation ---- */
 /* B/kernel_opt_pose.cc:39-97 + B/kernel_opt_pose.cu:251-383 + B/gauss_newton.cuh:46-93.
  * H: 21 floats (row-major upper triangle), b: 6 floats.  accumulate_double == 0: the backend's definition of the sum
- * (per-surfel fma chains, fixed 64-surfel tile tree, 48.16 fixed-point integer total; oracle_pose.c), which is what
+ * (per-surfel fma chains, fixed 64-surfel tile tree, fixed-point integer totals in two limbs; oracle_pose.c), which is what
  * orc_estimate_frame_pose uses; != 0: plain binary64 running sum in surfel order.  Returns the number of associated surfels. */
 float orc_tile_tree_sum(const float lane_values[64]);
 /* the classic xor butterfly (32, 16, 8, 4, 2, 1) in binary32: the backend's wave_sum */
@@ -203,7 +203,11 @@ uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camer
 uint32_t orc_accumulate_pose_coeffs_fixed(int use_depth, int use_desc, const orc_camera* color_cam,
                                           const orc_camera* depth_cam, const orc_depth_params* dp,
                                           const orc_keyframe* kf, const float frame_T_global[12],
-                                          const orc_surfels* s, long long fixed_out[27]);
+                                          const orc_surfels* s, long long fixed_out[54] /* [27][2] limb pairs */);
+/* value of a limb pair; and whether a tile total could not be added since the last reset (not finite, or 2^40 and beyond) */
+double orc_pose_limbs_value(long long lo, long long hi);
+int orc_pose_limbs(float v, long long out[2]);
+int orc_pose_sum_invalid(int reset);
 /* B/direct_ba_alternating.cc:42-283.  Returns number of GN iterations done; *converged set. */
 int orc_estimate_frame_pose(int use_depth, int use_desc, const orc_camera* color_cam,
                             const orc_camera* depth_cam, const orc_depth_params* dp,

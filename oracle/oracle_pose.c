@@ -12,9 +12,11 @@
  *      residual first, then the two descriptor residuals (acc_residual below);
  *   2. the 64 surfels [64 t, 64 t + 64) of tile t are summed by a fixed binary tree (tile_tree: lane pairs at distance
  *      32, 16, 8, then 7 - i inside groups of 8, then distance 2, 1 -- the halving butterfly of wave_reduce.h);
- *   3. each of the 27 tile totals is converted to 48.16 fixed point (round to nearest even) and the tiles are added as
- *      64-bit integers -- associative, hence order-free;
- *   4. H, b = the integer totals scaled back and rounded to binary32.
+ *   3. each of the 27 tile totals is converted to a multiple of 2^-32 (round to nearest even; exact for |total| >= 2^-9) and
+ *      added as two 64-bit integer limbs -- the low 32 bits of that integer (weight 2^-32) and the rest (weight 1) --
+ *      associative, hence order-free (hb_split below; round 2 used a single limb of weight 2^-16).  A total that is not
+ *      finite or not below 2^40 in magnitude is not added and raises orc_pose_sum_invalid();
+ *   4. H, b = the carry-normalised limb pairs as binary64 (hb_value), rounded to binary32.
  * accumulate_double != 0 is the plain binary64 running sum in surfel order (an independent check of 1.-4.). */
 static inline void acc_residual(float* acc, float raw, float w, const float* J) {
   int k = 0;
@@ -43,16 +45,46 @@ float orc_tile_tree_sum(const float x[64]) {
   const float B0 = A[0] + A[7], B1 = A[1] + A[6], B2 = A[2] + A[5], B3 = A[3] + A[4];
   return (B0 + B2) + (B1 + B3);
 }
-#define ORC_HB_FIXED_SCALE 65536.0
+/* The backend's hb_split / hb_value (ba_device.h), restated. */
+static int g_pose_sum_invalid = 0;
+int orc_pose_sum_invalid(int reset) { const int v = g_pose_sum_invalid; if (reset) g_pose_sum_invalid = 0; return v; }
+static int hb_split(float v, long long* lo_out, long long* hi_out) {
+  uint32_t bits;
+  memcpy(&bits, &v, sizeof(bits));
+  uint32_t e = (bits >> 23) & 0xffu, m = bits & 0x7fffffu;
+  long long lo = 0, hi = 0;
+  if (e) m |= 0x800000u; else e = 1u;
+  const int s = (int)e - 118;           /* |v| = m * 2^s in units of 2^-32 */
+  if (s > 48) return 0;                 /* 2^40 and beyond, infinite, NaN */
+  if (s >= 32) hi = (long long)((unsigned long long)m << (s - 32));
+  else if (s >= 0) { const unsigned long long w = (unsigned long long)m << s; lo = (long long)(w & 0xffffffffull); hi = (long long)(w >> 32); }
+  else if (s >= -25) {
+    const int sh = -s;
+    uint32_t q = m >> sh;
+    const uint32_t rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    lo = (long long)q;
+  }
+  if (bits >> 31) { lo = -lo; hi = -hi; }
+  *lo_out = lo; *hi_out = hi;
+  return 1;
+}
+/* test hook: the limb pair of one tile total; returns 0 if the value cannot be represented (not added, flag raised) */
+int orc_pose_limbs(float v, long long out[2]) { out[0] = out[1] = 0; return hb_split(v, &out[0], &out[1]); }
+static double hb_value(long long lo, long long hi) {
+  hi += lo >> 32;
+  lo &= 0xffffffffll;
+  return (double)hi + (double)lo * 2.3283064365386963e-10;
+}
 
 /* B/kernel_opt_pose.cc:39-97, kernel B/kernel_opt_pose.cu:251-383. */
 static uint32_t accumulate_pose_coeffs_impl(int use_depth, int use_desc, const orc_camera* color_cam,
                                             const orc_camera* depth_cam, const orc_depth_params* dp,
                                             const orc_keyframe* kf, const float F[12], const orc_surfels* s,
-                                            float H[21], float b[6], float* residual_sum, int accumulate_double, long long* fixed_out) {
+                                            float H[21], float b[6], float* residual_sum, int accumulate_double, long long* fixed_out /* [27][2] */) {
   proj_params p = make_proj_params(depth_cam, dp, s, kf, F);
   const depth_to_color d2c = make_depth_to_color(depth_cam, color_cam);
-  long long fixed[27] = {0};
+  long long fixed[27][2] = {{0}};
   double Hd[21] = {0}, bd[6] = {0};
   double cost = 0;
   uint32_t count = 0;
@@ -100,10 +132,14 @@ static uint32_t accumulate_pose_coeffs_impl(int use_depth, int use_desc, const o
       for (int q = 0; q < 27; ++q) lanes[q][lane] = acc[q];
     }
     if (any && !accumulate_double)
-      for (int q = 0; q < 27; ++q) fixed[q] += llrint((double)orc_tile_tree_sum(lanes[q]) * ORC_HB_FIXED_SCALE);
+      for (int q = 0; q < 27; ++q) {
+        long long lo, hi;
+        if (hb_split(orc_tile_tree_sum(lanes[q]), &lo, &hi)) { fixed[q][0] += lo; fixed[q][1] += hi; }
+        else g_pose_sum_invalid = 1;
+      }
   }
-  for (int k = 0; k < 21; ++k) H[k] = accumulate_double ? (float)Hd[k] : (float)((double)fixed[k] * (1.0 / ORC_HB_FIXED_SCALE));
-  for (int k = 0; k < 6; ++k) b[k] = accumulate_double ? (float)bd[k] : (float)((double)fixed[21 + k] * (1.0 / ORC_HB_FIXED_SCALE));
+  for (int k = 0; k < 21; ++k) H[k] = accumulate_double ? (float)Hd[k] : (float)hb_value(fixed[k][0], fixed[k][1]);
+  for (int k = 0; k < 6; ++k) b[k] = accumulate_double ? (float)bd[k] : (float)hb_value(fixed[21 + k][0], fixed[21 + k][1]);
   if (residual_sum) *residual_sum = (float)cost;
   if (fixed_out) memcpy(fixed_out, fixed, sizeof(fixed));
   return count;
@@ -116,11 +152,12 @@ uint32_t orc_accumulate_pose_coeffs(int use_depth, int use_desc, const orc_camer
   return accumulate_pose_coeffs_impl(use_depth, use_desc, color_cam, depth_cam, dp, kf, F, s, H, b, residual_sum, accumulate_double, NULL);
 }
 
-/* The 48.16 fixed-point totals themselves (what the ranks of a surfel-sharded run exchange: an integer sum over shards
- * made of whole 64-surfel tiles IS the unsharded total). */
+/* The fixed-point limb pairs themselves, [27][2] (what the ranks of a surfel-sharded run exchange: an integer sum over shards
+ * made of whole 64-surfel tiles IS the unsharded total), and their value. */
+double orc_pose_limbs_value(long long lo, long long hi) { return hb_value(lo, hi); }
 uint32_t orc_accumulate_pose_coeffs_fixed(int use_depth, int use_desc, const orc_camera* color_cam,
                                           const orc_camera* depth_cam, const orc_depth_params* dp,
-                                          const orc_keyframe* kf, const float F[12], const orc_surfels* s, long long fixed[27]) {
+                                          const orc_keyframe* kf, const float F[12], const orc_surfels* s, long long fixed[54]) {
   float H[21], b[6];
   return accumulate_pose_coeffs_impl(use_depth, use_desc, color_cam, depth_cam, dp, kf, F, s, H, b, NULL, 0, fixed);
 }

@@ -73,7 +73,7 @@ def test_reductions_use_the_gfx950_cross_lane_instructions(listings):
     body = next(v[0] for k, v in kernels.items() if "pose_accumulate_kernelILb1ELb1" in k)
     assert "v_permlane32_swap" in body and "v_permlane16_swap" in body and "dpp" in body
     assert "ds_bpermute" not in body                                             # no LDS round trips in the reduction
-    assert "global_atomic_add_x2" in body                                        # 64-bit integer atomics on the fixed-point totals
+    assert "global_atomic_add_x2" in body                                        # 64-bit integer atomics on the fixed-point limbs
     assert "global_atomic_add_f32" not in body                                   # ... no float atomics (order-dependent sums)
     assert "global_atomic_cmpswap" not in body                                   # ... and no compare-and-swap loop
 
@@ -92,23 +92,31 @@ def test_pose_sweep_puts_all_five_gathers_in_flight_before_the_first_wait(listin
     vmcnt, and that first wait is a counted one (it lets the later loads stay in flight).  A compiler that sinks one of the
     loads back into the branch that uses it puts the round trips in series again (-7 % measured)."""
     kernels = _kernels(listings["kernels_pose"])
-    body = next(v[0] for k, v in kernels.items() if "pose_accumulate_kernelILb1ELb1" in k)
-    assert "flat_load" not in body
-    loop = _innermost_loop(body)
-    assert loop
-    loads_before_wait, first_wait = 0, None
-    for line in loop:
-        s = line.strip()
-        if s.startswith("global_load_dword "):
-            loads_before_wait += 1
-        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", s)
-        if m and loads_before_wait:
-            first_wait = int(m.group(1))
-            break
-    assert loads_before_wait == 5, loads_before_wait
-    assert first_wait is not None and first_wait >= 3, first_wait
-    # the atomics of a candidate are issued one candidate late: one atomic instruction in the loop, one more after it
-    assert body.count("global_atomic_add_x2") == 2
+    for form in ("pose_accumulate_kernelILb1ELb1", "pose_accumulate_lds_kernelILb1ELb1"):
+        body = next(v[0] for k, v in kernels.items() if form in k)
+        assert "flat_load" not in body
+        loop = _innermost_loop(body)
+        assert loop
+        loads_before_wait, first_wait = 0, None
+        for line in loop:
+            s = line.strip()
+            if s.startswith("global_load_dword "):
+                loads_before_wait += 1
+            m = re.match(r"s_waitcnt vmcnt\((\d+)\)", s)
+            if m and loads_before_wait:
+                first_wait = int(m.group(1))
+                break
+        assert loads_before_wait == 5, (form, loads_before_wait)
+        assert first_wait is not None and first_wait >= 3, (form, first_wait)
+        if "lds" in form:
+            # persistent form: the tile totals go to the workgroup's table in LDS (two limbs per total); global atomics only
+            # for drawing tiles and for the flush at the end
+            inner = "\n".join(loop[:-200])     # (_innermost_loop returns 200 lines beyond the last block label of the loop)
+            assert inner.count("ds_add_u64") + "\n".join(loop[-200:]).count("ds_add_u64") == 2 and "global_atomic_add_x2" not in inner, form
+        else:
+            # the atomics of a candidate (two limbs per total) are issued one candidate late: two atomic instructions in the
+            # loop, two more after it
+            assert body.count("global_atomic_add_x2") == 4, form
 
 
 def test_sweeps_gather_through_global_loads(listings):

@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_dir):
     ba.surfel_data[:, :mine.size] = data[:, mine]
     ba.surfels.surfels_size = mine.size
     K = len(ba.keyframes)
-    Hb = np.zeros((K, 28), np.int64)
+    Hb = np.zeros((K, 28, 2), np.int64)          # the backend's buffer: [work item][coefficient][limb]
     for k in range(K):
         Hb[k, :27] = ba.accumulate_pose_coeffs_fixed(k)
     t = torch.from_numpy(Hb)
@@ -50,7 +50,7 @@ def test_surfel_sharded_pose_normal_equations_match_unsharded(tmp_path):
     from tests import common
     scene = common.small_scene(num_keyframes=3, seed=4, width=160, height=120)
     ba = common.build_oracle(scene, 60000)
-    ref = np.zeros((3, 28), np.int64)
+    ref = np.zeros((3, 28, 2), np.int64)
     for k in range(3):
         ref[k, :27] = ba.accumulate_pose_coeffs_fixed(k)
     owned = np.concatenate([np.load(tmp_path / "owned_0.npy"), np.load(tmp_path / "owned_1.npy")])
@@ -60,11 +60,13 @@ def test_surfel_sharded_pose_normal_equations_match_unsharded(tmp_path):
     # shards are whole 64-surfel tiles of the unsharded cloud (chunks of 1024) and integer addition is associative: the
     # sharded sums ARE the unsharded sums, bit for bit -- every rank takes exactly the single-GPU Gauss-Newton step
     assert np.array_equal(hb0, ref)
-    assert np.abs(ref[:, :21]).max() > 2 ** 30                                       # real magnitudes (H ~ 1e5 ... 1e8 in 48.16)
+    assert np.abs(ref[:, :21, 1]).max() > 2 ** 14 and np.abs(ref[:, :21, 0]).max() > 2 ** 32    # real magnitudes in both limbs
     for k in range(3):   # and the binary32 H, b agree with a plain binary64 running sum to binary32 precision
         H, b, _, _ = ba.accumulate_pose_coeffs(k, accumulate_double=True)
-        Hf = (ref[k, :21].astype(np.float64) / 65536.0).astype(np.float32)
+        Hf = ba.pose_limbs_value(ref[k, :21]).astype(np.float32)
         assert np.allclose(Hf, H, rtol=0, atol=2e-7 * np.abs(H).max())
+        H32, _, _, _ = ba.accumulate_pose_coeffs(k, accumulate_double=False)
+        assert np.array_equal(Hf.view(np.uint32), np.asarray(H32, np.float32).view(np.uint32))
 
 
 def test_shard_chunks_partition():

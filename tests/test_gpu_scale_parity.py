@@ -109,12 +109,20 @@ def _oracle_pose_estimates(orc, perturbed, pattern):
     return _ORACLE_POSES
 
 
-@pytest.mark.parametrize("pose_parts", [1, 2, 8])
+@pytest.mark.parametrize("pose_parts", [1, 2, 8, "lds"])
 def test_many_keyframes_batched_pose_estimation(many, pose_parts, request):
+    """pose_parts 1 / 2 / 8: one tile per wavefront, a tile's work items split over that many wavefronts, totals added to the
+    normal equations with global integer atomics; "lds": persistent workgroups that keep the normal equations of all 200 work
+    items in LDS and flush once (the form the bench size takes).  The sums are integer sums: the same bits for every form."""
     scene, orc, g = many
     K = len(orc.keyframes)
-    _shapes(g.ctx.lib, 0, pose_parts)
-    request.addfinalizer(lambda: _shapes(g.ctx.lib, 0, 0))
+    if pose_parts == "lds":
+        capi.check(g.ctx.lib.bahip_debug_set_pose_form(2))
+        request.addfinalizer(lambda: capi.check(g.ctx.lib.bahip_debug_set_pose_form(0)))
+    else:
+        capi.check(g.ctx.lib.bahip_debug_set_pose_form(1))
+        _shapes(g.ctx.lib, 0, pose_parts)
+        request.addfinalizer(lambda: (_shapes(g.ctx.lib, 0, 0), capi.check(g.ctx.lib.bahip_debug_set_pose_form(0))))
     orc.use_depth, orc.use_desc = 1, 1
     data, active = common.oracle_surfels(orc)
     g.upload_surfels(data, active)
