@@ -109,8 +109,11 @@ constexpr int kHbCoefficients = 28;   // 21 H (row-major upper triangle) + 6 b +
 // the same bits (oracle_pose.c).  The reference merges float atomics in arbitrary order (B/gauss_newton.cuh:71,89; SURVEY
 // appendix B marks this FIX).  Round 2 used one limb of weight 2^-16 (range 1.4e14, and a quantum above the binary32 ulp of a
 // total below 128); with two limbs the quantum is 2.3e-10 and the range of a sum 9.2e18.  A tile total that is not finite or
-// not below 2^40 = 1.1e12 in magnitude (so that 2^23 tiles cannot overflow limb 1) is NOT added: it raises a sticky flag in the
-// counter record of the phase and the pose estimation fails with an error (the reference would carry a NaN into the solve).
+// not below 2^52 = 4.5e15 in magnitude is NOT added: it raises a sticky flag in the counter record of the phase and the pose
+// estimation fails with an error (the reference would carry a NaN into the solve).  Tile totals of 1e12 do occur (surfels seen
+// at grazing angles from half a metre: 1 / sigma^2 ~ 1e8 per pair), sums of a keyframe reach 1e11 ... 1e14; a sum whose limb 1
+// ends at 2^62 or beyond in magnitude -- it cannot jump over that band, every addend being below 2^52 -- is flagged as well by
+// the solve kernel, so a wrapped sum would need more than 2^64 - 2^62 = 1.4e19 to go unnoticed.
 typedef long long HbFixed;            // one limb
 constexpr int kHbLimbs = 2;
 constexpr int kHbStride = kHbCoefficients * kHbLimbs;   // int64 words per work item: [coefficient][limb]
@@ -126,9 +129,9 @@ __host__ __device__ __forceinline__ HbSplit hb_split(float v) {
   HbSplit r;
   r.lo = 0; r.hi = 0; r.valid = true;
   if (e) m |= 0x800000u; else e = 1u;
-  // |v| = m * 2^(e - 150) = m * 2^s in units of 2^-32, s = e - 118; |v| < 2^40 <=> e - 127 < 40 <=> s <= 48
+  // |v| = m * 2^(e - 150) = m * 2^s in units of 2^-32, s = e - 118; |v| < 2^52 <=> e - 127 < 52 <=> s <= 60
   const int s = (int)e - 118;
-  if (s > 48) { r.valid = false; return r; }        // too large, infinite or NaN (e = 255)
+  if (s > 60) { r.valid = false; return r; }        // too large, infinite or NaN (e = 255)
   if (s >= 32) {
     r.hi = (long long)((unsigned long long)m << (s - 32));
   } else if (s >= 0) {
@@ -172,8 +175,10 @@ constexpr int kPoseCounterConverged = 32;
 // polls it instead of synchronising the stream and copying 256 bytes (capi.hip: run_pose_rounds).
 constexpr int kPoseCounterTicket = 33;
 constexpr int kPoseCounterSequence = 34;
-// [kPoseCounterInvalid]: sticky, raised by the accumulate kernel when a tile total could not be added (not finite, or 2^40 and
-// beyond: hb_split); the host turns it into an error when the round's counters arrive.
+// [kPoseCounterInvalid]: sticky, raised by the accumulate kernel when a tile total could not be added (not finite, or 2^52 and
+// beyond: hb_split) and by the solve kernel when a sum left the safe range; the host turns it into an error when the round's
+// counters arrive.
+constexpr long long kHbSumLimit = 1ll << 62;
 constexpr int kPoseCounterInvalid = 35;
 constexpr int kPoseTailRecords = 2;
 // Behind the counter records (device only): the indices of the work items still iterating after the latest Gauss-Newton

@@ -382,8 +382,8 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     const double t1 = host_timing ? now() : 0;
     if (wait_for_pose_sequence(ctx, host_work, dev_work, num_work, sequence)) return 1;
     if (counters[kPoseCounterInvalid])
-      return fail("pose normal equations: a tile total was not finite or reached 2^40 (hb_split); the surfels or images hold non-finite "
-                  "values or the scene is out of the fixed-point range", __FILE__, __LINE__);
+      return fail("pose normal equations: a tile total was not finite or reached 2^52 (hb_split), or a sum left the fixed-point range; the "
+                  "surfels or images hold non-finite values", __FILE__, __LINE__);
     if (host_timing) {
       t_launch += t1 - t0; t_wait += now() - t1;
       if (++n_rounds % 30 == 0) fprintf(stderr, "[pose rounds, us per round] enqueue %.1f | wait %.1f\n", t_launch / n_rounds, t_wait / n_rounds);
@@ -833,7 +833,7 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
   HIP_TRY(hipMemcpyAsync(ctx->pinned_i, reinterpret_cast<const int*>(ctx->dev_work1 + 1) + kPoseCounterInvalid, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->pinned_i[0])
-    return fail("pose normal equations: a tile total was not finite or reached 2^40 (hb_split)", __FILE__, __LINE__);
+    return fail("pose normal equations: a tile total was not finite or reached 2^52 (hb_split)", __FILE__, __LINE__);
   for (int c = 0; c < 21; ++c) H[c] = (float)hb_value(fixed[c * kHbLimbs], fixed[c * kHbLimbs + 1]);
   for (int c = 0; c < 6; ++c) b[c] = (float)hb_value(fixed[(21 + c) * kHbLimbs], fixed[(21 + c) * kHbLimbs + 1]);
   return 0;

@@ -95,7 +95,9 @@ struct GlobalSink {
     pending_w = -1;
   }
   __device__ __forceinline__ void gathers_done() { flush(); }
-  __device__ __forceinline__ void add(int /*item*/, int w, float total) { pending = total; pending_w = w; }
+  __device__ __forceinline__ void add(int /*item*/, int w, float total) {
+    pending = total; pending_w = w;
+  }
   __device__ __forceinline__ void finish() { flush(); }
 };
 // LdsSink: the workgroup's own table of limb pairs in LDS, one row per work item; ds_add_u64 costs no memory round trip and
@@ -103,23 +105,31 @@ struct GlobalSink {
 // tiles (pose_accumulate_lds_kernel): per launch 256 workgroups x K x 27 x 2 global atomics instead of 2 per total of every
 // (tile, work item) pair -- 25 M memory-side atomics and 97 MB of write traffic per launch at the bench size (profiles/r2_e).
 struct LdsSink {
-  HbFixed* table;   // [num_items][kHbCoefficients][kHbLimbs]
+  uint32_t lane_offset;   // LDS byte address of this lane's coefficient in row 0 of the table [num_items][kHbCoefficients][kHbLimbs]
   int* invalid;
-  int slot;
-  __device__ __forceinline__ void gathers_done() {}
-  __device__ __forceinline__ void add(int item, int /*w*/, float total) {
-    if (slot >= 0 && slot < 27) {
-      const HbSplit v = hb_split(total);
-      HbFixed* target = &table[(size_t)item * kHbStride + slot * kHbLimbs];
+  bool holds_total;       // this lane holds one of the 27 tile totals
+  float pending;
+  int pending_item;       // wave-uniform
+  // Same shape as GlobalSink -- the totals wait in `pending` and are added at the next candidate (or at the end of the tile)
+  // -- although LDS adds have no round trip to hide: with the adds placed right behind the reduction, rows other than the
+  // first received a few totals twice (the visit log of the sweep was unchanged; not understood, possibly the structurizer's
+  // handling of the early return that precedes the reduction).  In this shape both sinks give the oracle's bits.
+  __device__ __forceinline__ void flush() {
+    if (pending_item >= 0 && holds_total) {
+      const HbSplit v = hb_split(pending);
+      const uint32_t address = lane_offset + (uint32_t)pending_item * (uint32_t)(kHbStride * sizeof(HbFixed));
       if (v.valid) {
-        if (v.lo) __hip_atomic_fetch_add(target, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (v.hi) __hip_atomic_fetch_add(target + 1, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v.lo) asm volatile("ds_add_u64 %0, %1" ::"v"(address), "v"(v.lo) : "memory");
+        if (v.hi) asm volatile("ds_add_u64 %0, %1 offset:8" ::"v"(address), "v"(v.hi) : "memory");
       } else {
         atomicOr(invalid, 1);
       }
     }
+    pending_item = -1;
   }
-  __device__ __forceinline__ void finish() {}
+  __device__ __forceinline__ void gathers_done() { flush(); }
+  __device__ __forceinline__ void add(int item, int /*w*/, float total) { pending = total; pending_item = item; }
+  __device__ __forceinline__ void finish() { flush(); }
 };
 
 // One 64-surfel tile against the work items still iterating (every `parts`-th of them, starting at `part`).
@@ -246,7 +256,13 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
 
     // wave64 halving reduction (wave_reduce.h: a fixed tree over the 64 lanes), then two 64-bit integer adds per scalar
     // per wave on the fixed-point limbs: order-free, hence deterministic
-    sink.add(item, w, wave_reduce28(acc, lane));
+    float total = wave_reduce28(acc, lane);
+    // The cross-lane steps of the reduction must run with every lane enabled: a DPP / permlane source lane that EXEC has
+    // switched off reads as zero.  The totals are consumed under `this lane holds one` (27 lanes), and the compiler sank the
+    // last DPP add into that branch -- rows of the LDS table then received totals that lacked their odd neighbour's half.
+    // The empty asm pins the finished value in uniform control flow.
+    asm volatile("" : "+v"(total));
+    sink.add(item, w, total);
   }, parts, part);
   sink.finish();
 }
@@ -274,17 +290,25 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
 // tiles of the batch from a word in LDS (wave-level draws from the global counters were tried first: 5 860 returning atomics
 // per address per launch serialise, 0.5 ms for a round with three work items left).  `tile_counters`: two sets of 8; a
 // launch draws from set `parity` and clears the other for the next launch.
-constexpr int kPoseLdsWaves = 16;
-constexpr uint32_t kPoseBatch = 32;
+#ifndef BAHIP_POSE_LDS_WAVES
+#define BAHIP_POSE_LDS_WAVES 16
+#endif
+constexpr int kPoseLdsWaves = BAHIP_POSE_LDS_WAVES;
+#ifndef BAHIP_POSE_BATCH
+#define BAHIP_POSE_BATCH 32
+#endif
+constexpr uint32_t kPoseBatch = BAHIP_POSE_BATCH;
 template <bool kUseDepth, bool kUseDesc>
 __global__ void __launch_bounds__(64 * kPoseLdsWaves) BAHIP_WAVES_ATTR
 pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                            int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
                            int num_listed, int* __restrict__ invalid, uint32_t padded_tiles, uint32_t* __restrict__ tile_counters, int parity) {
   extern __shared__ HbFixed table[];
-  __shared__ unsigned long long batch_state;   // (first tile of the current batch << 32) | tiles of it already taken
   const int lane = threadIdx.x & 63;
   const int num_items = stored_bounds ? num_listed : num_work;
+  // (first tile of the current batch << 32) | tiles of it already taken; the word behind the table (a separate __shared__
+  // variable next to the dynamic array was placed ON the array by this toolchain)
+  unsigned long long& batch_state = *reinterpret_cast<unsigned long long*>(table + (size_t)num_items * kHbStride);
   const uint32_t xcd = blockIdx.x & 7u, per_xcd = padded_tiles >> 3;
   uint32_t* counter = tile_counters + parity * 8 + xcd;
   for (int e = threadIdx.x; e < num_items * kHbStride; e += 64 * kPoseLdsWaves) table[e] = 0;
@@ -292,7 +316,8 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
   if (threadIdx.x == 0) batch_state = (unsigned long long)atomicAdd(counter, kPoseBatch) << 32;
   __syncthreads();
   const int slot = wave_reduce28_slot(lane);
-  LdsSink sink{table, invalid, slot};
+  const uint32_t table_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) HbFixed*)table;   // LDS byte address
+  LdsSink sink{table_address + (uint32_t)(slot > 0 ? slot : 0) * (uint32_t)(kHbLimbs * sizeof(HbFixed)), invalid, slot >= 0 && slot < 27, 0.f, -1};
   for (;;) {
     unsigned long long taken = 0;
     if (lane == 0) taken = atomicAdd(&batch_state, 1ull);
@@ -401,7 +426,13 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
     HbFixed* fixed = Hb + (size_t)w * kHbStride;
     float hb[27];
     // the fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
-    for (int c = 0; c < 27; ++c) hb[c] = (float)hb_value(fixed[c * kHbLimbs], fixed[c * kHbLimbs + 1]);
+    bool out_of_range = false;
+    for (int c = 0; c < 27; ++c) {
+      const HbFixed hi = fixed[c * kHbLimbs + 1];
+      out_of_range = out_of_range || hi >= kHbSumLimit || hi <= -kHbSumLimit;
+      hb[c] = (float)hb_value(fixed[c * kHbLimbs], hi);
+    }
+    if (out_of_range) atomicOr(&counters[kPoseCounterInvalid], 1);
     for (int c = 0; c < kHbStride; ++c) fixed[c] = 0;
     float xf[6], next[7];
     pose_gn_step(hb, pw.T, xf, next);
@@ -593,7 +624,7 @@ static void launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEn
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsTableLimit) == hipSuccess;
   }();
   (void)raised;
-  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc>), dim3(compute_units), dim3(64 * kPoseLdsWaves), table_bytes, stream, in, frames,
+  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc>), dim3(compute_units), dim3(64 * kPoseLdsWaves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
                      pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity);
 }
 

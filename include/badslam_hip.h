@@ -331,7 +331,7 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
  * equations of every work item in LDS and flush them once (whenever the table fits 128 KB: up to 292 work items). */
 int bahip_debug_set_pose_form(int form);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):
- * out[3 i .. 3 i + 2] = limb 0 (weight 2^-32), limb 1 (weight 1), valid (0: not finite or 2^40 and beyond -- such a total is
+ * out[3 i .. 3 i + 2] = limb 0 (weight 2^-32), limb 1 (weight 1), valid (0: not finite or 2^52 and beyond -- such a total is
  * not added and fails the pose estimation). */
 int bahip_debug_pose_limbs(bahip_context* ctx, const float* values, size_t count, long long* out);
 /* The residual Jacobian functions of the kernels (ba_device.h: jac_*) on explicit inputs, for the golden vectors of

@@ -204,7 +204,7 @@ uint32_t orc_accumulate_pose_coeffs_fixed(int use_depth, int use_desc, const orc
                                           const orc_camera* depth_cam, const orc_depth_params* dp,
                                           const orc_keyframe* kf, const float frame_T_global[12],
                                           const orc_surfels* s, long long fixed_out[54] /* [27][2] limb pairs */);
-/* value of a limb pair; and whether a tile total could not be added since the last reset (not finite, or 2^40 and beyond) */
+/* value of a limb pair; and whether a tile total could not be added since the last reset (not finite, or 2^52 and beyond) */
 double orc_pose_limbs_value(long long lo, long long hi);
 int orc_pose_limbs(float v, long long out[2]);
 int orc_pose_sum_invalid(int reset);

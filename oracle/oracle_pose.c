@@ -15,7 +15,8 @@
  *   3. each of the 27 tile totals is converted to a multiple of 2^-32 (round to nearest even; exact for |total| >= 2^-9) and
  *      added as two 64-bit integer limbs -- the low 32 bits of that integer (weight 2^-32) and the rest (weight 1) --
  *      associative, hence order-free (hb_split below; round 2 used a single limb of weight 2^-16).  A total that is not
- *      finite or not below 2^40 in magnitude is not added and raises orc_pose_sum_invalid();
+ *      finite or not below 2^52 in magnitude is not added and raises orc_pose_sum_invalid(), and so does a sum whose
+ *      limb 1 ends at 2^62 or beyond;
  *   4. H, b = the carry-normalised limb pairs as binary64 (hb_value), rounded to binary32.
  * accumulate_double != 0 is the plain binary64 running sum in surfel order (an independent check of 1.-4.). */
 static inline void acc_residual(float* acc, float raw, float w, const float* J) {
@@ -55,7 +56,7 @@ static int hb_split(float v, long long* lo_out, long long* hi_out) {
   long long lo = 0, hi = 0;
   if (e) m |= 0x800000u; else e = 1u;
   const int s = (int)e - 118;           /* |v| = m * 2^s in units of 2^-32 */
-  if (s > 48) return 0;                 /* 2^40 and beyond, infinite, NaN */
+  if (s > 60) return 0;                 /* 2^52 and beyond, infinite, NaN */
   if (s >= 32) hi = (long long)((unsigned long long)m << (s - 32));
   else if (s >= 0) { const unsigned long long w = (unsigned long long)m << s; lo = (long long)(w & 0xffffffffull); hi = (long long)(w >> 32); }
   else if (s >= -25) {
@@ -138,6 +139,8 @@ static uint32_t accumulate_pose_coeffs_impl(int use_depth, int use_desc, const o
         else g_pose_sum_invalid = 1;
       }
   }
+  if (!accumulate_double)
+    for (int k = 0; k < 27; ++k) if (fixed[k][1] >= (1ll << 62) || fixed[k][1] <= -(1ll << 62)) g_pose_sum_invalid = 1;
   for (int k = 0; k < 21; ++k) H[k] = accumulate_double ? (float)Hd[k] : (float)hb_value(fixed[k][0], fixed[k][1]);
   for (int k = 0; k < 6; ++k) b[k] = accumulate_double ? (float)bd[k] : (float)hb_value(fixed[21 + k][0], fixed[21 + k][1]);
   if (residual_sum) *residual_sum = (float)cost;

@@ -98,11 +98,11 @@ def test_pose_coefficients(synced, use_depth, use_desc, pose_parts, request):
 
 @pytest.mark.parametrize("form", [1, 2])
 def test_pose_sums_refuse_what_they_cannot_represent(scene, form, request):
-    """The fixed-point pose sums (ba_device.h: hb_split) take tile totals that are finite and below 2^40.  Anything else -- a
+    """The fixed-point pose sums (ba_device.h: hb_split) take tile totals that are finite and below 2^52.  Anything else -- a
     NaN descriptor in a visible tile -- is not added silently: the call fails with an error on the GPU and the oracle raises
     its flag for the same input (VERDICT r2 weak 3 / ADVICE: a cast of NaN or of an out-of-range value to int64 is undefined
     behaviour and went unnoticed).  The range limit itself is exercised value by value in test_pose_limbs_of_single_values (the
-    robust weights keep w r J and w J J of a real pair far below 2^40, so no scene drives a total there)."""
+    robust weights keep w r J and w J J of a real pair far below 2^52, so no scene drives a total there)."""
     from badslam_amd import capi as _capi
     ba = common.build_oracle(scene, 400000)
     g = common.build_gpu(scene, 400000, create_from=[])
@@ -142,15 +142,15 @@ def test_pose_sums_refuse_what_they_cannot_represent(scene, form, request):
 
 def test_pose_limbs_of_single_values(scene):
     """hb_split on the device == the oracle's, value by value: exact above the quantum, round-to-nearest-even below it, sign
-    symmetric, invalid from 2^40 on and for NaN / infinity; and the limb pair's value is the float (or its rounding to 2^-32)."""
+    symmetric, invalid from 2^52 on and for NaN / infinity; and the limb pair's value is the float (or its rounding to 2^-32)."""
     import ctypes as C
     from oracle import binding as ob
     g = common.build_gpu(scene, 1000, create_from=[])
     rng = np.random.Generator(np.random.PCG64(12))
     special = np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -32, 2.0 ** -33, 3 * 2.0 ** -33, -3 * 2.0 ** -33, 5 * 2.0 ** -34, 2.0 ** -57, 2.0 ** -58, 1e-45,
-                        2.0 ** 40, -(2.0 ** 40), np.nextafter(np.float32(2.0 ** 40), np.float32(0)), 1e12, 1.2e12, 3e38, np.inf, -np.inf, np.nan,
+                        2.0 ** 52, -(2.0 ** 52), np.nextafter(np.float32(2.0 ** 52), np.float32(0)), 1e12, 1.2e12, 4e15, 5e15, 3e38, np.inf, -np.inf, np.nan,
                         123456.789, -0.001953125, 0.0019531249], np.float32)
-    values = np.concatenate([special, (rng.standard_normal(20000) * np.exp2(rng.integers(-50, 45, 20000))).astype(np.float32),
+    values = np.concatenate([special, (rng.standard_normal(20000) * np.exp2(rng.integers(-50, 56, 20000))).astype(np.float32),
                              np.frombuffer(rng.integers(0, 1 << 32, 20000, dtype=np.uint32).tobytes(), np.float32)])
     out = np.zeros((values.size, 3), np.int64)
     capi.check(g.ctx.lib.bahip_debug_pose_limbs(g.ctx.handle, values.ctypes.data_as(C.POINTER(C.c_float)), values.size,
@@ -164,7 +164,7 @@ def test_pose_limbs_of_single_values(scene):
     assert np.array_equal(out, ref)
     valid = out[:, 2] == 1
     finite = np.isfinite(values)
-    assert np.array_equal(valid, finite & (np.abs(np.where(finite, values, 0)) < 2.0 ** 40))
+    assert np.array_equal(valid, finite & (np.abs(np.where(finite, values, 0)) < 2.0 ** 52))
     exact = valid & (np.abs(values) >= 2.0 ** -9)
     got = out[:, 1].astype(np.float64) + out[:, 0].astype(np.float64) * 2.0 ** -32
     assert np.array_equal(got[exact], values[exact].astype(np.float64))
