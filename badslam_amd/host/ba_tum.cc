@@ -47,8 +47,33 @@ static int CheckDataset(const char* dataset, const char* trajectory) {
   return 0;
 }
 
+// ba_tum --decode-png <file.png> <rgb|depth> <out.raw>: decodes one PNG the way the dataset reader does (8-bit colour / grey as
+// RGB triples, 8- or 16-bit grey as 16-bit depth) and writes "width height\n" + the samples (u8 x 3 or native-endian u16).
+// Exit code 3 = the decoder refused the file (unsupported format or malformed), 0 = decoded.
+static int DecodePng(const char* path, const char* kind, const char* out_path) {
+  FILE* out = nullptr;
+  if (!strcmp(kind, "rgb")) {
+    Image<Vec3u8> image;
+    if (!ReadPNG(path, &image)) return 3;
+    if (!(out = fopen(out_path, "wb"))) return 1;
+    fprintf(out, "%d %d\n", image.width(), image.height());
+    fwrite(image.data(), 3, (size_t)image.width() * image.height(), out);
+  } else if (!strcmp(kind, "depth")) {
+    Image<u16> image;
+    if (!ReadPNG(path, &image)) return 3;
+    if (!(out = fopen(out_path, "wb"))) return 1;
+    fprintf(out, "%d %d\n", image.width(), image.height());
+    fwrite(image.data(), 2, (size_t)image.width() * image.height(), out);
+  } else {
+    return 2;
+  }
+  fclose(out);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 3 && !strcmp(argv[1], "--check-dataset")) return CheckDataset(argv[2], argc > 3 ? argv[3] : nullptr);
+  if (argc == 5 && !strcmp(argv[1], "--decode-png")) return DecodePng(argv[2], argv[3], argv[4]);
   if (argc < 4) {
     fprintf(stderr, "usage: ba_tum <dataset_dir> <trajectory_file> <out_prefix> [--interval N] [--iterations N] [--cell N] [--max_depth M]"
                     " [--raw_to_float_depth S] [--pcg] [--intrinsics]\n");
