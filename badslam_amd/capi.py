@@ -51,6 +51,13 @@ class Surfels(C.Structure):
                 ("surfels_size", C.c_uint32), ("capacity", C.c_uint32)]
 
 
+class PCGLayout(C.Structure):
+    _fields_ = [("optimize_poses", C.c_int), ("optimize_geometry", C.c_int), ("optimize_depth_intrinsics", C.c_int),
+                ("optimize_color_intrinsics", C.c_int), ("use_depth_residuals", C.c_int), ("use_descriptor_residuals", C.c_int),
+                ("unknown_count", C.c_uint32), ("surfel_unknown_start_index", C.c_uint32),
+                ("depth_intrinsics_unknown_start_index", C.c_uint32), ("color_intrinsics_unknown_start_index", C.c_uint32)]
+
+
 class PCGOptions(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("optimize_poses", "optimize_geometry", "optimize_depth_intrinsics",
                                        "optimize_color_intrinsics", "use_depth_residuals", "use_descriptor_residuals",
@@ -127,6 +134,18 @@ SIGNATURES = {
                                             C.POINTER(Camera), C.POINTER(C.c_float)]),
     "bahip_pcg_iteration": (C.c_int, [C.c_void_p, C.POINTER(PCGOptions), C.POINTER(Surfels), C.POINTER(Camera),
                                       C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bahip_pcg_begin": (C.c_int, [C.c_void_p, C.POINTER(PCGLayout), C.c_uint32]),
+    "bahip_pcg_init": (C.c_int, [C.c_void_p, C.POINTER(PCGLayout), C.POINTER(Frame), C.POINTER(C.c_float), C.c_uint32, C.c_int,
+                                 C.POINTER(Surfels), C.c_void_p, C.c_void_p]),
+    "bahip_pcg_init2": (C.c_int, [C.c_void_p, C.POINTER(PCGLayout), C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "bahip_pcg_step1": (C.c_int, [C.c_void_p, C.POINTER(PCGLayout), C.POINTER(Frame), C.POINTER(C.c_float), C.c_uint32, C.c_int,
+                                  C.POINTER(Surfels), C.c_void_p, C.c_void_p]),
+    "bahip_pcg_step2": (C.c_int, [C.c_void_p, C.POINTER(PCGLayout), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bahip_pcg_step3": (C.c_int, [C.c_void_p, C.POINTER(PCGLayout), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bahip_update_surfels_from_pcg_delta": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.c_int, C.c_uint32, C.c_void_p]),
+    "bahip_update_cfactors_from_pcg_delta": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "bahip_debug_evaluate_pairs": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.POINTER(C.c_float), C.POINTER(Surfels),
                                              C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_float)]),
     "bahip_debug_read_pcg_vector": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),

@@ -119,6 +119,9 @@ struct bahip_context {
   size_t pcg_capacity = 0;
   void* pcg_exact = nullptr;       // exact accumulators of the PCG solve (ExactCell[pcg_exact_capacity]; kernels_pcg.hip)
   size_t pcg_exact_capacity = 0;
+  void* pcg_stage_ctl = nullptr;   // stage API (bahip_pcg_begin ...): a control block that never stops, the head size the
+  uint32_t pcg_stage_head = 0;     // accumulators were set up for, and the bahip_pcg_step1 calls since the last step 2
+  int pcg_stage_step1_calls = 0;
   int world = 0;                   // ranks of the RCCL communicator (0 = none)
   long long exchange_calls = 0;    // sums over the ranks requested since the last reset (bahip_exchange_stats), and their bytes
   long long exchange_bytes = 0;
@@ -506,7 +509,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
-  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact);
+  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
@@ -1196,7 +1199,7 @@ static int ensure_pcg_exact(bahip_context* ctx, uint32_t head_count) {
   if (need <= ctx->pcg_exact_capacity && ctx->pcg_exact) return 0;
   void* grown = nullptr;
   HIP_TRY(hipMalloc(&grown, sizeof(ExactCell) * (need + need / 8)));
-  hipFree(ctx->pcg_exact);
+  hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl);
   ctx->pcg_exact = grown;
   ctx->pcg_exact_capacity = need + need / 8;
   return 0;
@@ -1206,6 +1209,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
                         int* num_converged_out) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   const bool sharded = is_sharded(ctx);   // (exact sums need no rank count: every rank adds its terms, the limbs are summed)
+  ctx->pcg_stage_head = 0xffffffffu;      // the accumulators are re-used: a stage-by-stage caller has to call bahip_pcg_begin again
   const int K = ctx->num_kfs;
   REQUIRE(K >= 1, "PCG needs at least one keyframe");
   const uint32_t N = surfels->surfels_size;
@@ -1357,6 +1361,140 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
     out_color_camera->cy = (float)(ctx->color_cam.cy + b[3]);
   }
   HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---- the PCG scheme stage by stage (B/kernels.h:397-491) ----------------------------------------------------------------------
+namespace {
+constexpr uint32_t kNoUnknown = 0xffffffffu;
+PcgLayout stage_layout(const bahip_pcg_layout* in, uint32_t surfels_size) {
+  PcgLayout L{};
+  L.use_depth = in->use_depth_residuals; L.use_desc = in->use_descriptor_residuals;
+  L.optimize_poses = in->optimize_poses; L.optimize_geometry = in->optimize_geometry;
+  L.optimize_depth_intrinsics = in->optimize_depth_intrinsics; L.optimize_color_intrinsics = in->optimize_color_intrinsics;
+  L.geom_stride = L.use_desc ? 3 : 1;
+  L.gauge = -1;
+  L.surfel_start = L.optimize_geometry ? in->surfel_unknown_start_index : kNoUnknown;
+  L.depth_intr_start = L.optimize_depth_intrinsics ? in->depth_intrinsics_unknown_start_index : kNoUnknown;
+  L.a_index = L.optimize_depth_intrinsics ? in->depth_intrinsics_unknown_start_index + 4 : kNoUnknown;
+  L.color_intr_start = L.optimize_color_intrinsics ? in->color_intrinsics_unknown_start_index : kNoUnknown;
+  L.unknown_count = in->unknown_count;
+  L.head_lo = L.optimize_geometry ? L.surfel_start : L.unknown_count;
+  L.head_hi = L.optimize_geometry ? L.surfel_start + (uint32_t)L.geom_stride * surfels_size : L.unknown_count;
+  L.single_keyframe = -1; L.single_pose_index = kNoUnknown; L.accumulate = 0;
+  return L;
+}
+uint32_t head_count_of(const PcgLayout& L) { return L.head_lo + (L.unknown_count - L.head_hi); }
+// One keyframe as a one-entry table on the device (the slot the single-frame pose entry points use).
+int stage_keyframe(bahip_context* ctx, const bahip_frame* frame, const float frame_T_global[12]) {
+  KfEntry e;
+  if (make_entry(ctx, *frame, 0, &e)) return 1;
+  memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(ctx->dev_frame1, &e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));   // e lives on this stack frame
+  return 0;
+}
+int stage_ready(bahip_context* ctx, const PcgLayout& L) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(ctx->pcg_exact != nullptr && ctx->pcg_stage_head == head_count_of(L), "bahip_pcg_begin was not called for this layout");
+  return 0;
+}
+}  // namespace
+
+int bahip_pcg_begin(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size) {
+  const PcgLayout L = stage_layout(layout, surfels_size);
+  const uint32_t head = head_count_of(L);
+  if (ensure_pcg_exact(ctx, head)) return 1;
+  // the control block the stage kernels look at: never stopped (the caller owns the inner loop)
+  HIP_TRY(hipMemsetAsync(ctx->pcg_exact, 0, sizeof(ExactCell) * pcg_exact_cells(head), ctx->stream));
+  if (!ctx->pcg_stage_ctl) HIP_TRY(hipMalloc(&ctx->pcg_stage_ctl, 64));
+  HIP_TRY(hipMemsetAsync(ctx->pcg_stage_ctl, 0, 64, ctx->stream));
+  ctx->pcg_stage_head = head;
+  ctx->pcg_stage_step1_calls = 0;
+  return 0;
+}
+
+int bahip_pcg_init(bahip_context* ctx, const bahip_pcg_layout* layout, const bahip_frame* frame, const float frame_T_global[12],
+                   uint32_t kf_pose_unknown_index, int optimize_pose_of_keyframe, const bahip_surfels* surfels, float* pcg_r, float* pcg_M) {
+  PcgLayout L = stage_layout(layout, surfels->surfels_size);
+  if (stage_ready(ctx, L) || stage_keyframe(ctx, frame, frame_T_global)) return 1;
+  L.single_keyframe = 0; L.single_pose_index = kf_pose_unknown_index; L.accumulate = 1;
+  L.optimize_poses = L.optimize_poses && optimize_pose_of_keyframe;
+  launch_pcg_init(ctx->stream, L, pcg_exact_view(ctx->pcg_exact, ctx->pcg_stage_head), ctx->in, ctx->dev_frame1, 1, make_view(surfels), pcg_r, pcg_M);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_pcg_init2(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size, float a, float* pcg_r, float* pcg_M,
+                    float* pcg_delta, float* pcg_g, float* pcg_p, float* pcg_alpha_n) {
+  const PcgLayout L = stage_layout(layout, surfels_size);
+  if (stage_ready(ctx, L)) return 1;
+  const PcgExact ex = pcg_exact_view(ctx->pcg_exact, ctx->pcg_stage_head);
+  launch_pcg_resolve_init(ctx->stream, L, ex, pcg_r, pcg_M);
+  launch_pcg_init2(ctx->stream, L, ex, a, pcg_r, pcg_M, pcg_delta, pcg_g, pcg_p);
+  launch_pcg_control_init(ctx->stream, ex, ctx->pcg_stage_ctl, pcg_alpha_n);
+  CHECK_LAUNCH();
+  ctx->pcg_stage_step1_calls = 0;
+  return 0;
+}
+
+int bahip_pcg_step1(bahip_context* ctx, const bahip_pcg_layout* layout, const bahip_frame* frame, const float frame_T_global[12],
+                    uint32_t kf_pose_unknown_index, int optimize_pose_of_keyframe, const bahip_surfels* surfels, const float* pcg_p,
+                    float* pcg_g) {
+  PcgLayout L = stage_layout(layout, surfels->surfels_size);
+  if (stage_ready(ctx, L) || stage_keyframe(ctx, frame, frame_T_global)) return 1;
+  L.single_keyframe = 0; L.single_pose_index = kf_pose_unknown_index; L.accumulate = 1;
+  L.optimize_poses = L.optimize_poses && optimize_pose_of_keyframe;
+  launch_pcg_step1(ctx->stream, L, pcg_exact_view(ctx->pcg_exact, ctx->pcg_stage_head), ctx->in, ctx->dev_frame1, 1, make_view(surfels), pcg_p, pcg_g,
+                   ctx->pcg_stage_ctl);
+  CHECK_LAUNCH();
+  if (surfels->surfels_size > 0) ctx->pcg_stage_step1_calls += 1;   // AddAlphaDEpsilonTerms runs in every PCGStep1CUDA call with surfels
+  return 0;
+}
+
+int bahip_pcg_step2(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size, float* pcg_r, const float* pcg_M,
+                    float* pcg_delta, float* pcg_g, const float* pcg_p, const float* pcg_alpha_n, float* pcg_alpha_d, float* pcg_beta_n) {
+  const PcgLayout L = stage_layout(layout, surfels_size);
+  if (stage_ready(ctx, L)) return 1;
+  const PcgExact ex = pcg_exact_view(ctx->pcg_exact, ctx->pcg_stage_head);
+  // the epsilon terms of alpha_d from the p this step works with (bahip_pcg_iteration folds them into the kernels that
+  // produce p; here p is the caller's): whatever an earlier stage left in those two slots is dropped first
+  HIP_TRY(hipMemsetAsync(ex.hot + (size_t)kHotEpsLocal * kHotReplicas, 0, sizeof(ExactCell) * kHotReplicas, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ex.hot_tail + (size_t)(kHotEpsHead - kHotExchanged1) * kHotReplicas, 0, sizeof(ExactCell) * kHotReplicas, ctx->stream));
+  launch_pcg_eps_terms(ctx->stream, L, ex, pcg_p);
+  launch_pcg_resolve_step1(ctx->stream, L, ex, pcg_g, pcg_alpha_d, (double)ctx->pcg_stage_step1_calls, ctx->pcg_stage_ctl);
+  launch_pcg_step2(ctx->stream, L, ex, pcg_r, pcg_M, pcg_delta, pcg_g, pcg_p, pcg_alpha_n, pcg_alpha_d, ctx->pcg_stage_ctl);
+  launch_pcg_control(ctx->stream, ex, ctx->pcg_stage_ctl, pcg_beta_n);
+  // the stage API never stops on its own: clear what the control kernel decided
+  HIP_TRY(hipMemsetAsync(ctx->pcg_stage_ctl, 0, 64, ctx->stream));
+  CHECK_LAUNCH();
+  ctx->pcg_stage_step1_calls = 0;
+  return 0;
+}
+
+int bahip_pcg_step3(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size, const float* pcg_g, float* pcg_p,
+                    const float* pcg_alpha_n, const float* pcg_beta_n) {
+  const PcgLayout L = stage_layout(layout, surfels_size);
+  if (stage_ready(ctx, L)) return 1;
+  launch_pcg_step3(ctx->stream, L, pcg_exact_view(ctx->pcg_exact, ctx->pcg_stage_head), pcg_g, pcg_p, pcg_alpha_n, pcg_beta_n, ctx->pcg_stage_ctl);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_update_surfels_from_pcg_delta(bahip_context* ctx, const bahip_surfels* surfels, int use_descriptor_residuals,
+                                        uint32_t surfel_unknown_start_index, const float* pcg_delta) {
+  PcgLayout L{};
+  L.surfel_start = surfel_unknown_start_index;
+  L.geom_stride = use_descriptor_residuals ? 3 : 1;
+  launch_pcg_update_surfels(ctx->stream, L, make_view(surfels), pcg_delta);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bahip_update_cfactors_from_pcg_delta(bahip_context* ctx, uint32_t cfactor_unknown_start_index, const float* pcg_delta) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  launch_pcg_update_cfactors(ctx->stream, ctx->in, cfactor_unknown_start_index, pcg_delta, ctx->dp.cfactor, ctx->dp.cfactor_pitch_bytes);
+  CHECK_LAUNCH();
   return 0;
 }
 

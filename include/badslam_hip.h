@@ -299,6 +299,54 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
                         int* inner_steps_out, int* num_converged_out /* keyframes whose pose update is below the
                         convergence threshold, gauge keyframe included (B/direct_ba_pcg.cc:556-575) */);
 
+/* ---- PCG solver, stage by stage (B/kernels.h:397-491): the entry points a caller that keeps the reference's own PCG driver
+ * (B/direct_ba_pcg.cc:229-646) binds -- one bahip_ function per *CUDA function, same call sequence:
+ *     r = M = 0; bahip_pcg_begin; for each keyframe bahip_pcg_init; bahip_pcg_init2;
+ *     per inner step: g = 0 (from the second step on); for each keyframe bahip_pcg_step1; bahip_pcg_step2; read beta_n;
+ *     bahip_pcg_step3; ... ; bahip_update_surfels_from_pcg_delta; bahip_update_cfactors_from_pcg_delta.
+ * All vectors (unknown_count floats) and the three scalars are DEVICE pointers owned by the caller (the reference's
+ * CUDABuffer_<PCGScalar>).  What the reference adds to the vectors with float atomics -- the entries of the poses, of the
+ * intrinsics and of the cfactor cells, and the three dot products -- is summed exactly in accumulators inside the context
+ * (badslam_amd/csrc/exact_sum.h) and written by the next stage that reads it: bahip_pcg_init2 writes those entries of r and
+ * M, bahip_pcg_step2 those of g and *alpha_d (so r, M, g hold only their per-surfel entries between the keyframe loop and the
+ * stage that follows it).  The per-surfel entries are read-modify-written per keyframe call exactly like the reference's.
+ * Same bits as bahip_pcg_iteration, which runs the keyframe loops as single sweeps. */
+typedef struct bahip_pcg_layout {   /* unknown layout (B/direct_ba_pcg.cc:232-307) */
+  int optimize_poses, optimize_geometry, optimize_depth_intrinsics, optimize_color_intrinsics;
+  int use_depth_residuals, use_descriptor_residuals;
+  uint32_t unknown_count;
+  uint32_t surfel_unknown_start_index;              /* valid if optimize_geometry */
+  uint32_t depth_intrinsics_unknown_start_index;    /* valid if optimize_depth_intrinsics; a_unknown_index = this + 4 */
+  uint32_t color_intrinsics_unknown_start_index;    /* valid if optimize_color_intrinsics */
+} bahip_pcg_layout;
+/* Sizes and clears the context's accumulators for a system with this layout over surfels_size surfels; before the first
+ * bahip_pcg_init of an outer iteration. */
+int bahip_pcg_begin(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size);
+/* PCGInitCUDA (B/kernels.h:397-416) for one keyframe: r -= J^T W F, M += diag(J^T W J).  kf_pose_unknown_index: first of the
+ * keyframe's 6 pose unknowns; optimize_pose_of_keyframe = 0 for the gauge keyframe. */
+int bahip_pcg_init(bahip_context* ctx, const bahip_pcg_layout* layout, const bahip_frame* frame, const float frame_T_global[12],
+                   uint32_t kf_pose_unknown_index, int optimize_pose_of_keyframe, const bahip_surfels* surfels, float* pcg_r, float* pcg_M);
+/* PCGInit2CUDA (B/kernels.h:418-428) */
+int bahip_pcg_init2(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size, float a, float* pcg_r, float* pcg_M,
+                    float* pcg_delta, float* pcg_g, float* pcg_p, float* pcg_alpha_n);
+/* PCGStep1CUDA (B/kernels.h:430-453) for one keyframe: g += J^T W J p; the keyframe's share of alpha_d is kept in the context
+ * until bahip_pcg_step2 (pcg_alpha_d is not touched here). */
+int bahip_pcg_step1(bahip_context* ctx, const bahip_pcg_layout* layout, const bahip_frame* frame, const float frame_T_global[12],
+                    uint32_t kf_pose_unknown_index, int optimize_pose_of_keyframe, const bahip_surfels* surfels, const float* pcg_p,
+                    float* pcg_g);
+/* PCGStep2CUDA (B/kernels.h:455-466); writes *pcg_alpha_d (the sum over the bahip_pcg_step1 calls since the last step 2,
+ * epsilon terms included once per call like the reference's AddAlphaDEpsilonTerms) and *pcg_beta_n. */
+int bahip_pcg_step2(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size, float* pcg_r, const float* pcg_M,
+                    float* pcg_delta, float* pcg_g, const float* pcg_p, const float* pcg_alpha_n, float* pcg_alpha_d, float* pcg_beta_n);
+/* PCGStep3CUDA (B/kernels.h:468-474) */
+int bahip_pcg_step3(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size, const float* pcg_g, float* pcg_p,
+                    const float* pcg_alpha_n, const float* pcg_beta_n);
+/* UpdateSurfelsFromPCGDeltaCUDA (B/kernels.h:484-490), UpdateCFactorsFromPCGDeltaCUDA (B/kernels.h:492-496; the cfactor image is
+ * the one of bahip_set_intrinsics) */
+int bahip_update_surfels_from_pcg_delta(bahip_context* ctx, const bahip_surfels* surfels, int use_descriptor_residuals,
+                                        uint32_t surfel_unknown_start_index, const float* pcg_delta);
+int bahip_update_cfactors_from_pcg_delta(bahip_context* ctx, uint32_t cfactor_unknown_start_index, const float* pcg_delta);
+
 /* ---- test hook --------------------------------------------------------------------------------------
  * Per-pair evaluation with the production device functions (association, the three raw residuals,
  * weights, pose Jacobians, image gradients) for `count` surfel indices against one frame; 40 floats
