@@ -13,10 +13,11 @@
 // DEFINITION of the dense sums (round 3; restated by oracle_pcg.c).  Everything the reference merges with binary32
 // atomics in arbitrary order (B/kernel_pcg.cu:98-154) is an EXACT sum here (exact_sum.h: 9 x int64 limbs, integer atomics),
 // rounded once to binary64 and then to the PCGScalar:
-//   - the 6 pose entries of a keyframe: per (64-surfel tile, keyframe) the halving tree of wave_reduce.h, tile totals exact;
-//   - the 5 + 4 global intrinsics entries and the pair part of alpha_d: per-surfel binary32 chains over the keyframes, the xor
-//     butterfly over the tile, tile totals exact (into one of 64 replicas, folded when resolved -- exactness makes the
-//     replication free, and 47 k tiles would otherwise serialise on one address);
+//   - the 6 pose entries of a keyframe, the 5 + 4 global intrinsics entries and the pair part of alpha_d: per (64-surfel tile,
+//     keyframe) the halving tree of wave_reduce.h over that keyframe's per-surfel terms, the (tile, keyframe) totals exact --
+//     the intrinsics entries and alpha_d into one of 64 replicas, folded when resolved (exactness makes the replication free,
+//     and 47 k tiles would otherwise serialise on one address).  Nothing is carried from one keyframe to the next, so one
+//     sweep over all keyframes and one call per keyframe (the stage entry points of the C ABI) give the same sums;
 //   - per-cell cfactor entries: per-pair terms, exact;
 //   - dot products over the unknowns (alpha_n, beta_n, the epsilon terms of alpha_d): the binary32 products, exact.
 // So the conjugate gradient is deterministic, bit-identical to the oracle (inner step count included), independent of the
@@ -192,23 +193,33 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
     gr[0] = r_[gi]; gM[0] = M_[gi];
     if (L.geom_stride == 3) { gr[1] = r_[gi + 1]; gM[1] = M_[gi + 1]; gr[2] = r_[gi + 2]; gM[2] = M_[gi + 2]; }
   }
-  float ir[9], iM[9];                             // 5 depth + 4 colour global intrinsics entries
-#pragma unroll
-  for (int q = 0; q < 9; ++q) { ir[q] = 0.f; iM[q] = 0.f; }
-
+  constexpr bool kIntr = kDepthIntr || kColorIntr;
   // The exact atomics of a candidate keyframe are issued one candidate late, behind the next candidate's gathers
-  // (exact_sum.h: exact_atomic_add_part_untracked): the tile totals of the pose entries wait in `pending`, the per-cell
-  // cfactor terms of a lane in pending_cf*.
-  float pending = 0.f;
-  uint32_t pending_base = 0xffffffffu;    // wave-uniform
-  uint32_t pending_cf = 0xffffffffu;      // per lane: head index of the cell
+  // (exact_sum.h: exact_atomic_add_part_untracked): the (tile, keyframe) totals wait in pending_a / pending_b -- lanes
+  // 4 j .. 4 j + 3 hold total j of a 16-value halving butterfly: pending_a = 6 pose entries of r, 6 of M, the first 4 global
+  // intrinsics entries of r; pending_b (intrinsics only) = the other 5 of r and the 9 of M -- and the per-cell cfactor terms
+  // of a lane in pending_cf*.
+  float pending_a = 0.f, pending_b = 0.f;
+  bool pending_any = false, pending_pose = false;   // wave-uniform
+  uint32_t pending_base = 0;                          // wave-uniform
+  uint32_t pending_cf = 0xffffffffu;                  // per lane: head index of the cell
   float pending_cf_r = 0.f, pending_cf_M = 0.f;
+  auto intr_enabled = [&](int q) { return q < 5 ? kDepthIntr : kColorIntr; };
   auto flush_pending = [&]() {
-    if (pending_base != 0xffffffffu) {
-      const int slot = lane >> 2, part = lane & 3;   // lanes 4 j .. 4 j + 3 hold tile total j: two of them add its two parts
-      if (slot < 12 && part < 2)
-        exact_atomic_add_part_untracked(slot < 6 ? &ex.head_a[pending_base + slot] : &ex.head_b[pending_base + slot - 6], pending, part, ex.invalid);
-      pending_base = 0xffffffffu;
+    if (pending_any) {
+      const int j = lane >> 2, part = lane & 3;   // two of the four lanes that hold total j add its two parts
+      if (part < 2) {
+        if (j < 12) {
+          if (pending_pose) exact_atomic_add_part_untracked(j < 6 ? &ex.head_a[pending_base + j] : &ex.head_b[pending_base + j - 6], pending_a, part, ex.invalid);
+        } else if (kIntr && intr_enabled(j - 12)) {
+          exact_atomic_add_part_untracked(hot_cell(ex, kHotA + (j - 12), replica), pending_a, part, ex.invalid);
+        }
+        if (kIntr) {
+          if (j < 5) { if (intr_enabled(4 + j)) exact_atomic_add_part_untracked(hot_cell(ex, kHotA + 4 + j, replica), pending_b, part, ex.invalid); }
+          else if (j < 14 && intr_enabled(j - 5)) exact_atomic_add_part_untracked(hot_cell(ex, kHotB + (j - 5), replica), pending_b, part, ex.invalid);
+        }
+      }
+      pending_any = false;
     }
     if (kDepthIntr) {
       if (pending_cf != 0xffffffffu) {
@@ -231,6 +242,7 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
         if (!__any(visible)) return;
         const bool pose_kf = kf_pose_is_unknown(L, k);
         float pr[6] = {0, 0, 0, 0, 0, 0}, pM[6] = {0, 0, 0, 0, 0, 0};
+        float ir[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, iM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // this keyframe's global intrinsics terms
         if (visible) {
           PairTerms t;
           eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, pg.a, pg.pix, pg.dw, gn, d1, d2, &t);
@@ -282,12 +294,17 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
             }
           }
         }
-        if (pose_kf) {
-          const uint32_t base = kf_pose_index(L, k);   // pose unknowns come first: head index == unknown index
-          // 12 tile totals with one halving butterfly (wave_reduce.h): lanes 4 j .. 4 j + 3 hold total j
-          const float v[16] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pM[0], pM[1], pM[2], pM[3], pM[4], pM[5], 0.f, 0.f, 0.f, 0.f};
-          pending = wave_reduce_small<16>(v, lane);
-          pending_base = base;
+        if (pose_kf || kIntr) {
+          // (tile, keyframe) totals with the halving butterfly of wave_reduce.h: lanes 4 j .. 4 j + 3 hold total j
+          const float va[16] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pM[0], pM[1], pM[2], pM[3], pM[4], pM[5], ir[0], ir[1], ir[2], ir[3]};
+          pending_a = wave_reduce_small<16>(va, lane);
+          if (kIntr) {
+            const float vb[16] = {ir[4], ir[5], ir[6], ir[7], ir[8], iM[0], iM[1], iM[2], iM[3], iM[4], iM[5], iM[6], iM[7], iM[8], 0.f, 0.f};
+            pending_b = wave_reduce_small<16>(vb, lane);
+          }
+          pending_any = true;
+          pending_pose = pose_kf;
+          pending_base = pose_kf ? kf_pose_index(L, k) : 0u;   // pose unknowns come first: head index == unknown index
         }
       });
   flush_pending();
@@ -295,21 +312,6 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
   if (in_range && L.optimize_geometry) {
     r_[gi] = gr[0]; M_[gi] = gM[0];
     if (L.geom_stride == 3) { r_[gi + 1] = gr[1]; M_[gi + 1] = gM[1]; r_[gi + 2] = gr[2]; M_[gi + 2] = gM[2]; }
-  }
-  if (kDepthIntr || kColorIntr) {
-    float mine = 0.f;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const float vr = wave_sum(ir[q]), vm = wave_sum(iM[q]);
-      if (lane == q) mine = vr;
-      if (lane == 9 + q) mine = vm;
-    }
-    if (lane < 18) {
-      const int q = lane % 9;
-      const bool is_depth = q < 5;
-      if ((is_depth && kDepthIntr) || (!is_depth && kColorIntr))
-        exact_atomic_add(hot_cell(ex, (lane < 9 ? kHotA : kHotB) + q, replica), mine, ex.invalid);
-    }
   }
 }
 
@@ -489,21 +491,23 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
     gs[0] = g_[gi];
     if (L.geom_stride == 3) { gs[1] = g_[gi + 1]; gs[2] = g_[gi + 2]; }
   }
-  float gi_acc[9];
-#pragma unroll
-  for (int q = 0; q < 9; ++q) gi_acc[q] = 0.f;
-  float ad = 0.f;
-
-  // exact atomics one candidate late, as in pcg_init_kernel
+  constexpr bool kIntr = kDepthIntr || kColorIntr;
+  // exact atomics one candidate late, as in pcg_init_kernel.  The (tile, keyframe) totals: 6 pose entries of g, the keyframe's
+  // share of alpha_d and (intrinsics) the 9 global intrinsics entries of g -- 8 or 16 values, one halving butterfly.
   float pending = 0.f;
-  uint32_t pending_base = 0xffffffffu;    // wave-uniform
-  uint32_t pending_cf = 0xffffffffu;      // per lane
+  bool pending_any = false, pending_pose = false;   // wave-uniform
+  uint32_t pending_base = 0;                          // wave-uniform
+  uint32_t pending_cf = 0xffffffffu;                  // per lane
   float pending_cf_g = 0.f;
   auto flush_pending = [&]() {
-    if (pending_base != 0xffffffffu) {
-      const int slot = lane >> 3, part = lane & 7;   // lanes 8 j .. 8 j + 7 hold tile total j
-      if (slot < 6 && part < 2) exact_atomic_add_part_untracked(&ex.head_a[pending_base + slot], pending, part, ex.invalid);
-      pending_base = 0xffffffffu;
+    if (pending_any) {
+      const int j = kIntr ? (lane >> 2) : (lane >> 3), part = kIntr ? (lane & 3) : (lane & 7);   // the lanes that hold total j
+      if (part < 2) {
+        if (j < 6) { if (pending_pose) exact_atomic_add_part_untracked(&ex.head_a[pending_base + j], pending, part, ex.invalid); }
+        else if (j == 6) exact_atomic_add_part_untracked(hot_cell(ex, kHotAlphaD, replica), pending, part, ex.invalid);
+        else if (kIntr && j < 16 && ((j - 7) < 5 ? kDepthIntr : kColorIntr)) exact_atomic_add_part_untracked(hot_cell(ex, kHotA + (j - 7), replica), pending, part, ex.invalid);
+      }
+      pending_any = false;
     }
     if (kDepthIntr) {
       if (pending_cf != 0xffffffffu) {
@@ -526,6 +530,8 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
         flush_pending();
         if (!__any(visible)) return;
         float gpose[6] = {0, 0, 0, 0, 0, 0};
+        float gi_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // this keyframe's terms of the global intrinsics entries
+        float ad = 0.f;                                   // ... and of alpha_d
         if (visible) {
           PairTerms t;
           eval_pair_terms<kDepthIntr, kColorIntr>(L, in, kf, pg.a, pg.pix, pg.dw, gn, d1, d2, &t);
@@ -593,11 +599,17 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
             }
           }
         }
-        if (pose_kf) {
-          const float v[8] = {gpose[0], gpose[1], gpose[2], gpose[3], gpose[4], gpose[5], 0.f, 0.f};
-          pending = wave_reduce_small<8>(v, lane);   // lanes 8 j .. 8 j + 7 hold total j
-          pending_base = base;
+        if (kIntr) {
+          const float v[16] = {gpose[0], gpose[1], gpose[2], gpose[3], gpose[4], gpose[5], ad, gi_acc[0], gi_acc[1], gi_acc[2], gi_acc[3], gi_acc[4],
+                               gi_acc[5], gi_acc[6], gi_acc[7], gi_acc[8]};
+          pending = wave_reduce_small<16>(v, lane);   // lanes 4 j .. 4 j + 3 hold total j
+        } else {
+          const float v[8] = {gpose[0], gpose[1], gpose[2], gpose[3], gpose[4], gpose[5], ad, 0.f};
+          pending = wave_reduce_small<8>(v, lane);    // lanes 8 j .. 8 j + 7 hold total j
         }
+        pending_any = true;
+        pending_pose = pose_kf;
+        pending_base = pose_kf ? base : 0u;
       });
   flush_pending();
 
@@ -605,18 +617,6 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
     g_[gi] = gs[0];
     if (L.geom_stride == 3) { g_[gi + 1] = gs[1]; g_[gi + 2] = gs[2]; }
   }
-  float mine = 0.f;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const float v = wave_sum(gi_acc[q]);
-    if (lane == q) mine = v;
-  }
-  const float adv = wave_sum(ad);
-  if (lane == 9) mine = adv;
-  if (lane < 9) {
-    if (lane < 5 ? kDepthIntr : kColorIntr) exact_atomic_add(hot_cell(ex, kHotA + lane, replica), mine, ex.invalid);
-  }
-  if (lane == 9) exact_atomic_add(hot_cell(ex, kHotAlphaD, replica), mine, ex.invalid);
 }
 
 // PCGStep2 (B/kernel_pcg.cu:1117-1158)

@@ -8,10 +8,10 @@
  * gradient is not reproducible run to run (FIX).  Here:
  *   - a surfel's own entries are binary32 chains over the keyframes in ascending order (as in the reference, whose launches
  *     are ordered by keyframe);
- *   - the 6 pose entries of a keyframe: per (64-surfel tile, keyframe) the per-surfel binary32 contributions are added by the
- *     fixed tree of orc_tile_tree_sum, and the tile totals are summed EXACTLY (oracle_exact.c);
- *   - the 5 + 4 global intrinsics entries and alpha_d: per-surfel binary32 chains over the keyframes, the xor butterfly over
- *     the 64 surfels of a tile (orc_wave_xor_sum), tile totals summed exactly;
+ *   - the 6 pose entries of a keyframe, the 5 + 4 global intrinsics entries and the pair part of alpha_d: per (64-surfel tile,
+ *     keyframe) the per-surfel binary32 contributions of that keyframe are added by the fixed tree of orc_tile_tree_sum, and
+ *     these (tile, keyframe) totals are summed EXACTLY (oracle_exact.c) -- so the sums do not depend on whether the
+ *     keyframes are swept in one pass or one call per keyframe (B/direct_ba_pcg.cc does the latter);
  *   - per-cell cfactor entries: the per-pair binary32 terms summed exactly;
  *   - dot products over the unknowns (alpha_n, beta_n, the epsilon terms of alpha_d): the binary32 products summed exactly;
  * every exact sum is rounded once to binary64 and from there to binary32 where it is stored in a PCGScalar.  Exact sums do
@@ -175,14 +175,14 @@ static void pcg_init_sweep(const pcg_sweep* w, pcg_real* r_, pcg_real* M_, pcg_h
 #pragma omp parallel for schedule(dynamic, 8)
   for (long tile_index = 0; tile_index < tiles; ++tile_index) {
     const uint32_t tile = (uint32_t)tile_index * 64u;
-    float gr[3][64], gM[3][64], ir[9][64], iM[9][64];
-    memset(gr, 0, sizeof(gr)); memset(gM, 0, sizeof(gM)); memset(ir, 0, sizeof(ir)); memset(iM, 0, sizeof(iM));
+    float gr[3][64], gM[3][64];
+    memset(gr, 0, sizeof(gr)); memset(gM, 0, sizeof(gM));
     for (int k = 0; k < w->K; ++k) {
       const orc_keyframe* kf = w->kfs[k];
       const int pose_kf = L->optimize_poses && k != w->gauge;
-      float pr[6][64], pM[6][64];
+      float pr[6][64], pM[6][64], ir[9][64], iM[9][64];   /* this keyframe's terms */
       int any = 0;
-      memset(pr, 0, sizeof(pr)); memset(pM, 0, sizeof(pM));
+      memset(pr, 0, sizeof(pr)); memset(pM, 0, sizeof(pM)); memset(ir, 0, sizeof(ir)); memset(iM, 0, sizeof(iM));
       for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
         const uint32_t i = tile + lane;
         proj_result pres;
@@ -239,18 +239,18 @@ static void pcg_init_sweep(const pcg_sweep* w, pcg_real* r_, pcg_real* M_, pcg_h
           orc_exact_add(&H->b[base + c], orc_tile_tree_sum(pM[c]), &H->invalid);
         }
       }
+      if (any && (L->optimize_depth_intrinsics || L->optimize_color_intrinsics))
+        for (int q = 0; q < 9; ++q) {
+          if ((q < 5) ? !L->optimize_depth_intrinsics : !L->optimize_color_intrinsics) continue;
+          orc_exact_add(&H->hot[HOT_A + q], orc_tile_tree_sum(ir[q]), &H->invalid);
+          orc_exact_add(&H->hot[HOT_B + q], orc_tile_tree_sum(iM[q]), &H->invalid);
+        }
     }
     for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
       if (!L->optimize_geometry) break;
       const uint32_t gi = L->surfel_start + (uint32_t)L->geom_stride * (tile + lane);
       for (int c = 0; c < L->geom_stride; ++c) { r_[gi + c] = gr[c][lane]; M_[gi + c] = gM[c][lane]; }
     }
-    if (L->optimize_depth_intrinsics || L->optimize_color_intrinsics)
-      for (int q = 0; q < 9; ++q) {
-        if ((q < 5) ? !L->optimize_depth_intrinsics : !L->optimize_color_intrinsics) continue;
-        orc_exact_add(&H->hot[HOT_A + q], orc_wave_xor_sum(ir[q]), &H->invalid);
-        orc_exact_add(&H->hot[HOT_B + q], orc_wave_xor_sum(iM[q]), &H->invalid);
-      }
   }
   head_resolve(H, L, r_, M_);
 }
@@ -267,9 +267,11 @@ static double pcg_step1_sweep(const pcg_sweep* w, const pcg_real* p_, pcg_real* 
 #pragma omp parallel for schedule(dynamic, 8)
   for (long tile_index = 0; tile_index < tiles; ++tile_index) {
     const uint32_t tile = (uint32_t)tile_index * 64u;
-    float gs[3][64], gia[9][64], ad[64];
-    memset(gs, 0, sizeof(gs)); memset(gia, 0, sizeof(gia)); memset(ad, 0, sizeof(ad));
+    float gs[3][64];
+    memset(gs, 0, sizeof(gs));
     for (int k = 0; k < w->K; ++k) {
+      float gia[9][64], ad[64];   /* this keyframe's terms */
+      memset(gia, 0, sizeof(gia)); memset(ad, 0, sizeof(ad));
       const orc_keyframe* kf = w->kfs[k];
       const int pose_kf = L->optimize_poses && k != w->gauge;
       const uint32_t base = kf_pose_index(w, k);
@@ -332,17 +334,19 @@ static double pcg_step1_sweep(const pcg_sweep* w, const pcg_real* p_, pcg_real* 
       }
       if (pose_kf && any)
         for (int c = 0; c < 6; ++c) orc_exact_add(&H->a[base + c], orc_tile_tree_sum(gpose[c]), &H->invalid);
+      if (any) {
+        for (int q = 0; q < 9; ++q) {
+          if ((q < 5) ? !L->optimize_depth_intrinsics : !L->optimize_color_intrinsics) continue;
+          orc_exact_add(&H->hot[HOT_A + q], orc_tile_tree_sum(gia[q]), &H->invalid);
+        }
+        orc_exact_add(&H->hot[HOT_ALPHA_D], orc_tile_tree_sum(ad), &H->invalid);
+      }
     }
     for (uint32_t lane = 0; lane < 64 && tile + lane < s->surfels_size; ++lane) {
       if (!L->optimize_geometry) break;
       const uint32_t gi = L->surfel_start + (uint32_t)L->geom_stride * (tile + lane);
       for (int c = 0; c < L->geom_stride; ++c) g_[gi + c] = gs[c][lane];
     }
-    for (int q = 0; q < 9; ++q) {
-      if ((q < 5) ? !L->optimize_depth_intrinsics : !L->optimize_color_intrinsics) continue;
-      orc_exact_add(&H->hot[HOT_A + q], orc_wave_xor_sum(gia[q]), &H->invalid);
-    }
-    orc_exact_add(&H->hot[HOT_ALPHA_D], orc_wave_xor_sum(ad), &H->invalid);
   }
   const double pairs = H->invalid ? (double)NAN : orc_exact_value(&H->hot[HOT_ALPHA_D]);
   memset(&H->hot[HOT_ALPHA_D], 0, sizeof(orc_exact));
