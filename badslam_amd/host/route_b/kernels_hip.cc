@@ -221,4 +221,131 @@ void AssignColorsCUDA(cudaStream_t stream, const PinholeCamera4f& color_camera, 
   BAHIP_CHECKED_CALL(bahip_assign_colors(ctx, &s));
 }
 
+// ---- the PCG scheme (B/kernels.h:397-491) on the stage entry points of the C ABI ------------------------------------------------
+// The reference's driver (B/direct_ba_pcg.cc:229-646) calls PCGInitCUDA / PCGStep1CUDA once per keyframe with the keyframe's
+// buffers packed in SurfelProjectionParameters; the backend keeps the dense sums of those calls in exact accumulators inside
+// its context and writes them when PCGInit2CUDA / PCGStep2CUDA run (include/badslam_hip.h, "PCG solver, stage by stage").  The
+// unknown layout is not an argument of every reference function: the shim remembers the one the last PCGInitCUDA /
+// PCGStep1CUDA call described (the driver uses one layout per outer iteration).
+namespace {
+struct PcgSession {
+  bahip_pcg_layout layout{};
+  u32 surfels_size = 0;
+  bool begun = false;      // bahip_pcg_begin ran for this outer iteration (reset by PCGInit2CUDA)
+};
+PcgSession& Session() { static thread_local PcgSession s; return s; }
+
+void BindFromProjection(bahip_context* ctx, const SurfelProjectionParameters& s, const DepthToColorPixelCorner& depth_to_color,
+                        const PixelCornerProjector& color_projector) {
+  bahip_camera dc{s.projector.fx, s.projector.fy, s.projector.cx, s.projector.cy, s.depth_buffer.width(), s.depth_buffer.height()};
+  bahip_camera cc{color_projector.fx, color_projector.fy, color_projector.cx, color_projector.cy, depth_to_color.width, depth_to_color.height};
+  const bahip_depth_params dp = ToBahipDepthParams(s.depth_params);
+  BAHIP_CHECKED_CALL(bahip_set_intrinsics(ctx, &cc, &dc, &dp));
+}
+bahip_frame FrameFromProjection(const SurfelProjectionParameters& s, cudaTextureObject_t color_texture) {
+  bahip_frame f{};
+  f.depth = s.depth_buffer.address(); f.depth_pitch_bytes = (uint32_t)s.depth_buffer.pitch();
+  f.normals = s.normals_buffer.address(); f.normals_pitch_bytes = (uint32_t)s.normals_buffer.pitch();
+  if (color_texture) { f.color = reinterpret_cast<uint8_t*>(color_texture->ToCUDA().address()); f.color_pitch_bytes = (uint32_t)color_texture->ToCUDA().pitch(); }
+  return f;
+}
+bahip_surfels SurfelsFromProjection(const SurfelProjectionParameters& s) {
+  bahip_surfels out{};
+  out.data = s.surfels.address(); out.pitch_bytes = (uint32_t)s.surfels.pitch();
+  out.surfels_size = s.surfels_size; out.capacity = (uint32_t)s.surfels.width();
+  return out;
+}
+bahip_pcg_layout Layout(u32 unknown_count, bool optimize_poses, bool optimize_geometry, bool use_depth_residuals, bool use_descriptor_residuals,
+                        bool optimize_depth_intrinsics, bool optimize_color_intrinsics, u32 surfel_start, u32 depth_intrinsics_start,
+                        u32 color_intrinsics_start) {
+  bahip_pcg_layout L{};
+  L.optimize_poses = optimize_poses; L.optimize_geometry = optimize_geometry;
+  L.optimize_depth_intrinsics = optimize_depth_intrinsics; L.optimize_color_intrinsics = optimize_color_intrinsics;
+  L.use_depth_residuals = use_depth_residuals; L.use_descriptor_residuals = use_descriptor_residuals;
+  L.unknown_count = unknown_count; L.surfel_unknown_start_index = surfel_start;
+  L.depth_intrinsics_unknown_start_index = depth_intrinsics_start; L.color_intrinsics_unknown_start_index = color_intrinsics_start;
+  return L;
+}
+}  // namespace
+
+void PCGInitCUDA(cudaStream_t stream, const SurfelProjectionParameters& s, const DepthToColorPixelCorner& depth_to_color,
+                 const PixelCenterUnprojector& /*depth_unprojector: derived from the depth camera*/, const PixelCornerProjector& color_projector,
+                 cudaTextureObject_t color_texture, u32 kf_pose_unknown_index, u32 surfel_unknown_start_index, bool optimize_poses,
+                 bool optimize_geometry, bool use_depth_residuals, bool use_descriptor_residuals, bool optimize_depth_intrinsics,
+                 bool optimize_color_intrinsics, u32 depth_intrinsics_unknown_start_index, u32 color_intrinsics_unknown_start_index,
+                 CUDABuffer_<PCGScalar>* pcg_r, CUDABuffer_<PCGScalar>* pcg_M, u32 surfels_size) {
+  bahip_context* ctx = Ctx(stream);
+  BindFromProjection(ctx, s, depth_to_color, color_projector);
+  PcgSession& session = Session();
+  if (!session.begun) {
+    // (whether a keyframe's pose is an unknown is said per call -- the reference passes optimize_poses = false for the gauge
+    // keyframe -- so the layout itself only needs the block boundaries; the unknown count is the width of the caller's vectors)
+    session.layout = Layout((u32)pcg_r->width(), true, optimize_geometry, use_depth_residuals, use_descriptor_residuals, optimize_depth_intrinsics,
+                            optimize_color_intrinsics, surfel_unknown_start_index, depth_intrinsics_unknown_start_index,
+                            color_intrinsics_unknown_start_index);
+    session.surfels_size = surfels_size;
+    BAHIP_CHECKED_CALL(bahip_pcg_begin(ctx, &session.layout, surfels_size));
+    session.begun = true;
+  }
+  const bahip_frame frame = FrameFromProjection(s, color_texture);
+  const bahip_surfels surfels = SurfelsFromProjection(s);
+  BAHIP_CHECKED_CALL(bahip_pcg_init(ctx, &session.layout, &frame, &s.frame_T_global.row0.x, kf_pose_unknown_index, optimize_poses ? 1 : 0, &surfels,
+                                    pcg_r->address(), pcg_M->address()));
+}
+
+void PCGInit2CUDA(cudaStream_t stream, u32 unknown_count, u32 /*a_unknown_index: depth_intrinsics_unknown_start_index + 4*/, float a,
+                  const CUDABuffer_<PCGScalar>& pcg_r, const CUDABuffer_<PCGScalar>& pcg_M, CUDABuffer_<PCGScalar>* pcg_delta,
+                  CUDABuffer_<PCGScalar>* pcg_g, CUDABuffer_<PCGScalar>* pcg_p, CUDABuffer_<PCGScalar>* pcg_alpha_n) {
+  bahip_context* ctx = Ctx(stream);
+  PcgSession& session = Session();
+  CHECK(session.begun) << "PCGInit2CUDA without a preceding PCGInitCUDA";
+  session.layout.unknown_count = unknown_count;
+  BAHIP_CHECKED_CALL(bahip_pcg_init2(ctx, &session.layout, session.surfels_size, a, pcg_r.address(), pcg_M.address(), pcg_delta->address(),
+                                     pcg_g->address(), pcg_p->address(), pcg_alpha_n->address()));
+  session.begun = false;   // the next PCGInitCUDA starts a new outer iteration
+}
+
+void PCGStep1CUDA(cudaStream_t stream, u32 /*unknown_count*/, const SurfelProjectionParameters& s, const DepthToColorPixelCorner& depth_to_color,
+                  const PixelCenterUnprojector&, const PixelCornerProjector& color_projector, cudaTextureObject_t color_texture,
+                  u32 kf_pose_unknown_index, u32 /*surfel_unknown_start_index*/, bool optimize_poses, bool /*optimize_geometry*/,
+                  bool /*use_depth_residuals*/, bool /*use_descriptor_residuals*/, bool /*optimize_depth_intrinsics*/,
+                  bool /*optimize_color_intrinsics*/, u32 /*depth_intrinsics_unknown_start_index*/, u32 /*a_unknown_index*/,
+                  u32 /*color_intrinsics_unknown_start_index*/, CUDABuffer_<PCGScalar>* pcg_p, CUDABuffer_<PCGScalar>* pcg_g,
+                  CUDABuffer_<PCGScalar>* /*pcg_alpha_d: written by PCGStep2CUDA*/, u32 /*surfels_size*/) {
+  bahip_context* ctx = Ctx(stream);
+  BindFromProjection(ctx, s, depth_to_color, color_projector);
+  const bahip_frame frame = FrameFromProjection(s, color_texture);
+  const bahip_surfels surfels = SurfelsFromProjection(s);
+  BAHIP_CHECKED_CALL(bahip_pcg_step1(ctx, &Session().layout, &frame, &s.frame_T_global.row0.x, kf_pose_unknown_index, optimize_poses ? 1 : 0, &surfels,
+                                     pcg_p->address(), pcg_g->address()));
+}
+
+void PCGStep2CUDA(cudaStream_t stream, u32 /*unknown_count*/, u32 /*a_unknown_index*/, const CUDABuffer_<PCGScalar>& pcg_r,
+                  const CUDABuffer_<PCGScalar>& pcg_M, CUDABuffer_<PCGScalar>* pcg_delta, CUDABuffer_<PCGScalar>* pcg_g,
+                  CUDABuffer_<PCGScalar>* pcg_p, CUDABuffer_<PCGScalar>* pcg_alpha_n, CUDABuffer_<PCGScalar>* pcg_alpha_d,
+                  CUDABuffer_<PCGScalar>* pcg_beta_n) {
+  PcgSession& session = Session();
+  BAHIP_CHECKED_CALL(bahip_pcg_step2(Ctx(stream), &session.layout, session.surfels_size, pcg_r.address(), pcg_M.address(), pcg_delta->address(),
+                                     pcg_g->address(), pcg_p->address(), pcg_alpha_n->address(), pcg_alpha_d->address(), pcg_beta_n->address()));
+}
+
+void PCGStep3CUDA(cudaStream_t stream, u32 /*unknown_count*/, CUDABuffer_<PCGScalar>* pcg_g, CUDABuffer_<PCGScalar>* pcg_p,
+                  CUDABuffer_<PCGScalar>* pcg_alpha_n, CUDABuffer_<PCGScalar>* pcg_beta_n) {
+  PcgSession& session = Session();
+  BAHIP_CHECKED_CALL(bahip_pcg_step3(Ctx(stream), &session.layout, session.surfels_size, pcg_g->address(), pcg_p->address(), pcg_alpha_n->address(),
+                                     pcg_beta_n->address()));
+}
+
+void UpdateSurfelsFromPCGDeltaCUDA(cudaStream_t stream, u32 surfels_size, CUDABuffer_<float>* surfels, bool use_descriptor_residuals,
+                                   u32 surfel_unknown_start_index, const CUDABuffer_<PCGScalar>& pcg_delta) {
+  bahip_surfels s{};
+  s.data = surfels->address(); s.pitch_bytes = (uint32_t)surfels->pitch(); s.surfels_size = surfels_size; s.capacity = (uint32_t)surfels->width();
+  BAHIP_CHECKED_CALL(bahip_update_surfels_from_pcg_delta(Ctx(stream), &s, use_descriptor_residuals ? 1 : 0, surfel_unknown_start_index, pcg_delta.address()));
+}
+
+void UpdateCFactorsFromPCGDeltaCUDA(cudaStream_t stream, CUDABuffer_<float>* /*cfactor_buffer: the one bound with the depth parameters*/,
+                                    u32 cfactor_unknown_start_index, const CUDABuffer_<PCGScalar>& pcg_delta) {
+  BAHIP_CHECKED_CALL(bahip_update_cfactors_from_pcg_delta(Ctx(stream), cfactor_unknown_start_index, pcg_delta.address()));
+}
+
 }  // namespace vis

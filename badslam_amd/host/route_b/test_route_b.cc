@@ -116,6 +116,69 @@ int main() {
   EXPECT(x0 > 0.001f && x0 < 0.008f);
   printf("route B: %u surfels created (same bits as Route A), geometry step identical, pose step %.4f m against a 0.004 m offset\n",
          count_a, x0);
+
+  // ---- one outer iteration of the PCG scheme: Route A (fused sweeps, stopping rule on the device) vs the reference's driver
+  // (B/direct_ba_pcg.cc:229-646: per-keyframe PCGInitCUDA / PCGStep1CUDA, host-side stopping rule) through the shim ----
+  {
+    const int gauge = 0;
+    ba.SetPCGGaugeKeyframe(gauge);
+    ba.BundleAdjustment(stream, false, false, false, /*optimize_poses*/ true, /*optimize_geometry*/ true, 1, 1, /*use_pcg*/ true, 0, K - 1,
+                        /*increase_ba_iteration_count*/ false, &done);
+    const u32 N = surfels_size;
+    const u32 pose_unknowns = 6 * (K - 1), U = pose_unknowns + 3 * N, kInvalid = 0xffffffffu;
+    active.Clear(1, stream);
+    UpdateSurfelNormalsCUDA(stream, camera, dp, keyframes, N, surfels, active);
+    CUDABuffer<PCGScalar> r(1, U), M(1, U), delta(1, U), g(1, U), p(1, U), alpha_n_buf(1, 1), alpha_d(1, 1), beta_n_buf(1, 1);
+    CUDABuffer<PCGScalar>*alpha_n = &alpha_n_buf, *beta_n = &beta_n_buf;
+    r.Clear(0, stream); M.Clear(0, stream);
+    const float* c = camera.parameters();
+    const PixelCornerProjector projector{c[0], c[1], c[2], c[3]};
+    const PixelCenterUnprojector unprojector{1.f / c[0], 1.f / c[1], -(c[2] - 0.5f) / c[0], -(c[3] - 0.5f) / c[1]};
+    const DepthToColorPixelCorner d2c{1.f, 1.f, 0.f, 0.f, W, H};
+    auto projection = [&](int k) {
+      float Fk[12];
+      keyframes[k]->frame_T_global().matrix3x4(Fk);
+      return SurfelProjectionParameters{surfels.ToCUDA(), keyframes[k]->depth_buffer().ToCUDA(), keyframes[k]->normals_buffer().ToCUDA(), dp,
+                                        projector, unprojector, CUDAMatrix3x4(Fk), N};
+    };
+    auto pose_index = [&](int k) { return k == gauge ? kInvalid : (u32)(6 * (k < gauge ? k : k - 1)); };
+    for (int k = 0; k < K; ++k)
+      PCGInitCUDA(stream, projection(k), d2c, unprojector, projector, keyframes[k]->color_texture(), pose_index(k), pose_unknowns, k != gauge, true, true,
+                  true, false, false, kInvalid, kInvalid, &r.ToCUDA(), &M.ToCUDA(), N);
+    PCGInit2CUDA(stream, U, kInvalid, dp.a, r.ToCUDA(), M.ToCUDA(), &delta.ToCUDA(), &g.ToCUDA(), &p.ToCUDA(), &alpha_n->ToCUDA());
+    double prev_r_norm = 1e300;
+    int without_improvement = 0, steps = 0;
+    for (int step = 0; step < 30; ++step) {
+      ++steps;
+      if (step > 0) { std::swap(alpha_n, beta_n); g.Clear(0, stream); }
+      alpha_d.Clear(0, stream);
+      for (int k = 0; k < K; ++k)
+        PCGStep1CUDA(stream, U, projection(k), d2c, unprojector, projector, keyframes[k]->color_texture(), pose_index(k), pose_unknowns, k != gauge, true,
+                     true, true, false, false, kInvalid, kInvalid, kInvalid, &p.ToCUDA(), &g.ToCUDA(), &alpha_d.ToCUDA(), N);
+      PCGStep2CUDA(stream, U, kInvalid, r.ToCUDA(), M.ToCUDA(), &delta.ToCUDA(), &g.ToCUDA(), &p.ToCUDA(), &alpha_n->ToCUDA(), &alpha_d.ToCUDA(),
+                   &beta_n->ToCUDA());
+      PCGScalar r_norm = 0;
+      beta_n->DownloadPartAsync(0, sizeof(PCGScalar), stream, &r_norm);
+      BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+      r_norm = std::sqrt(r_norm);
+      if (r_norm < prev_r_norm - 1e-3) without_improvement = 0;
+      else if (++without_improvement >= 3) break;
+      prev_r_norm = r_norm;
+      if (step < 29) PCGStep3CUDA(stream, U, &g.ToCUDA(), &p.ToCUDA(), &alpha_n->ToCUDA(), &beta_n->ToCUDA());
+    }
+    UpdateSurfelsFromPCGDeltaCUDA(stream, N, &surfels.ToCUDA(), true, pose_unknowns, delta.ToCUDA());
+    EXPECT(steps == ba.last_pcg_inner_steps());
+    vector<float> pcg_a(8 * (size_t)N), pcg_b(8 * (size_t)N);
+    for (int row = 0; row < 8; ++row) {
+      ba.surfels()->DownloadPartAsync((size_t)row * ba.surfels()->ToCUDA().pitch(), N * sizeof(float), stream, &pcg_a[(size_t)row * N]);
+      surfels.DownloadPartAsync((size_t)row * surfels.ToCUDA().pitch(), N * sizeof(float), stream, &pcg_b[(size_t)row * N]);
+    }
+    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    EXPECT(memcmp(pcg_a.data(), pcg_b.data(), pcg_a.size() * sizeof(float)) == 0);
+    EXPECT(memcmp(pcg_a.data(), after_a.data(), pcg_a.size() * sizeof(float)) != 0);   // the iteration moved the surfels
+    printf("route B: PCG outer iteration through PCGInit / Init2 / Step1 / Step2 / Step3 / UpdateSurfelsFromPCGDelta: %d inner steps, surfels "
+           "identical to Route A's fused iteration\n", steps);
+  }
   if (g_failures == 0) printf("ROUTE_B_OK\n");
   return g_failures == 0 ? 0 : 1;
 }
