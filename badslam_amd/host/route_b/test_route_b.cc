@@ -121,9 +121,6 @@ int main() {
   // (B/direct_ba_pcg.cc:229-646: per-keyframe PCGInitCUDA / PCGStep1CUDA, host-side stopping rule) through the shim ----
   {
     const int gauge = 0;
-    ba.SetPCGGaugeKeyframe(gauge);
-    ba.BundleAdjustment(stream, false, false, false, /*optimize_poses*/ true, /*optimize_geometry*/ true, 1, 1, /*use_pcg*/ true, 0, K - 1,
-                        /*increase_ba_iteration_count*/ false, &done);
     const u32 N = surfels_size;
     const u32 pose_unknowns = 6 * (K - 1), U = pose_unknowns + 3 * N, kInvalid = 0xffffffffu;
     active.Clear(1, stream);
@@ -167,6 +164,10 @@ int main() {
       if (step < 29) PCGStep3CUDA(stream, U, &g.ToCUDA(), &p.ToCUDA(), &alpha_n->ToCUDA(), &beta_n->ToCUDA());
     }
     UpdateSurfelsFromPCGDeltaCUDA(stream, N, &surfels.ToCUDA(), true, pose_unknowns, delta.ToCUDA());
+    // Route A afterwards: its call also moves the keyframes (shared with the loop above, which left the poses alone)
+    ba.SetPCGGaugeKeyframe(gauge);
+    ba.BundleAdjustment(stream, false, false, false, /*optimize_poses*/ true, /*optimize_geometry*/ true, 1, 1, /*use_pcg*/ true, 0, K - 1,
+                        /*increase_ba_iteration_count*/ false, &done);
     EXPECT(steps == ba.last_pcg_inner_steps());
     vector<float> pcg_a(8 * (size_t)N), pcg_b(8 * (size_t)N);
     for (int row = 0; row < 8; ++row) {
