@@ -118,6 +118,8 @@ void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& f
                           const uint32_t* indices, uint32_t surfels_size, const SurfelsView& s);
 void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                           int min_obs, uint32_t* deleted_count);
+void launch_shard_to_cloud(hipStream_t st, const SurfelsView& shard, const SurfelsView& cloud, uint32_t rank, uint32_t world, uint32_t chunk);
+void launch_cloud_to_shard(hipStream_t st, const SurfelsView& cloud, const SurfelsView& shard, uint32_t rank, uint32_t world, uint32_t chunk);
 hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float inv_cell);
 size_t scan_temp_bytes(size_t n);
 hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint8_t* flags, uint32_t* out, int n);

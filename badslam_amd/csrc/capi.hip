@@ -1673,6 +1673,67 @@ int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* 
   return 0;
 }
 
+namespace {
+float* host_row(const SurfelsView& v, int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(v.data) + (size_t)row * v.pitch); }
+// number of surfels of a cloud of `total` that the chunk-cyclic partition gives to `rank`
+uint32_t shard_size_of(uint32_t total, int rank, int world, uint32_t chunk) {
+  const uint64_t stride = (uint64_t)chunk * (uint64_t)world;
+  const uint64_t full = total / stride, rest = total % stride;
+  const uint64_t begin = (uint64_t)rank * chunk;
+  const uint64_t tail = rest > begin ? (rest - begin < chunk ? rest - begin : chunk) : 0;
+  return (uint32_t)(full * chunk + tail);
+}
+}  // namespace
+
+int bahip_gather_surfel_shards(bahip_context* ctx, const bahip_surfels* shard, uint32_t shard_surfel_count, int rank, int world, uint32_t chunk,
+                               bahip_surfels* cloud, uint32_t* cloud_surfels_size_out, uint32_t* cloud_surfel_count_out) {
+  REQUIRE(world >= 1 && rank >= 0 && rank < world && chunk > 0 && chunk % 64 == 0, "bahip_gather_surfel_shards: bad partition (chunks are whole 64-surfel tiles)");
+  REQUIRE(world <= 64, "bahip_gather_surfel_shards: at most 64 ranks");
+  hipStream_t st = ctx->stream;
+  // every rank's (size, count): a sum over the ranks of a table that is zero except for the own row
+  long long table[128] = {0};
+  table[2 * rank] = shard->surfels_size; table[2 * rank + 1] = shard_surfel_count;
+  DevMem dev_table;
+  HIP_TRY(hipMalloc(&dev_table.p, sizeof(table)));
+  HIP_TRY(hipMemcpyAsync(dev_table.p, table, sizeof(table), hipMemcpyHostToDevice, st));
+  if (reduce_over_ranks(ctx, dev_table.p, 2 * (size_t)world, BAHIP_SUM_I64)) return 1;
+  HIP_TRY(hipMemcpyAsync(table, dev_table.p, sizeof(table), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  uint64_t total = 0, count = 0;
+  for (int r = 0; r < world; ++r) { total += (uint64_t)table[2 * r]; count += (uint64_t)table[2 * r + 1]; }
+  REQUIRE(is_sharded(ctx) || world == 1, "bahip_gather_surfel_shards: world > 1 needs a communicator or an all-reduce hook");
+  REQUIRE(total <= cloud->capacity, "bahip_gather_surfel_shards: the cloud buffer is too small for the union of the shards");
+  REQUIRE(cloud->capacity % 8 == 0, "bahip_gather_surfel_shards: the cloud's capacity must be a multiple of 8 (rows travel as 64-bit words)");
+  for (int r = 0; r < world; ++r)
+    REQUIRE((uint64_t)table[2 * r] == shard_size_of((uint32_t)total, r, world, chunk),
+            "bahip_gather_surfel_shards: the shards are not the chunk-cyclic partition of one cloud");
+  cloud->surfels_size = (uint32_t)total;
+  const SurfelsView sv = make_view(shard), cv = make_view(cloud);
+  const size_t words = ((size_t)total + 1) / 2;   // int64 words per data row (rows start 8-byte aligned: pitched allocations)
+  for (int row = 0; row < kSurfelAccum0; ++row) HIP_TRY(hipMemsetAsync(host_row(cv, row), 0, words * 8, st));
+  if (cv.active) HIP_TRY(hipMemsetAsync(cv.active, 0, ((size_t)total + 7) / 8 * 8, st));
+  launch_shard_to_cloud(st, sv, cv, (uint32_t)rank, (uint32_t)world, chunk);
+  CHECK_LAUNCH();
+  for (int row = 0; row < kSurfelAccum0; ++row)
+    if (reduce_over_ranks(ctx, host_row(cv, row), words, BAHIP_SUM_I64)) return 1;
+  if (cv.active && reduce_over_ranks(ctx, cv.active, ((size_t)total + 7) / 8, BAHIP_SUM_I64)) return 1;
+  if (cloud_surfels_size_out) *cloud_surfels_size_out = (uint32_t)total;
+  if (cloud_surfel_count_out) *cloud_surfel_count_out = (uint32_t)count;
+  return 0;
+}
+
+int bahip_extract_surfel_shard(bahip_context* ctx, const bahip_surfels* cloud, int rank, int world, uint32_t chunk, bahip_surfels* shard,
+                               uint32_t* shard_surfels_size_out) {
+  REQUIRE(world >= 1 && rank >= 0 && rank < world && chunk > 0 && chunk % 64 == 0, "bahip_extract_surfel_shard: bad partition");
+  const uint32_t mine = shard_size_of(cloud->surfels_size, rank, world, chunk);
+  REQUIRE(mine <= shard->capacity, "bahip_extract_surfel_shard: the shard buffer is too small");
+  shard->surfels_size = mine;
+  launch_cloud_to_shard(ctx->stream, make_view(cloud), make_view(shard), (uint32_t)rank, (uint32_t)world, chunk);
+  CHECK_LAUNCH();
+  if (shard_surfels_size_out) *shard_surfels_size_out = mine;
+  return 0;
+}
+
 int bahip_exchange_stats(bahip_context* ctx, long long* calls_out, long long* bytes_out, int reset) {
   if (calls_out) *calls_out = ctx->exchange_calls;
   if (bytes_out) *bytes_out = ctx->exchange_bytes;

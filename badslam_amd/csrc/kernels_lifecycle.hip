@@ -454,4 +454,37 @@ hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float in
   return e;
 }
 
+// ---- surfel shards <-> the whole cloud (multi-GPU surfel sharding) --------------------------------------------------------------
+// Rank r of `world` owns every world-th chunk of `chunk` consecutive surfels of the cloud: local surfel l is global surfel
+// ((l / chunk) * world + rank) * chunk + l % chunk.  shard_to_cloud_kernel copies a shard's data rows (0 .. 7) and active
+// flags to their global places in a zeroed full-size buffer -- the ranks then sum their buffers as 64-bit integers, which
+// leaves every bit pattern (a deleted surfel's NaN marker included) as it is --, cloud_to_shard_kernel takes the shard back out.
+__device__ __forceinline__ uint32_t shard_global_index(uint32_t local, uint32_t rank, uint32_t world, uint32_t chunk) {
+  return ((local / chunk) * world + rank) * chunk + local % chunk;
+}
+__global__ void __launch_bounds__(kLcBlock)
+shard_to_cloud_kernel(SurfelsView shard, SurfelsView cloud, uint32_t rank, uint32_t world, uint32_t chunk) {
+  const uint32_t l = blockIdx.x * kLcBlock + threadIdx.x;
+  if (l >= shard.size) return;
+  const uint32_t g = shard_global_index(l, rank, world, chunk);
+#pragma unroll
+  for (int row = 0; row < kSurfelAccum0; ++row) cloud.row(row)[g] = shard.row(row)[l];
+  if (shard.active && cloud.active) cloud.active[g] = shard.active[l];
+}
+__global__ void __launch_bounds__(kLcBlock)
+cloud_to_shard_kernel(SurfelsView cloud, SurfelsView shard, uint32_t rank, uint32_t world, uint32_t chunk) {
+  const uint32_t l = blockIdx.x * kLcBlock + threadIdx.x;
+  if (l >= shard.size) return;
+  const uint32_t g = shard_global_index(l, rank, world, chunk);
+#pragma unroll
+  for (int row = 0; row < kSurfelAccum0; ++row) shard.row(row)[l] = cloud.row(row)[g];
+  if (shard.active && cloud.active) shard.active[l] = cloud.active[g];
+}
+void launch_shard_to_cloud(hipStream_t st, const SurfelsView& shard, const SurfelsView& cloud, uint32_t rank, uint32_t world, uint32_t chunk) {
+  if (shard.size) hipLaunchKernelGGL(shard_to_cloud_kernel, dim3((shard.size + kLcBlock - 1) / kLcBlock), dim3(kLcBlock), 0, st, shard, cloud, rank, world, chunk);
+}
+void launch_cloud_to_shard(hipStream_t st, const SurfelsView& cloud, const SurfelsView& shard, uint32_t rank, uint32_t world, uint32_t chunk) {
+  if (shard.size) hipLaunchKernelGGL(cloud_to_shard_kernel, dim3((shard.size + kLcBlock - 1) / kLcBlock), dim3(kLcBlock), 0, st, cloud, shard, rank, world, chunk);
+}
+
 }  // namespace bahip

@@ -52,6 +52,7 @@ def _load():
         L.dba_cfactor_size.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.dba_download_cfactor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dba_clear_cfactor.argtypes = [C.c_void_p, C.c_void_p]
+        L.dba_set_surfel_sharding.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32]
         L.dba_set_pcg_gauge_keyframe.argtypes = [C.c_void_p, C.c_int]
         L.dba_set_ba_iteration_counts.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.dba_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -233,6 +234,10 @@ class DirectBA:
 
     def set_ba_iteration_counts(self, ba_iteration_count, last_ba_iteration_count):
         self.L.dba_set_ba_iteration_counts(self.h, int(ba_iteration_count), int(last_ba_iteration_count))
+
+    def SetSurfelSharding(self, rank, world, chunk=1024):
+        """This object holds rank `rank`'s chunk-cyclic shard of one cloud; lifecycle phases run on the gathered cloud."""
+        assert self.L.dba_set_surfel_sharding(self.h, int(rank), int(world), int(chunk)) == 0
 
     def set_pcg_gauge_keyframe(self, k):
         self.L.dba_set_pcg_gauge_keyframe(self.h, int(k))

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 
 namespace vis {
 
@@ -203,8 +204,52 @@ void DirectBA::BindScene(hipStream_t stream) {
             t2 - t1, indices.size(), t3 - t2, now() - t3);
 }
 
+// ---- surfel sharding: whole-cloud phases -----------------------------------------------------------------------------
+void DirectBA::SetSurfelSharding(int rank, int world, u32 chunk) {
+  CHECK(world >= 1 && rank >= 0 && rank < world && chunk > 0 && chunk % 64 == 0) << "bad surfel partition";
+  CHECK_EQ(whole_cloud_depth_, 0);
+  shard_rank_ = rank; shard_world_ = world; shard_chunk_ = chunk;
+  if (world > 1 && !other_surfels_) {
+    CHECK_EQ(surfels_->width() % 8, 0) << "surfel sharding needs max_surfel_count to be a multiple of 8";
+    other_surfels_.reset(new CUDABuffer<float>(kSurfelAttributeCount, surfels_->width()));
+    other_active_surfels_.reset(new CUDABuffer<u8>(1, surfels_->width()));
+  }
+}
+
+void DirectBA::EnterWholeCloud(hipStream_t stream) {
+  if (shard_world_ <= 1 || whole_cloud_depth_++ > 0) return;
+  BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
+  const bahip_surfels shard = SurfelsStruct();
+  std::swap(surfels_, other_surfels_);
+  std::swap(active_surfels_, other_active_surfels_);
+  bahip_surfels cloud = SurfelsStruct();
+  uint32_t size = 0, count = 0;
+  BAHIP_CHECKED_CALL(bahip_gather_surfel_shards(ctx_, &shard, surfel_count_, shard_rank_, shard_world_, shard_chunk_, &cloud, &size, &count));
+  Lock();
+  surfels_size_ = size;
+  surfel_count_ = count;
+  Unlock();
+}
+
+void DirectBA::LeaveWholeCloud(hipStream_t stream) {
+  if (shard_world_ <= 1 || --whole_cloud_depth_ > 0) return;
+  BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
+  CHECK_EQ(surfels_size_, surfel_count_) << "a whole-cloud phase must end compacted";
+  const bahip_surfels cloud = SurfelsStruct();
+  std::swap(surfels_, other_surfels_);
+  std::swap(active_surfels_, other_active_surfels_);
+  bahip_surfels shard = SurfelsStruct();
+  uint32_t mine = 0;
+  BAHIP_CHECKED_CALL(bahip_extract_surfel_shard(ctx_, &cloud, shard_rank_, shard_world_, shard_chunk_, &shard, &mine));
+  Lock();
+  surfels_size_ = mine;
+  surfel_count_ = mine;
+  Unlock();
+}
+
 // ---- surfel creation (B/direct_ba.cc:340-405) ---------------------------------------------------------------------
 void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const shared_ptr<Keyframe>& keyframe) {
+  WholeCloudScope whole_cloud(this, stream);
   BindScene(stream);
   vector<int> covis;
   for (int id : keyframe->co_visibility_list())
@@ -288,6 +333,7 @@ void DirectBA::BundleAdjustment(hipStream_t stream, bool optimize_depth_intrinsi
 
 // ---- end-of-scheme tasks (B/direct_ba.cc:566-653) -----------------------------------------------------------------------
 void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates) {
+  WholeCloudScope whole_cloud(this, stream);
   BindScene(stream);
   if (do_surfel_updates) {
     for (shared_ptr<Keyframe>& keyframe : keyframes_) {
@@ -402,7 +448,10 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         }
       }
       Unlock();
-      for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
+      if (!keyframes_with_new_surfels.empty()) {
+        WholeCloudScope whole_cloud(this, stream);   // one gather for the whole batch
+        for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
+      }
       if (!keyframes_with_new_surfels.empty()) scene_bound = false;   // CreateSurfelsForKeyframe re-bound the keyframes: lists and window go again
     }
 
@@ -445,10 +494,11 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     lap(3);
 
     // --- surfel merge + compaction ---
-    if (do_surfel_updates) {
+    if (do_surfel_updates && !keyframes_with_new_surfels.empty()) {
+      WholeCloudScope whole_cloud(this, stream);
       for (u32 keyframe_id : keyframes_with_new_surfels)
         if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
-      if (!keyframes_with_new_surfels.empty()) {
+      {
         const bahip_surfels s = SurfelsStruct();
         BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count_, &s));
         Lock();
@@ -572,6 +622,8 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
   }
   vector<u32> keyframes_with_new_surfels;
   auto merge_and_compact = [&]() {
+    if (keyframes_with_new_surfels.empty()) return;
+    WholeCloudScope whole_cloud(this, stream);
     for (u32 keyframe_id : keyframes_with_new_surfels)
       if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
     if (!keyframes_with_new_surfels.empty()) {
@@ -586,6 +638,10 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
     if (num_iterations_done) ++*num_iterations_done;
     keyframes_with_new_surfels.clear();
     if (optimize_geometry && do_surfel_updates) {
+      bool any_new = false;
+      for (const shared_ptr<Keyframe>& keyframe : keyframes_)
+        any_new |= keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != ba_iteration_count_;
+      std::unique_ptr<WholeCloudScope> whole_cloud(any_new ? new WholeCloudScope(this, stream) : nullptr);   // one gather for the batch
       for (shared_ptr<Keyframe>& keyframe : keyframes_) {
         if (keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != ba_iteration_count_) {
           keyframe->SetLastActiveInBAIteration(ba_iteration_count_);

@@ -119,6 +119,12 @@ class DirectBA {
   // Multi-GPU surfel sharding: sums of the per-keyframe normal equations go through this hook
   // (see include/badslam_hip.h, bahip_allreduce_fn).
   void SetAllReduce(bahip_allreduce_fn fn, void* user) { BAHIP_CHECKED_CALL(bahip_context_set_allreduce(ctx_, fn, user)); }
+  // Multi-GPU surfel sharding WITH surfel updates: this object holds rank `rank`'s chunk-cyclic shard of one surfel cloud
+  // (chunks of `chunk` surfels, a multiple of 64; see bahip_gather_surfel_shards).  The sweeps of an iteration work on the
+  // shard; every phase of the surfel lifecycle (creation, merging, deletion, compaction) assembles the whole cloud on every
+  // rank, runs unchanged, and takes the shard back out -- so a sharded BundleAdjustment with do_surfel_updates ends with the
+  // bits of the unsharded one.  Needs SetAllReduce (or an RCCL communicator on the backend context) when world > 1.
+  void SetSurfelSharding(int rank, int world, u32 chunk);
   bahip_context* backend_context() { return ctx_; }
   // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
   // keyframe ids and the dense bound list.  Public so that a caller can drive single bahip_* stages
@@ -147,6 +153,14 @@ class DirectBA {
   void PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates);
 
   void MergeForKeyframe(const Keyframe& keyframe);
+  // Whole-cloud phases under surfel sharding (no-ops without it); they nest, only the outermost pair moves data.
+  void EnterWholeCloud(hipStream_t stream);
+  void LeaveWholeCloud(hipStream_t stream);
+  struct WholeCloudScope {
+    WholeCloudScope(DirectBA* ba, hipStream_t stream) : ba_(ba), stream_(stream) { ba_->EnterWholeCloud(stream_); }
+    ~WholeCloudScope() { ba_->LeaveWholeCloud(stream_); }
+    DirectBA* ba_; hipStream_t stream_;
+  };
 
   PinholeCamera4f color_camera_;
   int pyramid_level_for_color_;
@@ -171,6 +185,10 @@ class DirectBA {
   vector<int> bound_ids_;        // bound list index -> keyframe id
   vector<int> id_to_bound_;      // keyframe id -> bound list index (-1 for deleted keyframes)
   int pcg_gauge_keyframe_ = -1;
+  int shard_rank_ = 0, shard_world_ = 1, whole_cloud_depth_ = 0;
+  u32 shard_chunk_ = 0;
+  CUDABufferPtr<float> other_surfels_;      // under surfel sharding: the buffer not in use (whole cloud <-> shard)
+  CUDABufferPtr<u8> other_active_surfels_;
   int last_pose_rounds_ = 0, last_pose_steps_ = 0, last_pcg_inner_steps_ = 0;
 };
 

@@ -67,6 +67,8 @@ int dba_cfactor_size(dba_handle* h, int* width, int* height);
 int dba_download_cfactor(dba_handle* h, void* hip_stream, float* out);
 int dba_clear_cfactor(dba_handle* h, void* hip_stream);
 int dba_set_pcg_gauge_keyframe(dba_handle* h, int keyframe_id);
+/* DirectBA::SetSurfelSharding: this object holds rank `rank`'s chunk-cyclic shard of one surfel cloud (bahip_gather_surfel_shards) */
+int dba_set_surfel_sharding(dba_handle* h, int rank, int world, uint32_t chunk);
 /* DirectBA::SetBAIterationCount / SetLastBAIterationCount (direct_ba.h:362-366) */
 int dba_set_ba_iteration_counts(dba_handle* h, int ba_iteration_count, int last_ba_iteration_count);
 int dba_last_stats(dba_handle* h, int* pose_rounds, int* pose_steps, int* pcg_inner_steps);

@@ -416,6 +416,24 @@ int bahip_set_profiling(bahip_context* ctx, int enabled);
 /* Work units of the launches counted above (stage 2: sum over launches of the keyframes still
  * iterating in that Gauss-Newton round; other stages: launches). */
 int bahip_stage_work_units(bahip_context* ctx, int stage, long long* units_out);
+/* ---- surfel shards <-> the whole cloud ------------------------------------------------------------------------------------------
+ * Under surfel sharding rank r of `world` owns every world-th chunk of `chunk` consecutive surfels of ONE cloud (local surfel l is
+ * global surfel ((l / chunk) * world + r) * chunk + l % chunk).  The per-surfel work of an iteration needs no other rank's
+ * surfels; the surfel LIFECYCLE does -- whether a pixel is already supported, which surfels of a cell merge, where compaction
+ * moves the last surfels -- and is not worth a distributed algorithm: it runs a few times per BundleAdjustment call.  For those
+ * phases every rank assembles the whole cloud, runs the unsharded lifecycle code on it (identical work, identical result on
+ * every rank) and takes its shard back out, so a sharded run with surfel updates ends with the bits of the unsharded run.
+ *
+ * bahip_gather_surfel_shards: cloud := the union of all ranks' shards.  `cloud` must have room for the sum of the shard sizes;
+ * rows 0 .. 7 and the active flags travel (one int64 all-reduce per row: bit patterns are preserved), the scratch rows do not.
+ * Returns the cloud's size and surfel count (the sums over the ranks) and checks that the shard sizes are those of the
+ * chunk-cyclic partition.  bahip_extract_surfel_shard: shard := this rank's surfels of a cloud of cloud->surfels_size; returns
+ * the shard's size.  Without a communicator / hook (one GPU) both are plain copies. */
+int bahip_gather_surfel_shards(bahip_context* ctx, const bahip_surfels* shard, uint32_t shard_surfel_count, int rank, int world, uint32_t chunk,
+                               bahip_surfels* cloud, uint32_t* cloud_surfels_size_out, uint32_t* cloud_surfel_count_out);
+int bahip_extract_surfel_shard(bahip_context* ctx, const bahip_surfels* cloud, int rank, int world, uint32_t chunk, bahip_surfels* shard,
+                               uint32_t* shard_surfels_size_out);
+
 /* Multi-GPU accounting: how many sums over the ranks this context has requested (through the hook or RCCL) since the last
  * reset, and the bytes of the buffers summed (per rank, one direction).  A single-GPU context reports zeros. */
 int bahip_exchange_stats(bahip_context* ctx, long long* calls_out, long long* bytes_out, int reset);
