@@ -68,8 +68,19 @@ void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEnt
 // Intrinsics step (kernels_intrinsics.hip).  glob_d / cells_d: binary64 accumulators (34 sums; S records of 8: B0..B4, D, b2,
 // observation count) -- what a multi-GPU run sums over the ranks; glob_f / cells_f: their binary32 roundings after the
 // Schur complement (glob_f also carries x1 at [40..44] for the back-substitution).
+// Append buffers of the intrinsics sweep's per-cell records (kernels_intrinsics.hip): several per block of 32 x 32 sparse cells, each
+// 8 planes of `capacity` words; cursors[buffer] counts the records appended (and keeps counting when the buffer is full).
+// capacity == 0: no binning, every record goes out as atomics.
+struct IntrBins {
+  uint32_t* cursors;
+  uint32_t* records;
+  uint32_t capacity;
+  int bins_x;
+};
+int intrinsics_bin_count(const Intrinsics& in, int* bins_x_out);
+size_t intrinsics_bin_record_bytes();
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, double* glob_d, double* cells_d);
+                                  const SurfelsView& s, double* glob_d, double* cells_d, const IntrBins& bins);
 size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_finish needs
 void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* glob_d, const double* cells_d, float* glob_f, float* cells_f,
                               float* partials);

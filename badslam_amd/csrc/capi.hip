@@ -114,6 +114,15 @@ struct bahip_context {
 
   float* intr_scratch = nullptr;   // intrinsics step: (64 + 8 S) doubles, then (64 + 8 S) floats + Schur partials
   int intr_capacity = 0;
+  // append buffers of the intrinsics sweep's per-cell records (ba_launch.h: IntrBins), sized from the previous call's counts
+  uint32_t* intr_bin_cursors = nullptr;   // device, intr_bin_count words
+  uint32_t* intr_bin_records = nullptr;
+  uint32_t* intr_bin_counts_host = nullptr;   // pinned copy of the cursors after the sweep
+  int intr_bin_count = 0;
+  uint32_t intr_bin_capacity = 0;         // records per block the buffers hold
+  uint32_t intr_bin_wanted = 0;           // records per block the next call should have room for (0: estimate)
+  int intr_bin_forced = -1;
+  int intr_bin_last_overflow = 0;         // did the last call have records that did not fit?               // bahip_debug_set_intrinsics_bin_capacity: >= 0 fixes the capacity (0: no binning)
 
   float* pcg_buf = nullptr;        // PCG vectors r, M, delta, g, p (5 * pcg_capacity floats) + 16 scalars
   size_t pcg_capacity = 0;
@@ -509,6 +518,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
+  hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
@@ -1141,17 +1151,54 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   float* glob = reinterpret_cast<float*>(cells_d + 8 * (size_t)ctx->intr_capacity);   // the 34 sums rounded (+ Schur); x1 at [40..44]
   float* cells = glob + 64;
   float* partials = cells + 8 * (size_t)ctx->intr_capacity;
+  // Append buffers for the per-cell records (kernels_intrinsics.hip).  Their size follows the demand the previous call saw
+  // (+ 25 %); before the first call it is an estimate, and a call that finds them too small still gives the same result: the
+  // records that do not fit go out as atomics.
+  IntrBins bins{nullptr, nullptr, 0, 1};
+  const int num_bins = intrinsics_bin_count(ctx->in, &bins.bins_x);
+  if (optimize_depth) {
+    if (num_bins != ctx->intr_bin_count) {
+      hipFree(ctx->intr_bin_cursors); hipHostFree(ctx->intr_bin_counts_host); hipFree(ctx->intr_bin_records);
+      ctx->intr_bin_cursors = nullptr; ctx->intr_bin_counts_host = nullptr; ctx->intr_bin_records = nullptr;
+      ctx->intr_bin_capacity = 0; ctx->intr_bin_wanted = 0;
+      HIP_TRY(hipMalloc(&ctx->intr_bin_cursors, sizeof(uint32_t) * (size_t)num_bins));
+      HIP_TRY(hipHostMalloc(&ctx->intr_bin_counts_host, sizeof(uint32_t) * (size_t)num_bins));
+      ctx->intr_bin_count = num_bins;
+    }
+    uint64_t want = ctx->intr_bin_wanted;
+    if (!want) want = (uint64_t)surfels->surfels_size * (uint64_t)std::min(ctx->num_kfs, 16) * 2 / (uint64_t)num_bins + 4096;
+    if (ctx->intr_bin_forced >= 0) want = (uint64_t)ctx->intr_bin_forced;
+    const uint64_t limit = (32ull << 30) / (intrinsics_bin_record_bytes() * (uint64_t)num_bins);   // at most 32 GB of records
+    want = std::min(want, limit);
+    if (want > ctx->intr_bin_capacity || (ctx->intr_bin_forced >= 0 && want != ctx->intr_bin_capacity)) {
+      hipFree(ctx->intr_bin_records);
+      ctx->intr_bin_records = nullptr; ctx->intr_bin_capacity = 0;
+      const uint64_t cap = (want + 63) / 64 * 64;
+      if (cap) HIP_TRY(hipMalloc(&ctx->intr_bin_records, intrinsics_bin_record_bytes() * cap * (uint64_t)num_bins));
+      ctx->intr_bin_capacity = (uint32_t)cap;
+    }
+    bins.cursors = ctx->intr_bin_cursors; bins.records = ctx->intr_bin_records; bins.capacity = ctx->intr_bin_capacity;
+  }
   timer_begin(ctx, 4, true);
   HIP_TRY(hipMemsetAsync(glob_d, 0, sizeof(double) * (64 + 8 * (size_t)S), ctx->stream));
+  if (bins.capacity) HIP_TRY(hipMemsetAsync(bins.cursors, 0, sizeof(uint32_t) * (size_t)num_bins, ctx->stream));
   launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
-                               make_view(surfels), glob_d, cells_d);
+                               make_view(surfels), glob_d, cells_d, bins);
   CHECK_LAUNCH();
+  if (bins.capacity)
+    HIP_TRY(hipMemcpyAsync(ctx->intr_bin_counts_host, bins.cursors, sizeof(uint32_t) * (size_t)num_bins, hipMemcpyDeviceToHost, ctx->stream));
   if (reduce_over_ranks(ctx, glob_d, 64 + 8 * (size_t)S, BAHIP_SUM_F64)) return 1;
   launch_intrinsics_finish(ctx->stream, optimize_depth != 0, S, glob_d, cells_d, glob, cells, partials);
   CHECK_LAUNCH();
   timer_end(ctx, 4);   // the sweep and the Schur complement; the 5x5 / 4x4 solves and the cfactor update that follow are tiny
   HIP_TRY(hipMemcpyAsync(ctx->pinned_f, glob, 34 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (bins.capacity) {
+    uint32_t most = 0;
+    for (int b = 0; b < num_bins; ++b) most = std::max(most, ctx->intr_bin_counts_host[b]);
+    ctx->intr_bin_wanted = std::max(ctx->intr_bin_wanted, most + most / 4 + 1024);
+    ctx->intr_bin_last_overflow = most > bins.capacity ? 1 : 0;
+  }
   const float* g = ctx->pinned_f;
   if (optimize_depth) {
     double M[25], rhs[5], x[5];
@@ -1731,6 +1778,19 @@ int bahip_extract_surfel_shard(bahip_context* ctx, const bahip_surfels* cloud, i
   launch_cloud_to_shard(ctx->stream, make_view(cloud), make_view(shard), (uint32_t)rank, (uint32_t)world, chunk);
   CHECK_LAUNCH();
   if (shard_surfels_size_out) *shard_surfels_size_out = mine;
+  return 0;
+}
+
+int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block) {
+  ctx->intr_bin_forced = records_per_block;
+  return 0;
+}
+int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out) {
+  uint32_t most = 0; uint64_t total = 0;
+  for (int b = 0; b < ctx->intr_bin_count && ctx->intr_bin_counts_host; ++b) { most = std::max(most, ctx->intr_bin_counts_host[b]); total += ctx->intr_bin_counts_host[b]; }
+  if (capacity_out) *capacity_out = ctx->intr_bin_capacity;
+  if (most_out) *most_out = most;
+  if (total_out) *total_out = total;
   return 0;
 }
 

@@ -17,6 +17,20 @@
 // 64 x 8 contributions through LDS and issues 8 instructions in which 8 consecutive lanes carry the 8 values of one
 // surfel - one request per surfel instead of eight requests to eight lines.
 //
+// That still is one memory-side atomic request per associated pair, and gfx950 completes ~23.6 G of them per second whatever
+// their width, scope or target (scripts/experiments/atomic_rates.hip: 52 M records of 8 values take 2.2 ms, shared or per-XCD
+// tables, f64 / f32 / u64 alike) -- and while the queue to the atomic units is full the CU's other vector memory
+// instructions, the next candidate's gathers included, wait behind it: sweep (1.45 ms at the bench size) and atomics (2.6 ms)
+// add up instead of overlapping.  So the records are BINNED instead: the sparse cell grid is cut into blocks of 32 x 32 cells,
+// each block has an append buffer (eight planes: the cell within the block and seven values; the observation count is 1),
+// a wavefront reserves room for its records with ONE returning atomic per block it touches (one or two, seldom more) and
+// stores them with plain coalesced stores; a second kernel adds the records of a block slice by slice into a table in LDS
+// (1024 cells x 8 doubles = 64 KB, ds_add_f64) and adds the table to the global accumulators -- one request per touched cell
+// and slice instead of one per pair.  (That second kernel is bound by the LDS atomics: ds_add_f64 retires ~0.75 lanes per clock
+// and CU here, 0.9 ms for the 52 M x 8 additions of the bench size; ds_add_f32 is slower still.)  A record that finds its block's buffer full (the host sizes the buffers from the
+// previous call's counts, so: the first call on a larger scene), or that belongs to a fourth block of one wavefront, takes
+// the direct path above; the sums below do not depend on the path.
+//
 // DEFINITION of the sums (the oracle restates it, oracle_intrinsics.c).  The terms are binary32, exactly the reference's
 // expressions; they are ADDED IN BINARY64: the 34 global sums as per-surfel binary32 chains over the keyframes in ascending
 // order, then the xor butterfly over the 64 surfels of a tile (wave_sum), then binary64 over the tiles; the per-cell sums in
@@ -34,18 +48,38 @@ constexpr int kIntrBlock = 256;    // per-cell kernels (Schur complement, back-s
 constexpr int kIntrSweepBlock = 64; // the surfel sweep: one wavefront per workgroup, like the other sweeps
 constexpr int kARows = 5;
 constexpr int kCellFloats = 8;     // B0..B4, D, b2, observation count
+constexpr int kBinShift = 5;       // blocks of 32 x 32 sparse cells
+constexpr int kBinCells = 1 << (2 * kBinShift);
+constexpr int kBinGroups = 3;      // blocks one wavefront can append to per candidate keyframe (the rest: direct atomics)
+constexpr uint32_t kBinSlice = 32768;   // records one workgroup of the reduction adds into its LDS table
+constexpr int kBinReduceBlock = 512;
+#ifndef BAHIP_INTR_BIN_SUBS
+#define BAHIP_INTR_BIN_SUBS 16
+#endif
+// Every block has kBinSubs append buffers, a wavefront uses the one of its tile number: atomics on ONE address are served one
+// after the other, and with one cursor per block (80 at 640 x 480) the reservations alone took longer than the whole sweep.
+constexpr int kBinSubs = BAHIP_INTR_BIN_SUBS;
 __device__ __forceinline__ float& cell_B(float* cells, int cell, int c) { return cells[(size_t)cell * kCellFloats + c]; }
 __device__ __forceinline__ float& cell_D(float* cells, int cell) { return cells[(size_t)cell * kCellFloats + 5]; }
 __device__ __forceinline__ float& cell_b2(float* cells, int cell) { return cells[(size_t)cell * kCellFloats + 6]; }
 __device__ __forceinline__ float& cell_obs(float* cells, int cell) { return cells[(size_t)cell * kCellFloats + 7]; }
 
-// Layout of the accumulation scratch (floats): [0..14] A, [15..19] b1, [20..29] colour H, [30..33] colour b.
+// Layout of the accumulation scratch: [0..14] A, [15..19] b1, [20..29] colour H, [30..33] colour b.
+//
+// Shape of the sweep (as the PCG sweeps, kernels_pcg.hip): one 64-surfel tile per wavefront, tiles dealt to the XCDs in runs
+// (xcd_chunked_tile); per candidate keyframe all gathers of the pair -- the geometry word and the cfactor of the pixel, three
+// luminance words -- are issued before the first is waited for, and the per-cell atomics of a candidate go out one candidate
+// LATE, behind the next candidate's gathers: vmcnt retires in order, so an atomic issued before a gather would make the wait
+// for that gather a wait for the atomic's round trip.
+#ifndef BAHIP_INTR_WAVES_PER_EU
+#define BAHIP_INTR_WAVES_PER_EU 3   // 168 VGPRs: the 34 per-lane sums live across the sweep (at 4 waves: 57 spills)
+#endif
 template <bool kDepth, bool kColor>
-__global__ void __launch_bounds__(kIntrSweepBlock)
+__global__ void __launch_bounds__(kIntrSweepBlock) __attribute__((amdgpu_waves_per_eu(BAHIP_INTR_WAVES_PER_EU)))
 intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                             double* __restrict__ glob /* 34 */, double* __restrict__ cells /* S records of kCellFloats */) {
+                             double* __restrict__ glob /* 34 */, double* __restrict__ cells /* S records of kCellFloats */, IntrBins bins) {
   __shared__ float xpose[64 * (kCellFloats + 1)];   // lane-major: 8 values + the cell index, stride 9 (conflict-free both ways)
-  const uint32_t i = blockIdx.x * kIntrSweepBlock + threadIdx.x;
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kIntrSweepBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
@@ -53,29 +87,113 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
   const Vec3 gn = surfel_normal(s, ii);
   const float radius_sq = s.row(kSurfelRadiusSquared)[ii];
   const float d1 = s.row(kSurfelDescriptor1)[ii], d2 = s.row(kSurfelDescriptor2)[ii];
+  const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);   // per surfel, not per pair
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
+  if (wb.r < 0.f) return;   // a tile of the grid's padding, or one without a valid surfel (wave-uniform)
   float acc[34];
 #pragma unroll
   for (int q = 0; q < 34; ++q) acc[q] = 0.f;
 
+  // the per-cell terms of the previous candidate: {B0..B4, D, b2} (the observation count is 1) and the cell as
+  // (block << 10 | cell within the block), -1: none; and where they go: pending_slot = (group << 8 | rank within the group)
+  // for the lanes whose block got a reservation -- group g's returning atomic was issued by lane reserve_lane[g] into
+  // reserve_base[g], one candidate ago, so it has arrived with this candidate's gathers -- and -1 for the direct path.
+  float pending[kCellFloats - 1];
+  int pending_cell = -1, pending_slot = -1;
+  uint32_t reserve_base[kBinGroups] = {0, 0, 0};
+  int reserve_lane[kBinGroups] = {0, 0, 0};   // wave-uniform
+  const bool binned = bins.capacity != 0;     // wave-uniform
+  const uint32_t sub = xcd_chunked_tile(blockIdx.x) & (kBinSubs - 1);
+  auto flush_pending = [&]() {
+    if (!kDepth) return;
+    unsigned long long contributing = __ballot(pending_cell >= 0);
+    if (!contributing) return;
+    if (binned) {
+      uint32_t slot = 0xffffffffu;
+#pragma unroll
+      for (int g = 0; g < kBinGroups; ++g) {
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)reserve_base[g], reserve_lane[g]);
+        if (pending_slot >= 0 && (pending_slot >> 8) == g) slot = base + (uint32_t)(pending_slot & 0xff);
+      }
+      const bool stored = pending_cell >= 0 && slot < bins.capacity;
+      if (stored) {
+        uint32_t* rec = bins.records + ((size_t)(pending_cell >> (2 * kBinShift)) * kBinSubs + sub) * kCellFloats * bins.capacity + slot;
+        rec[0] = (uint32_t)(pending_cell & (kBinCells - 1));
+#pragma unroll
+        for (int c = 0; c < kCellFloats - 1; ++c) rec[(size_t)(c + 1) * bins.capacity] = __float_as_uint(pending[c]);
+        pending_cell = -1;
+      }
+      contributing = __ballot(pending_cell >= 0);
+    }
+    if (contributing) {
+      // direct path: transpose through LDS -- afterwards lanes 8 s .. 8 s + 7 of pass j carry the 8 values of the surfel in
+      // lane 8 j + s -- and one atomic instruction per 8 surfels
+      int cell = -1;
+      if (pending_cell >= 0) {
+        const int block = pending_cell >> (2 * kBinShift), within = pending_cell & (kBinCells - 1);
+        const int bx = block % bins.bins_x, by = block / bins.bins_x;
+        cell = ((by << kBinShift) + (within >> kBinShift)) * in.cf_width + (bx << kBinShift) + (within & ((1 << kBinShift) - 1));
+      }
+      float* mine = xpose + lane * (kCellFloats + 1);
+#pragma unroll
+      for (int c = 0; c < kCellFloats - 1; ++c) mine[c] = pending[c];
+      mine[kCellFloats - 1] = 1.0f;
+      mine[kCellFloats] = __int_as_float(cell);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (!((contributing >> (8 * j)) & 0xffull)) continue;   // wave-uniform
+        const float* src = xpose + (8 * j + (lane >> 3)) * (kCellFloats + 1);
+        const int c = __float_as_int(src[kCellFloats]);
+        if (c >= 0) unsafeAtomicAdd(&cells[(size_t)c * kCellFloats + (lane & 7)], (double)src[lane & 7]);
+      }
+      __builtin_amdgcn_wave_barrier();   // the next flush overwrites the buffer
+    }
+    pending_cell = -1;
+  };
+  // Room for the records of this candidate: one returning atomic per block the wavefront touches, issued now and read at the
+  // next flush.
+  auto reserve_pending = [&]() {
+    if (!kDepth || !binned) return;
+    pending_slot = -1;
+    unsigned long long todo = __ballot(pending_cell >= 0);
+#pragma unroll
+    for (int g = 0; g < kBinGroups; ++g) {
+      if (!todo) break;   // wave-uniform
+      const int first = __ffsll((long long)todo) - 1;
+      const int block = __builtin_amdgcn_readlane(pending_cell >> (2 * kBinShift), first);
+      const bool member = pending_cell >= 0 && (pending_cell >> (2 * kBinShift)) == block;
+      const unsigned long long m = __ballot(member);
+      if (member) pending_slot = (g << 8) | (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      reserve_lane[g] = first;
+      if (lane == first) reserve_base[g] = atomicAdd(&bins.cursors[block * kBinSubs + sub], (uint32_t)__popcll(m));
+      todo &= ~m;
+    }
+  };
+
   for_each_candidate(
       num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
-        const float* F = kfs[k].pose.F;
+        const KfEntry& kf = kfs[k];
+        const float* F = kf.pose.F;
+        const Projected p = project_surfel(in, F, gp);
+        const PixelWords pix = load_pixel_words(in, kf.geom, p);
+        DescWords dw;
+        if (kColor) dw = load_descriptor_words(in, kf.lumafp, F, tp, p);
         Assoc r;
-        const bool associated = in_range && project_associate<false>(in, F, kfs[k].geom, gp, gn, &r, nullptr);
+        const bool associated = in_range && associate_from_words<false>(in, F, gn, p, pix, &r, nullptr);
+        if (kColor) gathers_arrived(pix, dw);
+        else gathers_arrived(pix);
+        flush_pending();
         if (!__any(associated)) return;
-        float cv[kCellFloats];
-#pragma unroll
-        for (int c = 0; c < kCellFloats; ++c) cv[c] = 0.f;
-        int cell = -1;
         if (associated) {
           const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
           if (kDepth) {
-            // B/kernel_opt_intrinsics.cu:81-120
+            // B/kernel_opt_intrinsics.cu:81-120.  cfactor of the pixel's cell and the raw depth: the words the association
+            // already loaded (the geometry plane's low half is the keyframe's depth image)
             const int sparse_px = r.px / in.cell, sparse_py = r.py / in.cell;
-            const float cfactor = pitched_load(in.cfactor, in.cfactor_pitch, sparse_py, sparse_px);
-            const float raw_inv_depth = 1.0f / (in.raw_to_float_depth * pitched_load(kfs[k].depth, kfs[k].depth_pitch, r.py, r.px));
+            const float cfactor = pix.cfactor;
+            const float raw_inv_depth = 1.0f / (in.raw_to_float_depth * (uint16_t)(pix.geom & 0xffffu));
             const float exp_inv_depth = expf(-in.a * raw_inv_depth);
             const float corrected = cfactor * exp_inv_depth + raw_inv_depth;
             if (fabsf(corrected) > 1e-4f) {
@@ -95,60 +213,40 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
               const float wr = w * raw;
 #pragma unroll
               for (int c = 0; c < kARows; ++c) acc[15 + c] += wr * J[c];
-              cell = sparse_px + sparse_py * in.cf_width;
+              pending_cell = (((sparse_py >> kBinShift) * bins.bins_x + (sparse_px >> kBinShift)) << (2 * kBinShift)) |
+                             ((sparse_py & ((1 << kBinShift) - 1)) << kBinShift) | (sparse_px & ((1 << kBinShift) - 1));
 #pragma unroll
-              for (int c = 0; c < kARows; ++c) cv[c] = w * J[c] * J[kARows];
-              cv[5] = w * J[kARows] * J[kARows];
-              cv[6] = w * raw * J[kARows];
-              cv[7] = 1.0f;
+              for (int c = 0; c < kARows; ++c) pending[c] = w * J[c] * J[kARows];
+              pending[5] = w * J[kARows] * J[kARows];
+              pending[6] = w * raw * J[kARows];
             }
           }
-          if (kColor) {
-            float cx, cy;
-            if (depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) {
-              DescEval e;
-              eval_descriptor<true>(in, kfs[k].lumafp, F, gp, gn, radius_sq, cx, cy, d1, d2, &e);
-              // B/kernel_opt_intrinsics.cu:142-150,200-215: validity flag is "residual != 0"
+          if (kColor && dw.color_ok) {
+            DescEval e;
+            eval_descriptor_from_words(in, kf.lumafp, dw, d1, d2, &e);
+            // B/kernel_opt_intrinsics.cu:142-150,200-215: validity flag is "residual != 0"
 #pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                const float gx = t ? e.gx2 : e.gx1, gy = t ? e.gy2 : e.gy1, raw = t ? e.r2 : e.r1;
-                if (raw != 0) {
-                  float J[4];
-                  jac_descriptor_color_intrinsics(gx, gy, nx, ny, J);
-                  const float w = descriptor_residual_weight(raw);
-                  int q = 20;
+            for (int t = 0; t < 2; ++t) {
+              const float gx = t ? e.gx2 : e.gx1, gy = t ? e.gy2 : e.gy1, raw = t ? e.r2 : e.r1;
+              if (raw != 0) {
+                float J[4];
+                jac_descriptor_color_intrinsics(gx, gy, nx, ny, J);
+                const float w = descriptor_residual_weight(raw);
+                int q = 20;
 #pragma unroll
-                  for (int row = 0; row < 4; ++row)
+                for (int row = 0; row < 4; ++row)
 #pragma unroll
-                    for (int col = row; col < 4; ++col) acc[q++] += w * J[row] * J[col];
-                  const float wr = w * raw;
+                  for (int col = row; col < 4; ++col) acc[q++] += w * J[row] * J[col];
+                const float wr = w * raw;
 #pragma unroll
-                  for (int c = 0; c < 4; ++c) acc[30 + c] += wr * J[c];
-                }
+                for (int c = 0; c < 4; ++c) acc[30 + c] += wr * J[c];
               }
             }
           }
         }
-        if (kDepth) {
-          // transpose through LDS: afterwards lanes 8 s .. 8 s + 7 of pass j carry the 8 values of the surfel in lane 8 j + s
-          const unsigned long long contributing = __ballot(cell >= 0);
-          if (contributing) {
-            float* mine = xpose + lane * (kCellFloats + 1);
-#pragma unroll
-            for (int c = 0; c < kCellFloats; ++c) mine[c] = cv[c];
-            mine[kCellFloats] = __int_as_float(cell);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (!((contributing >> (8 * j)) & 0xffull)) continue;   // wave-uniform
-              const float* src = xpose + (8 * j + (lane >> 3)) * (kCellFloats + 1);
-              const int c = __float_as_int(src[kCellFloats]);
-              if (c >= 0) unsafeAtomicAdd(&cells[(size_t)c * kCellFloats + (lane & 7)], (double)src[lane & 7]);
-            }
-            __builtin_amdgcn_wave_barrier();   // the next candidate overwrites the buffer
-          }
-        }
+        reserve_pending();
       });
+  flush_pending();
 
   float mine = 0.f;
 #pragma unroll
@@ -157,6 +255,52 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
     if (lane == q) mine = v;
   }
   if (lane < 34 && mine != 0.f) unsafeAtomicAdd(&glob[lane], (double)mine);
+}
+
+// The records of one slice of one block's append buffer, added into a table in LDS and from there into the global per-cell
+// accumulators (see the head of this file).
+__global__ void __launch_bounds__(kBinReduceBlock)
+intrinsics_bin_reduce_kernel(IntrBins bins, int slices_per_bin, int cf_width, int cf_height, double* __restrict__ cells) {
+  // kCellFloats planes of kBinCells doubles: the 64 lanes of one ds_add_f64 carry the same value index c of 64 records, and with
+  // the records side by side (cell * 8 + c) they would meet in 4 of the 64 banks
+  extern __shared__ double table[];
+  const int buffer = blockIdx.x / slices_per_bin, slice = blockIdx.x % slices_per_bin, block = buffer / kBinSubs;
+  const uint32_t count = min(bins.cursors[buffer], bins.capacity);   // the cursor keeps counting past the capacity (the host reads it)
+  const uint32_t begin = (uint32_t)slice * kBinSlice;
+  if (begin >= count) return;
+  const uint32_t end = min(count, begin + kBinSlice);
+  for (int e = threadIdx.x; e < kBinCells * kCellFloats; e += kBinReduceBlock) table[e] = 0.0;
+  __syncthreads();
+  const uint32_t* rec = bins.records + (size_t)buffer * kCellFloats * bins.capacity;
+  // kBinUnroll records per thread and round, all their loads in flight before the first addition
+  constexpr int kBinUnroll = 4;
+  for (uint32_t r0 = begin + threadIdx.x; r0 < end; r0 += kBinUnroll * kBinReduceBlock) {
+    uint32_t within[kBinUnroll];
+    float v[kBinUnroll][kCellFloats - 1];
+#pragma unroll
+    for (int u = 0; u < kBinUnroll; ++u) {
+      const uint32_t r = min(r0 + u * kBinReduceBlock, end - 1);   // clamped: loaded, not added
+      within[u] = rec[r];
+#pragma unroll
+      for (int c = 0; c < kCellFloats - 1; ++c) v[u][c] = __uint_as_float(rec[(size_t)(c + 1) * bins.capacity + r]);
+    }
+#pragma unroll
+    for (int u = 0; u < kBinUnroll; ++u) {
+      if (r0 + u * kBinReduceBlock >= end) break;
+#pragma unroll
+      for (int c = 0; c < kCellFloats - 1; ++c) atomicAdd(table + c * kBinCells + within[u], (double)v[u][c]);
+      atomicAdd(table + (kCellFloats - 1) * kBinCells + within[u], 1.0);
+    }
+  }
+  __syncthreads();
+  const int bx = block % bins.bins_x, by = block / bins.bins_x;
+  for (int e = threadIdx.x; e < kBinCells * kCellFloats; e += kBinReduceBlock) {
+    const int within = e / kCellFloats, c = e % kCellFloats;   // 8 consecutive lanes: the record of one cell, one request
+    const double v = table[c * kBinCells + within];
+    if (v == 0.0) continue;
+    const int cx = (bx << kBinShift) + (within & ((1 << kBinShift) - 1)), cy = (by << kBinShift) + (within >> kBinShift);
+    unsafeAtomicAdd(&cells[((size_t)cy * cf_width + cx) * kCellFloats + c], v);
+  }
 }
 
 // Schur complement: B/kernel_opt_intrinsics.cu:266-350.  One thread per sparse cell.  This runs AFTER the multi-GPU
@@ -204,17 +348,28 @@ intrinsics_schur_kernel(int S, float* __restrict__ partials /* [wavefronts][20] 
   const int wave = (blockIdx.x * kIntrBlock + threadIdx.x) >> 6;
   if (lane < 20) partials[(size_t)wave * 20 + lane] = mine;
 }
-// glob_f[q] = (float)glob_d[q] for the 34 global sums [+ the Schur total of sum q < 20 when num_waves > 0]
-__global__ void __launch_bounds__(64)
+// glob_f[q] = (float)glob_d[q] for the 34 global sums [+ the Schur total of sum q < 20 when num_waves > 0].  The Schur total is a
+// chain over the wavefronts' partials in order; the workgroup stages them through LDS in pieces (a chain of dependent global
+// loads took 0.2 ms at 640 x 480), threads 0 .. 19 add.
+constexpr int kFinishBlock = 256, kFinishPiece = 128;   // wavefront partials per piece
+__global__ void __launch_bounds__(kFinishBlock)
 intrinsics_finish_kernel(int num_waves, const float* __restrict__ partials, const double* __restrict__ glob_d, float* __restrict__ glob_f) {
+  __shared__ float piece[kFinishPiece * 20];
   const int q = threadIdx.x;
+  float total = 0.f;
+  for (int first = 0; first < num_waves; first += kFinishPiece) {
+    const int n = min(kFinishPiece, num_waves - first) * 20;
+    for (int e = threadIdx.x; e < n; e += kFinishBlock) piece[e] = partials[(size_t)first * 20 + e];
+    __syncthreads();
+    if (q < 20) {
+#pragma unroll 8
+      for (int w = 0; w < n / 20; ++w) total += piece[w * 20 + q];
+    }
+    __syncthreads();
+  }
   if (q >= 34) return;
   float value = (float)glob_d[q];
-  if (q < 20 && num_waves > 0) {
-    float total = 0.f;
-    for (int w = 0; w < num_waves; ++w) total += partials[(size_t)w * 20 + q];
-    value += total;
-  }
+  if (q < 20 && num_waves > 0) value += total;
   glob_f[q] = value;
 }
 
@@ -238,13 +393,24 @@ intrinsics_solve_cells_kernel(Intrinsics in, int S, float* __restrict__ cells, c
   *p = value;
 }
 
+int intrinsics_bin_count(const Intrinsics& in, int* bins_x_out) {
+  const int bins_x = (in.cf_width + (1 << kBinShift) - 1) >> kBinShift, bins_y = (in.cf_height + (1 << kBinShift) - 1) >> kBinShift;
+  if (bins_x_out) *bins_x_out = bins_x;
+  return bins_x * bins_y * kBinSubs;   // append buffers
+}
+size_t intrinsics_bin_record_bytes() { return kCellFloats * sizeof(uint32_t); }
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, double* glob, double* cells) {
+                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins) {
   if (!s.size) return;
-  const dim3 grid((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock), block(kIntrSweepBlock);
-  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells);
-  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells);
-  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells);
+  const dim3 grid(xcd_padded_tiles((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock)), block(kIntrSweepBlock);
+  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins);
+  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins);
+  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins);
+  if (depth && bins.capacity) {
+    const int slices = (int)((bins.capacity + kBinSlice - 1) / kBinSlice);
+    hipLaunchKernelGGL(intrinsics_bin_reduce_kernel, dim3((unsigned)(intrinsics_bin_count(in, nullptr) * slices)), dim3(kBinReduceBlock),
+                       kBinCells * kCellFloats * sizeof(double), st, bins, slices, in.cf_width, in.cf_height, cells);
+  }
 }
 size_t intrinsics_schur_partials(int S) { return 20 * (size_t)((S + kIntrBlock - 1) / kIntrBlock) * (kIntrBlock / 64); }
 void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* glob_d, const double* cells_d, float* glob_f, float* cells_f,
@@ -255,7 +421,7 @@ void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* g
     hipLaunchKernelGGL(intrinsics_schur_kernel, dim3(blocks), dim3(kIntrBlock), 0, st, S, partials, cells_d, cells_f);
     waves = blocks * (kIntrBlock / 64);
   }
-  hipLaunchKernelGGL(intrinsics_finish_kernel, dim3(1), dim3(64), 0, st, waves, partials, glob_d, glob_f);
+  hipLaunchKernelGGL(intrinsics_finish_kernel, dim3(1), dim3(kFinishBlock), 0, st, waves, partials, glob_d, glob_f);
 }
 void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, float* cells, const float* x1, float* cfactor,
                                    uint32_t cfactor_pitch) {

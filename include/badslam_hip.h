@@ -377,6 +377,12 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
  * 1 = one wavefront per surfel tile, tile totals added to the normal equations with global 64-bit integer atomics (the only form
  * for shards and for more work items than fit the table); 2 = persistent workgroups, one per compute unit, that keep the normal
  * equations of every work item in LDS and flush them once (whenever the table fits 128 KB: up to 292 work items). */
+/* The intrinsics sweep appends its per-cell records to buffers sized from the previous call's demand (kernels_intrinsics.hip);
+ * records that do not fit go out as atomics, with the same result.  records_per_block >= 0 fixes the size (0: no buffers, < 0:
+ * automatic again) -- for the tests of the overflow path and for A/B timing.  bahip_debug_intrinsics_bin_stats: capacity and the
+ * largest / total demand of the last call. */
+int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block);
+int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out);
 int bahip_debug_set_pose_form(int form);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):
  * out[3 i .. 3 i + 2] = limb 0 (weight 2^-32), limb 1 (weight 1), valid (0: not finite or 2^52 and beyond -- such a total is

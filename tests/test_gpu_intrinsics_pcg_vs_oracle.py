@@ -70,6 +70,35 @@ def test_depth_intrinsics_step(scene):
     assert a_g2 == pytest.approx(a_r2, abs=1e-6)
 
 
+@pytest.mark.parametrize("capacity", [-1, 0, 16, 256])
+def test_depth_intrinsics_step_whatever_the_record_buffers_hold(scene, capacity):
+    """The sweep appends its per-cell records to per-block buffers and a second kernel adds them up in LDS; records that find
+    their buffer full go out as atomics (kernels_intrinsics.hip).  Automatic size (-1), no buffers (0), buffers far too small
+    (16 records per buffer: nearly everything overflows) and too small for the busier buffers only (256): the same bits."""
+    import ctypes as C
+    ba, g = _perturbed_pair(scene)
+    ba.use_depth, ba.use_desc = 1, 1
+    lib, h = g.ctx.lib, g.ctx.handle
+    assert lib.bahip_debug_set_intrinsics_bin_capacity(h, capacity) == 0
+    _, dc_r, a_r = ba.optimize_intrinsics(True, True)
+    _, dc_g, a_g = g.optimize_intrinsics(True, True)
+    cap, most, total = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    assert lib.bahip_debug_intrinsics_bin_stats(h, C.byref(cap), C.byref(most), C.byref(total)) == 0
+    if capacity == 0:
+        assert cap.value == 0
+    else:
+        assert total.value > 100000 and most.value > 256          # the scene's pairs went through the reservation
+        assert (most.value > cap.value) == (capacity > 0), (cap.value, most.value)
+    assert np.array_equal(_bits(_cam_tuple(dc_g)), _bits(_cam_tuple(dc_r))), (_cam_tuple(dc_g), _cam_tuple(dc_r))
+    assert np.array_equal(_bits([a_g]), _bits([a_r]))
+    assert np.array_equal(_bits(g.cfactor.download()), _bits(ba.cfactor))
+    if capacity == -1:
+        # the next call sizes its buffers from this call's demand
+        g.optimize_intrinsics(True, True)
+        assert lib.bahip_debug_intrinsics_bin_stats(h, C.byref(cap), C.byref(most), C.byref(total)) == 0
+        assert most.value <= cap.value
+
+
 def test_color_intrinsics_step(scene):
     ba, g = _perturbed_pair(scene, depth_cam_offset=(0, 0, 0, 0), color_cam_offset=(0.4, -0.3, 0.8, -0.6))
     ba.use_depth, ba.use_desc = 1, 1

@@ -208,3 +208,77 @@ def test_sharded_intrinsics_step_is_the_unsharded_step():
     cf = [x["scene"].cfactor.download() for x in (results[0], results[1], ref)]
     assert np.array_equal(cf[0].view(np.uint32), cf[2].view(np.uint32)) and np.array_equal(cf[1].view(np.uint32), cf[2].view(np.uint32))
     assert np.count_nonzero(cf[2]) > 0.5 * cf[2].size
+
+
+@pytest.mark.parametrize("use_pcg", [False, True])
+def test_sharded_bundle_adjustment_with_surfel_updates_is_the_unsharded_run(use_pcg):
+    """DirectBA::BundleAdjustment with do_surfel_updates = true on two surfel shards (DirectBA::SetSurfelSharding): creation,
+    merging, deletion and compaction need the whole cloud -- is this pixel already supported, which surfels of a cell merge,
+    where do the last surfels move --, so those phases gather it on every rank (bahip_gather_surfel_shards: int64 sums of
+    disjoint rows), run unchanged and take the shard back out.  Starting from NO surfels, two calls of two iterations each
+    (creation in the first, merging / deletion / compaction in both) must leave the union of the shards equal to the
+    unsharded cloud and the poses equal, bit for bit."""
+    import torch
+    from badslam_amd import capi, multigpu
+    from badslam_amd.directba import DirectBA
+    torch.cuda.set_device(0)
+    scene = common.small_scene(num_keyframes=6, seed=17)
+    rng = np.random.Generator(np.random.PCG64(9))
+    start = [common.synthetic.perturb_pose(rng, T, 0.002, 0.0005) for T in scene.poses_gt]
+    CHUNK = 1024
+
+    def build():
+        ba = DirectBA(600000, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, scene.width, scene.height, scene.camera, scene.camera)
+        for k in range(len(scene.depth)):
+            ba.AddKeyframe(scene.depth[k], scene.rgb[k], start[k])
+        ba.set_pcg_gauge_keyframe(0)
+        return ba
+
+    def run(ba):
+        sizes = []
+        for _ in range(2):
+            ba.BundleAdjustment(do_surfel_updates=True, optimize_poses=True, optimize_geometry=True, min_iterations=2, max_iterations=2,
+                                use_pcg=use_pcg, increase_ba_iteration_count=True)
+            sizes.append(ba.surfels_size())
+        return dict(sizes=sizes, surfels=ba.download_surfels(8), poses=[ba.keyframe_pose(k) for k in range(len(start))])
+
+    ref = run(build())
+    N = ref["surfels"].shape[1]
+    assert N > 10000 and ref["sizes"][1] != ref["sizes"][0]                     # the second call changed the cloud again
+
+    loop = _Loopback(WORLD)
+    results, errors = [None] * WORLD, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            ba = build()
+            hook = loop.hook_for(rank)
+            ctx = ba.backend_context()
+            capi.check(ctx.lib.bahip_context_set_allreduce(ctx.handle, hook, None))
+            ba.SetSurfelSharding(rank, WORLD, CHUNK)
+            out = run(ba)
+            out["keep"] = (hook, ba)
+            results[rank] = out
+        except Exception as e:
+            errors.append((rank, repr(e)))
+            loop.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    # the shards are the chunk-cyclic partition of the unsharded cloud, after either call
+    for call in range(2):
+        assert sum(r["sizes"][call] for r in results) == ref["sizes"][call]
+    merged = np.zeros_like(ref["surfels"])
+    for rank, r in enumerate(results):
+        mine = multigpu.shard_chunks(N, rank, WORLD, chunk=CHUNK)
+        assert r["surfels"].shape[1] == mine.size
+        merged[:, mine] = r["surfels"]
+    assert np.array_equal(merged.view(np.uint32), ref["surfels"].view(np.uint32))
+    for k in range(len(start)):
+        assert np.array_equal(results[0]["poses"][k], results[1]["poses"][k]) and np.array_equal(ref["poses"][k], results[0]["poses"][k]), k
