@@ -1168,7 +1168,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
     uint64_t want = ctx->intr_bin_wanted;
     if (!want) want = (uint64_t)surfels->surfels_size * (uint64_t)std::min(ctx->num_kfs, 16) * 2 / (uint64_t)num_bins + 4096;
     if (ctx->intr_bin_forced >= 0) want = (uint64_t)ctx->intr_bin_forced;
-    const uint64_t limit = (32ull << 30) / (intrinsics_bin_record_bytes() * (uint64_t)num_bins);   // at most 32 GB of records
+    const uint64_t limit = (96ull << 30) / (intrinsics_bin_record_bytes() * (uint64_t)num_bins);   // at most 96 GB of records
     want = std::min(want, limit);
     if (want > ctx->intr_bin_capacity || (ctx->intr_bin_forced >= 0 && want != ctx->intr_bin_capacity)) {
       hipFree(ctx->intr_bin_records);

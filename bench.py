@@ -80,12 +80,18 @@ def build_scene(args, log):
     t0 = time.time()
     rng = np.random.Generator(np.random.PCG64(args.seed))
     cam = synthetic.test_camera(args.width, args.height)
-    planes = synthetic.random_planes(rng, 20, slope=args.plane_slope)
     T0 = se3.exp([0.01, 0.02, 0.03, 0.004, 0.005, 0.006])
     ext = np.array([args.extent_x, args.extent_y, args.extent_z])
-    # small scenes (parity configs) shrink the extent with the keyframe count so coverage stays the same
-    ext[:2] *= np.sqrt(args.keyframes / 200.0 * (args.width * args.height) / (640.0 * 480.0))
     cells = ((args.width - 1) // args.cell + 1) * ((args.height - 1) // args.cell + 1)
+    # The area the keyframes spread over follows the surfel count asked for: a frame shows the same piece of the world at every
+    # resolution, and the surfels it creates are one per sparse cell of the part nobody covered yet, so
+    # (surfels created) ~ area x cells per frame.  The defaults (configs[2]: 3 M surfels, 320 x 240 cells) are scale 1 and
+    # yield 3.02 M; configs[4] (20 M, 640 x 480 cells, 1000 keyframes) gets 1.67 x that area and 5 x the keyframes, i.e. every
+    # surfel in ~50 keyframes.  "All the surfels the keyframes create" (surfels >= 1e8, the parity slices) keeps the
+    # observations per surfel of the defaults instead: area ~ keyframes.
+    scale2 = (args.surfels / 3.0e6) * (76800.0 / cells) if args.surfels < 10 ** 8 else args.keyframes / 200.0
+    ext[:2] *= np.sqrt(scale2)
+    planes = synthetic.random_planes(rng, 20, slope=args.plane_slope)
     cap = args.keyframes * cells + 1024   # worst case: no overlap between keyframes (288 GB of HBM: not a concern)
     if args.launch_shapes:
         from badslam_amd import capi
@@ -95,10 +101,17 @@ def build_scene(args, log):
     poses_gt = []
     for k in range(args.keyframes):
         xi = np.concatenate([ext * (rng.random(3) - 0.5), args.rotation_range * (rng.random(3) - 0.5)])
-        T = se3.mul(T0, se3.exp(xi))
-        raw, rgb = synthetic.render_planes(T, planes, cam, args.width, args.height, 1.0 / 5000)
+        if scale2 <= 1.0:
+            poses_gt.append(se3.mul(T0, se3.exp(xi)))
+        else:
+            # exp() of a twist moves the camera by ~ 1/2 omega x t along its axis as well: 1.3 m at the corners of the default
+            # area (part of that scene's depth variety), but on a wider area it carries the corner cameras into the walls
+            # (depth 0.04 .. 0.2 m; those poses never settle).  There: translation, then rotation.
+            poses_gt.append(se3.mul(T0, se3.mul(se3.exp(np.concatenate([xi[:3], np.zeros(3)])), se3.exp(np.concatenate([np.zeros(3), xi[3:]])))))
+    # rendered on a pool of host processes (the same frames in the same order whatever the pool size), preprocessed on the GPU
+    workers = None if args.keyframes * args.width * args.height >= 64 * 640 * 480 else 1
+    for T, (raw, rgb) in zip(poses_gt, synthetic.render_many(poses_gt, planes, cam, args.width, args.height, 1.0 / 5000, workers)):
         ba.AddKeyframe(raw, rgb, T)
-        poses_gt.append(T)
     log(f"rendered + preprocessed {args.keyframes} keyframes in {time.time() - t0:.1f}s")
     t1 = time.time()
     # surfels from the keyframes (unfiltered creation, reference B/direct_ba.cc:340-405)
@@ -108,7 +121,14 @@ def build_scene(args, log):
         per_kf.append(ba.surfels_size() - before)
         before = ba.surfels_size()
     created = ba.surfels_size()
-    if created > args.surfels:
+    if created > 1.02 * args.surfels:
+        # far more than asked for (the estimate above is tuned at the defaults): an even subset, so that every keyframe keeps
+        # its share of surfels -- a prefix would leave the last keyframes with next to nothing to estimate their poses from
+        everything = ba.download_surfels(rows=SURFEL_ROWS)
+        keep = (np.arange(args.surfels, dtype=np.int64) * created) // args.surfels
+        ba.upload_surfels(np.ascontiguousarray(everything[:, keep]))
+        del everything
+    elif created > args.surfels:
         ba.SetSurfelCount(args.surfels, args.surfels)
     if not args.no_spatial_sort:
         # maintenance step of the backend (DirectBA::SortSurfelsSpatially, not per iteration): surfels that an image

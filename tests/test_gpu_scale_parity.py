@@ -406,3 +406,52 @@ def test_c2_size_end_to_end_with_surfel_updates():
     # are in fact the same bits
     assert np.array_equal(got_poses.astype(np.float32), ref_poses.astype(np.float32))
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+# ---- (e): BASELINE configs[4]'s resolution, joint BA with the intrinsics -------------------------------------------------
+def test_c5_resolution_slice_with_intrinsics_matches_oracle():
+    """A 20-keyframe slice of configs[4]: 1280 x 960 images (640 x 480 sparse cells: 300 blocks of append buffers in the
+    intrinsics sweep, descriptor Jacobians 4 x those of 640 x 480 in the pose sums), every surfel the keyframes create, one
+    iteration of the alternating scheme over geometry, poses, depth intrinsics + deformation and colour intrinsics."""
+    ba, data, poses_gt, args = _bench_scene(width=1280, height=960, keyframes=20, surfels=10 ** 9)
+    K = ba.keyframe_count()
+    n = data.shape[1]
+    assert n > 1000000, n
+    ba.upload_surfels(data)
+    # perturbed cameras, so that the intrinsics step has something to do (as tests/test_gpu_intrinsics_pcg_vs_oracle.py)
+    cam = synthetic.test_camera(args.width, args.height).astype(np.float64)
+    depth_cam = cam + np.array([0.5, -0.6, 1.23, -2.17])
+    color_cam = cam + np.array([0.4, -0.3, 0.8, -0.6])
+    ba.set_cameras(color_cam, depth_cam, 0.0)
+    orc = _oracle_from_directba(ba, args, data)
+    for name, values in (("depth_cam", depth_cam), ("color_cam", color_cam)):
+        c = getattr(orc, name)
+        c.fx, c.fy, c.cx, c.cy = [float(np.float32(v)) for v in values]
+    ba.set_ba_iteration_counts(1, 1)               # equal counters: no end-of-scheme tasks (fixed surfel set)
+    done, _ = ba.BundleAdjustment(optimize_depth_intrinsics=True, optimize_color_intrinsics=True, do_surfel_updates=False,
+                                  optimize_poses=True, optimize_geometry=True, min_iterations=1, max_iterations=1,
+                                  active_keyframe_window_start=0, active_keyframe_window_end=K - 1, increase_ba_iteration_count=False)
+    orc.ba_iteration_count, orc.last_ba_iteration_count = 1, 1
+    orc.use_depth, orc.use_desc = 1, 1
+    stats = orc.bundle_adjustment(optimize_depth_intrinsics=True, optimize_color_intrinsics=True, do_surfel_updates=False,
+                                  optimize_poses=True, optimize_geometry=True, min_iterations=1, max_iterations=1,
+                                  increase_ba_iteration_count=False)
+    assert done == stats.iterations_done == 1
+    got = ba.download_surfels(8)
+    ref = orc.surfel_data[:8, :n]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    got_poses = np.array([ba.keyframe_pose(k) for k in range(K)])
+    ref_poses = np.array([orc.pose(k) for k in range(K)])
+    rmse = float(np.sqrt(np.mean(np.sum((got_poses[:, 4:] - ref_poses[:, 4:]) ** 2, axis=1))))
+    assert rmse <= 1e-5, rmse                                                    # the north-star gate
+    assert np.array_equal(got_poses.astype(np.float32), ref_poses.astype(np.float32))
+    cc, dc, a = ba.cameras()
+    ref_dc = np.array([orc.depth_cam.fx, orc.depth_cam.fy, orc.depth_cam.cx, orc.depth_cam.cy], np.float32)
+    ref_cc = np.array([orc.color_cam.fx, orc.color_cam.fy, orc.color_cam.cx, orc.color_cam.cy], np.float32)
+    moved = np.abs(ref_dc - depth_cam.astype(np.float32)).max()
+    print(f"1280 x 960 slice: {n} surfels, pose RMSE vs oracle {rmse:.2e} m, depth camera moved by up to {moved:.3f} px, a = {orc.dp.a:.3e}")
+    assert moved > 0.1                                                           # the step did something
+    assert np.array_equal(np.asarray(dc, np.float32).view(np.uint32), ref_dc.view(np.uint32)), (dc, ref_dc)
+    assert np.array_equal(np.asarray(cc, np.float32).view(np.uint32), ref_cc.view(np.uint32)), (cc, ref_cc)
+    assert np.float32(a).view(np.uint32) == np.float32(orc.dp.a).view(np.uint32)
+    assert np.array_equal(ba.cfactor().view(np.uint32), np.asarray(orc.cfactor, np.float32).view(np.uint32))
