@@ -1587,6 +1587,13 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
   return 0;
 }
 
+int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset) {
+  long long n[2];
+  pose_form_launches(n, reset != 0);
+  if (global_form) *global_form = n[0];
+  if (lds_form) *lds_form = n[1];
+  return 0;
+}
 int bahip_debug_set_pose_form(int form) {
   REQUIRE(form == 0 || form == 1 || form == 2, "pose form must be 0 (automatic), 1 (one tile per wavefront, global atomics) or 2 (persistent, LDS table)");
   set_pose_form(form);

@@ -269,6 +269,8 @@ intrinsics_bin_reduce_kernel(IntrBins bins, int slices_per_bin, int cf_width, in
   const uint32_t begin = (uint32_t)slice * kBinSlice;
   if (begin >= count) return;
   const uint32_t end = min(count, begin + kBinSlice);
+  // (the observation counts, plane 7, are integers: 32-bit LDS atomics are several times faster than ds_add_f64)
+  uint32_t* counts = reinterpret_cast<uint32_t*>(table + (kCellFloats - 1) * kBinCells);
   for (int e = threadIdx.x; e < kBinCells * kCellFloats; e += kBinReduceBlock) table[e] = 0.0;
   __syncthreads();
   const uint32_t* rec = bins.records + (size_t)buffer * kCellFloats * bins.capacity;
@@ -289,14 +291,14 @@ intrinsics_bin_reduce_kernel(IntrBins bins, int slices_per_bin, int cf_width, in
       if (r0 + u * kBinReduceBlock >= end) break;
 #pragma unroll
       for (int c = 0; c < kCellFloats - 1; ++c) atomicAdd(table + c * kBinCells + within[u], (double)v[u][c]);
-      atomicAdd(table + (kCellFloats - 1) * kBinCells + within[u], 1.0);
+      atomicAdd(counts + within[u], 1u);
     }
   }
   __syncthreads();
   const int bx = block % bins.bins_x, by = block / bins.bins_x;
   for (int e = threadIdx.x; e < kBinCells * kCellFloats; e += kBinReduceBlock) {
     const int within = e / kCellFloats, c = e % kCellFloats;   // 8 consecutive lanes: the record of one cell, one request
-    const double v = table[c * kBinCells + within];
+    const double v = c < kCellFloats - 1 ? table[c * kBinCells + within] : (double)counts[within];
     if (v == 0.0) continue;
     const int cx = (bx << kBinShift) + (within & ((1 << kBinShift) - 1)), cy = (by << kBinShift) + (within >> kBinShift);
     unsafeAtomicAdd(&cells[((size_t)cy * cf_width + cx) * kCellFloats + c], v);

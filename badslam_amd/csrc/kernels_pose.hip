@@ -32,6 +32,9 @@ constexpr int kPoseBlock = 64;    // one wavefront per workgroup: no LDS, no bar
 
 // acc += w * [upper(J J^T) | r J], as fused multiply-add chains (the oracle's orc_accumulate_pose_coeffs spells the same chain:
 // the per-lane sums, the wave tree and the fixed-point totals are part of the numerical definition, ba_device.h: HbFixed).
+// (Two entries per instruction with v_pk_fma_f32 -- entries (r, c) (r, c + 1) for even c, 45 VALU instructions fewer per pair,
+// bit-identical -- was measured in round 3: the pose sweep got 3 % SLOWER.  gfx950 issues a plain wave64 binary32 instruction
+// in about half the cycles of a packed one, so packing buys nothing here and costs register-pair alignment.)
 __device__ __forceinline__ void accumulate_jtj(float (&acc)[28], const float (&J)[6], float wgt, float raw) {
   int q = 0;
 #pragma unroll
@@ -607,6 +610,11 @@ size_t pose_tile_bounds_bytes(uint32_t surfels) {
 // form whenever the table fits (tests run both: same bits)
 static int g_forced_pose_form = [] { const char* e = getenv("BAHIP_POSE_FORM"); return e ? atoi(e) : 0; }();
 void set_pose_form(int form) { g_forced_pose_form = form; }
+static long long g_pose_form_launches[2] = {0, 0};   // [0] one tile per wavefront + global atomics, [1] persistent + LDS
+void pose_form_launches(long long out[2], bool reset) {
+  out[0] = g_pose_form_launches[0]; out[1] = g_pose_form_launches[1];
+  if (reset) g_pose_form_launches[0] = g_pose_form_launches[1] = 0;
+}
 constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a compute unit
 
 template <bool kUseDepth, bool kUseDesc>
@@ -649,6 +657,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   const size_t table_bytes = sizeof(HbFixed) * kHbStride * (size_t)(stored_bounds ? num_listed : num_work);
   const bool lds_form = tile_counters != nullptr && table_bytes <= kPoseLdsTableLimit &&
                         (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && parts == 1 && forced == 0));
+  ++g_pose_form_launches[lds_form ? 1 : 0];
   if (lds_form) {
     const int parity = *parity_inout;
     *parity_inout = parity ^ 1;

@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: peak FP32 (vector)
 SURFEL_ROWS = 17        # BAHIP_SURFEL_ATTRIBUTE_COUNT
 STAGES = ("surfel_activation", "geometry_optimization", "pose_accumulate", "pose_solve", "intrinsics_optimization")
 
@@ -173,7 +174,8 @@ def pmc_kernel_entry(pmc, source, kernel_prefix):
             fetch = counters["FETCH_SIZE"]["avg_per_launch"] * 1024.0 * cal["factor"]
             write = counters.get("WRITE_SIZE", {"avg_per_launch": 0.0})["avg_per_launch"] * 1024.0
             out = {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "fetch_factor": cal["factor"], "source": source}
-            for key in ("valu_issue_fraction", "valu_cycles_per_instruction"):
+            for key in ("valu_issue_fraction", "valu_cycles_per_instruction", "fp32_flops_per_launch", "non_arithmetic_valu_fraction",
+                        "valu_fraction_int32", "valu_fraction_int64", "valu_fraction_cvt"):
                 if key in counters:
                     out[key] = counters[key]
             return out
@@ -335,6 +337,7 @@ def main():
     # stages are timed in a few extra iterations afterwards, so their ten event records per iteration stay out of `value`
     capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 3))
     capi.check(ctx.lib.bahip_exchange_stats(ctx.handle, None, None, 1))
+    capi.check(ctx.lib.bahip_debug_pose_form_launches(None, None, 1))
     ctx.synchronize()
     if dist is not None:
         dist.barrier()
@@ -364,6 +367,8 @@ def main():
         return out_ms, out_n
 
     stage_ms, stage_launches = read_stage_timers()             # stage 2 over the timed region
+    form_global, form_lds = C.c_longlong(), C.c_longlong()
+    capi.check(ctx.lib.bahip_debug_pose_form_launches(C.byref(form_global), C.byref(form_lds), 0))
     units = C.c_longlong()
     capi.check(ctx.lib.bahip_stage_work_units(ctx.handle, 2, C.byref(units)))
     BREAKDOWN_STEPS = 5                                         # untimed: per-stage breakdown of the iterations that follow
@@ -459,17 +464,30 @@ def main():
             out["algorithmic_bytes_per_iteration"] = b_alg_iter
             out["iteration_fraction_of_hbm_roofline"] = b_alg_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9)
             pmc, pmc_source = committed_profile(args) if (world == 1 and shard_world == 1) else (None, None)
-            traffic = pmc_kernel_entry(pmc, pmc_source, "pose_accumulate_kernel<true, true>")
-            out["roofline"] = {"bound": "hbm", "kernel": "pose_accumulate_kernel<true,true>", "achieved": achieved,
+            # the pose sums have two kernels (kernels_pose.hip): persistent workgroups with the normal equations in LDS when the
+            # table of the launch's work items fits, one tile per wavefront with global atomics otherwise; the line names the one
+            # most of the timed launches used
+            lds = form_lds.value >= form_global.value
+            pose_kernel = "pose_accumulate_lds_kernel<true, true>" if lds else "pose_accumulate_kernel<true, true>"
+            traffic = pmc_kernel_entry(pmc, pmc_source, pose_kernel)
+            flops = traffic.get("fp32_flops_per_launch") if traffic else None
+            out["roofline"] = {"bound": "hbm", "kernel": pose_kernel.replace(", ", ","), "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": traffic["bytes"] if traffic else None,
                                "traffic_source": traffic["source"] if traffic else None,
                                "traffic_fetch_factor": traffic["fetch_factor"] if traffic else None,
                                "algorithmic_bytes_per_launch": bytes_pose_launch, "avg_launch_ms": avg_ms, "launches": launches,
+                               "launches_by_form": {"lds": int(form_lds.value), "global_atomics": int(form_global.value)},
                                "keyframes_per_launch": kf_per_launch,
-                               "limiter": "instruction issue, not HBM: ~700 VALU + ~150 scalar instructions per visited (surfel tile, "
-                                          "keyframe) candidate at 4 wavefronts per SIMD (125 VGPRs); measured ceiling 2.7 cycles per "
+                               "limiter": "instruction issue, not HBM: the sweep is ~700 VALU + ~150 scalar instructions per visited "
+                                          "(surfel tile, keyframe) candidate at 4 wavefronts per SIMD; measured ceiling 2.7 cycles per "
                                           "VALU instruction per SIMD (scripts/microbench/valu_rate.hip), DESIGN.md section 5",
+                               # binary32 flops of the VALU instruction mix (PMC: 64 lanes x (add + mul + transcendental + 2 fma) wave
+                               # instructions per launch, masked lanes included) over the live launch duration, against the 157.3
+                               # TFLOP/s vector peak; and the share of VALU instructions that are not floating-point arithmetic
+                               "fp32_tflops": flops / (avg_ms * 1e-3) / 1e12 if flops else None,
+                               "frac_of_vector_peak": flops / (avg_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS if flops else None,
+                               "non_arithmetic_valu_fraction": traffic.get("non_arithmetic_valu_fraction") if traffic else None,
                                "valu_issue_fraction": traffic.get("valu_issue_fraction") if traffic else None,
                                "valu_cycles_per_instruction": traffic.get("valu_cycles_per_instruction") if traffic else None}
             # the other sweep of an iteration: activation + normals + position/descriptor step in one launch
@@ -481,6 +499,9 @@ def main():
                                         "frac": bytes_geo / (geo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "traffic": geo_traffic["bytes"] if geo_traffic else None,
                                         "algorithmic_bytes_per_launch": bytes_geo, "avg_launch_ms": geo_ms,
+                                        "fp32_tflops": geo_traffic["fp32_flops_per_launch"] / (geo_ms * 1e-3) / 1e12
+                                                       if geo_traffic and geo_traffic.get("fp32_flops_per_launch") else None,
+                                        "non_arithmetic_valu_fraction": geo_traffic.get("non_arithmetic_valu_fraction") if geo_traffic else None,
                                         "valu_issue_fraction": geo_traffic.get("valu_issue_fraction") if geo_traffic else None}
         else:
             out["config"]["pcg_inner_steps_per_iteration"] = stats["pcg_inner_steps"] / args.steps

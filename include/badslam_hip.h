@@ -384,6 +384,8 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
 int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block);
 int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out);
 int bahip_debug_set_pose_form(int form);
+/* launches of the pose accumulation in either form since the last reset (process-wide); bench.py names the dominant kernel by it */
+int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):
  * out[3 i .. 3 i + 2] = limb 0 (weight 2^-32), limb 1 (weight 1), valid (0: not finite or 2^52 and beyond -- such a total is
  * not added and fails the pose estimation). */

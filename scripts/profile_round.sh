@@ -5,7 +5,9 @@
 # Pass 1: rocprofv3 --kernel-trace --stats (per-kernel time; the bench line of the same command is kept).
 # Passes 2-4: PMC counters alone, one pass each (FETCH_SIZE and WRITE_SIZE share TCC slots), --kernel-trace only as the pool
 # requires: FETCH_SIZE, WRITE_SIZE, and the issue-side counters behind "VALU-issue bound".
-# Pass 5: FETCH_SIZE over reads of known size (scripts/fetch_calibration.py): what the counter reports per byte at the
+# Passes 5-6: the VALU instruction mix (binary32 add / mul / fma / transcendental; integer, conversion and binary64 counts), from
+# which summarize_profile.py derives binary32 flops per launch and the share of VALU instructions that are not arithmetic.
+# Pass 7: FETCH_SIZE over reads of known size (scripts/fetch_calibration.py): what the counter reports per byte at the
 # 4-byte access width of the sweeps.
 set -u
 TAG=${1:-r2}
@@ -17,10 +19,14 @@ export TMPDIR=/tmp
 cd /tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.log"
+if [ -z "${ONLY_STATS:-}" ]; then   # ONLY_STATS=1: the kernel-time table alone (the intrinsics / PCG legs)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_write.log"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_sq.log"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --output-format csv -d "$OUT/pmc_flops" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_flops.log"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 --output-format csv -d "$OUT/pmc_mix" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_mix.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_cal" -- python $REPO/scripts/fetch_calibration.py > "$OUT/cal_bytes.txt" 2> "$OUT/pmc_cal.log"
+fi
 cd "$REPO"
 python scripts/summarize_profile.py "$OUT" "$TAG" $* > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

@@ -51,7 +51,7 @@ def main():
                   f"{float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['Percentage']):6.2f}")
 
     kernels = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mix", "pmc_flops"):
         for k, cs in counters_of(d, sub).items():
             kernels.setdefault(k, {}).update(cs)
     for k, cs in kernels.items():
@@ -62,6 +62,18 @@ def main():
             cycles = cs["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8.0
             cs["valu_cycles_per_instruction"] = 1024.0 * cycles / cs["SQ_INSTS_VALU"]["avg_per_launch"]
             cs["valu_issue_fraction"] = 2.7 / cs["valu_cycles_per_instruction"]
+
+    for k, cs in kernels.items():
+        if all(("SQ_INSTS_VALU_" + c) in cs for c in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")) and cs.get("SQ_INSTS_VALU", {}).get("avg_per_launch", 0) > 0:
+            # wave64 instruction counts; an FMA is two flops, all 64 lanes counted (an upper bound: masked lanes included)
+            n = {c: cs["SQ_INSTS_VALU_" + c]["avg_per_launch"] for c in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")}
+            cs["fp32_flops_per_launch"] = 64.0 * (n["ADD_F32"] + n["MUL_F32"] + n["TRANS_F32"] + 2.0 * n["FMA_F32"])
+            arithmetic = sum(n.values()) + sum(cs.get("SQ_INSTS_VALU_" + c, {"avg_per_launch": 0.0})["avg_per_launch"]
+                                               for c in ("ADD_F64", "MUL_F64", "FMA_F64"))
+            cs["non_arithmetic_valu_fraction"] = 1.0 - arithmetic / cs["SQ_INSTS_VALU"]["avg_per_launch"]
+            for c in ("INT32", "INT64", "CVT"):
+                if "SQ_INSTS_VALU_" + c in cs:
+                    cs["valu_fraction_" + c.lower()] = cs["SQ_INSTS_VALU_" + c]["avg_per_launch"] / cs["SQ_INSTS_VALU"]["avg_per_launch"]
 
     cal = None
     cal_counters = counters_of(d, "pmc_cal").get("read_pattern_kernel")

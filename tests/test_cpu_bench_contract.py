@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _latest(pattern):
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern)) if "config" not in f and "pcg" not in f)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern)) if "config" not in f and "pcg" not in f and "intr" not in f)
     assert files, pattern
     return files[-1]
 
