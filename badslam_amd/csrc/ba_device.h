@@ -77,6 +77,31 @@ __device__ __forceinline__ float sqrt_exact(float x) {
   return (x == 0.f) ? x : t;
 }
 
+// exp of a binary32 argument, defined by explicit binary32 operations (reduction by ln 2 in two pieces, Taylor polynomial of
+// degree 7 on |r| <= ln 2 / 2 in fused multiply-adds, scaled by 2^k): the depth deformation exp(-a / depth) enters every
+// residual once a != 0, and the device library's expf and glibc's differ in the last bit now and then -- with it defined (the
+// oracle restates the same operations) runs that optimise the depth intrinsics stay comparable bit for bit, as sincos_det does
+// for the pose updates; the weights of the preprocessing's bilateral filter use it too.  Within 2 ulp of the correctly rounded
+// value (the reference's own expf is CUDA's, documented at 2 ulp); 14 instructions, no binary64 (a binary64 evaluation made the
+// geometry sweep spill).
+__device__ __forceinline__ float exp_det(float xf) {
+  if (!(xf == xf)) return xf;
+  if (xf > 100.f) return __builtin_inff();
+  if (xf < -110.f) return 0.f;
+  const float k = __builtin_rintf(xf * 1.44269504f);                           /* nearest multiple of ln 2 */
+  float r = __builtin_fmaf(-k, 0.693145752f, xf);                              /* ln 2 = 0.693145752 + 1.42860677e-06 */
+  r = __builtin_fmaf(-k, 1.42860677e-06f, r);
+  float p = 1.f / 5040.f;
+  p = __builtin_fmaf(p, r, 1.f / 720.f);
+  p = __builtin_fmaf(p, r, 1.f / 120.f);
+  p = __builtin_fmaf(p, r, 1.f / 24.f);
+  p = __builtin_fmaf(p, r, 1.f / 6.f);
+  p = __builtin_fmaf(p, r, 0.5f);
+  p = __builtin_fmaf(p, r, 1.f);
+  p = __builtin_fmaf(p, r, 1.f);
+  return __builtin_ldexpf(p, (int)k);
+}
+
 // Pose of one keyframe as the kernels consume it: frame_T_global (3x4 row-major) and
 // global_R_frame (3x3 row-major), both cached whenever the pose is set (B/keyframe.h:160-172).
 struct KfPose {
@@ -339,7 +364,7 @@ __device__ __forceinline__ float raw_to_calibrated_depth(float a, float cfactor,
   // exp(-0 * inv_depth) is exactly 1 for every finite inv_depth, so the exponential is skipped -- the same bits; raw == 0
   // (inv_depth = inf, -0 * inf = NaN) keeps its NaN.
   if (a == 0.f) return rcp_exact(mad(cfactor, (raw == 0) ? __builtin_nanf("") : 1.f, inv_depth));
-  return rcp_exact(mad(cfactor, expf(-a * inv_depth), inv_depth));
+  return rcp_exact(mad(cfactor, exp_det(-a * inv_depth), inv_depth));
 }
 __device__ __forceinline__ float cfactor_at(const Intrinsics& in, int px, int py) {
   // px, py >= 0, so the shift is the same integer division

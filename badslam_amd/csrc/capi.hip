@@ -1637,7 +1637,7 @@ int bahip_debug_read_pattern(bahip_context* ctx, size_t bytes, int pattern, int 
 }
 
 int bahip_debug_exact_math(bahip_context* ctx, int kind, const float* in, float* out, size_t n) {
-  REQUIRE(kind >= 0 && kind <= 4, "bahip_debug_exact_math: kind must be 0 (reciprocal), 1 (square root), 2 (sin), 3 (cos) or 4 (atan)");
+  REQUIRE(kind >= 0 && kind <= 5, "bahip_debug_exact_math: kind must be 0 (reciprocal), 1 (square root), 2 (sin), 3 (cos), 4 (atan) or 5 (exp)");
   if (n == 0) return 0;
   float *d_in = nullptr, *d_out = nullptr;
   HIP_TRY(hipMalloc(&d_in, n * sizeof(float)));

@@ -118,7 +118,7 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
       const int sparse_px = r.px / in.cell, sparse_py = r.py / in.cell;
       const float cfactor = pix.cfactor;
       const float raw_inv_depth = 1.0f / (in.raw_to_float_depth * (uint16_t)(pix.geom & 0xffffu));
-      const float exp_inv_depth = expf(-in.a * raw_inv_depth);
+      const float exp_inv_depth = exp_det(-in.a * raw_inv_depth);
       const float corrected = cfactor * exp_inv_depth + raw_inv_depth;
       t->di_valid = !(fabsf(corrected) < 1e-4f);
       const float dot = dot3(mk3(nx, ny, 1), rn);

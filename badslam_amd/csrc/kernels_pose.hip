@@ -789,6 +789,7 @@ __global__ void exact_math_debug_kernel(int kind, const float* __restrict__ in, 
   if (kind == 0) out[i] = rcp_exact(in[i]);
   else if (kind == 1) out[i] = sqrt_exact(in[i]);
   else if (kind == 4) out[i] = atan_det(in[i]);
+  else if (kind == 5) out[i] = exp_det(in[i]);
   else {   // 2: sin, 3: cos (se3_device.h: sincos_det)
     float sn, cs;
     sincos_det(in[i], &sn, &cs);

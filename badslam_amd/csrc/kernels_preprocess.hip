@@ -55,7 +55,7 @@ bilateral_filter_kernel(float denom_xy, float denom_value, int radius, int radiu
       const float inv_sample = 1.0f / (raw_to_float_depth * sample);
       float value_distance_squared = inv_center_value - inv_sample;
       value_distance_squared *= value_distance_squared;
-      const float w = expf(-grid_distance_squared / denom_xy + -value_distance_squared / denom_value);
+      const float w = exp_det(-grid_distance_squared / denom_xy + -value_distance_squared / denom_value);
       sum += w * inv_sample;
       weight += w;
     }

@@ -108,6 +108,9 @@ typedef struct {
 void orc_se3_identity(orc_se3* T);
 /* sin / cos as the backend defines them (binary64 polynomial evaluation, se3_device.h: sincos_det) */
 void orc_sincos(float x, float* sin_out, float* cos_out);
+/* exp as the backend defines it (binary32 reduction + polynomial in fused multiply-adds, ba_device.h: exp_det): the depth
+ * deformation exp(-a / depth) and the bilateral filter's weights */
+float orc_exp(float x);
 float orc_atan(float x);
 void orc_se3_exp(const float tangent[6], orc_se3* out);
 void orc_se3_log(const orc_se3* T, float tangent[6]);

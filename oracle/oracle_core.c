@@ -97,6 +97,26 @@ static void mat3_mul(const float* a, const float* b, float* o) {
 /* sin / cos of a binary32 angle by explicit binary64 operations: the backend defines them this way (se3_device.h:
  * sincos_det) because device and host math libraries differ in the last bit of sinf / cosf; restated here operation by
  * operation (pi/2 split in two parts, Taylor polynomials on |r| <= pi/4, fused multiply-adds, one final rounding). */
+/* exp as the backend defines it (ba_device.h: exp_det), restated operation by operation: binary32 reduction by ln 2 in two
+ * pieces, Taylor polynomial of degree 7 in fused multiply-adds, ldexpf. */
+float orc_exp(float xf) {
+  if (!(xf == xf)) return xf;
+  if (xf > 100.f) return __builtin_inff();
+  if (xf < -110.f) return 0.f;
+  const float k = __builtin_rintf(xf * 1.44269504f);                           /* nearest multiple of ln 2 */
+  float r = __builtin_fmaf(-k, 0.693145752f, xf);                              /* ln 2 = 0.693145752 + 1.42860677e-06 */
+  r = __builtin_fmaf(-k, 1.42860677e-06f, r);
+  float p = 1.f / 5040.f;
+  p = __builtin_fmaf(p, r, 1.f / 720.f);
+  p = __builtin_fmaf(p, r, 1.f / 120.f);
+  p = __builtin_fmaf(p, r, 1.f / 24.f);
+  p = __builtin_fmaf(p, r, 1.f / 6.f);
+  p = __builtin_fmaf(p, r, 0.5f);
+  p = __builtin_fmaf(p, r, 1.f);
+  p = __builtin_fmaf(p, r, 1.f);
+  return __builtin_ldexpf(p, (int)k);
+}
+
 void orc_sincos(float xf, float* sin_out, float* cos_out) {
   const double x = (double)xf;
   const double k = rint(x * 0.63661977236758134308);
@@ -333,7 +353,7 @@ void orc_unproject(const orc_camera* cam, int x, int y, float depth, float out[3
 /* B/util.cuh:62-69 */
 float orc_raw_to_calibrated_depth(float a, float cfactor, float raw_to_float_depth, uint16_t measured_depth) {
   const float inv_depth = 1.0f / (raw_to_float_depth * measured_depth);
-  return 1.f / mad(cfactor, expf(-a * inv_depth), inv_depth);
+  return 1.f / mad(cfactor, orc_exp(-a * inv_depth), inv_depth);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ void orc_intrinsics_accumulate(int optimize_depth_intrinsics, int optimize_color
           const int sparse_px = r.px / dp->cell, sparse_py = r.py / dp->cell;
           const float cfactor = dp->cfactor[(size_t)sparse_py * dp->cf_width + sparse_px];
           const float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * kf->depth[(size_t)r.py * kf->width + r.px]);
-          const float exp_inv_depth = expf(-dp->a * raw_inv_depth);
+          const float exp_inv_depth = orc_exp(-dp->a * raw_inv_depth);
           const float corrected_inv_depth = cfactor * exp_inv_depth + raw_inv_depth;
           if (fabsf(corrected_inv_depth) > 1e-4f) {
             const v3 nl = m34_rotate(F, r.normal);

@@ -70,7 +70,7 @@ static void eval_pair_terms(const pcg_layout* L, const orc_camera* color_cam, co
       const int sparse_px = r->px / dp->cell, sparse_py = r->py / dp->cell;
       const float cfactor = dp->cfactor[(size_t)sparse_py * dp->cf_width + sparse_px];
       const float raw_inv_depth = 1.0f / (dp->raw_to_float_depth * kf->depth[(size_t)r->py * kf->width + r->px]);
-      const float exp_inv_depth = expf(-dp->a * raw_inv_depth);
+      const float exp_inv_depth = orc_exp(-dp->a * raw_inv_depth);
       const float corrected = cfactor * exp_inv_depth + raw_inv_depth;
       t->corrected_inv_depth = corrected;
       t->di_valid = !(fabsf(corrected) < 1e-4f);

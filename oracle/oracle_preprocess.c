@@ -39,7 +39,7 @@ void orc_bilateral_filter_and_depth_cutoff(float sigma_xy, float sigma_value, fl
           const float inv_sample = 1.0f / (raw_to_float_depth * sample);
           float value_distance_squared = inv_center_value - inv_sample;
           value_distance_squared *= value_distance_squared;
-          const float w = expf(-grid_distance_squared / denom_xy + -value_distance_squared / denom_value);
+          const float w = orc_exp(-grid_distance_squared / denom_xy + -value_distance_squared / denom_value);
           sum += w * inv_sample;
           weight += w;
         }

@@ -105,3 +105,30 @@ def test_defined_trigonometry_equals_the_oracle_and_is_correctly_rounded(ctx):
         ulps = _ulp_distance(got, rounded)
         assert ulps.max() <= 1, (kind, int(ulps.max()))
         assert np.count_nonzero(ulps) <= 1e-4 * x.size, (kind, int(np.count_nonzero(ulps)))
+
+
+def test_defined_exponential_equals_the_oracle_and_is_correctly_rounded(ctx):
+    """exp(-a / depth), the depth deformation (ba_device.h: exp_det / the oracle's orc_exp): the same binary32 reduction and
+    polynomial on both sides -- device == oracle on every sample --, within 2 ulp of the correctly rounded value (what CUDA
+    documents for the reference's expf); special values as expf has them."""
+    import ctypes as C
+    from oracle import binding as ob
+    ob.lib()
+    L = C.CDLL(ob._LIB_PATH)
+    L.orc_exp.restype = C.c_float
+    L.orc_exp.argtypes = [C.c_float]
+    rng = np.random.default_rng(23)
+    x = np.concatenate([rng.uniform(-2.0, 2.0, 400000), rng.uniform(-1e-3, 1e-3, 100000), rng.uniform(-100, 88, 100000),
+                        np.array([0.0, -0.0, 1e-30, -1e-30, 88.7, -87.3, -103.9, 0.34657359, -0.34657359])]).astype(np.float32)
+    got = _run(ctx, 5, x)
+    ref = np.array([L.orc_exp(float(v)) for v in x[::37]], np.float32)
+    assert np.array_equal(got[::37].view(np.uint32), ref.view(np.uint32))
+    with np.errstate(over="ignore", under="ignore"):
+        rounded = np.exp(x.astype(np.float64)).astype(np.float32)
+    normal = rounded > np.float32(1.2e-38)             # (subnormal results: ldexp rounds twice; the deformation never gets there)
+    ulps = _ulp_distance(got[normal], rounded[normal])
+    assert ulps.max() <= 2, int(ulps.max())
+    assert np.count_nonzero(ulps > 1) <= 1e-3 * x.size, int(np.count_nonzero(ulps > 1))
+    special = np.array([np.nan, np.inf, -np.inf, 200.0, -200.0], np.float32)
+    got = _run(ctx, 5, special)
+    assert np.isnan(got[0]) and np.isposinf(got[1]) and got[2] == 0 and np.isposinf(got[3]) and got[4] == 0

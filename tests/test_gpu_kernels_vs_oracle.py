@@ -299,8 +299,8 @@ def test_wave_reductions():
 
 def test_bilateral_filter_matches_oracle(scene):
     """Frame preprocessing ahead of the keyframe (BadSlam::PreprocessFrame): same raw depth through the HIP filter and the
-    oracle.  Both evaluate the same binary32 expressions except expf (device library vs glibc, each within 1 ulp), so a
-    filtered depth may differ by one raw unit where the float result sits on a truncation boundary."""
+    oracle.  Both evaluate the same binary32 expressions, the weights' exponential included (ba_device.h: exp_det): every
+    filtered depth is the same raw unit."""
     from badslam_amd import lowlevel
     from oracle import binding as ob
     ctx = lowlevel.Context()
@@ -313,9 +313,7 @@ def test_bilateral_filter_matches_oracle(scene):
         ref = ob.bilateral_filter_and_depth_cutoff(raw, sigma_xy, 0.005, radius_factor, int(max_depth_m / s), s)
         got = lowlevel.bilateral_filtering_and_depth_cutoff(ctx, raw, sigma_xy, 0.005, radius_factor, int(max_depth_m / s), s)
         assert np.array_equal(got == 65535, ref == 65535)        # cutoff and holes: exact
-        diff = np.abs(got.astype(np.int64) - ref.astype(np.int64))
-        assert diff.max() <= 1
-        assert (diff != 0).mean() < 1e-3
+        assert np.array_equal(got, ref)
         assert (ref != 65535).sum() > 10000
 
 
