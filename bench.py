@@ -193,25 +193,40 @@ def cpu_baseline(args, ba, data, log):
     t0 = time.time()
     cam = synthetic.test_camera(args.width, args.height)
     K, N = ba.keyframe_count(), data.shape[1]
+    images = {name: np.stack([ba.keyframe_image(k, name) for k in range(K)]) for name in ("depth", "normals", "radius", "color")}
+    poses = np.stack([ba.keyframe_pose(k) for k in range(K)])
+    from oracle import ref_binding as rb
+    if os.path.exists(rb.LIB_PATH) and not os.environ.get("BENCH_CPU_BASELINE_PORT"):
+        # the REFERENCE's own functions (its device-math headers compiled for the host: oracle/_ref, built in the build container
+        # from /root/reference and shipped prebuilt), OpenMP over the surfels, one keyframe per call -- in a process of its own,
+        # which holds neither the HIP runtime nor torch (in this process, next to them, the library crashed on the GPU box)
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="bench_cpu_baseline_") as d:
+            for name, a in images.items():
+                np.save(os.path.join(d, name + ".npy"), a)
+            np.save(os.path.join(d, "poses.npy"), poses)
+            np.save(os.path.join(d, "surfels.npy"), np.ascontiguousarray(data))
+            with open(os.path.join(d, "meta.json"), "w") as f:
+                json.dump(dict(width=args.width, height=args.height, keyframes=K, surfels=N, camera=[float(v) for v in cam],
+                               raw_to_float_depth=1.0 / 5000, baseline_fx=40.0, cell=args.cell), f)
+            log(f"cpu baseline: scene written for the reference's functions in {time.time() - t0:.1f}s ({K} keyframes, {N} surfels)")
+            proc = subprocess.run([sys.executable, "-m", "oracle.ref_cost_worker", d], capture_output=True, text=True, cwd=ROOT, timeout=900)
+        if proc.returncode == 0:
+            r = json.loads(proc.stdout.strip().splitlines()[-1])
+            return dict(pairs_per_s=K * N / r["seconds"], seconds_per_eval=r["seconds"], K=K, N=N, cores=r["cores"], nres=r["nres"], cost=r["cost"],
+                        kind="reference",
+                        who="the reference's own association / residual / robust-cost functions (oracle/_ref: B/surfel_projection_nvcc_only.cuh, "
+                            "B/cost_function.cuh, B/robust_weighting.cuh compiled for the host, OpenMP over the surfels, in a process of its own)")
+        log(f"cpu baseline: the reference library failed (exit {proc.returncode}: {proc.stderr.strip()[-300:]}); timing the oracle's restatement instead")
     orc = ob.OracleBA(N + 64, 1.0 / 5000, 40.0, args.cell, ob.make_camera(cam, args.width, args.height),
                       ob.make_camera(cam, args.width, args.height))
     for k in range(K):
-        orc.add_preprocessed_keyframe(ba.keyframe_image(k, "depth"), ba.keyframe_image(k, "normals"), ba.keyframe_image(k, "radius"),
-                                      ba.keyframe_image(k, "color"), ba.keyframe_pose(k))
+        orc.add_preprocessed_keyframe(images["depth"][k], images["normals"][k], images["radius"][k], images["color"][k], poses[k])
     orc.surfel_data[:data.shape[0], :N] = data
     orc.surfels.surfels_size = orc.surfels.surfel_count = N
     log(f"cpu baseline: scene handed to the oracle in {time.time() - t0:.1f}s ({K} keyframes, {N} surfels)")
     cores = ob.lib().orc_num_threads()
-    from oracle import ref_binding as rb
-    if os.path.exists(rb.LIB_PATH) and not os.environ.get("BENCH_CPU_BASELINE_PORT"):
-        # the REFERENCE's own functions (its device-math headers compiled for the host: oracle/_ref, built in the build container
-        # from /root/reference and shipped prebuilt), OpenMP over the surfels, one keyframe per call
-        t1 = time.time()
-        cost, nres = rb.evaluate_cost(orc)
-        dt = time.time() - t1
-        return dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=cores, nres=nres, cost=cost, kind="reference",
-                    who="the reference's own association / residual / robust-cost functions (oracle/_ref: B/surfel_projection_nvcc_only.cuh, "
-                        "B/cost_function.cuh, B/robust_weighting.cuh compiled for the host, OpenMP over the surfels)")
     t1 = time.time()
     cost, nres = orc.evaluate_cost()
     dt = time.time() - t1

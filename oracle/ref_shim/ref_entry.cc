@@ -22,6 +22,19 @@
 
 using namespace vis;
 
+// CUDA's float -> int conversion SATURATES (cvt.rzi.s32.f32); the host's is undefined beyond the int range and yields INT_MIN
+// on x86.  ProjectSurfelToImage (B/util.cuh:83-118) relies on the former: a surfel a hair in front of the camera plane projects
+// to pixel +1e10, px saturates to INT_MAX and fails `px >= width`; compiled for the host the same surfel gets px = INT_MIN,
+// passes every test and reads depth_buffer(py, INT_MIN) (found as a crash on a 200-keyframe scene).  This guard gives the
+// reference's function the outcome it has on its own platform: such a pixel is outside the image.
+static inline bool pixel_outside_int_range(const SurfelProjectionParameters& proj, unsigned int surfel_index) {
+  if (surfel_index >= proj.surfels_size) return false;
+  const float3 global_position = SurfelGetPosition(proj.surfels, surfel_index);
+  float3 local_position;
+  if (!proj.frame_T_global.MultiplyIfResultZIsPositive(global_position, &local_position)) return false;   // rejected there anyway
+  const float2 p = proj.projector.Project(local_position);
+  return !(p.x < 2147483648.f && p.y < 2147483648.f);   // (also true for NaN)
+}
 extern "C" {
 
 // mirrors orc_pair_eval (oracle/oracle.h) field for field; pose / surfel Jacobians are not in the reference's headers (they
@@ -118,7 +131,7 @@ void ref_evaluate_pairs(const ref_scene* sc, const uint32_t* surfel_indices, int
     ref_pair_eval& o = out[t];
     memset(&o, 0, sizeof(o));
     SurfelProjectionResult6 r;
-    if (!SurfelProjectsToAssociatedPixel(surfel_indices[t], proj, &r)) continue;
+    if (pixel_outside_int_range(proj, surfel_indices[t]) || !SurfelProjectsToAssociatedPixel(surfel_indices[t], proj, &r)) continue;
     o.associated = 1; o.px = r.px; o.py = r.py; o.calibrated_depth = r.pixel_calibrated_depth;
     const float3 local_normal = F.Rotate(r.surfel_normal);
     const float inv_std = ComputeDepthResidualInvStddevEstimate(unprojector.nx(r.px), unprojector.ny(r.py), r.pixel_calibrated_depth, local_normal, dp.baseline_fx);
@@ -174,7 +187,7 @@ double ref_evaluate_cost(const ref_scene* sc, unsigned long long* num_residuals,
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : total, count)
   for (long long i = 0; i < (long long)sc->surfels_size; ++i) {
     SurfelProjectionResult6 r;
-    if (!SurfelProjectsToAssociatedPixel((unsigned int)i, proj, &r)) continue;
+    if (pixel_outside_int_range(proj, (unsigned int)i) || !SurfelProjectsToAssociatedPixel((unsigned int)i, proj, &r)) continue;
     if (use_depth) {
       const float3 local_normal = F.Rotate(r.surfel_normal);
       const float inv_std = ComputeDepthResidualInvStddevEstimate(unprojector.nx(r.px), unprojector.ny(r.py), r.pixel_calibrated_depth, local_normal, dp.baseline_fx);

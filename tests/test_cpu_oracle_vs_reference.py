@@ -207,3 +207,29 @@ def test_cost_evaluation_matches_the_reference_functions(vga_scene):
     cost_r, n_r = rb.evaluate_cost(orc)
     assert n_r > 300000 and abs(n_o - n_r) <= 1e-4 * n_r, (n_o, n_r)
     assert abs(cost_o - cost_r) <= 1e-4 * cost_r, (cost_o, cost_r)
+
+
+def test_a_pixel_beyond_the_int_range_is_outside_the_image(vga_scene):
+    """ProjectSurfelToImage (B/util.cuh:83-118) converts the projected pixel to int and tests it afterwards; on CUDA the
+    conversion saturates, so a surfel a hair in front of the camera plane (pixel ~1e12) is rejected by `px >= width`.  The
+    host's conversion yields INT_MIN there and the function would read depth_buffer(py, INT_MIN) -- the shim's guard
+    (oracle/ref_shim/ref_entry.cc: pixel_outside_int_range) gives it CUDA's outcome.  Found as a crash of the cpu_baseline leg
+    on the 200-keyframe bench scene."""
+    from badslam_amd import se3
+    orc = vga_scene
+    pose = np.asarray(orc.pose(0), np.float64)
+    R, t = se3.quat_to_rot(pose[:4]), pose[4:]
+    n = orc.surfels_size
+    saved = orc.surfel_data[:3, :2].copy()
+    try:
+        for i, local in enumerate(([1.0, 0.5, 1e-10], [0.0, 1.0, 1e-12])):        # z > 0, pixel far beyond 2^31
+            orc.surfel_data[:3, i] = (R @ np.asarray(local) + t).astype(np.float32)
+        got = rb.evaluate_pairs(orc, 0, np.array([0, 1], np.uint32))
+        assert not _fields(got, "associated").any()
+        ref = orc.evaluate_pairs(0, np.array([0, 1], np.uint32))
+        assert not _fields(ref, "associated").any()
+        cost, count = rb.evaluate_cost(orc, keyframe_indices=[0])               # and the sweep over all surfels survives them
+        assert count > 50000 and np.isfinite(cost)
+    finally:
+        orc.surfel_data[:3, :2] = saved
+    assert n == orc.surfels_size
