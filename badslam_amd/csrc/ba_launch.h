@@ -54,6 +54,7 @@ void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, 
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
+void set_pose_lds_items(int items);   // test hook: slices of that many work items per launch of the LDS form (0: as many as the table holds)
 void pose_form_launches(long long out[2], bool reset);   // launches of either form since the last reset (bench: which kernel to name)
 void set_pose_form(int form);     // 0 = automatic; 1 = one tile per wavefront + global atomics; 2 = persistent workgroups with the normal equations in LDS
 void set_pose_parts(int parts);   // 0 = automatic; 1 | 2 | 4 | 8 wavefronts share a tile's keyframes in the pose kernel

@@ -1587,6 +1587,11 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
   return 0;
 }
 
+int bahip_debug_set_pose_lds_items(int items) {
+  if (items < 0) return fail("bahip_debug_set_pose_lds_items: items must be >= 0", __FILE__, __LINE__, hipSuccess);
+  set_pose_lds_items(items);
+  return 0;
+}
 int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset) {
   long long n[2];
   pose_form_launches(n, reset != 0);

@@ -139,13 +139,16 @@ struct LdsSink {
 template <bool kUseDepth, bool kUseDesc, typename Sink>
 __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                                           int num_work, const SurfelsView& s, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
-                                          int num_listed, uint32_t tile, int parts, int part, Sink& sink) {
+                                          int num_listed, uint32_t tile, int parts, int part, Sink& sink, int item_begin = 0,
+                                          int item_count = -1) {
   const int lane = threadIdx.x & 63;
   // Later rounds (stored_bounds): the items are the num_listed entries of the list behind the counter records -- the work
-  // items still iterating -- instead of all num_work work items.
-  const int* __restrict__ listed = reinterpret_cast<const int*>(work + num_work + kPoseTailRecords);
-  const int num_items = stored_bounds ? num_listed : num_work;
-  auto work_item_of = [&](int item) { return stored_bounds ? load_global(listed + item) : item; };
+  // items still iterating -- instead of all num_work work items.  A launch may cover a slice of the items only
+  // ([item_begin, item_begin + item_count): the LDS form cuts lists longer than its table); `item` below counts from the
+  // slice's start.
+  const int* __restrict__ listed = reinterpret_cast<const int*>(work + num_work + kPoseTailRecords) + item_begin;
+  const int num_items = item_count >= 0 ? item_count : (stored_bounds ? num_listed : num_work);
+  auto work_item_of = [&](int item) { return stored_bounds ? load_global(listed + item) : item_begin + item; };
   WaveBounds wb;
   if (stored_bounds) {
     wb = tile_bounds[tile];     // wave-uniform address: scalar loads
@@ -195,7 +198,7 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
       [&](int item) {
     // item = base + lane' * parts for the lane' that tested it: its w comes from that lane's register, not from memory
     // (a list lookup here was a dependent load and a wait at the top of every candidate of the later rounds)
-    const int w = __builtin_amdgcn_readfirstlane(stored_bounds ? __builtin_amdgcn_readlane(my_w, ((item - part) / parts) & 63) : item);
+    const int w = __builtin_amdgcn_readfirstlane(stored_bounds ? __builtin_amdgcn_readlane(my_w, ((item - part) / parts) & 63) : item_begin + item);
     const float* F = work[w].F;
     const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
     // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
@@ -301,14 +304,19 @@ constexpr int kPoseLdsWaves = BAHIP_POSE_LDS_WAVES;
 #define BAHIP_POSE_BATCH 32
 #endif
 constexpr uint32_t kPoseBatch = BAHIP_POSE_BATCH;
-template <bool kUseDepth, bool kUseDesc>
+// kSlice: the launch covers the items [slice_begin, slice_begin + slice_count) only -- a list longer than the table (292 work
+// items) is cut into slices, one launch each (1000 keyframes: four); without it the two arguments are not looked at, which
+// keeps them out of the scalar registers of the common case.
+template <bool kUseDepth, bool kUseDesc, bool kSlice>
 __global__ void __launch_bounds__(64 * kPoseLdsWaves) BAHIP_WAVES_ATTR
 pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                            int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
-                           int num_listed, int* __restrict__ invalid, uint32_t padded_tiles, uint32_t* __restrict__ tile_counters, int parity) {
+                           int num_listed, int* __restrict__ invalid, uint32_t padded_tiles, uint32_t* __restrict__ tile_counters, int parity,
+                           int slice_begin, int slice_count) {
   extern __shared__ HbFixed table[];
   const int lane = threadIdx.x & 63;
-  const int num_items = stored_bounds ? num_listed : num_work;
+  const int item_begin = kSlice ? slice_begin : 0;
+  const int num_items = kSlice ? slice_count : (stored_bounds ? num_listed : num_work);
   // (first tile of the current batch << 32) | tiles of it already taken; the word behind the table (a separate __shared__
   // variable next to the dynamic array was placed ON the array by this toolchain)
   unsigned long long& batch_state = *reinterpret_cast<unsigned long long*>(table + (size_t)num_items * kHbStride);
@@ -330,7 +338,7 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
     if (index < kPoseBatch) {
       if (first + index < per_xcd)
         pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed,
-                                       xcd_chunked_tile_of((first + index) * 8u + xcd, padded_tiles), 1, 0, sink);
+                                       xcd_chunked_tile_of((first + index) * 8u + xcd, padded_tiles), 1, 0, sink, item_begin, kSlice ? num_items : -1);
     } else if (index == kPoseBatch) {                    // this wavefront took the batch's last-plus-one: it fetches the next batch
       if (lane == 0) {
         const uint32_t next = atomicAdd(counter, kPoseBatch);
@@ -347,7 +355,7 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
     const HbFixed v = table[e];
     if (v != 0) {
       const int item = e / kHbStride;
-      const int w = stored_bounds ? listed[item] : item;
+      const int w = stored_bounds ? listed[item_begin + item] : item_begin + item;
       __hip_atomic_fetch_add(&Hb[(size_t)w * kHbStride + (e - item * kHbStride)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -610,6 +618,8 @@ size_t pose_tile_bounds_bytes(uint32_t surfels) {
 // form whenever the table fits (tests run both: same bits)
 static int g_forced_pose_form = [] { const char* e = getenv("BAHIP_POSE_FORM"); return e ? atoi(e) : 0; }();
 void set_pose_form(int form) { g_forced_pose_form = form; }
+static int g_pose_lds_items = 0;   // test hook: work items per launch of the LDS form (0: what the table holds)
+void set_pose_lds_items(int items) { g_pose_lds_items = items; }
 static long long g_pose_form_launches[2] = {0, 0};   // [0] one tile per wavefront + global atomics, [1] persistent + LDS
 void pose_form_launches(long long out[2], bool reset) {
   out[0] = g_pose_form_launches[0]; out[1] = g_pose_form_launches[1];
@@ -617,10 +627,10 @@ void pose_form_launches(long long out[2], bool reset) {
 }
 constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a compute unit
 
-template <bool kUseDepth, bool kUseDesc>
+template <bool kUseDepth, bool kUseDesc, bool kSlice>
 static void launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
                             const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
-                            uint32_t* tile_counters, int parity) {
+                            uint32_t* tile_counters, int parity, int slice_begin, int slice_count) {
   int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
   static int compute_units = [] {
     int dev = 0, cus = 0;
@@ -628,12 +638,20 @@ static void launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEn
     return cus;
   }();
   static bool raised = [] {   // dynamic LDS beyond 64 KB needs the opt-in
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_accumulate_lds_kernel<kUseDepth, kUseDesc>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsTableLimit) == hipSuccess;
   }();
   (void)raised;
-  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc>), dim3(compute_units), dim3(64 * kPoseLdsWaves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
-                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity);
+  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(compute_units), dim3(64 * kPoseLdsWaves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
+                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count);
+}
+template <bool kSlice>
+static void launch_pose_lds_any(bool use_depth, bool use_desc, hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw,
+                                int num_work, const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles,
+                                size_t table_bytes, uint32_t* tile_counters, int parity, int slice_begin, int slice_count) {
+  if (use_depth && use_desc) launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count);
+  else if (use_depth) launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count);
+  else launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count);
 }
 
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
@@ -654,16 +672,28 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   const int sb = stored_bounds ? 1 : 0;
   // The persistent LDS form when the grid fills the chip on its own (no splitting of a tile's work items) and the table of the
   // work items in this launch fits.
-  const size_t table_bytes = sizeof(HbFixed) * kHbStride * (size_t)(stored_bounds ? num_listed : num_work);
-  const bool lds_form = tile_counters != nullptr && table_bytes <= kPoseLdsTableLimit &&
-                        (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && parts == 1 && forced == 0));
+  const int num_items = stored_bounds ? num_listed : num_work;
+  const size_t item_bytes = sizeof(HbFixed) * kHbStride;
+  const bool lds_form = tile_counters != nullptr && (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && parts == 1 && forced == 0));
   ++g_pose_form_launches[lds_form ? 1 : 0];
   if (lds_form) {
-    const int parity = *parity_inout;
-    *parity_inout = parity ^ 1;
-    if (use_depth && use_desc) launch_pose_lds<true, true>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity);
-    else if (use_depth) launch_pose_lds<true, false>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity);
-    else launch_pose_lds<false, true>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity);
+    const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes))
+                                                : (int)(kPoseLdsTableLimit / item_bytes);   // 292 work items
+    if (num_items <= per_launch) {
+      const int parity = *parity_inout;
+      *parity_inout = parity ^ 1;
+      launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0);
+      return;
+    }
+    // more work items than the table holds: slices of equal size, one launch each (every launch sweeps all tiles and culls
+    // against its slice; the first round's launches all store the same tile bounds)
+    const int slices = (num_items + per_launch - 1) / per_launch, per_slice = (num_items + slices - 1) / slices;
+    for (int begin = 0; begin < num_items; begin += per_slice) {
+      const int count = std::min(per_slice, num_items - begin);
+      const int parity = *parity_inout;
+      *parity_inout = parity ^ 1;
+      launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count);
+    }
     return;
   }
   const dim3 grid(tiles, parts), block(kPoseBlock);

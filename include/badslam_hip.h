@@ -384,6 +384,9 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
 int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block);
 int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out);
 int bahip_debug_set_pose_form(int form);
+/* The LDS form holds the normal equations of at most 292 work items; longer lists are cut into slices, one launch each.  items > 0
+ * makes the slices that small (tests: 200 keyframes in slices of 64), 0 restores the default. */
+int bahip_debug_set_pose_lds_items(int items);
 /* launches of the pose accumulation in either form since the last reset (process-wide); bench.py names the dominant kernel by it */
 int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):

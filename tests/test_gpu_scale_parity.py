@@ -109,16 +109,19 @@ def _oracle_pose_estimates(orc, perturbed, pattern):
     return _ORACLE_POSES
 
 
-@pytest.mark.parametrize("pose_parts", [1, 2, 8, "lds"])
+@pytest.mark.parametrize("pose_parts", [1, 2, 8, "lds", "lds-sliced"])
 def test_many_keyframes_batched_pose_estimation(many, pose_parts, request):
     """pose_parts 1 / 2 / 8: one tile per wavefront, a tile's work items split over that many wavefronts, totals added to the
     normal equations with global integer atomics; "lds": persistent workgroups that keep the normal equations of all 200 work
-    items in LDS and flush once (the form the bench size takes).  The sums are integer sums: the same bits for every form."""
+    items in LDS and flush once (the form the bench size takes); "lds-sliced": the same with the work items cut into slices of
+    48 per launch (what happens beyond 292 work items, e.g. the 1000 keyframes of configs[4]; later rounds with fewer items
+    left take a single launch).  The sums are integer sums: the same bits for every form."""
     scene, orc, g = many
     K = len(orc.keyframes)
-    if pose_parts == "lds":
+    if pose_parts in ("lds", "lds-sliced"):
         capi.check(g.ctx.lib.bahip_debug_set_pose_form(2))
-        request.addfinalizer(lambda: capi.check(g.ctx.lib.bahip_debug_set_pose_form(0)))
+        capi.check(g.ctx.lib.bahip_debug_set_pose_lds_items(48 if pose_parts == "lds-sliced" else 0))
+        request.addfinalizer(lambda: (capi.check(g.ctx.lib.bahip_debug_set_pose_form(0)), capi.check(g.ctx.lib.bahip_debug_set_pose_lds_items(0))))
     else:
         capi.check(g.ctx.lib.bahip_debug_set_pose_form(1))
         _shapes(g.ctx.lib, 0, pose_parts)
