@@ -6,8 +6,14 @@
  * includes, links or calls anything in this directory.
  *
  * Parity pinning: the reference (ETH3D/badslam) ships no golden vectors, fixtures or
- * known-answer files for this path and cannot be compiled here (CUDA + Eigen + Qt + ...).
- * The oracle is pinned by (1) the reference's own closed-loop test criteria restated in
+ * known-answer files for this path and cannot be compiled as a whole here (CUDA + Eigen + Qt + ...).
+ * The oracle is pinned by (0) THE REFERENCE'S OWN FUNCTIONS: the device-math headers of the path
+ * (B/surfel_projection_nvcc_only.cuh, B/cost_function.cuh, B/robust_weighting.cuh, B/util.cuh, ...)
+ * compile for the host through a stand-in cuda_runtime.h (oracle/ref_shim/, oracle/Makefile ->
+ * oracle/_ref/libbadslam_ref.so, sources read where they lie under /root/reference), and
+ * tests/test_cpu_oracle_vs_reference.py compares association, residuals, weights, gradients and the
+ * cost of ~4e5 (surfel, keyframe) pairs with them (measured deltas: DESIGN.md section 6);
+ * (1) the reference's own closed-loop test criteria restated in
  * tests/test_oracle_*_closed_loop.py (applications/badslam/src/badslam/test/ *.cc tolerances; all
  * twelve of them also run against the HIP path, badslam_amd/host/test_directba.cc),
  * (2) its residual Jacobians checked against golden vectors generated HERE by importing the
@@ -17,8 +23,8 @@
  * weights, the rotation of the exponential map -- (scripts/make_golden_functions.py ->
  * tests/golden/functions.json) and (4) central finite differences of the oracle's own residual
  * functions.  Where the arithmetic is DEFINED here rather than taken from the reference (summation
- * orders, fixed point, defined sin / cos / atan: DESIGN.md section 3), the definitions are shared with
- * the kernels, and the closed-loop criteria of (1) are what ties them to the reference.
+ * orders, fixed point, exact sums, defined sin / cos / atan / exp: DESIGN.md section 3), the definitions are
+ * shared with the kernels, and (0) and (1) are what ties them to the reference.
  *
  * All arithmetic is IEEE binary32 unless stated (compiled with -ffp-contract=off); the small
  * dense solves are done in binary64 exactly where the reference does so (Eigen LDLT on
