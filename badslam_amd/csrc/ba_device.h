@@ -188,7 +188,7 @@ struct PoseWork {
   int32_t iterations;
   int32_t converged;
   int32_t moved;      // set when done (batched keyframe phase): log(T0^-1 * T) fails the convergence test
-  int32_t pad;
+  int32_t skip;       // the accumulate sweep leaves the item out: done, or (keyframe sharding) the keyframe's images live on another rank
 };
 static_assert(sizeof(PoseWork) == 128, "PoseWork is read back as 32-word records");
 // The two records after the last work item hold counters (as int32): [round] = work items still iterating after that
@@ -280,6 +280,14 @@ struct SurfelsView {
   uint8_t* active;
   uint32_t size;
   __device__ __forceinline__ float* row(int r) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(data) + (size_t)r * pitch); }
+};
+
+// Keyframe sharding: the partial sums of the four keyframe classes of the normals / geometry passes (kernels_surfel.hip), the
+// unit the ranks exchange.  data[(class * sums + q) * stride + surfel]; `owned` has bit c set when this rank visits class c.
+struct ClassPartials {
+  float* data;
+  uint32_t stride;   // floats per plane (>= surfels, even: the planes travel as 64-bit integer words)
+  uint32_t owned;
 };
 
 // A pointer read from a device table (KfEntry::geom, ...) is a generic pointer to the compiler, which then emits flat_load

@@ -34,6 +34,15 @@ void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
                      int num_kfs, const SurfelsView& s, long long activate_count = -1);
 
+// keyframe sharding (kernels_surfel.hip: geometry_step, kPhase): one phase of the geometry step over this rank's keyframe classes
+int geometry_normals_sums(bool activate);     // sums per class and surfel of the normals pass (cpn) ...
+int geometry_position_sums(bool use_desc);    // ... and of the position pass (cpp)
+void launch_geometry_phase(hipStream_t stream, int phase, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                           const SurfelsView& s, long long activate_count, const ClassPartials& cpn, const ClassPartials& cpp);
+void launch_activation_hits(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s, uint32_t surfels_size,
+                            int kf_rank, int kf_world, uint32_t* hits);
+void launch_activation_from_hits(hipStream_t stream, const SurfelsView& s, uint32_t surfels_size, const uint32_t* hits);
+
 void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                         unsigned long long* counts);
 
@@ -47,7 +56,8 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out,
                        int sequence /* published to the host copy of the counters when the launch is complete */);
-void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out);
+void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out,
+                                     int kf_rank = 0, int kf_world = 1 /* keyframe sharding: the sweep skips keyframes of other ranks */);
 
 void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window, const int* offsets,
                               const int* indices);   // window activation + co-visible propagation

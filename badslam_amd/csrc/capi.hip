@@ -132,6 +132,9 @@ struct bahip_context {
   uint32_t pcg_stage_head = 0;     // accumulators were set up for, and the bahip_pcg_step1 calls since the last step 2
   int pcg_stage_step1_calls = 0;
   int world = 0;                   // ranks of the RCCL communicator (0 = none)
+  int kf_rank = 0, kf_world = 1;   // keyframe sharding (bahip_context_set_keyframe_sharding): keyframe k lives on rank (k % 4) % kf_world
+  float* kf_partials = nullptr;    // class partials of the geometry step (normals, then position) / hit words of the activation
+  size_t kf_partials_capacity = 0; // floats
   long long exchange_calls = 0;    // sums over the ranks requested since the last reset (bahip_exchange_stats), and their bytes
   long long exchange_bytes = 0;
 
@@ -321,6 +324,7 @@ void timer_end(bahip_context* ctx, int stage) {
 }
 
 int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype);
+inline bool kf_sharded(const bahip_context* ctx) { return ctx->kf_world > 1; }
 
 int ensure_tile_bounds(bahip_context* ctx, uint32_t surfels) {
   const size_t need = pose_tile_bounds_bytes(surfels);
@@ -380,7 +384,9 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     timer_end(ctx, 2);
     CHECK_LAUNCH();
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
-    if (reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
+    // (keyframe sharding: the ranks hold disjoint keyframes and all surfels, so the sum completes each rank's table -- the
+    // "all-reduce of pose Hessians" of BASELINE configs[3]; a single frame outside the table is complete on every rank)
+    if (!(kf_sharded(ctx) && dev_frames == ctx->dev_frame1) && reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
     timer_begin(ctx, 3, round == 0);
     // process-wide and increasing: page-locked memory is recycled between contexts, and a word left behind by an earlier
     // context must never equal a sequence number somebody is going to wait for
@@ -466,6 +472,32 @@ int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype)
   return 0;
 }
 inline bool is_sharded(const bahip_context* ctx) { return ctx->allreduce != nullptr || ctx->rccl_comm != nullptr; }
+inline bool kf_owned(const bahip_context* ctx, int k) { return ((k & 3) & (ctx->kf_world - 1)) == ctx->kf_rank; }
+#define REQUIRE_NO_KF_SHARDING(what) \
+  REQUIRE(!kf_sharded(ctx), what " is not available under keyframe sharding (its per-surfel sums run over all keyframes in order): use surfel sharding")
+
+// Keyframe-sharded geometry step: three launches, the class partials of the normals pass and of the position pass summed over
+// the ranks in between (as 64-bit integers: a rank's partials are zero where another rank's are not, so bit patterns survive).
+int geometry_keyframe_sharded(bahip_context* ctx, bool use_depth, bool use_desc, const SurfelsView& v, long long activate_count) {
+  REQUIRE(is_sharded(ctx), "keyframe sharding needs an all-reduce hook or an RCCL communicator");
+  if (v.size == 0) return 0;
+  const int nn = geometry_normals_sums(activate_count >= 0), np = geometry_position_sums(use_desc);
+  const size_t stride = ((size_t)v.size + 63) & ~(size_t)63;
+  const size_t normals_floats = 4 * (size_t)nn * stride, position_floats = 4 * (size_t)np * stride;
+  if (grow_device(&ctx->kf_partials, &ctx->kf_partials_capacity, normals_floats + position_floats, 0, "the class partials of the geometry step")) return 1;
+  const uint32_t owned = ctx->kf_world == 2 ? (ctx->kf_rank == 0 ? 0x5u : 0xau) : (1u << ctx->kf_rank);
+  const ClassPartials cpn{ctx->kf_partials, (uint32_t)stride, owned}, cpp{ctx->kf_partials + normals_floats, (uint32_t)stride, owned};
+  HIP_TRY(hipMemsetAsync(ctx->kf_partials, 0, sizeof(float) * (normals_floats + position_floats), ctx->stream));
+  launch_geometry_phase(ctx->stream, 1, use_depth, use_desc, ctx->in, ctx->dev_kfs, ctx->num_kfs, v, activate_count, cpn, cpp);
+  CHECK_LAUNCH();
+  if (reduce_over_ranks(ctx, cpn.data, normals_floats / 2, BAHIP_SUM_I64)) return 1;
+  launch_geometry_phase(ctx->stream, 2, use_depth, use_desc, ctx->in, ctx->dev_kfs, ctx->num_kfs, v, activate_count, cpn, cpp);
+  CHECK_LAUNCH();
+  if (reduce_over_ranks(ctx, cpp.data, position_floats / 2, BAHIP_SUM_I64)) return 1;
+  launch_geometry_phase(ctx->stream, 3, use_depth, use_desc, ctx->in, ctx->dev_kfs, ctx->num_kfs, v, activate_count, cpn, cpp);
+  CHECK_LAUNCH();
+  return 0;
+}
 
 }  // namespace
 
@@ -519,7 +551,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
-  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl);
+  hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl); hipFree(ctx->kf_partials);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
@@ -542,6 +574,13 @@ int bahip_context_is_sharded(bahip_context* ctx) { return (ctx->allreduce != nul
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user) {
   ctx->allreduce = fn;
   ctx->allreduce_user = user;
+  return 0;
+}
+
+int bahip_context_set_keyframe_sharding(bahip_context* ctx, int rank, int world) {
+  REQUIRE(world == 1 || world == 2 || world == 4, "keyframe sharding: the per-surfel sums have four keyframe classes, so world must be 1, 2 or 4");
+  REQUIRE(rank >= 0 && rank < world, "keyframe sharding: rank out of range");
+  ctx->kf_rank = rank; ctx->kf_world = world;
   return 0;
 }
 
@@ -740,8 +779,8 @@ int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int
   REQUIRE(num_keyframes >= 0, "negative keyframe count");
   ctx->host_kfs.resize(num_keyframes);
   for (int k = 0; k < num_keyframes; ++k) {
-    KfEntry e;
-    if (make_entry(ctx, keyframes[k].frame, 1 + (size_t)k, &e)) return 1;
+    KfEntry e{};   // keyframe sharding: the images of a keyframe that lives on another rank are not looked at (null pointers)
+    if (kf_owned(ctx, k) && make_entry(ctx, keyframes[k].frame, 1 + (size_t)k, &e)) return 1;
     fill_pose(&e, keyframes[k].global_T_frame);
     e.activation = keyframes[k].activation;
     ctx->host_kfs[k] = e;
@@ -774,6 +813,23 @@ int bahip_get_keyframe_poses(bahip_context* ctx, float* out, int num_keyframes) 
 int bahip_update_surfel_activation(bahip_context* ctx, const bahip_surfels* surfels, uint32_t surfels_size) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(surfels->active != nullptr, "activation needs the active-surfel buffer");
+  if (kf_sharded(ctx)) {
+    // a surfel is active iff a kActive keyframe of ANY rank sees it: one hit word per surfel, summed over the ranks
+    REQUIRE(is_sharded(ctx), "keyframe sharding needs an all-reduce hook or an RCCL communicator");
+    if (surfels_size == 0) return 0;
+    const size_t words = ((size_t)surfels_size + 63) & ~(size_t)63;
+    if (grow_device(&ctx->kf_partials, &ctx->kf_partials_capacity, words, 0, "the activation hit words")) return 1;
+    uint32_t* hits = reinterpret_cast<uint32_t*>(ctx->kf_partials);
+    HIP_TRY(hipMemsetAsync(hits, 0, sizeof(uint32_t) * words, ctx->stream));
+    timer_begin(ctx, 0, true);
+    launch_activation_hits(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), surfels_size, ctx->kf_rank, ctx->kf_world, hits);
+    CHECK_LAUNCH();
+    if (reduce_over_ranks(ctx, hits, words / 2, BAHIP_SUM_I64)) return 1;
+    launch_activation_from_hits(ctx->stream, make_view(surfels), surfels_size, hits);
+    timer_end(ctx, 0);
+    CHECK_LAUNCH();
+    return 0;
+  }
   timer_begin(ctx, 0, true);
   launch_activation(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), surfels_size);
   timer_end(ctx, 0);
@@ -783,6 +839,7 @@ int bahip_update_surfel_activation(bahip_context* ctx, const bahip_surfels* surf
 
 int bahip_assign_colors(bahip_context* ctx, const bahip_surfels* surfels) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE_NO_KF_SHARDING("bahip_assign_colors");
   launch_assign_colors(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
   CHECK_LAUNCH();
   return 0;
@@ -791,6 +848,7 @@ int bahip_assign_colors(bahip_context* ctx, const bahip_surfels* surfels) {
 int bahip_update_surfel_normals(bahip_context* ctx, const bahip_surfels* surfels) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(surfels->active != nullptr, "normals update needs the active-surfel buffer");
+  REQUIRE_NO_KF_SHARDING("bahip_update_surfel_normals (a stage of the PCG scheme)");
   launch_normals(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
   CHECK_LAUNCH();
   return 0;
@@ -801,7 +859,11 @@ int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth, int use
   REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");   // B/kernel_opt_geometry.cc:91
   REQUIRE(surfels->active != nullptr, "geometry optimisation needs the active-surfel buffer");
   timer_begin(ctx, 1, true);
-  launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
+  if (kf_sharded(ctx)) {
+    if (geometry_keyframe_sharded(ctx, use_depth != 0, use_desc != 0, make_view(surfels), -1)) return 1;
+  } else {
+    launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
+  }
   timer_end(ctx, 1);
   CHECK_LAUNCH();
   return 0;
@@ -814,8 +876,12 @@ int bahip_update_activation_and_optimize_geometry(bahip_context* ctx, int use_de
   REQUIRE(surfels->active != nullptr, "geometry optimisation needs the active-surfel buffer");
   REQUIRE(activation_surfels_size <= surfels->surfels_size, "activation range exceeds surfels_size");
   timer_begin(ctx, 1, true);
-  launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels),
-                  (long long)activation_surfels_size);
+  if (kf_sharded(ctx)) {
+    if (geometry_keyframe_sharded(ctx, use_depth != 0, use_desc != 0, make_view(surfels), (long long)activation_surfels_size)) return 1;
+  } else {
+    launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels),
+                    (long long)activation_surfels_size);
+  }
   timer_end(ctx, 1);
   CHECK_LAUNCH();
   return 0;
@@ -840,7 +906,8 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
                          make_view(surfels), ctx->dev_Hb1, ctx->dev_tile_bounds, /*stored_bounds*/ false, /*num_listed*/ 0,
                          ctx->dev_tile_counters, &ctx->pose_parity);
   CHECK_LAUNCH();
-  if (reduce_over_ranks(ctx, ctx->dev_Hb1, kHbStride, BAHIP_SUM_I64)) return 1;
+  // (keyframe sharding: every rank holds all surfels, a single frame's equations are complete on each)
+  if (!kf_sharded(ctx) && reduce_over_ranks(ctx, ctx->dev_Hb1, kHbStride, BAHIP_SUM_I64)) return 1;
   HbFixed* fixed = reinterpret_cast<HbFixed*>(ctx->pinned_f);   // 56 x 8 bytes of the 128-float pinned buffer
   HIP_TRY(hipMemcpyAsync(fixed, ctx->dev_Hb1, sizeof(HbFixed) * kHbStride, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->pinned_i, reinterpret_cast<const int*>(ctx->dev_work1 + 1) + kPoseCounterInvalid, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -889,7 +956,8 @@ static int estimate_keyframe_poses_impl(bahip_context* ctx, int use_depth, int u
   if (num_converged_out) *num_converged_out = 0;
   if (K == 0) return 0;
   if (ensure_work(ctx, K)) return 1;
-  launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work);
+  REQUIRE(!kf_sharded(ctx) || is_sharded(ctx), "keyframe sharding needs an all-reduce hook or an RCCL communicator");
+  launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, ctx->kf_rank, ctx->kf_world);
   CHECK_LAUNCH();
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K,
                       make_view(surfels), /*write_back*/ 1, update_activation ? 1 : 0, ctx->pinned_work, rounds_out)) return 1;
@@ -1019,6 +1087,7 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
 int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merge_dist_factor, const bahip_frame* frame,
                                        const float frame_T_global[12], const bahip_surfels* surfels,
                                        uint32_t* const* supporting, uint32_t supporting_pitch, uint32_t* merged_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_determine_supporting_surfels");
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   SupportingView sup;
   REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
@@ -1031,6 +1100,7 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
 int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, int filter_new_surfels, int min_observation_count,
                                       const int* covis, int n_covis, const bahip_surfels* surfels, uint32_t* const* supporting,
                                       uint32_t supporting_pitch, uint32_t* new_surfel_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_create_surfels_for_keyframe");
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(keyframe_index >= 0 && keyframe_index < ctx->num_kfs, "keyframe index out of range");
   SupportingView sup;
@@ -1094,6 +1164,7 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
 
 int bahip_delete_surfels_and_update_radii(bahip_context* ctx, int min_observation_count, const bahip_surfels* surfels,
                                           uint32_t* deleted_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_delete_surfels_and_update_radii");
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   *deleted_count_out = 0;
   if (surfels->surfels_size == 0) return 0;
@@ -1130,6 +1201,7 @@ int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfel
 // B/kernel_opt_intrinsics.cc:39-281
 int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimize_color, const bahip_surfels* surfels,
                               bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a) {
+  REQUIRE_NO_KF_SHARDING("bahip_optimize_intrinsics");
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(optimize_depth || optimize_color, "at least one of depth / colour intrinsics must be optimised");  // :55
   *out_color_camera = ctx->color_cam;
@@ -1254,6 +1326,7 @@ static int ensure_pcg_exact(bahip_context* ctx, uint32_t head_count) {
 int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const bahip_surfels* surfels,
                         bahip_camera* out_color_camera, bahip_camera* out_depth_camera, float* out_a, int* inner_steps_out,
                         int* num_converged_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_pcg_iteration");
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   const bool sharded = is_sharded(ctx);   // (exact sums need no rank count: every rank adds its terms, the limbs are summed)
   ctx->pcg_stage_head = 0xffffffffu;      // the accumulators are re-used: a stage-by-stage caller has to call bahip_pcg_begin again
@@ -1449,6 +1522,7 @@ int stage_ready(bahip_context* ctx, const PcgLayout& L) {
 }  // namespace
 
 int bahip_pcg_begin(bahip_context* ctx, const bahip_pcg_layout* layout, uint32_t surfels_size) {
+  REQUIRE_NO_KF_SHARDING("bahip_pcg_begin");
   const PcgLayout L = stage_layout(layout, surfels_size);
   const uint32_t head = head_count_of(L);
   if (ensure_pcg_exact(ctx, head)) return 1;

@@ -192,7 +192,7 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
         my_w = w;
         float f[12];
         int32_t done;
-        load_candidate(work[w].F, &work[w].done, f, &done);
+        load_candidate(work[w].F, &work[w].skip, f, &done);   // skip = done, or the keyframe's images live on another rank
         return !done && sphere_may_project(in, f, wb);
       },
       [&](int item) {
@@ -456,6 +456,7 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
     if (conv) pw.converged = 1;
     if (conv || pw.iterations >= BAHIP_MAX_POSE_ITERATIONS) {
       pw.done = 1;
+      pw.skip = 1;
       if (write_back) {
         KfEntry& kf = frames[pw.kf_index];
         for (int c = 0; c < 7; ++c) kf.global_T_frame[c] = next[c];
@@ -522,7 +523,7 @@ void launch_pose_step_debug(hipStream_t stream, const float* in, float* out) {
 template <bool kSingleBlock>
 __global__ void __launch_bounds__(kSingleBlock ? 1024 : 64)
 pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs, PoseWork* __restrict__ work,
-                                HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out) {
+                                HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out, uint32_t owner_mask, uint32_t owner_rank) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = k < num_kfs;
   const bool inactive = in_range && frames[k].activation == BAHIP_KF_INACTIVE;
@@ -532,6 +533,9 @@ pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs,
     pw.iterations = 0;
     pw.converged = 0;
     pw.done = inactive ? 1 : 0;
+    // keyframe sharding: every rank solves every work item from the summed normal equations, but sweeps only the keyframes it
+    // holds (keyframe k lives on rank (k % 4) % world; owner_mask = world - 1, 0 without sharding)
+    pw.skip = (inactive || ((uint32_t)k & 3u & owner_mask) != owner_rank) ? 1 : 0;
     pw.moved = 0;
     for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
     for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
@@ -710,14 +714,16 @@ void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb
                      num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out), sequence);
 }
 
-void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out) {
+void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out,
+                                     int kf_rank, int kf_world) {
   if (num_kfs == 0) return;
+  const uint32_t mask = (uint32_t)(kf_world - 1), rank = (uint32_t)kf_rank;
   if (num_kfs <= 1024)
     hipLaunchKernelGGL(pose_init_from_keyframes_kernel<true>, dim3(1), dim3(1024), 0, stream, frames, num_kfs,
-                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out));
+                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), mask, rank);
   else
     hipLaunchKernelGGL(pose_init_from_keyframes_kernel<false>, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs,
-                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out));
+                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), mask, rank);
 }
 
 

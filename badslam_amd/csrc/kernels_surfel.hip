@@ -17,6 +17,12 @@
 //   kWaves = 2, 4  a workgroup of two / four wavefronts per tile sharing the classes, partials combined through LDS -
 //               divides the longest wavefront, which is what bounds the launch once the surfel set is a shard of a
 //               multi-GPU run and no longer fills the chip.
+//
+// The same definition is what makes KEYFRAME sharding (capi.hip: bahip_context_set_keyframe_sharding) reproduce the unsharded
+// bits: a rank that holds the images of whole classes only (keyframe k lives on rank (k % 4) % world, world = 2 | 4) computes
+// exactly those classes' partials (kSumsProduce: stored to a buffer [class][sum][surfel] that is zero elsewhere), the ranks
+// exchange the buffers as integer sums of bit patterns (x + 0 keeps every bit), and every rank then combines the four
+// partials as defined (kSumsConsume).  The geometry step becomes three launches with two exchanges between them.
 #include <stdlib.h>
 
 #include "ba_device.h"
@@ -34,10 +40,33 @@ constexpr int kSumClasses = 4;     // interleaved partial sums per surfel (part 
 // tot[q] = ((p0[q] + p1[q]) + p2[q]) + p3[q], p_c = what visit(acc, c) accumulates over the keyframes of class c.
 // kWaves > 1: the calling workgroup has kWaves wavefronts holding the same 64 surfels (wavefront w takes the classes
 // w, w + kWaves, ...); every thread must call.
-template <int kWaves, int kCount, typename Visit>
-__device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visit visit) {
+enum SumsMode { kSumsFused = 0, kSumsProduce = 1, kSumsConsume = 2 };
+template <int kWaves, int kCount, int kMode = kSumsFused, typename Visit>
+__device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visit visit, const ClassPartials& cp = ClassPartials{},
+                                          uint32_t i = 0, bool in_range = false) {
   static_assert(kWaves == 1 || kWaves == 2 || kWaves == kSumClasses, "1, 2 or 4 wavefronts per tile");
-  if (kWaves == 1) {
+  static_assert(kMode == kSumsFused || kWaves == 1, "the class partials are exchanged by the one-wavefront shape only");
+  if (kMode == kSumsProduce) {
+#pragma nounroll
+    for (int c = 0; c < kSumClasses; ++c) {
+      if (!((cp.owned >> c) & 1u)) continue;   // another rank holds this class's images
+      float acc[kCount];
+#pragma unroll
+      for (int q = 0; q < kCount; ++q) acc[q] = 0.f;
+      visit(acc, c);
+      if (in_range) {
+#pragma unroll
+        for (int q = 0; q < kCount; ++q) cp.data[(size_t)(c * kCount + q) * cp.stride + i] = acc[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kCount; ++q) tot[q] = 0.f;
+  } else if (kMode == kSumsConsume) {
+#pragma unroll
+    for (int q = 0; q < kCount; ++q)
+      tot[q] = ((cp.data[(size_t)(0 * kCount + q) * cp.stride + i] + cp.data[(size_t)(1 * kCount + q) * cp.stride + i]) +
+                cp.data[(size_t)(2 * kCount + q) * cp.stride + i]) + cp.data[(size_t)(3 * kCount + q) * cp.stride + i];
+  } else if (kWaves == 1) {
 #pragma unroll
     for (int q = 0; q < kCount; ++q) tot[q] = 0.f;   // +0 + p0 == p0 bit for bit (the partials are never -0)
 #pragma nounroll
@@ -167,16 +196,19 @@ assign_colors_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs
 // exactly those associations (same position, same old normal) on its way over the non-inactive keyframes.  Lanes with
 // `decide` set enter as live candidates, count their associations with kActive keyframes (a fifth sum), get their flag
 // written and stay live only if that count is >= 1; what an inactive surfel accumulated is dropped.
-template <int kWaves, bool kActivate>
+// kMode (keyframe sharding, tile_sums): kSumsProduce stores this rank's class partials and returns; kSumsConsume takes the sums
+// from the exchanged partials instead of visiting keyframes.
+template <int kWaves, bool kActivate, int kMode = kSumsFused>
 __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs,
                                              const WaveBounds& wb, SurfelsView& s, uint32_t i, bool* live_inout, bool decide,
-                                             Vec3 gp, Vec3* gn_inout, float* lds) {
+                                             Vec3 gp, Vec3* gn_inout, float* lds, const ClassPartials& cp = ClassPartials{},
+                                             bool in_range = false) {
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
   const Vec3 gn = *gn_inout;
   bool live = *live_inout;
   constexpr int kCount = kActivate ? 5 : 4;
   float sum[kCount];   // x, y, z, count [, count over kActive keyframes]
-  tile_sums<kWaves>(sum, lds, [&](float (&acc)[kCount], int cls) {
+  tile_sums<kWaves, kCount, kMode>(sum, lds, [&](float (&acc)[kCount], int cls) {
     for_each_candidate(
         num_kfs,
         [&](int k) {
@@ -198,7 +230,8 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
           }
         },
         kSumClasses, cls);
-  });
+  }, cp, i, in_range);
+  if (kMode == kSumsProduce) return;
   if (kActivate && decide) {
     const bool active = live && sum[kCount - 1] >= 1.f;
     if (writer) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (active ? kSurfelActiveFlag : 0);
@@ -238,25 +271,35 @@ normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Surf
 // UpdateSurfelActivationCUDA and OptimizeGeometryIterationCUDA of one BA iteration in one sweep; surfels beyond
 // activate_count keep the flag they have (the reference flags newly created surfels active without a test,
 // B/direct_ba_alternating.cc:448-452).
-template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate>
-__global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
-geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count) {
-  __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
+//
+// kPhase (keyframe sharding; 0 = the whole step in one launch): the step cut where the per-surfel sums over ALL keyframes are
+// needed, so that the ranks can exchange their class partials in between:
+//   1  normals pass over this rank's classes -> partials `cpn`;
+//   2  normals (and activation) finished from the exchanged `cpn`, then the position pass over this rank's classes -> `cpp`;
+//   3  position / descriptor solve from the exchanged `cpp`.
+// Every rank holds all surfels and ends each phase with the same bits (flags and normals after 2, positions after 3).
+template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate, int kPhase>
+__device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView& s,
+                                              uint32_t activate_count, float* lds, const ClassPartials& cpn, const ClassPartials& cpp) {
+  constexpr int kNormalsMode = kPhase == 1 ? kSumsProduce : kPhase == 2 ? kSumsConsume : kSumsFused;
+  constexpr int kPositionMode = kPhase == 2 ? kSumsProduce : kPhase == 3 ? kSumsConsume : kSumsFused;
   const int lane = threadIdx.x & 63;
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
   const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
-  const bool decide = kActivate && in_range && i < activate_count;
+  // (phase 3: the flags were decided by phase 2)
+  const bool decide = kActivate && kPhase != 3 && in_range && i < activate_count;
   bool live = in_range && (decide || (s.active[ii] & kSurfelActiveFlag));
   const Vec3 gp = surfel_position(s, ii);
   Vec3 gn = surfel_normal(s, ii);
   const WaveBounds wb = wave_bounds(gp, live && position_valid(gp));
   if (wb.r < 0.f) {   // workgroup-uniform (all wavefronts of the tile hold the same surfels): nothing a keyframe could see
-    if (decide && writer) s.active[ii] = s.active[ii] & (uint8_t)~kSurfelActiveFlag;   // (deleted surfels: never active)
+    if (decide && writer && kPhase != 1) s.active[ii] = s.active[ii] & (uint8_t)~kSurfelActiveFlag;   // (deleted surfels: never active)
     return;
   }
-  normals_pass<kWaves, kActivate>(in, kfs, num_kfs, wb, s, ii, &live, decide, gp, &gn, lds);
+  if (kPhase != 3) normals_pass<kWaves, kActivate, kNormalsMode>(in, kfs, num_kfs, wb, s, ii, &live, decide, gp, &gn, lds, cpn, in_range);
+  if (kPhase == 1) return;
 
   auto cand = [&](int k) {
     float f[12];
@@ -267,7 +310,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
 
   if (!kUseDesc) {
     float hb[2];
-    tile_sums<kWaves>(hb, lds, [&](float (&acc)[2], int cls) {
+    tile_sums<kWaves, 2, kPositionMode>(hb, lds, [&](float (&acc)[2], int cls) {
       for_each_candidate(num_kfs, cand, [&](int k) {
         const Projected p = project_surfel(in, kfs[k].pose.F, gp);
         const PixelWords pix = load_pixel_words(in, kfs[k].geom, p);
@@ -284,8 +327,8 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
         acc[0] = mad(wj, jac, acc[0]);
         acc[1] = mad(wj, raw, acc[1]);
       }, kSumClasses, cls);
-    });
-    if (!live || !writer) return;
+    }, cpp, ii, in_range);
+    if (kPhase == 2 || !live || !writer) return;
     const float H = hb[0], b = hb[1];
     if (H > 1e-6f) {
       const float t = -1.f * b / H;
@@ -300,7 +343,7 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   const float d2 = s.row(kSurfelDescriptor2)[ii];
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);
   float tot[8];   // a0 a1 a2 a3 a5 a6 a7 a8 of B/kernel_opt_geometry.cu:119-230 (a4 = H12 is exactly 0)
-  tile_sums<kWaves>(tot, lds, [&](float (&acc)[8], int cls) {
+  tile_sums<kWaves, 8, kPositionMode>(tot, lds, [&](float (&acc)[8], int cls) {
     float &a0 = acc[0], &a1 = acc[1], &a2 = acc[2], &a3 = acc[3], &a5 = acc[4], &a6 = acc[5], &a7 = acc[6], &a8 = acc[7];
     for_each_candidate(num_kfs, cand, [&](int k) {
       const float* F = kfs[k].pose.F;
@@ -343,8 +386,8 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
         a8 += wr2 * jd;
       }
     }, kSumClasses, cls);
-  });
-  if (!live || !writer) return;
+  }, cpp, ii, in_range);
+  if (kPhase == 2 || !live || !writer) return;
   const float a0 = tot[0], a1 = tot[1], a2 = tot[2], a3 = tot[3], a5 = tot[4], a6 = tot[5], a7 = tot[6], a8 = tot[7];
 
   // B/kernel_opt_geometry.cu:273-353: in-place Cholesky of the 3x3 system (H12 is exactly 0).
@@ -367,6 +410,52 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
   }
   if (x1 != 0) s.row(kSurfelDescriptor1)[i] = fmaxf(-180.f, fminf(180.f, d1 - x1));
   if (x2 != 0) s.row(kSurfelDescriptor2)[i] = fmaxf(-180.f, fminf(180.f, d2 - x2));
+}
+
+template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate>
+__global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
+geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count) {
+  __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
+  geometry_step<kUseDepth, kUseDesc, kWaves, kActivate, 0>(in, kfs, num_kfs, s, activate_count, lds, ClassPartials{}, ClassPartials{});
+}
+
+// One phase of the keyframe-sharded geometry step (geometry_step: kPhase).
+template <bool kUseDepth, bool kUseDesc, bool kActivate, int kPhase>
+__global__ void __launch_bounds__(64) BAHIP_WAVES_ATTR
+geometry_phase_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
+                      ClassPartials cpn, ClassPartials cpp) {
+  geometry_step<kUseDepth, kUseDesc, 1, kActivate, kPhase>(in, kfs, num_kfs, s, activate_count, nullptr, cpn, cpp);
+}
+
+// Surfel activation under keyframe sharding: this rank's kActive keyframes only; hits[i] = 1 where one of them sees surfel i
+// (the words are summed over the ranks as integers, then activation_from_hits_kernel sets the flags).
+__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
+activation_hits_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t surfels_size,
+                       uint32_t owner_mask, uint32_t owner_rank, uint32_t* __restrict__ hits) {
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + threadIdx.x;
+  const bool in_range = i < surfels_size;
+  const uint32_t ii = in_range ? i : 0;
+  const Vec3 gp = surfel_position(s, ii);
+  const Vec3 gn = surfel_normal(s, ii);
+  const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
+  bool active = false;
+  for_each_candidate_until(
+      num_kfs,
+      [&](int k) {
+        return ((uint32_t)k & 3u & owner_mask) == owner_rank && kfs[k].activation == BAHIP_KF_ACTIVE && sphere_may_project(in, kfs[k].pose.F, wb);
+      },
+      [&](int k) {
+        if (in_range && !active) {
+          Assoc r;
+          if (project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) active = true;
+        }
+        return __all(active || !in_range) != 0;
+      });
+  if (in_range) hits[i] = active ? 1u : 0u;
+}
+__global__ void activation_from_hits_kernel(SurfelsView s, uint32_t surfels_size, const uint32_t* __restrict__ hits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < surfels_size) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (hits[i] ? kSurfelActiveFlag : 0);
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
@@ -427,6 +516,49 @@ void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const In
     if (activate_count < 0) launch_geometry_shape<4, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
     else launch_geometry_shape<4, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
   }
+}
+
+// ---- keyframe sharding ------------------------------------------------------------------------------------------------
+int geometry_normals_sums(bool activate) { return activate ? 5 : 4; }
+int geometry_position_sums(bool use_desc) { return use_desc ? 8 : 2; }
+
+template <bool kUseDepth, bool kUseDesc, bool kActivate>
+static void launch_geometry_phase_of(hipStream_t stream, int phase, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                                     uint32_t activate_count, const ClassPartials& cpn, const ClassPartials& cpp) {
+  const dim3 grid(grid_for(s.size)), block(64);
+  if (phase == 1) hipLaunchKernelGGL((geometry_phase_kernel<kUseDepth, kUseDesc, kActivate, 1>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, cpn, cpp);
+  else if (phase == 2) hipLaunchKernelGGL((geometry_phase_kernel<kUseDepth, kUseDesc, kActivate, 2>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, cpn, cpp);
+  else hipLaunchKernelGGL((geometry_phase_kernel<kUseDepth, kUseDesc, kActivate, 3>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, cpn, cpp);
+}
+
+// One phase (1, 2, 3: geometry_step) of the keyframe-sharded geometry step; the caller clears the partials a phase produces
+// beforehand and sums them over the ranks afterwards.
+void launch_geometry_phase(hipStream_t stream, int phase, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                           const SurfelsView& s, long long activate_count, const ClassPartials& cpn, const ClassPartials& cpp) {
+  if (s.size == 0) return;
+  const uint32_t n = activate_count < 0 ? 0u : (uint32_t)activate_count;
+  const bool act = activate_count >= 0;
+  if (!use_desc) {
+    if (act) launch_geometry_phase_of<true, false, true>(stream, phase, in, kfs, num_kfs, s, n, cpn, cpp);
+    else launch_geometry_phase_of<true, false, false>(stream, phase, in, kfs, num_kfs, s, n, cpn, cpp);
+  } else if (use_depth) {
+    if (act) launch_geometry_phase_of<true, true, true>(stream, phase, in, kfs, num_kfs, s, n, cpn, cpp);
+    else launch_geometry_phase_of<true, true, false>(stream, phase, in, kfs, num_kfs, s, n, cpn, cpp);
+  } else {
+    if (act) launch_geometry_phase_of<false, true, true>(stream, phase, in, kfs, num_kfs, s, n, cpn, cpp);
+    else launch_geometry_phase_of<false, true, false>(stream, phase, in, kfs, num_kfs, s, n, cpn, cpp);
+  }
+}
+
+void launch_activation_hits(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s, uint32_t surfels_size,
+                            int kf_rank, int kf_world, uint32_t* hits) {
+  if (surfels_size == 0) return;
+  hipLaunchKernelGGL(activation_hits_kernel, dim3(grid_for(surfels_size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s, surfels_size,
+                     (uint32_t)(kf_world - 1), (uint32_t)kf_rank, hits);
+}
+void launch_activation_from_hits(hipStream_t stream, const SurfelsView& s, uint32_t surfels_size, const uint32_t* hits) {
+  if (surfels_size == 0) return;
+  hipLaunchKernelGGL(activation_from_hits_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, s, surfels_size, hits);
 }
 
 }  // namespace bahip

@@ -53,6 +53,7 @@ def _load():
         L.dba_download_cfactor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dba_clear_cfactor.argtypes = [C.c_void_p, C.c_void_p]
         L.dba_set_surfel_sharding.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        L.dba_set_keyframe_sharding.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.dba_set_pcg_gauge_keyframe.argtypes = [C.c_void_p, C.c_int]
         L.dba_set_ba_iteration_counts.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.dba_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -238,6 +239,10 @@ class DirectBA:
     def SetSurfelSharding(self, rank, world, chunk=1024):
         """This object holds rank `rank`'s chunk-cyclic shard of one cloud; lifecycle phases run on the gathered cloud."""
         assert self.L.dba_set_surfel_sharding(self.h, int(rank), int(world), int(chunk)) == 0
+
+    def SetKeyframeSharding(self, rank, world):
+        """This object holds all surfels and sweeps the keyframes k with (k % 4) % world == rank (alternating scheme only)."""
+        assert self.L.dba_set_keyframe_sharding(self.h, int(rank), int(world)) == 0
 
     def set_pcg_gauge_keyframe(self, k):
         self.L.dba_set_pcg_gauge_keyframe(self.h, int(k))

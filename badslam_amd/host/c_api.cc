@@ -184,6 +184,10 @@ int dba_set_surfel_sharding(dba_handle* h, int rank, int world, uint32_t chunk) 
   h->ba->SetSurfelSharding(rank, world, chunk);
   return 0;
 }
+int dba_set_keyframe_sharding(dba_handle* h, int rank, int world) {
+  h->ba->SetKeyframeSharding(rank, world);
+  return 0;
+}
 int dba_set_pcg_gauge_keyframe(dba_handle* h, int id) {
   h->ba->SetPCGGaugeKeyframe(id);
   return 0;

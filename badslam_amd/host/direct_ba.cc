@@ -207,6 +207,7 @@ void DirectBA::BindScene(hipStream_t stream) {
 // ---- surfel sharding: whole-cloud phases -----------------------------------------------------------------------------
 void DirectBA::SetSurfelSharding(int rank, int world, u32 chunk) {
   CHECK(world >= 1 && rank >= 0 && rank < world && chunk > 0 && chunk % 64 == 0) << "bad surfel partition";
+  CHECK(world == 1 || keyframe_shard_world_ == 1) << "surfel and keyframe sharding exclude each other";
   CHECK_EQ(whole_cloud_depth_, 0);
   shard_rank_ = rank; shard_world_ = world; shard_chunk_ = chunk;
   if (world > 1 && !other_surfels_) {
@@ -214,6 +215,12 @@ void DirectBA::SetSurfelSharding(int rank, int world, u32 chunk) {
     other_surfels_.reset(new CUDABuffer<float>(kSurfelAttributeCount, surfels_->width()));
     other_active_surfels_.reset(new CUDABuffer<u8>(1, surfels_->width()));
   }
+}
+
+void DirectBA::SetKeyframeSharding(int rank, int world) {
+  CHECK_EQ(shard_world_, 1) << "surfel and keyframe sharding exclude each other";
+  BAHIP_CHECKED_CALL(bahip_context_set_keyframe_sharding(ctx_, rank, world));
+  keyframe_shard_world_ = world;
 }
 
 void DirectBA::EnterWholeCloud(hipStream_t stream) {
@@ -318,6 +325,10 @@ void DirectBA::BundleAdjustment(hipStream_t stream, bool optimize_depth_intrinsi
     optimize_color_intrinsics = false;
   }
   last_pose_rounds_ = last_pose_steps_ = last_pcg_inner_steps_ = 0;
+  if (keyframe_shard_world_ > 1)
+    CHECK(!use_pcg && !optimize_depth_intrinsics && !optimize_color_intrinsics && !do_surfel_updates && !increase_ba_iteration_count)
+        << "keyframe sharding covers the alternating scheme over poses and geometry without surfel updates and end tasks "
+           "(their per-surfel sums run over all keyframes in order): use surfel sharding for the rest";
   if (use_pcg) {
     BundleAdjustmentPCG(stream, optimize_depth_intrinsics, optimize_color_intrinsics, do_surfel_updates, optimize_poses,
                         optimize_geometry, min_iterations, max_iterations, pcg_max_inner_iterations, pcg_max_keyframes,

@@ -125,6 +125,13 @@ class DirectBA {
   // rank, runs unchanged, and takes the shard back out -- so a sharded BundleAdjustment with do_surfel_updates ends with the
   // bits of the unsharded one.  Needs SetAllReduce (or an RCCL communicator on the backend context) when world > 1.
   void SetSurfelSharding(int rank, int world, u32 chunk);
+  // Multi-GPU KEYFRAME sharding (bahip_context_set_keyframe_sharding): this object holds ALL surfels; of the keyframes it needs
+  // the images of those with (index among the non-deleted keyframes) % 4 % world == rank only (world = 1, 2, 4).  Covers the
+  // alternating scheme over poses and geometry -- BundleAdjustment(stream, false, false, /*do_surfel_updates*/ false, ...,
+  // /*use_pcg*/ false, ..., /*increase_ba_iteration_count*/ false) -- and ends with the unsharded run's bits on every rank; the
+  // intrinsics step, the PCG scheme and the surfel lifecycle (end tasks included) are refused.  Needs SetAllReduce or an RCCL
+  // communicator when world > 1.
+  void SetKeyframeSharding(int rank, int world);
   bahip_context* backend_context() { return ctx_; }
   // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
   // keyframe ids and the dense bound list.  Public so that a caller can drive single bahip_* stages
@@ -186,6 +193,7 @@ class DirectBA {
   vector<int> id_to_bound_;      // keyframe id -> bound list index (-1 for deleted keyframes)
   int pcg_gauge_keyframe_ = -1;
   int shard_rank_ = 0, shard_world_ = 1, whole_cloud_depth_ = 0;
+  int keyframe_shard_world_ = 1;
   u32 shard_chunk_ = 0;
   CUDABufferPtr<float> other_surfels_;      // under surfel sharding: the buffer not in use (whole cloud <-> shard)
   CUDABufferPtr<u8> other_active_surfels_;

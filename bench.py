@@ -62,6 +62,11 @@ def parse_args():
                         "a planning aid, the JSON line then describes that share, not the whole job")
     p.add_argument("--emulate-rank", type=int, default=0)
     p.add_argument("--shard-chunk", type=int, default=4096, help="surfels per chunk of the chunk-cyclic partition; 0 = contiguous")
+    p.add_argument("--shard", choices=["surfels", "keyframes"], default="surfels",
+                   help="what N > 1 ranks divide: surfels (keyframe images replicated; the production axis, any N) or keyframes "
+                        "(BASELINE configs[3] as written: every rank holds all surfels and the images of the keyframes k with "
+                        "(k %% 4) %% N == rank; N = 2 or 4; class partials of the geometry step and the pose normal equations are "
+                        "exchanged; same bits as one GPU)")
     p.add_argument("--no-spatial-sort", action="store_true", help="leave the surfels in creation order")
     p.add_argument("--sort-cell", type=float, default=0.02, help="grid cell of DirectBA::SortSurfelsSpatially [m] (its default: 0.02)")
     p.add_argument("--launch-shapes", default="", help="experiment: 'tile_waves,pose_parts' forced through bahip_debug_set_launch_shapes (0 = heuristic)")
@@ -304,6 +309,7 @@ def main():
     from badslam_amd import capi, multigpu
     ba, data, poses_gt = build_scene(args, log)
     N_total = data.shape[1]
+    start_poses = [ba.keyframe_pose(k) for k in range(args.keyframes)]   # the perturbed poses (for the cold-start figure)
     if args.build_only:
         return
     # surfel sharding: rank r owns every world-th chunk of 4096 surfels (keyframe images replicated on every rank)
@@ -314,7 +320,14 @@ def main():
     else:
         lo, hi = multigpu.shard_range(N_total, shard_rank, shard_world)
         mine = np.arange(lo, hi, dtype=np.int64)
-    ba.upload_surfels(np.ascontiguousarray(data[:, mine]) if shard_world > 1 else data)
+    by_keyframes = args.shard == "keyframes" and shard_world > 1
+    if by_keyframes:
+        if shard_world not in (2, 4) or args.intrinsics or args.pcg:
+            print("bench.py: --shard keyframes takes 2 or 4 ranks and the alternating scheme over poses and geometry (the per-surfel "
+                  "sums have four keyframe classes; intrinsics / PCG need surfel sharding)", file=sys.stderr)
+            sys.exit(2)
+        mine = np.arange(N_total, dtype=np.int64)
+    ba.upload_surfels(np.ascontiguousarray(data[:, mine]) if (shard_world > 1 and not by_keyframes) else data)
     ctx = ba.backend_context()
     hook_keepalive = None
     if dist is not None:
@@ -335,6 +348,8 @@ def main():
         else:
             hook_keepalive = multigpu.install_allreduce(ctx, dist)
     K = args.keyframes
+    if by_keyframes:
+        ba.SetKeyframeSharding(shard_rank, shard_world)
 
     def run(iterations, intrinsics=args.intrinsics, pcg=args.pcg):
         # BA iteration counters equal -> BundleAdjustment skips PerformBASchemeEndTasks (fixed surfel set)
@@ -395,6 +410,27 @@ def main():
     # Untimed extras, so that the driver's default run also sees the other two stages of SURVEY 8d: the intrinsics step of the
     # alternating scheme (reference timing key BA_intrinsics_optimization, B/direct_ba_alternating.cc:687) and the PCG scheme.
     extras = {}
+    if not args.no_extras and not args.pcg and not args.intrinsics and shard_world == 1 and world == 1:
+        # Cold start: `value` is measured after the warm-up iterations have absorbed the 5 mm / 1 mrad
+        # perturbation (R close to 1 Gauss-Newton round per keyframe).  Here the scene is put back to its perturbed state --
+        # surfels re-uploaded, poses reset -- and the FIRST iterations are timed: every keyframe takes several rounds.
+        COLD_STEPS = 5
+        capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
+        ba.upload_surfels(data)
+        for k, T in enumerate(start_poses):
+            ba.set_keyframe_pose(k, T)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        t_cold = time.perf_counter()
+        run(COLD_STEPS)
+        ctx.synchronize()
+        dt_cold = time.perf_counter() - t_cold
+        cold_stats = ba.last_stats()
+        extras["cold_start"] = {"iterations": COLD_STEPS, "ba_iterations_per_s": COLD_STEPS / dt_cold, "ms_per_iteration": 1e3 * dt_cold / COLD_STEPS,
+                                "pose_gn_rounds_per_iteration": cold_stats["pose_rounds"] / COLD_STEPS,
+                                "pose_gn_steps_per_keyframe": cold_stats["pose_steps"] / (COLD_STEPS * K),
+                                "note": "iterations 1-5 from the perturbed state (poses * exp(N(0, 5 mm / 1 mrad)), surfels + U(0, 5 mm)), after the "
+                                        "timed region; `value` is the rate once the perturbation has been absorbed"}
     if not args.no_extras and not args.pcg and shard_world == 1 and world == 1:
         EXTRA_STEPS = 3
         if not args.intrinsics:
@@ -450,7 +486,8 @@ def main():
                        "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
                        "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
                        "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, %g cm grid)" % (100 * args.sort_cell),
-                       "parallelism": f"surfel-shard x{world}, RCCL all-reduce of pose H,b" if world > 1 else "single GPU"},
+                       "parallelism": (f"keyframe-shard x{world}, RCCL all-reduce of the geometry step's class partials and of pose H,b" if by_keyframes
+                                       else f"surfel-shard x{world}, RCCL all-reduce of pose H,b") if world > 1 else "single GPU"},
             **({"emulated_share_of_world": shard_world} if shard_world != world else {}),
             **({"exchange": {"calls_per_iteration": exchange_calls.value / args.steps, "bytes_per_iteration": exchange_bytes.value / args.steps,
                              "what": "int64 fixed-point pose normal equations, one all-reduce per Gauss-Newton round"

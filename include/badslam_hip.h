@@ -109,6 +109,23 @@ int bahip_context_is_sharded(bahip_context* ctx);
 enum { BAHIP_SUM_F32 = 0, BAHIP_SUM_I64 = 1, BAHIP_SUM_F64 = 2 };
 typedef int (*bahip_allreduce_fn)(void* device_buffer, size_t count, int dtype, void* hip_stream, void* user);
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user);
+/* Multi-GPU KEYFRAME sharding (BASELINE configs[3]: "sharded by keyframe, RCCL all-reduce of pose Hessians"; the loop it
+ * partitions: B/kernel_opt_geometry.cc:108-200, B/kernel_opt_pose.cc:67-96, B/kernel_surfel_activation.cc:53-66).  Every rank
+ * holds ALL surfels and the images of its own keyframes only: bound keyframe k lives on rank (k % 4) % world, world = 1, 2 or 4
+ * (the per-surfel sums are defined as four interleaved partial sums over the keyframe classes k % 4, kernels_surfel.hip, so
+ * whole classes per rank reproduce the unsharded bits; 8 ranks would need an 8-class definition).  bahip_set_keyframes still
+ * takes all keyframes -- poses and activation states are replicated -- but the image pointers of keyframes that live elsewhere
+ * are not looked at (pass NULL).  With it
+ *   - bahip_update_surfel_activation sums one hit word per surfel over the ranks (BAHIP_SUM_I64, N / 2 words);
+ *   - bahip_optimize_geometry_iteration / bahip_update_activation_and_optimize_geometry run in three launches with two
+ *     exchanges of the class partials (bit patterns as BAHIP_SUM_I64: 4 x 5 and 4 x 8 binary32 values per surfel);
+ *   - bahip_estimate_keyframe_poses* sweep this rank's keyframes, sum the fixed-point normal equations over the ranks
+ *     (K x 56 int64 per Gauss-Newton round, the exchange surfel sharding makes too) and solve every pose on every rank;
+ *   - everything ends with the bits of the unsharded run on every rank.
+ * The intrinsics step, the PCG scheme and the surfel lifecycle are refused in this mode (their per-surfel chains run over all
+ * keyframes in order; use surfel sharding).  A hook or an RCCL communicator must be installed when world > 1.  Surfel and
+ * keyframe sharding exclude each other on one context. */
+int bahip_context_set_keyframe_sharding(bahip_context* ctx, int rank, int world);
 #define BAHIP_RCCL_UNIQUE_ID_BYTES 128
 int bahip_rccl_get_unique_id(char unique_id_out[BAHIP_RCCL_UNIQUE_ID_BYTES]);
 int bahip_context_init_rccl(bahip_context* ctx, const char unique_id[BAHIP_RCCL_UNIQUE_ID_BYTES], int rank, int world_size);

@@ -32,6 +32,29 @@ def test_bench_under_torchrun_with_shared_device(world):
     assert [r["rank"] for r in out["per_rank"]] == list(range(world)) and sum(r["surfels"] for r in out["per_rank"]) == out["config"]["surfels"]
 
 
+def test_bench_sharded_by_keyframes():
+    """`--shard keyframes` (BASELINE configs[3] as written) under torch.distributed.run, two ranks sharing the device over gloo:
+    every rank holds the whole cloud, the geometry step's class partials and the pose normal equations are exchanged; the line
+    names the axis.  Three ranks are refused (four keyframe classes)."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--master-addr", "127.0.0.1"]
+    flags = ["--steps", "3", "--warmup", "1", "--keyframes", "16", "--surfels", "150000", "--no-cpu-baseline", "--shard", "keyframes"]
+    proc = subprocess.run(base + ["--nproc-per-node=2", "--master-port", "29711", os.path.join(ROOT, "bench.py"), "--gpus", "2", *flags],
+                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"].startswith("keyframe-shard x2")
+    N = out["config"]["surfels"]
+    assert all(r["surfels"] == N for r in out["per_rank"])                       # the whole cloud on every rank
+    # per iteration: two exchanges of class partials (4 x 5 and 4 x 8 binary32 values per surfel) + one of 16 x 56 int64 per pose round
+    assert out["exchange"]["calls_per_iteration"] >= 3 and out["exchange"]["bytes_per_iteration"] >= N * 4 * 13 * 4
+    proc = subprocess.run(base + ["--nproc-per-node=3", "--master-port", "29712", os.path.join(ROOT, "bench.py"), "--gpus", "3", *flags],
+                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert proc.returncode != 0 and "2 or 4 ranks" in proc.stderr
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (how the driver starts the N = 1 leg): bench.py starts the two
     ranks itself.  Over RCCL that needs two devices -- this box has one, so it must refuse; with BENCH_DIST_BACKEND=gloo the

@@ -282,3 +282,182 @@ def test_sharded_bundle_adjustment_with_surfel_updates_is_the_unsharded_run(use_
     assert np.array_equal(merged.view(np.uint32), ref["surfels"].view(np.uint32))
     for k in range(len(start)):
         assert np.array_equal(results[0]["poses"][k], results[1]["poses"][k]) and np.array_equal(ref["poses"][k], results[0]["poses"][k]), k
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_keyframe_shards_reproduce_the_unsharded_run(world):
+    """KEYFRAME sharding (BASELINE configs[3]; bahip_context_set_keyframe_sharding): every rank holds the whole cloud and the
+    images of its own keyframes only -- bound keyframe k lives on rank (k % 4) % world, the other keyframes are bound with null
+    image pointers.  Activation sums one hit word per surfel; the geometry step runs in three launches with the class partials
+    of the normals pass and of the position pass exchanged as bit patterns; the pose phase sums the fixed-point normal
+    equations of disjoint keyframes ("all-reduce of pose Hessians") and every rank solves every pose.  After ITERATIONS
+    alternating iterations every rank must hold the unsharded run's surfels (positions, normals, descriptors, flags) and
+    poses, bit for bit."""
+    import torch
+    from badslam_amd import capi
+    torch.cuda.set_device(0)
+    scene = common.small_scene(num_keyframes=7, seed=21)
+    rng = np.random.Generator(np.random.PCG64(4))
+    start_poses = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+
+    g = common.build_gpu(scene, 500000)
+    data = g.download_surfels()
+    data[2] += rng.uniform(0, 0.004, data.shape[1]).astype(np.float32)
+    N = data.shape[1]
+
+    def prepare(gr):
+        gr.upload_surfels(data, np.ones(N, np.uint8))
+        for k, T in enumerate(start_poses):
+            gr.keyframes[k]["pose"] = np.asarray(T, np.float32)
+
+    def step(gr):
+        # second iteration: keyframe 2 is inactive (neither swept by the geometry step nor re-estimated), 5 only co-visible
+        out = []
+        for it in range(ITERATIONS):
+            for k, kf in enumerate(gr.keyframes):
+                kf["activation"] = capi.KF_ACTIVE
+            if it == 1:
+                gr.keyframes[2]["activation"] = capi.KF_INACTIVE
+                gr.keyframes[5]["activation"] = capi.KF_COVISIBLE_ACTIVE
+            gr.bind_keyframes()
+            if it == 2:
+                gr.update_activation_and_optimize_geometry(True, True)      # the fused form DirectBA uses
+            else:
+                gr.update_surfel_activation()
+                gr.optimize_geometry_iteration(True, it != 1)                # depth + descriptors, then depth only
+            poses, its, conv, rounds = gr.estimate_keyframe_poses(True, True)
+            for k, kf in enumerate(gr.keyframes):
+                kf["pose"] = poses[k].astype(np.float32)
+            out.append((rounds, tuple(its), tuple(conv)))
+        return out
+
+    prepare(g)
+    ref = dict(out=step(g), surfels=g.download_surfels(), active=g.active_buf.download().ravel()[:N].copy(),
+               poses=[kf["pose"].copy() for kf in g.keyframes])
+
+    loop = _Loopback(world)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            gr = common.build_gpu(scene, 500000, create_from=[])
+            prepare(gr)
+            hook = loop.hook_for(rank)
+            capi.check(gr.ctx.lib.bahip_context_set_allreduce(gr.ctx.handle, hook, None))
+            gr.set_keyframe_sharding(rank, world)
+            out = step(gr)
+            results[rank] = dict(out=out, surfels=gr.download_surfels(), active=gr.active_buf.download().ravel()[:N].copy(),
+                                 poses=[kf["pose"].copy() for kf in gr.keyframes], keep=(hook, gr))
+        except Exception as e:
+            errors.append((rank, repr(e)))
+            loop.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    # per iteration: (activation 1 | 0 when fused) + geometry 2 + one exchange per Gauss-Newton round
+    assert loop.calls == sum((2 if it == 2 else 3) + o[0] for it, o in enumerate(ref["out"]))
+    for r in results:
+        assert r["out"] == ref["out"]                                          # rounds, iteration counts, convergence flags
+        for k in range(len(start_poses)):
+            assert np.array_equal(ref["poses"][k], r["poses"][k]), (k, common.pose_error(ref["poses"][k], r["poses"][k]))
+        assert np.array_equal(r["surfels"][:8].view(np.uint32), ref["surfels"][:8].view(np.uint32))
+        assert np.array_equal(r["active"], ref["active"])
+    # the scene exercises what the mode has to get right: some surfels inactive, some moved, every keyframe re-estimated
+    assert np.count_nonzero(ref["active"] & 1) > N // 2
+    assert np.count_nonzero(ref["surfels"][:3] != data[:3]) > N
+    assert all(sum(o[1]) >= len(start_poses) - 1 for o in ref["out"])
+
+
+def test_keyframe_sharding_refuses_what_it_does_not_cover():
+    """The intrinsics step, the PCG scheme and the lifecycle keep per-surfel chains over all keyframes in order: under keyframe
+    sharding they fail with an error that says so (no silent wrong answer); world sizes other than 1, 2, 4 are refused."""
+    import torch
+    from badslam_amd import capi
+    torch.cuda.set_device(0)
+    scene = common.small_scene(num_keyframes=3, seed=3)
+    g = common.build_gpu(scene, 200000)
+    lib, h = g.ctx.lib, g.ctx.handle
+    assert lib.bahip_context_set_keyframe_sharding(h, 0, 3) != 0 and b"1, 2 or 4" in lib.bahip_last_error()
+    assert lib.bahip_context_set_keyframe_sharding(h, 2, 2) != 0
+    g.set_keyframe_sharding(1, 2)
+    g.bind_keyframes()
+    with pytest.raises(RuntimeError, match="keyframe sharding"):
+        g.optimize_intrinsics(True, True)
+    with pytest.raises(RuntimeError, match="keyframe sharding"):
+        g.update_surfel_normals()
+    with pytest.raises(RuntimeError, match="keyframe sharding"):
+        g.delete_surfels_and_update_radii(1)
+    with pytest.raises(RuntimeError, match="hook or an RCCL communicator"):
+        g.update_surfel_activation()                                           # sharded, but nothing to exchange with
+    g.set_keyframe_sharding(0, 1)
+    g.bind_keyframes()
+    g.update_surfel_activation()
+
+
+def test_keyframe_sharded_bundle_adjustment_is_the_unsharded_run():
+    """DirectBA::BundleAdjustment under DirectBA::SetKeyframeSharding (two ranks): the alternating scheme over poses and
+    geometry, four iterations with the device-side activation state machine (keyframes that stop moving become inactive and
+    are woken by co-visible ones) -- every rank ends with the unsharded run's poses, surfels and iteration statistics."""
+    import torch
+    from badslam_amd import capi
+    from badslam_amd.directba import DirectBA
+    torch.cuda.set_device(0)
+    scene = common.small_scene(num_keyframes=6, seed=23)
+    rng = np.random.Generator(np.random.PCG64(11))
+    start = [common.synthetic.perturb_pose(rng, T, 0.003, 0.001) for T in scene.poses_gt]
+
+    def build():
+        ba = DirectBA(600000, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, scene.width, scene.height, scene.camera, scene.camera)
+        for k in range(len(scene.depth)):
+            ba.AddKeyframe(scene.depth[k], scene.rgb[k], scene.poses_gt[k])
+        for k in range(len(scene.depth)):
+            ba.CreateSurfelsForKeyframe(k)                        # the whole cloud on every rank, before the mode is switched on
+        for k, T in enumerate(start):
+            ba.set_keyframe_pose(k, T)
+        return ba
+
+    def run(ba):
+        ba.set_ba_iteration_counts(1, 1)                          # equal counters: no end tasks at the top of the call (SURVEY 8d)
+        ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=4, max_iterations=4,
+                            use_pcg=False, increase_ba_iteration_count=False)
+        return dict(stats=ba.last_stats(), surfels=ba.download_surfels(8), poses=[ba.keyframe_pose(k) for k in range(len(start))],
+                    activation=[ba.keyframe_activation(k) for k in range(len(start))])
+
+    ref = run(build())
+    world = 2
+    loop = _Loopback(world)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            ba = build()
+            hook = loop.hook_for(rank)
+            ctx = ba.backend_context()
+            capi.check(ctx.lib.bahip_context_set_allreduce(ctx.handle, hook, None))
+            ba.SetKeyframeSharding(rank, world)
+            out = run(ba)
+            out["keep"] = (hook, ba)
+            results[rank] = out
+        except Exception as e:
+            errors.append((rank, repr(e)))
+            loop.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    for r in results:
+        assert r is not None and r["stats"] == ref["stats"] and r["activation"] == ref["activation"]
+        for k in range(len(start)):
+            assert np.array_equal(np.asarray(ref["poses"][k]), np.asarray(r["poses"][k])), k
+        assert np.array_equal(r["surfels"].view(np.uint32), ref["surfels"].view(np.uint32))
+    assert ref["stats"]["pose_steps"] >= len(start)
