@@ -32,7 +32,8 @@ void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* 
 void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
 void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                     int num_kfs, const SurfelsView& s, long long activate_count = -1);
+                     int num_kfs, const SurfelsView& s, long long activate_count = -1,
+                     const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
 
 // keyframe sharding (kernels_surfel.hip: geometry_step, kPhase): one phase of the geometry step over this rank's keyframe classes
 int geometry_normals_sums(bool activate);     // sums per class and surfel of the normals pass (cpn) ...
@@ -52,7 +53,14 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
                             int num_listed /* stored_bounds: entries of the list of work items still iterating */,
                             uint32_t* tile_counters /* 16 words, zero before the first launch; NULL: never the persistent LDS form */,
-                            int* parity_inout /* which half of tile_counters the next persistent launch draws from */);
+                            int* parity_inout /* which half of tile_counters the next persistent launch draws from */,
+                            uint32_t* tile_cost = nullptr /* one word per tile, zero before a first round: += the candidates the tile visits */,
+                            const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
+uint32_t pose_padded_tiles(uint32_t surfels);   // tiles of the (padded) grid the sweeps run over: the length of tile_cost
+size_t tile_schedule_words(uint32_t padded_tiles);   // words of a schedule for such a grid
+// sched := heavy tiles + runs by descending cost (wave_cull.h; clears tile_cost); false if there are more runs than the kernel
+// handles (sched untouched)
+bool launch_tile_order(hipStream_t stream, uint32_t* tile_cost, uint32_t padded_tiles, uint32_t* sched);
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out,
                        int sequence /* published to the host copy of the counters when the launch is complete */);
@@ -99,6 +107,10 @@ void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* g
 void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, float* cells_f, const float* x1, float* cfactor,
                                    uint32_t cfactor_pitch);
 
+#ifdef BAHIP_TILE_TIMELINE
+void geometry_timeline_dump(const char* path);   // experiment build only (kernels_surfel.hip, kernels_pose.hip; scripts/tile_timeline.py)
+void pose_timeline_dump(const char* path);
+#endif
 #ifdef BAHIP_COUNT_CANDIDATES
 void pose_counters_dump();   // experiment build only (kernels_pose.hip)
 #endif

@@ -111,6 +111,13 @@ struct bahip_context {
   bool poll_disabled = false;        // the host copy of the pose counters is not updated by the kernel on this system: synchronise instead
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
+  // heavy runs first (wave_cull.h: xcd_ordered_tile): candidates per tile counted by the first pose round of a phase over the
+  // keyframe table, and the run permutation built from them, valid for grids of tile_order_tiles (padded) tiles (0: none yet)
+  uint32_t* dev_tile_cost = nullptr;
+  uint32_t* dev_tile_order = nullptr;
+  size_t tile_schedule_capacity = 0;   // tiles
+  uint32_t tile_order_tiles = 0;
+  int phases_since_schedule = 0;       // the schedule is rebuilt when the grid changes and every kSchedulePhases-th phase
 
   float* intr_scratch = nullptr;   // intrinsics step: (64 + 8 S) doubles, then (64 + 8 S) floats + Schur partials
   int intr_capacity = 0;
@@ -337,6 +344,27 @@ int ensure_tile_bounds(bahip_context* ctx, uint32_t surfels) {
   return 0;
 }
 
+static int g_tile_order_enabled = [] { const char* e = getenv("BAHIP_TILE_ORDER"); return e ? atoi(e) : 1; }();
+int ensure_tile_schedule(bahip_context* ctx, uint32_t padded_tiles) {
+  if (padded_tiles <= ctx->tile_schedule_capacity) return 0;
+  const size_t cap = (size_t)padded_tiles + padded_tiles / 4;
+  uint32_t* cost = nullptr; uint32_t* order = nullptr;
+  if (hipMalloc(&cost, sizeof(uint32_t) * cap) != hipSuccess || hipMalloc(&order, sizeof(uint32_t) * tile_schedule_words((uint32_t)cap)) != hipSuccess) {
+    hipFree(cost); hipFree(order);
+    return fail("allocation of the tile schedule failed", __FILE__, __LINE__);
+  }
+  HIP_TRY(hipMemsetAsync(cost, 0, sizeof(uint32_t) * cap, ctx->stream));
+  hipFree(ctx->dev_tile_cost); hipFree(ctx->dev_tile_order);
+  ctx->dev_tile_cost = cost; ctx->dev_tile_order = order;
+  ctx->tile_schedule_capacity = cap;
+  ctx->tile_order_tiles = 0;
+  return 0;
+}
+// The run permutation for a sweep over `surfels` surfels, or NULL (none built for this grid size yet, or switched off).
+const uint32_t* tile_order_for(const bahip_context* ctx, uint32_t surfels) {
+  return (g_tile_order_enabled && ctx->tile_order_tiles != 0 && ctx->tile_order_tiles == pose_padded_tiles(surfels)) ? ctx->dev_tile_order : nullptr;
+}
+
 // Waits until pose_solve_kernel has published `sequence` in the host copy of the counter records.  Polling a word of mapped
 // host memory costs a microsecond where hipStreamSynchronize + a 256-byte copy cost 25.  If the word does not show up within
 // two seconds (a runtime that does not map the allocation coherently), fall back to synchronising and copying.
@@ -368,11 +396,20 @@ int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_work, const PoseWo
 // Batched Gauss-Newton rounds over `num_work` work items already initialised on the device.
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
-                    PoseWork* host_work /* page-locked, num_work + kPoseTailRecords records */, int* rounds_out) {
+                    PoseWork* host_work /* page-locked, num_work + kPoseTailRecords records */, int* rounds_out,
+                    bool schedule = false /* a phase over the keyframe table: its first round counts the candidates per tile and the
+                    run order of the following sweeps is rebuilt from them */) {
   int rounds = 0;
   int iterating = num_work;
   const int* counters = reinterpret_cast<const int*>(host_work + num_work);
   if (ensure_tile_bounds(ctx, s.size)) return 1;
+  const uint32_t padded_tiles = pose_padded_tiles(s.size);
+  // (costs drift slowly -- poses move by millimetres, keyframes come one at a time -- so the census and the 10 us of the order
+  // kernel are spent on every 8th phase only, and whenever the grid has changed)
+  constexpr int kSchedulePhases = 8;
+  schedule = schedule && g_tile_order_enabled && s.size > 0 &&
+             (ctx->tile_order_tiles != padded_tiles || ++ctx->phases_since_schedule >= kSchedulePhases);
+  if (schedule && ensure_tile_schedule(ctx, padded_tiles)) return 1;
   static const bool host_timing = getenv("BADSLAM_HOST_TIMING") != nullptr;   // diagnostics: where a pose round's wall time goes
   static double t_launch = 0, t_wait = 0; static long n_rounds = 0;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -380,9 +417,15 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
     const double t0 = host_timing ? now() : 0;
     timer_begin(ctx, 2, round == 0, iterating);
     launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb, ctx->dev_tile_bounds,
-                           /*stored_bounds*/ round > 0, /*num_listed*/ iterating, ctx->dev_tile_counters, &ctx->pose_parity);
+                           /*stored_bounds*/ round > 0, /*num_listed*/ iterating, ctx->dev_tile_counters, &ctx->pose_parity,
+                           (schedule && round == 0) ? ctx->dev_tile_cost : nullptr, tile_order_for(ctx, s.size));
     timer_end(ctx, 2);
     CHECK_LAUNCH();
+    if (schedule && round == 0 && launch_tile_order(ctx->stream, ctx->dev_tile_cost, padded_tiles, ctx->dev_tile_order)) {
+      ctx->tile_order_tiles = padded_tiles;
+      ctx->phases_since_schedule = 0;
+      CHECK_LAUNCH();
+    }
     // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
     // (keyframe sharding: the ranks hold disjoint keyframes and all surfels, so the sum completes each rank's table -- the
     // "all-reduce of pose Hessians" of BASELINE configs[3]; a single frame outside the table is complete on every rank)
@@ -541,6 +584,12 @@ void bahip_context_destroy(bahip_context* ctx) {
 #ifdef BAHIP_COUNT_CANDIDATES
   bahip::pose_counters_dump();
 #endif
+#ifdef BAHIP_TILE_TIMELINE
+  if (const char* dir = getenv("BAHIP_TIMELINE_DIR")) {
+    bahip::geometry_timeline_dump((std::string(dir) + "/geometry_timeline.bin").c_str());
+    bahip::pose_timeline_dump((std::string(dir) + "/pose_timeline.bin").c_str());
+  }
+#endif
   if (ctx->pinned_work) hipHostFree(ctx->pinned_work);
   hipFree(ctx->dev_kfs); hipFree(ctx->dev_work); hipFree(ctx->dev_Hb);
   hipFree(ctx->dev_frame1); hipFree(ctx->dev_work1); hipFree(ctx->dev_Hb1); hipFree(ctx->dev_tile_counters);
@@ -552,6 +601,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl); hipFree(ctx->kf_partials);
+  hipFree(ctx->dev_tile_cost); hipFree(ctx->dev_tile_order);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
@@ -862,7 +912,8 @@ int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth, int use
   if (kf_sharded(ctx)) {
     if (geometry_keyframe_sharded(ctx, use_depth != 0, use_desc != 0, make_view(surfels), -1)) return 1;
   } else {
-    launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels));
+    launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), -1,
+                    tile_order_for(ctx, surfels->surfels_size));
   }
   timer_end(ctx, 1);
   CHECK_LAUNCH();
@@ -880,7 +931,7 @@ int bahip_update_activation_and_optimize_geometry(bahip_context* ctx, int use_de
     if (geometry_keyframe_sharded(ctx, use_depth != 0, use_desc != 0, make_view(surfels), (long long)activation_surfels_size)) return 1;
   } else {
     launch_geometry(ctx->stream, use_depth != 0, use_desc != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels),
-                    (long long)activation_surfels_size);
+                    (long long)activation_surfels_size, tile_order_for(ctx, surfels->surfels_size));
   }
   timer_end(ctx, 1);
   CHECK_LAUNCH();
@@ -960,7 +1011,7 @@ static int estimate_keyframe_poses_impl(bahip_context* ctx, int use_depth, int u
   launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, ctx->kf_rank, ctx->kf_world);
   CHECK_LAUNCH();
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K,
-                      make_view(surfels), /*write_back*/ 1, update_activation ? 1 : 0, ctx->pinned_work, rounds_out)) return 1;
+                      make_view(surfels), /*write_back*/ 1, update_activation ? 1 : 0, ctx->pinned_work, rounds_out, /*schedule*/ true)) return 1;
   const PoseWork* hw = ctx->pinned_work;
   const int* counters = reinterpret_cast<const int*>(hw + K);
   for (int k = 0; k < K; ++k) {
@@ -1673,6 +1724,11 @@ int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, 
   if (lds_form) *lds_form = n[1];
   return 0;
 }
+int bahip_debug_set_tile_order(int enabled) {
+  g_tile_order_enabled = enabled ? 1 : 0;
+  return 0;
+}
+
 int bahip_debug_set_pose_form(int form) {
   REQUIRE(form == 0 || form == 1 || form == 2, "pose form must be 0 (automatic), 1 (one tile per wavefront, global atomics) or 2 (persistent, LDS table)");
   set_pose_form(form);

@@ -62,6 +62,16 @@ void pose_counters_dump() {
     fprintf(stderr, "candidates %llu  with-any-association %llu  associated lanes %llu\n", c[0], c[1], c[2]);
 }
 #endif
+#ifdef BAHIP_TILE_TIMELINE
+// experiment build only: start / end of every tile of the last FULL round of the persistent pose sweep, by draw position
+__device__ unsigned long long g_pose_timeline[65536][4];   // start, end, tile, (candidates visited << 32) | candidates with an association
+__device__ unsigned int g_pose_tile_stats[65536][2];
+void pose_timeline_dump(const char* path) {
+  static unsigned long long host[65536][4];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pose_timeline), sizeof(host)) != hipSuccess) return;
+  if (FILE* f = fopen(path, "wb")) { fwrite(host, sizeof(host), 1, f); fclose(f); }
+}
+#endif
 // Where the 27 tile totals of a (tile, work item) pair go.
 //
 // GlobalSink: two 64-bit integer atomics per total on the Hb buffer.  They are issued one candidate late, behind the next
@@ -139,8 +149,8 @@ struct LdsSink {
 template <bool kUseDepth, bool kUseDesc, typename Sink>
 __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                                           int num_work, const SurfelsView& s, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
-                                          int num_listed, uint32_t tile, int parts, int part, Sink& sink, int item_begin = 0,
-                                          int item_count = -1) {
+                                          int num_listed, uint32_t tile, int parts, int part, Sink& sink, uint32_t* __restrict__ tile_cost,
+                                          int item_begin = 0, int item_count = -1) {
   const int lane = threadIdx.x & 63;
   // Later rounds (stored_bounds): the items are the num_listed entries of the list behind the counter records -- the work
   // items still iterating -- instead of all num_work work items.  A launch may cover a slice of the items only
@@ -185,6 +195,10 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
     if (part == 0 && lane == 0) tile_bounds[tile] = wb;
   }
   int my_w = 0;   // the work item of this lane's candidate item in the current chunk of 64 (read back by lane in the body)
+#ifdef BAHIP_TILE_TIMELINE
+  uint32_t with_association = 0;
+#endif
+  uint32_t visited = 0;   // wave-uniform: candidates this wavefront visits = what the tile costs (feeds tile_order_kernel)
   for_each_candidate(
       num_items,
       [&](int item) {
@@ -200,6 +214,7 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
     // (a list lookup here was a dependent load and a wait at the top of every candidate of the later rounds)
     const int w = __builtin_amdgcn_readfirstlane(stored_bounds ? __builtin_amdgcn_readlane(my_w, ((item - part) / parts) & 63) : item_begin + item);
     const float* F = work[w].F;
+    ++visited;
     const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
     // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
     const Projected p = project_surfel(in, F, gp);
@@ -224,6 +239,9 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
     }
 #endif
     if (!__any(visible)) return;
+#ifdef BAHIP_TILE_TIMELINE
+    ++with_association;
+#endif
 
     float acc[28];   // 21 H + 6 b + 1 pad (kHbCoefficients)
 #pragma unroll
@@ -271,6 +289,11 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
     sink.add(item, w, total);
   }, parts, part);
   sink.finish();
+  // first round of a phase over the keyframe table: the tile's cost for the run order of the next launches (wave_cull.h)
+  if (tile_cost && !stored_bounds && lane == 0 && visited) atomicAdd(&tile_cost[tile], visited);
+#ifdef BAHIP_TILE_TIMELINE
+  if (!stored_bounds && lane == 0 && tile < 65536) { g_pose_tile_stats[tile][0] = visited; g_pose_tile_stats[tile][1] = with_association; }
+#endif
 }
 
 // One wavefront per workgroup and tile; gridDim.y wavefronts share a tile's work items (shards of a multi-GPU run, and work
@@ -280,12 +303,15 @@ __global__ void __launch_bounds__(kPoseBlock) BAHIP_WAVES_ATTR
 pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                        int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
                        int num_listed, int* __restrict__ invalid /* counter word kPoseCounterInvalid; its own argument so that `work`
-                       stays read-only to the compiler: the per-candidate pose rows are then scalar loads */) {
+                       stays read-only to the compiler: the per-candidate pose rows are then scalar loads */,
+                       uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched) {
   const int lane = threadIdx.x & 63;
   const int slot = wave_reduce28_slot(lane);
   GlobalSink sink{Hb, invalid, 0.f, -1, (slot >= 0 && slot < 27) ? slot * kHbLimbs * (int)sizeof(HbFixed) : -1};
-  pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, xcd_chunked_tile(blockIdx.x),
-                                 (int)gridDim.y, (int)blockIdx.y, sink);
+  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile)
+  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
+  pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, tile, (int)gridDim.y, (int)blockIdx.y, sink,
+                                 tile_cost);
 }
 
 // Persistent form: one workgroup of 16 wavefronts per compute unit keeps the normal equations of every work item in LDS
@@ -312,19 +338,21 @@ __global__ void __launch_bounds__(64 * kPoseLdsWaves) BAHIP_WAVES_ATTR
 pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                            int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
                            int num_listed, int* __restrict__ invalid, uint32_t padded_tiles, uint32_t* __restrict__ tile_counters, int parity,
-                           int slice_begin, int slice_count) {
+                           int slice_begin, int slice_count, uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched) {
   extern __shared__ HbFixed table[];
   const int lane = threadIdx.x & 63;
   const int item_begin = kSlice ? slice_begin : 0;
   const int num_items = kSlice ? slice_count : (stored_bounds ? num_listed : num_work);
-  // (first tile of the current batch << 32) | tiles of it already taken; the word behind the table (a separate __shared__
-  // variable next to the dynamic array was placed ON the array by this toolchain)
+  // (first position of the current batch << 32) | (its size << 24) | positions of it already taken; the word behind the table (a
+  // separate __shared__ variable next to the dynamic array was placed ON the array by this toolchain).  Batches shrink towards
+  // the end of the XCD's queue (guided self-scheduling: a quarter of a workgroup's fair share of what is left, 2 .. kPoseBatch
+  // positions): a workgroup's LAST batch is what the launch waits for, and 32 positions are two rounds of its 16 wavefronts.
   unsigned long long& batch_state = *reinterpret_cast<unsigned long long*>(table + (size_t)num_items * kHbStride);
-  const uint32_t xcd = blockIdx.x & 7u, per_xcd = padded_tiles >> 3;
+  const uint32_t xcd = blockIdx.x & 7u, per_xcd = sched_positions(padded_tiles, sched) >> 3;   // positions, heavy tiles first (wave_cull.h)
   uint32_t* counter = tile_counters + parity * 8 + xcd;
   for (int e = threadIdx.x; e < num_items * kHbStride; e += 64 * kPoseLdsWaves) table[e] = 0;
   if (blockIdx.x == 0 && threadIdx.x < 8) tile_counters[(parity ^ 1) * 8 + threadIdx.x] = 0;
-  if (threadIdx.x == 0) batch_state = (unsigned long long)atomicAdd(counter, kPoseBatch) << 32;
+  if (threadIdx.x == 0) batch_state = ((unsigned long long)atomicAdd(counter, kPoseBatch) << 32) | ((unsigned long long)kPoseBatch << 24);
   __syncthreads();
   const int slot = wave_reduce28_slot(lane);
   const uint32_t table_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) HbFixed*)table;   // LDS byte address
@@ -333,18 +361,33 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
     unsigned long long taken = 0;
     if (lane == 0) taken = atomicAdd(&batch_state, 1ull);
     const uint32_t first = __builtin_amdgcn_readfirstlane((uint32_t)(taken >> 32));
-    const uint32_t index = __builtin_amdgcn_readfirstlane((uint32_t)taken);
+    const uint32_t size = __builtin_amdgcn_readfirstlane((uint32_t)taken >> 24);
+    const uint32_t index = __builtin_amdgcn_readfirstlane((uint32_t)taken & 0xffffffu);
     if (first >= per_xcd) break;                         // the XCD's tiles are used up
-    if (index < kPoseBatch) {
-      if (first + index < per_xcd)
-        pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed,
-                                       xcd_chunked_tile_of((first + index) * 8u + xcd, padded_tiles), 1, 0, sink, item_begin, kSlice ? num_items : -1);
-    } else if (index == kPoseBatch) {                    // this wavefront took the batch's last-plus-one: it fetches the next batch
-      if (lane == 0) {
-        const uint32_t next = atomicAdd(counter, kPoseBatch);
-        __hip_atomic_store(&batch_state, (unsigned long long)next << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (index < size) {
+      uint32_t tile;
+      if (first + index < per_xcd && scheduled_tile((first + index) * 8u + xcd, padded_tiles, sched, &tile)) {
+#ifdef BAHIP_TILE_TIMELINE
+        const unsigned long long t0 = wall_clock64();
+#endif
+        pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, tile, 1, 0, sink, tile_cost, item_begin,
+                                       kSlice ? num_items : -1);
+#ifdef BAHIP_TILE_TIMELINE
+        const uint32_t position = (first + index) * 8u + xcd;
+        if (!stored_bounds && lane == 0 && position < 65536 && tile < 65536) {
+          g_pose_timeline[position][0] = t0; g_pose_timeline[position][1] = wall_clock64(); g_pose_timeline[position][2] = tile;
+          g_pose_timeline[position][3] = ((unsigned long long)g_pose_tile_stats[tile][0] << 32) | g_pose_tile_stats[tile][1];
+        }
+#endif
       }
-    } else {                                             // the others wait for it (a few microseconds per kPoseBatch tiles)
+    } else if (index == size) {                          // this wavefront took the batch's last-plus-one: it fetches the next batch
+      if (lane == 0) {
+        const uint32_t left = per_xcd > first + size ? per_xcd - (first + size) : 0u;   // (as of this workgroup's last fetch)
+        const uint32_t want = min(kPoseBatch, max(2u, left / (4u * (gridDim.x >> 3))));
+        const uint32_t next = atomicAdd(counter, want);
+        __hip_atomic_store(&batch_state, ((unsigned long long)next << 32) | ((unsigned long long)want << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {                                             // the others wait for it (a few microseconds per batch)
       while ((uint32_t)(__hip_atomic_load(&batch_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == first)
         __builtin_amdgcn_s_sleep(8);
     }
@@ -634,7 +677,7 @@ constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a comput
 template <bool kUseDepth, bool kUseDesc, bool kSlice>
 static void launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
                             const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
-                            uint32_t* tile_counters, int parity, int slice_begin, int slice_count) {
+                            uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost, const uint32_t* sched) {
   int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
   static int compute_units = [] {
     int dev = 0, cus = 0;
@@ -647,20 +690,21 @@ static void launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEn
   }();
   (void)raised;
   hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(compute_units), dim3(64 * kPoseLdsWaves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
-                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count);
+                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
 }
 template <bool kSlice>
 static void launch_pose_lds_any(bool use_depth, bool use_desc, hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw,
                                 int num_work, const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles,
-                                size_t table_bytes, uint32_t* tile_counters, int parity, int slice_begin, int slice_count) {
-  if (use_depth && use_desc) launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count);
-  else if (use_depth) launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count);
-  else launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count);
+                                size_t table_bytes, uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost,
+                                const uint32_t* sched) {
+  if (use_depth && use_desc) launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
+  else if (use_depth) launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
+  else launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
 }
 
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
-                            int num_listed, uint32_t* tile_counters, int* parity_inout) {
+                            int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched) {
   if (s.size == 0 || num_work == 0) return;
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
@@ -686,7 +730,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
     if (num_items <= per_launch) {
       const int parity = *parity_inout;
       *parity_inout = parity ^ 1;
-      launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0);
+      launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0, tile_cost, sched);
       return;
     }
     // more work items than the table holds: slices of equal size, one launch each (every launch sweeps all tiles and culls
@@ -696,16 +740,72 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
       const int count = std::min(per_slice, num_items - begin);
       const int parity = *parity_inout;
       *parity_inout = parity ^ 1;
-      launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count);
+      launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count, tile_cost, sched);
     }
     return;
   }
-  const dim3 grid(tiles, parts), block(kPoseBlock);
+  const dim3 grid(sched_positions(tiles, sched), parts), block(kPoseBlock);
   int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched);
 }
+
+// The schedule of the sweeps that follow (wave_cull.h: scheduled_tile) from the candidates every tile visited in the pose sweep's
+// first round (tile_cost; cleared here for the next phase): the tiles of at least 2.5 x the mean cost go to the heavy list (at
+// most kHeavySlots; whatever exceeds that stays a regular tile), the runs are ranked by the descending cost of their most expensive
+// quarter (remaining tiles) -- by counting (368 runs at the bench size, 2 448 at 20 M surfels), ties by run index, so it is a permutation whatever
+// the costs are.  One workgroup.
+constexpr int kTileOrderMaxRuns = 4096;
+__global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__ tile_cost, uint32_t padded_tiles, uint32_t* __restrict__ sched) {
+  __shared__ uint32_t quarter_cost[4 * kTileOrderMaxRuns];   // cost of every quarter of a run, heavy tiles left out
+  __shared__ uint32_t key[kTileOrderMaxRuns];
+  __shared__ unsigned long long total;
+  __shared__ uint32_t heavy_count;
+  const uint32_t runs = xcd_run_count(padded_tiles), quarter_tiles = padded_tiles / runs / 4;
+  uint32_t* flags = sched + sched_flags_offset(padded_tiles);
+  if (threadIdx.x == 0) { total = 0; heavy_count = 0; }
+  for (uint32_t q = threadIdx.x; q < 4 * runs; q += blockDim.x) quarter_cost[q] = 0;
+  __syncthreads();
+  // every pass reads the costs with consecutive threads on consecutive tiles (a thread per run walking its 128 tiles took 0.3 ms)
+  unsigned long long mine_total = 0;
+  for (uint32_t t = threadIdx.x; t < padded_tiles; t += blockDim.x) mine_total += tile_cost[t];
+  atomicAdd(&total, mine_total);
+  __syncthreads();
+  const uint32_t threshold = (uint32_t)((total * 5ull) / (2ull * padded_tiles)) + 1u;   // 2.5 x the mean, at least 1
+  for (uint32_t t = threadIdx.x; t < padded_tiles; t += blockDim.x) {
+    const uint32_t c = tile_cost[t];
+    tile_cost[t] = 0;
+    uint32_t heavy = 0;
+    if (c >= threshold) {
+      const uint32_t slot = atomicAdd(&heavy_count, 1u);
+      if (slot < kHeavySlots) { sched[8 + slot] = t; heavy = 1; }
+    }
+    flags[t] = heavy;
+    if (!heavy && c) atomicAdd(&quarter_cost[t / quarter_tiles], c);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) sched[0] = min(heavy_count, kHeavySlots);
+  // a run's key: its most expensive quarter (a run that is light on average but has a heavy stretch must not come late: the
+  // end of a launch waits for single tiles, and the pose sweep's workgroups take a stretch of consecutive positions at once)
+  for (uint32_t r = threadIdx.x; r < runs; r += blockDim.x)
+    key[r] = max(max(quarter_cost[4 * r], quarter_cost[4 * r + 1]), max(quarter_cost[4 * r + 2], quarter_cost[4 * r + 3]));
+  __syncthreads();
+  for (uint32_t r = threadIdx.x; r < runs; r += blockDim.x) {
+    const uint32_t mine = key[r];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < runs; ++o) rank += (key[o] > mine || (key[o] == mine && o < r)) ? 1u : 0u;
+    sched[kSchedOrder + rank] = r;
+  }
+}
+bool launch_tile_order(hipStream_t stream, uint32_t* tile_cost, uint32_t padded_tiles, uint32_t* sched) {
+  if (padded_tiles == 0 || xcd_run_count(padded_tiles) > (uint32_t)kTileOrderMaxRuns) return false;
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, padded_tiles, sched);
+  return true;
+}
+// (an upper bound that also covers every smaller grid: those below kXcdLargeGrid have runs of 32 tiles, i.e. more runs per tile)
+size_t tile_schedule_words(uint32_t padded_tiles) { return (size_t)kSchedOrder + padded_tiles / 32 + 16 + padded_tiles; }
+uint32_t pose_padded_tiles(uint32_t surfels) { return xcd_padded_tiles((surfels + kPoseBlock - 1) / kPoseBlock); }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out, int sequence) {

@@ -24,6 +24,7 @@
 // exchange the buffers as integer sums of bit patterns (x + 0 keeps every bit), and every rank then combines the four
 // partials as defined (kSumsConsume).  The geometry step becomes three launches with two exchanges between them.
 #include <stdlib.h>
+#include <cstdio>
 
 #include "ba_device.h"
 #include "ba_launch.h"
@@ -280,12 +281,15 @@ normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Surf
 // Every rank holds all surfels and ends each phase with the same bits (flags and normals after 2, positions after 3).
 template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate, int kPhase>
 __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView& s,
-                                              uint32_t activate_count, float* lds, const ClassPartials& cpn, const ClassPartials& cpp) {
+                                              uint32_t activate_count, float* lds, const ClassPartials& cpn, const ClassPartials& cpp,
+                                              const uint32_t* __restrict__ sched) {
   constexpr int kNormalsMode = kPhase == 1 ? kSumsProduce : kPhase == 2 ? kSumsConsume : kSumsFused;
   constexpr int kPositionMode = kPhase == 2 ? kSumsProduce : kPhase == 3 ? kSumsConsume : kSumsFused;
   const int lane = threadIdx.x & 63;
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
-  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + lane;
+  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile); workgroup-uniform
+  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
+  const uint32_t i = tile * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   // (phase 3: the flags were decided by phase 2)
@@ -412,11 +416,28 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
   if (x2 != 0) s.row(kSurfelDescriptor2)[i] = fmaxf(-180.f, fminf(180.f, d2 - x2));
 }
 
+#ifdef BAHIP_TILE_TIMELINE
+// experiment build only (scripts/tile_timeline.py): when each tile of the LAST geometry launch started and ended (100 MHz clock)
+__device__ unsigned long long g_geometry_timeline[65536][2];
+void geometry_timeline_dump(const char* path) {
+  static unsigned long long host[65536][2];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_geometry_timeline), sizeof(host)) != hipSuccess) return;
+  if (FILE* f = fopen(path, "wb")) { fwrite(host, sizeof(host), 1, f); fclose(f); }
+}
+#endif
+
 template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate>
 __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
-geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count) {
+geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
+                const uint32_t* __restrict__ sched) {
   __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
-  geometry_step<kUseDepth, kUseDesc, kWaves, kActivate, 0>(in, kfs, num_kfs, s, activate_count, lds, ClassPartials{}, ClassPartials{});
+#ifdef BAHIP_TILE_TIMELINE
+  const unsigned long long t0 = wall_clock64();
+#endif
+  geometry_step<kUseDepth, kUseDesc, kWaves, kActivate, 0>(in, kfs, num_kfs, s, activate_count, lds, ClassPartials{}, ClassPartials{}, sched);
+#ifdef BAHIP_TILE_TIMELINE
+  if (threadIdx.x == 0 && blockIdx.x < 65536) { g_geometry_timeline[blockIdx.x][0] = t0; g_geometry_timeline[blockIdx.x][1] = wall_clock64(); }
+#endif
 }
 
 // One phase of the keyframe-sharded geometry step (geometry_step: kPhase).
@@ -424,7 +445,7 @@ template <bool kUseDepth, bool kUseDesc, bool kActivate, int kPhase>
 __global__ void __launch_bounds__(64) BAHIP_WAVES_ATTR
 geometry_phase_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
                       ClassPartials cpn, ClassPartials cpp) {
-  geometry_step<kUseDepth, kUseDesc, 1, kActivate, kPhase>(in, kfs, num_kfs, s, activate_count, nullptr, cpn, cpp);
+  geometry_step<kUseDepth, kUseDesc, 1, kActivate, kPhase>(in, kfs, num_kfs, s, activate_count, nullptr, cpn, cpp, nullptr);   // (buffer order)
 }
 
 // Surfel activation under keyframe sharding: this rank's kActive keyframes only; hits[i] = 1 where one of them sees surfel i
@@ -497,24 +518,25 @@ void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs
 
 template <int kWaves, bool kActivate>
 static void launch_geometry_shape(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                                  int num_kfs, const SurfelsView& s, uint32_t activate_count) {
-  const dim3 grid(grid_for(s.size)), block(64 * kWaves);
-  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count);
-  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count);
-  else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count);
+                                  int num_kfs, const SurfelsView& s, uint32_t activate_count, const uint32_t* sched) {
+  const dim3 grid(sched_positions(grid_for(s.size), sched)), block(64 * kWaves);
+  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched);
+  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched);
+  else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched);
 }
 
 // activate_count < 0: the activation flags are taken as they are; >= 0: surfels [0, activate_count) are (re)activated first.
+// `sched`: the schedule of a grid of grid_for(s.size) tiles (wave_cull.h: scheduled_tile), or NULL.
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                     int num_kfs, const SurfelsView& s, long long activate_count) {
+                     int num_kfs, const SurfelsView& s, long long activate_count, const uint32_t* sched) {
   if (s.size == 0) return;
   const uint32_t n = activate_count < 0 ? 0u : (uint32_t)activate_count;
   if (tile_waves(s.size) == 1) {
-    if (activate_count < 0) launch_geometry_shape<1, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
-    else launch_geometry_shape<1, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
+    if (activate_count < 0) launch_geometry_shape<1, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
+    else launch_geometry_shape<1, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
   } else {
-    if (activate_count < 0) launch_geometry_shape<4, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
-    else launch_geometry_shape<4, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n);
+    if (activate_count < 0) launch_geometry_shape<4, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
+    else launch_geometry_shape<4, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
   }
 }
 

@@ -45,6 +45,47 @@ __device__ __forceinline__ uint32_t xcd_chunked_tile_of(uint32_t block, uint32_t
   return ((((j >> shift) << 3) + xcd) << shift) + (j & ((1u << shift) - 1u));
 }
 
+// Heavy work first.  A tile's work is proportional to the keyframes that see it -- 20 on average at the bench size, 80 in the
+// middle of the scene, and far more for the few tiles that straddle a jump of the Morton curve (a bounding sphere that culls
+// nothing) -- so with the tiles taken in buffer order a launch ends with a tail: measured with scripts/tile_timeline.py, both
+// sweeps spent 18 % of their duration with fewer than half of the 4096 wavefront slots busy (914 us where 745 us of perfectly
+// packed work was done; the last 120 us belonged to EIGHT tiles of 180-270 us each).  The schedule (one buffer of words, built
+// by tile_order_kernel in kernels_pose.hip from the per-tile candidate counts the pose sweep's first round records):
+//   [0]                           number of heavy tiles (cost >= 2.5 x the mean; at most kHeavySlots)
+//   [8 .. 8 + kHeavySlots)        the heavy tiles: the first kHeavySlots positions of a launch run these (or nothing)
+//   [kSchedOrder .. + runs)       permutation of the runs by descending cost (longest-processing-time-first; consecutive
+//                                 positions go to the 8 XCDs, so every XCD gets one run of each octet)
+//   [sched_flags_offset ..)       one word per tile: non-zero = heavy, i.e. already done when its regular position comes up
+// A launch with a schedule has kHeavySlots more positions than tiles.  NULL = buffer order.  A scheduling hint only: every tile
+// is processed exactly once either way, and no result depends on the order.
+constexpr uint32_t kHeavySlots = 1024;
+constexpr uint32_t kSchedOrder = 8 + kHeavySlots;
+__host__ __device__ __forceinline__ uint32_t xcd_run_count(uint32_t padded_tiles) { return padded_tiles >> (padded_tiles >= kXcdLargeGrid ? 7u : 5u); }
+__host__ __device__ __forceinline__ uint32_t sched_flags_offset(uint32_t padded_tiles) { return kSchedOrder + ((xcd_run_count(padded_tiles) + 7u) & ~7u); }
+__host__ __device__ __forceinline__ size_t sched_words(uint32_t padded_tiles) { return (size_t)sched_flags_offset(padded_tiles) + padded_tiles; }
+// Positions of a launch over `padded_tiles` tiles.
+__host__ __device__ __forceinline__ uint32_t sched_positions(uint32_t padded_tiles, const uint32_t* sched) { return padded_tiles + (sched ? kHeavySlots : 0u); }
+// The tile position `position` of such a launch works on; false = nothing to do there.  Everything is wave-uniform (scalar loads).
+__device__ __forceinline__ bool scheduled_tile(uint32_t position, uint32_t padded_tiles, const uint32_t* __restrict__ sched, uint32_t* tile_out) {
+  const uint32_t shift = padded_tiles >= kXcdLargeGrid ? 7u : 5u;
+  if (!sched) {
+    const uint32_t xcd = position & 7u, j = position >> 3;
+    *tile_out = ((((j >> shift) << 3) + xcd) << shift) + (j & ((1u << shift) - 1u));
+    return true;
+  }
+  if (position < kHeavySlots) {
+    if (position >= sched[0]) return false;
+    *tile_out = sched[8 + position];
+    return true;
+  }
+  const uint32_t block = position - kHeavySlots;
+  const uint32_t xcd = block & 7u, j = block >> 3;
+  const uint32_t run = sched[kSchedOrder + ((j >> shift) << 3) + xcd];
+  const uint32_t tile = (run << shift) + (j & ((1u << shift) - 1u));
+  *tile_out = tile;
+  return sched[sched_flags_offset(padded_tiles) + tile] == 0;
+}
+
 struct WaveBounds {
   float cx, cy, cz;   // sphere centre (global frame)
   float r;            // inflated radius; negative = no valid surfel in this wave

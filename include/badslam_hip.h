@@ -394,13 +394,17 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
  * 1 = one wavefront per surfel tile, tile totals added to the normal equations with global 64-bit integer atomics (the only form
  * for shards and for more work items than fit the table); 2 = persistent workgroups, one per compute unit, that keep the normal
  * equations of every work item in LDS and flush them once (whenever the table fits 128 KB: up to 292 work items). */
+int bahip_debug_set_pose_form(int form);
+/* Test / experiment hook: 0 = the sweeps take their surfel tiles in buffer order; 1 (default; BAHIP_TILE_ORDER=0 in the
+ * environment switches it off too) = heavy runs first, from the candidate counts of the previous pose phase (wave_cull.h:
+ * xcd_ordered_tile).  A scheduling hint: results are bit-identical either way. */
+int bahip_debug_set_tile_order(int enabled);
 /* The intrinsics sweep appends its per-cell records to buffers sized from the previous call's demand (kernels_intrinsics.hip);
  * records that do not fit go out as atomics, with the same result.  records_per_block >= 0 fixes the size (0: no buffers, < 0:
  * automatic again) -- for the tests of the overflow path and for A/B timing.  bahip_debug_intrinsics_bin_stats: capacity and the
  * largest / total demand of the last call. */
 int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block);
 int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out);
-int bahip_debug_set_pose_form(int form);
 /* The LDS form holds the normal equations of at most 292 work items; longer lists are cut into slices, one launch each.  items > 0
  * makes the slices that small (tests: 200 keyframes in slices of 64), 0 restores the default. */
 int bahip_debug_set_pose_lds_items(int items);
