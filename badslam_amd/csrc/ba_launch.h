@@ -100,7 +100,8 @@ struct IntrBins {
 int intrinsics_bin_count(const Intrinsics& in, int* bins_x_out);
 size_t intrinsics_bin_record_bytes();
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, double* glob_d, double* cells_d, const IntrBins& bins);
+                                  const SurfelsView& s, double* glob_d, double* cells_d, const IntrBins& bins,
+                                  const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
 size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_finish needs
 void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* glob_d, const double* cells_d, float* glob_f, float* cells_f,
                               float* partials);
@@ -122,13 +123,14 @@ size_t pcg_exact_cells(uint32_t head_count);
 PcgExact pcg_exact_view(void* buffer, uint32_t head_count);
 size_t pcg_control_bytes();
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                     const SurfelsView& s, float* r, float* M);
+                     const SurfelsView& s, float* r, float* M,
+                     uint32_t* tile_cost = nullptr /* census for the schedule, as in launch_pose_accumulate */, const uint32_t* sched = nullptr);
 void launch_pcg_resolve_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, float* M);
 void launch_pcg_init2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float a, const float* r, const float* M, float* delta, float* g,
                       float* p);
 void launch_pcg_control_init(hipStream_t st, const PcgExact& ex, void* ctl, float* alpha_n);
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                      const SurfelsView& s, const float* p, float* g, const void* ctl);
+                      const SurfelsView& s, const float* p, float* g, const void* ctl, const uint32_t* sched = nullptr);
 void launch_pcg_eps_terms(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* p);
 void launch_pcg_resolve_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* g, float* alpha_d, double eps_repeat, const void* ctl);
 void launch_pcg_step2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, const float* M, float* delta, float* g, const float* p,

@@ -1306,7 +1306,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   HIP_TRY(hipMemsetAsync(glob_d, 0, sizeof(double) * (64 + 8 * (size_t)S), ctx->stream));
   if (bins.capacity) HIP_TRY(hipMemsetAsync(bins.cursors, 0, sizeof(uint32_t) * (size_t)num_bins, ctx->stream));
   launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
-                               make_view(surfels), glob_d, cells_d, bins);
+                               make_view(surfels), glob_d, cells_d, bins, tile_order_for(ctx, surfels->surfels_size));
   CHECK_LAUNCH();
   if (bins.capacity)
     HIP_TRY(hipMemcpyAsync(ctx->intr_bin_counts_host, bins.cursors, sizeof(uint32_t) * (size_t)num_bins, hipMemcpyDeviceToHost, ctx->stream));
@@ -1437,8 +1437,19 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   const size_t x1_init = ((size_t)kHotExchanged1 * kHotReplicas + 2 * (size_t)head_count) * kExactLimbs;
   const size_t x1_step = ((size_t)kHotExchanged1 * kHotReplicas + (size_t)head_count) * kExactLimbs;
   const size_t x2 = (size_t)kHotReplicas * kExactLimbs;
-  launch_pcg_init(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, r_, M_);
+  // heavy work first (wave_cull.h): the init sweep takes the census when there is no schedule for this grid yet (a PCG-only
+  // caller never runs the pose sweep that usually provides it), the inner steps use it
+  const uint32_t padded_tiles = pose_padded_tiles(sv.size);
+  const bool census = g_tile_order_enabled && sv.size > 0 && ctx->tile_order_tiles != padded_tiles;
+  if (census && ensure_tile_schedule(ctx, padded_tiles)) return 1;
+  launch_pcg_init(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, r_, M_, census ? ctx->dev_tile_cost : nullptr, tile_order_for(ctx, sv.size));
   CHECK_LAUNCH();
+  if (census && launch_tile_order(st, ctx->dev_tile_cost, padded_tiles, ctx->dev_tile_order)) {
+    ctx->tile_order_tiles = padded_tiles;
+    ctx->phases_since_schedule = 0;
+    CHECK_LAUNCH();
+  }
+  const uint32_t* sched = tile_order_for(ctx, sv.size);
   if (sharded && reduce_over_ranks(ctx, ex.hot, x1_init, BAHIP_SUM_I64)) return 1;
   launch_pcg_resolve_init(st, L, ex, r_, M_);
   CHECK_LAUNCH();
@@ -1458,7 +1469,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   int steps = 0;
   for (int step = 0; step < opt->max_inner_iterations; ++step) {
     if (step > 0) { const int t = i_an; i_an = i_bn; i_bn = t; }
-    launch_pcg_step1(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, p_, g_, ctl);
+    launch_pcg_step1(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, p_, g_, ctl, sched);
     CHECK_LAUNCH();
     if (sharded && reduce_over_ranks(ctx, ex.hot, x1_step, BAHIP_SUM_I64)) return 1;   // g head, intrinsics entries, alpha_d terms
     launch_pcg_resolve_step1(st, L, ex, g_, sc + 1, eps_repeat, ctl);
@@ -1724,6 +1735,15 @@ int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, 
   if (lds_form) *lds_form = n[1];
   return 0;
 }
+int bahip_debug_read_tile_schedule(bahip_context* ctx, uint32_t* padded_tiles_out, uint32_t* words_out, size_t max_words) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *padded_tiles_out = ctx->tile_order_tiles;
+  if (ctx->tile_order_tiles == 0 || words_out == nullptr) return 0;
+  const size_t words = std::min(max_words, tile_schedule_words(ctx->tile_order_tiles));
+  HIP_TRY(hipMemcpy(words_out, ctx->dev_tile_order, sizeof(uint32_t) * words, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int bahip_debug_set_tile_order(int enabled) {
   g_tile_order_enabled = enabled ? 1 : 0;
   return 0;

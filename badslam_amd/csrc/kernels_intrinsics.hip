@@ -77,9 +77,12 @@ __device__ __forceinline__ float& cell_obs(float* cells, int cell) { return cell
 template <bool kDepth, bool kColor>
 __global__ void __launch_bounds__(kIntrSweepBlock) __attribute__((amdgpu_waves_per_eu(BAHIP_INTR_WAVES_PER_EU)))
 intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                             double* __restrict__ glob /* 34 */, double* __restrict__ cells /* S records of kCellFloats */, IntrBins bins) {
+                             double* __restrict__ glob /* 34 */, double* __restrict__ cells /* S records of kCellFloats */, IntrBins bins,
+                             const uint32_t* __restrict__ sched) {
   __shared__ float xpose[64 * (kCellFloats + 1)];   // lane-major: 8 values + the cell index, stride 9 (conflict-free both ways)
-  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kIntrSweepBlock + threadIdx.x;
+  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile)
+  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
+  const uint32_t i = tile * kIntrSweepBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
@@ -103,7 +106,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
   uint32_t reserve_base[kBinGroups] = {0, 0, 0};
   int reserve_lane[kBinGroups] = {0, 0, 0};   // wave-uniform
   const bool binned = bins.capacity != 0;     // wave-uniform
-  const uint32_t sub = xcd_chunked_tile(blockIdx.x) & (kBinSubs - 1);
+  const uint32_t sub = tile & (kBinSubs - 1);
   auto flush_pending = [&]() {
     if (!kDepth) return;
     unsigned long long contributing = __ballot(pending_cell >= 0);
@@ -402,12 +405,12 @@ int intrinsics_bin_count(const Intrinsics& in, int* bins_x_out) {
 }
 size_t intrinsics_bin_record_bytes() { return kCellFloats * sizeof(uint32_t); }
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins) {
+                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched) {
   if (!s.size) return;
-  const dim3 grid(xcd_padded_tiles((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock)), block(kIntrSweepBlock);
-  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins);
-  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins);
-  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins);
+  const dim3 grid(sched_positions(xcd_padded_tiles((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock), sched)), block(kIntrSweepBlock);
+  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
+  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
+  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
   if (depth && bins.capacity) {
     const int slices = (int)((bins.capacity + kBinSlice - 1) / kBinSlice);
     hipLaunchKernelGGL(intrinsics_bin_reduce_kernel, dim3((unsigned)(intrinsics_bin_count(in, nullptr) * slices)), dim3(kBinReduceBlock),

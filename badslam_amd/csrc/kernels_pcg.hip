@@ -174,8 +174,10 @@ __device__ __forceinline__ bool gather_and_associate(const PcgLayout& L, const I
 template <bool kDepthIntr, bool kColorIntr>
 __global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
 pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                float* __restrict__ r_, float* __restrict__ M_) {
-  const uint32_t tile = xcd_chunked_tile(blockIdx.x);
+                float* __restrict__ r_, float* __restrict__ M_, uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched) {
+  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile); tile_cost: the census the schedule is built from
+  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
+  uint32_t visited = 0;
   const uint32_t i = tile * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
@@ -236,6 +238,7 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
       num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
       [&](int k) {
         const KfEntry& kf = kfs[k];
+        ++visited;
         PairGather pg;
         bool visible = gather_and_associate(L, in, kf, gp, gn, tp, in_range, &pg);
         flush_pending();
@@ -308,6 +311,7 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
         }
       });
   flush_pending();
+  if (tile_cost && lane == 0 && visited) atomicAdd(&tile_cost[tile], visited);
 
   if (in_range && L.optimize_geometry) {
     r_[gi] = gr[0]; M_[gi] = gM[0];
@@ -463,9 +467,10 @@ pcg_init2_kernel(PcgLayout L, PcgExact ex, float a, const float* __restrict__ r_
 template <bool kDepthIntr, bool kColorIntr>
 __global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
 pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                 const float* __restrict__ p_, float* __restrict__ g_, const PcgControl* ctl) {
+                 const float* __restrict__ p_, float* __restrict__ g_, const PcgControl* ctl, const uint32_t* __restrict__ sched) {
   if (ctl->stop) return;
-  const uint32_t tile = xcd_chunked_tile(blockIdx.x);
+  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile)
+  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
   const uint32_t i = tile * kPcgSweepBlock + threadIdx.x;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
@@ -756,14 +761,14 @@ PcgExact pcg_exact_view(void* buffer, uint32_t head_count) {
 }
 
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                     const SurfelsView& s, float* r, float* M) {
+                     const SurfelsView& s, float* r, float* M, uint32_t* tile_cost, const uint32_t* sched) {
   if (!s.size) return;
-  const dim3 grid(gS(s.size)), block(kPcgSweepBlock);
+  const dim3 grid(sched_positions(gS(s.size), sched)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
-  if (di && ci) hipLaunchKernelGGL((pcg_init_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
-  else if (di) hipLaunchKernelGGL((pcg_init_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
-  else if (ci) hipLaunchKernelGGL((pcg_init_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
-  else hipLaunchKernelGGL((pcg_init_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M);
+  if (di && ci) hipLaunchKernelGGL((pcg_init_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M, tile_cost, sched);
+  else if (di) hipLaunchKernelGGL((pcg_init_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M, tile_cost, sched);
+  else if (ci) hipLaunchKernelGGL((pcg_init_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M, tile_cost, sched);
+  else hipLaunchKernelGGL((pcg_init_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M, tile_cost, sched);
 }
 static inline unsigned resolve_grid(const PcgLayout& L) { return gU(L.head_lo + (L.unknown_count - L.head_hi)) + 1; }
 void launch_pcg_resolve_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, float* M) {
@@ -786,15 +791,15 @@ void launch_pcg_control(hipStream_t st, const PcgExact& ex, void* ctl, float* be
 size_t pcg_control_bytes() { return sizeof(PcgControl); }
 
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                      const SurfelsView& s, const float* p, float* g, const void* ctl_) {
+                      const SurfelsView& s, const float* p, float* g, const void* ctl_, const uint32_t* sched) {
   const PcgControl* ctl = static_cast<const PcgControl*>(ctl_);
   if (!s.size) return;
-  const dim3 grid(gS(s.size)), block(kPcgSweepBlock);
+  const dim3 grid(sched_positions(gS(s.size), sched)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
-  if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
-  else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
-  else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
-  else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl);
+  if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
+  else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
+  else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
+  else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
 }
 void launch_pcg_eps_terms(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* p) {
   if (L.unknown_count) hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, ex, p);

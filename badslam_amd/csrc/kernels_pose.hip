@@ -752,22 +752,36 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
 }
 
 // The schedule of the sweeps that follow (wave_cull.h: scheduled_tile) from the candidates every tile visited in the pose sweep's
-// first round (tile_cost; cleared here for the next phase): the tiles of at least 2.5 x the mean cost go to the heavy list (at
-// most kHeavySlots; whatever exceeds that stays a regular tile), the runs are ranked by the descending cost of their most expensive
-// quarter (remaining tiles) -- by counting (368 runs at the bench size, 2 448 at 20 M surfels), ties by run index, so it is a permutation whatever
-// the costs are.  One workgroup.
-constexpr int kTileOrderMaxRuns = 4096;
+// first round (tile_cost; cleared here for the next census).  One workgroup; every pass over the tiles reads them with
+// consecutive threads on consecutive tiles (a thread per run walking its 128 tiles took 0.3 ms).
+//   1. the tiles of at least 2.5 x the mean cost go to the heavy list (at most kHeavySlots; whatever exceeds that stays regular);
+//   2. the runs are ranked by the descending cost of their most expensive quarter (a run that is light on average but has a
+//      heavy stretch must not come late: the end of a launch waits for single tiles, and the pose sweep's workgroups take a
+//      stretch of consecutive positions at once) -- by counting, ties by run index, so it is a permutation whatever the costs are;
+//   3. position row * 8 + x runs on XCD x: within every row of eight runs the heavier run goes to the XCD that has received less
+//      so far (the XCDs' queues are separate -- the hardware deals workgroups round-robin, the pose sweep keeps a counter per XCD --
+//      and with the rows dealt in sorted order their totals differed by 5 %: 35 us between the first and the last queue running dry);
+//   4. the tiles of the last quarter of the rows are placed one by one, by descending cost (a counting sort; heavy tiles, which
+//      are skipped there anyway, last), so that the launch runs out on tiles of one or two candidates.
+constexpr int kTileOrderMaxRuns = 2560;   // 327 680 tiles = 21 M surfels
+#ifndef BAHIP_SCHED_TAIL_DIV
+#define BAHIP_SCHED_TAIL_DIV 4   // measured at the bench size: 8 -> 4: both sweeps 1 % shorter; 3: no further gain
+#endif
 __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__ tile_cost, uint32_t padded_tiles, uint32_t* __restrict__ sched) {
   __shared__ uint32_t quarter_cost[4 * kTileOrderMaxRuns];   // cost of every quarter of a run, heavy tiles left out
   __shared__ uint32_t key[kTileOrderMaxRuns];
+  __shared__ uint32_t sorted[kTileOrderMaxRuns];
+  __shared__ uint32_t order[kTileOrderMaxRuns];              // order[row * 8 + x] = the run at that place of XCD x's queue
+  __shared__ uint32_t bucket[257];
   __shared__ unsigned long long total;
   __shared__ uint32_t heavy_count;
-  const uint32_t runs = xcd_run_count(padded_tiles), quarter_tiles = padded_tiles / runs / 4;
-  uint32_t* flags = sched + sched_flags_offset(padded_tiles);
+  const uint32_t runs = xcd_run_count(padded_tiles), run_tiles = padded_tiles / runs, quarter_tiles = run_tiles / 4;
+  uint32_t* perm = sched + kSchedPerm;
+  uint32_t* flags = perm + padded_tiles;
   if (threadIdx.x == 0) { total = 0; heavy_count = 0; }
   for (uint32_t q = threadIdx.x; q < 4 * runs; q += blockDim.x) quarter_cost[q] = 0;
+  for (uint32_t q = threadIdx.x; q < 257; q += blockDim.x) bucket[q] = 0;
   __syncthreads();
-  // every pass reads the costs with consecutive threads on consecutive tiles (a thread per run walking its 128 tiles took 0.3 ms)
   unsigned long long mine_total = 0;
   for (uint32_t t = threadIdx.x; t < padded_tiles; t += blockDim.x) mine_total += tile_cost[t];
   atomicAdd(&total, mine_total);
@@ -775,7 +789,6 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__
   const uint32_t threshold = (uint32_t)((total * 5ull) / (2ull * padded_tiles)) + 1u;   // 2.5 x the mean, at least 1
   for (uint32_t t = threadIdx.x; t < padded_tiles; t += blockDim.x) {
     const uint32_t c = tile_cost[t];
-    tile_cost[t] = 0;
     uint32_t heavy = 0;
     if (c >= threshold) {
       const uint32_t slot = atomicAdd(&heavy_count, 1u);
@@ -786,8 +799,6 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__
   }
   __syncthreads();
   if (threadIdx.x == 0) sched[0] = min(heavy_count, kHeavySlots);
-  // a run's key: its most expensive quarter (a run that is light on average but has a heavy stretch must not come late: the
-  // end of a launch waits for single tiles, and the pose sweep's workgroups take a stretch of consecutive positions at once)
   for (uint32_t r = threadIdx.x; r < runs; r += blockDim.x)
     key[r] = max(max(quarter_cost[4 * r], quarter_cost[4 * r + 1]), max(quarter_cost[4 * r + 2], quarter_cost[4 * r + 3]));
   __syncthreads();
@@ -795,16 +806,64 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__
     const uint32_t mine = key[r];
     uint32_t rank = 0;
     for (uint32_t o = 0; o < runs; ++o) rank += (key[o] > mine || (key[o] == mine && o < r)) ? 1u : 0u;
-    sched[kSchedOrder + rank] = r;
+    sorted[rank] = r;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t row = 0; row * 8 < runs; ++row) {
+      uint32_t run_of[8], cost_of[8], xcd_of[8];
+      for (uint32_t c = 0; c < 8; ++c) {
+        const uint32_t r = sorted[row * 8 + c];
+        run_of[c] = r;
+        cost_of[c] = quarter_cost[4 * r] + quarter_cost[4 * r + 1] + quarter_cost[4 * r + 2] + quarter_cost[4 * r + 3];
+        xcd_of[c] = c;
+      }
+      for (uint32_t a = 1; a < 8; ++a)        // runs by descending total, XCDs by ascending load (insertion sorts of eight)
+        for (uint32_t b = a; b > 0 && cost_of[b] > cost_of[b - 1]; --b) {
+          const uint32_t t = cost_of[b]; cost_of[b] = cost_of[b - 1]; cost_of[b - 1] = t;
+          const uint32_t u = run_of[b]; run_of[b] = run_of[b - 1]; run_of[b - 1] = u;
+        }
+      for (uint32_t a = 1; a < 8; ++a)
+        for (uint32_t b = a; b > 0 && load[xcd_of[b]] < load[xcd_of[b - 1]]; --b) { const uint32_t t = xcd_of[b]; xcd_of[b] = xcd_of[b - 1]; xcd_of[b - 1] = t; }
+      for (uint32_t c = 0; c < 8; ++c) {
+        order[row * 8 + xcd_of[c]] = run_of[c];
+        load[xcd_of[c]] += cost_of[c];
+      }
+    }
+  }
+  __syncthreads();
+  // the permutation: whole runs for the leading rows ...
+  const uint32_t rows = runs / 8, tail_rows = max(1u, rows / BAHIP_SCHED_TAIL_DIV), head_positions = (rows - tail_rows) * 8 * run_tiles;
+  const uint32_t shift = padded_tiles >= kXcdLargeGrid ? 7u : 5u;
+  for (uint32_t p = threadIdx.x; p < head_positions; p += blockDim.x) {
+    const uint32_t xcd = p & 7u, j = p >> 3;
+    perm[p] = (order[((j >> shift) << 3) + xcd] << shift) + (j & ((1u << shift) - 1u));
+  }
+  // ... and the tiles of the last rows one by one: bucket 0 = cost >= 255 ... bucket 255 = cost 0, bucket 256 = heavy (skipped)
+  const uint32_t tail_tiles = padded_tiles - head_positions, first_tail_run = (rows - tail_rows) * 8;
+  auto tail_tile = [&](uint32_t e) { return order[first_tail_run + e / run_tiles] * run_tiles + e % run_tiles; };
+  auto bucket_of = [&](uint32_t t) { return flags[t] ? 256u : 255u - min(tile_cost[t], 255u); };
+  for (uint32_t e = threadIdx.x; e < tail_tiles; e += blockDim.x) atomicAdd(&bucket[bucket_of(tail_tile(e))], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t running = 0;
+    for (uint32_t q = 0; q < 257; ++q) { const uint32_t n = bucket[q]; bucket[q] = running; running += n; }
+  }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < tail_tiles; e += blockDim.x) {
+    const uint32_t t = tail_tile(e);
+    perm[head_positions + atomicAdd(&bucket[bucket_of(t)], 1u)] = t;
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < padded_tiles; t += blockDim.x) tile_cost[t] = 0;
 }
 bool launch_tile_order(hipStream_t stream, uint32_t* tile_cost, uint32_t padded_tiles, uint32_t* sched) {
   if (padded_tiles == 0 || xcd_run_count(padded_tiles) > (uint32_t)kTileOrderMaxRuns) return false;
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, padded_tiles, sched);
   return true;
 }
-// (an upper bound that also covers every smaller grid: those below kXcdLargeGrid have runs of 32 tiles, i.e. more runs per tile)
-size_t tile_schedule_words(uint32_t padded_tiles) { return (size_t)kSchedOrder + padded_tiles / 32 + 16 + padded_tiles; }
+size_t tile_schedule_words(uint32_t padded_tiles) { return sched_words(padded_tiles); }
 uint32_t pose_padded_tiles(uint32_t surfels) { return xcd_padded_tiles((surfels + kPoseBlock - 1) / kPoseBlock); }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,

@@ -53,24 +53,30 @@ __device__ __forceinline__ uint32_t xcd_chunked_tile_of(uint32_t block, uint32_t
 // by tile_order_kernel in kernels_pose.hip from the per-tile candidate counts the pose sweep's first round records):
 //   [0]                           number of heavy tiles (cost >= 2.5 x the mean; at most kHeavySlots)
 //   [8 .. 8 + kHeavySlots)        the heavy tiles: the first kHeavySlots positions of a launch run these (or nothing)
-//   [kSchedOrder .. + runs)       permutation of the runs by descending cost (longest-processing-time-first; consecutive
-//                                 positions go to the 8 XCDs, so every XCD gets one run of each octet)
-//   [sched_flags_offset ..)       one word per tile: non-zero = heavy, i.e. already done when its regular position comes up
+//   [kSchedPerm .. + tiles)       the tile of every further position: whole runs of consecutive tiles (the XCD runs: consecutive
+//                                 positions go to the 8 XCDs) ranked by the descending cost of their most expensive quarter
+//                                 (longest-processing-time-first), each row of eight dealt to the XCDs so that their totals
+//                                 stay level; the tiles of the last rows individually by descending cost, so that a launch
+//                                 ends on its cheapest tiles
+//   [kSchedPerm + tiles ..)       one word per tile: non-zero = heavy, i.e. already done when its regular position comes up
 // A launch with a schedule has kHeavySlots more positions than tiles.  NULL = buffer order.  A scheduling hint only: every tile
 // is processed exactly once either way, and no result depends on the order.
 constexpr uint32_t kHeavySlots = 1024;
-constexpr uint32_t kSchedOrder = 8 + kHeavySlots;
+constexpr uint32_t kSchedPerm = 8 + kHeavySlots;
 __host__ __device__ __forceinline__ uint32_t xcd_run_count(uint32_t padded_tiles) { return padded_tiles >> (padded_tiles >= kXcdLargeGrid ? 7u : 5u); }
-__host__ __device__ __forceinline__ uint32_t sched_flags_offset(uint32_t padded_tiles) { return kSchedOrder + ((xcd_run_count(padded_tiles) + 7u) & ~7u); }
-__host__ __device__ __forceinline__ size_t sched_words(uint32_t padded_tiles) { return (size_t)sched_flags_offset(padded_tiles) + padded_tiles; }
+__host__ __device__ __forceinline__ size_t sched_words(uint32_t padded_tiles) { return (size_t)kSchedPerm + 2 * (size_t)padded_tiles; }
 // Positions of a launch over `padded_tiles` tiles.
 __host__ __device__ __forceinline__ uint32_t sched_positions(uint32_t padded_tiles, const uint32_t* sched) { return padded_tiles + (sched ? kHeavySlots : 0u); }
-// The tile position `position` of such a launch works on; false = nothing to do there.  Everything is wave-uniform (scalar loads).
-__device__ __forceinline__ bool scheduled_tile(uint32_t position, uint32_t padded_tiles, const uint32_t* __restrict__ sched, uint32_t* tile_out) {
+// The tile of buffer-order position `block` (the XCD runs of xcd_chunked_tile).
+__host__ __device__ __forceinline__ uint32_t xcd_run_tile(uint32_t block, uint32_t padded_tiles) {
   const uint32_t shift = padded_tiles >= kXcdLargeGrid ? 7u : 5u;
+  const uint32_t xcd = block & 7u, j = block >> 3;
+  return ((((j >> shift) << 3) + xcd) << shift) + (j & ((1u << shift) - 1u));
+}
+// The tile position `position` of a launch works on; false = nothing to do there.  Everything is wave-uniform (scalar loads).
+__device__ __forceinline__ bool scheduled_tile(uint32_t position, uint32_t padded_tiles, const uint32_t* __restrict__ sched, uint32_t* tile_out) {
   if (!sched) {
-    const uint32_t xcd = position & 7u, j = position >> 3;
-    *tile_out = ((((j >> shift) << 3) + xcd) << shift) + (j & ((1u << shift) - 1u));
+    *tile_out = xcd_run_tile(position, padded_tiles);
     return true;
   }
   if (position < kHeavySlots) {
@@ -78,12 +84,9 @@ __device__ __forceinline__ bool scheduled_tile(uint32_t position, uint32_t padde
     *tile_out = sched[8 + position];
     return true;
   }
-  const uint32_t block = position - kHeavySlots;
-  const uint32_t xcd = block & 7u, j = block >> 3;
-  const uint32_t run = sched[kSchedOrder + ((j >> shift) << 3) + xcd];
-  const uint32_t tile = (run << shift) + (j & ((1u << shift) - 1u));
+  const uint32_t tile = sched[kSchedPerm + (position - kHeavySlots)];
   *tile_out = tile;
-  return sched[sched_flags_offset(padded_tiles) + tile] == 0;
+  return sched[kSchedPerm + padded_tiles + tile] == 0;
 }
 
 struct WaveBounds {

@@ -399,6 +399,10 @@ int bahip_debug_set_pose_form(int form);
  * environment switches it off too) = heavy runs first, from the candidate counts of the previous pose phase (wave_cull.h:
  * xcd_ordered_tile).  A scheduling hint: results are bit-identical either way. */
 int bahip_debug_set_tile_order(int enabled);
+/* The schedule in use (test hook): *padded_tiles_out = the grid size it is valid for (0: none yet); words_out (may be NULL)
+ * receives up to max_words of it: [0] heavy tiles, [8 .. 8 + 1024) their list, then one tile per regular position (padded_tiles
+ * words, a permutation of the tiles), then one flag per tile (non-zero = in the heavy list). */
+int bahip_debug_read_tile_schedule(bahip_context* ctx, uint32_t* padded_tiles_out, uint32_t* words_out, size_t max_words);
 /* The intrinsics sweep appends its per-cell records to buffers sized from the previous call's demand (kernels_intrinsics.hip);
  * records that do not fit go out as atomics, with the same result.  records_per_block >= 0 fixes the size (0: no buffers, < 0:
  * automatic again) -- for the tests of the overflow path and for A/B timing.  bahip_debug_intrinsics_bin_stats: capacity and the
