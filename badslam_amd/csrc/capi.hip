@@ -404,9 +404,9 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
   const int* counters = reinterpret_cast<const int*>(host_work + num_work);
   if (ensure_tile_bounds(ctx, s.size)) return 1;
   const uint32_t padded_tiles = pose_padded_tiles(s.size);
-  // (costs drift slowly -- poses move by millimetres, keyframes come one at a time -- so the census and the 10 us of the order
-  // kernel are spent on every 8th phase only, and whenever the grid has changed)
-  constexpr int kSchedulePhases = 8;
+  // (costs drift slowly -- poses move by millimetres, keyframes come one at a time -- so the census and the order kernel (one
+  // workgroup: 0.16 ms at 47 k tiles) are spent on every 32nd phase only, and whenever the grid has changed)
+  constexpr int kSchedulePhases = 32;
   schedule = schedule && g_tile_order_enabled && s.size > 0 &&
              (ctx->tile_order_tiles != padded_tiles || ++ctx->phases_since_schedule >= kSchedulePhases);
   if (schedule && ensure_tile_schedule(ctx, padded_tiles)) return 1;

@@ -722,7 +722,9 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   // work items in this launch fits.
   const int num_items = stored_bounds ? num_listed : num_work;
   const size_t item_bytes = sizeof(HbFixed) * kHbStride;
-  const bool lds_form = tile_counters != nullptr && (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && parts == 1 && forced == 0));
+  // (round 3, with the schedule: 23.4 k tiles -- half of the bench scene -- 0.43 ms in the LDS form against 0.77-0.89 ms with
+  // global atomics, 11.7 k tiles 0.32 against 0.39-0.45, 5.9 k tiles 0.30 against 0.25: the LDS form from 8192 tiles on)
+  const bool lds_form = tile_counters != nullptr && (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && tiles >= 8192 && forced == 0));
   ++g_pose_form_launches[lds_form ? 1 : 0];
   if (lds_form) {
     const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes))
@@ -809,16 +811,17 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__
     sorted[rank] = r;
   }
   __syncthreads();
+  for (uint32_t r = threadIdx.x; r < runs; r += blockDim.x)   // (key is free now: a run's total, for the balance below)
+    key[r] = quarter_cost[4 * r] + quarter_cost[4 * r + 1] + quarter_cost[4 * r + 2] + quarter_cost[4 * r + 3];
+  __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t row = 0; row * 8 < runs; ++row) {
       uint32_t run_of[8], cost_of[8], xcd_of[8];
-      for (uint32_t c = 0; c < 8; ++c) {
-        const uint32_t r = sorted[row * 8 + c];
-        run_of[c] = r;
-        cost_of[c] = quarter_cost[4 * r] + quarter_cost[4 * r + 1] + quarter_cost[4 * r + 2] + quarter_cost[4 * r + 3];
-        xcd_of[c] = c;
-      }
+#pragma unroll
+      for (uint32_t c = 0; c < 8; ++c) run_of[c] = sorted[row * 8 + c];
+#pragma unroll
+      for (uint32_t c = 0; c < 8; ++c) { cost_of[c] = key[run_of[c]]; xcd_of[c] = c; }
       for (uint32_t a = 1; a < 8; ++a)        // runs by descending total, XCDs by ascending load (insertion sorts of eight)
         for (uint32_t b = a; b > 0 && cost_of[b] > cost_of[b - 1]; --b) {
           const uint32_t t = cost_of[b]; cost_of[b] = cost_of[b - 1]; cost_of[b - 1] = t;
