@@ -763,12 +763,16 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
 //   3. position row * 8 + x runs on XCD x: within every row of eight runs the heavier run goes to the XCD that has received less
 //      so far (the XCDs' queues are separate -- the hardware deals workgroups round-robin, the pose sweep keeps a counter per XCD --
 //      and with the rows dealt in sorted order their totals differed by 5 %: 35 us between the first and the last queue running dry);
-//   4. the tiles of the last quarter of the rows are placed one by one, by descending cost (a counting sort; heavy tiles, which
+//   4. the tiles of the last rows (a quarter of them, at most 12 288 tiles) are placed one by one, by descending cost (a counting sort; heavy tiles, which
 //      are skipped there anyway, last), so that the launch runs out on tiles of one or two candidates.
 constexpr int kTileOrderMaxRuns = 2560;   // 327 680 tiles = 21 M surfels
 #ifndef BAHIP_SCHED_TAIL_DIV
 #define BAHIP_SCHED_TAIL_DIV 4   // measured at the bench size: 8 -> 4: both sweeps 1 % shorter; 3: no further gain
 #endif
+#ifndef BAHIP_SCHED_TAIL_TILES
+#define BAHIP_SCHED_TAIL_TILES 12288   // three rounds of the 4096 wavefront slots: the tile-by-tile tail gives up L2 locality, no need for more
+#endif
+constexpr uint32_t kSchedTailTiles = BAHIP_SCHED_TAIL_TILES;
 __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__ tile_cost, uint32_t padded_tiles, uint32_t* __restrict__ sched) {
   __shared__ uint32_t quarter_cost[4 * kTileOrderMaxRuns];   // cost of every quarter of a run, heavy tiles left out
   __shared__ uint32_t key[kTileOrderMaxRuns];
@@ -837,7 +841,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(uint32_t* __restrict__
   }
   __syncthreads();
   // the permutation: whole runs for the leading rows ...
-  const uint32_t rows = runs / 8, tail_rows = max(1u, rows / BAHIP_SCHED_TAIL_DIV), head_positions = (rows - tail_rows) * 8 * run_tiles;
+  const uint32_t rows = runs / 8, tail_rows = max(1u, min(rows / BAHIP_SCHED_TAIL_DIV, kSchedTailTiles / (8u * run_tiles))), head_positions = (rows - tail_rows) * 8 * run_tiles;
   const uint32_t shift = padded_tiles >= kXcdLargeGrid ? 7u : 5u;
   for (uint32_t p = threadIdx.x; p < head_positions; p += blockDim.x) {
     const uint32_t xcd = p & 7u, j = p >> 3;

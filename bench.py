@@ -524,8 +524,8 @@ def main():
             # table of the launch's work items fits, one tile per wavefront with global atomics otherwise; the line names the one
             # most of the timed launches used
             lds = form_lds.value >= form_global.value
-            pose_kernel = "pose_accumulate_lds_kernel<true, true>" if lds else "pose_accumulate_kernel<true, true>"
-            traffic = pmc_kernel_entry(pmc, pmc_source, pose_kernel)
+            pose_kernel = "pose_accumulate_lds_kernel<true, true, false>" if lds else "pose_accumulate_kernel<true, true>"
+            traffic = pmc_kernel_entry(pmc, pmc_source, pose_kernel.split(">")[0].rsplit(", false", 1)[0])   # (the prefix: profiles of earlier rounds list the LDS form without its third flag)
             flops = traffic.get("fp32_flops_per_launch") if traffic else None
             out["roofline"] = {"bound": "hbm", "kernel": pose_kernel.replace(", ", ","), "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

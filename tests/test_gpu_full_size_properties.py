@@ -79,3 +79,43 @@ def test_geometry_pass_is_deterministic_and_shape_independent_at_full_size(full_
     assert np.array_equal(results[0], results[1])      # same launch shape twice: no atomics, no races
     assert np.array_equal(results[0], results[2])      # one or four wavefronts per tile: same bits
     assert not np.array_equal(results[0][2], data[2].view(np.uint32))   # and the pass did move the surfels
+
+
+def test_schedule_changes_no_bit_at_full_size(full_scene):
+    """Heavy work first (wave_cull.h: scheduled_tile) at the bench size -- 46 875 tiles, runs of 128, ~400 heavy tiles: three
+    alternating iterations with the schedule off and on end with the same surfels and poses, bit for bit; the schedule in use
+    is a permutation of the tiles and its heavy list is exactly the flagged tiles."""
+    import ctypes as C
+    from badslam_amd import capi
+    ba, data, clean, poses_gt, args = full_scene
+    ctx = ba.backend_context()
+    rng = np.random.Generator(np.random.PCG64(77))
+    from badslam_amd import synthetic
+    start = [synthetic.perturb_pose(rng, T) for T in poses_gt]
+    results = []
+    try:
+        for enabled in (0, 1):
+            capi.check(ctx.lib.bahip_debug_set_tile_order(enabled))
+            for k in range(200):
+                ba.set_keyframe_pose(k, start[k])
+            ba.upload_surfels(data)
+            ba.set_ba_iteration_counts(1, 1)
+            ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=3, max_iterations=3,
+                                active_keyframe_window_start=0, active_keyframe_window_end=199, increase_ba_iteration_count=False)
+            results.append((ba.download_surfels(rows=8).view(np.uint32).copy(), np.array([ba.keyframe_pose(k) for k in range(200)])))
+    finally:
+        capi.check(ctx.lib.bahip_debug_set_tile_order(1))
+    assert np.array_equal(results[0][0], results[1][0])
+    assert np.array_equal(results[0][1], results[1][1])
+    padded = C.c_uint32()
+    capi.check(ctx.lib.bahip_debug_read_tile_schedule(ctx.handle, C.byref(padded), None, 0))
+    P = padded.value
+    assert P >= 46875 and P % 1024 == 0
+    words = (C.c_uint32 * (8 + 1024 + 2 * P))()
+    capi.check(ctx.lib.bahip_debug_read_tile_schedule(ctx.handle, C.byref(padded), words, len(words)))
+    w = np.frombuffer(words, np.uint32)
+    heavy = w[8:8 + int(w[0])]
+    perm, flags = w[1032:1032 + P], w[1032 + P:1032 + 2 * P]
+    assert 0 < len(heavy) <= 1024
+    assert np.array_equal(np.sort(perm), np.arange(P, dtype=np.uint32))
+    assert np.array_equal(np.sort(heavy), np.nonzero(flags)[0].astype(np.uint32))
