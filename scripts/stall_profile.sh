@@ -6,7 +6,8 @@ TAG=${1:-x}; shift || true
 REPO=$(pwd); OUT=$REPO/gpurun_out/stall_$TAG; mkdir -p "$OUT"
 export TMPDIR=/tmp; cd /tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-extras --steps 4 --warmup 1 $*"
-pass() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$n" -- $BENCH > /dev/null 2> "$OUT/$n.log"; }
+# every pass under its own time limit: pass d has hung twice on the pool (r3_a, r3_c) and took the rest of the call's budget with it
+pass() { n=$1; shift; timeout ${PASS_TIMEOUT:-60} rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$n" -- $BENCH > /dev/null 2> "$OUT/$n.log" || echo "pass $n: not completed" >&2; }
 pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 pass b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_BRANCH
 pass c SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT
