@@ -489,6 +489,8 @@ def main():
                                    f"{' (BASELINE configs[2])' if (W, H, K, args.surfels, args.intrinsics) == (640, 480, 200, 3000000, False) else ''}",
                        "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
                        "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
+                       "tile_schedule": ("buffer order (BAHIP_TILE_ORDER=0)" if os.environ.get("BAHIP_TILE_ORDER") == "0"
+                                         else "heavy work first, from the pose sweep's per-tile candidate counts (wave_cull.h: scheduled_tile)"),
                        "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, %g cm grid)" % (100 * args.sort_cell),
                        "parallelism": (f"keyframe-shard x{world}, RCCL all-reduce of the geometry step's class partials and of pose H,b" if by_keyframes
                                        else f"surfel-shard x{world}, RCCL all-reduce of pose H,b") if world > 1 else "single GPU"},
