@@ -93,3 +93,66 @@ def evaluate_cost(orc, keyframe_indices=None, quantize_texture_weights=False):
         total += float(L.ref_evaluate_cost(C.byref(sc), C.byref(n), int(orc.use_depth), int(orc.use_desc)))
         count += int(n.value)
     return total, count
+
+
+# ---- whole kernels of the reference (oracle/ref_shim/ref_kernels.cc) ---------------------------------------------------------
+class RefBaKeyframe(C.Structure):
+    _fields_ = [("depth", C.POINTER(C.c_uint16)), ("normals", C.POINTER(C.c_uint16)), ("rgba", C.POINTER(C.c_uint8)),
+                ("frame_T_global", C.c_float * 12), ("global_R_frame", C.c_float * 9), ("activation", C.c_int32), ("pad", C.c_int32)]
+
+
+class RefBaScene(C.Structure):
+    _fields_ = [("depth_cam", C.c_float * 4), ("color_cam", C.c_float * 4), ("width", C.c_int), ("height", C.c_int),
+                ("color_width", C.c_int), ("color_height", C.c_int), ("a", C.c_float), ("raw_to_float_depth", C.c_float),
+                ("baseline_fx", C.c_float), ("cell", C.c_int), ("cfactor", C.POINTER(C.c_float)), ("cf_width", C.c_int),
+                ("cf_height", C.c_int), ("surfel_rows", C.POINTER(C.c_float)), ("capacity", C.c_uint32), ("surfels_size", C.c_uint32),
+                ("active", C.POINTER(C.c_uint8)), ("quantize_texture_weights", C.c_int), ("num_keyframes", C.c_int),
+                ("keyframes", C.POINTER(RefBaKeyframe))]
+
+
+class ReferenceKernels:
+    """The reference's geometry-step and activation kernels (B/kernel_opt_geometry.cu, B/kernel_surfel_activation.cu, compiled
+    for the host) on a COPY of the state an oracle.binding.OracleBA holds: same keyframe images, poses, activations, cameras,
+    cfactor image; `surfel_data` (17 rows) and `active` are this object's own arrays."""
+
+    def __init__(self, orc, quantize_texture_weights=False):
+        from oracle import binding as ob
+        self.L = lib()
+        for name in ("ref_flag_pairs_outside_int_range", "ref_update_surfel_activation", "ref_optimize_geometry_iteration"):
+            getattr(self.L, name).restype = None
+        self.orc = orc
+        self.surfel_data = np.ascontiguousarray(orc.surfel_data.copy())
+        self.active = np.ascontiguousarray(orc.active.copy())
+        self.keep = []
+        K = len(orc.keyframes)
+        self.kfs = (RefBaKeyframe * K)()
+        for k in range(K):
+            arrs, kf = orc.kf_arrays(k), orc.keyframes[k]
+            self.kfs[k].depth, self.kfs[k].normals = ob._ptr(arrs["depth"], C.c_uint16), ob._ptr(arrs["normals"], C.c_uint16)
+            self.kfs[k].rgba = ob._ptr(arrs["color"], C.c_uint8)
+            self.kfs[k].frame_T_global[:] = list(kf.frame_T_global)
+            self.kfs[k].global_R_frame[:] = list(kf.global_R_frame)
+            self.kfs[k].activation = int(kf.activation)
+        sc = RefBaScene()
+        for name, cam in (("depth_cam", orc.depth_cam), ("color_cam", orc.color_cam)):
+            getattr(sc, name)[:] = [cam.fx, cam.fy, cam.cx, cam.cy]
+        sc.width, sc.height = orc.depth_cam.width, orc.depth_cam.height
+        sc.color_width, sc.color_height = orc.color_cam.width, orc.color_cam.height
+        sc.a, sc.raw_to_float_depth, sc.baseline_fx, sc.cell = orc.dp.a, orc.dp.raw_to_float_depth, orc.dp.baseline_fx, orc.dp.cell
+        sc.cfactor, sc.cf_width, sc.cf_height = ob._ptr(orc.cfactor, C.c_float), orc.cf_w, orc.cf_h
+        sc.surfel_rows, sc.capacity, sc.surfels_size = ob._ptr(self.surfel_data, C.c_float), self.surfel_data.shape[1], orc.surfels_size
+        sc.active = ob._ptr(self.active, C.c_uint8)
+        sc.quantize_texture_weights = int(quantize_texture_weights)
+        sc.num_keyframes, sc.keyframes = K, self.kfs
+        self.sc = sc
+
+    def pairs_outside_int_range(self):
+        flags = np.zeros(self.surfel_data.shape[1], np.uint8)
+        self.L.ref_flag_pairs_outside_int_range(C.byref(self.sc), flags.ctypes.data_as(C.c_void_p))
+        return flags[:self.sc.surfels_size].astype(bool)
+
+    def update_surfel_activation(self):
+        self.L.ref_update_surfel_activation(C.byref(self.sc))
+
+    def optimize_geometry_iteration(self, use_depth=True, use_desc=True):
+        self.L.ref_optimize_geometry_iteration(C.byref(self.sc), int(use_depth), int(use_desc))

@@ -1,0 +1,33 @@
+// libvis/cuda/cuda_auto_tuner.h -- HOST stand-in for the reference's kernel launcher (TEST INFRASTRUCTURE, see oracle/oracle.h).
+// The reference launches every kernel through CUDA_AUTO_TUNE_1D(kernel, block width, domain width, shared memory, stream,
+// arguments...) (L/cuda/cuda_auto_tuner.h:447-507: kernel<<<ceil(domain / width), width, shared, stream>>>(arguments)).  Here
+// the macro runs the grid on the host: blocks are dealt to OpenMP threads, the threads of a block run one after the other, and
+// threadIdx / blockIdx / blockDim / gridDim are thread-local variables the kernel bodies read.  Valid for kernels without block
+// collectives and without inter-thread communication -- which is what oracle/ref_shim/ref_kernels.cc compiles: every thread of
+// B/kernel_opt_geometry.cu and B/kernel_surfel_activation.cu owns one surfel (__syncthreads_or inside
+// SurfelProjectsToAssociatedPixel only lets a block leave early together; for one thread it is the identity, cuda_runtime.h).
+#pragma once
+
+#include <cuda_runtime.h>
+
+struct RefDim3 { unsigned int x, y, z; };
+extern thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#define CHECK_CUDA_NO_ERROR() do {} while (false)   // B/cuda_util.cuh:40-45: CUDA_CHECK() expands to this
+
+#define CUDA_AUTO_TUNE_1D(kernel_name, default_block_width, domain_width, shared_memory_size, stream, ...)                              \
+  do {                                                                                                                                   \
+    const long long ref_domain = (long long)(domain_width);                                                                             \
+    const unsigned int ref_width = (unsigned int)(default_block_width);                                                                 \
+    const long long ref_blocks = (ref_domain + ref_width - 1) / ref_width;                                                              \
+    _Pragma("omp parallel for schedule(dynamic, 4)")                                                                                    \
+    for (long long ref_block = 0; ref_block < ref_blocks; ++ref_block) {                                                                \
+      blockDim = RefDim3{ref_width, 1, 1};                                                                                              \
+      gridDim = RefDim3{(unsigned int)ref_blocks, 1, 1};                                                                                \
+      blockIdx = RefDim3{(unsigned int)ref_block, 0, 0};                                                                                \
+      for (unsigned int ref_thread = 0; ref_thread < ref_width; ++ref_thread) {                                                         \
+        threadIdx = RefDim3{ref_thread, 0, 0};                                                                                          \
+        kernel_name(__VA_ARGS__);                                                                                                       \
+      }                                                                                                                                  \
+    }                                                                                                                                    \
+  } while (false)

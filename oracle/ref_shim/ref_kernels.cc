@@ -1,0 +1,166 @@
+// ref_kernels.cc -- the REFERENCE's own geometry-step and activation KERNELS, compiled for the host and run over whole scenes.
+// TEST INFRASTRUCTURE (see oracle/oracle.h).  The two .cu files are included from where they lie under /root/reference
+// (oracle/Makefile passes the include paths; nothing is copied):
+//   B/kernel_opt_geometry.cu        ResetSurfelAccum*, AccumulateSurfelNormalOptimizationCoeffs, UpdateSurfelNormal,
+//                                   AccumulateSurfelPositionOptimizationCoeffsFromDepthResidual, UpdateSurfelPosition,
+//                                   AccumulateSurfelPositionAndDescriptorOptimizationCoeffs<use_depth>, UpdateSurfelPositionAndDescriptor
+//   B/kernel_surfel_activation.cu   SetSurfelInactive, DetermineActiveSurfels
+// (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
+// stand-in CUDA_AUTO_TUNE_1D of ref_shim/libvis/cuda/cuda_auto_tuner.h.  What this file adds is the sequence of calls the
+// reference's host drivers make -- B/kernel_opt_geometry.cc:80-201 (OptimizeGeometryIterationCUDA) and
+// B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA) -- over plain arrays instead of Keyframe objects, with
+// the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
+// keyframe, one launch after the other; that order is kept.
+#include <cstring>
+
+#include <libvis/cuda/cuda_auto_tuner.h>
+
+thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#include "badslam/kernel_opt_geometry.cu"
+#include "badslam/kernel_surfel_activation.cu"
+
+using namespace vis;
+
+extern "C" {
+
+struct ref_ba_keyframe {
+  uint16_t* depth; uint16_t* normals; uint8_t* rgba;   // dense, row-major; rgba.w = luma
+  float frame_T_global[12];
+  float global_R_frame[9];
+  int32_t activation;                                  // 0 kActive, 1 kCovisibleActive, 2 kInactive (B/keyframe.h:54-67)
+  int32_t pad;
+};
+
+struct ref_ba_scene {
+  float depth_cam[4], color_cam[4];                    // fx, fy, cx, cy in the pixel-corner convention
+  int width, height, color_width, color_height;
+  float a, raw_to_float_depth, baseline_fx;
+  int cell;
+  float* cfactor; int cf_width, cf_height;
+  float* surfel_rows; uint32_t capacity, surfels_size; // 17 rows of `capacity` floats
+  uint8_t* active;                                     // kSurfelActiveFlag per surfel
+  int quantize_texture_weights;
+  int num_keyframes;
+  const ref_ba_keyframe* keyframes;
+};
+
+}  // extern "C"
+
+namespace {
+
+struct Bound {
+  CUDABuffer_<float> surfels;
+  CUDABuffer_<u8> active;
+  DepthParameters dp;
+  PixelCornerProjector depth_projector, color_projector;
+  PixelCenterUnprojector unprojector;
+  DepthToColorPixelCorner d2c;
+  explicit Bound(const ref_ba_scene* sc)
+      : surfels(sc->surfel_rows, kSurfelAttributeCount, (int)sc->capacity, (size_t)sc->capacity * sizeof(float)),
+        active(sc->active, 1, (int)sc->capacity, (size_t)sc->capacity),
+        depth_projector(sc->depth_cam[0], sc->depth_cam[1], sc->depth_cam[2], sc->depth_cam[3]),
+        color_projector(sc->color_cam[0], sc->color_cam[1], sc->color_cam[2], sc->color_cam[3]),
+        unprojector(depth_projector) {                                    // B/surfel_projection.h:54-71
+    dp.cfactor_buffer = CUDABuffer_<float>(sc->cfactor, sc->cf_height, sc->cf_width, (size_t)sc->cf_width * sizeof(float));
+    dp.a = sc->a; dp.raw_to_float_depth = sc->raw_to_float_depth; dp.baseline_fx = sc->baseline_fx; dp.sparse_surfel_cell_size = sc->cell;
+    d2c.fx = sc->color_cam[0] / sc->depth_cam[0];                         // B/surfel_projection.h:100-124
+    d2c.fy = sc->color_cam[1] / sc->depth_cam[1];
+    d2c.cx = -1 * sc->color_cam[0] * sc->depth_cam[2] / sc->depth_cam[0] + sc->color_cam[2];
+    d2c.cy = -1 * sc->color_cam[1] * sc->depth_cam[3] / sc->depth_cam[1] + sc->color_cam[3];
+    d2c.width = sc->color_width; d2c.height = sc->color_height;
+  }
+};
+
+CUDAMatrix3x4 pose_of(const ref_ba_keyframe& kf) {
+  CUDAMatrix3x4 F;
+  F.row0 = make_float4(kf.frame_T_global[0], kf.frame_T_global[1], kf.frame_T_global[2], kf.frame_T_global[3]);
+  F.row1 = make_float4(kf.frame_T_global[4], kf.frame_T_global[5], kf.frame_T_global[6], kf.frame_T_global[7]);
+  F.row2 = make_float4(kf.frame_T_global[8], kf.frame_T_global[9], kf.frame_T_global[10], kf.frame_T_global[11]);
+  return F;
+}
+
+SurfelProjectionParameters projection_of(const ref_ba_scene* sc, const Bound& b, const ref_ba_keyframe& kf) {   // B/surfel_projection.h:69-84
+  CUDABuffer_<u16> depth_buffer(kf.depth, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+  CUDABuffer_<u16> normals_buffer(kf.normals, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+  return SurfelProjectionParameters(b.surfels, depth_buffer, normals_buffer, b.dp, b.depth_projector, b.unprojector, pose_of(kf), sc->surfels_size);
+}
+
+constexpr int kInactive = 2;
+
+}  // namespace
+
+extern "C" {
+
+// flags[i] |= 1 where surfel i, projected into some keyframe, lands beyond the int range: CUDA's float -> int conversion
+// saturates there (the pixel is outside the image), the host's yields INT_MIN and the reference's bounds test lets it through
+// (see pixel_outside_int_range in ref_entry.cc).  A caller keeps such surfels out of a whole-kernel comparison.
+void ref_flag_pairs_outside_int_range(const ref_ba_scene* sc, uint8_t* flags) {
+  const Bound b(sc);
+  for (int k = 0; k < sc->num_keyframes; ++k) {
+    const CUDAMatrix3x4 F = pose_of(sc->keyframes[k]);
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)sc->surfels_size; ++i) {
+      const float3 global_position = SurfelGetPosition(b.surfels, (unsigned int)i);
+      float3 local_position;
+      if (!F.MultiplyIfResultZIsPositive(global_position, &local_position)) continue;
+      const float2 p = b.depth_projector.Project(local_position);
+      if (!(p.x < 2147483648.f && p.y < 2147483648.f)) flags[i] |= 1;
+    }
+  }
+}
+
+// B/kernel_surfel_activation.cc:38-66
+void ref_update_surfel_activation(const ref_ba_scene* sc) {
+  if (sc->surfels_size == 0) return;
+  const Bound b(sc);
+  CallSetSurfelInactiveKernel(nullptr, sc->surfels_size, b.active);
+  for (int k = 0; k < sc->num_keyframes; ++k) {
+    if (sc->keyframes[k].activation != 0) continue;   // kActive only
+    CallDetermineActiveSurfelsKernel(nullptr, projection_of(sc, b, sc->keyframes[k]), b.active);
+  }
+}
+
+// B/kernel_opt_geometry.cc:80-201
+void ref_optimize_geometry_iteration(const ref_ba_scene* sc, int use_depth_residuals, int use_descriptor_residuals) {
+  if (sc->surfels_size == 0) return;
+  const Bound b(sc);
+  // --- normals (:108-134)
+  CallResetSurfelAccum0to3CUDAKernel(nullptr, sc->surfels_size, b.surfels, b.active);
+  for (int k = 0; k < sc->num_keyframes; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    if (kf.activation == kInactive) continue;
+    CUDAMatrix3x3 R;
+    R.row0 = make_float3(kf.global_R_frame[0], kf.global_R_frame[1], kf.global_R_frame[2]);
+    R.row1 = make_float3(kf.global_R_frame[3], kf.global_R_frame[4], kf.global_R_frame[5]);
+    R.row2 = make_float3(kf.global_R_frame[6], kf.global_R_frame[7], kf.global_R_frame[8]);
+    CallAccumulateSurfelNormalOptimizationCoeffsCUDAKernel(nullptr, projection_of(sc, b, kf), R, b.active);
+  }
+  CallUpdateSurfelNormalCUDAKernel(nullptr, sc->surfels_size, b.surfels, b.active);
+
+  if (!use_descriptor_residuals) {
+    // --- position from the depth residual (:137-168)
+    CallResetSurfelAccum0to1CUDAKernel(nullptr, sc->surfels_size, b.surfels, b.active);
+    for (int k = 0; k < sc->num_keyframes; ++k) {
+      const ref_ba_keyframe& kf = sc->keyframes[k];
+      if (kf.activation == kInactive) continue;
+      RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+      CallAccumulateSurfelPositionOptimizationCoeffsFromDepthResidualCUDAKernel(nullptr, projection_of(sc, b, kf), b.unprojector, b.d2c, sc->color_cam[0],
+                                                                               sc->color_cam[1], reinterpret_cast<cudaTextureObject_t>(&tex), b.active);
+    }
+    CallUpdateSurfelPositionCUDAKernel(nullptr, sc->surfels_size, b.surfels, b.active);
+  } else {
+    // --- position and descriptors jointly (:169-199)
+    CallResetSurfelAccumCUDAKernel(nullptr, sc->surfels_size, b.surfels, b.active);
+    for (int k = 0; k < sc->num_keyframes; ++k) {
+      const ref_ba_keyframe& kf = sc->keyframes[k];
+      if (kf.activation == kInactive) continue;
+      RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+      AccumulateSurfelPositionAndDescriptorOptimizationCoeffsCUDAKernel(nullptr, projection_of(sc, b, kf), b.unprojector, b.d2c, b.color_projector,
+                                                                        reinterpret_cast<cudaTextureObject_t>(&tex), b.active, use_depth_residuals != 0);
+    }
+    CallUpdateSurfelPositionAndDescriptorCUDAKernel(nullptr, sc->surfels_size, b.surfels, b.active);
+  }
+}
+
+}  // extern "C"
