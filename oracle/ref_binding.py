@@ -98,7 +98,7 @@ def evaluate_cost(orc, keyframe_indices=None, quantize_texture_weights=False):
 # ---- whole kernels of the reference (oracle/ref_shim/ref_kernels.cc) ---------------------------------------------------------
 class RefBaKeyframe(C.Structure):
     _fields_ = [("depth", C.POINTER(C.c_uint16)), ("normals", C.POINTER(C.c_uint16)), ("rgba", C.POINTER(C.c_uint8)),
-                ("frame_T_global", C.c_float * 12), ("global_R_frame", C.c_float * 9), ("activation", C.c_int32), ("pad", C.c_int32)]
+                ("radius", C.POINTER(C.c_uint16)), ("frame_T_global", C.c_float * 12), ("global_R_frame", C.c_float * 9), ("activation", C.c_int32), ("pad", C.c_int32)]
 
 
 class RefBaScene(C.Structure):
@@ -111,15 +111,16 @@ class RefBaScene(C.Structure):
 
 
 class ReferenceKernels:
-    """The reference's geometry-step and activation kernels (B/kernel_opt_geometry.cu, B/kernel_surfel_activation.cu, compiled
-    for the host) on a COPY of the state an oracle.binding.OracleBA holds: same keyframe images, poses, activations, cameras,
+    """The reference's geometry-step, activation, colour-assignment and deletion kernels (B/kernel_opt_geometry.cu,
+    B/kernel_surfel_activation.cu, B/kernel_assign_colors.cu, B/kernel_delete_surfels.cu, compiled for the host) on a COPY of the state an oracle.binding.OracleBA holds: same keyframe images, poses, activations, cameras,
     cfactor image; `surfel_data` (17 rows) and `active` are this object's own arrays."""
 
     def __init__(self, orc, quantize_texture_weights=False):
         from oracle import binding as ob
         self.L = lib()
-        for name in ("ref_flag_pairs_outside_int_range", "ref_update_surfel_activation", "ref_optimize_geometry_iteration"):
+        for name in ("ref_flag_pairs_outside_int_range", "ref_update_surfel_activation", "ref_optimize_geometry_iteration", "ref_assign_colors"):
             getattr(self.L, name).restype = None
+        self.L.ref_delete_surfels_and_update_radii.restype = C.c_uint32
         self.orc = orc
         self.surfel_data = np.ascontiguousarray(orc.surfel_data.copy())
         self.active = np.ascontiguousarray(orc.active.copy())
@@ -130,6 +131,7 @@ class ReferenceKernels:
             arrs, kf = orc.kf_arrays(k), orc.keyframes[k]
             self.kfs[k].depth, self.kfs[k].normals = ob._ptr(arrs["depth"], C.c_uint16), ob._ptr(arrs["normals"], C.c_uint16)
             self.kfs[k].rgba = ob._ptr(arrs["color"], C.c_uint8)
+            self.kfs[k].radius = ob._ptr(arrs["radius"], C.c_uint16)
             self.kfs[k].frame_T_global[:] = list(kf.frame_T_global)
             self.kfs[k].global_R_frame[:] = list(kf.global_R_frame)
             self.kfs[k].activation = int(kf.activation)
@@ -156,3 +158,9 @@ class ReferenceKernels:
 
     def optimize_geometry_iteration(self, use_depth=True, use_desc=True):
         self.L.ref_optimize_geometry_iteration(C.byref(self.sc), int(use_depth), int(use_desc))
+
+    def assign_colors(self):
+        self.L.ref_assign_colors(C.byref(self.sc))
+
+    def delete_surfels_and_update_radii(self, min_observation_count):
+        return int(self.L.ref_delete_surfels_and_update_radii(C.byref(self.sc), int(min_observation_count)))

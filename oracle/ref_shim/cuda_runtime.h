@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 
 #define __device__
 #define __host__
@@ -87,4 +88,21 @@ template <> inline float4 tex2D<float4>(cudaTextureObject_t handle, float x, flo
 template <> inline float tex2D<float>(cudaTextureObject_t handle, float x, float y) { return tex2D<float4>(handle, x, y).w; }
 
 inline int __syncthreads_or(int predicate) { return predicate; }
+
+// what the whole kernels of ref_kernels.cc need on top of the device-math headers (one "thread" at a time, several OpenMP threads)
+#define __shared__ static thread_local
+inline unsigned int atomicAdd(unsigned int* address, unsigned int value) { return __atomic_fetch_add(address, value, __ATOMIC_RELAXED); }
+inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, sizeof(i)); return i; }
+struct __half { unsigned short bits; };
+inline __half __ushort_as_half(unsigned short bits) { __half h = {bits}; return h; }
+inline float __half2float(__half h) {   // binary16 -> binary32, exact
+  const uint32_t sign = (uint32_t)(h.bits & 0x8000u) << 16, exponent = (h.bits >> 10) & 0x1fu, mantissa = h.bits & 0x3ffu;
+  uint32_t out;
+  if (exponent == 0) {
+    if (mantissa == 0) { out = sign; }
+    else { int e = -1; uint32_t m = mantissa; do { ++e; m <<= 1; } while (!(m & 0x400u)); out = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13); }
+  } else if (exponent == 31) { out = sign | 0x7f800000u | (mantissa << 13); }
+  else { out = sign | ((exponent + 127 - 15) << 23) | (mantissa << 13); }
+  float f; std::memcpy(&f, &out, sizeof(f)); return f;
+}
 inline int __all(int predicate) { return predicate; }

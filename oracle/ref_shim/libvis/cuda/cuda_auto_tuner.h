@@ -31,3 +31,24 @@ extern thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
       }                                                                                                                                  \
     }                                                                                                                                    \
   } while (false)
+
+// L/cuda/cuda_auto_tuner.h:517-610: the kernel's template arguments may name the block width (`block_width`)
+#define TEMPLATE_ARGUMENTS(...) __VA_ARGS__
+#define CUDA_AUTO_TUNE_1D_TEMPLATED(kernel_name, default_block_width, domain_width, shared_memory_size, stream, template_parameters, ...)   \
+  do {                                                                                                                                   \
+    constexpr int block_width = (default_block_width);                                                                                  \
+    (void)block_width;                                                                                                                  \
+    const long long ref_domain = (long long)(domain_width);                                                                             \
+    const unsigned int ref_width = (unsigned int)(default_block_width);                                                                 \
+    const long long ref_blocks = (ref_domain + ref_width - 1) / ref_width;                                                              \
+    _Pragma("omp parallel for schedule(dynamic, 4)")                                                                                    \
+    for (long long ref_block = 0; ref_block < ref_blocks; ++ref_block) {                                                                \
+      blockDim = RefDim3{ref_width, 1, 1};                                                                                              \
+      gridDim = RefDim3{(unsigned int)ref_blocks, 1, 1};                                                                                \
+      blockIdx = RefDim3{(unsigned int)ref_block, 0, 0};                                                                                \
+      for (unsigned int ref_thread = 0; ref_thread < ref_width; ++ref_thread) {                                                         \
+        threadIdx = RefDim3{ref_thread, 0, 0};                                                                                          \
+        kernel_name<template_parameters>(__VA_ARGS__);                                                                                  \
+      }                                                                                                                                  \
+    }                                                                                                                                    \
+  } while (false)

@@ -5,10 +5,14 @@
 //                                   AccumulateSurfelPositionOptimizationCoeffsFromDepthResidual, UpdateSurfelPosition,
 //                                   AccumulateSurfelPositionAndDescriptorOptimizationCoeffs<use_depth>, UpdateSurfelPositionAndDescriptor
 //   B/kernel_surfel_activation.cu   SetSurfelInactive, DetermineActiveSurfels
+//   B/kernel_assign_colors.cu       ResetSurfelForColorAssignment, AccumulateColorObservations, AssignColors
+//   B/kernel_delete_surfels.cu      ResetSurfelAccumForSurfelDeletionAndRadiusUpdate, CountObservationsAndFreeSpaceViolations,
+//                                   MarkDeletedSurfels
 // (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
 // stand-in CUDA_AUTO_TUNE_1D of ref_shim/libvis/cuda/cuda_auto_tuner.h.  What this file adds is the sequence of calls the
-// reference's host drivers make -- B/kernel_opt_geometry.cc:80-201 (OptimizeGeometryIterationCUDA) and
-// B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA) -- over plain arrays instead of Keyframe objects, with
+// reference's host drivers make -- B/kernel_opt_geometry.cc:80-201 (OptimizeGeometryIterationCUDA),
+// B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA), B/kernel_assign_colors.cc:38-74 (AssignColorsCUDA) and
+// B/kernel_delete_surfels.cc:38-98 (DeleteSurfelsAndUpdateRadiiCUDAImpl) -- over plain arrays instead of Keyframe objects, with
 // the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
 // keyframe, one launch after the other; that order is kept.
 #include <cstring>
@@ -19,6 +23,8 @@ thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
 
 #include "badslam/kernel_opt_geometry.cu"
 #include "badslam/kernel_surfel_activation.cu"
+#include "badslam/kernel_assign_colors.cu"
+#include "badslam/kernel_delete_surfels.cu"
 
 using namespace vis;
 
@@ -26,6 +32,7 @@ extern "C" {
 
 struct ref_ba_keyframe {
   uint16_t* depth; uint16_t* normals; uint8_t* rgba;   // dense, row-major; rgba.w = luma
+  uint16_t* radius;                                    // binary16 bits of the squared point radius (B/keyframe.h:227-231)
   float frame_T_global[12];
   float global_R_frame[9];
   int32_t activation;                                  // 0 kActive, 1 kCovisibleActive, 2 kInactive (B/keyframe.h:54-67)
@@ -161,6 +168,42 @@ void ref_optimize_geometry_iteration(const ref_ba_scene* sc, int use_depth_resid
     }
     CallUpdateSurfelPositionAndDescriptorCUDAKernel(nullptr, sc->surfels_size, b.surfels, b.active);
   }
+}
+
+// B/kernel_assign_colors.cc:38-74: every keyframe, whatever its activation
+void ref_assign_colors(const ref_ba_scene* sc) {
+  if (sc->surfels_size == 0) return;
+  const Bound b(sc);
+  CallResetSurfelForColorAssignmentKernel(nullptr, (int)sc->surfels_size, b.surfels);
+  for (int k = 0; k < sc->num_keyframes; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+    CallAccumulateColorObservationsCUDAKernel(nullptr, (int)sc->surfels_size, projection_of(sc, b, kf), b.d2c, reinterpret_cast<cudaTextureObject_t>(&tex));
+  }
+  CallAssignColorsCUDAKernel(nullptr, sc->surfels_size, b.surfels);
+}
+
+// B/kernel_delete_surfels.cc:38-98 with update_radii = true: every keyframe.  Returns the number of surfels the call marked
+// as deleted, counted from the marks (the kernel's own counter is not meaningful under the stand-in BlockReduce, cub/cub.cuh).
+uint32_t ref_delete_surfels_and_update_radii(const ref_ba_scene* sc, int min_observation_count) {
+  if (sc->surfels_size == 0) return 0;
+  const Bound b(sc);
+  auto deleted_marks = [&]() {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < sc->surfels_size; ++i) n += __float_as_int(b.surfels(kSurfelX, i)) == 0x7fffffff ? 1u : 0u;
+    return n;
+  };
+  const uint32_t before = deleted_marks();
+  CallResetSurfelAccumForSurfelDeletionAndRadiusUpdateCUDAKernel(nullptr, sc->surfels_size, b.surfels, true);
+  for (int k = 0; k < sc->num_keyframes; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    CUDABuffer_<u16> radius_buffer(kf.radius, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+    CallCountObservationsAndFreeSpaceViolationsCUDAKernel(nullptr, projection_of(sc, b, kf), radius_buffer, true);
+  }
+  u32 counter = 0;
+  CUDABuffer_<u32> deleted_count_buffer(&counter, 1, 1, sizeof(u32));
+  CallMarkDeletedSurfelsCUDAKernel(nullptr, min_observation_count, sc->surfels_size, b.surfels, &deleted_count_buffer, true);
+  return deleted_marks() - before;
 }
 
 }  // extern "C"

@@ -290,3 +290,47 @@ def test_geometry_step_and_activation_against_the_reference_kernels(seed, use_de
         # photometric only: medians two to three decades below the 2.7 mm the step moves a surfel
         assert np.median(dpos) < 5e-6 and np.percentile(dpos, 99) < 5e-4
         assert np.median(ddesc) < 1e-3 and np.percentile(ddesc, 99) < 5e-2
+
+
+def test_colour_assignment_against_the_reference_kernels():
+    """DirectBA::AssignColors: B/kernel_assign_colors.cu (reset, one accumulation launch per keyframe, assignment) in the order of
+    B/kernel_assign_colors.cc:38-74 against the oracle: the mean of the bilinear RGBA samples over all keyframes that see a surfel,
+    rounded to 8 bits.  The oracle samples with exact binary32 weights and adds in the same keyframe order; the few codes that
+    differ are off by one (a mean within an ulp of .5)."""
+    ba, N = _perturbed_oracle(11, True, True)
+    ref = rb.ReferenceKernels(ba)
+    assert not ref.pairs_outside_int_range().any()
+    ref.assign_colors()
+    ba.assign_colors()
+    got = ba.surfel_data[5, :N].view(np.uint32).view(np.uint8).reshape(-1, 4).astype(int)
+    want = ref.surfel_data[5, :N].view(np.uint32).view(np.uint8).reshape(-1, 4).astype(int)
+    assert np.abs(got - want).max() <= 1
+    assert np.count_nonzero((got != want).any(axis=1)) <= 2e-3 * N
+    assert len(np.unique(want[:, 0])) > 50                       # real colours, not a constant image
+
+
+@pytest.mark.parametrize("min_observation_count", [1, 2, 3])
+def test_deletion_and_radius_update_against_the_reference_kernels(min_observation_count):
+    """DeleteSurfelsAndUpdateRadiiCUDA: B/kernel_delete_surfels.cu (observation and free-space-violation counts per keyframe, the
+    minimum measured radius, then the deletion rule) in the order of B/kernel_delete_surfels.cc:38-98 against the oracle, on a
+    cloud where 5 % of the surfels were pushed up to 30 cm off the surface (in front of it: free-space violations; behind it:
+    lost observations).  The same surfels are deleted -- the oracle marks them with an explicit NaN test where the reference
+    relies on the always-invalid pixel (0, 0), SURVEY appendix B -- and every survivor gets the same radius, bit for bit."""
+    ba, N = _perturbed_oracle(13, True, True)
+    rng = np.random.Generator(np.random.PCG64(3))
+    far = rng.choice(N, N // 20, replace=False)
+    ba.surfel_data[2, far] += rng.uniform(-0.3, 0.3, far.size).astype(np.float32)
+    before = ba.surfel_data[:8, :N].copy()
+    ref = rb.ReferenceKernels(ba)
+    assert not ref.pairs_outside_int_range().any()
+    deleted_ref = ref.delete_surfels_and_update_radii(min_observation_count)
+    deleted = ba.delete_surfels_and_update_radii(min_observation_count)
+    got, want = ba.surfel_data[:8, :N], ref.surfel_data[:8, :N]
+    gone, gone_ref = np.isnan(got[0]), np.isnan(want[0])
+    assert deleted == deleted_ref == int(gone.sum()) and np.array_equal(gone, gone_ref)
+    assert 0.005 * N < deleted < 0.5 * N                          # the rule did fire, and not on everything
+    keep = ~gone
+    assert np.array_equal(got[4, keep].view(np.uint32), want[4, keep].view(np.uint32))            # squared radii of the survivors
+    assert np.count_nonzero(got[4, keep] != before[4, keep]) > 0.2 * keep.sum()                   # ... most of which did change
+    for row in (1, 2, 3, 5, 6, 7):                                                                  # nothing else is touched
+        assert np.array_equal(got[row].view(np.uint32), want[row].view(np.uint32))
