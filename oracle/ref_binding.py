@@ -164,3 +164,14 @@ class ReferenceKernels:
 
     def delete_surfels_and_update_radii(self, min_observation_count):
         return int(self.L.ref_delete_surfels_and_update_radii(C.byref(self.sc), int(min_observation_count)))
+
+    def determine_supporting_surfels(self, keyframe_index, merge=False, merge_dist_factor=None):
+        """The three supporting-surfel planes of keyframe `keyframe_index`, restricted to the sparse-cell grid (like
+        OracleBA.determine_supporting_surfels), and the number of surfels a merging call marked as deleted."""
+        W, H = self.sc.width, self.sc.height
+        planes = np.zeros((3, H, W), np.uint32)
+        self.L.ref_determine_supporting_surfels.restype = C.c_uint32
+        factor = self.orc.merge_factor if merge_dist_factor is None else merge_dist_factor
+        deleted = self.L.ref_determine_supporting_surfels(C.byref(self.sc), int(keyframe_index), int(merge), C.c_float(factor),
+                                                          planes.ctypes.data_as(C.c_void_p))
+        return planes[:, :self.orc.cf_h, :self.orc.cf_w].copy(), int(deleted)

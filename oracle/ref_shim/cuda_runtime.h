@@ -92,6 +92,10 @@ inline int __syncthreads_or(int predicate) { return predicate; }
 // what the whole kernels of ref_kernels.cc need on top of the device-math headers (one "thread" at a time, several OpenMP threads)
 #define __shared__ static thread_local
 inline unsigned int atomicAdd(unsigned int* address, unsigned int value) { return __atomic_fetch_add(address, value, __ATOMIC_RELAXED); }
+inline unsigned int atomicCAS(unsigned int* address, unsigned int compare, unsigned int value) {   // returns the old word
+  __atomic_compare_exchange_n(address, &compare, value, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return compare;
+}
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, sizeof(i)); return i; }
 struct __half { unsigned short bits; };
 inline __half __ushort_as_half(unsigned short bits) { __half h = {bits}; return h; }

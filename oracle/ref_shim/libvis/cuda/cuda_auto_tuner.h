@@ -12,6 +12,18 @@
 
 struct RefDim3 { unsigned int x, y, z; };
 extern thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
+// true: blocks run one after the other, in ascending order, on the calling thread -- for kernels whose result depends on which
+// thread wins an atomic (B/kernel_supporting_surfels.cu): the lowest surfel index then wins, which is the rule the oracle and
+// the HIP kernels define ("FIX: lowest-index winner")
+extern bool ref_launch_sequential;
+
+// selects the instantiation of a bool-templated kernel at run time (the reference's L/cuda/cuda_util.h:53-64 has the same helper;
+// that header cannot be included here: it pulls in the logging library)
+#define COMPILE_OPTION(option, ...)                                                                      \
+  do {                                                                                                   \
+    if (option) { constexpr bool _##option = true; (void)_##option; __VA_ARGS__; }                     \
+    else { constexpr bool _##option = false; (void)_##option; __VA_ARGS__; }                           \
+  } while (false)
 
 #define CHECK_CUDA_NO_ERROR() do {} while (false)   // B/cuda_util.cuh:40-45: CUDA_CHECK() expands to this
 
@@ -20,7 +32,7 @@ extern thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
     const long long ref_domain = (long long)(domain_width);                                                                             \
     const unsigned int ref_width = (unsigned int)(default_block_width);                                                                 \
     const long long ref_blocks = (ref_domain + ref_width - 1) / ref_width;                                                              \
-    _Pragma("omp parallel for schedule(dynamic, 4)")                                                                                    \
+    _Pragma("omp parallel for if(!ref_launch_sequential) schedule(dynamic, 4)")                                                                                    \
     for (long long ref_block = 0; ref_block < ref_blocks; ++ref_block) {                                                                \
       blockDim = RefDim3{ref_width, 1, 1};                                                                                              \
       gridDim = RefDim3{(unsigned int)ref_blocks, 1, 1};                                                                                \
@@ -41,7 +53,7 @@ extern thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
     const long long ref_domain = (long long)(domain_width);                                                                             \
     const unsigned int ref_width = (unsigned int)(default_block_width);                                                                 \
     const long long ref_blocks = (ref_domain + ref_width - 1) / ref_width;                                                              \
-    _Pragma("omp parallel for schedule(dynamic, 4)")                                                                                    \
+    _Pragma("omp parallel for if(!ref_launch_sequential) schedule(dynamic, 4)")                                                                                    \
     for (long long ref_block = 0; ref_block < ref_blocks; ++ref_block) {                                                                \
       blockDim = RefDim3{ref_width, 1, 1};                                                                                              \
       gridDim = RefDim3{(unsigned int)ref_blocks, 1, 1};                                                                                \

@@ -8,11 +8,13 @@
 //   B/kernel_assign_colors.cu       ResetSurfelForColorAssignment, AccumulateColorObservations, AssignColors
 //   B/kernel_delete_surfels.cu      ResetSurfelAccumForSurfelDeletionAndRadiusUpdate, CountObservationsAndFreeSpaceViolations,
 //                                   MarkDeletedSurfels
+//   B/kernel_supporting_surfels.cu  DetermineSupportingSurfels<merge_surfels>
 // (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
 // stand-in CUDA_AUTO_TUNE_1D of ref_shim/libvis/cuda/cuda_auto_tuner.h.  What this file adds is the sequence of calls the
 // reference's host drivers make -- B/kernel_opt_geometry.cc:80-201 (OptimizeGeometryIterationCUDA),
 // B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA), B/kernel_assign_colors.cc:38-74 (AssignColorsCUDA) and
-// B/kernel_delete_surfels.cc:38-98 (DeleteSurfelsAndUpdateRadiiCUDAImpl) -- over plain arrays instead of Keyframe objects, with
+// B/kernel_delete_surfels.cc:38-98 (DeleteSurfelsAndUpdateRadiiCUDAImpl), B/kernel_supporting_surfels.cc:38-108
+// (DetermineSupportingSurfelsCUDAImpl) -- over plain arrays instead of Keyframe objects, with
 // the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
 // keyframe, one launch after the other; that order is kept.
 #include <cstring>
@@ -20,11 +22,13 @@
 #include <libvis/cuda/cuda_auto_tuner.h>
 
 thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
+bool ref_launch_sequential = false;
 
 #include "badslam/kernel_opt_geometry.cu"
 #include "badslam/kernel_surfel_activation.cu"
 #include "badslam/kernel_assign_colors.cu"
 #include "badslam/kernel_delete_surfels.cu"
+#include "badslam/kernel_supporting_surfels.cu"
 
 using namespace vis;
 
@@ -203,6 +207,36 @@ uint32_t ref_delete_surfels_and_update_radii(const ref_ba_scene* sc, int min_obs
   u32 counter = 0;
   CUDABuffer_<u32> deleted_count_buffer(&counter, 1, 1, sizeof(u32));
   CallMarkDeletedSurfelsCUDAKernel(nullptr, min_observation_count, sc->surfels_size, b.surfels, &deleted_count_buffer, true);
+  return deleted_marks() - before;
+}
+
+// B/kernel_supporting_surfels.cc:38-108 for keyframe `keyframe_index`: the three planes (width x height words each, the cell grid
+// in their top-left corner) are cleared to kInvalidIndex and filled; with merge_surfels, surfels that project into an occupied
+// cell and are close to its occupant in normal and position are marked deleted.  The winner of a cell is whoever gets there
+// first: the launch runs sequentially, in ascending surfel order (see ref_launch_sequential).  Returns the number of surfels the
+// call marked as deleted.
+uint32_t ref_determine_supporting_surfels(const ref_ba_scene* sc, int keyframe_index, int merge_surfels, float merge_dist_factor, uint32_t* planes) {
+  const Bound b(sc);
+  const size_t plane_words = (size_t)sc->width * sc->height;
+  for (size_t w = 0; w < kMergeBufferCount * plane_words; ++w) planes[w] = kInvalidIndex;
+  if (sc->surfels_size == 0) return 0;
+  SupportingSurfelBuffers buffers;
+  for (int i = 0; i < kMergeBufferCount; ++i) buffers.b[i] = CUDABuffer_<u32>(planes + i * plane_words, sc->height, sc->width, (size_t)sc->width * sizeof(u32));
+  auto deleted_marks = [&]() {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < sc->surfels_size; ++i) n += __float_as_int(b.surfels(kSurfelX, i)) == 0x7fffffff ? 1u : 0u;
+    return n;
+  };
+  const uint32_t before = deleted_marks();
+  u32 counter = 0;
+  const float cell = (float)sc->cell;
+  ref_launch_sequential = true;
+  if (merge_surfels)
+    CallDetermineSupportingSurfelsCUDAKernel(nullptr, true, cell * cell * merge_dist_factor * merge_dist_factor, cos_normal_compatibility_threshold,
+                                             projection_of(sc, b, sc->keyframes[keyframe_index]), buffers, CUDABuffer_<u32>(&counter, 1, 1, sizeof(u32)));
+  else
+    CallDetermineSupportingSurfelsCUDAKernel(nullptr, false, 0, 0, projection_of(sc, b, sc->keyframes[keyframe_index]), buffers, CUDABuffer_<u32>());
+  ref_launch_sequential = false;
   return deleted_marks() - before;
 }
 

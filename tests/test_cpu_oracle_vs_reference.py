@@ -334,3 +334,39 @@ def test_deletion_and_radius_update_against_the_reference_kernels(min_observatio
     assert np.count_nonzero(got[4, keep] != before[4, keep]) > 0.2 * keep.sum()                   # ... most of which did change
     for row in (1, 2, 3, 5, 6, 7):                                                                  # nothing else is touched
         assert np.array_equal(got[row].view(np.uint32), want[row].view(np.uint32))
+
+
+@pytest.mark.parametrize("merge", [False, True])
+def test_supporting_surfels_and_merging_against_the_reference_kernel(merge):
+    """DetermineSupportingSurfelsCUDA / ...AndMergeSurfelsCUDA: B/kernel_supporting_surfels.cu as B/kernel_supporting_surfels.cc:38-108
+    launches it, against the oracle, for every keyframe of a six-keyframe scene (~48 000 surfels, three planes of ~18 600 cells).
+    The reference lets whichever thread comes first win a cell (atomicCAS); run sequentially in ascending surfel order that is the
+    lowest surfel index -- the rule oracle and HIP kernels define.  Then the planes agree word for word and the
+    same surfels are merged away, up to the rare pair whose association differs in the last bit (one surfel in ~50 000 pairs moves
+    at most its own three entries)."""
+    scene = common.small_scene(num_keyframes=6, seed=11)
+    ba = common.build_oracle(scene, 400000)
+    N = ba.surfels_size
+    total_filled = total_mismatch = total_deleted = total_set_mismatch = 0
+    for k in range(len(ba.keyframes)):
+        ref = rb.ReferenceKernels(ba)
+        planes_ref, deleted_ref = ref.determine_supporting_surfels(k, merge)
+        saved, count = ba.surfel_data.copy(), int(ba.surfels.surfel_count)
+        planes = ba.determine_supporting_surfels(k, merge)
+        deleted = count - int(ba.surfels.surfel_count)
+        gone, gone_ref = np.isnan(ba.surfel_data[0, :N]), np.isnan(ref.surfel_data[0, :N])
+        ba.surfel_data[:] = saved
+        ba.surfels.surfel_count = count
+        assert planes.shape == planes_ref.shape
+        total_filled += int((planes_ref != 0xffffffff).sum())
+        total_mismatch += int(np.count_nonzero(planes != planes_ref))
+        total_deleted += deleted_ref
+        total_set_mismatch += int(np.count_nonzero(gone != gone_ref))
+        assert abs(deleted - deleted_ref) <= 2 and (merge or deleted_ref == 0)
+        # first come, first served: the occupant of plane 0 is the lowest index among a cell's occupants
+        both = (planes_ref[0] != 0xffffffff) & (planes_ref[1] != 0xffffffff)
+        assert (planes_ref[0][both] < planes_ref[1][both]).all()
+    print(f"merge {merge}: {total_filled} entries, {total_mismatch} differ; {total_deleted} surfels merged away, {total_set_mismatch} differ")
+    assert total_filled > 150000 and total_mismatch <= 1e-3 * total_filled
+    if merge:
+        assert total_deleted > 20000 and total_set_mismatch <= 1e-3 * total_deleted
