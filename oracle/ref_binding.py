@@ -98,7 +98,8 @@ def evaluate_cost(orc, keyframe_indices=None, quantize_texture_weights=False):
 # ---- whole kernels of the reference (oracle/ref_shim/ref_kernels.cc) ---------------------------------------------------------
 class RefBaKeyframe(C.Structure):
     _fields_ = [("depth", C.POINTER(C.c_uint16)), ("normals", C.POINTER(C.c_uint16)), ("rgba", C.POINTER(C.c_uint8)),
-                ("radius", C.POINTER(C.c_uint16)), ("frame_T_global", C.c_float * 12), ("global_R_frame", C.c_float * 9), ("activation", C.c_int32), ("pad", C.c_int32)]
+                ("radius", C.POINTER(C.c_uint16)), ("frame_T_global", C.c_float * 12), ("global_T_frame", C.c_float * 12),
+                ("global_R_frame", C.c_float * 9), ("activation", C.c_int32), ("pad", C.c_int32)]
 
 
 class RefBaScene(C.Structure):
@@ -133,6 +134,7 @@ class ReferenceKernels:
             self.kfs[k].rgba = ob._ptr(arrs["color"], C.c_uint8)
             self.kfs[k].radius = ob._ptr(arrs["radius"], C.c_uint16)
             self.kfs[k].frame_T_global[:] = list(kf.frame_T_global)
+            ob.lib().orc_se3_matrix3x4(C.byref(kf.global_T_frame), self.kfs[k].global_T_frame)     # the oracle's own 3x4 of the pose
             self.kfs[k].global_R_frame[:] = list(kf.global_R_frame)
             self.kfs[k].activation = int(kf.activation)
         sc = RefBaScene()
@@ -175,3 +177,23 @@ class ReferenceKernels:
         deleted = self.L.ref_determine_supporting_surfels(C.byref(self.sc), int(keyframe_index), int(merge), C.c_float(factor),
                                                           planes.ctypes.data_as(C.c_void_p))
         return planes[:, :self.orc.cf_h, :self.orc.cf_w].copy(), int(deleted)
+
+    def create_surfels_for_keyframe(self, keyframe_index, filter_new_surfels=False, covis=None):
+        """DirectBA::CreateSurfelsForKeyframe by the reference's kernels; new surfels are appended to this object's surfel_data
+        behind surfels_size (which is advanced).  The relative poses of the co-visible keyframes are formed by the oracle's SE(3)
+        routines -- the host-side product of B/direct_ba.cc:359-365 -- so that both sides count observations from the same matrices."""
+        from oracle import binding as ob
+        orc, OL = self.orc, ob.lib()
+        if covis is None:
+            covis = [j for j in range(len(orc.keyframes)) if j != keyframe_index]
+        rel = (C.c_float * (12 * max(1, len(covis))))()
+        for c, j in enumerate(covis):
+            inv, prod = ob.SE3(), ob.SE3()
+            OL.orc_se3_inverse(C.byref(orc.keyframes[j].global_T_frame), C.byref(inv))
+            OL.orc_se3_mul(C.byref(inv), C.byref(orc.keyframes[keyframe_index].global_T_frame), C.byref(prod))
+            OL.orc_se3_matrix3x4(C.byref(prod), C.cast(C.byref(rel, 48 * c), C.POINTER(C.c_float)))
+        self.L.ref_create_surfels_for_keyframe.restype = C.c_uint32
+        created = int(self.L.ref_create_surfels_for_keyframe(C.byref(self.sc), int(keyframe_index), int(filter_new_surfels), int(orc.min_observation_count),
+                                                            len(covis), (C.c_int * max(1, len(covis)))(*covis), rel))
+        self.sc.surfels_size += created
+        return created

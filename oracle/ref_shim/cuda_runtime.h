@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #define __device__
@@ -88,6 +89,12 @@ template <> inline float4 tex2D<float4>(cudaTextureObject_t handle, float x, flo
 template <> inline float tex2D<float>(cudaTextureObject_t handle, float x, float y) { return tex2D<float4>(handle, x, y).w; }
 
 inline int __syncthreads_or(int predicate) { return predicate; }
+
+// host stand-ins for the three runtime calls of CreateSurfelsForKeyframeCUDA_CountNewSurfels (B/kernel_create_surfels.cu:432-475)
+enum cudaMemcpyKind { cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2 };
+inline int cudaMalloc(void** ptr, size_t bytes) { *ptr = std::malloc(bytes ? bytes : 1); return 0; }
+inline int cudaMemcpyAsync(void* dst, const void* src, size_t bytes, cudaMemcpyKind, cudaStream_t) { std::memcpy(dst, src, bytes); return 0; }
+inline int cudaStreamSynchronize(cudaStream_t) { return 0; }
 
 // what the whole kernels of ref_kernels.cc need on top of the device-math headers (one "thread" at a time, several OpenMP threads)
 #define __shared__ static thread_local

@@ -64,3 +64,23 @@ extern bool ref_launch_sequential;
       }                                                                                                                                  \
     }                                                                                                                                    \
   } while (false)
+
+// L/cuda/cuda_auto_tuner.h:288-294: a 2-D grid of default_block_width x default_block_height blocks over domain_width x
+// domain_height.  Within a block the threads run row by row (threadIdx.y outer, threadIdx.x inner): a sparse cell lies inside one
+// block, so under ref_launch_sequential its first pixel in row-major order is the one that wins the cell's atomicCAS.
+#define CUDA_AUTO_TUNE_2D(kernel_name, default_block_width, default_block_height, domain_width, domain_height, shared_memory_size, stream, ...) \
+  do {                                                                                                                                   \
+    const unsigned int ref_bw = (unsigned int)(default_block_width), ref_bh = (unsigned int)(default_block_height);                     \
+    const long long ref_bx = ((long long)(domain_width) + ref_bw - 1) / ref_bw, ref_by = ((long long)(domain_height) + ref_bh - 1) / ref_bh; \
+    _Pragma("omp parallel for if(!ref_launch_sequential) schedule(dynamic, 1)")                                                         \
+    for (long long ref_block = 0; ref_block < ref_bx * ref_by; ++ref_block) {                                                           \
+      blockDim = RefDim3{ref_bw, ref_bh, 1};                                                                                            \
+      gridDim = RefDim3{(unsigned int)ref_bx, (unsigned int)ref_by, 1};                                                                 \
+      blockIdx = RefDim3{(unsigned int)(ref_block % ref_bx), (unsigned int)(ref_block / ref_bx), 0};                                    \
+      for (unsigned int ref_ty = 0; ref_ty < ref_bh; ++ref_ty)                                                                          \
+        for (unsigned int ref_tx = 0; ref_tx < ref_bw; ++ref_tx) {                                                                      \
+          threadIdx = RefDim3{ref_tx, ref_ty, 0};                                                                                       \
+          kernel_name(__VA_ARGS__);                                                                                                     \
+        }                                                                                                                                \
+    }                                                                                                                                    \
+  } while (false)

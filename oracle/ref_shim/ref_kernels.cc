@@ -9,15 +9,19 @@
 //   B/kernel_delete_surfels.cu      ResetSurfelAccumForSurfelDeletionAndRadiusUpdate, CountObservationsAndFreeSpaceViolations,
 //                                   MarkDeletedSurfels
 //   B/kernel_supporting_surfels.cu  DetermineSupportingSurfels<merge_surfels>
+//   B/kernel_create_surfels.cu      CreateSurfelsForKeyframeCUDASerializing, ..._CountNewSurfels, WriteNewSurfelIndexAndInitializeObservations,
+//                                   CountObservationsForNewSurfels, FilterNewSurfels, CreateSurfelsForKeyframeCUDACreationAppend
 // (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
 // stand-in CUDA_AUTO_TUNE_1D of ref_shim/libvis/cuda/cuda_auto_tuner.h.  What this file adds is the sequence of calls the
 // reference's host drivers make -- B/kernel_opt_geometry.cc:80-201 (OptimizeGeometryIterationCUDA),
 // B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA), B/kernel_assign_colors.cc:38-74 (AssignColorsCUDA) and
 // B/kernel_delete_surfels.cc:38-98 (DeleteSurfelsAndUpdateRadiiCUDAImpl), B/kernel_supporting_surfels.cc:38-108
-// (DetermineSupportingSurfelsCUDAImpl) -- over plain arrays instead of Keyframe objects, with
+// (DetermineSupportingSurfelsCUDAImpl), B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-197 (CreateSurfelsForKeyframe) --
+// over plain arrays instead of Keyframe objects, with
 // the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
 // keyframe, one launch after the other; that order is kept.
 #include <cstring>
+#include <vector>
 
 #include <libvis/cuda/cuda_auto_tuner.h>
 
@@ -29,6 +33,7 @@ bool ref_launch_sequential = false;
 #include "badslam/kernel_assign_colors.cu"
 #include "badslam/kernel_delete_surfels.cu"
 #include "badslam/kernel_supporting_surfels.cu"
+#include "badslam/kernel_create_surfels.cu"
 
 using namespace vis;
 
@@ -38,6 +43,7 @@ struct ref_ba_keyframe {
   uint16_t* depth; uint16_t* normals; uint8_t* rgba;   // dense, row-major; rgba.w = luma
   uint16_t* radius;                                    // binary16 bits of the squared point radius (B/keyframe.h:227-231)
   float frame_T_global[12];
+  float global_T_frame[12];
   float global_R_frame[9];
   int32_t activation;                                  // 0 kActive, 1 kCovisibleActive, 2 kInactive (B/keyframe.h:54-67)
   int32_t pad;
@@ -238,6 +244,74 @@ uint32_t ref_determine_supporting_surfels(const ref_ba_scene* sc, int keyframe_i
     CallDetermineSupportingSurfelsCUDAKernel(nullptr, false, 0, 0, projection_of(sc, b, sc->keyframes[keyframe_index]), buffers, CUDABuffer_<u32>());
   ref_launch_sequential = false;
   return deleted_marks() - before;
+}
+
+// DirectBA::CreateSurfelsForKeyframe (B/direct_ba.cc:340-405 -> B/kernel_create_surfels.cc:40-197): supporting surfels of the
+// keyframe, one new surfel per free sparse cell with a valid depth (first pixel of the cell in row-major order: sequential
+// launches, see CUDA_AUTO_TUNE_2D), optionally filtered by the observations in the co-visible keyframes, appended behind
+// surfels_size in row-major pixel order.  covis_T_frame: n_covis 3x4 matrices = covis.frame_T_global * keyframe.global_T_frame
+// (computed by the caller, as B/direct_ba.cc:359-365 does outside the .cu file).  Returns the number of surfels created; the
+// caller's surfels_size is NOT advanced here.
+uint32_t ref_create_surfels_for_keyframe(const ref_ba_scene* sc, int keyframe_index, int filter_new_surfels, int min_observation_count, int n_covis,
+                                         const int* covis_indices, const float* covis_T_frame) {
+  const Bound b(sc);
+  const ref_ba_keyframe& kf = sc->keyframes[keyframe_index];
+  const size_t pixels = (size_t)sc->width * sc->height;
+  std::vector<uint32_t> planes(kMergeBufferCount * pixels);
+  {  // DetermineSupportingSurfelsCUDA (B/direct_ba.cc:349-358); a surfel already marked deleted cannot be one (its x is NaN)
+    ref_ba_scene copy = *sc;
+    ref_determine_supporting_surfels(&copy, keyframe_index, 0, 0.f, planes.data());
+  }
+  CUDABuffer_<u16> depth_buffer(kf.depth, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+  CUDABuffer_<u16> normals_buffer(kf.normals, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+  CUDABuffer_<u16> radius_buffer(kf.radius, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+  CUDABuffer_<uchar4> color_buffer(reinterpret_cast<uchar4*>(kf.rgba), sc->color_height, sc->color_width, (size_t)sc->color_width * sizeof(uchar4));
+  CUDABuffer_<u32> supporting0(planes.data(), sc->height, sc->width, (size_t)sc->width * sizeof(u32));
+  std::vector<u8> flags(pixels);
+  std::vector<u32> indices(pixels);
+  CUDABuffer_<u8> flag_vector(flags.data(), 1, (int)pixels, pixels);
+  CUDABuffer_<u32> index_vector(indices.data(), 1, (int)pixels, pixels * sizeof(u32));
+  void* scan_storage = nullptr;
+  usize scan_bytes = 0;
+
+  ref_launch_sequential = true;
+  CallCreateSurfelsForKeyframeCUDASerializingKernel(nullptr, sc->cell, depth_buffer, color_buffer, supporting0, flag_vector);
+  ref_launch_sequential = false;
+  u32 new_surfel_count = CreateSurfelsForKeyframeCUDA_CountNewSurfels(nullptr, (u32)pixels, &scan_storage, &scan_bytes, &flag_vector, &index_vector);
+  if (new_surfel_count != 0 && filter_new_surfels) {
+    // scratch in the accumulator rows, as the reference lays it out (B/kernel_create_surfels.cc:106-108)
+    u8* base = reinterpret_cast<u8*>(b.surfels.address());
+    u16* observation_vector = reinterpret_cast<u16*>(base + kSurfelAccum0 * b.surfels.pitch());
+    u16* free_space_violation_vector = reinterpret_cast<u16*>(base + kSurfelAccum1 * b.surfels.pitch());
+    u32* new_surfel_index_list = reinterpret_cast<u32*>(base + kSurfelAccum2 * b.surfels.pitch());
+    CallWriteNewSurfelIndexAndInitializeObservationsCUDAKernel(nullptr, (u32)pixels, flag_vector, index_vector, observation_vector, free_space_violation_vector,
+                                                               new_surfel_index_list);
+    for (int c = 0; c < n_covis; ++c) {
+      const ref_ba_keyframe& other = sc->keyframes[covis_indices[c]];
+      CUDAMatrix3x4 M;
+      M.row0 = make_float4(covis_T_frame[12 * c + 0], covis_T_frame[12 * c + 1], covis_T_frame[12 * c + 2], covis_T_frame[12 * c + 3]);
+      M.row1 = make_float4(covis_T_frame[12 * c + 4], covis_T_frame[12 * c + 5], covis_T_frame[12 * c + 6], covis_T_frame[12 * c + 7]);
+      M.row2 = make_float4(covis_T_frame[12 * c + 8], covis_T_frame[12 * c + 9], covis_T_frame[12 * c + 10], covis_T_frame[12 * c + 11]);
+      CallCountObservationsForNewSurfelsCUDAKernel(nullptr, (int)new_surfel_count, new_surfel_index_list, observation_vector, free_space_violation_vector, b.dp,
+                                                   b.unprojector, depth_buffer, normals_buffer, M, b.depth_projector,
+                                                   CUDABuffer_<u16>(other.depth, sc->height, sc->width, (size_t)sc->width * sizeof(u16)),
+                                                   CUDABuffer_<u16>(other.normals, sc->height, sc->width, (size_t)sc->width * sizeof(u16)));
+    }
+    CallFilterNewSurfelsCUDAKernel(nullptr, (u16)min_observation_count, new_surfel_count, new_surfel_index_list, observation_vector,
+                                   free_space_violation_vector, flag_vector);
+    new_surfel_count = CreateSurfelsForKeyframeCUDA_CountNewSurfels(nullptr, (u32)pixels, &scan_storage, &scan_bytes, &flag_vector, &index_vector);
+  }
+  std::free(scan_storage);
+  if (new_surfel_count == 0 || sc->surfels_size + new_surfel_count > sc->capacity) return 0;
+  CUDAMatrix3x4 G;
+  G.row0 = make_float4(kf.global_T_frame[0], kf.global_T_frame[1], kf.global_T_frame[2], kf.global_T_frame[3]);
+  G.row1 = make_float4(kf.global_T_frame[4], kf.global_T_frame[5], kf.global_T_frame[6], kf.global_T_frame[7]);
+  G.row2 = make_float4(kf.global_T_frame[8], kf.global_T_frame[9], kf.global_T_frame[10], kf.global_T_frame[11]);
+  RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+  CallCreateSurfelsForKeyframeCUDACreationAppendKernel(nullptr, b.unprojector, b.d2c, b.color_projector, G, pose_of(kf), b.dp, depth_buffer, normals_buffer,
+                                                       radius_buffer, reinterpret_cast<cudaTextureObject_t>(&tex), flag_vector, index_vector, sc->surfels_size,
+                                                       b.surfels);
+  return new_surfel_count;
 }
 
 }  // extern "C"

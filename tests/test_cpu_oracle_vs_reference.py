@@ -370,3 +370,38 @@ def test_supporting_surfels_and_merging_against_the_reference_kernel(merge):
     assert total_filled > 150000 and total_mismatch <= 1e-3 * total_filled
     if merge:
         assert total_deleted > 20000 and total_set_mismatch <= 1e-3 * total_deleted
+
+
+@pytest.mark.parametrize("filter_new_surfels", [False, True])
+def test_surfel_creation_against_the_reference_kernels(filter_new_surfels):
+    """DirectBA::CreateSurfelsForKeyframe: the reference's kernels (B/kernel_supporting_surfels.cu, B/kernel_create_surfels.cu incl. its
+    CountNewSurfels routine on a stand-in cub::DeviceScan) in the order of B/direct_ba.cc:340-405 and B/kernel_create_surfels.cc:40-197,
+    against the oracle, keyframe after keyframe from an empty cloud: which cells get a surfel (the first free pixel of a sparse cell
+    in row-major order on both sides -- sequential launches make the reference's atomicCAS pick it), and with the filter which of
+    them the co-visible keyframes confirm (min_observation_count 2, free-space violations).  The same number of surfels is created
+    every time; paired by position (the oracle appends in tile-major, the reference in row-major order) they have the same packed
+    normal, radius and colour words, positions within 1e-6 m and initial descriptors within 2e-3."""
+    from scipy.spatial import cKDTree
+    scene = common.small_scene(num_keyframes=5, seed=17)
+    ba = common.build_oracle(scene, 400000, create_from=[], min_observation_count=2)
+    ref = rb.ReferenceKernels(ba)
+    created_total = []
+    for k in range(5):
+        first = ba.surfels_size
+        created = ba.create_surfels_for_keyframe(k, filter_new_surfels=filter_new_surfels)
+        created_ref = ref.create_surfels_for_keyframe(k, filter_new_surfels=filter_new_surfels)
+        assert created == created_ref > 0
+        created_total.append(created)
+        got, want = ba.surfel_data[:8, first:first + created], ref.surfel_data[:8, first:first + created]
+        distance, partner = cKDTree(want[:3].T.astype(np.float64)).query(got[:3].T.astype(np.float64))
+        assert len(np.unique(partner)) == created and distance.max() < 1e-6
+        want = want[:, partner]
+        for row in (3, 4, 5):                                                     # packed normal, squared radius, colour
+            assert np.array_equal(got[row].view(np.uint32), want[row].view(np.uint32)), row
+        ddesc = np.abs(got[6:8] - want[6:8])
+        assert np.median(ddesc) < 5e-4 and ddesc.max() < 2e-3
+        assert np.abs(got[6:8]).max() > 1.0                                       # real descriptors
+        # the next keyframe sees the same cloud on both sides (the oracle's order)
+        ref.surfel_data[:, :ba.surfels_size] = ba.surfel_data[:, :ba.surfels_size]
+    if filter_new_surfels:
+        assert created_total[1] < 0.6 * 6559                                      # the filter did remove surfels (6559 unfiltered)
