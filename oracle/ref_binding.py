@@ -197,3 +197,13 @@ class ReferenceKernels:
                                                             len(covis), (C.c_int * max(1, len(covis)))(*covis), rel))
         self.sc.surfels_size += created
         return created
+
+    def accumulate_pose_coeffs(self, keyframe_index, frame_T_global=None, use_depth=True, use_desc=True):
+        """H (21, row-major upper triangle) and b (6) of the pose normal equations by the reference's kernel
+        (B/kernel_opt_pose.cu + B/gauss_newton.cuh) over this object's surfels, at the keyframe's own pose or at `frame_T_global`
+        (12 floats).  None if a surfel projects beyond the int range there."""
+        F = (C.c_float * 12)(*(list(self.kfs[keyframe_index].frame_T_global) if frame_T_global is None else [float(v) for v in frame_T_global]))
+        H, b = (C.c_float * 21)(), (C.c_float * 6)()
+        self.L.ref_accumulate_pose_estimation_coeffs.restype = C.c_int
+        rc = self.L.ref_accumulate_pose_estimation_coeffs(C.byref(self.sc), int(keyframe_index), F, int(use_depth), int(use_desc), H, b)
+        return None if rc != 0 else (np.array(list(H), np.float32), np.array(list(b), np.float32))

@@ -12,7 +12,8 @@
 //     "Linear Filtering"): xB = x - 0.5, i = floor(xB), alpha = frac(xB) kept in 9-bit fixed point with 8 fractional bits;
 //     result = (1-a)(1-b) T[i,j] + a (1-b) T[i+1,j] + (1-a) b T[i,j+1] + a b T[i+1,j+1].  `quantize_weights` selects the
 //     hardware's 8-bit weights (round to nearest) or exact binary32 weights (what oracle and kernels use);
-//   * __syncthreads_or(x) == x for the single "thread" that runs here.
+//   * __syncthreads_or(x) == x for the single "thread" that runs in ref_entry.cc; under REF_BLOCK_COLLECTIVES (ref_kernels.cc) the
+//     block vote of the stand-in launcher.
 #pragma once
 
 #include <algorithm>
@@ -88,7 +89,13 @@ template <> inline float4 tex2D<float4>(cudaTextureObject_t handle, float x, flo
 // single-channel float textures (the *WithFloatTexture variants of the headers; not exercised here, but they must compile)
 template <> inline float tex2D<float>(cudaTextureObject_t handle, float x, float y) { return tex2D<float4>(handle, x, y).w; }
 
+#ifdef REF_BLOCK_COLLECTIVES   // ref_kernels.cc: whole kernels under the stand-in launcher (libvis/cuda/cuda_auto_tuner.h)
+int ref_syncthreads_or(int predicate);
+inline int __syncthreads_or(int predicate) { return ref_syncthreads_or(predicate); }
+inline void __syncthreads() {}
+#else                          // ref_entry.cc: single functions, one "thread"
 inline int __syncthreads_or(int predicate) { return predicate; }
+#endif
 
 // host stand-ins for the three runtime calls of CreateSurfelsForKeyframeCUDA_CountNewSurfels (B/kernel_create_surfels.cu:432-475)
 enum cudaMemcpyKind { cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2 };
@@ -99,6 +106,17 @@ inline int cudaStreamSynchronize(cudaStream_t) { return 0; }
 // what the whole kernels of ref_kernels.cc need on top of the device-math headers (one "thread" at a time, several OpenMP threads)
 #define __shared__ static thread_local
 inline unsigned int atomicAdd(unsigned int* address, unsigned int value) { return __atomic_fetch_add(address, value, __ATOMIC_RELAXED); }
+inline float atomicAdd(float* address, float value) {   // binary32 add, atomically (blocks run on several OpenMP threads)
+  unsigned int* word = reinterpret_cast<unsigned int*>(address);
+  unsigned int seen = __atomic_load_n(word, __ATOMIC_RELAXED), wanted;
+  float before;
+  do {
+    std::memcpy(&before, &seen, sizeof(before));
+    const float after = before + value;
+    std::memcpy(&wanted, &after, sizeof(wanted));
+  } while (!__atomic_compare_exchange_n(word, &seen, wanted, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return before;
+}
 inline unsigned int atomicCAS(unsigned int* address, unsigned int compare, unsigned int value) {   // returns the old word
   __atomic_compare_exchange_n(address, &compare, value, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
   return compare;

@@ -9,6 +9,7 @@
 //   B/kernel_delete_surfels.cu      ResetSurfelAccumForSurfelDeletionAndRadiusUpdate, CountObservationsAndFreeSpaceViolations,
 //                                   MarkDeletedSurfels
 //   B/kernel_supporting_surfels.cu  DetermineSupportingSurfels<merge_surfels>
+//   B/kernel_opt_pose.cu            AccumulatePoseEstimationCoeffs<block_width, debug, use_depth, use_descriptors> with B/gauss_newton.cuh
 //   B/kernel_create_surfels.cu      CreateSurfelsForKeyframeCUDASerializing, ..._CountNewSurfels, WriteNewSurfelIndexAndInitializeObservations,
 //                                   CountObservationsForNewSurfels, FilterNewSurfels, CreateSurfelsForKeyframeCUDACreationAppend
 // (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
@@ -16,17 +17,29 @@
 // reference's host drivers make -- B/kernel_opt_geometry.cc:80-201 (OptimizeGeometryIterationCUDA),
 // B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA), B/kernel_assign_colors.cc:38-74 (AssignColorsCUDA) and
 // B/kernel_delete_surfels.cc:38-98 (DeleteSurfelsAndUpdateRadiiCUDAImpl), B/kernel_supporting_surfels.cc:38-108
-// (DetermineSupportingSurfelsCUDAImpl), B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-197 (CreateSurfelsForKeyframe) --
+// (DetermineSupportingSurfelsCUDAImpl), B/kernel_opt_pose.cc:38-96 (AccumulatePoseEstimationCoeffsCUDA), B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-197 (CreateSurfelsForKeyframe) --
 // over plain arrays instead of Keyframe objects, with
 // the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
 // keyframe, one launch after the other; that order is kept.
+#define REF_BLOCK_COLLECTIVES 1
 #include <cstring>
 #include <vector>
 
 #include <libvis/cuda/cuda_auto_tuner.h>
 
 thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
+thread_local RefBlockState ref_block;
 bool ref_launch_sequential = false;
+bool ref_thread0_last = false;
+// the block vote of the stand-in launcher (cuda_auto_tuner.h): a resolved vote is replayed, the first unresolved one takes the
+// thread's predicate and ends the thread's pass
+int ref_syncthreads_or(int predicate) {
+  RefBlockState& state = ref_block;
+  if (state.vote_call < (int)state.votes.size()) return state.votes[state.vote_call++];
+  state.pending_or |= predicate != 0 ? 1 : 0;
+  state.pending = true;
+  throw RefVotePending();
+}
 
 #include "badslam/kernel_opt_geometry.cu"
 #include "badslam/kernel_surfel_activation.cu"
@@ -34,6 +47,7 @@ bool ref_launch_sequential = false;
 #include "badslam/kernel_delete_surfels.cu"
 #include "badslam/kernel_supporting_surfels.cu"
 #include "badslam/kernel_create_surfels.cu"
+#include "badslam/kernel_opt_pose.cu"
 
 using namespace vis;
 
@@ -312,6 +326,41 @@ uint32_t ref_create_surfels_for_keyframe(const ref_ba_scene* sc, int keyframe_in
                                                        radius_buffer, reinterpret_cast<cudaTextureObject_t>(&tex), flag_vector, index_vector, sc->surfels_size,
                                                        b.surfels);
   return new_surfel_count;
+}
+
+// AccumulatePoseEstimationCoeffsCUDA (B/kernel_opt_pose.cc:38-96): H (21 entries, row-major upper triangle) and b (6) of the pose
+// normal equations of keyframe `keyframe_index`'s images at the pose estimate `frame_T_global` (3x4), over all surfels, by the
+// reference's kernel: per-thread Jacobians, 27 block reductions per residual (B/gauss_newton.cuh:46-93; here the block total is a
+// binary64 sum of the binary32 terms, cub/cub.cuh), one binary32 atomicAdd per block and entry.  Returns -1 without computing
+// if a surfel projects beyond the int range at this pose (see ref_flag_pairs_outside_int_range), else 0.
+int ref_accumulate_pose_estimation_coeffs(const ref_ba_scene* sc, int keyframe_index, const float* frame_T_global, int use_depth_residuals,
+                                          int use_descriptor_residuals, float* H, float* b) {
+  const Bound bound(sc);
+  ref_ba_keyframe kf = sc->keyframes[keyframe_index];
+  memcpy(kf.frame_T_global, frame_T_global, sizeof(kf.frame_T_global));
+  {
+    const CUDAMatrix3x4 F = pose_of(kf);
+    for (uint32_t i = 0; i < sc->surfels_size; ++i) {
+      float3 local_position;
+      if (!F.MultiplyIfResultZIsPositive(SurfelGetPosition(bound.surfels, i), &local_position)) continue;
+      const float2 p = bound.depth_projector.Project(local_position);
+      if (!(p.x < 2147483648.f && p.y < 2147483648.f)) return -1;
+    }
+  }
+  u32 residual_count = 0;
+  float residual_sum = 0;
+  for (int c = 0; c < 21; ++c) H[c] = 0;
+  for (int c = 0; c < 6; ++c) b[c] = 0;
+  const PixelCenterProjector color_center_projector(sc->color_cam[0], sc->color_cam[1], sc->color_cam[2] - 0.5f, sc->color_cam[3] - 0.5f);   // B/surfel_projection.h:50-56
+  RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+  ref_thread0_last = true;   // thread 0 of a block adds the block totals (B/gauss_newton.cuh:71,89)
+  CallAccumulatePoseEstimationCoeffsCUDAKernel(nullptr, /*debug*/ false, use_depth_residuals != 0, use_descriptor_residuals != 0, projection_of(sc, bound, kf),
+                                               bound.d2c, color_center_projector, bound.color_projector, bound.unprojector,
+                                               reinterpret_cast<cudaTextureObject_t>(&tex), CUDABuffer_<u32>(&residual_count, 1, 1, sizeof(u32)),
+                                               CUDABuffer_<float>(&residual_sum, 1, 1, sizeof(float)), CUDABuffer_<float>(H, 1, 21, 21 * sizeof(float)),
+                                               CUDABuffer_<float>(b, 1, 6, 6 * sizeof(float)));
+  ref_thread0_last = false;
+  return 0;
 }
 
 }  // extern "C"

@@ -405,3 +405,45 @@ def test_surfel_creation_against_the_reference_kernels(filter_new_surfels):
         ref.surfel_data[:, :ba.surfels_size] = ba.surfel_data[:, :ba.surfels_size]
     if filter_new_surfels:
         assert created_total[1] < 0.6 * 6559                                      # the filter did remove surfels (6559 unfiltered)
+
+
+def _full(H21):
+    H = np.zeros((6, 6))
+    H[np.triu_indices(6)] = H21
+    return H + np.triu(H, 1).T
+
+
+@pytest.mark.parametrize("use_depth,use_desc", [(True, True), (True, False), (False, True)])
+def test_pose_normal_equations_against_the_reference_kernel(use_depth, use_desc):
+    """AccumulatePoseEstimationCoeffsCUDA: the reference's kernel (B/kernel_opt_pose.cu:251-383 with the block reductions of
+    B/gauss_newton.cuh:46-93, launched as B/kernel_opt_pose.cc:38-96 does) on the host -- the stand-in launcher resolves the two
+    block votes of AnySurfelProjectsToAssociatedPixel and hands thread 0 the block totals (oracle/ref_shim) -- against the oracle's
+    pose normal equations at perturbed pose estimates (5 mm / 1 mrad), ~45 000 surfels.  The reference adds its block totals with
+    binary32 atomics in whatever order they arrive, so it differs from ITSELF between two runs by ~1e-7 of the largest entry; the
+    oracle (binary64 sum of its own per-pair terms) agrees with it to ~5e-6 -- single pairs whose association or robust weight
+    differs in the last bit weigh more than the summation noise -- and the Gauss-Newton steps the two systems give agree to
+    1e-5 ... 1e-4 of the step's length (1e-7 m on a 9 mm step; BASELINE's pose tolerance is 1e-5 m)."""
+    scene = common.small_scene(num_keyframes=5, seed=21)
+    ba = common.build_oracle(scene, 400000, use_depth=use_depth, use_desc=use_desc)
+    N = ba.surfels_size
+    rng = np.random.Generator(np.random.PCG64(4))
+    ba.surfel_data[2, :N] += rng.uniform(0, 0.004, N).astype(np.float32)
+    ref = rb.ReferenceKernels(ba)
+    for k in (0, 3):
+        T = synthetic.perturb_pose(rng, scene.poses_gt[k])
+        pose, inverse, M = ob.SE3.from_array(T), ob.SE3(), (C.c_float * 12)()
+        ob.lib().orc_se3_inverse(C.byref(pose), C.byref(inverse))
+        ob.lib().orc_se3_matrix3x4(C.byref(inverse), M)
+        F = list(M)
+        H, b, residuals, _ = ba.accumulate_pose_coeffs(k, F, accumulate_double=True)
+        first, second = ref.accumulate_pose_coeffs(k, F, use_depth, use_desc), ref.accumulate_pose_coeffs(k, F, use_depth, use_desc)
+        assert first is not None and residuals > 20000
+        scale_H, scale_b = np.abs(H).max(), np.abs(b).max()
+        own_spread = max(np.abs(first[0] - second[0]).max() / scale_H, np.abs(first[1] - second[1]).max() / scale_b)
+        dH, db = np.abs(first[0] - H).max() / scale_H, np.abs(first[1] - b).max() / scale_b
+        x, x_ref = np.linalg.solve(_full(H), b), np.linalg.solve(_full(first[0].astype(np.float64)), first[1].astype(np.float64))
+        dx = np.linalg.norm(x - x_ref) / np.linalg.norm(x)
+        print(f"depth {use_depth} desc {use_desc} keyframe {k}: {residuals} residuals; reference vs itself {own_spread:.1e}; oracle vs reference: "
+              f"H {dH:.1e}, b {db:.1e} of the largest entry, step {dx:.1e} of |x| = {np.linalg.norm(x):.2e}")
+        assert dH < 2e-5 and db < 2e-5 and dx < 5e-4
+        assert np.linalg.norm(x) > 1e-3                               # a real step: the pose estimate was 5 mm / 1 mrad off
