@@ -207,3 +207,16 @@ class ReferenceKernels:
         self.L.ref_accumulate_pose_estimation_coeffs.restype = C.c_int
         rc = self.L.ref_accumulate_pose_estimation_coeffs(C.byref(self.sc), int(keyframe_index), F, int(use_depth), int(use_desc), H, b)
         return None if rc != 0 else (np.array(list(H), np.float32), np.array(list(b), np.float32))
+
+    def pcg_assemble(self, optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=False, optimize_color_intrinsics=False,
+                     gauge_keyframe=0):
+        """r and M of the PCG scheme by the reference's PCGInit kernel, once per keyframe (B/direct_ba_pcg.cc:276-365), in the layout
+        of OracleBA.pcg_assemble.  None if a surfel projects beyond the int range in some keyframe."""
+        orc = self.orc
+        cap = 6 * len(orc.keyframes) + 3 * orc.surfels_size + 5 + orc.cf_w * orc.cf_h + 4
+        r, M = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        self.L.ref_pcg_assemble.restype = C.c_uint32
+        U = int(self.L.ref_pcg_assemble(C.byref(self.sc), int(optimize_poses), int(optimize_geometry), int(orc.use_depth), int(orc.use_desc),
+                                        int(optimize_depth_intrinsics), int(optimize_color_intrinsics), int(gauge_keyframe),
+                                        r.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p), C.c_uint32(cap)))
+        return None if U == 0 else (r[:U], M[:U])

@@ -102,6 +102,7 @@ enum cudaMemcpyKind { cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2 };
 inline int cudaMalloc(void** ptr, size_t bytes) { *ptr = std::malloc(bytes ? bytes : 1); return 0; }
 inline int cudaMemcpyAsync(void* dst, const void* src, size_t bytes, cudaMemcpyKind, cudaStream_t) { std::memcpy(dst, src, bytes); return 0; }
 inline int cudaStreamSynchronize(cudaStream_t) { return 0; }
+inline int cudaMemsetAsync(void* dst, int value, size_t bytes, cudaStream_t) { std::memset(dst, value, bytes); return 0; }
 
 // what the whole kernels of ref_kernels.cc need on top of the device-math headers (one "thread" at a time, several OpenMP threads)
 #define __shared__ static thread_local
@@ -121,6 +122,12 @@ inline unsigned int atomicCAS(unsigned int* address, unsigned int compare, unsig
   __atomic_compare_exchange_n(address, &compare, value, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
   return compare;
 }
+inline unsigned long long atomicCAS(unsigned long long* address, unsigned long long compare, unsigned long long value) {
+  __atomic_compare_exchange_n(address, &compare, value, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return compare;
+}
+inline long long __double_as_longlong(double d) { long long i; std::memcpy(&i, &d, sizeof(i)); return i; }
+inline double __longlong_as_double(long long i) { double d; std::memcpy(&d, &i, sizeof(d)); return d; }
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, sizeof(i)); return i; }
 struct __half { unsigned short bits; };
 inline __half __ushort_as_half(unsigned short bits) { __half h = {bits}; return h; }

@@ -10,6 +10,7 @@
 //                                   MarkDeletedSurfels
 //   B/kernel_supporting_surfels.cu  DetermineSupportingSurfels<merge_surfels>
 //   B/kernel_opt_pose.cu            AccumulatePoseEstimationCoeffs<block_width, debug, use_depth, use_descriptors> with B/gauss_newton.cuh
+//   B/kernel_pcg.cu                 PCGInit (r = -J^T W F, M = diag(J^T W J): every unknown block of the PCG scheme)
 //   B/kernel_create_surfels.cu      CreateSurfelsForKeyframeCUDASerializing, ..._CountNewSurfels, WriteNewSurfelIndexAndInitializeObservations,
 //                                   CountObservationsForNewSurfels, FilterNewSurfels, CreateSurfelsForKeyframeCUDACreationAppend
 // (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
@@ -17,7 +18,8 @@
 // reference's host drivers make -- B/kernel_opt_geometry.cc:80-201 (OptimizeGeometryIterationCUDA),
 // B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA), B/kernel_assign_colors.cc:38-74 (AssignColorsCUDA) and
 // B/kernel_delete_surfels.cc:38-98 (DeleteSurfelsAndUpdateRadiiCUDAImpl), B/kernel_supporting_surfels.cc:38-108
-// (DetermineSupportingSurfelsCUDAImpl), B/kernel_opt_pose.cc:38-96 (AccumulatePoseEstimationCoeffsCUDA), B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-197 (CreateSurfelsForKeyframe) --
+// (DetermineSupportingSurfelsCUDAImpl), B/kernel_opt_pose.cc:38-96 (AccumulatePoseEstimationCoeffsCUDA), B/direct_ba_pcg.cc:276-365 (the
+// unknown layout and the PCGInitCUDA loop of BundleAdjustmentPCG), B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-197 (CreateSurfelsForKeyframe) --
 // over plain arrays instead of Keyframe objects, with
 // the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
 // keyframe, one launch after the other; that order is kept.
@@ -48,6 +50,7 @@ int ref_syncthreads_or(int predicate) {
 #include "badslam/kernel_supporting_surfels.cu"
 #include "badslam/kernel_create_surfels.cu"
 #include "badslam/kernel_opt_pose.cu"
+#include "badslam/kernel_pcg.cu"
 
 using namespace vis;
 
@@ -361,6 +364,49 @@ int ref_accumulate_pose_estimation_coeffs(const ref_ba_scene* sc, int keyframe_i
                                                CUDABuffer_<float>(b, 1, 6, 6 * sizeof(float)));
   ref_thread0_last = false;
   return 0;
+}
+
+// The system the PCG scheme solves, as the reference assembles it (B/direct_ba_pcg.cc:276-365: unknown layout, then PCGInitCUDA
+// once per keyframe): r = -J^T W F and M = diag(J^T W J) over the unknowns
+//   6 per keyframe except the gauge keyframe | 1 or 3 per surfel (offset along the normal, descriptors) | fx^-1 fy^-1 cx^-1 cy^-1 a
+//   + one cfactor per sparse cell | 4 colour intrinsics
+// in that order, each block only if it is optimised.  Dense entries are block sums added with binary32 atomics (arrival order),
+// surfel entries per-thread sums keyframe by keyframe.  Returns the number of unknowns (0 if r / M are too short or a surfel
+// projects beyond the int range in some keyframe).
+uint32_t ref_pcg_assemble(const ref_ba_scene* sc, int optimize_poses, int optimize_geometry, int use_depth_residuals, int use_descriptor_residuals,
+                          int optimize_depth_intrinsics, int optimize_color_intrinsics, int gauge_keyframe, float* r, float* M, uint32_t capacity) {
+  const Bound bound(sc);
+  {
+    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
+    ref_flag_pairs_outside_int_range(sc, flags.data());
+    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return 0;
+  }
+  constexpr u32 kInvalidUnknownIndex = 0xffffffffu;
+  const int K = sc->num_keyframes;
+  u32 current = 0;
+  if (optimize_poses) current += 6 * (K - 1);
+  u32 surfel_start = kInvalidUnknownIndex;
+  if (optimize_geometry) { surfel_start = current; current += (use_descriptor_residuals ? 3 : 1) * sc->surfels_size; }
+  u32 depth_intrinsics_start = kInvalidUnknownIndex;
+  if (optimize_depth_intrinsics) { depth_intrinsics_start = current; current += 4 + 1 + (u32)sc->cf_width * sc->cf_height; }
+  u32 color_intrinsics_start = kInvalidUnknownIndex;
+  if (optimize_color_intrinsics) { color_intrinsics_start = current; current += 4; }
+  const u32 unknown_count = current;
+  if (unknown_count > capacity) return 0;
+  memset(r, 0, sizeof(float) * unknown_count);
+  memset(M, 0, sizeof(float) * unknown_count);
+  CUDABuffer_<PCGScalar> pcg_r(r, 1, (int)unknown_count, sizeof(float) * unknown_count), pcg_M(M, 1, (int)unknown_count, sizeof(float) * unknown_count);
+  ref_thread0_last = true;   // thread 0 of a block adds the block totals (B/kernel_pcg.cu:78-93)
+  for (int k = 0; k < K; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    const u32 pose_index = k == gauge_keyframe ? kInvalidUnknownIndex : (u32)(6 * (k < gauge_keyframe ? k : k - 1));   // :329-337
+    RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+    PCGInitCUDA(nullptr, projection_of(sc, bound, kf), bound.d2c, bound.unprojector, bound.color_projector, reinterpret_cast<cudaTextureObject_t>(&tex), pose_index,
+                surfel_start, k == gauge_keyframe ? false : optimize_poses != 0, optimize_geometry != 0, use_depth_residuals != 0, use_descriptor_residuals != 0,
+                optimize_depth_intrinsics != 0, optimize_color_intrinsics != 0, depth_intrinsics_start, color_intrinsics_start, &pcg_r, &pcg_M, sc->surfels_size);
+  }
+  ref_thread0_last = false;
+  return unknown_count;
 }
 
 }  // extern "C"

@@ -447,3 +447,51 @@ def test_pose_normal_equations_against_the_reference_kernel(use_depth, use_desc)
               f"H {dH:.1e}, b {db:.1e} of the largest entry, step {dx:.1e} of |x| = {np.linalg.norm(x):.2e}")
         assert dH < 2e-5 and db < 2e-5 and dx < 5e-4
         assert np.linalg.norm(x) > 1e-3                               # a real step: the pose estimate was 5 mm / 1 mrad off
+
+
+@pytest.mark.parametrize("with_intrinsics", [False, True])
+def test_pcg_system_against_the_reference_kernel(with_intrinsics):
+    """The system the PCG scheme solves -- r = -J^T W F and M = diag(J^T W J) over poses (gauge keyframe 1 left out), surfels
+    (offset along the normal + two descriptors), the depth intrinsics with one cfactor per sparse cell, and the colour intrinsics --
+    assembled by the reference's PCGInit kernel once per keyframe (B/kernel_pcg.cu:179-541, layout and loop of
+    B/direct_ba_pcg.cc:276-365; block sums and block votes through the stand-in launcher) against the oracle's assembly: poses 2 mm
+    / 0.5 mrad off, surfels up to 3 mm off.  Same unknown count and layout.  The diagonal M agrees to binary32 noise everywhere
+    (a handful of surfels aside: a pair whose association differs in the last bit).  r is a sum of terms of both signs: compared
+    in residual units (divided by sqrt(M)) it agrees to 1e-4 for 99.9 % of the surfel and cell entries, and to 1e-5 of the block's
+    largest entry where the sum runs over thousands of pairs (poses, global intrinsics)."""
+    scene = common.small_scene(num_keyframes=4, seed=23)
+    rng = np.random.Generator(np.random.PCG64(6))
+    ba = common.build_oracle(scene, 400000)
+    N, K = ba.surfels_size, len(ba.keyframes)
+    ba.surfel_data[2, :N] += rng.uniform(0, 0.003, N).astype(np.float32)
+    for k, T in enumerate(scene.poses_gt):
+        ba.set_pose(k, synthetic.perturb_pose(rng, T, 0.002, 0.0005))
+    r, M = ba.pcg_assemble(True, True, with_intrinsics, with_intrinsics, gauge_keyframe=1)
+    out = rb.ReferenceKernels(ba).pcg_assemble(True, True, with_intrinsics, with_intrinsics, gauge_keyframe=1)
+    assert out is not None
+    r_ref, M_ref = out
+    P, cells = 6 * (K - 1), ba.cf_w * ba.cf_h
+    assert len(r) == len(r_ref) == P + 3 * N + ((5 + cells + 4) if with_intrinsics else 0)
+
+    def dense(block, tolerance):     # entries summed over thousands of pairs: relative to the block's largest entry
+        for got, want in ((r[block], r_ref[block]), (M[block], M_ref[block])):
+            assert np.abs(got - want).max() <= tolerance * np.abs(want).max(), (block, got, want)
+
+    def sparse(block, what):         # entries summed over a few pairs
+        dM = np.abs(M[block] - M_ref[block]) / np.maximum(M_ref[block], 1e-6 * M_ref[block].max())
+        dr = np.abs(r[block] - r_ref[block]) / np.sqrt(np.maximum(M_ref[block], 1e-6 * M_ref[block].max()))
+        print(f"{what}: {dM.size} entries; M relative: p99.9 {np.percentile(dM, 99.9):.1e} max {dM.max():.1e}; "
+              f"r in residual units: median {np.median(dr):.1e} p99.9 {np.percentile(dr, 99.9):.1e} max {dr.max():.1e}")
+        assert np.percentile(dM, 99.9) < 1e-4 and np.count_nonzero(dM > 1e-3) <= 1e-3 * dM.size
+        assert np.percentile(dr, 99.9) < 1e-3 and np.median(dr) < 1e-5
+
+    dense(slice(0, P), 5e-5)
+    sparse(slice(P, P + 3 * N), "surfels")
+    assert np.count_nonzero(M_ref[P:P + 3 * N]) > 2.5 * N
+    if with_intrinsics:
+        start = P + 3 * N
+        dense(slice(start, start + 4), 1e-4)                                   # fx^-1, fy^-1, cx^-1, cy^-1
+        assert r[start + 4] == r_ref[start + 4] == 0 or abs(r[start + 4] - r_ref[start + 4]) <= 1e-4 * abs(r_ref[start + 4])   # a (cfactor = 0: no term)
+        sparse(slice(start + 5, start + 5 + cells), "cfactor cells")
+        assert np.count_nonzero(M_ref[start + 5:start + 5 + cells]) > 0.9 * cells
+        dense(slice(start + 5 + cells, start + 9 + cells), 1e-4)               # colour intrinsics
