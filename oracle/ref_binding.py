@@ -220,3 +220,13 @@ class ReferenceKernels:
                                         int(optimize_depth_intrinsics), int(optimize_color_intrinsics), int(gauge_keyframe),
                                         r.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p), C.c_uint32(cap)))
         return None if U == 0 else (r[:U], M[:U])
+
+    def intrinsics_accumulators(self, optimize_depth=True, optimize_color=True):
+        """(glob[34], cells[S, 8]) of the intrinsics step by the reference's accumulation kernel, once per keyframe
+        (B/kernel_opt_intrinsics.cc:39-104), in the layout of OracleBA.intrinsics_accumulators (binary32 here)."""
+        S = self.orc.cf_w * self.orc.cf_h
+        glob, cells = np.zeros(34, np.float32), np.zeros((S, 8), np.float32)
+        self.L.ref_intrinsics_accumulate.restype = C.c_int
+        rc = self.L.ref_intrinsics_accumulate(C.byref(self.sc), int(optimize_depth), int(optimize_color), glob.ctypes.data_as(C.c_void_p),
+                                              cells.ctypes.data_as(C.c_void_p))
+        return None if rc != 0 else (glob, cells)

@@ -46,6 +46,7 @@ inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
 inline uint2 make_uint2(unsigned int x, unsigned int y) { uint2 r = {x, y}; return r; }
 inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { uchar4 r = {x, y, z, w}; return r; }
 
+inline bool isnan(float x) { return x != x; }   // CUDA's global-namespace overload (B/kernel_opt_intrinsics.cu:400)
 // the headers call ::min / ::max (CUDA's global overloads)
 inline float max(float a, float b) { return a > b ? a : b; }
 inline float min(float a, float b) { return a < b ? a : b; }

@@ -11,6 +11,7 @@
 //   B/kernel_supporting_surfels.cu  DetermineSupportingSurfels<merge_surfels>
 //   B/kernel_opt_pose.cu            AccumulatePoseEstimationCoeffs<block_width, debug, use_depth, use_descriptors> with B/gauss_newton.cuh
 //   B/kernel_pcg.cu                 PCGInit (r = -J^T W F, M = diag(J^T W J): every unknown block of the PCG scheme)
+//   B/kernel_opt_intrinsics.cu      AccumulateIntrinsicsCoefficients<block_width, colour, depth> (the accumulation of the intrinsics step)
 //   B/kernel_create_surfels.cu      CreateSurfelsForKeyframeCUDASerializing, ..._CountNewSurfels, WriteNewSurfelIndexAndInitializeObservations,
 //                                   CountObservationsForNewSurfels, FilterNewSurfels, CreateSurfelsForKeyframeCUDACreationAppend
 // (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
@@ -19,7 +20,7 @@
 // B/kernel_surfel_activation.cc:38-66 (UpdateSurfelActivationCUDA), B/kernel_assign_colors.cc:38-74 (AssignColorsCUDA) and
 // B/kernel_delete_surfels.cc:38-98 (DeleteSurfelsAndUpdateRadiiCUDAImpl), B/kernel_supporting_surfels.cc:38-108
 // (DetermineSupportingSurfelsCUDAImpl), B/kernel_opt_pose.cc:38-96 (AccumulatePoseEstimationCoeffsCUDA), B/direct_ba_pcg.cc:276-365 (the
-// unknown layout and the PCGInitCUDA loop of BundleAdjustmentPCG), B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-197 (CreateSurfelsForKeyframe) --
+// unknown layout and the PCGInitCUDA loop of BundleAdjustmentPCG), B/kernel_opt_intrinsics.cc:39-104 (the accumulation of OptimizeIntrinsicsCUDA), B/direct_ba.cc:340-405 + B/kernel_create_surfels.cc:40-197 (CreateSurfelsForKeyframe) --
 // over plain arrays instead of Keyframe objects, with
 // the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
 // keyframe, one launch after the other; that order is kept.
@@ -51,6 +52,7 @@ int ref_syncthreads_or(int predicate) {
 #include "badslam/kernel_create_surfels.cu"
 #include "badslam/kernel_opt_pose.cu"
 #include "badslam/kernel_pcg.cu"
+#include "badslam/kernel_opt_intrinsics.cu"
 
 using namespace vis;
 
@@ -407,6 +409,46 @@ uint32_t ref_pcg_assemble(const ref_ba_scene* sc, int optimize_poses, int optimi
   }
   ref_thread0_last = false;
   return unknown_count;
+}
+
+// The accumulation of OptimizeIntrinsicsCUDA (B/kernel_opt_intrinsics.cc:39-104): buffers cleared, then the accumulation kernel
+// once per keyframe.  glob[34]: A (15, row-major upper triangle of the 5 x 5 block of fx^-1 fy^-1 cx^-1 cy^-1 a), b1 (5), colour
+// H (10), colour b (4); cells[8 S], per sparse cell: B0..B4, D, b2, observation count -- the layout of orc_intrinsics_accumulate.
+// Returns -1 if a surfel projects beyond the int range in some keyframe, else 0.
+int ref_intrinsics_accumulate(const ref_ba_scene* sc, int optimize_depth_intrinsics, int optimize_color_intrinsics, float* glob, float* cells) {
+  const Bound bound(sc);
+  {
+    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
+    ref_flag_pairs_outside_int_range(sc, flags.data());
+    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return -1;
+  }
+  const int S = sc->cf_width * sc->cf_height;
+  std::vector<u32> observation_count(S, 0);
+  std::vector<float> depth_A(15, 0.f), depth_B(5 * (size_t)S, 0.f), depth_D(S, 0.f), depth_b1(5, 0.f), depth_b2(S, 0.f), color_H(10, 0.f), color_b(4, 0.f);
+  ref_thread0_last = true;   // thread 0 of a block adds the block totals (B/gauss_newton.cuh:71,89)
+  for (int k = 0; k < sc->num_keyframes; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+    CallAccumulateIntrinsicsCoefficientsCUDAKernel(
+        nullptr, optimize_color_intrinsics != 0, optimize_depth_intrinsics != 0, projection_of(sc, bound, kf), bound.d2c, bound.color_projector, bound.unprojector,
+        sc->color_cam[0], sc->color_cam[1], reinterpret_cast<cudaTextureObject_t>(&tex), CUDABuffer_<u32>(observation_count.data(), 1, S, sizeof(u32) * S),
+        CUDABuffer_<float>(depth_A.data(), 1, 15, sizeof(float) * 15), CUDABuffer_<float>(depth_B.data(), 5, S, sizeof(float) * S),
+        CUDABuffer_<float>(depth_D.data(), 1, S, sizeof(float) * S), CUDABuffer_<float>(depth_b1.data(), 1, 5, sizeof(float) * 5),
+        CUDABuffer_<float>(depth_b2.data(), 1, S, sizeof(float) * S), CUDABuffer_<float>(color_H.data(), 1, 10, sizeof(float) * 10),
+        CUDABuffer_<float>(color_b.data(), 1, 4, sizeof(float) * 4));
+  }
+  ref_thread0_last = false;
+  for (int q = 0; q < 15; ++q) glob[q] = depth_A[q];
+  for (int q = 0; q < 5; ++q) glob[15 + q] = depth_b1[q];
+  for (int q = 0; q < 10; ++q) glob[20 + q] = color_H[q];
+  for (int q = 0; q < 4; ++q) glob[30 + q] = color_b[q];
+  for (int c = 0; c < S; ++c) {
+    for (int q = 0; q < 5; ++q) cells[8 * c + q] = depth_B[(size_t)q * S + c];
+    cells[8 * c + 5] = depth_D[c];
+    cells[8 * c + 6] = depth_b2[c];
+    cells[8 * c + 7] = (float)observation_count[c];
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -495,3 +495,31 @@ def test_pcg_system_against_the_reference_kernel(with_intrinsics):
         sparse(slice(start + 5, start + 5 + cells), "cfactor cells")
         assert np.count_nonzero(M_ref[start + 5:start + 5 + cells]) > 0.9 * cells
         dense(slice(start + 5 + cells, start + 9 + cells), 1e-4)               # colour intrinsics
+
+
+def test_intrinsics_accumulation_against_the_reference_kernel():
+    """The accumulation of OptimizeIntrinsicsCUDA: the reference's kernel (B/kernel_opt_intrinsics.cu:46-217: depth residual
+    Jacobians wrt fx^-1 fy^-1 cx^-1 cy^-1 a and the cell's cfactor, descriptor Jacobians wrt the colour camera; block sums for the
+    dense parts, atomics per sparse cell) once per keyframe as B/kernel_opt_intrinsics.cc:39-104 runs it, against the oracle's
+    accumulators: every cell has the same observation count; the dense blocks agree to 2e-5 of their largest entry, the per-cell
+    D to binary32 noise, the per-cell B and b2 (sums of both signs over the few pairs of a cell) to 1e-3 of the largest entry."""
+    scene = common.small_scene(num_keyframes=4, seed=27)
+    rng = np.random.Generator(np.random.PCG64(8))
+    ba = common.build_oracle(scene, 400000)
+    N = ba.surfels_size
+    ba.surfel_data[2, :N] += rng.uniform(0, 0.003, N).astype(np.float32)
+    glob, cells = ba.intrinsics_accumulators(True, True)
+    out = rb.ReferenceKernels(ba).intrinsics_accumulators(True, True)
+    assert out is not None
+    glob_ref, cells_ref = out
+    assert np.array_equal(cells[:, 7], cells_ref[:, 7]) and cells_ref[:, 7].sum() > 1.5 * N      # observation counts, cell by cell
+    for name, block, tolerance in (("A", slice(0, 15), 1e-5), ("b1", slice(15, 20), 5e-5), ("colour H", slice(20, 30), 5e-5), ("colour b", slice(30, 34), 1e-4)):
+        d = np.abs(glob[block] - glob_ref[block]).max() / np.abs(glob_ref[block]).max()
+        print(f"{name}: {d:.1e} of the largest entry")
+        assert d < tolerance, name
+    for name, column, tolerance in (("B0", 0, 2e-3), ("B1", 1, 2e-3), ("B2", 2, 2e-3), ("B3", 3, 2e-3), ("D", 5, 1e-5), ("b2", 6, 2e-3)):
+        scale = np.abs(cells_ref[:, column]).max()
+        d = np.abs(cells[:, column] - cells_ref[:, column])
+        print(f"{name}: max {d.max() / scale:.1e} of the largest entry, median {np.median(d / np.maximum(np.abs(cells_ref[:, column]), 1e-6 * scale)):.1e} relative")
+        assert scale > 0 and d.max() < tolerance * scale, name
+    assert np.array_equal(cells[:, 4], cells_ref[:, 4]) and not cells[:, 4].any()                  # a = 0, cfactor = 0: no term for `a`
