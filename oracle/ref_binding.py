@@ -230,3 +230,42 @@ class ReferenceKernels:
         rc = self.L.ref_intrinsics_accumulate(C.byref(self.sc), int(optimize_depth), int(optimize_color), glob.ctypes.data_as(C.c_void_p),
                                               cells.ctypes.data_as(C.c_void_p))
         return None if rc != 0 else (glob, cells)
+
+    def set_pose(self, keyframe_index, global_T_frame):
+        """Gives keyframe `keyframe_index` the pose `global_T_frame` (7 numbers, Sophus layout, or an oracle SE3): the three derived
+        matrices the kernels take -- frame_T_global, global_T_frame (3 x 4) and the rotation -- are formed by the oracle's SE(3)
+        routines, as OracleBA.set_pose forms them for the oracle."""
+        from oracle import binding as ob
+        OL = ob.lib()
+        T = global_T_frame if isinstance(global_T_frame, ob.SE3) else ob.SE3.from_array(global_T_frame)
+        inverse = ob.SE3()
+        OL.orc_se3_inverse(C.byref(T), C.byref(inverse))
+        kf = self.kfs[keyframe_index]
+        OL.orc_se3_matrix3x4(C.byref(inverse), kf.frame_T_global)
+        OL.orc_se3_matrix3x4(C.byref(T), kf.global_T_frame)
+        OL.orc_se3_rotation(C.byref(T), kf.global_R_frame)
+
+    def estimate_frame_pose(self, keyframe_index, init, use_depth=True, use_desc=True, max_iterations=30):
+        """DirectBA::EstimateFramePose (B/direct_ba_alternating.cc:126-244) with the reference's accumulation kernel: Gauss-Newton on
+        the pose of keyframe `keyframe_index`'s images from `init` (global_T_frame, 7 numbers): H x = b solved in binary64 (the
+        reference: Eigen LDLT on H.cast<double>()), T <- T * exp(-x) in binary32 by the oracle's SE(3) routines, until the step
+        passes the convergence test of B/convergence_analysis.h:43-51 or max_iterations.  Returns (pose as 7 numbers, steps)."""
+        from oracle import binding as ob
+        OL = ob.lib()
+        T = ob.SE3.from_array(init)
+        for step in range(max_iterations):
+            inverse, F = ob.SE3(), (C.c_float * 12)()
+            OL.orc_se3_inverse(C.byref(T), C.byref(inverse))
+            OL.orc_se3_matrix3x4(C.byref(inverse), F)
+            H21, b = self.accumulate_pose_coeffs(keyframe_index, list(F), use_depth, use_desc)
+            H = np.zeros((6, 6))
+            H[np.triu_indices(6)] = H21
+            H = H + np.triu(H, 1).T
+            x = np.linalg.solve(H, b.astype(np.float64)).astype(np.float32)
+            update, nxt = ob.SE3(), ob.SE3()
+            OL.orc_se3_exp((C.c_float * 6)(*[-float(v) for v in x]), C.byref(update))
+            OL.orc_se3_mul(C.byref(T), C.byref(update), C.byref(nxt))
+            T = nxt
+            if float(np.sum(x[:3] ** 2) + np.sum((10.0 * x[3:]) ** 2)) < 1e-6:
+                return T.to_array(), step + 1
+        return T.to_array(), max_iterations
