@@ -111,8 +111,9 @@ struct bahip_context {
   bool poll_disabled = false;        // the host copy of the pose counters is not updated by the kernel on this system: synchronise instead
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
-  // heavy runs first (wave_cull.h: xcd_ordered_tile): candidates per tile counted by the first pose round of a phase over the
-  // keyframe table, and the run permutation built from them, valid for grids of tile_order_tiles (padded) tiles (0: none yet)
+  // heavy work first (wave_cull.h: scheduled_tile): candidates per tile counted by the first pose round of a phase over the
+  // keyframe table (or by the PCG init sweep), and the schedule built from them, valid for grids of tile_order_tiles (padded)
+  // tiles (0: none yet)
   uint32_t* dev_tile_cost = nullptr;
   uint32_t* dev_tile_order = nullptr;
   size_t tile_schedule_capacity = 0;   // tiles
@@ -360,7 +361,7 @@ int ensure_tile_schedule(bahip_context* ctx, uint32_t padded_tiles) {
   ctx->tile_order_tiles = 0;
   return 0;
 }
-// The run permutation for a sweep over `surfels` surfels, or NULL (none built for this grid size yet, or switched off).
+// The schedule for a sweep over `surfels` surfels, or NULL (none built for this grid size yet, or switched off).
 const uint32_t* tile_order_for(const bahip_context* ctx, uint32_t surfels) {
   return (g_tile_order_enabled && ctx->tile_order_tiles != 0 && ctx->tile_order_tiles == pose_padded_tiles(surfels)) ? ctx->dev_tile_order : nullptr;
 }

@@ -396,8 +396,8 @@ int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
  * equations of every work item in LDS and flush them once (whenever the table fits 128 KB: up to 292 work items). */
 int bahip_debug_set_pose_form(int form);
 /* Test / experiment hook: 0 = the sweeps take their surfel tiles in buffer order; 1 (default; BAHIP_TILE_ORDER=0 in the
- * environment switches it off too) = heavy runs first, from the candidate counts of the previous pose phase (wave_cull.h:
- * xcd_ordered_tile).  A scheduling hint: results are bit-identical either way. */
+ * environment switches it off too) = heavy work first, from the candidate counts of an earlier pose phase (wave_cull.h:
+ * scheduled_tile).  A scheduling hint: results are bit-identical either way. */
 int bahip_debug_set_tile_order(int enabled);
 /* The schedule in use (test hook): *padded_tiles_out = the grid size it is valid for (0: none yet); words_out (may be NULL)
  * receives up to max_words of it: [0] heavy tiles, [8 .. 8 + 1024) their list, then one tile per regular position (padded_tiles
