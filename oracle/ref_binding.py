@@ -126,6 +126,7 @@ class ReferenceKernels:
         self.surfel_data = np.ascontiguousarray(orc.surfel_data.copy())
         self.active = np.ascontiguousarray(orc.active.copy())
         self.keep = []
+        self.poses = [ob.SE3.from_array(kf.global_T_frame.to_array()) for kf in orc.keyframes]   # global_T_frame of every keyframe
         K = len(orc.keyframes)
         self.kfs = (RefBaKeyframe * K)()
         for k in range(K):
@@ -244,6 +245,7 @@ class ReferenceKernels:
         OL.orc_se3_matrix3x4(C.byref(inverse), kf.frame_T_global)
         OL.orc_se3_matrix3x4(C.byref(T), kf.global_T_frame)
         OL.orc_se3_rotation(C.byref(T), kf.global_R_frame)
+        self.poses[keyframe_index] = ob.SE3.from_array(T.to_array())
 
     def estimate_frame_pose(self, keyframe_index, init, use_depth=True, use_desc=True, max_iterations=30):
         """DirectBA::EstimateFramePose (B/direct_ba_alternating.cc:126-244) with the reference's accumulation kernel: Gauss-Newton on
@@ -269,3 +271,25 @@ class ReferenceKernels:
             if float(np.sum(x[:3] ** 2) + np.sum((10.0 * x[3:]) ** 2)) < 1e-6:
                 return T.to_array(), step + 1
         return T.to_array(), max_iterations
+
+    def pcg_outer_iteration(self, gauge_keyframe=0, max_inner_iterations=30, use_depth=True, use_desc=True):
+        """One outer iteration of the PCG scheme over poses and geometry by the reference's kernels (ref_pcg_outer_iteration); the
+        pose update T <- T * exp(delta) -- host code in the reference, B/direct_ba_pcg.cc:566-583 -- is applied here with the oracle's
+        SE(3) routines.  `poses` (list of 7-vectors, global_T_frame) must be what set_pose last installed.  Returns the inner steps."""
+        from oracle import binding as ob
+        OL = ob.lib()
+        K = self.sc.num_keyframes
+        delta = (C.c_float * max(1, 6 * (K - 1)))()
+        self.L.ref_pcg_outer_iteration.restype = C.c_int
+        steps = int(self.L.ref_pcg_outer_iteration(C.byref(self.sc), int(use_depth), int(use_desc), int(gauge_keyframe), int(max_inner_iterations), delta))
+        if steps < 0:
+            return None
+        for k in range(K):
+            if k == gauge_keyframe:
+                continue
+            u = 6 * (k if k < gauge_keyframe else k - 1)
+            update, nxt = ob.SE3(), ob.SE3()
+            OL.orc_se3_exp((C.c_float * 6)(*[delta[u + c] for c in range(6)]), C.byref(update))
+            OL.orc_se3_mul(C.byref(self.poses[k]), C.byref(update), C.byref(nxt))
+            self.set_pose(k, nxt)
+        return steps

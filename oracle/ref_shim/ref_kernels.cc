@@ -10,7 +10,8 @@
 //                                   MarkDeletedSurfels
 //   B/kernel_supporting_surfels.cu  DetermineSupportingSurfels<merge_surfels>
 //   B/kernel_opt_pose.cu            AccumulatePoseEstimationCoeffs<block_width, debug, use_depth, use_descriptors> with B/gauss_newton.cuh
-//   B/kernel_pcg.cu                 PCGInit (r = -J^T W F, M = diag(J^T W J): every unknown block of the PCG scheme)
+//   B/kernel_pcg.cu                 PCGInit (r = -J^T W F, M = diag(J^T W J): every unknown block of the PCG scheme), PCGInit2, PCGStep1-3,
+//                                   UpdateSurfelsFromPCGDelta
 //   B/kernel_opt_intrinsics.cu      AccumulateIntrinsicsCoefficients<block_width, colour, depth> (the accumulation of the intrinsics step)
 //   B/kernel_create_surfels.cu      CreateSurfelsForKeyframeCUDASerializing, ..._CountNewSurfels, WriteNewSurfelIndexAndInitializeObservations,
 //                                   CountObservationsForNewSurfels, FilterNewSurfels, CreateSurfelsForKeyframeCUDACreationAppend
@@ -25,7 +26,9 @@
 // the projector PODs built as B/surfel_projection.h:54-124 builds them.  The reference accumulates a surfel's sums keyframe by
 // keyframe, one launch after the other; that order is kept.
 #define REF_BLOCK_COLLECTIVES 1
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include <libvis/cuda/cuda_auto_tuner.h>
@@ -449,6 +452,85 @@ int ref_intrinsics_accumulate(const ref_ba_scene* sc, int optimize_depth_intrins
     cells[8 * c + 7] = (float)observation_count[c];
   }
   return 0;
+}
+
+// One outer iteration of BundleAdjustmentPCG over poses and geometry (B/direct_ba_pcg.cc:172-560, without surfel creation /
+// merging and without the intrinsics blocks): every surfel active, UpdateSurfelNormalsCUDA (B/kernel_opt_geometry.cc:39-77), the
+// system assembled by PCGInit per keyframe, PCGInit2, then up to max_inner_iterations steps of PCGStep1 per keyframe / PCGStep2 /
+// the stopping rule of :441-456 / PCGStep3, and UpdateSurfelsFromPCGDeltaCUDA.  The surfels are updated in place; the pose block of
+// delta (6 (K - 1) values, gauge keyframe left out) is returned for the caller to apply T <- T * exp(delta) (:566-583, host code).
+// Returns the number of inner steps taken, or -1 (a surfel beyond the int range in some keyframe).
+int ref_pcg_outer_iteration(const ref_ba_scene* sc, int use_depth_residuals, int use_descriptor_residuals, int gauge_keyframe, int max_inner_iterations,
+                            float* pose_delta) {
+  const Bound bound(sc);
+  {
+    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
+    ref_flag_pairs_outside_int_range(sc, flags.data());
+    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return -1;
+  }
+  const int K = sc->num_keyframes;
+  memset(sc->active, kSurfelActiveFlag, sc->surfels_size);                                                            // :212-216
+  CallResetSurfelAccum0to3CUDAKernel(nullptr, sc->surfels_size, bound.surfels, bound.active);                        // UpdateSurfelNormalsCUDA
+  for (int k = 0; k < K; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    if (kf.activation == kInactive) continue;
+    CUDAMatrix3x3 R;
+    R.row0 = make_float3(kf.global_R_frame[0], kf.global_R_frame[1], kf.global_R_frame[2]);
+    R.row1 = make_float3(kf.global_R_frame[3], kf.global_R_frame[4], kf.global_R_frame[5]);
+    R.row2 = make_float3(kf.global_R_frame[6], kf.global_R_frame[7], kf.global_R_frame[8]);
+    CallAccumulateSurfelNormalOptimizationCoeffsCUDAKernel(nullptr, projection_of(sc, bound, kf), R, bound.active);
+  }
+  CallUpdateSurfelNormalCUDAKernel(nullptr, sc->surfels_size, bound.surfels, bound.active);
+
+  constexpr u32 kInvalidUnknownIndex = 0xffffffffu;
+  const u32 surfel_start = 6 * (K - 1);
+  const u32 unknown_count = surfel_start + (use_descriptor_residuals ? 3 : 1) * sc->surfels_size;
+  std::vector<float> r(unknown_count, 0.f), M(unknown_count, 0.f), delta(unknown_count, 0.f), g(unknown_count, 0.f), p(unknown_count, 0.f);
+  float alpha_n = 0, alpha_d = 0, beta_n = 0;
+  const size_t row = sizeof(float) * unknown_count;
+  CUDABuffer_<PCGScalar> pcg_r(r.data(), 1, (int)unknown_count, row), pcg_M(M.data(), 1, (int)unknown_count, row), pcg_delta(delta.data(), 1, (int)unknown_count, row),
+      pcg_g(g.data(), 1, (int)unknown_count, row), pcg_p(p.data(), 1, (int)unknown_count, row);
+  CUDABuffer_<PCGScalar> pcg_alpha_n(&alpha_n, 1, 1, sizeof(float)), pcg_alpha_d(&alpha_d, 1, 1, sizeof(float)), pcg_beta_n(&beta_n, 1, 1, sizeof(float));
+  auto pose_index = [&](int k) { return k == gauge_keyframe ? kInvalidUnknownIndex : (u32)(6 * (k < gauge_keyframe ? k : k - 1)); };   // :329-337
+  ref_thread0_last = true;   // thread 0 of a block adds the block totals (B/kernel_pcg.cu:78-93)
+  for (int k = 0; k < K; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+    PCGInitCUDA(nullptr, projection_of(sc, bound, kf), bound.d2c, bound.unprojector, bound.color_projector, reinterpret_cast<cudaTextureObject_t>(&tex), pose_index(k),
+                surfel_start, k != gauge_keyframe, true, use_depth_residuals != 0, use_descriptor_residuals != 0, false, false, kInvalidUnknownIndex,
+                kInvalidUnknownIndex, &pcg_r, &pcg_M, sc->surfels_size);
+  }
+  PCGInit2CUDA(nullptr, unknown_count, kInvalidUnknownIndex, sc->a, pcg_r, pcg_M, &pcg_delta, &pcg_g, &pcg_p, &pcg_alpha_n);
+  float prev_r_norm = std::numeric_limits<float>::infinity();
+  int without_improvement = 0, steps = 0;
+  CUDABuffer_<PCGScalar>* an = &pcg_alpha_n;
+  CUDABuffer_<PCGScalar>* bn = &pcg_beta_n;
+  for (int step = 0; step < max_inner_iterations; ++step) {
+    alpha_d = 0;
+    if (step > 0) {
+      std::swap(an, bn);                                                                                               // :388-392
+      std::fill(g.begin(), g.end(), 0.f);
+    }
+    for (int k = 0; k < K; ++k) {
+      const ref_ba_keyframe& kf = sc->keyframes[k];
+      RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+      PCGStep1CUDA(nullptr, unknown_count, projection_of(sc, bound, kf), bound.d2c, bound.unprojector, bound.color_projector, reinterpret_cast<cudaTextureObject_t>(&tex),
+                   pose_index(k), surfel_start, k != gauge_keyframe, true, use_depth_residuals != 0, use_descriptor_residuals != 0, false, false, kInvalidUnknownIndex,
+                   kInvalidUnknownIndex, kInvalidUnknownIndex, &pcg_p, &pcg_g, &pcg_alpha_d, sc->surfels_size);
+    }
+    PCGStep2CUDA(nullptr, unknown_count, kInvalidUnknownIndex, pcg_r, pcg_M, &pcg_delta, &pcg_g, &pcg_p, an, &pcg_alpha_d, bn);
+    ++steps;
+    const float r_norm = std::sqrt(*bn->address());                                                                    // :437-456
+    if (r_norm < prev_r_norm - 1e-3) without_improvement = 0;
+    else if (++without_improvement >= 3) break;
+    prev_r_norm = r_norm;
+    if (step < max_inner_iterations - 1) PCGStep3CUDA(nullptr, unknown_count, &pcg_g, &pcg_p, an, bn);
+  }
+  ref_thread0_last = false;
+  CUDABuffer_<float> surfels = bound.surfels;
+  UpdateSurfelsFromPCGDeltaCUDA(nullptr, sc->surfels_size, &surfels, use_descriptor_residuals != 0, surfel_start, pcg_delta);   // :585-594
+  for (u32 u = 0; u < surfel_start; ++u) pose_delta[u] = delta[u];
+  return steps;
 }
 
 }  // extern "C"
