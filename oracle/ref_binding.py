@@ -144,7 +144,8 @@ class ReferenceKernels:
         sc.width, sc.height = orc.depth_cam.width, orc.depth_cam.height
         sc.color_width, sc.color_height = orc.color_cam.width, orc.color_cam.height
         sc.a, sc.raw_to_float_depth, sc.baseline_fx, sc.cell = orc.dp.a, orc.dp.raw_to_float_depth, orc.dp.baseline_fx, orc.dp.cell
-        sc.cfactor, sc.cf_width, sc.cf_height = ob._ptr(orc.cfactor, C.c_float), orc.cf_w, orc.cf_h
+        self.cfactor = np.ascontiguousarray(orc.cfactor.copy())          # own copy: the intrinsics step updates it in place
+        sc.cfactor, sc.cf_width, sc.cf_height = ob._ptr(self.cfactor, C.c_float), orc.cf_w, orc.cf_h
         sc.surfel_rows, sc.capacity, sc.surfels_size = ob._ptr(self.surfel_data, C.c_float), self.surfel_data.shape[1], orc.surfels_size
         sc.active = ob._ptr(self.active, C.c_uint8)
         sc.quantize_texture_weights = int(quantize_texture_weights)
@@ -293,3 +294,11 @@ class ReferenceKernels:
             OL.orc_se3_mul(C.byref(self.poses[k]), C.byref(update), C.byref(nxt))
             self.set_pose(k, nxt)
         return steps
+
+    def optimize_intrinsics(self, optimize_depth=True, optimize_color=True):
+        """The intrinsics step of the alternating scheme by the reference's kernels (ref_optimize_intrinsics).  Updates this object's
+        cfactor image in place and returns (depth camera [fx, fy, cx, cy], colour camera, a), or None."""
+        dc, cc, a = (C.c_float * 4)(), (C.c_float * 4)(), C.c_float()
+        self.L.ref_optimize_intrinsics.restype = C.c_int
+        rc = self.L.ref_optimize_intrinsics(C.byref(self.sc), int(optimize_depth), int(optimize_color), dc, cc, C.byref(a))
+        return None if rc != 0 else (np.array(list(dc), np.float32), np.array(list(cc), np.float32), float(a.value))

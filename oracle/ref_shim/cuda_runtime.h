@@ -93,7 +93,8 @@ template <> inline float tex2D<float>(cudaTextureObject_t handle, float x, float
 #ifdef REF_BLOCK_COLLECTIVES   // ref_kernels.cc: whole kernels under the stand-in launcher (libvis/cuda/cuda_auto_tuner.h)
 int ref_syncthreads_or(int predicate);
 inline int __syncthreads_or(int predicate) { return ref_syncthreads_or(predicate); }
-inline void __syncthreads() {}
+void ref_syncthreads();
+inline void __syncthreads() { ref_syncthreads(); }
 #else                          // ref_entry.cc: single functions, one "thread"
 inline int __syncthreads_or(int predicate) { return predicate; }
 #endif

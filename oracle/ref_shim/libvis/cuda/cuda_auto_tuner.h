@@ -11,6 +11,10 @@
 //   * cub::BlockReduce(...).Sum (B/gauss_newton.cuh:46-93: 27 sums per residual, thread 0 adds each to H / b): the k-th Sum call
 //     of every thread of a block goes to slot k (binary64), and with ref_thread0_last set thread 0 runs after the others, so the
 //     value it gets back -- the only one the kernels use -- is the block's total.
+//   * __syncthreads() is nothing by default -- in the kernels above it only separates reuses of the reduction scratch.  One
+//     kernel (B/kernel_opt_intrinsics.cu:374-424) hands values from thread to thread through __shared__ memory across it; for that
+//     launch ref_barrier_passes makes the barrier end a pass exactly like a vote (nothing but __shared__ stores precede it).
+//     __shared__ variables are static thread_local here: one copy per OpenMP thread, i.e. per block being run.
 //   * kernels whose result depends on which thread wins an atomicCAS run with ref_launch_sequential: blocks and threads in
 //     ascending order on the calling thread, so the lowest index wins -- the rule oracle and HIP kernels define.
 #pragma once

@@ -8,6 +8,8 @@ struct RefDim3 { unsigned int x, y, z; };
 extern thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
 extern bool ref_launch_sequential;   // blocks one after the other, in ascending order, on the calling thread
 extern bool ref_thread0_last;        // within a block: threads 1 .. n - 1, then thread 0 (kernels that use a BlockReduce result)
+extern bool ref_barrier_passes;      // __syncthreads() ends a pass like a block vote (kernels that hand values from thread to thread
+                                     // through __shared__ memory and have no other side effect before the barrier)
 
 // per OpenMP thread: the collective state of the block it is running (see cuda_auto_tuner.h)
 struct RefBlockState {
@@ -21,3 +23,4 @@ struct RefBlockState {
 extern thread_local RefBlockState ref_block;
 struct RefVotePending {};
 int ref_syncthreads_or(int predicate);   // ref_kernels.cc
+void ref_syncthreads();

@@ -12,7 +12,8 @@
 //   B/kernel_opt_pose.cu            AccumulatePoseEstimationCoeffs<block_width, debug, use_depth, use_descriptors> with B/gauss_newton.cuh
 //   B/kernel_pcg.cu                 PCGInit (r = -J^T W F, M = diag(J^T W J): every unknown block of the PCG scheme), PCGInit2, PCGStep1-3,
 //                                   UpdateSurfelsFromPCGDelta
-//   B/kernel_opt_intrinsics.cu      AccumulateIntrinsicsCoefficients<block_width, colour, depth> (the accumulation of the intrinsics step)
+//   B/kernel_opt_intrinsics.cu      AccumulateIntrinsicsCoefficients<block_width, colour, depth>, ComputeIntrinsicsIntermediateMatrices,
+//                                   SolveForPixelIntrinsicsUpdate (the whole intrinsics step of the alternating scheme)
 //   B/kernel_create_surfels.cu      CreateSurfelsForKeyframeCUDASerializing, ..._CountNewSurfels, WriteNewSurfelIndexAndInitializeObservations,
 //                                   CountObservationsForNewSurfels, FilterNewSurfels, CreateSurfelsForKeyframeCUDACreationAppend
 // (B/ = applications/badslam/src/badslam/) with their own Call...CUDAKernel wrappers; the grid runs on the host through the
@@ -37,6 +38,14 @@ thread_local RefDim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local RefBlockState ref_block;
 bool ref_launch_sequential = false;
 bool ref_thread0_last = false;
+bool ref_barrier_passes = false;
+void ref_syncthreads() {
+  if (!ref_barrier_passes) return;
+  RefBlockState& state = ref_block;
+  if (state.vote_call < (int)state.votes.size()) { ++state.vote_call; return; }
+  state.pending = true;
+  throw RefVotePending();
+}
 // the block vote of the stand-in launcher (cuda_auto_tuner.h): a resolved vote is replayed, the first unresolved one takes the
 // thread's predicate and ends the thread's pass
 int ref_syncthreads_or(int predicate) {
@@ -531,6 +540,99 @@ int ref_pcg_outer_iteration(const ref_ba_scene* sc, int use_depth_residuals, int
   UpdateSurfelsFromPCGDeltaCUDA(nullptr, sc->surfels_size, &surfels, use_descriptor_residuals != 0, surfel_start, pcg_delta);   // :585-594
   for (u32 u = 0; u < surfel_start; ++u) pose_delta[u] = delta[u];
   return steps;
+}
+
+}  // extern "C"
+
+namespace {
+// x = A^-1 b for a small symmetric system given by its upper triangle, in binary64 (the reference: Eigen's
+// A.cast<double>().selfadjointView<Upper>().ldlt().solve(b.cast<double>()), B/kernel_opt_intrinsics.cc:173,269).  Gaussian
+// elimination with partial pivoting: for these well-conditioned-in-binary64 systems the two agree far below binary32 resolution.
+template <int N>
+void solve_symmetric(const float* upper, const float* rhs, float* x) {
+  double A[N][N + 1];
+  int index = 0;
+  for (int row = 0; row < N; ++row)
+    for (int col = row; col < N; ++col, ++index) A[row][col] = A[col][row] = (double)upper[index];
+  for (int row = 0; row < N; ++row) A[row][N] = (double)rhs[row];
+  for (int k = 0; k < N; ++k) {
+    int pivot = k;
+    for (int r = k + 1; r < N; ++r) if (std::fabs(A[r][k]) > std::fabs(A[pivot][k])) pivot = r;
+    for (int c = 0; c <= N; ++c) std::swap(A[k][c], A[pivot][c]);
+    for (int r = k + 1; r < N; ++r) {
+      const double f = A[r][k] / A[k][k];
+      for (int c = k; c <= N; ++c) A[r][c] -= f * A[k][c];
+    }
+  }
+  double y[N];
+  for (int k = N - 1; k >= 0; --k) {
+    double v = A[k][N];
+    for (int c = k + 1; c < N; ++c) v -= A[k][c] * y[c];
+    y[k] = v / A[k][k];
+  }
+  for (int k = 0; k < N; ++k) x[k] = (float)y[k];
+}
+}  // namespace
+
+extern "C" {
+
+// OptimizeIntrinsicsCUDA (B/kernel_opt_intrinsics.cc:39-281), the intrinsics step of the alternating scheme, by the reference's
+// kernels: accumulation once per keyframe, the Schur complement kernel, the 5 x 5 solve with the prior on `a` (host code of the
+// reference, :120-195, restated: binary64 solve), the per-cell back-substitution kernel -- which updates sc->cfactor in place --
+// and the 4 x 4 solve of the colour camera (:255-279).  Outputs: the new depth and colour cameras (fx, fy, cx, cy) and `a`.
+// Returns -1 if a surfel projects beyond the int range in some keyframe, else 0.
+int ref_optimize_intrinsics(const ref_ba_scene* sc, int optimize_depth_intrinsics, int optimize_color_intrinsics, float* out_depth_cam, float* out_color_cam,
+                            float* out_a) {
+  const Bound bound(sc);
+  {
+    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
+    ref_flag_pairs_outside_int_range(sc, flags.data());
+    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return -1;
+  }
+  for (int c = 0; c < 4; ++c) { out_depth_cam[c] = sc->depth_cam[c]; out_color_cam[c] = sc->color_cam[c]; }
+  *out_a = sc->a;
+  const int S = sc->cf_width * sc->cf_height;
+  std::vector<u32> observation_count(S, 0);
+  std::vector<float> depth_A(15, 0.f), depth_B(5 * (size_t)S, 0.f), depth_D(S, 0.f), depth_b1(5, 0.f), depth_b2(S, 0.f), color_H(10, 0.f), color_b(4, 0.f);
+  CUDABuffer_<u32> count_buffer(observation_count.data(), 1, S, sizeof(u32) * S);
+  CUDABuffer_<float> A(depth_A.data(), 1, 15, sizeof(float) * 15), B(depth_B.data(), 5, S, sizeof(float) * S), D(depth_D.data(), 1, S, sizeof(float) * S),
+      b1(depth_b1.data(), 1, 5, sizeof(float) * 5), b2(depth_b2.data(), 1, S, sizeof(float) * S), H(color_H.data(), 1, 10, sizeof(float) * 10),
+      hb(color_b.data(), 1, 4, sizeof(float) * 4);
+  ref_thread0_last = true;
+  for (int k = 0; k < sc->num_keyframes; ++k) {
+    const ref_ba_keyframe& kf = sc->keyframes[k];
+    RefTexture tex = {reinterpret_cast<const uchar4*>(kf.rgba), sc->color_width, sc->color_height, (size_t)sc->color_width * 4, sc->quantize_texture_weights};
+    CallAccumulateIntrinsicsCoefficientsCUDAKernel(nullptr, optimize_color_intrinsics != 0, optimize_depth_intrinsics != 0, projection_of(sc, bound, kf), bound.d2c,
+                                                   bound.color_projector, bound.unprojector, sc->color_cam[0], sc->color_cam[1],
+                                                   reinterpret_cast<cudaTextureObject_t>(&tex), count_buffer, A, B, D, b1, b2, H, hb);
+  }
+  if (optimize_depth_intrinsics) {
+    CallComputeIntrinsicsIntermediateMatricesCUDAKernel(nullptr, (u32)S, A, B, D, b1, b2);                                // :118-127
+    ref_thread0_last = false;
+    constexpr float kAPriorWeight = 10;                                                                                    // :150-152
+    depth_A[14] += kAPriorWeight * kAPriorWeight;
+    depth_b1[4] += kAPriorWeight * kAPriorWeight * sc->a;
+    float x1[5];
+    solve_symmetric<5>(depth_A.data(), depth_b1.data(), x1);                                                              // :173
+    const float new_fx = 1.0f / (bound.unprojector.fx_inv - x1[0]), new_fy = 1.0f / (bound.unprojector.fy_inv - x1[1]);    // :184-187
+    out_depth_cam[0] = new_fx;
+    out_depth_cam[1] = new_fy;
+    out_depth_cam[2] = -(new_fx * (bound.unprojector.cx_inv - x1[2])) + 0.5f;
+    out_depth_cam[3] = -(new_fy * (bound.unprojector.cy_inv - x1[3])) + 0.5f;
+    *out_a = sc->a - x1[4];
+    for (int c = 0; c < 5; ++c) depth_b1[c] = x1[c];                                                                       // b1 re-used for x1
+    ref_barrier_passes = true;   // x1 travels through __shared__ memory across a __syncthreads() (B/kernel_opt_intrinsics.cu:384-398)
+    CallSolveForPixelIntrinsicsUpdateCUDAKernel(nullptr, (u32)S, count_buffer, B, D, b1,
+                                                CUDABuffer_<float>(sc->cfactor, sc->cf_height, sc->cf_width, sizeof(float) * sc->cf_width));
+    ref_barrier_passes = false;
+  }
+  ref_thread0_last = false;
+  if (optimize_color_intrinsics) {
+    float x[4];
+    solve_symmetric<4>(color_H.data(), color_b.data(), x);                                                                // :255-279
+    for (int c = 0; c < 4; ++c) out_color_cam[c] = sc->color_cam[c] - x[c];
+  }
+  return 0;
 }
 
 }  // extern "C"

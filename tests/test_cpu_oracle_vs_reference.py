@@ -611,3 +611,37 @@ def test_pcg_outer_iterations_against_the_reference_kernels():
     assert moved > 2e-3 and np.median(np.abs(ba.surfel_data[:3, :N] - before).max(axis=0)) > 5e-4
     assert dt < 2e-6 and dr < 2e-6
     assert np.percentile(dpos, 99.9) < 2e-6 and np.count_nonzero(dpos > 1e-5) <= 2e-3 * N
+
+
+def test_intrinsics_step_against_the_reference_kernels():
+    """The whole intrinsics step of the alternating scheme (OptimizeIntrinsicsCUDA, B/kernel_opt_intrinsics.cc:39-281) by the
+    reference's three kernels on the host -- accumulation per keyframe, Schur complement (block sums), per-cell back-substitution
+    (x1 handed through __shared__ memory: the launcher's barrier passes) -- with the two small host solves restated in binary64,
+    against the oracle, from a miscalibrated state: depth camera 0.2 % / 0.3 px off, colour camera 0.1 % / 0.2 px off, a = 0.01,
+    cfactors U(+-2e-3).  Cameras agree to 1e-4 px, the cfactor image to 1e-5 (it moves by 1e-3), `a` -- weakly determined: the
+    reference's own tests accept +-1e-2 -- to 1e-4."""
+    scene = common.small_scene(num_keyframes=4, seed=27)
+    rng = np.random.Generator(np.random.PCG64(8))
+    ba = common.build_oracle(scene, 400000)
+    N = ba.surfels_size
+    ba.surfel_data[2, :N] += rng.uniform(0, 0.003, N).astype(np.float32)
+    ba.depth_cam.fx *= 1.002
+    ba.depth_cam.cx += 0.3
+    ba.color_cam.fy *= 0.999
+    ba.color_cam.cy -= 0.2
+    ba.cfactor[:] = rng.uniform(-2e-3, 2e-3, ba.cfactor.shape).astype(np.float32)
+    ba.dp.a = 0.01
+    start_depth, start_color = np.array([ba.depth_cam.fx, ba.depth_cam.fy, ba.depth_cam.cx, ba.depth_cam.cy]), np.array([ba.color_cam.fx, ba.color_cam.fy, ba.color_cam.cx, ba.color_cam.cy])
+    cfactor_before = ba.cfactor.copy()
+    ref = rb.ReferenceKernels(ba)
+    out = ref.optimize_intrinsics(True, True)
+    assert out is not None
+    cc, dc, a = ba.optimize_intrinsics(True, True)
+    depth, color = np.array([dc.fx, dc.fy, dc.cx, dc.cy]), np.array([cc.fx, cc.fy, cc.cx, cc.cy])
+    print("depth camera", depth, "reference", out[0], "| colour camera", color, "reference", out[1], "| a", a, "reference", out[2])
+    assert np.abs(depth - start_depth).max() > 0.1 and np.abs(color - start_color).max() > 0.05     # the step moved both cameras
+    assert np.abs(depth - out[0]).max() < 1e-4 and np.abs(color - out[1]).max() < 1e-4
+    assert abs(a - out[2]) < 1e-4 and abs(a - 0.01) > 5e-3
+    d = np.abs(ba.cfactor - ref.cfactor)
+    assert np.median(np.abs(ba.cfactor - cfactor_before)) > 3e-4
+    assert d.max() < 1e-5 and np.median(d) < 1e-6
