@@ -15,8 +15,9 @@
  * cost of ~4e5 (surfel, keyframe) pairs with them (measured deltas: DESIGN.md section 6); and whole
  * KERNELS of the reference -- B/kernel_surfel_activation.cu, kernel_opt_geometry.cu, kernel_assign_colors.cu,
  * kernel_delete_surfels.cu, kernel_supporting_surfels.cu, kernel_create_surfels.cu, and kernel_opt_pose.cu,
- * kernel_pcg.cu (PCGInit), kernel_opt_intrinsics.cu (accumulation) with their block votes and block sums
- * modelled -- run on the host through a stand-in launcher (oracle/ref_shim/ref_kernels.cc) in the
+ * kernel_pcg.cu, kernel_opt_intrinsics.cu with their block votes and block sums modelled, and
+ * cuda_depth_processing.cu, cuda_image_processing.cu (keyframe preprocessing), kernel_compact_surfels.cu
+ * -- run on the host through a stand-in launcher (oracle/ref_shim/ref_kernels.cc, ref_preprocess.cc) in the
  * order of the reference's host drivers, stage against stage with the oracle (same test file);
  * (1) the reference's own closed-loop test criteria restated in
  * tests/test_oracle_*_closed_loop.py (applications/badslam/src/badslam/test/ *.cc tolerances; all

@@ -302,3 +302,66 @@ class ReferenceKernels:
         self.L.ref_optimize_intrinsics.restype = C.c_int
         rc = self.L.ref_optimize_intrinsics(C.byref(self.sc), int(optimize_depth), int(optimize_color), dc, cc, C.byref(a))
         return None if rc != 0 else (np.array(list(dc), np.float32), np.array(list(cc), np.float32), float(a.value))
+
+
+# ---- the reference's preprocessing kernels and its compaction (oracle/ref_shim/ref_preprocess.cc) ---------------------------------
+def bilateral_filter_and_depth_cutoff(depth_u16, sigma_xy, sigma_value, radius_factor, max_depth, raw_to_float_depth):
+    """BilateralFilteringAndDepthCutoffCUDA (B/cuda_depth_processing.cu:42-128) on a dense u16 image."""
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    out = np.zeros_like(d)
+    L = lib()
+    L.ref_bilateral_filter_and_depth_cutoff.restype = None
+    L.ref_bilateral_filter_and_depth_cutoff.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint16, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.ref_bilateral_filter_and_depth_cutoff(sigma_xy, sigma_value, radius_factor, int(max_depth), raw_to_float_depth, d.ctypes.data, d.shape[1], d.shape[0],
+                                            out.ctypes.data)
+    return out
+
+
+def compute_brightness(rgb_u8):
+    """ComputeBrightnessCUDA (B/cuda_image_processing.cu:165-193): H x W x 3 -> H x W x 4 with the luma in .w."""
+    rgb = np.ascontiguousarray(rgb_u8, np.uint8)
+    out = np.zeros(rgb.shape[:2] + (4,), np.uint8)
+    L = lib()
+    L.ref_compute_brightness.restype = None
+    L.ref_compute_brightness.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.ref_compute_brightness(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], out.ctypes.data)
+    return out
+
+
+def keyframe_depth_preprocessing(depth_u16, camera, a, raw_to_float_depth, baseline_fx, cell, cfactor):
+    """The depth half of the Keyframe constructor (B/keyframe.cc:111-144) with the reference's own kernels.  camera: fx, fy, cx, cy
+    (pixel-corner convention).  Returns dict(depth, normals, radius, depth_after_normals, min_depth, max_depth)."""
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    H, W = d.shape
+    cf = np.ascontiguousarray(cfactor, np.float32)
+    out = {name: np.zeros((H, W), np.uint16) for name in ("depth", "normals", "radius", "depth_after_normals")}
+    lo, hi = C.c_float(), C.c_float()
+    L = lib()
+    L.ref_keyframe_depth_preprocessing.restype = None
+    L.ref_keyframe_depth_preprocessing.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    cam = (C.c_float * 4)(*[float(v) for v in camera])
+    L.ref_keyframe_depth_preprocessing(cam, a, raw_to_float_depth, baseline_fx, int(cell), cf.ctypes.data, cf.shape[1], cf.shape[0], d.ctypes.data, W, H,
+                                       out["depth"].ctypes.data, out["normals"].ctypes.data, out["radius"].ctypes.data,
+                                       out["depth_after_normals"].ctypes.data, C.byref(lo), C.byref(hi))
+    out["min_depth"], out["max_depth"] = lo.value, hi.value
+    return out
+
+
+def compact_surfels(surfel_data, surfels_size, surfel_count, active=None):
+    """CompactSurfelsCUDA (B/kernel_compact_surfels.cu:159-279) in place on a 17 x capacity float array (and the activity bytes).
+    Returns the new surfels_size."""
+    assert surfel_data.dtype == np.float32 and surfel_data.flags.c_contiguous and surfel_data.shape[0] == 17
+    L = lib()
+    L.ref_compact_surfels.restype = C.c_uint32
+    L.ref_compact_surfels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    return int(L.ref_compact_surfels(surfel_data.ctypes.data, surfel_data.shape[1], int(surfels_size), int(surfel_count),
+                                     None if active is None else active.ctypes.data))
+
+
+def float_to_half_bits(values):
+    """The stand-in's __float2half_rn (oracle/ref_shim/cuda_runtime.h) on an array of binary32 values."""
+    L = lib()
+    L.ref_float_to_half_bits.restype = C.c_uint16
+    L.ref_float_to_half_bits.argtypes = [C.c_float]
+    return np.array([L.ref_float_to_half_bits(float(v)) for v in np.asarray(values, np.float32)], np.uint16)

@@ -100,7 +100,7 @@ inline int __syncthreads_or(int predicate) { return predicate; }
 #endif
 
 // host stand-ins for the three runtime calls of CreateSurfelsForKeyframeCUDA_CountNewSurfels (B/kernel_create_surfels.cu:432-475)
-enum cudaMemcpyKind { cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2 };
+enum cudaMemcpyKind { cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2, cudaMemcpyDeviceToDevice = 3 };
 inline int cudaMalloc(void** ptr, size_t bytes) { *ptr = std::malloc(bytes ? bytes : 1); return 0; }
 inline int cudaMemcpyAsync(void* dst, const void* src, size_t bytes, cudaMemcpyKind, cudaStream_t) { std::memcpy(dst, src, bytes); return 0; }
 inline int cudaStreamSynchronize(cudaStream_t) { return 0; }
@@ -144,3 +144,36 @@ inline float __half2float(__half h) {   // binary16 -> binary32, exact
   float f; std::memcpy(&f, &out, sizeof(f)); return f;
 }
 inline int __all(int predicate) { return predicate; }
+// keyframe preprocessing (ref_preprocess.cc: B/cuda_depth_processing.cu, B/cuda_image_processing.cu)
+inline int atomicMin(int* address, int value) {   // returns the old word
+  int seen = __atomic_load_n(address, __ATOMIC_RELAXED);
+  while (value < seen && !__atomic_compare_exchange_n(address, &seen, value, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return seen;
+}
+inline int atomicMax(int* address, int value) {
+  int seen = __atomic_load_n(address, __ATOMIC_RELAXED);
+  while (value > seen && !__atomic_compare_exchange_n(address, &seen, value, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return seen;
+}
+inline __half __float2half_rn(float f) {   // binary32 -> binary16, round to nearest even, overflow to infinity, subnormals kept
+  uint32_t in; std::memcpy(&in, &f, sizeof(in));
+  const uint32_t sign = (in >> 16) & 0x8000u, magnitude = in & 0x7fffffffu;
+  uint16_t out;
+  if (magnitude >= 0x7f800000u) out = (uint16_t)(magnitude > 0x7f800000u ? 0x7fffu : 0x7c00u);          // NaN (CUDA's canonical 0x7fff) / infinity
+  else if (magnitude >= 0x477ff000u) out = 0x7c00u;                                                      // rounds to >= 2^16: infinity
+  else if (magnitude < 0x33000001u) out = 0;                                                             // <= 2^-25: rounds to zero
+  else {
+    const int exponent = (int)(magnitude >> 23) - 127;                                                   // unbiased
+    uint32_t mantissa = (magnitude & 0x7fffffu) | 0x800000u;                                             // 24 bits, leading one explicit
+    const int shift = exponent >= -14 ? 13 : 13 + (-14 - exponent);                                      // bits dropped (more for a subnormal result)
+    const uint32_t kept = mantissa >> shift, rest = mantissa & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    uint32_t rounded = kept + ((rest > half || (rest == half && (kept & 1u))) ? 1u : 0u);
+    // normal: rounded has its leading one at bit 10, adding (exponent + 14) << 10 on top of it gives biased exponent + mantissa, and a
+    // carry out of the mantissa moves into the exponent by itself; subnormal: the exponent field is what the carry makes it
+    out = (uint16_t)(exponent >= -14 ? rounded + ((uint32_t)(exponent + 14) << 10) : rounded);
+  }
+  __half h = {(unsigned short)(sign | out)};
+  return h;
+}
+inline unsigned short __half_as_ushort(__half h) { return h.bits; }
+

@@ -3,7 +3,7 @@
 // kernel<<<ceil(domain / block), block, shared, stream>>>(arguments)).  Here the macros run the grid on the host
 // (ref_run_grid): blocks are dealt to OpenMP threads, the threads of a block run one after the other, and threadIdx / blockIdx /
 // blockDim / gridDim are thread-local variables the kernel bodies read.  What a block's threads do TOGETHER is modelled just
-// far enough for the kernels oracle/ref_shim/ref_kernels.cc compiles:
+// far enough for the kernels oracle/ref_shim/ref_kernels.cc and ref_preprocess.cc compile:
 //   * __syncthreads_or (B/surfel_projection_nvcc_only.cuh:394,409: "leave together if nobody in the block is visible"): the
 //     block is run in passes.  In a pass every thread runs from the start; at the first vote that is not resolved yet it
 //     deposits its predicate and stops (RefVotePending); after the pass the vote's result is the OR of the deposits, and the
@@ -15,6 +15,8 @@
 //     kernel (B/kernel_opt_intrinsics.cu:374-424) hands values from thread to thread through __shared__ memory across it; for that
 //     launch ref_barrier_passes makes the barrier end a pass exactly like a vote (nothing but __shared__ stores precede it).
 //     __shared__ variables are static thread_local here: one copy per OpenMP thread, i.e. per block being run.
+//   * cub::BlockReduce(...).Reduce(value, cub::Min() / cub::Max()) (B/cuda_depth_processing.cu:406-418) keeps a running result per slot
+//     the same way; thread 0, run last, gets the result over the block.
 //   * kernels whose result depends on which thread wins an atomicCAS run with ref_launch_sequential: blocks and threads in
 //     ascending order on the calling thread, so the lowest index wins -- the rule oracle and HIP kernels define.
 #pragma once
@@ -54,6 +56,7 @@ void ref_run_grid(long long blocks_x, long long blocks_y, unsigned int width, un
       state.pending = false;
       state.pending_or = 0;
       state.sums.assign(state.sums.size(), 0.0);
+      state.slot_used.assign(state.slot_used.size(), 0);
       for (unsigned int step = 0; step < threads; ++step) {
         const unsigned int t = thread0_last ? (step + 1 == threads ? 0u : step + 1u) : step;
         threadIdx = RefDim3{t % width, t / width, 0};
@@ -93,4 +96,14 @@ void ref_run_grid(long long blocks_x, long long blocks_y, unsigned int width, un
     (void)block_width; (void)block_height;                                                                                              \
     ref_run_grid(((long long)(domain_width) + block_width - 1) / block_width, ((long long)(domain_height) + block_height - 1) / block_height, \
                  block_width, block_height, [&]() { kernel_name<template_parameters>(__VA_ARGS__); });                                   \
+  } while (false)
+
+// L/cuda/cuda_auto_tuner.h:309-345: blocks overlap by the border, the grid covers the domain with (block - border) per block
+#define CUDA_AUTO_TUNE_2D_BORDER_TEMPLATED(kernel_name, default_block_width, default_block_height, border_width, border_height, domain_width,    \
+                                           domain_height, shared_memory_size, stream, template_parameters, ...)                              \
+  do {                                                                                                                                   \
+    constexpr int block_width = (default_block_width), block_height = (default_block_height);                                           \
+    ref_run_grid(((long long)(domain_width) + (block_width - (border_width)) - 1) / (block_width - (border_width)),                     \
+                 ((long long)(domain_height) + (block_height - (border_height)) - 1) / (block_height - (border_height)), block_width,   \
+                 block_height, [&]() { kernel_name<template_parameters>(__VA_ARGS__); });                                                \
   } while (false)

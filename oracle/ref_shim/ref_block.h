@@ -19,6 +19,7 @@ struct RefBlockState {
   bool pending = false;
   std::vector<double> sums;          // BlockReduce slots, one per Sum call in program order
   int sum_call = 0;
+  std::vector<char> slot_used;       // BlockReduce::Reduce: has a thread of this pass put a value in the slot yet
 };
 extern thread_local RefBlockState ref_block;
 struct RefVotePending {};

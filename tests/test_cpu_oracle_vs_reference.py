@@ -645,3 +645,123 @@ def test_intrinsics_step_against_the_reference_kernels():
     d = np.abs(ba.cfactor - ref.cfactor)
     assert np.median(np.abs(ba.cfactor - cfactor_before)) > 3e-4
     assert d.max() < 1e-5 and np.median(d) < 1e-6
+
+
+# ---- preprocessing kernels and compaction of the reference (oracle/ref_shim/ref_preprocess.cc) -----------------------------------
+def test_the_stand_in_half_conversion_rounds_like_ieee():
+    """__float2half_rn of the stand-in runtime header (the radius image is binary16) against numpy's conversion: random bit
+    patterns, the binary16 range and its subnormals, ties, the overflow threshold."""
+    rng = np.random.Generator(np.random.PCG64(40))
+    v = rng.integers(0, 2**32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    v = v[np.isfinite(v)]
+    edge = np.array([0, 65504, 65519.99, 65520, 65536, 1e-8, 2**-25, 2**-25 * 1.0000001, 2**-24, 2**-24 * 1.5, 2**-14, 2**-14 * (1 - 2**-11),
+                     1.0, 1.00048828125, 1.0009765625, 1.00146484375, np.inf, -np.inf], np.float32)
+    w = np.concatenate([v, edge, -edge, rng.uniform(-70000, 70000, 15000).astype(np.float32), (rng.uniform(0, 1, 15000) * 2**-13).astype(np.float32)])
+    with np.errstate(over="ignore"):
+        want = w.astype(np.float16).view(np.uint16)
+    assert np.array_equal(rb.float_to_half_bits(w), want)
+
+
+def test_brightness_against_the_reference_kernel():
+    """ComputeBrightnessCUDA (B/cuda_image_processing.cu:165-193): the oracle evaluates 0.299 r + 0.587 g + 0.114 b as the fused
+    chain a GPU compiler emits, the host build of the reference rounds every product -- the luma differs by one in < 0.01 % of the
+    pixels and never by more; r, g, b are copied."""
+    rng = np.random.Generator(np.random.PCG64(41))
+    rgb = rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)
+    want = rb.compute_brightness(rgb)
+    got = np.zeros_like(want)
+    ob.lib().orc_compute_brightness(rgb.ctypes.data_as(C.c_void_p), 320, 240, got.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(got[..., :3], want[..., :3]) and np.array_equal(want[..., :3], rgb)
+    d = got[..., 3].astype(int) - want[..., 3].astype(int)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 1e-4, (np.abs(d).max(), (d != 0).mean())
+
+
+def _noisy_raw_depth(scene, k, rng):
+    raw = (scene.depth[k].astype(np.float64) + rng.normal(0, 8, scene.depth[k].shape)).clip(0, 65000).astype(np.uint16)
+    raw[rng.random(raw.shape) < 0.02] = 0          # holes: the sensor's "no measurement"
+    return raw
+
+
+def test_bilateral_filter_against_the_reference_kernel():
+    """BilateralFilteringAndDepthCutoffCUDA (B/cuda_depth_processing.cu:42-128) on a noisy depth image with holes and a cut-off
+    inside the scene's range: the same pixels become unknown; the filtered value (truncated to u16) differs by one raw unit in
+    < 0.02 % of the pixels (the oracle's defined exponential against the host's) and never by more."""
+    scene = common.small_scene(num_keyframes=1, seed=42)
+    rng = np.random.Generator(np.random.PCG64(42))
+    raw = _noisy_raw_depth(scene, 0, rng)
+    s = scene.raw_to_float_depth
+    max_depth = int(np.percentile(raw[raw > 0], 90))
+    want = rb.bilateral_filter_and_depth_cutoff(raw, 3.0, 0.05, 2.5, max_depth, s)
+    got = ob.bilateral_filter_and_depth_cutoff(raw, 3.0, 0.05, 2.5, max_depth, s)
+    assert np.array_equal(got == 65535, want == 65535)
+    assert 0.05 < (want == 65535).mean() < 0.5                      # holes and the cut-off both took pixels, most survived
+    d = got.astype(int) - want.astype(int)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 2e-4, (np.abs(d).max(), (d != 0).mean())
+
+
+@pytest.mark.parametrize("a,cfactor_range", [(0.0, 0.0), (0.01, 2e-3)], ids=["a=0", "deformed"])
+def test_keyframe_depth_preprocessing_against_the_reference_kernels(a, cfactor_range):
+    """ComputeNormalsCUDA, ComputePointRadiiAndRemoveIsolatedPixelsCUDA and ComputeMinMaxDepthCUDA in the order of the Keyframe
+    constructor (B/keyframe.cc:111-144) on a filtered noisy image: the pixels dropped by either pass, the depth range and the
+    radii (binary16; one unit in the last place on fewer than 1e-4 of the pixels) are the reference's; the 8-bit normals differ by
+    one step in < 0.1 % of the pixels.  With a deformation (a, cfactor != 0) the calibrated depths differ in the last places
+    (the oracle multiplies where the reference divides), the differences of neighbouring points amplify that, and the ratio test
+    that picks one-sided or central differences (B/cuda_depth_processing.cu:208-233) then tips on a few pixels in 10^5."""
+    scene = common.small_scene(num_keyframes=1, width=640, height=480, seed=43)
+    rng = np.random.Generator(np.random.PCG64(43))
+    s, W, H = scene.raw_to_float_depth, 640, 480
+    filtered = rb.bilateral_filter_and_depth_cutoff(_noisy_raw_depth(scene, 0, rng), 3.0, 0.05, 2.5, 60000, s)
+    cam = ob.make_camera(scene.camera, W, H)
+    cf = rng.uniform(-cfactor_range, cfactor_range, (H // 2, W // 2)).astype(np.float32)
+    dp = ob.DepthParams(a, s, scene.baseline_fx, 2, ob._ptr(cf, C.c_float), W // 2, H // 2)
+    L = ob.lib()
+    after_normals, normals, radius, depth = (np.zeros((H, W), np.uint16) for _ in range(4))
+    ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+    L.orc_compute_normals(C.byref(cam), C.byref(dp), ptr(filtered), ptr(after_normals), ptr(normals))
+    L.orc_compute_point_radii(C.byref(cam), C.c_float(s), ptr(after_normals), ptr(radius), ptr(depth))
+    lo, hi = C.c_float(), C.c_float()
+    L.orc_compute_min_max_depth(ptr(after_normals), W, H, C.c_float(s), C.byref(lo), C.byref(hi))
+    ref = rb.keyframe_depth_preprocessing(filtered, [cam.fx, cam.fy, cam.cx, cam.cy], a, s, scene.baseline_fx, 2, cf)
+    assert np.array_equal(after_normals, ref["depth_after_normals"]) and np.array_equal(depth, ref["depth"])
+    valid = (depth & 0x8000) == 0
+    assert 0.5 < valid.mean() < 0.95                                  # holes spread by both passes, most pixels kept
+    assert (lo.value, hi.value) == (ref["min_depth"], ref["max_depth"]) and 0 < lo.value < hi.value
+    rd = np.abs(radius.astype(int) - ref["radius"].astype(int))
+    assert rd.max() <= 1 and (rd != 0).mean() < 1e-4, (rd.max(), (rd != 0).mean())
+    step = np.maximum(np.abs((normals & 0xff).astype(np.int8).astype(int) - (ref["normals"] & 0xff).astype(np.int8).astype(int)),
+                      np.abs((normals >> 8).astype(np.int8).astype(int) - (ref["normals"] >> 8).astype(np.int8).astype(int)))
+    assert (step != 0).mean() < 1e-3, (step != 0).mean()
+    if a == 0.0:
+        assert step.max() <= 1, step.max()
+    else:
+        assert (step > 1).mean() < 1e-4, (step > 1).mean()
+
+
+@pytest.mark.parametrize("deleted_fraction", [0.0, 0.01, 0.3, 0.9, 1.0])
+def test_compaction_against_the_reference_kernel(deleted_fraction):
+    """CompactSurfelsCUDA (B/kernel_compact_surfels.cu:159-279: the last surviving surfels move into the free spots, in the
+    order two scans define) on a cloud with a random part marked deleted: the 8 data rows and the activity bytes of the
+    compacted cloud are the oracle's bit for bit, with and without the activity buffer."""
+    scene = common.small_scene(num_keyframes=3, seed=44)
+    ba = common.build_oracle(scene, 200000)
+    N = ba.surfels_size
+    rng = np.random.Generator(np.random.PCG64(44))
+    data, active = ba.surfel_data.copy(), (rng.random(ba.active.shape) < 0.5).astype(np.uint8)
+    dead = rng.random(N) < deleted_fraction
+    data[0, :N].view(np.uint32)[dead] = 0x7fffffff
+    count = int(N - dead.sum())
+    mine, mine_active = data.copy(), active.copy()
+    s = ob.Surfels(ob._ptr(mine, C.c_float), ob._ptr(mine_active, C.c_uint8), mine.shape[1], N, count)
+    ob.lib().orc_compact_surfels.restype = None
+    ob.lib().orc_compact_surfels(C.byref(s))
+    theirs, their_active = data.copy(), active.copy()
+    assert rb.compact_surfels(theirs, N, count, their_active) == count == s.surfels_size
+    assert np.array_equal(mine[:8, :count].view(np.uint32), theirs[:8, :count].view(np.uint32))
+    assert np.array_equal(mine_active[:count], their_active[:count])
+    assert not (theirs[0, :count].view(np.uint32) == 0x7fffffff).any()
+    # the survivors are the surfels that were not marked, each exactly once
+    key = lambda rows, n: np.sort(rows[:8, :n].view(np.uint32).T.copy().view([("", np.uint32)] * 8).ravel())
+    assert np.array_equal(key(theirs, count), key(data[:, :N][:, ~dead], count))
+    no_active = data.copy()
+    rb.compact_surfels(no_active, N, count, None)
+    assert np.array_equal(no_active[:8, :count].view(np.uint32), theirs[:8, :count].view(np.uint32))
