@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/reference_kernels.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN KERNELS for a small scene, stage by
+stage.  The kernels are the reference's .cu files compiled for the host (oracle/_ref/libbadslam_ref.so: oracle/Makefile reads the
+sources where they lie under /root/reference, oracle/ref_shim/ supplies the stand-in CUDA runtime and launcher), so this script
+runs only where /root/reference exists -- the build container.  The committed file travels: tests/test_cpu_golden_reference.py
+holds the oracle against it and tests/test_gpu_golden_reference.py the HIP path, on machines that have neither the reference nor
+the library built from it.
+
+Everything downstream of an input is produced by the reference's kernels from the reference's own earlier outputs (its filtered
+depth feeds its keyframe preprocessing, its keyframe images feed its surfel creation, ...); the oracle is used only as a container
+for arrays and for the SE(3) host arithmetic (pose -> 3 x 4 matrices), which the file stores as inputs.
+usage: python scripts/make_golden_reference_kernels.py [out.npz]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from badslam_amd import synthetic   # noqa: E402
+from oracle import binding as ob    # noqa: E402
+from oracle import ref_binding as rb   # noqa: E402
+from tests import golden_reference as gr   # noqa: E402
+
+out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "reference_kernels.npz")
+W, H, K, CELL = gr.WIDTH, gr.HEIGHT, gr.KEYFRAMES, gr.CELL
+scene = synthetic.make_scene(K, W, H, seed=51, cell=CELL, translation_range=0.5, rotation_range=0.2)
+rng = np.random.Generator(np.random.PCG64(52))
+s = scene.raw_to_float_depth
+fix = dict(camera=np.asarray(scene.camera, np.float32), raw_to_float_depth=np.float32(s), baseline_fx=np.float32(scene.baseline_fx),
+           poses=np.asarray(scene.poses_gt, np.float32), rgb=np.stack(scene.rgb).astype(np.uint8))
+
+# ---- inputs: noisy raw depth with holes --------------------------------------------------------------------------------------
+raw = np.stack([(d.astype(np.float64) + rng.normal(0, 6, d.shape)).clip(0, 65000).astype(np.uint16) for d in scene.depth])
+raw[rng.random(raw.shape) < 0.01] = 0
+fix["raw"] = raw
+
+# ---- stage 0: BilateralFilteringAndDepthCutoffCUDA ------------------------------------------------------------------------------
+fix["filtered"] = np.stack([rb.bilateral_filter_and_depth_cutoff(raw[k], *gr.BILATERAL, int(gr.MAX_DEPTH_M / s), s) for k in range(K)])
+
+# ---- stage 1: the Keyframe constructor's kernels ---------------------------------------------------------------------------------
+cam = ob.make_camera(scene.camera, W, H)
+cfactor = np.zeros(((H - 1) // CELL + 1, (W - 1) // CELL + 1), np.float32)
+pre = [rb.keyframe_depth_preprocessing(fix["filtered"][k], [cam.fx, cam.fy, cam.cx, cam.cy], 0.0, s, scene.baseline_fx, CELL, cfactor) for k in range(K)]
+for name in ("depth", "normals", "radius"):
+    fix[name] = np.stack([p[name] for p in pre])
+fix["min_max_depth"] = np.array([[p["min_depth"], p["max_depth"]] for p in pre], np.float32)
+fix["luma"] = np.stack([rb.compute_brightness(fix["rgb"][k])[..., 3] for k in range(K)])
+
+# the container: an oracle scene holding the REFERENCE's keyframe images
+orc = gr.oracle_with_reference_images(fix, capacity=gr.CAPACITY)
+fix["frame_T_global"] = np.array([list(kf.frame_T_global) for kf in orc.keyframes], np.float32)
+fix["global_R_frame"] = np.array([list(kf.global_R_frame) for kf in orc.keyframes], np.float32)
+
+# ---- stage 2: CreateSurfelsForKeyframe, keyframe after keyframe, from an empty cloud ---------------------------------------------
+ref = rb.ReferenceKernels(orc)
+ref.sc.surfels_size = 0
+fix["created_counts"] = np.array([ref.create_surfels_for_keyframe(k, filter_new_surfels=False) for k in range(K)], np.uint32)
+N = int(ref.sc.surfels_size)
+assert N == int(fix["created_counts"].sum()) and N > 3000
+fix["created_rows"] = ref.surfel_data[:8, :N].copy()
+
+# ---- stage 3: activation + geometry step from a perturbed cloud; keyframe 1 co-visible, keyframe 2 inactive -----------------------
+state = gr.perturbed_state(fix["created_rows"])
+orc.surfel_data[:8, :N] = state
+orc.surfels.surfels_size = orc.surfels.surfel_count = N
+for k, activation in enumerate(gr.ACTIVATIONS):
+    orc.keyframes[k].activation = activation
+ref = rb.ReferenceKernels(orc)
+assert not ref.pairs_outside_int_range().any()
+ref.update_surfel_activation()
+fix["active_flags"] = ref.active[:N].copy()
+ref.optimize_geometry_iteration(True, True)
+assert np.array_equal(ref.surfel_data[4:6, :N].view(np.uint32), state[4:6].view(np.uint32))   # radius and colour rows: untouched
+fix["geometry_rows"] = ref.surfel_data[gr.GEOMETRY_ROWS, :N].copy()
+
+# ---- stage 4: pose normal equations of keyframe 0 at a pose 5 mm / 1 mrad off -----------------------------------------------------
+off = synthetic.perturb_pose(np.random.Generator(np.random.PCG64(53)), scene.poses_gt[0])
+T, inverse, F = ob.SE3.from_array(off), ob.SE3(), (C.c_float * 12)()
+ob.lib().orc_se3_inverse(C.byref(T), C.byref(inverse))
+ob.lib().orc_se3_matrix3x4(C.byref(inverse), F)
+fix["pose_frame_T_global"] = np.array(list(F), np.float32)
+ref = rb.ReferenceKernels(orc)                         # the perturbed cloud again
+for name, flags in (("both", (True, True)), ("depth", (True, False)), ("desc", (False, True))):
+    Hm, b = ref.accumulate_pose_coeffs(0, list(F), *flags)
+    fix["pose_H_" + name], fix["pose_b_" + name] = Hm, b
+
+# ---- stage 5: deletion + radius update (every keyframe counts), then compaction ---------------------------------------------------
+orc.surfel_data[:8, :N] = gr.state_for_deletion(state)
+ref = rb.ReferenceKernels(orc)
+deleted = ref.delete_surfels_and_update_radii(gr.MIN_OBSERVATIONS)
+mask = ref.surfel_data[0, :N].view(np.uint32) == 0x7fffffff
+assert deleted == int(mask.sum()) and 100 < deleted < N // 2
+fix["deleted_mask"] = mask
+fix["radius_row"] = ref.surfel_data[4, :N].copy()
+rows, active = ref.surfel_data.copy(), (np.arange(ref.surfel_data.shape[1]) % 3 == 0).astype(np.uint8)
+assert rb.compact_surfels(rows, N, N - deleted, active) == N - deleted
+fix["compacted_digest"] = gr.digest(rows[:8, :N - deleted], active[:N - deleted])   # pure data movement: a digest of the result is enough
+
+np.savez_compressed(out_path, **fix)
+print(out_path, os.path.getsize(out_path), "bytes;", N, "surfels created", fix["created_counts"].tolist(), "; active", int(fix["active_flags"].sum()),
+      "; deleted", deleted)

@@ -13,8 +13,10 @@ if ROOT not in sys.path:
 # system's (/opt/rocm, 7.2).  Whichever is loaded first serves the whole process, and torch does not find its GPUs on the
 # system's copy ("No HIP GPUs are available") -- so a process that uses both (the loopback and gloo tests, bench.py) imports
 # torch FIRST.  A full run did that by accident (collection imports tests/test_cpu_multigpu_gloo.py); a partial run did not.
+# (BADSLAM_TESTS_NO_TORCH=1 skips it: for a quick run of tests that use the backend through ctypes only.)
 try:
-    import torch  # noqa: F401
+    if not os.environ.get("BADSLAM_TESTS_NO_TORCH"):
+        import torch  # noqa: F401
 except ImportError:
     pass
 

@@ -1,0 +1,160 @@
+"""What scripts/make_golden_reference_kernels.py (the generator of tests/golden/reference_kernels.npz: outputs of the REFERENCE's
+own kernels, stage by stage) and the two tests that replay the file -- tests/test_cpu_golden_reference.py with the oracle,
+tests/test_gpu_golden_reference.py with the HIP path -- have to agree on: the scene's constants and the deterministic
+perturbations applied between stages (plain binary32 arithmetic on the index, no random generator, so that every machine forms
+the same bits)."""
+import os
+
+import numpy as np
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kernels.npz")
+WIDTH, HEIGHT, KEYFRAMES, CELL = 128, 96, 3, 2
+CAPACITY = 20000
+BILATERAL = (2.0, 0.05, 2.5)            # sigma_xy, sigma_value (inverse depth), radius_factor
+MAX_DEPTH_M = 3.2
+ACTIVATIONS = (0, 1, 2)                 # kActive, kCovisibleActive, kInactive (B/keyframe.h:54-67)
+MIN_OBSERVATIONS = 2
+GEOMETRY_ROWS = [0, 1, 2, 3, 6, 7]      # what the geometry step writes: position, packed normal, the two descriptors
+
+
+def load():
+    with np.load(PATH) as f:
+        return {name: f[name] for name in f.files}
+
+
+def digest(rows, active):
+    """SHA-256 over the words of the surfel rows and the activity bytes, as 32 bytes."""
+    import hashlib
+    h = hashlib.sha256(np.ascontiguousarray(rows, np.float32).view(np.uint32).tobytes())
+    h.update(np.ascontiguousarray(active, np.uint8).tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
+def rgba_of(fix, k):
+    return np.concatenate([fix["rgb"][k], fix["luma"][k][..., None]], axis=2)
+
+
+def perturbed_state(created_rows):
+    """The cloud the optimisation stages start from: the created surfels moved up to 4 mm along z and detuned by up to 3
+    descriptor units, as a function of the surfel index."""
+    rows = np.array(created_rows, np.float32, copy=True)
+    i = np.arange(rows.shape[1], dtype=np.int64)
+    rows[2] += np.float32(0.004) * ((i * 2654435761 % 1000).astype(np.float32) / np.float32(1000))
+    rows[6] += (i * 40503 % 601).astype(np.float32) / np.float32(100) - np.float32(3)
+    rows[7] -= (i * 9973 % 601).astype(np.float32) / np.float32(100) - np.float32(3)
+    return rows
+
+
+def state_for_deletion(state_rows):
+    """Every 20th surfel pushed 30 cm off its surface, alternately behind it (unobserved) and in front of it (free-space
+    violations in the keyframes that see through it)."""
+    rows = np.array(state_rows, np.float32, copy=True)
+    i = np.arange(rows.shape[1])
+    rows[2, i % 40 == 7] += np.float32(0.3)
+    rows[2, i % 40 == 27] -= np.float32(0.3)
+    return rows
+
+
+def oracle_with_reference_images(fix, capacity=CAPACITY):
+    """An oracle scene whose keyframes hold the REFERENCE's preprocessed images (the file's), at the file's poses, empty cloud."""
+    from oracle import binding as ob
+    cam, cam2 = ob.make_camera(fix["camera"], WIDTH, HEIGHT), ob.make_camera(fix["camera"], WIDTH, HEIGHT)
+    ba = ob.OracleBA(capacity, float(fix["raw_to_float_depth"]), float(fix["baseline_fx"]), CELL, cam, cam2, min_observation_count=MIN_OBSERVATIONS)
+    for k in range(KEYFRAMES):
+        ba.add_preprocessed_keyframe(fix["depth"][k], fix["normals"][k], fix["radius"][k], rgba_of(fix, k), fix["poses"][k],
+                                     float(fix["min_max_depth"][k, 0]), float(fix["min_max_depth"][k, 1]))
+    return ba
+
+
+# ---- the checks both replays apply (tolerances: what tests/test_cpu_oracle_vs_reference.py measures on larger scenes) ------------
+def check_filtered(got, fix, k):
+    """Stage 0, bilateral filter + cut-off: the same pixels unknown, values within one raw unit on < 0.1 % of the pixels."""
+    want = fix["filtered"][k]
+    assert np.array_equal(got == 65535, want == 65535)
+    assert 0.01 < (want == 65535).mean() < 0.5
+    d = got.astype(int) - want.astype(int)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 1e-3, (k, np.abs(d).max(), (d != 0).mean())
+
+
+def check_keyframe_images(depth, normals, radius, luma, min_depth, max_depth, fix, k):
+    """Stage 1, the Keyframe constructor's kernels on the reference's filtered image: same dropped pixels, same depth range, radii
+    (binary16) within one unit in the last place on < 0.1 % of the valid pixels, 8-bit normals within one step on < 0.2 %, luma
+    within one on < 0.1 %."""
+    assert np.array_equal(depth, fix["depth"][k])
+    valid = (depth & 0x8000) == 0
+    assert 0.5 < valid.mean() < 0.95
+    assert (np.float32(min_depth), np.float32(max_depth)) == tuple(fix["min_max_depth"][k])
+    rd = np.abs(radius.astype(int) - fix["radius"][k].astype(int))[valid]
+    assert rd.max() <= 1 and (rd != 0).mean() < 1e-3, (k, rd.max(), (rd != 0).mean())
+    step = np.maximum(np.abs((normals & 0xff).astype(np.int8).astype(int) - (fix["normals"][k] & 0xff).astype(np.int8).astype(int)),
+                      np.abs((normals >> 8).astype(np.int8).astype(int) - (fix["normals"][k] >> 8).astype(np.int8).astype(int)))
+    assert step.max() <= 1 and (step != 0).mean() < 2e-3, (k, step.max(), (step != 0).mean())
+    dl = np.abs(luma.astype(int) - fix["luma"][k].astype(int))
+    assert dl.max() <= 1 and (dl != 0).mean() < 1e-3, (k, dl.max(), (dl != 0).mean())
+
+
+def check_created(rows, counts, fix):
+    """Stage 2, surfel creation keyframe after keyframe from an empty cloud: the same number of surfels every time; paired by
+    position within each keyframe's batch (the reference appends in pixel order, this implementation in its own defined order):
+    packed normal, radius and colour words identical, positions within 1e-6 m, initial descriptors within 2e-3."""
+    from scipy.spatial import cKDTree
+    assert [int(c) for c in counts] == fix["created_counts"].tolist()
+    want = fix["created_rows"]
+    assert rows.shape == want.shape
+    start = 0
+    for c in fix["created_counts"].tolist():
+        mine, theirs = rows[:, start:start + c], want[:, start:start + c]
+        dist, index = cKDTree(theirs[:3].T).query(mine[:3].T)
+        assert np.array_equal(np.sort(index), np.arange(c))                 # one to one
+        assert dist.max() < 1e-6, dist.max()
+        paired = theirs[:, index]
+        for row in (3, 4, 5):
+            assert np.array_equal(mine[row].view(np.uint32), paired[row].view(np.uint32)), row
+        assert np.abs(mine[6:8] - paired[6:8]).max() < 2e-3
+        start += c
+
+
+def check_activation_and_geometry(active, rows, state, fix):
+    """Stage 3: activation flags identical; after the geometry step packed normals identical but for a handful, positions within
+    5e-7 m for 99.9 % of the surfels and within 1e-4 m for all, descriptors within 2e-3 for 99.9 %."""
+    assert np.array_equal(active, fix["active_flags"]) and 0.5 < active.mean() < 1.0
+    want = fix["geometry_rows"]
+    got = rows[GEOMETRY_ROWS]
+    assert np.array_equal(rows[4:6].view(np.uint32), state[4:6].view(np.uint32))
+    assert (got[3].view(np.uint32) != want[3].view(np.uint32)).sum() <= 3
+    d = np.linalg.norm(got[:3] - want[:3], axis=0)
+    assert np.percentile(d, 99.9) < 5e-7 and d.max() < 1e-4, (np.percentile(d, 99.9), d.max())
+    assert np.percentile(np.abs(got[4:] - want[4:]), 99.9) < 2e-3
+    assert np.abs(want[2] - state[2]).mean() > 5e-4                           # the step moved the cloud
+
+
+def _full(h21):
+    m = np.zeros((6, 6))
+    m[np.triu_indices(6)] = h21
+    return m + np.triu(m, 1).T
+
+
+def check_pose_equations(H, b, name, fix):
+    """Stage 4: H and b within 2e-5 of their largest entry (binary32 sums in another order), the Gauss-Newton step they imply
+    within 1e-6 of the reference's (a 5 mm step)."""
+    Hr, br = fix["pose_H_" + name].astype(np.float64), fix["pose_b_" + name].astype(np.float64)
+    H, b = np.asarray(H, np.float64), np.asarray(b, np.float64)
+    assert np.abs(H - Hr).max() < 2e-5 * np.abs(Hr).max() and np.abs(b - br).max() < 2e-5 * np.abs(br).max(), name
+    x, xr = np.linalg.solve(_full(H), b), np.linalg.solve(_full(Hr), br)
+    assert 1e-3 < np.linalg.norm(xr) < 2e-2 and np.linalg.norm(x - xr) < 1e-6, (name, np.linalg.norm(xr), np.linalg.norm(x - xr))
+
+
+def check_deletion(rows, deleted, fix):
+    """Stage 5: the same surfels deleted, every survivor's updated radius bit for bit."""
+    mask = rows[0].view(np.uint32) == 0x7fffffff
+    assert int(deleted) == int(mask.sum()) == int(fix["deleted_mask"].sum())
+    assert np.array_equal(mask, fix["deleted_mask"])
+    assert np.array_equal(rows[4][~mask].view(np.uint32), fix["radius_row"][~mask].view(np.uint32))
+
+
+def reference_state_after_deletion(fix):
+    """(8 x N rows, activity bytes) as the reference's deletion left them: what the compaction stage starts from."""
+    rows = state_for_deletion(perturbed_state(fix["created_rows"]))
+    rows[0].view(np.uint32)[fix["deleted_mask"]] = 0x7fffffff
+    rows[4] = fix["radius_row"]
+    return rows, (np.arange(rows.shape[1]) % 3 == 0).astype(np.uint8)

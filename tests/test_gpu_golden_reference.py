@@ -1,0 +1,108 @@
+"""The HIP path, called through the C ABI, against tests/golden/reference_kernels.npz: outputs of the REFERENCE's own kernels (its
+.cu files compiled for the host, scripts/make_golden_reference_kernels.py) for a three-keyframe scene, stage by stage -- depth
+filter, keyframe preprocessing, surfel creation, activation + geometry step, pose normal equations, deletion + radius update,
+compaction.  The checks and their tolerances are the ones tests/test_cpu_golden_reference.py applies to the oracle
+(tests/golden_reference.py); neither /root/reference nor the oracle is needed here."""
+import numpy as np
+import pytest
+
+from badslam_amd import capi
+from tests import golden_reference as gr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fix():
+    return gr.load()
+
+
+def _scene(fix, ctx=None):
+    from badslam_amd import lowlevel as ll
+    ctx = ctx or ll.Context()
+    cam, cam2 = ll.make_camera(fix["camera"], gr.WIDTH, gr.HEIGHT), ll.make_camera(fix["camera"], gr.WIDTH, gr.HEIGHT)
+    return ll.Scene(ctx, gr.CAPACITY, float(fix["raw_to_float_depth"]), float(fix["baseline_fx"]), gr.CELL, cam, cam2)
+
+
+def test_depth_filter(fix):
+    from badslam_amd import lowlevel as ll
+    ctx = ll.Context()
+    s = float(fix["raw_to_float_depth"])
+    for k in range(gr.KEYFRAMES):
+        got = ll.bilateral_filtering_and_depth_cutoff(ctx, fix["raw"][k], *gr.BILATERAL, int(gr.MAX_DEPTH_M / s), s)
+        gr.check_filtered(got, fix, k)
+
+
+@pytest.fixture(scope="module")
+def gpu(fix):
+    """Keyframes built by the backend's own preprocessing from the reference's filtered depth (checked against the reference's
+    keyframe images on the way), then given the reference's images so that every later stage starts from the file's state."""
+    g = _scene(fix)
+    for k in range(gr.KEYFRAMES):
+        g.add_keyframe(fix["filtered"][k], fix["rgb"][k], fix["poses"][k])
+        kf = g.keyframes[k]
+        rgba = kf["color"].download()
+        assert np.array_equal(rgba[..., :3], fix["rgb"][k])
+        gr.check_keyframe_images(kf["depth"].download(), kf["normals"].download(), kf["radius"].download(), rgba[..., 3], kf["min_depth"], kf["max_depth"],
+                                 fix, k)
+        kf["depth"].upload(np.ascontiguousarray(fix["depth"][k]))
+        kf["normals"].upload(np.ascontiguousarray(fix["normals"][k]))
+        kf["radius"].upload(np.ascontiguousarray(fix["radius"][k]))
+        kf["color"].upload(np.ascontiguousarray(gr.rgba_of(fix, k)))
+        kf["min_depth"], kf["max_depth"] = float(fix["min_max_depth"][k, 0]), float(fix["min_max_depth"][k, 1])
+    g.bind_keyframes()
+    return g
+
+
+def test_keyframe_preprocessing(gpu):
+    assert len(gpu.keyframes) == gr.KEYFRAMES        # the checks ran while the fixture built the keyframes
+
+
+def test_surfel_creation(fix, gpu):
+    gpu.upload_surfels(np.zeros((8, 0), np.float32), np.zeros(0, np.uint8))
+    counts = [gpu.create_surfels_for_keyframe(k, filter_new_surfels=False) for k in range(gr.KEYFRAMES)]
+    gr.check_created(gpu.download_surfels()[:8], counts, fix)
+
+
+def test_activation_and_geometry_step(fix, gpu):
+    state = gr.perturbed_state(fix["created_rows"])
+    n = state.shape[1]
+    gpu.upload_surfels(state, np.zeros(n, np.uint8))
+    for k, activation in enumerate(gr.ACTIVATIONS):
+        gpu.keyframes[k]["activation"] = activation
+    gpu.bind_keyframes()
+    try:
+        gpu.update_surfel_activation()
+        active = gpu.active_buf.download()[0, :n].copy()
+        gpu.optimize_geometry_iteration(True, True)
+        rows = gpu.download_surfels()[:8].copy()
+    finally:
+        for k in range(gr.KEYFRAMES):
+            gpu.keyframes[k]["activation"] = capi.KF_ACTIVE
+        gpu.bind_keyframes()
+    gr.check_activation_and_geometry(active, rows, state, fix)
+
+
+@pytest.mark.parametrize("name,use_depth,use_desc", [("both", True, True), ("depth", True, False), ("desc", False, True)])
+def test_pose_normal_equations(fix, gpu, name, use_depth, use_desc):
+    state = gr.perturbed_state(fix["created_rows"])
+    gpu.upload_surfels(state, np.ones(state.shape[1], np.uint8))
+    gpu.bind_keyframes()
+    H, b = gpu.accumulate_pose_coeffs(0, use_depth, use_desc, fix["pose_frame_T_global"])
+    gr.check_pose_equations(H, b, name, fix)
+
+
+def test_deletion_then_compaction(fix, gpu):
+    state = gr.state_for_deletion(gr.perturbed_state(fix["created_rows"]))
+    n = state.shape[1]
+    gpu.upload_surfels(state, np.zeros(n, np.uint8))
+    gpu.bind_keyframes()
+    deleted = gpu.delete_surfels_and_update_radii(gr.MIN_OBSERVATIONS)
+    gr.check_deletion(gpu.surfel_buf.download()[:8, :n], deleted, fix)
+    rows, active = gr.reference_state_after_deletion(fix)       # compaction from the reference's own state: pure data movement
+    gpu.upload_surfels(rows, active)
+    gpu.surfel_count = n - int(fix["deleted_mask"].sum())
+    gpu.compact_surfels(with_active=True)
+    m = gpu.surfels_size
+    assert m == n - int(fix["deleted_mask"].sum())
+    assert np.array_equal(gr.digest(gpu.download_surfels()[:8], gpu.active_buf.download()[0, :m]), fix["compacted_digest"])
