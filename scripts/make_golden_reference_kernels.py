@@ -98,6 +98,53 @@ rows, active = ref.surfel_data.copy(), (np.arange(ref.surfel_data.shape[1]) % 3 
 assert rb.compact_surfels(rows, N, N - deleted, active) == N - deleted
 fix["compacted_digest"] = gr.digest(rows[:8, :N - deleted], active[:N - deleted])   # pure data movement: a digest of the result is enough
 
+# ---- stage 6: creation with the observation filter (co-visible keyframes must confirm a new surfel) -------------------------------
+for k in range(K):
+    orc.keyframes[k].activation = ob.KF_ACTIVE
+orc.surfel_data[:] = 0
+orc.surfels.surfels_size = orc.surfels.surfel_count = 0
+ref = rb.ReferenceKernels(orc)
+fix["filtered_created_counts"] = np.array([ref.create_surfels_for_keyframe(k, filter_new_surfels=True) for k in range(K)], np.uint32)
+M = int(ref.sc.surfels_size)
+assert 500 < M < N
+fix["filtered_created_rows"] = ref.surfel_data[:8, :M].copy()
+
+# ---- stage 7: colour assignment on the perturbed cloud ----------------------------------------------------------------------------
+orc.surfel_data[:8, :N] = state
+orc.surfels.surfels_size = orc.surfels.surfel_count = N
+ref = rb.ReferenceKernels(orc)
+ref.assign_colors()
+fix["assigned_colours"] = ref.surfel_data[5, :N].view(np.uint32).copy()
+
+# ---- stage 8: supporting surfels of keyframe 1 over the created cloud, without and with merging -------------------------------------
+orc.surfel_data[:8, :N] = fix["created_rows"]
+ref = rb.ReferenceKernels(orc)
+fix["supporting_planes"], none = ref.determine_supporting_surfels(1, merge=False)
+assert none == 0
+ref = rb.ReferenceKernels(orc)
+fix["merge_planes"], merged = ref.determine_supporting_surfels(1, merge=True)
+fix["merged_mask"] = ref.surfel_data[0, :N].view(np.uint32) == 0x7fffffff
+assert merged == int(fix["merged_mask"].sum()) and merged > 100
+
+# ---- stage 9: the PCG system (r, M) over poses, surfels and both sets of intrinsics at perturbed poses, gauge keyframe 1 ------------
+orc.surfel_data[:8, :N] = state
+pose_rng = np.random.Generator(np.random.PCG64(54))
+fix["pcg_poses"] = np.asarray([synthetic.perturb_pose(pose_rng, T, 0.002, 0.0005) for T in scene.poses_gt], np.float32)
+for k in range(K):
+    orc.set_pose(k, fix["pcg_poses"][k])
+fix["pcg_frame_T_global"] = np.array([list(kf.frame_T_global) for kf in orc.keyframes], np.float32)
+orc.use_depth = orc.use_desc = 1
+fix["pcg_r"], fix["pcg_M"] = rb.ReferenceKernels(orc).pcg_assemble(True, True, True, True, gauge_keyframe=gr.GAUGE_KEYFRAME)
+for k in range(K):
+    orc.set_pose(k, fix["poses"][k])
+
+# ---- stage 10: the intrinsics step of the alternating scheme from a miscalibrated state ---------------------------------------------
+gr.miscalibrate(orc)
+ref = rb.ReferenceKernels(orc)
+depth_camera, colour_camera, a = ref.optimize_intrinsics(True, True)
+fix["intrinsics_depth_camera"], fix["intrinsics_colour_camera"], fix["intrinsics_a"] = depth_camera, colour_camera, np.float32(a)
+fix["intrinsics_cfactor"] = ref.cfactor.copy()
+
 np.savez_compressed(out_path, **fix)
 print(out_path, os.path.getsize(out_path), "bytes;", N, "surfels created", fix["created_counts"].tolist(), "; active", int(fix["active_flags"].sum()),
       "; deleted", deleted)

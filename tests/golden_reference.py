@@ -14,6 +14,7 @@ BILATERAL = (2.0, 0.05, 2.5)            # sigma_xy, sigma_value (inverse depth),
 MAX_DEPTH_M = 3.2
 ACTIVATIONS = (0, 1, 2)                 # kActive, kCovisibleActive, kInactive (B/keyframe.h:54-67)
 MIN_OBSERVATIONS = 2
+GAUGE_KEYFRAME = 1
 GEOMETRY_ROWS = [0, 1, 2, 3, 6, 7]      # what the geometry step writes: position, packed normal, the two descriptors
 
 
@@ -55,6 +56,29 @@ def state_for_deletion(state_rows):
     return rows
 
 
+def miscalibrated_cfactor():
+    """The cfactor image of the intrinsics stage: +-2e-3, a function of the cell index."""
+    cf_h, cf_w = (HEIGHT - 1) // CELL + 1, (WIDTH - 1) // CELL + 1
+    i = np.arange(cf_h * cf_w, dtype=np.int64)
+    return (((i * 7919 % 401).astype(np.float32) / np.float32(100) - np.float32(2)) * np.float32(1e-3)).reshape(cf_h, cf_w)
+
+
+MISCALIBRATION = dict(depth_fx=1.002, depth_cx=0.3, colour_fy=0.999, colour_cy=-0.2, a=0.01)
+
+
+def miscalibrate(scene):
+    """Depth camera 0.2 % / 0.3 px off, colour camera 0.1 % / 0.2 px off, a = 0.01, cfactor = miscalibrated_cfactor(): on an oracle
+    scene or a backend scene (both have depth_cam, color_cam, dp.a; the caller of a backend scene uploads the cfactor image and
+    calls set_intrinsics)."""
+    scene.depth_cam.fx *= MISCALIBRATION["depth_fx"]
+    scene.depth_cam.cx += MISCALIBRATION["depth_cx"]
+    scene.color_cam.fy *= MISCALIBRATION["colour_fy"]
+    scene.color_cam.cy += MISCALIBRATION["colour_cy"]
+    scene.dp.a = MISCALIBRATION["a"]
+    if isinstance(scene.cfactor, np.ndarray):
+        scene.cfactor[:] = miscalibrated_cfactor()
+
+
 def oracle_with_reference_images(fix, capacity=CAPACITY):
     """An oracle scene whose keyframes hold the REFERENCE's preprocessed images (the file's), at the file's poses, empty cloud."""
     from oracle import binding as ob
@@ -93,16 +117,16 @@ def check_keyframe_images(depth, normals, radius, luma, min_depth, max_depth, fi
     assert dl.max() <= 1 and (dl != 0).mean() < 1e-3, (k, dl.max(), (dl != 0).mean())
 
 
-def check_created(rows, counts, fix):
+def check_created(rows, counts, fix, prefix=""):
     """Stage 2, surfel creation keyframe after keyframe from an empty cloud: the same number of surfels every time; paired by
     position within each keyframe's batch (the reference appends in pixel order, this implementation in its own defined order):
     packed normal, radius and colour words identical, positions within 1e-6 m, initial descriptors within 2e-3."""
     from scipy.spatial import cKDTree
-    assert [int(c) for c in counts] == fix["created_counts"].tolist()
-    want = fix["created_rows"]
+    assert [int(c) for c in counts] == fix[prefix + "created_counts"].tolist()
+    want = fix[prefix + "created_rows"]
     assert rows.shape == want.shape
     start = 0
-    for c in fix["created_counts"].tolist():
+    for c in fix[prefix + "created_counts"].tolist():
         mine, theirs = rows[:, start:start + c], want[:, start:start + c]
         dist, index = cKDTree(theirs[:3].T).query(mine[:3].T)
         assert np.array_equal(np.sort(index), np.arange(c))                 # one to one
@@ -158,3 +182,63 @@ def reference_state_after_deletion(fix):
     rows[0].view(np.uint32)[fix["deleted_mask"]] = 0x7fffffff
     rows[4] = fix["radius_row"]
     return rows, (np.arange(rows.shape[1]) % 3 == 0).astype(np.uint8)
+
+
+def check_colours(colour_words, fix):
+    """Stage 7, colour assignment: colour words identical but for < 0.2 % of the surfels, those one code off in a channel."""
+    got = np.ascontiguousarray(colour_words).view(np.uint32).view(np.uint8).reshape(-1, 4).astype(int)
+    want = fix["assigned_colours"].view(np.uint8).reshape(-1, 4).astype(int)
+    assert np.abs(got - want).max() <= 1 and (got != want).any(axis=1).mean() < 2e-3
+    assert len(np.unique(want[:, 0])) > 50
+
+
+def check_supporting(planes, merged_mask, merge, fix):
+    """Stage 8: the three supporting-surfel planes of keyframe 1 word for word up to 0.1 % of the filled entries; with merging the
+    same surfels merged away up to 0.5 %."""
+    want = fix["merge_planes" if merge else "supporting_planes"]
+    filled = int((want != 0xffffffff).sum())
+    assert planes.shape == want.shape and filled > 3000
+    assert np.count_nonzero(planes != want) <= 1e-3 * filled
+    if merge:
+        assert fix["merged_mask"].sum() > 100 and np.count_nonzero(merged_mask != fix["merged_mask"]) <= 5e-3 * fix["merged_mask"].sum()
+    else:
+        assert not merged_mask.any()
+
+
+def check_pcg_system(r, M, surfels, cells, fix):
+    """Stage 9, r = -J^T W F and M = diag(J^T W J) of the PCG scheme: same unknown count and layout; blocks summed over thousands of
+    pairs (poses, global intrinsics) within 5e-5 of their largest entry; per-surfel and per-cell entries: M within 1e-4 relative,
+    r within 1e-3 residual units (r / sqrt(M)) at the 99.9th percentile."""
+    rr, Mr = fix["pcg_r"], fix["pcg_M"]
+    P = 6 * (KEYFRAMES - 1)
+    assert len(r) == len(M) == len(rr) == P + 3 * surfels + 5 + cells + 4
+
+    def dense(block, tolerance):
+        for got, want in ((r[block], rr[block]), (M[block], Mr[block])):
+            assert np.abs(got - want).max() <= tolerance * np.abs(want).max(), block
+
+    def sparse(block):
+        scale = np.maximum(Mr[block], 1e-6 * Mr[block].max())
+        dM, dr = np.abs(M[block] - Mr[block]) / scale, np.abs(r[block] - rr[block]) / np.sqrt(scale)
+        assert np.percentile(dM, 99.9) < 1e-4 and np.count_nonzero(dM > 1e-3) <= 1e-3 * dM.size, (block, np.percentile(dM, 99.9))
+        assert np.percentile(dr, 99.9) < 1e-3 and np.median(dr) < 1e-4, (block, np.percentile(dr, 99.9), np.median(dr))
+
+    start = P + 3 * surfels
+    dense(slice(0, P), 5e-5)
+    sparse(slice(P, start))
+    assert np.count_nonzero(Mr[P:start]) > 2.5 * surfels
+    dense(slice(start, start + 4), 1e-4)
+    assert r[start + 4] == rr[start + 4] == 0                      # a: no term while cfactor = 0
+    sparse(slice(start + 5, start + 5 + cells))
+    dense(slice(start + 5 + cells, start + 9 + cells), 1e-4)
+
+
+def check_intrinsics_step(depth_camera, colour_camera, a, cfactor, fix):
+    """Stage 10, the intrinsics step from the miscalibrated state: cameras within 3e-4 px, `a` within 3e-4 (weakly determined: the
+    reference's own runs differ by 2e-5 in it), the cfactor image within 1e-5 (it moves by 1e-3)."""
+    assert np.abs(np.asarray(depth_camera, np.float64) - fix["intrinsics_depth_camera"]).max() < 3e-4
+    assert np.abs(np.asarray(colour_camera, np.float64) - fix["intrinsics_colour_camera"]).max() < 3e-4
+    assert abs(float(a) - float(fix["intrinsics_a"])) < 3e-4 and abs(float(fix["intrinsics_a"]) - MISCALIBRATION["a"]) > 5e-3
+    d = np.abs(np.asarray(cfactor, np.float32) - fix["intrinsics_cfactor"])
+    assert d.max() < 1e-5 and np.median(d) < 1e-6
+    assert np.median(np.abs(fix["intrinsics_cfactor"] - miscalibrated_cfactor())) > 3e-4

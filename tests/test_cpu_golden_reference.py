@@ -1,6 +1,7 @@
 """The oracle against tests/golden/reference_kernels.npz: outputs of the REFERENCE's own kernels (its .cu files compiled for the
 host, scripts/make_golden_reference_kernels.py) for a three-keyframe scene, stage by stage -- depth filter, keyframe
-preprocessing, surfel creation, activation + geometry step, pose normal equations, deletion + radius update, compaction.  Unlike
+preprocessing, surfel creation (plain and filtered), activation + geometry step, pose normal equations, deletion + radius update,
+compaction, colour assignment, supporting surfels + merging, the PCG system, the intrinsics step.  Unlike
 tests/test_cpu_oracle_vs_reference.py this needs neither /root/reference nor the library built from it: the file is committed.
 tests/test_gpu_golden_reference.py replays the same file through the HIP path."""
 import ctypes as C
@@ -109,3 +110,51 @@ def test_deletion_then_compaction(fix, oracle):
     m = oracle.surfels_size
     assert m == n - int(fix["deleted_mask"].sum())
     assert np.array_equal(gr.digest(oracle.surfel_data[:8, :m], oracle.active[:m]), fix["compacted_digest"])
+
+
+def test_filtered_surfel_creation(fix, oracle):
+    _load(oracle, np.zeros((8, 0), np.float32))
+    counts = []
+    for k in range(gr.KEYFRAMES):
+        before = oracle.surfels_size
+        oracle.create_surfels_for_keyframe(k, filter_new_surfels=True)
+        counts.append(oracle.surfels_size - before)
+    gr.check_created(oracle.surfel_data[:8, :oracle.surfels_size], counts, fix, prefix="filtered_")
+
+
+def test_colour_assignment(fix, oracle):
+    state = gr.perturbed_state(fix["created_rows"])
+    _load(oracle, state)
+    oracle.assign_colors()
+    gr.check_colours(oracle.surfel_data[5, :state.shape[1]].copy(), fix)
+
+
+@pytest.mark.parametrize("merge", [False, True])
+def test_supporting_surfels(fix, oracle, merge):
+    n = fix["created_rows"].shape[1]
+    _load(oracle, fix["created_rows"])
+    planes = oracle.determine_supporting_surfels(1, merge)
+    gr.check_supporting(planes, oracle.surfel_data[0, :n].view(np.uint32) == 0x7fffffff, merge, fix)
+
+
+def test_pcg_system(fix, oracle):
+    state = gr.perturbed_state(fix["created_rows"])
+    _load(oracle, state)
+    for k in range(gr.KEYFRAMES):
+        oracle.set_pose(k, fix["pcg_poses"][k])
+        assert np.array_equal(np.array(list(oracle.keyframes[k].frame_T_global), np.float32), fix["pcg_frame_T_global"][k])
+    oracle.use_depth = oracle.use_desc = 1
+    try:
+        r, M = oracle.pcg_assemble(True, True, True, True, gauge_keyframe=gr.GAUGE_KEYFRAME)
+    finally:
+        for k in range(gr.KEYFRAMES):
+            oracle.set_pose(k, fix["poses"][k])
+    gr.check_pcg_system(r, M, state.shape[1], oracle.cf_w * oracle.cf_h, fix)
+
+
+def test_intrinsics_step(fix):
+    ba = gr.oracle_with_reference_images(fix)                     # its own scene: the step changes cameras and the cfactor image
+    _load(ba, gr.perturbed_state(fix["created_rows"]))
+    gr.miscalibrate(ba)
+    cc, dc, a = ba.optimize_intrinsics(True, True)
+    gr.check_intrinsics_step([dc.fx, dc.fy, dc.cx, dc.cy], [cc.fx, cc.fy, cc.cx, cc.cy], a, ba.cfactor, fix)

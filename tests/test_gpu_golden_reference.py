@@ -1,7 +1,7 @@
 """The HIP path, called through the C ABI, against tests/golden/reference_kernels.npz: outputs of the REFERENCE's own kernels (its
 .cu files compiled for the host, scripts/make_golden_reference_kernels.py) for a three-keyframe scene, stage by stage -- depth
-filter, keyframe preprocessing, surfel creation, activation + geometry step, pose normal equations, deletion + radius update,
-compaction.  The checks and their tolerances are the ones tests/test_cpu_golden_reference.py applies to the oracle
+filter, keyframe preprocessing, surfel creation (plain and filtered), activation + geometry step, pose normal equations, deletion +
+radius update, compaction, colour assignment, supporting surfels + merging, the PCG system, the intrinsics step.  The checks and their tolerances are the ones tests/test_cpu_golden_reference.py applies to the oracle
 (tests/golden_reference.py); neither /root/reference nor the oracle is needed here."""
 import numpy as np
 import pytest
@@ -33,18 +33,18 @@ def test_depth_filter(fix):
         gr.check_filtered(got, fix, k)
 
 
-@pytest.fixture(scope="module")
-def gpu(fix):
-    """Keyframes built by the backend's own preprocessing from the reference's filtered depth (checked against the reference's
-    keyframe images on the way), then given the reference's images so that every later stage starts from the file's state."""
+def _scene_with_reference_images(fix, check):
+    """Keyframes built by the backend's own preprocessing from the reference's filtered depth (with `check`: held against the
+    reference's keyframe images on the way), then given the reference's images so that every later stage starts from the file's state."""
     g = _scene(fix)
     for k in range(gr.KEYFRAMES):
         g.add_keyframe(fix["filtered"][k], fix["rgb"][k], fix["poses"][k])
         kf = g.keyframes[k]
-        rgba = kf["color"].download()
-        assert np.array_equal(rgba[..., :3], fix["rgb"][k])
-        gr.check_keyframe_images(kf["depth"].download(), kf["normals"].download(), kf["radius"].download(), rgba[..., 3], kf["min_depth"], kf["max_depth"],
-                                 fix, k)
+        if check:
+            rgba = kf["color"].download()
+            assert np.array_equal(rgba[..., :3], fix["rgb"][k])
+            gr.check_keyframe_images(kf["depth"].download(), kf["normals"].download(), kf["radius"].download(), rgba[..., 3], kf["min_depth"],
+                                     kf["max_depth"], fix, k)
         kf["depth"].upload(np.ascontiguousarray(fix["depth"][k]))
         kf["normals"].upload(np.ascontiguousarray(fix["normals"][k]))
         kf["radius"].upload(np.ascontiguousarray(fix["radius"][k]))
@@ -52,6 +52,11 @@ def gpu(fix):
         kf["min_depth"], kf["max_depth"] = float(fix["min_max_depth"][k, 0]), float(fix["min_max_depth"][k, 1])
     g.bind_keyframes()
     return g
+
+
+@pytest.fixture(scope="module")
+def gpu(fix):
+    return _scene_with_reference_images(fix, check=True)
 
 
 def test_keyframe_preprocessing(gpu):
@@ -106,3 +111,55 @@ def test_deletion_then_compaction(fix, gpu):
     m = gpu.surfels_size
     assert m == n - int(fix["deleted_mask"].sum())
     assert np.array_equal(gr.digest(gpu.download_surfels()[:8], gpu.active_buf.download()[0, :m]), fix["compacted_digest"])
+
+
+def test_filtered_surfel_creation(fix, gpu):
+    gpu.upload_surfels(np.zeros((8, 0), np.float32), np.zeros(0, np.uint8))
+    counts = [gpu.create_surfels_for_keyframe(k, filter_new_surfels=True, min_observation_count=gr.MIN_OBSERVATIONS) for k in range(gr.KEYFRAMES)]
+    gr.check_created(gpu.download_surfels()[:8], counts, fix, prefix="filtered_")
+
+
+def test_colour_assignment(fix, gpu):
+    state = gr.perturbed_state(fix["created_rows"])
+    gpu.upload_surfels(state, np.zeros(state.shape[1], np.uint8))
+    gpu.bind_keyframes()
+    gpu.assign_colors()
+    gr.check_colours(gpu.download_surfels()[5].copy(), fix)
+
+
+@pytest.mark.parametrize("merge", [False, True])
+def test_supporting_surfels(fix, gpu, merge):
+    n = fix["created_rows"].shape[1]
+    gpu.upload_surfels(fix["created_rows"], np.zeros(n, np.uint8))
+    gpu.bind_keyframes()
+    planes, merged = gpu.determine_supporting_surfels(1, fix["frame_T_global"][1], merge=merge)
+    mask = gpu.surfel_buf.download()[0, :n].view(np.uint32) == 0x7fffffff
+    assert merged == int(mask.sum())
+    gr.check_supporting(planes, mask, merge, fix)
+
+
+def test_pcg_system(fix):
+    g = _scene_with_reference_images(fix, check=False)           # its own scene: the call adopts poses and intrinsics
+    state = gr.perturbed_state(fix["created_rows"])
+    n = state.shape[1]
+    g.upload_surfels(state, np.ones(n, np.uint8))
+    for k in range(gr.KEYFRAMES):
+        g.keyframes[k]["pose"] = np.asarray(fix["pcg_poses"][k], np.float32)
+    g.bind_keyframes()
+    cells = g.cf_w * g.cf_h
+    U = 6 * (gr.KEYFRAMES - 1) + 3 * n + 5 + cells + 4
+    g.pcg_iteration(optimize_poses=True, optimize_geometry=True, optimize_depth_intrinsics=True, optimize_color_intrinsics=True,
+                    max_inner_iterations=0, gauge_keyframe=gr.GAUGE_KEYFRAME)
+    gr.check_pcg_system(g.read_pcg_vector(0, U), g.read_pcg_vector(1, U), n, cells, fix)
+
+
+def test_intrinsics_step(fix):
+    g = _scene_with_reference_images(fix, check=False)           # its own scene: the step changes cameras and the cfactor image
+    state = gr.perturbed_state(fix["created_rows"])
+    g.upload_surfels(state, np.ones(state.shape[1], np.uint8))
+    gr.miscalibrate(g)
+    g.cfactor.upload(gr.miscalibrated_cfactor())
+    g.set_intrinsics()
+    g.bind_keyframes()
+    cc, dc, a = g.optimize_intrinsics(True, True)
+    gr.check_intrinsics_step([dc.fx, dc.fy, dc.cx, dc.cy], [cc.fx, cc.fy, cc.cx, cc.cy], a, g.cfactor.download(), fix)
