@@ -20,7 +20,7 @@
  * -- run on the host through a stand-in launcher (oracle/ref_shim/ref_kernels.cc, ref_preprocess.cc) in the
  * order of the reference's host drivers, stage against stage with the oracle (same test file);
  * the outputs of those kernels for a small scene are also COMMITTED as a golden file
- * (scripts/make_golden_reference_kernels.py -> tests/golden/reference_kernels.npz), replayed by the
+ * (tests/make_golden_reference_kernels.py -> tests/golden/reference_kernels.npz), replayed by the
  * oracle (tests/test_cpu_golden_reference.py) and by the HIP path (tests/test_gpu_golden_reference.py)
  * on machines that have neither the reference nor the library built from it;
  * (1) the reference's own closed-loop test criteria restated in

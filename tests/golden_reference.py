@@ -1,4 +1,4 @@
-"""What scripts/make_golden_reference_kernels.py (the generator of tests/golden/reference_kernels.npz: outputs of the REFERENCE's
+"""What tests/make_golden_reference_kernels.py (the generator of tests/golden/reference_kernels.npz: outputs of the REFERENCE's
 own kernels, stage by stage) and the two tests that replay the file -- tests/test_cpu_golden_reference.py with the oracle,
 tests/test_gpu_golden_reference.py with the HIP path -- have to agree on: the scene's constants and the deterministic
 perturbations applied between stages (plain binary32 arithmetic on the index, no random generator, so that every machine forms

@@ -9,7 +9,13 @@ the library built from it.
 Everything downstream of an input is produced by the reference's kernels from the reference's own earlier outputs (its filtered
 depth feeds its keyframe preprocessing, its keyframe images feed its surfel creation, ...); the oracle is used only as a container
 for arrays and for the SE(3) host arithmetic (pose -> 3 x 4 matrices), which the file stores as inputs.
-usage: python scripts/make_golden_reference_kernels.py [out.npz]"""
+Two runs of this script give the same file except for the stages in which the reference adds with binary32 atomics in arrival
+order (blocks run on OpenMP threads here as they run concurrently on a GPU): the pose normal equations, the dense entries of the PCG
+system and the intrinsics step differ between runs by ~1e-7 of their largest entry -- the reference's own run-to-run noise, a
+hundred times below the tolerances of tests/golden_reference.py.  Everything else is reproduced bit for bit.
+(The script lives under tests/ because it uses the oracle's bindings as a container: nothing outside tests/, smoke() and bench.py's
+cpu_baseline leg may import oracle/.)
+usage: python tests/make_golden_reference_kernels.py [out.npz]"""
 import ctypes as C
 import os
 import sys

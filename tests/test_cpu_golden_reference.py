@@ -1,5 +1,5 @@
 """The oracle against tests/golden/reference_kernels.npz: outputs of the REFERENCE's own kernels (its .cu files compiled for the
-host, scripts/make_golden_reference_kernels.py) for a three-keyframe scene, stage by stage -- depth filter, keyframe
+host, tests/make_golden_reference_kernels.py) for a three-keyframe scene, stage by stage -- depth filter, keyframe
 preprocessing, surfel creation (plain and filtered), activation + geometry step, pose normal equations, deletion + radius update,
 compaction, colour assignment, supporting surfels + merging, the PCG system, the intrinsics step.  Unlike
 tests/test_cpu_oracle_vs_reference.py this needs neither /root/reference nor the library built from it: the file is committed.

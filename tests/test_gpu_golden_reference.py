@@ -1,5 +1,5 @@
 """The HIP path, called through the C ABI, against tests/golden/reference_kernels.npz: outputs of the REFERENCE's own kernels (its
-.cu files compiled for the host, scripts/make_golden_reference_kernels.py) for a three-keyframe scene, stage by stage -- depth
+.cu files compiled for the host, tests/make_golden_reference_kernels.py) for a three-keyframe scene, stage by stage -- depth
 filter, keyframe preprocessing, surfel creation (plain and filtered), activation + geometry step, pose normal equations, deletion +
 radius update, compaction, colour assignment, supporting surfels + merging, the PCG system, the intrinsics step.  The checks and their tolerances are the ones tests/test_cpu_golden_reference.py applies to the oracle
 (tests/golden_reference.py); neither /root/reference nor the oracle is needed here."""
