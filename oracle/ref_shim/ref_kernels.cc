@@ -128,10 +128,51 @@ CUDAMatrix3x4 pose_of(const ref_ba_keyframe& kf) {
   return F;
 }
 
-SurfelProjectionParameters projection_of(const ref_ba_scene* sc, const Bound& b, const ref_ba_keyframe& kf) {   // B/surfel_projection.h:69-84
+// The projection parameters of one launch over keyframe `kf`, and a guard around that launch.  ProjectSurfelToImage (B/util.cuh:83-118)
+// converts the projected pixel to int BEFORE testing it: CUDA's conversion saturates and turns NaN into 0, so on the GPU a surfel
+// marked deleted (x = NaN: pixel (0, 0), whose depth is always invalid) or projecting beyond 2^31 (INT_MAX >= width) is simply not
+// associated; the host's conversion yields INT_MIN for both, which passes every test and reads depth_buffer(py, INT_MIN).  To give
+// the kernels the outcome they have on their own platform, such surfels are parked behind the keyframe's camera for the duration of
+// the launch (local z = -1: rejected by the first test of the association, nothing is read or written for them) and put back, bit
+// for bit, when the temporary dies at the end of the launch expression.
+struct GuardedProjection {
+  SurfelProjectionParameters params;
+  CUDABuffer_<float> surfels;
+  std::vector<uint32_t> parked;        // surfel index, then the three original words
+  operator SurfelProjectionParameters() const { return params; }
+  GuardedProjection(const SurfelProjectionParameters& p, const CUDABuffer_<float>& s) : params(p), surfels(s) {}
+  GuardedProjection(GuardedProjection&& other) : params(other.params), surfels(other.surfels), parked(std::move(other.parked)) { other.parked.clear(); }
+  GuardedProjection(const GuardedProjection&) = delete;
+  ~GuardedProjection() {
+    for (size_t e = 0; e + 3 < parked.size(); e += 4)
+      for (int c = 0; c < 3; ++c) std::memcpy(&surfels(kSurfelX + c, parked[e]), &parked[e + 1 + c], sizeof(uint32_t));
+  }
+};
+
+GuardedProjection projection_of(const ref_ba_scene* sc, const Bound& b, const ref_ba_keyframe& kf) {   // B/surfel_projection.h:69-84
   CUDABuffer_<u16> depth_buffer(kf.depth, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
   CUDABuffer_<u16> normals_buffer(kf.normals, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
-  return SurfelProjectionParameters(b.surfels, depth_buffer, normals_buffer, b.dp, b.depth_projector, b.unprojector, pose_of(kf), sc->surfels_size);
+  const CUDAMatrix3x4 F = pose_of(kf);
+  GuardedProjection guarded(SurfelProjectionParameters(b.surfels, depth_buffer, normals_buffer, b.dp, b.depth_projector, b.unprojector, F, sc->surfels_size), b.surfels);
+  // behind the camera: p with F p = (0, 0, -1), i.e. p = R^T ((0, 0, -1) - t)
+  const float3 d = make_float3(-F.row0.w, -F.row1.w, -1.f - F.row2.w);
+  const float safe[3] = {F.row0.x * d.x + F.row1.x * d.y + F.row2.x * d.z, F.row0.y * d.x + F.row1.y * d.y + F.row2.y * d.z,
+                         F.row0.z * d.x + F.row1.z * d.y + F.row2.z * d.z};
+  for (uint32_t i = 0; i < sc->surfels_size; ++i) {
+    const float3 global_position = SurfelGetPosition(b.surfels, i);
+    float3 local_position;
+    if (!F.MultiplyIfResultZIsPositive(global_position, &local_position)) continue;   // rejected there anyway
+    const float2 p = b.depth_projector.Project(local_position);
+    if (p.x < 2147483648.f && p.y < 2147483648.f) continue;                           // (false for NaN too)
+    guarded.parked.push_back(i);
+    for (int c = 0; c < 3; ++c) {
+      uint32_t word;
+      std::memcpy(&word, &guarded.surfels(kSurfelX + c, i), sizeof(word));
+      guarded.parked.push_back(word);
+      guarded.surfels(kSurfelX + c, i) = safe[c];
+    }
+  }
+  return guarded;
 }
 
 constexpr int kInactive = 2;
@@ -142,7 +183,8 @@ extern "C" {
 
 // flags[i] |= 1 where surfel i, projected into some keyframe, lands beyond the int range: CUDA's float -> int conversion
 // saturates there (the pixel is outside the image), the host's yields INT_MIN and the reference's bounds test lets it through
-// (see pixel_outside_int_range in ref_entry.cc).  A caller keeps such surfels out of a whole-kernel comparison.
+// (see pixel_outside_int_range in ref_entry.cc).  The launch guard of projection_of gives the kernels CUDA's outcome for such surfels;
+// this function lets a test see whether a scene has any.
 void ref_flag_pairs_outside_int_range(const ref_ba_scene* sc, uint8_t* flags) {
   const Bound b(sc);
   for (int k = 0; k < sc->num_keyframes; ++k) {
@@ -348,22 +390,13 @@ uint32_t ref_create_surfels_for_keyframe(const ref_ba_scene* sc, int keyframe_in
 // AccumulatePoseEstimationCoeffsCUDA (B/kernel_opt_pose.cc:38-96): H (21 entries, row-major upper triangle) and b (6) of the pose
 // normal equations of keyframe `keyframe_index`'s images at the pose estimate `frame_T_global` (3x4), over all surfels, by the
 // reference's kernel: per-thread Jacobians, 27 block reductions per residual (B/gauss_newton.cuh:46-93; here the block total is a
-// binary64 sum of the binary32 terms, cub/cub.cuh), one binary32 atomicAdd per block and entry.  Returns -1 without computing
-// if a surfel projects beyond the int range at this pose (see ref_flag_pairs_outside_int_range), else 0.
+// binary64 sum of the binary32 terms, cub/cub.cuh), one binary32 atomicAdd per block and entry.  Returns 0 (surfels that project
+// beyond the int range or are marked deleted are handled by the launch guard of projection_of).
 int ref_accumulate_pose_estimation_coeffs(const ref_ba_scene* sc, int keyframe_index, const float* frame_T_global, int use_depth_residuals,
                                           int use_descriptor_residuals, float* H, float* b) {
   const Bound bound(sc);
   ref_ba_keyframe kf = sc->keyframes[keyframe_index];
   memcpy(kf.frame_T_global, frame_T_global, sizeof(kf.frame_T_global));
-  {
-    const CUDAMatrix3x4 F = pose_of(kf);
-    for (uint32_t i = 0; i < sc->surfels_size; ++i) {
-      float3 local_position;
-      if (!F.MultiplyIfResultZIsPositive(SurfelGetPosition(bound.surfels, i), &local_position)) continue;
-      const float2 p = bound.depth_projector.Project(local_position);
-      if (!(p.x < 2147483648.f && p.y < 2147483648.f)) return -1;
-    }
-  }
   u32 residual_count = 0;
   float residual_sum = 0;
   for (int c = 0; c < 21; ++c) H[c] = 0;
@@ -385,16 +418,10 @@ int ref_accumulate_pose_estimation_coeffs(const ref_ba_scene* sc, int keyframe_i
 //   6 per keyframe except the gauge keyframe | 1 or 3 per surfel (offset along the normal, descriptors) | fx^-1 fy^-1 cx^-1 cy^-1 a
 //   + one cfactor per sparse cell | 4 colour intrinsics
 // in that order, each block only if it is optimised.  Dense entries are block sums added with binary32 atomics (arrival order),
-// surfel entries per-thread sums keyframe by keyframe.  Returns the number of unknowns (0 if r / M are too short or a surfel
-// projects beyond the int range in some keyframe).
+// surfel entries per-thread sums keyframe by keyframe.  Returns the number of unknowns (0 if r / M are too short).
 uint32_t ref_pcg_assemble(const ref_ba_scene* sc, int optimize_poses, int optimize_geometry, int use_depth_residuals, int use_descriptor_residuals,
                           int optimize_depth_intrinsics, int optimize_color_intrinsics, int gauge_keyframe, float* r, float* M, uint32_t capacity) {
   const Bound bound(sc);
-  {
-    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
-    ref_flag_pairs_outside_int_range(sc, flags.data());
-    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return 0;
-  }
   constexpr u32 kInvalidUnknownIndex = 0xffffffffu;
   const int K = sc->num_keyframes;
   u32 current = 0;
@@ -426,14 +453,9 @@ uint32_t ref_pcg_assemble(const ref_ba_scene* sc, int optimize_poses, int optimi
 // The accumulation of OptimizeIntrinsicsCUDA (B/kernel_opt_intrinsics.cc:39-104): buffers cleared, then the accumulation kernel
 // once per keyframe.  glob[34]: A (15, row-major upper triangle of the 5 x 5 block of fx^-1 fy^-1 cx^-1 cy^-1 a), b1 (5), colour
 // H (10), colour b (4); cells[8 S], per sparse cell: B0..B4, D, b2, observation count -- the layout of orc_intrinsics_accumulate.
-// Returns -1 if a surfel projects beyond the int range in some keyframe, else 0.
+// Returns 0.
 int ref_intrinsics_accumulate(const ref_ba_scene* sc, int optimize_depth_intrinsics, int optimize_color_intrinsics, float* glob, float* cells) {
   const Bound bound(sc);
-  {
-    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
-    ref_flag_pairs_outside_int_range(sc, flags.data());
-    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return -1;
-  }
   const int S = sc->cf_width * sc->cf_height;
   std::vector<u32> observation_count(S, 0);
   std::vector<float> depth_A(15, 0.f), depth_B(5 * (size_t)S, 0.f), depth_D(S, 0.f), depth_b1(5, 0.f), depth_b2(S, 0.f), color_H(10, 0.f), color_b(4, 0.f);
@@ -468,15 +490,10 @@ int ref_intrinsics_accumulate(const ref_ba_scene* sc, int optimize_depth_intrins
 // system assembled by PCGInit per keyframe, PCGInit2, then up to max_inner_iterations steps of PCGStep1 per keyframe / PCGStep2 /
 // the stopping rule of :441-456 / PCGStep3, and UpdateSurfelsFromPCGDeltaCUDA.  The surfels are updated in place; the pose block of
 // delta (6 (K - 1) values, gauge keyframe left out) is returned for the caller to apply T <- T * exp(delta) (:566-583, host code).
-// Returns the number of inner steps taken, or -1 (a surfel beyond the int range in some keyframe).
+// Returns the number of inner steps taken.
 int ref_pcg_outer_iteration(const ref_ba_scene* sc, int use_depth_residuals, int use_descriptor_residuals, int gauge_keyframe, int max_inner_iterations,
                             float* pose_delta) {
   const Bound bound(sc);
-  {
-    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
-    ref_flag_pairs_outside_int_range(sc, flags.data());
-    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return -1;
-  }
   const int K = sc->num_keyframes;
   memset(sc->active, kSurfelActiveFlag, sc->surfels_size);                                                            // :212-216
   CallResetSurfelAccum0to3CUDAKernel(nullptr, sc->surfels_size, bound.surfels, bound.active);                        // UpdateSurfelNormalsCUDA
@@ -580,15 +597,10 @@ extern "C" {
 // kernels: accumulation once per keyframe, the Schur complement kernel, the 5 x 5 solve with the prior on `a` (host code of the
 // reference, :120-195, restated: binary64 solve), the per-cell back-substitution kernel -- which updates sc->cfactor in place --
 // and the 4 x 4 solve of the colour camera (:255-279).  Outputs: the new depth and colour cameras (fx, fy, cx, cy) and `a`.
-// Returns -1 if a surfel projects beyond the int range in some keyframe, else 0.
+// Returns 0.
 int ref_optimize_intrinsics(const ref_ba_scene* sc, int optimize_depth_intrinsics, int optimize_color_intrinsics, float* out_depth_cam, float* out_color_cam,
                             float* out_a) {
   const Bound bound(sc);
-  {
-    std::vector<uint8_t> flags(sc->surfels_size ? sc->surfels_size : 1, 0);
-    ref_flag_pairs_outside_int_range(sc, flags.data());
-    for (uint32_t i = 0; i < sc->surfels_size; ++i) if (flags[i]) return -1;
-  }
   for (int c = 0; c < 4; ++c) { out_depth_cam[c] = sc->depth_cam[c]; out_color_cam[c] = sc->color_cam[c]; }
   *out_a = sc->a;
   const int S = sc->cf_width * sc->cf_height;
