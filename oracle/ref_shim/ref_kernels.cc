@@ -365,10 +365,30 @@ uint32_t ref_create_surfels_for_keyframe(const ref_ba_scene* sc, int keyframe_in
       M.row0 = make_float4(covis_T_frame[12 * c + 0], covis_T_frame[12 * c + 1], covis_T_frame[12 * c + 2], covis_T_frame[12 * c + 3]);
       M.row1 = make_float4(covis_T_frame[12 * c + 4], covis_T_frame[12 * c + 5], covis_T_frame[12 * c + 6], covis_T_frame[12 * c + 7]);
       M.row2 = make_float4(covis_T_frame[12 * c + 8], covis_T_frame[12 * c + 9], covis_T_frame[12 * c + 10], covis_T_frame[12 * c + 11]);
-      CallCountObservationsForNewSurfelsCUDAKernel(nullptr, (int)new_surfel_count, new_surfel_index_list, observation_vector, free_space_violation_vector, b.dp,
-                                                   b.unprojector, depth_buffer, normals_buffer, M, b.depth_projector,
-                                                   CUDABuffer_<u16>(other.depth, sc->height, sc->width, (size_t)sc->width * sizeof(u16)),
-                                                   CUDABuffer_<u16>(other.normals, sc->height, sc->width, (size_t)sc->width * sizeof(u16)));
+      // The kernel projects every candidate into the co-visible keyframe through ProjectSurfelToImage: a candidate whose pixel there lies
+      // beyond the int range is outside the image on the GPU (saturating conversion) and reads depth_buffer(py, INT_MIN) on the host
+      // (see GuardedProjection).  Such candidates -- one in ~1e8 pairs -- are left out of the launch: the kernel runs on the stretches
+      // of the candidate list between them, which is what the GPU's early return amounts to.
+      const CUDABuffer_<u16> covis_depth(other.depth, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+      const CUDABuffer_<u16> covis_normals(other.normals, sc->height, sc->width, (size_t)sc->width * sizeof(u16));
+      auto beyond_int_range = [&](u32 candidate) {
+        const u32 pixel = new_surfel_index_list[candidate], y = pixel / (u32)sc->width, x = pixel - y * (u32)sc->width;
+        const float depth = RawToCalibratedDepth(b.dp.a, b.dp.cfactor_buffer(y / b.dp.sparse_surfel_cell_size, x / b.dp.sparse_surfel_cell_size),
+                                                 b.dp.raw_to_float_depth, depth_buffer(y, x));
+        float3 local_position;
+        if (!M.MultiplyIfResultZIsPositive(b.unprojector.UnprojectPoint(x, y, depth), &local_position)) return false;
+        const float2 p = b.depth_projector.Project(local_position);
+        return !(p.x < 2147483648.f && p.y < 2147483648.f);
+      };
+      u32 first = 0;
+      for (u32 candidate = 0; candidate <= new_surfel_count; ++candidate) {
+        if (candidate < new_surfel_count && !beyond_int_range(candidate)) continue;
+        if (candidate > first)
+          CallCountObservationsForNewSurfelsCUDAKernel(nullptr, (int)(candidate - first), new_surfel_index_list + first, observation_vector + first,
+                                                       free_space_violation_vector + first, b.dp, b.unprojector, depth_buffer, normals_buffer, M,
+                                                       b.depth_projector, covis_depth, covis_normals);
+        first = candidate + 1;
+      }
     }
     CallFilterNewSurfelsCUDAKernel(nullptr, (u16)min_observation_count, new_surfel_count, new_surfel_index_list, observation_vector,
                                    free_space_violation_vector, flag_vector);
