@@ -15,6 +15,7 @@ MAX_DEPTH_M = 3.2
 ACTIVATIONS = (0, 1, 2)                 # kActive, kCovisibleActive, kInactive (B/keyframe.h:54-67)
 MIN_OBSERVATIONS = 2
 GAUGE_KEYFRAME = 1
+ALTERNATING_ITERATIONS = 2
 GEOMETRY_ROWS = [0, 1, 2, 3, 6, 7]      # what the geometry step writes: position, packed normal, the two descriptors
 
 
@@ -242,3 +243,20 @@ def check_intrinsics_step(depth_camera, colour_camera, a, cfactor, fix):
     d = np.abs(np.asarray(cfactor, np.float32) - fix["intrinsics_cfactor"])
     assert d.max() < 1e-5 and np.median(d) < 1e-6
     assert np.median(np.abs(fix["intrinsics_cfactor"] - miscalibrated_cfactor())) > 3e-4
+
+
+def check_alternating_iterations(poses, positions, gn_steps, fix):
+    """Stage 11, BASELINE's bar ("pose RMSE within 1e-5 m of reference", surfel positions alike) after two alternating iterations from
+    poses 2 mm / 0.5 mrad off and surfels up to 4 mm off: translations and rotations within 2e-6 of the reference's kernels (RMSE
+    below 1e-6 m), positions within 2e-6 m for 99.9 % of the surfels, the same number of Gauss-Newton steps up to two."""
+    from badslam_amd import se3
+    want = fix["alternating_poses"]
+    poses = np.asarray(poses, np.float64)
+    dt = np.linalg.norm(poses[:, 4:] - want[:, 4:], axis=1)
+    dr = np.array([np.linalg.norm(se3.log(se3.mul(se3.inverse(want[k]), poses[k]))[3:]) for k in range(KEYFRAMES)])
+    moved = np.linalg.norm(want[:, 4:] - fix["pcg_poses"][:, 4:].astype(np.float64), axis=1).max()
+    assert moved > 1e-3                                                      # the poses did move
+    assert np.sqrt(np.mean(dt ** 2)) < 1e-6 and dt.max() < 2e-6 and dr.max() < 2e-6, (dt, dr)
+    d = np.abs(np.asarray(positions, np.float32) - fix["alternating_positions"]).max(axis=0)
+    assert np.percentile(d, 99.9) < 2e-6 and np.count_nonzero(d > 1e-5) <= 2e-3 * d.size, (np.percentile(d, 99.9), d.max())
+    assert abs(int(gn_steps) - int(fix["alternating_gn_steps"])) <= 2

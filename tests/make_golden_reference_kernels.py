@@ -151,6 +151,27 @@ depth_camera, colour_camera, a = ref.optimize_intrinsics(True, True)
 fix["intrinsics_depth_camera"], fix["intrinsics_colour_camera"], fix["intrinsics_a"] = depth_camera, colour_camera, np.float32(a)
 fix["intrinsics_cfactor"] = ref.cfactor.copy()
 
+# ---- stage 11: two alternating BA iterations end to end (activation, geometry step, Gauss-Newton pose estimation of every keyframe) ---
+orc2 = gr.oracle_with_reference_images(fix, capacity=gr.CAPACITY)      # calibrated cameras again, every keyframe active
+orc2.surfel_data[:8, :N] = state
+orc2.surfels.surfels_size = orc2.surfels.surfel_count = N
+for k in range(K):
+    orc2.set_pose(k, fix["pcg_poses"][k])
+ref = rb.ReferenceKernels(orc2)
+poses = [np.asarray(T, np.float64) for T in fix["pcg_poses"]]
+steps = 0
+for iteration in range(gr.ALTERNATING_ITERATIONS):
+    ref.update_surfel_activation()
+    ref.optimize_geometry_iteration(True, True)
+    for k in range(K):
+        poses[k], n = ref.estimate_frame_pose(k, poses[k])
+        steps += n
+    for k in range(K):                                                   # poses take effect after the phase
+        ref.set_pose(k, poses[k])
+fix["alternating_poses"] = np.asarray(poses, np.float64)
+fix["alternating_positions"] = ref.surfel_data[:3, :N].copy()
+fix["alternating_gn_steps"] = np.int32(steps)
+
 np.savez_compressed(out_path, **fix)
 print(out_path, os.path.getsize(out_path), "bytes;", N, "surfels created", fix["created_counts"].tolist(), "; active", int(fix["active_flags"].sum()),
       "; deleted", deleted)

@@ -158,3 +158,25 @@ def test_intrinsics_step(fix):
     gr.miscalibrate(ba)
     cc, dc, a = ba.optimize_intrinsics(True, True)
     gr.check_intrinsics_step([dc.fx, dc.fy, dc.cx, dc.cy], [cc.fx, cc.fy, cc.cx, cc.cy], a, ba.cfactor, fix)
+
+
+def test_alternating_iterations_end_to_end(fix):
+    ba = gr.oracle_with_reference_images(fix)
+    state = gr.perturbed_state(fix["created_rows"])
+    n = state.shape[1]
+    _load(ba, state)
+    poses = [np.asarray(T, np.float64) for T in fix["pcg_poses"]]
+    for k in range(gr.KEYFRAMES):
+        ba.set_pose(k, poses[k])
+    ba.use_depth = ba.use_desc = 1
+    steps = 0
+    for _ in range(gr.ALTERNATING_ITERATIONS):
+        ba.update_surfel_activation()
+        ba.optimize_geometry_iteration()
+        for k in range(gr.KEYFRAMES):
+            estimate, its, _ = ba.estimate_frame_pose(k, poses[k])
+            poses[k] = estimate.to_array()
+            steps += its
+        for k in range(gr.KEYFRAMES):
+            ba.set_pose(k, poses[k])
+    gr.check_alternating_iterations(poses, ba.surfel_data[:3, :n], steps, fix)

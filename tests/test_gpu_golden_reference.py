@@ -163,3 +163,26 @@ def test_intrinsics_step(fix):
     g.bind_keyframes()
     cc, dc, a = g.optimize_intrinsics(True, True)
     gr.check_intrinsics_step([dc.fx, dc.fy, dc.cx, dc.cy], [cc.fx, cc.fy, cc.cx, cc.cy], a, g.cfactor.download(), fix)
+
+
+def test_alternating_iterations_end_to_end(fix):
+    """BASELINE's bar, HIP path against the reference's own kernels: keyframe poses and surfel positions after two alternating
+    iterations (activation, geometry step, batched Gauss-Newton pose estimation)."""
+    g = _scene_with_reference_images(fix, check=False)           # its own scene: the poses change
+    state = gr.perturbed_state(fix["created_rows"])
+    n = state.shape[1]
+    g.upload_surfels(state, np.zeros(n, np.uint8))
+    for k in range(gr.KEYFRAMES):
+        g.keyframes[k]["pose"] = np.asarray(fix["pcg_poses"][k], np.float32)
+    g.bind_keyframes()
+    steps = 0
+    poses = None
+    for _ in range(gr.ALTERNATING_ITERATIONS):
+        g.update_surfel_activation()
+        g.optimize_geometry_iteration(True, True)
+        poses, its, _, _ = g.estimate_keyframe_poses(True, True)
+        steps += int(np.sum(its))
+        for k in range(gr.KEYFRAMES):
+            g.keyframes[k]["pose"] = np.asarray(poses[k], np.float32)
+        g.bind_keyframes()
+    gr.check_alternating_iterations(poses, g.download_surfels()[:3], steps, fix)
