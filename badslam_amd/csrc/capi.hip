@@ -1370,7 +1370,7 @@ static int ensure_pcg_exact(bahip_context* ctx, uint32_t head_count) {
   if (need <= ctx->pcg_exact_capacity && ctx->pcg_exact) return 0;
   void* grown = nullptr;
   HIP_TRY(hipMalloc(&grown, sizeof(ExactCell) * (need + need / 8)));
-  hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl);
+  hipFree(ctx->pcg_exact);   // (pcg_stage_ctl is an allocation of its own, 64 bytes, and stays: ADVICE r3 -- it was freed here and used afterwards)
   ctx->pcg_exact = grown;
   ctx->pcg_exact_capacity = need + need / 8;
   return 0;

@@ -4,6 +4,7 @@
 // does the same three things: describe the caller's buffers as bahip_* structs (pointers are borrowed), bind cameras / depth
 // parameters / keyframes, call the one bahip_* function that replaces the reference function, and turn a failure into
 // LOG(FATAL) like the reference's CUDA_CHECK().  One backend context per host thread, re-pointed at the caller's stream.
+#include <algorithm>
 #include "badslam/kernels.h"
 
 namespace vis {
@@ -278,15 +279,28 @@ void PCGInitCUDA(cudaStream_t stream, const SurfelProjectionParameters& s, const
   BindFromProjection(ctx, s, depth_to_color, color_projector);
   PcgSession& session = Session();
   if (!session.begun) {
-    // (whether a keyframe's pose is an unknown is said per call -- the reference passes optimize_poses = false for the gauge
-    // keyframe -- so the layout itself only needs the block boundaries; the unknown count is the width of the caller's vectors)
-    session.layout = Layout((u32)pcg_r->width(), true, optimize_geometry, use_depth_residuals, use_descriptor_residuals, optimize_depth_intrinsics,
+    // Whether a keyframe's pose is an unknown is said per call (the reference passes optimize_poses = false for the gauge
+    // keyframe), so the layout itself only needs the block boundaries.  The unknown count is NOT the width of the caller's
+    // vectors: the reference allocates them for max_unknown_count (B/direct_ba_pcg.cc:249-268) and hands the count of this
+    // outer iteration to PCGInit2CUDA only.  It follows from the block starts (the unknown ordering of :270-300: poses,
+    // surfels, 4 + 1 + cfactor cells, 4): the end of the last block present.  With poses as the only unknowns nothing but the
+    // width bounds it; PCGInit2CUDA then says how many of those entries exist (a smaller head is accepted there).
+    const u32 cfactor_cells = (u32)s.depth_params.cfactor_buffer.width() * (u32)s.depth_params.cfactor_buffer.height();
+    // (poses only: at most 65 536 keyframes' worth of exact accumulators, not 72 bytes for every entry of a vector that was
+    // sized for all surfels)
+    u32 unknown_count = std::min<u32>((u32)pcg_r->width(), 6u * 65536u);
+    if (optimize_color_intrinsics) unknown_count = color_intrinsics_unknown_start_index + 4;
+    else if (optimize_depth_intrinsics) unknown_count = depth_intrinsics_unknown_start_index + 5 + cfactor_cells;
+    else if (optimize_geometry) unknown_count = surfel_unknown_start_index + (use_descriptor_residuals ? 3u : 1u) * surfels_size;
+    CHECK_LE(unknown_count, (u32)pcg_r->width()) << "the PCG vectors are narrower than the unknown layout";
+    session.layout = Layout(unknown_count, true, optimize_geometry, use_depth_residuals, use_descriptor_residuals, optimize_depth_intrinsics,
                             optimize_color_intrinsics, surfel_unknown_start_index, depth_intrinsics_unknown_start_index,
                             color_intrinsics_unknown_start_index);
     session.surfels_size = surfels_size;
     BAHIP_CHECKED_CALL(bahip_pcg_begin(ctx, &session.layout, surfels_size));
     session.begun = true;
   }
+  if (optimize_poses) CHECK_LE(kf_pose_unknown_index + 6, session.layout.unknown_count) << "pose unknown outside the layout";
   const bahip_frame frame = FrameFromProjection(s, color_texture);
   const bahip_surfels surfels = SurfelsFromProjection(s);
   BAHIP_CHECKED_CALL(bahip_pcg_init(ctx, &session.layout, &frame, &s.frame_T_global.row0.x, kf_pose_unknown_index, optimize_poses ? 1 : 0, &surfels,
@@ -299,7 +313,9 @@ void PCGInit2CUDA(cudaStream_t stream, u32 unknown_count, u32 /*a_unknown_index:
   bahip_context* ctx = Ctx(stream);
   PcgSession& session = Session();
   CHECK(session.begun) << "PCGInit2CUDA without a preceding PCGInitCUDA";
-  session.layout.unknown_count = unknown_count;
+  CHECK_LE(unknown_count, session.layout.unknown_count) << "PCGInit2CUDA: more unknowns than the layout PCGInitCUDA described";
+  if (session.layout.optimize_geometry || session.layout.optimize_depth_intrinsics || session.layout.optimize_color_intrinsics)
+    CHECK_EQ(unknown_count, session.layout.unknown_count) << "PCGInit2CUDA: the unknown count differs from the block layout PCGInitCUDA described";
   BAHIP_CHECKED_CALL(bahip_pcg_init2(ctx, &session.layout, session.surfels_size, a, pcg_r.address(), pcg_M.address(), pcg_delta->address(),
                                      pcg_g->address(), pcg_p->address(), pcg_alpha_n->address()));
   session.begun = false;   // the next PCGInitCUDA starts a new outer iteration

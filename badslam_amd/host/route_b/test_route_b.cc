@@ -125,7 +125,10 @@ int main() {
     const u32 pose_unknowns = 6 * (K - 1), U = pose_unknowns + 3 * N, kInvalid = 0xffffffffu;
     active.Clear(1, stream);
     UpdateSurfelNormalsCUDA(stream, camera, dp, keyframes, N, surfels, active);
-    CUDABuffer<PCGScalar> r(1, U), M(1, U), delta(1, U), g(1, U), p(1, U), alpha_n_buf(1, 1), alpha_d(1, 1), beta_n_buf(1, 1);
+    // the vectors are as wide as the reference allocates them (max_unknown_count, B/direct_ba_pcg.cc:249-268: room for every
+    // surfel the buffer can hold, 64 keyframes, the depth and colour intrinsics), not U wide
+    const u32 Umax = 6 * 63 + 3 * (u32)surfels.width() + 5 + (u32)(dp.cfactor_buffer.width() * dp.cfactor_buffer.height()) + 4;
+    CUDABuffer<PCGScalar> r(1, Umax), M(1, Umax), delta(1, Umax), g(1, Umax), p(1, Umax), alpha_n_buf(1, 1), alpha_d(1, 1), beta_n_buf(1, 1);
     CUDABuffer<PCGScalar>*alpha_n = &alpha_n_buf, *beta_n = &beta_n_buf;
     r.Clear(0, stream); M.Clear(0, stream);
     const float* c = camera.parameters();

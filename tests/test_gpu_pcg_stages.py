@@ -67,6 +67,11 @@ def test_stage_api_reproduces_the_fused_iteration(mode):
     frames = [h.frame_struct(k) for k in range(K)]
     # frame_T_global of a pose with the bits the backend's own keyframe table holds (the oracle's SE(3) inverse is the device's)
     Fs = [(C.c_float * 12)(*[float(v) for v in ob.se3_matrix3x4(ob.se3_inverse(ob.SE3.from_array(h.keyframes[k]["pose"])))]) for k in range(K)]
+    if di:
+        # a smaller layout first on the same context: the exact accumulators then REGROW for the real layout (its
+        # head has the S cfactor cells), and the 64-byte control block -- an allocation of its own -- must survive that
+        small = capi.PCGLayout(1, 1, 0, 0, 1, 1, 6 * (K - 1) + 3 * N, 6 * (K - 1), INVALID, INVALID)
+        capi.check(lib.bahip_pcg_begin(ctx, C.byref(small), N))
     capi.check(lib.bahip_pcg_begin(ctx, C.byref(layout), N))
     for k in range(K):
         capi.check(lib.bahip_pcg_init(ctx, C.byref(layout), C.byref(frames[k]), Fs[k], _pose_index(k, gauge), int(k != gauge), C.byref(s), r.ptr, M.ptr))
