@@ -163,6 +163,8 @@ SIGNATURES = {
     "bahip_debug_set_launch_shapes": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_pose_form": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_items": (C.c_int, [C.c_int]),
+    "bahip_debug_set_pose_lds_shape": (C.c_int, [C.c_int, C.c_int]),
+    "bahip_debug_set_pose_rounds_ahead": (C.c_int, [C.c_int]),
     "bahip_debug_pose_form_launches": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "bahip_debug_pose_limbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_longlong)]),
     "bahip_debug_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),

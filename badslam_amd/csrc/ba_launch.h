@@ -55,7 +55,11 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
                             uint32_t* tile_counters /* 16 words, zero before the first launch; NULL: never the persistent LDS form */,
                             int* parity_inout /* which half of tile_counters the next persistent launch draws from */,
                             uint32_t* tile_cost = nullptr /* one word per tile, zero before a first round: += the candidates the tile visits */,
-                            const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
+                            const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */,
+                            const int* listed_count = nullptr /* device word holding num_listed (a round queued before the host
+                            knows it; num_listed is then an upper bound and sizes the LDS table); 0 there: the launch does nothing */);
+// May a later round over at most num_items work items be queued ahead (launch_pose_accumulate with listed_count)?
+bool pose_round_can_be_queued_ahead(uint32_t surfels, int num_items, bool have_tile_counters);
 uint32_t pose_padded_tiles(uint32_t surfels);   // tiles of the (padded) grid the sweeps run over: the length of tile_cost
 size_t tile_schedule_words(uint32_t padded_tiles);   // words of a schedule for such a grid
 // sched := heavy tiles + runs by descending cost (wave_cull.h; clears tile_cost); false if there are more runs than the kernel
@@ -72,6 +76,8 @@ void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, 
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
+void set_pose_lds_waves(int waves);        // test hook: wavefronts per workgroup of the LDS form (0: 16)
+void set_pose_lds_parts_shift(int shift);  // test hook: 2^shift wavefronts share a tile's work items in the LDS form (-1: from the grid size)
 void set_pose_lds_items(int items);   // test hook: slices of that many work items per launch of the LDS form (0: as many as the table holds)
 void pose_form_launches(long long out[2], bool reset);   // launches of either form since the last reset (bench: which kernel to name)
 void set_pose_form(int form);     // 0 = automatic; 1 = one tile per wavefront + global atomics; 2 = persistent workgroups with the normal equations in LDS

@@ -119,6 +119,9 @@ struct bahip_context {
   size_t tile_schedule_capacity = 0;   // tiles
   uint32_t tile_order_tiles = 0;
   int phases_since_schedule = 0;       // the schedule is rebuilt when the grid changes and every kSchedulePhases-th phase
+  uint32_t tile_order_unavailable_tiles = 0;   // a grid the order kernel cannot schedule (too many runs): no census for it again
+  bool tile_order_unavailable_for(uint32_t padded_tiles) const { return padded_tiles != 0 && tile_order_unavailable_tiles == padded_tiles; }
+  int rounds_hint_table = 1, rounds_hint_frame = 1;   // Gauss-Newton rounds the previous pose phase took (keyframe table / single frame)
 
   float* intr_scratch = nullptr;   // intrinsics step: (64 + 8 S) doubles, then (64 + 8 S) floats + Schur partials
   int intr_capacity = 0;
@@ -354,7 +357,10 @@ int ensure_tile_schedule(bahip_context* ctx, uint32_t padded_tiles) {
     hipFree(cost); hipFree(order);
     return fail("allocation of the tile schedule failed", __FILE__, __LINE__);
   }
-  HIP_TRY(hipMemsetAsync(cost, 0, sizeof(uint32_t) * cap, ctx->stream));
+  if (hipMemsetAsync(cost, 0, sizeof(uint32_t) * cap, ctx->stream) != hipSuccess) {
+    hipFree(cost); hipFree(order);
+    return fail("clearing the tile census failed", __FILE__, __LINE__);
+  }
   hipFree(ctx->dev_tile_cost); hipFree(ctx->dev_tile_order);
   ctx->dev_tile_cost = cost; ctx->dev_tile_order = order;
   ctx->tile_schedule_capacity = cap;
@@ -395,52 +401,81 @@ int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_work, const PoseWo
 }
 
 // Batched Gauss-Newton rounds over `num_work` work items already initialised on the device.
+//
+// Rounds are queued AHEAD of the host (round 4): a later round's accumulate launch reads the number of work items still
+// iterating from the counter the previous round's solve kernel left on the device (and does nothing when it is zero), so a
+// batch of rounds -- accumulate, exchange, solve each -- goes out without the host in between, and the host waits once per
+// batch, for the last solve's sequence number.  The batch size follows the previous phase on the same table (*rounds_hint):
+// in the steady state of a BA loop a phase needs one or two rounds and costs one host reaction instead of one per round.
+// A round queued in vain costs two near-empty launches (and, sharded, an exchange of zeros); results do not depend on the batch
+// size (tests run 1, the default and 4).
+int g_pose_rounds_ahead = [] { const char* e = getenv("BAHIP_POSE_ROUNDS_AHEAD"); return e ? atoi(e) : 0; }();
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
                     PoseWork* host_work /* page-locked, num_work + kPoseTailRecords records */, int* rounds_out,
                     bool schedule = false /* a phase over the keyframe table: its first round counts the candidates per tile and the
-                    run order of the following sweeps is rebuilt from them */) {
+                    run order of the following sweeps is rebuilt from them */, int* rounds_hint = nullptr) {
   int rounds = 0;
   int iterating = num_work;
   const int* counters = reinterpret_cast<const int*>(host_work + num_work);
+  const int* dev_counters = reinterpret_cast<const int*>(dev_work + num_work);
   if (ensure_tile_bounds(ctx, s.size)) return 1;
   const uint32_t padded_tiles = pose_padded_tiles(s.size);
   // (costs drift slowly -- poses move by millimetres, keyframes come one at a time -- so the census and the order kernel (one
   // workgroup: 0.16 ms at 47 k tiles) are spent on every 32nd phase only, and whenever the grid has changed)
   constexpr int kSchedulePhases = 32;
-  schedule = schedule && g_tile_order_enabled && s.size > 0 &&
+  schedule = schedule && g_tile_order_enabled && s.size > 0 && !ctx->tile_order_unavailable_for(padded_tiles) &&
              (ctx->tile_order_tiles != padded_tiles || ++ctx->phases_since_schedule >= kSchedulePhases);
   if (schedule && ensure_tile_schedule(ctx, padded_tiles)) return 1;
   static const bool host_timing = getenv("BADSLAM_HOST_TIMING") != nullptr;   // diagnostics: where a pose round's wall time goes
   static double t_launch = 0, t_wait = 0; static long n_rounds = 0;
   auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  for (int round = 0; round < BAHIP_MAX_POSE_ITERATIONS; ++round) {
+  // process-wide and increasing: page-locked memory is recycled between contexts, and a word left behind by an earlier
+  // context must never equal a sequence number somebody is going to wait for
+  static std::atomic<int> g_pose_sequence{0};
+  const int wanted_ahead = g_pose_rounds_ahead > 0 ? g_pose_rounds_ahead : std::max(1, std::min(rounds_hint ? *rounds_hint : 1, 4));
+  int round = 0;
+  while (round < BAHIP_MAX_POSE_ITERATIONS && iterating > 0) {
     const double t0 = host_timing ? now() : 0;
-    timer_begin(ctx, 2, round == 0, iterating);
-    launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb, ctx->dev_tile_bounds,
-                           /*stored_bounds*/ round > 0, /*num_listed*/ iterating, ctx->dev_tile_counters, &ctx->pose_parity,
-                           (schedule && round == 0) ? ctx->dev_tile_cost : nullptr, tile_order_for(ctx, s.size));
-    timer_end(ctx, 2);
-    CHECK_LAUNCH();
-    if (schedule && round == 0 && launch_tile_order(ctx->stream, ctx->dev_tile_cost, padded_tiles, ctx->dev_tile_order)) {
-      ctx->tile_order_tiles = padded_tiles;
-      ctx->phases_since_schedule = 0;
+    int batch = std::min(wanted_ahead, BAHIP_MAX_POSE_ITERATIONS - round);
+    if (batch > 1 && !pose_round_can_be_queued_ahead(s.size, round == 0 ? num_work : iterating, ctx->dev_tile_counters != nullptr)) batch = 1;
+    int sequence = 0;
+    StageTimer& acc_timer = ctx->timers[2];
+    for (int ahead = 0; ahead < batch; ++ahead) {
+      const int r = round + ahead;
+      // `iterating`: what the host knows -- exact for the first round of the batch, an upper bound for the rounds queued ahead
+      // (the list only shrinks), which read the exact count from the device
+      timer_begin(ctx, 2, r == 0, ahead == 0 ? iterating : 0);
+      launch_pose_accumulate(ctx->stream, use_depth, use_desc, ctx->in, dev_frames, dev_work, num_work, s, dev_Hb, ctx->dev_tile_bounds,
+                             /*stored_bounds*/ r > 0, /*num_listed*/ iterating, ctx->dev_tile_counters, &ctx->pose_parity,
+                             (schedule && r == 0) ? ctx->dev_tile_cost : nullptr, tile_order_for(ctx, s.size),
+                             ahead > 0 ? dev_counters + (r - 1) : nullptr);
+      timer_end(ctx, 2);
+      CHECK_LAUNCH();
+      if (schedule && r == 0) {
+        if (launch_tile_order(ctx->stream, ctx->dev_tile_cost, padded_tiles, ctx->dev_tile_order)) {
+          ctx->tile_order_tiles = padded_tiles;
+          ctx->phases_since_schedule = 0;
+          CHECK_LAUNCH();
+        } else {
+          // more runs than the order kernel handles: remember it, so that the census is not taken again for this grid
+          ctx->tile_order_unavailable_tiles = padded_tiles;
+          HIP_TRY(hipMemsetAsync(ctx->dev_tile_cost, 0, sizeof(uint32_t) * padded_tiles, ctx->stream));
+        }
+      }
+      // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
+      // (keyframe sharding: the ranks hold disjoint keyframes and all surfels, so the sum completes each rank's table -- the
+      // "all-reduce of pose Hessians" of BASELINE configs[3]; a single frame outside the table is complete on every rank)
+      if (!(kf_sharded(ctx) && dev_frames == ctx->dev_frame1) && reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
+      timer_begin(ctx, 3, r == 0);
+      sequence = ++g_pose_sequence;
+      launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, r, host_work, sequence);
+      timer_end(ctx, 3);
       CHECK_LAUNCH();
     }
-    // integer sum over the ranks: exact, so a sharded run produces the H, b of the unsharded one bit for bit
-    // (keyframe sharding: the ranks hold disjoint keyframes and all surfels, so the sum completes each rank's table -- the
-    // "all-reduce of pose Hessians" of BASELINE configs[3]; a single frame outside the table is complete on every rank)
-    if (!(kf_sharded(ctx) && dev_frames == ctx->dev_frame1) && reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
-    timer_begin(ctx, 3, round == 0);
-    // process-wide and increasing: page-locked memory is recycled between contexts, and a word left behind by an earlier
-    // context must never equal a sequence number somebody is going to wait for
-    static std::atomic<int> g_pose_sequence{0};
-    const int sequence = ++g_pose_sequence;
-    launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, round, host_work, sequence);
-    timer_end(ctx, 3);
-    CHECK_LAUNCH();
-    // No stream synchronisation and no copy per round: the solve kernel writes finished work items and, last, the counters and
-    // this launch's sequence number into host_work (mapped, coherent host memory); the host polls the sequence number.
+    // No stream synchronisation and no copy: the solve kernel writes finished work items and, last, the counters and its
+    // launch's sequence number into host_work (mapped, coherent host memory); the host polls the sequence number of the
+    // batch's last solve.
     const double t1 = host_timing ? now() : 0;
     if (wait_for_pose_sequence(ctx, host_work, dev_work, num_work, sequence)) return 1;
     if (counters[kPoseCounterInvalid])
@@ -448,12 +483,24 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
                   "surfels or images hold non-finite values", __FILE__, __LINE__);
     if (host_timing) {
       t_launch += t1 - t0; t_wait += now() - t1;
-      if (++n_rounds % 30 == 0) fprintf(stderr, "[pose rounds, us per round] enqueue %.1f | wait %.1f\n", t_launch / n_rounds, t_wait / n_rounds);
+      n_rounds += batch;
+      if (n_rounds % 30 < batch) fprintf(stderr, "[pose rounds, us per round] enqueue %.1f | wait %.1f\n", t_launch / n_rounds, t_wait / n_rounds);
     }
-    ++rounds;
-    iterating = counters[round];
-    if (iterating == 0) break;
+    // which of the batch's rounds had work: round r did iff something was still iterating after round r - 1
+    int executed = 0;
+    for (int ahead = 0; ahead < batch && iterating > 0; ++ahead) {
+      if (ahead > 0 && timer_on(ctx, 2)) acc_timer.units += iterating;   // the keyframes that launch swept (known only now)
+      ++executed;
+      iterating = counters[round + ahead];
+    }
+    // the launches queued in vain are not launches of the sweep: their event pairs (the last ones recorded) are dropped, so
+    // that launch counts and average durations keep describing launches that did work
+    if (timer_on(ctx, 2) && executed < batch) acc_timer.used = std::max(0, acc_timer.used - (batch - executed));
+    if (timer_on(ctx, 3) && executed < batch) ctx->timers[3].used = std::max(0, ctx->timers[3].used - (batch - executed));
+    rounds += executed;
+    round += batch;
   }
+  if (rounds_hint) *rounds_hint = rounds;
   if (rounds_out) *rounds_out = rounds;
   return 0;
 }
@@ -990,7 +1037,7 @@ int bahip_estimate_frame_pose(bahip_context* ctx, int use_depth, int use_desc, c
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   // surfels_size == 0: H = b = 0 -> x = 0 -> converged after one step (B/direct_ba_alternating.cc:148-151)
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_frame1, ctx->dev_frame1, ctx->dev_work1, ctx->dev_Hb1, 1,
-                      make_view(surfels), /*write_back*/ 0, /*update_activation*/ 0, ctx->pinned_work1, nullptr)) return 1;
+                      make_view(surfels), /*write_back*/ 0, /*update_activation*/ 0, ctx->pinned_work1, nullptr, false, &ctx->rounds_hint_frame)) return 1;
   const PoseWork& result = ctx->pinned_work1[0];
   memcpy(out, result.T, 7 * sizeof(float));
   if (iterations_done) *iterations_done = result.iterations;
@@ -1012,7 +1059,8 @@ static int estimate_keyframe_poses_impl(bahip_context* ctx, int use_depth, int u
   launch_pose_init_from_keyframes(ctx->stream, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, ctx->kf_rank, ctx->kf_world);
   CHECK_LAUNCH();
   if (run_pose_rounds(ctx, use_depth != 0, use_desc != 0, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K,
-                      make_view(surfels), /*write_back*/ 1, update_activation ? 1 : 0, ctx->pinned_work, rounds_out, /*schedule*/ true)) return 1;
+                      make_view(surfels), /*write_back*/ 1, update_activation ? 1 : 0, ctx->pinned_work, rounds_out, /*schedule*/ true,
+                      &ctx->rounds_hint_table)) return 1;
   const PoseWork* hw = ctx->pinned_work;
   const int* counters = reinterpret_cast<const int*>(hw + K);
   for (int k = 0; k < K; ++k) {
@@ -1441,14 +1489,19 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   // heavy work first (wave_cull.h): the init sweep takes the census when there is no schedule for this grid yet (a PCG-only
   // caller never runs the pose sweep that usually provides it), the inner steps use it
   const uint32_t padded_tiles = pose_padded_tiles(sv.size);
-  const bool census = g_tile_order_enabled && sv.size > 0 && ctx->tile_order_tiles != padded_tiles;
+  const bool census = g_tile_order_enabled && sv.size > 0 && ctx->tile_order_tiles != padded_tiles && !ctx->tile_order_unavailable_for(padded_tiles);
   if (census && ensure_tile_schedule(ctx, padded_tiles)) return 1;
   launch_pcg_init(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, r_, M_, census ? ctx->dev_tile_cost : nullptr, tile_order_for(ctx, sv.size));
   CHECK_LAUNCH();
-  if (census && launch_tile_order(st, ctx->dev_tile_cost, padded_tiles, ctx->dev_tile_order)) {
-    ctx->tile_order_tiles = padded_tiles;
-    ctx->phases_since_schedule = 0;
-    CHECK_LAUNCH();
+  if (census) {
+    if (launch_tile_order(st, ctx->dev_tile_cost, padded_tiles, ctx->dev_tile_order)) {
+      ctx->tile_order_tiles = padded_tiles;
+      ctx->phases_since_schedule = 0;
+      CHECK_LAUNCH();
+    } else {
+      ctx->tile_order_unavailable_tiles = padded_tiles;
+      HIP_TRY(hipMemsetAsync(ctx->dev_tile_cost, 0, sizeof(uint32_t) * padded_tiles, st));
+    }
   }
   const uint32_t* sched = tile_order_for(ctx, sv.size);
   if (sharded && reduce_over_ranks(ctx, ex.hot, x1_init, BAHIP_SUM_I64)) return 1;
@@ -1727,6 +1780,17 @@ int bahip_debug_read_pcg_vector(bahip_context* ctx, int which, size_t offset, si
 int bahip_debug_set_pose_lds_items(int items) {
   if (items < 0) return fail("bahip_debug_set_pose_lds_items: items must be >= 0", __FILE__, __LINE__, hipSuccess);
   set_pose_lds_items(items);
+  return 0;
+}
+int bahip_debug_set_pose_lds_shape(int waves, int parts_shift) {
+  if (waves < 0 || waves > 16 || parts_shift < -1 || parts_shift > 3) return fail("bahip_debug_set_pose_lds_shape: waves 0 .. 16, parts_shift -1 .. 3", __FILE__, __LINE__, hipSuccess);
+  set_pose_lds_waves(waves);
+  set_pose_lds_parts_shift(parts_shift);
+  return 0;
+}
+int bahip_debug_set_pose_rounds_ahead(int rounds) {
+  if (rounds < 0 || rounds > BAHIP_MAX_POSE_ITERATIONS) return fail("bahip_debug_set_pose_rounds_ahead: 0 .. BAHIP_MAX_POSE_ITERATIONS", __FILE__, __LINE__, hipSuccess);
+  g_pose_rounds_ahead = rounds;
   return 0;
 }
 int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset) {

@@ -132,8 +132,15 @@ struct LdsSink {
       const HbSplit v = hb_split(pending);
       const uint32_t address = lane_offset + (uint32_t)pending_item * (uint32_t)(kHbStride * sizeof(HbFixed));
       if (v.valid) {
+#ifdef BAHIP_LDS_ASM
         if (v.lo) asm volatile("ds_add_u64 %0, %1" ::"v"(address), "v"(v.lo) : "memory");
         if (v.hi) asm volatile("ds_add_u64 %0, %1 offset:8" ::"v"(address), "v"(v.hi) : "memory");
+#else
+        // the compiler's own LDS atomic (ds_add_u64 without return): tracked by its waitcnt pass, unlike an asm statement
+        auto* cell = reinterpret_cast<__attribute__((address_space(3))) HbFixed*>(address);
+        if (v.lo) __hip_atomic_fetch_add(cell, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v.hi) __hip_atomic_fetch_add(cell + 1, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
       } else {
         atomicOr(invalid, 1);
       }
@@ -141,7 +148,12 @@ struct LdsSink {
     pending_item = -1;
   }
   __device__ __forceinline__ void gathers_done() { flush(); }
-  __device__ __forceinline__ void add(int item, int /*w*/, float total) { pending = total; pending_item = item; }
+  __device__ __forceinline__ void add(int item, int /*w*/, float total) {
+    pending = total; pending_item = item;
+#ifndef BAHIP_LDS_DEFERRED
+    flush();
+#endif
+  }
   __device__ __forceinline__ void finish() { flush(); }
 };
 
@@ -304,8 +316,14 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
                        int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
                        int num_listed, int* __restrict__ invalid /* counter word kPoseCounterInvalid; its own argument so that `work`
                        stays read-only to the compiler: the per-candidate pose rows are then scalar loads */,
-                       uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched) {
+                       uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched,
+                       const int* __restrict__ listed_count /* a later round queued before the host knew how many work items are
+                       left (run_pose_rounds): the count the previous round's solve kernel left on the device; 0 = nothing to do */) {
   const int lane = threadIdx.x & 63;
+  if (listed_count) {
+    num_listed = __builtin_amdgcn_readfirstlane(load_global(listed_count));
+    if (num_listed == 0) return;
+  }
   const int slot = wave_reduce28_slot(lane);
   GlobalSink sink{Hb, invalid, 0.f, -1, (slot >= 0 && slot < 27) ? slot * kHbLimbs * (int)sizeof(HbFixed) : -1};
   uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile)
@@ -338,9 +356,18 @@ __global__ void __launch_bounds__(64 * kPoseLdsWaves) BAHIP_WAVES_ATTR
 pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const PoseWork* __restrict__ work,
                            int num_work, SurfelsView s, HbFixed* __restrict__ Hb, WaveBounds* __restrict__ tile_bounds, int stored_bounds,
                            int num_listed, int* __restrict__ invalid, uint32_t padded_tiles, uint32_t* __restrict__ tile_counters, int parity,
-                           int slice_begin, int slice_count, uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched) {
+                           int slice_begin, int slice_count, uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched,
+                           const int* __restrict__ listed_count /* as in pose_accumulate_kernel */,
+                           uint32_t parts_shift /* 2^parts_shift wavefronts share a tile's work items: the unit a wavefront draws is
+                           (tile, part) -- small grids (a shard of a multi-GPU run) otherwise last as long as their longest tile */) {
   extern __shared__ HbFixed table[];
   const int lane = threadIdx.x & 63;
+  // (both sets of tile counters are in a defined state after every launch, also one that finds nothing to do)
+  if (blockIdx.x == 0 && threadIdx.x < 8) tile_counters[(parity ^ 1) * 8 + threadIdx.x] = 0;
+  if (listed_count) {
+    num_listed = __builtin_amdgcn_readfirstlane(load_global(listed_count));
+    if (num_listed == 0) return;
+  }
   const int item_begin = kSlice ? slice_begin : 0;
   const int num_items = kSlice ? slice_count : (stored_bounds ? num_listed : num_work);
   // (first position of the current batch << 32) | (its size << 24) | positions of it already taken; the word behind the table (a
@@ -348,10 +375,10 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
   // the end of the XCD's queue (guided self-scheduling: a quarter of a workgroup's fair share of what is left, 2 .. kPoseBatch
   // positions): a workgroup's LAST batch is what the launch waits for, and 32 positions are two rounds of its 16 wavefronts.
   unsigned long long& batch_state = *reinterpret_cast<unsigned long long*>(table + (size_t)num_items * kHbStride);
-  const uint32_t xcd = blockIdx.x & 7u, per_xcd = sched_positions(padded_tiles, sched) >> 3;   // positions, heavy tiles first (wave_cull.h)
+  // units of an XCD's queue: positions (heavy tiles first, wave_cull.h) x parts
+  const uint32_t xcd = blockIdx.x & 7u, per_xcd = (sched_positions(padded_tiles, sched) >> 3) << parts_shift;
   uint32_t* counter = tile_counters + parity * 8 + xcd;
-  for (int e = threadIdx.x; e < num_items * kHbStride; e += 64 * kPoseLdsWaves) table[e] = 0;
-  if (blockIdx.x == 0 && threadIdx.x < 8) tile_counters[(parity ^ 1) * 8 + threadIdx.x] = 0;
+  for (int e = threadIdx.x; e < num_items * kHbStride; e += blockDim.x) table[e] = 0;
   if (threadIdx.x == 0) batch_state = ((unsigned long long)atomicAdd(counter, kPoseBatch) << 32) | ((unsigned long long)kPoseBatch << 24);
   __syncthreads();
   const int slot = wave_reduce28_slot(lane);
@@ -366,14 +393,15 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
     if (first >= per_xcd) break;                         // the XCD's tiles are used up
     if (index < size) {
       uint32_t tile;
-      if (first + index < per_xcd && scheduled_tile((first + index) * 8u + xcd, padded_tiles, sched, &tile)) {
+      const uint32_t unit = first + index;
+      if (unit < per_xcd && scheduled_tile((unit >> parts_shift) * 8u + xcd, padded_tiles, sched, &tile)) {
 #ifdef BAHIP_TILE_TIMELINE
         const unsigned long long t0 = wall_clock64();
 #endif
-        pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, tile, 1, 0, sink, tile_cost, item_begin,
-                                       kSlice ? num_items : -1);
+        pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, tile, 1 << parts_shift,
+                                       (int)(unit & ((1u << parts_shift) - 1u)), sink, tile_cost, item_begin, kSlice ? num_items : -1);
 #ifdef BAHIP_TILE_TIMELINE
-        const uint32_t position = (first + index) * 8u + xcd;
+        const uint32_t position = (unit >> parts_shift) * 8u + xcd;
         if (!stored_bounds && lane == 0 && position < 65536 && tile < 65536) {
           g_pose_timeline[position][0] = t0; g_pose_timeline[position][1] = wall_clock64(); g_pose_timeline[position][2] = tile;
           g_pose_timeline[position][3] = ((unsigned long long)g_pose_tile_stats[tile][0] << 32) | g_pose_tile_stats[tile][1];
@@ -394,7 +422,7 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
   }
   __syncthreads();
   const int* __restrict__ listed = reinterpret_cast<const int*>(work + num_work + kPoseTailRecords);
-  for (int e = threadIdx.x; e < num_items * kHbStride; e += 64 * kPoseLdsWaves) {
+  for (int e = threadIdx.x; e < num_items * kHbStride; e += blockDim.x) {
     const HbFixed v = table[e];
     if (v != 0) {
       const int item = e / kHbStride;
@@ -673,42 +701,84 @@ void pose_form_launches(long long out[2], bool reset) {
   if (reset) g_pose_form_launches[0] = g_pose_form_launches[1] = 0;
 }
 constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a compute unit
+#ifndef BAHIP_POSE_LDS_MIN_TILES
+#define BAHIP_POSE_LDS_MIN_TILES 2048
+#endif
+constexpr unsigned kPoseLdsMinTiles = BAHIP_POSE_LDS_MIN_TILES;   // smaller grids: one tile per wavefront, global atomics
+static int g_pose_lds_parts_shift = [] { const char* e = getenv("BAHIP_POSE_LDS_PARTS_SHIFT"); return e ? atoi(e) : -1; }();   // -1: from the grid size
+void set_pose_lds_parts_shift(int shift) { g_pose_lds_parts_shift = (shift >= 0 && shift <= 3) ? shift : -1; }
 
+static int g_pose_lds_waves = 0;   // test hook: wavefronts per workgroup of the LDS form (0: kPoseLdsWaves)
+void set_pose_lds_waves(int waves) { g_pose_lds_waves = (waves >= 1 && waves <= kPoseLdsWaves) ? waves : 0; }
+
+// What a launch of the persistent form needs to know about the device the stream runs on, per device (a process
+// that drives contexts on several devices must not reuse the first device's numbers or its opt-in).
+struct PoseLdsDevice { int compute_units = 0; bool raised[8] = {}; bool failed[8] = {}; };
+static PoseLdsDevice& pose_lds_device() {
+  static PoseLdsDevice devices[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  PoseLdsDevice& d = devices[dev];
+  if (d.compute_units == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    d.compute_units = cus;
+  }
+  return d;
+}
+
+// false: the launch could not be made (the opt-in for more than 64 KB of dynamic LDS was refused): the caller falls back to the
+// one-tile-per-wavefront form.
 template <bool kUseDepth, bool kUseDesc, bool kSlice>
-static void launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
+static bool launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
                             const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
-                            uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost, const uint32_t* sched) {
+                            uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost, const uint32_t* sched,
+                            const int* listed_count, uint32_t parts_shift) {
   int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
-  static int compute_units = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus;
-  }();
-  static bool raised = [] {   // dynamic LDS beyond 64 KB needs the opt-in
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsTableLimit) == hipSuccess;
-  }();
-  (void)raised;
-  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(compute_units), dim3(64 * kPoseLdsWaves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
-                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
+  PoseLdsDevice& device = pose_lds_device();
+  constexpr int variant = (kUseDepth ? 1 : 0) + (kUseDesc ? 2 : 0) + (kSlice ? 4 : 0);
+  if (!device.raised[variant] && !device.failed[variant]) {   // dynamic LDS beyond 64 KB needs the opt-in
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsTableLimit) == hipSuccess) device.raised[variant] = true;
+    else { device.failed[variant] = true; (void)hipGetLastError(); }
+  }
+  if (device.failed[variant] && table_bytes + sizeof(HbFixed) > 64 * 1024) return false;
+  const int waves = g_pose_lds_waves > 0 ? g_pose_lds_waves : kPoseLdsWaves;
+  // one workgroup per compute unit, fewer when there is less to do than that (at least one per XCD queue)
+  const unsigned units = sched_positions(tiles, sched) << parts_shift;
+  const unsigned grid = std::max(8u, std::min((unsigned)device.compute_units, ((units + waves - 1) / waves + 7u) & ~7u));
+  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(grid), dim3(64 * waves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
+                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
+  return true;
 }
 template <bool kSlice>
-static void launch_pose_lds_any(bool use_depth, bool use_desc, hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw,
+static bool launch_pose_lds_any(bool use_depth, bool use_desc, hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw,
                                 int num_work, const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles,
                                 size_t table_bytes, uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost,
-                                const uint32_t* sched) {
-  if (use_depth && use_desc) launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
-  else if (use_depth) launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
-  else launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched);
+                                const uint32_t* sched, const int* listed_count, uint32_t parts_shift) {
+  if (use_depth && use_desc) return launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
+  if (use_depth) return launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
+  return launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
+}
+
+// Can a later round over (at most) `num_items` work items be queued before the host knows how many are left?  Yes unless the
+// launch would have to be cut into slices by the host (more items than the LDS table holds).
+bool pose_round_can_be_queued_ahead(uint32_t /*surfels*/, int num_items, bool /*have_tile_counters*/) {
+  // (decided from the item count alone, whatever form this rank's launch takes: the ranks of a sharded run hold different
+  // numbers of surfels and must all make the same decision, or they disagree on the number of exchanges per host wait)
+  const size_t item_bytes = sizeof(HbFixed) * kHbStride;
+  const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes)) : (int)(kPoseLdsTableLimit / item_bytes);
+  return num_items <= per_launch;
 }
 
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
-                            int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched) {
+                            int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched,
+                            const int* listed_count) {
   if (s.size == 0 || num_work == 0) return;
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
-  // wavefront with the most candidate keyframes: split every wavefront's candidates over gridDim.y wavefronts
-  // (the sums are merged by integer atomics, so who visits a keyframe does not matter: same bits for every split).
+  // wavefront with the most candidate keyframes: split every wavefront's candidates over several wavefronts
+  // (the sums are merged by integer adds, so who visits a keyframe does not matter: same bits for every split).
   const unsigned tiles = xcd_padded_tiles((s.size + kPoseBlock - 1) / kPoseBlock);   // whole XCD runs
   const int forced = g_forced_pose_parts;
   const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
@@ -718,39 +788,44 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   const PoseWork* pw = static_cast<const PoseWork*>(work);
   WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);
   const int sb = stored_bounds ? 1 : 0;
-  // The persistent LDS form when the grid fills the chip on its own (no splitting of a tile's work items) and the table of the
-  // work items in this launch fits.
+  // The persistent LDS form when the table of the work items in this launch fits.  (round 3, with the schedule: 23.4 k tiles --
+  // half of the bench scene -- 0.43 ms in the LDS form against 0.77-0.89 ms with global atomics, 11.7 k tiles 0.32 against
+  // 0.39-0.45; 5.9 k tiles 0.30 against 0.25 while every wavefront of the LDS form took whole tiles: round 4 lets the
+  // wavefronts of the LDS form share a tile's work items as well -- g_pose_lds_parts_shift below -- and uses it from
+  // kPoseLdsMinTiles tiles on.)
   const int num_items = stored_bounds ? num_listed : num_work;
   const size_t item_bytes = sizeof(HbFixed) * kHbStride;
-  // (round 3, with the schedule: 23.4 k tiles -- half of the bench scene -- 0.43 ms in the LDS form against 0.77-0.89 ms with
-  // global atomics, 11.7 k tiles 0.32 against 0.39-0.45, 5.9 k tiles 0.30 against 0.25: the LDS form from 8192 tiles on)
-  const bool lds_form = tile_counters != nullptr && (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && tiles >= 8192 && forced == 0));
-  ++g_pose_form_launches[lds_form ? 1 : 0];
+  const bool lds_form = tile_counters != nullptr && (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && tiles >= kPoseLdsMinTiles && forced == 0));
   if (lds_form) {
+    // units per wavefront slot of the chip (256 x 16): below ~4 a launch lasts as long as its longest unit
+    const uint32_t parts_shift = g_pose_lds_parts_shift >= 0 ? (uint32_t)g_pose_lds_parts_shift : tiles >= 16384 ? 0u : tiles >= 8192 ? 1u : 2u;
     const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes))
                                                 : (int)(kPoseLdsTableLimit / item_bytes);   // 292 work items
+    bool launched = true;
     if (num_items <= per_launch) {
       const int parity = *parity_inout;
-      *parity_inout = parity ^ 1;
-      launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0, tile_cost, sched);
-      return;
+      launched = launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0, tile_cost, sched, listed_count, parts_shift);
+      if (launched) *parity_inout = parity ^ 1;
+    } else {
+      // more work items than the table holds: slices of equal size, one launch each (every launch sweeps all tiles and culls
+      // against its slice; the first round's launches all store the same tile bounds)
+      const int slices = (num_items + per_launch - 1) / per_launch, per_slice = (num_items + slices - 1) / slices;
+      for (int begin = 0; begin < num_items && launched; begin += per_slice) {
+        const int count = std::min(per_slice, num_items - begin);
+        const int parity = *parity_inout;
+        launched = launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count, tile_cost, sched, nullptr, parts_shift);
+        if (launched) *parity_inout = parity ^ 1;
+      }
     }
-    // more work items than the table holds: slices of equal size, one launch each (every launch sweeps all tiles and culls
-    // against its slice; the first round's launches all store the same tile bounds)
-    const int slices = (num_items + per_launch - 1) / per_launch, per_slice = (num_items + slices - 1) / slices;
-    for (int begin = 0; begin < num_items; begin += per_slice) {
-      const int count = std::min(per_slice, num_items - begin);
-      const int parity = *parity_inout;
-      *parity_inout = parity ^ 1;
-      launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count, tile_cost, sched);
-    }
-    return;
+    if (launched) { ++g_pose_form_launches[1]; return; }
+    // (only a refused LDS opt-in gets here, before the first slice: nothing has been added yet)
   }
+  ++g_pose_form_launches[0];
   const dim3 grid(sched_positions(tiles, sched), parts), block(kPoseBlock);
   int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count);
 }
 
 // The schedule of the sweeps that follow (wave_cull.h: scheduled_tile) from the candidates every tile visited in the pose sweep's

@@ -412,6 +412,15 @@ int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out,
 /* The LDS form holds the normal equations of at most 292 work items; longer lists are cut into slices, one launch each.  items > 0
  * makes the slices that small (tests: 200 keyframes in slices of 64), 0 restores the default. */
 int bahip_debug_set_pose_lds_items(int items);
+/* Shape of the LDS form (test hooks; 0 / -1 restore the defaults): wavefronts per workgroup (1 .. 16, default 16), and
+ * parts_shift: 2^parts_shift wavefronts share a tile's work items (0 .. 3; -1: chosen from the grid size -- small grids, i.e.
+ * shards of a multi-GPU run, split their tiles).  Integer sums: every shape gives the same bits. */
+int bahip_debug_set_pose_lds_shape(int waves, int parts_shift);
+/* Gauss-Newton rounds queued ahead per host wait (bahip_estimate_*: the later rounds of a phase read the number of work items
+ * still iterating from device memory and do nothing when it is zero, so the host need not wait for a round before it queues
+ * the next): 0 = as many as the previous phase needed (default), n >= 1 = exactly n (1: wait after every round, the round-3
+ * behaviour).  Results do not depend on it. */
+int bahip_debug_set_pose_rounds_ahead(int rounds);
 /* launches of the pose accumulation in either form since the last reset (process-wide); bench.py names the dominant kernel by it */
 int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):

@@ -109,7 +109,14 @@ def _oracle_pose_estimates(orc, perturbed, pattern):
     return _ORACLE_POSES
 
 
-@pytest.mark.parametrize("pose_parts", [1, 2, 8, "lds", "lds-sliced"])
+# The persistent LDS form as a regression matrix: wavefronts per workgroup 1 / 2 / 16 x work items per
+# launch 1 / 37 / 292 (200 keyframes: 200 slices, 6 slices, one launch), then the shapes round 4 added: a tile's work items
+# shared by 4 wavefronts (p2), and Gauss-Newton rounds queued ahead of the host one / four at a time (a1 / a4).
+_LDS_MATRIX = [f"lds:w{w}:i{i}" for w in (1, 2, 16) for i in (1, 37, 292)] + ["lds:w16:i292:p2", "lds:w2:i292:p3", "lds:w16:i292:a1", "lds:w16:i292:a4",
+                                                                               "lds:w16:i292:p1:a4"]
+
+
+@pytest.mark.parametrize("pose_parts", [1, 2, 8, "lds", "lds-sliced", "global:a4"] + _LDS_MATRIX)
 def test_many_keyframes_batched_pose_estimation(many, pose_parts, request):
     """pose_parts 1 / 2 / 8: one tile per wavefront, a tile's work items split over that many wavefronts, totals added to the
     normal equations with global integer atomics; "lds": persistent workgroups that keep the normal equations of all 200 work
@@ -118,7 +125,17 @@ def test_many_keyframes_batched_pose_estimation(many, pose_parts, request):
     left take a single launch).  The sums are integer sums: the same bits for every form."""
     scene, orc, g = many
     K = len(orc.keyframes)
-    if pose_parts in ("lds", "lds-sliced"):
+    lib = g.ctx.lib
+    if isinstance(pose_parts, str) and ":" in pose_parts:
+        form, *options = pose_parts.split(":")
+        opt = {o[0]: int(o[1:]) for o in options}
+        capi.check(lib.bahip_debug_set_pose_form(2 if form == "lds" else 1))
+        capi.check(lib.bahip_debug_set_pose_lds_items(opt.get("i", 0) if opt.get("i", 292) < 292 else 0))
+        capi.check(lib.bahip_debug_set_pose_lds_shape(opt.get("w", 0), opt.get("p", -1)))
+        capi.check(lib.bahip_debug_set_pose_rounds_ahead(opt.get("a", 0)))
+        request.addfinalizer(lambda: (capi.check(lib.bahip_debug_set_pose_form(0)), capi.check(lib.bahip_debug_set_pose_lds_items(0)),
+                                      capi.check(lib.bahip_debug_set_pose_lds_shape(0, -1)), capi.check(lib.bahip_debug_set_pose_rounds_ahead(0))))
+    elif pose_parts in ("lds", "lds-sliced"):
         capi.check(g.ctx.lib.bahip_debug_set_pose_form(2))
         capi.check(g.ctx.lib.bahip_debug_set_pose_lds_items(48 if pose_parts == "lds-sliced" else 0))
         request.addfinalizer(lambda: (capi.check(g.ctx.lib.bahip_debug_set_pose_form(0)), capi.check(g.ctx.lib.bahip_debug_set_pose_lds_items(0))))
