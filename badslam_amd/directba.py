@@ -177,6 +177,15 @@ class DirectBA:
         self.L.dba_sort_surfels_spatially.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
         assert self.L.dba_sort_surfels_spatially(self.h, self.stream, float(grid_cell_size)) == 0
 
+    def SetSpatialSortCellSize(self, grid_cell_size):
+        self.L.dba_set_spatial_sort_cell_size.argtypes = [C.c_void_p, C.c_float]
+        assert self.L.dba_set_spatial_sort_cell_size(self.h, float(grid_cell_size)) == 0
+
+    def unsorted_surfels(self):
+        self.L.dba_unsorted_surfels.restype = C.c_uint32
+        self.L.dba_unsorted_surfels.argtypes = [C.c_void_p]
+        return int(self.L.dba_unsorted_surfels(self.h))
+
     def SetSurfelCount(self, surfel_count, surfels_size):
         self.L.dba_set_surfel_count(self.h, int(surfel_count), int(surfels_size))
 

@@ -136,6 +136,12 @@ int dba_sort_surfels_spatially(dba_handle* h, void* stream, float grid_cell_size
   return 0;
 }
 
+int dba_set_spatial_sort_cell_size(dba_handle* h, float grid_cell_size) {
+  h->ba->SetSpatialSortCellSize(grid_cell_size);
+  return 0;
+}
+uint32_t dba_unsorted_surfels(dba_handle* h) { return h->ba->unsorted_surfels(); }
+
 int dba_download_surfels(dba_handle* h, void* stream, int rows, uint32_t count, float* out) {
   auto s = h->ba->surfels();
   for (int r = 0; r < rows; ++r)

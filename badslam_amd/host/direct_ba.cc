@@ -272,6 +272,7 @@ void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surf
   Lock();
   surfels_size_ += new_surfel_count;
   surfel_count_ += new_surfel_count;
+  unsorted_surfels_ += new_surfel_count;
   Unlock();
 }
 
@@ -357,17 +358,25 @@ void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_update
   BAHIP_CHECKED_CALL(bahip_delete_surfels_and_update_radii(ctx_, GetMinObservationCount(), &s, &deleted));
   u32 surfel_count = surfel_count_ - deleted;
   const bahip_surfels s2 = SurfelsStruct(/*with_active*/ false);   // B/direct_ba.cc:619: no active-flag buffer
+  unsorted_surfels_ += surfels_size_ - surfel_count;               // the holes compaction fills with surfels from the end
   BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count, &s2));
   Lock();
   surfels_size_ = surfel_count;
   surfel_count_ = surfel_count;
   Unlock();
+  // Ours: back into Morton order if anything was appended or moved since the last reorder (direct_ba.h: SetSpatialSortCellSize;
+  // the oracle's end tasks do the same, oracle_ba.c).  Under surfel sharding this runs on the gathered cloud, on every rank alike.
+  if (spatial_sort_cell_size_ > 0.f) {
+    if (unsorted_surfels_ > 0 && surfels_size_ > 1) SortSurfelsSpatially(stream, spatial_sort_cell_size_);
+    unsorted_surfels_ = 0;
+  }
 }
 
 void DirectBA::SortSurfelsSpatially(hipStream_t stream, float grid_cell_size) {
   BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
   const bahip_surfels s = SurfelsStruct();
   BAHIP_CHECKED_CALL(bahip_sort_surfels_spatially(ctx_, &s, grid_cell_size));
+  unsorted_surfels_ = 0;
 }
 
 // ---- alternating scheme (B/direct_ba_alternating.cc:285-738) ----------------------------------------------------------------
@@ -511,6 +520,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
       {
         const bahip_surfels s = SurfelsStruct();
+        unsorted_surfels_ += surfels_size_ - surfel_count_;
         BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count_, &s));
         Lock();
         surfels_size_ = surfel_count_;
@@ -639,6 +649,7 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
     if (!keyframes_with_new_surfels.empty()) {
       const bahip_surfels s = SurfelsStruct();
+      unsorted_surfels_ += surfels_size_ - surfel_count_;
       BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count_, &s));
       surfels_size_ = surfel_count_;
     }

@@ -96,11 +96,21 @@ class DirectBA {
   void SetIntrinsicsUpdatedCallback(const std::function<void()>& callback) { intrinsics_updated_callback_ = callback; }
   u32 surfel_count() const { lock_guard<mutex> lock(ba_thread_mutex_); return surfel_count_; }
   u32 surfels_size() const { lock_guard<mutex> lock(ba_thread_mutex_); return surfels_size_; }
-  void SetSurfelCount(u32 surfel_count, u32 surfels_size) { surfel_count_ = surfel_count; surfels_size_ = surfels_size; }
+  void SetSurfelCount(u32 surfel_count, u32 surfels_size) {
+    surfel_count_ = surfel_count; surfels_size_ = surfels_size;
+    if (unsorted_surfels_ > surfels_size) unsorted_surfels_ = surfels_size;   // (an emptied buffer has nothing out of order)
+  }
   // Not in the reference.  Reorders the surfel buffer along a Morton curve over a world grid (bahip_sort_surfels_spatially):
   // surfels that an image region shows become neighbours in the buffer, which the sweeps' cache behaviour wants.  No
   // result depends on the order; call it when the surfel set has grown (after adding keyframes), not per iteration.
   void SortSurfelsSpatially(hipStream_t stream, float grid_cell_size = 0.02f);
+  // Spatial order as part of the reference's own call path (round 4): PerformBASchemeEndTasks -- which compacts, i.e. moves
+  // surfels, anyway (B/direct_ba.cc:619-640) -- puts the buffer back into Morton order whenever surfels were appended or moved
+  // since the last reorder, so a caller that knows only B/direct_ba.h:73-388 gets the buffer the sweeps are fast on.
+  // cell size 0 switches it off (the reference's surfel order stays observable); default 0.02 m.
+  void SetSpatialSortCellSize(float grid_cell_size) { spatial_sort_cell_size_ = grid_cell_size; }
+  float spatial_sort_cell_size() const { return spatial_sort_cell_size_; }
+  u32 unsorted_surfels() const { return unsorted_surfels_; }
   CUDABufferConstPtr<float> surfels() const { return surfels_; }
   CUDABufferPtr<float> surfels() { return surfels_; }
   CUDABufferPtr<u8> active_surfels() { return active_surfels_; }
@@ -176,6 +186,8 @@ class DirectBA {
   DepthParameters depth_params_;
   vector<shared_ptr<Keyframe>> keyframes_;
   u32 surfel_count_ = 0, surfels_size_ = 0;
+  u32 unsorted_surfels_ = 0;            // appended, or moved by a compaction, since the buffer was last in Morton order
+  float spatial_sort_cell_size_ = 0.02f;
   CUDABufferPtr<float> surfels_;
   CUDABufferPtr<u8> active_surfels_;
   int ba_iteration_count_ = 0, last_ba_iteration_count_ = -1;

@@ -58,6 +58,11 @@ uint32_t dba_surfels_size(dba_handle* h);
 int dba_set_surfel_count(dba_handle* h, uint32_t surfel_count, uint32_t surfels_size);
 /* DirectBA::SortSurfelsSpatially (ours: Morton order of the surfel buffer over a world grid of grid_cell_size metres) */
 int dba_sort_surfels_spatially(dba_handle* h, void* hip_stream, float grid_cell_size);
+/* DirectBA::SetSpatialSortCellSize: the grid cell PerformBASchemeEndTasks re-establishes that order with whenever surfels were
+ * appended or moved since the last reorder (default 0.02 m; 0 = never: the reference's surfel order stays observable);
+ * dba_unsorted_surfels: how many were appended / moved since then */
+int dba_set_spatial_sort_cell_size(dba_handle* h, float grid_cell_size);
+uint32_t dba_unsorted_surfels(dba_handle* h);
 /* surfels()->Download/UploadPartAsync of `rows` attribute rows x `count` surfels starting at row 0 */
 int dba_download_surfels(dba_handle* h, void* hip_stream, int rows, uint32_t count, float* out);
 int dba_upload_surfels(dba_handle* h, void* hip_stream, int rows, uint32_t count, const float* in);

@@ -97,7 +97,8 @@ class BAState(C.Structure):
                 ("kfs", C.POINTER(C.POINTER(Keyframe))), ("num_kfs", C.c_int),
                 ("covis_lists", C.POINTER(C.POINTER(C.c_int))), ("covis_counts", C.POINTER(C.c_int)),
                 ("surfels", C.POINTER(Surfels)), ("supporting", C.POINTER(C.c_uint32)),
-                ("ba_iteration_count", C.c_int), ("last_ba_iteration_count", C.c_int)]
+                ("ba_iteration_count", C.c_int), ("last_ba_iteration_count", C.c_int),
+                ("unsorted_surfels", C.c_uint32), ("spatial_sort_cell", C.c_float)]
 
 
 _lib = None
@@ -231,6 +232,10 @@ class OracleBA:
         self.merge_factor = surfel_merge_dist_factor
         self.min_observation_count = min_observation_count
         self.ba_iteration_count, self.last_ba_iteration_count = 0, -1
+        # spatial order of the surfel buffer, as vis::DirectBA keeps it: surfels appended / moved since the last Morton reorder,
+        # and the grid cell PerformBASchemeEndTasks reorders with (0: never -- the reference's behaviour and the default here;
+        # tests that compare with vis::DirectBA, whose default is 0.02, set it)
+        self.unsorted_surfels, self.spatial_sort_cell = 0, 0.0
         self.covis = None  # list of lists, or None for fully connected
 
     # -- keyframes --
@@ -306,10 +311,12 @@ class OracleBA:
         if covis is None:
             covis = [j for j in range(len(self.keyframes)) if j != i]
         cv = (C.c_int * max(1, len(covis)))(*covis)
-        return int(self.L.orc_create_surfels_for_keyframe(
+        created = int(self.L.orc_create_surfels_for_keyframe(
             int(filter_new_surfels), int(self.min_observation_count), C.byref(self.color_cam), C.byref(self.depth_cam),
             C.byref(self.dp), C.byref(self.keyframes[i]), kfs, cv, len(covis), C.byref(self.surfels),
             _ptr(self.supporting, C.c_uint32)))
+        self.unsorted_surfels += created
+        return created
 
     def determine_supporting_surfels(self, i, merge=False):
         """orc_determine_supporting_surfels for keyframe i at its current pose; returns the three planes restricted to the
@@ -420,6 +427,7 @@ class OracleBA:
         self.L.orc_sort_surfels_spatially.argtypes = [C.c_void_p, C.c_float]
         self.L.orc_sort_surfels_spatially.restype = None
         self.L.orc_sort_surfels_spatially(C.byref(self.surfels), float(grid_cell_size))
+        self.unsorted_surfels = 0
 
     def update_surfel_normals(self):
         self.L.orc_update_surfel_normals(C.byref(self.depth_cam), C.byref(self.dp), self._kf_ptr_array(), len(self.keyframes),
@@ -505,10 +513,12 @@ class OracleBA:
         st.surfels = C.pointer(self.surfels)
         st.supporting = _ptr(self.supporting, C.c_uint32)
         st.ba_iteration_count, st.last_ba_iteration_count = self.ba_iteration_count, self.last_ba_iteration_count
+        st.unsorted_surfels, st.spatial_sort_cell = int(self.unsorted_surfels), float(self.spatial_sort_cell)
         stats = BAStats()
         fn = self.L.orc_bundle_adjustment_pcg if use_pcg else self.L.orc_bundle_adjustment_alternating
         fn(C.byref(st), C.byref(opt), C.byref(stats))
         self.color_cam, self.depth_cam = st.color_cam, st.depth_cam
         self.dp.a = st.dp.a
         self.ba_iteration_count, self.last_ba_iteration_count = st.ba_iteration_count, st.last_ba_iteration_count
+        self.unsorted_surfels = int(st.unsorted_surfels)
         return stats

@@ -325,6 +325,11 @@ typedef struct {
   orc_surfels* surfels;
   uint32_t* supporting;     /* ORC_MERGE_BUFFER_COUNT * height * width */
   int ba_iteration_count, last_ba_iteration_count;
+  /* Spatial order of the surfel buffer (ours, badslam_amd/host/direct_ba.cc: PerformBASchemeEndTasks; the reference has no
+   * counterpart): surfels appended or moved by a compaction since the buffer was last put in Morton order, and the grid cell
+   * of that order in metres (0: the end tasks never reorder).  Mirrors DirectBA::unsorted_surfels_ / spatial_sort_cell_size_. */
+  uint32_t unsorted_surfels;
+  float spatial_sort_cell;
 } orc_ba_state;
 
 void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* opt, orc_ba_stats* stats);

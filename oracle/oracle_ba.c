@@ -37,8 +37,13 @@ static void perform_ba_scheme_end_tasks(orc_ba_state* st, const orc_ba_options* 
   /* B/direct_ba.cc:619: compaction without the active-flag buffer */
   uint8_t* active = s->active;
   s->active = NULL;
+  st->unsorted_surfels += s->surfels_size - s->surfel_count;   /* the holes compaction fills with surfels from the end */
   orc_compact_surfels(s);
   s->active = active;
+  /* ours (host/direct_ba.cc: PerformBASchemeEndTasks): surfels were appended or moved since the buffer was last in Morton
+   * order -> reorder, so that a caller of the reference's API gets the spatially coherent buffer the sweeps are fast on */
+  if (st->spatial_sort_cell > 0.f && st->unsorted_surfels > 0 && s->surfels_size > 1) orc_sort_surfels_spatially(s, st->spatial_sort_cell);
+  if (st->spatial_sort_cell > 0.f) st->unsorted_surfels = 0;
 }
 
 void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* opt, orc_ba_stats* stats) {
@@ -93,8 +98,10 @@ void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* o
           for (int c = 0; c < st->num_kfs; ++c) if (c != k && st->kfs[c]) all[n_covis++] = c;
           covis = all;
         }
+        const uint32_t size_before = s->surfels_size;
         orc_create_surfels_for_keyframe(1, opt->min_observation_count, &st->color_cam, &st->depth_cam, &st->dp,
                                         st->kfs[k], st->kfs, covis, n_covis, s, st->supporting);
+        st->unsorted_surfels += s->surfels_size - size_before;
         free(all);
       }
     }
@@ -116,7 +123,7 @@ void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* o
         if (!kf) continue;
         orc_determine_supporting_surfels(1, opt->surfel_merge_dist_factor, &st->depth_cam, &st->dp, kf, s, st->supporting);
       }
-      if (n_new_kfs > 0) orc_compact_surfels(s);
+      if (n_new_kfs > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); }
     }
 
     /* --- poses --- */

@@ -454,8 +454,10 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
             for (int c = 0; c < K; ++c) if (c != k) all[n_covis++] = c;
             covis = all;
           }
+          const uint32_t size_before = s->surfels_size;
           orc_create_surfels_for_keyframe(1, opt->min_observation_count, &st->color_cam, &st->depth_cam, &st->dp, kf, st->kfs,
                                           covis, n_covis, s, st->supporting);
+          st->unsorted_surfels += s->surfels_size - size_before;
           free(all);
           new_kfs[n_new++] = k;
         } else if (kf->activation == ORC_KF_COVIS_ACTIVE && kf->last_covis_in_ba_iteration != st->ba_iteration_count) {
@@ -590,7 +592,7 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     if (opt->do_surfel_updates) {
       for (int j = 0; j < n_new; ++j)
         orc_determine_supporting_surfels(1, opt->surfel_merge_dist_factor, &st->depth_cam, &st->dp, st->kfs[new_kfs[j]], s, st->supporting);
-      if (n_new > 0) orc_compact_surfels(s);
+      if (n_new > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); }
     }
     if (iteration >= opt->min_iterations - 1 && (num_converged == K || !L.optimize_poses)) { stats->converged = 1; break; }
   }
@@ -605,7 +607,7 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     /* B/direct_ba_pcg.cc:775-812: the merge + compaction of the last iteration is repeated */
     for (int j = 0; j < n_new; ++j)
       orc_determine_supporting_surfels(1, opt->surfel_merge_dist_factor, &st->depth_cam, &st->dp, st->kfs[new_kfs[j]], s, st->supporting);
-    if (n_new > 0) orc_compact_surfels(s);
+    if (n_new > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); }
   }
   free(new_kfs);
 }

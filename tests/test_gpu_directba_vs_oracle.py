@@ -58,6 +58,9 @@ def test_bundle_adjustment_fixed_surfels(scene, use_pcg):
         orc.set_pose(k, T)
         ba.set_keyframe_pose(k, T)
     iters = 3 if use_pcg else 5
+    # vis::DirectBA re-establishes the Morton order of the buffer in its end tasks (default grid 0.02 m); the oracle does the
+    # same when told to (its default is the reference's behaviour: never)
+    orc.spatial_sort_cell, orc.unsorted_surfels = 0.02, ba.unsorted_surfels()
     cost_before, _ = orc.evaluate_cost()
     ba.set_pcg_gauge_keyframe(0)
     # increase_ba_iteration_count = True on both sides: the end-of-scheme tasks (surfel deletion, radius
@@ -113,6 +116,7 @@ def test_bundle_adjustment_with_surfel_updates(scene):
         orc.set_pose(k, T)
         ba.set_keyframe_pose(k, T)
     orc.covis = [ba.keyframe_covisibility(k) for k in range(len(perturbed))]     # the host's frustum-based lists
+    orc.spatial_sort_cell, orc.unsorted_surfels = 0.02, ba.unsorted_surfels()   # the end tasks reorder on both sides
     for call in range(2):
         done, _ = ba.BundleAdjustment(do_surfel_updates=True, min_iterations=2, max_iterations=2, increase_ba_iteration_count=True)
         orc.bundle_adjustment(do_surfel_updates=True, min_iterations=2, max_iterations=2, increase_ba_iteration_count=True)

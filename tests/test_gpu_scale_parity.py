@@ -402,6 +402,7 @@ def test_c2_size_end_to_end_with_surfel_updates():
                                       ba.keyframe_image(k, "color"), ba.keyframe_pose(k))
     orc.covis = [ba.keyframe_covisibility(k) for k in range(K)]
     assert 1 <= min(len(l) for l in orc.covis) < K - 1                          # a real co-visibility structure, not "all with all"
+    orc.spatial_sort_cell, orc.unsorted_surfels = 0.02, ba.unsorted_surfels()   # the end tasks put the buffer in Morton order on both sides
     for call in range(2):
         done, _ = ba.BundleAdjustment(do_surfel_updates=True, optimize_poses=True, optimize_geometry=True, min_iterations=2,
                                       max_iterations=2, increase_ba_iteration_count=True)

@@ -123,7 +123,9 @@ def test_two_shards_reproduce_the_unsharded_run():
     rounds_ref, ref_poses, ref_surfels = ref["out"], ref["poses"], ref["surfels"]
     for r in results:
         r["rounds"] = r["out"]
-    assert loop.calls == sum(rounds_ref)                      # one exchange per Gauss-Newton round, nothing else
+    # one exchange per Gauss-Newton round and nothing else -- plus, since round 4, one per round that was queued ahead of the host
+    # and found nothing left to do (run_pose_rounds: at most three per phase)
+    assert sum(rounds_ref) <= loop.calls <= sum(rounds_ref) + 3 * ITERATIONS, (loop.calls, rounds_ref)
     # every rank took the same number of rounds and ended at the same poses (they see the same summed equations)
     assert results[0]["rounds"] == results[1]["rounds"] == rounds_ref
     # the pose normal equations are summed in fixed point (ba_device.h: HbFixed) and the shards consist of whole 64-surfel
@@ -361,7 +363,9 @@ def test_keyframe_shards_reproduce_the_unsharded_run(world):
     assert not errors, errors
     assert all(r is not None for r in results)
     # per iteration: (activation 1 | 0 when fused) + geometry 2 + one exchange per Gauss-Newton round
-    assert loop.calls == sum((2 if it == 2 else 3) + o[0] for it, o in enumerate(ref["out"]))
+    # (+ at most three per phase for rounds queued ahead of the host that found nothing left to do)
+    expected = sum((2 if it == 2 else 3) + o[0] for it, o in enumerate(ref["out"]))
+    assert expected <= loop.calls <= expected + 3 * len(ref["out"]), (loop.calls, expected)
     for r in results:
         assert r["out"] == ref["out"]                                          # rounds, iteration counts, convergence flags
         for k in range(len(start_poses)):
