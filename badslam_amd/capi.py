@@ -58,6 +58,12 @@ class PCGLayout(C.Structure):
                 ("depth_intrinsics_unknown_start_index", C.c_uint32), ("color_intrinsics_unknown_start_index", C.c_uint32)]
 
 
+class AlternatingOptions(C.Structure):
+    _fields_ = [("use_depth_residuals", C.c_int), ("use_descriptor_residuals", C.c_int), ("fixed_window", C.c_int),
+                ("activate_in_geometry", C.c_int), ("activation_surfels_size", C.c_uint32), ("min_iterations", C.c_int),
+                ("max_iterations", C.c_int)]
+
+
 class PCGOptions(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("optimize_poses", "optimize_geometry", "optimize_depth_intrinsics",
                                        "optimize_color_intrinsics", "use_depth_residuals", "use_descriptor_residuals",
@@ -122,6 +128,9 @@ SIGNATURES = {
     "bahip_estimate_keyframe_poses_and_update_activation": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_float),
                                                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bahip_alternating_iterations": (C.c_int, [C.c_void_p, C.POINTER(AlternatingOptions), C.POINTER(Surfels), C.POINTER(C.c_float),
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bahip_set_covisibility": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "bahip_propagate_covisible_activation": (C.c_int, [C.c_void_p]),
     "bahip_set_activation_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int]),
@@ -165,6 +174,7 @@ SIGNATURES = {
     "bahip_debug_set_pose_lds_items": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_shape": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_pose_rounds_ahead": (C.c_int, [C.c_int]),
+    "bahip_debug_set_device_loop": (C.c_int, [C.c_int]),
     "bahip_debug_pose_form_launches": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "bahip_debug_pose_limbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_longlong)]),
     "bahip_debug_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),

@@ -206,6 +206,14 @@ constexpr int kPoseCounterSequence = 34;
 constexpr long long kHbSumLimit = 1ll << 62;
 constexpr int kPoseCounterInvalid = 35;
 constexpr int kPoseTailRecords = 2;
+// [kPoseCounterWorked]: workgroups of the current solve launch in which a work item took a Gauss-Newton step (cleared by the
+// publishing workgroup; feeds the round count of the device-driven loop)
+constexpr int kPoseCounterWorked = 36;
+// Control words of the device-driven BA loop (capi.hip: bahip_alternating_iterations).  kLoopStop: 0 = run, 1 = the loop has
+// converged (B/direct_ba_alternating.cc:693-701: every keyframe counts as converged and iteration >= min_iterations - 1),
+// 2 = a pose phase ran out of queued Gauss-Newton rounds with work items still iterating (the host continues it) -- every launch
+// of the loop does nothing once it is non-zero.  The rest are totals since the host last cleared them.
+constexpr int kLoopStop = 0, kLoopIterationsDone = 1, kLoopRounds = 2, kLoopSteps = 3, kLoopNotConverged = 4, kLoopWords = 8;
 // Behind the counter records (device only): the indices of the work items still iterating after the latest Gauss-Newton
 // round, in arbitrary order (pose_solve_kernel appends with the same atomic that counts them).  The later rounds of a phase
 // sweep over this list instead of over all work items (a handful of entries instead of K).

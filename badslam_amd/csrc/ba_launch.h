@@ -33,7 +33,8 @@ void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntr
 void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
                      int num_kfs, const SurfelsView& s, long long activate_count = -1,
-                     const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
+                     const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */,
+                     const int* stop = nullptr /* device word: non-zero = the launch does nothing (device-driven BA loop) */);
 
 // keyframe sharding (kernels_surfel.hip: geometry_step, kPhase): one phase of the geometry step over this rank's keyframe classes
 int geometry_normals_sums(bool activate);     // sums per class and surfel of the normals pass (cpn) ...
@@ -57,7 +58,8 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
                             uint32_t* tile_cost = nullptr /* one word per tile, zero before a first round: += the candidates the tile visits */,
                             const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */,
                             const int* listed_count = nullptr /* device word holding num_listed (a round queued before the host
-                            knows it; num_listed is then an upper bound and sizes the LDS table); 0 there: the launch does nothing */);
+                            knows it; num_listed is then an upper bound and sizes the LDS table); 0 there: the launch does nothing */,
+                            const int* stop = nullptr /* device word: non-zero = the launch does nothing (device-driven BA loop) */);
 // May a later round over at most num_items work items be queued ahead (launch_pose_accumulate with listed_count)?
 bool pose_round_can_be_queued_ahead(uint32_t surfels, int num_items, bool have_tile_counters);
 uint32_t pose_padded_tiles(uint32_t surfels);   // tiles of the (padded) grid the sweeps run over: the length of tile_cost
@@ -65,15 +67,29 @@ size_t tile_schedule_words(uint32_t padded_tiles);   // words of a schedule for 
 // sched := heavy tiles + runs by descending cost (wave_cull.h; clears tile_cost); false if there are more runs than the kernel
 // handles (sched untouched)
 bool launch_tile_order(hipStream_t stream, uint32_t* tile_cost, uint32_t padded_tiles, uint32_t* sched);
+// The device-driven BA loop (capi.hip: bahip_alternating_iterations): the control words the last solve launch of a pose phase
+// updates and every launch of the loop looks at (ba_device.h: kLoop*), and what that solve launch needs to decide.
+struct PoseLoopControl {
+  int* ctl = nullptr;          // device, kLoopWords ints; ctl + kLoopStop is the `stop` word of the other launches
+  int* host_ctl = nullptr;     // mapped host copy, written by the publishing workgroup before the sequence number
+  int phase_end = 0;           // this launch is the last queued round of its phase: it decides
+  int iteration = 0;           // index of the BA iteration the phase belongs to (for min_iterations)
+  int min_iterations = 0;
+  int* round_log = nullptr;    // mapped host memory: [log_slot] = work items that iterated in this round (for the stage timers)
+  int log_slot = 0;
+};
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out,
-                       int sequence /* published to the host copy of the counters when the launch is complete */);
+                       int sequence /* published to the host copy of the counters when the launch is complete */,
+                       const PoseLoopControl* loop = nullptr);
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out,
-                                     int kf_rank = 0, int kf_world = 1 /* keyframe sharding: the sweep skips keyframes of other ranks */);
+                                     int kf_rank = 0, int kf_world = 1 /* keyframe sharding: the sweep skips keyframes of other ranks */,
+                                     const int* stop = nullptr);
 
 void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window, const int* offsets,
-                              const int* indices);   // window activation + co-visible propagation
-void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices);
+                              const int* indices, const int* stop = nullptr);   // window activation + co-visible propagation
+void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices,
+                                const int* stop = nullptr);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
 void set_pose_lds_waves(int waves);        // test hook: wavefronts per workgroup of the LDS form (0: 16)

@@ -51,6 +51,7 @@ struct DevMem {
 
 struct StageTimer {
   std::vector<hipEvent_t> ev;   // pairs (start, stop)
+  std::vector<char> skip;       // per pair: not a launch that did work (queued ahead in vain): left out of sums and counts
   int used = 0;                 // number of pairs used by the last call (mode 1) / since set_profiling (mode 2)
   long long units = 0;          // work units of those launches (stage 2: keyframes still iterating)
 };
@@ -121,6 +122,8 @@ struct bahip_context {
   int phases_since_schedule = 0;       // the schedule is rebuilt when the grid changes and every kSchedulePhases-th phase
   uint32_t tile_order_unavailable_tiles = 0;   // a grid the order kernel cannot schedule (too many runs): no census for it again
   bool tile_order_unavailable_for(uint32_t padded_tiles) const { return padded_tiles != 0 && tile_order_unavailable_tiles == padded_tiles; }
+  int* dev_loop_ctl = nullptr;     // device-driven BA loop (bahip_alternating_iterations): kLoopWords control words ...
+  int* host_loop_ctl = nullptr;    // ... their mapped host copy, followed by kLoopLogSlots words of per-round log
   int rounds_hint_table = 1, rounds_hint_frame = 1;   // Gauss-Newton rounds the previous pose phase took (keyframe table / single frame)
 
   float* intr_scratch = nullptr;   // intrinsics step: (64 + 8 S) doubles, then (64 + 8 S) floats + Schur partials
@@ -324,7 +327,9 @@ void timer_begin(bahip_context* ctx, int stage, bool first, int units = 1) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     t.ev.push_back(a); t.ev.push_back(b);
+    t.skip.push_back(0);
   }
+  t.skip[t.used] = 0;
   hipEventRecord(t.ev[2 * t.used], ctx->stream);
 }
 void timer_end(bahip_context* ctx, int stage) {
@@ -414,9 +419,12 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
                     PoseWork* host_work /* page-locked, num_work + kPoseTailRecords records */, int* rounds_out,
                     bool schedule = false /* a phase over the keyframe table: its first round counts the candidates per tile and the
-                    run order of the following sweeps is rebuilt from them */, int* rounds_hint = nullptr) {
+                    run order of the following sweeps is rebuilt from them */, int* rounds_hint = nullptr,
+                    int first_round = 0, int first_iterating = -1 /* continue a phase whose rounds [0, first_round) have run (the
+                    device-driven loop hands over a phase that needs more rounds than it had queued) */,
+                    const PoseLoopControl* loop_stats = nullptr /* keeps the loop's totals going (never ends a phase) */) {
   int rounds = 0;
-  int iterating = num_work;
+  int iterating = first_round > 0 ? first_iterating : num_work;
   const int* counters = reinterpret_cast<const int*>(host_work + num_work);
   const int* dev_counters = reinterpret_cast<const int*>(dev_work + num_work);
   if (ensure_tile_bounds(ctx, s.size)) return 1;
@@ -434,7 +442,7 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
   // context must never equal a sequence number somebody is going to wait for
   static std::atomic<int> g_pose_sequence{0};
   const int wanted_ahead = g_pose_rounds_ahead > 0 ? g_pose_rounds_ahead : std::max(1, std::min(rounds_hint ? *rounds_hint : 1, 4));
-  int round = 0;
+  int round = first_round;
   while (round < BAHIP_MAX_POSE_ITERATIONS && iterating > 0) {
     const double t0 = host_timing ? now() : 0;
     int batch = std::min(wanted_ahead, BAHIP_MAX_POSE_ITERATIONS - round);
@@ -469,7 +477,7 @@ int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfE
       if (!(kf_sharded(ctx) && dev_frames == ctx->dev_frame1) && reduce_over_ranks(ctx, dev_Hb, (size_t)num_work * kHbStride, BAHIP_SUM_I64)) return 1;
       timer_begin(ctx, 3, r == 0);
       sequence = ++g_pose_sequence;
-      launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, r, host_work, sequence);
+      launch_pose_solve(ctx->stream, dev_work, num_work, dev_Hb, dev_frames_rw, write_back, update_activation, r, host_work, sequence, loop_stats);
       timer_end(ctx, 3);
       CHECK_LAUNCH();
     }
@@ -650,6 +658,8 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl); hipFree(ctx->kf_partials);
   hipFree(ctx->dev_tile_cost); hipFree(ctx->dev_tile_order);
+  hipFree(ctx->dev_loop_ctl);
+  if (ctx->host_loop_ctl) hipHostFree(ctx->host_loop_ctl);
   if (ctx->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->rccl_comm);
   for (bahip_frame_planes* p : ctx->auto_planes) planes_free(p);
   for (auto& t : ctx->timers) for (auto e : t.ev) hipEventDestroy(e);
@@ -1085,6 +1095,158 @@ int bahip_estimate_keyframe_poses_and_update_activation(bahip_context* ctx, int 
                                                         int* rounds_out, int* num_converged_out) {
   return estimate_keyframe_poses_impl(ctx, use_depth, use_desc, surfels, global_T_frame_out, iterations_done, converged, rounds_out,
                                       true, moved, num_converged_out);
+}
+
+// ---- the alternating loop, driven by the device (include/badslam_hip.h) ---------------------------------------------------------
+namespace {
+constexpr int kLoopLogSlots = 4096;
+int g_device_loop_enabled = [] { const char* e = getenv("BAHIP_DEVICE_LOOP"); return (e && atoi(e) == 0) ? 0 : 1; }();
+}
+int bahip_debug_set_device_loop(int enabled) { g_device_loop_enabled = enabled ? 1 : 0; return 0; }
+int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_options* opt, const bahip_surfels* surfels,
+                                 float* global_T_frame_out, int* activation_out, int* handled_out, int* iterations_done_out,
+                                 int* converged_out, int* pose_rounds_out, int* pose_steps_out, int* not_converged_out) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(opt != nullptr && handled_out != nullptr, "bahip_alternating_iterations: NULL argument");
+  REQUIRE(opt->use_depth_residuals || opt->use_descriptor_residuals, "at least one residual type must be enabled");
+  const int K = ctx->num_kfs;
+  *handled_out = 0;
+  if (iterations_done_out) *iterations_done_out = 0;
+  if (converged_out) *converged_out = 0;
+  if (pose_rounds_out) *pose_rounds_out = 0;
+  if (pose_steps_out) *pose_steps_out = 0;
+  if (not_converged_out) *not_converged_out = 0;
+  if (!g_device_loop_enabled || K == 0 || kf_sharded(ctx) || opt->max_iterations <= 0 || !pose_round_can_be_queued_ahead(surfels->surfels_size, K, true)) return 0;
+  REQUIRE(surfels->active != nullptr, "the alternating loop needs the active-surfel buffer");
+  REQUIRE(ctx->have_covisibility && (int)ctx->covis_offsets.size() == K + 1, "bahip_set_covisibility must follow bahip_set_keyframes");
+  REQUIRE(!opt->fixed_window || (int)ctx->window.size() == K, "bahip_set_activation_window must follow bahip_set_keyframes");
+  REQUIRE(opt->activation_surfels_size <= surfels->surfels_size, "activation range exceeds surfels_size");
+  if (ensure_work(ctx, K)) return 1;
+  if (!ctx->dev_loop_ctl) {
+    HIP_TRY(hipMalloc(&ctx->dev_loop_ctl, sizeof(int) * kLoopWords));
+    HIP_TRY(hipHostMalloc(&ctx->host_loop_ctl, sizeof(int) * (kLoopWords + kLoopLogSlots), hipHostMallocMapped | hipHostMallocCoherent));
+  }
+  const SurfelsView sv = make_view(surfels);
+  if (ensure_tile_bounds(ctx, sv.size)) return 1;
+  const bool use_depth = opt->use_depth_residuals != 0, use_desc = opt->use_descriptor_residuals != 0;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(hipMemsetAsync(ctx->dev_loop_ctl, 0, sizeof(int) * kLoopWords, st));
+  memset(ctx->host_loop_ctl, 0, sizeof(int) * kLoopWords);
+  if (ctx->profiling == 1) for (int stage = 1; stage <= 3; ++stage) { ctx->timers[stage].used = 0; ctx->timers[stage].units = 0; }   // "the last call"
+  const int* stop = ctx->dev_loop_ctl + kLoopStop;
+  const int* dev_counters = reinterpret_cast<const int*>(ctx->dev_work + K);
+  const int* counters = reinterpret_cast<const int*>(ctx->pinned_work + K);
+  const int* csr = ctx->dev_covis_csr;
+  static std::atomic<int> g_loop_sequence{1 << 30};   // disjoint from run_pose_rounds' numbers (which count up from 1)
+  const uint32_t padded_tiles = pose_padded_tiles(sv.size);
+  int rounds_ahead = g_pose_rounds_ahead > 0 ? g_pose_rounds_ahead : std::max(1, std::min(ctx->rounds_hint_table, 4));
+  int it = 0, done_before = 0;
+  bool converged = false;
+  while (it < opt->max_iterations) {
+    // heavy work first (wave_cull.h): the first phase queued here takes the census when one is due
+    constexpr int kSchedulePhases = 32;
+    bool schedule = g_tile_order_enabled && sv.size > 0 && !ctx->tile_order_unavailable_for(padded_tiles) &&
+                    (ctx->tile_order_tiles != padded_tiles || ++ctx->phases_since_schedule >= kSchedulePhases);
+    if (schedule && ensure_tile_schedule(ctx, padded_tiles)) return 1;
+    StageTimer& acc_timer = ctx->timers[2];
+    const int acc_mark = acc_timer.used;
+    int log_slot = 0, sequence = 0;
+    for (int i = it; i < opt->max_iterations; ++i) {
+      if (opt->fixed_window) launch_window_activation(st, ctx->dev_kfs, K, ctx->dev_window, csr, csr + K + 1, stop);
+      else if (i > 0) launch_propagate_covisible(st, ctx->dev_kfs, K, csr, csr + K + 1, stop);   // closes iteration i - 1 (B/direct_ba_alternating.cc:703-709)
+      timer_begin(ctx, 1, true);
+      launch_geometry(st, use_depth, use_desc, ctx->in, ctx->dev_kfs, K, sv, opt->activate_in_geometry ? (long long)opt->activation_surfels_size : -1,
+                      tile_order_for(ctx, sv.size), stop);
+      timer_end(ctx, 1);
+      launch_pose_init_from_keyframes(st, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, 0, 1, stop);
+      CHECK_LAUNCH();
+      for (int r = 0; r < rounds_ahead; ++r) {
+        timer_begin(ctx, 2, false, 0);
+        launch_pose_accumulate(st, use_depth, use_desc, ctx->in, ctx->dev_kfs, ctx->dev_work, K, sv, ctx->dev_Hb, ctx->dev_tile_bounds,
+                               /*stored_bounds*/ r > 0, /*num_listed: upper bound*/ K, ctx->dev_tile_counters, &ctx->pose_parity,
+                               (schedule && r == 0) ? ctx->dev_tile_cost : nullptr, tile_order_for(ctx, sv.size),
+                               r > 0 ? dev_counters + (r - 1) : nullptr, stop);
+        timer_end(ctx, 2);
+        CHECK_LAUNCH();
+        if (schedule && r == 0) {
+          if (launch_tile_order(st, ctx->dev_tile_cost, padded_tiles, ctx->dev_tile_order)) {
+            ctx->tile_order_tiles = padded_tiles;
+            ctx->phases_since_schedule = 0;
+            CHECK_LAUNCH();
+          } else {
+            ctx->tile_order_unavailable_tiles = padded_tiles;
+            HIP_TRY(hipMemsetAsync(ctx->dev_tile_cost, 0, sizeof(uint32_t) * padded_tiles, st));
+          }
+          schedule = false;
+        }
+        if (reduce_over_ranks(ctx, ctx->dev_Hb, (size_t)K * kHbStride, BAHIP_SUM_I64)) return 1;
+        PoseLoopControl loop;
+        loop.ctl = ctx->dev_loop_ctl; loop.host_ctl = ctx->host_loop_ctl;
+        loop.phase_end = r == rounds_ahead - 1 ? 1 : 0;
+        loop.iteration = i; loop.min_iterations = opt->min_iterations;
+        loop.round_log = log_slot < kLoopLogSlots ? ctx->host_loop_ctl + kLoopWords : nullptr;
+        loop.log_slot = log_slot++;
+        timer_begin(ctx, 3, false);
+        sequence = ++g_loop_sequence;
+        launch_pose_solve(st, ctx->dev_work, K, ctx->dev_Hb, ctx->dev_kfs, /*write_back*/ 1, /*update_activation*/ 1, r, ctx->pinned_work, sequence, &loop);
+        timer_end(ctx, 3);
+        CHECK_LAUNCH();
+      }
+    }
+    if (wait_for_pose_sequence(ctx, ctx->pinned_work, ctx->dev_work, K, sequence)) return 1;
+    if (ctx->poll_disabled) HIP_TRY(hipMemcpy(ctx->host_loop_ctl, ctx->dev_loop_ctl, sizeof(int) * kLoopWords, hipMemcpyDeviceToHost));
+    if (counters[kPoseCounterInvalid])
+      return fail("pose normal equations: a tile total was not finite or reached 2^52 (hb_split), or a sum left the fixed-point range; the "
+                  "surfels or images hold non-finite values", __FILE__, __LINE__);
+    const int* ctl = ctx->host_loop_ctl;
+    // the stage timers describe launches that did work: the log says how many work items every queued round iterated
+    if (timer_on(ctx, 2)) {
+      const int* log = ctl + kLoopWords;
+      for (int j = 0; j < log_slot && acc_mark + j < acc_timer.used; ++j) {
+        if (j < kLoopLogSlots && !ctx->poll_disabled) {
+          if (log[j] == 0) acc_timer.skip[acc_mark + j] = 1;
+          else acc_timer.units += log[j];
+        }
+      }
+    }
+    const int completed = ctl[kLoopIterationsDone] - done_before;
+    done_before = ctl[kLoopIterationsDone];
+    it += completed;
+    if (ctl[kLoopStop] == 1) { converged = true; break; }
+    if (ctl[kLoopStop] == 2) {
+      // iteration `it`'s pose phase has work items left after the rounds queued for it: the host finishes it round by round,
+      // applies the loop's stopping rule itself, and queues what is left with more rounds per phase
+      HIP_TRY(hipMemsetAsync(ctx->dev_loop_ctl + kLoopStop, 0, sizeof(int), st));
+      PoseLoopControl totals;
+      totals.ctl = ctx->dev_loop_ctl; totals.host_ctl = ctx->host_loop_ctl;
+      if (run_pose_rounds(ctx, use_depth, use_desc, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K, sv, 1, 1, ctx->pinned_work, nullptr,
+                          false, nullptr, rounds_ahead, counters[rounds_ahead - 1], &totals)) return 1;
+      const bool all_converged = counters[kPoseCounterConverged] == K;
+      const bool ends_loop = it >= opt->min_iterations - 1 && all_converged;
+      it += 1;
+      rounds_ahead = std::min(2 * rounds_ahead, 8);
+      if (ends_loop) { converged = true; break; }
+      continue;
+    }
+    break;   // every queued iteration ran
+  }
+  // the table after the last pose phase: poses and activations
+  HIP_TRY(hipMemcpyAsync(ctx->host_kfs.data(), ctx->dev_kfs, sizeof(KfEntry) * K, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->host_loop_ctl, ctx->dev_loop_ctl, sizeof(int) * kLoopWords, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int k = 0; k < K; ++k) {
+    if (global_T_frame_out) memcpy(global_T_frame_out + 7 * k, ctx->host_kfs[k].global_T_frame, 7 * sizeof(float));
+    if (activation_out) activation_out[k] = ctx->host_kfs[k].activation;
+  }
+  const int rounds_total = ctx->host_loop_ctl[kLoopRounds];
+  if (it > 0) ctx->rounds_hint_table = std::max(1, (rounds_total + it - 1) / it);
+  *handled_out = 1;
+  if (iterations_done_out) *iterations_done_out = it;
+  if (converged_out) *converged_out = converged ? 1 : 0;
+  if (pose_rounds_out) *pose_rounds_out = rounds_total;
+  if (pose_steps_out) *pose_steps_out = ctx->host_loop_ctl[kLoopSteps];
+  if (not_converged_out) *not_converged_out = ctx->host_loop_ctl[kLoopNotConverged];
+  return 0;
 }
 
 int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* indices, int num_keyframes) {
@@ -1936,14 +2098,17 @@ int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* 
   REQUIRE(stage >= 0 && stage < 6, "stage out of range");
   StageTimer& t = ctx->timers[stage];
   float total = 0.f;
+  int launches = 0;
   for (int i = 0; i < t.used; ++i) {
+    if (t.skip[i]) continue;
     HIP_TRY(hipEventSynchronize(t.ev[2 * i + 1]));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]));
     total += ms;
+    ++launches;
   }
   *ms_out = total;
-  if (launches_out) *launches_out = t.used;
+  if (launches_out) *launches_out = launches;
   return 0;
 }
 

@@ -318,8 +318,10 @@ pose_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ frames, const 
                        stays read-only to the compiler: the per-candidate pose rows are then scalar loads */,
                        uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched,
                        const int* __restrict__ listed_count /* a later round queued before the host knew how many work items are
-                       left (run_pose_rounds): the count the previous round's solve kernel left on the device; 0 = nothing to do */) {
+                       left (run_pose_rounds): the count the previous round's solve kernel left on the device; 0 = nothing to do */,
+                       const int* __restrict__ stop /* device-driven BA loop: non-zero = nothing to do */) {
   const int lane = threadIdx.x & 63;
+  if (stop && __builtin_amdgcn_readfirstlane(load_global(stop)) != 0) return;
   if (listed_count) {
     num_listed = __builtin_amdgcn_readfirstlane(load_global(listed_count));
     if (num_listed == 0) return;
@@ -359,11 +361,13 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
                            int slice_begin, int slice_count, uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ sched,
                            const int* __restrict__ listed_count /* as in pose_accumulate_kernel */,
                            uint32_t parts_shift /* 2^parts_shift wavefronts share a tile's work items: the unit a wavefront draws is
-                           (tile, part) -- small grids (a shard of a multi-GPU run) otherwise last as long as their longest tile */) {
+                           (tile, part) -- small grids (a shard of a multi-GPU run) otherwise last as long as their longest tile */,
+                           const int* __restrict__ stop /* as in pose_accumulate_kernel */) {
   extern __shared__ HbFixed table[];
   const int lane = threadIdx.x & 63;
   // (both sets of tile counters are in a defined state after every launch, also one that finds nothing to do)
   if (blockIdx.x == 0 && threadIdx.x < 8) tile_counters[(parity ^ 1) * 8 + threadIdx.x] = 0;
+  if (stop && __builtin_amdgcn_readfirstlane(load_global(stop)) != 0) return;
   if (listed_count) {
     num_listed = __builtin_amdgcn_readfirstlane(load_global(listed_count));
     if (num_listed == 0) return;
@@ -500,10 +504,15 @@ __device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* 
 // so the host needs no copy of the work array, only the 256 bytes of counters per round.
 __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
                                   KfEntry* __restrict__ frames, int write_back, int update_activation, int round,
-                                  PoseWork* __restrict__ host_out, int sequence) {
+                                  PoseWork* __restrict__ host_out, int sequence, PoseLoopControl loop) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   int* counters = reinterpret_cast<int*>(work + num_work);
-  if (w < num_work && !work[w].done) {
+  // device-driven BA loop: once the loop has stopped, the launches queued behind do no work -- but still publish their
+  // sequence number, the host may be waiting for exactly this launch
+  const bool stopped = loop.ctl != nullptr && __hip_atomic_load(&loop.ctl[kLoopStop], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  bool stepped = false;
+  if (!stopped && w < num_work && !work[w].done) {
+    stepped = true;
     PoseWork& pw = work[w];
     HbFixed* fixed = Hb + (size_t)w * kHbStride;
     float hb[27];
@@ -528,6 +537,7 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
     if (conv || pw.iterations >= BAHIP_MAX_POSE_ITERATIONS) {
       pw.done = 1;
       pw.skip = 1;
+      if (!conv && loop.ctl) atomicAdd(&loop.ctl[kLoopNotConverged], 1);
       if (write_back) {
         KfEntry& kf = frames[pw.kf_index];
         for (int c = 0; c < 7; ++c) kf.global_T_frame[c] = next[c];
@@ -552,12 +562,37 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
   }
   // The last workgroup to finish publishes the counters to the host copy and then the launch's sequence number, which the
   // host polls: the records written to host_out above (mapped, coherent host memory) are fenced before it.
+  const int steps_here = __syncthreads_count(stepped ? 1 : 0);
+  if (loop.ctl && threadIdx.x == 0 && steps_here) {
+    atomicAdd(&loop.ctl[kLoopSteps], steps_here);
+    atomicAdd(&counters[kPoseCounterWorked], steps_here);
+  }
   __threadfence_system();
   __syncthreads();
   __shared__ int is_last;
   if (threadIdx.x == 0) is_last = atomicAdd(&counters[kPoseCounterTicket], 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (is_last) {   // workgroup-uniform; 64 threads = the 64 counter words
+    if (loop.ctl && threadIdx.x == 0) {
+      // what this round did, and -- at the end of a phase -- whether the loop goes on (B/direct_ba_alternating.cc:693-701)
+      const int worked = __hip_atomic_load(&counters[kPoseCounterWorked], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      counters[kPoseCounterWorked] = 0;
+      if (loop.round_log) loop.round_log[loop.log_slot] = worked;
+      if (worked) atomicAdd(&loop.ctl[kLoopRounds], 1);
+      if (!stopped && loop.phase_end) {
+        const int iterating = __hip_atomic_load(&counters[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (iterating > 0) {
+          __hip_atomic_store(&loop.ctl[kLoopStop], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the host continues this phase
+        } else {
+          atomicAdd(&loop.ctl[kLoopIterationsDone], 1);
+          const int converged = __hip_atomic_load(&counters[kPoseCounterConverged], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (loop.iteration >= loop.min_iterations - 1 && converged == num_work)
+            __hip_atomic_store(&loop.ctl[kLoopStop], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      for (int c = 0; c < kLoopWords; ++c) loop.host_ctl[c] = __hip_atomic_load(&loop.ctl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     int* host_counters = reinterpret_cast<int*>(host_out + num_work);
     const int c = threadIdx.x;
     if (c < kPoseTailRecords * 32 && c != kPoseCounterTicket && c != kPoseCounterSequence)
@@ -594,7 +629,9 @@ void launch_pose_step_debug(hipStream_t stream, const float* in, float* out) {
 template <bool kSingleBlock>
 __global__ void __launch_bounds__(kSingleBlock ? 1024 : 64)
 pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs, PoseWork* __restrict__ work,
-                                HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out, uint32_t owner_mask, uint32_t owner_rank) {
+                                HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out, uint32_t owner_mask, uint32_t owner_rank,
+                                const int* __restrict__ stop) {
+  if (stop && load_global(stop) != 0) return;   // device-driven BA loop: the loop has ended, the work items stay as they are
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = k < num_kfs;
   const bool inactive = in_range && frames[k].activation == BAHIP_KF_INACTIVE;
@@ -629,7 +666,8 @@ pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs,
 // co-visible with a kActive one becomes kCovisibleActive.  Lists in CSR form over bound keyframe indices.  Order-free: a
 // write only turns kInactive into kCovisibleActive and only kActive entries are sources.
 __global__ void propagate_covisible_kernel(KfEntry* __restrict__ frames, int num_kfs, const int* __restrict__ offsets,
-                                           const int* __restrict__ indices) {
+                                           const int* __restrict__ indices, const int* __restrict__ stop) {
+  if (stop && load_global(stop) != 0) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num_kfs || frames[k].activation != BAHIP_KF_ACTIVE) return;
   for (int j = offsets[k]; j < offsets[k + 1]; ++j) {
@@ -640,7 +678,9 @@ __global__ void propagate_covisible_kernel(KfEntry* __restrict__ frames, int num
 
 // Top of an alternating iteration with a fixed active window (B/direct_ba_alternating.cc:353-371): keyframes inside the window
 // become kActive, all others kInactive (the co-visible ones are then raised by propagate_covisible_kernel).
-__global__ void window_activation_kernel(KfEntry* __restrict__ frames, int num_kfs, const uint8_t* __restrict__ in_window) {
+__global__ void window_activation_kernel(KfEntry* __restrict__ frames, int num_kfs, const uint8_t* __restrict__ in_window,
+                                         const int* __restrict__ stop) {
+  if (stop && load_global(stop) != 0) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < num_kfs) frames[k].activation = in_window[k] ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
 }
@@ -650,7 +690,9 @@ __global__ void window_activation_kernel(KfEntry* __restrict__ frames, int num_k
 // alone took 43 us at 200 keyframes: 200 dependent loads).
 __global__ void __launch_bounds__(1024) window_and_propagate_kernel(KfEntry* __restrict__ frames, int num_kfs,
                                                                     const uint8_t* __restrict__ in_window,
-                                                                    const int* __restrict__ offsets, const int* __restrict__ indices) {
+                                                                    const int* __restrict__ offsets, const int* __restrict__ indices,
+                                                                    const int* __restrict__ stop) {
+  if (stop && load_global(stop) != 0) return;
   const int k = threadIdx.x;
   const bool inside = k < num_kfs && in_window[k];
   if (k < num_kfs) frames[k].activation = inside ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
@@ -668,17 +710,17 @@ __global__ void __launch_bounds__(1024) window_and_propagate_kernel(KfEntry* __r
 
 // ---- launchers -----------------------------------------------------------------------------------
 void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, const uint8_t* in_window, const int* offsets,
-                              const int* indices) {
+                              const int* indices, const int* stop) {
   if (num_kfs == 0) return;
   if (num_kfs <= 1024) {
-    hipLaunchKernelGGL(window_and_propagate_kernel, dim3(1), dim3(1024), 0, stream, frames, num_kfs, in_window, offsets, indices);
+    hipLaunchKernelGGL(window_and_propagate_kernel, dim3(1), dim3(1024), 0, stream, frames, num_kfs, in_window, offsets, indices, stop);
   } else {
-    hipLaunchKernelGGL(window_activation_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, in_window);
-    hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices);
+    hipLaunchKernelGGL(window_activation_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, in_window, stop);
+    hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices, stop);
   }
 }
-void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices) {
-  if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices);
+void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices, const int* stop) {
+  if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices, stop);
 }
 
 static int g_forced_pose_parts = [] { const char* e = getenv("BAHIP_POSE_PARTS"); return e ? atoi(e) : 0; }();
@@ -733,7 +775,7 @@ template <bool kUseDepth, bool kUseDesc, bool kSlice>
 static bool launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
                             const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
                             uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost, const uint32_t* sched,
-                            const int* listed_count, uint32_t parts_shift) {
+                            const int* listed_count, uint32_t parts_shift, const int* stop) {
   int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
   PoseLdsDevice& device = pose_lds_device();
   constexpr int variant = (kUseDepth ? 1 : 0) + (kUseDesc ? 2 : 0) + (kSlice ? 4 : 0);
@@ -748,17 +790,17 @@ static bool launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEn
   const unsigned units = sched_positions(tiles, sched) << parts_shift;
   const unsigned grid = std::max(8u, std::min((unsigned)device.compute_units, ((units + waves - 1) / waves + 7u) & ~7u));
   hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(grid), dim3(64 * waves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
-                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
+                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
   return true;
 }
 template <bool kSlice>
 static bool launch_pose_lds_any(bool use_depth, bool use_desc, hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw,
                                 int num_work, const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles,
                                 size_t table_bytes, uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost,
-                                const uint32_t* sched, const int* listed_count, uint32_t parts_shift) {
-  if (use_depth && use_desc) return launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
-  if (use_depth) return launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
-  return launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift);
+                                const uint32_t* sched, const int* listed_count, uint32_t parts_shift, const int* stop) {
+  if (use_depth && use_desc) return launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
+  if (use_depth) return launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
+  return launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
 }
 
 // Can a later round over (at most) `num_items` work items be queued before the host knows how many are left?  Yes unless the
@@ -774,7 +816,7 @@ bool pose_round_can_be_queued_ahead(uint32_t /*surfels*/, int num_items, bool /*
 void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
                             const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
                             int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched,
-                            const int* listed_count) {
+                            const int* listed_count, const int* stop) {
   if (s.size == 0 || num_work == 0) return;
   // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
   // wavefront with the most candidate keyframes: split every wavefront's candidates over several wavefronts
@@ -804,7 +846,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
     bool launched = true;
     if (num_items <= per_launch) {
       const int parity = *parity_inout;
-      launched = launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0, tile_cost, sched, listed_count, parts_shift);
+      launched = launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0, tile_cost, sched, listed_count, parts_shift, stop);
       if (launched) *parity_inout = parity ^ 1;
     } else {
       // more work items than the table holds: slices of equal size, one launch each (every launch sweeps all tiles and culls
@@ -813,7 +855,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
       for (int begin = 0; begin < num_items && launched; begin += per_slice) {
         const int count = std::min(per_slice, num_items - begin);
         const int parity = *parity_inout;
-        launched = launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count, tile_cost, sched, nullptr, parts_shift);
+        launched = launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count, tile_cost, sched, nullptr, parts_shift, stop);
         if (launched) *parity_inout = parity ^ 1;
       }
     }
@@ -823,9 +865,9 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   ++g_pose_form_launches[0];
   const dim3 grid(sched_positions(tiles, sched), parts), block(kPoseBlock);
   int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
 }
 
 // The schedule of the sweeps that follow (wave_cull.h: scheduled_tile) from the candidates every tile visited in the pose sweep's
@@ -949,22 +991,23 @@ size_t tile_schedule_words(uint32_t padded_tiles) { return sched_words(padded_ti
 uint32_t pose_padded_tiles(uint32_t surfels) { return xcd_padded_tiles((surfels + kPoseBlock - 1) / kPoseBlock); }
 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
-                       int update_activation, int round, void* host_out, int sequence) {
+                       int update_activation, int round, void* host_out, int sequence, const PoseLoopControl* loop) {
   if (num_work == 0) return;
   hipLaunchKernelGGL(pose_solve_kernel, dim3((num_work + 63) / 64), dim3(64), 0, stream, static_cast<PoseWork*>(work),
-                     num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out), sequence);
+                     num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out), sequence,
+                     loop ? *loop : PoseLoopControl{});
 }
 
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out,
-                                     int kf_rank, int kf_world) {
+                                     int kf_rank, int kf_world, const int* stop) {
   if (num_kfs == 0) return;
   const uint32_t mask = (uint32_t)(kf_world - 1), rank = (uint32_t)kf_rank;
   if (num_kfs <= 1024)
     hipLaunchKernelGGL(pose_init_from_keyframes_kernel<true>, dim3(1), dim3(1024), 0, stream, frames, num_kfs,
-                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), mask, rank);
+                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), mask, rank, stop);
   else
     hipLaunchKernelGGL(pose_init_from_keyframes_kernel<false>, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs,
-                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), mask, rank);
+                       static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), mask, rank, stop);
 }
 
 

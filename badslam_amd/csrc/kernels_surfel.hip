@@ -429,8 +429,10 @@ void geometry_timeline_dump(const char* path) {
 template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate>
 __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
 geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
-                const uint32_t* __restrict__ sched) {
+                const uint32_t* __restrict__ sched, const int* __restrict__ stop /* device-driven BA loop (capi.hip:
+                bahip_alternating_iterations): a launch queued behind the iteration that ended the loop does nothing; NULL: always runs */) {
   __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
+  if (stop && load_global(stop) != 0) return;
 #ifdef BAHIP_TILE_TIMELINE
   const unsigned long long t0 = wall_clock64();
 #endif
@@ -518,25 +520,25 @@ void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs
 
 template <int kWaves, bool kActivate>
 static void launch_geometry_shape(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                                  int num_kfs, const SurfelsView& s, uint32_t activate_count, const uint32_t* sched) {
+                                  int num_kfs, const SurfelsView& s, uint32_t activate_count, const uint32_t* sched, const int* stop) {
   const dim3 grid(sched_positions(grid_for(s.size), sched)), block(64 * kWaves);
-  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched);
-  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched);
-  else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched);
+  if (!use_desc) hipLaunchKernelGGL((geometry_kernel<true, false, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched, stop);
+  else if (use_depth) hipLaunchKernelGGL((geometry_kernel<true, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched, stop);
+  else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched, stop);
 }
 
 // activate_count < 0: the activation flags are taken as they are; >= 0: surfels [0, activate_count) are (re)activated first.
 // `sched`: the schedule of a grid of grid_for(s.size) tiles (wave_cull.h: scheduled_tile), or NULL.
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
-                     int num_kfs, const SurfelsView& s, long long activate_count, const uint32_t* sched) {
+                     int num_kfs, const SurfelsView& s, long long activate_count, const uint32_t* sched, const int* stop) {
   if (s.size == 0) return;
   const uint32_t n = activate_count < 0 ? 0u : (uint32_t)activate_count;
   if (tile_waves(s.size) == 1) {
-    if (activate_count < 0) launch_geometry_shape<1, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
-    else launch_geometry_shape<1, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
+    if (activate_count < 0) launch_geometry_shape<1, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
+    else launch_geometry_shape<1, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
   } else {
-    if (activate_count < 0) launch_geometry_shape<4, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
-    else launch_geometry_shape<4, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched);
+    if (activate_count < 0) launch_geometry_shape<4, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
+    else launch_geometry_shape<4, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
   }
 }
 

@@ -431,7 +431,59 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
   double t_mark = now();
   auto lap = [&](int phase) { if (host_timing) { const double t = now(); t_phase[phase] += t - t_mark; t_mark = t; } };
 
-  for (int iteration = 0; iteration < max_iterations; ++iteration) {
+  // ---- the loop driven by the device (bahip_alternating_iterations): poses + geometry over a fixed surfel set, nothing the
+  // host has to look at between the iterations.  All iterations are queued at once; the stopping rule of :693-701 is evaluated
+  // by the last solve launch of every pose phase, and the host waits once.  Everything else takes the loop below.
+  bool device_loop_done = false;
+  if (optimize_poses && optimize_geometry && !do_surfel_updates && !optimize_depth_intrinsics && !optimize_color_intrinsics &&
+      !progress_function && !timer && !timings_stream_ && keyframe_shard_world_ == 1 && full_window && max_iterations > 0) {
+    if (fixed_active_keyframe_set) {
+      Lock();
+      set_window_activation();
+      Unlock();
+    }
+    BindScene(stream);
+    if (fixed_active_keyframe_set) {
+      vector<uint8_t> in_window(bound_ids_.size());
+      for (usize b = 0; b < bound_ids_.size(); ++b)
+        in_window[b] = (bound_ids_[b] >= active_keyframe_window_start && bound_ids_[b] <= active_keyframe_window_end) ? 1 : 0;
+      BAHIP_CHECKED_CALL(bahip_set_activation_window(ctx_, in_window.data(), (int)in_window.size()));
+    }
+    const int K = (int)bound_ids_.size();
+    vector<float> poses(7 * (size_t)std::max(K, 1));
+    vector<int> activation(std::max(K, 1));
+    bahip_alternating_options options;
+    options.use_depth_residuals = use_depth_residuals_; options.use_descriptor_residuals = use_descriptor_residuals_;
+    options.fixed_window = fixed_active_keyframe_set ? 1 : 0;
+    options.activate_in_geometry = 1;                        // full window: UpdateSurfelActivation inside the geometry sweep
+    options.activation_surfels_size = surfels_size_;
+    options.min_iterations = min_iterations; options.max_iterations = max_iterations;
+    const bahip_surfels s = SurfelsStruct();
+    int handled = 0, done = 0, conv = 0, rounds = 0, steps = 0, not_converged = 0;
+    BAHIP_CHECKED_CALL(bahip_alternating_iterations(ctx_, &options, &s, poses.data(), activation.data(), &handled, &done, &conv, &rounds, &steps,
+                                                    &not_converged));
+    if (handled) {
+      device_loop_done = true;
+      Lock();
+      for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
+        if (!keyframe) continue;
+        const int b = id_to_bound_[keyframe->id()];
+        keyframe->set_global_T_frame(SE3f(&poses[7 * (size_t)b]));
+        keyframe->SetActivation(static_cast<Keyframe::Activation>(activation[b]));
+      }
+      // the device table is in the state after the last pose phase; an iteration that did not end the loop is followed by
+      // DetermineCovisibleActiveKeyframes (:703-709)
+      if (!conv) DetermineCovisibleActiveKeyframes();
+      Unlock();
+      if (num_iterations_done) *num_iterations_done = done;
+      if (converged) *converged = conv != 0;
+      last_pose_rounds_ += rounds;
+      last_pose_steps_ += steps;
+      if (not_converged) LOG(WARNING) << "Pose estimation not converged (" << not_converged << " estimations)";
+    }
+  }
+
+  for (int iteration = 0; iteration < max_iterations && !device_loop_done; ++iteration) {
     if (progress_function) {
       apply_pending();   // the callback may look at the keyframes
       if (!progress_function(iteration)) break;

@@ -37,6 +37,7 @@ int main() {
 
   // ---- Route A: vis::DirectBA ----
   DirectBA ba(400000, kRawToFloat, kBaselineFx, CELL, 0.8f, 1, 1, 1, camera, camera, 0, true, true, nullptr, SE3f());
+  ba.SetSpatialSortCellSize(0);   // Route B keeps its caller's buffers in the reference's order: Route A must not reorder its own (index-wise memcmp below)
   vector<shared_ptr<Keyframe>> keyframes;
   for (int k = 0; k < K; ++k) {
     Image<u16> depth(W, H); Image<Vec3u8> rgb(W, H);

@@ -255,6 +255,30 @@ int bahip_estimate_keyframe_poses_and_update_activation(bahip_context* ctx, int 
                                                         const bahip_surfels* surfels, float* global_T_frame_out,
                                                         int* iterations_done, int* converged, int* moved, int* rounds_out,
                                                         int* num_converged_out);
+/* The whole loop of the alternating scheme (B/direct_ba_alternating.cc:345-718) over poses and geometry for a FIXED surfel set,
+ * driven by the device: up to max_iterations iterations -- [activation window | co-visible propagation], activation + geometry
+ * sweep, pose phase -- are queued back to back; the last solve launch of every pose phase evaluates the loop's stopping rule
+ * (every keyframe counts as converged and iteration >= min_iterations - 1, :693-701) and raises a device word that turns
+ * every launch queued behind it into a no-op.  The host waits ONCE, for the last launch, instead of after every Gauss-Newton
+ * round.  A pose phase that needs more rounds than were queued for it raises the word too; the host then finishes that phase
+ * round by round and queues the rest again -- results never depend on how many rounds were queued.  Needs bahip_set_keyframes,
+ * bahip_set_covisibility and (fixed_window) bahip_set_activation_window; the device keyframe table carries the new poses and
+ * activations afterwards (without the co-visible propagation that follows an iteration that did not end the loop: the caller
+ * applies DetermineCovisibleActiveKeyframes itself when *converged_out == 0).
+ * *handled_out = 0 and nothing done when the configuration is not covered (keyframe sharding, more keyframes than one launch of
+ * the pose sums takes): the caller then drives the iterations through the stage functions above.
+ * global_T_frame_out: 7 floats per bound keyframe; activation_out: BAHIP_KF_* per bound keyframe; not_converged_out: pose
+ * estimations that hit BAHIP_MAX_POSE_ITERATIONS. */
+typedef struct {
+  int use_depth_residuals, use_descriptor_residuals;
+  int fixed_window;              /* apply the bound activation window at the top of every iteration */
+  int activate_in_geometry;      /* 1: UpdateSurfelActivation is part of the geometry sweep (full window); 0: flags as they are */
+  uint32_t activation_surfels_size;
+  int min_iterations, max_iterations;
+} bahip_alternating_options;
+int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_options* options, const bahip_surfels* surfels,
+                                 float* global_T_frame_out, int* activation_out, int* handled_out, int* iterations_done_out,
+                                 int* converged_out, int* pose_rounds_out, int* pose_steps_out, int* not_converged_out);
 /* Co-visibility lists of the bound keyframes in CSR form over bound indices (offsets: num_keyframes + 1 entries); call after
  * bahip_set_keyframes.  bahip_propagate_covisible_activation is DirectBA::DetermineCovisibleActiveKeyframes
  * (B/direct_ba.cc:549-564) on the device table: kInactive keyframes co-visible with a kActive one become kCovisibleActive.
@@ -421,6 +445,9 @@ int bahip_debug_set_pose_lds_shape(int waves, int parts_shift);
  * the next): 0 = as many as the previous phase needed (default), n >= 1 = exactly n (1: wait after every round, the round-3
  * behaviour).  Results do not depend on it. */
 int bahip_debug_set_pose_rounds_ahead(int rounds);
+/* 0: bahip_alternating_iterations reports "not handled" and callers drive the loop through the stage functions, one host wait
+ * per Gauss-Newton round (BAHIP_DEVICE_LOOP=0 in the environment does the same); 1 (default): the device-driven loop.  Same bits. */
+int bahip_debug_set_device_loop(int enabled);
 /* launches of the pose accumulation in either form since the last reset (process-wide); bench.py names the dominant kernel by it */
 int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):

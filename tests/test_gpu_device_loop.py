@@ -1,0 +1,63 @@
+"""The alternating loop driven by the device (bahip_alternating_iterations, used by vis::DirectBA::BundleAdjustment whenever
+poses + geometry are optimised over a fixed surfel set): every iteration is queued at once, the last solve launch of each pose
+phase evaluates the stopping rule of B/direct_ba_alternating.cc:693-701 on the device, and the host waits once.  Against the loop
+driven through the stage functions (one host wait per Gauss-Newton round, bahip_debug_set_device_loop(0)): the same iteration
+counts, convergence flags, statistics, poses, activations and surfels, bit for bit -- with a fixed number of iterations, with a
+loop that ends by convergence, and when a pose phase needs more rounds than were queued for it (the host finishes that phase)."""
+import numpy as np
+import pytest
+
+from badslam_amd import capi, synthetic
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(scene, perturbed, surfels, device_loop, rounds_ahead, **ba_args):
+    from badslam_amd.directba import DirectBA
+    lib = capi.load()
+    capi.check(lib.bahip_debug_set_device_loop(int(device_loop)))
+    capi.check(lib.bahip_debug_set_pose_rounds_ahead(rounds_ahead))
+    try:
+        ba = DirectBA(600000, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, scene.width, scene.height, scene.camera, scene.camera)
+        for k in range(len(scene.depth)):
+            ba.AddKeyframe(scene.depth[k], scene.rgb[k], scene.poses_gt[k])
+        if surfels is None:
+            for k in range(len(scene.depth)):
+                ba.CreateSurfelsForKeyframe(k, filter_new_surfels=False)
+            surfels = ba.download_surfels(8)
+            rng = np.random.Generator(np.random.PCG64(5))
+            surfels[2] += rng.uniform(0, 0.004, surfels.shape[1]).astype(np.float32)
+        ba.upload_surfels(surfels)
+        for k, T in enumerate(perturbed):
+            ba.set_keyframe_pose(k, T)
+        ba.set_ba_iteration_counts(1, 1)      # no end tasks: the surfel set and its order stay
+        done, conv = ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True,
+                                         increase_ba_iteration_count=False, **ba_args)
+        K = len(perturbed)
+        return dict(done=done, conv=conv, stats=ba.last_stats(), poses=np.asarray([ba.keyframe_pose(k) for k in range(K)], np.float32),
+                    activation=[ba.keyframe_activation(k) for k in range(K)], surfels=ba.download_surfels(8)), surfels
+    finally:
+        capi.check(lib.bahip_debug_set_device_loop(1))
+        capi.check(lib.bahip_debug_set_pose_rounds_ahead(0))
+
+
+@pytest.mark.parametrize("case", ["fixed iterations", "until converged", "phase outruns the queue", "single keyframe"])
+def test_device_driven_loop_is_the_host_driven_loop(case):
+    scene = common.small_scene(num_keyframes=1 if case == "single keyframe" else 6, seed=33)
+    rng = np.random.Generator(np.random.PCG64(4))
+    perturbed = [synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    args = dict(min_iterations=4, max_iterations=4) if case in ("fixed iterations", "phase outruns the queue") else dict(min_iterations=1, max_iterations=40)
+    ahead = 1 if case == "phase outruns the queue" else 0
+    ref, surfels = _run(scene, perturbed, None, device_loop=False, rounds_ahead=1, **args)
+    got, _ = _run(scene, perturbed, surfels, device_loop=True, rounds_ahead=ahead, **args)
+    assert got["done"] == ref["done"] and got["conv"] == ref["conv"], (got["done"], ref["done"], got["conv"], ref["conv"])
+    if case in ("until converged", "single keyframe"):
+        assert ref["conv"] and 1 <= ref["done"] < 40
+    if case == "phase outruns the queue":
+        assert ref["stats"]["pose_rounds"] > ref["done"]                     # phases of more than one round: the hand-over was exercised
+    assert got["stats"]["pose_rounds"] == ref["stats"]["pose_rounds"] and got["stats"]["pose_steps"] == ref["stats"]["pose_steps"], (got["stats"], ref["stats"])
+    assert got["activation"] == ref["activation"]
+    assert np.array_equal(got["poses"], ref["poses"])
+    assert np.array_equal(got["surfels"].view(np.uint32), ref["surfels"].view(np.uint32))
+    assert np.abs(got["poses"] - np.asarray(perturbed, np.float32)).max() > 1e-4     # the loop did move the poses

@@ -85,10 +85,22 @@ def test_bundle_adjustment_without_surfels_and_with_one_keyframe():
     n = ba.surfel_count()
     assert n > 1000
     before = ba.download_surfels(3)
+    assert ba.unsorted_surfels() == n
     ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=2, max_iterations=2)
     after = ba.download_surfels(3)
     assert after.shape == before.shape and np.isfinite(after).all()
-    assert np.abs(after - before).max() < 1e-4          # consistent input: nothing to correct
+    # the end tasks of that call put the buffer into Morton order (the surfels were appended since the last reorder): the same
+    # surfels, permuted -- and, the input being consistent, nothing was there to correct
+    assert ba.unsorted_surfels() == 0
+    order_before, order_after = np.lexsort(before), np.lexsort(after)
+    assert np.abs(after[:, order_after] - before[:, order_before]).max() < 1e-4
+    assert not np.array_equal(order_before, order_after)
+    # ... and with the reorder switched off the reference's surfel order stays observable
+    ba.SetSpatialSortCellSize(0)
+    ba.CreateSurfelsForKeyframe(0, filter_new_surfels=False)       # (nothing new: every cell is supported)
+    again = ba.download_surfels(3)
+    ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=1, max_iterations=1)
+    assert np.abs(ba.download_surfels(3) - again).max() < 1e-4
 
 
 def test_all_invalid_depth_creates_no_surfels():
