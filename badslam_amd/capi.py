@@ -86,6 +86,7 @@ SIGNATURES = {
     "bahip_context_is_sharded": (C.c_int, [C.c_void_p]),
     "bahip_context_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "bahip_context_set_keyframe_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "bahip_context_set_sum_classes": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_debug_set_tile_order": (C.c_int, [C.c_int]),
     "bahip_debug_read_tile_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     "bahip_rccl_get_unique_id": (C.c_int, [C.c_char_p]),
@@ -175,6 +176,7 @@ SIGNATURES = {
     "bahip_debug_set_pose_lds_shape": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_pose_rounds_ahead": (C.c_int, [C.c_int]),
     "bahip_debug_set_device_loop": (C.c_int, [C.c_int]),
+    "bahip_debug_set_pcg_lds_form": (C.c_int, [C.c_int]),
     "bahip_debug_pose_form_launches": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "bahip_debug_pose_limbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_longlong)]),
     "bahip_debug_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),

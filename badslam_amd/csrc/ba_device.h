@@ -280,6 +280,9 @@ struct Intrinsics {
   const float* cfactor;
   uint32_t cfactor_pitch;
   int cf_width, cf_height;
+  // Interleaved partial sums per surfel in the normals / geometry passes (kernels_surfel.hip: tile_sums) -- part of the NUMERICAL
+  // DEFINITION of those sums: 4 (default) or 8 (bahip_context_set_sum_classes; what keyframe sharding over 8 ranks needs)
+  int sum_classes;
 };
 
 struct SurfelsView {
@@ -290,7 +293,7 @@ struct SurfelsView {
   __device__ __forceinline__ float* row(int r) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(data) + (size_t)r * pitch); }
 };
 
-// Keyframe sharding: the partial sums of the four keyframe classes of the normals / geometry passes (kernels_surfel.hip), the
+// Keyframe sharding: the partial sums of the keyframe classes (4 or 8) of the normals / geometry passes (kernels_surfel.hip), the
 // unit the ranks exchange.  data[(class * sums + q) * stride + surfel]; `owned` has bit c set when this rank visits class c.
 struct ClassPartials {
   float* data;

@@ -90,6 +90,10 @@ void launch_window_activation(hipStream_t stream, KfEntry* frames, int num_kfs, 
                               const int* indices, const int* stop = nullptr);   // window activation + co-visible propagation
 void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs, const int* offsets, const int* indices,
                                 const int* stop = nullptr);
+// window (mode 1) / propagation (mode 2) / nothing (mode 0), then the work items of the pose phase, in one launch; false (and
+// nothing launched) beyond 1024 keyframes
+bool launch_iteration_begin(hipStream_t stream, KfEntry* frames, int num_kfs, int mode, const uint8_t* in_window, const int* offsets, const int* indices,
+                            void* work, HbFixed* Hb, void* host_out, const int* stop);
 
 void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
 void set_pose_lds_waves(int waves);        // test hook: wavefronts per workgroup of the LDS form (0: 16)
@@ -152,7 +156,10 @@ void launch_pcg_init2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, fl
                       float* p);
 void launch_pcg_control_init(hipStream_t st, const PcgExact& ex, void* ctl, float* alpha_n);
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                      const SurfelsView& s, const float* p, float* g, const void* ctl, const uint32_t* sched = nullptr);
+                      const SurfelsView& s, const float* p, float* g, const void* ctl, const uint32_t* sched = nullptr,
+                      uint32_t* tile_counters = nullptr /* the context's two sets of eight tile counters: allows the persistent LDS form */,
+                      int* parity_inout = nullptr);
+void set_pcg_lds_form(int mode);   // test hook: 0 = always the one-tile-per-wavefront form of the step-1 sweep, 1 = automatic, 2 = the LDS form whenever the table fits
 void launch_pcg_eps_terms(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* p);
 void launch_pcg_resolve_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* g, float* alpha_d, double eps_repeat, const void* ctl);
 void launch_pcg_step2(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, const float* M, float* delta, float* g, const float* p,

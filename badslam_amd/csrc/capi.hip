@@ -146,7 +146,8 @@ struct bahip_context {
   uint32_t pcg_stage_head = 0;     // accumulators were set up for, and the bahip_pcg_step1 calls since the last step 2
   int pcg_stage_step1_calls = 0;
   int world = 0;                   // ranks of the RCCL communicator (0 = none)
-  int kf_rank = 0, kf_world = 1;   // keyframe sharding (bahip_context_set_keyframe_sharding): keyframe k lives on rank (k % 4) % kf_world
+  int kf_rank = 0, kf_world = 1;   // keyframe sharding (bahip_context_set_keyframe_sharding): keyframe k lives on rank k % kf_world (1, 2, 4 or 8)
+  int sum_classes = 4;             // interleaved partial sums per surfel of the normals / geometry passes: 4 or 8 (bahip_context_set_sum_classes)
   float* kf_partials = nullptr;    // class partials of the geometry step (normals, then position) / hit words of the activation
   size_t kf_partials_capacity = 0; // floats
   long long exchange_calls = 0;    // sums over the ranks requested since the last reset (bahip_exchange_stats), and their bytes
@@ -191,6 +192,7 @@ Intrinsics make_intrinsics(const bahip_camera& cc, const bahip_camera& dc, const
   in.cf_width = dp.cfactor_width; in.cf_height = dp.cfactor_height;
   in.geom_tpr = plane_tiles_x(dc.width);
   in.fp_tpr = plane_tiles_x(cc.width + 2);
+  in.sum_classes = 4;   // (the context's choice is written over this: bahip_set_intrinsics, bahip_context_set_sum_classes)
   return in;
 }
 
@@ -571,7 +573,7 @@ int reduce_over_ranks(bahip_context* ctx, void* buffer, size_t count, int dtype)
   return 0;
 }
 inline bool is_sharded(const bahip_context* ctx) { return ctx->allreduce != nullptr || ctx->rccl_comm != nullptr; }
-inline bool kf_owned(const bahip_context* ctx, int k) { return ((k & 3) & (ctx->kf_world - 1)) == ctx->kf_rank; }
+inline bool kf_owned(const bahip_context* ctx, int k) { return (k & (ctx->kf_world - 1)) == ctx->kf_rank; }
 #define REQUIRE_NO_KF_SHARDING(what) \
   REQUIRE(!kf_sharded(ctx), what " is not available under keyframe sharding (its per-surfel sums run over all keyframes in order): use surfel sharding")
 
@@ -582,9 +584,12 @@ int geometry_keyframe_sharded(bahip_context* ctx, bool use_depth, bool use_desc,
   if (v.size == 0) return 0;
   const int nn = geometry_normals_sums(activate_count >= 0), np = geometry_position_sums(use_desc);
   const size_t stride = ((size_t)v.size + 63) & ~(size_t)63;
-  const size_t normals_floats = 4 * (size_t)nn * stride, position_floats = 4 * (size_t)np * stride;
+  // class c (the keyframes k with k % classes == c) lives on rank c % world: world divides classes, both powers of two
+  const int classes = ctx->sum_classes;
+  const size_t normals_floats = (size_t)classes * nn * stride, position_floats = (size_t)classes * np * stride;
   if (grow_device(&ctx->kf_partials, &ctx->kf_partials_capacity, normals_floats + position_floats, 0, "the class partials of the geometry step")) return 1;
-  const uint32_t owned = ctx->kf_world == 2 ? (ctx->kf_rank == 0 ? 0x5u : 0xau) : (1u << ctx->kf_rank);
+  uint32_t owned = 0;
+  for (int c = 0; c < classes; ++c) if ((c & (ctx->kf_world - 1)) == ctx->kf_rank) owned |= 1u << c;
   const ClassPartials cpn{ctx->kf_partials, (uint32_t)stride, owned}, cpp{ctx->kf_partials + normals_floats, (uint32_t)stride, owned};
   HIP_TRY(hipMemsetAsync(ctx->kf_partials, 0, sizeof(float) * (normals_floats + position_floats), ctx->stream));
   launch_geometry_phase(ctx->stream, 1, use_depth, use_desc, ctx->in, ctx->dev_kfs, ctx->num_kfs, v, activate_count, cpn, cpp);
@@ -685,8 +690,18 @@ int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void*
   return 0;
 }
 
+int bahip_context_set_sum_classes(bahip_context* ctx, int classes) {
+  REQUIRE(classes == 4 || classes == 8, "the per-surfel sums of the normals / geometry passes are defined over 4 or 8 keyframe classes");
+  REQUIRE(ctx->kf_world <= classes, "keyframe sharding over more ranks than classes");
+  ctx->sum_classes = classes;
+  ctx->in.sum_classes = classes;
+  return 0;
+}
+
 int bahip_context_set_keyframe_sharding(bahip_context* ctx, int rank, int world) {
-  REQUIRE(world == 1 || world == 2 || world == 4, "keyframe sharding: the per-surfel sums have four keyframe classes, so world must be 1, 2 or 4");
+  REQUIRE(world == 1 || world == 2 || world == 4 || world == 8, "keyframe sharding: world must be 1, 2, 4 or 8 (a rank holds whole keyframe classes)");
+  REQUIRE(world <= ctx->sum_classes, "keyframe sharding over 8 ranks needs the 8-class definition of the per-surfel sums: bahip_context_set_sum_classes(ctx, 8) "
+                                     "first (on the single-GPU run it is compared with as well: the class count is part of the sums' definition)");
   REQUIRE(rank >= 0 && rank < world, "keyframe sharding: rank out of range");
   ctx->kf_rank = rank; ctx->kf_world = world;
   return 0;
@@ -861,6 +876,7 @@ int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, c
   REQUIRE(dp->sparse_surfel_cell_size >= 1, "sparse_surfel_cell_size must be >= 1");
   ctx->color_cam = *color_camera; ctx->depth_cam = *depth_camera; ctx->dp = *dp;
   ctx->in = make_intrinsics(*color_camera, *depth_camera, *dp);
+  ctx->in.sum_classes = ctx->sum_classes;
   ctx->have_intrinsics = true;
   return 0;
 }
@@ -1103,6 +1119,7 @@ constexpr int kLoopLogSlots = 4096;
 int g_device_loop_enabled = [] { const char* e = getenv("BAHIP_DEVICE_LOOP"); return (e && atoi(e) == 0) ? 0 : 1; }();
 }
 int bahip_debug_set_device_loop(int enabled) { g_device_loop_enabled = enabled ? 1 : 0; return 0; }
+int bahip_debug_set_pcg_lds_form(int mode) { set_pcg_lds_form(mode); return 0; }
 int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_options* opt, const bahip_surfels* surfels,
                                  float* global_T_frame_out, int* activation_out, int* handled_out, int* iterations_done_out,
                                  int* converged_out, int* pose_rounds_out, int* pose_steps_out, int* not_converged_out) {
@@ -1152,13 +1169,18 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
     const int acc_mark = acc_timer.used;
     int log_slot = 0, sequence = 0;
     for (int i = it; i < opt->max_iterations; ++i) {
-      if (opt->fixed_window) launch_window_activation(st, ctx->dev_kfs, K, ctx->dev_window, csr, csr + K + 1, stop);
-      else if (i > 0) launch_propagate_covisible(st, ctx->dev_kfs, K, csr, csr + K + 1, stop);   // closes iteration i - 1 (B/direct_ba_alternating.cc:703-709)
+      // window / propagation (which closes iteration i - 1, B/direct_ba_alternating.cc:703-709) and the pose phase's work items
+      const int begin_mode = opt->fixed_window ? 1 : (i > 0 ? 2 : 0);
+      const bool begun = launch_iteration_begin(st, ctx->dev_kfs, K, begin_mode, ctx->dev_window, csr, csr + K + 1, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, stop);
+      if (!begun) {
+        if (begin_mode == 1) launch_window_activation(st, ctx->dev_kfs, K, ctx->dev_window, csr, csr + K + 1, stop);
+        else if (begin_mode == 2) launch_propagate_covisible(st, ctx->dev_kfs, K, csr, csr + K + 1, stop);
+      }
       timer_begin(ctx, 1, true);
       launch_geometry(st, use_depth, use_desc, ctx->in, ctx->dev_kfs, K, sv, opt->activate_in_geometry ? (long long)opt->activation_surfels_size : -1,
                       tile_order_for(ctx, sv.size), stop);
       timer_end(ctx, 1);
-      launch_pose_init_from_keyframes(st, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, 0, 1, stop);
+      if (!begun) launch_pose_init_from_keyframes(st, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, 0, 1, stop);
       CHECK_LAUNCH();
       for (int r = 0; r < rounds_ahead; ++r) {
         timer_begin(ctx, 2, false, 0);
@@ -1685,7 +1707,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   int steps = 0;
   for (int step = 0; step < opt->max_inner_iterations; ++step) {
     if (step > 0) { const int t = i_an; i_an = i_bn; i_bn = t; }
-    launch_pcg_step1(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, p_, g_, ctl, sched);
+    launch_pcg_step1(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, p_, g_, ctl, sched, ctx->dev_tile_counters, &ctx->pose_parity);
     CHECK_LAUNCH();
     if (sharded && reduce_over_ranks(ctx, ex.hot, x1_step, BAHIP_SUM_I64)) return 1;   // g head, intrinsics entries, alpha_d terms
     launch_pcg_resolve_step1(st, L, ex, g_, sc + 1, eps_repeat, ctl);

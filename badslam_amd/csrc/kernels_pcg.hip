@@ -464,14 +464,39 @@ pcg_init2_kernel(PcgLayout L, PcgExact ex, float a, const float* __restrict__ r_
 }
 
 // ---- PCGStep1: g += J^T W J p, alpha_d += p^T J^T W J p  (B/kernel_pcg.cu:646-1026) -------------------
-template <bool kDepthIntr, bool kColorIntr>
-__global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
-pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
-                 const float* __restrict__ p_, float* __restrict__ g_, const PcgControl* ctl, const uint32_t* __restrict__ sched) {
-  if (ctl->stop) return;
-  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile)
-  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
-  const uint32_t i = tile * kPcgSweepBlock + threadIdx.x;
+// Where the (tile, keyframe) totals of the dense head go: straight to the exact accumulators in global memory (two 64-bit integer
+// atomics per total, issued one candidate late), or into a copy of the pose block of the head that a persistent workgroup keeps
+// in LDS and flushes once (pcg_step1_lds_kernel).  The cfactor-cell entries (one per pair) go to global memory either way.
+constexpr int kPcgLdsHotCells = 16;   // of the LDS form's table: [0] alpha_d, [1 .. 9] the nine global intrinsics entries of g; padded
+__device__ __forceinline__ uint32_t pcg_lds_hot_index(int slot) { return slot == kHotAlphaD ? 0u : 1u + (uint32_t)(slot - kHotA); }
+__device__ __forceinline__ int pcg_lds_hot_slot(uint32_t index) { return index == 0u ? (int)kHotAlphaD : (int)kHotA + (int)index - 1; }
+struct PcgGlobalSink {
+  PcgExact ex;
+  int replica;
+  __device__ __forceinline__ void add_pose(uint32_t head_index, float v, int part) const { exact_atomic_add_part_untracked(&ex.head_a[head_index], v, part, ex.invalid); }
+  __device__ __forceinline__ void add_hot(int slot, float v, int part) const { exact_atomic_add_part_untracked(hot_cell(ex, slot, replica), v, part, ex.invalid); }
+};
+struct PcgLdsSink {
+  PcgExact ex;
+  uint32_t table;        // LDS byte address of the table: ExactCell[pose_cells + kPcgLdsHotCells]
+  uint32_t pose_cells;   // 6 per pose unknown: head indices [0, pose_cells)
+  __device__ __forceinline__ void add_cell(uint32_t cell, float v, int part) const {
+    const ExactSplit sp = exact_split(v);
+    if (sp.limb >= 0) {
+      const long long addend = part ? sp.hi : sp.lo;
+      auto* limb = reinterpret_cast<__attribute__((address_space(3))) long long*>(table + cell * (uint32_t)sizeof(ExactCell) + (uint32_t)(sp.limb + part) * 8u);
+      if (addend != 0) __hip_atomic_fetch_add(limb, addend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (sp.limb == -2 && part == 0) {
+      atomicOr(ex.invalid, 1u);
+    }
+  }
+  __device__ __forceinline__ void add_pose(uint32_t head_index, float v, int part) const { add_cell(head_index, v, part); }
+  __device__ __forceinline__ void add_hot(int slot, float v, int part) const { add_cell(pose_cells + pcg_lds_hot_index(slot), v, part); }
+};
+template <bool kDepthIntr, bool kColorIntr, typename Sink>
+__device__ __forceinline__ void pcg_step1_tile(const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs,
+                                               const SurfelsView& s, const float* __restrict__ p_, float* __restrict__ g_, uint32_t tile, const Sink& sink) {
+  const uint32_t i = tile * kPcgSweepBlock + (threadIdx.x & 63);
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
   const Vec3 gp = surfel_position(s, ii);
@@ -481,7 +506,6 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);   // per surfel, not per pair
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
   const int lane = threadIdx.x & 63;
-  const int replica = (int)(tile & (kHotReplicas - 1));
   const uint32_t gi = L.optimize_geometry ? (L.surfel_start + (uint32_t)L.geom_stride * ii) : 0u;
   float ps[3] = {0, 0, 0};
   if (L.optimize_geometry) {
@@ -508,9 +532,9 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
     if (pending_any) {
       const int j = kIntr ? (lane >> 2) : (lane >> 3), part = kIntr ? (lane & 3) : (lane & 7);   // the lanes that hold total j
       if (part < 2) {
-        if (j < 6) { if (pending_pose) exact_atomic_add_part_untracked(&ex.head_a[pending_base + j], pending, part, ex.invalid); }
-        else if (j == 6) exact_atomic_add_part_untracked(hot_cell(ex, kHotAlphaD, replica), pending, part, ex.invalid);
-        else if (kIntr && j < 16 && ((j - 7) < 5 ? kDepthIntr : kColorIntr)) exact_atomic_add_part_untracked(hot_cell(ex, kHotA + (j - 7), replica), pending, part, ex.invalid);
+        if (j < 6) { if (pending_pose) sink.add_pose(pending_base + j, pending, part); }
+        else if (j == 6) sink.add_hot(kHotAlphaD, pending, part);
+        else if (kIntr && j < 16 && ((j - 7) < 5 ? kDepthIntr : kColorIntr)) sink.add_hot(kHotA + (j - 7), pending, part);
       }
       pending_any = false;
     }
@@ -621,6 +645,78 @@ pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restr
   if (in_range && L.optimize_geometry) {
     g_[gi] = gs[0];
     if (L.geom_stride == 3) { g_[gi + 1] = gs[1]; g_[gi + 2] = gs[2]; }
+  }
+}
+
+template <bool kDepthIntr, bool kColorIntr>
+__global__ void __launch_bounds__(kPcgSweepBlock) BAHIP_PCG_SWEEP_ATTR
+pcg_step1_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
+                 const float* __restrict__ p_, float* __restrict__ g_, const PcgControl* ctl, const uint32_t* __restrict__ sched) {
+  if (ctl->stop) return;
+  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile)
+  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
+  const PcgGlobalSink sink{ex, (int)(tile & (kHotReplicas - 1))};
+  pcg_step1_tile<kDepthIntr, kColorIntr>(L, ex, in, kfs, num_kfs, s, p_, g_, tile, sink);
+}
+
+// Persistent form (round 4), like pose_accumulate_lds_kernel: one workgroup of 16 wavefronts per compute unit keeps the pose
+// block of g's dense head -- 6 exact cells per pose unknown, 72 bytes each: 86 KB at 200 keyframes -- and the hot scalars in
+// LDS; its wavefronts draw tiles (batches from a counter per XCD, single tiles from a word in LDS) and add their (tile,
+// keyframe) totals there; the workgroup adds its non-zero limbs to the global accumulators once.  The one-tile-per-wavefront
+// form issued 14 global 64-bit atomics per (tile, keyframe) with an association -- 12 M per inner step at the bench size, half a
+// millisecond of the memory side's 23.6 G atomic requests per second behind a 0.8 ms sweep.  Integer sums: the same bits.
+constexpr int kPcgLdsWaves = 16;
+constexpr uint32_t kPcgLdsBatch = 32;
+template <bool kDepthIntr, bool kColorIntr>
+__global__ void __launch_bounds__(64 * kPcgLdsWaves) BAHIP_PCG_SWEEP_ATTR
+pcg_step1_lds_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
+                     const float* __restrict__ p_, float* __restrict__ g_, const PcgControl* ctl, const uint32_t* __restrict__ sched,
+                     uint32_t padded_tiles, uint32_t* __restrict__ tile_counters, int parity, uint32_t pose_cells) {
+  extern __shared__ long long pcg_table[];   // ExactCell[pose_cells + kPcgLdsHotCells], then the batch word
+  if (blockIdx.x == 0 && threadIdx.x < 8) tile_counters[(parity ^ 1) * 8 + threadIdx.x] = 0;
+  if (ctl->stop) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t cells = pose_cells + kPcgLdsHotCells, words = cells * kExactLimbs;
+  unsigned long long& batch_state = *reinterpret_cast<unsigned long long*>(pcg_table + words);
+  const uint32_t xcd = blockIdx.x & 7u, per_xcd = sched_positions(padded_tiles, sched) >> 3;
+  uint32_t* counter = tile_counters + parity * 8 + xcd;
+  for (uint32_t e = threadIdx.x; e < words; e += blockDim.x) pcg_table[e] = 0;
+  if (threadIdx.x == 0) batch_state = ((unsigned long long)atomicAdd(counter, kPcgLdsBatch) << 32) | ((unsigned long long)kPcgLdsBatch << 24);
+  __syncthreads();
+  const PcgLdsSink sink{ex, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) long long*)pcg_table, pose_cells};
+  for (;;) {
+    unsigned long long taken = 0;
+    if (lane == 0) taken = atomicAdd(&batch_state, 1ull);
+    const uint32_t first = __builtin_amdgcn_readfirstlane((uint32_t)(taken >> 32));
+    const uint32_t size = __builtin_amdgcn_readfirstlane((uint32_t)taken >> 24);
+    const uint32_t index = __builtin_amdgcn_readfirstlane((uint32_t)taken & 0xffffffu);
+    if (first >= per_xcd) break;
+    if (index < size) {
+      uint32_t tile;
+      if (first + index < per_xcd && scheduled_tile((first + index) * 8u + xcd, padded_tiles, sched, &tile))
+        pcg_step1_tile<kDepthIntr, kColorIntr>(L, ex, in, kfs, num_kfs, s, p_, g_, tile, sink);
+    } else if (index == size) {
+      if (lane == 0) {
+        const uint32_t left = per_xcd > first + size ? per_xcd - (first + size) : 0u;
+        const uint32_t want = min(kPcgLdsBatch, max(2u, left / (4u * (gridDim.x >> 3))));
+        const uint32_t next = atomicAdd(counter, want);
+        __hip_atomic_store(&batch_state, ((unsigned long long)next << 32) | ((unsigned long long)want << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {
+      while ((uint32_t)(__hip_atomic_load(&batch_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == first)
+        __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  const int replica = (int)(blockIdx.x & (kHotReplicas - 1));
+  for (uint32_t e = threadIdx.x; e < words; e += blockDim.x) {
+    const long long v = pcg_table[e];
+    if (v != 0) {
+      const uint32_t cell = e / kExactLimbs, limb = e - cell * kExactLimbs;
+      if (cell >= pose_cells + 10u) continue;   // (padding)
+      ExactCell* target = cell < pose_cells ? &ex.head_a[cell] : hot_cell(ex, pcg_lds_hot_slot(cell - pose_cells), replica);
+      limb_atomic_add(&target->limb[limb], v);
+    }
   }
 }
 
@@ -790,12 +886,58 @@ void launch_pcg_control(hipStream_t st, const PcgExact& ex, void* ctl, float* be
 }
 size_t pcg_control_bytes() { return sizeof(PcgControl); }
 
+static int g_pcg_lds_form = [] { const char* e = getenv("BAHIP_PCG_LDS"); return e ? atoi(e) : 1; }();   // 0: always the one-tile-per-wavefront form
+void set_pcg_lds_form(int mode) { g_pcg_lds_form = (mode >= 0 && mode <= 2) ? mode : 1; }   // 2: also on grids that do not fill the chip (tests)
+constexpr size_t kPcgLdsTableLimit = 128 * 1024;
+template <bool kDepthIntr, bool kColorIntr>
+static bool launch_pcg_step1_lds(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                                 const SurfelsView& s, const float* p, float* g, const PcgControl* ctl, const uint32_t* sched,
+                                 uint32_t* tile_counters, int* parity_inout) {
+  // the pose block of the unknown vector (and of the dense head: head index = unknown index there) ends where the next block begins
+  uint32_t pose_end = L.unknown_count;
+  if (L.optimize_geometry) pose_end = std::min(pose_end, L.surfel_start);
+  if (L.optimize_depth_intrinsics) pose_end = std::min(pose_end, L.depth_intr_start);
+  if (L.optimize_color_intrinsics) pose_end = std::min(pose_end, L.color_intr_start);
+  const uint32_t pose_cells = L.optimize_poses ? pose_end : 0u;
+  const size_t bytes = ((size_t)pose_cells + kPcgLdsHotCells) * sizeof(ExactCell) + sizeof(long long);
+  if (bytes > kPcgLdsTableLimit) return false;
+  static bool raised[64] = {}, failed[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!raised[dev] && !failed[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_step1_lds_kernel<kDepthIntr, kColorIntr>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kPcgLdsTableLimit) == hipSuccess) raised[dev] = true;
+    else { failed[dev] = true; (void)hipGetLastError(); }
+  }
+  if (failed[dev] && bytes > 64 * 1024) return false;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const unsigned tiles = gS(s.size);
+  const unsigned grid = std::max(8u, std::min((unsigned)cus, ((sched_positions(tiles, sched) + kPcgLdsWaves - 1) / kPcgLdsWaves + 7u) & ~7u));
+  const int parity = *parity_inout;
+  *parity_inout = parity ^ 1;
+  hipLaunchKernelGGL((pcg_step1_lds_kernel<kDepthIntr, kColorIntr>), dim3(grid), dim3(64 * kPcgLdsWaves), bytes, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched,
+                     tiles, tile_counters, parity, pose_cells);
+  return true;
+}
+
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                      const SurfelsView& s, const float* p, float* g, const void* ctl_, const uint32_t* sched) {
+                      const SurfelsView& s, const float* p, float* g, const void* ctl_, const uint32_t* sched, uint32_t* tile_counters,
+                      int* parity_inout) {
   const PcgControl* ctl = static_cast<const PcgControl*>(ctl_);
   if (!s.size) return;
-  const dim3 grid(sched_positions(gS(s.size), sched)), block(kPcgSweepBlock);
   const bool di = L.optimize_depth_intrinsics, ci = L.optimize_color_intrinsics;
+  // the persistent LDS form when the grid fills the chip, the per-keyframe entry points (Route B) are not in play and the pose
+  // block of the head fits the table
+  if (tile_counters && parity_inout && L.single_keyframe < 0 && (g_pcg_lds_form == 2 || (g_pcg_lds_form == 1 && gS(s.size) >= 8192))) {
+    bool launched;
+    if (di && ci) launched = launch_pcg_step1_lds<true, true>(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout);
+    else if (di) launched = launch_pcg_step1_lds<true, false>(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout);
+    else if (ci) launched = launch_pcg_step1_lds<false, true>(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout);
+    else launched = launch_pcg_step1_lds<false, false>(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout);
+    if (launched) return;
+  }
+  const dim3 grid(sched_positions(gS(s.size), sched)), block(kPcgSweepBlock);
   if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
   else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
   else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);

@@ -642,8 +642,8 @@ pose_init_from_keyframes_kernel(const KfEntry* __restrict__ frames, int num_kfs,
     pw.converged = 0;
     pw.done = inactive ? 1 : 0;
     // keyframe sharding: every rank solves every work item from the summed normal equations, but sweeps only the keyframes it
-    // holds (keyframe k lives on rank (k % 4) % world; owner_mask = world - 1, 0 without sharding)
-    pw.skip = (inactive || ((uint32_t)k & 3u & owner_mask) != owner_rank) ? 1 : 0;
+    // holds (keyframe k lives on rank k % world, world a power of two; owner_mask = world - 1, 0 without sharding)
+    pw.skip = (inactive || ((uint32_t)k & owner_mask) != owner_rank) ? 1 : 0;
     pw.moved = 0;
     for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
     for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
@@ -706,6 +706,73 @@ __global__ void __launch_bounds__(1024) window_and_propagate_kernel(KfEntry* __r
       if (!in_window[other]) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
     }
   }
+}
+
+// The top of an iteration of the device-driven loop in ONE launch (num_kfs <= 1024): the activation window with its co-visible
+// propagation (mode 1), or the propagation that closes the previous iteration (mode 2), or neither (mode 0) -- then the work
+// items of the pose phase (pose_init_from_keyframes_kernel).  Geometry, which runs between this and the pose rounds, touches
+// neither the work items nor the activations, so the phase's items can be set up before it: one launch and one launch gap less
+// per iteration than window kernel + init kernel.
+__global__ void __launch_bounds__(1024)
+iteration_begin_kernel(KfEntry* __restrict__ frames, int num_kfs, int mode, const uint8_t* __restrict__ in_window, const int* __restrict__ offsets,
+                       const int* __restrict__ indices, PoseWork* __restrict__ work, HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out,
+                       const int* __restrict__ stop) {
+  if (stop && load_global(stop) != 0) return;
+  const int k = threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (mode == 1) {
+    const bool inside = k < num_kfs && in_window[k];
+    if (k < num_kfs) frames[k].activation = inside ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+    if (__syncthreads_count(inside ? 1 : 0) != num_kfs) {        // (workgroup-uniform) a window that holds every keyframe leaves nothing to wake up
+      for (int row = wave; row < num_kfs; row += 16) {
+        if (!in_window[row]) continue;
+        for (int j = offsets[row] + lane; j < offsets[row + 1]; j += 64) {
+          const int other = indices[j];
+          if (!in_window[other]) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
+        }
+      }
+    }
+  } else if (mode == 2) {
+    // sources are the keyframes that are kActive NOW; a write only turns kInactive into kCovisibleActive (never a source)
+    const bool source = k < num_kfs && frames[k].activation == BAHIP_KF_ACTIVE;
+    __shared__ uint8_t is_source[1024];
+    is_source[k] = source ? 1 : 0;
+    __syncthreads();
+    for (int row = wave; row < num_kfs; row += 16) {
+      if (!is_source[row]) continue;
+      for (int j = offsets[row] + lane; j < offsets[row + 1]; j += 64) {
+        const int other = indices[j];
+        if (!is_source[other] && frames[other].activation == BAHIP_KF_INACTIVE) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
+      }
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  const bool in_range = k < num_kfs;
+  const bool inactive = in_range && __hip_atomic_load(&frames[k].activation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == BAHIP_KF_INACTIVE;
+  if (in_range) {
+    PoseWork& pw = work[k];
+    pw.kf_index = k;
+    pw.iterations = 0;
+    pw.converged = 0;
+    pw.done = inactive ? 1 : 0;
+    pw.skip = inactive ? 1 : 0;
+    pw.moved = 0;
+    for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
+    for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
+    for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
+    if (pw.done) host_out[k] = pw;
+  }
+  int* counters = reinterpret_cast<int*>(work + num_kfs);
+  const int num_inactive = __syncthreads_count(inactive ? 1 : 0);
+  if (threadIdx.x < kPoseTailRecords * 32) counters[threadIdx.x] = (threadIdx.x == kPoseCounterConverged) ? num_inactive : 0;
+}
+bool launch_iteration_begin(hipStream_t stream, KfEntry* frames, int num_kfs, int mode, const uint8_t* in_window, const int* offsets, const int* indices,
+                            void* work, HbFixed* Hb, void* host_out, const int* stop) {
+  if (num_kfs == 0 || num_kfs > 1024) return false;
+  hipLaunchKernelGGL(iteration_begin_kernel, dim3(1), dim3(1024), 0, stream, frames, num_kfs, mode, in_window, offsets, indices,
+                     static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), stop);
+  return true;
 }
 
 // ---- launchers -----------------------------------------------------------------------------------

@@ -36,20 +36,22 @@ namespace bahip {
 #define BAHIP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))   // cap the allocation at 128 VGPRs: 4 waves per SIMD (5 spills: measured slower)
 #endif
 constexpr int kSurfelBlock = 64;   // one wavefront per workgroup (per-wave work varies with the keyframe candidates)
-constexpr int kSumClasses = 4;     // interleaved partial sums per surfel (part of the numerical definition, not a tuning knob)
+constexpr int kMaxSumClasses = 8;  // interleaved partial sums per surfel: Intrinsics::sum_classes = 4 or 8 (part of the numerical
+                                   // definition, not a tuning knob; 8 exists for keyframe sharding over 8 ranks)
 
-// tot[q] = ((p0[q] + p1[q]) + p2[q]) + p3[q], p_c = what visit(acc, c) accumulates over the keyframes of class c.
+// tot[q] = ((p0[q] + p1[q]) + p2[q]) + p3[q] (... + p7[q]), p_c = what visit(acc, c) accumulates over the keyframes of class c
+// (the keyframes whose index in the bound table is congruent to c modulo `classes`), c ascending.
 // kWaves > 1: the calling workgroup has kWaves wavefronts holding the same 64 surfels (wavefront w takes the classes
 // w, w + kWaves, ...); every thread must call.
 enum SumsMode { kSumsFused = 0, kSumsProduce = 1, kSumsConsume = 2 };
 template <int kWaves, int kCount, int kMode = kSumsFused, typename Visit>
-__device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visit visit, const ClassPartials& cp = ClassPartials{},
+__device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visit visit, int classes, const ClassPartials& cp = ClassPartials{},
                                           uint32_t i = 0, bool in_range = false) {
-  static_assert(kWaves == 1 || kWaves == 2 || kWaves == kSumClasses, "1, 2 or 4 wavefronts per tile");
+  static_assert(kWaves == 1 || kWaves == 2 || kWaves == 4, "1, 2 or 4 wavefronts per tile");
   static_assert(kMode == kSumsFused || kWaves == 1, "the class partials are exchanged by the one-wavefront shape only");
   if (kMode == kSumsProduce) {
 #pragma nounroll
-    for (int c = 0; c < kSumClasses; ++c) {
+    for (int c = 0; c < classes; ++c) {
       if (!((cp.owned >> c) & 1u)) continue;   // another rank holds this class's images
       float acc[kCount];
 #pragma unroll
@@ -64,14 +66,16 @@ __device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visi
     for (int q = 0; q < kCount; ++q) tot[q] = 0.f;
   } else if (kMode == kSumsConsume) {
 #pragma unroll
-    for (int q = 0; q < kCount; ++q)
-      tot[q] = ((cp.data[(size_t)(0 * kCount + q) * cp.stride + i] + cp.data[(size_t)(1 * kCount + q) * cp.stride + i]) +
-                cp.data[(size_t)(2 * kCount + q) * cp.stride + i]) + cp.data[(size_t)(3 * kCount + q) * cp.stride + i];
+    for (int q = 0; q < kCount; ++q) {
+      float t = cp.data[(size_t)(0 * kCount + q) * cp.stride + i] + cp.data[(size_t)(1 * kCount + q) * cp.stride + i];
+      for (int c = 2; c < classes; ++c) t += cp.data[(size_t)(c * kCount + q) * cp.stride + i];
+      tot[q] = t;
+    }
   } else if (kWaves == 1) {
 #pragma unroll
     for (int q = 0; q < kCount; ++q) tot[q] = 0.f;   // +0 + p0 == p0 bit for bit (the partials are never -0)
 #pragma nounroll
-    for (int c = 0; c < kSumClasses; ++c) {
+    for (int c = 0; c < classes; ++c) {
       float acc[kCount];
 #pragma unroll
       for (int q = 0; q < kCount; ++q) acc[q] = 0.f;
@@ -82,7 +86,7 @@ __device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visi
   } else {
     const int part = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma nounroll
-    for (int c = part; c < kSumClasses; c += kWaves) {
+    for (int c = part; c < classes; c += kWaves) {
       float acc[kCount];
 #pragma unroll
       for (int q = 0; q < kCount; ++q) acc[q] = 0.f;
@@ -92,9 +96,11 @@ __device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visi
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kCount; ++q)
-      tot[q] = ((lds[(0 * kCount + q) * 64 + lane] + lds[(1 * kCount + q) * 64 + lane]) + lds[(2 * kCount + q) * 64 + lane]) +
-               lds[(3 * kCount + q) * 64 + lane];
+    for (int q = 0; q < kCount; ++q) {
+      float t = lds[(0 * kCount + q) * 64 + lane] + lds[(1 * kCount + q) * 64 + lane];
+      for (int c = 2; c < classes; ++c) t += lds[(c * kCount + q) * 64 + lane];
+      tot[q] = t;
+    }
     __syncthreads();   // the buffer is reused by the next call
   }
 }
@@ -230,8 +236,8 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
             if (kActivate) acc[kCount - 1] += (kfs[k].activation == BAHIP_KF_ACTIVE) ? 1.f : 0.f;
           }
         },
-        kSumClasses, cls);
-  }, cp, i, in_range);
+        in.sum_classes, cls);
+  }, in.sum_classes, cp, i, in_range);
   if (kMode == kSumsProduce) return;
   if (kActivate && decide) {
     const bool active = live && sum[kCount - 1] >= 1.f;
@@ -254,7 +260,7 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
 template <int kWaves>
 __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
 normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
-  __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 4 * 64];
+  __shared__ float lds[kWaves == 1 ? 1 : kMaxSumClasses * 4 * 64];
   const int lane = threadIdx.x & 63;
   const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + lane;
   const bool in_range = i < s.size;
@@ -330,8 +336,8 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
         const float wj = w * jac;
         acc[0] = mad(wj, jac, acc[0]);
         acc[1] = mad(wj, raw, acc[1]);
-      }, kSumClasses, cls);
-    }, cpp, ii, in_range);
+      }, in.sum_classes, cls);
+    }, in.sum_classes, cpp, ii, in_range);
     if (kPhase == 2 || !live || !writer) return;
     const float H = hb[0], b = hb[1];
     if (H > 1e-6f) {
@@ -389,8 +395,8 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
         a5 += w2 * jd * jd;
         a8 += wr2 * jd;
       }
-    }, kSumClasses, cls);
-  }, cpp, ii, in_range);
+    }, in.sum_classes, cls);
+  }, in.sum_classes, cpp, ii, in_range);
   if (kPhase == 2 || !live || !writer) return;
   const float a0 = tot[0], a1 = tot[1], a2 = tot[2], a3 = tot[3], a5 = tot[4], a6 = tot[5], a7 = tot[6], a8 = tot[7];
 
@@ -431,7 +437,7 @@ __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
 geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
                 const uint32_t* __restrict__ sched, const int* __restrict__ stop /* device-driven BA loop (capi.hip:
                 bahip_alternating_iterations): a launch queued behind the iteration that ended the loop does nothing; NULL: always runs */) {
-  __shared__ float lds[kWaves == 1 ? 1 : kSumClasses * 8 * 64];
+  __shared__ float lds[kWaves == 1 ? 1 : kMaxSumClasses * 8 * 64];
   if (stop && load_global(stop) != 0) return;
 #ifdef BAHIP_TILE_TIMELINE
   const unsigned long long t0 = wall_clock64();
@@ -465,7 +471,7 @@ activation_hits_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_k
   for_each_candidate_until(
       num_kfs,
       [&](int k) {
-        return ((uint32_t)k & 3u & owner_mask) == owner_rank && kfs[k].activation == BAHIP_KF_ACTIVE && sphere_may_project(in, kfs[k].pose.F, wb);
+        return ((uint32_t)k & owner_mask) == owner_rank && kfs[k].activation == BAHIP_KF_ACTIVE && sphere_may_project(in, kfs[k].pose.F, wb);
       },
       [&](int k) {
         if (in_range && !active) {

@@ -249,6 +249,10 @@ class DirectBA:
         """This object holds rank `rank`'s chunk-cyclic shard of one cloud; lifecycle phases run on the gathered cloud."""
         assert self.L.dba_set_surfel_sharding(self.h, int(rank), int(world), int(chunk)) == 0
 
+    def SetSumClasses(self, classes):
+        self.L.dba_set_sum_classes.argtypes = [C.c_void_p, C.c_int]
+        assert self.L.dba_set_sum_classes(self.h, int(classes)) == 0
+
     def SetKeyframeSharding(self, rank, world):
         """This object holds all surfels and sweeps the keyframes k with (k % 4) % world == rank (alternating scheme only)."""
         assert self.L.dba_set_keyframe_sharding(self.h, int(rank), int(world)) == 0

@@ -190,6 +190,10 @@ int dba_set_surfel_sharding(dba_handle* h, int rank, int world, uint32_t chunk) 
   h->ba->SetSurfelSharding(rank, world, chunk);
   return 0;
 }
+int dba_set_sum_classes(dba_handle* h, int classes) {
+  h->ba->SetSumClasses(classes);
+  return 0;
+}
 int dba_set_keyframe_sharding(dba_handle* h, int rank, int world) {
   h->ba->SetKeyframeSharding(rank, world);
   return 0;

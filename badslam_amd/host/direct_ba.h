@@ -142,6 +142,9 @@ class DirectBA {
   // intrinsics step, the PCG scheme and the surfel lifecycle (end tasks included) are refused.  Needs SetAllReduce or an RCCL
   // communicator when world > 1.
   void SetKeyframeSharding(int rank, int world);
+  // The per-surfel sums of the normals / geometry passes are defined over 4 (default) or 8 interleaved keyframe classes
+  // (bahip_context_set_sum_classes); keyframe sharding over 8 ranks needs 8 -- and so does the single-GPU run it is compared with.
+  void SetSumClasses(int classes);
   bahip_context* backend_context() { return ctx_; }
   // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
   // keyframe ids and the dense bound list.  Public so that a caller can drive single bahip_* stages

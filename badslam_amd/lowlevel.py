@@ -142,8 +142,12 @@ class Scene:
         return capi.Frame(kf["depth"].ptr, kf["depth"].pitch, kf["normals"].ptr, kf["normals"].pitch,
                           kf["radius"].ptr, kf["radius"].pitch, kf["color"].ptr, kf["color"].pitch)
 
+    def set_sum_classes(self, classes):
+        """4 (default) or 8 interleaved keyframe classes in the per-surfel sums (bahip_context_set_sum_classes)."""
+        capi.check(self.lib.bahip_context_set_sum_classes(self.ctx.handle, int(classes)))
+
     def set_keyframe_sharding(self, rank, world):
-        """Keyframe k lives on rank (k % 4) % world (bahip_context_set_keyframe_sharding); bind_keyframes then hands over the
+        """Keyframe k lives on rank k % world (bahip_context_set_keyframe_sharding); bind_keyframes then hands over the
         images of this rank's keyframes only (null pointers for the others: the backend must not look at them)."""
         capi.check(self.lib.bahip_context_set_keyframe_sharding(self.ctx.handle, int(rank), int(world)))
         self.kf_shard = (int(rank), int(world))
@@ -152,7 +156,7 @@ class Scene:
         arr = (capi.Keyframe * max(1, len(self.keyframes)))()
         rank, world = getattr(self, "kf_shard", (0, 1))
         for i, kf in enumerate(self.keyframes):
-            arr[i].frame = self.frame_struct(i) if (i % 4) % world == rank else capi.Frame()
+            arr[i].frame = self.frame_struct(i) if i % world == rank else capi.Frame()
             for c in range(7):
                 arr[i].global_T_frame[c] = float(kf["pose"][c])
             arr[i].activation = int(kf["activation"])

@@ -65,7 +65,7 @@ def parse_args():
     p.add_argument("--shard", choices=["surfels", "keyframes"], default="surfels",
                    help="what N > 1 ranks divide: surfels (keyframe images replicated; the production axis, any N) or keyframes "
                         "(BASELINE configs[3] as written: every rank holds all surfels and the images of the keyframes k with "
-                        "(k %% 4) %% N == rank; N = 2 or 4; class partials of the geometry step and the pose normal equations are "
+                        "k %% N == rank; N = 2, 4 or 8 (8: the 8-class definition of the per-surfel sums); class partials of the geometry step and the pose normal equations are "
                         "exchanged; same bits as one GPU)")
     p.add_argument("--no-spatial-sort", action="store_true", help="leave the surfels in creation order")
     p.add_argument("--sort-cell", type=float, default=0.02, help="grid cell of DirectBA::SortSurfelsSpatially [m] (its default: 0.02)")
@@ -227,11 +227,15 @@ def cpu_baseline(args, ba, data, log):
             proc = subprocess.run([sys.executable, "-m", "oracle.ref_cost_worker", d], capture_output=True, text=True, cwd=ROOT, timeout=900)
         if proc.returncode == 0:
             r = json.loads(proc.stdout.strip().splitlines()[-1])
-            return dict(pairs_per_s=K * N / r["seconds"], seconds_per_eval=r["seconds"], K=K, N=N, cores=r["cores"], nres=r["nres"], cost=r["cost"],
-                        kind="reference",
-                        who="the reference's own association / residual / robust-cost functions (oracle/_ref: B/surfel_projection_nvcc_only.cuh, "
-                            "B/cost_function.cuh, B/robust_weighting.cuh compiled for the host, OpenMP over the surfels, in a process of its own)")
-        log(f"cpu baseline: the reference library failed (exit {proc.returncode}: {proc.stderr.strip()[-300:]}); timing the oracle's restatement instead")
+            reference = dict(pairs_per_s=K * N / r["seconds"], seconds_per_eval=r["seconds"], K=K, N=N, cores=r["cores"], nres=r["nres"], cost=r["cost"],
+                             kind="reference",
+                             who="the reference's own association / residual / robust-cost functions (oracle/_ref: B/surfel_projection_nvcc_only.cuh, "
+                                 "B/cost_function.cuh, B/robust_weighting.cuh compiled for the host, OpenMP over the surfels, in a process of its own)")
+        else:
+            log(f"cpu baseline: the reference library failed (exit {proc.returncode}: {proc.stderr.strip()[-300:]}); timing the oracle's restatement only")
+            reference = None
+    else:
+        reference = None
     orc = ob.OracleBA(N + 64, 1.0 / 5000, 40.0, args.cell, ob.make_camera(cam, args.width, args.height),
                       ob.make_camera(cam, args.width, args.height))
     for k in range(K):
@@ -243,8 +247,14 @@ def cpu_baseline(args, ba, data, log):
     t1 = time.time()
     cost, nres = orc.evaluate_cost()
     dt = time.time() - t1
-    return dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=cores, nres=nres, cost=cost, kind="port",
-                who="the oracle's restatement (OpenMP)")
+    port = dict(pairs_per_s=K * N / dt, seconds_per_eval=dt, K=K, N=N, cores=cores, nres=nres, cost=cost, kind="port",
+                who="the oracle's restatement (OpenMP over the surfels, keyframes culled per 64-surfel tile against their frusta like the GPU sweeps)")
+    # both legs every time: the reference's functions are a brute-force K x N loop, the port culls -- a line that
+    # switched from one to the other moved the "GPU / CPU" ratio 45-fold for no reason
+    if reference is not None:
+        reference["port"] = port
+        return reference
+    return port
 
 
 def launch_ranks(args):
@@ -331,9 +341,9 @@ def main():
         mine = np.arange(lo, hi, dtype=np.int64)
     by_keyframes = args.shard == "keyframes" and shard_world > 1
     if by_keyframes:
-        if shard_world not in (2, 4) or args.intrinsics or args.pcg:
-            print("bench.py: --shard keyframes takes 2 or 4 ranks and the alternating scheme over poses and geometry (the per-surfel "
-                  "sums have four keyframe classes; intrinsics / PCG need surfel sharding)", file=sys.stderr)
+        if shard_world not in (2, 4, 8) or args.intrinsics or args.pcg:
+            print("bench.py: --shard keyframes takes 2, 4 or 8 ranks and the alternating scheme over poses and geometry (a rank holds "
+                  "whole keyframe classes of the per-surfel sums; intrinsics / PCG need surfel sharding)", file=sys.stderr)
             sys.exit(2)
         mine = np.arange(N_total, dtype=np.int64)
     ba.upload_surfels(np.ascontiguousarray(data[:, mine]) if (shard_world > 1 and not by_keyframes) else data)
@@ -358,6 +368,8 @@ def main():
             hook_keepalive = multigpu.install_allreduce(ctx, dist)
     K = args.keyframes
     if by_keyframes:
+        if shard_world == 8:
+            ba.SetSumClasses(8)      # eight ranks hold whole classes of the 8-class definition of the per-surfel sums
         ba.SetKeyframeSharding(shard_rank, shard_world)
 
     def run(iterations, intrinsics=args.intrinsics, pcg=args.pcg):
@@ -643,6 +655,10 @@ def main():
                                              f"{cb['N']} surfels {W}x{H} = {cb['K'] * cb['N']:.3g} pairs, {cb['nres']} residuals, "
                                              f"{cb['seconds_per_eval']:.2f} s; nothing extrapolated",
                                    "seconds_per_cost_evaluation": cb["seconds_per_eval"],
+                                   **({"port": {"value": cb["port"]["pairs_per_s"], "unit": "surfel-keyframe pairs/s (full cost evaluation)",
+                                                "cores": cb["port"]["cores"], "seconds_per_cost_evaluation": cb["port"]["seconds_per_eval"],
+                                                "residuals": cb["port"]["nres"],
+                                                "what": "the same evaluation by " + cb["port"]["who"]}} if "port" in cb else {}),
                                    "ba_iteration_lower_bound_note": f"one BA iteration makes >= {sweeps:.1f} such sweeps (activation, normals, "
                                                                     "position step, pose rounds) plus the Jacobians",
                                    "equivalent_ba_iterations_per_s": 1.0 / (sweeps * cb["seconds_per_eval"])}

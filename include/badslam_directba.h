@@ -74,8 +74,11 @@ int dba_clear_cfactor(dba_handle* h, void* hip_stream);
 int dba_set_pcg_gauge_keyframe(dba_handle* h, int keyframe_id);
 /* DirectBA::SetSurfelSharding: this object holds rank `rank`'s chunk-cyclic shard of one surfel cloud (bahip_gather_surfel_shards) */
 int dba_set_surfel_sharding(dba_handle* h, int rank, int world, uint32_t chunk);
-/* DirectBA::SetKeyframeSharding: this object holds all surfels and the images of the keyframes k with (k % 4) % world == rank
- * (bahip_context_set_keyframe_sharding; world = 1, 2, 4) */
+/* DirectBA::SetSumClasses: 4 (default) or 8 interleaved keyframe classes in the definition of the per-surfel sums
+ * (bahip_context_set_sum_classes) */
+int dba_set_sum_classes(dba_handle* h, int classes);
+/* DirectBA::SetKeyframeSharding: this object holds all surfels and the images of the keyframes k with k % world == rank
+ * (bahip_context_set_keyframe_sharding; world = 1, 2, 4, or 8 after dba_set_sum_classes(h, 8)) */
 int dba_set_keyframe_sharding(dba_handle* h, int rank, int world);
 /* DirectBA::SetBAIterationCount / SetLastBAIterationCount (direct_ba.h:362-366) */
 int dba_set_ba_iteration_counts(dba_handle* h, int ba_iteration_count, int last_ba_iteration_count);

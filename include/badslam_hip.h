@@ -111,9 +111,11 @@ typedef int (*bahip_allreduce_fn)(void* device_buffer, size_t count, int dtype, 
 int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void* user);
 /* Multi-GPU KEYFRAME sharding (BASELINE configs[3]: "sharded by keyframe, RCCL all-reduce of pose Hessians"; the loop it
  * partitions: B/kernel_opt_geometry.cc:108-200, B/kernel_opt_pose.cc:67-96, B/kernel_surfel_activation.cc:53-66).  Every rank
- * holds ALL surfels and the images of its own keyframes only: bound keyframe k lives on rank (k % 4) % world, world = 1, 2 or 4
- * (the per-surfel sums are defined as four interleaved partial sums over the keyframe classes k % 4, kernels_surfel.hip, so
- * whole classes per rank reproduce the unsharded bits; 8 ranks would need an 8-class definition).  bahip_set_keyframes still
+ * holds ALL surfels and the images of its own keyframes only: bound keyframe k lives on rank k % world, world = 1, 2, 4 or 8
+ * (the per-surfel sums are defined as C interleaved partial sums over the keyframe classes k % C, kernels_surfel.hip, so whole
+ * classes per rank reproduce the unsharded bits: C = 4 by default, which serves 2 and 4 ranks; 8 ranks -- BASELINE configs[3] as
+ * written -- need C = 8, bahip_context_set_sum_classes, which is then also the definition the single-GPU run it is compared with
+ * must use).  bahip_set_keyframes still
  * takes all keyframes -- poses and activation states are replicated -- but the image pointers of keyframes that live elsewhere
  * are not looked at (pass NULL).  With it
  *   - bahip_update_surfel_activation sums one hit word per surfel over the ranks (BAHIP_SUM_I64, N / 2 words);
@@ -126,6 +128,11 @@ int bahip_context_set_allreduce(bahip_context* ctx, bahip_allreduce_fn fn, void*
  * keyframes in order; use surfel sharding).  A hook or an RCCL communicator must be installed when world > 1.  Surfel and
  * keyframe sharding exclude each other on one context. */
 int bahip_context_set_keyframe_sharding(bahip_context* ctx, int rank, int world);
+/* The number of interleaved partial sums (keyframe classes) the per-surfel sums of the normals and geometry passes are DEFINED
+ * over: 4 (default) or 8.  In exact arithmetic both are the reference's sum (B/kernel_opt_geometry.cu: keyframe after keyframe);
+ * in binary32 they differ in the last bits like any reordering.  The oracle takes the same parameter (orc_set_sum_classes), and
+ * both class counts are held against it bit for bit.  Takes effect at once (no re-binding needed). */
+int bahip_context_set_sum_classes(bahip_context* ctx, int classes);
 #define BAHIP_RCCL_UNIQUE_ID_BYTES 128
 int bahip_rccl_get_unique_id(char unique_id_out[BAHIP_RCCL_UNIQUE_ID_BYTES]);
 int bahip_context_init_rccl(bahip_context* ctx, const char unique_id[BAHIP_RCCL_UNIQUE_ID_BYTES], int rank, int world_size);
@@ -448,6 +455,10 @@ int bahip_debug_set_pose_rounds_ahead(int rounds);
 /* 0: bahip_alternating_iterations reports "not handled" and callers drive the loop through the stage functions, one host wait
  * per Gauss-Newton round (BAHIP_DEVICE_LOOP=0 in the environment does the same); 1 (default): the device-driven loop.  Same bits. */
 int bahip_debug_set_device_loop(int enabled);
+/* 0: the step-1 sweep of the PCG scheme always runs one tile per wavefront with global atomics on the exact accumulators; 1
+ * (default): persistent workgroups that keep the pose block of the dense head in LDS when it fits (up to ~295 keyframes) and
+ * the grid fills the chip; 2: that form whenever the table fits (tests on small scenes).  Exact (integer) sums: the same bits. */
+int bahip_debug_set_pcg_lds_form(int mode);
 /* launches of the pose accumulation in either form since the last reset (process-wide); bench.py names the dominant kernel by it */
 int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):

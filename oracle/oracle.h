@@ -290,6 +290,11 @@ void orc_optimize_intrinsics(int optimize_depth_intrinsics, int optimize_color_i
                              const orc_camera* depth_cam, orc_depth_params* dp, const orc_surfels* s,
                              orc_camera* out_color_cam, orc_camera* out_depth_cam, float* out_a);
 
+/* The per-surfel sums of the normals / geometry passes are defined over 4 (default) or 8 interleaved keyframe classes
+ * (oracle_geometry.c; the HIP side: bahip_context_set_sum_classes).  Process-wide. */
+void orc_set_sum_classes(int classes);
+int orc_get_sum_classes(void);
+
 /* ---- BA drivers ---- */
 typedef struct {
   int use_depth_residuals, use_descriptor_residuals;

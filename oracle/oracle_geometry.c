@@ -58,8 +58,17 @@ void orc_assign_colors(const orc_camera* color_cam, const orc_camera* depth_cam,
  * index among the non-deleted keyframes is congruent to j modulo 4, in ascending order - combined as
  * ((p0 + p1) + p2) + p3 (kernels_surfel.hip: tile_sums).  The oracle follows that definition so
  * that the comparison can be bit-exact; in exact arithmetic it is the reference's sum. */
-#define ORC_SPLIT 4
-static inline float combine4(const float p[ORC_SPLIT]) { return ((p[0] + p[1]) + p[2]) + p[3]; }
+/* The class count is part of the definition: 4 by default, 8 on request (orc_set_sum_classes; kernels_surfel.hip: Intrinsics::
+ * sum_classes, what keyframe sharding over 8 ranks needs): p0 + p1 + ... in ascending order of the class. */
+#define ORC_SPLIT 8            /* room for either */
+static int g_sum_classes = 4;
+void orc_set_sum_classes(int classes) { if (classes == 4 || classes == 8) g_sum_classes = classes; }
+int orc_get_sum_classes(void) { return g_sum_classes; }
+static inline float combine4(const float p[ORC_SPLIT]) {
+  float t = p[0] + p[1];
+  for (int c = 2; c < g_sum_classes; ++c) t += p[c];
+  return t;
+}
 
 /* Normals pass shared by B/kernel_opt_geometry.cc:39-77 and :108-134; kernels
  * B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update). */
@@ -84,7 +93,7 @@ void orc_update_surfel_normals(const orc_camera* depth_cam, const orc_depth_para
       float m[3];
       orc_unpack_normal8(kf->normals[(size_t)r.py * kf->width + r.px], m);
       const v3 g = m33_mul(kf->global_R_frame, v3_make(m[0], m[1], m[2]));
-      const int j = bound_index % ORC_SPLIT;
+      const int j = bound_index % g_sum_classes;
       part[0][j] += g.x; part[1][j] += g.y; part[2][j] += g.z; part[3][j] += 1.f;
     }
     a0[i] = combine4(part[0]); a1[i] = combine4(part[1]); a2[i] = combine4(part[2]); a3[i] = combine4(part[3]);
@@ -116,7 +125,7 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
         if (!kf) continue;
         ++bound_index;
         if (kf->activation == ORC_KF_INACTIVE) continue;
-        const int j = bound_index % ORC_SPLIT;
+        const int j = bound_index % g_sum_classes;
         proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
         proj_result r;
         if (!orc_project_associate(&p, i, &r, NULL)) continue;
@@ -154,7 +163,7 @@ void orc_optimize_geometry_iteration(int use_depth, int use_desc, const orc_came
       if (!kf) continue;
       ++bound_index;
       if (kf->activation == ORC_KF_INACTIVE) continue;
-      const int j = bound_index % ORC_SPLIT;
+      const int j = bound_index % g_sum_classes;
       proj_params p = make_proj_params(depth_cam, dp, s, kf, kf->frame_T_global);
       proj_result r;
       if (!orc_project_associate(&p, i, &r, NULL)) continue;

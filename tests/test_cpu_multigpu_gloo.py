@@ -252,8 +252,9 @@ def test_surfel_sharded_intrinsics_accumulators_round_to_the_unsharded_ones(tmp_
 ACCUM0 = 8      # first accumulator row of the surfel buffer (B/kernels.cuh:69-93); the oracle parks its sums there
 
 
-def _keyframe_shard_worker(rank, world, port, out_dir):
-    """Rank `rank` holds all surfels and the images of the keyframes k with (k % 4) % world == rank.  Normals pass: the
+def _keyframe_shard_worker(rank, world, port, out_dir, classes=4, num_keyframes=6):
+    """Rank `rank` holds all surfels and the images of the keyframes k with k % world == rank (whole keyframe classes k % classes
+    of the per-surfel sums: classes = 4, or 8 for eight ranks).  Normals pass: the
     partial sums of each keyframe class it owns (the oracle run with only that class's keyframes not inactive leaves
     ((0 + p_c) ...) = p_c in the accumulator rows); pose phase: the fixed-point normal equations of its keyframes, zero rows
     for the others.  Both travel as int64 sums -- the class partials as BIT PATTERNS, two binary32 values per word."""
@@ -263,29 +264,30 @@ def _keyframe_shard_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import binding as ob
     from tests import common
-    scene = common.small_scene(num_keyframes=6, seed=8, width=160, height=120)
+    scene = common.small_scene(num_keyframes=num_keyframes, seed=8, width=160, height=120)
     ba = common.build_oracle(scene, 60000)
+    ob.lib().orc_set_sum_classes(classes)
     N, K = ba.surfels_size, len(ba.keyframes)
     ba.active[:N] = 1
     stride = (N + 63) & ~63
-    partials = np.zeros((4, 4, stride), np.float32)             # [class][x, y, z, count][surfel], zero where another rank computes
+    partials = np.zeros((classes, 4, stride), np.float32)       # [class][x, y, z, count][surfel], zero where another rank computes
     normals_before = ba.surfel_data[3, :N].copy()
-    for cls in range(4):
+    for cls in range(classes):
         if cls % world != rank:
             continue
         for k in range(K):
-            ba.keyframes[k].activation = ob.KF_ACTIVE if k % 4 == cls else ob.KF_INACTIVE
+            ba.keyframes[k].activation = ob.KF_ACTIVE if k % classes == cls else ob.KF_INACTIVE
         ba.surfel_data[3, :N] = normals_before                  # every class is evaluated at the same (old) normals
         ba.update_surfel_normals()
         partials[cls, :, :N] = ba.surfel_data[ACCUM0:ACCUM0 + 4, :N]
     ba.surfel_data[3, :N] = normals_before
     words = torch.from_numpy(partials.reshape(-1).view(np.int64))
-    dist.all_reduce(words, op=dist.ReduceOp.SUM)                # BAHIP_SUM_I64 over 4 * 4 * stride / 2 words
-    np.save(os.path.join(out_dir, f"partials_{rank}.npy"), words.numpy().view(np.float32).reshape(4, 4, stride)[:, :, :N])
+    dist.all_reduce(words, op=dist.ReduceOp.SUM)                # BAHIP_SUM_I64 over classes * 4 * stride / 2 words
+    np.save(os.path.join(out_dir, f"partials_{rank}.npy"), words.numpy().view(np.float32).reshape(classes, 4, stride)[:, :, :N])
 
     Hb = np.zeros((K, 28, 2), np.int64)
     for k in range(K):
-        if (k % 4) % world == rank:
+        if k % world == rank:
             Hb[k, :27] = ba.accumulate_pose_coeffs_fixed(k)
     t = torch.from_numpy(Hb)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -293,27 +295,36 @@ def _keyframe_shard_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_keyframe_sharded_class_partials_and_pose_equations_match_unsharded(tmp_path):
-    world = 2
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_keyframe_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,classes,num_keyframes", [(2, 4, 6), (8, 8, 11)])
+def test_keyframe_sharded_class_partials_and_pose_equations_match_unsharded(tmp_path, world, classes, num_keyframes):
+    """(8, 8, 11): BASELINE configs[3]'s rank count -- eight ranks, one keyframe class of the 8-class definition each."""
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_keyframe_shard_worker, args=(world, port, str(tmp_path), classes, num_keyframes), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
+    from oracle import binding as ob
     from tests import common
-    scene = common.small_scene(num_keyframes=6, seed=8, width=160, height=120)
+    scene = common.small_scene(num_keyframes=num_keyframes, seed=8, width=160, height=120)
     ba = common.build_oracle(scene, 60000)
+    ob.lib().orc_set_sum_classes(classes)
     N, K = ba.surfels_size, len(ba.keyframes)
     ba.active[:N] = 1
     want = np.zeros((K, 28, 2), np.int64)                        # (before the normals pass below changes the normals)
     for k in range(K):
         want[k, :27] = ba.accumulate_pose_coeffs_fixed(k)
-    ba.update_surfel_normals()                                   # unsharded: ((p0 + p1) + p2) + p3 over all six keyframes
+    try:
+        ba.update_surfel_normals()                               # unsharded: ((p0 + p1) + p2) + p3 (+ ... + p7) over all keyframes
+    finally:
+        ob.lib().orc_set_sum_classes(4)
     ref = ba.surfel_data[ACCUM0:ACCUM0 + 4, :N].copy()
-    p0, p1 = np.load(tmp_path / "partials_0.npy"), np.load(tmp_path / "partials_1.npy")
-    assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))                     # every rank holds every class's partials
-    assert all(np.count_nonzero(p0[c, 3]) > N // 10 for c in range(4))                # all four classes saw surfels
-    total = ((p0[0] + p0[1]) + p0[2]) + p0[3]                                         # the defined combination, binary32
+    parts = [np.load(tmp_path / f"partials_{r}.npy") for r in range(world)]
+    p0 = parts[0]
+    assert all(np.array_equal(p0.view(np.uint32), p.view(np.uint32)) for p in parts)  # every rank holds every class's partials
+    assert all(np.count_nonzero(p0[c, 3]) > N // 10 for c in range(classes))          # every class saw surfels
+    total = p0[0] + p0[1]                                                             # the defined combination, binary32, ascending
+    for c in range(2, classes):
+        total = total + p0[c]
     assert total.dtype == np.float32
     assert np.array_equal(total.view(np.uint32), ref.view(np.uint32))                 # the unsharded sums, bit for bit
 
-    h0, h1 = np.load(tmp_path / "kf_hb_0.npy"), np.load(tmp_path / "kf_hb_1.npy")
-    assert np.array_equal(h0, h1) and np.array_equal(h0, want)                        # the "all-reduce of pose Hessians"
+    hs = [np.load(tmp_path / f"kf_hb_{r}.npy") for r in range(world)]
+    assert all(np.array_equal(hs[0], h) for h in hs) and np.array_equal(hs[0], want)  # the "all-reduce of pose Hessians"

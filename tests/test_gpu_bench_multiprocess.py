@@ -52,7 +52,23 @@ def test_bench_sharded_by_keyframes():
     assert out["exchange"]["calls_per_iteration"] >= 3 and out["exchange"]["bytes_per_iteration"] >= N * 4 * 13 * 4
     proc = subprocess.run(base + ["--nproc-per-node=3", "--master-port", "29712", os.path.join(ROOT, "bench.py"), "--gpus", "3", *flags],
                           capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert proc.returncode != 0 and "2 or 4 ranks" in proc.stderr
+    assert proc.returncode != 0 and "2, 4 or 8 ranks" in proc.stderr
+
+
+def test_bench_sharded_by_keyframes_over_eight_ranks():
+    """BASELINE configs[3] as written -- "sharded by keyframe across 8 MI355X" -- as a launch: eight ranks (sharing the one device
+    over gloo here), the 8-class definition of the per-surfel sums, one JSON line that says n_gpus = 8."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29713",
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--keyframes", "16", "--surfels", "100000", "--no-cpu-baseline",
+           "--shard", "keyframes"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["parallelism"].startswith("keyframe-shard x8")
+    assert len(out["per_rank"]) == 8 and all(r["surfels"] == out["config"]["surfels"] for r in out["per_rank"])
 
 
 def test_bench_launches_its_own_ranks():

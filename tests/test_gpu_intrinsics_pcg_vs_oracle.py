@@ -157,10 +157,14 @@ def test_pcg_system_assembly(scene, mode):
     assert np.array_equal(_bits(g.read_pcg_vector(0, U)), _bits(r))
 
 
-@pytest.mark.parametrize("mode", ["poses+geometry", "geometry-only", "all"])
-def test_pcg_iteration(scene, mode):
+@pytest.mark.parametrize("mode,lds_form", [("poses+geometry", 0), ("geometry-only", 0), ("all", 0), ("poses+geometry", 2), ("all", 2)])
+def test_pcg_iteration(scene, mode, lds_form, request):
     """One outer iteration of the PCG scheme: the same number of inner steps, the same surfels, poses and calibration, bit for
-    bit (with a != 0 in the joint mode: exp_det)."""
+    bit (with a != 0 in the joint mode: exp_det).  lds_form 2: the step-1 sweep by persistent workgroups that keep the pose block
+    of the dense head in LDS (round 4; the form the bench size takes) -- exact integer sums, the same bits."""
+    from badslam_amd import capi as _capi
+    _capi.check(_capi.load().bahip_debug_set_pcg_lds_form(lds_form))
+    request.addfinalizer(lambda: _capi.check(_capi.load().bahip_debug_set_pcg_lds_form(1)))
     ba, g, data, perturbed = _pcg_setup(scene, mode)
     poses_on = mode != "geometry-only"
     di = ci = (mode == "all")

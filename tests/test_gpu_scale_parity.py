@@ -55,12 +55,18 @@ def _set_activations(orc, g, pattern):
         g.keyframes[k]["activation"] = int(pattern[k])
 
 
-@pytest.mark.parametrize("tile_waves,fused", [(1, False), (4, False), (1, True), (4, True)])
-def test_many_keyframes_activation_and_geometry_bit_exact(many, tile_waves, fused, request):
+@pytest.mark.parametrize("tile_waves,fused,classes", [(1, False, 4), (4, False, 4), (1, True, 4), (4, True, 4), (1, True, 8), (4, True, 8), (4, False, 8)])
+def test_many_keyframes_activation_and_geometry_bit_exact(many, tile_waves, fused, classes, request):
+    """classes: the number of interleaved keyframe classes the per-surfel sums are defined over -- 4 by default, 8 for keyframe
+    sharding over 8 ranks (bahip_context_set_sum_classes / orc_set_sum_classes): either definition, both launch shapes, the
+    oracle's bits."""
+    from oracle import binding as ob
     scene, orc, g = many
     K = len(orc.keyframes)
     _shapes(g.ctx.lib, tile_waves, 0)
-    request.addfinalizer(lambda: _shapes(g.ctx.lib, 0, 0))
+    g.set_sum_classes(classes)
+    ob.lib().orc_set_sum_classes(classes)
+    request.addfinalizer(lambda: (_shapes(g.ctx.lib, 0, 0), g.set_sum_classes(4), ob.lib().orc_set_sum_classes(4)))
     orc.use_depth, orc.use_desc = 1, 1
     data, active = common.oracle_surfels(orc)
     n = data.shape[1]

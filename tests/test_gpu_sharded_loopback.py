@@ -286,11 +286,12 @@ def test_sharded_bundle_adjustment_with_surfel_updates_is_the_unsharded_run(use_
         assert np.array_equal(results[0]["poses"][k], results[1]["poses"][k]) and np.array_equal(ref["poses"][k], results[0]["poses"][k]), k
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_keyframe_shards_reproduce_the_unsharded_run(world):
     """KEYFRAME sharding (BASELINE configs[3]; bahip_context_set_keyframe_sharding): every rank holds the whole cloud and the
-    images of its own keyframes only -- bound keyframe k lives on rank (k % 4) % world, the other keyframes are bound with null
-    image pointers.  Activation sums one hit word per surfel; the geometry step runs in three launches with the class partials
+    images of its own keyframes only -- bound keyframe k lives on rank k % world, the other keyframes are bound with null
+    image pointers.  Eight ranks (BASELINE configs[3] as written) take the 8-class definition of the per-surfel sums
+    (bahip_context_set_sum_classes: a rank holds whole classes), which the single-GPU run it is compared with then uses too.  Activation sums one hit word per surfel; the geometry step runs in three launches with the class partials
     of the normals pass and of the position pass exchanged as bit patterns; the pose phase sums the fixed-point normal
     equations of disjoint keyframes ("all-reduce of pose Hessians") and every rank solves every pose.  After ITERATIONS
     alternating iterations every rank must hold the unsharded run's surfels (positions, normals, descriptors, flags) and
@@ -298,11 +299,13 @@ def test_keyframe_shards_reproduce_the_unsharded_run(world):
     import torch
     from badslam_amd import capi
     torch.cuda.set_device(0)
-    scene = common.small_scene(num_keyframes=7, seed=21)
+    scene = common.small_scene(num_keyframes=7 if world < 8 else 11, seed=21)
     rng = np.random.Generator(np.random.PCG64(4))
     start_poses = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    classes = 8 if world == 8 else 4
 
     g = common.build_gpu(scene, 500000)
+    g.set_sum_classes(classes)
     data = g.download_surfels()
     data[2] += rng.uniform(0, 0.004, data.shape[1]).astype(np.float32)
     N = data.shape[1]
@@ -347,6 +350,7 @@ def test_keyframe_shards_reproduce_the_unsharded_run(world):
             prepare(gr)
             hook = loop.hook_for(rank)
             capi.check(gr.ctx.lib.bahip_context_set_allreduce(gr.ctx.handle, hook, None))
+            gr.set_sum_classes(classes)
             gr.set_keyframe_sharding(rank, world)
             out = step(gr)
             results[rank] = dict(out=out, surfels=gr.download_surfels(), active=gr.active_buf.download().ravel()[:N].copy(),
@@ -380,14 +384,17 @@ def test_keyframe_shards_reproduce_the_unsharded_run(world):
 
 def test_keyframe_sharding_refuses_what_it_does_not_cover():
     """The intrinsics step, the PCG scheme and the lifecycle keep per-surfel chains over all keyframes in order: under keyframe
-    sharding they fail with an error that says so (no silent wrong answer); world sizes other than 1, 2, 4 are refused."""
+    sharding they fail with an error that says so (no silent wrong answer); world sizes other than 1, 2, 4, 8 are refused, and 8
+    without the 8-class definition of the per-surfel sums."""
     import torch
     from badslam_amd import capi
     torch.cuda.set_device(0)
     scene = common.small_scene(num_keyframes=3, seed=3)
     g = common.build_gpu(scene, 200000)
     lib, h = g.ctx.lib, g.ctx.handle
-    assert lib.bahip_context_set_keyframe_sharding(h, 0, 3) != 0 and b"1, 2 or 4" in lib.bahip_last_error()
+    assert lib.bahip_context_set_keyframe_sharding(h, 0, 3) != 0 and b"1, 2, 4 or 8" in lib.bahip_last_error()
+    assert lib.bahip_context_set_keyframe_sharding(h, 0, 8) != 0 and b"bahip_context_set_sum_classes" in lib.bahip_last_error()
+    assert lib.bahip_context_set_sum_classes(h, 5) != 0
     assert lib.bahip_context_set_keyframe_sharding(h, 2, 2) != 0
     g.set_keyframe_sharding(1, 2)
     g.bind_keyframes()
