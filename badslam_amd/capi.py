@@ -138,6 +138,7 @@ SIGNATURES = {
     "bahip_apply_activation_window": (C.c_int, [C.c_void_p]),
     "bahip_determine_supporting_surfels": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(Frame), C.POINTER(C.c_float),
                                                      C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bahip_take_merged_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "bahip_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
                                                     C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_delete_surfels_and_update_radii": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_uint32)]),

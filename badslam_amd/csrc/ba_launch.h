@@ -128,6 +128,7 @@ size_t intrinsics_bin_record_bytes();
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
                                   const SurfelsView& s, double* glob_d, double* cells_d, const IntrBins& bins,
                                   const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
+void launch_intrinsics_bin_reduce(hipStream_t st, bool depth, const Intrinsics& in, const SurfelsView& s, double* cells, const IntrBins& bins);
 size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_finish needs
 void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* glob_d, const double* cells_d, float* glob_f, float* cells_f,
                               float* partials);

@@ -162,7 +162,8 @@ struct bahip_context {
   void* rccl_comm = nullptr;       // ncclComm_t created by bahip_context_init_rccl (native all-reduce on ctx->stream)
 
   int profiling = 0;               // 0 off, 1 last call of each stage, 2 cumulative since bahip_set_profiling
-  StageTimer timers[6];              // 0 activation, 1 geometry, 2 pose accumulate, 3 pose solve, 4 intrinsics, 5 PCG iteration
+  StageTimer timers[8];              // 0 activation, 1 geometry, 2 pose accumulate, 3 pose solve, 4 intrinsics (whole step), 5 PCG step-1 sweep,
+                                     // 6 intrinsics sweep alone, 7 intrinsics reduction of the binned records alone
 };
 
 namespace {
@@ -622,7 +623,7 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   REQUIRE(n > 0, "bahip_context_create: no HIP device (the HIP backend has no CPU fallback)");
   bahip_context* ctx = new bahip_context();
   ctx->stream = static_cast<hipStream_t>(hip_stream);
-  const bool ok = hipMalloc(&ctx->dev_counter, 16 * sizeof(int)) == hipSuccess &&
+  const bool ok = hipMalloc(&ctx->dev_counter, 16 * sizeof(int)) == hipSuccess && hipMemset(ctx->dev_counter, 0, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_f, 128 * sizeof(float)) == hipSuccess &&
                   hipMalloc(&ctx->dev_tile_counters, 16 * sizeof(uint32_t)) == hipSuccess &&
@@ -1355,15 +1356,21 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
   if (merge) {
     const float cell = (float)ctx->in.cell;
     const float cell_merge_dist_sq = cell * cell * merge_dist_factor * merge_dist_factor;
-    HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
     // per-surfel decision flags live in accum row 0 (scratch by contract, B/kernels.cuh:78-90)
     uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
-    launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags,
-                 reinterpret_cast<uint32_t*>(ctx->dev_counter));
-    CHECK_LAUNCH();
-    HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (merged_count_out) *merged_count_out = (uint32_t)ctx->pinned_i[0];
+    if (merged_count_out) {
+      HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter));
+      CHECK_LAUNCH();
+      HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      *merged_count_out = (uint32_t)ctx->pinned_i[0];
+    } else {
+      // deferred count: a batch of keyframes merges without a read-back and a stream synchronisation per keyframe; the total
+      // waits in dev_counter[3] for bahip_take_merged_count
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3);
+      CHECK_LAUNCH();
+    }
   }
   return 0;
 }
@@ -1379,6 +1386,15 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
   if (make_entry(ctx, *frame, 0, &e)) return 1;
   memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
   return determine_supporting_impl(ctx, merge, merge_dist_factor, e, surfels, sup, merged_count_out);
+}
+
+int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out) {
+  REQUIRE(merged_count_out != nullptr, "bahip_take_merged_count: NULL argument");
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dev_counter + 3, 0, sizeof(int), ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *merged_count_out = (uint32_t)ctx->pinned_i[0];
+  return 0;
 }
 
 int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, int filter_new_surfels, int min_observation_count,
@@ -1538,8 +1554,13 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   timer_begin(ctx, 4, true);
   HIP_TRY(hipMemsetAsync(glob_d, 0, sizeof(double) * (64 + 8 * (size_t)S), ctx->stream));
   if (bins.capacity) HIP_TRY(hipMemsetAsync(bins.cursors, 0, sizeof(uint32_t) * (size_t)num_bins, ctx->stream));
+  timer_begin(ctx, 6, true);
   launch_intrinsics_accumulate(ctx->stream, optimize_depth != 0, optimize_color != 0, ctx->in, ctx->dev_kfs, ctx->num_kfs,
                                make_view(surfels), glob_d, cells_d, bins, tile_order_for(ctx, surfels->surfels_size));
+  timer_end(ctx, 6);
+  timer_begin(ctx, 7, true);
+  launch_intrinsics_bin_reduce(ctx->stream, optimize_depth != 0, ctx->in, make_view(surfels), cells_d, bins);
+  timer_end(ctx, 7);
   CHECK_LAUNCH();
   if (bins.capacity)
     HIP_TRY(hipMemcpyAsync(ctx->intr_bin_counts_host, bins.cursors, sizeof(uint32_t) * (size_t)num_bins, hipMemcpyDeviceToHost, ctx->stream));
@@ -1707,7 +1728,9 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   int steps = 0;
   for (int step = 0; step < opt->max_inner_iterations; ++step) {
     if (step > 0) { const int t = i_an; i_an = i_bn; i_bn = t; }
+    timer_begin(ctx, 5, step == 0);
     launch_pcg_step1(st, L, ex, ctx->in, ctx->dev_kfs, K, sv, p_, g_, ctl, sched, ctx->dev_tile_counters, &ctx->pose_parity);
+    timer_end(ctx, 5);
     CHECK_LAUNCH();
     if (sharded && reduce_over_ranks(ctx, ex.hot, x1_step, BAHIP_SUM_I64)) return 1;   // g head, intrinsics entries, alpha_d terms
     launch_pcg_resolve_step1(st, L, ex, g_, sc + 1, eps_repeat, ctl);
@@ -2117,7 +2140,7 @@ int bahip_set_profiling(bahip_context* ctx, int enabled) {
 }
 
 int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* launches_out) {
-  REQUIRE(stage >= 0 && stage < 6, "stage out of range");
+  REQUIRE(stage >= 0 && stage < 8, "stage out of range");
   StageTimer& t = ctx->timers[stage];
   float total = 0.f;
   int launches = 0;
@@ -2216,7 +2239,7 @@ int bahip_exchange_stats(bahip_context* ctx, long long* calls_out, long long* by
 }
 
 int bahip_stage_work_units(bahip_context* ctx, int stage, long long* units_out) {
-  REQUIRE(stage >= 0 && stage < 6 && units_out != nullptr, "stage out of range");
+  REQUIRE(stage >= 0 && stage < 8 && units_out != nullptr, "stage out of range");
   *units_out = ctx->timers[stage].units;
   return 0;
 }

@@ -411,6 +411,10 @@ void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const 
   if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
   else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
   else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
+}
+// The second kernel of the step: the binned per-cell records into the per-cell accumulators (nothing to do without bins).
+void launch_intrinsics_bin_reduce(hipStream_t st, bool depth, const Intrinsics& in, const SurfelsView& s, double* cells, const IntrBins& bins) {
+  if (!s.size) return;
   if (depth && bins.capacity) {
     const int slices = (int)((bins.capacity + kBinSlice - 1) / kBinSlice);
     hipLaunchKernelGGL(intrinsics_bin_reduce_kernel, dim3((unsigned)(intrinsics_bin_count(in, nullptr) * slices)), dim3(kBinReduceBlock),

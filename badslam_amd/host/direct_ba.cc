@@ -259,7 +259,9 @@ void DirectBA::LeaveWholeCloud(hipStream_t stream) {
 // ---- surfel creation (B/direct_ba.cc:340-405) ---------------------------------------------------------------------
 void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const shared_ptr<Keyframe>& keyframe) {
   WholeCloudScope whole_cloud(this, stream);
-  BindScene(stream);
+  // inside a batch (the BA loop's creation pass) the scene was bound once for all its keyframes: nothing the binding reads
+  // (poses, activations, co-visibility lists, intrinsics) changes between the creations of one batch
+  if (!creation_batch_bound_) BindScene(stream);
   vector<int> covis;
   for (int id : keyframe->co_visibility_list())
     if (id >= 0 && id < (int)id_to_bound_.size() && id_to_bound_[id] >= 0) covis.push_back(id_to_bound_[id]);
@@ -278,7 +280,7 @@ void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surf
   Unlock();
 }
 
-void DirectBA::MergeForKeyframe(const Keyframe& keyframe) {
+void DirectBA::MergeForKeyframe(const Keyframe& keyframe, bool defer_count) {
   uint32_t* sup[kMergeBufferCount];
   for (int i = 0; i < kMergeBufferCount; ++i) sup[i] = supporting_surfels_[i]->ToCUDA().address();
   const bahip_frame frame = keyframe.ToBahipFrame();
@@ -287,7 +289,15 @@ void DirectBA::MergeForKeyframe(const Keyframe& keyframe) {
   const bahip_surfels s = SurfelsStruct();
   uint32_t merged = 0;
   BAHIP_CHECKED_CALL(bahip_determine_supporting_surfels(ctx_, 1, surfel_merge_dist_factor_, &frame, F, &s, sup,
-                                                        (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(), &merged));
+                                                        (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(), defer_count ? nullptr : &merged));
+  surfel_count_ -= merged;
+}
+
+// The merges of a batch of keyframes run back to back on the stream; their total is read once, before the compaction that needs it
+// (the reference reads one count per keyframe, B/direct_ba.cc:618-622 -- the buffer contents are the same either way).
+void DirectBA::TakeDeferredMergeCount() {
+  uint32_t merged = 0;
+  BAHIP_CHECKED_CALL(bahip_take_merged_count(ctx_, &merged));
   surfel_count_ -= merged;
 }
 
@@ -352,8 +362,9 @@ void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_update
   if (do_surfel_updates) {
     for (shared_ptr<Keyframe>& keyframe : keyframes_) {
       if (!keyframe) continue;
-      if (keyframe->last_active_in_ba_iteration() == ba_iteration_count_) MergeForKeyframe(*keyframe);
+      if (keyframe->last_active_in_ba_iteration() == ba_iteration_count_) MergeForKeyframe(*keyframe, /*defer_count*/ true);
     }
+    TakeDeferredMergeCount();
   }
   const bahip_surfels s = SurfelsStruct();
   uint32_t deleted = 0;
@@ -524,7 +535,11 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       Unlock();
       if (!keyframes_with_new_surfels.empty()) {
         WholeCloudScope whole_cloud(this, stream);   // one gather for the whole batch
+        apply_pending();
+        BindScene(stream);                           // ... and one binding
+        creation_batch_bound_ = true;
         for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
+        creation_batch_bound_ = false;
       }
       if (!keyframes_with_new_surfels.empty()) scene_bound = false;   // CreateSurfelsForKeyframe re-bound the keyframes: lists and window go again
     }
@@ -571,7 +586,8 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     if (do_surfel_updates && !keyframes_with_new_surfels.empty()) {
       WholeCloudScope whole_cloud(this, stream);
       for (u32 keyframe_id : keyframes_with_new_surfels)
-        if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
+        if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
+      TakeDeferredMergeCount();
       {
         const bahip_surfels s = SurfelsStruct();
         unsorted_surfels_ += surfels_size_ - surfel_count_;
@@ -700,7 +716,8 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
     if (keyframes_with_new_surfels.empty()) return;
     WholeCloudScope whole_cloud(this, stream);
     for (u32 keyframe_id : keyframes_with_new_surfels)
-      if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id]);
+      if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
+    TakeDeferredMergeCount();
     if (!keyframes_with_new_surfels.empty()) {
       const bahip_surfels s = SurfelsStruct();
       unsorted_surfels_ += surfels_size_ - surfel_count_;
@@ -718,6 +735,8 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       for (const shared_ptr<Keyframe>& keyframe : keyframes_)
         any_new |= keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != ba_iteration_count_;
       std::unique_ptr<WholeCloudScope> whole_cloud(any_new ? new WholeCloudScope(this, stream) : nullptr);   // one gather for the batch
+      if (any_new) BindScene(stream);                                                                          // ... and one binding
+      creation_batch_bound_ = any_new;
       for (shared_ptr<Keyframe>& keyframe : keyframes_) {
         if (keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != ba_iteration_count_) {
           keyframe->SetLastActiveInBAIteration(ba_iteration_count_);
@@ -728,6 +747,7 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
           keyframe->SetLastCovisInBAIteration(ba_iteration_count_);
         }
       }
+      creation_batch_bound_ = false;
     }
     BindScene(stream);
     BAHIP_CHECKED_CALL(bahip_memset_async(stream, active_surfels_->ToCUDA().address(), 1, surfels_size_));

@@ -172,7 +172,9 @@ class DirectBA {
   void DetermineNewKeyframeCoVisibility(const shared_ptr<Keyframe>& new_keyframe);
   void PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_updates);
 
-  void MergeForKeyframe(const Keyframe& keyframe);
+  void MergeForKeyframe(const Keyframe& keyframe, bool defer_count = false);
+  void TakeDeferredMergeCount();
+  bool creation_batch_bound_ = false;
   // Whole-cloud phases under surfel sharding (no-ops without it); they nest, only the outermost pair moves data.
   void EnterWholeCloud(hipStream_t stream);
   void LeaveWholeCloud(hipStream_t stream);

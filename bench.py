@@ -410,8 +410,8 @@ def main():
     stats = ba.last_stats()
 
     def read_stage_timers():
-        out_ms, out_n = np.zeros(5), np.zeros(5, dtype=np.int64)
-        for s in range(5):
+        out_ms, out_n = np.zeros(8), np.zeros(8, dtype=np.int64)
+        for s in range(8):
             ms, n = C.c_float(), C.c_int()
             capi.check(ctx.lib.bahip_last_stage_time_ms(ctx.handle, s, C.byref(ms), C.byref(n)))
             out_ms[s], out_n[s] = ms.value, n.value
@@ -438,8 +438,19 @@ def main():
             run(EXTRA_STEPS, intrinsics=True)
             ctx.synchronize()
             ms, _ = read_stage_timers()
+            pairs = None
             extras["intrinsics"] = {"BA_intrinsics_optimization_ms_per_iteration": ms[4] / EXTRA_STEPS, "iterations": EXTRA_STEPS,
+                                    "sweep_ms": ms[6] / EXTRA_STEPS, "record_reduction_ms": ms[7] / EXTRA_STEPS,
                                     "note": "alternating iterations with depth + colour intrinsics optimisation after the timed region"}
+            # the stage's dominant kernel against the HBM roof: its algorithmic bytes are the pose sweep's (surfel rows once, 5 bytes of
+            # every keyframe pixel) plus the 32-byte record it writes per associated pair with a depth residual (read back by the reduction)
+            sweep_bytes = N_total * 28 + K * args.width * args.height * 5
+            extras["roofline_intrinsics"] = {"bound": "hbm", "kernel": "intrinsics_accumulate_kernel<true,true>", "avg_launch_ms": ms[6] / EXTRA_STEPS,
+                                             "algorithmic_bytes_per_launch": sweep_bytes, "achieved": sweep_bytes / (ms[6] / EXTRA_STEPS * 1e-3) / 1e9,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sweep_bytes / (ms[6] / EXTRA_STEPS * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "traffic": None,
+                                             "limiter": "instruction issue (the sweep carries 34 per-lane sums: 168 VGPRs, 3 wavefronts per SIMD) and, in "
+                                                        "the second kernel, the LDS atomics that add the binned per-cell records"}
             cc, dc, _a = ba.cameras()
             ba.set_cameras(cc, dc, 0.0)        # back to a = 0 for what follows (the cfactor image keeps its update)
         capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
@@ -450,6 +461,23 @@ def main():
         ctx.synchronize()
         dt_pcg = time.perf_counter() - t_pcg
         inner = ba.last_stats()["pcg_inner_steps"] / EXTRA_STEPS
+        # one more outer iteration with event pairs around the step-1 sweeps (the scheme's dominant kernel), outside the timed ones
+        capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 2))
+        run(1, intrinsics=False, pcg=True)
+        ctx.synchronize()
+        ms_pcg, n_pcg = read_stage_timers()
+        capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
+        if n_pcg[5] > 0:
+            U = 6 * (K - 1) + 3 * N_total
+            step1_ms = ms_pcg[5] / n_pcg[5]
+            # algorithmic bytes of one step-1 sweep: surfel rows once, p and g of the surfel block (3 + 3 floats
+            # per surfel), 5 bytes of every keyframe pixel
+            step1_bytes = N_total * (28 + 6 * 4) + K * args.width * args.height * 5
+            extras["roofline_pcg"] = {"bound": "hbm", "kernel": "pcg_step1_lds_kernel<false,false> (persistent, pose block of the dense head in LDS)",
+                                      "avg_launch_ms": step1_ms, "launches": int(n_pcg[5]), "algorithmic_bytes_per_launch": step1_bytes,
+                                      "achieved": step1_bytes / (step1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": step1_bytes / (step1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "unknowns": int(U),
+                                      "limiter": "instruction issue, as the pose sweep: the same pair work plus s = J p and g += J^T (w s)"}
         extras["pcg"] = {"outer_iterations_per_s": EXTRA_STEPS / dt_pcg, "ms_per_outer_iteration": 1e3 * dt_pcg / EXTRA_STEPS,
                          "inner_steps_per_outer_iteration": inner, "inner_steps_per_s": inner * EXTRA_STEPS / dt_pcg,
                          "max_inner_iterations": 30, "iterations": EXTRA_STEPS,

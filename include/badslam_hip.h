@@ -308,6 +308,10 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
                                        const bahip_frame* frame, const float frame_T_global[12],
                                        const bahip_surfels* surfels, uint32_t* const* supporting,
                                        uint32_t supporting_pitch_bytes, uint32_t* merged_count_out);
+/* merged_count_out == NULL in bahip_determine_supporting_surfels(merge = 1, ...) defers the count: no read-back and no stream
+ * synchronisation per keyframe; the surfels merged by all such calls since the last bahip_take_merged_count are returned (and
+ * the counter cleared) here -- one synchronisation per batch of keyframes instead of one per keyframe. */
+int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out);
 /* B/kernels.h CreateSurfelsForKeyframeCUDA (B/kernel_create_surfels.cc:40-183), including the
  * DetermineSupportingSurfelsCUDA call that DirectBA::CreateSurfelsForKeyframe issues first
  * (B/direct_ba.cc:345-355).  keyframe_index selects the bound keyframe; covis / n_covis: indices
@@ -491,7 +495,8 @@ int bahip_debug_count_pairs(bahip_context* ctx, const bahip_surfels* surfels, ui
 /* ---- instrumentation ---------------------------------------------------------------------------- */
 /* Time (ms, hipEvent on the context stream) and launch count of the kernels issued by the last
  * call of each stage; used by bench.py for the roofline line.  stage: 0 activation, 1 geometry,
- * 2 pose accumulate, 3 pose solve, 4 intrinsics (accumulation sweep + Schur complement), 5 reserved. */
+ * 2 pose accumulate, 3 pose solve, 4 intrinsics (accumulation sweep + reduction of the binned records + Schur complement),
+ * 5 the step-1 sweeps of the PCG scheme, 6 the intrinsics sweep alone, 7 the reduction of the binned records alone. */
 int bahip_last_stage_time_ms(bahip_context* ctx, int stage, float* ms_out, int* launches_out);
 /* enabled: 0 off; 1 = the counters cover the last call of each stage; 2 = cumulative since this call; 3 = cumulative,
  * stage 2 only (two event records per pose round instead of ten per BA iteration). */
