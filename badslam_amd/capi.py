@@ -139,6 +139,8 @@ SIGNATURES = {
     "bahip_determine_supporting_surfels": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(Frame), C.POINTER(C.c_float),
                                                      C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_take_merged_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "bahip_lifecycle_batch_begin": (C.c_int, [C.c_void_p, C.POINTER(Surfels)]),
+    "bahip_lifecycle_batch_end": (C.c_int, [C.c_void_p]),
     "bahip_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
                                                     C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_delete_surfels_and_update_radii": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Surfels), C.POINTER(C.c_uint32)]),
@@ -175,6 +177,7 @@ SIGNATURES = {
     "bahip_debug_set_pose_form": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_items": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_shape": (C.c_int, [C.c_int, C.c_int]),
+    "bahip_debug_set_fused_iteration_begin": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_rounds_ahead": (C.c_int, [C.c_int]),
     "bahip_debug_set_device_loop": (C.c_int, [C.c_int]),
     "bahip_debug_set_pcg_lds_form": (C.c_int, [C.c_int]),

@@ -213,7 +213,8 @@ constexpr int kPoseCounterWorked = 36;
 // converged (B/direct_ba_alternating.cc:693-701: every keyframe counts as converged and iteration >= min_iterations - 1),
 // 2 = a pose phase ran out of queued Gauss-Newton rounds with work items still iterating (the host continues it) -- every launch
 // of the loop does nothing once it is non-zero.  The rest are totals since the host last cleared them.
-constexpr int kLoopStop = 0, kLoopIterationsDone = 1, kLoopRounds = 2, kLoopSteps = 3, kLoopNotConverged = 4, kLoopWords = 8;
+constexpr int kLoopStop = 0, kLoopIterationsDone = 1, kLoopRounds = 2, kLoopSteps = 3, kLoopNotConverged = 4,
+              kLoopInvalid = 5 /* a pose phase of the loop raised kPoseCounterInvalid */, kLoopWords = 8;
 // Behind the counter records (device only): the indices of the work items still iterating after the latest Gauss-Newton
 // round, in arbitrary order (pose_solve_kernel appends with the same atomic that counts them).  The later rounds of a phase
 // sweep over this list instead of over all work items (a handful of entries instead of K).

@@ -77,6 +77,13 @@ struct PoseLoopControl {
   int min_iterations = 0;
   int* round_log = nullptr;    // mapped host memory: [log_slot] = work items that iterated in this round (for the stage timers)
   int log_slot = 0;
+  // >= 0 (with phase_end, at most 1024 work items): when the phase is complete and the loop goes on, this launch also runs the top
+  // of the next iteration -- mode 1: activation window + propagation, 2: propagation -- and sets up its work items
+  // (kernels_pose.hip: iteration_begin_body); the caller then queues no launch_iteration_begin for that iteration
+  int next_mode = -1;
+  const uint8_t* in_window = nullptr;
+  const int* covis_offsets = nullptr;
+  const int* covis_indices = nullptr;
 };
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out,
@@ -174,9 +181,12 @@ void launch_pcg_update_cfactors(hipStream_t st, const Intrinsics& in, uint32_t s
 
 // kernels_lifecycle.hip
 void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, int h);
-void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup);
+void launch_lifecycle_bounds(hipStream_t st, const SurfelsView& s, uint32_t tiles, void* spheres);   // bounding spheres of tiles [0, tiles)
+// spheres / bounded_tiles: the batch's tile bounds (kernels_lifecycle.hip: LifecycleBounds), or nullptr / 0
+void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                              const void* spheres, uint32_t bounded_tiles);
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count);
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const void* spheres, uint32_t bounded_tiles);
 size_t create_padded_count(const Intrinsics& in);   // length of the tile-major flag / index vectors
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags);
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,

@@ -110,6 +110,11 @@ struct bahip_context {
   size_t window_capacity = 0;
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
   bool poll_disabled = false;        // the host copy of the pose counters is not updated by the kernel on this system: synchronise instead
+  // lifecycle batch (bahip_lifecycle_batch_begin): bounding spheres of the cloud's whole tiles, for the per-keyframe sweeps of a batch
+  void* dev_lifecycle_bounds = nullptr;
+  size_t lifecycle_bounds_capacity = 0;   // tiles
+  uint32_t lifecycle_bounds_tiles = 0;    // 0: no batch open
+  const void* lifecycle_bounds_data = nullptr;   // the surfel buffer they describe
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
   // heavy work first (wave_cull.h: scheduled_tile): candidates per tile counted by the first pose round of a phase over the
@@ -417,6 +422,8 @@ int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_work, const PoseWo
 // in the steady state of a BA loop a phase needs one or two rounds and costs one host reaction instead of one per round.
 // A round queued in vain costs two near-empty launches (and, sharded, an exchange of zeros); results do not depend on the batch
 // size (tests run 1, the default and 4).
+// the launch that ends a pose phase of the device-driven loop also sets up the next iteration (kernels_pose.hip: pose_solve_begin_kernel)
+int g_fused_iteration_begin = [] { const char* e = getenv("BAHIP_FUSED_ITERATION_BEGIN"); return e ? atoi(e) : 1; }();
 int g_pose_rounds_ahead = [] { const char* e = getenv("BAHIP_POSE_ROUNDS_AHEAD"); return e ? atoi(e) : 0; }();
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
@@ -660,7 +667,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   if (ctx->pinned_f) hipHostFree(ctx->pinned_f);
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
-  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_window);
+  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_lifecycle_bounds); hipFree(ctx->dev_window);
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl); hipFree(ctx->kf_partials);
   hipFree(ctx->dev_tile_cost); hipFree(ctx->dev_tile_order);
@@ -980,6 +987,7 @@ int bahip_update_surfel_normals(bahip_context* ctx, const bahip_surfels* surfels
 }
 
 int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels) {
+  ctx->lifecycle_bounds_tiles = 0;   // positions change or surfels move: a batch's tile bounds end here
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");   // B/kernel_opt_geometry.cc:91
   REQUIRE(surfels->active != nullptr, "geometry optimisation needs the active-surfel buffer");
@@ -997,6 +1005,7 @@ int bahip_optimize_geometry_iteration(bahip_context* ctx, int use_depth, int use
 
 int bahip_update_activation_and_optimize_geometry(bahip_context* ctx, int use_depth, int use_desc, const bahip_surfels* surfels,
                                                   uint32_t activation_surfels_size) {
+  ctx->lifecycle_bounds_tiles = 0;
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(use_depth || use_desc, "at least one residual type must be enabled");   // B/kernel_opt_geometry.cc:91
   REQUIRE(surfels->active != nullptr, "geometry optimisation needs the active-surfel buffer");
@@ -1126,6 +1135,7 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
                                  int* converged_out, int* pose_rounds_out, int* pose_steps_out, int* not_converged_out) {
   REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
   REQUIRE(opt != nullptr && handled_out != nullptr, "bahip_alternating_iterations: NULL argument");
+  ctx->lifecycle_bounds_tiles = 0;
   REQUIRE(opt->use_depth_residuals || opt->use_descriptor_residuals, "at least one residual type must be enabled");
   const int K = ctx->num_kfs;
   *handled_out = 0;
@@ -1157,7 +1167,16 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
   const int* csr = ctx->dev_covis_csr;
   static std::atomic<int> g_loop_sequence{1 << 30};   // disjoint from run_pose_rounds' numbers (which count up from 1)
   const uint32_t padded_tiles = pose_padded_tiles(sv.size);
-  int rounds_ahead = g_pose_rounds_ahead > 0 ? g_pose_rounds_ahead : std::max(1, std::min(ctx->rounds_hint_table, 4));
+  // Rounds queued per pose phase.  A phase right after something changed (a new keyframe, a loop closure) needs three or four
+  // Gauss-Newton rounds, the phases behind it fewer, the steady state one or two: the first phase queued here gets what the
+  // phases at the end of the previous call needed (rounds_hint_table) or what the phase handed to the host just took, every
+  // following phase one round less, down to the steady-state floor.  A round queued in vain costs two near-empty launches and
+  // their dependencies (~20 us, and an exchange of zeros when sharded); a phase with too few rounds costs one host reaction.
+  const bool rounds_forced = g_pose_rounds_ahead > 0;
+  int rounds_ahead = rounds_forced ? g_pose_rounds_ahead : std::max(1, std::min(ctx->rounds_hint_table, 4));
+  int rounds_floor = rounds_forced ? rounds_ahead : std::min(rounds_ahead, 2);
+  std::vector<int> queued_rounds;    // per queued iteration of the current batch
+  int last_needed[2] = {0, 0};       // rounds the last two completed phases needed
   int it = 0, done_before = 0;
   bool converged = false;
   while (it < opt->max_iterations) {
@@ -1169,10 +1188,17 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
     StageTimer& acc_timer = ctx->timers[2];
     const int acc_mark = acc_timer.used;
     int log_slot = 0, sequence = 0;
+    bool begun_by_previous = false;
+    queued_rounds.clear();
     for (int i = it; i < opt->max_iterations; ++i) {
+      const int phase_rounds = std::max(rounds_floor, rounds_ahead - (i - it));
+      queued_rounds.push_back(phase_rounds);
       // window / propagation (which closes iteration i - 1, B/direct_ba_alternating.cc:703-709) and the pose phase's work items
+      // (done already by the launch that ended iteration i - 1's pose phase when that launch could take it along: begun_by_previous)
       const int begin_mode = opt->fixed_window ? 1 : (i > 0 ? 2 : 0);
-      const bool begun = launch_iteration_begin(st, ctx->dev_kfs, K, begin_mode, ctx->dev_window, csr, csr + K + 1, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, stop);
+      const bool begun = begun_by_previous ||
+                         launch_iteration_begin(st, ctx->dev_kfs, K, begin_mode, ctx->dev_window, csr, csr + K + 1, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, stop);
+      begun_by_previous = false;
       if (!begun) {
         if (begin_mode == 1) launch_window_activation(st, ctx->dev_kfs, K, ctx->dev_window, csr, csr + K + 1, stop);
         else if (begin_mode == 2) launch_propagate_covisible(st, ctx->dev_kfs, K, csr, csr + K + 1, stop);
@@ -1183,7 +1209,7 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
       timer_end(ctx, 1);
       if (!begun) launch_pose_init_from_keyframes(st, ctx->dev_kfs, K, ctx->dev_work, ctx->dev_Hb, ctx->pinned_work, 0, 1, stop);
       CHECK_LAUNCH();
-      for (int r = 0; r < rounds_ahead; ++r) {
+      for (int r = 0; r < phase_rounds; ++r) {
         timer_begin(ctx, 2, false, 0);
         launch_pose_accumulate(st, use_depth, use_desc, ctx->in, ctx->dev_kfs, ctx->dev_work, K, sv, ctx->dev_Hb, ctx->dev_tile_bounds,
                                /*stored_bounds*/ r > 0, /*num_listed: upper bound*/ K, ctx->dev_tile_counters, &ctx->pose_parity,
@@ -1205,10 +1231,15 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
         if (reduce_over_ranks(ctx, ctx->dev_Hb, (size_t)K * kHbStride, BAHIP_SUM_I64)) return 1;
         PoseLoopControl loop;
         loop.ctl = ctx->dev_loop_ctl; loop.host_ctl = ctx->host_loop_ctl;
-        loop.phase_end = r == rounds_ahead - 1 ? 1 : 0;
+        loop.phase_end = r == phase_rounds - 1 ? 1 : 0;
         loop.iteration = i; loop.min_iterations = opt->min_iterations;
         loop.round_log = log_slot < kLoopLogSlots ? ctx->host_loop_ctl + kLoopWords : nullptr;
         loop.log_slot = log_slot++;
+        if (loop.phase_end && begun && g_fused_iteration_begin && K <= 1024 && i + 1 < opt->max_iterations) {
+          loop.next_mode = opt->fixed_window ? 1 : 2;
+          loop.in_window = ctx->dev_window; loop.covis_offsets = csr; loop.covis_indices = csr + K + 1;
+          begun_by_previous = true;
+        }
         timer_begin(ctx, 3, false);
         sequence = ++g_loop_sequence;
         launch_pose_solve(st, ctx->dev_work, K, ctx->dev_Hb, ctx->dev_kfs, /*write_back*/ 1, /*update_activation*/ 1, r, ctx->pinned_work, sequence, &loop);
@@ -1218,7 +1249,7 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
     }
     if (wait_for_pose_sequence(ctx, ctx->pinned_work, ctx->dev_work, K, sequence)) return 1;
     if (ctx->poll_disabled) HIP_TRY(hipMemcpy(ctx->host_loop_ctl, ctx->dev_loop_ctl, sizeof(int) * kLoopWords, hipMemcpyDeviceToHost));
-    if (counters[kPoseCounterInvalid])
+    if (counters[kPoseCounterInvalid] || ctx->host_loop_ctl[kLoopInvalid])
       return fail("pose normal equations: a tile total was not finite or reached 2^52 (hb_split), or a sum left the fixed-point range; the "
                   "surfels or images hold non-finite values", __FILE__, __LINE__);
     const int* ctl = ctx->host_loop_ctl;
@@ -1234,6 +1265,20 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
     }
     const int completed = ctl[kLoopIterationsDone] - done_before;
     done_before = ctl[kLoopIterationsDone];
+    // rounds the completed phases needed: the log holds the work items every queued round iterated
+    if (!ctx->poll_disabled) {
+      const int* log = ctl + kLoopWords;
+      int slot = 0;
+      for (int j = 0; j < completed && j < (int)queued_rounds.size(); ++j) {
+        int needed = 0;
+        for (int r = 0; r < queued_rounds[j] && slot + r < kLoopLogSlots; ++r) if (log[slot + r] > 0) needed = r + 1;
+        slot += queued_rounds[j];
+        if (slot > kLoopLogSlots) break;
+        last_needed[0] = last_needed[1];
+        last_needed[1] = std::max(1, needed);
+      }
+    }
+    const int handed_over_rounds = completed < (int)queued_rounds.size() ? queued_rounds[completed] : rounds_ahead;
     it += completed;
     if (ctl[kLoopStop] == 1) { converged = true; break; }
     if (ctl[kLoopStop] == 2) {
@@ -1242,12 +1287,16 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
       HIP_TRY(hipMemsetAsync(ctx->dev_loop_ctl + kLoopStop, 0, sizeof(int), st));
       PoseLoopControl totals;
       totals.ctl = ctx->dev_loop_ctl; totals.host_ctl = ctx->host_loop_ctl;
-      if (run_pose_rounds(ctx, use_depth, use_desc, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K, sv, 1, 1, ctx->pinned_work, nullptr,
-                          false, nullptr, rounds_ahead, counters[rounds_ahead - 1], &totals)) return 1;
+      int more_rounds = 0;
+      if (run_pose_rounds(ctx, use_depth, use_desc, ctx->dev_kfs, ctx->dev_kfs, ctx->dev_work, ctx->dev_Hb, K, sv, 1, 1, ctx->pinned_work, &more_rounds,
+                          false, nullptr, handed_over_rounds, counters[handed_over_rounds - 1], &totals)) return 1;
       const bool all_converged = counters[kPoseCounterConverged] == K;
       const bool ends_loop = it >= opt->min_iterations - 1 && all_converged;
       it += 1;
-      rounds_ahead = std::min(2 * rounds_ahead, 8);
+      last_needed[0] = last_needed[1];
+      last_needed[1] = handed_over_rounds + more_rounds;
+      // the next phase gets what this one took (it decays from there)
+      if (!rounds_forced) { rounds_ahead = std::max(1, std::min(handed_over_rounds + more_rounds, 8)); rounds_floor = std::min(rounds_ahead, 2); }
       if (ends_loop) { converged = true; break; }
       continue;
     }
@@ -1262,7 +1311,8 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
     if (activation_out) activation_out[k] = ctx->host_kfs[k].activation;
   }
   const int rounds_total = ctx->host_loop_ctl[kLoopRounds];
-  if (it > 0) ctx->rounds_hint_table = std::max(1, (rounds_total + it - 1) / it);
+  if (last_needed[1] > 0) ctx->rounds_hint_table = std::max(last_needed[0], last_needed[1]);
+  else if (it > 0) ctx->rounds_hint_table = std::max(1, (rounds_total + it - 1) / it);
   *handled_out = 1;
   if (iterations_done_out) *iterations_done_out = it;
   if (converged_out) *converged_out = converged ? 1 : 0;
@@ -1351,7 +1401,11 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
   if (merged_count_out) *merged_count_out = 0;
   if (surfels->surfels_size == 0) return 0;
   const SurfelsView s = make_view(surfels);
-  launch_supporting_insert(ctx->stream, ctx->in, e, s, sup);
+  // a batch's tile bounds hold for the buffer they were taken from, while it only grows
+  const bool bounded = ctx->lifecycle_bounds_tiles && ctx->lifecycle_bounds_data == surfels->data && (uint64_t)ctx->lifecycle_bounds_tiles * 64 <= s.size;
+  const void* spheres = bounded ? ctx->dev_lifecycle_bounds : nullptr;
+  const uint32_t bounded_tiles = bounded ? ctx->lifecycle_bounds_tiles : 0u;
+  launch_supporting_insert(ctx->stream, ctx->in, e, s, sup, spheres, bounded_tiles);
   CHECK_LAUNCH();
   if (merge) {
     const float cell = (float)ctx->in.cell;
@@ -1360,7 +1414,7 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
     uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
     if (merged_count_out) {
       HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
-      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter));
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter), spheres, bounded_tiles);
       CHECK_LAUNCH();
       HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1368,7 +1422,7 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
     } else {
       // deferred count: a batch of keyframes merges without a read-back and a stream synchronisation per keyframe; the total
       // waits in dev_counter[3] for bahip_take_merged_count
-      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3);
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3, spheres, bounded_tiles);
       CHECK_LAUNCH();
     }
   }
@@ -1386,6 +1440,31 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
   if (make_entry(ctx, *frame, 0, &e)) return 1;
   memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
   return determine_supporting_impl(ctx, merge, merge_dist_factor, e, surfels, sup, merged_count_out);
+}
+
+int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels) {
+  REQUIRE(surfels != nullptr, "bahip_lifecycle_batch_begin: NULL argument");
+  ctx->lifecycle_bounds_tiles = 0;
+  const uint32_t tiles = surfels->surfels_size / 64;   // whole tiles only: what is appended later starts in the tile behind them
+  if (tiles == 0) return 0;
+  if (tiles > ctx->lifecycle_bounds_capacity) {
+    void* grown = nullptr;
+    const size_t capacity = (size_t)tiles + tiles / 4 + 1024;
+    HIP_TRY(hipMalloc(&grown, capacity * 16));   // WaveBounds: four floats
+    hipFree(ctx->dev_lifecycle_bounds);
+    ctx->dev_lifecycle_bounds = grown;
+    ctx->lifecycle_bounds_capacity = capacity;
+  }
+  launch_lifecycle_bounds(ctx->stream, make_view(surfels), tiles, ctx->dev_lifecycle_bounds);
+  CHECK_LAUNCH();
+  ctx->lifecycle_bounds_tiles = tiles;
+  ctx->lifecycle_bounds_data = surfels->data;
+  return 0;
+}
+
+int bahip_lifecycle_batch_end(bahip_context* ctx) {
+  ctx->lifecycle_bounds_tiles = 0;
+  return 0;
 }
 
 int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out) {
@@ -1479,6 +1558,7 @@ int bahip_delete_surfels_and_update_radii(bahip_context* ctx, int min_observatio
 }
 
 int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip_surfels* surfels) {
+  ctx->lifecycle_bounds_tiles = 0;   // positions change or surfels move: a batch's tile bounds end here
   if (surfels->surfels_size == surfel_count) return 0;
   REQUIRE(surfel_count < surfels->surfels_size, "surfel_count larger than surfels_size");
   if (ensure_px(ctx, 1, surfels->capacity)) return 1;
@@ -1492,6 +1572,7 @@ int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip
 }
 
 int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfels, float grid_cell_size) {
+  ctx->lifecycle_bounds_tiles = 0;   // positions change or surfels move: a batch's tile bounds end here
   REQUIRE(grid_cell_size > 0.f, "grid_cell_size must be positive");
   const float inv_cell = 1.0f / grid_cell_size;
   HIP_TRY(sort_surfels_spatially(ctx->stream, make_view(surfels), inv_cell));
@@ -1995,6 +2076,11 @@ int bahip_debug_set_pose_lds_shape(int waves, int parts_shift) {
   set_pose_lds_parts_shift(parts_shift);
   return 0;
 }
+int bahip_debug_set_fused_iteration_begin(int enabled) {
+  g_fused_iteration_begin = enabled ? 1 : 0;
+  return 0;
+}
+
 int bahip_debug_set_pose_rounds_ahead(int rounds) {
   if (rounds < 0 || rounds > BAHIP_MAX_POSE_ITERATIONS) return fail("bahip_debug_set_pose_rounds_ahead: 0 .. BAHIP_MAX_POSE_ITERATIONS", __FILE__, __LINE__, hipSuccess);
   g_pose_rounds_ahead = rounds;

@@ -14,6 +14,7 @@
 
 #include "ba_device.h"
 #include "ba_launch.h"
+#include "wave_cull.h"
 
 namespace bahip {
 
@@ -30,11 +31,36 @@ supporting_fill_kernel(SupportingView sup, int width, int height) {
   for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) *pitched_ptr(sup.b[b], sup.pitch, y, x) = kInvalidIndex;
 }
 
+// A batch of keyframes sweeps the same cloud once per keyframe (creation) or twice (merging), and one keyframe sees a few percent
+// of it.  LifecycleBounds: bounding spheres of the 64-surfel tiles [0, tiles), taken once per batch (lifecycle_bounds_kernel);
+// a wavefront whose tile cannot project into the keyframe (wave_cull.h: sphere_may_project, the test of the BA sweeps) returns
+// before it loads a surfel.  The spheres stay valid through a batch: creation appends behind the bounded tiles, merging only
+// marks surfels deleted (a sphere then bounds a superset).  tiles == 0: no bounds, every wavefront sweeps.
+struct LifecycleBounds {
+  const WaveBounds* spheres;
+  uint32_t tiles;
+};
+__device__ __forceinline__ bool lifecycle_tile_culled(const Intrinsics& in, const KfEntry& frame, const LifecycleBounds& lb, uint32_t i) {
+  const uint32_t tile = i >> 6;   // wave-uniform: kLcBlock is a multiple of 64
+  if (tile >= lb.tiles) return false;
+  const WaveBounds wb = lb.spheres[tile];
+  return !sphere_may_project(in, frame.pose.F, wb);
+}
+__global__ void __launch_bounds__(kLcBlock)
+lifecycle_bounds_kernel(SurfelsView s, uint32_t tiles, WaveBounds* __restrict__ spheres) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if ((i >> 6) >= tiles) return;
+  const Vec3 gp = surfel_position(s, i);   // tiles are whole: i < s.size
+  const WaveBounds wb = wave_bounds(gp, gp.x == gp.x);
+  if ((threadIdx.x & 63) == 0) spheres[i >> 6] = wb;
+}
+
 // Phase A: every associated surfel offers its index to the cell's slot chain.
 __global__ void __launch_bounds__(kLcBlock)
-supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup) {
+supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, LifecycleBounds lb) {
   const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
   if (i >= s.size) return;
+  if (lifecycle_tile_culled(in, frame, lb, i)) return;
   Assoc r;
   if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
   const int cx = r.px / in.cell, cy = r.py / in.cell;
@@ -60,9 +86,10 @@ __device__ __forceinline__ bool merge_test(const SurfelsView& s, uint32_t a, uin
 // merge away.  flags: one u32 per surfel.
 __global__ void __launch_bounds__(kLcBlock)
 merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, float cell_merge_dist_sq,
-                    float cos_thr, uint32_t* __restrict__ flags) {
+                    float cos_thr, uint32_t* __restrict__ flags, LifecycleBounds lb) {
   const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
   if (i >= s.size) return;
+  if (lifecycle_tile_culled(in, frame, lb, i)) return;   // merge_apply_kernel skips the same tiles: their flags are never read
   flags[i] = 0;
   Assoc r;
   if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
@@ -88,9 +115,11 @@ merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView 
 }
 
 __global__ void __launch_bounds__(kLcBlock)
-merge_apply_kernel(SurfelsView s, const uint32_t* __restrict__ flags, uint32_t* __restrict__ deleted_count) {
+merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ flags, uint32_t* __restrict__ deleted_count,
+                   LifecycleBounds lb) {
   const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
-  const bool del = (i < s.size) && flags[i];
+  if (i >= s.size || lifecycle_tile_culled(in, frame, lb, i)) return;   // wave-uniform beyond the last tile's tail lanes (ballot below: active lanes)
+  const bool del = flags[i];
   if (del) s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits);
   const unsigned long long m = __ballot(del);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(deleted_count, (uint32_t)__popcll(m));
@@ -144,45 +173,81 @@ create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __
   if (claimed) *slot = 0;
 }
 
-// B/kernel_create_surfels.cu:213-276 + :314-337: outlier filter for new surfels, one thread per pixel.
+// B/kernel_create_surfels.cu:213-276 + :314-337: outlier filter for new surfels.
+//
+// One candidate pixel against one co-visible keyframe: bit 0 = an observation, bit 1 = a free-space violation.
+__device__ __forceinline__ uint32_t create_filter_pair(const Intrinsics& in, const KfEntry* __restrict__ kfs, const int* __restrict__ covis,
+                                                       const float* __restrict__ covis_T_frame, int c, const Vec3& input_pos, const Vec3& m) {
+  const KfEntry& ck = kfs[covis[c]];
+  const float* M = covis_T_frame + 12 * c;
+  Vec3 lp;
+  lp.z = M[8] * input_pos.x + M[9] * input_pos.y + M[10] * input_pos.z + M[11];
+  if (!(lp.z > 0.f)) return 0;
+  lp.x = M[0] * input_pos.x + M[1] * input_pos.y + M[2] * input_pos.z + M[3];
+  lp.y = M[4] * input_pos.x + M[5] * input_pos.y + M[6] * input_pos.z + M[7];
+  const float pxx = in.fx * (lp.x / lp.z) + in.cx, pxy = in.fy * (lp.y / lp.z) + in.cy;
+  if (!(pxx >= 0.f) || !(pxy >= 0.f) || !(pxx < (float)in.width) || !(pxy < (float)in.height)) return 0;
+  const int px = (int)pxx, py = (int)pxy;
+  // B/surfel_projection_nvcc_only.cuh:131-231
+  const uint16_t raw = pitched_load(ck.depth, ck.depth_pitch, py, px);
+  if (raw & kInvalidDepthBit) return 0;
+  const Vec3 nl = rotate34(M, m);
+  const float d = raw_to_calibrated_depth(in.a, cfactor_at(in, px, py), in.raw_to_float_depth, raw);
+  const float thr = 10.f * depth_stddev(unp_nx(in, (float)px), unp_ny(in, (float)py), d, nl, in.baseline_fx);
+  const float diff = d - lp.z;
+  if (diff > thr) return 2;
+  else if (diff < -thr) return 0;
+  if (dot3(lp, nl) > 0) return 0;   // sign of (1 / |p|) * dot(p, n), see project_associate
+  if (dot3(nl, unpack_normal8(pitched_load(ck.normals, ck.normals_pitch, py, px))) < kCosNormalCompat) return 0;
+  return 1;
+}
+
+// One lane per pixel cell.  Past the first keyframes of a scene most cells are supported by existing surfels and a wavefront
+// holds a handful of candidates: a lane-per-candidate loop over the co-visible keyframes then runs at 1-2 lanes in 64 and is a
+// chain of dependent gathers (79 us per keyframe at the bench scene, round 4 trace).  With few candidates the wavefront takes
+// them one at a time and spreads the co-visible keyframes over its lanes; the two counts are integers, so both shapes decide
+// alike.
 __global__ void __launch_bounds__(kLcBlock)
 create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ kfs, const int* __restrict__ covis,
                      const float* __restrict__ covis_T_frame /* 12 floats each */, int n_covis,
                      int min_observation_count, int padded_count, uint8_t* __restrict__ flags) {
   const int idx = blockIdx.x * kLcBlock + threadIdx.x;
-  if (idx >= padded_count) return;
-  if (!flags[idx]) return;
-  int x, y;
-  if (!tile_xy(in, (size_t)idx, &x, &y)) return;
-  uint32_t observations = 1, violations = 0;
-  const float cd = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y), in.raw_to_float_depth, pitched_load(frame.depth, frame.depth_pitch, y, x));
-  const Vec3 input_pos = unproject(in, x, y, cd);
-  const Vec3 m = unpack_normal8(pitched_load(frame.normals, frame.normals_pitch, y, x));
-  for (int c = 0; c < n_covis; ++c) {
-    const KfEntry& ck = kfs[covis[c]];
-    const float* M = covis_T_frame + 12 * c;
-    Vec3 lp;
-    lp.z = M[8] * input_pos.x + M[9] * input_pos.y + M[10] * input_pos.z + M[11];
-    if (!(lp.z > 0.f)) continue;
-    lp.x = M[0] * input_pos.x + M[1] * input_pos.y + M[2] * input_pos.z + M[3];
-    lp.y = M[4] * input_pos.x + M[5] * input_pos.y + M[6] * input_pos.z + M[7];
-    const float pxx = in.fx * (lp.x / lp.z) + in.cx, pxy = in.fy * (lp.y / lp.z) + in.cy;
-    if (!(pxx >= 0.f) || !(pxy >= 0.f) || !(pxx < (float)in.width) || !(pxy < (float)in.height)) continue;
-    const int px = (int)pxx, py = (int)pxy;
-    // B/surfel_projection_nvcc_only.cuh:131-231
-    const uint16_t raw = pitched_load(ck.depth, ck.depth_pitch, py, px);
-    if (raw & kInvalidDepthBit) continue;
-    const Vec3 nl = rotate34(M, m);
-    const float d = raw_to_calibrated_depth(in.a, cfactor_at(in, px, py), in.raw_to_float_depth, raw);
-    const float thr = 10.f * depth_stddev(unp_nx(in, (float)px), unp_ny(in, (float)py), d, nl, in.baseline_fx);
-    const float diff = d - lp.z;
-    if (diff > thr) { violations += 1; continue; }
-    else if (diff < -thr) continue;
-    if (dot3(lp, nl) > 0) continue;   // sign of (1 / |p|) * dot(p, n), see project_associate
-    if (dot3(nl, unpack_normal8(pitched_load(ck.normals, ck.normals_pitch, py, px))) < kCosNormalCompat) continue;
-    observations += 1;
+  const int lane = threadIdx.x & 63;
+  int x = 0, y = 0;
+  const bool candidate = idx < padded_count && flags[idx] && tile_xy(in, (size_t)idx, &x, &y);
+  unsigned long long todo = __ballot(candidate);
+  if (!todo) return;
+  Vec3 input_pos = mk3(0, 0, 0), m = mk3(0, 0, 0);
+  if (candidate) {
+    const float cd = raw_to_calibrated_depth(in.a, cfactor_at(in, x, y), in.raw_to_float_depth, pitched_load(frame.depth, frame.depth_pitch, y, x));
+    input_pos = unproject(in, x, y, cd);
+    m = unpack_normal8(pitched_load(frame.normals, frame.normals_pitch, y, x));
   }
-  if (observations < (uint32_t)min_observation_count || violations > observations) flags[idx] = 0;
+  uint32_t observations = 1, violations = 0;
+  const int passes = (n_covis + 63) >> 6;
+  if (__popcll(todo) * passes < n_covis) {
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      Vec3 cp, cm;
+      cp.x = __shfl(input_pos.x, src); cp.y = __shfl(input_pos.y, src); cp.z = __shfl(input_pos.z, src);
+      cm.x = __shfl(m.x, src); cm.y = __shfl(m.y, src); cm.z = __shfl(m.z, src);
+      uint32_t obs = 0, vio = 0;
+      for (int c = lane; c < passes * 64; c += 64) {
+        const uint32_t r = c < n_covis ? create_filter_pair(in, kfs, covis, covis_T_frame, c, cp, cm) : 0u;
+        obs += (uint32_t)__popcll(__ballot(r & 1u));
+        vio += (uint32_t)__popcll(__ballot(r & 2u));
+      }
+      if (lane == src) { observations += obs; violations += vio; }
+    }
+  } else if (candidate) {
+    for (int c = 0; c < n_covis; ++c) {
+      const uint32_t r = create_filter_pair(in, kfs, covis, covis_T_frame, c, input_pos, m);
+      observations += r & 1u;
+      violations += r >> 1;
+    }
+  }
+  if (candidate && (observations < (uint32_t)min_observation_count || violations > observations)) flags[idx] = 0;
 }
 
 // B/kernel_create_surfels.cu:91-160,357-390
@@ -312,14 +377,20 @@ static inline unsigned g1(uint32_t n) { return (n + kLcBlock - 1) / kLcBlock; }
 void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, int h) {
   hipLaunchKernelGGL(supporting_fill_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(kLcBlock), 0, st, sup, w, h);
 }
-void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup) {
-  if (s.size) hipLaunchKernelGGL(supporting_insert_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup);
+void launch_lifecycle_bounds(hipStream_t st, const SurfelsView& s, uint32_t tiles, void* spheres) {
+  if (tiles) hipLaunchKernelGGL(lifecycle_bounds_kernel, dim3(g1(tiles * 64u)), dim3(kLcBlock), 0, st, s, tiles, static_cast<WaveBounds*>(spheres));
+}
+void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                              const void* spheres, uint32_t bounded_tiles) {
+  const LifecycleBounds lb{static_cast<const WaveBounds*>(spheres), spheres ? bounded_tiles : 0u};
+  if (s.size) hipLaunchKernelGGL(supporting_insert_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, lb);
 }
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count) {
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const void* spheres, uint32_t bounded_tiles) {
   if (!s.size) return;
-  hipLaunchKernelGGL(merge_decide_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags);
-  hipLaunchKernelGGL(merge_apply_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, flags, deleted_count);
+  const LifecycleBounds lb{static_cast<const WaveBounds*>(spheres), spheres ? bounded_tiles : 0u};
+  hipLaunchKernelGGL(merge_decide_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, lb);
+  hipLaunchKernelGGL(merge_apply_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, flags, deleted_count, lb);
 }
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags) {
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags);

@@ -446,36 +446,78 @@ __device__ __forceinline__ bool is_scale1_pose_converged(const float* x) {
 
 // LDLT with symmetric diagonal pivoting + pseudo-inverse rule on D, binary64 (what Eigen's
 // H.cast<double>().selfadjointView<Upper>().ldlt().solve(b) does, B/direct_ba_alternating.cc:206).
+// Every index below is a compile-time constant once the loops are unrolled -- the pivot search and the row / column / perm
+// exchanges are selects over the candidates, not dynamically indexed accesses -- so the 36 + 6 + 6 binary64 values live in
+// registers: with dynamic indices they lived in scratch memory and one step of 200 keyframes took 24 us, most of it the
+// latency of dependent scratch accesses (round 4 trace, profiles/r4_emu8_timeline.txt).  Same operations on the same values in
+// the same order as the loop form (which the oracle restates, oracle_pose.c), only where the values are kept differs.
 template <int N>
-__device__ void ldlt_solve(double* A, const double* b, double* x) {
+__device__ __forceinline__ void ldlt_solve(double (&A)[N * N], const double (&b)[N], double (&x)[N]) {
+  constexpr double kTiny = 2.2250738585072014e-308;
   int perm[N];
+#pragma unroll
   for (int c = 0; c < N; ++c) perm[c] = c;
+#pragma unroll
   for (int k = 0; k < N; ++k) {
-    int piv = k; double best = fabs(A[k * N + k]);
-    for (int c = k + 1; c < N; ++c) if (fabs(A[c * N + c]) > best) { best = fabs(A[c * N + c]); piv = c; }
-    if (piv != k) {
-      for (int j = 0; j < N; ++j) { const double t = A[k * N + j]; A[k * N + j] = A[piv * N + j]; A[piv * N + j] = t; }
-      for (int j = 0; j < N; ++j) { const double t = A[j * N + k]; A[j * N + k] = A[j * N + piv]; A[j * N + piv] = t; }
-      const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    int piv = k;
+    double best = fabs(A[k * N + k]);
+#pragma unroll
+    for (int c = k + 1; c < N; ++c) {
+      const double v = fabs(A[c * N + c]);
+      const bool better = v > best;
+      best = better ? v : best;
+      piv = better ? c : piv;
+    }
+#pragma unroll
+    for (int c = k + 1; c < N; ++c) {
+      const bool exchange = piv == c;   // true for at most one c: rows, then columns, then perm, as the loop form
+#pragma unroll
+      for (int j = 0; j < N; ++j) { const double t = A[k * N + j], u = A[c * N + j]; A[k * N + j] = exchange ? u : t; A[c * N + j] = exchange ? t : u; }
+#pragma unroll
+      for (int j = 0; j < N; ++j) { const double t = A[j * N + k], u = A[j * N + c]; A[j * N + k] = exchange ? u : t; A[j * N + c] = exchange ? t : u; }
+      const int tp = perm[k], up = perm[c];
+      perm[k] = exchange ? up : tp;
+      perm[c] = exchange ? tp : up;
     }
     const double d = A[k * N + k];
-    if (fabs(d) > 2.2250738585072014e-308) {
+    if (fabs(d) > kTiny) {
+#pragma unroll
       for (int c = k + 1; c < N; ++c) A[c * N + k] /= d;
+#pragma unroll
       for (int c = k + 1; c < N; ++c)
+#pragma unroll
         for (int j = k + 1; j <= c; ++j) {
           A[c * N + j] -= A[c * N + k] * d * A[j * N + k];
           A[j * N + c] = A[c * N + j];
         }
     } else {
+#pragma unroll
       for (int c = k + 1; c < N; ++c) A[c * N + k] = 0;
     }
   }
   double y[N];
-  for (int c = 0; c < N; ++c) y[c] = b[perm[c]];
-  for (int c = 0; c < N; ++c) for (int j = 0; j < c; ++j) y[c] -= A[c * N + j] * y[j];
-  for (int c = 0; c < N; ++c) { const double d = A[c * N + c]; y[c] = (fabs(d) > 2.2250738585072014e-308) ? y[c] / d : 0.0; }
-  for (int c = N - 1; c >= 0; --c) for (int j = c + 1; j < N; ++j) y[c] -= A[j * N + c] * y[j];
-  for (int c = 0; c < N; ++c) x[perm[c]] = y[c];
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    y[c] = b[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) y[c] = perm[c] == j ? b[j] : y[c];
+  }
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int j = 0; j < c; ++j) y[c] -= A[c * N + j] * y[j];
+#pragma unroll
+  for (int c = 0; c < N; ++c) { const double d = A[c * N + c]; y[c] = (fabs(d) > kTiny) ? y[c] / d : 0.0; }
+#pragma unroll
+  for (int c = N - 1; c >= 0; --c)
+#pragma unroll
+    for (int j = c + 1; j < N; ++j) y[c] -= A[j * N + c] * y[j];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    x[j] = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) x[j] = perm[c] == j ? y[c] : x[j];
+  }
 }
 
 // One Gauss-Newton update of a pose: B/direct_ba_alternating.cc:173-244.  hb = H (21, row-major upper triangle) and b (6) in
@@ -484,8 +526,11 @@ __device__ void ldlt_solve(double* A, const double* b, double* x) {
 __device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* T_next) {
   double A[36], b[6], x[6];
   int q = 0;
+#pragma unroll
   for (int row = 0; row < 6; ++row)
+#pragma unroll
     for (int col = row; col < 6; ++col) { const double v = (double)hb[q]; A[row * 6 + col] = v; A[col * 6 + row] = v; ++q; }
+#pragma unroll
   for (int c = 0; c < 6; ++c) b[c] = (double)hb[21 + c];
   ldlt_solve<6>(A, b, x);
   float mx[6];
@@ -495,6 +540,73 @@ __device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* 
   se3_mul(T, upd, T_next);
 }
 
+// The top of an iteration of the device-driven loop in ONE launch (num_kfs <= 1024): the activation window with its co-visible
+// propagation (mode 1), or the propagation that closes the previous iteration (mode 2), or neither (mode 0) -- then the work
+// items of the pose phase (pose_init_from_keyframes_kernel).  Geometry, which runs between this and the pose rounds, touches
+// neither the work items nor the activations, so the phase's items can be set up before it: one launch and one launch gap less
+// per iteration than window kernel + init kernel.
+// (A workgroup of 1024 threads runs the body: the kernel below, or the last solve launch of the previous iteration's pose phase,
+// pose_solve_begin_kernel.)
+__device__ __forceinline__ void iteration_begin_body(KfEntry* __restrict__ frames, int num_kfs, int mode, const uint8_t* __restrict__ in_window,
+                                                     const int* __restrict__ offsets, const int* __restrict__ indices, PoseWork* __restrict__ work,
+                                                     HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out) {
+  const int k = threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (mode == 1) {
+    const bool inside = k < num_kfs && in_window[k];
+    if (k < num_kfs) frames[k].activation = inside ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
+    if (__syncthreads_count(inside ? 1 : 0) != num_kfs) {        // (workgroup-uniform) a window that holds every keyframe leaves nothing to wake up
+      for (int row = wave; row < num_kfs; row += 16) {
+        if (!in_window[row]) continue;
+        for (int j = offsets[row] + lane; j < offsets[row + 1]; j += 64) {
+          const int other = indices[j];
+          if (!in_window[other]) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
+        }
+      }
+    }
+  } else if (mode == 2) {
+    // sources are the keyframes that are kActive NOW; a write only turns kInactive into kCovisibleActive (never a source)
+    const bool source = k < num_kfs && frames[k].activation == BAHIP_KF_ACTIVE;
+    __shared__ uint8_t is_source[1024];
+    is_source[k] = source ? 1 : 0;
+    __syncthreads();
+    for (int row = wave; row < num_kfs; row += 16) {
+      if (!is_source[row]) continue;
+      for (int j = offsets[row] + lane; j < offsets[row + 1]; j += 64) {
+        const int other = indices[j];
+        if (!is_source[other] && frames[other].activation == BAHIP_KF_INACTIVE) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
+      }
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  const bool in_range = k < num_kfs;
+  const bool inactive = in_range && __hip_atomic_load(&frames[k].activation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == BAHIP_KF_INACTIVE;
+  if (in_range) {
+    PoseWork& pw = work[k];
+    pw.kf_index = k;
+    pw.iterations = 0;
+    pw.converged = 0;
+    pw.done = inactive ? 1 : 0;
+    pw.skip = inactive ? 1 : 0;
+    pw.moved = 0;
+    for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
+    for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
+    for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
+    if (pw.done) host_out[k] = pw;
+  }
+  int* counters = reinterpret_cast<int*>(work + num_kfs);
+  const int num_inactive = __syncthreads_count(inactive ? 1 : 0);
+  if (threadIdx.x < kPoseTailRecords * 32) counters[threadIdx.x] = (threadIdx.x == kPoseCounterConverged) ? num_inactive : 0;
+}
+__global__ void __launch_bounds__(1024)
+iteration_begin_kernel(KfEntry* __restrict__ frames, int num_kfs, int mode, const uint8_t* __restrict__ in_window, const int* __restrict__ offsets,
+                       const int* __restrict__ indices, PoseWork* __restrict__ work, HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out,
+                       const int* __restrict__ stop) {
+  if (stop && load_global(stop) != 0) return;
+  iteration_begin_body(frames, num_kfs, mode, in_window, offsets, indices, work, Hb, host_out);
+}
+
 // `round`: the Gauss-Newton round this launch closes (its not-done count goes to counter [round]).  update_activation: when
 // a work item is done, the activation update of B/direct_ba_alternating.cc:556-577 is applied to its keyframe right here:
 // moved (the logarithm of old^-1 * new fails the convergence test) -> kActive, else kInactive and one more converged keyframe.
@@ -502,9 +614,15 @@ __device__ void pose_gn_step(const float* hb, const float* T, float* xf, float* 
 // next iteration's sweeps can be queued while the host is still copying the results into its Keyframe objects.
 // host_out: page-locked host memory mapped into the device (zero-copy): a work item that is done writes its final record there,
 // so the host needs no copy of the work array, only the 256 bytes of counters per round.
-__global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
-                                  KfEntry* __restrict__ frames, int write_back, int update_activation, int round,
-                                  PoseWork* __restrict__ host_out, int sequence, PoseLoopControl loop) {
+//
+// kBeginsNext (one workgroup of 1024 threads, num_work <= 1024): the launch that ends a pose phase of the device-driven loop also
+// does what the top of the next iteration would do in a launch of its own (iteration_begin_body) -- when the phase is complete and
+// the loop goes on.  One launch and one launch dependency less per BA iteration (~15 us; a tenth of an iteration at an eighth of
+// the cloud).
+template <bool kBeginsNext>
+__device__ __forceinline__ void pose_solve_body(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
+                                                KfEntry* __restrict__ frames, int write_back, int update_activation, int round,
+                                                PoseWork* __restrict__ host_out, int sequence, const PoseLoopControl& loop) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   int* counters = reinterpret_cast<int*>(work + num_work);
   // device-driven BA loop: once the loop has stopped, the launches queued behind do no work -- but still publish their
@@ -518,6 +636,7 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
     float hb[27];
     // the fixed-point totals are rounded to binary32 first, so H and b are what bahip_accumulate_pose_estimation_coeffs returns
     bool out_of_range = false;
+#pragma unroll
     for (int c = 0; c < 27; ++c) {
       const HbFixed hi = fixed[c * kHbLimbs + 1];
       out_of_range = out_of_range || hi >= kHbSumLimit || hi <= -kHbSumLimit;
@@ -569,11 +688,13 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
   }
   __threadfence_system();
   __syncthreads();
-  __shared__ int is_last;
-  if (threadIdx.x == 0) is_last = atomicAdd(&counters[kPoseCounterTicket], 1) == (int)gridDim.x - 1;
+  __shared__ int is_last, begins_next;
+  if (threadIdx.x == 0) { is_last = atomicAdd(&counters[kPoseCounterTicket], 1) == (int)gridDim.x - 1; begins_next = 0; }
   __syncthreads();
   if (is_last) {   // workgroup-uniform; 64 threads = the 64 counter words
     if (loop.ctl && threadIdx.x == 0) {
+      // (sticky over the loop: the next phase's work-item set-up clears the counter words)
+      if (__hip_atomic_load(&counters[kPoseCounterInvalid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&loop.ctl[kLoopInvalid], 1);
       // what this round did, and -- at the end of a phase -- whether the loop goes on (B/direct_ba_alternating.cc:693-701)
       const int worked = __hip_atomic_load(&counters[kPoseCounterWorked], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       counters[kPoseCounterWorked] = 0;
@@ -588,6 +709,8 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
           const int converged = __hip_atomic_load(&counters[kPoseCounterConverged], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (loop.iteration >= loop.min_iterations - 1 && converged == num_work)
             __hip_atomic_store(&loop.ctl[kLoopStop], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else if (kBeginsNext && loop.next_mode >= 0)
+            begins_next = 1;
         }
       }
       for (int c = 0; c < kLoopWords; ++c) loop.host_ctl[c] = __hip_atomic_load(&loop.ctl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -599,11 +722,30 @@ __global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbF
       host_counters[c] = __hip_atomic_load(&counters[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) {
-      counters[kPoseCounterTicket] = 0;
-      __hip_atomic_store(&host_counters[kPoseCounterSequence], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) counters[kPoseCounterTicket] = 0;
+    if (kBeginsNext) {
+      // the host copy of this phase's counters is out; the work items of the next phase (and its counter words) are set up
+      // before the sequence number says that this launch is complete
+      if (begins_next) {   // workgroup-uniform (read after the barrier above)
+        iteration_begin_body(frames, num_work, loop.next_mode, loop.in_window, loop.covis_offsets, loop.covis_indices, work, Hb, host_out);
+        __threadfence_system();
+        __syncthreads();
+      }
     }
+    if (threadIdx.x == 0) __hip_atomic_store(&host_counters[kPoseCounterSequence], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+__global__ void pose_solve_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
+                                  KfEntry* __restrict__ frames, int write_back, int update_activation, int round,
+                                  PoseWork* __restrict__ host_out, int sequence, PoseLoopControl loop) {
+  pose_solve_body<false>(work, num_work, Hb, frames, write_back, update_activation, round, host_out, sequence, loop);
+}
+__global__ void __launch_bounds__(1024)
+pose_solve_begin_kernel(PoseWork* __restrict__ work, int num_work, HbFixed* __restrict__ Hb,
+                        KfEntry* __restrict__ frames, int write_back, int update_activation, int round,
+                        PoseWork* __restrict__ host_out, int sequence, PoseLoopControl loop) {
+  pose_solve_body<true>(work, num_work, Hb, frames, write_back, update_activation, round, host_out, sequence, loop);
 }
 
 // Test hook: pose_gn_step on explicit inputs.  in = hb[27] | T[7]; out = x[6] | T_next[7] | frame_T_global of T_next [12].
@@ -708,65 +850,6 @@ __global__ void __launch_bounds__(1024) window_and_propagate_kernel(KfEntry* __r
   }
 }
 
-// The top of an iteration of the device-driven loop in ONE launch (num_kfs <= 1024): the activation window with its co-visible
-// propagation (mode 1), or the propagation that closes the previous iteration (mode 2), or neither (mode 0) -- then the work
-// items of the pose phase (pose_init_from_keyframes_kernel).  Geometry, which runs between this and the pose rounds, touches
-// neither the work items nor the activations, so the phase's items can be set up before it: one launch and one launch gap less
-// per iteration than window kernel + init kernel.
-__global__ void __launch_bounds__(1024)
-iteration_begin_kernel(KfEntry* __restrict__ frames, int num_kfs, int mode, const uint8_t* __restrict__ in_window, const int* __restrict__ offsets,
-                       const int* __restrict__ indices, PoseWork* __restrict__ work, HbFixed* __restrict__ Hb, PoseWork* __restrict__ host_out,
-                       const int* __restrict__ stop) {
-  if (stop && load_global(stop) != 0) return;
-  const int k = threadIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (mode == 1) {
-    const bool inside = k < num_kfs && in_window[k];
-    if (k < num_kfs) frames[k].activation = inside ? BAHIP_KF_ACTIVE : BAHIP_KF_INACTIVE;
-    if (__syncthreads_count(inside ? 1 : 0) != num_kfs) {        // (workgroup-uniform) a window that holds every keyframe leaves nothing to wake up
-      for (int row = wave; row < num_kfs; row += 16) {
-        if (!in_window[row]) continue;
-        for (int j = offsets[row] + lane; j < offsets[row + 1]; j += 64) {
-          const int other = indices[j];
-          if (!in_window[other]) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
-        }
-      }
-    }
-  } else if (mode == 2) {
-    // sources are the keyframes that are kActive NOW; a write only turns kInactive into kCovisibleActive (never a source)
-    const bool source = k < num_kfs && frames[k].activation == BAHIP_KF_ACTIVE;
-    __shared__ uint8_t is_source[1024];
-    is_source[k] = source ? 1 : 0;
-    __syncthreads();
-    for (int row = wave; row < num_kfs; row += 16) {
-      if (!is_source[row]) continue;
-      for (int j = offsets[row] + lane; j < offsets[row + 1]; j += 64) {
-        const int other = indices[j];
-        if (!is_source[other] && frames[other].activation == BAHIP_KF_INACTIVE) frames[other].activation = BAHIP_KF_COVISIBLE_ACTIVE;
-      }
-    }
-  }
-  __threadfence();
-  __syncthreads();
-  const bool in_range = k < num_kfs;
-  const bool inactive = in_range && __hip_atomic_load(&frames[k].activation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == BAHIP_KF_INACTIVE;
-  if (in_range) {
-    PoseWork& pw = work[k];
-    pw.kf_index = k;
-    pw.iterations = 0;
-    pw.converged = 0;
-    pw.done = inactive ? 1 : 0;
-    pw.skip = inactive ? 1 : 0;
-    pw.moved = 0;
-    for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
-    for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
-    for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
-    if (pw.done) host_out[k] = pw;
-  }
-  int* counters = reinterpret_cast<int*>(work + num_kfs);
-  const int num_inactive = __syncthreads_count(inactive ? 1 : 0);
-  if (threadIdx.x < kPoseTailRecords * 32) counters[threadIdx.x] = (threadIdx.x == kPoseCounterConverged) ? num_inactive : 0;
-}
 bool launch_iteration_begin(hipStream_t stream, KfEntry* frames, int num_kfs, int mode, const uint8_t* in_window, const int* offsets, const int* indices,
                             void* work, HbFixed* Hb, void* host_out, const int* stop) {
   if (num_kfs == 0 || num_kfs > 1024) return false;
@@ -1060,9 +1143,15 @@ uint32_t pose_padded_tiles(uint32_t surfels) { return xcd_padded_tiles((surfels 
 void launch_pose_solve(hipStream_t stream, void* work, int num_work, HbFixed* Hb, KfEntry* frames, int write_back,
                        int update_activation, int round, void* host_out, int sequence, const PoseLoopControl* loop) {
   if (num_work == 0) return;
+  if (loop && loop->next_mode >= 0 && num_work <= 1024) {
+    hipLaunchKernelGGL(pose_solve_begin_kernel, dim3(1), dim3(1024), 0, stream, static_cast<PoseWork*>(work),
+                       num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out), sequence, *loop);
+    return;
+  }
+  PoseLoopControl plain = loop ? *loop : PoseLoopControl{};
+  plain.next_mode = -1;
   hipLaunchKernelGGL(pose_solve_kernel, dim3((num_work + 63) / 64), dim3(64), 0, stream, static_cast<PoseWork*>(work),
-                     num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out), sequence,
-                     loop ? *loop : PoseLoopControl{});
+                     num_work, Hb, frames, write_back, update_activation, round, static_cast<PoseWork*>(host_out), sequence, plain);
 }
 
 void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, int num_kfs, void* work, HbFixed* Hb, void* host_out,

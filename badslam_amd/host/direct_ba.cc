@@ -293,6 +293,13 @@ void DirectBA::MergeForKeyframe(const Keyframe& keyframe, bool defer_count) {
   surfel_count_ -= merged;
 }
 
+// Tile bounds for the per-keyframe sweeps of a batch (include/badslam_hip.h: bahip_lifecycle_batch_begin).
+DirectBA::LifecycleBatch::LifecycleBatch(DirectBA* ba) : ba_(ba) {
+  const bahip_surfels s = ba_->SurfelsStruct();
+  BAHIP_CHECKED_CALL(bahip_lifecycle_batch_begin(ba_->ctx_, &s));
+}
+DirectBA::LifecycleBatch::~LifecycleBatch() { bahip_lifecycle_batch_end(ba_->ctx_); }
+
 // The merges of a batch of keyframes run back to back on the stream; their total is read once, before the compaction that needs it
 // (the reference reads one count per keyframe, B/direct_ba.cc:618-622 -- the buffer contents are the same either way).
 void DirectBA::TakeDeferredMergeCount() {
@@ -360,11 +367,13 @@ void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_update
   WholeCloudScope whole_cloud(this, stream);
   BindScene(stream);
   if (do_surfel_updates) {
+    std::unique_ptr<LifecycleBatch> batch(new LifecycleBatch(this));
     for (shared_ptr<Keyframe>& keyframe : keyframes_) {
       if (!keyframe) continue;
       if (keyframe->last_active_in_ba_iteration() == ba_iteration_count_) MergeForKeyframe(*keyframe, /*defer_count*/ true);
     }
     TakeDeferredMergeCount();
+    batch.reset();
   }
   const bahip_surfels s = SurfelsStruct();
   uint32_t deleted = 0;
@@ -538,6 +547,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         apply_pending();
         BindScene(stream);                           // ... and one binding
         creation_batch_bound_ = true;
+        LifecycleBatch batch(this);
         for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
         creation_batch_bound_ = false;
       }
@@ -585,9 +595,12 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     // --- surfel merge + compaction ---
     if (do_surfel_updates && !keyframes_with_new_surfels.empty()) {
       WholeCloudScope whole_cloud(this, stream);
-      for (u32 keyframe_id : keyframes_with_new_surfels)
-        if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
-      TakeDeferredMergeCount();
+      {
+        LifecycleBatch batch(this);
+        for (u32 keyframe_id : keyframes_with_new_surfels)
+          if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
+        TakeDeferredMergeCount();
+      }
       {
         const bahip_surfels s = SurfelsStruct();
         unsorted_surfels_ += surfels_size_ - surfel_count_;
@@ -715,9 +728,12 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
   auto merge_and_compact = [&]() {
     if (keyframes_with_new_surfels.empty()) return;
     WholeCloudScope whole_cloud(this, stream);
-    for (u32 keyframe_id : keyframes_with_new_surfels)
-      if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
-    TakeDeferredMergeCount();
+    {
+      LifecycleBatch batch(this);
+      for (u32 keyframe_id : keyframes_with_new_surfels)
+        if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
+      TakeDeferredMergeCount();
+    }
     if (!keyframes_with_new_surfels.empty()) {
       const bahip_surfels s = SurfelsStruct();
       unsorted_surfels_ += surfels_size_ - surfel_count_;
@@ -737,6 +753,7 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       std::unique_ptr<WholeCloudScope> whole_cloud(any_new ? new WholeCloudScope(this, stream) : nullptr);   // one gather for the batch
       if (any_new) BindScene(stream);                                                                          // ... and one binding
       creation_batch_bound_ = any_new;
+      std::unique_ptr<LifecycleBatch> batch(any_new ? new LifecycleBatch(this) : nullptr);
       for (shared_ptr<Keyframe>& keyframe : keyframes_) {
         if (keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != ba_iteration_count_) {
           keyframe->SetLastActiveInBAIteration(ba_iteration_count_);

@@ -174,6 +174,15 @@ class DirectBA {
 
   void MergeForKeyframe(const Keyframe& keyframe, bool defer_count = false);
   void TakeDeferredMergeCount();
+  class LifecycleBatch {   // RAII: bahip_lifecycle_batch_begin / _end around the creations or merges of a batch of keyframes
+   public:
+    explicit LifecycleBatch(DirectBA* ba);
+    ~LifecycleBatch();
+    LifecycleBatch(const LifecycleBatch&) = delete;
+    LifecycleBatch& operator=(const LifecycleBatch&) = delete;
+   private:
+    DirectBA* ba_;
+  };
   bool creation_batch_bound_ = false;
   // Whole-cloud phases under surfel sharding (no-ops without it); they nest, only the outermost pair moves data.
   void EnterWholeCloud(hipStream_t stream);

@@ -3,6 +3,7 @@ image sets and a context object.  Used by the kernel-level parity tests and by t
 DirectBA-level API lives in the C++ host library (badslam_amd/host) and its binding
 (badslam_amd.directba).  No arithmetic happens here and nothing falls back to the CPU.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -178,6 +179,16 @@ class Scene:
         self.surfels_size += n.value
         self.surfel_count += n.value
         return n.value
+
+    @contextlib.contextmanager
+    def lifecycle_batch(self):
+        """bahip_lifecycle_batch_begin / _end around the creations or merges of a batch of keyframes."""
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_lifecycle_batch_begin(self.ctx.handle, C.byref(s)))
+        try:
+            yield
+        finally:
+            capi.check(self.lib.bahip_lifecycle_batch_end(self.ctx.handle))
 
     def determine_supporting_surfels(self, i, frame_T_global, merge=False, merge_dist_factor=0.8):
         """DetermineSupportingSurfels[AndMergeSurfels]CUDA for keyframe i; returns (the three supporting planes restricted to

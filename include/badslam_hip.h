@@ -312,6 +312,15 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
  * synchronisation per keyframe; the surfels merged by all such calls since the last bahip_take_merged_count are returned (and
  * the counter cleared) here -- one synchronisation per batch of keyframes instead of one per keyframe. */
 int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out);
+/* A batch of keyframes creating or merging surfels on one cloud (the BA loop's creation pass, its merge pass, the merges of the
+ * end tasks): bahip_lifecycle_batch_begin takes the bounding spheres of the cloud's 64-surfel tiles once; until
+ * bahip_lifecycle_batch_end the per-keyframe sweeps of bahip_determine_supporting_surfels / bahip_create_surfels_for_keyframe over
+ * the same buffer skip, per wavefront, the tiles the keyframe cannot see.  Results do not depend on the bracket (the test is the
+ * conservative one of the BA sweeps); surfels may be appended and marked deleted inside it, not moved: compaction, the spatial
+ * sort and the geometry step end the batch by themselves.  Ours: the reference sweeps the whole cloud per keyframe
+ * (B/kernel_supporting_surfels.cu:36-60). */
+int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels);
+int bahip_lifecycle_batch_end(bahip_context* ctx);
 /* B/kernels.h CreateSurfelsForKeyframeCUDA (B/kernel_create_surfels.cc:40-183), including the
  * DetermineSupportingSurfelsCUDA call that DirectBA::CreateSurfelsForKeyframe issues first
  * (B/direct_ba.cc:345-355).  keyframe_index selects the bound keyframe; covis / n_covis: indices
@@ -456,6 +465,10 @@ int bahip_debug_set_pose_lds_shape(int waves, int parts_shift);
  * the next): 0 = as many as the previous phase needed (default), n >= 1 = exactly n (1: wait after every round, the round-3
  * behaviour).  Results do not depend on it. */
 int bahip_debug_set_pose_rounds_ahead(int rounds);
+/* 1 (default): in bahip_alternating_iterations the launch that ends an iteration's pose phase also opens the next iteration
+ * (activation window / propagation, work items) when the keyframe table has at most 1024 entries; 0: a launch of its own does.
+ * Results do not depend on it. */
+int bahip_debug_set_fused_iteration_begin(int enabled);
 /* 0: bahip_alternating_iterations reports "not handled" and callers drive the loop through the stage functions, one host wait
  * per Gauss-Newton round (BAHIP_DEVICE_LOOP=0 in the environment does the same); 1 (default): the device-driven loop.  Same bits. */
 int bahip_debug_set_device_loop(int enabled);

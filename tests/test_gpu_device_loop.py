@@ -13,10 +13,11 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 
-def _run(scene, perturbed, surfels, device_loop, rounds_ahead, **ba_args):
+def _run(scene, perturbed, surfels, device_loop, rounds_ahead, fused_begin=True, **ba_args):
     from badslam_amd.directba import DirectBA
     lib = capi.load()
     capi.check(lib.bahip_debug_set_device_loop(int(device_loop)))
+    capi.check(lib.bahip_debug_set_fused_iteration_begin(int(fused_begin)))
     capi.check(lib.bahip_debug_set_pose_rounds_ahead(rounds_ahead))
     try:
         ba = DirectBA(600000, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, scene.width, scene.height, scene.camera, scene.camera)
@@ -39,18 +40,22 @@ def _run(scene, perturbed, surfels, device_loop, rounds_ahead, **ba_args):
                     activation=[ba.keyframe_activation(k) for k in range(K)], surfels=ba.download_surfels(8)), surfels
     finally:
         capi.check(lib.bahip_debug_set_device_loop(1))
+        capi.check(lib.bahip_debug_set_fused_iteration_begin(1))
         capi.check(lib.bahip_debug_set_pose_rounds_ahead(0))
 
 
+@pytest.mark.parametrize("fused_begin", [True, False], ids=["phase end opens the next iteration", "iteration_begin launch"])
 @pytest.mark.parametrize("case", ["fixed iterations", "until converged", "phase outruns the queue", "single keyframe"])
-def test_device_driven_loop_is_the_host_driven_loop(case):
+def test_device_driven_loop_is_the_host_driven_loop(case, fused_begin):
     scene = common.small_scene(num_keyframes=1 if case == "single keyframe" else 6, seed=33)
     rng = np.random.Generator(np.random.PCG64(4))
     perturbed = [synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
     args = dict(min_iterations=4, max_iterations=4) if case in ("fixed iterations", "phase outruns the queue") else dict(min_iterations=1, max_iterations=40)
+    # (six keyframes, window 0 .. 5: the fixed set of B/direct_ba_alternating.cc:338-361, re-applied by every iteration's top; one
+    # keyframe, window 0 .. 0: no fixed set, the top of an iteration is the co-visible propagation)
     ahead = 1 if case == "phase outruns the queue" else 0
     ref, surfels = _run(scene, perturbed, None, device_loop=False, rounds_ahead=1, **args)
-    got, _ = _run(scene, perturbed, surfels, device_loop=True, rounds_ahead=ahead, **args)
+    got, _ = _run(scene, perturbed, surfels, device_loop=True, rounds_ahead=ahead, fused_begin=fused_begin, **args)
     assert got["done"] == ref["done"] and got["conv"] == ref["conv"], (got["done"], ref["done"], got["conv"], ref["conv"])
     if case in ("until converged", "single keyframe"):
         assert ref["conv"] and 1 <= ref["done"] < 40

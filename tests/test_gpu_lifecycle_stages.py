@@ -49,9 +49,17 @@ def test_supporting_surfels_lists_bit_exact(world):
         assert filled[0] > 5000 and filled[1] > 100, filled           # second slots are in use: cells seen by several surfels
 
 
-def test_merge_bit_exact(world):
+@pytest.mark.parametrize("batch", [False, True], ids=["per keyframe", "lifecycle batch"])
+def test_merge_bit_exact(world, batch):
+    """batch: inside bahip_lifecycle_batch_begin / _end the sweeps skip the tiles a keyframe cannot see (here: a copy of the cloud
+    50 m away, in the middle of the buffer) -- the oracle knows no such bracket and must see the same buffer."""
+    import contextlib
     scene, orc, g = world
     data, _ = common.oracle_surfels(orc)
+    if batch:
+        far = data.copy()
+        far[0] += 50.0
+        data = np.concatenate([data[:, :data.shape[1] // 2], far, data[:, data.shape[1] // 2:]], axis=1)
     n = data.shape[1]
     # near-duplicates of a third of the cloud (1 mm away, same normal): candidates for merging, appended after the originals
     rng = np.random.Generator(np.random.PCG64(3))
@@ -61,16 +69,17 @@ def test_merge_bit_exact(world):
     both = np.concatenate([data, dup], axis=1)
     _sync(orc, g, both)
     total_merged = 0
-    for k in (0, 1, 3):
-        F = np.array(list(orc.keyframes[k].frame_T_global), np.float32)
-        before = int(orc.surfels.surfel_count)
-        planes, merged = g.determine_supporting_surfels(k, F, merge=True, merge_dist_factor=orc.merge_factor)
-        ref = orc.determine_supporting_surfels(k, merge=True)
-        assert merged == before - int(orc.surfels.surfel_count), k
-        assert np.array_equal(planes, ref), k
-        got = g.surfel_buf.download()[:, :both.shape[1]]
-        assert np.array_equal(_rows(got), _rows(orc.surfel_data[:, :both.shape[1]])), k     # the same surfels carry the NaN marker
-        total_merged += merged
+    with (g.lifecycle_batch() if batch else contextlib.nullcontext()):
+        for k in (0, 1, 3):
+            F = np.array(list(orc.keyframes[k].frame_T_global), np.float32)
+            before = int(orc.surfels.surfel_count)
+            planes, merged = g.determine_supporting_surfels(k, F, merge=True, merge_dist_factor=orc.merge_factor)
+            ref = orc.determine_supporting_surfels(k, merge=True)
+            assert merged == before - int(orc.surfels.surfel_count), k
+            assert np.array_equal(planes, ref), k
+            got = g.surfel_buf.download()[:, :both.shape[1]]
+            assert np.array_equal(_rows(got), _rows(orc.surfel_data[:, :both.shape[1]])), k     # the same surfels carry the NaN marker
+            total_merged += merged
     assert total_merged > 1000, total_merged
     assert g.surfel_count == int(orc.surfels.surfel_count)
     # compaction after merging (what the BA loop does next, B/direct_ba_alternating.cc:505-520), with the active flags
@@ -87,8 +96,9 @@ def test_merge_bit_exact(world):
     assert not np.any(_rows(orc.surfel_data[:, :m])[0] == NAN_BITS)
 
 
+@pytest.mark.parametrize("batch", [False, True], ids=["per keyframe", "lifecycle batch"])
 @pytest.mark.parametrize("min_obs", [1, 2, 3])
-def test_filtered_creation_bit_exact(min_obs):
+def test_filtered_creation_bit_exact(min_obs, batch):
     """CreateSurfelsForKeyframe with filter_new_surfels: observation / free-space-violation counting over the co-visible
     keyframes (B/kernel_create_surfels.cu:213-356), for complete and partial co-visibility lists."""
     scene = common.small_scene(num_keyframes=5, seed=29)
@@ -99,9 +109,12 @@ def test_filtered_creation_bit_exact(min_obs):
     g = common.build_gpu(scene, 600000, poses=poses, create_from=[])
     plan = [(0, [1, 2, 3, 4]), (1, [0, 2]), (2, [4]), (3, [0, 1, 2, 4]), (4, [])]
     created = []
+    import contextlib
     for k, covis in plan:
-        n_ref = orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis)
-        n_got = g.create_surfels_for_keyframe(k, filter_new_surfels=True, min_observation_count=min_obs, covis=covis)
+        # (a batch opened when the cloud already holds surfels: the bounded tiles, and behind them what this batch appends)
+        with (g.lifecycle_batch() if batch and k >= 2 else contextlib.nullcontext()):
+            n_ref = orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis)
+            n_got = g.create_surfels_for_keyframe(k, filter_new_surfels=True, min_observation_count=min_obs, covis=covis)
         assert n_got == n_ref, (k, n_got, n_ref)
         created.append(n_ref)
         assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :orc.surfels_size])), k
