@@ -178,6 +178,7 @@ SIGNATURES = {
     "bahip_debug_set_pose_lds_items": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_shape": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_fused_iteration_begin": (C.c_int, [C.c_int]),
+    "bahip_debug_set_intrinsics_reduce_form": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_rounds_ahead": (C.c_int, [C.c_int]),
     "bahip_debug_set_device_loop": (C.c_int, [C.c_int]),
     "bahip_debug_set_pcg_lds_form": (C.c_int, [C.c_int]),

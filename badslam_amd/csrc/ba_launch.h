@@ -136,6 +136,7 @@ void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const 
                                   const SurfelsView& s, double* glob_d, double* cells_d, const IntrBins& bins,
                                   const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
 void launch_intrinsics_bin_reduce(hipStream_t st, bool depth, const Intrinsics& in, const SurfelsView& s, double* cells, const IntrBins& bins);
+void set_intrinsics_reduce_form(int form);   // 0: LDS table of ds_add_f64, 1: records sorted by cell in LDS, sums in registers
 size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_finish needs
 void launch_intrinsics_finish(hipStream_t st, bool schur, int S, const double* glob_d, const double* cells_d, float* glob_f, float* cells_f,
                               float* partials);

@@ -423,7 +423,9 @@ int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_work, const PoseWo
 // A round queued in vain costs two near-empty launches (and, sharded, an exchange of zeros); results do not depend on the batch
 // size (tests run 1, the default and 4).
 // the launch that ends a pose phase of the device-driven loop also sets up the next iteration (kernels_pose.hip: pose_solve_begin_kernel)
-int g_fused_iteration_begin = [] { const char* e = getenv("BAHIP_FUSED_ITERATION_BEGIN"); return e ? atoi(e) : 1; }();
+// (off by default: measured SLOWER in round 4 -- 583 against 598 BA iterations/s, 0.420 against 0.411 ms on an eighth of the cloud:
+// sixteen wavefronts on one compute unit take longer over the set-up, and over a real solve, than the launch they save)
+int g_fused_iteration_begin = [] { const char* e = getenv("BAHIP_FUSED_ITERATION_BEGIN"); return e ? atoi(e) : 0; }();
 int g_pose_rounds_ahead = [] { const char* e = getenv("BAHIP_POSE_ROUNDS_AHEAD"); return e ? atoi(e) : 0; }();
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
@@ -2076,6 +2078,12 @@ int bahip_debug_set_pose_lds_shape(int waves, int parts_shift) {
   set_pose_lds_parts_shift(parts_shift);
   return 0;
 }
+int bahip_debug_set_intrinsics_reduce_form(int form) {
+  if (form < -1 || form > 1) return fail("bahip_debug_set_intrinsics_reduce_form: 0, 1 or -1 (the default)", __FILE__, __LINE__, hipSuccess);
+  set_intrinsics_reduce_form(form);
+  return 0;
+}
+
 int bahip_debug_set_fused_iteration_begin(int enabled) {
   g_fused_iteration_begin = enabled ? 1 : 0;
   return 0;

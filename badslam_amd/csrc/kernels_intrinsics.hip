@@ -53,6 +53,9 @@ constexpr int kBinCells = 1 << (2 * kBinShift);
 constexpr int kBinGroups = 3;      // blocks one wavefront can append to per candidate keyframe (the rest: direct atomics)
 constexpr uint32_t kBinSlice = 32768;   // records one workgroup of the reduction adds into its LDS table
 constexpr int kBinReduceBlock = 512;
+#ifndef BAHIP_INTR_REDUCE_FORM_DEFAULT
+#define BAHIP_INTR_REDUCE_FORM_DEFAULT 1   // measured: 0.57 ms against 0.85 ms for the 52 M records of the bench scene
+#endif
 #ifndef BAHIP_INTR_BIN_SUBS
 #define BAHIP_INTR_BIN_SUBS 16
 #endif
@@ -308,6 +311,121 @@ intrinsics_bin_reduce_kernel(IntrBins bins, int slices_per_bin, int cf_width, in
   }
 }
 
+// The same reduction without a floating-point atomic in LDS (round 4).  ds_add_f64 is what bounds the kernel above; 32-bit integer
+// LDS atomics and plain LDS traffic are several times faster.  So a chunk of kSortChunk records is SORTED by cell in LDS -- a
+// histogram by returning 32-bit atomics (the returned value is the record's rank within its cell), a scan of the 1024 counts, and
+// the seven values of every record stored at start[cell] + rank -- and then every thread adds the records of ITS two cells, which
+// now lie side by side, into binary64 sums it keeps in registers across the chunks of the slice.  At the end the sums go through
+// the table layout of the kernel above into the global accumulators (one request per touched cell).  The order in which a cell's
+// records are added is the order the atomics arrived in, as arbitrary as before; the definition at the head of this file makes
+// the result independent of it.
+constexpr int kSortChunk = 4096;
+constexpr int kSortBlock = 512;                     // two cells per thread
+constexpr int kSortUnroll = kSortChunk / kSortBlock;
+constexpr size_t kSortStartBytes = 4352;            // 1025 offsets, padded to 256 B
+constexpr size_t kSortLdsBytes = kSortStartBytes + (size_t)(kCellFloats - 1) * kSortChunk * sizeof(float);
+static_assert(kBinCells == 2 * kSortBlock, "two cells per thread");
+static_assert(kSortLdsBytes >= (size_t)kBinCells * kCellFloats * sizeof(double), "the flush table reuses the sort buffers");
+__global__ void __launch_bounds__(kSortBlock)
+intrinsics_bin_reduce_sorted_kernel(IntrBins bins, int slices_per_bin, int cf_width, int cf_height, double* __restrict__ cells) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+  uint32_t* start = reinterpret_cast<uint32_t*>(sort_lds);                     // counts, then exclusive offsets; [kBinCells] = total
+  float* vals = reinterpret_cast<float*>(sort_lds + kSortStartBytes);          // [kCellFloats - 1][kSortChunk], sorted by cell
+  __shared__ uint32_t wave_total[kSortBlock / 64];
+  const int buffer = blockIdx.x / slices_per_bin, slice = blockIdx.x % slices_per_bin, block = buffer / kBinSubs;
+  const uint32_t count = min(bins.cursors[buffer], bins.capacity);
+  const uint32_t begin = (uint32_t)slice * kBinSlice;
+  if (begin >= count) return;
+  const uint32_t end = min(count, begin + kBinSlice);
+  const uint32_t* rec = bins.records + (size_t)buffer * kCellFloats * bins.capacity;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double acc[2][kCellFloats - 1];
+  uint32_t observations[2] = {0u, 0u};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int c = 0; c < kCellFloats - 1; ++c) acc[h][c] = 0.0;
+
+  for (uint32_t chunk = begin; chunk < end; chunk += kSortChunk) {
+    const uint32_t chunk_n = min((uint32_t)kSortChunk, end - chunk);
+    for (int e = tid; e <= kBinCells; e += kSortBlock) start[e] = 0u;
+    uint32_t within[kSortUnroll], rank[kSortUnroll];
+    float v[kSortUnroll][kCellFloats - 1];
+#pragma unroll
+    for (int u = 0; u < kSortUnroll; ++u) {
+      const uint32_t r = min(chunk + (uint32_t)(tid + u * kSortBlock), end - 1);   // clamped: loaded, not used
+      within[u] = rec[r];
+#pragma unroll
+      for (int c = 0; c < kCellFloats - 1; ++c) v[u][c] = __uint_as_float(rec[(size_t)(c + 1) * bins.capacity + r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSortUnroll; ++u) {
+      rank[u] = 0u;
+      if ((uint32_t)(tid + u * kSortBlock) < chunk_n) rank[u] = atomicAdd(start + within[u], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 counts: two per thread, an inclusive scan per wavefront, the wavefront totals through LDS
+    const uint32_t a = start[2 * tid], b = start[2 * tid + 1];
+    uint32_t inclusive = a + b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t other = __shfl_up(inclusive, d);
+      if (lane >= d) inclusive += other;
+    }
+    if (lane == 63) wave_total[wave] = inclusive;
+    __syncthreads();
+    uint32_t base = 0u;
+#pragma unroll
+    for (int w = 0; w < kSortBlock / 64; ++w) base += w < wave ? wave_total[w] : 0u;
+    const uint32_t exclusive = base + inclusive - (a + b);
+    start[2 * tid] = exclusive;
+    start[2 * tid + 1] = exclusive + a;
+    if (tid == kSortBlock - 1) start[kBinCells] = exclusive + a + b;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSortUnroll; ++u) {
+      if ((uint32_t)(tid + u * kSortBlock) < chunk_n) {
+        const uint32_t pos = start[within[u]] + rank[u];
+#pragma unroll
+        for (int c = 0; c < kCellFloats - 1; ++c) vals[c * kSortChunk + pos] = v[u][c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cell = tid + h * kSortBlock;
+      const uint32_t j0 = start[cell], j1 = start[cell + 1];
+      for (uint32_t j = j0; j < j1; ++j) {
+#pragma unroll
+        for (int c = 0; c < kCellFloats - 1; ++c) acc[h][c] += (double)vals[c * kSortChunk + j];
+      }
+      observations[h] += j1 - j0;
+    }
+    __syncthreads();   // the next chunk overwrites the offsets and the sorted values
+  }
+
+  // the sums of this slice through the table of the kernel above: planes of kBinCells doubles, the counts as integers in plane 7
+  double* table = reinterpret_cast<double*>(sort_lds);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(table + (kCellFloats - 1) * kBinCells);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int cell = tid + h * kSortBlock;
+#pragma unroll
+    for (int c = 0; c < kCellFloats - 1; ++c) table[c * kBinCells + cell] = acc[h][c];
+    counts[cell] = observations[h];
+  }
+  __syncthreads();
+  const int bx = block % bins.bins_x, by = block / bins.bins_x;
+  for (int e = tid; e < kBinCells * kCellFloats; e += kSortBlock) {
+    const int within_block = e / kCellFloats, c = e % kCellFloats;   // 8 consecutive lanes: the record of one cell, one request
+    const double value = c < kCellFloats - 1 ? table[c * kBinCells + within_block] : (double)counts[within_block];
+    if (value == 0.0) continue;
+    const int cx = (bx << kBinShift) + (within_block & ((1 << kBinShift) - 1)), cy = (by << kBinShift) + (within_block >> kBinShift);
+    unsafeAtomicAdd(&cells[((size_t)cy * cf_width + cx) * kCellFloats + c], value);
+  }
+}
+
 // Schur complement: B/kernel_opt_intrinsics.cu:266-350.  One thread per sparse cell.  This runs AFTER the multi-GPU
 // all-reduce of the accumulators, on every rank.  The binary64 accumulators are rounded to binary32 here (cells_f: what the
 // reference holds at this point); the 20 sums over the cells are formed without atomics - the xor butterfly per wavefront
@@ -413,10 +531,29 @@ void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const 
   else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
 }
 // The second kernel of the step: the binned per-cell records into the per-cell accumulators (nothing to do without bins).
+// 0: the table of ds_add_f64 (round 3), 1: records sorted by cell in LDS, sums in registers (round 4)
+static int g_intr_reduce_form = [] { const char* e = getenv("BAHIP_INTR_REDUCE_FORM"); return e ? atoi(e) : BAHIP_INTR_REDUCE_FORM_DEFAULT; }();
+void set_intrinsics_reduce_form(int form) { g_intr_reduce_form = form < 0 ? BAHIP_INTR_REDUCE_FORM_DEFAULT : form; }
 void launch_intrinsics_bin_reduce(hipStream_t st, bool depth, const Intrinsics& in, const SurfelsView& s, double* cells, const IntrBins& bins) {
   if (!s.size) return;
   if (depth && bins.capacity) {
     const int slices = (int)((bins.capacity + kBinSlice - 1) / kBinSlice);
+    if (g_intr_reduce_form == 1) {
+      // more than 64 KB of LDS per workgroup: an opt-in per device, as the persistent pose sweep's
+      static bool raised[64] = {}, failed[64] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+      if (!raised[dev] && !failed[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&intrinsics_bin_reduce_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kSortLdsBytes) == hipSuccess) raised[dev] = true;
+        else { failed[dev] = true; (void)hipGetLastError(); }
+      }
+      if (raised[dev]) {
+        hipLaunchKernelGGL(intrinsics_bin_reduce_sorted_kernel, dim3((unsigned)(intrinsics_bin_count(in, nullptr) * slices)), dim3(kSortBlock),
+                           kSortLdsBytes, st, bins, slices, in.cf_width, in.cf_height, cells);
+        return;
+      }
+    }
     hipLaunchKernelGGL(intrinsics_bin_reduce_kernel, dim3((unsigned)(intrinsics_bin_count(in, nullptr) * slices)), dim3(kBinReduceBlock),
                        kBinCells * kCellFloats * sizeof(double), st, bins, slices, in.cf_width, in.cf_height, cells);
   }

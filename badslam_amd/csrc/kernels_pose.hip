@@ -350,6 +350,7 @@ constexpr int kPoseLdsWaves = BAHIP_POSE_LDS_WAVES;
 #define BAHIP_POSE_BATCH 32
 #endif
 constexpr uint32_t kPoseBatch = BAHIP_POSE_BATCH;
+constexpr int kPoseShortList = 16;   // later rounds with at most this many work items: static deal of the tiles (below)
 // kSlice: the launch covers the items [slice_begin, slice_begin + slice_count) only -- a list longer than the table (292 work
 // items) is cut into slices, one launch each (1000 keyframes: four); without it the two arguments are not looked at, which
 // keeps them out of the scalar registers of the common case.
@@ -383,45 +384,66 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
   const uint32_t xcd = blockIdx.x & 7u, per_xcd = (sched_positions(padded_tiles, sched) >> 3) << parts_shift;
   uint32_t* counter = tile_counters + parity * 8 + xcd;
   for (int e = threadIdx.x; e < num_items * kHbStride; e += blockDim.x) table[e] = 0;
-  if (threadIdx.x == 0) batch_state = ((unsigned long long)atomicAdd(counter, kPoseBatch) << 32) | ((unsigned long long)kPoseBatch << 24);
+  // A later round over a short list (the two or three keyframes that have not converged -- the steady state of a BA loop): nearly
+  // every tile ends at its stored bound, and drawing batches of such tiles from the XCD's queue (a global atomic per batch, fifteen
+  // wavefronts waiting for the sixteenth's fetch) took several times as long as the tiles: 43 us on an eighth of the bench cloud,
+  // 70 - 125 us on all of it (round 4 traces).  Such a launch deals the positions to the wavefronts statically instead, heavy
+  // tiles first and interleaved; the items are not split into parts.  (Integer sums: the same bits either way.)
+  const bool short_list = !kSlice && stored_bounds && num_listed <= kPoseShortList;   // workgroup-uniform, launch-uniform
+  if (threadIdx.x == 0 && !short_list) batch_state = ((unsigned long long)atomicAdd(counter, kPoseBatch) << 32) | ((unsigned long long)kPoseBatch << 24);
   __syncthreads();
   const int slot = wave_reduce28_slot(lane);
   const uint32_t table_address = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) HbFixed*)table;   // LDS byte address
   LdsSink sink{table_address + (uint32_t)(slot > 0 ? slot : 0) * (uint32_t)(kHbLimbs * sizeof(HbFixed)), invalid, slot >= 0 && slot < 27, 0.f, -1};
+  // (one call site of pose_tile for both ways of handing out tiles: the body is ~2700 instructions)
+  const uint32_t positions = sched_positions(padded_tiles, sched), static_stride = gridDim.x * (blockDim.x >> 6);
+  uint32_t static_position = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   for (;;) {
-    unsigned long long taken = 0;
-    if (lane == 0) taken = atomicAdd(&batch_state, 1ull);
-    const uint32_t first = __builtin_amdgcn_readfirstlane((uint32_t)(taken >> 32));
-    const uint32_t size = __builtin_amdgcn_readfirstlane((uint32_t)taken >> 24);
-    const uint32_t index = __builtin_amdgcn_readfirstlane((uint32_t)taken & 0xffffffu);
-    if (first >= per_xcd) break;                         // the XCD's tiles are used up
-    if (index < size) {
-      uint32_t tile;
-      const uint32_t unit = first + index;
-      if (unit < per_xcd && scheduled_tile((unit >> parts_shift) * 8u + xcd, padded_tiles, sched, &tile)) {
-#ifdef BAHIP_TILE_TIMELINE
-        const unsigned long long t0 = wall_clock64();
-#endif
-        pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, tile, 1 << parts_shift,
-                                       (int)(unit & ((1u << parts_shift) - 1u)), sink, tile_cost, item_begin, kSlice ? num_items : -1);
-#ifdef BAHIP_TILE_TIMELINE
-        const uint32_t position = (unit >> parts_shift) * 8u + xcd;
-        if (!stored_bounds && lane == 0 && position < 65536 && tile < 65536) {
-          g_pose_timeline[position][0] = t0; g_pose_timeline[position][1] = wall_clock64(); g_pose_timeline[position][2] = tile;
-          g_pose_timeline[position][3] = ((unsigned long long)g_pose_tile_stats[tile][0] << 32) | g_pose_tile_stats[tile][1];
+    uint32_t tile = 0, position = 0;
+    int parts = 1, part = 0;
+    bool have_tile = false;
+    if (short_list) {
+      if (static_position >= positions) break;
+      position = static_position;
+      static_position += static_stride;
+      have_tile = scheduled_tile(position, padded_tiles, sched, &tile);
+    } else {
+      unsigned long long taken = 0;
+      if (lane == 0) taken = atomicAdd(&batch_state, 1ull);
+      const uint32_t first = __builtin_amdgcn_readfirstlane((uint32_t)(taken >> 32));
+      const uint32_t size = __builtin_amdgcn_readfirstlane((uint32_t)taken >> 24);
+      const uint32_t index = __builtin_amdgcn_readfirstlane((uint32_t)taken & 0xffffffu);
+      if (first >= per_xcd) break;                         // the XCD's tiles are used up
+      if (index < size) {
+        const uint32_t unit = first + index;
+        position = (unit >> parts_shift) * 8u + xcd;
+        parts = 1 << parts_shift;
+        part = (int)(unit & ((1u << parts_shift) - 1u));
+        have_tile = unit < per_xcd && scheduled_tile(position, padded_tiles, sched, &tile);
+      } else if (index == size) {                          // this wavefront took the batch's last-plus-one: it fetches the next batch
+        if (lane == 0) {
+          const uint32_t left = per_xcd > first + size ? per_xcd - (first + size) : 0u;   // (as of this workgroup's last fetch)
+          const uint32_t want = min(kPoseBatch, max(2u, left / (4u * (gridDim.x >> 3))));
+          const uint32_t next = atomicAdd(counter, want);
+          __hip_atomic_store(&batch_state, ((unsigned long long)next << 32) | ((unsigned long long)want << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+      } else {                                             // the others wait for it (a few microseconds per batch)
+        while ((uint32_t)(__hip_atomic_load(&batch_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == first)
+          __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (have_tile) {
+#ifdef BAHIP_TILE_TIMELINE
+      const unsigned long long t0 = wall_clock64();
 #endif
+      pose_tile<kUseDepth, kUseDesc>(in, frames, work, num_work, s, tile_bounds, stored_bounds, num_listed, tile, parts, part, sink, tile_cost,
+                                     item_begin, kSlice ? num_items : -1);
+#ifdef BAHIP_TILE_TIMELINE
+      if (!stored_bounds && lane == 0 && position < 65536 && tile < 65536) {
+        g_pose_timeline[position][0] = t0; g_pose_timeline[position][1] = wall_clock64(); g_pose_timeline[position][2] = tile;
+        g_pose_timeline[position][3] = ((unsigned long long)g_pose_tile_stats[tile][0] << 32) | g_pose_tile_stats[tile][1];
       }
-    } else if (index == size) {                          // this wavefront took the batch's last-plus-one: it fetches the next batch
-      if (lane == 0) {
-        const uint32_t left = per_xcd > first + size ? per_xcd - (first + size) : 0u;   // (as of this workgroup's last fetch)
-        const uint32_t want = min(kPoseBatch, max(2u, left / (4u * (gridDim.x >> 3))));
-        const uint32_t next = atomicAdd(counter, want);
-        __hip_atomic_store(&batch_state, ((unsigned long long)next << 32) | ((unsigned long long)want << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    } else {                                             // the others wait for it (a few microseconds per batch)
-      while ((uint32_t)(__hip_atomic_load(&batch_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32) == first)
-        __builtin_amdgcn_s_sleep(8);
+#endif
     }
   }
   __syncthreads();

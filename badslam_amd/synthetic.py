@@ -96,6 +96,8 @@ def render_many(poses, planes, camera, width, height, raw_to_float_depth, worker
     jobs = [(p, planes, camera, width, height, raw_to_float_depth) for p in poses]
     if workers is None:
         workers = min(len(jobs) // 4, max(1, (os.cpu_count() or 1) - 2), 96)
+        if os.environ.get("BADSLAM_RENDER_WORKERS"):      # e.g. under a profiler, which attaches to every spawned worker
+            workers = max(1, min(workers, int(os.environ["BADSLAM_RENDER_WORKERS"])))
     if workers <= 1:
         for job in jobs:
             yield _render_job(job)

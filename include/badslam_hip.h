@@ -465,10 +465,14 @@ int bahip_debug_set_pose_lds_shape(int waves, int parts_shift);
  * the next): 0 = as many as the previous phase needed (default), n >= 1 = exactly n (1: wait after every round, the round-3
  * behaviour).  Results do not depend on it. */
 int bahip_debug_set_pose_rounds_ahead(int rounds);
-/* 1 (default): in bahip_alternating_iterations the launch that ends an iteration's pose phase also opens the next iteration
- * (activation window / propagation, work items) when the keyframe table has at most 1024 entries; 0: a launch of its own does.
- * Results do not depend on it. */
+/* 1: in bahip_alternating_iterations the launch that ends an iteration's pose phase also opens the next iteration (activation
+ * window / propagation, work items) when the keyframe table has at most 1024 entries; 0 (default -- the fused launch measured
+ * slower): a launch of its own does.  Results do not depend on it. */
 int bahip_debug_set_fused_iteration_begin(int enabled);
+/* How the binned per-cell records of the intrinsics step are added (kernels_intrinsics.hip): 0 = into a table in LDS by
+ * binary64 LDS atomics, 1 = sorted by cell in LDS and added by the thread that owns the cell, -1 = the default.  Same sums (binary64 sums of
+ * binary32 terms, rounded to binary32 afterwards). */
+int bahip_debug_set_intrinsics_reduce_form(int form);
 /* 0: bahip_alternating_iterations reports "not handled" and callers drive the loop through the stage functions, one host wait
  * per Gauss-Newton round (BAHIP_DEVICE_LOOP=0 in the environment does the same); 1 (default): the device-driven loop.  Same bits. */
 int bahip_debug_set_device_loop(int enabled);

@@ -40,7 +40,7 @@ def _run(scene, perturbed, surfels, device_loop, rounds_ahead, fused_begin=True,
                     activation=[ba.keyframe_activation(k) for k in range(K)], surfels=ba.download_surfels(8)), surfels
     finally:
         capi.check(lib.bahip_debug_set_device_loop(1))
-        capi.check(lib.bahip_debug_set_fused_iteration_begin(1))
+        capi.check(lib.bahip_debug_set_fused_iteration_begin(0))
         capi.check(lib.bahip_debug_set_pose_rounds_ahead(0))
 
 

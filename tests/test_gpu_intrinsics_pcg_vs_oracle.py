@@ -21,6 +21,17 @@ def scene():
     return common.small_scene(num_keyframes=5, seed=21)
 
 
+@pytest.fixture(params=[0, 1], ids=["records added by LDS f64 atomics", "records sorted by cell in LDS"])
+def reduce_form(request):
+    """Both forms of the second kernel of the intrinsics step (kernels_intrinsics.hip: intrinsics_bin_reduce_kernel /
+    intrinsics_bin_reduce_sorted_kernel) against the oracle."""
+    from badslam_amd import capi
+    lib = capi.load()
+    capi.check(lib.bahip_debug_set_intrinsics_reduce_form(request.param))
+    yield request.param
+    capi.check(lib.bahip_debug_set_intrinsics_reduce_form(-1))
+
+
 def _perturbed_pair(scene, depth_cam_offset=(0.5, -0.6, 1.23, -2.17), color_cam_offset=(0, 0, 0, 0)):
     """Oracle + GPU scenes with identical surfels and identically perturbed cameras."""
     ba = common.build_oracle(scene, 400000)
@@ -41,7 +52,7 @@ def _bits(values):
     return np.asarray(values, np.float32).view(np.uint32)
 
 
-def test_depth_intrinsics_step(scene):
+def test_depth_intrinsics_step(scene, reduce_form):
     """One depth-intrinsics + deformation step (Schur complement over the sparse cfactor cells).  The accumulation is DEFINED
     (binary32 terms, per-surfel chains, xor butterfly per tile, binary64 across tiles and per cell, xor butterfly + ordered
     partials in the Schur complement: kernels_intrinsics.hip / oracle_intrinsics.c), so kernels and oracle agree to the last
@@ -76,7 +87,7 @@ def test_depth_intrinsics_step(scene):
 
 
 @pytest.mark.parametrize("capacity", [-1, 0, 16, 256])
-def test_depth_intrinsics_step_whatever_the_record_buffers_hold(scene, capacity):
+def test_depth_intrinsics_step_whatever_the_record_buffers_hold(scene, capacity, reduce_form):
     """The sweep appends its per-cell records to per-block buffers and a second kernel adds them up in LDS; records that find
     their buffer full go out as atomics (kernels_intrinsics.hip).  Automatic size (-1), no buffers (0), buffers far too small
     (16 records per buffer: nearly everything overflows) and too small for the busier buffers only (256): the same bits."""

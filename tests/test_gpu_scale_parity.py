@@ -206,13 +206,22 @@ def test_many_keyframes_intrinsics_step_bit_exact(many):
         g.set_intrinsics()
         g.bind_keyframes()
         cc_r, dc_r, a_r = orc.optimize_intrinsics(True, True, apply=False)
-        cc_g, dc_g, a_g = g.optimize_intrinsics(True, True, apply=False)
-        for got, ref in ((dc_g, dc_r), (cc_g, cc_r)):
-            assert (got.fx, got.fy, got.cx, got.cy) == (ref.fx, ref.fy, ref.cx, ref.cy), ((got.fx, got.fy, got.cx, got.cy), (ref.fx, ref.fy, ref.cx, ref.cy))
-        assert np.float32(a_g) == np.float32(a_r)
-        cf_g = g.cfactor.download()
         assert np.count_nonzero(orc.cfactor) > 0.5 * orc.cfactor.size
-        assert np.array_equal(cf_g.view(np.uint32), orc.cfactor.view(np.uint32))
+        # both forms of the record reduction (kernels_intrinsics.hip), each once with the record buffers sized by the call before
+        # (the second call of a form: every record goes through the buffers, several chunks and slices per buffer at this size)
+        lib = g.ctx.lib
+        try:
+            for form in (0, 0, 1, 1):
+                assert lib.bahip_debug_set_intrinsics_reduce_form(form) == 0
+                g.cfactor.upload(cf_saved)
+                cc_g, dc_g, a_g = g.optimize_intrinsics(True, True, apply=False)
+                for got, ref in ((dc_g, dc_r), (cc_g, cc_r)):
+                    assert (got.fx, got.fy, got.cx, got.cy) == (ref.fx, ref.fy, ref.cx, ref.cy), (form, (got.fx, got.fy, got.cx, got.cy), (ref.fx, ref.fy, ref.cx, ref.cy))
+                assert np.float32(a_g) == np.float32(a_r), form
+                cf_g = g.cfactor.download()
+                assert np.array_equal(cf_g.view(np.uint32), orc.cfactor.view(np.uint32)), form
+        finally:
+            assert lib.bahip_debug_set_intrinsics_reduce_form(-1) == 0
     finally:
         for obj, name, values in saved:
             cam = getattr(obj, name)
