@@ -1047,9 +1047,10 @@ int bahip_accumulate_pose_estimation_coeffs(bahip_context* ctx, int use_depth, i
   if (!kf_sharded(ctx) && reduce_over_ranks(ctx, ctx->dev_Hb1, kHbStride, BAHIP_SUM_I64)) return 1;
   HbFixed* fixed = reinterpret_cast<HbFixed*>(ctx->pinned_f);   // 56 x 8 bytes of the 128-float pinned buffer
   HIP_TRY(hipMemcpyAsync(fixed, ctx->dev_Hb1, sizeof(HbFixed) * kHbStride, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, reinterpret_cast<const int*>(ctx->dev_work1 + 1) + kPoseCounterInvalid, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (ctx->pinned_i[0])
+  // the sweep's "not representable" flag travels in the row's unused 28th coefficient (kernels_pose.hip: pose_invalid_word), summed
+  // over the ranks like the rest of the row
+  if (fixed[27 * kHbLimbs] != 0)
     return fail("pose normal equations: a tile total was not finite or reached 2^52 (hb_split)", __FILE__, __LINE__);
   for (int c = 0; c < 21; ++c) H[c] = (float)hb_value(fixed[c * kHbLimbs], fixed[c * kHbLimbs + 1]);
   for (int c = 0; c < 6; ++c) b[c] = (float)hb_value(fixed[(21 + c) * kHbLimbs], fixed[(21 + c) * kHbLimbs + 1]);

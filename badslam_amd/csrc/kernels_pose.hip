@@ -123,10 +123,14 @@ struct LdsSink {
   bool holds_total;       // this lane holds one of the 27 tile totals
   float pending;
   int pending_item;       // wave-uniform
-  // Same shape as GlobalSink -- the totals wait in `pending` and are added at the next candidate (or at the end of the tile)
-  // -- although LDS adds have no round trip to hide: with the adds placed right behind the reduction, rows other than the
-  // first received a few totals twice (the visit log of the sweep was unchanged; not understood, possibly the structurizer's
-  // handling of the early return that precedes the reduction).  In this shape both sinks give the oracle's bits.
+  // The totals are added right behind the reduction (add() flushes at once; BAHIP_LDS_DEFERRED restores the GlobalSink shape,
+  // where they wait in `pending` for the next candidate).  History: the round-3 builds gave wrong sums for rows > 0 in the immediate
+  // shape and the oracle's bits in the deferred one.  The round-4 bisect (profiles/r4_lds_anomaly_bisect.txt) reproduced that on the
+  // old commits, showed that the sink and the LDS atomics were innocent -- a shadow table kept by global atomics held the same wrong
+  // values, add() was called once per (tile, item): the values REACHING the sink were already wrong, i.e. code generation upstream
+  // of it -- and that every build from commit b4280f8 on is right in both shapes.  The instruction at fault was not pinned down;
+  // tests/test_gpu_scale_parity.py runs the sweep at 1 / 2 / 16 wavefronts x 1 / 37 / 292 items x parts x rounds-ahead against the
+  // oracle so that a toolchain or source change that brings it back cannot pass.
   __device__ __forceinline__ void flush() {
     if (pending_item >= 0 && holds_total) {
       const HbSplit v = hb_split(pending);
@@ -350,6 +354,10 @@ constexpr int kPoseLdsWaves = BAHIP_POSE_LDS_WAVES;
 #define BAHIP_POSE_BATCH 32
 #endif
 constexpr uint32_t kPoseBatch = BAHIP_POSE_BATCH;
+// Where a sweep reports a tile total it could not represent (hb_split): the low word of the unused 28th coefficient of work item
+// 0's row -- inside the buffer the ranks of a sharded run exchange, so that after the exchange EVERY rank's solve launch sees the
+// flag and every host fails the call alike (a flag in the rank's own counter record let the other ranks run on).
+__host__ __device__ inline int* pose_invalid_word(HbFixed* Hb) { return reinterpret_cast<int*>(Hb + 27 * kHbLimbs); }
 constexpr int kPoseShortList = 16;   // later rounds with at most this many work items: static deal of the tiles (below)
 // kSlice: the launch covers the items [slice_begin, slice_begin + slice_count) only -- a list longer than the table (292 work
 // items) is cut into slices, one launch each (1000 keyframes: four); without it the two arguments are not looked at, which
@@ -651,6 +659,10 @@ __device__ __forceinline__ void pose_solve_body(PoseWork* __restrict__ work, int
   // sequence number, the host may be waiting for exactly this launch
   const bool stopped = loop.ctl != nullptr && __hip_atomic_load(&loop.ctl[kLoopStop], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   bool stepped = false;
+  if (!stopped && w == 0 && *pose_invalid_word(Hb) != 0) {   // raised by a sweep of this round, on this rank or another (see pose_invalid_word)
+    atomicOr(&counters[kPoseCounterInvalid], 1);
+    Hb[27 * kHbLimbs] = 0;
+  }
   if (!stopped && w < num_work && !work[w].done) {
     stepped = true;
     PoseWork& pw = work[w];
@@ -948,7 +960,7 @@ static bool launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEn
                             const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
                             uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost, const uint32_t* sched,
                             const int* listed_count, uint32_t parts_shift, const int* stop) {
-  int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
+  int* invalid = pose_invalid_word(Hb);
   PoseLdsDevice& device = pose_lds_device();
   constexpr int variant = (kUseDepth ? 1 : 0) + (kUseDesc ? 2 : 0) + (kSlice ? 4 : 0);
   if (!device.raised[variant] && !device.failed[variant]) {   // dynamic LDS beyond 64 KB needs the opt-in
@@ -1036,7 +1048,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
   }
   ++g_pose_form_launches[0];
   const dim3 grid(sched_positions(tiles, sched), parts), block(kPoseBlock);
-  int* invalid = reinterpret_cast<int*>(const_cast<PoseWork*>(pw) + num_work) + kPoseCounterInvalid;
+  int* invalid = pose_invalid_word(Hb);
   if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
   else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
   else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);

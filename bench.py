@@ -159,12 +159,13 @@ def build_scene(args, log):
     return ba, data, poses_gt
 
 
-def committed_profile(args):
+def committed_profile(args, intrinsics=None, pcg=None):
     """The newest committed PMC summary (scripts/profile_round.sh -> profiles/<tag>_pmc_per_kernel.json) whose recorded
-    config is THIS run's workload -- counters of another scene are not this run's traffic.  None if there is none."""
+    config is THIS run's workload -- counters of another scene are not this run's traffic.  None if there is none.
+    intrinsics / pcg: the leg of the extras (the same scene with the intrinsics step / the PCG scheme) instead of the run's own."""
     import glob
     want = {"keyframes": args.keyframes, "surfels": args.surfels, "width": args.width, "height": args.height,
-            "intrinsics": bool(args.intrinsics), "pcg": bool(args.pcg)}
+            "intrinsics": bool(args.intrinsics if intrinsics is None else intrinsics), "pcg": bool(args.pcg if pcg is None else pcg)}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.json")), reverse=True):
         with open(path) as f:
             pmc = json.load(f)
@@ -445,12 +446,18 @@ def main():
             # the stage's dominant kernel against the HBM roof: its algorithmic bytes are the pose sweep's (surfel rows once, 5 bytes of
             # every keyframe pixel) plus the 32-byte record it writes per associated pair with a depth residual (read back by the reduction)
             sweep_bytes = N_total * 28 + K * args.width * args.height * 5
+            intr_pmc, intr_source = committed_profile(args, intrinsics=True, pcg=False)
+            intr_traffic = pmc_kernel_entry(intr_pmc, intr_source, "intrinsics_accumulate_kernel")
+            reduce_traffic = pmc_kernel_entry(intr_pmc, intr_source, "intrinsics_bin_reduce")
             extras["roofline_intrinsics"] = {"bound": "hbm", "kernel": "intrinsics_accumulate_kernel<true,true>", "avg_launch_ms": ms[6] / EXTRA_STEPS,
                                              "algorithmic_bytes_per_launch": sweep_bytes, "achieved": sweep_bytes / (ms[6] / EXTRA_STEPS * 1e-3) / 1e9,
                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sweep_bytes / (ms[6] / EXTRA_STEPS * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "traffic": None,
-                                             "limiter": "instruction issue (the sweep carries 34 per-lane sums: 168 VGPRs, 3 wavefronts per SIMD) and, in "
-                                                        "the second kernel, the LDS atomics that add the binned per-cell records"}
+                                             "traffic": intr_traffic["bytes"] if intr_traffic else None,
+                                             "traffic_source": intr_traffic["source"] if intr_traffic else None,
+                                             "record_reduction_traffic": reduce_traffic["bytes"] if reduce_traffic else None,
+                                             "limiter": "instruction issue (the sweep carries 34 per-lane sums: 168 VGPRs, 3 wavefronts per SIMD) and the "
+                                                        "32-byte record it writes per associated pair with a depth residual (read back by the second "
+                                                        "kernel, which sorts the records of a chunk by cell in LDS and adds them from registers)"}
             cc, dc, _a = ba.cameras()
             ba.set_cameras(cc, dc, 0.0)        # back to a = 0 for what follows (the cfactor image keeps its update)
         capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
@@ -473,10 +480,14 @@ def main():
             # algorithmic bytes of one step-1 sweep: surfel rows once, p and g of the surfel block (3 + 3 floats
             # per surfel), 5 bytes of every keyframe pixel
             step1_bytes = N_total * (28 + 6 * 4) + K * args.width * args.height * 5
+            pcg_pmc, pcg_source = committed_profile(args, intrinsics=False, pcg=True)
+            pcg_traffic = pmc_kernel_entry(pcg_pmc, pcg_source, "pcg_step1_lds_kernel")
             extras["roofline_pcg"] = {"bound": "hbm", "kernel": "pcg_step1_lds_kernel<false,false> (persistent, pose block of the dense head in LDS)",
                                       "avg_launch_ms": step1_ms, "launches": int(n_pcg[5]), "algorithmic_bytes_per_launch": step1_bytes,
                                       "achieved": step1_bytes / (step1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": step1_bytes / (step1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "unknowns": int(U),
+                                      "frac": step1_bytes / (step1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "traffic": pcg_traffic["bytes"] if pcg_traffic else None, "traffic_source": pcg_traffic["source"] if pcg_traffic else None,
+                                      "unknowns": int(U),
                                       "limiter": "instruction issue, as the pose sweep: the same pair work plus s = J p and g += J^T (w s)"}
         extras["pcg"] = {"outer_iterations_per_s": EXTRA_STEPS / dt_pcg, "ms_per_outer_iteration": 1e3 * dt_pcg / EXTRA_STEPS,
                          "inner_steps_per_outer_iteration": inner, "inner_steps_per_s": inner * EXTRA_STEPS / dt_pcg,

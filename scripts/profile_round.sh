@@ -16,16 +16,24 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export BADSLAM_RENDER_WORKERS=${BADSLAM_RENDER_WORKERS:-8}   # rocprofv3 attaches to every spawned render worker; a run with 96 of them hung once
+PASSES=${PASSES:-all}                                         # all | basic (stats, FETCH_SIZE, WRITE_SIZE, calibration) | stats
+[ -n "${ONLY_STATS:-}" ] && PASSES=stats
+LIMIT="timeout -k 5 ${PASS_TIMEOUT:-150}"                     # a pass that hangs must not take the GPU budget with it (-k: rocprofv3 traps SIGTERM)
 cd /tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-extras $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.log"
-if [ -z "${ONLY_STATS:-}" ]; then   # ONLY_STATS=1: the kernel-time table alone (the intrinsics / PCG legs)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_fetch.log"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_write.log"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_sq.log"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --output-format csv -d "$OUT/pmc_flops" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_flops.log"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 --output-format csv -d "$OUT/pmc_mix" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_mix.log"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_cal" -- python $REPO/scripts/fetch_calibration.py > "$OUT/cal_bytes.txt" 2> "$OUT/pmc_cal.log"
+$LIMIT rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.log"
+if [ "$PASSES" != stats ]; then   # PASSES=stats (or ONLY_STATS=1): the kernel-time table alone
+$LIMIT rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_fetch.log"
+$LIMIT rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_write.log"
+[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_sq.log"
+[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --output-format csv -d "$OUT/pmc_flops" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_flops.log"
+[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 --output-format csv -d "$OUT/pmc_mix" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_mix.log"
+if [ -n "${CAL_FROM:-}" ] && [ -d "$CAL_FROM/pmc_cal" ]; then   # the calibration of another profile of the same call
+  cp -r "$CAL_FROM/pmc_cal" "$OUT/pmc_cal"; cp "$CAL_FROM/cal_bytes.txt" "$OUT/cal_bytes.txt"
+else
+$LIMIT rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_cal" -- python $REPO/scripts/fetch_calibration.py > "$OUT/cal_bytes.txt" 2> "$OUT/pmc_cal.log"
+fi
 fi
 cd "$REPO"
 python scripts/summarize_profile.py "$OUT" "$TAG" $* > "$OUT/summary.txt" 2>&1
