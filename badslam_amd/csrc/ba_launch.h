@@ -185,7 +185,11 @@ void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, in
 void launch_lifecycle_bounds(hipStream_t st, const SurfelsView& s, uint32_t tiles, void* spheres);   // bounding spheres of tiles [0, tiles)
 // spheres / bounded_tiles: the batch's tile bounds (kernels_lifecycle.hip: LifecycleBounds), or nullptr / 0
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                              const void* spheres, uint32_t bounded_tiles);
+                              const void* spheres, uint32_t bounded_tiles,
+                              const uint32_t* size_on_device = nullptr /* a creation batch: min(*size_on_device, s.size) surfels exist */);
+// a creation batch: appends at *size_on_device and advances it, or raises *capacity_exceeded and appends nothing
+void launch_create_append_batched(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const uint32_t* indices,
+                                  const SurfelsView& s, uint32_t* size_on_device, uint32_t capacity, uint32_t* capacity_exceeded);
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
                   float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const void* spheres, uint32_t bounded_tiles);
 size_t create_padded_count(const Intrinsics& in);   // length of the tile-major flag / index vectors

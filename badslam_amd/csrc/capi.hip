@@ -1544,6 +1544,99 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
   return 0;
 }
 
+// A batch of keyframes creating surfels, one after the other as the reference does (each sees what the ones before it appended,
+// B/direct_ba_alternating.cc:389-425), but without the host in between: the cloud's size lives on the device for the duration of
+// the batch, the co-visibility lists and relative poses of all keyframes go up front in one copy, and the host reads the final size
+// once.  Same kernels on the same data in the same order as n calls of bahip_create_surfels_for_keyframe.
+int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes, int filter_new_surfels,
+                                       int min_observation_count, const int* covis_offsets, const int* covis_indices,
+                                       const bahip_surfels* surfels, uint32_t* const* supporting, uint32_t supporting_pitch,
+                                       uint32_t* new_surfel_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_create_surfels_for_keyframes");
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(keyframe_indices != nullptr && covis_offsets != nullptr && new_surfel_count_out != nullptr && num_keyframes >= 0,
+          "bahip_create_surfels_for_keyframes: NULL argument");
+  SupportingView sup;
+  REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
+  *new_surfel_count_out = 0;
+  if (num_keyframes == 0) return 0;
+  const int total_covis = covis_offsets[num_keyframes];
+  REQUIRE(total_covis == 0 || covis_indices != nullptr, "bahip_create_surfels_for_keyframes: co-visibility indices missing");
+  for (int j = 0; j < num_keyframes; ++j) {
+    REQUIRE(keyframe_indices[j] >= 0 && keyframe_indices[j] < ctx->num_kfs, "keyframe index out of range");
+    REQUIRE(covis_offsets[j] <= covis_offsets[j + 1], "co-visibility offsets must ascend");
+  }
+  const size_t px = create_padded_count(ctx->in);
+  if (ensure_px(ctx, px, px > surfels->capacity ? px : surfels->capacity)) return 1;
+  hipStream_t st = ctx->stream;
+  if (filter_new_surfels && total_covis > 0) {
+    if (total_covis > ctx->covis_capacity) {
+      int* idx = nullptr; float* T = nullptr;
+      const int cap = total_covis + 64;
+      if (hipMalloc(&idx, sizeof(int) * cap) != hipSuccess || hipMalloc(&T, sizeof(float) * 12 * cap) != hipSuccess) {
+        hipFree(idx); hipFree(T);
+        return fail("allocation of the co-visibility scratch failed", __FILE__, __LINE__);
+      }
+      hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
+      ctx->dev_covis = idx; ctx->dev_covis_T = T;
+      ctx->covis_capacity = cap;
+    }
+    std::vector<float> rel(12 * (size_t)total_covis);
+    for (int j = 0; j < num_keyframes; ++j) {
+      const KfEntry& e = ctx->host_kfs[keyframe_indices[j]];
+      for (int c = covis_offsets[j]; c < covis_offsets[j + 1]; ++c) {
+        REQUIRE(covis_indices[c] >= 0 && covis_indices[c] < ctx->num_kfs, "co-visibility index out of range");
+        // covis_T_frame = covis.frame_T_global * keyframe.global_T_frame (B/direct_ba.cc:359-365)
+        float cinv[7], prod[7];
+        se3_inverse(ctx->host_kfs[covis_indices[c]].global_T_frame, cinv);
+        se3_mul(cinv, e.global_T_frame, prod);
+        se3_matrix3x4(prod, &rel[12 * (size_t)c]);
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis, covis_indices, sizeof(int) * total_covis, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis_T, rel.data(), sizeof(float) * 12 * (size_t)total_covis, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // `rel` is pageable and goes out of scope
+  }
+  uint32_t* size_on_device = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 4;
+  uint32_t* exceeded_on_device = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 5;
+  ctx->pinned_i[2] = (int)surfels->surfels_size; ctx->pinned_i[3] = 0;
+  HIP_TRY(hipMemcpyAsync(size_on_device, ctx->pinned_i + 2, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+  const uint32_t cells = (uint32_t)ctx->in.cf_width * (uint32_t)ctx->in.cf_height;   // a keyframe appends at most one surfel per sparse cell
+  for (int j = 0; j < num_keyframes; ++j) {
+    const KfEntry& e = ctx->host_kfs[keyframe_indices[j]];
+    // what the cloud can hold by now at most: the grid of the sweep; the size itself is read on the device
+    bahip_surfels bound = *surfels;
+    bound.surfels_size = (uint32_t)std::min<uint64_t>(surfels->capacity, (uint64_t)surfels->surfels_size + (uint64_t)j * cells);
+    const SurfelsView s = make_view(&bound);
+    launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
+    const bool bounded = ctx->lifecycle_bounds_tiles && ctx->lifecycle_bounds_data == surfels->data &&
+                         (uint64_t)ctx->lifecycle_bounds_tiles * 64 <= surfels->surfels_size;
+    launch_supporting_insert(st, ctx->in, e, s, sup, bounded ? ctx->dev_lifecycle_bounds : nullptr, bounded ? ctx->lifecycle_bounds_tiles : 0u, size_on_device);
+    HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));
+    launch_create_flag(st, ctx->in, e, sup, ctx->dev_flags);
+    const int n_covis = covis_offsets[j + 1] - covis_offsets[j];
+    if (filter_new_surfels && n_covis > 0) {
+      launch_create_filter(st, ctx->in, e, ctx->dev_kfs, ctx->dev_covis + covis_offsets[j], ctx->dev_covis_T + 12 * (size_t)covis_offsets[j], n_covis,
+                           min_observation_count, ctx->dev_flags);
+    } else if (filter_new_surfels) {
+      if (1 < min_observation_count) HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));   // no co-visible keyframe: one observation
+    }
+    HIP_TRY(scan_flags_inclusive(st, ctx->scan_temp, ctx->scan_temp_bytes, ctx->dev_flags, ctx->dev_indices, (int)px));
+    bound.surfels_size = surfels->capacity;   // (the append addresses rows by index; the view's size is not looked at)
+    launch_create_append_batched(st, ctx->in, e, ctx->dev_flags, ctx->dev_indices, make_view(&bound), size_on_device, (uint32_t)surfels->capacity,
+                                 exceeded_on_device);
+    CHECK_LAUNCH();
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i + 2, size_on_device, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *new_surfel_count_out = (uint32_t)ctx->pinned_i[2] - surfels->surfels_size;
+  if (ctx->pinned_i[3]) {
+    g_last_error = "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";
+    ctx->capacity_exceeded = true;
+  }
+  return 0;
+}
+
 int bahip_delete_surfels_and_update_radii(bahip_context* ctx, int min_observation_count, const bahip_surfels* surfels,
                                           uint32_t* deleted_count_out) {
   REQUIRE_NO_KF_SHARDING("bahip_delete_surfels_and_update_radii");

@@ -57,9 +57,10 @@ lifecycle_bounds_kernel(SurfelsView s, uint32_t tiles, WaveBounds* __restrict__ 
 
 // Phase A: every associated surfel offers its index to the cell's slot chain.
 __global__ void __launch_bounds__(kLcBlock)
-supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, LifecycleBounds lb) {
+supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, LifecycleBounds lb,
+                         const uint32_t* __restrict__ size_on_device /* a creation batch: the cloud's current size lives on the device, s.size bounds it */) {
   const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
-  if (i >= s.size) return;
+  if (i >= (size_on_device ? min(*size_on_device, s.size) : s.size)) return;
   if (lifecycle_tile_culled(in, frame, lb, i)) return;
   Assoc r;
   if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
@@ -253,12 +254,18 @@ create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ k
 // B/kernel_create_surfels.cu:91-160,357-390
 __global__ void __launch_bounds__(kLcBlock)
 create_append_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ indices,
-                     int padded_count, uint32_t surfels_size, SurfelsView s) {
+                     int padded_count, uint32_t surfels_size, SurfelsView s,
+                     const uint32_t* __restrict__ size_on_device /* a creation batch: the append position lives on the device */, uint32_t capacity) {
   const int idx = blockIdx.x * kLcBlock + threadIdx.x;
   if (idx >= padded_count) return;
   if (flags[idx] != 1) return;
   int x, y;
   if (!tile_xy(in, (size_t)idx, &x, &y)) return;
+  if (size_on_device) {
+    surfels_size = *size_on_device;
+    // the soft failure of B/kernel_create_surfels.cc:162-165, decided on the device: this keyframe creates nothing (create_advance_kernel raises the flag)
+    if ((uint64_t)surfels_size + indices[padded_count - 1] > capacity) return;
+  }
   const uint32_t si = surfels_size + indices[idx] - 1;   // inclusive scan
   float G[12];
   {
@@ -342,6 +349,14 @@ delete_update_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(deleted_count, (uint32_t)__popcll(m));
 }
 
+// A creation batch: the keyframe's surfels are appended, the cloud's size on the device moves on (or the capacity flag is raised).
+__global__ void create_advance_kernel(uint32_t* __restrict__ size_on_device, const uint32_t* __restrict__ last_index, uint32_t capacity,
+                                      uint32_t* __restrict__ capacity_exceeded) {
+  const uint32_t size = *size_on_device, count = *last_index;
+  if ((uint64_t)size + count > capacity) *capacity_exceeded = 1u;
+  else *size_on_device = size + count;
+}
+
 // ---- compaction (B/kernel_compact_surfels.cu:101-157) --------------------------------------------------
 __global__ void __launch_bounds__(kLcBlock)
 compact_flag_kernel(SurfelsView s, uint32_t* __restrict__ invalid) {
@@ -381,9 +396,9 @@ void launch_lifecycle_bounds(hipStream_t st, const SurfelsView& s, uint32_t tile
   if (tiles) hipLaunchKernelGGL(lifecycle_bounds_kernel, dim3(g1(tiles * 64u)), dim3(kLcBlock), 0, st, s, tiles, static_cast<WaveBounds*>(spheres));
 }
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                              const void* spheres, uint32_t bounded_tiles) {
+                              const void* spheres, uint32_t bounded_tiles, const uint32_t* size_on_device) {
   const LifecycleBounds lb{static_cast<const WaveBounds*>(spheres), spheres ? bounded_tiles : 0u};
-  if (s.size) hipLaunchKernelGGL(supporting_insert_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, lb);
+  if (s.size) hipLaunchKernelGGL(supporting_insert_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, lb, size_on_device);
 }
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
                   float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const void* spheres, uint32_t bounded_tiles) {
@@ -409,7 +424,14 @@ void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& f
                           const uint32_t* indices, uint32_t surfels_size, const SurfelsView& s) {
   const int padded = (int)create_padded_count(in);
   hipLaunchKernelGGL(create_append_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, flags, indices,
-                     padded, surfels_size, s);
+                     padded, surfels_size, s, static_cast<const uint32_t*>(nullptr), 0u);
+}
+void launch_create_append_batched(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const uint32_t* indices,
+                                  const SurfelsView& s, uint32_t* size_on_device, uint32_t capacity, uint32_t* capacity_exceeded) {
+  const int padded = (int)create_padded_count(in);
+  hipLaunchKernelGGL(create_append_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, flags, indices, padded, 0u, s,
+                     static_cast<const uint32_t*>(size_on_device), capacity);
+  hipLaunchKernelGGL(create_advance_kernel, dim3(1), dim3(1), 0, st, size_on_device, indices + (padded - 1), capacity, capacity_exceeded);
 }
 void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                           int min_obs, uint32_t* deleted_count) {

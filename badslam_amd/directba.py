@@ -177,6 +177,10 @@ class DirectBA:
         self.L.dba_sort_surfels_spatially.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
         assert self.L.dba_sort_surfels_spatially(self.h, self.stream, float(grid_cell_size)) == 0
 
+    def SetBatchedCreation(self, enabled):
+        self.L.dba_set_batched_creation.argtypes = [C.c_void_p, C.c_int]
+        assert self.L.dba_set_batched_creation(self.h, int(bool(enabled))) == 0
+
     def SetSpatialSortCellSize(self, grid_cell_size):
         self.L.dba_set_spatial_sort_cell_size.argtypes = [C.c_void_p, C.c_float]
         assert self.L.dba_set_spatial_sort_cell_size(self.h, float(grid_cell_size)) == 0

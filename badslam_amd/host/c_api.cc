@@ -136,6 +136,10 @@ int dba_sort_surfels_spatially(dba_handle* h, void* stream, float grid_cell_size
   return 0;
 }
 
+int dba_set_batched_creation(dba_handle* h, int enabled) {
+  h->ba->SetBatchedCreation(enabled != 0);
+  return 0;
+}
 int dba_set_spatial_sort_cell_size(dba_handle* h, float grid_cell_size) {
   h->ba->SetSpatialSortCellSize(grid_cell_size);
   return 0;

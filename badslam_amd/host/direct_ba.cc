@@ -280,6 +280,38 @@ void DirectBA::CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surf
   Unlock();
 }
 
+// A batch of keyframes in one call of the backend (bahip_create_surfels_for_keyframes): the creations of B/direct_ba_alternating.cc:
+// 389-425 in their order, the cloud's size on the device in between.
+void DirectBA::CreateSurfelsForKeyframes(hipStream_t stream, bool filter_new_surfels, const vector<u32>& keyframe_ids) {
+  if (keyframe_ids.empty()) return;
+  if (!batched_creation_) {
+    for (u32 id : keyframe_ids) CreateSurfelsForKeyframe(stream, filter_new_surfels, keyframes_[id]);
+    return;
+  }
+  WholeCloudScope whole_cloud(this, stream);
+  if (!creation_batch_bound_) BindScene(stream);
+  vector<int> bound, offsets(1, 0), covis;
+  for (u32 id : keyframe_ids) {
+    bound.push_back(id_to_bound_[id]);
+    for (int other : keyframes_[id]->co_visibility_list())
+      if (other >= 0 && other < (int)id_to_bound_.size() && id_to_bound_[other] >= 0) covis.push_back(id_to_bound_[other]);
+    offsets.push_back((int)covis.size());
+  }
+  uint32_t* sup[kMergeBufferCount];
+  for (int i = 0; i < kMergeBufferCount; ++i) sup[i] = supporting_surfels_[i]->ToCUDA().address();
+  const bahip_surfels s = SurfelsStruct();
+  uint32_t new_surfel_count = 0;
+  BAHIP_CHECKED_CALL(bahip_create_surfels_for_keyframes(ctx_, bound.data(), (int)bound.size(), filter_new_surfels ? 1 : 0, GetMinObservationCount(),
+                                                        offsets.data(), covis.data(), &s, sup, (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(),
+                                                        &new_surfel_count));
+  if (bahip_context_take_capacity_exceeded(ctx_)) LOG(ERROR) << "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";
+  Lock();
+  surfels_size_ += new_surfel_count;
+  surfel_count_ += new_surfel_count;
+  unsorted_surfels_ += new_surfel_count;
+  Unlock();
+}
+
 void DirectBA::MergeForKeyframe(const Keyframe& keyframe, bool defer_count) {
   uint32_t* sup[kMergeBufferCount];
   for (int i = 0; i < kMergeBufferCount; ++i) sup[i] = supporting_surfels_[i]->ToCUDA().address();
@@ -548,7 +580,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         BindScene(stream);                           // ... and one binding
         creation_batch_bound_ = true;
         LifecycleBatch batch(this);
-        for (u32 keyframe_id : keyframes_with_new_surfels) CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframes_[keyframe_id]);
+        CreateSurfelsForKeyframes(stream, /*filter_new_surfels*/ true, keyframes_with_new_surfels);
         creation_batch_bound_ = false;
       }
       if (!keyframes_with_new_surfels.empty()) scene_bound = false;   // CreateSurfelsForKeyframe re-bound the keyframes: lists and window go again
@@ -757,13 +789,13 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       for (shared_ptr<Keyframe>& keyframe : keyframes_) {
         if (keyframe->activation() == Keyframe::Activation::kActive && keyframe->last_active_in_ba_iteration() != ba_iteration_count_) {
           keyframe->SetLastActiveInBAIteration(ba_iteration_count_);
-          CreateSurfelsForKeyframe(stream, /*filter_new_surfels*/ true, keyframe);
           keyframes_with_new_surfels.push_back(keyframe->id());
         } else if (keyframe->activation() == Keyframe::Activation::kCovisibleActive &&
                    keyframe->last_covis_in_ba_iteration() != ba_iteration_count_) {
           keyframe->SetLastCovisInBAIteration(ba_iteration_count_);
         }
       }
+      CreateSurfelsForKeyframes(stream, /*filter_new_surfels*/ true, keyframes_with_new_surfels);   // in keyframe order, as the loop above met them
       creation_batch_bound_ = false;
     }
     BindScene(stream);

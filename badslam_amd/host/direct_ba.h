@@ -109,6 +109,9 @@ class DirectBA {
   // since the last reorder, so a caller that knows only B/direct_ba.h:73-388 gets the buffer the sweeps are fast on.
   // cell size 0 switches it off (the reference's surfel order stays observable); default 0.02 m.
   void SetSpatialSortCellSize(float grid_cell_size) { spatial_sort_cell_size_ = grid_cell_size; }
+  // Ours: the creations of a BA iteration as one call of the backend (default) or keyframe by keyframe with the host in between
+  // (the reference's shape).  Same surfels either way.
+  void SetBatchedCreation(bool enabled) { batched_creation_ = enabled; }
   float spatial_sort_cell_size() const { return spatial_sort_cell_size_; }
   u32 unsorted_surfels() const { return unsorted_surfels_; }
   CUDABufferConstPtr<float> surfels() const { return surfels_; }
@@ -174,6 +177,8 @@ class DirectBA {
 
   void MergeForKeyframe(const Keyframe& keyframe, bool defer_count = false);
   void TakeDeferredMergeCount();
+  void CreateSurfelsForKeyframes(hipStream_t stream, bool filter_new_surfels, const vector<u32>& keyframe_ids);
+  bool batched_creation_ = true;
   class LifecycleBatch {   // RAII: bahip_lifecycle_batch_begin / _end around the creations or merges of a batch of keyframes
    public:
     explicit LifecycleBatch(DirectBA* ba);

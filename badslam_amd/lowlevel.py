@@ -180,6 +180,24 @@ class Scene:
         self.surfel_count += n.value
         return n.value
 
+    def create_surfels_for_keyframes(self, plan, filter_new_surfels=False, min_observation_count=2):
+        """bahip_create_surfels_for_keyframes; plan = [(keyframe index, co-visible keyframe indices or None for all others), ...]."""
+        self.bind_keyframes()
+        ids, offsets, covis = [], [0], []
+        for i, cv in plan:
+            ids.append(i)
+            covis += [j for j in range(len(self.keyframes)) if j != i] if cv is None else list(cv)
+            offsets.append(len(covis))
+        n = C.c_uint32()
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_create_surfels_for_keyframes(self.ctx.handle, (C.c_int * len(ids))(*ids), len(ids), int(filter_new_surfels),
+                                                               int(min_observation_count), (C.c_int * len(offsets))(*offsets),
+                                                               (C.c_int * max(1, len(covis)))(*covis), C.byref(s), self._supporting_ptrs(),
+                                                               self.supporting[0].pitch, C.byref(n)))
+        self.surfels_size += n.value
+        self.surfel_count += n.value
+        return n.value
+
     @contextlib.contextmanager
     def lifecycle_batch(self):
         """bahip_lifecycle_batch_begin / _end around the creations or merges of a batch of keyframes."""

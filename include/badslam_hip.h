@@ -330,6 +330,16 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
                                       int min_observation_count, const int* covis, int n_covis,
                                       const bahip_surfels* surfels, uint32_t* const* supporting,
                                       uint32_t supporting_pitch_bytes, uint32_t* new_surfel_count_out);
+/* A batch of keyframes, in the order given, each seeing what the ones before it appended -- n calls of
+ * bahip_create_surfels_for_keyframe without the host in between (the cloud's size stays on the device during the batch; one host
+ * wait at the end instead of two per keyframe).  covis_offsets[num_keyframes + 1] / covis_indices: the co-visibility lists of the
+ * keyframes, concatenated, as indices into the bound keyframe list.  new_surfel_count_out: the surfels all of them appended; the
+ * caller adds it to surfels_size.  A keyframe that does not fit the capacity creates nothing and raises the flag of
+ * bahip_context_take_capacity_exceeded, the others go on (B/kernel_create_surfels.cc:162-165 per keyframe). */
+int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes, int filter_new_surfels,
+                                       int min_observation_count, const int* covis_offsets, const int* covis_indices,
+                                       const bahip_surfels* surfels, uint32_t* const* supporting, uint32_t supporting_pitch,
+                                       uint32_t* new_surfel_count_out);
 /* 1 if the last bahip_create_surfels_for_keyframe on this context created nothing because the surfels would not have fit
  * into `capacity` (the reference's soft failure, B/kernel_create_surfels.cc:162-165); reading clears the flag. */
 int bahip_context_take_capacity_exceeded(bahip_context* ctx);

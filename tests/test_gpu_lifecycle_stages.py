@@ -126,6 +126,40 @@ def test_filtered_creation_bit_exact(min_obs, batch):
         assert sum(created) > 10000
 
 
+@pytest.mark.parametrize("min_obs", [1, 2])
+def test_creation_batch_is_the_sequence_of_creations(min_obs):
+    """bahip_create_surfels_for_keyframes -- the creations of a batch of keyframes with the cloud's size on the device in between --
+    against the oracle's creations one by one: the same surfels in the same places, also when the batch starts on an empty cloud,
+    when a keyframe of it has no co-visible keyframe, and inside a lifecycle batch (tile bounds)."""
+    scene = common.small_scene(num_keyframes=5, seed=29)
+    rng = np.random.Generator(np.random.PCG64(7))
+    poses = [T if k in (0, 2, 4) else synthetic.perturb_pose(rng, T, 0.03, 0.01) for k, T in enumerate(scene.poses_gt)]
+    orc = common.build_oracle(scene, 600000, poses=poses, create_from=[], min_observation_count=min_obs)
+    g = common.build_gpu(scene, 600000, poses=poses, create_from=[])
+    first, second = [(0, [1, 2, 3, 4]), (1, [0, 2])], [(2, [4]), (3, [0, 1, 2, 4]), (4, [])]
+    for plan in (first, second):
+        n_ref = sum(orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis) for k, covis in plan)
+        with g.lifecycle_batch():
+            n_got = g.create_surfels_for_keyframes(plan, filter_new_surfels=True, min_observation_count=min_obs)
+        assert n_got == n_ref > 0, (n_got, n_ref)
+        assert g.surfels_size == orc.surfels_size
+        assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :orc.surfels_size]))
+
+
+def test_creation_batch_respects_the_capacity():
+    """A keyframe of the batch that does not fit creates nothing and raises the flag; the ones before it did create
+    (B/kernel_create_surfels.cc:162-165, per keyframe)."""
+    scene = common.small_scene(num_keyframes=3, seed=29)
+    full = common.build_gpu(scene, 600000, create_from=[])
+    counts = [full.create_surfels_for_keyframe(k, filter_new_surfels=False) for k in range(3)]
+    assert min(counts[:2]) > 0
+    g = common.build_gpu(scene, counts[0] + counts[1] // 2, create_from=[])
+    created = g.create_surfels_for_keyframes([(0, None), (1, None)], filter_new_surfels=False)
+    assert created == counts[0]
+    assert g.ctx.lib.bahip_context_take_capacity_exceeded(g.ctx.handle) == 1
+    assert np.array_equal(_rows(g.download_surfels()), _rows(full.download_surfels()[:, :counts[0]]))
+
+
 def test_delete_and_update_radii_then_compact_bit_exact(world):
     scene, orc, g = world
     data, _ = common.oracle_surfels(orc)
