@@ -319,13 +319,22 @@ intrinsics_bin_reduce_kernel(IntrBins bins, int slices_per_bin, int cf_width, in
 // the table layout of the kernel above into the global accumulators (one request per touched cell).  The order in which a cell's
 // records are added is the order the atomics arrived in, as arbitrary as before; the definition at the head of this file makes
 // the result independent of it.
-constexpr int kSortChunk = 4096;
-constexpr int kSortBlock = 512;                     // two cells per thread
+#ifndef BAHIP_SORT_CHUNK
+#define BAHIP_SORT_CHUNK 4096
+#endif
+#ifndef BAHIP_SORT_BLOCK
+#define BAHIP_SORT_BLOCK 512
+#endif
+constexpr int kSortChunk = BAHIP_SORT_CHUNK;
+constexpr int kSortBlock = BAHIP_SORT_BLOCK;
+constexpr int kSortCells = kBinCells / kSortBlock;  // cells per thread
 constexpr int kSortUnroll = kSortChunk / kSortBlock;
 constexpr size_t kSortStartBytes = 4352;            // 1025 offsets, padded to 256 B
-constexpr size_t kSortLdsBytes = kSortStartBytes + (size_t)(kCellFloats - 1) * kSortChunk * sizeof(float);
-static_assert(kBinCells == 2 * kSortBlock, "two cells per thread");
-static_assert(kSortLdsBytes >= (size_t)kBinCells * kCellFloats * sizeof(double), "the flush table reuses the sort buffers");
+constexpr size_t kSortValueBytes = (size_t)(kCellFloats - 1) * kSortChunk * sizeof(float);
+constexpr size_t kSortTableBytes = (size_t)kBinCells * kCellFloats * sizeof(double);
+// (the flush table reuses the sort buffers)
+constexpr size_t kSortLdsBytes = kSortStartBytes + kSortValueBytes > kSortTableBytes ? kSortStartBytes + kSortValueBytes : kSortTableBytes;
+static_assert(kBinCells % kSortBlock == 0 && kSortChunk % kSortBlock == 0 && kSortBlock % 64 == 0 && kSortBlock <= 1024, "shape of the sorted reduction");
 __global__ void __launch_bounds__(kSortBlock)
 intrinsics_bin_reduce_sorted_kernel(IntrBins bins, int slices_per_bin, int cf_width, int cf_height, double* __restrict__ cells) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
@@ -339,12 +348,14 @@ intrinsics_bin_reduce_sorted_kernel(IntrBins bins, int slices_per_bin, int cf_wi
   const uint32_t end = min(count, begin + kBinSlice);
   const uint32_t* rec = bins.records + (size_t)buffer * kCellFloats * bins.capacity;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double acc[2][kCellFloats - 1];
-  uint32_t observations[2] = {0u, 0u};
+  double acc[kSortCells][kCellFloats - 1];
+  uint32_t observations[kSortCells];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < kSortCells; ++h) {
+    observations[h] = 0u;
 #pragma unroll
     for (int c = 0; c < kCellFloats - 1; ++c) acc[h][c] = 0.0;
+  }
 
   for (uint32_t chunk = begin; chunk < end; chunk += kSortChunk) {
     const uint32_t chunk_n = min((uint32_t)kSortChunk, end - chunk);
@@ -365,9 +376,11 @@ intrinsics_bin_reduce_sorted_kernel(IntrBins bins, int slices_per_bin, int cf_wi
       if ((uint32_t)(tid + u * kSortBlock) < chunk_n) rank[u] = atomicAdd(start + within[u], 1u);
     }
     __syncthreads();
-    // exclusive scan of the 1024 counts: two per thread, an inclusive scan per wavefront, the wavefront totals through LDS
-    const uint32_t a = start[2 * tid], b = start[2 * tid + 1];
-    uint32_t inclusive = a + b;
+    // exclusive scan of the 1024 counts: kSortCells per thread, an inclusive scan per wavefront, the wavefront totals through LDS
+    uint32_t mine[kSortCells], sum_mine = 0u;
+#pragma unroll
+    for (int h = 0; h < kSortCells; ++h) { mine[h] = start[kSortCells * tid + h]; sum_mine += mine[h]; }
+    uint32_t inclusive = sum_mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t other = __shfl_up(inclusive, d);
@@ -378,10 +391,10 @@ intrinsics_bin_reduce_sorted_kernel(IntrBins bins, int slices_per_bin, int cf_wi
     uint32_t base = 0u;
 #pragma unroll
     for (int w = 0; w < kSortBlock / 64; ++w) base += w < wave ? wave_total[w] : 0u;
-    const uint32_t exclusive = base + inclusive - (a + b);
-    start[2 * tid] = exclusive;
-    start[2 * tid + 1] = exclusive + a;
-    if (tid == kSortBlock - 1) start[kBinCells] = exclusive + a + b;
+    uint32_t running = base + inclusive - sum_mine;
+#pragma unroll
+    for (int h = 0; h < kSortCells; ++h) { start[kSortCells * tid + h] = running; running += mine[h]; }
+    if (tid == kSortBlock - 1) start[kBinCells] = running;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kSortUnroll; ++u) {
@@ -393,8 +406,8 @@ intrinsics_bin_reduce_sorted_kernel(IntrBins bins, int slices_per_bin, int cf_wi
     }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int cell = tid + h * kSortBlock;
+    for (int h = 0; h < kSortCells; ++h) {
+      const int cell = tid + h * kSortBlock;   // neighbouring lanes, neighbouring cells: their records lie side by side
       const uint32_t j0 = start[cell], j1 = start[cell + 1];
       for (uint32_t j = j0; j < j1; ++j) {
 #pragma unroll
@@ -409,7 +422,7 @@ intrinsics_bin_reduce_sorted_kernel(IntrBins bins, int slices_per_bin, int cf_wi
   double* table = reinterpret_cast<double*>(sort_lds);
   uint32_t* counts = reinterpret_cast<uint32_t*>(table + (kCellFloats - 1) * kBinCells);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < kSortCells; ++h) {
     const int cell = tid + h * kSortBlock;
 #pragma unroll
     for (int c = 0; c < kCellFloats - 1; ++c) table[c * kBinCells + cell] = acc[h][c];
