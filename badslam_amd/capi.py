@@ -141,6 +141,8 @@ SIGNATURES = {
     "bahip_take_merged_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "bahip_lifecycle_batch_begin": (C.c_int, [C.c_void_p, C.POINTER(Surfels)]),
     "bahip_lifecycle_batch_end": (C.c_int, [C.c_void_p]),
+    "bahip_lifecycle_batch_set_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "bahip_lifecycle_batch_set_keyframes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "bahip_create_surfels_for_keyframes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                      C.POINTER(Surfels), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_create_surfels_for_keyframe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,

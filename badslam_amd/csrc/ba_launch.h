@@ -183,10 +183,22 @@ void launch_pcg_update_cfactors(hipStream_t st, const Intrinsics& in, uint32_t s
 // kernels_lifecycle.hip
 void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, int h);
 void launch_lifecycle_bounds(hipStream_t st, const SurfelsView& s, uint32_t tiles, void* spheres);   // bounding spheres of tiles [0, tiles)
-// spheres / bounded_tiles: the batch's tile bounds (kernels_lifecycle.hip: LifecycleBounds), or nullptr / 0
+// What a per-keyframe sweep of a lifecycle batch may skip (kernels_lifecycle.hip: LifecycleBounds): the bounding spheres of the
+// tiles [0, tiles) taken at the start of the batch, and -- when the batch knows its frames -- the list of those tiles this frame sees.
+struct LifecycleCull {
+  const void* spheres = nullptr;
+  uint32_t tiles = 0;
+  const uint32_t* list = nullptr;
+  uint32_t list_count = 0;
+};
+// counts (offsets == nullptr: cursors[f] += visible tiles of frame f) or lists (lists[offsets[f] + ...] = tile)
+void launch_lifecycle_visible_tiles(hipStream_t st, const Intrinsics& in, const float* frames_F, int num_frames, const void* spheres, uint32_t tiles,
+                                    const uint32_t* offsets, uint32_t* cursors, uint32_t* lists);
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                              const void* spheres, uint32_t bounded_tiles,
+                              const LifecycleCull& cull = LifecycleCull(),
                               const uint32_t* size_on_device = nullptr /* a creation batch: min(*size_on_device, s.size) surfels exist */);
+void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const LifecycleCull& cull = LifecycleCull());
 // a creation batch: appends at *size_on_device and advances it, or raises *capacity_exceeded and appends nothing
 void launch_create_append_batched(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const uint32_t* indices,
                                   const SurfelsView& s, uint32_t* size_on_device, uint32_t capacity, uint32_t* capacity_exceeded);

@@ -115,6 +115,14 @@ struct bahip_context {
   size_t lifecycle_bounds_capacity = 0;   // tiles
   uint32_t lifecycle_bounds_tiles = 0;    // 0: no batch open
   const void* lifecycle_bounds_data = nullptr;   // the surfel buffer they describe
+  // ... and, when the batch knows its frames (bahip_lifecycle_batch_set_frames), which of those tiles each frame can see
+  std::vector<float> lifecycle_frames;           // 12 floats per frame: frame_T_global as given
+  std::vector<uint32_t> lifecycle_list_offsets, lifecycle_list_counts;
+  float* dev_lifecycle_frames = nullptr;
+  uint32_t* dev_lifecycle_cursors = nullptr;     // [2 * capacity]: cursors, offsets
+  size_t lifecycle_frames_capacity = 0;
+  uint32_t* dev_lifecycle_lists = nullptr;
+  size_t lifecycle_lists_capacity = 0;
   void* dev_tile_bounds = nullptr;   // bounding sphere per 64-surfel tile, written by the first pose round of a phase
   size_t tile_bounds_bytes = 0;
   // heavy work first (wave_cull.h: scheduled_tile): candidates per tile counted by the first pose round of a phase over the
@@ -669,7 +677,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   if (ctx->pinned_f) hipHostFree(ctx->pinned_f);
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
-  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_lifecycle_bounds); hipFree(ctx->dev_window);
+  hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_lifecycle_bounds); hipFree(ctx->dev_lifecycle_frames); hipFree(ctx->dev_lifecycle_cursors); hipFree(ctx->dev_lifecycle_lists); hipFree(ctx->dev_window);
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl); hipFree(ctx->kf_partials);
   hipFree(ctx->dev_tile_cost); hipFree(ctx->dev_tile_order);
@@ -1395,6 +1403,25 @@ static int supporting_view(uint32_t* const* supporting, uint32_t pitch, Supporti
   return 0;
 }
 
+// What the per-keyframe sweeps of an open lifecycle batch may skip for the frame with this frame_T_global (ba_launch.h: LifecycleCull).
+// The bounds hold for the buffer they were taken from, while it only grows; the list is found by the frame's 12 coefficients.
+static LifecycleCull lifecycle_cull_for(const bahip_context* ctx, const bahip_surfels* surfels, const float* frame_T_global) {
+  LifecycleCull cull;
+  if (!ctx->lifecycle_bounds_tiles || ctx->lifecycle_bounds_data != surfels->data || (uint64_t)ctx->lifecycle_bounds_tiles * 64 > surfels->surfels_size)
+    return cull;
+  cull.spheres = ctx->dev_lifecycle_bounds;
+  cull.tiles = ctx->lifecycle_bounds_tiles;
+  const size_t n = ctx->lifecycle_list_counts.size();
+  for (size_t f = 0; f < n; ++f) {
+    if (memcmp(&ctx->lifecycle_frames[12 * f], frame_T_global, 12 * sizeof(float)) == 0) {
+      cull.list = ctx->dev_lifecycle_lists + ctx->lifecycle_list_offsets[f];
+      cull.list_count = ctx->lifecycle_list_counts[f];
+      break;
+    }
+  }
+  return cull;
+}
+
 static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_dist_factor, const KfEntry& e,
                                      const bahip_surfels* surfels, const SupportingView& sup, uint32_t* merged_count_out) {
   // The reference clears full-resolution planes (B/kernel_supporting_surfels.cc:58-60); only the
@@ -1404,11 +1431,8 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
   if (merged_count_out) *merged_count_out = 0;
   if (surfels->surfels_size == 0) return 0;
   const SurfelsView s = make_view(surfels);
-  // a batch's tile bounds hold for the buffer they were taken from, while it only grows
-  const bool bounded = ctx->lifecycle_bounds_tiles && ctx->lifecycle_bounds_data == surfels->data && (uint64_t)ctx->lifecycle_bounds_tiles * 64 <= s.size;
-  const void* spheres = bounded ? ctx->dev_lifecycle_bounds : nullptr;
-  const uint32_t bounded_tiles = bounded ? ctx->lifecycle_bounds_tiles : 0u;
-  launch_supporting_insert(ctx->stream, ctx->in, e, s, sup, spheres, bounded_tiles);
+  const LifecycleCull cull = lifecycle_cull_for(ctx, surfels, e.pose.F);
+  launch_supporting_insert(ctx->stream, ctx->in, e, s, sup, cull);
   CHECK_LAUNCH();
   if (merge) {
     const float cell = (float)ctx->in.cell;
@@ -1417,7 +1441,7 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
     uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
     if (merged_count_out) {
       HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
-      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter), spheres, bounded_tiles);
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter), cull);
       CHECK_LAUNCH();
       HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1425,7 +1449,7 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
     } else {
       // deferred count: a batch of keyframes merges without a read-back and a stream synchronisation per keyframe; the total
       // waits in dev_counter[3] for bahip_take_merged_count
-      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3, spheres, bounded_tiles);
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3, cull);
       CHECK_LAUNCH();
     }
   }
@@ -1448,6 +1472,7 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
 int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels) {
   REQUIRE(surfels != nullptr, "bahip_lifecycle_batch_begin: NULL argument");
   ctx->lifecycle_bounds_tiles = 0;
+  ctx->lifecycle_frames.clear(); ctx->lifecycle_list_offsets.clear(); ctx->lifecycle_list_counts.clear();
   const uint32_t tiles = surfels->surfels_size / 64;   // whole tiles only: what is appended later starts in the tile behind them
   if (tiles == 0) return 0;
   if (tiles > ctx->lifecycle_bounds_capacity) {
@@ -1463,6 +1488,66 @@ int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels
   ctx->lifecycle_bounds_tiles = tiles;
   ctx->lifecycle_bounds_data = surfels->data;
   return 0;
+}
+
+int bahip_lifecycle_batch_set_frames(bahip_context* ctx, const float* frame_T_global_3x4, int num_frames) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(num_frames >= 0 && (num_frames == 0 || frame_T_global_3x4 != nullptr), "bahip_lifecycle_batch_set_frames: NULL argument");
+  ctx->lifecycle_frames.clear(); ctx->lifecycle_list_offsets.clear(); ctx->lifecycle_list_counts.clear();
+  const uint32_t tiles = ctx->lifecycle_bounds_tiles;
+  if (tiles == 0 || num_frames == 0) return 0;   // no batch open (or an empty cloud): the sweeps take everything
+  hipStream_t st = ctx->stream;
+  if ((size_t)num_frames > ctx->lifecycle_frames_capacity) {
+    float* F = nullptr; uint32_t* cursors = nullptr;
+    const size_t capacity = (size_t)num_frames + 64;
+    if (hipMalloc(&F, capacity * 12 * sizeof(float)) != hipSuccess || hipMalloc(&cursors, 2 * capacity * sizeof(uint32_t)) != hipSuccess) {
+      hipFree(F); hipFree(cursors);
+      return fail("allocation of the lifecycle batch's frame table failed", __FILE__, __LINE__);
+    }
+    hipFree(ctx->dev_lifecycle_frames); hipFree(ctx->dev_lifecycle_cursors);
+    ctx->dev_lifecycle_frames = F; ctx->dev_lifecycle_cursors = cursors;
+    ctx->lifecycle_frames_capacity = capacity;
+  }
+  uint32_t* cursors = ctx->dev_lifecycle_cursors;
+  uint32_t* offsets = ctx->dev_lifecycle_cursors + ctx->lifecycle_frames_capacity;
+  std::vector<uint32_t> counts(num_frames), starts(num_frames);
+  HIP_TRY(hipMemcpyAsync(ctx->dev_lifecycle_frames, frame_T_global_3x4, (size_t)num_frames * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)num_frames * sizeof(uint32_t), st));
+  launch_lifecycle_visible_tiles(st, ctx->in, ctx->dev_lifecycle_frames, num_frames, ctx->dev_lifecycle_bounds, tiles, nullptr, cursors, nullptr);
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(counts.data(), cursors, (size_t)num_frames * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  size_t total = 0;
+  for (int f = 0; f < num_frames; ++f) { starts[f] = (uint32_t)total; total += counts[f]; }
+  if (total > ctx->lifecycle_lists_capacity) {
+    uint32_t* lists = nullptr;
+    const size_t capacity = total + total / 4 + 4096;
+    HIP_TRY(hipMalloc(&lists, capacity * sizeof(uint32_t)));
+    hipFree(ctx->dev_lifecycle_lists);
+    ctx->dev_lifecycle_lists = lists;
+    ctx->lifecycle_lists_capacity = capacity;
+  }
+  if (total > 0) {
+    HIP_TRY(hipMemcpyAsync(offsets, starts.data(), (size_t)num_frames * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)num_frames * sizeof(uint32_t), st));
+    launch_lifecycle_visible_tiles(st, ctx->in, ctx->dev_lifecycle_frames, num_frames, ctx->dev_lifecycle_bounds, tiles, offsets, cursors, ctx->dev_lifecycle_lists);
+    CHECK_LAUNCH();
+    HIP_TRY(hipStreamSynchronize(st));   // `starts` is pageable and goes out of scope
+  }
+  ctx->lifecycle_frames.assign(frame_T_global_3x4, frame_T_global_3x4 + (size_t)num_frames * 12);
+  ctx->lifecycle_list_offsets = starts;
+  ctx->lifecycle_list_counts = counts;
+  return 0;
+}
+
+int bahip_lifecycle_batch_set_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes) {
+  REQUIRE(num_keyframes >= 0 && (num_keyframes == 0 || keyframe_indices != nullptr), "bahip_lifecycle_batch_set_keyframes: NULL argument");
+  std::vector<float> F(12 * (size_t)num_keyframes);
+  for (int j = 0; j < num_keyframes; ++j) {
+    REQUIRE(keyframe_indices[j] >= 0 && keyframe_indices[j] < ctx->num_kfs, "keyframe index out of range");
+    memcpy(&F[12 * (size_t)j], ctx->host_kfs[keyframe_indices[j]].pose.F, 12 * sizeof(float));
+  }
+  return bahip_lifecycle_batch_set_frames(ctx, F.data(), num_keyframes);
 }
 
 int bahip_lifecycle_batch_end(bahip_context* ctx) {
@@ -1609,9 +1694,7 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
     bound.surfels_size = (uint32_t)std::min<uint64_t>(surfels->capacity, (uint64_t)surfels->surfels_size + (uint64_t)j * cells);
     const SurfelsView s = make_view(&bound);
     launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
-    const bool bounded = ctx->lifecycle_bounds_tiles && ctx->lifecycle_bounds_data == surfels->data &&
-                         (uint64_t)ctx->lifecycle_bounds_tiles * 64 <= surfels->surfels_size;
-    launch_supporting_insert(st, ctx->in, e, s, sup, bounded ? ctx->dev_lifecycle_bounds : nullptr, bounded ? ctx->lifecycle_bounds_tiles : 0u, size_on_device);
+    launch_supporting_insert(st, ctx->in, e, s, sup, lifecycle_cull_for(ctx, surfels, e.pose.F), size_on_device);
     HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));
     launch_create_flag(st, ctx->in, e, sup, ctx->dev_flags);
     const int n_covis = covis_offsets[j + 1] - covis_offsets[j];

@@ -39,12 +39,49 @@ supporting_fill_kernel(SupportingView sup, int width, int height) {
 struct LifecycleBounds {
   const WaveBounds* spheres;
   uint32_t tiles;
+  // (when the batch knows its keyframes: bahip_lifecycle_batch_set_frames) the bounded tiles THIS keyframe can see, in no particular
+  // order; the sweep then runs over the list and, behind it, over the tiles appended since the bounds were taken -- a launch of a few
+  // hundred workgroups instead of one over the whole cloud whose wavefronts nearly all return at their bound
+  const uint32_t* list;
+  uint32_t list_count;
 };
-__device__ __forceinline__ bool lifecycle_tile_culled(const Intrinsics& in, const KfEntry& frame, const LifecycleBounds& lb, uint32_t i) {
-  const uint32_t tile = i >> 6;   // wave-uniform: kLcBlock is a multiple of 64
-  if (tile >= lb.tiles) return false;
+// The surfel of this thread, or false if there is none.  Wave-uniform tile; without a list: the plain index and the bound test.
+__device__ __forceinline__ bool lifecycle_surfel(const Intrinsics& in, const KfEntry& frame, const LifecycleBounds& lb, uint32_t size, uint32_t* index) {
+  const uint32_t t = blockIdx.x * kLcBlock + threadIdx.x;
+  if (lb.list) {
+    const uint32_t w = t >> 6;
+    const uint32_t tile = w < lb.list_count ? lb.list[w] : lb.tiles + (w - lb.list_count);
+    *index = tile * 64u + (t & 63u);
+    return *index < size;
+  }
+  *index = t;
+  if (t >= size) return false;
+  const uint32_t tile = t >> 6;   // wave-uniform: kLcBlock is a multiple of 64
+  if (tile >= lb.tiles) return true;
   const WaveBounds wb = lb.spheres[tile];
-  return !sphere_may_project(in, frame.pose.F, wb);
+  return sphere_may_project(in, frame.pose.F, wb);
+}
+// Which bounded tiles each frame of a batch can see: counts first (the host turns them into offsets), then the lists.
+__global__ void __launch_bounds__(kLcBlock)
+lifecycle_visible_tiles_kernel(Intrinsics in, const float* __restrict__ frames_F /* [num_frames][12] */, int num_frames,
+                               const WaveBounds* __restrict__ spheres, uint32_t tiles, const uint32_t* __restrict__ offsets /* nullptr: count only */,
+                               uint32_t* __restrict__ cursors /* [num_frames], zeroed */, uint32_t* __restrict__ lists) {
+  const uint32_t tile = blockIdx.x * kLcBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  WaveBounds wb;
+  wb.cx = wb.cy = wb.cz = 0.f; wb.r = -1.f;
+  if (tile < tiles) wb = spheres[tile];
+  for (int f = 0; f < num_frames; ++f) {
+    const bool visible = sphere_may_project(in, frames_F + 12 * f, wb);   // (r < 0: never)
+    const unsigned long long m = __ballot(visible);
+    if (!m) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cursors[f], (uint32_t)__popcll(m));
+    if (offsets) {
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (visible) lists[offsets[f] + base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tile;
+    }
+  }
 }
 __global__ void __launch_bounds__(kLcBlock)
 lifecycle_bounds_kernel(SurfelsView s, uint32_t tiles, WaveBounds* __restrict__ spheres) {
@@ -59,9 +96,8 @@ lifecycle_bounds_kernel(SurfelsView s, uint32_t tiles, WaveBounds* __restrict__ 
 __global__ void __launch_bounds__(kLcBlock)
 supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, LifecycleBounds lb,
                          const uint32_t* __restrict__ size_on_device /* a creation batch: the cloud's current size lives on the device, s.size bounds it */) {
-  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
-  if (i >= (size_on_device ? min(*size_on_device, s.size) : s.size)) return;
-  if (lifecycle_tile_culled(in, frame, lb, i)) return;
+  uint32_t i;
+  if (!lifecycle_surfel(in, frame, lb, size_on_device ? min(*size_on_device, s.size) : s.size, &i)) return;
   Assoc r;
   if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
   const int cx = r.px / in.cell, cy = r.py / in.cell;
@@ -88,9 +124,8 @@ __device__ __forceinline__ bool merge_test(const SurfelsView& s, uint32_t a, uin
 __global__ void __launch_bounds__(kLcBlock)
 merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, float cell_merge_dist_sq,
                     float cos_thr, uint32_t* __restrict__ flags, LifecycleBounds lb) {
-  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
-  if (i >= s.size) return;
-  if (lifecycle_tile_culled(in, frame, lb, i)) return;   // merge_apply_kernel skips the same tiles: their flags are never read
+  uint32_t i;
+  if (!lifecycle_surfel(in, frame, lb, s.size, &i)) return;   // merge_apply_kernel visits the same surfels: the other flags are never read
   flags[i] = 0;
   Assoc r;
   if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
@@ -118,8 +153,8 @@ merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView 
 __global__ void __launch_bounds__(kLcBlock)
 merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ flags, uint32_t* __restrict__ deleted_count,
                    LifecycleBounds lb) {
-  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
-  if (i >= s.size || lifecycle_tile_culled(in, frame, lb, i)) return;   // wave-uniform beyond the last tile's tail lanes (ballot below: active lanes)
+  uint32_t i;
+  if (!lifecycle_surfel(in, frame, lb, s.size, &i)) return;   // (wave-uniform but for the last tile's tail lanes; the ballot below counts active lanes)
   const bool del = flags[i];
   if (del) s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits);
   const unsigned long long m = __ballot(del);
@@ -395,17 +430,40 @@ void launch_supporting_fill(hipStream_t st, const SupportingView& sup, int w, in
 void launch_lifecycle_bounds(hipStream_t st, const SurfelsView& s, uint32_t tiles, void* spheres) {
   if (tiles) hipLaunchKernelGGL(lifecycle_bounds_kernel, dim3(g1(tiles * 64u)), dim3(kLcBlock), 0, st, s, tiles, static_cast<WaveBounds*>(spheres));
 }
+static LifecycleBounds device_cull(const LifecycleCull& cull) {
+  LifecycleBounds lb;
+  lb.spheres = static_cast<const WaveBounds*>(cull.spheres);
+  lb.tiles = cull.spheres ? cull.tiles : 0u;
+  lb.list = cull.spheres ? cull.list : nullptr;
+  lb.list_count = lb.list ? cull.list_count : 0u;
+  return lb;
+}
+// workgroups of a per-keyframe sweep: over everything, or over the keyframe's list and the tiles behind the bounded ones
+static unsigned sweep_groups(const LifecycleBounds& lb, uint32_t size) {
+  if (!lb.list) return g1(size);
+  const uint32_t all_tiles = (size + 63u) / 64u, tail = all_tiles > lb.tiles ? all_tiles - lb.tiles : 0u;
+  return g1((lb.list_count + tail) * 64u);
+}
+void launch_lifecycle_visible_tiles(hipStream_t st, const Intrinsics& in, const float* frames_F, int num_frames, const void* spheres, uint32_t tiles,
+                                    const uint32_t* offsets, uint32_t* cursors, uint32_t* lists) {
+  if (tiles && num_frames)
+    hipLaunchKernelGGL(lifecycle_visible_tiles_kernel, dim3(g1(tiles)), dim3(kLcBlock), 0, st, in, frames_F, num_frames,
+                       static_cast<const WaveBounds*>(spheres), tiles, offsets, cursors, lists);
+}
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                              const void* spheres, uint32_t bounded_tiles, const uint32_t* size_on_device) {
-  const LifecycleBounds lb{static_cast<const WaveBounds*>(spheres), spheres ? bounded_tiles : 0u};
-  if (s.size) hipLaunchKernelGGL(supporting_insert_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, lb, size_on_device);
+                              const LifecycleCull& cull, const uint32_t* size_on_device) {
+  const LifecycleBounds lb = device_cull(cull);
+  const unsigned groups = sweep_groups(lb, s.size);
+  if (s.size && groups) hipLaunchKernelGGL(supporting_insert_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, lb, size_on_device);
 }
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const void* spheres, uint32_t bounded_tiles) {
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const LifecycleCull& cull) {
   if (!s.size) return;
-  const LifecycleBounds lb{static_cast<const WaveBounds*>(spheres), spheres ? bounded_tiles : 0u};
-  hipLaunchKernelGGL(merge_decide_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, lb);
-  hipLaunchKernelGGL(merge_apply_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, frame, s, flags, deleted_count, lb);
+  const LifecycleBounds lb = device_cull(cull);
+  const unsigned groups = sweep_groups(lb, s.size);
+  if (!groups) return;
+  hipLaunchKernelGGL(merge_decide_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, lb);
+  hipLaunchKernelGGL(merge_apply_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, flags, deleted_count, lb);
 }
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags) {
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags);

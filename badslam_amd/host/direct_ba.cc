@@ -301,6 +301,7 @@ void DirectBA::CreateSurfelsForKeyframes(hipStream_t stream, bool filter_new_sur
   for (int i = 0; i < kMergeBufferCount; ++i) sup[i] = supporting_surfels_[i]->ToCUDA().address();
   const bahip_surfels s = SurfelsStruct();
   uint32_t new_surfel_count = 0;
+  BAHIP_CHECKED_CALL(bahip_lifecycle_batch_set_keyframes(ctx_, bound.data(), (int)bound.size()));   // (nothing without an open batch)
   BAHIP_CHECKED_CALL(bahip_create_surfels_for_keyframes(ctx_, bound.data(), (int)bound.size(), filter_new_surfels ? 1 : 0, GetMinObservationCount(),
                                                         offsets.data(), covis.data(), &s, sup, (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(),
                                                         &new_surfel_count));
@@ -331,6 +332,24 @@ DirectBA::LifecycleBatch::LifecycleBatch(DirectBA* ba) : ba_(ba) {
   BAHIP_CHECKED_CALL(bahip_lifecycle_batch_begin(ba_->ctx_, &s));
 }
 DirectBA::LifecycleBatch::~LifecycleBatch() { bahip_lifecycle_batch_end(ba_->ctx_); }
+
+// The merges of a batch of keyframes (the BA loop's merge pass, the end tasks'): one lifecycle batch that knows its frames -- each
+// keyframe's sweeps then run over the tiles it can see --, counts deferred to one read at the end.
+void DirectBA::MergeForKeyframes(const vector<u32>& keyframe_ids) {
+  vector<float> frames;
+  for (u32 id : keyframe_ids) {
+    if (!keyframes_[id]) continue;
+    float F[12];
+    keyframes_[id]->frame_T_global().matrix3x4(F);   // what MergeForKeyframe passes: the list is found by these coefficients
+    frames.insert(frames.end(), F, F + 12);
+  }
+  if (frames.empty()) return;
+  LifecycleBatch batch(this);
+  BAHIP_CHECKED_CALL(bahip_lifecycle_batch_set_frames(ctx_, frames.data(), (int)(frames.size() / 12)));
+  for (u32 id : keyframe_ids)
+    if (keyframes_[id]) MergeForKeyframe(*keyframes_[id], /*defer_count*/ true);
+  TakeDeferredMergeCount();
+}
 
 // The merges of a batch of keyframes run back to back on the stream; their total is read once, before the compaction that needs it
 // (the reference reads one count per keyframe, B/direct_ba.cc:618-622 -- the buffer contents are the same either way).
@@ -399,13 +418,10 @@ void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_update
   WholeCloudScope whole_cloud(this, stream);
   BindScene(stream);
   if (do_surfel_updates) {
-    std::unique_ptr<LifecycleBatch> batch(new LifecycleBatch(this));
-    for (shared_ptr<Keyframe>& keyframe : keyframes_) {
-      if (!keyframe) continue;
-      if (keyframe->last_active_in_ba_iteration() == ba_iteration_count_) MergeForKeyframe(*keyframe, /*defer_count*/ true);
-    }
-    TakeDeferredMergeCount();
-    batch.reset();
+    vector<u32> active_this_call;
+    for (shared_ptr<Keyframe>& keyframe : keyframes_)
+      if (keyframe && keyframe->last_active_in_ba_iteration() == ba_iteration_count_) active_this_call.push_back(keyframe->id());
+    MergeForKeyframes(active_this_call);
   }
   const bahip_surfels s = SurfelsStruct();
   uint32_t deleted = 0;
@@ -627,12 +643,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     // --- surfel merge + compaction ---
     if (do_surfel_updates && !keyframes_with_new_surfels.empty()) {
       WholeCloudScope whole_cloud(this, stream);
-      {
-        LifecycleBatch batch(this);
-        for (u32 keyframe_id : keyframes_with_new_surfels)
-          if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
-        TakeDeferredMergeCount();
-      }
+      MergeForKeyframes(keyframes_with_new_surfels);
       {
         const bahip_surfels s = SurfelsStruct();
         unsorted_surfels_ += surfels_size_ - surfel_count_;
@@ -760,12 +771,7 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
   auto merge_and_compact = [&]() {
     if (keyframes_with_new_surfels.empty()) return;
     WholeCloudScope whole_cloud(this, stream);
-    {
-      LifecycleBatch batch(this);
-      for (u32 keyframe_id : keyframes_with_new_surfels)
-        if (keyframes_[keyframe_id]) MergeForKeyframe(*keyframes_[keyframe_id], /*defer_count*/ true);
-      TakeDeferredMergeCount();
-    }
+    MergeForKeyframes(keyframes_with_new_surfels);
     if (!keyframes_with_new_surfels.empty()) {
       const bahip_surfels s = SurfelsStruct();
       unsorted_surfels_ += surfels_size_ - surfel_count_;

@@ -177,6 +177,7 @@ class DirectBA {
 
   void MergeForKeyframe(const Keyframe& keyframe, bool defer_count = false);
   void TakeDeferredMergeCount();
+  void MergeForKeyframes(const vector<u32>& keyframe_ids);
   void CreateSurfelsForKeyframes(hipStream_t stream, bool filter_new_surfels, const vector<u32>& keyframe_ids);
   bool batched_creation_ = true;
   class LifecycleBatch {   // RAII: bahip_lifecycle_batch_begin / _end around the creations or merges of a batch of keyframes

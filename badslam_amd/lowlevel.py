@@ -199,10 +199,17 @@ class Scene:
         return n.value
 
     @contextlib.contextmanager
-    def lifecycle_batch(self):
-        """bahip_lifecycle_batch_begin / _end around the creations or merges of a batch of keyframes."""
+    def lifecycle_batch(self, keyframes=None, frames=None):
+        """bahip_lifecycle_batch_begin / _end around the creations or merges of a batch of keyframes; keyframes (bound indices) or
+        frames (frame_T_global 3x4 each): the batch knows its frames and keeps a list of visible tiles for each."""
         s = self.surfels_struct()
         capi.check(self.lib.bahip_lifecycle_batch_begin(self.ctx.handle, C.byref(s)))
+        if keyframes is not None:
+            self.bind_keyframes()
+            capi.check(self.lib.bahip_lifecycle_batch_set_keyframes(self.ctx.handle, (C.c_int * max(1, len(keyframes)))(*keyframes), len(keyframes)))
+        if frames is not None:
+            flat = [float(v) for F in frames for v in F]
+            capi.check(self.lib.bahip_lifecycle_batch_set_frames(self.ctx.handle, (C.c_float * max(1, len(flat)))(*flat), len(frames)))
         try:
             yield
         finally:

@@ -320,6 +320,12 @@ int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out);
  * sort and the geometry step end the batch by themselves.  Ours: the reference sweeps the whole cloud per keyframe
  * (B/kernel_supporting_surfels.cu:36-60). */
 int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels);
+/* Optional, after _begin: the frames of the batch -- frame_T_global as 3x4 row-major matrices, exactly the 12 coefficients the
+ * per-keyframe calls will be given (bahip_determine_supporting_surfels), or bound keyframe indices (bahip_create_surfels_for_
+ * keyframe[s]).  The batch then knows which tiles each frame can see and that frame's sweeps run over those tiles only (a launch of a
+ * few hundred workgroups instead of one over the whole cloud).  A frame that is not found sweeps with the per-tile test as before. */
+int bahip_lifecycle_batch_set_frames(bahip_context* ctx, const float* frame_T_global_3x4, int num_frames);
+int bahip_lifecycle_batch_set_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes);
 int bahip_lifecycle_batch_end(bahip_context* ctx);
 /* B/kernels.h CreateSurfelsForKeyframeCUDA (B/kernel_create_surfels.cc:40-183), including the
  * DetermineSupportingSurfelsCUDA call that DirectBA::CreateSurfelsForKeyframe issues first

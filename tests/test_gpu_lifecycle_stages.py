@@ -49,7 +49,7 @@ def test_supporting_surfels_lists_bit_exact(world):
         assert filled[0] > 5000 and filled[1] > 100, filled           # second slots are in use: cells seen by several surfels
 
 
-@pytest.mark.parametrize("batch", [False, True], ids=["per keyframe", "lifecycle batch"])
+@pytest.mark.parametrize("batch", [False, True, "frames"], ids=["per keyframe", "lifecycle batch", "lifecycle batch that knows its frames"])
 def test_merge_bit_exact(world, batch):
     """batch: inside bahip_lifecycle_batch_begin / _end the sweeps skip the tiles a keyframe cannot see (here: a copy of the cloud
     50 m away, in the middle of the buffer) -- the oracle knows no such bracket and must see the same buffer."""
@@ -69,7 +69,8 @@ def test_merge_bit_exact(world, batch):
     both = np.concatenate([data, dup], axis=1)
     _sync(orc, g, both)
     total_merged = 0
-    with (g.lifecycle_batch() if batch else contextlib.nullcontext()):
+    frames = [np.array(list(orc.keyframes[k].frame_T_global), np.float32) for k in (0, 1, 3)] if batch == "frames" else None
+    with (g.lifecycle_batch(frames=frames) if batch else contextlib.nullcontext()):
         for k in (0, 1, 3):
             F = np.array(list(orc.keyframes[k].frame_T_global), np.float32)
             before = int(orc.surfels.surfel_count)
@@ -96,7 +97,7 @@ def test_merge_bit_exact(world, batch):
     assert not np.any(_rows(orc.surfel_data[:, :m])[0] == NAN_BITS)
 
 
-@pytest.mark.parametrize("batch", [False, True], ids=["per keyframe", "lifecycle batch"])
+@pytest.mark.parametrize("batch", [False, True, "frames"], ids=["per keyframe", "lifecycle batch", "lifecycle batch that knows its frames"])
 @pytest.mark.parametrize("min_obs", [1, 2, 3])
 def test_filtered_creation_bit_exact(min_obs, batch):
     """CreateSurfelsForKeyframe with filter_new_surfels: observation / free-space-violation counting over the co-visible
@@ -112,7 +113,7 @@ def test_filtered_creation_bit_exact(min_obs, batch):
     import contextlib
     for k, covis in plan:
         # (a batch opened when the cloud already holds surfels: the bounded tiles, and behind them what this batch appends)
-        with (g.lifecycle_batch() if batch and k >= 2 else contextlib.nullcontext()):
+        with (g.lifecycle_batch(keyframes=[k] if batch == "frames" else None) if batch and k >= 2 else contextlib.nullcontext()):
             n_ref = orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis)
             n_got = g.create_surfels_for_keyframe(k, filter_new_surfels=True, min_observation_count=min_obs, covis=covis)
         assert n_got == n_ref, (k, n_got, n_ref)
@@ -139,7 +140,7 @@ def test_creation_batch_is_the_sequence_of_creations(min_obs):
     first, second = [(0, [1, 2, 3, 4]), (1, [0, 2])], [(2, [4]), (3, [0, 1, 2, 4]), (4, [])]
     for plan in (first, second):
         n_ref = sum(orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis) for k, covis in plan)
-        with g.lifecycle_batch():
+        with g.lifecycle_batch(keyframes=[k for k, _ in plan] if min_obs == 2 else None):     # (with and without per-frame tile lists)
             n_got = g.create_surfels_for_keyframes(plan, filter_new_surfels=True, min_observation_count=min_obs)
         assert n_got == n_ref > 0, (n_got, n_ref)
         assert g.surfels_size == orc.surfels_size
