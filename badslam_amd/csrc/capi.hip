@@ -1797,17 +1797,27 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
       HIP_TRY(hipHostMalloc(&ctx->intr_bin_counts_host, sizeof(uint32_t) * (size_t)num_bins));
       ctx->intr_bin_count = num_bins;
     }
-    uint64_t want = ctx->intr_bin_wanted;
+    // Keep what there is unless the previous call OVERFLOWED it (intr_bin_wanted is raised only then).  Round 4, configs[4]: sized
+    // as "the previous call's largest count + 25 %" the request crept up by 64 records per call while the poses converged, and each
+    // time 53 GB of record buffers were freed and allocated again -- 1.5 to 2.5 s per reallocation, in whichever call it fell
+    // (gpurun_out/r4_call30: 3.4 BA iterations/s with one of them inside the timed call, 14.4 without).
+    uint64_t want = std::max<uint64_t>(ctx->intr_bin_capacity, ctx->intr_bin_wanted);
     if (!want) want = (uint64_t)surfels->surfels_size * (uint64_t)std::min(ctx->num_kfs, 16) * 2 / (uint64_t)num_bins + 4096;
     if (ctx->intr_bin_forced >= 0) want = (uint64_t)ctx->intr_bin_forced;
     const uint64_t limit = (96ull << 30) / (intrinsics_bin_record_bytes() * (uint64_t)num_bins);   // at most 96 GB of records
     want = std::min(want, limit);
     if (want > ctx->intr_bin_capacity || (ctx->intr_bin_forced >= 0 && want != ctx->intr_bin_capacity)) {
+      static const bool host_timing = getenv("BADSLAM_HOST_TIMING") != nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
       hipFree(ctx->intr_bin_records);
       ctx->intr_bin_records = nullptr; ctx->intr_bin_capacity = 0;
       const uint64_t cap = (want + 63) / 64 * 64;
       if (cap) HIP_TRY(hipMalloc(&ctx->intr_bin_records, intrinsics_bin_record_bytes() * cap * (uint64_t)num_bins));
       ctx->intr_bin_capacity = (uint32_t)cap;
+      if (host_timing)
+        fprintf(stderr, "[intrinsics record buffers] %d buffers x %llu records = %.2f GB (re)allocated in %.1f ms\n", num_bins, (unsigned long long)cap,
+                (double)(intrinsics_bin_record_bytes() * cap * (uint64_t)num_bins) / 1e9,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     bins.cursors = ctx->intr_bin_cursors; bins.records = ctx->intr_bin_records; bins.capacity = ctx->intr_bin_capacity;
   }
@@ -1829,11 +1839,17 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   CHECK_LAUNCH();
   timer_end(ctx, 4);   // the sweep and the Schur complement; the 5x5 / 4x4 solves and the cfactor update that follow are tiny
   HIP_TRY(hipMemcpyAsync(ctx->pinned_f, glob, 34 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  {
+    static const bool host_timing = getenv("BADSLAM_HOST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (host_timing && waited > 100.0) fprintf(stderr, "[intrinsics step] waited %.1f ms for the stream (capacity %u per buffer)\n", waited, bins.capacity);
+  }
   if (bins.capacity) {
     uint32_t most = 0;
     for (int b = 0; b < num_bins; ++b) most = std::max(most, ctx->intr_bin_counts_host[b]);
-    ctx->intr_bin_wanted = std::max(ctx->intr_bin_wanted, most + most / 4 + 1024);
+    if (most > bins.capacity) ctx->intr_bin_wanted = std::max(ctx->intr_bin_wanted, most + most / 4 + 1024);   // the next call regrows
     ctx->intr_bin_last_overflow = most > bins.capacity ? 1 : 0;
   }
   const float* g = ctx->pinned_f;
