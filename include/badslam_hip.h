@@ -463,8 +463,9 @@ int bahip_debug_set_tile_order(int enabled);
  * receives up to max_words of it: [0] heavy tiles, [8 .. 8 + 1024) their list, then one tile per regular position (padded_tiles
  * words, a permutation of the tiles), then one flag per tile (non-zero = in the heavy list). */
 int bahip_debug_read_tile_schedule(bahip_context* ctx, uint32_t* padded_tiles_out, uint32_t* words_out, size_t max_words);
-/* The intrinsics sweep appends its per-cell records to buffers sized from the previous call's demand (kernels_intrinsics.hip);
- * records that do not fit go out as atomics, with the same result.  records_per_block >= 0 fixes the size (0: no buffers, < 0:
+/* The intrinsics sweep appends its per-cell records to buffers that keep their size unless a call overflows them (the next call
+ * then takes that call's largest demand + 25 %; the first call an estimate) (kernels_intrinsics.hip); records that do not fit go
+ * out as atomics, with the same result.  records_per_block >= 0 fixes the size (0: no buffers, < 0:
  * automatic again) -- for the tests of the overflow path and for A/B timing.  bahip_debug_intrinsics_bin_stats: capacity and the
  * largest / total demand of the last call. */
 int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block);
@@ -478,8 +479,9 @@ int bahip_debug_set_pose_lds_items(int items);
 int bahip_debug_set_pose_lds_shape(int waves, int parts_shift);
 /* Gauss-Newton rounds queued ahead per host wait (bahip_estimate_*: the later rounds of a phase read the number of work items
  * still iterating from device memory and do nothing when it is zero, so the host need not wait for a round before it queues
- * the next): 0 = as many as the previous phase needed (default), n >= 1 = exactly n (1: wait after every round, the round-3
- * behaviour).  Results do not depend on it. */
+ * the next): 0 = as many as the previous phase needed (default; in bahip_alternating_iterations: what the last phases needed,
+ * one less per following iteration down to two), n >= 1 = exactly n (1: wait after every round, the round-3 behaviour).  Results
+ * do not depend on it. */
 int bahip_debug_set_pose_rounds_ahead(int rounds);
 /* 1: in bahip_alternating_iterations the launch that ends an iteration's pose phase also opens the next iteration (activation
  * window / propagation, work items) when the keyframe table has at most 1024 entries; 0 (default -- the fused launch measured
