@@ -187,6 +187,7 @@ SIGNATURES = {
     "bahip_debug_set_device_loop": (C.c_int, [C.c_int]),
     "bahip_debug_set_pcg_lds_form": (C.c_int, [C.c_int]),
     "bahip_debug_pose_form_launches": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
+    "bahip_debug_pose_kernel_dispatches": (C.c_int, [C.POINTER(C.c_longlong)]),
     "bahip_debug_pose_limbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_longlong)]),
     "bahip_debug_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
     "bahip_debug_read_pattern": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int]),

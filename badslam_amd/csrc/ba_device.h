@@ -60,11 +60,17 @@ __device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {
 // for EVERY binary32 significand (2^23 values per binade) on the device, so parity with the oracle's `1.f / x` and
 // `sqrtf(x)` stays bit for bit.  Domain: |x| and 1 / |x| normal (2^-126 < |x| < 2^126), or 0 / inf / NaN, which get the
 // hardware's IEEE result.
+// (Round 5 measured what an instruction of each class costs -- scripts/microbench/inst_cost.hip, profiles/r5_inst_cost.txt: a VOP2
+// binary32 op on VGPRs 1.6 cycles of a SIMD, v_fma_f32 1.8, a conversion / compare / 24-bit multiply 2.6, three-operand integer
+// ops, selects, v_med3 / v_min3, DPP forms and anything with an SGPR source 2.6 - 2.8, v_rcp / v_sqrt / v_permlane*_swap 5.1 -- and
+// which respellings pay on the sweeps: see DESIGN.md section 5, "Round 5".)
 __device__ __forceinline__ float rcp_exact(float x) {
   const float y0 = __builtin_amdgcn_rcpf(x);
   const float e = __builtin_fmaf(-x, y0, 1.f);
   const float y1 = __builtin_fmaf(e, y0, y0);
-  return (e == e) ? y1 : y0;            // x = 0, inf, NaN: e is NaN and v_rcp_f32 already returned inf, 0, NaN
+  // x = 0, inf, NaN (y1 is NaN there): v_div_fixup_f32 substitutes the IEEE quotient 1 / x (inf, 0, NaN with the operand's sign) and
+  // passes |y1| with the quotient's sign through otherwise -- one instruction instead of a compare and a select
+  return __builtin_amdgcn_div_fixupf(y1, x, 1.f);
 }
 // x in [2^-96, 2^127) or 0 (the range in which the compiler's sequence does not rescale).
 __device__ __forceinline__ float sqrt_exact(float x) {
@@ -173,6 +179,34 @@ __host__ __device__ __forceinline__ HbSplit hb_split(float v) {
   if (bits >> 31) { r.lo = -r.lo; r.hi = -r.hi; }
   return r;
 }
+// The same limbs as sign and magnitudes, without a branch (device only): hb_split walks four exponent ranges, and the 27 totals of a
+// tile lie in all of them, so a wavefront executes every branch -- ~35 vector instructions and eight execution-mask regions per
+// candidate.  Here the split is float arithmetic, every step exact for |v| < 2^52:
+//   hi  = trunc(v)                       (integer part: limb 1)
+//   lo  = rint((v - hi) * 2^32)          (v - hi is exact; for |v| >= 2^-9 the product is an integer already, below that rint is
+//                                         hb_split's round-to-nearest-even of m >> sh)
+//   hi  = hh * 2^32 + hl, hh = trunc(hi * 2^-32), hl = hi - hh * 2^32   (both below 2^32: v_cvt_u32_f32 converts them)
+// |lo| < 2^32 (below 2^23 in the rounding range), so the magnitudes are what hb_split returns and the sign is v's.  A sink adds the
+// magnitudes with an add or a subtract instruction according to the sign (tests/test_gpu_kernels_vs_oracle.py compares value by value).
+struct HbMagnitudes {
+  uint32_t lo;          // |limb 0|
+  uint32_t hi_lo, hi_hi;   // |limb 1| as two words
+  bool negative, valid;
+};
+__device__ __forceinline__ HbMagnitudes hb_split_magnitudes(float v) {
+  HbMagnitudes r;
+  const float a = fabsf(v);
+  r.valid = a < 4503599627370496.f;                       // 2^52; false for NaN
+  r.negative = (__float_as_uint(v) >> 31) != 0u;
+  const float hi = __builtin_truncf(a);
+  const float lo = __builtin_rintf((a - hi) * 4294967296.f);
+  const float hh = __builtin_truncf(hi * 2.3283064365386963e-10f);
+  const float hl = __builtin_fmaf(-hh, 4294967296.f, hi);
+  r.lo = (uint32_t)lo;
+  r.hi_lo = (uint32_t)hl;
+  r.hi_hi = (uint32_t)hh;
+  return r;
+}
 // The value of a limb pair (carry-normalised first): binary64; H and b are its rounding to binary32.
 __host__ __device__ __forceinline__ double hb_value(long long lo, long long hi) {
   hi += lo >> 32;                 // arithmetic shift: floor
@@ -277,7 +311,7 @@ struct Intrinsics {
   float a, raw_to_float_depth, baseline_fx;
   int cell;
   int cell_shift;   // log2(cell) if cell is a power of two, else -1 (host-side hint: shifts instead of integer division)
-  uint32_t geom_tpr, fp_tpr;   // tiles per row of the geom / lumafp planes
+  uint32_t geom_skip, fp_skip;   // plane_strip_skip() of the geom / lumafp planes
   const float* cfactor;
   uint32_t cfactor_pitch;
   int cf_width, cf_height;
@@ -321,11 +355,27 @@ __device__ __forceinline__ T* pitched_ptr(T* base, uint32_t pitch, int y, int x)
 }
 
 // ---- BA planes: 8x4-pixel tiles of 32-bit words, one tile = one 128-byte line ------------------------------
+// Memory order of the tiles: COLUMN STRIPS.  A strip is 8 pixels wide and as high as the (padded) image; inside a strip the rows
+// follow each other (8 words = 32 bytes per row), so every aligned 128-byte line holds rows 4 k .. 4 k + 3 of the strip -- the same
+// 8x4 tile per line as a row-major order of tiles, but the byte offset of pixel (x, y) is three terms,
+//   (x >> 3) * strip_bytes + (y << 5) + ((x & 7) << 2)  =  (x << 2) + (x >> 3) * (strip_bytes - 32) + (y << 5),
+// i.e. a shift, a 24-bit multiply-add and a shift-add (four vector instructions where the row-major tile index took eight), and as
+// a 32-bit offset from the wave-uniform plane pointer it rides in the load's own address operand (no 64-bit add).  The sweeps
+// compute four such addresses per (surfel, keyframe) pair.
 constexpr uint32_t kPlaneTileW = 8, kPlaneTileH = 4;
 __host__ __device__ __forceinline__ uint32_t plane_tiles_x(uint32_t width) { return (width + kPlaneTileW - 1) / kPlaneTileW; }
 __host__ __device__ __forceinline__ uint32_t plane_tiles_y(uint32_t height) { return (height + kPlaneTileH - 1) / kPlaneTileH; }
-__device__ __forceinline__ uint32_t plane_index(uint32_t x, uint32_t y, uint32_t tiles_per_row) {
-  return ((__umul24(y >> 2, tiles_per_row) + (x >> 3)) << 5) | ((y & 3u) << 3) | (x & 7u);   // 24-bit multiply: full rate
+// bytes from one strip to the next, minus the 32 bytes that `x << 2` has already advanced by then (Intrinsics::geom_skip, fp_skip)
+__host__ __device__ __forceinline__ uint32_t plane_strip_skip(uint32_t height) { return plane_tiles_y(height) * kPlaneTileH * 32u - 32u; }
+__device__ __forceinline__ uint32_t plane_byte_offset(uint32_t x, uint32_t y, uint32_t strip_skip) {
+  return __umul24(x >> 3, strip_skip) + (x << 2) + (y << 5);   // 24-bit multiply: full rate; planes are far below 16 MiB
+}
+__device__ __forceinline__ uint32_t plane_load(const uint32_t* __restrict__ plane, uint32_t byte_offset) {
+  return load_global(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(plane) + byte_offset));
+}
+// word index of pixel (x, y) (the packing kernels' view of the same order)
+__host__ __device__ __forceinline__ uint32_t plane_word(uint32_t x, uint32_t y, uint32_t padded_height) {
+  return (x >> 3) * (padded_height * 8u) + y * 8u + (x & 7u);
 }
 
 // ---- packing (B/util.cuh:121-153, B/util_nvcc_only.cuh:66-95) ------------------------------------
@@ -397,6 +447,10 @@ __device__ __forceinline__ Vec3 unproject(const Intrinsics& in, int x, int y, fl
   return mk3(depth * mad(in.fx_inv, (float)x, in.cx_inv), depth * mad(in.fy_inv, (float)y, in.cy_inv), depth);
 }
 // B/cost_function.cuh:81-88
+// the factor both functions below share: 0.1 |n . (nx, ny, 1)| depth^2
+__device__ __forceinline__ float depth_sigma_factor(float nx, float ny, float depth, Vec3 nl) {
+  return 0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth);
+}
 __device__ __forceinline__ float depth_stddev(float nx, float ny, float depth, Vec3 nl, float baseline_fx) {
   return (0.1f * fabsf(mad(nl.y, ny, mad(nl.x, nx, nl.z))) * (depth * depth)) * (1.f / baseline_fx);
 }
@@ -426,6 +480,9 @@ struct Assoc {
   int px, py;
   float pxx, pxy;    // float pixel position, pixel-corner convention
   uint16_t normal_bits;   // packed measured normal of the associated pixel
+  // what the depth residual shares with the association test (assoc_inv_std / assoc_unproject below): the unprojection
+  // coordinates of the pixel and 0.1 |n . (nx, ny, 1)| depth^2, the factor of depth_stddev and depth_inv_stddev
+  float nx, ny, sigma;
 };
 
 // B/surfel_projection_nvcc_only.cuh:332-359 with IsAssociatedWithPixel :48-127; the order of the
@@ -446,6 +503,7 @@ struct Projected {
   float inv_z;       // 1 / local.z (IEEE)
   float pxx, pxy;    // float pixel position, pixel-corner convention
   int px, py;
+  float fpx, fpy;    // (float)px, (float)py
   bool ok;           // z > 0 and the pixel lies in the image
 };
 __device__ __forceinline__ Projected project_surfel(const Intrinsics& in, const float* F, Vec3 gp) {
@@ -458,8 +516,10 @@ __device__ __forceinline__ Projected project_surfel(const Intrinsics& in, const 
   p.pxy = mad(in.fy, p.local.y * p.inv_z, in.cy);
   p.px = (int)p.pxx;
   p.py = (int)p.pxy;
-  p.ok = (p.local.z > 0.f) && (p.pxx >= 0.f) && (p.pxy >= 0.f) && (p.pxx < (float)in.width) && (p.pxy < (float)in.height) &&
-         p.px < in.width && p.py < in.height;
+  p.fpx = (float)p.px;
+  p.fpy = (float)p.py;
+  // 0 <= pxx < (float)width implies (int)pxx < width: the reference's integer compares (B/surfel_projection_nvcc_only.cuh:343) add nothing
+  p.ok = (p.local.z > 0.f) && (p.pxx >= 0.f) && (p.pxy >= 0.f) && (p.pxx < (float)in.width) && (p.pxy < (float)in.height);
   return p;
 }
 struct PixelWords {
@@ -469,7 +529,7 @@ struct PixelWords {
 __device__ __forceinline__ PixelWords load_pixel_words(const Intrinsics& in, const uint32_t* __restrict__ geom, const Projected& p) {
   const int cx = min(max(p.px, 0), in.width - 1), cy = min(max(p.py, 0), in.height - 1);
   PixelWords w;
-  w.geom = load_global(geom + plane_index((uint32_t)cx, (uint32_t)cy, in.geom_tpr));
+  w.geom = plane_load(geom, plane_byte_offset((uint32_t)cx, (uint32_t)cy, in.geom_skip));
   w.cfactor = cfactor_at(in, cx, cy);
   return w;
 }
@@ -482,7 +542,10 @@ __device__ __forceinline__ bool associate_from_words(const Intrinsics& in, const
   if (measured & kInvalidDepthBit) return false;
   r->depth = raw_to_calibrated_depth(in.a, w.cfactor, in.raw_to_float_depth, measured);
   r->nl = rotate34(F, gn);
-  const float thr = 10.f * depth_stddev(unp_nx(in, (float)r->px), unp_ny(in, (float)r->py), r->depth, r->nl, in.baseline_fx);
+  r->nx = unp_nx(in, p.fpx);
+  r->ny = unp_ny(in, p.fpy);
+  r->sigma = depth_sigma_factor(r->nx, r->ny, r->depth, r->nl);
+  const float thr = 10.f * (r->sigma * (1.f / in.baseline_fx));   // == 10 depth_stddev(nx, ny, depth, nl, baseline_fx)
   if (kFreeSpace) {
     const float diff = r->depth - r->local.z;
     if (diff > thr) { *free_space_violation = true; return false; }
@@ -506,11 +569,16 @@ __device__ __forceinline__ bool project_associate(const Intrinsics& in, const fl
   return associate_from_words<kFreeSpace>(in, F, gn, p, w, r, free_space_violation);
 }
 
+// The depth residual's inputs from what the association test already computed (the same expressions as
+// depth_inv_stddev(unp_nx(px), unp_ny(py), depth, nl, baseline_fx) and unproject(px, py, depth), on the same values).
+__device__ __forceinline__ float assoc_inv_std(const Intrinsics& in, const Assoc& r) { return in.baseline_fx / r.sigma; }
+__device__ __forceinline__ Vec3 assoc_unproject(const Assoc& r) { return mk3(r.depth * r.nx, r.depth * r.ny, r.depth); }
+
 // ---- colour sampling -------------------------------------------------------------------------------
 // 2x2 luma footprint with top-left texel (ix, iy), ix in [-1, w], iy in [-1, h] (clamp addressing baked in).
 struct Luma4 { float tl, tr, bl, br; };
 __device__ __forceinline__ uint32_t luma_footprint_word(const Intrinsics& in, const uint32_t* __restrict__ lumafp, int ix, int iy) {
-  return load_global(lumafp + plane_index((uint32_t)(ix + 1), (uint32_t)(iy + 1), in.fp_tpr));
+  return plane_load(lumafp, plane_byte_offset((uint32_t)(ix + 1), (uint32_t)(iy + 1), in.fp_skip));
 }
 __device__ __forceinline__ Luma4 unpack_luma_footprint(uint32_t word) {
   Luma4 t;
@@ -598,14 +666,16 @@ __device__ __forceinline__ bool luma_sample_is_interior(int w, int h, float x, f
 // when the point is interior, some valid word otherwise (the caller then does not use it).  NaN coordinates clamp too.
 __device__ __forceinline__ uint32_t luma_word_clamped(const Intrinsics& in, const uint32_t* __restrict__ lumafp, float x, float y) {
   // v_med3_f32: one instruction, and none to quiet a NaN first (a NaN coordinate gives the minimum of the bounds: valid)
-  const float fx = __builtin_amdgcn_fmed3f(floorf(x - 0.5f), -1.f, (float)in.cwidth);
-  const float fy = __builtin_amdgcn_fmed3f(floorf(y - 0.5f), -1.f, (float)in.cheight);
-  return luma_footprint_word(in, lumafp, (int)fx, (int)fy);
+  // No floor: for an interior point (0 <= x - 0.5 < w) the clamp is the identity and the conversion's truncation IS the floor; anywhere
+  // else (-1 <= clamped < 0 truncates to 0 instead of -1) the result is still a valid word, which the caller does not use.
+  const float ux = __builtin_amdgcn_fmed3f(x - 0.5f, -1.f, (float)in.cwidth);
+  const float uy = __builtin_amdgcn_fmed3f(y - 0.5f, -1.f, (float)in.cheight);
+  return luma_footprint_word(in, lumafp, (int)ux, (int)uy);
 }
 __device__ __forceinline__ void sample_luma_and_gradient_interior(uint32_t word, float x, float y, float* value, float* dx, float* dy) {
   const float xb = x - 0.5f, yb = y - 0.5f;
-  const float fx = floorf(xb), fy = floorf(yb);
-  const float a = xb - fx, b = yb - fy;
+  // xb, yb >= 0 here: xb - floor(xb) is exact, which is what v_fract_f32 returns (its clamp below 1 never acts on an exact fraction)
+  const float a = __builtin_amdgcn_fractf(xb), b = __builtin_amdgcn_fractf(yb);
   const Luma4 t = unpack_luma_footprint(word);
   {
     const float qa = bilinear_weight(a), qb = bilinear_weight(b);
@@ -621,7 +691,7 @@ __device__ __forceinline__ void sample_luma_and_gradient_interior(uint32_t word,
 __device__ __forceinline__ bool depth_to_color_pixel(const Intrinsics& in, float pxx, float pxy, float* cx, float* cy) {
   *cx = mad(in.d2c_fx, pxx, in.d2c_cx);
   *cy = mad(in.d2c_fy, pxy, in.d2c_cy);
-  return *cx >= 0 && *cy >= 0 && (int)(*cx) < in.cwidth && (int)(*cy) < in.cheight;
+  return *cx >= 0 && *cy >= 0 && *cx < (float)in.cwidth && *cy < (float)in.cheight;   // for cx >= 0: (int)cx < w <=> cx < w (w an integer)
 }
 
 // B/cost_function.cuh:115-136.  The two tangent sample points gp + t1, gp + t2 depend on the surfel only, so the hot

@@ -106,6 +106,7 @@ void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel 
 void set_pose_lds_waves(int waves);        // test hook: wavefronts per workgroup of the LDS form (0: 16)
 void set_pose_lds_parts_shift(int shift);  // test hook: 2^shift wavefronts share a tile's work items in the LDS form (-1: from the grid size)
 void set_pose_lds_items(int items);   // test hook: slices of that many work items per launch of the LDS form (0: as many as the table holds)
+long long pose_kernel_dispatches();   // kernel dispatches of the accumulate sweep since the process started
 void pose_form_launches(long long out[2], bool reset);   // launches of either form since the last reset (bench: which kernel to name)
 void set_pose_form(int form);     // 0 = automatic; 1 = one tile per wavefront + global atomics; 2 = persistent workgroups with the normal equations in LDS
 void set_pose_parts(int parts);   // 0 = automatic; 1 | 2 | 4 | 8 wavefronts share a tile's keyframes in the pose kernel

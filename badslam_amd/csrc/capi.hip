@@ -204,8 +204,8 @@ Intrinsics make_intrinsics(const bahip_camera& cc, const bahip_camera& dc, const
   if (in.cell > 0 && (in.cell & (in.cell - 1)) == 0) { in.cell_shift = 0; while ((1 << in.cell_shift) < in.cell) ++in.cell_shift; }
   in.cfactor = dp.cfactor; in.cfactor_pitch = dp.cfactor_pitch_bytes;
   in.cf_width = dp.cfactor_width; in.cf_height = dp.cfactor_height;
-  in.geom_tpr = plane_tiles_x(dc.width);
-  in.fp_tpr = plane_tiles_x(cc.width + 2);
+  in.geom_skip = plane_strip_skip(dc.height);
+  in.fp_skip = plane_strip_skip(cc.height + 2);
   in.sum_classes = 4;   // (the context's choice is written over this: bahip_set_intrinsics, bahip_context_set_sum_classes)
   return in;
 }
@@ -2292,6 +2292,10 @@ int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, 
   pose_form_launches(n, reset != 0);
   if (global_form) *global_form = n[0];
   if (lds_form) *lds_form = n[1];
+  return 0;
+}
+int bahip_debug_pose_kernel_dispatches(long long* dispatches_out) {
+  if (dispatches_out) *dispatches_out = pose_kernel_dispatches();
   return 0;
 }
 int bahip_debug_read_tile_schedule(bahip_context* ctx, uint32_t* padded_tiles_out, uint32_t* words_out, size_t max_words) {

@@ -193,7 +193,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
         flush_pending();
         if (!__any(associated)) return;
         if (associated) {
-          const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
+          const float nx = r.nx, ny = r.ny;   // the association computed them (ba_device.h: Assoc)
           if (kDepth) {
             // B/kernel_opt_intrinsics.cu:81-120.  cfactor of the pixel's cell and the raw depth: the words the association
             // already loaded (the geometry plane's low half is the keyframe's depth image)
@@ -204,7 +204,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
             const float corrected = cfactor * exp_inv_depth + raw_inv_depth;
             if (fabsf(corrected) > 1e-4f) {
               const float dot = dot3(mk3(nx, ny, 1), r.nl);
-              const float inv_std = depth_inv_stddev(nx, ny, r.depth, r.nl, in.baseline_fx);
+              const float inv_std = assoc_inv_std(in, r);
               float J[kARows + 1];
               jac_depth_intrinsics(r.px, r.py, r.depth, inv_std, dot3(gn, mk3(F[0], F[1], F[2])), dot3(gn, mk3(F[4], F[5], F[6])), dot, cfactor,
                                    raw_inv_depth, exp_inv_depth, corrected, J);

@@ -100,14 +100,14 @@ __device__ __forceinline__ void eval_pair_terms(const PcgLayout& L, const Intrin
                                                 const PixelWords& pix, const DescWords& dw, Vec3 gn, float d1, float d2, PairTerms* t) {
   const float* F = kf.pose.F;
   const Vec3 rn = r.nl;
-  const float nx = unp_nx(in, (float)r.px), ny = unp_ny(in, (float)r.py);
+  const float nx = r.nx, ny = r.ny;   // the association computed them (ba_device.h: Assoc)
   t->di_valid = false;
   t->color_ok = false;
   // All Jacobians come from the jac_* functions of ba_device.h -- the ones the alternating sweeps use and the ones checked
   // against the golden vectors derived from the reference's own script (tests/golden/jacobians.json).
   if (L.use_depth) {
-    const float inv_std = depth_inv_stddev(nx, ny, r.depth, rn, in.baseline_fx);
-    const Vec3 u = unproject(in, r.px, r.py, r.depth);
+    const float inv_std = assoc_inv_std(in, r);
+    const Vec3 u = assoc_unproject(r);
     t->raw = inv_std * dot3(rn, u - r.local);
     t->w = depth_residual_weight(t->raw);
     t->Jgeom = -inv_std;

@@ -90,17 +90,18 @@ struct GlobalSink {
   int slot_offset;   // byte offset of this lane's coefficient in a work item's row, or -1 (lane holds no total)
   __device__ __forceinline__ void flush() {
     if (pending_w >= 0 && slot_offset >= 0) {
-      const HbSplit v = hb_split(pending);
       const HbFixed* row = Hb + (size_t)pending_w * kHbStride;   // wave-uniform: a scalar base, the lane adds its 32-bit offset
-      if (v.valid) {
-#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__)
-        if (v.lo) asm volatile("global_atomic_add_x2 %0, %1, %2" ::"v"(slot_offset), "v"(v.lo), "s"(row) : "memory");
-        if (v.hi) asm volatile("global_atomic_add_x2 %0, %1, %2 offset:8" ::"v"(slot_offset), "v"(v.hi), "s"(row) : "memory");
-#else
-        HbFixed* target = const_cast<HbFixed*>(row) + slot_offset / (int)sizeof(HbFixed);
-        if (v.lo) __hip_atomic_fetch_add(target, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v.hi) __hip_atomic_fetch_add(target + 1, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+      // magnitudes added or subtracted according to the total's sign (ba_device.h: hb_split_magnitudes): the same sums
+      const HbMagnitudes m = hb_split_magnitudes(pending);
+      const unsigned long long lo = m.lo, hi = ((unsigned long long)m.hi_hi << 32) | m.hi_lo;
+      if (m.valid) {
+        if (m.negative) {
+          if (lo) asm volatile("global_atomic_sub_x2 %0, %1, %2" ::"v"(slot_offset), "v"(lo), "s"(row) : "memory");
+          if (hi) asm volatile("global_atomic_sub_x2 %0, %1, %2 offset:8" ::"v"(slot_offset), "v"(hi), "s"(row) : "memory");
+        } else {
+          if (lo) asm volatile("global_atomic_add_x2 %0, %1, %2" ::"v"(slot_offset), "v"(lo), "s"(row) : "memory");
+          if (hi) asm volatile("global_atomic_add_x2 %0, %1, %2 offset:8" ::"v"(slot_offset), "v"(hi), "s"(row) : "memory");
+        }
       } else {
         atomicOr(invalid, 1);
       }
@@ -132,6 +133,27 @@ struct LdsSink {
   // tests/test_gpu_scale_parity.py runs the sweep at 1 / 2 / 16 wavefronts x 1 / 37 / 292 items x parts x rounds-ahead against the
   // oracle so that a toolchain or source change that brings it back cannot pass.
   __device__ __forceinline__ void flush() {
+    if (pending_item >= 0 && holds_total) {
+      // magnitudes added or subtracted according to the total's sign (ba_device.h: hb_split_magnitudes): the same sums as the
+      // signed limbs of hb_split, without its four exponent ranges and without the 64-bit negations
+      const HbMagnitudes m = hb_split_magnitudes(pending);
+      const uint32_t address = lane_offset + (uint32_t)pending_item * (uint32_t)(kHbStride * sizeof(HbFixed));
+      auto* cell = reinterpret_cast<__attribute__((address_space(3))) HbFixed*>(address);
+      const HbFixed lo = (HbFixed)(unsigned long long)m.lo, hi = (HbFixed)(((unsigned long long)m.hi_hi << 32) | m.hi_lo);
+      if (m.valid) {
+        if (m.negative) {
+          if (lo) __hip_atomic_fetch_sub(cell, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (hi) __hip_atomic_fetch_sub(cell + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          if (lo) __hip_atomic_fetch_add(cell, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (hi) __hip_atomic_fetch_add(cell + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        atomicOr(invalid, 1);
+      }
+    }
+    pending_item = -1;
+    return;
     if (pending_item >= 0 && holds_total) {
       const HbSplit v = hb_split(pending);
       const uint32_t address = lane_offset + (uint32_t)pending_item * (uint32_t)(kHbStride * sizeof(HbFixed));
@@ -254,26 +276,47 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
       }
     }
 #endif
-    if (!__any(visible)) return;
+    if (__builtin_amdgcn_ballot_w64(visible) == 0ull) return;   // (a scalar compare on the mask; __any costs a select and a compare per lane)
 #ifdef BAHIP_TILE_TIMELINE
     ++with_association;
 #endif
 
     float acc[28];   // 21 H + 6 b + 1 pad (kHbCoefficients)
+    // The depth residual opens the 27 sums as plain products, in every lane: a lane without an association computes on whatever its
+    // Assoc holds (no memory is touched), and eight selects then give it J = 0, weight 0, residual 0, so that its products are
+    // zeros -- instead of 27 cleared accumulators + 27 fused multiply-adds onto them under the lanes' mask.  Same bits where it
+    // matters: fma(a, b, +0) and a * b differ in the sign of a zero product only, a zero addend never changes a non-zero sum, and a
+    // total that is a zero of either sign is the fixed-point 0 (hb_split).  (Not applicable to the lanes' garbage directly: their
+    // Jacobians may be infinite or NaN, and 0 * inf is not 0.)
+    if (kUseDepth) {
+      float J[6];
+      const float inv_std = assoc_inv_std(in, r);
+      const Vec3 u = assoc_unproject(r);
+      float raw = inv_std * dot3(r.nl, u - r.local);
+      jac_depth_pose(r.nl, u, inv_std, J);
+      float wgt = depth_residual_weight(raw);
 #pragma unroll
-    for (int q = 0; q < 28; ++q) acc[q] = 0.f;
+      for (int c = 0; c < 6; ++c) J[c] = visible ? J[c] : 0.f;
+      wgt = visible ? wgt : 0.f;
+      raw = visible ? raw : 0.f;
+      int q = 0;
+#pragma unroll
+      for (int row = 0; row < 6; ++row) {
+        const float wj = wgt * J[row];
+#pragma unroll
+        for (int col = row; col < 6; ++col, ++q) acc[q] = wj * J[col];
+      }
+      const float wr = wgt * raw;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[21 + c] = wr * J[c];
+      acc[27] = 0.f;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 28; ++q) acc[q] = 0.f;
+    }
 
     if (visible) {
       float J[6];
-      if (kUseDepth) {
-        // B/kernel_opt_pose.cu:45-94
-        const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
-        const Vec3 u = unproject(in, r.px, r.py, r.depth);
-        const float raw = inv_std * dot3(r.nl, u - r.local);
-        jac_depth_pose(r.nl, u, inv_std, J);
-        const float wgt = depth_residual_weight(raw);
-        accumulate_jtj(acc, J, wgt, raw);
-      }
       if (kUseDesc) {
         // B/kernel_opt_pose.cu:303-353: nothing is added when the colour-pixel transform fails.
         if (dw.color_ok) {
@@ -926,6 +969,10 @@ void pose_form_launches(long long out[2], bool reset) {
   out[0] = g_pose_form_launches[0]; out[1] = g_pose_form_launches[1];
   if (reset) g_pose_form_launches[0] = g_pose_form_launches[1] = 0;
 }
+// Kernel dispatches of the accumulate sweep since the process started (every slice of a sliced launch counts; never reset): lets a
+// profile of a bench run pick the dispatches of the timed region out of rocprofv3's per-dispatch rows (scripts/summarize_profile.py).
+static long long g_pose_kernel_dispatches = 0;
+long long pose_kernel_dispatches() { return g_pose_kernel_dispatches; }
 constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a compute unit
 #ifndef BAHIP_POSE_LDS_MIN_TILES
 #define BAHIP_POSE_LDS_MIN_TILES 2048
@@ -973,6 +1020,7 @@ static bool launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEn
   // one workgroup per compute unit, fewer when there is less to do than that (at least one per XCD queue)
   const unsigned units = sched_positions(tiles, sched) << parts_shift;
   const unsigned grid = std::max(8u, std::min((unsigned)device.compute_units, ((units + waves - 1) / waves + 7u) & ~7u));
+  ++g_pose_kernel_dispatches;
   hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(grid), dim3(64 * waves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
                      pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
   return true;
@@ -1047,6 +1095,7 @@ void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, c
     // (only a refused LDS opt-in gets here, before the first slice: nothing has been added yet)
   }
   ++g_pose_form_launches[0];
+  ++g_pose_kernel_dispatches;
   const dim3 grid(sched_positions(tiles, sched), parts), block(kPoseBlock);
   int* invalid = pose_invalid_word(Hb);
   if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
@@ -1227,8 +1276,8 @@ __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView 
   Assoc r;
   if (!project_associate<false>(in, F, frame.geom, gp, gn, &r, nullptr)) return;
   o[0] = 1.f; o[1] = (float)r.px; o[2] = (float)r.py; o[4] = r.depth; o[34] = r.pxx; o[35] = r.pxy;
-  const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
-  const Vec3 u = unproject(in, r.px, r.py, r.depth);
+  const float inv_std = assoc_inv_std(in, r);
+  const Vec3 u = assoc_unproject(r);
   const float raw = inv_std * dot3(r.nl, u - r.local);
   o[5] = raw; o[6] = depth_residual_weight(raw); o[7] = inv_std;
   { float Jd[6]; jac_depth_pose(r.nl, u, inv_std, Jd); for (int c = 0; c < 6; ++c) o[8 + c] = Jd[c]; }
@@ -1310,8 +1359,10 @@ __global__ void exact_math_debug_kernel(int kind, const float* __restrict__ in, 
 __global__ void pose_limbs_debug_kernel(const float* __restrict__ in, long long* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const HbSplit v = hb_split(in[i]);
-  out[3 * i] = v.lo; out[3 * i + 1] = v.hi; out[3 * i + 2] = v.valid ? 1 : 0;
+  // what the sinks add: the magnitudes of hb_split_magnitudes with the total's sign (the oracle's hb_split returns these limbs)
+  const HbMagnitudes m = hb_split_magnitudes(in[i]);
+  const long long lo = (long long)m.lo, hi = (long long)(((unsigned long long)m.hi_hi << 32) | m.hi_lo);
+  out[3 * i] = m.valid ? (m.negative ? -lo : lo) : 0; out[3 * i + 1] = m.valid ? (m.negative ? -hi : hi) : 0; out[3 * i + 2] = m.valid ? 1 : 0;
 }
 void launch_pose_limbs_debug(hipStream_t stream, const float* in, long long* out, size_t n) {
   if (n) hipLaunchKernelGGL(pose_limbs_debug_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);

@@ -212,16 +212,17 @@ void launch_min_max_depth(hipStream_t stream, const uint16_t* depth, uint32_t de
 }
 
 // ---- BA planes (ba_device.h): tiled, packed copies of a frame's images for the surfel sweeps ------------------------
-// One thread per output word; a wavefront writes two whole 128-byte tiles.
+// One thread per output word, in the planes' memory order (ba_device.h: column strips of 8 pixels, rows of a strip contiguous): a
+// wavefront writes two whole 128-byte tiles.
 __global__ void __launch_bounds__(256)
 pack_geom_kernel(const uint16_t* __restrict__ depth, uint32_t depth_pitch, const uint16_t* __restrict__ normals,
-                 uint32_t normals_pitch, int width, int height, uint32_t tiles_per_row, uint32_t words,
+                 uint32_t normals_pitch, int width, int height, uint32_t strip_words, uint32_t words,
                  uint32_t* __restrict__ out) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= words) return;
-  const uint32_t tile = t >> 5;
-  const int x = (int)((tile % tiles_per_row) * kPlaneTileW + (t & 7u));
-  const int y = (int)((tile / tiles_per_row) * kPlaneTileH + ((t >> 3) & 3u));
+  const uint32_t strip = t / strip_words, in_strip = t - strip * strip_words;
+  const int x = (int)(strip * kPlaneTileW + (in_strip & 7u));
+  const int y = (int)(in_strip >> 3);
   uint32_t word = kInvalidDepthBit;   // padding pixels are never addressed; keep them "invalid depth"
   if (x < width && y < height)
     word = (uint32_t)pitched_load(depth, depth_pitch, y, x) | ((uint32_t)pitched_load(normals, normals_pitch, y, x) << 16);
@@ -229,13 +230,13 @@ pack_geom_kernel(const uint16_t* __restrict__ depth, uint32_t depth_pitch, const
 }
 
 __global__ void __launch_bounds__(256)
-pack_luma_footprint_kernel(const uint8_t* __restrict__ rgba, uint32_t rgba_pitch, int width, int height, uint32_t tiles_per_row,
+pack_luma_footprint_kernel(const uint8_t* __restrict__ rgba, uint32_t rgba_pitch, int width, int height, uint32_t strip_words,
                            uint32_t words, uint32_t* __restrict__ out) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= words) return;
-  const uint32_t tile = t >> 5;
-  const int ix = (int)((tile % tiles_per_row) * kPlaneTileW + (t & 7u)) - 1;     // top-left texel of the footprint
-  const int iy = (int)((tile / tiles_per_row) * kPlaneTileH + ((t >> 3) & 3u)) - 1;
+  const uint32_t strip = t / strip_words, in_strip = t - strip * strip_words;
+  const int ix = (int)(strip * kPlaneTileW + (in_strip & 7u)) - 1;     // top-left texel of the footprint
+  const int iy = (int)(in_strip >> 3) - 1;
   uint32_t word = 0;
   if (ix <= width && iy <= height) {
     const int x0 = max(0, min(ix, width - 1)), x1 = max(0, min(ix + 1, width - 1));
@@ -249,15 +250,15 @@ pack_luma_footprint_kernel(const uint8_t* __restrict__ rgba, uint32_t rgba_pitch
 
 void launch_pack_planes(hipStream_t stream, const KfEntry& frame, int width, int height, int cwidth, int cheight, uint32_t* geom,
                         uint32_t* lumafp) {
-  const uint32_t gtpr = plane_tiles_x(width), gwords = gtpr * plane_tiles_y(height) * 32;
+  const uint32_t gstrip = plane_tiles_y(height) * kPlaneTileH * 8u, gwords = plane_tiles_x(width) * gstrip;   // words per strip, per plane
   hipLaunchKernelGGL(pack_geom_kernel, dim3((gwords + 255) / 256), dim3(256), 0, stream, frame.depth, frame.depth_pitch, frame.normals,
-                     frame.normals_pitch, width, height, gtpr, gwords, geom);
+                     frame.normals_pitch, width, height, gstrip, gwords, geom);
   // a frame handed over without a colour image (the supporting-surfel entry point of B/kernels.h:94-119 gets depth and
   // normals only) has no luma plane to pack; the calls that take such a frame never sample colour
   if (frame.color == nullptr) return;
-  const uint32_t ftpr = plane_tiles_x(cwidth + 2), fwords = ftpr * plane_tiles_y(cheight + 2) * 32;
+  const uint32_t fstrip = plane_tiles_y(cheight + 2) * kPlaneTileH * 8u, fwords = plane_tiles_x(cwidth + 2) * fstrip;
   hipLaunchKernelGGL(pack_luma_footprint_kernel, dim3((fwords + 255) / 256), dim3(256), 0, stream, frame.color, frame.color_pitch,
-                     cwidth, cheight, ftpr, fwords, lumafp);
+                     cwidth, cheight, fstrip, fwords, lumafp);
 }
 
 // ---- counter calibration (tooling) -------------------------------------------------------------------------------------

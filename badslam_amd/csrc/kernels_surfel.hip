@@ -328,9 +328,9 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
         const bool associated = live && associate_from_words<false>(in, kfs[k].pose.F, gn, p, pix, &r, nullptr);
         gathers_arrived(pix);
         if (!associated) return;
-        const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
+        const float inv_std = assoc_inv_std(in, r);
         const float jac = -inv_std;
-        const Vec3 u = unproject(in, r.px, r.py, r.depth);
+        const Vec3 u = assoc_unproject(r);
         const float raw = inv_std * dot3(r.nl, u - r.local);
         const float w = depth_residual_weight(raw);
         const float wj = w * jac;
@@ -368,9 +368,9 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
 #endif
       if (!associated) return;
       if (kUseDepth) {
-        const float inv_std = depth_inv_stddev(unp_nx(in, (float)r.px), unp_ny(in, (float)r.py), r.depth, r.nl, in.baseline_fx);
+        const float inv_std = assoc_inv_std(in, r);
         const float jac = -inv_std;
-        const Vec3 u = unproject(in, r.px, r.py, r.depth);
+        const Vec3 u = assoc_unproject(r);
         const float raw = inv_std * dot3(r.nl, u - r.local);
         const float w = depth_residual_weight(raw);
         a0 = mad(w * jac, jac, a0);

@@ -385,11 +385,16 @@ def main():
 
     if args.warmup > 0:
         run(args.warmup)
-    # hipEvent pairs around every launch of the dominant kernel in the timed region (the roofline's duration); the other
-    # stages are timed in a few extra iterations afterwards, so their ten event records per iteration stay out of `value`
-    capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 3))
+
+    def pose_dispatches():
+        n = C.c_longlong()
+        capi.check(ctx.lib.bahip_debug_pose_kernel_dispatches(C.byref(n)))
+        return int(n.value)
+
+    # THE TIMED REGION: exactly `steps` iterations, no measurement code in it (round 5 measured what the hipEvent pairs round 4 kept
+    # inside it cost: 5 % -- every record is a barrier packet between two launches of the device-driven loop).
+    capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
     capi.check(ctx.lib.bahip_exchange_stats(ctx.handle, None, None, 1))
-    capi.check(ctx.lib.bahip_debug_pose_form_launches(None, None, 1))
     ctx.synchronize()
     if dist is not None:
         dist.barrier()
@@ -418,7 +423,19 @@ def main():
             out_ms[s], out_n[s] = ms.value, n.value
         return out_ms, out_n
 
-    stage_ms, stage_launches = read_stage_timers()             # stage 2 over the timed region
+    # THE SAME `steps` ITERATIONS ONCE MORE, INSTRUMENTED: hipEvent pairs around every launch of the dominant kernel, on the
+    # backend's own stream -- the roofline's launch duration, measured live; the line carries this region's own ms per step beside
+    # `ms_per_step`.  The other stages are timed in a few extra iterations afterwards (ten event records per iteration).
+    capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 3))
+    capi.check(ctx.lib.bahip_debug_pose_form_launches(None, None, 1))
+    dispatches_before = pose_dispatches()
+    ctx.synchronize()
+    t_instr = time.perf_counter()
+    run(args.steps)
+    ctx.synchronize()
+    instrumented_elapsed = time.perf_counter() - t_instr
+    dispatches_timed = pose_dispatches() - dispatches_before
+    stage_ms, stage_launches = read_stage_timers()             # stage 2 over the instrumented region
     form_global, form_lds = C.c_longlong(), C.c_longlong()
     capi.check(ctx.lib.bahip_debug_pose_form_launches(C.byref(form_global), C.byref(form_lds), 0))
     units = C.c_longlong()
@@ -634,55 +651,110 @@ def main():
             launches = max(1, int(stage_launches[2]))
             # algorithmic bytes of one pose-accumulate launch (DESIGN.md "pose_accumulate"): this rank's surfel
             # positions / normals / descriptors once (28 B) + the depth, normal and luma texels (5 B/pixel) of the
-            # keyframes still iterating in that Gauss-Newton round, averaged over the timed launches
+            # keyframes still iterating in that Gauss-Newton round, averaged over the timed launches that did work
             kf_per_launch = units.value / launches
             bytes_pose_launch = N_rank * 28 + kf_per_launch * W * H * 5
             avg_ms = stage_ms[2] / launches
             achieved = bytes_pose_launch / (avg_ms * 1e-3) / 1e9
-            b_alg_iter = N_total * (17 + 21 + 49 + 28 * R) + K * W * H * (4 + 4 + 5 + 5 * Rbar)
+            # One convention for the whole line: the passes as they are LAUNCHED.  The geometry launch fuses the
+            # reference's activation and normals passes (one read of the depth / normal plane, 4 B per pixel, and of the surfel
+            # rows, 21 B incl. the flag and the normal written back) with the position / descriptor pass (4 + 1 B per pixel,
+            # 49 B per surfel); a pose launch reads 28 B per surfel and 5 B per pixel of the keyframes still iterating.
+            # SURVEY 8d's formula charges the activation as a pass of its own (17 B per surfel, 4 B per pixel more): kept beside it.
+            geo_bytes_surfel, geo_bytes_pixel = 21 + 49, 4 + 5
+            pose_bytes_iter = launches * N_rank * 28 / args.steps + (units.value / args.steps) * W * H * 5
+            b_alg_iter = N_total * geo_bytes_surfel + K * W * H * geo_bytes_pixel + (pose_bytes_iter if N_rank == N_total else N_total * 28 * R + K * W * H * 5 * Rbar)
+            b_alg_survey = N_total * (17 + 21 + 49 + 28 * R) + K * W * H * (4 + 4 + 5 + 5 * Rbar)
             out["config"].update({"pose_gn_rounds_per_iteration": R, "pose_gn_steps_per_keyframe": Rbar})
             out["algorithmic_bytes_per_iteration"] = b_alg_iter
+            out["algorithmic_bytes_per_iteration_by_survey_8d_formula"] = b_alg_survey
             out["iteration_fraction_of_hbm_roofline"] = b_alg_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9)
+            out["launch_window"] = {"pose_dispatches_before": dispatches_before, "pose_dispatches_timed": dispatches_timed,
+                                    "pose_launches_with_work_timed": launches, "keyframes_visited_timed": int(units.value),
+                                    "geometry_dispatches_before": args.warmup + args.steps, "geometry_dispatches_timed": args.steps,
+                                    "iterations_timed": args.steps, "surfels": N_rank,
+                                    "note": "which dispatches of the sweeps belong to the instrumented repeat of the timed region (in process "
+                                            "order; the timed region's own iterations count as `before`); "
+                                            "scripts/summarize_profile.py sums rocprofv3's per-dispatch rows over exactly these"}
+            out["instrumented_region"] = {"ms_per_step": 1e3 * instrumented_elapsed / args.steps,
+                                          "ba_iterations_per_s": args.steps / instrumented_elapsed,
+                                          "slowdown_by_event_records": instrumented_elapsed / local_elapsed - 1.0,
+                                          "note": "the timed region's iterations repeated right after it with a hipEvent pair around every "
+                                                  "pose-accumulate launch: where roofline.avg_launch_ms is measured; `value` has no event record in it"}
             pmc, pmc_source = committed_profile(args) if (world == 1 and shard_world == 1) else (None, None)
             # the pose sums have two kernels (kernels_pose.hip): persistent workgroups with the normal equations in LDS when the
             # table of the launch's work items fits, one tile per wavefront with global atomics otherwise; the line names the one
             # most of the timed launches used
             lds = form_lds.value >= form_global.value
             pose_kernel = "pose_accumulate_lds_kernel<true, true, false>" if lds else "pose_accumulate_kernel<true, true>"
-            traffic = pmc_kernel_entry(pmc, pmc_source, pose_kernel.split(">")[0].rsplit(", false", 1)[0])   # (the prefix: profiles of earlier rounds list the LDS form without its third flag)
-            flops = traffic.get("fp32_flops_per_launch") if traffic else None
+            # Counter evidence: sums over the dispatches of the PROFILE RUN's own timed region, divided by that run's own
+            # launches / keyframes visited / iterations (profiles/*_pmc_per_kernel.json "timed_window") -- like by like; the
+            # per-launch averages over all 40-odd dispatches of a profile run (warm-up rounds, rounds queued in vain) that
+            # round 4's line divided by the timed region's figures are not used any more.
+            win = (pmc or {}).get("timed_window", {}).get("pose") if pmc else None
+            cal = (pmc or {}).get("fetch_calibration") if pmc else None
+            pose_counters = None
+            if win and cal and win.get("launches_with_work"):
+                traffic_total = win["FETCH_SIZE_kb"] * 1024.0 * cal["factor"] + win.get("WRITE_SIZE_kb", 0.0) * 1024.0
+                pose_counters = {
+                    "source": pmc_source, "profile_iterations": win["iterations"], "profile_dispatches": win["dispatches"],
+                    "profile_launches_with_work": win["launches_with_work"],
+                    "traffic_per_launch": traffic_total / win["launches_with_work"],
+                    "traffic_per_iteration": traffic_total / win["iterations"],
+                    "algorithmic_bytes_per_iteration": win["algorithmic_bytes"] / win["iterations"],
+                    "traffic_over_algorithmic": traffic_total / win["algorithmic_bytes"],
+                    "fetch_factor": cal["factor"]}
+                if win.get("duration_ns") and win.get("fp32_flops"):
+                    pose_counters["fp32_tflops"] = win["fp32_flops"] / (win["duration_ns"] * 1e-9) / 1e12
+                    pose_counters["frac_of_vector_peak"] = pose_counters["fp32_tflops"] / FP32_VECTOR_PEAK_TFLOPS
+                for key in ("non_arithmetic_valu_fraction", "valu_cycles_per_instruction", "valu_instructions_per_keyframe_visit",
+                            "shader_clock_mhz", "valu_fraction_int32", "valu_fraction_int64", "valu_fraction_cvt"):
+                    if key in win:
+                        pose_counters[key] = win[key]
             out["roofline"] = {"bound": "hbm", "kernel": pose_kernel.replace(", ", ","), "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": traffic["bytes"] if traffic else None,
-                               "traffic_source": traffic["source"] if traffic else None,
-                               "traffic_fetch_factor": traffic["fetch_factor"] if traffic else None,
+                               "traffic": pose_counters["traffic_per_launch"] if pose_counters else None,
+                               "traffic_source": pose_counters["source"] if pose_counters else None,
+                               "traffic_fetch_factor": pose_counters["fetch_factor"] if pose_counters else None,
+                               "traffic_over_algorithmic": pose_counters["traffic_over_algorithmic"] if pose_counters else None,
                                "algorithmic_bytes_per_launch": bytes_pose_launch, "avg_launch_ms": avg_ms, "launches": launches,
                                "launches_by_form": {"lds": int(form_lds.value), "global_atomics": int(form_global.value)},
                                "keyframes_per_launch": kf_per_launch,
-                               "limiter": "instruction issue, not HBM: the sweep is ~700 VALU + ~150 scalar instructions per visited "
-                                          "(surfel tile, keyframe) candidate at 4 wavefronts per SIMD; measured ceiling 2.7 cycles per "
-                                          "VALU instruction per SIMD (scripts/microbench/valu_rate.hip), DESIGN.md section 5",
+                               "limiter": "instruction issue, not HBM: the sweep is several hundred VALU + ~150 scalar instructions per visited "
+                                          "(surfel tile, keyframe) candidate at 4 wavefronts per SIMD; a wave64 VALU instruction occupies "
+                                          "the SIMD-32 for 2 cycles at best (scripts/microbench/inst_cost.hip), DESIGN.md section 5",
+                               "counters": pose_counters,
                                # binary32 flops of the VALU instruction mix (PMC: 64 lanes x (add + mul + transcendental + 2 fma) wave
-                               # instructions per launch, masked lanes included) over the live launch duration, against the 157.3
-                               # TFLOP/s vector peak; and the share of VALU instructions that are not floating-point arithmetic
-                               "fp32_tflops": flops / (avg_ms * 1e-3) / 1e12 if flops else None,
-                               "frac_of_vector_peak": flops / (avg_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS if flops else None,
-                               "non_arithmetic_valu_fraction": traffic.get("non_arithmetic_valu_fraction") if traffic else None,
-                               "valu_issue_fraction": traffic.get("valu_issue_fraction") if traffic else None,
-                               "valu_cycles_per_instruction": traffic.get("valu_cycles_per_instruction") if traffic else None}
+                               # instructions, masked lanes included) of the profile run's timed region over the kernel time of the
+                               # same dispatches in that run, against the 157.3 TFLOP/s vector peak; and the share of VALU
+                               # instructions that are not floating-point arithmetic
+                               "fp32_tflops": pose_counters.get("fp32_tflops") if pose_counters else None,
+                               "frac_of_vector_peak": pose_counters.get("frac_of_vector_peak") if pose_counters else None,
+                               "non_arithmetic_valu_fraction": pose_counters.get("non_arithmetic_valu_fraction") if pose_counters else None,
+                               "valu_cycles_per_instruction": pose_counters.get("valu_cycles_per_instruction") if pose_counters else None}
             # the other sweep of an iteration: activation + normals + position/descriptor step in one launch
             geo_ms = breakdown_ms[1] / BREAKDOWN_STEPS
-            bytes_geo = N_rank * (17 + 21 + 49) + K * W * H * (4 + 5)
-            geo_traffic = pmc_kernel_entry(pmc, pmc_source, "geometry_kernel<true, true")
+            bytes_geo = N_rank * geo_bytes_surfel + K * W * H * geo_bytes_pixel
+            gwin = (pmc or {}).get("timed_window", {}).get("geometry") if pmc else None
+            geo_counters = None
+            if gwin and cal and gwin.get("dispatches"):
+                g_total = gwin["FETCH_SIZE_kb"] * 1024.0 * cal["factor"] + gwin.get("WRITE_SIZE_kb", 0.0) * 1024.0
+                geo_counters = {"source": pmc_source, "traffic_per_launch": g_total / gwin["dispatches"],
+                                "traffic_over_algorithmic": g_total / gwin["dispatches"] / bytes_geo}
+                if gwin.get("duration_ns") and gwin.get("fp32_flops"):
+                    geo_counters["fp32_tflops"] = gwin["fp32_flops"] / (gwin["duration_ns"] * 1e-9) / 1e12
+                for key in ("non_arithmetic_valu_fraction", "valu_cycles_per_instruction", "shader_clock_mhz"):
+                    if key in gwin:
+                        geo_counters[key] = gwin[key]
             out["roofline_geometry"] = {"bound": "hbm", "kernel": "geometry_kernel<true,true> (activation + normals + position step)",
                                         "achieved": bytes_geo / (geo_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": bytes_geo / (geo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": geo_traffic["bytes"] if geo_traffic else None,
+                                        "traffic": geo_counters["traffic_per_launch"] if geo_counters else None,
+                                        "traffic_over_algorithmic": geo_counters["traffic_over_algorithmic"] if geo_counters else None,
                                         "algorithmic_bytes_per_launch": bytes_geo, "avg_launch_ms": geo_ms,
-                                        "fp32_tflops": geo_traffic["fp32_flops_per_launch"] / (geo_ms * 1e-3) / 1e12
-                                                       if geo_traffic and geo_traffic.get("fp32_flops_per_launch") else None,
-                                        "non_arithmetic_valu_fraction": geo_traffic.get("non_arithmetic_valu_fraction") if geo_traffic else None,
-                                        "valu_issue_fraction": geo_traffic.get("valu_issue_fraction") if geo_traffic else None}
+                                        "counters": geo_counters,
+                                        "fp32_tflops": geo_counters.get("fp32_tflops") if geo_counters else None,
+                                        "non_arithmetic_valu_fraction": geo_counters.get("non_arithmetic_valu_fraction") if geo_counters else None}
         else:
             out["config"]["pcg_inner_steps_per_iteration"] = stats["pcg_inner_steps"] / args.steps
         if not args.no_cpu_baseline and world == 1:

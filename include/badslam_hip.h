@@ -500,6 +500,9 @@ int bahip_debug_set_device_loop(int enabled);
 int bahip_debug_set_pcg_lds_form(int mode);
 /* launches of the pose accumulation in either form since the last reset (process-wide); bench.py names the dominant kernel by it */
 int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, int reset);
+/* Kernel dispatches of the pose accumulate sweep since the process started (each slice of a sliced launch counts; never reset).
+ * A profile of a bench run uses it to pick the dispatches of the timed region out of rocprofv3's per-dispatch rows. */
+int bahip_debug_pose_kernel_dispatches(long long* dispatches_out);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):
  * out[3 i .. 3 i + 2] = limb 0 (weight 2^-32), limb 1 (weight 1), valid (0: not finite or 2^52 and beyond -- such a total is
  * not added and fails the pose estimation). */

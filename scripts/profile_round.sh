@@ -24,11 +24,11 @@ cd /tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-extras $*"
 $LIMIT rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/bench_stats.log"
 if [ "$PASSES" != stats ]; then   # PASSES=stats (or ONLY_STATS=1): the kernel-time table alone
-$LIMIT rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_fetch.log"
-$LIMIT rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_write.log"
-[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_sq.log"
-[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --output-format csv -d "$OUT/pmc_flops" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_flops.log"
-[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 --output-format csv -d "$OUT/pmc_mix" -- $BENCH --steps 5 > /dev/null 2> "$OUT/pmc_mix.log"
+$LIMIT rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps ${PMC_STEPS:-10} > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.log"
+$LIMIT rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps ${PMC_STEPS:-10} > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.log"
+[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps ${PMC_STEPS:-10} > "$OUT/bench_pmc_sq.json" 2> "$OUT/pmc_sq.log"
+[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --output-format csv -d "$OUT/pmc_flops" -- $BENCH --steps ${PMC_STEPS:-10} > "$OUT/bench_pmc_flops.json" 2> "$OUT/pmc_flops.log"
+[ "$PASSES" = all ] && $LIMIT rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 --output-format csv -d "$OUT/pmc_mix" -- $BENCH --steps ${PMC_STEPS:-10} > "$OUT/bench_pmc_mix.json" 2> "$OUT/pmc_mix.log"
 if [ -n "${CAL_FROM:-}" ] && [ -d "$CAL_FROM/pmc_cal" ]; then   # the calibration of another profile of the same call
   cp -r "$CAL_FROM/pmc_cal" "$OUT/pmc_cal"; cp "$CAL_FROM/cal_bytes.txt" "$OUT/cal_bytes.txt"
 else
@@ -38,6 +38,8 @@ fi
 cd "$REPO"
 python scripts/summarize_profile.py "$OUT" "$TAG" $* > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# (every pass keeps its own bench line: summarize_profile.py reads the pass's "launch_window" to sum the counters over the
+# dispatches of that run's timed region and divides by that run's own launches / keyframes visited / iterations)
 # keep only the small files (kernel trace CSVs are large)
 find "$OUT" -name '*kernel_trace.csv' -size +2M -delete
 find "$OUT" -name '*counter_collection.csv' -size +2M -delete

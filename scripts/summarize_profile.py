@@ -30,6 +30,131 @@ def counters_of(d, sub):
     return {k: {c: {"avg_per_launch": t / n, "launches": n} for c, (t, n) in cs.items()} for k, cs in acc.items()}
 
 
+POSE_KERNELS = ("pose_accumulate_lds_kernel", "pose_accumulate_kernel")
+GEOMETRY_KERNELS = ("geometry_kernel",)
+
+
+def bench_line(path):
+    try:
+        with open(path) as f:
+            lines = [l for l in f.read().splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    except OSError:
+        return None
+
+
+def window_rows(rows, kernels, before, count):
+    """The rows (one per dispatch and counter / one per dispatch of a kernel trace) of `kernels` in dispatch order, cut to the
+    dispatches [before, before + count) of those kernels: the timed region of the bench run that produced them."""
+    mine = [r for r in rows if short(r.get("Kernel_Name", r.get("Name", ""))).startswith(kernels)]
+    ids = sorted({int(r["Dispatch_Id"]) for r in mine})
+    keep = set(ids[before:before + count])
+    return [r for r in mine if int(r["Dispatch_Id"]) in keep], len(keep)
+
+
+def timed_window(d):
+    """Counter SUMS over the dispatches of each pass's own timed region (bench.py "launch_window"), with that run's own launch /
+    keyframe / iteration counts beside them -- what bench.py divides like by like (per-launch averages over all
+    dispatches of a profile run mix warm-up rounds, full rounds and rounds queued in vain)."""
+    out = {}
+    passes = {"pmc_fetch": "bench_pmc_fetch.json", "pmc_write": "bench_pmc_write.json", "pmc_sq": "bench_pmc_sq.json",
+              "pmc_flops": "bench_pmc_flops.json", "pmc_mix": "bench_pmc_mix.json"}
+    per_pass = {}
+    for sub, bench_file in passes.items():
+        line = bench_line(os.path.join(d, bench_file))
+        if not line or "launch_window" not in line:
+            continue
+        w = line["launch_window"]
+        rows = []
+        for path in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                rows += list(csv.DictReader(f))
+        per_pass[sub] = w
+        trace = []
+        for path in glob.glob(os.path.join(d, sub, "**", "*kernel_trace.csv"), recursive=True):
+            with open(path) as f:
+                trace += list(csv.DictReader(f))
+        for name, kernels, before, count in (("pose", POSE_KERNELS, w["pose_dispatches_before"], w["pose_dispatches_timed"]),
+                                             ("geometry", GEOMETRY_KERNELS, w["geometry_dispatches_before"], w["geometry_dispatches_timed"])):
+            sel, n = window_rows(rows, kernels, before, count)
+            e = out.setdefault(name, {"passes": {}})
+            sums = collections.defaultdict(float)
+            for r in sel:
+                sums[r["Counter_Name"]] += float(r["Counter_Value"])
+            e["passes"][sub] = {"dispatches": n, "iterations": w["iterations_timed"], "sums": dict(sums),
+                                "launches_with_work": w["pose_launches_with_work_timed"] if name == "pose" else n,
+                                "keyframes_visited": w["keyframes_visited_timed"] if name == "pose" else None, "surfels": w["surfels"]}
+            tsel, _ = window_rows(trace, kernels, before, count)
+            if tsel:   # kernel time of the same dispatches in this (counter) pass
+                e["passes"][sub]["duration_ns"] = sum(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in tsel)
+    # kernel time of the same dispatches in the stats pass (its own bench line)
+    stats_line = bench_line(os.path.join(d, "bench_stats.json"))
+    if stats_line and "launch_window" in stats_line:
+        w = stats_line["launch_window"]
+        rows = []
+        for path in glob.glob(os.path.join(d, "stats", "**", "*kernel_trace.csv"), recursive=True):
+            with open(path) as f:
+                rows += list(csv.DictReader(f))
+        for name, kernels, before, count in (("pose", POSE_KERNELS, w["pose_dispatches_before"], w["pose_dispatches_timed"]),
+                                             ("geometry", GEOMETRY_KERNELS, w["geometry_dispatches_before"], w["geometry_dispatches_timed"])):
+            sel, n = window_rows(rows, kernels, before, count)
+            if sel:
+                e = out.setdefault(name, {"passes": {}})
+                e["passes"]["stats"] = {"dispatches": n, "iterations": w["iterations_timed"],
+                                        "duration_ns": sum(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in sel)}
+    return out, stats_line
+
+
+def flatten_window(name, e, config):
+    """One record per sweep: every figure per ITERATION-normalised pass, scaled to the FETCH pass's iteration count."""
+    p = e["passes"]
+    if "pmc_fetch" not in p:
+        return None
+    ref = p["pmc_fetch"]
+    it = ref["iterations"]
+
+    def scaled(sub, counter):   # a pass may have run another number of iterations: per iteration, times the reference pass's count
+        q = p.get(sub)
+        if not q or counter not in q["sums"] or not q["iterations"]:
+            return None
+        return q["sums"][counter] * it / q["iterations"]
+
+    rec = {"iterations": it, "dispatches": ref["dispatches"], "launches_with_work": ref["launches_with_work"],
+           "FETCH_SIZE_kb": ref["sums"].get("FETCH_SIZE", 0.0), "WRITE_SIZE_kb": scaled("pmc_write", "WRITE_SIZE") or 0.0}
+    W, H, N = config["width"], config["height"], ref["surfels"]
+    if name == "pose":
+        rec["keyframes_visited"] = ref["keyframes_visited"]
+        rec["algorithmic_bytes"] = ref["launches_with_work"] * N * 28.0 + ref["keyframes_visited"] * W * H * 5.0
+    else:
+        rec["algorithmic_bytes"] = ref["dispatches"] * (N * 70.0 + config["keyframes"] * W * H * 9.0)
+    if "stats" in p and p["stats"]["iterations"]:
+        rec["duration_ns"] = p["stats"]["duration_ns"] * it / p["stats"]["iterations"]
+    valu = scaled("pmc_flops", "SQ_INSTS_VALU") or scaled("pmc_sq", "SQ_INSTS_VALU")
+    n = {c: scaled("pmc_flops", "SQ_INSTS_VALU_" + c) for c in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")}
+    if valu and all(v is not None for v in n.values()):
+        rec["SQ_INSTS_VALU"] = valu
+        rec["fp32_flops"] = 64.0 * (n["ADD_F32"] + n["MUL_F32"] + n["TRANS_F32"] + 2.0 * n["FMA_F32"])
+        f64 = sum(scaled("pmc_mix", "SQ_INSTS_VALU_" + c) or 0.0 for c in ("ADD_F64", "MUL_F64", "FMA_F64"))
+        rec["non_arithmetic_valu_fraction"] = 1.0 - (sum(n.values()) + f64) / valu
+        for c in ("INT32", "INT64", "CVT"):
+            v = scaled("pmc_mix", "SQ_INSTS_VALU_" + c)
+            if v is not None:
+                rec["valu_fraction_" + c.lower()] = v / valu
+        if name == "pose" and rec.get("keyframes_visited"):
+            # wave-level VALU instructions per (64-surfel tile, keyframe) visit, had every tile been a candidate of every visited
+            # keyframe: an upper-bound denominator; the cull leaves ~20 candidates per tile of the bench scene
+            rec["valu_instructions_per_keyframe_visit"] = valu / rec["keyframes_visited"]
+    cycles = scaled("pmc_sq", "GRBM_GUI_ACTIVE")
+    valu_sq = scaled("pmc_sq", "SQ_INSTS_VALU")
+    if cycles and valu_sq:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs; 256 CUs x 4 SIMDs.  A wave64 VALU instruction occupies a SIMD-32 for 2 cycles at best.
+        rec["valu_cycles_per_instruction"] = 1024.0 * (cycles / 8.0) / valu_sq
+        dur = p.get("pmc_sq", {}).get("duration_ns")
+        if dur:   # shader cycles over the kernel time of the same dispatches in the same pass: the clock the sweep ran at
+            rec["shader_clock_mhz"] = (cycles / 8.0) / (dur * it / p["pmc_sq"]["iterations"] * 1e-9) / 1e6
+    return rec
+
+
 def main():
     d, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r2")
     p = argparse.ArgumentParser()
@@ -96,7 +221,22 @@ def main():
                    "one_dword_per_128B_line_reported_bytes": gather,
                    "one_dword_per_128B_line_bytes_moved_at_that_factor": gather * cal_bytes / coalesced,
                    "note": "factor = bytes read / bytes FETCH_SIZE reported, for global_load_dword over a 2 GiB buffer read once"}
-    out = {"config": config, "tag": tag, "kernels": kernels, "fetch_calibration": cal}
+    windows, stats_line = timed_window(d)
+    flat = {name: flatten_window(name, e, config) for name, e in windows.items()}
+    flat = {k: v for k, v in flat.items() if v}
+    out = {"config": config, "tag": tag, "kernels": kernels, "fetch_calibration": cal, "timed_window": flat}
+    if flat and cal:
+        print("\ntimed region of the profile run (sums over its dispatches; bench.py divides these like by like):")
+        for name, r in flat.items():
+            traffic = r["FETCH_SIZE_kb"] * 1024.0 * cal["factor"] + r["WRITE_SIZE_kb"] * 1024.0
+            print(f"  {name:9s} iterations {r['iterations']}  dispatches {r['dispatches']}  launches with work {r['launches_with_work']}  "
+                  f"traffic {traffic / 1e6:.1f} MB = {traffic / r['iterations'] / 1e6:.1f} MB per iteration  algorithmic "
+                  f"{r['algorithmic_bytes'] / r['iterations'] / 1e6:.1f} MB per iteration  ratio {traffic / r['algorithmic_bytes']:.3f}"
+                  + (f"  kernel time {r['duration_ns'] / r['iterations'] / 1e3:.1f} us per iteration" if r.get("duration_ns") else "")
+                  + (f"  {r['fp32_flops'] / (r['duration_ns'] * 1e-9) / 1e12:.1f} TFLOP/s binary32" if r.get("duration_ns") and r.get("fp32_flops") else "")
+                  + (f"  non-arithmetic VALU {r['non_arithmetic_valu_fraction']:.3f}" if "non_arithmetic_valu_fraction" in r else "")
+                  + (f"  {r['valu_cycles_per_instruction']:.2f} cycles per VALU instruction" if "valu_cycles_per_instruction" in r else "")
+                  + (f"  shader clock ~{r['shader_clock_mhz']:.0f} MHz" if "shader_clock_mhz" in r else ""))
     with open(os.path.join(d, "pmc_per_kernel.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("\nfetch calibration:", json.dumps(cal))
