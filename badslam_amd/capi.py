@@ -87,10 +87,12 @@ SIGNATURES = {
     "bahip_context_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "bahip_context_set_keyframe_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bahip_context_set_sum_classes": (C.c_int, [C.c_void_p, C.c_int]),
+    "bahip_context_set_creation_order": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_debug_set_tile_order": (C.c_int, [C.c_int]),
     "bahip_debug_read_tile_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     "bahip_rccl_get_unique_id": (C.c_int, [C.c_char_p]),
     "bahip_context_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "bahip_context_count_ranks": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "bahip_malloc_pitch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),
     "bahip_free": (C.c_int, [C.c_void_p]),
     "bahip_memcpy_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),

@@ -318,6 +318,10 @@ struct Intrinsics {
   // Interleaved partial sums per surfel in the normals / geometry passes (kernels_surfel.hip: tile_sums) -- part of the NUMERICAL
   // DEFINITION of those sums: 4 (default) or 8 (bahip_context_set_sum_classes; what keyframe sharding over 8 ranks needs)
   int sum_classes;
+  // Side, in pixels, of the square tiles new surfels are numbered by (kernels_lifecycle.hip: tile_seq): 8 * cell (default: the 64
+  // surfels of a wavefront form a compact patch) or, for the reference's row-major append order, a side that covers the whole image
+  // (bahip_context_set_creation_order)
+  int create_tile;
 };
 
 struct SurfelsView {

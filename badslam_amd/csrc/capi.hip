@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <thread>
 
 #include <string>
 #include <vector>
@@ -109,6 +110,7 @@ struct bahip_context {
   uint8_t* dev_window = nullptr;
   size_t window_capacity = 0;
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
+  bool row_major_creation = false;   // new surfels of a keyframe appended in row-major pixel order (the reference's) instead of tile-major
   bool poll_disabled = false;        // the host copy of the pose counters is not updated by the kernel on this system: synchronise instead
   // lifecycle batch (bahip_lifecycle_batch_begin): bounding spheres of the cloud's whole tiles, for the per-keyframe sweeps of a batch
   void* dev_lifecycle_bounds = nullptr;
@@ -207,6 +209,7 @@ Intrinsics make_intrinsics(const bahip_camera& cc, const bahip_camera& dc, const
   in.geom_skip = plane_strip_skip(dc.height);
   in.fp_skip = plane_strip_skip(cc.height + 2);
   in.sum_classes = 4;   // (the context's choice is written over this: bahip_set_intrinsics, bahip_context_set_sum_classes)
+  in.create_tile = 8 * dp.sparse_surfel_cell_size;   // (likewise: bahip_context_set_creation_order)
   return in;
 }
 
@@ -750,6 +753,43 @@ int bahip_context_init_rccl(bahip_context* ctx, const char unique_id[BAHIP_RCCL_
   return 0;
 }
 
+// The first exchange of a run, as a probe: every rank contributes 1 through whatever transport the context uses (the hook or the
+// native RCCL communicator), on the context's stream, and the host waits for the sum with a time limit.  A multi-rank job whose
+// collective cannot complete (a rank that never arrived, a fabric that does not come up) otherwise hangs in the first BA
+// iteration without a word; this returns an error that says which exchange it was and how long it waited.
+int bahip_context_count_ranks(bahip_context* ctx, int timeout_ms, int* ranks_out) {
+  REQUIRE(ctx != nullptr && ranks_out != nullptr, "bahip_context_count_ranks: NULL argument");
+  *ranks_out = 1;
+  if (!is_sharded(ctx)) return 0;
+  DevMem word;
+  HIP_TRY(hipMalloc(&word.p, sizeof(long long)));
+  const long long one = 1;
+  HIP_TRY(hipMemcpyAsync(word.p, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
+  if (reduce_over_ranks(ctx, word.p, 1, BAHIP_SUM_I64)) return 1;
+  hipEvent_t done;
+  HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(done, ctx->stream));
+  const auto start = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t state = hipEventQuery(done);
+    if (state == hipSuccess) break;
+    if (state != hipErrorNotReady) { hipEventDestroy(done); return fail("the probe exchange failed on the device", __FILE__, __LINE__); }
+    if (timeout_ms > 0 && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start).count() > timeout_ms) {
+      // (the event and the buffer are left alone: the collective may still own them)
+      word.p = nullptr;
+      return fail(ctx->allreduce ? "the first all-reduce (hook transport) did not complete within the time limit: not every rank reached it"
+                                 : "the first ncclAllReduce (native RCCL transport over xGMI) did not complete within the time limit: not every rank "
+                                   "reached it, or the communicator's links did not come up (NCCL_DEBUG=INFO shows the ring)", __FILE__, __LINE__);
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  HIP_TRY(hipEventDestroy(done));
+  long long seen = 0;
+  HIP_TRY(hipMemcpy(&seen, word.p, sizeof(seen), hipMemcpyDeviceToHost));
+  *ranks_out = (int)seen;
+  return 0;
+}
+
 int bahip_malloc_pitch(void** ptr, size_t* pitch_bytes, size_t width_bytes, size_t height) {
   // Rows padded to 256 B (what hipMallocPitch would give), one plain allocation.
   const size_t pitch = (width_bytes + 255) & ~size_t(255);
@@ -895,7 +935,14 @@ int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, c
   ctx->color_cam = *color_camera; ctx->depth_cam = *depth_camera; ctx->dp = *dp;
   ctx->in = make_intrinsics(*color_camera, *depth_camera, *dp);
   ctx->in.sum_classes = ctx->sum_classes;
+  if (ctx->row_major_creation) ctx->in.create_tile = std::max(ctx->in.width, ctx->in.height);
   ctx->have_intrinsics = true;
+  return 0;
+}
+
+int bahip_context_set_creation_order(bahip_context* ctx, int row_major) {
+  ctx->row_major_creation = row_major != 0;
+  if (ctx->have_intrinsics) ctx->in.create_tile = ctx->row_major_creation ? std::max(ctx->in.width, ctx->in.height) : 8 * ctx->in.cell;
   return 0;
 }
 
@@ -1156,14 +1203,23 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
   if (pose_steps_out) *pose_steps_out = 0;
   if (not_converged_out) *not_converged_out = 0;
   if (!g_device_loop_enabled || K == 0 || kf_sharded(ctx) || opt->max_iterations <= 0 || !pose_round_can_be_queued_ahead(surfels->surfels_size, K, true)) return 0;
+  // With a HOST all-reduce hook every queued round is a stream synchronisation plus a host collective -- also the rounds queued
+  // behind the iteration that ended the loop, which exchange zeros: the host loop, which knows when to stop, serves
+  // that configuration.  The native RCCL path (collectives enqueued on the stream) keeps the device-driven loop.
+  if (ctx->allreduce != nullptr) return 0;
   REQUIRE(surfels->active != nullptr, "the alternating loop needs the active-surfel buffer");
   REQUIRE(ctx->have_covisibility && (int)ctx->covis_offsets.size() == K + 1, "bahip_set_covisibility must follow bahip_set_keyframes");
   REQUIRE(!opt->fixed_window || (int)ctx->window.size() == K, "bahip_set_activation_window must follow bahip_set_keyframes");
   REQUIRE(opt->activation_surfels_size <= surfels->surfels_size, "activation range exceeds surfels_size");
   if (ensure_work(ctx, K)) return 1;
-  if (!ctx->dev_loop_ctl) {
-    HIP_TRY(hipMalloc(&ctx->dev_loop_ctl, sizeof(int) * kLoopWords));
-    HIP_TRY(hipHostMalloc(&ctx->host_loop_ctl, sizeof(int) * (kLoopWords + kLoopLogSlots), hipHostMallocMapped | hipHostMallocCoherent));
+  if (!ctx->dev_loop_ctl || !ctx->host_loop_ctl) {   // both or neither: a call that got only the first must not leave it behind
+    if (!ctx->dev_loop_ctl) HIP_TRY(hipMalloc(&ctx->dev_loop_ctl, sizeof(int) * kLoopWords));
+    if (hipHostMalloc(&ctx->host_loop_ctl, sizeof(int) * (kLoopWords + kLoopLogSlots), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      ctx->host_loop_ctl = nullptr;
+      hipFree(ctx->dev_loop_ctl);
+      ctx->dev_loop_ctl = nullptr;
+      return fail("hipHostMalloc of the loop control words failed", __FILE__, __LINE__);
+    }
   }
   const SurfelsView sv = make_view(surfels);
   if (ensure_tile_bounds(ctx, sv.size)) return 1;
@@ -1188,8 +1244,13 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
   int rounds_floor = rounds_forced ? rounds_ahead : std::min(rounds_ahead, 2);
   std::vector<int> queued_rounds;    // per queued iteration of the current batch
   int last_needed[2] = {0, 0};       // rounds the last two completed phases needed
-  int it = 0, done_before = 0;
+  int it = 0, done_before = 0, rounds_before = 0;
   bool converged = false;
+  // Under surfel sharding every rank must queue the SAME rounds (each is a collective): the schedule may depend on nothing but what
+  // all ranks hold alike -- the loop's control words on the device, identical everywhere because the sums are exchanged and the
+  // solve is replicated.  The per-round log in mapped host memory is not used then (whether a rank can poll it, poll_disabled, is a
+  // property of that rank's runtime: ADVICE r4, ranks that differed in it would have queued different numbers of collectives).
+  const bool rank_invariant_schedule = is_sharded(ctx);
   while (it < opt->max_iterations) {
     // heavy work first (wave_cull.h): the first phase queued here takes the census when one is due
     constexpr int kSchedulePhases = 32;
@@ -1276,8 +1337,14 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
     }
     const int completed = ctl[kLoopIterationsDone] - done_before;
     done_before = ctl[kLoopIterationsDone];
-    // rounds the completed phases needed: the log holds the work items every queued round iterated
-    if (!ctx->poll_disabled) {
+    const int rounds_now = ctl[kLoopRounds];
+    if (rank_invariant_schedule) {
+      if (completed > 0) {   // rounds with work per completed phase, rounded up (the control words: the same on every rank)
+        last_needed[0] = last_needed[1];
+        last_needed[1] = std::max(1, (rounds_now - rounds_before + completed - 1) / completed);
+      }
+    } else if (!ctx->poll_disabled) {
+      // rounds the completed phases needed: the log holds the work items every queued round iterated
       const int* log = ctl + kLoopWords;
       int slot = 0;
       for (int j = 0; j < completed && j < (int)queued_rounds.size(); ++j) {
@@ -1289,6 +1356,7 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
         last_needed[1] = std::max(1, needed);
       }
     }
+    rounds_before = rounds_now;
     const int handed_over_rounds = completed < (int)queued_rounds.size() ? queued_rounds[completed] : rounds_ahead;
     it += completed;
     if (ctl[kLoopStop] == 1) { converged = true; break; }
@@ -1966,7 +2034,8 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   // what a sharded run exchanges: the limbs, as int64 -- an exact sum, so sharded == unsharded bit for bit
   const size_t x1_init = ((size_t)kHotExchanged1 * kHotReplicas + 2 * (size_t)head_count) * kExactLimbs;
   const size_t x1_step = ((size_t)kHotExchanged1 * kHotReplicas + (size_t)head_count) * kExactLimbs;
-  const size_t x2 = (size_t)kHotReplicas * kExactLimbs;
+  const size_t x2 = ((size_t)kHotReplicas + 1) * kExactLimbs;   // the sticky flag's cell + slot 20, from ex.invalid on
+  void* const x2_from = ex.invalid;
   // heavy work first (wave_cull.h): the init sweep takes the census when there is no schedule for this grid yet (a PCG-only
   // caller never runs the pose sweep that usually provides it), the inner steps use it
   const uint32_t padded_tiles = pose_padded_tiles(sv.size);
@@ -1990,7 +2059,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
   CHECK_LAUNCH();
   launch_pcg_init2(st, L, ex, ctx->dp.a, r_, M_, delta, g_, p_);
   CHECK_LAUNCH();
-  if (sharded && reduce_over_ranks(ctx, ex.hot_tail, x2, BAHIP_SUM_I64)) return 1;
+  if (sharded && reduce_over_ranks(ctx, x2_from, x2, BAHIP_SUM_I64)) return 1;
 
   // Inner loop: the stopping rule runs on the device (pcg_control_kernel), so steps are queued in groups without a host
   // round trip per step; kernels queued after the stop return at once.  The host only looks at `stop` between groups.
@@ -2013,7 +2082,7 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
     CHECK_LAUNCH();
     launch_pcg_step2(st, L, ex, r_, M_, delta, g_, p_, sc + i_an, sc + 1, ctl);
     CHECK_LAUNCH();
-    if (sharded && reduce_over_ranks(ctx, ex.hot_tail, x2, BAHIP_SUM_I64)) return 1;
+    if (sharded && reduce_over_ranks(ctx, x2_from, x2, BAHIP_SUM_I64)) return 1;
     launch_pcg_control(st, ex, ctl, sc + i_bn);
     CHECK_LAUNCH();
     if (step < opt->max_inner_iterations - 1) {
@@ -2022,8 +2091,13 @@ int bahip_pcg_iteration(bahip_context* ctx, const bahip_pcg_options* opt, const 
     }
     if ((step + 1) % kStepsPerGroup == 0 || step == opt->max_inner_iterations - 1) {
       HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctl, 24, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ctx->pinned_i + 8, ex.invalid, sizeof(unsigned), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       steps = ctx->pinned_i[4];
+      // the sticky flag has been through exchange 2 of this step: every rank reads the same value here and fails alike
+      if (ctx->pinned_i[8])
+        return fail("PCG scheme: a non-finite term was added to the exact sums (on this rank or on another one); the surfels or images hold "
+                    "non-finite values", __FILE__, __LINE__);
       if (ctx->pinned_i[3]) break;   // stop
     }
   }

@@ -164,10 +164,15 @@ merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* 
 // ---- creation ---------------------------------------------------------------------------------------
 // New surfels are numbered tile-major: tiles of 8x8 sparse cells (TP = 8*cell pixels per side),
 // row-major inside a tile, so that the 64 surfels of a wavefront form a compact patch that
-// wave_cull.h can bound tightly.  (The reference numbers them by a prefix sum over the row-major
-// pixel index, B/kernel_create_surfels.cu:357-390; the order is not observable in its results.)
+// wave_cull.h can bound tightly.  The reference numbers them by a prefix sum over the row-major
+// pixel index (B/kernel_create_surfels.cu:357-390).  The order IS observable once surfels merge -- of
+// two mergeable surfels the lower index survives (B/kernel_supporting_surfels.cu:60-86): ~1 % of the
+// survivors of tests/golden/e2e_vga.npz -- so the reference's order is offered as a mode: with one
+// "tile" that covers the whole image (Intrinsics::create_tile >= width, height) the same sequence
+// is y * create_tile + x, i.e. row-major (bahip_context_set_creation_order; tests/test_gpu_e2e_vga.py
+// holds that mode against the unmodified reference run).
 // The flag / index vectors are laid out in that sequence order, padded to whole tiles.
-__device__ __forceinline__ int tile_side(const Intrinsics& in) { return 8 * in.cell; }
+__device__ __forceinline__ int tile_side(const Intrinsics& in) { return in.create_tile; }
 __device__ __forceinline__ int tiles_per_row(const Intrinsics& in) { return (in.width + tile_side(in) - 1) / tile_side(in); }
 __device__ __forceinline__ size_t tile_seq(const Intrinsics& in, int x, int y) {
   const int tp = tile_side(in);
@@ -469,7 +474,7 @@ void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& fra
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags);
 }
 size_t create_padded_count(const Intrinsics& in) {
-  const size_t tp = 8 * (size_t)in.cell;
+  const size_t tp = (size_t)in.create_tile;
   return ((in.width + tp - 1) / tp) * ((in.height + tp - 1) / tp) * tp * tp;
 }
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,

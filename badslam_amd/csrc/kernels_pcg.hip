@@ -58,8 +58,12 @@ __device__ __forceinline__ int intrinsics_slot(const PcgLayout& L, uint32_t u) {
 
 // ---- the exact accumulators of one PCG solve ------------------------------------------------------------------------------
 // One device allocation, laid out so that what a sharded run exchanges is contiguous:
-//   [ replicated slots 0..19 | head A | head B | replicated slot 20 | replicated slots 21..22 | invalid flag ]
-// exchange 1 (after a sweep) = slots 0..19 + head A (+ head B after PCGInit); exchange 2 (after a dot product) = slot 20.
+//   [ replicated slots 0..19 | head A | head B | invalid flag | replicated slot 20 | replicated slots 21..22 ]
+// exchange 1 (after a sweep) = slots 0..19 + head A (+ head B after PCGInit); exchange 2 (after a dot product) = the flag's cell +
+// slot 20.  The sticky flag travels with exchange 2, which precedes every evaluation of the stopping rule: once any rank has
+// added a non-finite term, every rank's flag is non-zero (the integer sum counts the ranks that raised it) from the next control
+// step on, all ranks stop after the same inner step and all fail the call alike (round 4 kept the flag behind the block: a
+// rank that saw a NaN stopped three steps later, its peers went on, and the collective sequence diverged -- a hang).
 // Slots 21 / 22 hold the dense head's share of the dot products: the head is replicated over the ranks, so every rank adds the
 // same terms there and they are NOT exchanged.
 __device__ __forceinline__ ExactCell* hot_cell(const PcgExact& ex, int slot, int replica) {
@@ -851,8 +855,8 @@ PcgExact pcg_exact_view(void* buffer, uint32_t head_count) {
   ex.hot = base;
   ex.head_a = base + (size_t)kHotExchanged1 * kHotReplicas;
   ex.head_b = ex.head_a + head_count;
-  ex.hot_tail = ex.head_b + head_count;
-  ex.invalid = reinterpret_cast<unsigned*>(ex.hot_tail + (size_t)(kHotSlots - kHotExchanged1) * kHotReplicas);
+  ex.invalid = reinterpret_cast<unsigned*>(ex.head_b + head_count);   // a whole cell: the first word of what exchange 2 carries
+  ex.hot_tail = ex.head_b + head_count + 1;
   return ex;
 }
 

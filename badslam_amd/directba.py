@@ -253,6 +253,24 @@ class DirectBA:
         """This object holds rank `rank`'s chunk-cyclic shard of one cloud; lifecycle phases run on the gathered cloud."""
         assert self.L.dba_set_surfel_sharding(self.h, int(rank), int(world), int(chunk)) == 0
 
+    def MergeKeyframes(self, approx_merge_count=10):
+        self.L.dba_merge_keyframes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        assert self.L.dba_merge_keyframes(self.h, self.stream, int(approx_merge_count)) == 0
+
+    def keyframe_exists(self, k):
+        self.L.dba_keyframe_exists.argtypes = [C.c_void_p, C.c_int]
+        return bool(self.L.dba_keyframe_exists(self.h, int(k)))
+
+    def ExportToPointCloud_count(self):
+        n = C.c_uint()
+        self.L.dba_export_point_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]
+        assert self.L.dba_export_point_count(self.h, self.stream, C.byref(n)) == 0
+        return int(n.value)
+
+    def SetRowMajorCreation(self, enabled):
+        self.L.dba_set_row_major_creation.argtypes = [C.c_void_p, C.c_int]
+        assert self.L.dba_set_row_major_creation(self.h, int(bool(enabled))) == 0
+
     def SetSumClasses(self, classes):
         self.L.dba_set_sum_classes.argtypes = [C.c_void_p, C.c_int]
         assert self.L.dba_set_sum_classes(self.h, int(classes)) == 0

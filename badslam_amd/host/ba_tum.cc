@@ -10,6 +10,13 @@
 //
 //   ba_tum <dataset_dir> <trajectory_file> <out_prefix> [--interval N] [--iterations N] [--cell N] [--max_depth M]
 //          [--raw_to_float_depth S] [--pcg] [--intrinsics] [--incremental | --parallel_ba] [--save_state F] [--load_state F]
+//          [--ba_call_iterations N] [--baseline_fx F] [--spatial_sort_cell C] [--row_major_creation]
+//          [--bilateral_sigma_xy S] [--bilateral_sigma_inv_depth S] [--bilateral_radius_factor R]
+//
+// --ba_call_iterations N: every BA call runs exactly N iterations (min = max = N) instead of 1 .. 10; the remaining options set
+// what B/bad_slam_config.h makes configurable (and the two order switches of this backend): together they let a TUM-format copy of
+// a test scene go through exactly the chain of tests/e2e_vga.py (tests/test_gpu_tum_pipeline.py holds the result against the
+// reference's own kernels).
 //
 // --incremental / --parallel_ba feed the keyframes one at a time through vis::BAScheduler (ba_scheduler.h), the way
 // BadSlam::ProcessFrame does: each keyframe arrives with its pose relative to the previous keyframe (taken from the
@@ -82,6 +89,9 @@ int main(int argc, char** argv) {
   const std::string dataset = argv[1], trajectory = argv[2], out = argv[3];
   int interval = 1, iterations = 10, cell = 4;
   float raw_to_float_depth = 1.0f / 5000;   // TUM RGB-D depth PNGs: 5000 units per metre
+  float baseline_fx = 40.f, spatial_sort_cell = -1.f;
+  int ba_call_iterations = 0;
+  bool row_major_creation = false;
   bool use_pcg = false, intrinsics = false, incremental = false, parallel_ba = false;
   std::string save_state, load_state;
   PreprocessConfig config;
@@ -92,6 +102,13 @@ int main(int argc, char** argv) {
     else if (a == "--cell" && i + 1 < argc) cell = atoi(argv[++i]);
     else if (a == "--max_depth" && i + 1 < argc) config.max_depth = (float)atof(argv[++i]);
     else if (a == "--raw_to_float_depth" && i + 1 < argc) raw_to_float_depth = (float)atof(argv[++i]);
+    else if (a == "--ba_call_iterations" && i + 1 < argc) ba_call_iterations = atoi(argv[++i]);
+    else if (a == "--baseline_fx" && i + 1 < argc) baseline_fx = (float)atof(argv[++i]);
+    else if (a == "--spatial_sort_cell" && i + 1 < argc) spatial_sort_cell = (float)atof(argv[++i]);
+    else if (a == "--row_major_creation") row_major_creation = true;
+    else if (a == "--bilateral_sigma_xy" && i + 1 < argc) config.bilateral_filter_sigma_xy = (float)atof(argv[++i]);
+    else if (a == "--bilateral_sigma_inv_depth" && i + 1 < argc) config.bilateral_filter_sigma_inv_depth = (float)atof(argv[++i]);
+    else if (a == "--bilateral_radius_factor" && i + 1 < argc) config.bilateral_filter_radius_factor = (float)atof(argv[++i]);
     else if (a == "--pcg") use_pcg = true;
     else if (a == "--intrinsics") intrinsics = true;
     else if (a == "--incremental") incremental = true;
@@ -111,10 +128,12 @@ int main(int argc, char** argv) {
   BAHIP_CHECKED_CALL(bahip_stream_create(&stream));
   {
     // B/bad_slam.cc:125-142 with the defaults of B/bad_slam_config.h
-    DirectBA ba(/*max_surfel_count*/ 25 * 1000 * 1000, raw_to_float_depth, /*baseline_fx*/ 40, cell, /*surfel_merge_dist_factor*/ 0.8f,
+    DirectBA ba(/*max_surfel_count*/ 25 * 1000 * 1000, raw_to_float_depth, baseline_fx, cell, /*surfel_merge_dist_factor*/ 0.8f,
                 /*min_observation_count_while_bootstrapping_1*/ 1, /*min_observation_count_while_bootstrapping_2*/ 2, /*min_observation_count*/ 2,
                 *video.color_camera(), *video.depth_camera(), /*pyramid_level_for_color*/ 0, /*use_depth_residuals*/ true,
                 /*use_descriptor_residuals*/ true, nullptr, SE3f());
+    if (spatial_sort_cell >= 0.f) ba.SetSpatialSortCellSize(spatial_sort_cell);
+    if (row_major_creation) ba.SetRowMajorCreation(true);
     vector<SE3f> original_keyframe_T_global;
     if (incremental) {
       BASchedulerConfig scheduler_config;
@@ -153,7 +172,8 @@ int main(int argc, char** argv) {
         int done = 0;
         bool converged = false;
         ba.BundleAdjustment(stream, /*optimize_depth_intrinsics*/ intrinsics, /*optimize_color_intrinsics*/ intrinsics, /*do_surfel_updates*/ true,
-                            /*optimize_poses*/ true, /*optimize_geometry*/ true, /*min_iterations*/ 1, /*max_iterations*/ 10, use_pcg, 0,
+                            /*optimize_poses*/ true, /*optimize_geometry*/ true, /*min_iterations*/ ba_call_iterations > 0 ? ba_call_iterations : 1,
+                            /*max_iterations*/ ba_call_iterations > 0 ? ba_call_iterations : 10, use_pcg, 0,
                             (int)ba.keyframes().size() - 1, /*increase_ba_iteration_count*/ true, &done, &converged);
         printf("BA call %d: %d iteration(s)%s, %u surfels\n", i + 1, done, converged ? ", converged" : "", ba.surfel_count());
       }

@@ -2,6 +2,7 @@
 #include "../../include/badslam_directba.h"
 
 #include "direct_ba.h"
+#include "rgbd_io.h"   // Point3fC3u8Nf
 
 using namespace vis;
 
@@ -87,6 +88,17 @@ int dba_upload_keyframe_image(dba_handle* h, void* stream, int id, int which, co
     default: return 1;
   }
   kf->RefreshPlanes(static_cast<hipStream_t>(stream));
+  return 0;
+}
+int dba_keyframe_exists(dba_handle* h, int id) { return (id >= 0 && id < (int)h->ba->keyframes().size() && h->ba->keyframes()[id]) ? 1 : 0; }
+int dba_merge_keyframes(dba_handle* h, void* stream, int approx_merge_count) {
+  h->ba->MergeKeyframes(static_cast<hipStream_t>(stream), nullptr, (vis::usize)approx_merge_count);
+  return 0;
+}
+int dba_export_point_count(dba_handle* h, void* stream, unsigned* count_out) {
+  std::vector<vis::Point3fC3u8Nf> cloud;
+  h->ba->ExportToPointCloud(static_cast<hipStream_t>(stream), &cloud);
+  *count_out = (unsigned)cloud.size();
   return 0;
 }
 int dba_delete_keyframe(dba_handle* h, int id) {
@@ -192,6 +204,10 @@ int dba_set_ba_iteration_counts(dba_handle* h, int count, int last) {
 }
 int dba_set_surfel_sharding(dba_handle* h, int rank, int world, uint32_t chunk) {
   h->ba->SetSurfelSharding(rank, world, chunk);
+  return 0;
+}
+int dba_set_row_major_creation(dba_handle* h, int enabled) {
+  h->ba->SetRowMajorCreation(enabled != 0);
   return 0;
 }
 int dba_set_sum_classes(dba_handle* h, int classes) {

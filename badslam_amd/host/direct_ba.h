@@ -21,6 +21,7 @@ constexpr int kSurfelAttributeCount = BAHIP_SURFEL_ATTRIBUTE_COUNT;
 constexpr int kSurfelX = 0, kSurfelY = 1, kSurfelZ = 2, kSurfelNormal = 3, kSurfelRadiusSquared = 4, kSurfelColor = 5,
               kSurfelDescriptor1 = 6, kSurfelDescriptor2 = 7, kSurfelAccum0 = 8;   // B/kernels.cuh:69-88
 
+struct Point3fC3u8Nf;   // rgbd_io.h (L/point_cloud.h: the element of Point3fC3u8NfCloud)
 class DirectBA {
  public:
   DirectBA(int max_surfel_count, float raw_to_float_depth, float baseline_fx, int sparse_surfel_cell_size,
@@ -34,6 +35,8 @@ class DirectBA {
   void AddKeyframe(const shared_ptr<Keyframe>& new_keyframe);
   void DeleteKeyframe(int keyframe_index, void* loop_detector = nullptr);
   void MergeKeyframes(hipStream_t stream, void* loop_detector, usize approx_merge_count = 10);
+  // B/direct_ba.h:175, B/direct_ba.cc:461-547: the valid surfels as a point cloud (position, colour, normal), in index order
+  void ExportToPointCloud(hipStream_t stream, vector<Point3fC3u8Nf>* cloud);
   void CreateSurfelsForKeyframe(hipStream_t stream, bool filter_new_surfels, const shared_ptr<Keyframe>& keyframe);
   void EstimateFramePose(hipStream_t stream, const SE3f& global_T_frame_initial_estimate, const CUDABuffer<u16>& depth_buffer,
                          const CUDABuffer<u16>& normals_buffer, hipTextureHandle_t color_texture,
@@ -148,6 +151,10 @@ class DirectBA {
   // The per-surfel sums of the normals / geometry passes are defined over 4 (default) or 8 interleaved keyframe classes
   // (bahip_context_set_sum_classes); keyframe sharding over 8 ranks needs 8 -- and so does the single-GPU run it is compared with.
   void SetSumClasses(int classes);
+  // Ours: new surfels of a keyframe in the reference's row-major append order (B/kernel_create_surfels.cu:357-390) instead of this
+  // backend's tile-major one (bahip_context_set_creation_order): the same surfels, the reference's indices -- and therefore the
+  // reference's survivors when surfels merge.  Slower sweeps until the next spatial reorder (SetSpatialSortCellSize).
+  void SetRowMajorCreation(bool enabled);
   bahip_context* backend_context() { return ctx_; }
   // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
   // keyframe ids and the dense bound list.  Public so that a caller can drive single bahip_* stages

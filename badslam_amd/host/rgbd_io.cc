@@ -304,6 +304,8 @@ bool LoadCalibration(DirectBA* direct_ba, const std::string& import_base_path) {
   return true;
 }
 
+// the member of B/direct_ba.h:175 (declared in direct_ba.h; the element type and the row downloads live in this file)
+void DirectBA::ExportToPointCloud(hipStream_t stream, vector<Point3fC3u8Nf>* cloud) { vis::ExportToPointCloud(stream, *this, cloud); }
 void ExportToPointCloud(hipStream_t stream, DirectBA& direct_ba, vector<Point3fC3u8Nf>* cloud) {
   const u32 surfels_size = direct_ba.surfels_size();
   cloud->clear();

@@ -302,7 +302,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+
+    class Watchdog:
+        """A multi-rank job that cannot complete its rendezvous or its first collective hangs without a word (the driver then only
+        sees its own time limit).  This prints which step did not finish, on which rank, and ends the rank with a non-zero code."""
+        def __init__(self, what, seconds):
+            import threading
+            self.timer = threading.Timer(seconds, self.fire, (what, seconds))
+            self.timer.daemon = True
+        def fire(self, what, seconds):
+            print(f"bench.py: rank {rank} of {world}: {what} did not finish within {seconds:.0f} s -- not every rank arrived, or the "
+                  f"transport (RCCL over xGMI; MASTER_ADDR={os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}) did not come up. "
+                  f"NCCL_DEBUG=INFO shows the communicator's rings; BENCH_COLLECTIVE_TIMEOUT_S changes this limit.", file=sys.stderr, flush=True)
+            os._exit(4)
+        def __enter__(self):
+            self.timer.start()
+            return self
+        def __exit__(self, *exc):
+            self.timer.cancel()
+            return False
+
+    collective_timeout = float(os.environ.get("BENCH_COLLECTIVE_TIMEOUT_S", "180"))
     if world > 1 or args.force_allreduce:
+        import datetime
         import torch.distributed as dist
         # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a device (plumbing test on a 1-GPU box: RCCL
         # refuses two ranks on one device, gloo stages the all-reduce through the host)
@@ -314,10 +336,12 @@ def main():
         torch.cuda.set_device(device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with Watchdog("the torch.distributed rendezvous (init_process_group)", collective_timeout):
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index),
+                                        timeout=datetime.timedelta(seconds=collective_timeout))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=collective_timeout))
     else:
         torch.cuda.set_device(0)
 
@@ -350,23 +374,33 @@ def main():
     ba.upload_surfels(np.ascontiguousarray(data[:, mine]) if (shard_world > 1 and not by_keyframes) else data)
     ctx = ba.backend_context()
     hook_keepalive = None
+    ranks_seen = 1
     if dist is not None:
-        if dist.get_backend() == "nccl" and not os.environ.get("BENCH_ALLREDUCE_HOOK"):
-            # native path: the backend owns an RCCL communicator and issues ncclAllReduce on its own stream.  Should the
-            # communicator not come up on some system (all ranks must agree, hence the vote), the hook over torch.distributed
-            # carries the same sums.
-            try:
-                multigpu.init_rccl(ctx, dist)
-                native_ok = 1
-            except Exception as e:   # noqa: BLE001 -- whatever it is, the run should still be measured
-                log(f"native RCCL path unavailable ({e}); using the torch.distributed hook")
-                native_ok = 0
-            vote = torch.tensor([native_ok], device="cuda", dtype=torch.int32)
-            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
-            if int(vote.item()) == 0:
+        with Watchdog("setting up the backend's transport (ncclCommInitRank / the first all-reduce)", collective_timeout):
+            if dist.get_backend() == "nccl" and not os.environ.get("BENCH_ALLREDUCE_HOOK"):
+                # native path: the backend owns an RCCL communicator and issues ncclAllReduce on its own stream.  Should the
+                # communicator not come up on some system (all ranks must agree, hence the vote), the hook over torch.distributed
+                # carries the same sums.
+                try:
+                    multigpu.init_rccl(ctx, dist)
+                    native_ok = 1
+                except Exception as e:   # noqa: BLE001 -- whatever it is, the run should still be measured
+                    log(f"native RCCL path unavailable ({e}); using the torch.distributed hook")
+                    native_ok = 0
+                vote = torch.tensor([native_ok], device="cuda", dtype=torch.int32)
+                dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+                if int(vote.item()) == 0:
+                    hook_keepalive = multigpu.install_allreduce(ctx, dist)
+            else:
                 hook_keepalive = multigpu.install_allreduce(ctx, dist)
-        else:
-            hook_keepalive = multigpu.install_allreduce(ctx, dist)
+            # the first exchange of the run, as a probe with a time limit: every rank contributes 1 through the transport the BA
+            # loop is going to use; the line reports how many took part
+            seen = C.c_int()
+            capi.check(ctx.lib.bahip_context_count_ranks(ctx.handle, int(1e3 * collective_timeout), C.byref(seen)))
+            ranks_seen = int(seen.value)
+            if ranks_seen != world:
+                print(f"bench.py: rank {rank}: the probe exchange counted {ranks_seen} rank(s), the launcher started {world}", file=sys.stderr)
+                sys.exit(2)
     K = args.keyframes
     if by_keyframes:
         if shard_world == 8:
@@ -423,9 +457,19 @@ def main():
             out_ms[s], out_n[s] = ms.value, n.value
         return out_ms, out_n
 
-    # THE SAME `steps` ITERATIONS ONCE MORE, INSTRUMENTED: hipEvent pairs around every launch of the dominant kernel, on the
-    # backend's own stream -- the roofline's launch duration, measured live; the line carries this region's own ms per step beside
-    # `ms_per_step`.  The other stages are timed in a few extra iterations afterwards (ten event records per iteration).
+    # THE SAME ITERATIONS ONCE MORE, INSTRUMENTED: the scene is put back to its perturbed start (surfels re-uploaded, poses, cameras
+    # and cfactor image reset) and warmed up again -- the backend is deterministic, so iterations warmup + 1 .. warmup + steps repeat
+    # bit for bit, the same keyframes taking the same Gauss-Newton steps -- now with a hipEvent pair around every launch of the dominant
+    # kernel, on the backend's own stream: the roofline's launch duration, measured live on the work of the timed region.  The line
+    # carries this region's own ms per step beside `ms_per_step`.  The other stages are timed in a few extra iterations afterwards.
+    ba.upload_surfels(np.ascontiguousarray(data[:, mine]) if (shard_world > 1 and not by_keyframes) else data)
+    for k, T in enumerate(start_poses):
+        ba.set_keyframe_pose(k, T)
+    ba.set_cameras(*start_cameras)
+    ba.L.dba_clear_cfactor(ba.h, ba.stream)
+    capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
+    if args.warmup > 0:
+        run(args.warmup)
     capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 3))
     capi.check(ctx.lib.bahip_debug_pose_form_launches(None, None, 1))
     dispatches_before = pose_dispatches()
@@ -435,6 +479,10 @@ def main():
     ctx.synchronize()
     instrumented_elapsed = time.perf_counter() - t_instr
     dispatches_timed = pose_dispatches() - dispatches_before
+    repeat_stats = ba.last_stats()
+    if (repeat_stats["pose_rounds"], repeat_stats["pose_steps"]) != (stats["pose_rounds"], stats["pose_steps"]):
+        log(f"note: the instrumented repeat took {repeat_stats['pose_rounds']} rounds / {repeat_stats['pose_steps']} steps, the timed region "
+            f"{stats['pose_rounds']} / {stats['pose_steps']}")
     stage_ms, stage_launches = read_stage_timers()             # stage 2 over the instrumented region
     form_global, form_lds = C.c_longlong(), C.c_longlong()
     capi.check(ctx.lib.bahip_debug_pose_form_launches(C.byref(form_global), C.byref(form_lds), 0))
@@ -638,7 +686,10 @@ def main():
                              "what": "int64 fixed-point pose normal equations, one all-reduce per Gauss-Newton round"
                                      + ("; binary64 intrinsics accumulators" if args.intrinsics else "")
                                      + ("; int64 limbs of the PCG scheme's exact sums, two per inner step" if args.pcg else ""),
-                             "transport": "torch.distributed hook" if hook_keepalive is not None else "native RCCL (ncclAllReduce on the backend's stream)"},
+                             "transport": "torch.distributed hook" if hook_keepalive is not None else "native RCCL (ncclAllReduce on the backend's stream)",
+                             "torch_backend": dist.get_backend() if dist is not None else None,
+                             "n_ranks_seen": ranks_seen,
+                             "n_ranks_seen_note": "sum of 1 over the ranks through that transport before the first iteration (bahip_context_count_ranks, with a time limit)"},
                 "per_rank": per_rank} if per_rank is not None else {}),
             "stage_ms_per_iteration": {STAGES[s]: breakdown_ms[s] / BREAKDOWN_STEPS for s in range(5 if args.intrinsics else 4)},
             "stage_ms_note": f"{BREAKDOWN_STEPS} further iterations after the timed region, all stages timed; the surfel activation "
@@ -671,7 +722,7 @@ def main():
             out["iteration_fraction_of_hbm_roofline"] = b_alg_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9)
             out["launch_window"] = {"pose_dispatches_before": dispatches_before, "pose_dispatches_timed": dispatches_timed,
                                     "pose_launches_with_work_timed": launches, "keyframes_visited_timed": int(units.value),
-                                    "geometry_dispatches_before": args.warmup + args.steps, "geometry_dispatches_timed": args.steps,
+                                    "geometry_dispatches_before": 2 * args.warmup + args.steps, "geometry_dispatches_timed": args.steps,
                                     "iterations_timed": args.steps, "surfels": N_rank,
                                     "note": "which dispatches of the sweeps belong to the instrumented repeat of the timed region (in process "
                                             "order; the timed region's own iterations count as `before`); "
@@ -679,8 +730,10 @@ def main():
             out["instrumented_region"] = {"ms_per_step": 1e3 * instrumented_elapsed / args.steps,
                                           "ba_iterations_per_s": args.steps / instrumented_elapsed,
                                           "slowdown_by_event_records": instrumented_elapsed / local_elapsed - 1.0,
-                                          "note": "the timed region's iterations repeated right after it with a hipEvent pair around every "
-                                                  "pose-accumulate launch: where roofline.avg_launch_ms is measured; `value` has no event record in it"}
+                                          "same_work_as_timed_region": (repeat_stats["pose_rounds"], repeat_stats["pose_steps"]) == (stats["pose_rounds"], stats["pose_steps"]),
+                                          "note": "the timed region's iterations repeated from the same start state (scene reset, same warm-up: "
+                                                  "the same Gauss-Newton rounds and steps) with a hipEvent pair around every pose-accumulate launch: "
+                                                  "where roofline.avg_launch_ms is measured; `value` has no event record in it"}
             pmc, pmc_source = committed_profile(args) if (world == 1 and shard_world == 1) else (None, None)
             # the pose sums have two kernels (kernels_pose.hip): persistent workgroups with the normal equations in LDS when the
             # table of the launch's work items fits, one tile per wavefront with global atomics otherwise; the line names the one

@@ -40,6 +40,12 @@ int dba_get_keyframe_activation(dba_handle* h, int keyframe_id);
 int dba_download_keyframe_image(dba_handle* h, void* hip_stream, int keyframe_id, int which, void* out);
 int dba_upload_keyframe_image(dba_handle* h, void* hip_stream, int keyframe_id, int which, const void* in);
 int dba_delete_keyframe(dba_handle* h, int keyframe_id);
+/* DirectBA::MergeKeyframes(stream, loop_detector = NULL, approx_merge_count) (B/direct_ba.h:98-101, B/direct_ba.cc:251-338): deletes
+ * up to approx_merge_count keyframes whose neighbours in the sequence are closest (never keyframe 0); dba_keyframe_exists: 1 while
+ * the slot of that id still holds a keyframe.  dba_export_point_count: DirectBA::ExportToPointCloud (B/direct_ba.h:175), size only. */
+int dba_merge_keyframes(dba_handle* h, void* hip_stream, int approx_merge_count);
+int dba_keyframe_exists(dba_handle* h, int keyframe_id);
+int dba_export_point_count(dba_handle* h, void* hip_stream, unsigned* count_out);
 
 /* DirectBA::CreateSurfelsForKeyframe */
 int dba_create_surfels_for_keyframe(dba_handle* h, void* hip_stream, int filter_new_surfels, int keyframe_id);
@@ -80,6 +86,9 @@ int dba_set_surfel_sharding(dba_handle* h, int rank, int world, uint32_t chunk);
 /* DirectBA::SetSumClasses: 4 (default) or 8 interleaved keyframe classes in the definition of the per-surfel sums
  * (bahip_context_set_sum_classes) */
 int dba_set_sum_classes(dba_handle* h, int classes);
+/* DirectBA::SetRowMajorCreation (ours): 1 = the surfels a keyframe creates are appended in the reference's row-major pixel order
+ * (B/kernel_create_surfels.cu:357-390), 0 (default) = tile-major (bahip_context_set_creation_order) */
+int dba_set_row_major_creation(dba_handle* h, int enabled);
 /* DirectBA::SetKeyframeSharding: this object holds all surfels and the images of the keyframes k with k % world == rank
  * (bahip_context_set_keyframe_sharding; world = 1, 2, 4, or 8 after dba_set_sum_classes(h, 8)) */
 int dba_set_keyframe_sharding(dba_handle* h, int rank, int world);

@@ -133,9 +133,20 @@ int bahip_context_set_keyframe_sharding(bahip_context* ctx, int rank, int world)
  * in binary32 they differ in the last bits like any reordering.  The oracle takes the same parameter (orc_set_sum_classes), and
  * both class counts are held against it bit for bit.  Takes effect at once (no re-binding needed). */
 int bahip_context_set_sum_classes(bahip_context* ctx, int classes);
+/* Order in which the surfels a keyframe creates are appended: 0 (default) = by tiles of 8 x 8 sparse cells of the creating
+ * keyframe, row-major inside a tile -- the 64 surfels of a wavefront form a compact patch, which is what the sweeps' culling wants;
+ * 1 = row-major over the whole image, the reference's order (B/kernel_create_surfels.cu:357-390).  The same surfels either way;
+ * their indices differ inside each keyframe's block, and with them which of two mergeable surfels survives (the lower index:
+ * B/kernel_supporting_surfels.cu:60-86).  Takes effect for the creations that follow. */
+int bahip_context_set_creation_order(bahip_context* ctx, int row_major);
 #define BAHIP_RCCL_UNIQUE_ID_BYTES 128
 int bahip_rccl_get_unique_id(char unique_id_out[BAHIP_RCCL_UNIQUE_ID_BYTES]);
 int bahip_context_init_rccl(bahip_context* ctx, const char unique_id[BAHIP_RCCL_UNIQUE_ID_BYTES], int rank, int world_size);
+/* The first exchange of a run, as a probe: every rank contributes 1 through the context's transport (hook or native RCCL) on the
+ * context's stream; the host waits for the sum at most timeout_ms (<= 0: for ever) and returns the number of ranks that took
+ * part.  A job whose first collective cannot complete fails here with a message instead of hanging inside the first BA iteration.
+ * Every rank must call it at the same point.  1 rank / no transport: *ranks_out = 1. */
+int bahip_context_count_ranks(bahip_context* ctx, int timeout_ms, int* ranks_out);
 
 /* Device memory helpers (what libvis CUDABuffer does with cudaMallocPitch / cudaMemcpy2DAsync,
  * libvis/src/libvis/cuda/cuda_buffer_inl.h:36-186). */

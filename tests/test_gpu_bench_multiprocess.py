@@ -30,6 +30,11 @@ def test_bench_under_torchrun_with_shared_device(world):
     assert "roofline" in out and out["roofline"]["launches"] >= 3   # >= one pose round per iteration on rank 0
     assert out["exchange"]["calls_per_iteration"] >= 1 and out["exchange"]["bytes_per_iteration"] >= 16 * 28 * 8
     assert [r["rank"] for r in out["per_rank"]] == list(range(world)) and sum(r["surfels"] for r in out["per_rank"]) == out["config"]["surfels"]
+    # what makes the first real multi-GPU run readable: how many ranks the first exchange counted through the
+    # transport the loop uses, which transport that is, and every rank's own time
+    assert out["exchange"]["n_ranks_seen"] == world and out["exchange"]["torch_backend"] == "gloo"
+    assert out["exchange"]["transport"] == "torch.distributed hook"          # gloo: the hook; over RCCL the native path
+    assert all(r["ms_per_step_before_barrier"] > 0 and "pose_accumulate" in r["stage_ms_per_iteration"] for r in out["per_rank"])
 
 
 def test_bench_sharded_by_keyframes():
@@ -69,6 +74,7 @@ def test_bench_sharded_by_keyframes_over_eight_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["parallelism"].startswith("keyframe-shard x8")
     assert len(out["per_rank"]) == 8 and all(r["surfels"] == out["config"]["surfels"] for r in out["per_rank"])
+    assert out["exchange"]["n_ranks_seen"] == 8 and out["exchange"]["calls_per_iteration"] >= 3
 
 
 def test_bench_launches_its_own_ranks():
@@ -88,3 +94,14 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, proc.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and len(out["per_rank"]) == 2
+
+
+def test_first_collective_watchdog_names_the_step():
+    """A rank whose peers never arrive must end with a message, not hang: one process claims to be rank 0 of 2 and nobody else
+    comes to the rendezvous."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29719",
+               BENCH_COLLECTIVE_TIMEOUT_S="8")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--keyframes", "8",
+                           "--surfels", "50000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert proc.returncode != 0 and proc.stdout.strip() == ""
+    assert "did not finish within" in proc.stderr or "rendezvous" in proc.stderr.lower() or "timeout" in proc.stderr.lower(), proc.stderr[-2000:]

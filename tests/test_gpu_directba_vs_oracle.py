@@ -131,3 +131,73 @@ def test_bundle_adjustment_with_surfel_updates(scene):
     assert np.array_equal(np.asarray(got_poses, np.float32), np.asarray(ref_poses, np.float32))
     got, ref = ba.download_surfels(8), orc.surfel_data[:8, :orc.surfels_size]
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_merge_keyframes_deletes_what_the_reference_rule_names():
+    """DirectBA::MergeKeyframes (B/direct_ba.cc:251-338; VERDICT r4 next 7c: implemented since round 3, never called by a test).
+    The rule, restated here from the reference: for every keyframe with a successor, the z-axis angle and the distance to the successor;
+    pairs beyond 45 degrees or 0.3 m break the chain; keyframe i > 0 becomes a candidate with the sum of its two half distances
+    (distance + angle * 0.5 / (pi / 2)); the approx_merge_count smallest are deleted in that order unless a neighbour has gone."""
+    from badslam_amd import se3
+    from badslam_amd.directba import DirectBA
+    scene = common.small_scene(num_keyframes=9, width=160, height=120, seed=23)
+    # poses along a line with hand-picked gaps: (1, 2, 3) and (5, 6, 7) are tight groups, 3 -> 4 is too far, 7 -> 8 turns too much
+    gaps = [0.20, 0.03, 0.02, 0.45, 0.10, 0.015, 0.05, 0.10]
+    poses, x = [], 0.0
+    for k in range(9):
+        rot = [0.0, 0.9 if k == 8 else 0.02 * k, 0.0]
+        poses.append(se3.exp(np.array([x, 0.0, 0.0] + rot, np.float64)))
+        if k < 8:
+            x += gaps[k]
+    ba = DirectBA(200000, scene.raw_to_float_depth, scene.baseline_fx, scene.cell, scene.width, scene.height, scene.camera, scene.camera)
+    for k in range(9):
+        ba.AddKeyframe(scene.depth[k], scene.rgb[k], poses[k])
+
+    def expected(alive, count):
+        R = [se3.quat_to_rot(np.asarray(ba.keyframe_pose(k), np.float64)[:4]) if alive[k] else None for k in range(9)]
+        t = [np.asarray(ba.keyframe_pose(k), np.float64)[4:] if alive[k] else None for k in range(9)]
+        cands, prev_half, prev_id = [], np.float32(0), 0
+        for k in range(8):
+            if not alive[k]:
+                continue
+            nxt = next((n for n in range(k + 1, 9) if alive[n]), None)
+            if nxt is None:
+                break
+            angle = np.float32(np.arccos(np.float32(np.dot(R[k][:, 2], R[nxt][:, 2]))))
+            if angle > np.float32(0.5 * np.pi / 2):
+                continue
+            dist = np.float32(np.linalg.norm(t[k] - t[nxt]))
+            if dist > np.float32(0.3):
+                continue
+            half = np.float32(dist + np.float32(0.5 / (np.pi / 2)) * angle)
+            if k > 0:
+                cands.append((float(prev_half + half), prev_id, k, nxt))
+            prev_half, prev_id = half, k
+        cands.sort(key=lambda c: c[0])
+        gone = []
+        for _, a, b, c in cands[:count]:
+            if alive[a] and alive[b] and alive[c] and a not in gone and b not in gone and c not in gone:
+                gone.append(b)
+        return gone
+
+    alive = [True] * 9
+    want = expected(alive, 2)
+    assert len(want) >= 1 and 0 not in want
+    ba.MergeKeyframes(2)
+    got = [k for k in range(9) if not ba.keyframe_exists(k)]
+    assert sorted(got) == sorted(want), (got, want)
+    assert ba.keyframe_exists(0) and ba.keyframe_exists(8)
+    # a second call works on the thinned sequence (deleted slots are skipped when looking for the successor)
+    for k in got:
+        alive[k] = False
+    want2 = expected(alive, 10)
+    ba.MergeKeyframes(10)
+    got2 = [k for k in range(9) if alive[k] and not ba.keyframe_exists(k)]
+    assert sorted(got2) == sorted(want2), (got2, want2)
+    # and the backend still runs on what is left (bound table rebuilt from the surviving keyframes)
+    left = [k for k in range(9) if ba.keyframe_exists(k)]
+    for k in left:
+        ba.CreateSurfelsForKeyframe(k, filter_new_surfels=False)
+    done, _ = ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=1, max_iterations=1,
+                                  increase_ba_iteration_count=False)
+    assert done == 1 and ba.surfel_count() > 0 and ba.ExportToPointCloud_count() == ba.surfel_count()

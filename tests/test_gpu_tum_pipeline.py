@@ -203,3 +203,56 @@ def test_non_keyframes_follow_their_keyframes(tmp_path):
     # the in-between frames inherit the interpolated correction: most of their drift is gone too (the synthetic frames are
     # far apart in pose, so interpolating the correction by frame index is only approximately right)
     assert (err_after[others] < 0.5 * err_before[others]).all()
+
+
+def test_e2e_vga_golden_through_a_tum_format_directory(tmp_path):
+    """"outputs match the reference on identical TUM-format input".  The raw input of tests/golden/e2e_vga.npz
+    (20 noisy 640x480 depth frames with holes + RGB, perturbed start poses) is written as a TUM RGB-D directory -- 16-bit depth
+    PNGs, RGB PNGs, associated.txt, calibration.txt, a trajectory file -- and goes through `ba_tum`: the dataset reader, the PNG
+    decoder, the PreprocessFrame chain (bilateral filter + depth cut-off), the Keyframe constructor and
+    DirectBA::BundleAdjustment(do_surfel_updates, three iterations, end tasks) with the chain's parameters.  The trajectory it writes
+    is held against the REFERENCE's own kernels on the same raw input (the golden's poses, relative to the first keyframe as
+    SavePoses writes them): pose RMSE <= 1e-5 m (BASELINE.json), and the PLY holds the golden's number of surfels (<= 0.1 % apart).
+    The same with --row_major_creation against the reference run in its own append order."""
+    import types
+    from tests import e2e_vga as e2e
+    assert os.path.exists(BIN)
+    scene, raw, rgb, start = e2e.scene_and_raw_input()
+    with np.load(e2e.PATH) as f:
+        golden = {name: f[name] for name in f.files}
+    assert np.array_equal(e2e.input_digest(raw, rgb, start), golden["input_digest"])
+    depth = [np.where(r == 0, 65535, r).astype(np.uint16) for r in raw]        # the writer's convention: 65535 = no measurement -> PNG 0
+    as_scene = types.SimpleNamespace(depth=depth, rgb=[c for c in rgb], camera=scene.camera)
+    stamps = tum_writer.write_dataset(str(tmp_path), as_scene, {"initial.txt": [np.asarray(T, np.float64) for T in start]})
+    s = scene.raw_to_float_depth
+
+    def run(extra, tag):
+        out = str(tmp_path / tag)
+        cmd = [BIN, str(tmp_path), "initial.txt", out, "--cell", str(e2e.CELL), "--iterations", "1", "--ba_call_iterations", str(e2e.ITERATIONS),
+               "--max_depth", repr(e2e.MAX_DEPTH_M), "--raw_to_float_depth", repr(float(s)), "--baseline_fx", repr(float(scene.baseline_fx)),
+               "--spatial_sort_cell", "0", "--bilateral_sigma_xy", repr(e2e.BILATERAL[0]), "--bilateral_sigma_inv_depth", repr(e2e.BILATERAL[1]),
+               "--bilateral_radius_factor", repr(e2e.BILATERAL[2])] + extra
+        log = _run(cmd, timeout=900)
+        assert "BA call 1: %d iteration(s)" % e2e.ITERATIONS in log
+        result = _read_trajectory(out + ".poses.txt")
+        assert [t for t, _ in result] == stamps
+        blob = open(out + ".ply", "rb").read()
+        header = blob[:blob.index(b"end_header\n")].decode()
+        n = int([l for l in header.splitlines() if l.startswith("element vertex")][0].split()[-1])
+        return np.asarray([p for _, p in result], np.float64), n
+
+    def relative_rmse(est_rel, reference_absolute):
+        ref_rel = np.asarray(_relative([np.asarray(p, np.float64) for p in reference_absolute]))
+        d = est_rel[:, 4:] - ref_rel[:, 4:]
+        return float(np.sqrt(np.mean(np.sum(d * d, axis=1)))), float(np.max(np.linalg.norm(d, axis=1)))
+
+    est, n = run([], "tile_major")
+    rmse, worst = relative_rmse(est, golden["poses"])
+    print(f"ba_tum on the TUM copy of the e2e input vs the reference's kernels: pose RMSE {rmse:.2e} m (max {worst:.2e} m), {n} vs {int(golden['final_surfels'])} surfels")
+    assert rmse <= 1e-5 and worst <= 1e-5 and rmse <= 3e-6, (rmse, worst)
+    assert abs(n - int(golden["final_surfels"])) <= 1e-3 * int(golden["final_surfels"])
+    est_rm, n_rm = run(["--row_major_creation"], "row_major")
+    rmse_rm, worst_rm = relative_rmse(est_rm, golden["rowmajor_poses"])
+    print(f"... with the reference's append order vs the unmodified reference run: pose RMSE {rmse_rm:.2e} m (max {worst_rm:.2e} m), {n_rm} vs {int(golden['rowmajor_final_surfels'])} surfels")
+    assert rmse_rm <= 1e-5 and worst_rm <= 1e-5 and rmse_rm <= 3e-6, (rmse_rm, worst_rm)
+    assert abs(n_rm - int(golden["rowmajor_final_surfels"])) <= 1e-3 * int(golden["rowmajor_final_surfels"])
