@@ -199,12 +199,14 @@ void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntr
                               const LifecycleCull& cull = LifecycleCull(),
                               const uint32_t* size_on_device = nullptr /* a creation batch: min(*size_on_device, s.size) surfels exist */);
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const LifecycleCull& cull = LifecycleCull());
-// a creation batch: appends at *size_on_device and advances it, or raises *capacity_exceeded and appends nothing
-void launch_create_append_batched(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const uint32_t* indices,
-                                  const SurfelsView& s, uint32_t* size_on_device, uint32_t capacity, uint32_t* capacity_exceeded);
-void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const void* spheres, uint32_t bounded_tiles);
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* cell_of, bool empty_the_planes, uint32_t* deleted_count,
+                  const LifecycleCull& cull = LifecycleCull());
+// a creation batch: scan + append at *size_in + the new size into *size_out (or *capacity_exceeded raised and nothing appended) in one
+// launch; group_words: create_append_groups() words, cleared before tag 1 and whenever a tag (1 .. 255) would repeat
+int create_append_groups();
+void launch_create_append_fused(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const SurfelsView& s,
+                                const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded,
+                                uint32_t* group_words, uint32_t tag);
 size_t create_padded_count(const Intrinsics& in);   // length of the tile-major flag / index vectors
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags);
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,

@@ -110,6 +110,7 @@ struct bahip_context {
   uint8_t* dev_window = nullptr;
   size_t window_capacity = 0;
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
+  const void* supporting_planes_empty = nullptr;   // the supporting planes (by their first plane) that the last merge call left empty
   bool row_major_creation = false;   // new surfels of a keyframe appended in row-major pixel order (the reference's) instead of tile-major
   bool poll_disabled = false;        // the host copy of the pose counters is not updated by the kernel on this system: synchronise instead
   // lifecycle batch (bahip_lifecycle_batch_begin): bounding spheres of the cloud's whole tiles, for the per-keyframe sweeps of a batch
@@ -1494,8 +1495,16 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
                                      const bahip_surfels* surfels, const SupportingView& sup, uint32_t* merged_count_out) {
   // The reference clears full-resolution planes (B/kernel_supporting_surfels.cc:58-60); only the
   // sparse-cell region is ever addressed, so clearing that region is equivalent.
-  launch_supporting_fill(ctx->stream, sup, ctx->in.cf_width, ctx->in.cf_height);
-  CHECK_LAUNCH();
+  // Inside a lifecycle batch that knows its frames (the merge pass of a BA iteration, the end tasks: one call per keyframe, back to
+  // back) the planes belong to the backend, and a merge call leaves them empty (merge_apply_kernel): the fill launch is needed for the
+  // first keyframe of the batch only.
+  const bool backend_owns_planes = merge && ctx->lifecycle_bounds_tiles != 0 && !ctx->lifecycle_frames.empty();
+  const bool planes_known_empty = backend_owns_planes && ctx->supporting_planes_empty == sup.b[0];
+  ctx->supporting_planes_empty = nullptr;
+  if (!planes_known_empty) {
+    launch_supporting_fill(ctx->stream, sup, ctx->in.cf_width, ctx->in.cf_height);
+    CHECK_LAUNCH();
+  }
   if (merged_count_out) *merged_count_out = 0;
   if (surfels->surfels_size == 0) return 0;
   const SurfelsView s = make_view(surfels);
@@ -1507,9 +1516,10 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
     const float cell_merge_dist_sq = cell * cell * merge_dist_factor * merge_dist_factor;
     // per-surfel decision flags live in accum row 0 (scratch by contract, B/kernels.cuh:78-90)
     uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
+    uint32_t* cell_of = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)(kSurfelAccum0 + 1) * surfels->pitch_bytes);
     if (merged_count_out) {
       HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
-      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter), cull);
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, cell_of, backend_owns_planes, reinterpret_cast<uint32_t*>(ctx->dev_counter), cull);
       CHECK_LAUNCH();
       HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1517,9 +1527,10 @@ static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_
     } else {
       // deferred count: a batch of keyframes merges without a read-back and a stream synchronisation per keyframe; the total
       // waits in dev_counter[3] for bahip_take_merged_count
-      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3, cull);
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, cell_of, backend_owns_planes, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3, cull);
       CHECK_LAUNCH();
     }
+    if (backend_owns_planes) ctx->supporting_planes_empty = sup.b[0];
   }
   return 0;
 }
@@ -1540,6 +1551,7 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
 int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels) {
   REQUIRE(surfels != nullptr, "bahip_lifecycle_batch_begin: NULL argument");
   ctx->lifecycle_bounds_tiles = 0;
+  ctx->supporting_planes_empty = nullptr;
   ctx->lifecycle_frames.clear(); ctx->lifecycle_list_offsets.clear(); ctx->lifecycle_list_counts.clear();
   const uint32_t tiles = surfels->surfels_size / 64;   // whole tiles only: what is appended later starts in the tile behind them
   if (tiles == 0) return 0;
@@ -1620,6 +1632,7 @@ int bahip_lifecycle_batch_set_keyframes(bahip_context* ctx, const int* keyframe_
 
 int bahip_lifecycle_batch_end(bahip_context* ctx) {
   ctx->lifecycle_bounds_tiles = 0;
+  ctx->supporting_planes_empty = nullptr;
   return 0;
 }
 
@@ -1750,20 +1763,31 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
     HIP_TRY(hipMemcpyAsync(ctx->dev_covis_T, rel.data(), sizeof(float) * 12 * (size_t)total_covis, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // `rel` is pageable and goes out of scope
   }
-  uint32_t* size_on_device = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 4;
-  uint32_t* exceeded_on_device = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 5;
-  ctx->pinned_i[2] = (int)surfels->surfels_size; ctx->pinned_i[3] = 0;
-  HIP_TRY(hipMemcpyAsync(size_on_device, ctx->pinned_i + 2, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+  // The cloud's size lives on the device between the keyframes of the batch, in TWO cells: a keyframe's launches read one, its append
+  // writes the other (kernels_lifecycle.hip: create_append_fused_kernel); [6] = the sticky "capacity exceeded" flag.
+  uint32_t* size_cell[2] = {reinterpret_cast<uint32_t*>(ctx->dev_counter) + 4, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 5};
+  uint32_t* exceeded_on_device = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 6;
+  ctx->pinned_i[2] = (int)surfels->surfels_size; ctx->pinned_i[3] = (int)surfels->surfels_size; ctx->pinned_i[4] = 0;
+  HIP_TRY(hipMemcpyAsync(size_cell[0], ctx->pinned_i + 2, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+  // scratch of the fused appends in the (otherwise unused) index vector: one tagged word per slice of the flag sequence
+  const int groups = create_append_groups();
+  REQUIRE((size_t)groups <= px, "bahip_create_surfels_for_keyframes: flag sequence shorter than the append's scratch");
+  uint32_t* group_words = ctx->dev_indices;
+  HIP_TRY(hipMemsetAsync(group_words, 0, sizeof(uint32_t) * (size_t)groups, st));
+  // the flag kernel writes every in-image entry of the flag sequence for every keyframe; the padding of the tile-major sequence is
+  // cleared once per batch
+  HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));
   const uint32_t cells = (uint32_t)ctx->in.cf_width * (uint32_t)ctx->in.cf_height;   // a keyframe appends at most one surfel per sparse cell
   for (int j = 0; j < num_keyframes; ++j) {
     const KfEntry& e = ctx->host_kfs[keyframe_indices[j]];
+    const uint32_t* size_in = size_cell[j & 1];
     // what the cloud can hold by now at most: the grid of the sweep; the size itself is read on the device
     bahip_surfels bound = *surfels;
     bound.surfels_size = (uint32_t)std::min<uint64_t>(surfels->capacity, (uint64_t)surfels->surfels_size + (uint64_t)j * cells);
     const SurfelsView s = make_view(&bound);
+    ctx->supporting_planes_empty = nullptr;
     launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
-    launch_supporting_insert(st, ctx->in, e, s, sup, lifecycle_cull_for(ctx, surfels, e.pose.F), size_on_device);
-    HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));
+    launch_supporting_insert(st, ctx->in, e, s, sup, lifecycle_cull_for(ctx, surfels, e.pose.F), size_in);
     launch_create_flag(st, ctx->in, e, sup, ctx->dev_flags);
     const int n_covis = covis_offsets[j + 1] - covis_offsets[j];
     if (filter_new_surfels && n_covis > 0) {
@@ -1772,13 +1796,15 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
     } else if (filter_new_surfels) {
       if (1 < min_observation_count) HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));   // no co-visible keyframe: one observation
     }
-    HIP_TRY(scan_flags_inclusive(st, ctx->scan_temp, ctx->scan_temp_bytes, ctx->dev_flags, ctx->dev_indices, (int)px));
     bound.surfels_size = surfels->capacity;   // (the append addresses rows by index; the view's size is not looked at)
-    launch_create_append_batched(st, ctx->in, e, ctx->dev_flags, ctx->dev_indices, make_view(&bound), size_on_device, (uint32_t)surfels->capacity,
-                                 exceeded_on_device);
+    const uint32_t tag = (uint32_t)(j % 255) + 1u;
+    if (j > 0 && tag == 1u) HIP_TRY(hipMemsetAsync(group_words, 0, sizeof(uint32_t) * (size_t)groups, st));   // the tags start over
+    launch_create_append_fused(st, ctx->in, e, ctx->dev_flags, make_view(&bound), size_in, size_cell[(j & 1) ^ 1], (uint32_t)surfels->capacity,
+                               exceeded_on_device, group_words, tag);
     CHECK_LAUNCH();
   }
-  HIP_TRY(hipMemcpyAsync(ctx->pinned_i + 2, size_on_device, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i + 2, size_cell[num_keyframes & 1], sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i + 3, exceeded_on_device, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   *new_surfel_count_out = (uint32_t)ctx->pinned_i[2] - surfels->surfels_size;
   if (ctx->pinned_i[3]) {

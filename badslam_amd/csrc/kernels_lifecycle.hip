@@ -123,13 +123,16 @@ __device__ __forceinline__ bool merge_test(const SurfelsView& s, uint32_t a, uin
 // merge away.  flags: one u32 per surfel.
 __global__ void __launch_bounds__(kLcBlock)
 merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, float cell_merge_dist_sq,
-                    float cos_thr, uint32_t* __restrict__ flags, LifecycleBounds lb) {
+                    float cos_thr, uint32_t* __restrict__ flags, uint32_t* __restrict__ cell_of /* per surfel: 1 + the sparse cell it is
+                    associated with in this keyframe, 0 = none -- merge_apply_kernel empties exactly those cells again */, LifecycleBounds lb) {
   uint32_t i;
   if (!lifecycle_surfel(in, frame, lb, s.size, &i)) return;   // merge_apply_kernel visits the same surfels: the other flags are never read
   flags[i] = 0;
+  cell_of[i] = 0;
   Assoc r;
   if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
   const int cx = r.px / in.cell, cy = r.py / in.cell;
+  cell_of[i] = 1u + (uint32_t)cy * (uint32_t)in.cf_width + (uint32_t)cx;
   const uint32_t s0 = *pitched_ptr(sup.b[0], sup.pitch, cy, cx);
   const uint32_t s1 = *pitched_ptr(sup.b[1], sup.pitch, cy, cx);
   const uint32_t s2 = *pitched_ptr(sup.b[2], sup.pitch, cy, cx);
@@ -150,12 +153,22 @@ merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView 
   flags[i] = deleted ? 1u : 0u;
 }
 
+// ... and, inside a merge batch that knows its frames (empty_the_planes), leaves the supporting planes as they were before the
+// insertion, all slots empty: the surfels that inserted themselves are the associated ones, whose cells merge_decide_kernel has
+// recorded -- so the NEXT keyframe of the batch needs no fill launch (capi.hip: determine_supporting_impl; a merge batch of 200
+// keyframes is launch-bound).  Otherwise the planes keep the lists, the reference function's second output.
 __global__ void __launch_bounds__(kLcBlock)
-merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ flags, uint32_t* __restrict__ deleted_count,
-                   LifecycleBounds lb) {
+merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ cell_of,
+                   SupportingView sup, int empty_the_planes, uint32_t* __restrict__ deleted_count, LifecycleBounds lb) {
   uint32_t i;
   if (!lifecycle_surfel(in, frame, lb, s.size, &i)) return;   // (wave-uniform but for the last tile's tail lanes; the ballot below counts active lanes)
   const bool del = flags[i];
+  const uint32_t cell = empty_the_planes ? cell_of[i] : 0u;
+  if (cell) {
+    const uint32_t cy = (cell - 1u) / (uint32_t)in.cf_width, cx = (cell - 1u) - cy * (uint32_t)in.cf_width;
+#pragma unroll
+    for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) *pitched_ptr(sup.b[b], sup.pitch, (int)cy, (int)cx) = kInvalidIndex;
+  }
   if (del) s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits);
   const unsigned long long m = __ballot(del);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(deleted_count, (uint32_t)__popcll(m));
@@ -291,22 +304,8 @@ create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ k
   if (candidate && (observations < (uint32_t)min_observation_count || violations > observations)) flags[idx] = 0;
 }
 
-// B/kernel_create_surfels.cu:91-160,357-390
-__global__ void __launch_bounds__(kLcBlock)
-create_append_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ indices,
-                     int padded_count, uint32_t surfels_size, SurfelsView s,
-                     const uint32_t* __restrict__ size_on_device /* a creation batch: the append position lives on the device */, uint32_t capacity) {
-  const int idx = blockIdx.x * kLcBlock + threadIdx.x;
-  if (idx >= padded_count) return;
-  if (flags[idx] != 1) return;
-  int x, y;
-  if (!tile_xy(in, (size_t)idx, &x, &y)) return;
-  if (size_on_device) {
-    surfels_size = *size_on_device;
-    // the soft failure of B/kernel_create_surfels.cc:162-165, decided on the device: this keyframe creates nothing (create_advance_kernel raises the flag)
-    if ((uint64_t)surfels_size + indices[padded_count - 1] > capacity) return;
-  }
-  const uint32_t si = surfels_size + indices[idx] - 1;   // inclusive scan
+// B/kernel_create_surfels.cu:91-160: the attributes of the surfel that pixel (x, y) of `frame` creates, written to index si.
+__device__ __forceinline__ void append_surfel(const Intrinsics& in, const KfEntry& frame, int x, int y, uint32_t si, const SurfelsView& s) {
   float G[12];
   {
     // global_T_frame as 3x4: rotation = transpose of frame_T_global's, translation from the pose
@@ -358,6 +357,91 @@ create_append_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ f
   s.row(kSurfelDescriptor2)[si] = e.r2;
 }
 
+// B/kernel_create_surfels.cu:91-160,357-390
+__global__ void __launch_bounds__(kLcBlock)
+create_append_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ indices,
+                     int padded_count, uint32_t surfels_size, SurfelsView s) {
+  const int idx = blockIdx.x * kLcBlock + threadIdx.x;
+  if (idx >= padded_count) return;
+  if (flags[idx] != 1) return;
+  int x, y;
+  if (!tile_xy(in, (size_t)idx, &x, &y)) return;
+  append_surfel(in, frame, x, y, surfels_size + indices[idx] - 1 /* inclusive scan */, s);
+}
+
+// The append of a creation BATCH (bahip_create_surfels_for_keyframes): scan, append and the advance of the cloud's size in ONE
+// launch -- round 4 spent five launches per keyframe on them (two of the library scan, the append, a one-thread advance, a memset),
+// and a batch of 200 keyframes is launch-bound.  gridDim.x <= kAppendGroups workgroups, all resident at once,
+// own consecutive slices of the flag sequence:
+//   count the flags of the own slice -> publish the count as ONE tagged word (tag << 24 | count; the tag is the keyframe's number in
+//   the batch + 1, so a word of the previous keyframe's launch is never mistaken; the words are cleared once per batch) -> every
+//   workgroup waits until all slices' words carry the tag (agent-scope atomic loads of the words themselves: the data IS the flag,
+//   no fence, no cache write-back / invalidate -- a first version with a separate arrival counter and release / acquire fences took
+//   37 us per launch) -> prefix over the counts = the slice's first index, their sum = what the keyframe creates -> the soft failure
+//   of B/kernel_create_surfels.cc:162-165 or the append, in sequence order (a block-level scan per 256 flags) -> workgroup 0 writes
+//   the new size to the OTHER of two cells (the next keyframe's launches read that one: nobody reads a size while it is written).
+// Same surfels at the same indices as flag scan + create_append_kernel.
+constexpr int kAppendGroups = 256;
+__global__ void __launch_bounds__(kLcBlock)
+create_append_fused_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restrict__ flags, int padded_count, SurfelsView s,
+                           const uint32_t* __restrict__ size_in, uint32_t* __restrict__ size_out, uint32_t capacity,
+                           uint32_t* __restrict__ capacity_exceeded, uint32_t* __restrict__ group_words, uint32_t tag) {
+  __shared__ uint32_t wave_sums[kLcBlock / 64];
+  __shared__ uint32_t wave_sums_b[kLcBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int groups = (int)gridDim.x;
+  const int per_group = (((padded_count + groups - 1) / groups + kLcBlock - 1) / kLcBlock) * kLcBlock;
+  const int begin = min(padded_count, (int)blockIdx.x * per_group), end = min(padded_count, begin + per_group);
+  // the flags of the own slice (a slice is far below 2^24 entries)
+  uint32_t mine = 0;
+  for (int idx = begin + tid; idx < end; idx += kLcBlock) mine += flags[idx] == 1 ? 1u : 0u;
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+  if (lane == 0) wave_sums[wave] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < kLcBlock / 64; ++w) total += wave_sums[w];
+    __hip_atomic_store(&group_words[blockIdx.x], (tag << 24) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // every slice's word, once it carries this launch's tag: prefix over the slices in front of this one, and the keyframe's total
+  uint32_t before = 0, all = 0;
+  for (int g = tid; g < groups; g += kLcBlock) {
+    uint32_t word;
+    while (((word = __hip_atomic_load(&group_words[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 24) != tag) __builtin_amdgcn_s_sleep(1);
+    const uint32_t c = word & 0xffffffu;
+    all += c;
+    if (g < (int)blockIdx.x) before += c;
+  }
+  for (int d = 32; d > 0; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+  __syncthreads();   // (wave_sums has been read)
+  if (lane == 0) { wave_sums[wave] = before; wave_sums_b[wave] = all; }
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < kLcBlock / 64; ++w) { base += wave_sums[w]; total += wave_sums_b[w]; }
+  const uint32_t size = *size_in;
+  const bool fits = (uint64_t)size + total <= capacity;
+  if (blockIdx.x == 0 && tid == 0) {
+    *size_out = fits ? size + total : size;
+    if (!fits) *capacity_exceeded = 1u;       // the soft failure: this keyframe creates nothing
+  }
+  if (!fits) return;
+  uint32_t running = size + base;
+  for (int slab = begin; slab < end; slab += kLcBlock) {
+    const int idx = slab + tid;
+    const bool flagged = idx < end && flags[idx] == 1;
+    const unsigned long long m = __ballot(flagged);
+    const uint32_t rank_in_wave = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    __syncthreads();   // (the sums of the previous round have been read)
+    if (lane == 0) wave_sums[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t waves_before = 0, slab_total = 0;
+    for (int w = 0; w < kLcBlock / 64; ++w) { const uint32_t c = wave_sums[w]; slab_total += c; if (w < wave) waves_before += c; }
+    int x, y;
+    if (flagged && tile_xy(in, (size_t)idx, &x, &y)) append_surfel(in, frame, x, y, running + waves_before + rank_in_wave, s);
+    running += slab_total;
+  }
+}
+
 // ---- deletion + radius update (B/kernel_delete_surfels.cu:42-176), one launch for all keyframes ------
 __global__ void __launch_bounds__(kLcBlock)
 delete_update_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
@@ -387,14 +471,6 @@ delete_update_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs
   }
   const unsigned long long m = __ballot(newly_deleted);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(deleted_count, (uint32_t)__popcll(m));
-}
-
-// A creation batch: the keyframe's surfels are appended, the cloud's size on the device moves on (or the capacity flag is raised).
-__global__ void create_advance_kernel(uint32_t* __restrict__ size_on_device, const uint32_t* __restrict__ last_index, uint32_t capacity,
-                                      uint32_t* __restrict__ capacity_exceeded) {
-  const uint32_t size = *size_on_device, count = *last_index;
-  if ((uint64_t)size + count > capacity) *capacity_exceeded = 1u;
-  else *size_on_device = size + count;
 }
 
 // ---- compaction (B/kernel_compact_surfels.cu:101-157) --------------------------------------------------
@@ -461,14 +537,16 @@ void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntr
   const unsigned groups = sweep_groups(lb, s.size);
   if (s.size && groups) hipLaunchKernelGGL(supporting_insert_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, lb, size_on_device);
 }
+// flags, cell_of: one word per surfel each (scratch rows).  empty_the_planes: see merge_apply_kernel.
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
-                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* deleted_count, const LifecycleCull& cull) {
+                  float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* cell_of, bool empty_the_planes, uint32_t* deleted_count,
+                  const LifecycleCull& cull) {
   if (!s.size) return;
   const LifecycleBounds lb = device_cull(cull);
   const unsigned groups = sweep_groups(lb, s.size);
   if (!groups) return;
-  hipLaunchKernelGGL(merge_decide_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, lb);
-  hipLaunchKernelGGL(merge_apply_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, flags, deleted_count, lb);
+  hipLaunchKernelGGL(merge_decide_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, cell_of, lb);
+  hipLaunchKernelGGL(merge_apply_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, flags, cell_of, sup, empty_the_planes ? 1 : 0, deleted_count, lb);
 }
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags) {
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags);
@@ -486,15 +564,18 @@ void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& f
 void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags,
                           const uint32_t* indices, uint32_t surfels_size, const SurfelsView& s) {
   const int padded = (int)create_padded_count(in);
-  hipLaunchKernelGGL(create_append_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, flags, indices,
-                     padded, surfels_size, s, static_cast<const uint32_t*>(nullptr), 0u);
+  hipLaunchKernelGGL(create_append_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, flags, indices, padded, surfels_size, s);
 }
-void launch_create_append_batched(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const uint32_t* indices,
-                                  const SurfelsView& s, uint32_t* size_on_device, uint32_t capacity, uint32_t* capacity_exceeded) {
+int create_append_groups() { return kAppendGroups; }
+// group_words: kAppendGroups words, cleared once per batch; tag: the keyframe's number in the batch + 1 (1 .. 255; the caller clears the
+// words again before a tag repeats)
+void launch_create_append_fused(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const SurfelsView& s,
+                                const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded,
+                                uint32_t* group_words, uint32_t tag) {
   const int padded = (int)create_padded_count(in);
-  hipLaunchKernelGGL(create_append_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, flags, indices, padded, 0u, s,
-                     static_cast<const uint32_t*>(size_on_device), capacity);
-  hipLaunchKernelGGL(create_advance_kernel, dim3(1), dim3(1), 0, st, size_on_device, indices + (padded - 1), capacity, capacity_exceeded);
+  const int groups = std::min(kAppendGroups, (int)g1(padded));
+  hipLaunchKernelGGL(create_append_fused_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, flags, padded, s, size_in, size_out, capacity,
+                     capacity_exceeded, group_words, tag);
 }
 void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                           int min_obs, uint32_t* deleted_count) {

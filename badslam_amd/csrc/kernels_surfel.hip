@@ -205,18 +205,21 @@ assign_colors_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs
 // written and stay live only if that count is >= 1; what an inactive surfel accumulated is dropped.
 // kMode (keyframe sharding, tile_sums): kSumsProduce stores this rank's class partials and returns; kSumsConsume takes the sums
 // from the exchanged partials instead of visiting keyframes.
+// Candidate masks of the normals pass, replayed by the position pass of the same tile (wave_cull.h: for_each_candidate_cached): per
+// class kMaskChunks chunks of 64 keyframes (4 classes: 1024 keyframes; beyond that the position pass tests again).
+constexpr int kMaskChunks = 4;
 template <int kWaves, bool kActivate, int kMode = kSumsFused>
 __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs,
                                              const WaveBounds& wb, SurfelsView& s, uint32_t i, bool* live_inout, bool decide,
                                              Vec3 gp, Vec3* gn_inout, float* lds, const ClassPartials& cp = ClassPartials{},
-                                             bool in_range = false) {
+                                             bool in_range = false, unsigned long long* masks = nullptr) {
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
   const Vec3 gn = *gn_inout;
   bool live = *live_inout;
   constexpr int kCount = kActivate ? 5 : 4;
   float sum[kCount];   // x, y, z, count [, count over kActive keyframes]
   tile_sums<kWaves, kCount, kMode>(sum, lds, [&](float (&acc)[kCount], int cls) {
-    for_each_candidate(
+    for_each_candidate_cached(
         num_kfs,
         [&](int k) {
           float f[12];
@@ -236,7 +239,7 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
             if (kActivate) acc[kCount - 1] += (kfs[k].activation == BAHIP_KF_ACTIVE) ? 1.f : 0.f;
           }
         },
-        in.sum_classes, cls);
+        in.sum_classes, cls, masks ? masks + cls * kMaskChunks : nullptr, masks ? kMaskChunks : 0, false);
   }, in.sum_classes, cp, i, in_range);
   if (kMode == kSumsProduce) return;
   if (kActivate && decide) {
@@ -308,7 +311,11 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
     if (decide && writer && kPhase != 1) s.active[ii] = s.active[ii] & (uint8_t)~kSurfelActiveFlag;   // (deleted surfels: never active)
     return;
   }
-  if (kPhase != 3) normals_pass<kWaves, kActivate, kNormalsMode>(in, kfs, num_kfs, wb, s, ii, &live, decide, gp, &gn, lds, cpn, in_range);
+  // one wavefront per tile, the whole step in one launch: the position pass replays the candidate masks of the normals pass
+  constexpr bool kReplayMasks = kWaves == 1 && kPhase == 0;   // (measured: geometry sweep 0.749 -> 0.731 ms at the bench size, profiles/r5_ab_*.txt)
+  __shared__ unsigned long long candidate_masks[kReplayMasks ? kMaxSumClasses * kMaskChunks : 1];
+  unsigned long long* masks = kReplayMasks ? candidate_masks : nullptr;
+  if (kPhase != 3) normals_pass<kWaves, kActivate, kNormalsMode>(in, kfs, num_kfs, wb, s, ii, &live, decide, gp, &gn, lds, cpn, in_range, masks);
   if (kPhase == 1) return;
 
   auto cand = [&](int k) {
@@ -321,7 +328,7 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
   if (!kUseDesc) {
     float hb[2];
     tile_sums<kWaves, 2, kPositionMode>(hb, lds, [&](float (&acc)[2], int cls) {
-      for_each_candidate(num_kfs, cand, [&](int k) {
+      for_each_candidate_cached(num_kfs, cand, [&](int k) {
         const Projected p = project_surfel(in, kfs[k].pose.F, gp);
         const PixelWords pix = load_pixel_words(in, kfs[k].geom, p);
         Assoc r;
@@ -336,7 +343,7 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
         const float wj = w * jac;
         acc[0] = mad(wj, jac, acc[0]);
         acc[1] = mad(wj, raw, acc[1]);
-      }, in.sum_classes, cls);
+      }, in.sum_classes, cls, masks ? masks + cls * kMaskChunks : nullptr, masks ? kMaskChunks : 0, masks != nullptr);
     }, in.sum_classes, cpp, ii, in_range);
     if (kPhase == 2 || !live || !writer) return;
     const float H = hb[0], b = hb[1];
@@ -355,7 +362,7 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
   float tot[8];   // a0 a1 a2 a3 a5 a6 a7 a8 of B/kernel_opt_geometry.cu:119-230 (a4 = H12 is exactly 0)
   tile_sums<kWaves, 8, kPositionMode>(tot, lds, [&](float (&acc)[8], int cls) {
     float &a0 = acc[0], &a1 = acc[1], &a2 = acc[2], &a3 = acc[3], &a5 = acc[4], &a6 = acc[5], &a7 = acc[6], &a8 = acc[7];
-    for_each_candidate(num_kfs, cand, [&](int k) {
+    for_each_candidate_cached(num_kfs, cand, [&](int k) {
       const float* F = kfs[k].pose.F;
       // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
       const Projected p = project_surfel(in, F, gp);
@@ -395,7 +402,7 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
         a5 += w2 * jd * jd;
         a8 += wr2 * jd;
       }
-    }, in.sum_classes, cls);
+    }, in.sum_classes, cls, masks ? masks + cls * kMaskChunks : nullptr, masks ? kMaskChunks : 0, masks != nullptr);
   }, in.sum_classes, cpp, ii, in_range);
   if (kPhase == 2 || !live || !writer) return;
   const float a0 = tot[0], a1 = tot[1], a2 = tot[2], a3 = tot[3], a5 = tot[4], a6 = tot[5], a7 = tot[6], a8 = tot[7];

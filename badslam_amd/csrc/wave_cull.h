@@ -185,6 +185,33 @@ __device__ __forceinline__ void for_each_candidate(int num_items, Pred pred, Bod
   }
 }
 
+// The same loop with the candidate masks kept: a first sweep (replay == false) stores the ballot of every 64-item chunk it tests in
+// `masks` (LDS or global, one 64-bit word per chunk of this part, at most max_masks), a later sweep over the SAME items with the same
+// predicate (replay == true) reads them back instead of loading the items and testing again -- the two passes of the geometry step
+// visit the same keyframes (same bounding sphere, same poses, same activations).  Chunks beyond max_masks are tested both times.
+template <typename Pred, typename Body>
+__device__ __forceinline__ void for_each_candidate_cached(int num_items, Pred pred, Body body, int parts, int part, unsigned long long* masks,
+                                                          int max_masks, bool replay) {
+  const int lane = threadIdx.x & 63;
+  int chunk = 0;
+  for (int base = part; base < num_items; base += 64 * parts, ++chunk) {
+    unsigned long long m;
+    if (replay && chunk < max_masks) {
+      m = masks[chunk];                     // wave-uniform address
+    } else {
+      const int item = base + lane * parts;
+      const bool cand = (item < num_items) && pred(item);
+      m = __ballot(cand);
+      if (!replay && chunk < max_masks && lane == 0) masks[chunk] = m;
+    }
+    while (m) {
+      const int k = base + __builtin_ctzll(m) * parts;
+      m &= m - 1;
+      body(k);
+    }
+  }
+}
+
 // Like for_each_candidate (one part), but stops as soon as body(k) returns true for the whole wavefront
 // (wave-uniform return value), e.g. "every lane has found what it was looking for".
 template <typename Pred, typename Body>

@@ -334,7 +334,10 @@ int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels
 /* Optional, after _begin: the frames of the batch -- frame_T_global as 3x4 row-major matrices, exactly the 12 coefficients the
  * per-keyframe calls will be given (bahip_determine_supporting_surfels), or bound keyframe indices (bahip_create_surfels_for_
  * keyframe[s]).  The batch then knows which tiles each frame can see and that frame's sweeps run over those tiles only (a launch of a
- * few hundred workgroups instead of one over the whole cloud).  A frame that is not found sweeps with the per-tile test as before. */
+ * few hundred workgroups instead of one over the whole cloud).  A frame that is not found sweeps with the per-tile test as before.
+ * From here to _end the supporting planes passed to the MERGING calls (bahip_determine_supporting_surfels with merge != 0) belong to
+ * the backend: every such call leaves them empty (all slots kInvalidIndex) instead of holding the keyframe's lists, which spares the
+ * next keyframe of the batch its fill launch; the surfel buffer and the merged counts are what they are without the bracket. */
 int bahip_lifecycle_batch_set_frames(bahip_context* ctx, const float* frame_T_global_3x4, int num_frames);
 int bahip_lifecycle_batch_set_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes);
 int bahip_lifecycle_batch_end(bahip_context* ctx);

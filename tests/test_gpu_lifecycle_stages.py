@@ -77,7 +77,12 @@ def test_merge_bit_exact(world, batch):
             planes, merged = g.determine_supporting_surfels(k, F, merge=True, merge_dist_factor=orc.merge_factor)
             ref = orc.determine_supporting_surfels(k, merge=True)
             assert merged == before - int(orc.surfels.surfel_count), k
-            assert np.array_equal(planes, ref), k
+            if batch == "frames":
+                # a batch that knows its frames owns the supporting planes: every merge call leaves them empty for the next keyframe
+                # (merge_apply_kernel), the lists are not an output there (include/badslam_hip.h: bahip_lifecycle_batch_set_frames)
+                assert np.all(planes == 0xffffffff), k
+            else:
+                assert np.array_equal(planes, ref), k
             got = g.surfel_buf.download()[:, :both.shape[1]]
             assert np.array_equal(_rows(got), _rows(orc.surfel_data[:, :both.shape[1]])), k     # the same surfels carry the NaN marker
             total_merged += merged
