@@ -176,6 +176,7 @@ SIGNATURES = {
     "bahip_extract_surfel_shard": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.c_int, C.c_int, C.c_uint32, C.POINTER(Surfels), C.POINTER(C.c_uint32)]),
     "bahip_debug_set_intrinsics_bin_capacity": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_debug_intrinsics_bin_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "bahip_debug_set_intrinsics_slices": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_exchange_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "bahip_debug_exact_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "bahip_debug_count_pairs": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.POINTER(C.c_uint64)]),
@@ -190,6 +191,7 @@ SIGNATURES = {
     "bahip_debug_set_pcg_lds_form": (C.c_int, [C.c_int]),
     "bahip_debug_pose_form_launches": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "bahip_debug_pose_kernel_dispatches": (C.c_int, [C.POINTER(C.c_longlong)]),
+    "bahip_debug_pcg_step1_form_launches": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bahip_debug_pose_limbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_longlong)]),
     "bahip_debug_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
     "bahip_debug_read_pattern": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int]),

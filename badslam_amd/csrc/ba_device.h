@@ -231,7 +231,7 @@ static_assert(sizeof(PoseWork) == 128, "PoseWork is read back as 32-word records
 constexpr int kPoseCounterConverged = 32;
 // [kPoseCounterTicket]: workgroups of pose_solve_kernel that have finished (the last one publishes the counters to the host);
 // [kPoseCounterSequence] (host copy only): the sequence number of the launch whose counters the host copy holds -- the host
-// polls it instead of synchronising the stream and copying 256 bytes (capi.hip: run_pose_rounds).
+// polls it instead of synchronising the stream and copying 256 bytes (capi_ba.hip: run_pose_rounds).
 constexpr int kPoseCounterTicket = 33;
 constexpr int kPoseCounterSequence = 34;
 // [kPoseCounterInvalid]: sticky, raised by the accumulate kernel when a tile total could not be added (not finite, or 2^52 and
@@ -243,7 +243,7 @@ constexpr int kPoseTailRecords = 2;
 // [kPoseCounterWorked]: workgroups of the current solve launch in which a work item took a Gauss-Newton step (cleared by the
 // publishing workgroup; feeds the round count of the device-driven loop)
 constexpr int kPoseCounterWorked = 36;
-// Control words of the device-driven BA loop (capi.hip: bahip_alternating_iterations).  kLoopStop: 0 = run, 1 = the loop has
+// Control words of the device-driven BA loop (capi_ba.hip: bahip_alternating_iterations).  kLoopStop: 0 = run, 1 = the loop has
 // converged (B/direct_ba_alternating.cc:693-701: every keyframe counts as converged and iteration >= min_iterations - 1),
 // 2 = a pose phase ran out of queued Gauss-Newton rounds with work items still iterating (the host continues it) -- every launch
 // of the loop does nothing once it is non-zero.  The rest are totals since the host last cleared them.

@@ -1,5 +1,5 @@
 // ba_launch.h -- host-callable launch wrappers shared between the kernel translation units and
-// the C-ABI layer (capi.hip).
+// the C-ABI layer (capi*.hip; capi_internal.h lists the units).
 #pragma once
 
 #include "ba_device.h"
@@ -67,7 +67,7 @@ size_t tile_schedule_words(uint32_t padded_tiles);   // words of a schedule for 
 // sched := heavy tiles + runs by descending cost (wave_cull.h; clears tile_cost); false if there are more runs than the kernel
 // handles (sched untouched)
 bool launch_tile_order(hipStream_t stream, uint32_t* tile_cost, uint32_t padded_tiles, uint32_t* sched);
-// The device-driven BA loop (capi.hip: bahip_alternating_iterations): the control words the last solve launch of a pose phase
+// The device-driven BA loop (capi_ba.hip: bahip_alternating_iterations): the control words the last solve launch of a pose phase
 // updates and every launch of the loop looks at (ba_device.h: kLoop*), and what that solve launch needs to decide.
 struct PoseLoopControl {
   int* ctl = nullptr;          // device, kLoopWords ints; ctl + kLoopStop is the `stop` word of the other launches
@@ -106,6 +106,7 @@ void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel 
 void set_pose_lds_waves(int waves);        // test hook: wavefronts per workgroup of the LDS form (0: 16)
 void set_pose_lds_parts_shift(int shift);  // test hook: 2^shift wavefronts share a tile's work items in the LDS form (-1: from the grid size)
 void set_pose_lds_items(int items);   // test hook: slices of that many work items per launch of the LDS form (0: as many as the table holds)
+void pcg_step1_form_launches(long long out[2]);   // launches of the PCG step-1 sweep: [0] one tile per wavefront, [1] persistent LDS form
 long long pose_kernel_dispatches();   // kernel dispatches of the accumulate sweep since the process started
 void pose_form_launches(long long out[2], bool reset);   // launches of either form since the last reset (bench: which kernel to name)
 void set_pose_form(int form);     // 0 = automatic; 1 = one tile per wavefront + global atomics; 2 = persistent workgroups with the normal equations in LDS
@@ -134,8 +135,9 @@ struct IntrBins {
 int intrinsics_bin_count(const Intrinsics& in, int* bins_x_out);
 size_t intrinsics_bin_record_bytes();
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, double* glob_d, double* cells_d, const IntrBins& bins,
-                                  const uint32_t* sched = nullptr /* heavy work first (wave_cull.h: scheduled_tile) */);
+                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched,
+                                  uint32_t position_begin = 0, uint32_t position_count = 0 /* 0: all positions of the schedule */);
+uint32_t intrinsics_sweep_positions(uint32_t surfels, const uint32_t* sched);   // positions of a full sweep (what the slices cut)
 void launch_intrinsics_bin_reduce(hipStream_t st, bool depth, const Intrinsics& in, const SurfelsView& s, double* cells, const IntrBins& bins);
 void set_intrinsics_reduce_form(int form);   // 0: LDS table of ds_add_f64, 1: records sorted by cell in LDS, sums in registers
 size_t intrinsics_schur_partials(int S);   // floats of scratch launch_intrinsics_finish needs

@@ -1,0 +1,400 @@
+// capi_lifecycle.hip -- the surfel lifecycle behind the C boundary: supporting surfels and merging, creation (one keyframe or a batch on
+// the device), deletion + radius update, compaction, the spatial reorder.
+#include "capi_internal.h"
+
+using namespace bahip;
+using namespace bahip_capi;
+
+extern "C" {
+// ---- lifecycle ---------------------------------------------------------------------------------------------
+static int supporting_view(uint32_t* const* supporting, uint32_t pitch, SupportingView* v) {
+  for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) {
+    if (!supporting[b]) return 1;
+    v->b[b] = supporting[b];
+  }
+  v->pitch = pitch;
+  return 0;
+}
+
+// What the per-keyframe sweeps of an open lifecycle batch may skip for the frame with this frame_T_global (ba_launch.h: LifecycleCull).
+// The bounds hold for the buffer they were taken from, while it only grows; the list is found by the frame's 12 coefficients.
+static LifecycleCull lifecycle_cull_for(const bahip_context* ctx, const bahip_surfels* surfels, const float* frame_T_global) {
+  LifecycleCull cull;
+  if (!ctx->lifecycle_bounds_tiles || ctx->lifecycle_bounds_data != surfels->data || (uint64_t)ctx->lifecycle_bounds_tiles * 64 > surfels->surfels_size)
+    return cull;
+  cull.spheres = ctx->dev_lifecycle_bounds;
+  cull.tiles = ctx->lifecycle_bounds_tiles;
+  const size_t n = ctx->lifecycle_list_counts.size();
+  for (size_t f = 0; f < n; ++f) {
+    if (memcmp(&ctx->lifecycle_frames[12 * f], frame_T_global, 12 * sizeof(float)) == 0) {
+      cull.list = ctx->dev_lifecycle_lists + ctx->lifecycle_list_offsets[f];
+      cull.list_count = ctx->lifecycle_list_counts[f];
+      break;
+    }
+  }
+  return cull;
+}
+
+static int determine_supporting_impl(bahip_context* ctx, int merge, float merge_dist_factor, const KfEntry& e,
+                                     const bahip_surfels* surfels, const SupportingView& sup, uint32_t* merged_count_out) {
+  // The reference clears full-resolution planes (B/kernel_supporting_surfels.cc:58-60); only the
+  // sparse-cell region is ever addressed, so clearing that region is equivalent.
+  // Inside a lifecycle batch that knows its frames (the merge pass of a BA iteration, the end tasks: one call per keyframe, back to
+  // back) the planes belong to the backend, and a merge call leaves them empty (merge_apply_kernel): the fill launch is needed for the
+  // first keyframe of the batch only.
+  const bool backend_owns_planes = merge && ctx->lifecycle_bounds_tiles != 0 && !ctx->lifecycle_frames.empty();
+  const bool planes_known_empty = backend_owns_planes && ctx->supporting_planes_empty == sup.b[0];
+  ctx->supporting_planes_empty = nullptr;
+  if (!planes_known_empty) {
+    launch_supporting_fill(ctx->stream, sup, ctx->in.cf_width, ctx->in.cf_height);
+    CHECK_LAUNCH();
+  }
+  if (merged_count_out) *merged_count_out = 0;
+  if (surfels->surfels_size == 0) return 0;
+  const SurfelsView s = make_view(surfels);
+  const LifecycleCull cull = lifecycle_cull_for(ctx, surfels, e.pose.F);
+  launch_supporting_insert(ctx->stream, ctx->in, e, s, sup, cull);
+  CHECK_LAUNCH();
+  if (merge) {
+    const float cell = (float)ctx->in.cell;
+    const float cell_merge_dist_sq = cell * cell * merge_dist_factor * merge_dist_factor;
+    // per-surfel decision flags live in accum row 0 (scratch by contract, B/kernels.cuh:78-90)
+    uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
+    uint32_t* cell_of = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)(kSurfelAccum0 + 1) * surfels->pitch_bytes);
+    if (merged_count_out) {
+      HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, cell_of, backend_owns_planes, reinterpret_cast<uint32_t*>(ctx->dev_counter), cull);
+      CHECK_LAUNCH();
+      HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      *merged_count_out = (uint32_t)ctx->pinned_i[0];
+    } else {
+      // deferred count: a batch of keyframes merges without a read-back and a stream synchronisation per keyframe; the total
+      // waits in dev_counter[3] for bahip_take_merged_count
+      launch_merge(ctx->stream, ctx->in, e, s, sup, cell_merge_dist_sq, kCosNormalCompat, flags, cell_of, backend_owns_planes, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3, cull);
+      CHECK_LAUNCH();
+    }
+    if (backend_owns_planes) ctx->supporting_planes_empty = sup.b[0];
+  }
+  return 0;
+}
+
+int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merge_dist_factor, const bahip_frame* frame,
+                                       const float frame_T_global[12], const bahip_surfels* surfels,
+                                       uint32_t* const* supporting, uint32_t supporting_pitch, uint32_t* merged_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_determine_supporting_surfels");
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  SupportingView sup;
+  REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
+  KfEntry e;
+  if (make_entry(ctx, *frame, 0, &e)) return 1;
+  memcpy(e.pose.F, frame_T_global, 12 * sizeof(float));
+  return determine_supporting_impl(ctx, merge, merge_dist_factor, e, surfels, sup, merged_count_out);
+}
+
+int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels) {
+  REQUIRE(surfels != nullptr, "bahip_lifecycle_batch_begin: NULL argument");
+  ctx->lifecycle_bounds_tiles = 0;
+  ctx->supporting_planes_empty = nullptr;
+  ctx->lifecycle_frames.clear(); ctx->lifecycle_list_offsets.clear(); ctx->lifecycle_list_counts.clear();
+  const uint32_t tiles = surfels->surfels_size / 64;   // whole tiles only: what is appended later starts in the tile behind them
+  if (tiles == 0) return 0;
+  if (tiles > ctx->lifecycle_bounds_capacity) {
+    void* grown = nullptr;
+    const size_t capacity = (size_t)tiles + tiles / 4 + 1024;
+    HIP_TRY(hipMalloc(&grown, capacity * 16));   // WaveBounds: four floats
+    hipFree(ctx->dev_lifecycle_bounds);
+    ctx->dev_lifecycle_bounds = grown;
+    ctx->lifecycle_bounds_capacity = capacity;
+  }
+  launch_lifecycle_bounds(ctx->stream, make_view(surfels), tiles, ctx->dev_lifecycle_bounds);
+  CHECK_LAUNCH();
+  ctx->lifecycle_bounds_tiles = tiles;
+  ctx->lifecycle_bounds_data = surfels->data;
+  return 0;
+}
+
+int bahip_lifecycle_batch_set_frames(bahip_context* ctx, const float* frame_T_global_3x4, int num_frames) {
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(num_frames >= 0 && (num_frames == 0 || frame_T_global_3x4 != nullptr), "bahip_lifecycle_batch_set_frames: NULL argument");
+  ctx->lifecycle_frames.clear(); ctx->lifecycle_list_offsets.clear(); ctx->lifecycle_list_counts.clear();
+  const uint32_t tiles = ctx->lifecycle_bounds_tiles;
+  if (tiles == 0 || num_frames == 0) return 0;   // no batch open (or an empty cloud): the sweeps take everything
+  hipStream_t st = ctx->stream;
+  if ((size_t)num_frames > ctx->lifecycle_frames_capacity) {
+    float* F = nullptr; uint32_t* cursors = nullptr;
+    const size_t capacity = (size_t)num_frames + 64;
+    if (hipMalloc(&F, capacity * 12 * sizeof(float)) != hipSuccess || hipMalloc(&cursors, 2 * capacity * sizeof(uint32_t)) != hipSuccess) {
+      hipFree(F); hipFree(cursors);
+      return fail("allocation of the lifecycle batch's frame table failed", __FILE__, __LINE__);
+    }
+    hipFree(ctx->dev_lifecycle_frames); hipFree(ctx->dev_lifecycle_cursors);
+    ctx->dev_lifecycle_frames = F; ctx->dev_lifecycle_cursors = cursors;
+    ctx->lifecycle_frames_capacity = capacity;
+  }
+  uint32_t* cursors = ctx->dev_lifecycle_cursors;
+  uint32_t* offsets = ctx->dev_lifecycle_cursors + ctx->lifecycle_frames_capacity;
+  std::vector<uint32_t> counts(num_frames), starts(num_frames);
+  HIP_TRY(hipMemcpyAsync(ctx->dev_lifecycle_frames, frame_T_global_3x4, (size_t)num_frames * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)num_frames * sizeof(uint32_t), st));
+  launch_lifecycle_visible_tiles(st, ctx->in, ctx->dev_lifecycle_frames, num_frames, ctx->dev_lifecycle_bounds, tiles, nullptr, cursors, nullptr);
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(counts.data(), cursors, (size_t)num_frames * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  size_t total = 0;
+  for (int f = 0; f < num_frames; ++f) { starts[f] = (uint32_t)total; total += counts[f]; }
+  if (total > ctx->lifecycle_lists_capacity) {
+    uint32_t* lists = nullptr;
+    const size_t capacity = total + total / 4 + 4096;
+    HIP_TRY(hipMalloc(&lists, capacity * sizeof(uint32_t)));
+    hipFree(ctx->dev_lifecycle_lists);
+    ctx->dev_lifecycle_lists = lists;
+    ctx->lifecycle_lists_capacity = capacity;
+  }
+  if (total > 0) {
+    HIP_TRY(hipMemcpyAsync(offsets, starts.data(), (size_t)num_frames * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)num_frames * sizeof(uint32_t), st));
+    launch_lifecycle_visible_tiles(st, ctx->in, ctx->dev_lifecycle_frames, num_frames, ctx->dev_lifecycle_bounds, tiles, offsets, cursors, ctx->dev_lifecycle_lists);
+    CHECK_LAUNCH();
+    HIP_TRY(hipStreamSynchronize(st));   // `starts` is pageable and goes out of scope
+  }
+  ctx->lifecycle_frames.assign(frame_T_global_3x4, frame_T_global_3x4 + (size_t)num_frames * 12);
+  ctx->lifecycle_list_offsets = starts;
+  ctx->lifecycle_list_counts = counts;
+  return 0;
+}
+
+int bahip_lifecycle_batch_set_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes) {
+  REQUIRE(num_keyframes >= 0 && (num_keyframes == 0 || keyframe_indices != nullptr), "bahip_lifecycle_batch_set_keyframes: NULL argument");
+  std::vector<float> F(12 * (size_t)num_keyframes);
+  for (int j = 0; j < num_keyframes; ++j) {
+    REQUIRE(keyframe_indices[j] >= 0 && keyframe_indices[j] < ctx->num_kfs, "keyframe index out of range");
+    memcpy(&F[12 * (size_t)j], ctx->host_kfs[keyframe_indices[j]].pose.F, 12 * sizeof(float));
+  }
+  return bahip_lifecycle_batch_set_frames(ctx, F.data(), num_keyframes);
+}
+
+int bahip_lifecycle_batch_end(bahip_context* ctx) {
+  ctx->lifecycle_bounds_tiles = 0;
+  ctx->supporting_planes_empty = nullptr;
+  return 0;
+}
+
+int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out) {
+  REQUIRE(merged_count_out != nullptr, "bahip_take_merged_count: NULL argument");
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->dev_counter + 3, 0, sizeof(int), ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *merged_count_out = (uint32_t)ctx->pinned_i[0];
+  return 0;
+}
+
+int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, int filter_new_surfels, int min_observation_count,
+                                      const int* covis, int n_covis, const bahip_surfels* surfels, uint32_t* const* supporting,
+                                      uint32_t supporting_pitch, uint32_t* new_surfel_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_create_surfels_for_keyframe");
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(keyframe_index >= 0 && keyframe_index < ctx->num_kfs, "keyframe index out of range");
+  SupportingView sup;
+  REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
+  const KfEntry& e = ctx->host_kfs[keyframe_index];
+  *new_surfel_count_out = 0;
+  if (determine_supporting_impl(ctx, 0, 0.f, e, surfels, sup, nullptr)) return 1;
+  const size_t px = create_padded_count(ctx->in);   // tile-major sequence, padded to whole tiles
+  if (ensure_px(ctx, px, px > surfels->capacity ? px : surfels->capacity)) return 1;
+  HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, ctx->stream));
+  launch_create_flag(ctx->stream, ctx->in, e, sup, ctx->dev_flags);
+  CHECK_LAUNCH();
+  if (filter_new_surfels && n_covis > 0) {
+    if (n_covis > ctx->covis_capacity) {
+      int* idx = nullptr; float* T = nullptr;
+      const int cap = n_covis + 64;
+      if (hipMalloc(&idx, sizeof(int) * cap) != hipSuccess || hipMalloc(&T, sizeof(float) * 12 * cap) != hipSuccess) {
+        hipFree(idx); hipFree(T);
+        return fail("allocation of the co-visibility scratch failed", __FILE__, __LINE__);
+      }
+      hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
+      ctx->dev_covis = idx; ctx->dev_covis_T = T;
+      ctx->covis_capacity = cap;
+    }
+    std::vector<float> rel(12 * (size_t)n_covis);
+    for (int c = 0; c < n_covis; ++c) {
+      REQUIRE(covis[c] >= 0 && covis[c] < ctx->num_kfs, "co-visibility index out of range");
+      // covis_T_frame = covis.frame_T_global * keyframe.global_T_frame (B/direct_ba.cc:359-365)
+      float cinv[7], prod[7];
+      se3_inverse(ctx->host_kfs[covis[c]].global_T_frame, cinv);
+      se3_mul(cinv, e.global_T_frame, prod);
+      se3_matrix3x4(prod, &rel[12 * c]);
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis, covis, sizeof(int) * n_covis, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis_T, rel.data(), sizeof(float) * 12 * n_covis, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    launch_create_filter(ctx->stream, ctx->in, e, ctx->dev_kfs, ctx->dev_covis, ctx->dev_covis_T, n_covis,
+                         min_observation_count, ctx->dev_flags);
+    CHECK_LAUNCH();
+  } else if (filter_new_surfels) {
+    // no co-visible keyframe: every candidate has exactly one observation
+    if (1 < min_observation_count) HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, ctx->stream));
+  }
+  HIP_TRY(scan_flags_inclusive(ctx->stream, ctx->scan_temp, ctx->scan_temp_bytes, ctx->dev_flags, ctx->dev_indices, (int)px));
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_indices + (px - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const uint32_t count = (uint32_t)ctx->pinned_i[0];
+  if (count == 0) return 0;
+  if ((uint64_t)surfels->surfels_size + count > surfels->capacity) {
+    // soft failure in the reference: logs and returns without creating (B/kernel_create_surfels.cc:162-165); the caller asks
+    // bahip_context_take_capacity_exceeded() to tell this from "no new surfels"
+    g_last_error = "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";
+    ctx->capacity_exceeded = true;
+    return 0;
+  }
+  launch_create_append(ctx->stream, ctx->in, e, ctx->dev_flags, ctx->dev_indices, surfels->surfels_size, make_view(surfels));
+  CHECK_LAUNCH();
+  *new_surfel_count_out = count;
+  return 0;
+}
+
+// A batch of keyframes creating surfels, one after the other as the reference does (each sees what the ones before it appended,
+// B/direct_ba_alternating.cc:389-425), but without the host in between: the cloud's size lives on the device for the duration of
+// the batch, the co-visibility lists and relative poses of all keyframes go up front in one copy, and the host reads the final size
+// once.  Same kernels on the same data in the same order as n calls of bahip_create_surfels_for_keyframe.
+int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes, int filter_new_surfels,
+                                       int min_observation_count, const int* covis_offsets, const int* covis_indices,
+                                       const bahip_surfels* surfels, uint32_t* const* supporting, uint32_t supporting_pitch,
+                                       uint32_t* new_surfel_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_create_surfels_for_keyframes");
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(keyframe_indices != nullptr && covis_offsets != nullptr && new_surfel_count_out != nullptr && num_keyframes >= 0,
+          "bahip_create_surfels_for_keyframes: NULL argument");
+  SupportingView sup;
+  REQUIRE(supporting_view(supporting, supporting_pitch, &sup) == 0, "supporting-surfel planes missing");
+  *new_surfel_count_out = 0;
+  if (num_keyframes == 0) return 0;
+  const int total_covis = covis_offsets[num_keyframes];
+  REQUIRE(total_covis == 0 || covis_indices != nullptr, "bahip_create_surfels_for_keyframes: co-visibility indices missing");
+  for (int j = 0; j < num_keyframes; ++j) {
+    REQUIRE(keyframe_indices[j] >= 0 && keyframe_indices[j] < ctx->num_kfs, "keyframe index out of range");
+    REQUIRE(covis_offsets[j] <= covis_offsets[j + 1], "co-visibility offsets must ascend");
+  }
+  const size_t px = create_padded_count(ctx->in);
+  if (ensure_px(ctx, px, px > surfels->capacity ? px : surfels->capacity)) return 1;
+  hipStream_t st = ctx->stream;
+  if (filter_new_surfels && total_covis > 0) {
+    if (total_covis > ctx->covis_capacity) {
+      int* idx = nullptr; float* T = nullptr;
+      const int cap = total_covis + 64;
+      if (hipMalloc(&idx, sizeof(int) * cap) != hipSuccess || hipMalloc(&T, sizeof(float) * 12 * cap) != hipSuccess) {
+        hipFree(idx); hipFree(T);
+        return fail("allocation of the co-visibility scratch failed", __FILE__, __LINE__);
+      }
+      hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T);
+      ctx->dev_covis = idx; ctx->dev_covis_T = T;
+      ctx->covis_capacity = cap;
+    }
+    std::vector<float> rel(12 * (size_t)total_covis);
+    for (int j = 0; j < num_keyframes; ++j) {
+      const KfEntry& e = ctx->host_kfs[keyframe_indices[j]];
+      for (int c = covis_offsets[j]; c < covis_offsets[j + 1]; ++c) {
+        REQUIRE(covis_indices[c] >= 0 && covis_indices[c] < ctx->num_kfs, "co-visibility index out of range");
+        // covis_T_frame = covis.frame_T_global * keyframe.global_T_frame (B/direct_ba.cc:359-365)
+        float cinv[7], prod[7];
+        se3_inverse(ctx->host_kfs[covis_indices[c]].global_T_frame, cinv);
+        se3_mul(cinv, e.global_T_frame, prod);
+        se3_matrix3x4(prod, &rel[12 * (size_t)c]);
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis, covis_indices, sizeof(int) * total_covis, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->dev_covis_T, rel.data(), sizeof(float) * 12 * (size_t)total_covis, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // `rel` is pageable and goes out of scope
+  }
+  // The cloud's size lives on the device between the keyframes of the batch, in TWO cells: a keyframe's launches read one, its append
+  // writes the other (kernels_lifecycle.hip: create_append_fused_kernel); [6] = the sticky "capacity exceeded" flag.
+  uint32_t* size_cell[2] = {reinterpret_cast<uint32_t*>(ctx->dev_counter) + 4, reinterpret_cast<uint32_t*>(ctx->dev_counter) + 5};
+  uint32_t* exceeded_on_device = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 6;
+  ctx->pinned_i[2] = (int)surfels->surfels_size; ctx->pinned_i[3] = (int)surfels->surfels_size; ctx->pinned_i[4] = 0;
+  HIP_TRY(hipMemcpyAsync(size_cell[0], ctx->pinned_i + 2, 3 * sizeof(int), hipMemcpyHostToDevice, st));
+  // scratch of the fused appends in the (otherwise unused) index vector: one tagged word per slice of the flag sequence
+  const int groups = create_append_groups();
+  REQUIRE((size_t)groups <= px, "bahip_create_surfels_for_keyframes: flag sequence shorter than the append's scratch");
+  uint32_t* group_words = ctx->dev_indices;
+  HIP_TRY(hipMemsetAsync(group_words, 0, sizeof(uint32_t) * (size_t)groups, st));
+  // the flag kernel writes every in-image entry of the flag sequence for every keyframe; the padding of the tile-major sequence is
+  // cleared once per batch
+  HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));
+  const uint32_t cells = (uint32_t)ctx->in.cf_width * (uint32_t)ctx->in.cf_height;   // a keyframe appends at most one surfel per sparse cell
+  for (int j = 0; j < num_keyframes; ++j) {
+    const KfEntry& e = ctx->host_kfs[keyframe_indices[j]];
+    const uint32_t* size_in = size_cell[j & 1];
+    // what the cloud can hold by now at most: the grid of the sweep; the size itself is read on the device
+    bahip_surfels bound = *surfels;
+    bound.surfels_size = (uint32_t)std::min<uint64_t>(surfels->capacity, (uint64_t)surfels->surfels_size + (uint64_t)j * cells);
+    const SurfelsView s = make_view(&bound);
+    ctx->supporting_planes_empty = nullptr;
+    launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
+    launch_supporting_insert(st, ctx->in, e, s, sup, lifecycle_cull_for(ctx, surfels, e.pose.F), size_in);
+    launch_create_flag(st, ctx->in, e, sup, ctx->dev_flags);
+    const int n_covis = covis_offsets[j + 1] - covis_offsets[j];
+    if (filter_new_surfels && n_covis > 0) {
+      launch_create_filter(st, ctx->in, e, ctx->dev_kfs, ctx->dev_covis + covis_offsets[j], ctx->dev_covis_T + 12 * (size_t)covis_offsets[j], n_covis,
+                           min_observation_count, ctx->dev_flags);
+    } else if (filter_new_surfels) {
+      if (1 < min_observation_count) HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));   // no co-visible keyframe: one observation
+    }
+    bound.surfels_size = surfels->capacity;   // (the append addresses rows by index; the view's size is not looked at)
+    const uint32_t tag = (uint32_t)(j % 255) + 1u;
+    if (j > 0 && tag == 1u) HIP_TRY(hipMemsetAsync(group_words, 0, sizeof(uint32_t) * (size_t)groups, st));   // the tags start over
+    launch_create_append_fused(st, ctx->in, e, ctx->dev_flags, make_view(&bound), size_in, size_cell[(j & 1) ^ 1], (uint32_t)surfels->capacity,
+                               exceeded_on_device, group_words, tag);
+    CHECK_LAUNCH();
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i + 2, size_cell[num_keyframes & 1], sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i + 3, exceeded_on_device, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *new_surfel_count_out = (uint32_t)ctx->pinned_i[2] - surfels->surfels_size;
+  if (ctx->pinned_i[3]) {
+    g_last_error = "Maximum surfel count exceeded! Retry with a higher max_surfel_count.";
+    ctx->capacity_exceeded = true;
+  }
+  return 0;
+}
+
+int bahip_delete_surfels_and_update_radii(bahip_context* ctx, int min_observation_count, const bahip_surfels* surfels,
+                                          uint32_t* deleted_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_delete_surfels_and_update_radii");
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  *deleted_count_out = 0;
+  if (surfels->surfels_size == 0) return 0;
+  HIP_TRY(hipMemsetAsync(ctx->dev_counter, 0, sizeof(int), ctx->stream));
+  launch_delete_update(ctx->stream, ctx->in, ctx->dev_kfs, ctx->num_kfs, make_view(surfels), min_observation_count,
+                       reinterpret_cast<uint32_t*>(ctx->dev_counter));
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(ctx->pinned_i, ctx->dev_counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *deleted_count_out = (uint32_t)ctx->pinned_i[0];
+  return 0;
+}
+
+int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip_surfels* surfels) {
+  ctx->lifecycle_bounds_tiles = 0;   // positions change or surfels move: a batch's tile bounds end here
+  if (surfels->surfels_size == surfel_count) return 0;
+  REQUIRE(surfel_count < surfels->surfels_size, "surfel_count larger than surfels_size");
+  if (ensure_px(ctx, 1, surfels->capacity)) return 1;
+  char* base = reinterpret_cast<char*>(surfels->data);
+  // scratch rows as in the reference: accum2 = invalid flags, accum0 = ranks, accum3 = free-spot list
+  uint32_t* invalid = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 2) * surfels->pitch_bytes);
+  uint32_t* free_rank = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 0) * surfels->pitch_bytes);
+  uint32_t* free_list = reinterpret_cast<uint32_t*>(base + (size_t)(kSurfelAccum0 + 3) * surfels->pitch_bytes);
+  HIP_TRY(launch_compact(ctx->stream, make_view(surfels), invalid, free_rank, free_list, surfel_count, ctx->scan_temp, ctx->scan_temp_bytes));
+  return 0;
+}
+
+int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfels, float grid_cell_size) {
+  ctx->lifecycle_bounds_tiles = 0;   // positions change or surfels move: a batch's tile bounds end here
+  REQUIRE(grid_cell_size > 0.f, "grid_cell_size must be positive");
+  const float inv_cell = 1.0f / grid_cell_size;
+  HIP_TRY(sort_surfels_spatially(ctx->stream, make_view(surfels), inv_cell));
+  return 0;
+}
+
+// B/kernel_opt_intrinsics.cc:39-281
+}  // extern "C"

@@ -81,10 +81,11 @@ template <bool kDepth, bool kColor>
 __global__ void __launch_bounds__(kIntrSweepBlock) __attribute__((amdgpu_waves_per_eu(BAHIP_INTR_WAVES_PER_EU)))
 intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
                              double* __restrict__ glob /* 34 */, double* __restrict__ cells /* S records of kCellFloats */, IntrBins bins,
-                             const uint32_t* __restrict__ sched) {
+                             const uint32_t* __restrict__ sched, uint32_t padded_tiles, uint32_t position_begin /* the launch covers the
+                             positions [position_begin, position_begin + gridDim.x) of the schedule: a slice of the sweep */) {
   __shared__ float xpose[64 * (kCellFloats + 1)];   // lane-major: 8 values + the cell index, stride 9 (conflict-free both ways)
   uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile)
-  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
+  if (!scheduled_tile(blockIdx.x + position_begin, padded_tiles, sched, &tile)) return;
   const uint32_t i = tile * kIntrSweepBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool in_range = i < s.size;
@@ -535,13 +536,21 @@ int intrinsics_bin_count(const Intrinsics& in, int* bins_x_out) {
   return bins_x * bins_y * kBinSubs;   // append buffers
 }
 size_t intrinsics_bin_record_bytes() { return kCellFloats * sizeof(uint32_t); }
+// positions [position_begin, position_begin + position_count) of the sweep's schedule (position_count == 0: all of them)
 void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched) {
+                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched,
+                                  uint32_t position_begin, uint32_t position_count) {
   if (!s.size) return;
-  const dim3 grid(sched_positions(xcd_padded_tiles((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock), sched)), block(kIntrSweepBlock);
-  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
-  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
-  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched);
+  const uint32_t padded = xcd_padded_tiles((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock), positions = sched_positions(padded, sched);
+  if (position_begin >= positions) return;
+  const uint32_t count = position_count ? std::min(position_count, positions - position_begin) : positions - position_begin;
+  const dim3 grid(count), block(kIntrSweepBlock);
+  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
+  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
+  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
+}
+uint32_t intrinsics_sweep_positions(uint32_t surfels, const uint32_t* sched) {
+  return sched_positions(xcd_padded_tiles((surfels + kIntrSweepBlock - 1) / kIntrSweepBlock), sched);
 }
 // The second kernel of the step: the binned per-cell records into the per-cell accumulators (nothing to do without bins).
 // 0: the table of ds_add_f64 (round 3), 1: records sorted by cell in LDS, sums in registers (round 4)

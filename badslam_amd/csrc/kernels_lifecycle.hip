@@ -155,7 +155,7 @@ merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView 
 
 // ... and, inside a merge batch that knows its frames (empty_the_planes), leaves the supporting planes as they were before the
 // insertion, all slots empty: the surfels that inserted themselves are the associated ones, whose cells merge_decide_kernel has
-// recorded -- so the NEXT keyframe of the batch needs no fill launch (capi.hip: determine_supporting_impl; a merge batch of 200
+// recorded -- so the NEXT keyframe of the batch needs no fill launch (capi_lifecycle.hip: determine_supporting_impl; a merge batch of 200
 // keyframes is launch-bound).  Otherwise the planes keep the lists, the reference function's second output.
 __global__ void __launch_bounds__(kLcBlock)
 merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ cell_of,

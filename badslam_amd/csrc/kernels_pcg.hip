@@ -925,6 +925,9 @@ static bool launch_pcg_step1_lds(hipStream_t st, const PcgLayout& L, const PcgEx
   return true;
 }
 
+// launches of the step-1 sweep by form since the process started: [0] one tile per wavefront, [1] persistent with the pose block in LDS
+static long long g_pcg_step1_form_launches[2] = {0, 0};
+void pcg_step1_form_launches(long long out[2]) { out[0] = g_pcg_step1_form_launches[0]; out[1] = g_pcg_step1_form_launches[1]; }
 void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
                       const SurfelsView& s, const float* p, float* g, const void* ctl_, const uint32_t* sched, uint32_t* tile_counters,
                       int* parity_inout) {
@@ -939,8 +942,9 @@ void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, co
     else if (di) launched = launch_pcg_step1_lds<true, false>(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout);
     else if (ci) launched = launch_pcg_step1_lds<false, true>(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout);
     else launched = launch_pcg_step1_lds<false, false>(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout);
-    if (launched) return;
+    if (launched) { ++g_pcg_step1_form_launches[1]; return; }
   }
+  ++g_pcg_step1_form_launches[0];
   const dim3 grid(sched_positions(gS(s.size), sched)), block(kPcgSweepBlock);
   if (di && ci) hipLaunchKernelGGL((pcg_step1_kernel<true, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
   else if (di) hipLaunchKernelGGL((pcg_step1_kernel<true, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);

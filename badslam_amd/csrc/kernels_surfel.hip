@@ -18,7 +18,7 @@
 //               divides the longest wavefront, which is what bounds the launch once the surfel set is a shard of a
 //               multi-GPU run and no longer fills the chip.
 //
-// The same definition is what makes KEYFRAME sharding (capi.hip: bahip_context_set_keyframe_sharding) reproduce the unsharded
+// The same definition is what makes KEYFRAME sharding (capi_rccl.hip: bahip_context_set_keyframe_sharding) reproduce the unsharded
 // bits: a rank that holds the images of whole classes only (keyframe k lives on rank (k % 4) % world, world = 2 | 4) computes
 // exactly those classes' partials (kSumsProduce: stored to a buffer [class][sum][surfel] that is zero elsewhere), the ranks
 // exchange the buffers as integer sums of bit patterns (x + 0 keeps every bit), and every rank then combines the four
@@ -442,7 +442,7 @@ void geometry_timeline_dump(const char* path) {
 template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate>
 __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
 geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
-                const uint32_t* __restrict__ sched, const int* __restrict__ stop /* device-driven BA loop (capi.hip:
+                const uint32_t* __restrict__ sched, const int* __restrict__ stop /* device-driven BA loop (capi_ba.hip:
                 bahip_alternating_iterations): a launch queued behind the iteration that ended the loop does nothing; NULL: always runs */) {
   __shared__ float lds[kWaves == 1 ? 1 : kMaxSumClasses * 8 * 64];
   if (stop && load_global(stop) != 0) return;

@@ -276,7 +276,7 @@ class DirectBA:
         assert self.L.dba_set_sum_classes(self.h, int(classes)) == 0
 
     def SetKeyframeSharding(self, rank, world):
-        """This object holds all surfels and sweeps the keyframes k with (k % 4) % world == rank (alternating scheme only)."""
+        """This object holds all surfels and sweeps the keyframes k with k % world == rank (world = 2, 4 or 8: whole keyframe classes of the per-surfel sums; alternating scheme only)."""
         assert self.L.dba_set_keyframe_sharding(self.h, int(rank), int(world)) == 0
 
     def set_pcg_gauge_keyframe(self, k):

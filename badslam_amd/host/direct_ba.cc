@@ -539,7 +539,12 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       for (const shared_ptr<Keyframe>& keyframe : keyframes_) {
         if (!keyframe) continue;
         const int b = id_to_bound_[keyframe->id()];
-        keyframe->set_global_T_frame(SE3f(&poses[7 * (size_t)b]));
+        // Only a keyframe whose pose the loop changed gets it written back: a keyframe that stayed kInactive (or converged without
+        // moving a bit) keeps the SE3f object it has -- set_global_T_frame rebuilds frame_T_global as the inverse, which is not
+        // bit for bit what a caller may have set through set_frame_T_global (the host loop and the reference touch only the
+        // keyframes that took a Gauss-Newton step).
+        if (memcmp(keyframe->global_T_frame().data(), &poses[7 * (size_t)b], 7 * sizeof(float)) != 0)
+          keyframe->set_global_T_frame(SE3f(&poses[7 * (size_t)b]));
         keyframe->SetActivation(static_cast<Keyframe::Activation>(activation[b]));
       }
       // the device table is in the state after the last pose phase; an iteration that did not end the loop is followed by

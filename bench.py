@@ -507,6 +507,8 @@ def main():
             pairs = None
             extras["intrinsics"] = {"BA_intrinsics_optimization_ms_per_iteration": ms[4] / EXTRA_STEPS, "iterations": EXTRA_STEPS,
                                     "sweep_ms": ms[6] / EXTRA_STEPS, "record_reduction_ms": ms[7] / EXTRA_STEPS,
+                                    "sweep_ms_note": ("sweep in slices with the record reductions on a second stream behind it: sweep_ms covers both"
+                                                      if ms[7] == 0 else "sweep, then the reduction of the records"),
                                     "note": "alternating iterations with depth + colour intrinsics optimisation after the timed region"}
             # the stage's dominant kernel against the HBM roof: its algorithmic bytes are the pose sweep's (surfel rows once, 5 bytes of
             # every keyframe pixel) plus the 32-byte record it writes per associated pair with a depth residual (read back by the reduction)
@@ -546,8 +548,14 @@ def main():
             # per surfel), 5 bytes of every keyframe pixel
             step1_bytes = N_total * (28 + 6 * 4) + K * args.width * args.height * 5
             pcg_pmc, pcg_source = committed_profile(args, intrinsics=False, pcg=True)
-            pcg_traffic = pmc_kernel_entry(pcg_pmc, pcg_source, "pcg_step1_lds_kernel")
-            extras["roofline_pcg"] = {"bound": "hbm", "kernel": "pcg_step1_lds_kernel<false,false> (persistent, pose block of the dense head in LDS)",
+            # which form of the sweep ran (the LDS form needs >= 8192 tiles, a pose block that fits its table and the opt-in)
+            tile_form, lds_form_n = C.c_longlong(), C.c_longlong()
+            capi.check(ctx.lib.bahip_debug_pcg_step1_form_launches(C.byref(tile_form), C.byref(lds_form_n)))
+            pcg_lds = lds_form_n.value >= tile_form.value
+            pcg_traffic = pmc_kernel_entry(pcg_pmc, pcg_source, "pcg_step1_lds_kernel" if pcg_lds else "pcg_step1_kernel")
+            extras["roofline_pcg"] = {"bound": "hbm", "kernel": ("pcg_step1_lds_kernel<false,false> (persistent, pose block of the dense head in LDS)" if pcg_lds
+                                                                 else "pcg_step1_kernel<false,false> (one tile per wavefront, global atomics on the exact accumulators)"),
+                                      "launches_by_form": {"lds": int(lds_form_n.value), "tile_per_wavefront": int(tile_form.value)},
                                       "avg_launch_ms": step1_ms, "launches": int(n_pcg[5]), "algorithmic_bytes_per_launch": step1_bytes,
                                       "achieved": step1_bytes / (step1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": step1_bytes / (step1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

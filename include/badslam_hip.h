@@ -484,6 +484,10 @@ int bahip_debug_read_tile_schedule(bahip_context* ctx, uint32_t* padded_tiles_ou
  * largest / total demand of the last call. */
 int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block);
 int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out);
+/* The intrinsics step's sweep runs in slices of its schedule when the cloud is large (the per-pair records of a slice are reduced on a
+ * second stream while the next slice sweeps; two buffer sets of one slice's records each): 1 .. 8 fixes the number of slices (tests on
+ * small scenes), 0 = by the size of the sweep (default).  The sums do not depend on it. */
+int bahip_debug_set_intrinsics_slices(bahip_context* ctx, int slices);
 /* The LDS form holds the normal equations of at most 292 work items; longer lists are cut into slices, one launch each.  items > 0
  * makes the slices that small (tests: 200 keyframes in slices of 64), 0 restores the default. */
 int bahip_debug_set_pose_lds_items(int items);
@@ -517,6 +521,9 @@ int bahip_debug_pose_form_launches(long long* global_form, long long* lds_form, 
 /* Kernel dispatches of the pose accumulate sweep since the process started (each slice of a sliced launch counts; never reset).
  * A profile of a bench run uses it to pick the dispatches of the timed region out of rocprofv3's per-dispatch rows. */
 int bahip_debug_pose_kernel_dispatches(long long* dispatches_out);
+/* launches of the PCG scheme's step-1 sweep by form since the process started: one tile per wavefront with global atomics on the
+ * exact accumulators / persistent workgroups with the pose block of the dense head in LDS (bench.py names the kernel it measured) */
+int bahip_debug_pcg_step1_form_launches(long long* tile_form, long long* lds_form);
 /* The fixed-point representation of a tile total of the pose normal equations (badslam_amd/csrc/ba_device.h: hb_split):
  * out[3 i .. 3 i + 2] = limb 0 (weight 2^-32), limb 1 (weight 1), valid (0: not finite or 2^52 and beyond -- such a total is
  * not added and fails the pose estimation). */

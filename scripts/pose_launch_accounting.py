@@ -3,7 +3,7 @@
 
 Since round 4 the Gauss-Newton rounds of a pose phase are queued ahead of the host: a round queued in vain is a launch of the pose
 sweep that finds no work item iterating and returns at once.  rocprofv3 --stats averages over EVERY launch; the bench line's
-roofline object describes the launches that did work (the event pairs of the others are dropped, capi.hip).  This script splits the
+roofline object describes the launches that did work (the event pairs of the others are dropped, capi_ba.hip).  This script splits the
 launches of the kernel trace of scripts/profile_round.sh's pass 1 by duration and writes the accounting as JSON.
 usage: pose_launch_accounting.py gpurun_out/prof_<tag> profiles/<tag>_bench.json > profiles/<tag>_pose_launches.json"""
 import csv

@@ -93,7 +93,7 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-# ---- sharded PCG: the exchange protocol of capi.hip (bahip_pcg_iteration) on a model problem ---------------------------------
+# ---- sharded PCG: the exchange protocol of capi_solvers.hip (bahip_pcg_iteration) on a model problem ---------------------------------
 def _pcg_model_problem(seed=3, head=13, surfels=600, rows_per_surfel=5):
     """Residuals that each touch the dense head (poses / intrinsics) and ONE surfel unknown -- the arrowhead structure of
     the BA normal equations.  Returns (J_head [R, head], J_surfel [R], surfel index [R], residual [R]), binary32."""

@@ -115,6 +115,29 @@ def test_depth_intrinsics_step_whatever_the_record_buffers_hold(scene, capacity,
         assert most.value <= cap.value
 
 
+@pytest.mark.parametrize("slices", [2, 3, 8])
+def test_depth_intrinsics_step_in_slices(scene, slices):
+    """Round 5: on a large cloud the sweep runs in slices of its schedule, the records of a slice being added up on a second stream while
+    the next slice sweeps into the other buffer set (capi_solvers.hip: bahip_optimize_intrinsics).  Forced on the small scene: the
+    same bits as the oracle, whatever the number of slices, also with buffers that overflow into the direct path."""
+    import ctypes as C
+    for capacity in (-1, 64):
+        ba, g = _perturbed_pair(scene)
+        ba.use_depth, ba.use_desc = 1, 1
+        lib, h = g.ctx.lib, g.ctx.handle
+        assert lib.bahip_debug_set_intrinsics_slices(h, slices) == 0
+        assert lib.bahip_debug_set_intrinsics_bin_capacity(h, capacity) == 0
+        for _ in range(2):                       # the second call reuses the buffer sets and the second stream
+            _, dc_r, a_r = ba.optimize_intrinsics(True, True)
+            _, dc_g, a_g = g.optimize_intrinsics(True, True)
+            assert np.array_equal(_bits(_cam_tuple(dc_g)), _bits(_cam_tuple(dc_r))), (slices, capacity)
+            assert np.array_equal(_bits([a_g]), _bits([a_r]))
+            assert np.array_equal(_bits(g.cfactor.download()), _bits(ba.cfactor))
+        cap, most, total = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        assert lib.bahip_debug_intrinsics_bin_stats(h, C.byref(cap), C.byref(most), C.byref(total)) == 0
+        assert total.value > 100000                # the pairs of all slices went through the reservation
+
+
 def test_color_intrinsics_step(scene):
     ba, g = _perturbed_pair(scene, depth_cam_offset=(0, 0, 0, 0), color_cam_offset=(0.4, -0.3, 0.8, -0.6))
     ba.use_depth, ba.use_desc = 1, 1
