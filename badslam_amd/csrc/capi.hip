@@ -233,6 +233,7 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   REQUIRE(n > 0, "bahip_context_create: no HIP device (the HIP backend has no CPU fallback)");
   bahip_context* ctx = new bahip_context();
   ctx->stream = static_cast<hipStream_t>(hip_stream);
+  if (const char* e = getenv("BAHIP_INTR_SLICES")) ctx->intr_slices_forced = std::min(std::max(atoi(e), 0), 8);   // experiments: slices of the intrinsics sweep
   const bool ok = hipMalloc(&ctx->dev_counter, 16 * sizeof(int)) == hipSuccess && hipMemset(ctx->dev_counter, 0, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_f, 128 * sizeof(float)) == hipSuccess &&

@@ -31,19 +31,22 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
   float* cells = glob + 64;
   float* partials = cells + 8 * (size_t)ctx->intr_capacity;
   // Append buffers for the per-cell records (kernels_intrinsics.hip).  A record exists per associated pair with a depth residual (52 M
-  // at the bench size, 1.0 G at BASELINE configs[4]: 53 GB when one set of buffers had to hold them all, round 4).  The sweep therefore
-  // runs in SLICES of its schedule: slice p appends to buffer set p & 1 and the reduction of that set runs on a second stream while
-  // slice p + 1 sweeps into the other set -- the buffers hold the records of one slice (scratch: pairs / slices x 2), and the
-  // reduction (LDS-bound, a third of the stage) is hidden behind the next slice's sweep (instruction-bound) where the scheduler lets
-  // the two kernels share the chip.  Their size follows the demand the previous call saw; before the first call it is an estimate, and
-  // a call that finds them too small still gives the same result: the records that do not fit go out as atomics.  The sums do not
-  // depend on the slicing (binary64 sums of binary32 terms: kernels_intrinsics.hip "DEFINITION").
+  // at the bench size, 1.0 G at BASELINE configs[4]: 53 GB when one set of buffers had to hold them all, round 4).  On a LARGE cloud the
+  // sweep therefore runs in SLICES of its schedule: slice p appends to buffer set p & 1, and the reduction of that set is queued on a
+  // second stream while slice p + 1 sweeps into the other set, so the buffers hold the records of one slice at a time (configs[4]: 30 GB
+  // in 8 slices where one set took 53 GB, the same 36 ms per step).  Measured in round 5 (profiles/r5_intrinsics_slices.txt): the
+  // reduction does NOT overlap the next slice's sweep -- the sweep's wavefronts hold 504 of a SIMD's 512 vector registers, a workgroup of
+  // the reduction finds no room until the sweep drains -- and at the bench size slices cost time (1.99 ms in one piece, 2.33-2.57 ms in
+  // 2-5 slices: every slice ends in its own tail), so small clouds keep one slice.  A call that finds the buffers too small still gives
+  // the same result: the records that do not fit go out as atomics.  The sums do not depend on the slicing (binary64 sums of
+  // binary32 terms: kernels_intrinsics.hip "DEFINITION").
   IntrBins bins{nullptr, nullptr, 0, 1};
   const int num_bins = intrinsics_bin_count(ctx->in, &bins.bins_x);
   const uint32_t* sched = tile_order_for(ctx, surfels->surfels_size);
   const uint32_t positions = intrinsics_sweep_positions(surfels->surfels_size, sched);
-  // slices of >= 8192 positions (two rounds of the chip's 4096 wavefront slots), at most 8; multiples of 8 keep the position -> XCD deal
-  int slices = ctx->intr_slices_forced > 0 ? ctx->intr_slices_forced : (int)std::min<uint32_t>(8u, std::max<uint32_t>(1u, positions / 8192u));
+  // one slice below 131072 tiles (8.4 M surfels); beyond, slices of >= 32768 positions, at most 8; multiples of 8 keep the position -> XCD deal
+  int slices = ctx->intr_slices_forced > 0 ? ctx->intr_slices_forced
+                                           : (positions < 131072u ? 1 : (int)std::min<uint32_t>(8u, positions / 32768u));
   if (!optimize_depth) slices = 1;   // no records, nothing to overlap
   const uint32_t per_slice = ((positions + (uint32_t)slices - 1) / (uint32_t)slices + 7u) & ~7u;
   const int sets = slices > 1 ? 2 : 1;
