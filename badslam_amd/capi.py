@@ -188,6 +188,7 @@ SIGNATURES = {
     "bahip_debug_set_intrinsics_reduce_form": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_rounds_ahead": (C.c_int, [C.c_int]),
     "bahip_debug_set_device_loop": (C.c_int, [C.c_int]),
+    "bahip_debug_alternating_loop_calls": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "bahip_debug_set_pcg_lds_form": (C.c_int, [C.c_int]),
     "bahip_debug_pose_form_launches": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "bahip_debug_pose_kernel_dispatches": (C.c_int, [C.POINTER(C.c_longlong)]),

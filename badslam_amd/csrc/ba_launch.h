@@ -3,6 +3,16 @@
 #pragma once
 
 #include "ba_device.h"
+#include <cstdlib>
+
+// An integer switch from the environment, read once at load time.  A plain function on purpose: these switches used to be initialised by
+// lambdas at namespace scope, and hipcc gave two such lambdas in two openings of one namespace of one file the SAME mangled name (host
+// and device passes number them per context) -- the linker kept one body, and `g_device_loop_enabled` was initialised by the lambda of
+// BAHIP_FUSED_ITERATION_BEGIN (default 0): the device-driven loop silently declined every call (round 5, found in the kernel trace).
+inline int bahip_env_int(const char* name, int fallback) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : fallback;
+}
 
 namespace bahip {
 

@@ -189,7 +189,7 @@ int ensure_tile_bounds(bahip_context* ctx, uint32_t surfels) {
   return 0;
 }
 
-int g_tile_order_enabled = [] { const char* e = getenv("BAHIP_TILE_ORDER"); return e ? atoi(e) : 1; }();
+int g_tile_order_enabled = bahip_env_int("BAHIP_TILE_ORDER", 1);
 int ensure_tile_schedule(bahip_context* ctx, uint32_t padded_tiles) {
   if (padded_tiles <= ctx->tile_schedule_capacity) return 0;
   const size_t cap = (size_t)padded_tiles + padded_tiles / 4;

@@ -46,8 +46,8 @@ int wait_for_pose_sequence(bahip_context* ctx, PoseWork* host_work, const PoseWo
 // the launch that ends a pose phase of the device-driven loop also sets up the next iteration (kernels_pose.hip: pose_solve_begin_kernel)
 // (off by default: measured SLOWER in round 4 -- 583 against 598 BA iterations/s, 0.420 against 0.411 ms on an eighth of the cloud:
 // sixteen wavefronts on one compute unit take longer over the set-up, and over a real solve, than the launch they save)
-int g_fused_iteration_begin = [] { const char* e = getenv("BAHIP_FUSED_ITERATION_BEGIN"); return e ? atoi(e) : 0; }();
-int g_pose_rounds_ahead = [] { const char* e = getenv("BAHIP_POSE_ROUNDS_AHEAD"); return e ? atoi(e) : 0; }();
+int g_fused_iteration_begin = bahip_env_int("BAHIP_FUSED_ITERATION_BEGIN", 0);
+int g_pose_rounds_ahead = bahip_env_int("BAHIP_POSE_ROUNDS_AHEAD", 0);
 int run_pose_rounds(bahip_context* ctx, bool use_depth, bool use_desc, const KfEntry* dev_frames, KfEntry* dev_frames_rw,
                     PoseWork* dev_work, HbFixed* dev_Hb, int num_work, const SurfelsView& s, int write_back, int update_activation,
                     PoseWork* host_work /* page-locked, num_work + kPoseTailRecords records */, int* rounds_out,
@@ -361,13 +361,19 @@ int bahip_estimate_keyframe_poses_and_update_activation(bahip_context* ctx, int 
 // ---- the alternating loop, driven by the device (include/badslam_hip.h) ---------------------------------------------------------
 }  // extern "C"
 namespace bahip_capi {
-int g_device_loop_enabled = [] { const char* e = getenv("BAHIP_DEVICE_LOOP"); return (e && atoi(e) == 0) ? 0 : 1; }();
+int g_device_loop_enabled = bahip_env_int("BAHIP_DEVICE_LOOP", 1) != 0 ? 1 : 0;
 }  // namespace bahip_capi
 namespace {
 constexpr int kLoopLogSlots = 4096;
 }
 extern "C" {
 int bahip_debug_set_device_loop(int enabled) { g_device_loop_enabled = enabled ? 1 : 0; return 0; }
+static std::atomic<long long> g_loop_calls_handled{0}, g_loop_calls_declined{0};
+int bahip_debug_alternating_loop_calls(long long* handled_out, long long* declined_out) {
+  if (handled_out) *handled_out = g_loop_calls_handled.load();
+  if (declined_out) *declined_out = g_loop_calls_declined.load();
+  return 0;
+}
 int bahip_debug_set_pcg_lds_form(int mode) { set_pcg_lds_form(mode); return 0; }
 int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_options* opt, const bahip_surfels* surfels,
                                  float* global_T_frame_out, int* activation_out, int* handled_out, int* iterations_done_out,
@@ -383,6 +389,13 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
   if (pose_rounds_out) *pose_rounds_out = 0;
   if (pose_steps_out) *pose_steps_out = 0;
   if (not_converged_out) *not_converged_out = 0;
+  static const bool say_why = getenv("BADSLAM_HOST_TIMING") != nullptr;
+  if (say_why)
+    fprintf(stderr, "[bahip_alternating_iterations] enabled %d K %d kf_sharded %d max_it %d queued-ahead %d hook %d\n", g_device_loop_enabled, K,
+            (int)kf_sharded(ctx), opt->max_iterations, (int)pose_round_can_be_queued_ahead(surfels->surfels_size, K, true), ctx->allreduce != nullptr ? 1 : 0);
+  if (!g_device_loop_enabled || K == 0 || kf_sharded(ctx) || opt->max_iterations <= 0 || !pose_round_can_be_queued_ahead(surfels->surfels_size, K, true) ||
+      ctx->allreduce != nullptr)
+    ++g_loop_calls_declined;   // (bahip_debug_alternating_loop_calls: a caller that expects the device loop can check that it got it)
   if (!g_device_loop_enabled || K == 0 || kf_sharded(ctx) || opt->max_iterations <= 0 || !pose_round_can_be_queued_ahead(surfels->surfels_size, K, true)) return 0;
   // With a HOST all-reduce hook every queued round is a stream synchronisation plus a host collective -- also the rounds queued
   // behind the iteration that ended the loop, which exchange zeros: the host loop, which knows when to stop, serves
@@ -574,6 +587,7 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
   if (last_needed[1] > 0) ctx->rounds_hint_table = std::max(last_needed[0], last_needed[1]);
   else if (it > 0) ctx->rounds_hint_table = std::max(1, (rounds_total + it - 1) / it);
   *handled_out = 1;
+  ++g_loop_calls_handled;
   if (iterations_done_out) *iterations_done_out = it;
   if (converged_out) *converged_out = converged ? 1 : 0;
   if (pose_rounds_out) *pose_rounds_out = rounds_total;

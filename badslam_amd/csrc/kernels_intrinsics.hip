@@ -554,7 +554,7 @@ uint32_t intrinsics_sweep_positions(uint32_t surfels, const uint32_t* sched) {
 }
 // The second kernel of the step: the binned per-cell records into the per-cell accumulators (nothing to do without bins).
 // 0: the table of ds_add_f64 (round 3), 1: records sorted by cell in LDS, sums in registers (round 4)
-static int g_intr_reduce_form = [] { const char* e = getenv("BAHIP_INTR_REDUCE_FORM"); return e ? atoi(e) : BAHIP_INTR_REDUCE_FORM_DEFAULT; }();
+static int g_intr_reduce_form = bahip_env_int("BAHIP_INTR_REDUCE_FORM", BAHIP_INTR_REDUCE_FORM_DEFAULT);
 void set_intrinsics_reduce_form(int form) { g_intr_reduce_form = form < 0 ? BAHIP_INTR_REDUCE_FORM_DEFAULT : form; }
 void launch_intrinsics_bin_reduce(hipStream_t st, bool depth, const Intrinsics& in, const SurfelsView& s, double* cells, const IntrBins& bins) {
   if (!s.size) return;

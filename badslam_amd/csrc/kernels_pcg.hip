@@ -890,7 +890,7 @@ void launch_pcg_control(hipStream_t st, const PcgExact& ex, void* ctl, float* be
 }
 size_t pcg_control_bytes() { return sizeof(PcgControl); }
 
-static int g_pcg_lds_form = [] { const char* e = getenv("BAHIP_PCG_LDS"); return e ? atoi(e) : 1; }();   // 0: always the one-tile-per-wavefront form
+static int g_pcg_lds_form = bahip_env_int("BAHIP_PCG_LDS", 1);   // 0: always the one-tile-per-wavefront form
 void set_pcg_lds_form(int mode) { g_pcg_lds_form = (mode >= 0 && mode <= 2) ? mode : 1; }   // 2: also on grids that do not fill the chip (tests)
 constexpr size_t kPcgLdsTableLimit = 128 * 1024;
 template <bool kDepthIntr, bool kColorIntr>

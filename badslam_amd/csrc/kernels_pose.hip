@@ -950,7 +950,7 @@ void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs
   if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices, stop);
 }
 
-static int g_forced_pose_parts = [] { const char* e = getenv("BAHIP_POSE_PARTS"); return e ? atoi(e) : 0; }();
+static int g_forced_pose_parts = bahip_env_int("BAHIP_POSE_PARTS", 0);
 void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
 
 size_t pose_tile_bounds_bytes(uint32_t surfels) {
@@ -960,7 +960,7 @@ size_t pose_tile_bounds_bytes(uint32_t surfels) {
 
 // 0 = chosen from the sizes (default), 1 = always the one-tile-per-wavefront form with global atomics, 2 = the persistent LDS
 // form whenever the table fits (tests run both: same bits)
-static int g_forced_pose_form = [] { const char* e = getenv("BAHIP_POSE_FORM"); return e ? atoi(e) : 0; }();
+static int g_forced_pose_form = bahip_env_int("BAHIP_POSE_FORM", 0);
 void set_pose_form(int form) { g_forced_pose_form = form; }
 static int g_pose_lds_items = 0;   // test hook: work items per launch of the LDS form (0: what the table holds)
 void set_pose_lds_items(int items) { g_pose_lds_items = items; }
@@ -978,7 +978,7 @@ constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a comput
 #define BAHIP_POSE_LDS_MIN_TILES 2048
 #endif
 constexpr unsigned kPoseLdsMinTiles = BAHIP_POSE_LDS_MIN_TILES;   // smaller grids: one tile per wavefront, global atomics
-static int g_pose_lds_parts_shift = [] { const char* e = getenv("BAHIP_POSE_LDS_PARTS_SHIFT"); return e ? atoi(e) : -1; }();   // -1: from the grid size
+static int g_pose_lds_parts_shift = bahip_env_int("BAHIP_POSE_LDS_PARTS_SHIFT", -1);   // -1: from the grid size
 void set_pose_lds_parts_shift(int shift) { g_pose_lds_parts_shift = (shift >= 0 && shift <= 3) ? shift : -1; }
 
 static int g_pose_lds_waves = 0;   // test hook: wavefronts per workgroup of the LDS form (0: kPoseLdsWaves)

@@ -512,7 +512,7 @@ void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntr
 // Launch shape of the normals / geometry passes (see the header comment): one wavefront per tile when the tiles alone
 // fill the chip several times over, else four.  Results do not depend on it; BAHIP_TILE_WAVES=1|4 or
 // bahip_debug_set_launch_shapes force one (tests run both).
-static int g_forced_tile_waves = [] { const char* e = getenv("BAHIP_TILE_WAVES"); return e ? atoi(e) : 0; }();
+static int g_forced_tile_waves = bahip_env_int("BAHIP_TILE_WAVES", 0);
 void set_tile_waves(int waves) { g_forced_tile_waves = waves; }
 static int tile_waves(uint32_t surfels) {
   const int forced = g_forced_tile_waves;

@@ -506,6 +506,10 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
   // host has to look at between the iterations.  All iterations are queued at once; the stopping rule of :693-701 is evaluated
   // by the last solve launch of every pose phase, and the host waits once.  Everything else takes the loop below.
   bool device_loop_done = false;
+  if (host_timing)
+    fprintf(stderr, "[DirectBA] loop conditions: poses %d geometry %d updates %d intr %d/%d progress %d timer %d timings %d kfworld %d full_window %d max_it %d\n",
+            (int)optimize_poses, (int)optimize_geometry, (int)do_surfel_updates, (int)optimize_depth_intrinsics, (int)optimize_color_intrinsics,
+            progress_function ? 1 : 0, timer ? 1 : 0, timings_stream_ ? 1 : 0, keyframe_shard_world_, (int)full_window, max_iterations);
   if (optimize_poses && optimize_geometry && !do_surfel_updates && !optimize_depth_intrinsics && !optimize_color_intrinsics &&
       !progress_function && !timer && !timings_stream_ && keyframe_shard_world_ == 1 && full_window && max_iterations > 0) {
     if (fixed_active_keyframe_set) {
@@ -533,6 +537,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     int handled = 0, done = 0, conv = 0, rounds = 0, steps = 0, not_converged = 0;
     BAHIP_CHECKED_CALL(bahip_alternating_iterations(ctx_, &options, &s, poses.data(), activation.data(), &handled, &done, &conv, &rounds, &steps,
                                                     &not_converged));
+    if (host_timing) fprintf(stderr, "[DirectBA] device loop %s\n", handled ? "handled the call" : "declined");
     if (handled) {
       device_loop_done = true;
       Lock();

@@ -433,11 +433,15 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    loop_handled0, loop_declined0 = C.c_longlong(), C.c_longlong()
+    capi.check(ctx.lib.bahip_debug_alternating_loop_calls(C.byref(loop_handled0), C.byref(loop_declined0)))
     t0 = time.perf_counter()
     run(args.steps)
     ctx.synchronize()
     torch.cuda.synchronize()
     local_elapsed = time.perf_counter() - t0       # this rank alone, before it waits for the others
+    loop_handled1, loop_declined1 = C.c_longlong(), C.c_longlong()
+    capi.check(ctx.lib.bahip_debug_alternating_loop_calls(C.byref(loop_handled1), C.byref(loop_declined1)))
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -699,6 +703,11 @@ def main():
                              "n_ranks_seen": ranks_seen,
                              "n_ranks_seen_note": "sum of 1 over the ranks through that transport before the first iteration (bahip_context_count_ranks, with a time limit)"},
                 "per_rank": per_rank} if per_rank is not None else {}),
+            "loop": {"timed_calls_driven_by_the_device": int(loop_handled1.value - loop_handled0.value),
+                     "timed_calls_driven_by_the_host": int(loop_declined1.value - loop_declined0.value),
+                     "note": "bahip_alternating_iterations: all iterations of a BundleAdjustment call queued at once, the stopping rule on the device, "
+                             "one host wait -- or declined (surfel updates, intrinsics, PCG, keyframe sharding, a host all-reduce hook) and driven "
+                             "by the host class round by round; the plain alternating bench must read 1 / 0"},
             "stage_ms_per_iteration": {STAGES[s]: breakdown_ms[s] / BREAKDOWN_STEPS for s in range(5 if args.intrinsics else 4)},
             "stage_ms_note": f"{BREAKDOWN_STEPS} further iterations after the timed region, all stages timed; the surfel activation "
                              "is decided inside the normals pass of the geometry sweep (one launch), hence 0",

@@ -512,6 +512,10 @@ int bahip_debug_set_intrinsics_reduce_form(int form);
 /* 0: bahip_alternating_iterations reports "not handled" and callers drive the loop through the stage functions, one host wait
  * per Gauss-Newton round (BAHIP_DEVICE_LOOP=0 in the environment does the same); 1 (default): the device-driven loop.  Same bits. */
 int bahip_debug_set_device_loop(int enabled);
+/* Calls of bahip_alternating_iterations since the process started that the device-driven loop handled / declined (handled_out = 0:
+ * switched off, keyframe sharding, a host all-reduce hook, more work items than one launch of the pose sweep takes).  bench.py prints
+ * both; the test suite checks that the default configuration is handled. */
+int bahip_debug_alternating_loop_calls(long long* handled_out, long long* declined_out);
 /* 0: the step-1 sweep of the PCG scheme always runs one tile per wavefront with global atomics on the exact accumulators; 1
  * (default): persistent workgroups that keep the pose block of the dense head in LDS when it fits (up to ~295 keyframes) and
  * the grid fills the chip; 2: that form whenever the table fits (tests on small scenes).  Exact (integer) sums: the same bits. */

@@ -33,8 +33,15 @@ def _run(scene, perturbed, surfels, device_loop, rounds_ahead, fused_begin=True,
         for k, T in enumerate(perturbed):
             ba.set_keyframe_pose(k, T)
         ba.set_ba_iteration_counts(1, 1)      # no end tasks: the surfel set and its order stay
+        import ctypes as C
+        h0, d0, h1, d1 = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+        capi.check(lib.bahip_debug_alternating_loop_calls(C.byref(h0), C.byref(d0)))
         done, conv = ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True,
                                          increase_ba_iteration_count=False, **ba_args)
+        capi.check(lib.bahip_debug_alternating_loop_calls(C.byref(h1), C.byref(d1)))
+        # the call went where it was sent (round 5: the switch's initialiser was miscompiled and EVERY call was declined; results are
+        # the same either way, so only this counter can tell)
+        assert (h1.value - h0.value, d1.value - d0.value) == ((1, 0) if device_loop else (0, 1))
         K = len(perturbed)
         return dict(done=done, conv=conv, stats=ba.last_stats(), poses=np.asarray([ba.keyframe_pose(k) for k in range(K)], np.float32),
                     activation=[ba.keyframe_activation(k) for k in range(K)], surfels=ba.download_surfels(8)), surfels
@@ -67,3 +74,17 @@ def test_device_driven_loop_is_the_host_driven_loop(case, fused_begin):
     assert np.array_equal(got["surfels"].view(np.uint32), ref["surfels"].view(np.uint32))
     if case != "single keyframe":          # (one keyframe against its own, slightly displaced surfels: microns)
         assert np.abs(got["poses"] - np.asarray(perturbed, np.float32)).max() > 1e-4     # the loop did move the poses
+
+
+def test_the_default_configuration_takes_the_device_driven_loop():
+    """In a fresh process, with nothing set: vis::DirectBA::BundleAdjustment over poses + geometry is handled by
+    bahip_alternating_iterations (the tests above switch the loop on explicitly and restore `1` afterwards, which hid a default of 0 --
+    the initialiser of the switch had been given another lambda's body by the compiler -- for half a round)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("BAHIP_")}
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--keyframes", "12", "--surfels", "100000",
+                           "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.strip()][-1])
+    assert out["loop"]["timed_calls_driven_by_the_device"] == 1 and out["loop"]["timed_calls_driven_by_the_host"] == 0, out["loop"]
