@@ -390,6 +390,9 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
   if (pose_steps_out) *pose_steps_out = 0;
   if (not_converged_out) *not_converged_out = 0;
   static const bool say_why = getenv("BADSLAM_HOST_TIMING") != nullptr;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_enter = say_why ? now_us() : 0;
+  double t_queued = 0, t_waited = 0;
   if (say_why)
     fprintf(stderr, "[bahip_alternating_iterations] enabled %d K %d kf_sharded %d max_it %d queued-ahead %d hook %d\n", g_device_loop_enabled, K,
             (int)kf_sharded(ctx), opt->max_iterations, (int)pose_round_can_be_queued_ahead(surfels->surfels_size, K, true), ctx->allreduce != nullptr ? 1 : 0);
@@ -513,7 +516,9 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
         CHECK_LAUNCH();
       }
     }
+    if (say_why && t_queued == 0) t_queued = now_us();
     if (wait_for_pose_sequence(ctx, ctx->pinned_work, ctx->dev_work, K, sequence)) return 1;
+    if (say_why && t_waited == 0) t_waited = now_us();
     if (ctx->poll_disabled) HIP_TRY(hipMemcpy(ctx->host_loop_ctl, ctx->dev_loop_ctl, sizeof(int) * kLoopWords, hipMemcpyDeviceToHost));
     if (counters[kPoseCounterInvalid] || ctx->host_loop_ctl[kLoopInvalid])
       return fail("pose normal equations: a tile total was not finite or reached 2^52 (hb_split), or a sum left the fixed-point range; the "
@@ -588,6 +593,9 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
   else if (it > 0) ctx->rounds_hint_table = std::max(1, (rounds_total + it - 1) / it);
   *handled_out = 1;
   ++g_loop_calls_handled;
+  if (say_why)
+    fprintf(stderr, "[bahip_alternating_iterations, us] queueing %.0f | first wait %.0f | rest (hand-overs, read-back) %.0f | iterations %d\n",
+            t_queued - t_enter, t_waited - t_queued, now_us() - t_waited, it);
   if (iterations_done_out) *iterations_done_out = it;
   if (converged_out) *converged_out = converged ? 1 : 0;
   if (pose_rounds_out) *pose_rounds_out = rounds_total;

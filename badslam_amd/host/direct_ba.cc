@@ -535,8 +535,10 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
     options.min_iterations = min_iterations; options.max_iterations = max_iterations;
     const bahip_surfels s = SurfelsStruct();
     int handled = 0, done = 0, conv = 0, rounds = 0, steps = 0, not_converged = 0;
+    const double t_before_loop = host_timing ? now() : 0;
     BAHIP_CHECKED_CALL(bahip_alternating_iterations(ctx_, &options, &s, poses.data(), activation.data(), &handled, &done, &conv, &rounds, &steps,
                                                     &not_converged));
+    const double t_after_loop = host_timing ? now() : 0;
     if (host_timing) fprintf(stderr, "[DirectBA] device loop %s\n", handled ? "handled the call" : "declined");
     if (handled) {
       device_loop_done = true;
@@ -562,6 +564,9 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
       last_pose_steps_ += steps;
       if (not_converged) LOG(WARNING) << "Pose estimation not converged (" << not_converged << " estimations)";
     }
+    if (host_timing)
+      fprintf(stderr, "[DirectBA, us] bind + window %.0f | bahip_alternating_iterations %.0f | write-back %.0f\n", t_before_loop - t_mark,
+              t_after_loop - t_before_loop, now() - t_after_loop);
   }
 
   for (int iteration = 0; iteration < max_iterations && !device_loop_done; ++iteration) {
