@@ -84,6 +84,7 @@ SIGNATURES = {
     "bahip_context_synchronize": (C.c_int, [C.c_void_p]),
     "bahip_context_take_capacity_exceeded": (C.c_int, [C.c_void_p]),
     "bahip_context_is_sharded": (C.c_int, [C.c_void_p]),
+    "bahip_context_surfels_rearranged": (C.c_int, [C.c_void_p]),
     "bahip_context_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "bahip_context_set_keyframe_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bahip_context_set_sum_classes": (C.c_int, [C.c_void_p, C.c_int]),

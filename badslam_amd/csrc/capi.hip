@@ -451,6 +451,13 @@ int bahip_context_set_creation_order(bahip_context* ctx, int row_major) {
   return 0;
 }
 
+int bahip_context_surfels_rearranged(bahip_context* ctx) {
+  REQUIRE(ctx != nullptr, "bahip_context_surfels_rearranged: NULL context");
+  ctx->tile_order_tiles = 0;          // the next pose phase counts the candidates per tile again and rebuilds the run order
+  ctx->lifecycle_bounds_tiles = 0;    // and an open lifecycle batch's tile bounds describe the previous arrangement
+  return 0;
+}
+
 int bahip_frame_planes_create(bahip_context* ctx, int depth_width, int depth_height, int color_width, int color_height,
                               bahip_frame_planes** out) {
   REQUIRE(ctx != nullptr && out != nullptr, "bahip_frame_planes_create: NULL argument");

@@ -378,6 +378,7 @@ int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip
   ctx->lifecycle_bounds_tiles = 0;   // positions change or surfels move: a batch's tile bounds end here
   if (surfels->surfels_size == surfel_count) return 0;
   REQUIRE(surfel_count < surfels->surfels_size, "surfel_count larger than surfels_size");
+  ctx->tile_order_tiles = 0;         // surfels move to other tiles: the run order of the sweeps is rebuilt by the next pose phase
   if (ensure_px(ctx, 1, surfels->capacity)) return 1;
   char* base = reinterpret_cast<char*>(surfels->data);
   // scratch rows as in the reference: accum2 = invalid flags, accum0 = ranks, accum3 = free-spot list
@@ -391,6 +392,7 @@ int bahip_compact_surfels(bahip_context* ctx, uint32_t surfel_count, const bahip
 int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfels, float grid_cell_size) {
   ctx->lifecycle_bounds_tiles = 0;   // positions change or surfels move: a batch's tile bounds end here
   REQUIRE(grid_cell_size > 0.f, "grid_cell_size must be positive");
+  ctx->tile_order_tiles = 0;         // every surfel changes its tile: the run order of the sweeps is rebuilt by the next pose phase
   const float inv_cell = 1.0f / grid_cell_size;
   HIP_TRY(sort_surfels_spatially(ctx->stream, make_view(surfels), inv_cell));
   return 0;

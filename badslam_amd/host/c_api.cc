@@ -169,6 +169,7 @@ int dba_upload_surfels(dba_handle* h, void* stream, int rows, uint32_t count, co
   if ((int)count > s->width()) return 1;
   for (int r = 0; r < rows; ++r)
     s->UploadPartAsync((size_t)r * s->ToCUDA().pitch(), (size_t)count * sizeof(float), stream, in + (size_t)r * count);
+  bahip_context_surfels_rearranged(h->ba->backend_context());   // (other surfels in every tile: the sweeps' run order is rebuilt)
   return 0;
 }
 

@@ -139,6 +139,11 @@ int bahip_context_set_sum_classes(bahip_context* ctx, int classes);
  * their indices differ inside each keyframe's block, and with them which of two mergeable surfels survives (the lower index:
  * B/kernel_supporting_surfels.cu:60-86).  Takes effect for the creations that follow. */
 int bahip_context_set_creation_order(bahip_context* ctx, int row_major);
+/* A hint, for callers that write the surfel buffer themselves (an upload, a permutation of their own): which surfels share a tile has
+ * changed, so the run order the sweeps derive from a census of the tiles ("heavy work first", rebuilt on its own only every 32nd pose
+ * phase or when the number of tiles changes) is stale -- the next pose phase takes the census again.  The backend's own movers
+ * (bahip_compact_surfels, bahip_sort_surfels_spatially) do this themselves.  Results never depend on the run order. */
+int bahip_context_surfels_rearranged(bahip_context* ctx);
 #define BAHIP_RCCL_UNIQUE_ID_BYTES 128
 int bahip_rccl_get_unique_id(char unique_id_out[BAHIP_RCCL_UNIQUE_ID_BYTES]);
 int bahip_context_init_rccl(bahip_context* ctx, const char unique_id[BAHIP_RCCL_UNIQUE_ID_BYTES], int rank, int world_size);
