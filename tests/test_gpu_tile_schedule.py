@@ -79,3 +79,32 @@ def test_schedule_is_a_permutation_and_changes_no_bit(surfels_per_side):
     assert np.array_equal(np.sort(perm), np.arange(padded, dtype=np.uint32))           # every tile at exactly one regular position
     assert len(set(heavy.tolist())) == heavy_count                                       # no tile twice in the heavy list
     assert np.array_equal(np.sort(heavy), np.nonzero(flags)[0].astype(np.uint32))       # flagged <=> listed
+
+
+def test_run_order_is_rebuilt_after_the_surfels_were_rearranged():
+    """Round 5: the order describes an ARRANGEMENT of the surfels.  The Morton sort, a compaction that moves something and the hint
+    for outside writers (bahip_context_surfels_rearranged) drop it; the next pose phase takes the census again and the order is back --
+    a permutation of the tiles as before.  (It used to survive a reorder for up to 32 pose phases: the sweeps then ran 10-15 % slower,
+    results unchanged, and which bench figure suffered was a lottery of the phase counter.)"""
+    import torch
+    from badslam_amd import capi
+    torch.cuda.set_device(0)
+    scene = common.small_scene(num_keyframes=6, seed=31)
+    rng = np.random.Generator(np.random.PCG64(5))
+    poses = [common.synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    g = common.build_gpu(scene, 900000)
+    lib, h = g.ctx.lib, g.ctx.handle
+    for _ in range(2):
+        poses = _iteration(g, poses)
+    padded, _ = _schedule(g)
+    assert padded > 0
+    for rearrange in ("sort", "hint", "sort"):
+        if rearrange == "sort":
+            g.sort_surfels_spatially(0.02)
+        else:
+            capi.check(lib.bahip_context_surfels_rearranged(h))
+        assert _schedule(g)[0] == 0                      # dropped: the sweeps of the next iteration run in buffer order ...
+        poses = _iteration(g, poses)
+        padded_again, words = _schedule(g)               # ... and its pose phase has rebuilt it
+        assert padded_again == padded
+        assert np.array_equal(np.sort(words[PERM:PERM + padded]), np.arange(padded, dtype=np.uint32))
