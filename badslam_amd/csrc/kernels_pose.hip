@@ -253,7 +253,10 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
     const int w = __builtin_amdgcn_readfirstlane(stored_bounds ? __builtin_amdgcn_readlane(my_w, ((item - part) / parts) & 63) : item_begin + item);
     const float* F = work[w].F;
     ++visited;
-    const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(work[w].kf_index)];
+    // (work[w].kf_index == w for every writer of the table -- the batched phase binds work item k to keyframe k, the single-frame
+    // estimate has one of each -- so the image pointers are read from frames[w] at once, together with F, instead of behind a second,
+    // dependent scalar load of the index)
+    const KfEntry& kf = frames[w];
     // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
     const Projected p = project_surfel(in, F, gp);
     const PixelWords pix = load_pixel_words(in, kf.geom, p);
