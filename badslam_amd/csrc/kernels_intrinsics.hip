@@ -74,8 +74,21 @@ __device__ __forceinline__ float& cell_obs(float* cells, int cell) { return cell
 // luminance words -- are issued before the first is waited for, and the per-cell atomics of a candidate go out one candidate
 // LATE, behind the next candidate's gathers: vmcnt retires in order, so an atomic issued before a gather would make the wait
 // for that gather a wait for the atomic's round trip.
+// Round 5: kIntrLdsSums of the 34 per-lane sums live in LDS instead of registers -- slot q of lane l at lds_sums[q * 64 + l], touched by
+// that lane only (a plain read / add / write: the same binary32 additions in the same order, no atomics, no bank conflicts) -- which takes
+// the sweep from 151 VGPRs and 3 wavefronts per SIMD to 4.  24 of them is what 16 one-wavefront workgroups per CU leave room for next to
+// the transpose buffer (16 x (24 x 256 + 2304) bytes = 132 KB of the 160 KB).  0 restores the round-4 form.
+// Measured (call 26): stage 1.98-2.00 -> 1.92-1.94 ms per iteration, bit-identical.  What the sweep's time is (calls 27 / 28: counters and
+// timing builds without the record stores / the reservation atomics): 6.1e8 VALU wave-instructions per launch against the pose sweep's
+// 4.2e8 in the same state -- depth and colour Jacobians, exp_det once a != 0, two IEEE divisions -- i.e. 1.3 x the pose sweep's work;
+// the eight record stores per candidate cost 9 % of the launch, the returning reservation atomic 4 %, both together 13 %.
+#ifndef BAHIP_INTR_LDS_SUMS
+#define BAHIP_INTR_LDS_SUMS 24
+#endif
+constexpr int kIntrLdsSums = BAHIP_INTR_LDS_SUMS;
+constexpr int kIntrRegSums = 34 - kIntrLdsSums;
 #ifndef BAHIP_INTR_WAVES_PER_EU
-#define BAHIP_INTR_WAVES_PER_EU 3   // 168 VGPRs: the 34 per-lane sums live across the sweep (at 4 waves: 57 spills)
+#define BAHIP_INTR_WAVES_PER_EU (BAHIP_INTR_LDS_SUMS >= 24 ? 4 : 3)   // all 34 sums in registers: 151 VGPRs (at 4 waves: 57 spills)
 #endif
 template <bool kDepth, bool kColor>
 __global__ void __launch_bounds__(kIntrSweepBlock) __attribute__((amdgpu_waves_per_eu(BAHIP_INTR_WAVES_PER_EU)))
@@ -97,9 +110,18 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
   const TangentPoints tp = surfel_tangent_points(gp, gn, radius_sq);   // per surfel, not per pair
   const WaveBounds wb = wave_bounds(gp, in_range && (gp.x == gp.x));
   if (wb.r < 0.f) return;   // a tile of the grid's padding, or one without a valid surfel (wave-uniform)
-  float acc[34];
+  __shared__ float lds_sums[(kIntrLdsSums > 0 ? kIntrLdsSums : 1) * 64];
+  float reg_sums[kIntrRegSums > 0 ? kIntrRegSums : 1];
 #pragma unroll
-  for (int q = 0; q < 34; ++q) acc[q] = 0.f;
+  for (int q = 0; q < kIntrRegSums; ++q) reg_sums[q] = 0.f;
+#pragma unroll
+  for (int q = 0; q < kIntrLdsSums; ++q) lds_sums[q * 64 + lane] = 0.f;
+  // sum q (a compile-time index after unrolling): the first kIntrRegSums in registers, the others in this lane's LDS slots
+  auto sum_add = [&](int q, float term) {
+    if (q < kIntrRegSums) reg_sums[q] += term;
+    else lds_sums[(q - kIntrRegSums) * 64 + lane] += term;
+  };
+  auto sum_value = [&](int q) { return q < kIntrRegSums ? reg_sums[q] : lds_sums[(q - kIntrRegSums) * 64 + lane]; };
 
   // the per-cell terms of the previous candidate: {B0..B4, D, b2} (the observation count is 1) and the cell as
   // (block << 10 | cell within the block), -1: none; and where they go: pending_slot = (group << 8 | rank within the group)
@@ -216,10 +238,10 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
 #pragma unroll
               for (int row = 0; row < kARows; ++row)
 #pragma unroll
-                for (int col = row; col < kARows; ++col) acc[q++] += w * J[row] * J[col];
+                for (int col = row; col < kARows; ++col) sum_add(q++, w * J[row] * J[col]);
               const float wr = w * raw;
 #pragma unroll
-              for (int c = 0; c < kARows; ++c) acc[15 + c] += wr * J[c];
+              for (int c = 0; c < kARows; ++c) sum_add(15 + c, wr * J[c]);
               pending_cell = (((sparse_py >> kBinShift) * bins.bins_x + (sparse_px >> kBinShift)) << (2 * kBinShift)) |
                              ((sparse_py & ((1 << kBinShift) - 1)) << kBinShift) | (sparse_px & ((1 << kBinShift) - 1));
 #pragma unroll
@@ -243,10 +265,10 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
 #pragma unroll
                 for (int row = 0; row < 4; ++row)
 #pragma unroll
-                  for (int col = row; col < 4; ++col) acc[q++] += w * J[row] * J[col];
+                  for (int col = row; col < 4; ++col) sum_add(q++, w * J[row] * J[col]);
                 const float wr = w * raw;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[30 + c] += wr * J[c];
+                for (int c = 0; c < 4; ++c) sum_add(30 + c, wr * J[c]);
               }
             }
           }
@@ -258,7 +280,7 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
   float mine = 0.f;
 #pragma unroll
   for (int q = 0; q < 34; ++q) {
-    const float v = wave_sum(acc[q]);
+    const float v = wave_sum(sum_value(q));
     if (lane == q) mine = v;
   }
   if (lane < 34 && mine != 0.f) unsafeAtomicAdd(&glob[lane], (double)mine);
