@@ -219,7 +219,8 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
   constexpr int kCount = kActivate ? 5 : 4;
   float sum[kCount];   // x, y, z, count [, count over kActive keyframes]
   tile_sums<kWaves, kCount, kMode>(sum, lds, [&](float (&acc)[kCount], int cls) {
-    for_each_candidate_cached(
+    struct Started { Projected p; PixelWords pix; };
+    for_each_candidate_pipelined<Started>(
         num_kfs,
         [&](int k) {
           float f[12];
@@ -227,9 +228,15 @@ __device__ __forceinline__ void normals_pass(const Intrinsics& in, const KfEntry
           load_candidate(kfs[k].pose.F, &kfs[k].activation, f, &activation);
           return activation != BAHIP_KF_INACTIVE && sphere_may_project(in, f, wb);
         },
-        [&](int k) {
-          const Projected p = project_surfel(in, kfs[k].pose.F, gp);
-          const PixelWords pix = load_pixel_words(in, kfs[k].geom, p);   // both gathers in flight at once (ba_device.h)
+        [&](int k) {   // candidate k + 1's gathers go out before candidate k's words are waited for (wave_cull.h)
+          Started st;
+          st.p = project_surfel(in, kfs[k].pose.F, gp);
+          st.pix = load_pixel_words(in, kfs[k].geom, st.p);   // both gathers in flight at once (ba_device.h)
+          return st;
+        },
+        [&](int k, const Started& st) {
+          const Projected& p = st.p;
+          const PixelWords& pix = st.pix;
           Assoc r;
           const bool associated = live && associate_from_words<false>(in, kfs[k].pose.F, gn, p, pix, &r, nullptr);
           gathers_arrived(pix);

@@ -212,6 +212,41 @@ __device__ __forceinline__ void for_each_candidate_cached(int num_items, Pred pr
   }
 }
 
+// Two-stage form of for_each_candidate_cached: issue(k) starts candidate k -- the projection and its gathers -- and returns its state,
+// consume(k, state) finishes it.  Within a chunk candidate k + 1 is issued BEFORE candidate k is consumed, so its gathers are in flight
+// while k's arithmetic runs (vmcnt retires in order: the wait in front of consume(k) leaves the younger loads outstanding).  For passes
+// whose per-candidate arithmetic is short against a gather's round trip (the normals pass: ~350 issue cycles per candidate, four
+// wavefronts per SIMD cover 0.6 us of a ~1 us round trip).  Candidates are consumed in the same ascending order: the same bits.
+template <typename State, typename Pred, typename Issue, typename Consume>
+__device__ __forceinline__ void for_each_candidate_pipelined(int num_items, Pred pred, Issue issue, Consume consume, int parts, int part,
+                                                             unsigned long long* masks, int max_masks, bool replay) {
+  const int lane = threadIdx.x & 63;
+  int chunk = 0;
+  for (int base = part; base < num_items; base += 64 * parts, ++chunk) {
+    unsigned long long m;
+    if (replay && chunk < max_masks) {
+      m = masks[chunk];                     // wave-uniform address
+    } else {
+      const int item = base + lane * parts;
+      const bool cand = (item < num_items) && pred(item);
+      m = __ballot(cand);
+      if (!replay && chunk < max_masks && lane == 0) masks[chunk] = m;
+    }
+    if (!m) continue;
+    int k = base + __builtin_ctzll(m) * parts;
+    m &= m - 1;
+    State state = issue(k);
+    while (m) {
+      const int next = base + __builtin_ctzll(m) * parts;
+      m &= m - 1;
+      State ahead = issue(next);
+      consume(k, state);
+      k = next;
+      state = ahead;
+    }
+    consume(k, state);
+  }
+}
 // Like for_each_candidate (one part), but stops as soon as body(k) returns true for the whole wavefront
 // (wave-uniform return value), e.g. "every lane has found what it was looking for".
 template <typename Pred, typename Body>
