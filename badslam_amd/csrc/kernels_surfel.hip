@@ -369,11 +369,21 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
   float tot[8];   // a0 a1 a2 a3 a5 a6 a7 a8 of B/kernel_opt_geometry.cu:119-230 (a4 = H12 is exactly 0)
   tile_sums<kWaves, 8, kPositionMode>(tot, lds, [&](float (&acc)[8], int cls) {
     float &a0 = acc[0], &a1 = acc[1], &a2 = acc[2], &a3 = acc[3], &a5 = acc[4], &a6 = acc[5], &a7 = acc[6], &a8 = acc[7];
-    for_each_candidate_cached(num_kfs, cand, [&](int k) {
+    // Two-stage candidate loop for the pixel word (wave_cull.h: for_each_candidate_pipelined): candidate k + 1 is projected and its
+    // geometry word requested before candidate k is worked on; the footprint gathers stay where they were, behind the start of the
+    // candidate's own turn (the state they would add -- six more registers -- spills).  One-wavefront form only: the four-wavefront
+    // form of small clouds has no registers left for the state either.
+    struct StartedPair { Projected p; PixelWords pix; };
+    auto start_pair = [&](int k) {
+      StartedPair st;
+      st.p = project_surfel(in, kfs[k].pose.F, gp);
+      st.pix = load_pixel_words(in, kfs[k].geom, st.p);
+      return st;
+    };
+    auto finish_pair = [&](int k, const StartedPair& st) {
       const float* F = kfs[k].pose.F;
-      // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
-      const Projected p = project_surfel(in, F, gp);
-      const PixelWords pix = load_pixel_words(in, kfs[k].geom, p);
+      const Projected& p = st.p;
+      const PixelWords& pix = st.pix;
       const DescWords dw = load_descriptor_words(in, kfs[k].lumafp, F, tp, p);
       Assoc r;
       const bool associated = live && associate_from_words<false>(in, F, gn, p, pix, &r, nullptr);
@@ -409,7 +419,13 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
         a5 += w2 * jd * jd;
         a8 += wr2 * jd;
       }
-    }, in.sum_classes, cls, masks ? masks + cls * kMaskChunks : nullptr, masks ? kMaskChunks : 0, masks != nullptr);
+    };
+    if (kWaves == 1)
+      for_each_candidate_pipelined<StartedPair>(num_kfs, cand, start_pair, finish_pair, in.sum_classes, cls, masks ? masks + cls * kMaskChunks : nullptr,
+                                                masks ? kMaskChunks : 0, masks != nullptr);
+    else
+      for_each_candidate_cached(num_kfs, cand, [&](int k) { finish_pair(k, start_pair(k)); }, in.sum_classes, cls,
+                                masks ? masks + cls * kMaskChunks : nullptr, masks ? kMaskChunks : 0, masks != nullptr);
   }, in.sum_classes, cpp, ii, in_range);
   if (kPhase == 2 || !live || !writer) return;
   const float a0 = tot[0], a1 = tot[1], a2 = tot[2], a3 = tot[3], a5 = tot[4], a6 = tot[5], a7 = tot[6], a8 = tot[7];
