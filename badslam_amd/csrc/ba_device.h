@@ -664,7 +664,9 @@ __device__ __forceinline__ void sample_luma_and_gradient(const Intrinsics& in, c
 // so they are not evaluated.  Same operations in the same order on the values that matter: identical results.
 __device__ __forceinline__ bool luma_sample_is_interior(int w, int h, float x, float y) {
   const float xb = x - 0.5f, yb = y - 0.5f;
-  return xb >= 0.f && xb < (float)w && yb >= 0.f && yb < (float)h;
+  // (bitwise on purpose: `&&` made the compiler guard each comparison by the one before it -- a save-exec and a branch per test, six
+  // of them per candidate for the three sample points -- where four compares and three scalar ANDs do)
+  return (bool)((int)(xb >= 0.f) & (int)(xb < (float)w) & (int)(yb >= 0.f) & (int)(yb < (float)h));
 }
 // The footprint word of the sample at (x, y), from coordinates clamped into the plane: the word the interior sampler uses
 // when the point is interior, some valid word otherwise (the caller then does not use it).  NaN coordinates clamp too.
@@ -740,7 +742,7 @@ __device__ __forceinline__ void eval_descriptor(const Intrinsics& in, const uint
   const int w = in.cwidth, h = in.cheight;
   if (kWithGradient) {
     float i0, i1, i2, cdx, cdy, adx, ady, bdx, bdy;
-    if (luma_sample_is_interior(w, h, cx, cy) && luma_sample_is_interior(w, h, t1x, t1y) && luma_sample_is_interior(w, h, t2x, t2y)) {
+    if ((int)luma_sample_is_interior(w, h, cx, cy) & (int)luma_sample_is_interior(w, h, t1x, t1y) & (int)luma_sample_is_interior(w, h, t2x, t2y)) {
       sample_luma_and_gradient_interior(luma_word_clamped(in, lumafp, cx, cy), cx, cy, &i0, &cdx, &cdy);
       sample_luma_and_gradient_interior(luma_word_clamped(in, lumafp, t1x, t1y), t1x, t1y, &i1, &adx, &ady);
       sample_luma_and_gradient_interior(luma_word_clamped(in, lumafp, t2x, t2y), t2x, t2y, &i2, &bdx, &bdy);
@@ -778,8 +780,8 @@ __device__ __forceinline__ DescWords load_descriptor_words(const Intrinsics& in,
   d.color_ok = depth_to_color_pixel(in, p.pxx, p.pxy, &d.cx, &d.cy);
   project_tangents(in, F, tp, &d.t1x, &d.t1y, &d.t2x, &d.t2y);
   const int w = in.cwidth, h = in.cheight;
-  d.interior = luma_sample_is_interior(w, h, d.cx, d.cy) && luma_sample_is_interior(w, h, d.t1x, d.t1y) &&
-               luma_sample_is_interior(w, h, d.t2x, d.t2y);
+  d.interior = (bool)((int)luma_sample_is_interior(w, h, d.cx, d.cy) & (int)luma_sample_is_interior(w, h, d.t1x, d.t1y) &
+                      (int)luma_sample_is_interior(w, h, d.t2x, d.t2y));
   d.w0 = luma_word_clamped(in, lumafp, d.cx, d.cy);
   d.w1 = luma_word_clamped(in, lumafp, d.t1x, d.t1y);
   d.w2 = luma_word_clamped(in, lumafp, d.t2x, d.t2y);
