@@ -791,14 +791,19 @@ __device__ __forceinline__ void eval_descriptor_from_words(const Intrinsics& in,
                                                            float d2, DescEval* e) {
   const int w = in.cwidth, h = in.cheight;
   float i0, i1, i2, cdx, cdy, adx, ady, bdx, bdy;
-  if (d.interior) {
-    sample_luma_and_gradient_interior(d.w0, d.cx, d.cy, &i0, &cdx, &cdy);
-    sample_luma_and_gradient_interior(d.w1, d.t1x, d.t1y, &i1, &adx, &ady);
-    sample_luma_and_gradient_interior(d.w2, d.t2x, d.t2y, &i2, &bdx, &bdy);
-  } else {
-    sample_luma_and_gradient(in, lumafp, w, h, d.cx, d.cy, &i0, &cdx, &cdy);
-    sample_luma_and_gradient(in, lumafp, w, h, d.t1x, d.t1y, &i1, &adx, &ady);
-    sample_luma_and_gradient(in, lumafp, w, h, d.t2x, d.t2y, &i2, &bdx, &bdy);
+  // The interior form for every lane -- the three words were loaded from clamped coordinates, so they are valid memory for any lane,
+  // and a lane whose footprints are not all inside the image computes values that are replaced below -- and then, behind a
+  // wave-uniform test that practically never fires, the border form for the lanes that need it.  (As an if / else per lane the three
+  // samples compiled into three diamonds with their save-exec pairs and nine register copies, on every candidate.)
+  sample_luma_and_gradient_interior(d.w0, d.cx, d.cy, &i0, &cdx, &cdy);
+  sample_luma_and_gradient_interior(d.w1, d.t1x, d.t1y, &i1, &adx, &ady);
+  sample_luma_and_gradient_interior(d.w2, d.t2x, d.t2y, &i2, &bdx, &bdy);
+  if (__builtin_amdgcn_ballot_w64(!d.interior) != 0ull) {
+    if (!d.interior) {
+      sample_luma_and_gradient(in, lumafp, w, h, d.cx, d.cy, &i0, &cdx, &cdy);
+      sample_luma_and_gradient(in, lumafp, w, h, d.t1x, d.t1y, &i1, &adx, &ady);
+      sample_luma_and_gradient(in, lumafp, w, h, d.t2x, d.t2y, &i2, &bdx, &bdy);
+    }
   }
   e->r1 = mad(180.f, i1 - i0, -d1);
   e->r2 = mad(180.f, i2 - i0, -d2);
