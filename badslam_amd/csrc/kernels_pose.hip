@@ -153,25 +153,6 @@ struct LdsSink {
       }
     }
     pending_item = -1;
-    return;
-    if (pending_item >= 0 && holds_total) {
-      const HbSplit v = hb_split(pending);
-      const uint32_t address = lane_offset + (uint32_t)pending_item * (uint32_t)(kHbStride * sizeof(HbFixed));
-      if (v.valid) {
-#ifdef BAHIP_LDS_ASM
-        if (v.lo) asm volatile("ds_add_u64 %0, %1" ::"v"(address), "v"(v.lo) : "memory");
-        if (v.hi) asm volatile("ds_add_u64 %0, %1 offset:8" ::"v"(address), "v"(v.hi) : "memory");
-#else
-        // the compiler's own LDS atomic (ds_add_u64 without return): tracked by its waitcnt pass, unlike an asm statement
-        auto* cell = reinterpret_cast<__attribute__((address_space(3))) HbFixed*>(address);
-        if (v.lo) __hip_atomic_fetch_add(cell, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (v.hi) __hip_atomic_fetch_add(cell + 1, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-      } else {
-        atomicOr(invalid, 1);
-      }
-    }
-    pending_item = -1;
   }
   __device__ __forceinline__ void gathers_done() { flush(); }
   __device__ __forceinline__ void add(int item, int /*w*/, float total) {
