@@ -220,7 +220,7 @@ void launch_create_append_fused(hipStream_t st, const Intrinsics& in, const KfEn
                                 const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded,
                                 uint32_t* group_words, uint32_t tag);
 size_t create_padded_count(const Intrinsics& in);   // length of the tile-major flag / index vectors
-void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags);
+void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags, bool leave_planes_empty = false);
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,
                           const float* covis_T_frame, int n_covis, int min_obs, uint8_t* flags);
 void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags,

@@ -330,9 +330,11 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
     bound.surfels_size = (uint32_t)std::min<uint64_t>(surfels->capacity, (uint64_t)surfels->surfels_size + (uint64_t)j * cells);
     const SurfelsView s = make_view(&bound);
     ctx->supporting_planes_empty = nullptr;
-    launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
+    // the planes are filled once per batch: every keyframe but the last leaves them empty behind its flag pass (one thread per cell reads
+    // the cell and resets it); after the last one they hold what a one-keyframe call leaves -- the lists and the claim marks
+    if (j == 0) launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
     launch_supporting_insert(st, ctx->in, e, s, sup, lifecycle_cull_for(ctx, surfels, e.pose.F), size_in);
-    launch_create_flag(st, ctx->in, e, sup, ctx->dev_flags);
+    launch_create_flag(st, ctx->in, e, sup, ctx->dev_flags, j + 1 < num_keyframes);
     const int n_covis = covis_offsets[j + 1] - covis_offsets[j];
     if (filter_new_surfels && n_covis > 0) {
       launch_create_filter(st, ctx->in, e, ctx->dev_kfs, ctx->dev_covis + covis_offsets[j], ctx->dev_covis_T + 12 * (size_t)covis_offsets[j], n_covis,

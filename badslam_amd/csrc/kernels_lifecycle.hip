@@ -204,7 +204,8 @@ __device__ __forceinline__ bool tile_xy(const Intrinsics& in, size_t seq, int* x
 
 // One thread per sparse cell: B/kernel_create_surfels.cu:41-75 with a deterministic winner.
 __global__ void __launch_bounds__(kLcBlock)
-create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __restrict__ flags /* tile-major, padded */) {
+create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __restrict__ flags /* tile-major, padded */,
+                   int leave_planes_empty /* a creation batch, not its last keyframe: the next keyframe needs no fill launch */) {
   const int cxy = blockIdx.x * kLcBlock + threadIdx.x;
   if (cxy >= in.cf_width * in.cf_height) return;
   const int cy = cxy / in.cf_width, cx = cxy - cy * in.cf_width;
@@ -224,7 +225,12 @@ create_flag_kernel(Intrinsics in, KfEntry frame, SupportingView sup, uint8_t* __
       flags[tile_seq(in, x, y)] = flag ? 1 : 0;
     }
   }
-  if (claimed) *slot = 0;
+  if (leave_planes_empty) {   // this thread is the only reader of its cell: it may as well empty it for the next keyframe of the batch
+#pragma unroll
+    for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) *pitched_ptr(sup.b[b], sup.pitch, cy, cx) = kInvalidIndex;
+  } else if (claimed) {
+    *slot = 0;
+  }
 }
 
 // B/kernel_create_surfels.cu:213-276 + :314-337: outlier filter for new surfels.
@@ -548,8 +554,8 @@ void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, co
   hipLaunchKernelGGL(merge_decide_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, cell_of, lb);
   hipLaunchKernelGGL(merge_apply_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, flags, cell_of, sup, empty_the_planes ? 1 : 0, deleted_count, lb);
 }
-void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags) {
-  hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags);
+void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags, bool leave_planes_empty) {
+  hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags, leave_planes_empty ? 1 : 0);
 }
 size_t create_padded_count(const Intrinsics& in) {
   const size_t tp = (size_t)in.create_tile;
