@@ -270,6 +270,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   if (ctx->pinned_i) hipHostFree(ctx->pinned_i);
   if (ctx->pinned_f) hipHostFree(ctx->pinned_f);
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
+  stage_free(&ctx->stage_kfs); stage_free(&ctx->stage_covis); stage_free(&ctx->stage_window);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_lifecycle_bounds); hipFree(ctx->dev_lifecycle_frames); hipFree(ctx->dev_lifecycle_cursors); hipFree(ctx->dev_lifecycle_lists); hipFree(ctx->dev_window);
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
@@ -323,7 +324,14 @@ int bahip_memset_2d(bahip_context* ctx, void* dst, size_t pitch, int value, size
 
 // ---- stream-level helpers for the host-side CUDABuffer<T> (no context needed) ------------------------
 int bahip_context_set_stream(bahip_context* ctx, void* hip_stream) {
-  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  hipStream_t next = static_cast<hipStream_t>(hip_stream);
+  if (next != ctx->stream) {
+    // the tables of the bound scene went out on the previous stream without a host wait (UploadStage): work on the new stream is
+    // ordered behind those copies
+    for (UploadStage* stage : {&ctx->stage_kfs, &ctx->stage_covis, &ctx->stage_window})
+      if (stage->pending && stage->done) HIP_TRY(hipStreamWaitEvent(next, stage->done, 0));
+  }
+  ctx->stream = next;
   return 0;
 }
 int bahip_stream_create(void** out) {
@@ -476,6 +484,36 @@ int bahip_frame_planes_update(bahip_context* ctx, bahip_frame_planes* planes, co
 
 void bahip_frame_planes_destroy(bahip_frame_planes* planes) { planes_free(planes); }
 
+}  // extern "C"
+int stage_upload(UploadStage* stage, void* dev_dst, const void* src, size_t bytes, hipStream_t stream, const void* src2, size_t bytes2, void* dev_dst2) {
+  if (stage->pending) {   // the previous upload through this stage still owns the buffer (it has normally completed long ago)
+    HIP_TRY(hipEventSynchronize(stage->done));
+    stage->pending = false;
+  }
+  const size_t total = bytes + bytes2;
+  if (total == 0) return 0;
+  if (total > stage->capacity) {
+    void* grown = nullptr;
+    HIP_TRY(hipHostMalloc(&grown, total + total / 4 + 4096));
+    if (stage->pinned) hipHostFree(stage->pinned);
+    stage->pinned = grown;
+    stage->capacity = total + total / 4 + 4096;
+  }
+  if (!stage->done) HIP_TRY(hipEventCreateWithFlags(&stage->done, hipEventDisableTiming));
+  char* p = static_cast<char*>(stage->pinned);
+  if (bytes) { memcpy(p, src, bytes); HIP_TRY(hipMemcpyAsync(dev_dst, p, bytes, hipMemcpyHostToDevice, stream)); }
+  if (bytes2) { memcpy(p + bytes, src2, bytes2); HIP_TRY(hipMemcpyAsync(dev_dst2, p + bytes, bytes2, hipMemcpyHostToDevice, stream)); }
+  HIP_TRY(hipEventRecord(stage->done, stream));
+  stage->pending = true;
+  return 0;
+}
+void stage_free(UploadStage* stage) {
+  if (stage->done) { hipEventSynchronize(stage->done); hipEventDestroy(stage->done); }
+  if (stage->pinned) hipHostFree(stage->pinned);
+  *stage = UploadStage{};
+}
+extern "C" {
+
 int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int num_keyframes) {
   REQUIRE(num_keyframes >= 0, "negative keyframe count");
   ctx->host_kfs.resize(num_keyframes);
@@ -494,10 +532,8 @@ int bahip_set_keyframes(bahip_context* ctx, const bahip_keyframe* keyframes, int
   ctx->num_kfs = num_keyframes;
   ctx->have_covisibility = false;   // lists refer to the previous binding
   ctx->window.clear();
-  if (num_keyframes > 0) {
-    HIP_TRY(hipMemcpyAsync(ctx->dev_kfs, ctx->host_kfs.data(), sizeof(KfEntry) * num_keyframes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // host_kfs is pageable
-  }
+  // (through a page-locked stage of the context: no host wait; everything that reads the table is ordered behind the copy on this stream)
+  if (num_keyframes > 0 && stage_upload(&ctx->stage_kfs, ctx->dev_kfs, ctx->host_kfs.data(), sizeof(KfEntry) * num_keyframes, ctx->stream)) return 1;
   return 0;
 }
 

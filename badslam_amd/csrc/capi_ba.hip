@@ -621,9 +621,8 @@ int bahip_set_covisibility(bahip_context* ctx, const int* offsets, const int* in
     ctx->dev_covis_csr = grown;
     ctx->covis_csr_capacity = need + 1024;
   }
-  HIP_TRY(hipMemcpyAsync(ctx->dev_covis_csr, ctx->covis_offsets.data(), sizeof(int) * (K + 1), hipMemcpyHostToDevice, ctx->stream));
-  if (total) HIP_TRY(hipMemcpyAsync(ctx->dev_covis_csr + K + 1, ctx->covis_indices.data(), sizeof(int) * total, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));   // the vectors are pageable
+  if (stage_upload(&ctx->stage_covis, ctx->dev_covis_csr, ctx->covis_offsets.data(), sizeof(int) * (size_t)(K + 1), ctx->stream,
+                   ctx->covis_indices.data(), sizeof(int) * (size_t)total, ctx->dev_covis_csr + K + 1)) return 1;   // (no host wait: capi_internal.h)
   ctx->have_covisibility = true;
   return 0;
 }
@@ -638,10 +637,7 @@ int bahip_set_activation_window(bahip_context* ctx, const uint8_t* in_window, in
     ctx->dev_window = grown;
     ctx->window_capacity = (size_t)num_keyframes + 256;
   }
-  if (num_keyframes) {
-    HIP_TRY(hipMemcpyAsync(ctx->dev_window, ctx->window.data(), num_keyframes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-  }
+  if (num_keyframes && stage_upload(&ctx->stage_window, ctx->dev_window, ctx->window.data(), (size_t)num_keyframes, ctx->stream)) return 1;
   return 0;
 }
 

@@ -70,7 +70,21 @@ struct bahip_frame_planes {
   int width = 0, height = 0, cwidth = 0, cheight = 0;
 };
 
+// A small host-to-device upload without a host wait: the bytes are copied into a page-locked buffer the context owns and go out with
+// hipMemcpyAsync; the event says when the buffer may be overwritten (checked -- normally long over -- by the next upload through the
+// same stage).  Scene binding used to synchronise the stream three times per BundleAdjustment call for its three tables.
+struct UploadStage {
+  void* pinned = nullptr;
+  size_t capacity = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+int stage_upload(UploadStage* stage, void* dev_dst, const void* src, size_t bytes, hipStream_t stream,
+                 const void* src2 = nullptr, size_t bytes2 = 0, void* dev_dst2 = nullptr);
+void stage_free(UploadStage* stage);
+
 struct bahip_context {
+  UploadStage stage_kfs, stage_covis, stage_window;
   hipStream_t stream = nullptr;
   bool have_intrinsics = false;
   bahip_camera color_cam{}, depth_cam{};
