@@ -444,7 +444,7 @@ def main():
         return int(n.value)
 
     # THE TIMED REGION: exactly `steps` iterations, no measurement code in it (round 5 measured what the hipEvent pairs round 4 kept
-    # inside it cost: 5 % -- every record is a barrier packet between two launches of the device-driven loop).
+    # inside it cost: 0.8-0.9 % in alternating runs -- every record is a barrier packet between two launches of the device-driven loop).
     capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
     capi.check(ctx.lib.bahip_exchange_stats(ctx.handle, None, None, 1))
     ctx.synchronize()
@@ -540,7 +540,7 @@ def main():
                                              "traffic": intr_traffic["bytes"] if intr_traffic else None,
                                              "traffic_source": intr_traffic["source"] if intr_traffic else None,
                                              "record_reduction_traffic": reduce_traffic["bytes"] if reduce_traffic else None,
-                                             "limiter": "instruction issue (the sweep carries 34 per-lane sums: 168 VGPRs, 3 wavefronts per SIMD) and the "
+                                             "limiter": "instruction issue (1.3 x the pose sweep's VALU work; 24 of its 34 per-lane sums live in LDS: 127 VGPRs, 4 wavefronts per SIMD) and the "
                                                         "32-byte record it writes per associated pair with a depth residual (read back by the second "
                                                         "kernel, which sorts the records of a chunk by cell in LDS and adds them from registers)"}
             cc, dc, _a = ba.cameras()
