@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.environ.get("BADSLAM_LIB_DIR") or os.path.join(_HERE,
 SURFEL_ATTRIBUTE_COUNT = 17
 MERGE_BUFFER_COUNT = 3
 KF_ACTIVE, KF_COVISIBLE_ACTIVE, KF_INACTIVE = 0, 1, 2
+ARITHMETIC_EXACT, ARITHMETIC_FAST = 0, 1   # bahip_context_set_arithmetic
 
 # surfel rows, applications/badslam/src/badslam/kernels.cuh:69-88
 SURFEL_X, SURFEL_Y, SURFEL_Z, SURFEL_NORMAL, SURFEL_RADIUS_SQUARED, SURFEL_COLOR, SURFEL_DESCRIPTOR1, SURFEL_DESCRIPTOR2 = range(8)
@@ -89,6 +90,8 @@ SIGNATURES = {
     "bahip_context_set_keyframe_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bahip_context_set_sum_classes": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_context_set_creation_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "bahip_context_set_arithmetic": (C.c_int, [C.c_void_p, C.c_int]),
+    "bahip_context_get_arithmetic": (C.c_int, [C.c_void_p]),
     "bahip_debug_set_tile_order": (C.c_int, [C.c_int]),
     "bahip_debug_read_tile_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     "bahip_rccl_get_unique_id": (C.c_int, [C.c_char_p]),
@@ -183,6 +186,7 @@ SIGNATURES = {
     "bahip_debug_count_pairs": (C.c_int, [C.c_void_p, C.POINTER(Surfels), C.POINTER(C.c_uint64)]),
     "bahip_debug_set_launch_shapes": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_pose_form": (C.c_int, [C.c_int]),
+    "bahip_debug_set_append_groups": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_items": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_shape": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_fused_iteration_begin": (C.c_int, [C.c_int]),

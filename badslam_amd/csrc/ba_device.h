@@ -65,6 +65,9 @@ __device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b) {
 // ops, selects, v_med3 / v_min3, DPP forms and anything with an SGPR source 2.6 - 2.8, v_rcp / v_sqrt / v_permlane*_swap 5.1 -- and
 // which respellings pay on the sweeps: see DESIGN.md section 5, "Round 5".)
 __device__ __forceinline__ float rcp_exact(float x) {
+#ifdef BAHIP_FAST_MATH
+  return __builtin_amdgcn_rcpf(x);   // fast flavour: the hardware approximation (<= 1 ulp), what nvcc -use_fast_math gives the reference
+#endif
   const float y0 = __builtin_amdgcn_rcpf(x);
   const float e = __builtin_fmaf(-x, y0, 1.f);
   const float y1 = __builtin_fmaf(e, y0, y0);
@@ -74,6 +77,9 @@ __device__ __forceinline__ float rcp_exact(float x) {
 }
 // x in [2^-96, 2^127) or 0 (the range in which the compiler's sequence does not rescale).
 __device__ __forceinline__ float sqrt_exact(float x) {
+#ifdef BAHIP_FAST_MATH
+  return __builtin_amdgcn_sqrtf(x);   // fast flavour: v_sqrt_f32 (<= 1 ulp)
+#endif
   const float s = __builtin_amdgcn_sqrtf(x);
   const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
   const float r_dn = __builtin_fmaf(-dn, s, x);
@@ -91,6 +97,9 @@ __device__ __forceinline__ float sqrt_exact(float x) {
 // value (the reference's own expf is CUDA's, documented at 2 ulp); 14 instructions, no binary64 (a binary64 evaluation made the
 // geometry sweep spill).
 __device__ __forceinline__ float exp_det(float xf) {
+#ifdef BAHIP_FAST_MATH
+  return __builtin_amdgcn_exp2f(xf * 1.44269504f);   // fast flavour: v_exp_f32, as __expf
+#endif
   if (!(xf == xf)) return xf;
   if (xf > 100.f) return __builtin_inff();
   if (xf < -110.f) return 0.f;
@@ -322,6 +331,9 @@ struct Intrinsics {
   // surfels of a wavefront form a compact patch) or, for the reference's row-major append order, a side that covers the whole image
   // (bahip_context_set_creation_order)
   int create_tile;
+  // Arithmetic flavour of the sweeps (bahip_context_set_arithmetic; ba_launch.h: "Two arithmetic flavours"): 0 = the exact flavour that
+  // shares every bit with the oracle, 1 = the fast flavour.  Read by the host-side dispatchers only; the kernels ignore it.
+  int fast_math;
 };
 
 struct SurfelsView {

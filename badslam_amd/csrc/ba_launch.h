@@ -14,6 +14,29 @@ inline int bahip_env_int(const char* name, int fallback) {
   return e ? std::atoi(e) : fallback;
 }
 
+// ---- Two arithmetic flavours of the sweeps ----------------------------------------------------------------------------------------
+// The sweeps over (surfel, keyframe) pairs -- activation, normals / geometry step, pose normal equations, intrinsics sweep, the PCG
+// init and step-1 sweeps -- exist twice in the library, compiled from the same source:
+//   exact  IEEE reciprocal / square root / division in few instructions (ba_device.h: rcp_exact, sqrt_exact), defined exp / sin / cos,
+//          no contraction beyond the spelled fused multiply-adds: every bit is the oracle's (the checker's flavour, and the default);
+//   fast   the hardware's v_rcp_f32 / v_sqrt_f32 / v_exp_f32 (<= 1 ulp), contraction at the compiler's discretion, denormals flushed
+//          -- the arithmetic the reference itself ships with (B/../CMakeLists.txt:74: nvcc -use_fast_math), held to the reference's
+//          kernels by tolerance (tests/test_gpu_fast_flavour.py), selected per context by bahip_context_set_arithmetic.
+// What does NOT change with the flavour: the order of every sum (fixed trees, fixed-point pose sums, exact PCG sums, binary64
+// intrinsics accumulation), so the fast flavour is as deterministic and as shard-invariant as the exact one; the rejection order of the
+// association tests; preprocessing, lifecycle, the pose solve and the PCG vector kernels (compiled once, exact).
+// Mechanics: a kernel translation unit wraps its sweeps in BAHIP_FLAVOURED_BEGIN / _END (namespace bahip::exact or bahip::fast); it
+// is compiled once per flavour (Makefile: *_fast.o with -DBAHIP_FAST_MATH and the device-side flags); everything else in the unit
+// sits under #ifndef BAHIP_FAST_MATH in plain bahip::, including the dispatchers that carry the public names below and pick the
+// flavour from Intrinsics::fast_math.
+#ifdef BAHIP_FAST_MATH
+#define BAHIP_FLAVOUR fast
+#else
+#define BAHIP_FLAVOUR exact
+#endif
+#define BAHIP_FLAVOURED_BEGIN namespace bahip { namespace BAHIP_FLAVOUR {
+#define BAHIP_FLAVOURED_END } }
+
 namespace bahip {
 
 struct SupportingView {
@@ -216,6 +239,7 @@ void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, co
 // a creation batch: scan + append at *size_in + the new size into *size_out (or *capacity_exceeded raised and nothing appended) in one
 // launch; group_words: create_append_groups() words, cleared before tag 1 and whenever a tag (1 .. 255) would repeat
 int create_append_groups();
+void set_append_groups_limit(int groups);   // test hook: the fused append's grid as on a device that holds at most `groups` of its workgroups (0: ask the device)
 void launch_create_append_fused(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const SurfelsView& s,
                                 const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded,
                                 uint32_t* group_words, uint32_t tag);
@@ -235,5 +259,50 @@ hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, c
 hipError_t scan_u32_exclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n);
 hipError_t launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invalid, uint32_t* free_rank, uint32_t* free_list,
                           uint32_t surfel_count, void* temp, size_t temp_bytes);
+
+
+// The flavoured launchers (same parameters as the public names above, no defaults: only the dispatchers call them) and the test
+// hooks / counters that live with them, declared in both flavour namespaces.
+#define BAHIP_FLAVOURED_DECLARATIONS                                                                                                          \
+  /* kernels_surfel.hip */                                                                                                                    \
+  void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s, uint32_t surfels_size); \
+  void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s);                       \
+  void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs, int num_kfs,              \
+                       const SurfelsView& s, long long activate_count, const uint32_t* sched, const int* stop);                              \
+  void launch_geometry_phase(hipStream_t stream, int phase, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,          \
+                             int num_kfs, const SurfelsView& s, long long activate_count, const ClassPartials& cpn, const ClassPartials& cpp); \
+  void launch_activation_hits(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,                \
+                              uint32_t surfels_size, int kf_rank, int kf_world, uint32_t* hits);                                              \
+  void set_tile_waves(int waves);                                                                                                             \
+  /* kernels_pose.hip */                                                                                                                      \
+  void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,                 \
+                              const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,       \
+                              int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched,         \
+                              const int* listed_count, const int* stop);                                                                      \
+  bool pose_round_can_be_queued_ahead(uint32_t surfels, int num_items, bool have_tile_counters);                                              \
+  void set_pose_lds_waves(int waves);                                                                                                         \
+  void set_pose_lds_parts_shift(int shift);                                                                                                   \
+  void set_pose_lds_items(int items);                                                                                                         \
+  long long pose_kernel_dispatches();                                                                                                         \
+  void pose_form_launches(long long out[2], bool reset);                                                                                      \
+  void set_pose_form(int form);                                                                                                               \
+  void set_pose_parts(int parts);                                                                                                             \
+  void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const uint32_t* indices,   \
+                             int count, float* out);                                                                                          \
+  /* kernels_intrinsics.hip */                                                                                                                \
+  void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,            \
+                                    const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched,           \
+                                    uint32_t position_begin, uint32_t position_count);                                                        \
+  /* kernels_pcg.hip */                                                                                                                       \
+  void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,         \
+                       const SurfelsView& s, float* r, float* M, uint32_t* tile_cost, const uint32_t* sched);                                 \
+  void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,        \
+                        const SurfelsView& s, const float* p, float* g, const void* ctl, const uint32_t* sched, uint32_t* tile_counters,      \
+                        int* parity_inout);                                                                                                   \
+  void set_pcg_lds_form(int mode);                                                                                                            \
+  void pcg_step1_form_launches(long long out[2]);
+namespace exact { BAHIP_FLAVOURED_DECLARATIONS }
+namespace fast { BAHIP_FLAVOURED_DECLARATIONS }
+#define BAHIP_PICK(in, call) do { if ((in).fast_math) fast::call; else exact::call; } while (0)
 
 }  // namespace bahip

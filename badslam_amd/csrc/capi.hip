@@ -233,6 +233,8 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   REQUIRE(n > 0, "bahip_context_create: no HIP device (the HIP backend has no CPU fallback)");
   bahip_context* ctx = new bahip_context();
   ctx->stream = static_cast<hipStream_t>(hip_stream);
+  if (const char* e = getenv("BAHIP_ARITHMETIC")) ctx->arithmetic = (strcmp(e, "fast") == 0 || strcmp(e, "1") == 0) ? BAHIP_ARITHMETIC_FAST : BAHIP_ARITHMETIC_EXACT;
+  ctx->in.fast_math = ctx->arithmetic;
   if (const char* e = getenv("BAHIP_INTR_SLICES")) ctx->intr_slices_forced = std::min(std::max(atoi(e), 0), 8);   // experiments: slices of the intrinsics sweep
   const bool ok = hipMalloc(&ctx->dev_counter, 16 * sizeof(int)) == hipSuccess && hipMemset(ctx->dev_counter, 0, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)) == hipSuccess &&
@@ -448,10 +450,20 @@ int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, c
   ctx->color_cam = *color_camera; ctx->depth_cam = *depth_camera; ctx->dp = *dp;
   ctx->in = make_intrinsics(*color_camera, *depth_camera, *dp);
   ctx->in.sum_classes = ctx->sum_classes;
+  ctx->in.fast_math = ctx->arithmetic;
   if (ctx->row_major_creation) ctx->in.create_tile = std::max(ctx->in.width, ctx->in.height);
   ctx->have_intrinsics = true;
   return 0;
 }
+
+int bahip_context_set_arithmetic(bahip_context* ctx, int arithmetic) {
+  REQUIRE(ctx != nullptr, "bahip_context_set_arithmetic: NULL context");
+  REQUIRE(arithmetic == BAHIP_ARITHMETIC_EXACT || arithmetic == BAHIP_ARITHMETIC_FAST, "bahip_context_set_arithmetic: BAHIP_ARITHMETIC_EXACT or BAHIP_ARITHMETIC_FAST");
+  ctx->arithmetic = arithmetic;
+  ctx->in.fast_math = arithmetic;
+  return 0;
+}
+int bahip_context_get_arithmetic(bahip_context* ctx) { return ctx ? ctx->arithmetic : -1; }
 
 int bahip_context_set_creation_order(bahip_context* ctx, int row_major) {
   ctx->row_major_creation = row_major != 0;

@@ -106,6 +106,12 @@ int bahip_debug_set_tile_order(int enabled) {
   return 0;
 }
 
+int bahip_debug_set_append_groups(int groups) {
+  REQUIRE(groups >= 0, "bahip_debug_set_append_groups: groups must be >= 0");
+  set_append_groups_limit(groups);
+  return 0;
+}
+
 int bahip_debug_set_pose_form(int form) {
   REQUIRE(form == 0 || form == 1 || form == 2, "pose form must be 0 (automatic), 1 (one tile per wavefront, global atomics) or 2 (persistent, LDS table)");
   set_pose_form(form);

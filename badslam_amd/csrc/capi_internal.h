@@ -186,6 +186,7 @@ struct bahip_context {
   int pcg_stage_step1_calls = 0;
   int world = 0;                   // ranks of the RCCL communicator (0 = none)
   int kf_rank = 0, kf_world = 1;   // keyframe sharding (bahip_context_set_keyframe_sharding): keyframe k lives on rank k % kf_world (1, 2, 4 or 8)
+  int arithmetic = 0;              // BAHIP_ARITHMETIC_EXACT / _FAST: flavour of the sweeps (bahip_context_set_arithmetic), mirrored in in.fast_math
   int sum_classes = 4;             // interleaved partial sums per surfel of the normals / geometry passes: 4 or 8 (bahip_context_set_sum_classes)
   float* kf_partials = nullptr;    // class partials of the geometry step (normals, then position) / hit words of the activation
   size_t kf_partials_capacity = 0; // floats

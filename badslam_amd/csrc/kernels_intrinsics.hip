@@ -90,6 +90,10 @@ constexpr int kIntrRegSums = 34 - kIntrLdsSums;
 #ifndef BAHIP_INTR_WAVES_PER_EU
 #define BAHIP_INTR_WAVES_PER_EU (BAHIP_INTR_LDS_SUMS >= 24 ? 4 : 3)   // all 34 sums in registers: 151 VGPRs (at 4 waves: 57 spills)
 #endif
+}  // namespace bahip
+
+// ---- the sweep: compiled once per arithmetic flavour (ba_launch.h) ----------------------------------------------------------------
+BAHIP_FLAVOURED_BEGIN
 template <bool kDepth, bool kColor>
 __global__ void __launch_bounds__(kIntrSweepBlock) __attribute__((amdgpu_waves_per_eu(BAHIP_INTR_WAVES_PER_EU)))
 intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s,
@@ -284,6 +288,30 @@ intrinsics_accumulate_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int
     if (lane == q) mine = v;
   }
   if (lane < 34 && mine != 0.f) unsafeAtomicAdd(&glob[lane], (double)mine);
+}
+
+// positions [position_begin, position_begin + position_count) of the sweep's schedule (position_count == 0: all of them)
+void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched,
+                                  uint32_t position_begin, uint32_t position_count) {
+  if (!s.size) return;
+  const uint32_t padded = xcd_padded_tiles((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock), positions = sched_positions(padded, sched);
+  if (position_begin >= positions) return;
+  const uint32_t count = position_count ? std::min(position_count, positions - position_begin) : positions - position_begin;
+  const dim3 grid(count), block(kIntrSweepBlock);
+  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
+  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
+  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
+}
+BAHIP_FLAVOURED_END
+
+// ---- what exists once (the exact unit): record reduction, Schur complement, back-substitution, the dispatcher ---------------------
+#ifndef BAHIP_FAST_MATH
+namespace bahip {
+void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched,
+                                  uint32_t position_begin, uint32_t position_count) {
+  BAHIP_PICK(in, launch_intrinsics_accumulate(st, depth, color, in, kfs, num_kfs, s, glob, cells, bins, sched, position_begin, position_count));
 }
 
 // The records of one slice of one block's append buffer, added into a table in LDS and from there into the global per-cell
@@ -558,19 +586,6 @@ int intrinsics_bin_count(const Intrinsics& in, int* bins_x_out) {
   return bins_x * bins_y * kBinSubs;   // append buffers
 }
 size_t intrinsics_bin_record_bytes() { return kCellFloats * sizeof(uint32_t); }
-// positions [position_begin, position_begin + position_count) of the sweep's schedule (position_count == 0: all of them)
-void launch_intrinsics_accumulate(hipStream_t st, bool depth, bool color, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
-                                  const SurfelsView& s, double* glob, double* cells, const IntrBins& bins, const uint32_t* sched,
-                                  uint32_t position_begin, uint32_t position_count) {
-  if (!s.size) return;
-  const uint32_t padded = xcd_padded_tiles((s.size + kIntrSweepBlock - 1) / kIntrSweepBlock), positions = sched_positions(padded, sched);
-  if (position_begin >= positions) return;
-  const uint32_t count = position_count ? std::min(position_count, positions - position_begin) : positions - position_begin;
-  const dim3 grid(count), block(kIntrSweepBlock);
-  if (depth && color) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
-  else if (depth) hipLaunchKernelGGL((intrinsics_accumulate_kernel<true, false>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
-  else hipLaunchKernelGGL((intrinsics_accumulate_kernel<false, true>), grid, block, 0, st, in, kfs, num_kfs, s, glob, cells, bins, sched, padded, position_begin);
-}
 uint32_t intrinsics_sweep_positions(uint32_t surfels, const uint32_t* sched) {
   return sched_positions(xcd_padded_tiles((surfels + kIntrSweepBlock - 1) / kIntrSweepBlock), sched);
 }
@@ -620,3 +635,4 @@ void launch_intrinsics_solve_cells(hipStream_t st, const Intrinsics& in, int S, 
 }
 
 }  // namespace bahip
+#endif   // !BAHIP_FAST_MATH

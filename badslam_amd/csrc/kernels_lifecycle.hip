@@ -573,13 +573,29 @@ void launch_create_append(hipStream_t st, const Intrinsics& in, const KfEntry& f
   hipLaunchKernelGGL(create_append_kernel, dim3(g1(padded)), dim3(kLcBlock), 0, st, in, frame, flags, indices, padded, surfels_size, s);
 }
 int create_append_groups() { return kAppendGroups; }
+static int g_append_groups_limit = 0;   // test hook: as if the device held at most that many workgroups of the kernel (0: what it holds)
+void set_append_groups_limit(int groups) { g_append_groups_limit = groups > 0 ? groups : 0; }
 // group_words: kAppendGroups words, cleared once per batch; tag: the keyframe's number in the batch + 1 (1 .. 255; the caller clears the
 // words again before a tag repeats)
 void launch_create_append_fused(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const uint8_t* flags, const SurfelsView& s,
                                 const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded,
                                 uint32_t* group_words, uint32_t tag) {
   const int padded = (int)create_padded_count(in);
-  const int groups = std::min(kAppendGroups, (int)g1(padded));
+  // The kernel's grid handshake (every workgroup waits for every other's tagged word) ends only if ALL workgroups of the launch are
+  // resident at once, which a plain launch does not promise: the grid is therefore clamped to what the device the stream
+  // runs on can hold of this kernel -- occupancy per compute unit x compute units, asked once per device; a partition mode with 38
+  // CUs, a CU mask or a build whose register use lowers the occupancy then gets fewer, longer slices (per_group adapts to gridDim).
+  static int resident_limit[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (resident_limit[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, create_append_fused_kernel, kLcBlock, 0) != hipSuccess || per_cu < 1) { per_cu = 1; (void)hipGetLastError(); }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { cus = 1; (void)hipGetLastError(); }
+    resident_limit[dev] = std::max(1, per_cu * cus);
+  }
+  const int limit = g_append_groups_limit > 0 ? std::min(g_append_groups_limit, resident_limit[dev]) : resident_limit[dev];
+  const int groups = std::min(std::min(kAppendGroups, limit), (int)g1(padded));
   hipLaunchKernelGGL(create_append_fused_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, flags, padded, s, size_in, size_out, capacity,
                      capacity_exceeded, group_words, tag);
 }

@@ -86,6 +86,10 @@ __device__ __forceinline__ double fold_hot(const PcgExact& ex, int a, int b, boo
   return exact_value(l);
 }
 
+}  // namespace bahip
+
+// ---- the sweeps (PCGInit, PCGStep1): compiled once per arithmetic flavour (ba_launch.h) ----
+BAHIP_FLAVOURED_BEGIN
 // Terms of one associated pair (B/kernel_pcg.cu:213-303,334-395 and :663-748,786-905).
 struct PairTerms {
   float raw, w, Jgeom;
@@ -323,6 +327,8 @@ pcg_init_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __restri
   }
 }
 
+BAHIP_FLAVOURED_END
+namespace bahip {
 // ---- inner-loop control on the device -------------------------------------------------------------------------------------
 // The reference reads beta_n back after every inner step and decides on the host whether the residual norm still improves
 // (B/direct_ba_pcg.cc:427-456: stop after three steps without an improvement of 1e-3).  Here a one-wavefront kernel resolves
@@ -336,8 +342,22 @@ struct PcgControl {
   int pad;
 };
 static_assert(sizeof(PcgControl) == 24, "PcgControl lives behind the scalars of the PCG buffer");
+}  // namespace bahip
+#ifndef BAHIP_FAST_MATH   // exists once (the exact unit)
+namespace bahip {
+// The sticky flag travels in exchange 2 as a 64-bit integer sum: after an exchange it holds (ranks that raised it) x (what it held
+// before), and a host that keeps queuing exchanges for the rest of a step group after the device has stopped would multiply it by the
+// world size every time -- at 64 ranks the low 32 bits, which is all the readers look at, wrap to 0 after six exchanges.
+// Every control step therefore puts it back to 0 / 1, stopped or not.
+__device__ __forceinline__ void pcg_renormalise_invalid(const PcgExact& ex) {
+  if (threadIdx.x == 0) {
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(ex.invalid);
+    if (*flag != 0ull) *flag = 1ull;
+  }
+}
 // after PCGInit2: alpha_n = the exact dot product, rounded; the control block starts over
 __global__ void __launch_bounds__(64) pcg_control_init_kernel(PcgExact ex, PcgControl* ctl, float* alpha_n) {
+  pcg_renormalise_invalid(ex);
   const double v = fold_hot(ex, kHotDotLocal, kHotDotHead, true);
   if (threadIdx.x == 0) {
     *alpha_n = (*ex.invalid) ? __builtin_nanf("") : (float)v;
@@ -347,6 +367,7 @@ __global__ void __launch_bounds__(64) pcg_control_init_kernel(PcgExact ex, PcgCo
 // after PCGStep2: beta_n, then the stopping rule.  r_norm is a PCGScalar (binary32 square root), the comparison is evaluated
 // in double like the reference's `r_norm < prev_r_norm - 1e-3` (B/direct_ba_pcg.cc:441-446).
 __global__ void __launch_bounds__(64) pcg_control_kernel(PcgExact ex, PcgControl* ctl, float* beta_n) {
+  pcg_renormalise_invalid(ex);
   if (ctl->stop) return;
   const double v = fold_hot(ex, kHotDotLocal, kHotDotHead, true);
   if (threadIdx.x == 0) {
@@ -467,6 +488,9 @@ pcg_init2_kernel(PcgLayout L, PcgExact ex, float a, const float* __restrict__ r_
   block_exact_flush(acc, ex, slots);
 }
 
+}  // namespace bahip
+#endif
+BAHIP_FLAVOURED_BEGIN
 // ---- PCGStep1: g += J^T W J p, alpha_d += p^T J^T W J p  (B/kernel_pcg.cu:646-1026) -------------------
 // Where the (tile, keyframe) totals of the dense head go: straight to the exact accumulators in global memory (two 64-bit integer
 // atomics per total, issued one candidate late), or into a copy of the pose block of the head that a persistent workgroup keeps
@@ -724,6 +748,9 @@ pcg_step1_lds_kernel(PcgLayout L, PcgExact ex, Intrinsics in, const KfEntry* __r
   }
 }
 
+BAHIP_FLAVOURED_END
+#ifndef BAHIP_FAST_MATH   // exists once (the exact unit)
+namespace bahip {
 // PCGStep2 (B/kernel_pcg.cu:1117-1158)
 __global__ void __launch_bounds__(kPcgBlock)
 pcg_step2_kernel(PcgLayout L, PcgExact ex, float* __restrict__ r_, const float* __restrict__ M_, float* __restrict__ delta,
@@ -839,6 +866,9 @@ void launch_exact_sum_debug(hipStream_t st, const PcgExact& ex, const float* val
   hipLaunchKernelGGL(exact_sum_debug_resolve_kernel, dim3(1), dim3(64), 0, st, ex, out);
 }
 
+}  // namespace bahip
+#endif
+namespace bahip {
 // ---- launchers -----------------------------------------------------------------------------------------------
 static inline unsigned gU(uint32_t n) { return (n + kPcgBlock - 1) / kPcgBlock; }
 // The per-unknown kernels run a grid-stride loop over at most kPcgReduceBlocks workgroups: each ends in 9 atomics per sum.
@@ -848,6 +878,9 @@ static inline unsigned gR(uint32_t n) { return gU(n) < kPcgReduceBlocks ? gU(n) 
 // whole XCD chunks, as in kernels_surfel.hip (xcd_chunked_tile)
 static inline unsigned gS(uint32_t n) { return xcd_padded_tiles((n + kPcgSweepBlock - 1) / kPcgSweepBlock); }
 
+}  // namespace bahip
+#ifndef BAHIP_FAST_MATH   // exists once (the exact unit)
+namespace bahip {
 size_t pcg_exact_cells(uint32_t head_count) { return (size_t)kHotSlots * kHotReplicas + 2 * (size_t)head_count + 1; }
 PcgExact pcg_exact_view(void* buffer, uint32_t head_count) {
   PcgExact ex;
@@ -860,6 +893,9 @@ PcgExact pcg_exact_view(void* buffer, uint32_t head_count) {
   return ex;
 }
 
+}  // namespace bahip
+#endif
+BAHIP_FLAVOURED_BEGIN
 void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
                      const SurfelsView& s, float* r, float* M, uint32_t* tile_cost, const uint32_t* sched) {
   if (!s.size) return;
@@ -870,6 +906,9 @@ void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, con
   else if (ci) hipLaunchKernelGGL((pcg_init_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M, tile_cost, sched);
   else hipLaunchKernelGGL((pcg_init_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, r, M, tile_cost, sched);
 }
+BAHIP_FLAVOURED_END
+#ifndef BAHIP_FAST_MATH   // exists once (the exact unit)
+namespace bahip {
 static inline unsigned resolve_grid(const PcgLayout& L) { return gU(L.head_lo + (L.unknown_count - L.head_hi)) + 1; }
 void launch_pcg_resolve_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, float* r, float* M) {
   hipLaunchKernelGGL((pcg_resolve_kernel<true>), dim3(resolve_grid(L)), dim3(kPcgBlock), 0, st, L, ex, r, M, nullptr, 0.0, nullptr);
@@ -890,6 +929,9 @@ void launch_pcg_control(hipStream_t st, const PcgExact& ex, void* ctl, float* be
 }
 size_t pcg_control_bytes() { return sizeof(PcgControl); }
 
+}  // namespace bahip
+#endif
+BAHIP_FLAVOURED_BEGIN
 static int g_pcg_lds_form = bahip_env_int("BAHIP_PCG_LDS", 1);   // 0: always the one-tile-per-wavefront form
 void set_pcg_lds_form(int mode) { g_pcg_lds_form = (mode >= 0 && mode <= 2) ? mode : 1; }   // 2: also on grids that do not fill the chip (tests)
 constexpr size_t kPcgLdsTableLimit = 128 * 1024;
@@ -951,6 +993,9 @@ void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, co
   else if (ci) hipLaunchKernelGGL((pcg_step1_kernel<false, true>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
   else hipLaunchKernelGGL((pcg_step1_kernel<false, false>), grid, block, 0, st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched);
 }
+BAHIP_FLAVOURED_END
+#ifndef BAHIP_FAST_MATH   // exists once (the exact unit)
+namespace bahip {
 void launch_pcg_eps_terms(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const float* p) {
   if (L.unknown_count) hipLaunchKernelGGL(pcg_eps_terms_kernel, dim3(gR(L.unknown_count)), dim3(kPcgBlock), 0, st, L, ex, p);
 }
@@ -971,4 +1016,22 @@ void launch_pcg_update_cfactors(hipStream_t st, const Intrinsics& in, uint32_t s
   hipLaunchKernelGGL(pcg_update_cfactors_kernel, dim3(gU(in.cf_width * in.cf_height)), dim3(kPcgBlock), 0, st, in, start, delta, cfactor, pitch);
 }
 
+
+// dispatchers (ba_launch.h: "Two arithmetic flavours")
+void launch_pcg_init(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                     const SurfelsView& s, float* r, float* M, uint32_t* tile_cost, const uint32_t* sched) {
+  BAHIP_PICK(in, launch_pcg_init(st, L, ex, in, kfs, num_kfs, s, r, M, tile_cost, sched));
+}
+void launch_pcg_step1(hipStream_t st, const PcgLayout& L, const PcgExact& ex, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                      const SurfelsView& s, const float* p, float* g, const void* ctl, const uint32_t* sched, uint32_t* tile_counters,
+                      int* parity_inout) {
+  BAHIP_PICK(in, launch_pcg_step1(st, L, ex, in, kfs, num_kfs, s, p, g, ctl, sched, tile_counters, parity_inout));
+}
+void set_pcg_lds_form(int mode) { exact::set_pcg_lds_form(mode); fast::set_pcg_lds_form(mode); }
+void pcg_step1_form_launches(long long out[2]) {
+  long long a[2], b[2];
+  exact::pcg_step1_form_launches(a); fast::pcg_step1_form_launches(b);
+  out[0] = a[0] + b[0]; out[1] = a[1] + b[1];
+}
 }  // namespace bahip
+#endif

@@ -24,11 +24,18 @@
 #include "wave_reduce.h"
 
 namespace bahip {
-
 #ifndef BAHIP_WAVES_ATTR
 #define BAHIP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))   // cap the allocation at 128 VGPRs: 4 waves per SIMD (5 spills: measured slower)
 #endif
 constexpr int kPoseBlock = 64;    // one wavefront per workgroup: no LDS, no barriers, and finished waves free their slot at once
+// Where a sweep reports a tile total it could not represent (hb_split): the low word of the unused 28th coefficient of work item
+// 0's row -- inside the buffer the ranks of a sharded run exchange, so that after the exchange EVERY rank's solve launch sees the
+// flag and every host fails the call alike (ADVICE r3: a flag in the rank's own counter record let the other ranks run on).
+__host__ __device__ inline int* pose_invalid_word(HbFixed* Hb) { return reinterpret_cast<int*>(Hb + 27 * kHbLimbs); }
+}  // namespace bahip
+
+// ---- the accumulate sweep: compiled once per arithmetic flavour (ba_launch.h) -----------------------------------------------------
+BAHIP_FLAVOURED_BEGIN
 
 // acc += w * [upper(J J^T) | r J], as fused multiply-add chains (the oracle's orc_accumulate_pose_coeffs spells the same chain:
 // the per-lane sums, the wave tree and the fixed-point totals are part of the numerical definition, ba_device.h: HbFixed).
@@ -82,6 +89,9 @@ void pose_timeline_dump(const char* path) {
 // waits for the (non-returning) atomics at the top of the next candidate.  Not tracking them is safe: vmcnt retires in order,
 // so an untracked older operation can only make a later s_waitcnt vmcnt(N) wait for more than the compiler intended, never
 // for less.  (Mnemonic of the gfx9 family, validated on gfx950; later families call it global_atomic_add_u64.)
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__))
+#error "GlobalSink::flush spells the gfx9 family's 64-bit integer atomics (global_atomic_add_x2 / _sub_x2): this backend is built for gfx950"
+#endif
 struct GlobalSink {
   HbFixed* Hb;
   int* invalid;
@@ -234,10 +244,9 @@ __device__ __forceinline__ void pose_tile(const Intrinsics& in, const KfEntry* _
     const int w = __builtin_amdgcn_readfirstlane(stored_bounds ? __builtin_amdgcn_readlane(my_w, ((item - part) / parts) & 63) : item_begin + item);
     const float* F = work[w].F;
     ++visited;
-    // (work[w].kf_index == w for every writer of the table -- the batched phase binds work item k to keyframe k, the single-frame
-    // estimate has one of each -- so the image pointers are read from frames[w] at once, together with F, instead of behind a second,
-    // dependent scalar load of the index)
-    const KfEntry& kf = frames[w];
+    // (the entry of the frame table that provides the images: today every writer binds work item w to entry w, but the field is what
+    // pose_solve honours too, and reading frames[w] directly measured no gain over this dependent scalar load: ADVICE r5)
+    const KfEntry& kf = frames[__builtin_amdgcn_readfirstlane(load_global(&work[w].kf_index))];
     // every gather of the pair goes out before the first one is waited for (ba_device.h: project_surfel)
     const Projected p = project_surfel(in, F, gp);
     const PixelWords pix = load_pixel_words(in, kf.geom, p);
@@ -381,10 +390,6 @@ constexpr int kPoseLdsWaves = BAHIP_POSE_LDS_WAVES;
 #define BAHIP_POSE_BATCH 32
 #endif
 constexpr uint32_t kPoseBatch = BAHIP_POSE_BATCH;
-// Where a sweep reports a tile total it could not represent (hb_split): the low word of the unused 28th coefficient of work item
-// 0's row -- inside the buffer the ranks of a sharded run exchange, so that after the exchange EVERY rank's solve launch sees the
-// flag and every host fails the call alike (ADVICE r3: a flag in the rank's own counter record let the other ranks run on).
-__host__ __device__ inline int* pose_invalid_word(HbFixed* Hb) { return reinterpret_cast<int*>(Hb + 27 * kHbLimbs); }
 constexpr int kPoseShortList = 16;   // later rounds with at most this many work items: static deal of the tiles (below)
 // kSlice: the launch covers the items [slice_begin, slice_begin + slice_count) only -- a list longer than the table (292 work
 // items) is cut into slices, one launch each (1000 keyframes: four); without it the two arguments are not looked at, which
@@ -491,6 +496,166 @@ pose_accumulate_lds_kernel(Intrinsics in, const KfEntry* __restrict__ frames, co
       __hip_atomic_fetch_add(&Hb[(size_t)w * kHbStride + (e - item * kHbStride)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// ---- launchers of the sweep ----
+static int g_forced_pose_parts = bahip_env_int("BAHIP_POSE_PARTS", 0);
+void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
+
+
+// 0 = chosen from the sizes (default), 1 = always the one-tile-per-wavefront form with global atomics, 2 = the persistent LDS
+// form whenever the table fits (tests run both: same bits)
+static int g_forced_pose_form = bahip_env_int("BAHIP_POSE_FORM", 0);
+void set_pose_form(int form) { g_forced_pose_form = form; }
+static int g_pose_lds_items = 0;   // test hook: work items per launch of the LDS form (0: what the table holds)
+void set_pose_lds_items(int items) { g_pose_lds_items = items; }
+static long long g_pose_form_launches[2] = {0, 0};   // [0] one tile per wavefront + global atomics, [1] persistent + LDS
+void pose_form_launches(long long out[2], bool reset) {
+  out[0] = g_pose_form_launches[0]; out[1] = g_pose_form_launches[1];
+  if (reset) g_pose_form_launches[0] = g_pose_form_launches[1] = 0;
+}
+// Kernel dispatches of the accumulate sweep since the process started (every slice of a sliced launch counts; never reset): lets a
+// profile of a bench run pick the dispatches of the timed region out of rocprofv3's per-dispatch rows (scripts/summarize_profile.py).
+static long long g_pose_kernel_dispatches = 0;
+long long pose_kernel_dispatches() { return g_pose_kernel_dispatches; }
+constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a compute unit
+#ifndef BAHIP_POSE_LDS_MIN_TILES
+#define BAHIP_POSE_LDS_MIN_TILES 2048
+#endif
+constexpr unsigned kPoseLdsMinTiles = BAHIP_POSE_LDS_MIN_TILES;   // smaller grids: one tile per wavefront, global atomics
+static int g_pose_lds_parts_shift = bahip_env_int("BAHIP_POSE_LDS_PARTS_SHIFT", -1);   // -1: from the grid size
+void set_pose_lds_parts_shift(int shift) { g_pose_lds_parts_shift = (shift >= 0 && shift <= 3) ? shift : -1; }
+
+static int g_pose_lds_waves = 0;   // test hook: wavefronts per workgroup of the LDS form (0: kPoseLdsWaves)
+void set_pose_lds_waves(int waves) { g_pose_lds_waves = (waves >= 1 && waves <= kPoseLdsWaves) ? waves : 0; }
+
+// What a launch of the persistent form needs to know about the device the stream runs on, per device (ADVICE r3: a process
+// that drives contexts on several devices must not reuse the first device's numbers or its opt-in).
+struct PoseLdsDevice { int compute_units = 0; bool raised[8] = {}; bool failed[8] = {}; };
+static PoseLdsDevice& pose_lds_device() {
+  static PoseLdsDevice devices[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  PoseLdsDevice& d = devices[dev];
+  if (d.compute_units == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    d.compute_units = cus;
+  }
+  return d;
+}
+
+// false: the launch could not be made (the opt-in for more than 64 KB of dynamic LDS was refused): the caller falls back to the
+// one-tile-per-wavefront form.
+template <bool kUseDepth, bool kUseDesc, bool kSlice>
+static bool launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
+                            const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
+                            uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost, const uint32_t* sched,
+                            const int* listed_count, uint32_t parts_shift, const int* stop) {
+  int* invalid = pose_invalid_word(Hb);
+  PoseLdsDevice& device = pose_lds_device();
+  constexpr int variant = (kUseDepth ? 1 : 0) + (kUseDesc ? 2 : 0) + (kSlice ? 4 : 0);
+  if (!device.raised[variant] && !device.failed[variant]) {   // dynamic LDS beyond 64 KB needs the opt-in
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsTableLimit) == hipSuccess) device.raised[variant] = true;
+    else { device.failed[variant] = true; (void)hipGetLastError(); }
+  }
+  if (device.failed[variant] && table_bytes + sizeof(HbFixed) > 64 * 1024) return false;
+  const int waves = g_pose_lds_waves > 0 ? g_pose_lds_waves : kPoseLdsWaves;
+  // one workgroup per compute unit, fewer when there is less to do than that (at least one per XCD queue)
+  const unsigned units = sched_positions(tiles, sched) << parts_shift;
+  const unsigned grid = std::max(8u, std::min((unsigned)device.compute_units, ((units + waves - 1) / waves + 7u) & ~7u));
+  ++g_pose_kernel_dispatches;
+  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(grid), dim3(64 * waves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
+                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
+  return true;
+}
+template <bool kSlice>
+static bool launch_pose_lds_any(bool use_depth, bool use_desc, hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw,
+                                int num_work, const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles,
+                                size_t table_bytes, uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost,
+                                const uint32_t* sched, const int* listed_count, uint32_t parts_shift, const int* stop) {
+  if (use_depth && use_desc) return launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
+  if (use_depth) return launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
+  return launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
+}
+
+// Can a later round over (at most) `num_items` work items be queued before the host knows how many are left?  Yes unless the
+// launch would have to be cut into slices by the host (more items than the LDS table holds).
+bool pose_round_can_be_queued_ahead(uint32_t /*surfels*/, int num_items, bool /*have_tile_counters*/) {
+  // (decided from the item count alone, whatever form this rank's launch takes: the ranks of a sharded run hold different
+  // numbers of surfels and must all make the same decision, or they disagree on the number of exchanges per host wait)
+  const size_t item_bytes = sizeof(HbFixed) * kHbStride;
+  const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes)) : (int)(kPoseLdsTableLimit / item_bytes);
+  return num_items <= per_launch;
+}
+
+void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
+                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
+                            int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched,
+                            const int* listed_count, const int* stop) {
+  if (s.size == 0 || num_work == 0) return;
+  // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
+  // wavefront with the most candidate keyframes: split every wavefront's candidates over several wavefronts
+  // (the sums are merged by integer adds, so who visits a keyframe does not matter: same bits for every split).
+  const unsigned tiles = xcd_padded_tiles((s.size + kPoseBlock - 1) / kPoseBlock);   // whole XCD runs
+  const int forced = g_forced_pose_parts;
+  const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
+                         : tiles >= 32768 ? 1 : tiles >= 8192 ? 2 : 4;
+  // measured (r2, pose stage per iteration, ms): 46.9 k tiles 1.03 / 1.08 / 1.30 with 1 / 2 / 4 parts; 23.4 k tiles 0.578 / 0.557 / 0.618
+  // with 1 / 2 / 4; 11.7 k tiles 0.29 / 0.30 with 2 / 4; 5.9 k tiles 0.155 / 0.172 with 4 / 8
+  const PoseWork* pw = static_cast<const PoseWork*>(work);
+  WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);
+  const int sb = stored_bounds ? 1 : 0;
+  // The persistent LDS form when the table of the work items in this launch fits.  (round 3, with the schedule: 23.4 k tiles --
+  // half of the bench scene -- 0.43 ms in the LDS form against 0.77-0.89 ms with global atomics, 11.7 k tiles 0.32 against
+  // 0.39-0.45; 5.9 k tiles 0.30 against 0.25 while every wavefront of the LDS form took whole tiles: round 4 lets the
+  // wavefronts of the LDS form share a tile's work items as well -- g_pose_lds_parts_shift below -- and uses it from
+  // kPoseLdsMinTiles tiles on.)
+  const int num_items = stored_bounds ? num_listed : num_work;
+  const size_t item_bytes = sizeof(HbFixed) * kHbStride;
+  const bool lds_form = tile_counters != nullptr && (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && tiles >= kPoseLdsMinTiles && forced == 0));
+  if (lds_form) {
+    // units per wavefront slot of the chip (256 x 16): below ~4 a launch lasts as long as its longest unit
+    const uint32_t parts_shift = g_pose_lds_parts_shift >= 0 ? (uint32_t)g_pose_lds_parts_shift : tiles >= 16384 ? 0u : tiles >= 8192 ? 1u : 2u;
+    const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes))
+                                                : (int)(kPoseLdsTableLimit / item_bytes);   // 292 work items
+    bool launched = true;
+    if (num_items <= per_launch) {
+      const int parity = *parity_inout;
+      launched = launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0, tile_cost, sched, listed_count, parts_shift, stop);
+      if (launched) *parity_inout = parity ^ 1;
+    } else {
+      // more work items than the table holds: slices of equal size, one launch each (every launch sweeps all tiles and culls
+      // against its slice; the first round's launches all store the same tile bounds)
+      const int slices = (num_items + per_launch - 1) / per_launch, per_slice = (num_items + slices - 1) / slices;
+      for (int begin = 0; begin < num_items && launched; begin += per_slice) {
+        const int count = std::min(per_slice, num_items - begin);
+        const int parity = *parity_inout;
+        launched = launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count, tile_cost, sched, nullptr, parts_shift, stop);
+        if (launched) *parity_inout = parity ^ 1;
+      }
+    }
+    if (launched) { ++g_pose_form_launches[1]; return; }
+    // (only a refused LDS opt-in gets here, before the first slice: nothing has been added yet)
+  }
+  ++g_pose_form_launches[0];
+  ++g_pose_kernel_dispatches;
+  const dim3 grid(sched_positions(tiles, sched), parts), block(kPoseBlock);
+  int* invalid = pose_invalid_word(Hb);
+  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
+  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
+  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
+}
+
+BAHIP_FLAVOURED_END
+
+// ---- what exists once (the exact unit): the Gauss-Newton solve, the loop control, the tile schedule, test hooks, dispatchers -----
+#ifndef BAHIP_FAST_MATH
+namespace bahip {
+size_t pose_tile_bounds_bytes(uint32_t surfels) {
+  const size_t tiles = xcd_padded_tiles((surfels + kPoseBlock - 1) / kPoseBlock);
+  return tiles * sizeof(WaveBounds);
 }
 
 // B/convergence_analysis.h:43-51
@@ -934,159 +1099,6 @@ void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs
   if (num_kfs) hipLaunchKernelGGL(propagate_covisible_kernel, dim3((num_kfs + 63) / 64), dim3(64), 0, stream, frames, num_kfs, offsets, indices, stop);
 }
 
-static int g_forced_pose_parts = bahip_env_int("BAHIP_POSE_PARTS", 0);
-void set_pose_parts(int parts) { g_forced_pose_parts = parts; }
-
-size_t pose_tile_bounds_bytes(uint32_t surfels) {
-  const size_t tiles = xcd_padded_tiles((surfels + kPoseBlock - 1) / kPoseBlock);
-  return tiles * sizeof(WaveBounds);
-}
-
-// 0 = chosen from the sizes (default), 1 = always the one-tile-per-wavefront form with global atomics, 2 = the persistent LDS
-// form whenever the table fits (tests run both: same bits)
-static int g_forced_pose_form = bahip_env_int("BAHIP_POSE_FORM", 0);
-void set_pose_form(int form) { g_forced_pose_form = form; }
-static int g_pose_lds_items = 0;   // test hook: work items per launch of the LDS form (0: what the table holds)
-void set_pose_lds_items(int items) { g_pose_lds_items = items; }
-static long long g_pose_form_launches[2] = {0, 0};   // [0] one tile per wavefront + global atomics, [1] persistent + LDS
-void pose_form_launches(long long out[2], bool reset) {
-  out[0] = g_pose_form_launches[0]; out[1] = g_pose_form_launches[1];
-  if (reset) g_pose_form_launches[0] = g_pose_form_launches[1] = 0;
-}
-// Kernel dispatches of the accumulate sweep since the process started (every slice of a sliced launch counts; never reset): lets a
-// profile of a bench run pick the dispatches of the timed region out of rocprofv3's per-dispatch rows (scripts/summarize_profile.py).
-static long long g_pose_kernel_dispatches = 0;
-long long pose_kernel_dispatches() { return g_pose_kernel_dispatches; }
-constexpr size_t kPoseLdsTableLimit = 128 * 1024;   // of the 160 KB of a compute unit
-#ifndef BAHIP_POSE_LDS_MIN_TILES
-#define BAHIP_POSE_LDS_MIN_TILES 2048
-#endif
-constexpr unsigned kPoseLdsMinTiles = BAHIP_POSE_LDS_MIN_TILES;   // smaller grids: one tile per wavefront, global atomics
-static int g_pose_lds_parts_shift = bahip_env_int("BAHIP_POSE_LDS_PARTS_SHIFT", -1);   // -1: from the grid size
-void set_pose_lds_parts_shift(int shift) { g_pose_lds_parts_shift = (shift >= 0 && shift <= 3) ? shift : -1; }
-
-static int g_pose_lds_waves = 0;   // test hook: wavefronts per workgroup of the LDS form (0: kPoseLdsWaves)
-void set_pose_lds_waves(int waves) { g_pose_lds_waves = (waves >= 1 && waves <= kPoseLdsWaves) ? waves : 0; }
-
-// What a launch of the persistent form needs to know about the device the stream runs on, per device (ADVICE r3: a process
-// that drives contexts on several devices must not reuse the first device's numbers or its opt-in).
-struct PoseLdsDevice { int compute_units = 0; bool raised[8] = {}; bool failed[8] = {}; };
-static PoseLdsDevice& pose_lds_device() {
-  static PoseLdsDevice devices[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  PoseLdsDevice& d = devices[dev];
-  if (d.compute_units == 0) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    d.compute_units = cus;
-  }
-  return d;
-}
-
-// false: the launch could not be made (the opt-in for more than 64 KB of dynamic LDS was refused): the caller falls back to the
-// one-tile-per-wavefront form.
-template <bool kUseDepth, bool kUseDesc, bool kSlice>
-static bool launch_pose_lds(hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw, int num_work,
-                            const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles, size_t table_bytes,
-                            uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost, const uint32_t* sched,
-                            const int* listed_count, uint32_t parts_shift, const int* stop) {
-  int* invalid = pose_invalid_word(Hb);
-  PoseLdsDevice& device = pose_lds_device();
-  constexpr int variant = (kUseDepth ? 1 : 0) + (kUseDesc ? 2 : 0) + (kSlice ? 4 : 0);
-  if (!device.raised[variant] && !device.failed[variant]) {   // dynamic LDS beyond 64 KB needs the opt-in
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsTableLimit) == hipSuccess) device.raised[variant] = true;
-    else { device.failed[variant] = true; (void)hipGetLastError(); }
-  }
-  if (device.failed[variant] && table_bytes + sizeof(HbFixed) > 64 * 1024) return false;
-  const int waves = g_pose_lds_waves > 0 ? g_pose_lds_waves : kPoseLdsWaves;
-  // one workgroup per compute unit, fewer when there is less to do than that (at least one per XCD queue)
-  const unsigned units = sched_positions(tiles, sched) << parts_shift;
-  const unsigned grid = std::max(8u, std::min((unsigned)device.compute_units, ((units + waves - 1) / waves + 7u) & ~7u));
-  ++g_pose_kernel_dispatches;
-  hipLaunchKernelGGL((pose_accumulate_lds_kernel<kUseDepth, kUseDesc, kSlice>), dim3(grid), dim3(64 * waves), table_bytes + sizeof(HbFixed) /* the batch word */, stream, in, frames,
-                     pw, num_work, s, Hb, tb, sb, num_listed, invalid, tiles, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
-  return true;
-}
-template <bool kSlice>
-static bool launch_pose_lds_any(bool use_depth, bool use_desc, hipStream_t stream, const Intrinsics& in, const KfEntry* frames, const PoseWork* pw,
-                                int num_work, const SurfelsView& s, HbFixed* Hb, WaveBounds* tb, int sb, int num_listed, unsigned tiles,
-                                size_t table_bytes, uint32_t* tile_counters, int parity, int slice_begin, int slice_count, uint32_t* tile_cost,
-                                const uint32_t* sched, const int* listed_count, uint32_t parts_shift, const int* stop) {
-  if (use_depth && use_desc) return launch_pose_lds<true, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
-  if (use_depth) return launch_pose_lds<true, false, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
-  return launch_pose_lds<false, true, kSlice>(stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, table_bytes, tile_counters, parity, slice_begin, slice_count, tile_cost, sched, listed_count, parts_shift, stop);
-}
-
-// Can a later round over (at most) `num_items` work items be queued before the host knows how many are left?  Yes unless the
-// launch would have to be cut into slices by the host (more items than the LDS table holds).
-bool pose_round_can_be_queued_ahead(uint32_t /*surfels*/, int num_items, bool /*have_tile_counters*/) {
-  // (decided from the item count alone, whatever form this rank's launch takes: the ranks of a sharded run hold different
-  // numbers of surfels and must all make the same decision, or they disagree on the number of exchanges per host wait)
-  const size_t item_bytes = sizeof(HbFixed) * kHbStride;
-  const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes)) : (int)(kPoseLdsTableLimit / item_bytes);
-  return num_items <= per_launch;
-}
-
-void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
-                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
-                            int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched,
-                            const int* listed_count, const int* stop) {
-  if (s.size == 0 || num_work == 0) return;
-  // Small surfel sets (a shard of a multi-GPU run) leave the chip under-filled and the launch then lasts as long as the
-  // wavefront with the most candidate keyframes: split every wavefront's candidates over several wavefronts
-  // (the sums are merged by integer adds, so who visits a keyframe does not matter: same bits for every split).
-  const unsigned tiles = xcd_padded_tiles((s.size + kPoseBlock - 1) / kPoseBlock);   // whole XCD runs
-  const int forced = g_forced_pose_parts;
-  const unsigned parts = (forced == 1 || forced == 2 || forced == 4 || forced == 8) ? (unsigned)forced
-                         : tiles >= 32768 ? 1 : tiles >= 8192 ? 2 : 4;
-  // measured (r2, pose stage per iteration, ms): 46.9 k tiles 1.03 / 1.08 / 1.30 with 1 / 2 / 4 parts; 23.4 k tiles 0.578 / 0.557 / 0.618
-  // with 1 / 2 / 4; 11.7 k tiles 0.29 / 0.30 with 2 / 4; 5.9 k tiles 0.155 / 0.172 with 4 / 8
-  const PoseWork* pw = static_cast<const PoseWork*>(work);
-  WaveBounds* tb = static_cast<WaveBounds*>(tile_bounds);
-  const int sb = stored_bounds ? 1 : 0;
-  // The persistent LDS form when the table of the work items in this launch fits.  (round 3, with the schedule: 23.4 k tiles --
-  // half of the bench scene -- 0.43 ms in the LDS form against 0.77-0.89 ms with global atomics, 11.7 k tiles 0.32 against
-  // 0.39-0.45; 5.9 k tiles 0.30 against 0.25 while every wavefront of the LDS form took whole tiles: round 4 lets the
-  // wavefronts of the LDS form share a tile's work items as well -- g_pose_lds_parts_shift below -- and uses it from
-  // kPoseLdsMinTiles tiles on.)
-  const int num_items = stored_bounds ? num_listed : num_work;
-  const size_t item_bytes = sizeof(HbFixed) * kHbStride;
-  const bool lds_form = tile_counters != nullptr && (g_forced_pose_form == 2 || (g_forced_pose_form == 0 && tiles >= kPoseLdsMinTiles && forced == 0));
-  if (lds_form) {
-    // units per wavefront slot of the chip (256 x 16): below ~4 a launch lasts as long as its longest unit
-    const uint32_t parts_shift = g_pose_lds_parts_shift >= 0 ? (uint32_t)g_pose_lds_parts_shift : tiles >= 16384 ? 0u : tiles >= 8192 ? 1u : 2u;
-    const int per_launch = g_pose_lds_items > 0 ? std::min(g_pose_lds_items, (int)(kPoseLdsTableLimit / item_bytes))
-                                                : (int)(kPoseLdsTableLimit / item_bytes);   // 292 work items
-    bool launched = true;
-    if (num_items <= per_launch) {
-      const int parity = *parity_inout;
-      launched = launch_pose_lds_any<false>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)num_items, tile_counters, parity, 0, 0, tile_cost, sched, listed_count, parts_shift, stop);
-      if (launched) *parity_inout = parity ^ 1;
-    } else {
-      // more work items than the table holds: slices of equal size, one launch each (every launch sweeps all tiles and culls
-      // against its slice; the first round's launches all store the same tile bounds)
-      const int slices = (num_items + per_launch - 1) / per_launch, per_slice = (num_items + slices - 1) / slices;
-      for (int begin = 0; begin < num_items && launched; begin += per_slice) {
-        const int count = std::min(per_slice, num_items - begin);
-        const int parity = *parity_inout;
-        launched = launch_pose_lds_any<true>(use_depth, use_desc, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, tiles, item_bytes * (size_t)count, tile_counters, parity, begin, count, tile_cost, sched, nullptr, parts_shift, stop);
-        if (launched) *parity_inout = parity ^ 1;
-      }
-    }
-    if (launched) { ++g_pose_form_launches[1]; return; }
-    // (only a refused LDS opt-in gets here, before the first slice: nothing has been added yet)
-  }
-  ++g_pose_form_launches[0];
-  ++g_pose_kernel_dispatches;
-  const dim3 grid(sched_positions(tiles, sched), parts), block(kPoseBlock);
-  int* invalid = pose_invalid_word(Hb);
-  if (use_depth && use_desc) hipLaunchKernelGGL((pose_accumulate_kernel<true, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
-  else if (use_depth) hipLaunchKernelGGL((pose_accumulate_kernel<true, false>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
-  else hipLaunchKernelGGL((pose_accumulate_kernel<false, true>), grid, block, 0, stream, in, frames, pw, num_work, s, Hb, tb, sb, num_listed, invalid, tile_cost, sched, listed_count, stop);
-}
-
 // The schedule of the sweeps that follow (wave_cull.h: scheduled_tile) from the candidates every tile visited in the pose sweep's
 // first round (tile_cost; cleared here for the next census).  One workgroup; every pass over the tiles reads them with
 // consecutive threads on consecutive tiles (a thread per run walking its 128 tiles took 0.3 ms).
@@ -1233,8 +1245,34 @@ void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, 
                        static_cast<PoseWork*>(work), Hb, static_cast<PoseWork*>(host_out), mask, rank, stop);
 }
 
-
-
+// dispatchers (ba_launch.h: "Two arithmetic flavours"); the hooks reach both flavours, the counters add up
+void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,
+                            const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,
+                            int num_listed, uint32_t* tile_counters, int* parity_inout, uint32_t* tile_cost, const uint32_t* sched,
+                            const int* listed_count, const int* stop) {
+  BAHIP_PICK(in, launch_pose_accumulate(stream, use_depth, use_desc, in, frames, work, num_work, s, Hb, tile_bounds, stored_bounds, num_listed,
+                                        tile_counters, parity_inout, tile_cost, sched, listed_count, stop));
+}
+bool pose_round_can_be_queued_ahead(uint32_t surfels, int num_items, bool have_tile_counters) {
+  return exact::pose_round_can_be_queued_ahead(surfels, num_items, have_tile_counters);   // (the hooks it looks at are set alike in both)
+}
+void set_pose_parts(int parts) { exact::set_pose_parts(parts); fast::set_pose_parts(parts); }
+void set_pose_form(int form) { exact::set_pose_form(form); fast::set_pose_form(form); }
+void set_pose_lds_items(int items) { exact::set_pose_lds_items(items); fast::set_pose_lds_items(items); }
+void set_pose_lds_parts_shift(int shift) { exact::set_pose_lds_parts_shift(shift); fast::set_pose_lds_parts_shift(shift); }
+void set_pose_lds_waves(int waves) { exact::set_pose_lds_waves(waves); fast::set_pose_lds_waves(waves); }
+long long pose_kernel_dispatches() { return exact::pose_kernel_dispatches() + fast::pose_kernel_dispatches(); }
+void pose_form_launches(long long out[2], bool reset) {
+  long long a[2], b[2];
+  exact::pose_form_launches(a, reset); fast::pose_form_launches(b, reset);
+  out[0] = a[0] + b[0]; out[1] = a[1] + b[1];
+}
+#ifdef BAHIP_COUNT_CANDIDATES
+void pose_counters_dump() { exact::pose_counters_dump(); }
+#endif
+#ifdef BAHIP_TILE_TIMELINE
+void pose_timeline_dump(const char* path) { exact::pose_timeline_dump(path); }
+#endif
 
 }  // namespace bahip
 
@@ -1245,7 +1283,8 @@ void launch_pose_init_from_keyframes(hipStream_t stream, const KfEntry* frames, 
 // [0] associated, [1] px, [2] py, [3] colour-valid, [4] calibrated depth, [5] depth residual,
 // [6] depth weight, [7] inv stddev, [8..13] depth J, [14..15] desc residuals, [16..17] desc weights,
 // [18..23] desc J1, [24..29] desc J2, [30..33] gradients, [34..35] pxx, pxy.
-namespace bahip {
+#endif   // !BAHIP_FAST_MATH (the per-pair hook exists in both flavours: the flavours' association decisions are compared pair by pair)
+BAHIP_FLAVOURED_BEGIN
 __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ indices,
                                       int count, float* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1283,6 +1322,13 @@ __global__ void evaluate_pairs_kernel(Intrinsics in, KfEntry frame, SurfelsView 
 void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
                            const uint32_t* indices, int count, float* out) {
   if (count) hipLaunchKernelGGL(evaluate_pairs_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, in, frame, s, indices, count, out);
+}
+BAHIP_FLAVOURED_END
+#ifndef BAHIP_FAST_MATH
+namespace bahip {
+void launch_evaluate_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s,
+                           const uint32_t* indices, int count, float* out) {
+  BAHIP_PICK(in, launch_evaluate_pairs(stream, in, frame, s, indices, count, out));
 }
 // Debug: one wave64; in = 64 x 28 floats (lane-major).  out[0..27] = wave_reduce28 totals scattered by slot,
 // out[28..55] = wave_sum of every column (what lane 17 receives; every lane holds the same value).
@@ -1358,3 +1404,4 @@ void launch_jacobian_debug(hipStream_t stream, int kind, const float* in, float*
   hipLaunchKernelGGL(jacobian_debug_kernel, dim3(1), dim3(64), 0, stream, kind, in, out);
 }
 }  // namespace bahip
+#endif   // !BAHIP_FAST_MATH

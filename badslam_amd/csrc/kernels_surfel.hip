@@ -44,6 +44,23 @@ constexpr int kMaxSumClasses = 8;  // interleaved partial sums per surfel: Intri
 // kWaves > 1: the calling workgroup has kWaves wavefronts holding the same 64 surfels (wavefront w takes the classes
 // w, w + kWaves, ...); every thread must call.
 enum SumsMode { kSumsFused = 0, kSumsProduce = 1, kSumsConsume = 2 };
+__device__ __forceinline__ bool position_valid(Vec3 p) { return p.x == p.x; }   // deleted surfels carry NaN x
+static inline unsigned grid_for(uint32_t n) { return xcd_padded_tiles((n + kSurfelBlock - 1) / kSurfelBlock); }   // whole XCD runs
+#if defined(BAHIP_TILE_TIMELINE) && !defined(BAHIP_FAST_MATH)
+// experiment build only (scripts/tile_timeline.py): when each tile of the LAST geometry launch started and ended (100 MHz clock)
+__device__ unsigned long long g_geometry_timeline[65536][2];
+void geometry_timeline_dump(const char* path) {
+  static unsigned long long host[65536][2];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_geometry_timeline), sizeof(host)) != hipSuccess) return;
+  if (FILE* f = fopen(path, "wb")) { fwrite(host, sizeof(host), 1, f); fclose(f); }
+}
+#define BAHIP_RECORD_GEOMETRY_TIMELINE 1
+#endif
+}  // namespace bahip
+
+// ---- the sweeps: compiled once per arithmetic flavour (ba_launch.h) ---------------------------------------------------------------
+BAHIP_FLAVOURED_BEGIN
+
 template <int kWaves, int kCount, int kMode = kSumsFused, typename Visit>
 __device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visit visit, int classes, const ClassPartials& cp = ClassPartials{},
                                           uint32_t i = 0, bool in_range = false) {
@@ -105,8 +122,6 @@ __device__ __forceinline__ void tile_sums(float (&tot)[kCount], float* lds, Visi
   }
 }
 
-__device__ __forceinline__ bool position_valid(Vec3 p) { return p.x == p.x; }   // deleted surfels carry NaN x
-
 // B/kernel_surfel_activation.cu:38-94
 __global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
 activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t surfels_size) {
@@ -130,70 +145,6 @@ activation_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, S
         return __all(active || !in_range) != 0;
       });
   if (in_range) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (active ? kSurfelActiveFlag : 0);
-}
-
-// ---- DirectBA::AssignColors (B/kernel_assign_colors.cu:41-125, B/kernel_assign_colors.cc:39-80) --------------------------
-// Bilinear RGBA sample at unnormalised coordinates, clamp addressing, texel centres at +0.5 (the tex2D<float4> of the
-// reference on the keyframe's pitch-linear uchar4 image); per channel the arithmetic of sample_luma (oracle: orc_sample_rgba).
-__device__ __forceinline__ void sample_rgba(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y, float (&out)[4]) {
-  float xb = x - 0.5f, yb = y - 0.5f;
-  if (!(xb >= -1.f)) xb = -1.f;
-  if (xb > (float)w) xb = (float)w;
-  if (!(yb >= -1.f)) yb = -1.f;
-  if (yb > (float)h) yb = (float)h;
-  const float fx = floorf(xb), fy = floorf(yb);
-  const float a = xb - fx, b = yb - fy;
-  const int x0 = min(max((int)fx, 0), w - 1), x1 = min(max((int)fx + 1, 0), w - 1);
-  const int y0 = min(max((int)fy, 0), h - 1), y1 = min(max((int)fy + 1, 0), h - 1);
-  const uchar4* image = reinterpret_cast<const uchar4*>(color);
-  const uchar4 tl = pitched_load(image, pitch, y0, x0), tr = pitched_load(image, pitch, y0, x1);
-  const uchar4 bl = pitched_load(image, pitch, y1, x0), br = pitched_load(image, pitch, y1, x1);
-  const uint8_t ctl[4] = {tl.x, tl.y, tl.z, tl.w}, ctr[4] = {tr.x, tr.y, tr.z, tr.w};
-  const uint8_t cbl[4] = {bl.x, bl.y, bl.z, bl.w}, cbr[4] = {br.x, br.y, br.z, br.w};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float vtl = (float)ctl[c] * (1.0f / 255.0f), vtr = (float)ctr[c] * (1.0f / 255.0f);
-    const float vbl = (float)cbl[c] * (1.0f / 255.0f), vbr = (float)cbr[c] * (1.0f / 255.0f);
-    const float top = mad(a, vtr - vtl, vtl);
-    const float bot = mad(a, vbr - vbl, vbl);
-    out[c] = mad(b, bot - top, top);
-  }
-}
-
-// Every keyframe a surfel is associated with (whatever its activation) contributes the RGBA sample at the surfel's colour
-// pixel, in keyframe order; the mean, rounded, becomes the surfel colour.  Surfels no keyframe sees keep theirs.  The
-// reference parks count and sums in accumulator rows 0-4 between its K + 2 launches; here they live in registers.
-__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
-assign_colors_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
-  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + threadIdx.x;
-  const bool in_range = i < s.size;
-  const uint32_t ii = in_range ? i : 0;
-  const Vec3 gp = surfel_position(s, ii);
-  const Vec3 gn = surfel_normal(s, ii);
-  const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
-  float count = 0.f, sum[4] = {0.f, 0.f, 0.f, 0.f};
-  for_each_candidate(
-      num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
-      [&](int k) {
-        if (!in_range) return;
-        Assoc r;
-        if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) return;
-        float cx, cy;
-        if (!depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) return;
-        float c[4];
-        sample_rgba(kfs[k].color, kfs[k].color_pitch, in.cwidth, in.cheight, cx, cy, c);
-        count += 1.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sum[q] += c[q];
-      });
-  if (in_range && count > 0.f) {
-    uchar4 out;
-    out.x = (uint8_t)(255.f * sum[0] / count + 0.5f);
-    out.y = (uint8_t)(255.f * sum[1] / count + 0.5f);
-    out.z = (uint8_t)(255.f * sum[2] / count + 0.5f);
-    out.w = (uint8_t)(255.f * sum[3] / count + 0.5f);
-    reinterpret_cast<uchar4*>(s.row(kSurfelColor))[i] = out;
-  }
 }
 
 // Normals pass: B/kernel_opt_geometry.cu:82-101 (reset), :527-553 (accumulate), :577-597 (update).
@@ -452,15 +403,6 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
   if (x2 != 0) s.row(kSurfelDescriptor2)[i] = fmaxf(-180.f, fminf(180.f, d2 - x2));
 }
 
-#ifdef BAHIP_TILE_TIMELINE
-// experiment build only (scripts/tile_timeline.py): when each tile of the LAST geometry launch started and ended (100 MHz clock)
-__device__ unsigned long long g_geometry_timeline[65536][2];
-void geometry_timeline_dump(const char* path) {
-  static unsigned long long host[65536][2];
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_geometry_timeline), sizeof(host)) != hipSuccess) return;
-  if (FILE* f = fopen(path, "wb")) { fwrite(host, sizeof(host), 1, f); fclose(f); }
-}
-#endif
 
 template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate>
 __global__ void __launch_bounds__(64 * kWaves) BAHIP_WAVES_ATTR
@@ -469,11 +411,11 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
                 bahip_alternating_iterations): a launch queued behind the iteration that ended the loop does nothing; NULL: always runs */) {
   __shared__ float lds[kWaves == 1 ? 1 : kMaxSumClasses * 8 * 64];
   if (stop && load_global(stop) != 0) return;
-#ifdef BAHIP_TILE_TIMELINE
+#ifdef BAHIP_RECORD_GEOMETRY_TIMELINE
   const unsigned long long t0 = wall_clock64();
 #endif
   geometry_step<kUseDepth, kUseDesc, kWaves, kActivate, 0>(in, kfs, num_kfs, s, activate_count, lds, ClassPartials{}, ClassPartials{}, sched);
-#ifdef BAHIP_TILE_TIMELINE
+#ifdef BAHIP_RECORD_GEOMETRY_TIMELINE
   if (threadIdx.x == 0 && blockIdx.x < 65536) { g_geometry_timeline[blockIdx.x][0] = t0; g_geometry_timeline[blockIdx.x][1] = wall_clock64(); }
 #endif
 }
@@ -512,24 +454,12 @@ activation_hits_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_k
       });
   if (in_range) hits[i] = active ? 1u : 0u;
 }
-__global__ void activation_from_hits_kernel(SurfelsView s, uint32_t surfels_size, const uint32_t* __restrict__ hits) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < surfels_size) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (hits[i] ? kSurfelActiveFlag : 0);
-}
-
 // ---- launchers ---------------------------------------------------------------------------------
-static inline unsigned grid_for(uint32_t n) { return xcd_padded_tiles((n + kSurfelBlock - 1) / kSurfelBlock); }   // whole XCD runs
-
 void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                        uint32_t surfels_size) {
   if (surfels_size == 0) return;
   hipLaunchKernelGGL(activation_kernel, dim3(grid_for(surfels_size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s,
                      surfels_size);
-}
-
-void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s) {
-  if (s.size == 0) return;
-  hipLaunchKernelGGL(assign_colors_kernel, dim3(grid_for(s.size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s);
 }
 
 // Launch shape of the normals / geometry passes (see the header comment): one wavefront per tile when the tiles alone
@@ -579,9 +509,6 @@ void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const In
 }
 
 // ---- keyframe sharding ------------------------------------------------------------------------------------------------
-int geometry_normals_sums(bool activate) { return activate ? 5 : 4; }
-int geometry_position_sums(bool use_desc) { return use_desc ? 8 : 2; }
-
 template <bool kUseDepth, bool kUseDesc, bool kActivate>
 static void launch_geometry_phase_of(hipStream_t stream, int phase, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                                      uint32_t activate_count, const ClassPartials& cpn, const ClassPartials& cpp) {
@@ -616,11 +543,113 @@ void launch_activation_hits(hipStream_t stream, const Intrinsics& in, const KfEn
   hipLaunchKernelGGL(activation_hits_kernel, dim3(grid_for(surfels_size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s, surfels_size,
                      (uint32_t)(kf_world - 1), (uint32_t)kf_rank, hits);
 }
+BAHIP_FLAVOURED_END
+
+// ---- what exists once (the exact unit): colour assignment, diagnostics, and the dispatchers carrying the public names -------------
+#ifndef BAHIP_FAST_MATH
+namespace bahip {
+// ---- DirectBA::AssignColors (B/kernel_assign_colors.cu:41-125, B/kernel_assign_colors.cc:39-80) --------------------------
+// Bilinear RGBA sample at unnormalised coordinates, clamp addressing, texel centres at +0.5 (the tex2D<float4> of the
+// reference on the keyframe's pitch-linear uchar4 image); per channel the arithmetic of sample_luma (oracle: orc_sample_rgba).
+__device__ __forceinline__ void sample_rgba(const uint8_t* color, uint32_t pitch, int w, int h, float x, float y, float (&out)[4]) {
+  float xb = x - 0.5f, yb = y - 0.5f;
+  if (!(xb >= -1.f)) xb = -1.f;
+  if (xb > (float)w) xb = (float)w;
+  if (!(yb >= -1.f)) yb = -1.f;
+  if (yb > (float)h) yb = (float)h;
+  const float fx = floorf(xb), fy = floorf(yb);
+  const float a = xb - fx, b = yb - fy;
+  const int x0 = min(max((int)fx, 0), w - 1), x1 = min(max((int)fx + 1, 0), w - 1);
+  const int y0 = min(max((int)fy, 0), h - 1), y1 = min(max((int)fy + 1, 0), h - 1);
+  const uchar4* image = reinterpret_cast<const uchar4*>(color);
+  const uchar4 tl = pitched_load(image, pitch, y0, x0), tr = pitched_load(image, pitch, y0, x1);
+  const uchar4 bl = pitched_load(image, pitch, y1, x0), br = pitched_load(image, pitch, y1, x1);
+  const uint8_t ctl[4] = {tl.x, tl.y, tl.z, tl.w}, ctr[4] = {tr.x, tr.y, tr.z, tr.w};
+  const uint8_t cbl[4] = {bl.x, bl.y, bl.z, bl.w}, cbr[4] = {br.x, br.y, br.z, br.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float vtl = (float)ctl[c] * (1.0f / 255.0f), vtr = (float)ctr[c] * (1.0f / 255.0f);
+    const float vbl = (float)cbl[c] * (1.0f / 255.0f), vbr = (float)cbr[c] * (1.0f / 255.0f);
+    const float top = mad(a, vtr - vtl, vtl);
+    const float bot = mad(a, vbr - vbl, vbl);
+    out[c] = mad(b, bot - top, top);
+  }
+}
+
+// Every keyframe a surfel is associated with (whatever its activation) contributes the RGBA sample at the surfel's colour
+// pixel, in keyframe order; the mean, rounded, becomes the surfel colour.  Surfels no keyframe sees keep theirs.  The
+// reference parks count and sums in accumulator rows 0-4 between its K + 2 launches; here they live in registers.
+__global__ void __launch_bounds__(kSurfelBlock) BAHIP_WAVES_ATTR
+assign_colors_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s) {
+  const uint32_t i = xcd_chunked_tile(blockIdx.x) * kSurfelBlock + threadIdx.x;
+  const bool in_range = i < s.size;
+  const uint32_t ii = in_range ? i : 0;
+  const Vec3 gp = surfel_position(s, ii);
+  const Vec3 gn = surfel_normal(s, ii);
+  const WaveBounds wb = wave_bounds(gp, in_range && position_valid(gp));
+  float count = 0.f, sum[4] = {0.f, 0.f, 0.f, 0.f};
+  for_each_candidate(
+      num_kfs, [&](int k) { return sphere_may_project_item(in, kfs[k].pose.F, wb); },
+      [&](int k) {
+        if (!in_range) return;
+        Assoc r;
+        if (!project_associate<false>(in, kfs[k].pose.F, kfs[k].geom, gp, gn, &r, nullptr)) return;
+        float cx, cy;
+        if (!depth_to_color_pixel(in, r.pxx, r.pxy, &cx, &cy)) return;
+        float c[4];
+        sample_rgba(kfs[k].color, kfs[k].color_pitch, in.cwidth, in.cheight, cx, cy, c);
+        count += 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum[q] += c[q];
+      });
+  if (in_range && count > 0.f) {
+    uchar4 out;
+    out.x = (uint8_t)(255.f * sum[0] / count + 0.5f);
+    out.y = (uint8_t)(255.f * sum[1] / count + 0.5f);
+    out.z = (uint8_t)(255.f * sum[2] / count + 0.5f);
+    out.w = (uint8_t)(255.f * sum[3] / count + 0.5f);
+    reinterpret_cast<uchar4*>(s.row(kSurfelColor))[i] = out;
+  }
+}
+
+__global__ void activation_from_hits_kernel(SurfelsView s, uint32_t surfels_size, const uint32_t* __restrict__ hits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < surfels_size) s.active[i] = (s.active[i] & (uint8_t)~kSurfelActiveFlag) | (hits[i] ? kSurfelActiveFlag : 0);
+}
+
+void launch_assign_colors(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s) {
+  if (s.size == 0) return;
+  hipLaunchKernelGGL(assign_colors_kernel, dim3(grid_for(s.size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s);
+}
+
+int geometry_normals_sums(bool activate) { return activate ? 5 : 4; }
+int geometry_position_sums(bool use_desc) { return use_desc ? 8 : 2; }
 void launch_activation_from_hits(hipStream_t stream, const SurfelsView& s, uint32_t surfels_size, const uint32_t* hits) {
   if (surfels_size == 0) return;
   hipLaunchKernelGGL(activation_from_hits_kernel, dim3((surfels_size + 255) / 256), dim3(256), 0, stream, s, surfels_size, hits);
 }
 
+
+// dispatchers (ba_launch.h: "Two arithmetic flavours")
+void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s, uint32_t surfels_size) {
+  BAHIP_PICK(in, launch_activation(stream, in, kfs, num_kfs, s, surfels_size));
+}
+void launch_normals(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s) {
+  BAHIP_PICK(in, launch_normals(stream, in, kfs, num_kfs, s));
+}
+void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
+                     long long activate_count, const uint32_t* sched, const int* stop) {
+  BAHIP_PICK(in, launch_geometry(stream, use_depth, use_desc, in, kfs, num_kfs, s, activate_count, sched, stop));
+}
+void launch_geometry_phase(hipStream_t stream, int phase, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs, int num_kfs,
+                           const SurfelsView& s, long long activate_count, const ClassPartials& cpn, const ClassPartials& cpp) {
+  BAHIP_PICK(in, launch_geometry_phase(stream, phase, use_depth, use_desc, in, kfs, num_kfs, s, activate_count, cpn, cpp));
+}
+void launch_activation_hits(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s, uint32_t surfels_size,
+                            int kf_rank, int kf_world, uint32_t* hits) {
+  BAHIP_PICK(in, launch_activation_hits(stream, in, kfs, num_kfs, s, surfels_size, kf_rank, kf_world, hits));
+}
+void set_tile_waves(int waves) { exact::set_tile_waves(waves); fast::set_tile_waves(waves); }
 }  // namespace bahip
 
 // ---- diagnostics: how much work does a sweep over all keyframes contain? ----------------------------
@@ -656,3 +685,4 @@ void launch_count_pairs(hipStream_t stream, const Intrinsics& in, const KfEntry*
   if (s.size) hipLaunchKernelGGL(count_pairs_kernel, dim3(grid_for(s.size)), dim3(kSurfelBlock), 0, stream, in, kfs, num_kfs, s, counts);
 }
 }  // namespace bahip
+#endif   // !BAHIP_FAST_MATH

@@ -271,6 +271,10 @@ class DirectBA:
         self.L.dba_set_row_major_creation.argtypes = [C.c_void_p, C.c_int]
         assert self.L.dba_set_row_major_creation(self.h, int(bool(enabled))) == 0
 
+    def SetFastArithmetic(self, enabled):
+        self.L.dba_set_fast_arithmetic.argtypes = [C.c_void_p, C.c_int]
+        assert self.L.dba_set_fast_arithmetic(self.h, int(bool(enabled))) == 0
+
     def SetSumClasses(self, classes):
         self.L.dba_set_sum_classes.argtypes = [C.c_void_p, C.c_int]
         assert self.L.dba_set_sum_classes(self.h, int(classes)) == 0

@@ -211,6 +211,10 @@ int dba_set_row_major_creation(dba_handle* h, int enabled) {
   h->ba->SetRowMajorCreation(enabled != 0);
   return 0;
 }
+int dba_set_fast_arithmetic(dba_handle* h, int enabled) {
+  h->ba->SetFastArithmetic(enabled != 0);
+  return 0;
+}
 int dba_set_sum_classes(dba_handle* h, int classes) {
   h->ba->SetSumClasses(classes);
   return 0;

@@ -218,6 +218,7 @@ void DirectBA::SetSurfelSharding(int rank, int world, u32 chunk) {
 }
 
 void DirectBA::SetSumClasses(int classes) { BAHIP_CHECKED_CALL(bahip_context_set_sum_classes(ctx_, classes)); }
+void DirectBA::SetFastArithmetic(bool enabled) { BAHIP_CHECKED_CALL(bahip_context_set_arithmetic(ctx_, enabled ? BAHIP_ARITHMETIC_FAST : BAHIP_ARITHMETIC_EXACT)); }
 void DirectBA::SetRowMajorCreation(bool enabled) { BAHIP_CHECKED_CALL(bahip_context_set_creation_order(ctx_, enabled ? 1 : 0)); }
 
 void DirectBA::SetKeyframeSharding(int rank, int world) {

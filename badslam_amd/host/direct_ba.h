@@ -142,7 +142,8 @@ class DirectBA {
   // bits of the unsharded one.  Needs SetAllReduce (or an RCCL communicator on the backend context) when world > 1.
   void SetSurfelSharding(int rank, int world, u32 chunk);
   // Multi-GPU KEYFRAME sharding (bahip_context_set_keyframe_sharding): this object holds ALL surfels; of the keyframes it needs
-  // the images of those with (index among the non-deleted keyframes) % 4 % world == rank only (world = 1, 2, 4).  Covers the
+  // the images of those with (index among the non-deleted keyframes) % world == rank only (world = 1, 2, 4, or 8 after
+  // SetSumClasses(8)).  Covers the
   // alternating scheme over poses and geometry -- BundleAdjustment(stream, false, false, /*do_surfel_updates*/ false, ...,
   // /*use_pcg*/ false, ..., /*increase_ba_iteration_count*/ false) -- and ends with the unsharded run's bits on every rank; the
   // intrinsics step, the PCG scheme and the surfel lifecycle (end tasks included) are refused.  Needs SetAllReduce or an RCCL
@@ -155,6 +156,10 @@ class DirectBA {
   // backend's tile-major one (bahip_context_set_creation_order): the same surfels, the reference's indices -- and therefore the
   // reference's survivors when surfels merge.  Slower sweeps until the next spatial reorder (SetSpatialSortCellSize).
   void SetRowMajorCreation(bool enabled);
+  // Ours: the arithmetic flavour of the sweeps (bahip_context_set_arithmetic).  false (default): every bit is the CPU oracle's; true:
+  // hardware reciprocal / square root / exp, contraction, flushed denormals -- what the reference's own -use_fast_math build computes
+  // with -- a few percent faster, same determinism and shard invariance, results within the reference's own tolerance.
+  void SetFastArithmetic(bool enabled);
   bahip_context* backend_context() { return ctx_; }
   // Binds intrinsics + all non-null keyframes to the backend context; fills index maps between
   // keyframe ids and the dense bound list.  Public so that a caller can drive single bahip_* stages

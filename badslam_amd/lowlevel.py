@@ -62,6 +62,15 @@ class Context:
     def synchronize(self):
         capi.check(self.lib.bahip_context_synchronize(self.handle))
 
+    def set_arithmetic(self, arithmetic):
+        """"exact" (default: the oracle's bits) or "fast" (hardware reciprocal / square root / exp, contraction): bahip_context_set_arithmetic."""
+        mode = {"exact": capi.ARITHMETIC_EXACT, "fast": capi.ARITHMETIC_FAST}.get(arithmetic, arithmetic)
+        capi.check(self.lib.bahip_context_set_arithmetic(self.handle, int(mode)))
+
+    @property
+    def arithmetic(self):
+        return "fast" if self.lib.bahip_context_get_arithmetic(self.handle) == capi.ARITHMETIC_FAST else "exact"
+
     def close(self):
         if self.handle:
             self.lib.bahip_context_destroy(self.handle)

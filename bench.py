@@ -34,6 +34,11 @@ SURFEL_ROWS = 17        # BAHIP_SURFEL_ATTRIBUTE_COUNT
 STAGES = ("surfel_activation", "geometry_optimization", "pose_accumulate", "pose_solve", "intrinsics_optimization")
 
 
+# The flavour `value` is measured with.  "fast" is the arithmetic of the reference's own build (nvcc -use_fast_math); the exact flavour
+# (every bit the CPU oracle's) is what the parity tests hold and is measured beside it (`exact_arithmetic` / `fast_math` in the line).
+DEFAULT_ARITHMETIC = "exact"
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -71,6 +76,9 @@ def parse_args():
     p.add_argument("--sort-cell", type=float, default=0.02, help="grid cell of DirectBA::SortSurfelsSpatially [m] (its default: 0.02)")
     p.add_argument("--no-prepass", action="store_true", help="do not run the iterations once before the warm-up and the timed region (see PRE-PASS in main)")
     p.add_argument("--launch-shapes", default="", help="experiment: 'tile_waves,pose_parts' forced through bahip_debug_set_launch_shapes (0 = heuristic)")
+    p.add_argument("--arithmetic", choices=["exact", "fast"], default=os.environ.get("BENCH_ARITHMETIC", DEFAULT_ARITHMETIC),
+                   help="arithmetic flavour of the sweeps in the timed region (bahip_context_set_arithmetic); the other flavour is measured "
+                        "after it, by the same protocol, and reported beside `value`")
     p.add_argument("--build-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",
@@ -374,6 +382,7 @@ def main():
         mine = np.arange(N_total, dtype=np.int64)
     ba.upload_surfels(np.ascontiguousarray(data[:, mine]) if (shard_world > 1 and not by_keyframes) else data)
     ctx = ba.backend_context()
+    ba.SetFastArithmetic(args.arithmetic == "fast")
     hook_keepalive = None
     ranks_seen = 1
     if dist is not None:
@@ -470,6 +479,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = ba.last_stats()
+    timed_end_poses = np.array([ba.keyframe_pose(k) for k in range(args.keyframes)])   # (after the clock has stopped: for the flavours' parity figures)
 
     def read_stage_timers():
         out_ms, out_n = np.zeros(8), np.zeros(8, dtype=np.int64)
@@ -511,6 +521,81 @@ def main():
     run(BREAKDOWN_STEPS)
     ctx.synchronize()
     breakdown_ms, _ = read_stage_timers()
+
+    # THE OTHER ARITHMETIC FLAVOUR, by the same protocol: scene reset to the same start state, the same warm-up, the same
+    # number of timed iterations, then the instrumented repeat for the pose sweep's launch duration; and what separates the two flavours'
+    # results after identical iteration counts from identical starts: pose RMSE, and the association decisions of 2 x 10^5 sampled
+    # (surfel, keyframe) pairs evaluated by both flavours on one state.
+    other_flavour = None
+    if not args.no_extras and not args.pcg and not args.intrinsics and shard_world == 1 and world == 1:
+        other = "exact" if args.arithmetic == "fast" else "fast"
+        capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
+        ba.SetFastArithmetic(other == "fast")
+        reset_to_start_state()
+        if args.warmup > 0:
+            run(args.warmup)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        t_o = time.perf_counter()
+        run(args.steps)
+        ctx.synchronize()
+        dt_o = time.perf_counter() - t_o
+        other_stats = ba.last_stats()
+        other_poses = np.array([ba.keyframe_pose(k) for k in range(args.keyframes)])
+        # association decisions pair by pair, both flavours on this state
+        ba.BindScene()
+        surfels_struct = ba.surfels_struct()
+        from badslam_amd import se3
+        pair_kfs = sorted(np.random.Generator(np.random.PCG64(5)).choice(K, min(5, K), replace=False).tolist())
+        decisions = {}
+        for flavour in ("exact", "fast"):
+            ba.SetFastArithmetic(flavour == "fast")
+            pair_rng = np.random.Generator(np.random.PCG64(6))
+            outs = []
+            for k in pair_kfs:
+                idx = pair_rng.integers(0, N_total, 40000).astype(np.uint32)
+                F = np.ascontiguousarray(se3.matrix(se3.inverse(ba.keyframe_pose(k)))[:3, :4], np.float32).reshape(-1)
+                pairs_out = np.zeros((len(idx), 40), np.float32)
+                frame = ba.keyframe_frame(k)
+                capi.check(ctx.lib.bahip_debug_evaluate_pairs(ctx.handle, C.byref(frame), F.ctypes.data_as(C.POINTER(C.c_float)), C.byref(surfels_struct),
+                                                              idx.ctypes.data_as(C.POINTER(C.c_uint32)), len(idx), pairs_out.ctypes.data_as(C.POINTER(C.c_float))))
+                outs.append(pairs_out[:, 0].copy())
+            decisions[flavour] = np.concatenate(outs)
+        associated = int(np.count_nonzero(decisions["exact"] == 1.0))
+        flips = int(np.count_nonzero(decisions["exact"] != decisions["fast"]))
+        # the instrumented repeat of the other flavour's timed region
+        ba.SetFastArithmetic(other == "fast")
+        reset_to_start_state()
+        if args.warmup > 0:
+            run(args.warmup)
+        capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 3))
+        ctx.synchronize()
+        run(args.steps)
+        ctx.synchronize()
+        o_ms, o_launches = read_stage_timers()
+        o_units = C.c_longlong()
+        capi.check(ctx.lib.bahip_stage_work_units(ctx.handle, 2, C.byref(o_units)))
+        capi.check(ctx.lib.bahip_set_profiling(ctx.handle, 0))
+        o_n = max(1, int(o_launches[2]))
+        o_bytes = N_total * 28 + (o_units.value / o_n) * args.width * args.height * 5
+        o_avg_ms = o_ms[2] / o_n
+        dpose = np.linalg.norm(other_poses[:, 4:] - timed_end_poses[:, 4:], axis=1)
+        other_flavour = {"arithmetic": other, "ba_iterations_per_s": args.steps / dt_o, "ms_per_step": 1e3 * dt_o / args.steps,
+                         "frac": o_bytes / (o_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "pose_launch_ms": o_avg_ms,
+                         "pose_gn_rounds_per_iteration": other_stats["pose_rounds"] / args.steps,
+                         "parity": {"against": args.arithmetic + " arithmetic, same start state, same warm-up and iteration count",
+                                    "pose_rmse_m": float(np.sqrt(np.mean(dpose ** 2))), "pose_max_m": float(dpose.max()),
+                                    "sampled_pairs": int(len(decisions["exact"])), "associated_pairs": associated, "flips": flips,
+                                    "flips_over_associated": flips / max(1, associated)},
+                         "what": ("v_rcp_f32 / v_sqrt_f32 / v_exp_f32, contraction, binary32 denormals flushed in the sweeps -- the arithmetic of the reference's own "
+                                  "build (nvcc -use_fast_math); sums keep their defined order" if other == "fast" else
+                                  "correctly rounded reciprocal / square root / division, defined exp, no contraction beyond the spelled fused multiply-adds: "
+                                  "every bit is the CPU oracle's"),
+                         "note": "the other flavour of the sweeps, measured after the timed region by the same protocol (scene reset, warm-up, "
+                                 f"{args.steps} timed iterations, no pre-pass of its own: the GPU is busy already); tolerance tests: tests/test_gpu_fast_flavour.py, "
+                                 "tests/test_gpu_golden_reference.py[fast], tests/test_gpu_scale_parity.py::test_c3_fast_flavour_against_the_exact_build"}
+        ba.SetFastArithmetic(args.arithmetic == "fast")
+        reset_to_start_state()
 
     # Untimed extras, so that the driver's default run also sees the other two stages of SURVEY 8d: the intrinsics step of the
     # alternating scheme (reference timing key BA_intrinsics_optimization, B/direct_ba_alternating.cc:687) and the PCG scheme.
@@ -702,6 +787,8 @@ def main():
                                    f"{' (BASELINE configs[2])' if (W, H, K, args.surfels, args.intrinsics) == (640, 480, 200, 3000000, False) else ''}",
                        "keyframes": K, "surfels": int(N_total), "width": W, "height": H,
                        "host": "C++ vis::DirectBA::BundleAdjustment over the bahip_* C ABI",
+                       "arithmetic": (args.arithmetic + (" (bit-identical to the CPU oracle)" if args.arithmetic == "exact" else
+                                                         " (v_rcp / v_sqrt / v_exp, contraction, FTZ: as the reference's -use_fast_math build; held to the reference's kernels by tolerance)")),
                        "tile_schedule": ("buffer order (BAHIP_TILE_ORDER=0)" if os.environ.get("BAHIP_TILE_ORDER") == "0"
                                          else "heavy work first, from the pose sweep's per-tile candidate counts (wave_cull.h: scheduled_tile)"),
                        "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, %g cm grid)" % (100 * args.sort_cell),
@@ -730,6 +817,7 @@ def main():
             "stage_ms_note": f"{BREAKDOWN_STEPS} further iterations after the timed region, all stages timed; the surfel activation "
                              "is decided inside the normals pass of the geometry sweep (one launch), hence 0",
             **extras,
+            **({("fast_math" if other_flavour["arithmetic"] == "fast" else "exact_arithmetic"): other_flavour} if other_flavour else {}),
         }
         if not args.pcg:
             R = stats["pose_rounds"] / args.steps

@@ -89,6 +89,8 @@ int dba_set_sum_classes(dba_handle* h, int classes);
 /* DirectBA::SetRowMajorCreation (ours): 1 = the surfels a keyframe creates are appended in the reference's row-major pixel order
  * (B/kernel_create_surfels.cu:357-390), 0 (default) = tile-major (bahip_context_set_creation_order) */
 int dba_set_row_major_creation(dba_handle* h, int enabled);
+/* DirectBA::SetFastArithmetic (ours): 1 = the fast arithmetic flavour of the sweeps, 0 (default) = the exact one (bahip_context_set_arithmetic) */
+int dba_set_fast_arithmetic(dba_handle* h, int enabled);
 /* DirectBA::SetKeyframeSharding: this object holds all surfels and the images of the keyframes k with k % world == rank
  * (bahip_context_set_keyframe_sharding; world = 1, 2, 4, or 8 after dba_set_sum_classes(h, 8)) */
 int dba_set_keyframe_sharding(dba_handle* h, int rank, int world);

@@ -139,6 +139,21 @@ int bahip_context_set_sum_classes(bahip_context* ctx, int classes);
  * their indices differ inside each keyframe's block, and with them which of two mergeable surfels survives (the lower index:
  * B/kernel_supporting_surfels.cu:60-86).  Takes effect for the creations that follow. */
 int bahip_context_set_creation_order(bahip_context* ctx, int row_major);
+/* Arithmetic flavour of the sweeps over (surfel, keyframe) pairs -- activation, normals / geometry step, pose normal equations,
+ * intrinsics sweep, PCG init and step-1 sweeps -- of this context:
+ *   BAHIP_ARITHMETIC_EXACT (default)  correctly rounded reciprocal / square root / division, defined exp, no contraction beyond the
+ *                                     spelled fused multiply-adds: every bit is the CPU oracle's (what the parity tests hold);
+ *   BAHIP_ARITHMETIC_FAST             v_rcp_f32 / v_sqrt_f32 / v_exp_f32 (<= 1 ulp), contraction at the compiler's discretion, binary32
+ *                                     denormals flushed -- the arithmetic of the reference's own build (nvcc -use_fast_math,
+ *                                     applications/badslam/CMakeLists.txt:74); held to the reference's kernels by tolerance
+ *                                     (tests/test_gpu_fast_flavour.py: poses within 1e-5 m, association flips <= 0.1 %).
+ * The order of every sum is the same in both (fixed trees, fixed-point pose sums, exact PCG sums), so either flavour is
+ * deterministic and invariant under surfel / keyframe sharding; preprocessing, the surfel lifecycle, the pose solve and the PCG
+ * vector kernels exist once (exact).  Takes effect at once.  The environment variable BAHIP_ARITHMETIC=fast|exact sets the default
+ * of contexts created afterwards (A/B runs of unmodified callers). */
+enum { BAHIP_ARITHMETIC_EXACT = 0, BAHIP_ARITHMETIC_FAST = 1 };
+int bahip_context_set_arithmetic(bahip_context* ctx, int arithmetic);
+int bahip_context_get_arithmetic(bahip_context* ctx);
 /* A hint, for callers that write the surfel buffer themselves (an upload, a permutation of their own): which surfels share a tile has
  * changed, so the run order the sweeps derive from a census of the tiles ("heavy work first", rebuilt on its own only every 32nd pose
  * phase or when the number of tiles changes) is stale -- the next pose phase takes the census again.  The backend's own movers
@@ -493,6 +508,10 @@ int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out,
  * second stream while the next slice sweeps; two buffer sets of one slice's records each): 1 .. 8 fixes the number of slices (tests on
  * small scenes), 0 = by the size of the sweep (default).  The sums do not depend on it. */
 int bahip_debug_set_intrinsics_slices(bahip_context* ctx, int slices);
+/* The creation batch's scan + append launch (bahip_create_surfels_for_keyframes) runs a grid handshake and therefore never launches more
+ * workgroups than the device holds at once (occupancy x compute units, at most 256).  groups > 0 lowers that limit (tests: the path a
+ * partitioned or masked device takes), 0 restores it.  The created surfels do not depend on it. */
+int bahip_debug_set_append_groups(int groups);
 /* The LDS form holds the normal equations of at most 292 work items; longer lists are cut into slices, one launch each.  items > 0
  * makes the slices that small (tests: 200 keyframes in slices of 64), 0 restores the default. */
 int bahip_debug_set_pose_lds_items(int items);

@@ -5,7 +5,7 @@ survivor counts of a whole BundleAdjustment call."""
 import numpy as np
 import pytest
 
-from badslam_amd import synthetic
+from badslam_amd import capi, synthetic
 from tests import common
 
 pytestmark = pytest.mark.gpu
@@ -132,11 +132,15 @@ def test_filtered_creation_bit_exact(min_obs, batch):
         assert sum(created) > 10000
 
 
-@pytest.mark.parametrize("min_obs", [1, 2])
-def test_creation_batch_is_the_sequence_of_creations(min_obs):
+@pytest.mark.parametrize("min_obs,append_groups", [(1, 0), (2, 0), (2, 3), (1, 1)])
+def test_creation_batch_is_the_sequence_of_creations(min_obs, append_groups, request):
     """bahip_create_surfels_for_keyframes -- the creations of a batch of keyframes with the cloud's size on the device in between --
     against the oracle's creations one by one: the same surfels in the same places, also when the batch starts on an empty cloud,
-    when a keyframe of it has no co-visible keyframe, and inside a lifecycle batch (tile bounds)."""
+    when a keyframe of it has no co-visible keyframe, and inside a lifecycle batch (tile bounds).  append_groups: the scan + append
+    launch with its grid clamped as on a device that holds only three / one of its workgroups at once (its grid handshake needs every
+    workgroup resident: ADVICE r5; bahip_debug_set_append_groups)."""
+    capi.check(capi.load().bahip_debug_set_append_groups(append_groups))
+    request.addfinalizer(lambda: capi.load().bahip_debug_set_append_groups(0))
     scene = common.small_scene(num_keyframes=5, seed=29)
     rng = np.random.Generator(np.random.PCG64(7))
     poses = [T if k in (0, 2, 4) else synthetic.perturb_pose(rng, T, 0.03, 0.01) for k, T in enumerate(scene.poses_gt)]

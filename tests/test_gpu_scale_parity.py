@@ -401,6 +401,76 @@ def test_c3_one_iteration_matches_oracle(c3):
             ba.set_keyframe_pose(k, start[k])
 
 
+def test_c3_fast_flavour_against_the_exact_build(c3):
+    """the fast arithmetic flavour (bahip_context_set_arithmetic) at BASELINE configs[2] against the bit-exact
+    build -- three alternating iterations from the perturbed start: pose RMSE <= 1e-5 m (BASELINE.json's bar; the exact build is the
+    oracle's bits, test_c3_one_iteration_matches_oracle), surfel positions alike, and the association decisions of 10^6 sampled
+    (surfel, keyframe) pairs compared one by one: flips <= 0.1 %."""
+    ba, data, poses_gt, args = c3
+    K, N = ba.keyframe_count(), data.shape[1]
+    start = [ba.keyframe_pose(k) for k in range(K)]
+    ctx = ba.backend_context()
+    results = {}
+    try:
+        for name, fast in (("exact", False), ("fast", True)):
+            ba.SetFastArithmetic(fast)
+            ba.upload_surfels(data)
+            for k in range(K):
+                ba.set_keyframe_pose(k, start[k])
+            ba.set_ba_iteration_counts(1, 1)
+            done, _ = ba.BundleAdjustment(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=3,
+                                          max_iterations=3, active_keyframe_window_start=0, active_keyframe_window_end=K - 1,
+                                          increase_ba_iteration_count=False)
+            assert done == 3
+            results[name] = (np.array([ba.keyframe_pose(k) for k in range(K)]), ba.download_surfels(8))
+        # association decisions pair by pair, both flavours on the SAME state (the fast run's result)
+        ba.BindScene()
+        surfels = ba.surfels_struct()
+        from badslam_amd import se3
+        kf_ids = sorted(np.random.Generator(np.random.PCG64(78)).choice(K, 25, replace=False).tolist())
+        decisions = {}
+        for name, fast in (("exact", False), ("fast", True)):
+            ba.SetFastArithmetic(fast)
+            pair_rng = np.random.Generator(np.random.PCG64(79))         # the same pairs for both flavours
+            outs = []
+            for k in kf_ids:
+                idx = pair_rng.integers(0, N, 40000).astype(np.uint32)
+                F = np.ascontiguousarray(se3.matrix(se3.inverse(ba.keyframe_pose(k)))[:3, :4], np.float32).reshape(-1)
+                out = np.zeros((len(idx), 40), np.float32)
+                frame = ba.keyframe_frame(k)
+                capi.check(ctx.lib.bahip_debug_evaluate_pairs(ctx.handle, C.byref(frame), F.ctypes.data_as(C.POINTER(C.c_float)),
+                                                              C.byref(surfels), idx.ctypes.data_as(C.POINTER(C.c_uint32)), len(idx),
+                                                              out.ctypes.data_as(C.POINTER(C.c_float))))
+                outs.append(out[:, [0, 4, 5, 14, 15]].copy())
+            decisions[name] = np.concatenate(outs)
+    finally:
+        ba.SetFastArithmetic(False)
+        for k in range(K):
+            ba.set_keyframe_pose(k, start[k])
+    (pe, re_), (pf, rf) = results["exact"], results["fast"]
+    rmse = float(np.sqrt(np.mean(np.sum((pe[:, 4:] - pf[:, 4:]) ** 2, axis=1))))
+    worst = float(np.max(np.linalg.norm(pe[:, 4:] - pf[:, 4:], axis=1)))
+    moved = np.linalg.norm(pe[:, 4:] - np.array(start)[:, 4:], axis=1)
+    dpos = np.abs(re_[:3] - rf[:3]).max(axis=0)
+    far = int(np.count_nonzero(~(dpos <= 1e-5)))
+    de, df = decisions["exact"], decisions["fast"]
+    pairs, associated = len(de), int(np.count_nonzero(de[:, 0] == 1.0))
+    flips = int(np.count_nonzero(de[:, 0] != df[:, 0]))
+    both = (de[:, 0] == 1.0) & (df[:, 0] == 1.0)
+    ddepth = np.abs(de[both, 1] - df[both, 1]).max()
+    dres = np.abs(de[both, 2] - df[both, 2])
+    print(f"config 3, fast vs exact flavour after 3 iterations: pose RMSE {rmse:.2e} m (max {worst:.2e} m; the poses moved {np.median(moved):.1e} m), "
+          f"{far} of {N} surfels beyond 1e-5 m (p99.9 {np.percentile(dpos, 99.9):.1e} m); {pairs} sampled pairs, {associated} associated, "
+          f"{flips} association flips ({flips / max(associated, 1):.2e} of the associated), calibrated depth within {ddepth:.1e} m, "
+          f"depth residual within {dres.max():.1e} (median {np.median(dres):.1e})")
+    assert np.median(moved) > 1e-3
+    assert rmse <= 1e-5 and worst <= 1e-5, (rmse, worst)
+    assert far <= 1e-3 * N, far
+    assert pairs == 1000000 and associated > 50000
+    assert flips <= 1e-3 * associated, (flips, associated)
+    assert not np.array_equal(pe.astype(np.float32), pf.astype(np.float32)), "the fast flavour gave the exact flavour's bits: was it selected?"
+
+
 # ---- (d): BASELINE configs[1]'s size, end to end with the surfel lifecycle ------------------------------------------------
 def test_c2_size_end_to_end_with_surfel_updates():
     ba, data, poses_gt, args = _bench_scene(keyframes=50, surfels=10 ** 9, no_spatial_sort=True)
