@@ -90,6 +90,9 @@ SIGNATURES = {
     "bahip_context_set_keyframe_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bahip_context_set_sum_classes": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_context_set_creation_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "bahip_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "bahip_host_free": (C.c_int, [C.c_void_p]),
+    "bahip_host_is_pinned": (C.c_int, [C.c_void_p, C.c_size_t]),
     "bahip_context_set_arithmetic": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_context_get_arithmetic": (C.c_int, [C.c_void_p]),
     "bahip_debug_set_tile_order": (C.c_int, [C.c_int]),

@@ -361,6 +361,26 @@ int bahip_memcpy_async(void* stream, void* dst, const void* src, size_t bytes, i
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, k, static_cast<hipStream_t>(stream)));
   return 0;
 }
+int bahip_host_alloc(void** ptr, size_t bytes) {
+  REQUIRE(ptr != nullptr, "bahip_host_alloc: NULL argument");
+  HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return 0;
+}
+int bahip_host_free(void* ptr) {
+  if (ptr) HIP_TRY(hipHostFree(ptr));
+  return 0;
+}
+int bahip_host_is_pinned(const void* ptr, size_t bytes) {
+  if (!ptr) return 0;
+  hipPointerAttribute_t first{}, last{};
+  if (hipPointerGetAttributes(&first, ptr) != hipSuccess) { (void)hipGetLastError(); return 0; }   // unknown to the runtime: pageable
+  if (first.type != hipMemoryTypeHost) return 0;
+  if (bytes > 1) {
+    if (hipPointerGetAttributes(&last, static_cast<const char*>(ptr) + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (last.type != hipMemoryTypeHost) return 0;
+  }
+  return 1;
+}
 int bahip_memset_async(void* stream, void* dst, int value, size_t bytes) {
   HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
   return 0;

@@ -47,38 +47,45 @@ class CUDABuffer {
   const CUDABuffer_<T>& ToCUDA() const { return data_; }
   CUDABuffer_<T>& ToCUDA() { return data_; }
 
+  // The *Async transfers return with the copy in flight on `stream` when the host range is page-locked (bahip_host_alloc,
+  // hipHostMalloc, hipHostRegister) -- cudaMemcpy2DAsync's behaviour, libvis/src/libvis/cuda/cuda_buffer_inl.h:73-90 -- and wait for
+  // it when the range is pageable, where the CUDA runtime stages an upload and completes a download before it returns (a caller of
+  // the reference that passes a std::vector and reads it right after DownloadAsync relies on exactly that).
+  static void FinishTransfer(hipStream_t stream, const void* host, size_t bytes) {
+    if (!bahip_host_is_pinned(host, bytes)) BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+  }
   // dense host array (width*height elements)
   void UploadAsync(hipStream_t stream, const T* host) {
     BAHIP_CHECKED_CALL(bahip_memcpy_2d_async(stream, data_.address_, data_.pitch_, host, (size_t)data_.width_ * sizeof(T),
                                              (size_t)data_.width_ * sizeof(T), (size_t)data_.height_, 1));
-    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));   // pageable host memory
+    FinishTransfer(stream, host, (size_t)data_.width_ * sizeof(T) * (size_t)data_.height_);
   }
   void UploadAsync(hipStream_t stream, const Image<T>& image) {
     CHECK_EQ((int)image.width(), data_.width_); CHECK_EQ((int)image.height(), data_.height_);
     BAHIP_CHECKED_CALL(bahip_memcpy_2d_async(stream, data_.address_, data_.pitch_, image.data(), image.stride(),
                                              (size_t)data_.width_ * sizeof(T), (size_t)data_.height_, 1));
-    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    FinishTransfer(stream, image.data(), image.stride() * (size_t)data_.height_);
   }
   void DownloadAsync(hipStream_t stream, T* host) const {
     BAHIP_CHECKED_CALL(bahip_memcpy_2d_async(stream, host, (size_t)data_.width_ * sizeof(T), data_.address_, data_.pitch_,
                                              (size_t)data_.width_ * sizeof(T), (size_t)data_.height_, 2));
-    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    FinishTransfer(stream, host, (size_t)data_.width_ * sizeof(T) * (size_t)data_.height_);
   }
   void DownloadAsync(hipStream_t stream, Image<T>* image) const {
     CHECK_EQ((int)image->width(), data_.width_); CHECK_EQ((int)image->height(), data_.height_);
     BAHIP_CHECKED_CALL(bahip_memcpy_2d_async(stream, image->data(), image->stride(), data_.address_, data_.pitch_,
                                              (size_t)data_.width_ * sizeof(T), (size_t)data_.height_, 2));
-    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    FinishTransfer(stream, image->data(), image->stride() * (size_t)data_.height_);
   }
   // byte ranges relative to the start of the allocation (used to move single surfel rows,
   // B/direct_ba.cc:469, test_geometry_optimization_geometric_residual.cc:159-161)
   void UploadPartAsync(size_t start_bytes, size_t length_bytes, hipStream_t stream, const T* host) {
     BAHIP_CHECKED_CALL(bahip_memcpy_async(stream, reinterpret_cast<char*>(data_.address_) + start_bytes, host, length_bytes, 1));
-    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    FinishTransfer(stream, host, length_bytes);
   }
   void DownloadPartAsync(size_t start_bytes, size_t length_bytes, hipStream_t stream, T* host) const {
     BAHIP_CHECKED_CALL(bahip_memcpy_async(stream, host, reinterpret_cast<const char*>(data_.address_) + start_bytes, length_bytes, 2));
-    BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+    FinishTransfer(stream, host, length_bytes);
   }
   void Clear(T value, hipStream_t stream) {
     static_assert(sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4, "Clear() supports 1/2/4-byte elements");

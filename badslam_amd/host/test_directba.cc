@@ -520,6 +520,43 @@ int IntrinsicsOptimizationWithGeometricResidual(bool use_pcg) {
   return failures;
 }
 
+// Ours: CUDABuffer<T>::*Async follow cudaMemcpy2DAsync (libvis/src/libvis/cuda/cuda_buffer_inl.h:73-90) -- a transfer
+// from / to page-locked memory is left in flight on the stream, one from / to pageable memory has completed when the call returns.
+int CUDABufferAsyncTransfers() {
+  int failures = 0;
+  const int w = 333, h = 77;
+  void* stream = nullptr;
+  BAHIP_CHECKED_CALL(bahip_stream_create(&stream));
+  CUDABuffer<float> buffer(h, w), copy(h, w);
+  void* pinned_raw = nullptr;
+  BAHIP_CHECKED_CALL(bahip_host_alloc(&pinned_raw, 2 * sizeof(float) * w * h));
+  float* pinned = static_cast<float*>(pinned_raw);
+  std::vector<float> pageable((size_t)w * h), back((size_t)w * h, -1.f);
+  for (int i = 0; i < w * h; ++i) { pinned[i] = 0.5f * (float)i; pageable[i] = (float)i - 3.f; }
+  EXPECT_TRUE(bahip_host_is_pinned(pinned, sizeof(float) * w * h) == 1, "page-locked memory not recognised");
+  EXPECT_TRUE(bahip_host_is_pinned(pageable.data(), sizeof(float) * w * h) == 0, "pageable memory taken for page-locked");
+  // pageable: complete on return (no explicit synchronisation before the data is looked at)
+  buffer.UploadAsync((hipStream_t)stream, pageable.data());
+  buffer.DownloadAsync((hipStream_t)stream, back.data());
+  EXPECT_TRUE(back == pageable, "pageable round trip");
+  // page-locked: in flight; ordered on the stream; complete after the stream has been waited for
+  buffer.UploadAsync((hipStream_t)stream, pinned);
+  copy.SetTo(buffer, (hipStream_t)stream);
+  copy.DownloadAsync((hipStream_t)stream, pinned + (size_t)w * h);
+  BAHIP_CHECKED_CALL(bahip_stream_synchronize(stream));
+  int wrong = 0;
+  for (int i = 0; i < w * h; ++i) wrong += pinned[(size_t)w * h + i] != pinned[i];
+  EXPECT_TRUE(wrong == 0, "%d elements differ after the page-locked round trip", wrong);
+  // a single row as a byte range (B/direct_ba.cc:469)
+  buffer.UploadPartAsync(5 * buffer.ToCUDA().pitch(), sizeof(float) * w, (hipStream_t)stream, pageable.data());
+  std::vector<float> row(w, -1.f);
+  buffer.DownloadPartAsync(5 * buffer.ToCUDA().pitch(), sizeof(float) * w, (hipStream_t)stream, row.data());
+  EXPECT_TRUE(std::equal(row.begin(), row.end(), pageable.begin()), "row round trip");
+  BAHIP_CHECKED_CALL(bahip_host_free(pinned_raw));
+  BAHIP_CHECKED_CALL(bahip_stream_destroy(stream));
+  return failures;
+}
+
 struct TestCase { const char* name; std::function<int()> fn; };
 
 }  // namespace
@@ -538,6 +575,7 @@ int main(int argc, char** argv) {
       {"PCGDepthDeformationOptimizationWithGeometricResidual", [] { return DepthDeformationOptimizationWithGeometricResidual(true); }},
       {"AlternatingIntrinsicsOptimizationWithGeometricResidual", [] { return IntrinsicsOptimizationWithGeometricResidual(false); }},
       {"PCGIntrinsicsOptimizationWithGeometricResidual", [] { return IntrinsicsOptimizationWithGeometricResidual(true); }},
+      {"CUDABufferAsyncTransfers", CUDABufferAsyncTransfers},
   };
   if (bahip_device_count() <= 0) { printf("no HIP device: these tests need an MI355X\n"); return 99; }
   for (const TestCase& t : tests) {

@@ -187,6 +187,14 @@ int bahip_memcpy_2d_async(void* hip_stream, void* dst, size_t dst_pitch, const v
                           size_t width_bytes, size_t height, int kind);
 int bahip_memcpy_async(void* hip_stream, void* dst, const void* src, size_t bytes, int kind);
 int bahip_memset_async(void* hip_stream, void* dst, int value, size_t bytes);
+/* Page-locked host memory, and the question CUDABuffer<T>::UploadAsync / DownloadAsync ask before they return: a transfer to or from
+ * page-locked memory is left in flight on the stream, as cudaMemcpy2DAsync leaves it (libvis/src/libvis/cuda/cuda_buffer_inl.h:73-90);
+ * for pageable memory the call waits, which is what the CUDA runtime does there too (the copy is staged, a download has completed
+ * when the call returns).  bahip_host_is_pinned: 1 if both ends of [ptr, ptr + bytes) are page-locked host memory
+ * (bahip_host_alloc, hipHostMalloc, hipHostRegister), else 0. */
+int bahip_host_alloc(void** ptr, size_t bytes);
+int bahip_host_free(void* ptr);
+int bahip_host_is_pinned(const void* ptr, size_t bytes);
 /* CUDABuffer<T>::Clear(value, stream) (libvis/src/libvis/cuda/cuda_buffer.cu:41-60) for 1/2/4-byte T. */
 int bahip_fill_2d(void* hip_stream, void* data, size_t pitch_bytes, int elem_bytes, uint32_t value_bits, int width, int height);
 

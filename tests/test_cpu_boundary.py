@@ -61,3 +61,20 @@ def test_product_package_does_not_import_the_oracle():
                        (top != "scripts" and "oracle/" in text):
                         offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
     assert not offenders, offenders
+
+
+def test_build_refuses_an_unpinned_compiler(tmp_path, monkeypatch):
+    """__graft_entry__.check_toolchain: the pinned `hipcc --version` passes, any other fails the build loudly
+    unless BADSLAM_ACCEPT_TOOLCHAIN=1 says the GPU suite is about to be re-run with it."""
+    import shutil
+    import __graft_entry__ as entry
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box")
+    entry.check_toolchain()
+    other = tmp_path / "TOOLCHAIN.txt"
+    other.write_text("HIP version: 0.0.0-none\nAMD clang version 0.0.0\n")
+    monkeypatch.delenv("BADSLAM_ACCEPT_TOOLCHAIN", raising=False)
+    with pytest.raises(RuntimeError, match="not the pinned toolchain"):
+        entry.check_toolchain(str(other))
+    monkeypatch.setenv("BADSLAM_ACCEPT_TOOLCHAIN", "1")
+    entry.check_toolchain(str(other))

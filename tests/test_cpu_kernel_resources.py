@@ -24,16 +24,32 @@ def _makefile_flags():
     return [f for f in flags.replace("$(ARCH)", arch).split() if f != "-fPIC"]
 
 
+def _fast_flags(unit):
+    """FASTFLAGS + the unit's FASTFTZ_<unit> of the Makefile (the fast arithmetic flavour: ba_launch.h)."""
+    text = open(os.path.join(CSRC, "Makefile")).read()
+    fast = re.search(r"^FASTFLAGS \?= (.*)$", text, re.M).group(1).split()
+    ftz = re.search(r"^FASTFTZ \?= (.*)$", text, re.M).group(1).split()
+    per_unit = re.search(r"^FASTFTZ_%s \?=(.*)$" % unit, text, re.M).group(1).strip()
+    return fast + (ftz if per_unit == "$(FASTFTZ)" else per_unit.split())
+
+
+def _compile(d, name, extra, suffix):
+    path = str(d / (name + suffix + ".s"))
+    subprocess.run([HIPCC] + _makefile_flags() + extra + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", path,
+                    os.path.join(CSRC, name + ".hip")], check=True, timeout=900, capture_output=True)
+    return open(path).read()
+
+
 @pytest.fixture(scope="module")
 def listings(tmp_path_factory):
-    out = {}
     d = tmp_path_factory.mktemp("isa")
-    for name in ("kernels_surfel", "kernels_pose", "kernels_pcg"):
-        path = str(d / (name + ".s"))
-        subprocess.run([HIPCC] + _makefile_flags() + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", path,
-                        os.path.join(CSRC, name + ".hip")], check=True, timeout=900, capture_output=True)
-        out[name] = open(path).read()
-    return out
+    return {name: _compile(d, name, [], "") for name in ("kernels_surfel", "kernels_pose", "kernels_pcg")}
+
+
+@pytest.fixture(scope="module")
+def fast_listings(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa_fast")
+    return {name: _compile(d, name, _fast_flags(name), "_fast") for name in ("kernels_surfel", "kernels_pose")}
 
 
 def _kernels(listing):
@@ -66,6 +82,30 @@ def test_hot_kernels_keep_four_waves_per_simd_without_spills(listings):
             assert scratch <= (64 if unit == "kernels_pcg" else 0), (name, scratch)
             assert not re.search(r"\bv_pk_(fma|mul|add)_f32\b", body), name       # SLP packing stays off
     assert seen >= 12
+
+
+def test_fast_flavour_of_the_sweeps_keeps_the_budget_and_is_shorter(listings, fast_listings):
+    """The fast arithmetic flavour (Makefile: *_fast.o): its own namespace (no symbol shared with the exact kernels: the linker must
+    never pick one flavour's body for the other), the same register budget without spills (FTZ is off in the pose unit for exactly
+    that reason), and fewer VALU instructions -- raw v_rcp_f32 / v_sqrt_f32 instead of the correctly rounded sequences."""
+    def valu(body):
+        return len(re.findall(r"^\s+v_", body, re.M))
+    for unit, pick in (("kernels_surfel", "geometry_kernelILb1ELb1ELi1ELb1"), ("kernels_pose", "pose_accumulate_lds_kernelILb1ELb1ELb0")):
+        exact = {k: v for k, v in _kernels(listings[unit]).items() if pick in k}
+        fast = {k: v for k, v in _kernels(fast_listings[unit]).items() if pick in k}
+        assert len(exact) == len(fast) == 1
+        (en, (eb, ev, es, eo)), (fn, (fb, fv, fs, fo)) = next(iter(exact.items())), next(iter(fast.items()))
+        assert "5exact" in en and "4fast" in fn, (en, fn)
+        assert fv <= 128 and fo >= 4 and fs == 0, (fn, fv, fo, fs)
+        assert valu(fb) < 0.95 * valu(eb), (unit, valu(fb), valu(eb))
+        # the exact flavour's reciprocals end in v_div_fixup_f32 (ba_device.h: rcp_exact), the fast flavour's are bare v_rcp_f32 (what is
+        # left there: 1 / baseline_fx of a kernel argument, once per launch)
+        # (and a few per-surfel divisions whose operands the compiler cannot bound)
+        assert eb.count("v_div_fixup_f32") >= 5 and 4 * fb.count("v_div_fixup_f32") <= eb.count("v_div_fixup_f32"), (unit, eb.count("v_div_fixup_f32"), fb.count("v_div_fixup_f32"))
+    # nothing but the sweeps is compiled a second time: no solve / schedule / debug kernel in the fast unit
+    names = list(_kernels(fast_listings["kernels_pose"]))
+    assert names and all("4fast" in n for n in names), names
+    assert not any("pose_solve" in n or "tile_order" in n for n in names)
 
 
 def test_reductions_use_the_gfx950_cross_lane_instructions(listings):

@@ -20,7 +20,8 @@ BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
                                   "AlternatingDepthDeformationOptimizationWithGeometricResidual",
                                   "PCGDepthDeformationOptimizationWithGeometricResidual",
                                   "AlternatingIntrinsicsOptimizationWithGeometricResidual",
-                                  "PCGIntrinsicsOptimizationWithGeometricResidual"])
+                                  "PCGIntrinsicsOptimizationWithGeometricResidual",
+                                  "CUDABufferAsyncTransfers"])
 def test_reference_closed_loop(name):
     assert os.path.exists(BIN), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     proc = subprocess.run([BIN, name], capture_output=True, text=True, timeout=600)
