@@ -794,7 +794,14 @@ def main():
                        "surfel_order": "creation order" if args.no_spatial_sort else "DirectBA::SortSurfelsSpatially (Morton, %g cm grid)" % (100 * args.sort_cell),
                        "parallelism": (f"keyframe-shard x{world}, RCCL all-reduce of the geometry step's class partials and of pose H,b" if by_keyframes
                                        else f"surfel-shard x{world}, RCCL all-reduce of pose H,b") if world > 1 else "single GPU"},
-            **({"emulated_share_of_world": shard_world} if shard_world != world else {}),
+            **({"emulated_share_of_world": shard_world,
+                "emulated_share_with_link": {
+                    "exchanges_per_iteration": stats["pose_rounds"] / args.steps,
+                    "assumed_us_per_exchange": [20, 40],
+                    "ms_per_step_with_link": [1e3 * elapsed / args.steps + 1e-3 * us * stats["pose_rounds"] / args.steps for us in (20, 40)],
+                    "note": "one rank's share of the surfels on one GPU, every exchange a no-op: no link time is in ms_per_step.  A real run adds one "
+                            "all-reduce of K x 56 int64 (21.6 KB at 200 keyframes: latency-bound, SURVEY 8e: 20-40 us over xGMI) per Gauss-Newton "
+                            "round; ms_per_step_with_link adds that budget.  Not a measurement of a multi-GPU run."}} if shard_world != world else {}),
             **({"exchange": {"calls_per_iteration": exchange_calls.value / args.steps, "bytes_per_iteration": exchange_bytes.value / args.steps,
                              "what": "int64 fixed-point pose normal equations, one all-reduce per Gauss-Newton round"
                                      + ("; binary64 intrinsics accumulators" if args.intrinsics else "")
