@@ -16,7 +16,8 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0].replace("bahip::", "").replace("(anonymous namespace)::", "").replace("void ", "")[:70]
+    # (the sweeps live in bahip::exact / bahip::fast, one arithmetic flavour each; a profile run uses one of them: config["arithmetic"])
+    return name.split("(")[0].replace("bahip::", "").replace("exact::", "").replace("fast::", "").replace("(anonymous namespace)::", "").replace("void ", "")[:70]
 
 
 def counters_of(d, sub):
@@ -162,8 +163,14 @@ def main():
         p.add_argument("--" + name, type=int, default=default)
     p.add_argument("--intrinsics", action="store_true")
     p.add_argument("--pcg", action="store_true")
+    p.add_argument("--arithmetic", default=None)
     a, _ = p.parse_known_args(sys.argv[3:])
-    config = {"keyframes": a.keyframes, "surfels": a.surfels, "width": a.width, "height": a.height, "intrinsics": a.intrinsics, "pcg": a.pcg}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from badslam_amd import buildinfo
+    arithmetic = a.arithmetic or os.environ.get("BENCH_ARITHMETIC", bench.DEFAULT_ARITHMETIC)
+    config = {"keyframes": a.keyframes, "surfels": a.surfels, "width": a.width, "height": a.height, "intrinsics": a.intrinsics, "pcg": a.pcg,
+              "arithmetic": arithmetic}
 
     stats = glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
@@ -224,7 +231,8 @@ def main():
     windows, stats_line = timed_window(d)
     flat = {name: flatten_window(name, e, config) for name, e in windows.items()}
     flat = {k: v for k, v in flat.items() if v}
-    out = {"config": config, "tag": tag, "kernels": kernels, "fetch_calibration": cal, "timed_window": flat}
+    out = {"config": config, "tag": tag, "kernels": kernels, "fetch_calibration": cal, "timed_window": flat,
+           "csrc_digest": buildinfo.csrc_digest()}   # bench.py quotes these counters only while the kernel sources are the ones profiled
     if flat and cal:
         print("\ntimed region of the profile run (sums over its dispatches; bench.py divides these like by like):")
         for name, r in flat.items():
