@@ -93,6 +93,8 @@ SIGNATURES = {
     "bahip_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "bahip_host_free": (C.c_int, [C.c_void_p]),
     "bahip_host_is_pinned": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "bahip_merge_surfels_for_keyframes": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(Frame), C.POINTER(C.c_float), C.c_int, C.POINTER(Surfels),
+                                                   C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]),
     "bahip_context_set_arithmetic": (C.c_int, [C.c_void_p, C.c_int]),
     "bahip_context_get_arithmetic": (C.c_int, [C.c_void_p]),
     "bahip_debug_set_tile_order": (C.c_int, [C.c_int]),

@@ -236,6 +236,13 @@ void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntr
 void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
                   float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* cell_of, bool empty_the_planes, uint32_t* deleted_count,
                   const LifecycleCull& cull = LifecycleCull());
+void launch_merge_decide(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                         float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* cell_of, const LifecycleCull& cull);
+// one launch: the apply sweep of apply_frame (NULL: none) beside the insert sweep of insert_frame (NULL: none); flags must have been
+// cleared before the batch's first decide (kernels_lifecycle.hip: merge_apply_insert_kernel)
+void launch_merge_apply_insert(hipStream_t st, const Intrinsics& in, const KfEntry* apply_frame, const KfEntry* insert_frame, const SurfelsView& s,
+                               const uint32_t* flags, const uint32_t* cell_of, const SupportingView& apply_sup, const SupportingView& insert_sup,
+                               uint32_t* deleted_count, const LifecycleCull& apply_cull, const LifecycleCull& insert_cull);
 // a creation batch: scan + append at *size_in + the new size into *size_out (or *capacity_exceeded raised and nothing appended) in one
 // launch; group_words: create_append_groups() words, cleared before tag 1 and whenever a tag (1 .. 255) would repeat
 int create_append_groups();

@@ -278,6 +278,7 @@ void bahip_context_destroy(bahip_context* ctx) {
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
   if (ctx->intr_aux_stream) { hipStreamDestroy(ctx->intr_aux_stream); for (hipEvent_t e : ctx->intr_events) if (e) hipEventDestroy(e); }
   hipFree(ctx->intr_scratch); hipFree(ctx->pcg_buf); hipFree(ctx->pcg_exact); hipFree(ctx->pcg_stage_ctl); hipFree(ctx->kf_partials);
+  for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) hipFree(ctx->merge_planes[b]);
   hipFree(ctx->dev_tile_cost); hipFree(ctx->dev_tile_order);
   hipFree(ctx->dev_loop_ctl);
   if (ctx->host_loop_ctl) hipHostFree(ctx->host_loop_ctl);

@@ -128,6 +128,8 @@ struct bahip_context {
   uint8_t* dev_window = nullptr;
   size_t window_capacity = 0;
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
+  uint32_t* merge_planes[BAHIP_MERGE_BUFFER_COUNT] = {};   // the second set of supporting planes of a pipelined merge batch (bahip_merge_surfels_for_keyframes)
+  size_t merge_planes_bytes = 0;
   const void* supporting_planes_empty = nullptr;   // the supporting planes (by their first plane) that the last merge call left empty
   bool row_major_creation = false;   // new surfels of a keyframe appended in row-major pixel order (the reference's) instead of tile-major
   bool poll_disabled = false;        // the host copy of the pose counters is not updated by the kernel on this system: synchronise instead

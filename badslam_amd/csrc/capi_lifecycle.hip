@@ -92,6 +92,71 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
   return determine_supporting_impl(ctx, merge, merge_dist_factor, e, surfels, sup, merged_count_out);
 }
 
+// The merges of a batch of keyframes, pipelined: per keyframe two dependent launches -- [apply of the previous keyframe beside the insert
+// of this one], decide -- instead of three (kernels_lifecycle.hip: merge_apply_insert_kernel).  The keyframes alternate between the
+// caller's supporting planes and a second set the context owns; both end empty.
+int bahip_merge_surfels_for_keyframes(bahip_context* ctx, float merge_dist_factor, const bahip_frame* frames, const float* frame_T_global_3x4,
+                                      int num_frames, const bahip_surfels* surfels, uint32_t* const* supporting, uint32_t supporting_pitch,
+                                      uint32_t* merged_count_out) {
+  REQUIRE_NO_KF_SHARDING("bahip_merge_surfels_for_keyframes");
+  REQUIRE(ctx->have_intrinsics, "bahip_set_intrinsics not called");
+  REQUIRE(num_frames >= 0 && (num_frames == 0 || (frames != nullptr && frame_T_global_3x4 != nullptr)) && surfels != nullptr,
+          "bahip_merge_surfels_for_keyframes: NULL argument");
+  SupportingView sup[2];
+  REQUIRE(supporting_view(supporting, supporting_pitch, &sup[0]) == 0, "supporting-surfel planes missing");
+  if (merged_count_out) *merged_count_out = 0;
+  hipStream_t st = ctx->stream;
+  if (num_frames > 0 && surfels->surfels_size > 0) {
+    // the second set of planes: same pitch, the sparse-cell region's rows
+    const size_t plane_bytes = (size_t)supporting_pitch * (size_t)ctx->in.cf_height;
+    if (plane_bytes > ctx->merge_planes_bytes) {
+      for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) {
+        hipFree(ctx->merge_planes[b]);
+        ctx->merge_planes[b] = nullptr;
+      }
+      ctx->merge_planes_bytes = 0;
+      for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) HIP_TRY(hipMalloc(&ctx->merge_planes[b], plane_bytes));
+      ctx->merge_planes_bytes = plane_bytes;
+    }
+    for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) sup[1].b[b] = ctx->merge_planes[b];
+    sup[1].pitch = supporting_pitch;
+    if (ctx->supporting_planes_empty != sup[0].b[0]) launch_supporting_fill(st, sup[0], ctx->in.cf_width, ctx->in.cf_height);
+    launch_supporting_fill(st, sup[1], ctx->in.cf_width, ctx->in.cf_height);
+    ctx->supporting_planes_empty = nullptr;
+    const float cell = (float)ctx->in.cell;
+    const float cell_merge_dist_sq = cell * cell * merge_dist_factor * merge_dist_factor;
+    // per-surfel decision words and cells live in accum rows 0 and 1 (scratch by contract, B/kernels.cuh:78-90); the decision words
+    // start cleared: an insert sweep reads them for surfels no decide sweep of this batch has visited
+    uint32_t* flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
+    uint32_t* cell_of = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)(kSurfelAccum0 + 1) * surfels->pitch_bytes);
+    HIP_TRY(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)surfels->surfels_size, st));
+    uint32_t* counter = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3;   // the deferred count of bahip_take_merged_count
+    const SurfelsView s = make_view(surfels);
+    std::vector<KfEntry> entries((size_t)num_frames);
+    std::vector<LifecycleCull> culls((size_t)num_frames);
+    for (int j = 0; j <= num_frames; ++j) {
+      if (j < num_frames) {
+        // (here, not up front: frames handed over without BA planes share ONE packing slot of the context, re-packed on the stream by
+        // make_entry -- behind keyframe j - 1's decide sweep, the last reader of the previous packing; an apply sweep reads no image)
+        if (make_entry(ctx, frames[j], 0, &entries[j])) return 1;
+        memcpy(entries[j].pose.F, frame_T_global_3x4 + 12 * (size_t)j, 12 * sizeof(float));
+        culls[j] = lifecycle_cull_for(ctx, surfels, entries[j].pose.F);
+      }
+      // [apply of keyframe j - 1] beside [insert of keyframe j]
+      launch_merge_apply_insert(st, ctx->in, j > 0 ? &entries[j - 1] : nullptr, j < num_frames ? &entries[j] : nullptr, s, flags, cell_of,
+                                sup[(j + 1) & 1], sup[j & 1], counter, j > 0 ? culls[j - 1] : LifecycleCull(), j < num_frames ? culls[j] : LifecycleCull());
+      CHECK_LAUNCH();
+      if (j < num_frames) {
+        launch_merge_decide(st, ctx->in, entries[j], s, sup[j & 1], cell_merge_dist_sq, kCosNormalCompat, flags, cell_of, culls[j]);
+        CHECK_LAUNCH();
+      }
+    }
+    ctx->supporting_planes_empty = sup[0].b[0];   // (every apply sweep left its set empty)
+  }
+  if (merged_count_out) return bahip_take_merged_count(ctx, merged_count_out);
+  return 0;
+}
+
 int bahip_lifecycle_batch_begin(bahip_context* ctx, const bahip_surfels* surfels) {
   REQUIRE(surfels != nullptr, "bahip_lifecycle_batch_begin: NULL argument");
   ctx->lifecycle_bounds_tiles = 0;

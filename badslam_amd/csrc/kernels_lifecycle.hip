@@ -46,8 +46,9 @@ struct LifecycleBounds {
   uint32_t list_count;
 };
 // The surfel of this thread, or false if there is none.  Wave-uniform tile; without a list: the plain index and the bound test.
-__device__ __forceinline__ bool lifecycle_surfel(const Intrinsics& in, const KfEntry& frame, const LifecycleBounds& lb, uint32_t size, uint32_t* index) {
-  const uint32_t t = blockIdx.x * kLcBlock + threadIdx.x;
+__device__ __forceinline__ bool lifecycle_surfel(const Intrinsics& in, const KfEntry& frame, const LifecycleBounds& lb, uint32_t size, uint32_t* index,
+                                                 uint32_t block /* of this sweep: blockIdx.x, or its offset inside a launch that runs two sweeps */) {
+  const uint32_t t = block * kLcBlock + threadIdx.x;
   if (lb.list) {
     const uint32_t w = t >> 6;
     const uint32_t tile = w < lb.list_count ? lb.list[w] : lb.tiles + (w - lb.list_count);
@@ -93,11 +94,14 @@ lifecycle_bounds_kernel(SurfelsView s, uint32_t tiles, WaveBounds* __restrict__ 
 }
 
 // Phase A: every associated surfel offers its index to the cell's slot chain.
-__global__ void __launch_bounds__(kLcBlock)
-supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, LifecycleBounds lb,
-                         const uint32_t* __restrict__ size_on_device /* a creation batch: the cloud's current size lives on the device, s.size bounds it */) {
+// pending_flags (a pipelined merge batch, merge_apply_insert_kernel): a surfel whose word has bit 0 set has been merged away by the
+// PREVIOUS keyframe of the batch, whose apply sweep -- the one that writes the NaN -- runs beside this sweep: it is skipped here as
+// its NaN position would skip it.
+__device__ __forceinline__ void supporting_insert_body(const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                                                       const LifecycleBounds& lb, uint32_t size, uint32_t block, const uint32_t* __restrict__ pending_flags) {
   uint32_t i;
-  if (!lifecycle_surfel(in, frame, lb, size_on_device ? min(*size_on_device, s.size) : s.size, &i)) return;
+  if (!lifecycle_surfel(in, frame, lb, size, &i, block)) return;
+  if (pending_flags && (pending_flags[i] & 1u)) return;
   Assoc r;
   if (!project_associate<false>(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) return;
   const int cx = r.px / in.cell, cy = r.py / in.cell;
@@ -108,6 +112,11 @@ supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, Supporting
     if (old == kInvalidIndex) break;     // an empty slot absorbed the value
     if (old > cur) cur = old;            // displaced a larger index: push it down the chain
   }
+}
+__global__ void __launch_bounds__(kLcBlock)
+supporting_insert_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView sup, LifecycleBounds lb,
+                         const uint32_t* __restrict__ size_on_device /* a creation batch: the cloud's current size lives on the device, s.size bounds it */) {
+  supporting_insert_body(in, frame, s, sup, lb, size_on_device ? min(*size_on_device, s.size) : s.size, blockIdx.x, nullptr);
 }
 
 __device__ __forceinline__ bool merge_test(const SurfelsView& s, uint32_t a, uint32_t b, float cos_thr, float cell_merge_dist_sq) {
@@ -126,7 +135,7 @@ merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView 
                     float cos_thr, uint32_t* __restrict__ flags, uint32_t* __restrict__ cell_of /* per surfel: 1 + the sparse cell it is
                     associated with in this keyframe, 0 = none -- merge_apply_kernel empties exactly those cells again */, LifecycleBounds lb) {
   uint32_t i;
-  if (!lifecycle_surfel(in, frame, lb, s.size, &i)) return;   // merge_apply_kernel visits the same surfels: the other flags are never read
+  if (!lifecycle_surfel(in, frame, lb, s.size, &i, blockIdx.x)) return;   // merge_apply_kernel visits the same surfels: the other flags are never read
   flags[i] = 0;
   cell_of[i] = 0;
   Assoc r;
@@ -157,11 +166,11 @@ merge_decide_kernel(Intrinsics in, KfEntry frame, SurfelsView s, SupportingView 
 // insertion, all slots empty: the surfels that inserted themselves are the associated ones, whose cells merge_decide_kernel has
 // recorded -- so the NEXT keyframe of the batch needs no fill launch (capi_lifecycle.hip: determine_supporting_impl; a merge batch of 200
 // keyframes is launch-bound).  Otherwise the planes keep the lists, the reference function's second output.
-__global__ void __launch_bounds__(kLcBlock)
-merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ cell_of,
-                   SupportingView sup, int empty_the_planes, uint32_t* __restrict__ deleted_count, LifecycleBounds lb) {
+__device__ __forceinline__ void merge_apply_body(const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const uint32_t* __restrict__ flags,
+                                                 const uint32_t* __restrict__ cell_of, const SupportingView& sup, int empty_the_planes,
+                                                 uint32_t* __restrict__ deleted_count, const LifecycleBounds& lb, uint32_t block) {
   uint32_t i;
-  if (!lifecycle_surfel(in, frame, lb, s.size, &i)) return;   // (wave-uniform but for the last tile's tail lanes; the ballot below counts active lanes)
+  if (!lifecycle_surfel(in, frame, lb, s.size, &i, block)) return;   // (wave-uniform but for the last tile's tail lanes; the ballot below counts active lanes)
   const bool del = flags[i];
   const uint32_t cell = empty_the_planes ? cell_of[i] : 0u;
   if (cell) {
@@ -172,6 +181,25 @@ merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* 
   if (del) s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits);
   const unsigned long long m = __ballot(del);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(deleted_count, (uint32_t)__popcll(m));
+}
+__global__ void __launch_bounds__(kLcBlock)
+merge_apply_kernel(Intrinsics in, KfEntry frame, SurfelsView s, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ cell_of,
+                   SupportingView sup, int empty_the_planes, uint32_t* __restrict__ deleted_count, LifecycleBounds lb) {
+  merge_apply_body(in, frame, s, flags, cell_of, sup, empty_the_planes, deleted_count, lb, blockIdx.x);
+}
+// A merge batch that knows its frames, pipelined (bahip_merge_surfels_for_keyframes): the apply sweep of keyframe j and the insert sweep
+// of keyframe j + 1 in ONE launch -- workgroups [0, apply_groups) apply, the rest insert -- so that a keyframe costs two dependent
+// launches instead of three (the batch is bound by launch dependencies and the latency chains inside these small kernels: 54 us per
+// keyframe for 39 us of kernels, profiles/r5_drop_in_trace_by_kernel.csv).  The two sweeps touch disjoint memory but for the surfels
+// keyframe j merges away, which keyframe j + 1 must not insert: the insert sweep reads their decision word (supporting_insert_body)
+// instead of the NaN the apply sweep is writing; the keyframes alternate between two sets of supporting planes, so the set keyframe
+// j + 1 fills is the one keyframe j - 1 left empty.  Same planes, same deletions as the three launches per keyframe.
+__global__ void __launch_bounds__(kLcBlock)
+merge_apply_insert_kernel(Intrinsics in, KfEntry apply_frame, KfEntry insert_frame, SurfelsView s, const uint32_t* __restrict__ flags,
+                          const uint32_t* __restrict__ cell_of, SupportingView apply_sup, SupportingView insert_sup,
+                          uint32_t* __restrict__ deleted_count, LifecycleBounds apply_lb, LifecycleBounds insert_lb, uint32_t apply_groups) {
+  if (blockIdx.x < apply_groups) merge_apply_body(in, apply_frame, s, flags, cell_of, apply_sup, 1, deleted_count, apply_lb, blockIdx.x);
+  else supporting_insert_body(in, insert_frame, s, insert_sup, insert_lb, s.size, blockIdx.x - apply_groups, flags);
 }
 
 // ---- creation ---------------------------------------------------------------------------------------
@@ -553,6 +581,27 @@ void launch_merge(hipStream_t st, const Intrinsics& in, const KfEntry& frame, co
   if (!groups) return;
   hipLaunchKernelGGL(merge_decide_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, cell_of, lb);
   hipLaunchKernelGGL(merge_apply_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, flags, cell_of, sup, empty_the_planes ? 1 : 0, deleted_count, lb);
+}
+// The pieces of a pipelined merge batch (merge_apply_insert_kernel): decide alone; apply (of `apply_frame`, may be absent: the batch's
+// first step) beside insert (of `insert_frame`, may be absent: its last step).
+void launch_merge_decide(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
+                         float cell_merge_dist_sq, float cos_thr, uint32_t* flags, uint32_t* cell_of, const LifecycleCull& cull) {
+  if (!s.size) return;
+  const LifecycleBounds lb = device_cull(cull);
+  const unsigned groups = sweep_groups(lb, s.size);
+  if (groups) hipLaunchKernelGGL(merge_decide_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, s, sup, cell_merge_dist_sq, cos_thr, flags, cell_of, lb);
+}
+void launch_merge_apply_insert(hipStream_t st, const Intrinsics& in, const KfEntry* apply_frame, const KfEntry* insert_frame, const SurfelsView& s,
+                               const uint32_t* flags, const uint32_t* cell_of, const SupportingView& apply_sup, const SupportingView& insert_sup,
+                               uint32_t* deleted_count, const LifecycleCull& apply_cull, const LifecycleCull& insert_cull) {
+  if (!s.size) return;
+  const LifecycleBounds alb = device_cull(apply_cull), ilb = device_cull(insert_cull);
+  const unsigned apply_groups = apply_frame ? sweep_groups(alb, s.size) : 0u, insert_groups = insert_frame ? sweep_groups(ilb, s.size) : 0u;
+  if (apply_groups + insert_groups == 0) return;
+  const KfEntry& a = apply_frame ? *apply_frame : *insert_frame;
+  const KfEntry& i = insert_frame ? *insert_frame : *apply_frame;
+  hipLaunchKernelGGL(merge_apply_insert_kernel, dim3(apply_groups + insert_groups), dim3(kLcBlock), 0, st, in, a, i, s, flags, cell_of, apply_sup, insert_sup,
+                     deleted_count, alb, ilb, apply_groups);
 }
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags, bool leave_planes_empty) {
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags, leave_planes_empty ? 1 : 0);

@@ -348,8 +348,20 @@ void DirectBA::MergeForKeyframes(const vector<u32>& keyframe_ids) {
   if (frames.empty()) return;
   LifecycleBatch batch(this);
   BAHIP_CHECKED_CALL(bahip_lifecycle_batch_set_frames(ctx_, frames.data(), (int)(frames.size() / 12)));
-  for (u32 id : keyframe_ids)
-    if (keyframes_[id]) MergeForKeyframe(*keyframes_[id], /*defer_count*/ true);
+  if (batched_creation_) {
+    // one call for the batch: two dependent launches per keyframe instead of three (bahip_merge_surfels_for_keyframes)
+    vector<bahip_frame> structs;
+    for (u32 id : keyframe_ids)
+      if (keyframes_[id]) structs.push_back(keyframes_[id]->ToBahipFrame());
+    uint32_t* sup[kMergeBufferCount];
+    for (int i = 0; i < kMergeBufferCount; ++i) sup[i] = supporting_surfels_[i]->ToCUDA().address();
+    const bahip_surfels s = SurfelsStruct();
+    BAHIP_CHECKED_CALL(bahip_merge_surfels_for_keyframes(ctx_, surfel_merge_dist_factor_, structs.data(), frames.data(), (int)structs.size(), &s, sup,
+                                                         (uint32_t)supporting_surfels_[0]->ToCUDA().pitch(), nullptr));
+  } else {
+    for (u32 id : keyframe_ids)
+      if (keyframes_[id]) MergeForKeyframe(*keyframes_[id], /*defer_count*/ true);
+  }
   TakeDeferredMergeCount();
 }
 

@@ -112,8 +112,9 @@ class DirectBA {
   // since the last reorder, so a caller that knows only B/direct_ba.h:73-388 gets the buffer the sweeps are fast on.
   // cell size 0 switches it off (the reference's surfel order stays observable); default 0.02 m.
   void SetSpatialSortCellSize(float grid_cell_size) { spatial_sort_cell_size_ = grid_cell_size; }
-  // Ours: the creations of a BA iteration as one call of the backend (default) or keyframe by keyframe with the host in between
-  // (the reference's shape).  Same surfels either way.
+  // Ours: the creations of a BA iteration and the merges of a merge pass as ONE call of the backend each (default:
+  // bahip_create_surfels_for_keyframes, bahip_merge_surfels_for_keyframes) or keyframe by keyframe with the host in between (the
+  // reference's shape).  Same surfels either way.
   void SetBatchedCreation(bool enabled) { batched_creation_ = enabled; }
   float spatial_sort_cell_size() const { return spatial_sort_cell_size_; }
   u32 unsorted_surfels() const { return unsorted_surfels_; }

@@ -238,6 +238,21 @@ class Scene:
         planes = np.stack([b.download()[:self.cf_h, :self.cf_w] for b in self.supporting])
         return planes, merged.value
 
+    def merge_surfels_for_keyframes(self, keyframes, frames_T_global, merge_dist_factor=0.8):
+        """bahip_merge_surfels_for_keyframes: the merges of a batch of keyframes, pipelined (two dependent launches per keyframe);
+        returns (the three supporting planes afterwards -- left empty --, surfels merged away)."""
+        n = len(keyframes)
+        structs = (capi.Frame * n)(*[self.frame_struct(k) for k in keyframes])
+        F = (C.c_float * (12 * n))(*[float(v) for T in frames_T_global for v in T])
+        merged = C.c_uint32()
+        s = self.surfels_struct()
+        capi.check(self.lib.bahip_merge_surfels_for_keyframes(self.ctx.handle, float(merge_dist_factor), structs, F, n, C.byref(s),
+                                                              self._supporting_ptrs(), self.supporting[0].pitch, C.byref(merged)))
+        self.ctx.synchronize()
+        self.surfel_count -= merged.value
+        planes = np.stack([b.download()[:self.cf_h, :self.cf_w] for b in self.supporting])
+        return planes, merged.value
+
     def delete_surfels_and_update_radii(self, min_observation_count):
         deleted = C.c_uint32()
         s = self.surfels_struct()

@@ -64,8 +64,9 @@ uint32_t dba_surfels_size(dba_handle* h);
 int dba_set_surfel_count(dba_handle* h, uint32_t surfel_count, uint32_t surfels_size);
 /* DirectBA::SortSurfelsSpatially (ours: Morton order of the surfel buffer over a world grid of grid_cell_size metres) */
 int dba_sort_surfels_spatially(dba_handle* h, void* hip_stream, float grid_cell_size);
-/* DirectBA::SetBatchedCreation (ours): 1 (default) = the surfel creations of a BA iteration go to the backend as one batch
- * (bahip_create_surfels_for_keyframes), 0 = keyframe by keyframe with the host in between.  Same surfels. */
+/* DirectBA::SetBatchedCreation (ours): 1 (default) = the surfel creations of a BA iteration and the merges of a merge pass go to the
+ * backend as one batch each (bahip_create_surfels_for_keyframes, bahip_merge_surfels_for_keyframes), 0 = keyframe by keyframe with the
+ * host in between.  Same surfels. */
 int dba_set_batched_creation(dba_handle* h, int enabled);
 /* DirectBA::SetSpatialSortCellSize: the grid cell PerformBASchemeEndTasks re-establishes that order with whenever surfels were
  * appended or moved since the last reorder (default 0.02 m; 0 = never: the reference's surfel order stays observable);

@@ -351,6 +351,16 @@ int bahip_determine_supporting_surfels(bahip_context* ctx, int merge, float merg
  * synchronisation per keyframe; the surfels merged by all such calls since the last bahip_take_merged_count are returned (and
  * the counter cleared) here -- one synchronisation per batch of keyframes instead of one per keyframe. */
 int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out);
+/* The merges of a BATCH of keyframes in one call (DirectBA's merge pass of a BA iteration and of the end tasks,
+ * B/direct_ba_alternating.cc:491-540, B/direct_ba.cc:566-620): bahip_determine_supporting_surfels(merge = 1) for frames[0],
+ * frames[1], ... in this order, with the same deletions -- but two dependent launches per keyframe instead of three: the sweep that
+ * applies keyframe j's decisions runs beside the one that inserts keyframe j + 1's surfels (they alternate between the caller's planes
+ * and a second set the context owns).  frame_T_global_3x4: 12 floats per frame.  Inside bahip_lifecycle_batch_begin / _set_frames
+ * each keyframe's sweeps run over the tiles it can see.  Both sets of planes end EMPTY (the lists are not an output of a merge batch).
+ * merged_count_out: NULL defers the count to bahip_take_merged_count. */
+int bahip_merge_surfels_for_keyframes(bahip_context* ctx, float merge_dist_factor, const bahip_frame* frames, const float* frame_T_global_3x4,
+                                      int num_frames, const bahip_surfels* surfels, uint32_t* const* supporting, uint32_t supporting_pitch_bytes,
+                                      uint32_t* merged_count_out);
 /* A batch of keyframes creating or merging surfels on one cloud (the BA loop's creation pass, its merge pass, the merges of the
  * end tasks): bahip_lifecycle_batch_begin takes the bounding spheres of the cloud's 64-surfel tiles once; until
  * bahip_lifecycle_batch_end the per-keyframe sweeps of bahip_determine_supporting_surfels / bahip_create_surfels_for_keyframe over

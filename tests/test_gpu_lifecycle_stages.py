@@ -49,10 +49,14 @@ def test_supporting_surfels_lists_bit_exact(world):
         assert filled[0] > 5000 and filled[1] > 100, filled           # second slots are in use: cells seen by several surfels
 
 
-@pytest.mark.parametrize("batch", [False, True, "frames"], ids=["per keyframe", "lifecycle batch", "lifecycle batch that knows its frames"])
+@pytest.mark.parametrize("batch", [False, True, "frames", "pipelined", "pipelined without lists"],
+                         ids=["per keyframe", "lifecycle batch", "lifecycle batch that knows its frames", "pipelined batch", "pipelined batch without tile lists"])
 def test_merge_bit_exact(world, batch):
     """batch: inside bahip_lifecycle_batch_begin / _end the sweeps skip the tiles a keyframe cannot see (here: a copy of the cloud
-    50 m away, in the middle of the buffer) -- the oracle knows no such bracket and must see the same buffer."""
+    50 m away, in the middle of the buffer) -- the oracle knows no such bracket and must see the same buffer.
+    pipelined: bahip_merge_surfels_for_keyframes, the whole batch in one call with keyframe j's apply sweep beside keyframe j + 1's
+    insert sweep (two sets of planes; a surfel keyframe j merges away must not enter keyframe j + 1's planes although its NaN is being
+    written in the same launch) -- against the oracle's keyframe-by-keyframe merges; the keyframes overlap, so the order matters."""
     import contextlib
     scene, orc, g = world
     data, _ = common.oracle_surfels(orc)
@@ -69,9 +73,29 @@ def test_merge_bit_exact(world, batch):
     both = np.concatenate([data, dup], axis=1)
     _sync(orc, g, both)
     total_merged = 0
-    frames = [np.array(list(orc.keyframes[k].frame_T_global), np.float32) for k in (0, 1, 3)] if batch == "frames" else None
-    with (g.lifecycle_batch(frames=frames) if batch else contextlib.nullcontext()):
-        for k in (0, 1, 3):
+    frames = [np.array(list(orc.keyframes[k].frame_T_global), np.float32) for k in (0, 1, 3)] if batch in ("frames", "pipelined") else None
+    if batch in ("pipelined", "pipelined without lists"):
+        order = (0, 1, 3, 2, 0)          # (a keyframe twice: its second visit finds its first visit's deletions)
+        Fs = [np.array(list(orc.keyframes[k].frame_T_global), np.float32) for k in order]
+        before = int(orc.surfels.surfel_count)
+        with (g.lifecycle_batch(frames=Fs) if batch == "pipelined" else contextlib.nullcontext()):
+            planes, total_merged = g.merge_surfels_for_keyframes(order, Fs, merge_dist_factor=orc.merge_factor)
+        for k in order:
+            orc.determine_supporting_surfels(k, merge=True)
+        assert total_merged == before - int(orc.surfels.surfel_count)
+        assert np.all(planes == 0xffffffff)
+        got = g.surfel_buf.download()[:, :both.shape[1]]
+        assert np.array_equal(_rows(got), _rows(orc.surfel_data[:, :both.shape[1]]))
+        # ... and a second batch on the same context (the planes were left empty, the decision words are cleared again)
+        before = int(orc.surfels.surfel_count)
+        _, again = g.merge_surfels_for_keyframes((3, 1), [Fs[2], Fs[1]], merge_dist_factor=orc.merge_factor)
+        for k in (3, 1):
+            orc.determine_supporting_surfels(k, merge=True)
+        assert again == before - int(orc.surfels.surfel_count)
+        total_merged += again
+        assert np.array_equal(_rows(g.surfel_buf.download()[:, :both.shape[1]]), _rows(orc.surfel_data[:, :both.shape[1]]))
+    with (g.lifecycle_batch(frames=frames) if batch in (True, "frames") else contextlib.nullcontext()):
+        for k in (0, 1, 3) if batch in (False, True, "frames") else ():
             F = np.array(list(orc.keyframes[k].frame_T_global), np.float32)
             before = int(orc.surfels.surfel_count)
             planes, merged = g.determine_supporting_surfels(k, F, merge=True, merge_dist_factor=orc.merge_factor)
