@@ -453,10 +453,19 @@ def main():
     # the first sustained load of the process and reads 1.5-2 % below its own repeat (alternating runs on one box: 641 / 651 it/s; the
     # geometry launches of a first pass go 786, 771, 767, 756 ... 726 us while those of a second pass over the same work start at 751:
     # clocks and first touch, not the work): `value` is meant to be the rate of a busy GPU.  --no-prepass / BENCH_PREPASS=0 switch it off.
-    prepass = (not args.no_prepass) and os.environ.get("BENCH_PREPASS", "1") != "0" and not (args.pcg or args.intrinsics)
+    # (round 6, ADVICE r5: every mode takes it -- PCG and intrinsics runs too --, and the pre-pass itself is timed the way the contract
+    # times a run without it: W untimed iterations, then K timed ones; the line carries that figure beside `value`.)
+    prepass = (not args.no_prepass) and os.environ.get("BENCH_PREPASS", "1") != "0"
+    first_pass_rate = None
     if prepass:
-        run(args.warmup + args.steps)
+        if args.warmup > 0:
+            run(args.warmup)
         ctx.synchronize()
+        torch.cuda.synchronize()
+        t_first = time.perf_counter()
+        run(args.steps)
+        ctx.synchronize()
+        first_pass_rate = args.steps / (time.perf_counter() - t_first)
         reset_to_start_state()
     if args.warmup > 0:
         run(args.warmup)
@@ -834,6 +843,9 @@ def main():
                              "n_ranks_seen_note": "sum of 1 over the ranks through that transport before the first iteration (bahip_context_count_ranks, with a time limit)"},
                 "per_rank": per_rank} if per_rank is not None else {}),
             "prepass": {"iterations": (args.warmup + args.steps) if prepass else 0,
+                        "first_pass_ba_iterations_per_s": first_pass_rate,
+                        "first_pass_note": "the pre-pass timed by the contract's protocol (W untimed iterations, then K timed): what `value` reads "
+                                           "without a pre-pass, i.e. as the first sustained load of the process (this rank's clock, no barrier)",
                         "note": "the iterations of warm-up + timed region run once before and are discarded, the scene is reset to the same start "
                                 "state: the timed region is then not the first sustained load of the process (clocks, first touch: +1.5-2 %); "
                                 "--no-prepass switches it off"},
@@ -895,7 +907,8 @@ def main():
             # table of the launch's work items fits, one tile per wavefront with global atomics otherwise; the line names the one
             # most of the timed launches used
             lds = form_lds.value >= form_global.value
-            pose_kernel = "pose_accumulate_lds_kernel<true, true, false>" if lds else "pose_accumulate_kernel<true, true>"
+            # (the sweeps exist once per arithmetic flavour, in namespace bahip::exact / bahip::fast: the name says which one ran)
+            pose_kernel = args.arithmetic + "::" + ("pose_accumulate_lds_kernel<true, true, false>" if lds else "pose_accumulate_kernel<true, true>")
             # Counter evidence: sums over the dispatches of the PROFILE RUN's own timed region, divided by that run's own
             # launches / keyframes visited / iterations (profiles/*_pmc_per_kernel.json "timed_window") -- like by like; the
             # per-launch averages over all 40-odd dispatches of a profile run (warm-up rounds, rounds queued in vain) that
@@ -955,7 +968,7 @@ def main():
                 for key in ("non_arithmetic_valu_fraction", "valu_cycles_per_instruction", "shader_clock_mhz"):
                     if key in gwin:
                         geo_counters[key] = gwin[key]
-            out["roofline_geometry"] = {"bound": "hbm", "kernel": "geometry_kernel<true,true> (activation + normals + position step)",
+            out["roofline_geometry"] = {"bound": "hbm", "kernel": args.arithmetic + "::geometry_kernel<true,true> (activation + normals + position step)",
                                         "achieved": bytes_geo / (geo_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": bytes_geo / (geo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "traffic": geo_counters["traffic_per_launch"] if geo_counters else None,
