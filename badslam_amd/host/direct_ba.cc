@@ -456,6 +456,17 @@ void DirectBA::PerformBASchemeEndTasks(hipStream_t stream, bool do_surfel_update
   }
 }
 
+// Ours: the compaction inside the loop fills the holes of merged surfels with surfels from the END of the buffer (the reference's rule,
+// B/kernel_compact_surfels.cu:101-157) -- after a creation + merge pass over many keyframes nearly every 64-surfel tile of the Morton-
+// ordered part then holds a surfel from somewhere else, its bounding sphere covers half the scene, and the sweeps of the call's remaining
+// iterations cull nothing (measured: geometry 1.0 ms instead of 0.47 at 2.2 M surfels, profiles/r6_drop_in_trace_by_kernel.csv).  So once
+// the surfels out of order amount to one per tile, the buffer goes back into Morton order here instead of at the end tasks only
+// (same switch: SetSpatialSortCellSize(0) leaves the reference's order alone; the oracle's loop applies the same rule, oracle_ba.c).
+void DirectBA::SortAfterInLoopCompaction(hipStream_t stream) {
+  if (spatial_sort_cell_size_ > 0.f && surfels_size_ > 1 && (uint64_t)unsorted_surfels_ * 64 >= (uint64_t)surfels_size_)
+    SortSurfelsSpatially(stream, spatial_sort_cell_size_);
+}
+
 void DirectBA::SortSurfelsSpatially(hipStream_t stream, float grid_cell_size) {
   BAHIP_CHECKED_CALL(bahip_context_set_stream(ctx_, stream));
   const bahip_surfels s = SurfelsStruct();
@@ -681,6 +692,7 @@ void DirectBA::BundleAdjustmentAlternating(hipStream_t stream, bool optimize_dep
         surfels_size_ = surfel_count_;
         Unlock();
       }
+      SortAfterInLoopCompaction(stream);
     }
 
     // --- poses: every non-inactive keyframe, batched per Gauss-Newton round; activations updated on the device ---
@@ -806,6 +818,7 @@ void DirectBA::BundleAdjustmentPCG(hipStream_t stream, bool optimize_depth_intri
       unsorted_surfels_ += surfels_size_ - surfel_count_;
       BAHIP_CHECKED_CALL(bahip_compact_surfels(ctx_, surfel_count_, &s));
       surfels_size_ = surfel_count_;
+      SortAfterInLoopCompaction(stream);
     }
   };
 

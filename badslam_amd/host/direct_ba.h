@@ -111,7 +111,10 @@ class DirectBA {
   // surfels, anyway (B/direct_ba.cc:619-640) -- puts the buffer back into Morton order whenever surfels were appended or moved
   // since the last reorder, so a caller that knows only B/direct_ba.h:73-388 gets the buffer the sweeps are fast on.
   // cell size 0 switches it off (the reference's surfel order stays observable); default 0.02 m.
+  // Round 6: the compaction INSIDE the loop (after a merge pass) is followed by the same reorder once the surfels out of order amount
+  // to one per 64-surfel tile, so that the call's remaining iterations sweep a coherent buffer (direct_ba.cc: SortAfterInLoopCompaction).
   void SetSpatialSortCellSize(float grid_cell_size) { spatial_sort_cell_size_ = grid_cell_size; }
+  void SortAfterInLoopCompaction(hipStream_t stream);
   // Ours: the creations of a BA iteration and the merges of a merge pass as ONE call of the backend each (default:
   // bahip_create_surfels_for_keyframes, bahip_merge_surfels_for_keyframes) or keyframe by keyframe with the host in between (the
   // reference's shape).  Same surfels either way.

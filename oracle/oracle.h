@@ -337,6 +337,7 @@ typedef struct {
   float spatial_sort_cell;
 } orc_ba_state;
 
+void orc_sort_after_in_loop_compaction(orc_ba_state* st);   /* oracle_ba.c: the reorder behind the loop's compaction (ours) */
 void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* opt, orc_ba_stats* stats);
 /* B/direct_ba_pcg.cc:43-819 */
 void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_ba_stats* stats);

@@ -22,6 +22,16 @@ static void determine_covisible_active(orc_ba_state* st) {
   }
 }
 
+/* ours (host/direct_ba.cc: SortAfterInLoopCompaction): the compaction inside the loop is followed by the Morton reorder once the
+ * surfels out of order -- appended, or moved into holes from the end of the buffer -- amount to one per 64-surfel tile */
+void orc_sort_after_in_loop_compaction(orc_ba_state* st) {
+  orc_surfels* s = st->surfels;
+  if (st->spatial_sort_cell > 0.f && s->surfels_size > 1 && (uint64_t)st->unsorted_surfels * 64 >= (uint64_t)s->surfels_size) {
+    orc_sort_surfels_spatially(s, st->spatial_sort_cell);
+    st->unsorted_surfels = 0;
+  }
+}
+
 /* B/direct_ba.cc:566-653 */
 static void perform_ba_scheme_end_tasks(orc_ba_state* st, const orc_ba_options* opt) {
   orc_surfels* s = st->surfels;
@@ -123,7 +133,7 @@ void orc_bundle_adjustment_alternating(orc_ba_state* st, const orc_ba_options* o
         if (!kf) continue;
         orc_determine_supporting_surfels(1, opt->surfel_merge_dist_factor, &st->depth_cam, &st->dp, kf, s, st->supporting);
       }
-      if (n_new_kfs > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); }
+      if (n_new_kfs > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); orc_sort_after_in_loop_compaction(st); }
     }
 
     /* --- poses --- */

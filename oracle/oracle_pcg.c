@@ -592,7 +592,7 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     if (opt->do_surfel_updates) {
       for (int j = 0; j < n_new; ++j)
         orc_determine_supporting_surfels(1, opt->surfel_merge_dist_factor, &st->depth_cam, &st->dp, st->kfs[new_kfs[j]], s, st->supporting);
-      if (n_new > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); }
+      if (n_new > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); orc_sort_after_in_loop_compaction(st); }
     }
     if (iteration >= opt->min_iterations - 1 && (num_converged == K || !L.optimize_poses)) { stats->converged = 1; break; }
   }
@@ -607,7 +607,7 @@ void orc_bundle_adjustment_pcg(orc_ba_state* st, const orc_ba_options* opt, orc_
     /* B/direct_ba_pcg.cc:775-812: the merge + compaction of the last iteration is repeated */
     for (int j = 0; j < n_new; ++j)
       orc_determine_supporting_surfels(1, opt->surfel_merge_dist_factor, &st->depth_cam, &st->dp, st->kfs[new_kfs[j]], s, st->supporting);
-    if (n_new > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); }
+    if (n_new > 0) { st->unsorted_surfels += s->surfels_size - s->surfel_count; orc_compact_surfels(s); orc_sort_after_in_loop_compaction(st); }
   }
   free(new_kfs);
 }
