@@ -251,6 +251,20 @@ void launch_create_append_fused(hipStream_t st, const Intrinsics& in, const KfEn
                                 const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded,
                                 uint32_t* group_words, uint32_t tag);
 size_t create_padded_count(const Intrinsics& in);   // length of the tile-major flag / index vectors
+// a creation batch whose keyframes do not wait for each other's sweeps (kernels_lifecycle.hip: create_chain_kernel).  Up front, for all
+// keyframes of the batch: occupancy [n][cells] bytes (cleared by the caller) <- the cloud at the batch's begin, candidates [n][padded]
+// bytes (cleared by the caller) <- the pixels that would create a surfel, filtered; then one launch per keyframe of the chain.
+struct CreateBatchItem {
+  int kf_index;                       // bound keyframe
+  uint32_t list_offset, list_count;   // its visible bounded tiles in `lists`
+  int covis_offset, n_covis;          // its slice of the batch's co-visibility lists
+};
+void launch_create_batch_prepare(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, const CreateBatchItem* items, int num_items, uint32_t max_list_count,
+                                 const SurfelsView& cloud_at_begin, const uint32_t* lists, uint32_t bounded_tiles, uint8_t* occupancy, uint8_t* candidates,
+                                 bool filter_new_surfels, const int* covis, const float* covis_T_frame, int min_obs);
+void launch_create_chain(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* next_frame, const uint8_t* candidates,
+                         const uint8_t* occupancy, uint8_t* next_occupancy, const SurfelsView& s, uint32_t batch_begin_size, const uint32_t* size_in,
+                         uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded, uint32_t* group_words, uint32_t tag, uint32_t appended_bound);
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags, bool leave_planes_empty = false);
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,
                           const float* covis_T_frame, int n_covis, int min_obs, uint8_t* flags);
@@ -260,7 +274,8 @@ void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* k
                           int min_obs, uint32_t* deleted_count);
 void launch_shard_to_cloud(hipStream_t st, const SurfelsView& shard, const SurfelsView& cloud, uint32_t rank, uint32_t world, uint32_t chunk);
 void launch_cloud_to_shard(hipStream_t st, const SurfelsView& cloud, const SurfelsView& shard, uint32_t rank, uint32_t world, uint32_t chunk);
-hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float inv_cell);
+size_t sort_scratch_bytes(uint32_t n);
+hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float inv_cell, void* scratch, size_t scratch_bytes);   // stream-ordered, no host wait
 size_t scan_temp_bytes(size_t n);
 hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint8_t* flags, uint32_t* out, int n);
 hipError_t scan_u32_exclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, int n);

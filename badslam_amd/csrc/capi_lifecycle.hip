@@ -5,7 +5,13 @@
 using namespace bahip;
 using namespace bahip_capi;
 
+// the creation chain (create_chain_kernel): on unless BAHIP_CREATION_CHAIN=0 / bahip_debug_set_creation_chain(0); how many batches took it
+static int g_creation_chain_enabled = bahip_env_int("BAHIP_CREATION_CHAIN", 1);
+static long long g_creation_chain_batches = 0;
+
 extern "C" {
+int bahip_debug_set_creation_chain(int enabled) { g_creation_chain_enabled = enabled ? 1 : 0; return 0; }
+int bahip_debug_creation_chain_batches(long long* batches_out) { if (batches_out) *batches_out = g_creation_chain_batches; return 0; }
 // ---- lifecycle ---------------------------------------------------------------------------------------------
 static int supporting_view(uint32_t* const* supporting, uint32_t pitch, SupportingView* v) {
   for (int b = 0; b < BAHIP_MERGE_BUFFER_COUNT; ++b) {
@@ -387,7 +393,76 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
   // cleared once per batch
   HIP_TRY(hipMemsetAsync(ctx->dev_flags, 0, px, st));
   const uint32_t cells = (uint32_t)ctx->in.cf_width * (uint32_t)ctx->in.cf_height;   // a keyframe appends at most one surfel per sparse cell
-  for (int j = 0; j < num_keyframes; ++j) {
+  // The chain (round 6; kernels_lifecycle.hip: create_chain_kernel): when the open lifecycle batch knows every keyframe of this call
+  // (their visible-tile lists exist), keyframes 0 .. n - 2 cost ONE launch each behind three launches for the whole batch; the last
+  // keyframe goes the old way below, so that the caller's supporting planes end as a one-keyframe call leaves them.
+  int chained = 0;
+  if (num_keyframes >= 2 && g_creation_chain_enabled) {
+    std::vector<CreateBatchItem> items((size_t)num_keyframes - 1);
+    uint32_t max_list = 0, bounded_tiles = 0;
+    bool known = true;
+    const bool bounds_valid = ctx->lifecycle_bounds_tiles != 0 && ctx->lifecycle_bounds_data == surfels->data &&
+                              (uint64_t)ctx->lifecycle_bounds_tiles * 64 <= surfels->surfels_size && !ctx->lifecycle_list_counts.empty();
+    known = bounds_valid;
+    bounded_tiles = ctx->lifecycle_bounds_tiles;
+    for (int j = 0; j + 1 < num_keyframes && known; ++j) {
+      const float* F = ctx->host_kfs[keyframe_indices[j]].pose.F;
+      const size_t frames = ctx->lifecycle_list_counts.size();
+      size_t f = 0;
+      while (f < frames && memcmp(&ctx->lifecycle_frames[12 * f], F, 12 * sizeof(float)) != 0) ++f;
+      if (f == frames) { known = false; break; }
+      items[j].kf_index = keyframe_indices[j];
+      items[j].list_offset = ctx->lifecycle_list_offsets[f];
+      items[j].list_count = ctx->lifecycle_list_counts[f];
+      items[j].covis_offset = covis_offsets[j];
+      items[j].n_covis = covis_offsets[j + 1] - covis_offsets[j];
+      max_list = std::max(max_list, items[j].list_count);
+    }
+    const size_t n = (size_t)num_keyframes - 1, occupancy_bytes = n * cells, candidates_bytes = n * px;
+    if (known && occupancy_bytes + candidates_bytes <= ((size_t)4 << 30)) {
+      if (occupancy_bytes > ctx->create_occupancy_bytes) {
+        hipFree(ctx->dev_create_occupancy); ctx->dev_create_occupancy = nullptr; ctx->create_occupancy_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->dev_create_occupancy, occupancy_bytes + occupancy_bytes / 4));
+        ctx->create_occupancy_bytes = occupancy_bytes + occupancy_bytes / 4;
+      }
+      if (candidates_bytes > ctx->create_candidates_bytes) {
+        hipFree(ctx->dev_create_candidates); ctx->dev_create_candidates = nullptr; ctx->create_candidates_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->dev_create_candidates, candidates_bytes + candidates_bytes / 4));
+        ctx->create_candidates_bytes = candidates_bytes + candidates_bytes / 4;
+      }
+      if (n > ctx->create_items_capacity) {
+        hipFree(ctx->dev_create_items); ctx->dev_create_items = nullptr; ctx->create_items_capacity = 0;
+        HIP_TRY(hipMalloc(&ctx->dev_create_items, (n + 64) * sizeof(CreateBatchItem)));
+        ctx->create_items_capacity = n + 64;
+      }
+      HIP_TRY(hipMemcpyAsync(ctx->dev_create_items, items.data(), n * sizeof(CreateBatchItem), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemsetAsync(ctx->dev_create_occupancy, 0, occupancy_bytes, st));
+      HIP_TRY(hipMemsetAsync(ctx->dev_create_candidates, 0, candidates_bytes, st));
+      const SurfelsView cloud_at_begin = make_view(surfels);
+      launch_create_batch_prepare(st, ctx->in, ctx->dev_kfs, static_cast<const CreateBatchItem*>(ctx->dev_create_items), (int)n, max_list, cloud_at_begin,
+                                  ctx->dev_lifecycle_lists, bounded_tiles, ctx->dev_create_occupancy, ctx->dev_create_candidates, filter_new_surfels != 0,
+                                  ctx->dev_covis, ctx->dev_covis_T, min_observation_count);
+      CHECK_LAUNCH();
+      HIP_TRY(hipStreamSynchronize(st));   // `items` is pageable and goes out of scope
+      bahip_surfels whole = *surfels;
+      whole.surfels_size = surfels->capacity;   // (the chain addresses rows by index; sizes are read on the device)
+      const SurfelsView s = make_view(&whole);
+      for (int j = 0; j + 1 < num_keyframes; ++j) {
+        const uint32_t tag = (uint32_t)(j % 255) + 1u;
+        if (j > 0 && tag == 1u) HIP_TRY(hipMemsetAsync(group_words, 0, sizeof(uint32_t) * (size_t)groups, st));   // the tags start over
+        const bool has_next = j + 2 < num_keyframes;   // (the last keyframe takes the old path: it looks at the cloud itself)
+        const uint32_t appended_bound = (uint32_t)std::min<uint64_t>((uint64_t)surfels->capacity - surfels->surfels_size, (uint64_t)j * cells);
+        launch_create_chain(st, ctx->in, ctx->host_kfs[keyframe_indices[j]], has_next ? &ctx->host_kfs[keyframe_indices[j + 1]] : nullptr,
+                            ctx->dev_create_candidates + (size_t)j * px, ctx->dev_create_occupancy + (size_t)j * cells,
+                            has_next ? ctx->dev_create_occupancy + (size_t)(j + 1) * cells : nullptr, s, (uint32_t)surfels->surfels_size,
+                            size_cell[j & 1], size_cell[(j & 1) ^ 1], (uint32_t)surfels->capacity, exceeded_on_device, group_words, tag, appended_bound);
+        CHECK_LAUNCH();
+      }
+      chained = num_keyframes - 1;
+      ++g_creation_chain_batches;
+    }
+  }
+  for (int j = chained; j < num_keyframes; ++j) {
     const KfEntry& e = ctx->host_kfs[keyframe_indices[j]];
     const uint32_t* size_in = size_cell[j & 1];
     // what the cloud can hold by now at most: the grid of the sweep; the size itself is read on the device
@@ -397,7 +472,7 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
     ctx->supporting_planes_empty = nullptr;
     // the planes are filled once per batch: every keyframe but the last leaves them empty behind its flag pass (one thread per cell reads
     // the cell and resets it); after the last one they hold what a one-keyframe call leaves -- the lists and the claim marks
-    if (j == 0) launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
+    if (j == chained) launch_supporting_fill(st, sup, ctx->in.cf_width, ctx->in.cf_height);
     launch_supporting_insert(st, ctx->in, e, s, sup, lifecycle_cull_for(ctx, surfels, e.pose.F), size_in);
     launch_create_flag(st, ctx->in, e, sup, ctx->dev_flags, j + 1 < num_keyframes);
     const int n_covis = covis_offsets[j + 1] - covis_offsets[j];
@@ -461,7 +536,16 @@ int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfel
   REQUIRE(grid_cell_size > 0.f, "grid_cell_size must be positive");
   ctx->tile_order_tiles = 0;         // every surfel changes its tile: the run order of the sweeps is rebuilt by the next pose phase
   const float inv_cell = 1.0f / grid_cell_size;
-  HIP_TRY(sort_surfels_spatially(ctx->stream, make_view(surfels), inv_cell));
+  if (surfels->surfels_size >= 2) {
+    const size_t need = sort_scratch_bytes(surfels->surfels_size);
+    if (need > ctx->sort_scratch_bytes) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));   // (a sort still reading the old scratch)
+      hipFree(ctx->dev_sort_scratch); ctx->dev_sort_scratch = nullptr; ctx->sort_scratch_bytes = 0;
+      HIP_TRY(hipMalloc(&ctx->dev_sort_scratch, need + need / 4));
+      ctx->sort_scratch_bytes = need + need / 4;
+    }
+    HIP_TRY(sort_surfels_spatially(ctx->stream, make_view(surfels), inv_cell, ctx->dev_sort_scratch, ctx->sort_scratch_bytes));
+  }
   return 0;
 }
 

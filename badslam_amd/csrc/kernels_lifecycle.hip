@@ -295,11 +295,9 @@ __device__ __forceinline__ uint32_t create_filter_pair(const Intrinsics& in, con
 // chain of dependent gathers (79 us per keyframe at the bench scene, round 4 trace).  With few candidates the wavefront takes
 // them one at a time and spreads the co-visible keyframes over its lanes; the two counts are integers, so both shapes decide
 // alike.
-__global__ void __launch_bounds__(kLcBlock)
-create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ kfs, const int* __restrict__ covis,
-                     const float* __restrict__ covis_T_frame /* 12 floats each */, int n_covis,
-                     int min_observation_count, int padded_count, uint8_t* __restrict__ flags) {
-  const int idx = blockIdx.x * kLcBlock + threadIdx.x;
+__device__ __forceinline__ void create_filter_body(const Intrinsics& in, const KfEntry& frame, const KfEntry* __restrict__ kfs, const int* __restrict__ covis,
+                                                   const float* __restrict__ covis_T_frame /* 12 floats each */, int n_covis,
+                                                   int min_observation_count, int padded_count, uint8_t* __restrict__ flags, int idx) {
   const int lane = threadIdx.x & 63;
   int x = 0, y = 0;
   const bool candidate = idx < padded_count && flags[idx] && tile_xy(in, (size_t)idx, &x, &y);
@@ -337,9 +335,15 @@ create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ k
   }
   if (candidate && (observations < (uint32_t)min_observation_count || violations > observations)) flags[idx] = 0;
 }
+__global__ void __launch_bounds__(kLcBlock)
+create_filter_kernel(Intrinsics in, KfEntry frame, const KfEntry* __restrict__ kfs, const int* __restrict__ covis,
+                     const float* __restrict__ covis_T_frame, int n_covis, int min_observation_count, int padded_count, uint8_t* __restrict__ flags) {
+  create_filter_body(in, frame, kfs, covis, covis_T_frame, n_covis, min_observation_count, padded_count, flags, blockIdx.x * kLcBlock + threadIdx.x);
+}
 
 // B/kernel_create_surfels.cu:91-160: the attributes of the surfel that pixel (x, y) of `frame` creates, written to index si.
-__device__ __forceinline__ void append_surfel(const Intrinsics& in, const KfEntry& frame, int x, int y, uint32_t si, const SurfelsView& s) {
+__device__ __forceinline__ void append_surfel(const Intrinsics& in, const KfEntry& frame, int x, int y, uint32_t si, const SurfelsView& s,
+                                              Vec3* stored_position = nullptr, uint32_t* stored_normal = nullptr) {
   float G[12];
   {
     // global_T_frame as 3x4: rotation = transpose of frame_T_global's, translation from the pose
@@ -357,7 +361,10 @@ __device__ __forceinline__ void append_surfel(const Intrinsics& in, const KfEntr
   const Vec3 gp = transform34(G, unproject(in, x, y, cd));
   s.row(kSurfelX)[si] = gp.x; s.row(kSurfelY)[si] = gp.y; s.row(kSurfelZ)[si] = gp.z;
   const Vec3 gn = rotate34(G, unpack_normal8(pitched_load(frame.normals, frame.normals_pitch, y, x)));
-  reinterpret_cast<uint32_t*>(s.row(kSurfelNormal))[si] = pack_normal10(gn);
+  const uint32_t packed_normal = pack_normal10(gn);
+  reinterpret_cast<uint32_t*>(s.row(kSurfelNormal))[si] = packed_normal;
+  if (stored_position) *stored_position = gp;
+  if (stored_normal) *stored_normal = packed_normal;
   const float radius_sq = __half2float(__ushort_as_half(pitched_load(frame.radius, frame.radius_pitch, y, x)));
   s.row(kSurfelRadiusSquared)[si] = radius_sq;
   float cx, cy;
@@ -472,6 +479,150 @@ create_append_fused_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restri
     for (int w = 0; w < kLcBlock / 64; ++w) { const uint32_t c = wave_sums[w]; slab_total += c; if (w < wave) waves_before += c; }
     int x, y;
     if (flagged && tile_xy(in, (size_t)idx, &x, &y)) append_surfel(in, frame, x, y, running + waves_before + rank_in_wave, s);
+    running += slab_total;
+  }
+}
+
+// ---- a creation batch whose keyframes do not wait for each other's sweeps (round 6) -------------------------------------------------
+// The keyframes of a creation batch depend on each other only through the surfels the earlier ones APPEND: whether a sparse cell of
+// keyframe j is free is decided by the cloud as it was when the batch began plus what keyframes 0 .. j - 1 of the batch appended, while
+// which pixel of a free cell would create a surfel and whether that candidate passes the outlier filter are functions of the
+// keyframes' images and poses alone (create_flag_kernel, create_filter_pair read no surfel).  So the batch is cut in two:
+//   up front, for ALL keyframes of the batch at once (three launches whatever the batch's length):
+//     occupancy[j][cell] <- 1 where a surfel of the cloud at the batch's begin is associated with keyframe j   (create_batch_occupancy_kernel)
+//     candidates[j][seq] <- 1 for the first valid pixel of every cell that is free so far                      (create_batch_flag_kernel)
+//     candidates[j][seq] <- 0 where the candidate fails the filter                                             (create_batch_filter_kernel)
+//   then the chain, ONE launch per keyframe (create_chain_kernel) instead of four:
+//     the candidates of keyframe j whose cell is still free are counted, scanned and appended exactly like create_append_fused_kernel
+//     does (tagged-word grid handshake, soft failure, two size cells); every appended surfel is at once projected into keyframe j + 1
+//     (push), and further workgroups of the same launch project what keyframes 0 .. j - 1 appended into keyframe j + 1 (pull): when the
+//     launch ends, occupancy[j + 1] is complete.
+// Same surfels at the same indices as n one-keyframe creations (tests/test_gpu_lifecycle_stages.py).
+__device__ __forceinline__ void mark_occupied(const Intrinsics& in, const float* __restrict__ F, const uint32_t* __restrict__ geom, const Vec3& gp, const Vec3& gn,
+                                              uint8_t* __restrict__ occupancy) {
+  Assoc r;
+  if (!project_associate<false>(in, F, geom, gp, gn, &r, nullptr)) return;
+  occupancy[(size_t)(r.py / in.cell) * (size_t)in.cf_width + (size_t)(r.px / in.cell)] = 1;   // (every writer stores the same value)
+}
+__global__ void __launch_bounds__(kLcBlock)
+create_batch_occupancy_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, const CreateBatchItem* __restrict__ items, SurfelsView s /* size: the cloud at the
+                              batch's begin */, const uint32_t* __restrict__ lists, uint32_t bounded_tiles, uint8_t* __restrict__ occupancy, size_t cells) {
+  const CreateBatchItem item = items[blockIdx.y];
+  const KfEntry& frame = kfs[item.kf_index];
+  const uint32_t all_tiles = (s.size + 63u) / 64u, tail = all_tiles > bounded_tiles ? all_tiles - bounded_tiles : 0u;
+  const uint32_t positions = item.list_count + tail;
+  for (uint32_t w = (blockIdx.x * kLcBlock + threadIdx.x) >> 6; w < positions; w += gridDim.x * (kLcBlock / 64)) {
+    const uint32_t tile = w < item.list_count ? lists[item.list_offset + w] : bounded_tiles + (w - item.list_count);
+    const uint32_t i = tile * 64u + (threadIdx.x & 63u);
+    if (i < s.size) mark_occupied(in, frame.pose.F, frame.geom, surfel_position(s, i), surfel_normal(s, i), occupancy + blockIdx.y * cells);
+  }
+}
+// create_flag_kernel's choice for every cell that no surfel occupies so far (the candidate vector starts cleared)
+__global__ void __launch_bounds__(kLcBlock)
+create_batch_flag_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, const CreateBatchItem* __restrict__ items, const uint8_t* __restrict__ occupancy, size_t cells,
+                         uint8_t* __restrict__ candidates, size_t padded_count) {
+  const int cxy = blockIdx.x * kLcBlock + threadIdx.x;
+  if (cxy >= in.cf_width * in.cf_height) return;
+  if (occupancy[blockIdx.y * cells + (size_t)cxy]) return;
+  const KfEntry& frame = kfs[items[blockIdx.y].kf_index];
+  const int cy = cxy / in.cf_width, cx = cxy - cy * in.cf_width;
+  for (int dy = 0; dy < in.cell; ++dy) {
+    for (int dx = 0; dx < in.cell; ++dx) {
+      const int x = cx * in.cell + dx, y = cy * in.cell + dy;
+      if (x >= 1 && y >= 1 && x < in.width - 1 && y < in.height - 1 && !(pitched_load(frame.depth, frame.depth_pitch, y, x) & kInvalidDepthBit)) {
+        candidates[blockIdx.y * padded_count + tile_seq(in, x, y)] = 1;
+        return;
+      }
+    }
+  }
+}
+
+// the outlier filter over the candidates of every keyframe of the batch (a keyframe without co-visible keyframes: one observation, its own)
+__global__ void __launch_bounds__(kLcBlock)
+create_batch_filter_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, const CreateBatchItem* __restrict__ items, const int* __restrict__ covis,
+                           const float* __restrict__ covis_T_frame, int min_observation_count, int padded_count, uint8_t* __restrict__ candidates) {
+  const CreateBatchItem item = items[blockIdx.y];
+  create_filter_body(in, kfs[item.kf_index], kfs, covis + item.covis_offset, covis_T_frame + 12 * (size_t)item.covis_offset, item.n_covis, min_observation_count,
+                     padded_count, candidates + (size_t)blockIdx.y * (size_t)padded_count, blockIdx.x * kLcBlock + threadIdx.x);
+}
+
+// One keyframe of the chain.  Workgroups [0, append_groups): create_append_fused_kernel over the keyframe's candidates whose cell is
+// still free (same handshake, same soft failure, same size cells), each appended surfel pushed into next_occupancy; the other
+// workgroups: what the batch appended before this keyframe -- surfels [batch_begin_size, *size_in) -- pulled into next_occupancy.
+// next_occupancy == nullptr: nothing follows (no push, no pull workgroups).
+__global__ void __launch_bounds__(kLcBlock)
+create_chain_kernel(Intrinsics in, KfEntry frame, KfEntry next_frame, const uint8_t* __restrict__ candidates, const uint8_t* __restrict__ occupancy,
+                    uint8_t* __restrict__ next_occupancy, int padded_count, SurfelsView s, uint32_t batch_begin_size,
+                    const uint32_t* __restrict__ size_in, uint32_t* __restrict__ size_out, uint32_t capacity,
+                    uint32_t* __restrict__ capacity_exceeded, uint32_t* __restrict__ group_words, uint32_t tag, uint32_t append_groups) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x >= append_groups) {   // ---- pull
+    const uint32_t end = min(*size_in, s.size);
+    const uint32_t stride = (gridDim.x - append_groups) * kLcBlock;
+    for (uint32_t i = batch_begin_size + (blockIdx.x - append_groups) * kLcBlock + tid; i < end; i += stride)
+      mark_occupied(in, next_frame.pose.F, next_frame.geom, surfel_position(s, i), surfel_normal(s, i), next_occupancy);
+    return;
+  }
+  __shared__ uint32_t wave_sums[kLcBlock / 64];
+  __shared__ uint32_t wave_sums_b[kLcBlock / 64];
+  const int groups = (int)append_groups;
+  const int per_group = (((padded_count + groups - 1) / groups + kLcBlock - 1) / kLcBlock) * kLcBlock;
+  const int begin = min(padded_count, (int)blockIdx.x * per_group), end = min(padded_count, begin + per_group);
+  // a candidate creates a surfel iff no surfel has come to occupy its cell: the cloud at the batch's begin was looked at before the
+  // candidates were chosen, what the batch appended since is in `occupancy` (complete: the previous launch of the chain wrote it)
+  auto creates = [&](int idx, int* x, int* y) -> bool {
+    if (idx >= end || candidates[idx] != 1) return false;
+    if (!tile_xy(in, (size_t)idx, x, y)) return false;
+    return occupancy[(size_t)(*y / in.cell) * (size_t)in.cf_width + (size_t)(*x / in.cell)] == 0;
+  };
+  uint32_t mine = 0;
+  for (int idx = begin + tid; idx < end; idx += kLcBlock) { int x, y; mine += creates(idx, &x, &y) ? 1u : 0u; }
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+  if (lane == 0) wave_sums[wave] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < kLcBlock / 64; ++w) total += wave_sums[w];
+    __hip_atomic_store(&group_words[blockIdx.x], (tag << 24) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  uint32_t before = 0, all = 0;
+  for (int g = tid; g < groups; g += kLcBlock) {
+    uint32_t word;
+    while (((word = __hip_atomic_load(&group_words[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 24) != tag) __builtin_amdgcn_s_sleep(1);
+    const uint32_t c = word & 0xffffffu;
+    all += c;
+    if (g < (int)blockIdx.x) before += c;
+  }
+  for (int d = 32; d > 0; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+  __syncthreads();   // (wave_sums has been read)
+  if (lane == 0) { wave_sums[wave] = before; wave_sums_b[wave] = all; }
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < kLcBlock / 64; ++w) { base += wave_sums[w]; total += wave_sums_b[w]; }
+  const uint32_t size = *size_in;
+  const bool fits = (uint64_t)size + total <= capacity;
+  if (blockIdx.x == 0 && tid == 0) {
+    *size_out = fits ? size + total : size;
+    if (!fits) *capacity_exceeded = 1u;       // the soft failure: this keyframe creates nothing
+  }
+  if (!fits) return;
+  uint32_t running = size + base;
+  for (int slab = begin; slab < end; slab += kLcBlock) {
+    const int idx = slab + tid;
+    int x = 0, y = 0;
+    const bool flagged = creates(idx, &x, &y);
+    const unsigned long long m = __ballot(flagged);
+    const uint32_t rank_in_wave = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    __syncthreads();   // (the sums of the previous round have been read)
+    if (lane == 0) wave_sums[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t waves_before = 0, slab_total = 0;
+    for (int w = 0; w < kLcBlock / 64; ++w) { const uint32_t c = wave_sums[w]; slab_total += c; if (w < wave) waves_before += c; }
+    if (flagged) {
+      Vec3 gp; uint32_t packed_normal;
+      append_surfel(in, frame, x, y, running + waves_before + rank_in_wave, s, &gp, &packed_normal);
+      if (next_occupancy) mark_occupied(in, next_frame.pose.F, next_frame.geom, gp, unpack_normal10(packed_normal), next_occupancy);   // push: what a sweep would read back
+    }
     running += slab_total;
   }
 }
@@ -648,6 +799,46 @@ void launch_create_append_fused(hipStream_t st, const Intrinsics& in, const KfEn
   hipLaunchKernelGGL(create_append_fused_kernel, dim3(groups), dim3(kLcBlock), 0, st, in, frame, flags, padded, s, size_in, size_out, capacity,
                      capacity_exceeded, group_words, tag);
 }
+// the grid of the fused append / the chain's append part: what the device can hold of `kernel` at once, at most kAppendGroups
+template <typename Kernel>
+static int resident_append_groups(Kernel kernel, int* cache /* per device */) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kLcBlock, 0) != hipSuccess || per_cu < 1) { per_cu = 1; (void)hipGetLastError(); }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { cus = 1; (void)hipGetLastError(); }
+    cache[dev] = std::max(1, per_cu * cus);
+  }
+  const int limit = g_append_groups_limit > 0 ? std::min(g_append_groups_limit, cache[dev]) : cache[dev];
+  return std::min(kAppendGroups, limit);
+}
+void launch_create_batch_prepare(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, const CreateBatchItem* items, int num_items, uint32_t max_list_count,
+                                 const SurfelsView& cloud_at_begin, const uint32_t* lists, uint32_t bounded_tiles, uint8_t* occupancy, uint8_t* candidates,
+                                 bool filter_new_surfels, const int* covis, const float* covis_T_frame, int min_obs) {
+  if (num_items <= 0) return;
+  const size_t cells = (size_t)in.cf_width * (size_t)in.cf_height;
+  const int padded = (int)create_padded_count(in);
+  const uint32_t all_tiles = (cloud_at_begin.size + 63u) / 64u, tail = all_tiles > bounded_tiles ? all_tiles - bounded_tiles : 0u;
+  const uint32_t positions = max_list_count + tail;
+  if (cloud_at_begin.size && positions)
+    hipLaunchKernelGGL(create_batch_occupancy_kernel, dim3(std::min<unsigned>(g1(positions * 64u), 1024u), num_items), dim3(kLcBlock), 0, st, in, kfs, items,
+                       cloud_at_begin, lists, bounded_tiles, occupancy, cells);
+  hipLaunchKernelGGL(create_batch_flag_kernel, dim3(g1((uint32_t)cells), num_items), dim3(kLcBlock), 0, st, in, kfs, items, occupancy, cells, candidates, (size_t)padded);
+  if (filter_new_surfels)
+    hipLaunchKernelGGL(create_batch_filter_kernel, dim3(g1(padded), num_items), dim3(kLcBlock), 0, st, in, kfs, items, covis, covis_T_frame, min_obs, padded, candidates);
+}
+// appended_bound: an upper bound of what the batch has appended before this keyframe (sizes the pull part of the grid)
+void launch_create_chain(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* next_frame, const uint8_t* candidates,
+                         const uint8_t* occupancy, uint8_t* next_occupancy, const SurfelsView& s, uint32_t batch_begin_size, const uint32_t* size_in,
+                         uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded, uint32_t* group_words, uint32_t tag, uint32_t appended_bound) {
+  static int resident_limit[64] = {};
+  const int padded = (int)create_padded_count(in);
+  const unsigned append_groups = (unsigned)std::min(resident_append_groups(create_chain_kernel, resident_limit), (int)g1(padded));
+  const unsigned pull_groups = (next_frame && next_occupancy && appended_bound) ? std::min<unsigned>(g1(appended_bound), 512u) : 0u;
+  hipLaunchKernelGGL(create_chain_kernel, dim3(append_groups + pull_groups), dim3(kLcBlock), 0, st, in, frame, next_frame ? *next_frame : frame, candidates, occupancy,
+                     (next_frame ? next_occupancy : nullptr), padded, s, batch_begin_size, size_in, size_out, capacity, capacity_exceeded, group_words, tag, append_groups);
+}
 void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                           int min_obs, uint32_t* deleted_count) {
   if (s.size) hipLaunchKernelGGL(delete_update_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, in, kfs, num_kfs, s, min_obs, deleted_count);
@@ -720,46 +911,57 @@ sort_keys_kernel(SurfelsView s, float inv_cell, unsigned long long* __restrict__
   keys[i] = surfel_sort_key(surfel_position(s, i), inv_cell);
   idx[i] = i;
 }
-template <typename T>
+// the 8 data rows (and the active flags) of surfel idx[i] to place i of a dense scratch [8][n] (+ [n] bytes)
 __global__ void __launch_bounds__(kLcBlock)
-gather_kernel(const T* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, T* __restrict__ dst) {
+gather_rows_kernel(SurfelsView s, const uint32_t* __restrict__ idx, uint32_t n, float* __restrict__ rows_out, uint8_t* __restrict__ active_out) {
   const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
+  if (i >= n) return;
+  const uint32_t src = idx[i];
+#pragma unroll
+  for (int row = 0; row < kSurfelAccum0; ++row) rows_out[(size_t)row * n + i] = s.row(row)[src];
+  if (s.active) active_out[i] = s.active[src];
+}
+__global__ void __launch_bounds__(kLcBlock)
+scatter_rows_back_kernel(SurfelsView s, uint32_t n, const float* __restrict__ rows_in, const uint8_t* __restrict__ active_in) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int row = 0; row < kSurfelAccum0; ++row) s.row(row)[i] = rows_in[(size_t)row * n + i];
+  if (s.active) s.active[i] = active_in[i];
 }
 
-// Stable sort (radix sort of (key, index) pairs), then the 8 data rows and the active flags are gathered through a
-// scratch row.  Temporary memory is allocated here: this is not on the iteration path.
-hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float inv_cell) {
+// Stable sort (radix sort of (key, index) pairs), then the 8 data rows and the active flags are gathered into a dense copy and
+// written back: four kernels and the library's sort passes, all on the stream, no allocation and no host wait (round 6: the end
+// tasks AND the loop's compaction reorder now; the first version allocated and freed six buffers and synchronised per call).
+// scratch: sort_scratch_bytes(n) bytes, owned by the caller.
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t sort_scratch_bytes(uint32_t n) {
+  size_t temp_bytes = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, (int)n, 0, 63, (hipStream_t)0);
+  return 2 * align256(sizeof(unsigned long long) * (size_t)n) + 2 * align256(sizeof(uint32_t) * (size_t)n) + align256(sizeof(float) * (size_t)n * kSurfelAccum0) +
+         align256((size_t)n) + align256(temp_bytes);
+}
+hipError_t sort_surfels_spatially(hipStream_t st, const SurfelsView& s, float inv_cell, void* scratch, size_t scratch_bytes) {
   const uint32_t n = s.size;
   if (n < 2) return hipSuccess;
-  unsigned long long *keys_in = nullptr, *keys_out = nullptr;
-  uint32_t *idx_in = nullptr, *idx_out = nullptr;
-  float* row_tmp = nullptr;
-  void* temp = nullptr;
-  size_t temp_bytes = 0;
-  hipError_t e = hipSuccess;
-  auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-  if (ok(hipMalloc(&keys_in, sizeof(unsigned long long) * n)) && ok(hipMalloc(&keys_out, sizeof(unsigned long long) * n)) &&
-      ok(hipMalloc(&idx_in, sizeof(uint32_t) * n)) && ok(hipMalloc(&idx_out, sizeof(uint32_t) * n)) && ok(hipMalloc(&row_tmp, sizeof(float) * n)) &&
-      ok(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, 63, st)) &&
-      ok(hipMalloc(&temp, temp_bytes))) {
-    hipLaunchKernelGGL(sort_keys_kernel, dim3(g1(n)), dim3(kLcBlock), 0, st, s, inv_cell, keys_in, idx_in);
-    if (ok(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, 63, st))) {
-      for (int row = 0; row < kSurfelAccum0; ++row) {
-        float* row_ptr = reinterpret_cast<float*>(reinterpret_cast<char*>(s.data) + (size_t)row * s.pitch);
-        hipLaunchKernelGGL(gather_kernel<float>, dim3(g1(n)), dim3(kLcBlock), 0, st, row_ptr, idx_out, n, row_tmp);
-        ok(hipMemcpyAsync(row_ptr, row_tmp, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
-      }
-      if (s.active) {
-        uint8_t* tmp8 = reinterpret_cast<uint8_t*>(row_tmp);
-        hipLaunchKernelGGL(gather_kernel<uint8_t>, dim3(g1(n)), dim3(kLcBlock), 0, st, s.active, idx_out, n, tmp8);
-        ok(hipMemcpyAsync(s.active, tmp8, n, hipMemcpyDeviceToDevice, st));
-      }
-      ok(hipStreamSynchronize(st));
-    }
-  }
-  hipFree(keys_in); hipFree(keys_out); hipFree(idx_in); hipFree(idx_out); hipFree(row_tmp); hipFree(temp);
-  return e;
+  if (!scratch || scratch_bytes < sort_scratch_bytes(n)) return hipErrorInvalidValue;
+  char* p = static_cast<char*>(scratch);
+  auto take = [&](size_t bytes) { char* q = p; p += align256(bytes); return q; };
+  unsigned long long* keys_in = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n));
+  unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n));
+  uint32_t* idx_in = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)n));
+  uint32_t* idx_out = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)n));
+  float* rows = reinterpret_cast<float*>(take(sizeof(float) * (size_t)n * kSurfelAccum0));
+  uint8_t* active = reinterpret_cast<uint8_t*>(take((size_t)n));
+  void* temp = p;
+  size_t temp_bytes = scratch_bytes - (size_t)(p - static_cast<char*>(scratch));
+  hipLaunchKernelGGL(sort_keys_kernel, dim3(g1(n)), dim3(kLcBlock), 0, st, s, inv_cell, keys_in, idx_in);
+  const hipError_t sorted = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, 63, st);
+  if (sorted != hipSuccess) return sorted;   // nothing has been moved yet
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(g1(n)), dim3(kLcBlock), 0, st, s, idx_out, n, rows, active);
+  hipLaunchKernelGGL(scatter_rows_back_kernel, dim3(g1(n)), dim3(kLcBlock), 0, st, s, n, rows, active);
+  return hipGetLastError();
 }
 
 // ---- surfel shards <-> the whole cloud (multi-GPU surfel sharding) --------------------------------------------------------------

@@ -530,6 +530,11 @@ int bahip_debug_set_intrinsics_slices(bahip_context* ctx, int slices);
  * workgroups than the device holds at once (occupancy x compute units, at most 256).  groups > 0 lowers that limit (tests: the path a
  * partitioned or masked device takes), 0 restores it.  The created surfels do not depend on it. */
 int bahip_debug_set_append_groups(int groups);
+/* The creation batch as a chain of one launch per keyframe (bahip_create_surfels_for_keyframes inside a lifecycle batch that knows the
+ * keyframes): 1 (default; environment BAHIP_CREATION_CHAIN=0 switches it off) or 0 = four launches per keyframe as in round 5; the same
+ * surfels either way.  ..._batches: how many calls have taken the chain so far (tests assert the route). */
+int bahip_debug_set_creation_chain(int enabled);
+int bahip_debug_creation_chain_batches(long long* batches_out);
 /* The LDS form holds the normal equations of at most 292 work items; longer lists are cut into slices, one launch each.  items > 0
  * makes the slices that small (tests: 200 keyframes in slices of 64), 0 restores the default. */
 int bahip_debug_set_pose_lds_items(int items);

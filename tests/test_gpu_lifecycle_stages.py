@@ -2,6 +2,8 @@
 B/kernel_supporting_surfels.cu:45, B/kernel_create_surfels.cu:213-356, B/kernel_delete_surfels.cu:84-133 and
 B/kernel_compact_surfels.cu:101-279 against the oracle's restatement of the same function, bit for bit -- not only the
 survivor counts of a whole BundleAdjustment call."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -178,6 +180,68 @@ def test_creation_batch_is_the_sequence_of_creations(min_obs, append_groups, req
         assert n_got == n_ref > 0, (n_got, n_ref)
         assert g.surfels_size == orc.surfels_size
         assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :orc.surfels_size]))
+
+
+def _chain_batches():
+    n = C.c_longlong()
+    capi.check(capi.load().bahip_debug_creation_chain_batches(C.byref(n)))
+    return int(n.value)
+
+
+@pytest.mark.parametrize("min_obs,append_groups,chain", [(2, 0, True), (1, 0, True), (2, 3, True), (2, 0, False)])
+def test_creation_chain_is_the_sequence_of_creations(min_obs, append_groups, chain, request):
+    """The creation batch as a chain of ONE launch per keyframe (kernels_lifecycle.hip: create_chain_kernel -- occupancy of the cloud at
+    the batch's begin, candidates and filter for all keyframes up front; then per keyframe the append, the push of what it appended
+    into the next keyframe's occupancy and the pull of what the batch appended before) against the oracle's creations one by one: the
+    same surfels at the same indices.  Seven keyframes: one creates alone, six form the batch (pushes, pulls over a growing tail, the
+    last keyframe on the old path); the route is asserted."""
+    lib = capi.load()
+    capi.check(lib.bahip_debug_set_append_groups(append_groups))
+    capi.check(lib.bahip_debug_set_creation_chain(1 if chain else 0))
+    request.addfinalizer(lambda: (lib.bahip_debug_set_append_groups(0), lib.bahip_debug_set_creation_chain(1)))
+    scene = common.small_scene(num_keyframes=7, seed=31)
+    rng = np.random.Generator(np.random.PCG64(11))
+    poses = [T if k in (0, 2, 4, 6) else synthetic.perturb_pose(rng, T, 0.03, 0.01) for k, T in enumerate(scene.poses_gt)]
+    orc = common.build_oracle(scene, 900000, poses=poses, create_from=[], min_observation_count=min_obs)
+    g = common.build_gpu(scene, 900000, poses=poses, create_from=[])
+    assert orc.create_surfels_for_keyframe(3, filter_new_surfels=True, covis=[0, 1, 2, 4, 5, 6]) == \
+        g.create_surfels_for_keyframe(3, filter_new_surfels=True, min_observation_count=min_obs, covis=[0, 1, 2, 4, 5, 6]) > 0
+    plan = [(0, [1, 2, 3, 4, 5, 6]), (1, [0, 2]), (2, [4, 6]), (4, [0, 1, 2, 3, 5, 6]), (5, []), (6, [0, 5])]
+    n_ref = [orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis) for k, covis in plan]
+    before = _chain_batches()
+    with g.lifecycle_batch(keyframes=[k for k, _ in plan]):
+        n_got = g.create_surfels_for_keyframes(plan, filter_new_surfels=True, min_observation_count=min_obs)
+    assert _chain_batches() - before == (1 if chain else 0)
+    assert n_got == sum(n_ref) and sum(1 for n in n_ref if n > 0) >= (4 if min_obs == 1 else 2), (n_got, n_ref)
+    assert g.surfels_size == orc.surfels_size
+    assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :orc.surfels_size]))
+
+
+def test_creation_chain_respects_the_capacity():
+    """A keyframe in the middle of the chain that does not fit creates nothing and raises the flag; the keyframes behind it see the
+    cloud without it (B/kernel_create_surfels.cc:162-165, per keyframe)."""
+    scene = common.small_scene(num_keyframes=5, seed=29)
+    lib = capi.load()
+    runs = []
+    for chain in (0, 1):
+        capi.check(lib.bahip_debug_set_creation_chain(chain))
+        try:
+            probe = common.build_gpu(scene, 600000, create_from=[])
+            first = probe.create_surfels_for_keyframe(0, filter_new_surfels=False)
+            second = probe.create_surfels_for_keyframe(1, filter_new_surfels=False)
+            third = probe.create_surfels_for_keyframe(2, filter_new_surfels=False)
+            assert min(first, second, third) > 0
+            g = common.build_gpu(scene, first + second + third // 2, create_from=[])
+            assert g.create_surfels_for_keyframe(0, filter_new_surfels=False) == first
+            before = _chain_batches()
+            with g.lifecycle_batch(keyframes=[1, 2, 3, 4]):
+                created = g.create_surfels_for_keyframes([(1, None), (2, None), (3, None), (4, None)], filter_new_surfels=False)
+            assert _chain_batches() - before == chain
+            assert g.ctx.lib.bahip_context_take_capacity_exceeded(g.ctx.handle) == 1
+            runs.append((created, _rows(g.download_surfels()).copy()))
+        finally:
+            capi.check(lib.bahip_debug_set_creation_chain(1))
+    assert runs[0][0] == runs[1][0] >= second and np.array_equal(runs[0][1], runs[1][1])
 
 
 def test_creation_batch_respects_the_capacity():
