@@ -194,6 +194,8 @@ SIGNATURES = {
     "bahip_debug_set_append_groups": (C.c_int, [C.c_int]),
     "bahip_debug_set_creation_chain": (C.c_int, [C.c_int]),
     "bahip_debug_creation_chain_batches": (C.c_int, [C.POINTER(C.c_longlong)]),
+    "bahip_debug_set_merge_cells": (C.c_int, [C.c_int]),
+    "bahip_debug_merge_cells_batches": (C.c_int, [C.POINTER(C.c_longlong)]),
     "bahip_debug_set_pose_lds_items": (C.c_int, [C.c_int]),
     "bahip_debug_set_pose_lds_shape": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_fused_iteration_begin": (C.c_int, [C.c_int]),

@@ -243,6 +243,23 @@ void launch_merge_decide(hipStream_t st, const Intrinsics& in, const KfEntry& fr
 void launch_merge_apply_insert(hipStream_t st, const Intrinsics& in, const KfEntry* apply_frame, const KfEntry* insert_frame, const SurfelsView& s,
                                const uint32_t* flags, const uint32_t* cell_of, const SupportingView& apply_sup, const SupportingView& insert_sup,
                                uint32_t* deleted_count, const LifecycleCull& apply_cull, const LifecycleCull& insert_cull);
+// a merge batch by cell lists (kernels_lifecycle.hip: merge_pairs_kernel): the associated (surfel, frame) pairs grouped by (frame, cell)
+// up front -- counts and offsets [num_frames * cells + 1] words; pair_cells and pair_ranks [64 * total sweep positions] words; members
+// (words) and member_cell (uint2) [pairs <= 64 * total sweep positions] --, then one launch per frame over its pairs
+// (frame_first[j] = offsets[j * cells], read back by the caller) and one launch that writes the deleted markers.  deleted_at: one word per surfel, ~0 before.
+struct MergeBatchFrame {
+  KfEntry entry;
+  uint32_t list_offset, list_count;   // its visible bounded tiles in `lists`
+  uint32_t pair_offset;               // its first sweep position (wavefront) in pair_cells / pair_ranks
+  uint32_t pad_;
+};
+hipError_t launch_merge_batch_lists(hipStream_t st, const Intrinsics& in, const MergeBatchFrame* frames, int num_frames, uint32_t max_positions, const SurfelsView& s,
+                                    const uint32_t* lists, uint32_t bounded_tiles, uint32_t* counts, uint32_t* offsets, uint32_t* pair_cells, uint32_t* pair_ranks,
+                                    uint32_t* members, void* member_cell, uint32_t* frame_first /* [num_frames + 1] */, void* scan_temp, size_t scan_temp_bytes);
+size_t merge_batch_scan_temp_bytes(size_t entries);
+void launch_merge_pairs(hipStream_t st, const SurfelsView& s, const uint32_t* members, const void* member_cell, uint32_t first_pair,
+                        uint32_t end_pair, uint32_t step, uint32_t* deleted_at, float cell_merge_dist_sq, float cos_thr, uint32_t* deleted_count);
+void launch_merge_batch_apply(hipStream_t st, const SurfelsView& s, const uint32_t* deleted_at);
 // a creation batch: scan + append at *size_in + the new size into *size_out (or *capacity_exceeded raised and nothing appended) in one
 // launch; group_words: create_append_groups() words, cleared before tag 1 and whenever a tag (1 .. 255) would repeat
 int create_append_groups();
@@ -259,12 +276,17 @@ struct CreateBatchItem {
   uint32_t list_offset, list_count;   // its visible bounded tiles in `lists`
   int covis_offset, n_covis;          // its slice of the batch's co-visibility lists
 };
-void launch_create_batch_prepare(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, const CreateBatchItem* items, int num_items, uint32_t max_list_count,
-                                 const SurfelsView& cloud_at_begin, const uint32_t* lists, uint32_t bounded_tiles, uint8_t* occupancy, uint8_t* candidates,
-                                 bool filter_new_surfels, const int* covis, const float* covis_T_frame, int min_obs);
-void launch_create_chain(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* next_frame, const uint8_t* candidates,
-                         const uint8_t* occupancy, uint8_t* next_occupancy, const SurfelsView& s, uint32_t batch_begin_size, const uint32_t* size_in,
-                         uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded, uint32_t* group_words, uint32_t tag, uint32_t appended_bound);
+// scan: [num_items * padded] words; cand_cell: one word, records: kSurfelAccum0 rows (a view whose pitch is the row length), per list
+// position -- at most one candidate per sparse cell and keyframe; first_of_item: [num_items + 1] words (read back by the caller)
+size_t create_batch_scan_temp_bytes(size_t entries);
+hipError_t launch_create_batch_prepare(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, const CreateBatchItem* items, int num_items, uint32_t max_list_count,
+                                       const SurfelsView& cloud_at_begin, const uint32_t* lists, uint32_t bounded_tiles, uint8_t* occupancy, uint8_t* candidates,
+                                       bool filter_new_surfels, const int* covis, const float* covis_T_frame, int min_obs, uint32_t* scan, void* scan_temp,
+                                       size_t scan_temp_bytes, uint32_t* cand_cell, const SurfelsView& records, uint32_t* first_of_item);
+void launch_create_chain(hipStream_t st, const Intrinsics& in, const KfEntry* next_frame, const uint32_t* cand_cell, const SurfelsView& records, uint32_t first,
+                         uint32_t end_of_frame, const uint8_t* occupancy, uint8_t* next_occupancy, const SurfelsView& s, uint32_t batch_begin_size,
+                         const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded, uint32_t* group_words, uint32_t tag,
+                         uint32_t appended_bound);
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags, bool leave_planes_empty = false);
 void launch_create_filter(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* kfs, const int* covis,
                           const float* covis_T_frame, int n_covis, int min_obs, uint8_t* flags);

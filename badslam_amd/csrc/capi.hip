@@ -274,8 +274,9 @@ void bahip_context_destroy(bahip_context* ctx) {
   if (ctx->pinned_work1) hipHostFree(ctx->pinned_work1);
   stage_free(&ctx->stage_kfs); stage_free(&ctx->stage_covis); stage_free(&ctx->stage_window);
   hipFree(ctx->dev_flags); hipFree(ctx->dev_indices); hipFree(ctx->scan_temp);
+  hipFree(ctx->dev_merge_batch);
   hipFree(ctx->dev_sort_scratch);
-  hipFree(ctx->dev_create_occupancy); hipFree(ctx->dev_create_candidates); hipFree(ctx->dev_create_items);
+  hipFree(ctx->dev_create_batch);
   hipFree(ctx->dev_covis); hipFree(ctx->dev_covis_T); hipFree(ctx->dev_covis_csr); hipFree(ctx->dev_tile_bounds); hipFree(ctx->dev_lifecycle_bounds); hipFree(ctx->dev_lifecycle_frames); hipFree(ctx->dev_lifecycle_cursors); hipFree(ctx->dev_lifecycle_lists); hipFree(ctx->dev_window);
   hipFree(ctx->intr_bin_cursors); hipFree(ctx->intr_bin_records); hipHostFree(ctx->intr_bin_counts_host);
   if (ctx->intr_aux_stream) { hipStreamDestroy(ctx->intr_aux_stream); for (hipEvent_t e : ctx->intr_events) if (e) hipEventDestroy(e); }

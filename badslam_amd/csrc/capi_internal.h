@@ -130,12 +130,12 @@ struct bahip_context {
   PoseWork* pinned_work = nullptr;   // read-back of the pose work items + their counter records (page-locked)
   // a creation batch as a chain of one launch per keyframe (bahip_create_surfels_for_keyframes; kernels_lifecycle.hip: create_chain_kernel):
   // per keyframe of the batch the bytes "cell occupied" and "pixel would create a surfel", and the batch's item table
+  void* dev_merge_batch = nullptr;    // bahip_merge_surfels_for_keyframes by cell lists: frame table, counts, offsets, pair cells, members, scan temporary
+  size_t merge_batch_bytes = 0;
   void* dev_sort_scratch = nullptr;   // bahip_sort_surfels_spatially: keys, indices, a dense copy of the data rows, the library's temporary
   size_t sort_scratch_bytes = 0;
-  uint8_t* dev_create_occupancy = nullptr;
-  uint8_t* dev_create_candidates = nullptr;
-  void* dev_create_items = nullptr;
-  size_t create_occupancy_bytes = 0, create_candidates_bytes = 0, create_items_capacity = 0;
+  void* dev_create_batch = nullptr;   // occupancy, candidates, their scan, the compact candidate list with its records, the item table
+  size_t create_batch_bytes = 0;
   uint32_t* merge_planes[BAHIP_MERGE_BUFFER_COUNT] = {};   // the second set of supporting planes of a pipelined merge batch (bahip_merge_surfels_for_keyframes)
   size_t merge_planes_bytes = 0;
   const void* supporting_planes_empty = nullptr;   // the supporting planes (by their first plane) that the last merge call left empty

@@ -8,9 +8,14 @@ using namespace bahip_capi;
 // the creation chain (create_chain_kernel): on unless BAHIP_CREATION_CHAIN=0 / bahip_debug_set_creation_chain(0); how many batches took it
 static int g_creation_chain_enabled = bahip_env_int("BAHIP_CREATION_CHAIN", 1);
 static long long g_creation_chain_batches = 0;
+// a merge batch by cell lists (merge_cells_kernel): on unless BAHIP_MERGE_CELLS=0 / bahip_debug_set_merge_cells(0)
+static int g_merge_cells_enabled = bahip_env_int("BAHIP_MERGE_CELLS", 1);
+static long long g_merge_cells_batches = 0;
 
 extern "C" {
 int bahip_debug_set_creation_chain(int enabled) { g_creation_chain_enabled = enabled ? 1 : 0; return 0; }
+int bahip_debug_set_merge_cells(int enabled) { g_merge_cells_enabled = enabled ? 1 : 0; return 0; }
+int bahip_debug_merge_cells_batches(long long* batches_out) { if (batches_out) *batches_out = g_merge_cells_batches; return 0; }
 int bahip_debug_creation_chain_batches(long long* batches_out) { if (batches_out) *batches_out = g_creation_chain_batches; return 0; }
 // ---- lifecycle ---------------------------------------------------------------------------------------------
 static int supporting_view(uint32_t* const* supporting, uint32_t pitch, SupportingView* v) {
@@ -112,7 +117,89 @@ int bahip_merge_surfels_for_keyframes(bahip_context* ctx, float merge_dist_facto
   REQUIRE(supporting_view(supporting, supporting_pitch, &sup[0]) == 0, "supporting-surfel planes missing");
   if (merged_count_out) *merged_count_out = 0;
   hipStream_t st = ctx->stream;
-  if (num_frames > 0 && surfels->surfels_size > 0) {
+  // By cell lists (round 6; kernels_lifecycle.hip: merge_cells_kernel): when the open lifecycle batch knows every frame of this call and
+  // every frame brings its BA planes (the association sweep reads all of them at once), the members of every (frame, cell) are listed
+  // up front and each frame costs ONE launch of one thread per cell.
+  bool by_cells = false;
+  if (g_merge_cells_enabled && num_frames > 0 && surfels->surfels_size > 0) {
+    const bool bounds_valid = ctx->lifecycle_bounds_tiles != 0 && ctx->lifecycle_bounds_data == surfels->data &&
+                              (uint64_t)ctx->lifecycle_bounds_tiles * 64 <= surfels->surfels_size && !ctx->lifecycle_list_counts.empty();
+    const uint32_t bounded_tiles = ctx->lifecycle_bounds_tiles;
+    const uint32_t all_tiles = (surfels->surfels_size + 63u) / 64u, tail = all_tiles > bounded_tiles ? all_tiles - bounded_tiles : 0u;
+    std::vector<MergeBatchFrame> table((size_t)num_frames);
+    bool known = bounds_valid;
+    uint64_t positions = 0;
+    uint32_t max_positions = 0;
+    for (int j = 0; j < num_frames && known; ++j) {
+      const float* F = frame_T_global_3x4 + 12 * (size_t)j;
+      const size_t listed = ctx->lifecycle_list_counts.size();
+      size_t f = 0;
+      while (f < listed && memcmp(&ctx->lifecycle_frames[12 * f], F, 12 * sizeof(float)) != 0) ++f;
+      // (the association sweep reads the BA planes of all frames at once: a frame handed over without them gets a packing slot of its
+      // own -- for a small batch; a long one without planes takes the pipelined path, which re-packs ONE slot frame after frame)
+      if (f == listed || (frames[j].planes == nullptr && num_frames > 64)) { known = false; break; }
+      if (make_entry(ctx, frames[j], frames[j].planes ? 0 : (size_t)j + 1, &table[j].entry)) return 1;
+      memcpy(table[j].entry.pose.F, F, 12 * sizeof(float));
+      table[j].list_offset = ctx->lifecycle_list_offsets[f];
+      table[j].list_count = ctx->lifecycle_list_counts[f];
+      table[j].pair_offset = (uint32_t)positions;
+      table[j].pad_ = 0;
+      positions += (uint64_t)table[j].list_count + tail;
+      max_positions = std::max(max_positions, table[j].list_count + tail);
+    }
+    const size_t cells = (size_t)ctx->in.cf_width * (size_t)ctx->in.cf_height;
+    const size_t entries = (size_t)num_frames * cells + 1;
+    if (known && positions * 64 < ((uint64_t)1 << 31) && entries < ((size_t)1 << 31)) {
+      auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+      const size_t sweep = 64 * (size_t)positions;   // lanes of all sweep positions: an upper bound of the pairs
+      const size_t table_bytes = align(sizeof(MergeBatchFrame) * (size_t)num_frames), entry_bytes = align(sizeof(uint32_t) * entries),
+                   word_bytes = align(sizeof(uint32_t) * sweep), first_bytes = align(sizeof(uint32_t) * ((size_t)num_frames + 1)),
+                   temp_bytes = align(merge_batch_scan_temp_bytes(entries));
+      const size_t need = table_bytes + 2 * entry_bytes + 3 * word_bytes + 2 * word_bytes + first_bytes + temp_bytes;
+      if (need > ctx->merge_batch_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        hipFree(ctx->dev_merge_batch); ctx->dev_merge_batch = nullptr; ctx->merge_batch_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->dev_merge_batch, need + need / 4));
+        ctx->merge_batch_bytes = need + need / 4;
+      }
+      char* p = static_cast<char*>(ctx->dev_merge_batch);
+      MergeBatchFrame* dev_table = reinterpret_cast<MergeBatchFrame*>(p); p += table_bytes;
+      uint32_t* counts = reinterpret_cast<uint32_t*>(p); p += entry_bytes;
+      uint32_t* offsets = reinterpret_cast<uint32_t*>(p); p += entry_bytes;
+      uint32_t* pair_cells = reinterpret_cast<uint32_t*>(p); p += word_bytes;
+      uint32_t* pair_ranks = reinterpret_cast<uint32_t*>(p); p += word_bytes;
+      uint32_t* members = reinterpret_cast<uint32_t*>(p); p += word_bytes;
+      void* member_cell = p; p += 2 * word_bytes;
+      uint32_t* frame_first = reinterpret_cast<uint32_t*>(p); p += first_bytes;
+      void* scan_temp = p;
+      HIP_TRY(hipMemcpyAsync(dev_table, table.data(), sizeof(MergeBatchFrame) * (size_t)num_frames, hipMemcpyHostToDevice, st));
+      const SurfelsView s = make_view(surfels);
+      HIP_TRY(launch_merge_batch_lists(st, ctx->in, dev_table, num_frames, max_positions, s, ctx->dev_lifecycle_lists, bounded_tiles, counts, offsets, pair_cells,
+                                       pair_ranks, members, member_cell, frame_first, scan_temp, temp_bytes));
+      // per-surfel words "deleted at step" in accum row 0 (scratch by contract, B/kernels.cuh:78-90): ~0 = not deleted by this batch
+      uint32_t* deleted_at = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(surfels->data) + (size_t)kSurfelAccum0 * surfels->pitch_bytes);
+      HIP_TRY(hipMemsetAsync(deleted_at, 0xff, sizeof(uint32_t) * (size_t)surfels->surfels_size, st));
+      std::vector<uint32_t> first((size_t)num_frames + 1);
+      HIP_TRY(hipMemcpyAsync(first.data(), frame_first, sizeof(uint32_t) * first.size(), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));   // `table` is pageable and goes out of scope; the grids below come from `first`
+      const float cell = (float)ctx->in.cell;
+      const float cell_merge_dist_sq = cell * cell * merge_dist_factor * merge_dist_factor;
+      uint32_t* counter = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3;   // the deferred count of bahip_take_merged_count
+      for (int j = 0; j < num_frames; ++j) {
+        launch_merge_pairs(st, s, members, member_cell, first[(size_t)j], first[(size_t)j + 1], (uint32_t)j, deleted_at, cell_merge_dist_sq,
+                           kCosNormalCompat, counter);
+        CHECK_LAUNCH();
+      }
+      launch_merge_batch_apply(st, s, deleted_at);
+      CHECK_LAUNCH();
+      // (the planes are not used; the batch's contract is that they end empty)
+      if (ctx->supporting_planes_empty != sup[0].b[0]) launch_supporting_fill(st, sup[0], ctx->in.cf_width, ctx->in.cf_height);
+      ctx->supporting_planes_empty = sup[0].b[0];
+      by_cells = true;
+      ++g_merge_cells_batches;
+    }
+  }
+  if (!by_cells && num_frames > 0 && surfels->surfels_size > 0) {
     // the second set of planes: same pitch, the sparse-cell region's rows
     const size_t plane_bytes = (size_t)supporting_pitch * (size_t)ctx->in.cf_height;
     if (plane_bytes > ctx->merge_planes_bytes) {
@@ -419,31 +506,40 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
       max_list = std::max(max_list, items[j].list_count);
     }
     const size_t n = (size_t)num_keyframes - 1, occupancy_bytes = n * cells, candidates_bytes = n * px;
-    if (known && occupancy_bytes + candidates_bytes <= ((size_t)4 << 30)) {
-      if (occupancy_bytes > ctx->create_occupancy_bytes) {
-        hipFree(ctx->dev_create_occupancy); ctx->dev_create_occupancy = nullptr; ctx->create_occupancy_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->dev_create_occupancy, occupancy_bytes + occupancy_bytes / 4));
-        ctx->create_occupancy_bytes = occupancy_bytes + occupancy_bytes / 4;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // one block: occupancy, candidates, the scan over them, the compact list's cells and records (at most one candidate per cell and
+    // keyframe), the items, the list position of every keyframe's first candidate, the library's temporary
+    const size_t columns = n * cells, scan_temp_bytes = known ? create_batch_scan_temp_bytes(n * px) : 0;
+    const size_t need = align(occupancy_bytes) + align(candidates_bytes) + align(sizeof(uint32_t) * n * px) + align(sizeof(uint32_t) * columns) +
+                        align(sizeof(float) * columns * kSurfelAccum0) + align(sizeof(CreateBatchItem) * n) + align(sizeof(uint32_t) * (n + 1)) + align(scan_temp_bytes);
+    if (known && need <= ((size_t)16 << 30) && sizeof(float) * columns < ((size_t)1 << 32)) {
+      if (need > ctx->create_batch_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        hipFree(ctx->dev_create_batch); ctx->dev_create_batch = nullptr; ctx->create_batch_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->dev_create_batch, need + need / 4));
+        ctx->create_batch_bytes = need + need / 4;
       }
-      if (candidates_bytes > ctx->create_candidates_bytes) {
-        hipFree(ctx->dev_create_candidates); ctx->dev_create_candidates = nullptr; ctx->create_candidates_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->dev_create_candidates, candidates_bytes + candidates_bytes / 4));
-        ctx->create_candidates_bytes = candidates_bytes + candidates_bytes / 4;
-      }
-      if (n > ctx->create_items_capacity) {
-        hipFree(ctx->dev_create_items); ctx->dev_create_items = nullptr; ctx->create_items_capacity = 0;
-        HIP_TRY(hipMalloc(&ctx->dev_create_items, (n + 64) * sizeof(CreateBatchItem)));
-        ctx->create_items_capacity = n + 64;
-      }
-      HIP_TRY(hipMemcpyAsync(ctx->dev_create_items, items.data(), n * sizeof(CreateBatchItem), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemsetAsync(ctx->dev_create_occupancy, 0, occupancy_bytes, st));
-      HIP_TRY(hipMemsetAsync(ctx->dev_create_candidates, 0, candidates_bytes, st));
+      char* p = static_cast<char*>(ctx->dev_create_batch);
+      uint8_t* occupancy = reinterpret_cast<uint8_t*>(p); p += align(occupancy_bytes);
+      uint8_t* candidates = reinterpret_cast<uint8_t*>(p); p += align(candidates_bytes);
+      uint32_t* scan = reinterpret_cast<uint32_t*>(p); p += align(sizeof(uint32_t) * n * px);
+      uint32_t* cand_cell = reinterpret_cast<uint32_t*>(p); p += align(sizeof(uint32_t) * columns);
+      SurfelsView records;
+      records.data = reinterpret_cast<float*>(p); records.pitch = (uint32_t)(sizeof(float) * columns); records.active = nullptr; records.size = (uint32_t)columns;
+      p += align(sizeof(float) * columns * kSurfelAccum0);
+      CreateBatchItem* dev_items = reinterpret_cast<CreateBatchItem*>(p); p += align(sizeof(CreateBatchItem) * n);
+      uint32_t* first_of_item = reinterpret_cast<uint32_t*>(p); p += align(sizeof(uint32_t) * (n + 1));
+      void* scan_temp = p;
+      HIP_TRY(hipMemcpyAsync(dev_items, items.data(), n * sizeof(CreateBatchItem), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemsetAsync(occupancy, 0, occupancy_bytes, st));
+      HIP_TRY(hipMemsetAsync(candidates, 0, candidates_bytes, st));
       const SurfelsView cloud_at_begin = make_view(surfels);
-      launch_create_batch_prepare(st, ctx->in, ctx->dev_kfs, static_cast<const CreateBatchItem*>(ctx->dev_create_items), (int)n, max_list, cloud_at_begin,
-                                  ctx->dev_lifecycle_lists, bounded_tiles, ctx->dev_create_occupancy, ctx->dev_create_candidates, filter_new_surfels != 0,
-                                  ctx->dev_covis, ctx->dev_covis_T, min_observation_count);
-      CHECK_LAUNCH();
-      HIP_TRY(hipStreamSynchronize(st));   // `items` is pageable and goes out of scope
+      HIP_TRY(launch_create_batch_prepare(st, ctx->in, ctx->dev_kfs, dev_items, (int)n, max_list, cloud_at_begin, ctx->dev_lifecycle_lists, bounded_tiles, occupancy,
+                                          candidates, filter_new_surfels != 0, ctx->dev_covis, ctx->dev_covis_T, min_observation_count, scan, scan_temp,
+                                          scan_temp_bytes, cand_cell, records, first_of_item));
+      std::vector<uint32_t> first(n + 1);
+      HIP_TRY(hipMemcpyAsync(first.data(), first_of_item, sizeof(uint32_t) * (n + 1), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));   // `items` is pageable and goes out of scope; the chain's grids come from `first`
       bahip_surfels whole = *surfels;
       whole.surfels_size = surfels->capacity;   // (the chain addresses rows by index; sizes are read on the device)
       const SurfelsView s = make_view(&whole);
@@ -451,10 +547,9 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
         const uint32_t tag = (uint32_t)(j % 255) + 1u;
         if (j > 0 && tag == 1u) HIP_TRY(hipMemsetAsync(group_words, 0, sizeof(uint32_t) * (size_t)groups, st));   // the tags start over
         const bool has_next = j + 2 < num_keyframes;   // (the last keyframe takes the old path: it looks at the cloud itself)
-        const uint32_t appended_bound = (uint32_t)std::min<uint64_t>((uint64_t)surfels->capacity - surfels->surfels_size, (uint64_t)j * cells);
-        launch_create_chain(st, ctx->in, ctx->host_kfs[keyframe_indices[j]], has_next ? &ctx->host_kfs[keyframe_indices[j + 1]] : nullptr,
-                            ctx->dev_create_candidates + (size_t)j * px, ctx->dev_create_occupancy + (size_t)j * cells,
-                            has_next ? ctx->dev_create_occupancy + (size_t)(j + 1) * cells : nullptr, s, (uint32_t)surfels->surfels_size,
+        const uint32_t appended_bound = (uint32_t)std::min<uint64_t>((uint64_t)surfels->capacity - surfels->surfels_size, (uint64_t)first[(size_t)j]);
+        launch_create_chain(st, ctx->in, has_next ? &ctx->host_kfs[keyframe_indices[j + 1]] : nullptr, cand_cell, records, first[(size_t)j], first[(size_t)j + 1],
+                            occupancy + (size_t)j * cells, has_next ? occupancy + (size_t)(j + 1) * cells : nullptr, s, (uint32_t)surfels->surfels_size,
                             size_cell[j & 1], size_cell[(j & 1) ^ 1], (uint32_t)surfels->capacity, exceeded_on_device, group_words, tag, appended_bound);
         CHECK_LAUNCH();
       }

@@ -202,6 +202,130 @@ merge_apply_insert_kernel(Intrinsics in, KfEntry apply_frame, KfEntry insert_fra
   else supporting_insert_body(in, insert_frame, s, insert_sup, insert_lb, s.size, blockIdx.x - apply_groups, flags);
 }
 
+// ---- a merge batch by cell lists (round 6) ------------------------------------------------------------------------------------------
+// Which sparse cell of keyframe j a surfel is associated with does not change during a merge batch (merging only marks surfels deleted),
+// and the decision about a surfel needs nothing but the members of its own cell: the three lowest indices still alive and the merge
+// tests against them (merge_decide_kernel).  So the batch is cut in two:
+//   up front, for ALL keyframes of the batch at once: the associated (surfel, keyframe) PAIRS, grouped by (keyframe, cell) --
+//     merge_batch_associate_kernel notes each pair's cell and its rank in the cell (the returning atomic that counts the cell), a
+//     library scan turns the counts into offsets, merge_batch_fill_kernel writes each pair to offset + rank (no atomics);
+//   then ONE launch per keyframe, one thread per PAIR, no atomics, no planes (merge_pairs_kernel): which of the cell's members earlier
+//     keyframes of the batch have deleted, the three lowest indices of the rest, merge_decide_kernel's decision about this pair's surfel.
+// A deletion is recorded as the STEP at which it happened (deleted_at[i] = j; the word starts as ~0): for step j a member counts as
+// alive iff deleted_at >= j, so the threads of one launch read the same answer whether or not a neighbour has already written its own
+// deletion, and positions stay readable; merge_batch_apply_kernel writes the deleted markers once the batch is through.
+// Per keyframe that is one dependency chain of four loads (pair -> deleted_at of its mates -> rows -> word) instead of insert (an
+// atomicMin chain per surfel), decide and apply.  Same deletions as the keyframe-by-keyframe merges
+// (tests/test_gpu_lifecycle_stages.py::test_merge_bit_exact).
+__global__ void __launch_bounds__(kLcBlock)
+merge_batch_associate_kernel(Intrinsics in, const MergeBatchFrame* __restrict__ frames, SurfelsView s, const uint32_t* __restrict__ lists, uint32_t bounded_tiles,
+                             uint32_t* __restrict__ counts /* [n * cells (+ 1)], zeroed */, uint32_t cells, uint32_t* __restrict__ pair_cells,
+                             uint32_t* __restrict__ pair_ranks) {
+  const MergeBatchFrame& f = frames[blockIdx.y];
+  const uint32_t all_tiles = (s.size + 63u) / 64u, tail = all_tiles > bounded_tiles ? all_tiles - bounded_tiles : 0u;
+  const uint32_t positions = f.list_count + tail;
+  for (uint32_t w = (blockIdx.x * kLcBlock + threadIdx.x) >> 6; w < positions; w += gridDim.x * (kLcBlock / 64)) {
+    const uint32_t tile = w < f.list_count ? lists[f.list_offset + w] : bounded_tiles + (w - f.list_count);
+    const uint32_t i = tile * 64u + (threadIdx.x & 63u);
+    const size_t at = ((size_t)f.pair_offset + w) * 64u + (threadIdx.x & 63u);
+    uint32_t cell = 0;
+    Assoc r;
+    if (i < s.size && project_associate<false>(in, f.entry.pose.F, f.entry.geom, surfel_position(s, i), surfel_normal(s, i), &r, nullptr)) {
+      cell = 1u + (uint32_t)(r.py / in.cell) * (uint32_t)in.cf_width + (uint32_t)(r.px / in.cell);
+      pair_ranks[at] = atomicAdd(&counts[(size_t)blockIdx.y * cells + (cell - 1u)], 1u);
+    }
+    pair_cells[at] = cell;
+  }
+}
+__global__ void __launch_bounds__(kLcBlock)
+merge_batch_fill_kernel(const MergeBatchFrame* __restrict__ frames, uint32_t surfels_size, const uint32_t* __restrict__ lists, uint32_t bounded_tiles,
+                        const uint32_t* __restrict__ offsets, uint32_t cells, const uint32_t* __restrict__ pair_cells, const uint32_t* __restrict__ pair_ranks,
+                        uint32_t* __restrict__ members, uint2* __restrict__ member_cell /* begin, count of the member's cell */) {
+  const MergeBatchFrame& f = frames[blockIdx.y];
+  const uint32_t all_tiles = (surfels_size + 63u) / 64u, tail = all_tiles > bounded_tiles ? all_tiles - bounded_tiles : 0u;
+  const uint32_t positions = f.list_count + tail;
+  for (uint32_t w = (blockIdx.x * kLcBlock + threadIdx.x) >> 6; w < positions; w += gridDim.x * (kLcBlock / 64)) {
+    const size_t at = ((size_t)f.pair_offset + w) * 64u + (threadIdx.x & 63u);
+    const uint32_t cell = pair_cells[at];
+    if (!cell) continue;
+    const uint32_t tile = w < f.list_count ? lists[f.list_offset + w] : bounded_tiles + (w - f.list_count);
+    const size_t slot = (size_t)blockIdx.y * cells + (cell - 1u);
+    const uint32_t begin = offsets[slot], count = offsets[slot + 1] - begin, pos = begin + pair_ranks[at];
+    members[pos] = tile * 64u + (threadIdx.x & 63u);
+    member_cell[pos] = make_uint2(begin, count);
+  }
+}
+// One keyframe (step) of the batch: thread p decides the surfel of pair first + p.  The rows of the (up to) four surfels a decision
+// looks at are requested together, before any test: merge_test's early return would put a round trip to memory between its loads.
+struct MergeRows { Vec3 p, n; float r2; };
+__device__ __forceinline__ MergeRows merge_rows(const SurfelsView& s, uint32_t i) {
+  MergeRows r;
+  r.p = surfel_position(s, i); r.n = surfel_normal(s, i); r.r2 = s.row(kSurfelRadiusSquared)[i];
+  return r;
+}
+__device__ __forceinline__ bool merge_test_rows(const MergeRows& a, const MergeRows& b, float cos_thr, float cell_merge_dist_sq) {   // merge_test(s, a, b, ...)
+  if (!(dot3(b.n, a.n) > cos_thr)) return false;
+  const float min_r = fminf(b.r2, a.r2);
+  const Vec3 d = b.p - a.p;
+  return (d.x * d.x + d.y * d.y + d.z * d.z) < min_r * cell_merge_dist_sq;
+}
+__global__ void __launch_bounds__(kLcBlock)
+merge_pairs_kernel(SurfelsView s, const uint32_t* __restrict__ members, const uint2* __restrict__ member_cell,
+                   uint32_t first, uint32_t end /* the pairs of this frame */, uint32_t step,
+                   uint32_t* __restrict__ deleted_at, float cell_merge_dist_sq, float cos_thr, uint32_t* __restrict__ deleted_count) {
+  for (uint32_t pos = first + blockIdx.x * kLcBlock + threadIdx.x; pos < end; pos += gridDim.x * kLcBlock) {
+    const uint2 c = member_cell[pos];
+    const uint32_t i = members[pos];
+    if (c.y < 2u) continue;
+    // the three lowest indices among the cell's members that no EARLIER step has deleted: the cell's slots.  The members of a cell are
+    // neighbours in `members` (this pair is one of them): up to eight are requested at once, their words at once, before any is looked at
+    uint32_t s0 = kInvalidIndex, s1 = kInvalidIndex, s2 = kInvalidIndex;
+    auto offer = [&](uint32_t k, uint32_t at) {
+      if (at < step) return;
+      if (k < s0) { const uint32_t t = s0; s0 = k; k = t; }
+      if (k < s1) { const uint32_t t = s1; s1 = k; k = t; }
+      if (k < s2) s2 = k;
+    };
+    {
+      uint32_t mate[8], at[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) mate[k] = members[c.x + (k < c.y ? k : 0u)];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) at[k] = deleted_at[mate[k]];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) if (k < c.y) offer(mate[k], at[k]);
+    }
+    for (uint32_t k = 8u; k < c.y; ++k) { const uint32_t o = members[c.x + k]; offer(o, deleted_at[o]); }
+    if (i == s0 || s1 == kInvalidIndex || deleted_at[i] < step) continue;
+    const MergeRows r0 = merge_rows(s, s0), r1 = merge_rows(s, s1), r2 = merge_rows(s, s2 != kInvalidIndex ? s2 : s1), ri = merge_rows(s, i);
+    // merge_decide_kernel's decisions (B/kernel_supporting_surfels.cu:60-86 as a sequential ascending sweep would take them)
+    const bool d1 = merge_test_rows(r1, r0, cos_thr, cell_merge_dist_sq);
+    bool del;
+    if (i == s1) {
+      del = d1;
+    } else {
+      const bool d2 = (s2 != kInvalidIndex) && (merge_test_rows(r2, r0, cos_thr, cell_merge_dist_sq) || (!d1 && merge_test_rows(r2, r1, cos_thr, cell_merge_dist_sq)));
+      if (i == s2) del = d2;
+      else del = merge_test_rows(ri, r0, cos_thr, cell_merge_dist_sq) || (!d1 && merge_test_rows(ri, r1, cos_thr, cell_merge_dist_sq)) ||
+                 (!d2 && merge_test_rows(ri, r2, cos_thr, cell_merge_dist_sq));
+    }
+    if (del) deleted_at[i] = step;
+    const unsigned long long b = __ballot(del);
+    if (b && (threadIdx.x & 63) == __ffsll((long long)b) - 1) atomicAdd(deleted_count, (uint32_t)__popcll(b));
+  }
+}
+// frame_first[j] = the first pair of frame j (offsets[j * cells]); [n] = all pairs
+__global__ void __launch_bounds__(kLcBlock)
+merge_batch_frame_first_kernel(const uint32_t* __restrict__ offsets, uint32_t cells, uint32_t num_frames, uint32_t* __restrict__ frame_first) {
+  const uint32_t j = blockIdx.x * kLcBlock + threadIdx.x;
+  if (j <= num_frames) frame_first[j] = offsets[(size_t)j * cells];
+}
+__global__ void __launch_bounds__(kLcBlock)
+merge_batch_apply_kernel(SurfelsView s, const uint32_t* __restrict__ deleted_at) {
+  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
+  if (i < s.size && deleted_at[i] != kInvalidIndex) s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits);
+}
+
 // ---- creation ---------------------------------------------------------------------------------------
 // New surfels are numbered tile-major: tiles of 8x8 sparse cells (TP = 8*cell pixels per side),
 // row-major inside a tile, so that the 64 surfels of a wavefront form a compact patch that
@@ -488,15 +612,19 @@ create_append_fused_kernel(Intrinsics in, KfEntry frame, const uint8_t* __restri
 // keyframe j is free is decided by the cloud as it was when the batch began plus what keyframes 0 .. j - 1 of the batch appended, while
 // which pixel of a free cell would create a surfel and whether that candidate passes the outlier filter are functions of the
 // keyframes' images and poses alone (create_flag_kernel, create_filter_pair read no surfel).  So the batch is cut in two:
-//   up front, for ALL keyframes of the batch at once (three launches whatever the batch's length):
+//   up front, for ALL keyframes of the batch at once (a handful of launches whatever the batch's length):
 //     occupancy[j][cell] <- 1 where a surfel of the cloud at the batch's begin is associated with keyframe j   (create_batch_occupancy_kernel)
 //     candidates[j][seq] <- 1 for the first valid pixel of every cell that is free so far                      (create_batch_flag_kernel)
 //     candidates[j][seq] <- 0 where the candidate fails the filter                                             (create_batch_filter_kernel)
+//     the candidates of all keyframes as ONE compact list in (keyframe, sequence) order (a library scan over the flags), and for every
+//     entry its cell and the eight data rows of the surfel it would create -- append_surfel writes them into a record buffer
+//     (create_batch_records_kernel): nothing of that depends on the cloud either
 //   then the chain, ONE launch per keyframe (create_chain_kernel) instead of four:
-//     the candidates of keyframe j whose cell is still free are counted, scanned and appended exactly like create_append_fused_kernel
-//     does (tagged-word grid handshake, soft failure, two size cells); every appended surfel is at once projected into keyframe j + 1
-//     (push), and further workgroups of the same launch project what keyframes 0 .. j - 1 appended into keyframe j + 1 (pull): when the
-//     launch ends, occupancy[j + 1] is complete.
+//     the candidates of keyframe j whose cell is still free are counted and scanned like create_append_fused_kernel does (tagged-word
+//     grid handshake, soft failure, two size cells) and their records COPIED to the end of the cloud; every appended surfel is at once
+//     projected into keyframe j + 1 (push), and further workgroups of the same launch project what keyframes 0 .. j - 1 appended into
+//     keyframe j + 1 (pull): when the launch ends, occupancy[j + 1] is complete.  The chain's launch is a short dependency chain:
+//     candidate cell -> occupancy byte -> handshake -> record rows -> the next keyframe's pixel word.
 // Same surfels at the same indices as n one-keyframe creations (tests/test_gpu_lifecycle_stages.py).
 __device__ __forceinline__ void mark_occupied(const Intrinsics& in, const float* __restrict__ F, const uint32_t* __restrict__ geom, const Vec3& gp, const Vec3& gn,
                                               uint8_t* __restrict__ occupancy) {
@@ -546,13 +674,34 @@ create_batch_filter_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, const
                      padded_count, candidates + (size_t)blockIdx.y * (size_t)padded_count, blockIdx.x * kLcBlock + threadIdx.x);
 }
 
-// One keyframe of the chain.  Workgroups [0, append_groups): create_append_fused_kernel over the keyframe's candidates whose cell is
-// still free (same handshake, same soft failure, same size cells), each appended surfel pushed into next_occupancy; the other
-// workgroups: what the batch appended before this keyframe -- surfels [batch_begin_size, *size_in) -- pulled into next_occupancy.
-// next_occupancy == nullptr: nothing follows (no push, no pull workgroups).
+// The compact candidate list: position scan[idx] - 1 of flagged entry idx = item * padded_count + seq (inclusive scan of the flags).
+// For every entry: the sparse cell of its pixel, and the surfel it would create, written by append_surfel itself into `records` -- a
+// SurfelsView over a buffer with one column per list position.  first_of_item[j] = the list position of keyframe j's first candidate.
 __global__ void __launch_bounds__(kLcBlock)
-create_chain_kernel(Intrinsics in, KfEntry frame, KfEntry next_frame, const uint8_t* __restrict__ candidates, const uint8_t* __restrict__ occupancy,
-                    uint8_t* __restrict__ next_occupancy, int padded_count, SurfelsView s, uint32_t batch_begin_size,
+create_batch_records_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, const CreateBatchItem* __restrict__ items, const uint8_t* __restrict__ candidates,
+                            const uint32_t* __restrict__ scan, int padded_count, uint32_t* __restrict__ cand_cell, SurfelsView records,
+                            uint32_t* __restrict__ first_of_item /* [n + 1] */) {
+  const int seq = blockIdx.x * kLcBlock + threadIdx.x;
+  const size_t base = (size_t)blockIdx.y * (size_t)padded_count;
+  if (seq == 0) {
+    first_of_item[blockIdx.y] = base ? scan[base - 1] : 0u;
+    if (blockIdx.y + 1 == gridDim.y) first_of_item[gridDim.y] = scan[base + (size_t)padded_count - 1];
+  }
+  if (seq >= padded_count || candidates[base + seq] != 1) return;
+  int x, y;
+  if (!tile_xy(in, (size_t)seq, &x, &y)) return;   // (never: padding is not flagged)
+  const uint32_t pos = scan[base + seq] - 1u;
+  cand_cell[pos] = (uint32_t)(y / in.cell) * (uint32_t)in.cf_width + (uint32_t)(x / in.cell);
+  append_surfel(in, kfs[items[blockIdx.y].kf_index], x, y, pos, records);
+}
+
+// One keyframe of the chain.  Workgroups [0, append_groups): the keyframe's candidates [first, end) of the compact list whose cell is
+// still free are counted, scanned (create_append_fused_kernel's handshake, soft failure and size cells) and their records copied to
+// the cloud, each appended surfel pushed into next_occupancy; the other workgroups: what the batch appended before this keyframe --
+// surfels [batch_begin_size, *size_in) -- pulled into next_occupancy.  next_occupancy == nullptr: nothing follows.
+__global__ void __launch_bounds__(kLcBlock)
+create_chain_kernel(Intrinsics in, KfEntry next_frame, const uint32_t* __restrict__ cand_cell, SurfelsView records, uint32_t first, uint32_t end_of_frame,
+                    const uint8_t* __restrict__ occupancy, uint8_t* __restrict__ next_occupancy, SurfelsView s, uint32_t batch_begin_size,
                     const uint32_t* __restrict__ size_in, uint32_t* __restrict__ size_out, uint32_t capacity,
                     uint32_t* __restrict__ capacity_exceeded, uint32_t* __restrict__ group_words, uint32_t tag, uint32_t append_groups) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,18 +714,14 @@ create_chain_kernel(Intrinsics in, KfEntry frame, KfEntry next_frame, const uint
   }
   __shared__ uint32_t wave_sums[kLcBlock / 64];
   __shared__ uint32_t wave_sums_b[kLcBlock / 64];
-  const int groups = (int)append_groups;
-  const int per_group = (((padded_count + groups - 1) / groups + kLcBlock - 1) / kLcBlock) * kLcBlock;
-  const int begin = min(padded_count, (int)blockIdx.x * per_group), end = min(padded_count, begin + per_group);
+  const uint32_t size = *size_in;   // (requested first: the launch's longest wait is for memory)
+  const uint32_t groups = append_groups, count = end_of_frame - first;
+  const uint32_t per_group = (((count + groups - 1u) / groups + kLcBlock - 1u) / kLcBlock) * kLcBlock;
+  const uint32_t begin = first + min(count, blockIdx.x * per_group), end = first + min(count, blockIdx.x * per_group + per_group);
   // a candidate creates a surfel iff no surfel has come to occupy its cell: the cloud at the batch's begin was looked at before the
   // candidates were chosen, what the batch appended since is in `occupancy` (complete: the previous launch of the chain wrote it)
-  auto creates = [&](int idx, int* x, int* y) -> bool {
-    if (idx >= end || candidates[idx] != 1) return false;
-    if (!tile_xy(in, (size_t)idx, x, y)) return false;
-    return occupancy[(size_t)(*y / in.cell) * (size_t)in.cf_width + (size_t)(*x / in.cell)] == 0;
-  };
   uint32_t mine = 0;
-  for (int idx = begin + tid; idx < end; idx += kLcBlock) { int x, y; mine += creates(idx, &x, &y) ? 1u : 0u; }
+  for (uint32_t c = begin + tid; c < end; c += kLcBlock) mine += occupancy[cand_cell[c]] == 0 ? 1u : 0u;
   for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
   if (lane == 0) wave_sums[wave] = mine;
   __syncthreads();
@@ -586,12 +731,12 @@ create_chain_kernel(Intrinsics in, KfEntry frame, KfEntry next_frame, const uint
     __hip_atomic_store(&group_words[blockIdx.x], (tag << 24) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   uint32_t before = 0, all = 0;
-  for (int g = tid; g < groups; g += kLcBlock) {
+  for (uint32_t g = tid; g < groups; g += kLcBlock) {
     uint32_t word;
     while (((word = __hip_atomic_load(&group_words[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 24) != tag) __builtin_amdgcn_s_sleep(1);
-    const uint32_t c = word & 0xffffffu;
-    all += c;
-    if (g < (int)blockIdx.x) before += c;
+    const uint32_t n = word & 0xffffffu;
+    all += n;
+    if (g < blockIdx.x) before += n;
   }
   for (int d = 32; d > 0; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
   __syncthreads();   // (wave_sums has been read)
@@ -599,7 +744,6 @@ create_chain_kernel(Intrinsics in, KfEntry frame, KfEntry next_frame, const uint
   __syncthreads();
   uint32_t base = 0, total = 0;
   for (int w = 0; w < kLcBlock / 64; ++w) { base += wave_sums[w]; total += wave_sums_b[w]; }
-  const uint32_t size = *size_in;
   const bool fits = (uint64_t)size + total <= capacity;
   if (blockIdx.x == 0 && tid == 0) {
     *size_out = fits ? size + total : size;
@@ -607,21 +751,26 @@ create_chain_kernel(Intrinsics in, KfEntry frame, KfEntry next_frame, const uint
   }
   if (!fits) return;
   uint32_t running = size + base;
-  for (int slab = begin; slab < end; slab += kLcBlock) {
-    const int idx = slab + tid;
-    int x = 0, y = 0;
-    const bool flagged = creates(idx, &x, &y);
+  for (uint32_t slab = begin; slab < end; slab += kLcBlock) {
+    const uint32_t c = slab + tid;
+    const bool flagged = c < end && occupancy[cand_cell[c]] == 0;
     const unsigned long long m = __ballot(flagged);
     const uint32_t rank_in_wave = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     __syncthreads();   // (the sums of the previous round have been read)
     if (lane == 0) wave_sums[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     uint32_t waves_before = 0, slab_total = 0;
-    for (int w = 0; w < kLcBlock / 64; ++w) { const uint32_t c = wave_sums[w]; slab_total += c; if (w < wave) waves_before += c; }
+    for (int w = 0; w < kLcBlock / 64; ++w) { const uint32_t n = wave_sums[w]; slab_total += n; if (w < wave) waves_before += n; }
     if (flagged) {
-      Vec3 gp; uint32_t packed_normal;
-      append_surfel(in, frame, x, y, running + waves_before + rank_in_wave, s, &gp, &packed_normal);
-      if (next_occupancy) mark_occupied(in, next_frame.pose.F, next_frame.geom, gp, unpack_normal10(packed_normal), next_occupancy);   // push: what a sweep would read back
+      const uint32_t si = running + waves_before + rank_in_wave;
+      float row[kSurfelAccum0];
+#pragma unroll
+      for (int r = 0; r < kSurfelAccum0; ++r) row[r] = records.row(r)[c];
+#pragma unroll
+      for (int r = 0; r < kSurfelAccum0; ++r) s.row(r)[si] = row[r];
+      if (next_occupancy)   // push: position and (stored, i.e. quantised) normal as a sweep over the cloud would read them back
+        mark_occupied(in, next_frame.pose.F, next_frame.geom, mk3(row[kSurfelX], row[kSurfelY], row[kSurfelZ]),
+                      unpack_normal10(__float_as_uint(row[kSurfelNormal])), next_occupancy);
     }
     running += slab_total;
   }
@@ -754,6 +903,39 @@ void launch_merge_apply_insert(hipStream_t st, const Intrinsics& in, const KfEnt
   hipLaunchKernelGGL(merge_apply_insert_kernel, dim3(apply_groups + insert_groups), dim3(kLcBlock), 0, st, in, a, i, s, flags, cell_of, apply_sup, insert_sup,
                      deleted_count, alb, ilb, apply_groups);
 }
+// a merge batch by cell lists: the pairs of all frames up front, then launch_merge_pairs per frame, launch_merge_batch_apply at the end
+hipError_t launch_merge_batch_lists(hipStream_t st, const Intrinsics& in, const MergeBatchFrame* frames, int num_frames, uint32_t max_positions, const SurfelsView& s,
+                                    const uint32_t* lists, uint32_t bounded_tiles, uint32_t* counts, uint32_t* offsets, uint32_t* pair_cells, uint32_t* pair_ranks,
+                                    uint32_t* members, void* member_cell, uint32_t* frame_first, void* scan_temp, size_t scan_temp_bytes) {
+  const uint32_t cells = (uint32_t)in.cf_width * (uint32_t)in.cf_height;
+  const size_t entries = (size_t)num_frames * cells + 1;
+  hipError_t e = hipMemsetAsync(counts, 0, entries * sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  const dim3 grid(std::max(1u, std::min<unsigned>(g1(max_positions * 64u), 2048u)), num_frames);
+  if (max_positions)
+    hipLaunchKernelGGL(merge_batch_associate_kernel, grid, dim3(kLcBlock), 0, st, in, frames, s, lists, bounded_tiles, counts, cells, pair_cells, pair_ranks);
+  e = hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_temp_bytes, counts, offsets, (int)entries, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(merge_batch_frame_first_kernel, dim3(g1((uint32_t)num_frames + 1u)), dim3(kLcBlock), 0, st, offsets, cells, (uint32_t)num_frames, frame_first);
+  if (!max_positions) return hipGetLastError();
+  hipLaunchKernelGGL(merge_batch_fill_kernel, grid, dim3(kLcBlock), 0, st, frames, s.size, lists, bounded_tiles, offsets, cells, pair_cells, pair_ranks, members,
+                     static_cast<uint2*>(member_cell));
+  return hipGetLastError();
+}
+size_t merge_batch_scan_temp_bytes(size_t entries) {
+  size_t bytes = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)entries);
+  return bytes;
+}
+void launch_merge_pairs(hipStream_t st, const SurfelsView& s, const uint32_t* members, const void* member_cell, uint32_t first_pair,
+                        uint32_t end_pair, uint32_t step, uint32_t* deleted_at, float cell_merge_dist_sq, float cos_thr, uint32_t* deleted_count) {
+  if (end_pair <= first_pair) return;
+  hipLaunchKernelGGL(merge_pairs_kernel, dim3(g1(end_pair - first_pair)), dim3(kLcBlock), 0, st, s, members, static_cast<const uint2*>(member_cell),
+                     first_pair, end_pair, step, deleted_at, cell_merge_dist_sq, cos_thr, deleted_count);
+}
+void launch_merge_batch_apply(hipStream_t st, const SurfelsView& s, const uint32_t* deleted_at) {
+  if (s.size) hipLaunchKernelGGL(merge_batch_apply_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, deleted_at);
+}
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags, bool leave_planes_empty) {
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags, leave_planes_empty ? 1 : 0);
 }
@@ -813,10 +995,21 @@ static int resident_append_groups(Kernel kernel, int* cache /* per device */) {
   const int limit = g_append_groups_limit > 0 ? std::min(g_append_groups_limit, cache[dev]) : cache[dev];
   return std::min(kAppendGroups, limit);
 }
-void launch_create_batch_prepare(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, const CreateBatchItem* items, int num_items, uint32_t max_list_count,
-                                 const SurfelsView& cloud_at_begin, const uint32_t* lists, uint32_t bounded_tiles, uint8_t* occupancy, uint8_t* candidates,
-                                 bool filter_new_surfels, const int* covis, const float* covis_T_frame, int min_obs) {
-  if (num_items <= 0) return;
+struct U8ToU32 {
+  __host__ __device__ uint32_t operator()(const uint8_t& v) const { return (uint32_t)v; }
+};
+size_t create_batch_scan_temp_bytes(size_t entries) {
+  size_t bytes = 0;
+  hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t*> it((const uint8_t*)nullptr, U8ToU32());
+  hipcub::DeviceScan::InclusiveSum(nullptr, bytes, it, (uint32_t*)nullptr, (int)entries);
+  return bytes;
+}
+// records: a view over [kSurfelAccum0 rows][record_capacity columns] floats (its pitch the row length in bytes)
+hipError_t launch_create_batch_prepare(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, const CreateBatchItem* items, int num_items, uint32_t max_list_count,
+                                       const SurfelsView& cloud_at_begin, const uint32_t* lists, uint32_t bounded_tiles, uint8_t* occupancy, uint8_t* candidates,
+                                       bool filter_new_surfels, const int* covis, const float* covis_T_frame, int min_obs, uint32_t* scan, void* scan_temp,
+                                       size_t scan_temp_bytes, uint32_t* cand_cell, const SurfelsView& records, uint32_t* first_of_item) {
+  if (num_items <= 0) return hipSuccess;
   const size_t cells = (size_t)in.cf_width * (size_t)in.cf_height;
   const int padded = (int)create_padded_count(in);
   const uint32_t all_tiles = (cloud_at_begin.size + 63u) / 64u, tail = all_tiles > bounded_tiles ? all_tiles - bounded_tiles : 0u;
@@ -827,17 +1020,26 @@ void launch_create_batch_prepare(hipStream_t st, const Intrinsics& in, const KfE
   hipLaunchKernelGGL(create_batch_flag_kernel, dim3(g1((uint32_t)cells), num_items), dim3(kLcBlock), 0, st, in, kfs, items, occupancy, cells, candidates, (size_t)padded);
   if (filter_new_surfels)
     hipLaunchKernelGGL(create_batch_filter_kernel, dim3(g1(padded), num_items), dim3(kLcBlock), 0, st, in, kfs, items, covis, covis_T_frame, min_obs, padded, candidates);
+  hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t*> it(candidates, U8ToU32());
+  const hipError_t e = hipcub::DeviceScan::InclusiveSum(scan_temp, scan_temp_bytes, it, scan, (int)((size_t)num_items * (size_t)padded), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(create_batch_records_kernel, dim3(g1(padded), num_items), dim3(kLcBlock), 0, st, in, kfs, items, candidates, scan, padded, cand_cell, records,
+                     first_of_item);
+  return hipGetLastError();
 }
 // appended_bound: an upper bound of what the batch has appended before this keyframe (sizes the pull part of the grid)
-void launch_create_chain(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const KfEntry* next_frame, const uint8_t* candidates,
-                         const uint8_t* occupancy, uint8_t* next_occupancy, const SurfelsView& s, uint32_t batch_begin_size, const uint32_t* size_in,
-                         uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded, uint32_t* group_words, uint32_t tag, uint32_t appended_bound) {
+void launch_create_chain(hipStream_t st, const Intrinsics& in, const KfEntry* next_frame, const uint32_t* cand_cell, const SurfelsView& records, uint32_t first,
+                         uint32_t end_of_frame, const uint8_t* occupancy, uint8_t* next_occupancy, const SurfelsView& s, uint32_t batch_begin_size,
+                         const uint32_t* size_in, uint32_t* size_out, uint32_t capacity, uint32_t* capacity_exceeded, uint32_t* group_words, uint32_t tag,
+                         uint32_t appended_bound) {
   static int resident_limit[64] = {};
-  const int padded = (int)create_padded_count(in);
-  const unsigned append_groups = (unsigned)std::min(resident_append_groups(create_chain_kernel, resident_limit), (int)g1(padded));
+  const unsigned append_groups = (unsigned)std::max(1, std::min(resident_append_groups(create_chain_kernel, resident_limit), (int)g1(end_of_frame - first)));
   const unsigned pull_groups = (next_frame && next_occupancy && appended_bound) ? std::min<unsigned>(g1(appended_bound), 512u) : 0u;
-  hipLaunchKernelGGL(create_chain_kernel, dim3(append_groups + pull_groups), dim3(kLcBlock), 0, st, in, frame, next_frame ? *next_frame : frame, candidates, occupancy,
-                     (next_frame ? next_occupancy : nullptr), padded, s, batch_begin_size, size_in, size_out, capacity, capacity_exceeded, group_words, tag, append_groups);
+  KfEntry none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(create_chain_kernel, dim3(append_groups + pull_groups), dim3(kLcBlock), 0, st, in, next_frame ? *next_frame : none, cand_cell, records, first,
+                     end_of_frame, occupancy, (next_frame ? next_occupancy : nullptr), s, batch_begin_size, size_in, size_out, capacity, capacity_exceeded, group_words,
+                     tag, append_groups);
 }
 void launch_delete_update(hipStream_t st, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,
                           int min_obs, uint32_t* deleted_count) {
@@ -851,9 +1053,6 @@ size_t scan_temp_bytes(size_t n) {
   hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
   return a > b ? a : b;
 }
-struct U8ToU32 {
-  __host__ __device__ uint32_t operator()(const uint8_t& v) const { return (uint32_t)v; }
-};
 hipError_t scan_flags_inclusive(hipStream_t st, void* temp, size_t temp_bytes, const uint8_t* flags, uint32_t* out, int n) {
   hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t*> it(flags, U8ToU32());
   return hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, it, out, n, st);

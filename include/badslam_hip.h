@@ -357,6 +357,10 @@ int bahip_take_merged_count(bahip_context* ctx, uint32_t* merged_count_out);
  * applies keyframe j's decisions runs beside the one that inserts keyframe j + 1's surfels (they alternate between the caller's planes
  * and a second set the context owns).  frame_T_global_3x4: 12 floats per frame.  Inside bahip_lifecycle_batch_begin / _set_frames
  * each keyframe's sweeps run over the tiles it can see.  Both sets of planes end EMPTY (the lists are not an output of a merge batch).
+ * Round 6, second form: when the lifecycle batch knows every frame of the call, the planes are not used at all -- which surfels share
+ * a sparse cell of frame j does not change while a batch merges, so the members of every (frame, cell) are listed up front for all
+ * frames at once and every frame costs ONE launch of one thread per cell (the three lowest indices still alive, the decisions of
+ * B/kernel_supporting_surfels.cu:60-86 in ascending order); the same deletions (bahip_debug_set_merge_cells selects the form).
  * merged_count_out: NULL defers the count to bahip_take_merged_count. */
 int bahip_merge_surfels_for_keyframes(bahip_context* ctx, float merge_dist_factor, const bahip_frame* frames, const float* frame_T_global_3x4,
                                       int num_frames, const bahip_surfels* surfels, uint32_t* const* supporting, uint32_t supporting_pitch_bytes,
@@ -393,7 +397,13 @@ int bahip_create_surfels_for_keyframe(bahip_context* ctx, int keyframe_index, in
  * wait at the end instead of two per keyframe).  covis_offsets[num_keyframes + 1] / covis_indices: the co-visibility lists of the
  * keyframes, concatenated, as indices into the bound keyframe list.  new_surfel_count_out: the surfels all of them appended; the
  * caller adds it to surfels_size.  A keyframe that does not fit the capacity creates nothing and raises the flag of
- * bahip_context_take_capacity_exceeded, the others go on (B/kernel_create_surfels.cc:162-165 per keyframe). */
+ * bahip_context_take_capacity_exceeded, the others go on (B/kernel_create_surfels.cc:162-165 per keyframe).
+ * Round 6: inside a lifecycle batch that knows the keyframes (bahip_lifecycle_batch_set_keyframes) the keyframes do not wait for each
+ * other's sweeps: what the cloud at the batch's begin occupies, which pixel of a free cell would create a surfel and whether it passes
+ * the filter are found for ALL keyframes up front (three launches); each keyframe but the last then costs ONE launch -- its candidates
+ * whose cell is still free are counted, scanned and appended, what it appends is pushed into the next keyframe's occupancy, what the
+ * batch appended earlier is pulled into it.  The last keyframe takes the four-launch path, so the supporting planes end as a
+ * one-keyframe call leaves them.  The same surfels at the same indices (bahip_debug_set_creation_chain selects the form). */
 int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_indices, int num_keyframes, int filter_new_surfels,
                                        int min_observation_count, const int* covis_offsets, const int* covis_indices,
                                        const bahip_surfels* surfels, uint32_t* const* supporting, uint32_t supporting_pitch,
@@ -535,6 +545,11 @@ int bahip_debug_set_append_groups(int groups);
  * surfels either way.  ..._batches: how many calls have taken the chain so far (tests assert the route). */
 int bahip_debug_set_creation_chain(int enabled);
 int bahip_debug_creation_chain_batches(long long* batches_out);
+/* A merge batch by cell lists (bahip_merge_surfels_for_keyframes inside a lifecycle batch that knows the frames, every frame with its
+ * BA planes): 1 (default; BAHIP_MERGE_CELLS=0 switches it off) or 0 = the pipelined insert / decide / apply sweeps of round 6's first
+ * version; the same deletions either way.  ..._batches: how many calls have gone by cell lists. */
+int bahip_debug_set_merge_cells(int enabled);
+int bahip_debug_merge_cells_batches(long long* batches_out);
 /* The LDS form holds the normal equations of at most 292 work items; longer lists are cut into slices, one launch each.  items > 0
  * makes the slices that small (tests: 200 keyframes in slices of 64), 0 restores the default. */
 int bahip_debug_set_pose_lds_items(int items);

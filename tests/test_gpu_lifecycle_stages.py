@@ -51,9 +51,10 @@ def test_supporting_surfels_lists_bit_exact(world):
         assert filled[0] > 5000 and filled[1] > 100, filled           # second slots are in use: cells seen by several surfels
 
 
-@pytest.mark.parametrize("batch", [False, True, "frames", "pipelined", "pipelined without lists"],
-                         ids=["per keyframe", "lifecycle batch", "lifecycle batch that knows its frames", "pipelined batch", "pipelined batch without tile lists"])
-def test_merge_bit_exact(world, batch):
+@pytest.mark.parametrize("batch", [False, True, "frames", "pipelined", "pipelined without lists", "cells"],
+                         ids=["per keyframe", "lifecycle batch", "lifecycle batch that knows its frames", "pipelined batch", "pipelined batch without tile lists",
+                              "batch by cell lists"])
+def test_merge_bit_exact(world, batch, request):
     """batch: inside bahip_lifecycle_batch_begin / _end the sweeps skip the tiles a keyframe cannot see (here: a copy of the cloud
     50 m away, in the middle of the buffer) -- the oracle knows no such bracket and must see the same buffer.
     pipelined: bahip_merge_surfels_for_keyframes, the whole batch in one call with keyframe j's apply sweep beside keyframe j + 1's
@@ -61,6 +62,15 @@ def test_merge_bit_exact(world, batch):
     written in the same launch) -- against the oracle's keyframe-by-keyframe merges; the keyframes overlap, so the order matters."""
     import contextlib
     scene, orc, g = world
+    lib = capi.load()
+    by_cells = batch == "cells"      # bahip_merge_surfels_for_keyframes by cell lists (merge_cells_kernel): the members of every (frame, cell) up front,
+    if by_cells:                     # one launch per frame -- same deletions; "pipelined" keeps round 6's first form under test
+        batch = "pipelined"
+    else:
+        capi.check(lib.bahip_debug_set_merge_cells(0))
+        request.addfinalizer(lambda: lib.bahip_debug_set_merge_cells(1))
+    cells_before = C.c_longlong()
+    capi.check(lib.bahip_debug_merge_cells_batches(C.byref(cells_before)))
     data, _ = common.oracle_surfels(orc)
     if batch:
         far = data.copy()
@@ -85,6 +95,9 @@ def test_merge_bit_exact(world, batch):
         for k in order:
             orc.determine_supporting_surfels(k, merge=True)
         assert total_merged == before - int(orc.surfels.surfel_count)
+        cells_after = C.c_longlong()
+        capi.check(lib.bahip_debug_merge_cells_batches(C.byref(cells_after)))
+        assert cells_after.value - cells_before.value == (1 if by_cells else 0)
         assert np.all(planes == 0xffffffff)
         got = g.surfel_buf.download()[:, :both.shape[1]]
         assert np.array_equal(_rows(got), _rows(orc.surfel_data[:, :both.shape[1]]))
