@@ -227,9 +227,9 @@ struct LifecycleCull {
   const uint32_t* list = nullptr;
   uint32_t list_count = 0;
 };
-// counts (offsets == nullptr: cursors[f] += visible tiles of frame f) or lists (lists[offsets[f] + ...] = tile)
+// cursors[f] (zeroed) <- the number of bounded tiles frame f can see, lists[f * tiles + ...] <- those tiles (no particular order)
 void launch_lifecycle_visible_tiles(hipStream_t st, const Intrinsics& in, const float* frames_F, int num_frames, const void* spheres, uint32_t tiles,
-                                    const uint32_t* offsets, uint32_t* cursors, uint32_t* lists);
+                                    uint32_t* cursors, uint32_t* lists);
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
                               const LifecycleCull& cull = LifecycleCull(),
                               const uint32_t* size_on_device = nullptr /* a creation batch: min(*size_on_device, s.size) surfels exist */);

@@ -291,31 +291,24 @@ int bahip_lifecycle_batch_set_frames(bahip_context* ctx, const float* frame_T_gl
     ctx->lifecycle_frames_capacity = capacity;
   }
   uint32_t* cursors = ctx->dev_lifecycle_cursors;
-  uint32_t* offsets = ctx->dev_lifecycle_cursors + ctx->lifecycle_frames_capacity;
   std::vector<uint32_t> counts(num_frames), starts(num_frames);
-  HIP_TRY(hipMemcpyAsync(ctx->dev_lifecycle_frames, frame_T_global_3x4, (size_t)num_frames * 12 * sizeof(float), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)num_frames * sizeof(uint32_t), st));
-  launch_lifecycle_visible_tiles(st, ctx->in, ctx->dev_lifecycle_frames, num_frames, ctx->dev_lifecycle_bounds, tiles, nullptr, cursors, nullptr);
-  CHECK_LAUNCH();
-  HIP_TRY(hipMemcpyAsync(counts.data(), cursors, (size_t)num_frames * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  size_t total = 0;
-  for (int f = 0; f < num_frames; ++f) { starts[f] = (uint32_t)total; total += counts[f]; }
+  const size_t total = (size_t)num_frames * tiles;   // room for every tile in every frame's list: one pass, no counting pass, one host wait
   if (total > ctx->lifecycle_lists_capacity) {
     uint32_t* lists = nullptr;
     const size_t capacity = total + total / 4 + 4096;
+    HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMalloc(&lists, capacity * sizeof(uint32_t)));
     hipFree(ctx->dev_lifecycle_lists);
     ctx->dev_lifecycle_lists = lists;
     ctx->lifecycle_lists_capacity = capacity;
   }
-  if (total > 0) {
-    HIP_TRY(hipMemcpyAsync(offsets, starts.data(), (size_t)num_frames * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)num_frames * sizeof(uint32_t), st));
-    launch_lifecycle_visible_tiles(st, ctx->in, ctx->dev_lifecycle_frames, num_frames, ctx->dev_lifecycle_bounds, tiles, offsets, cursors, ctx->dev_lifecycle_lists);
-    CHECK_LAUNCH();
-    HIP_TRY(hipStreamSynchronize(st));   // `starts` is pageable and goes out of scope
-  }
+  HIP_TRY(hipMemcpyAsync(ctx->dev_lifecycle_frames, frame_T_global_3x4, (size_t)num_frames * 12 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(cursors, 0, (size_t)num_frames * sizeof(uint32_t), st));
+  launch_lifecycle_visible_tiles(st, ctx->in, ctx->dev_lifecycle_frames, num_frames, ctx->dev_lifecycle_bounds, tiles, cursors, ctx->dev_lifecycle_lists);
+  CHECK_LAUNCH();
+  HIP_TRY(hipMemcpyAsync(counts.data(), cursors, (size_t)num_frames * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));   // (also: frame_T_global_3x4 may be pageable memory of the caller)
+  for (int f = 0; f < num_frames; ++f) starts[f] = (uint32_t)((size_t)f * tiles);
   ctx->lifecycle_frames.assign(frame_T_global_3x4, frame_T_global_3x4 + (size_t)num_frames * 12);
   ctx->lifecycle_list_offsets = starts;
   ctx->lifecycle_list_counts = counts;

@@ -62,26 +62,28 @@ __device__ __forceinline__ bool lifecycle_surfel(const Intrinsics& in, const KfE
   const WaveBounds wb = lb.spheres[tile];
   return sphere_may_project(in, frame.pose.F, wb);
 }
-// Which bounded tiles each frame of a batch can see: counts first (the host turns them into offsets), then the lists.
+// Which bounded tiles each frame of a batch can see.  One pass: frame f's list lives at lists[f * tiles ...) (room for every tile: 4 bytes
+// x tiles x frames, 27 MB at the bench scene), its length in cursors[f]; a workgroup takes 256 tiles and kVisibleFramesPerGroup frames.
+// (Round 5 counted first, let the host turn the counts into offsets and ran the sweep again -- two launches of one thread per tile
+// looping over all frames, 190 us each, and a host wait in between, three times per BundleAdjustment call.)
+constexpr int kVisibleFramesPerGroup = 8;
 __global__ void __launch_bounds__(kLcBlock)
 lifecycle_visible_tiles_kernel(Intrinsics in, const float* __restrict__ frames_F /* [num_frames][12] */, int num_frames,
-                               const WaveBounds* __restrict__ spheres, uint32_t tiles, const uint32_t* __restrict__ offsets /* nullptr: count only */,
-                               uint32_t* __restrict__ cursors /* [num_frames], zeroed */, uint32_t* __restrict__ lists) {
+                               const WaveBounds* __restrict__ spheres, uint32_t tiles, uint32_t* __restrict__ cursors /* [num_frames], zeroed */,
+                               uint32_t* __restrict__ lists /* [num_frames][tiles] */) {
   const uint32_t tile = blockIdx.x * kLcBlock + threadIdx.x;
-  const int lane = threadIdx.x & 63;
   WaveBounds wb;
   wb.cx = wb.cy = wb.cz = 0.f; wb.r = -1.f;
   if (tile < tiles) wb = spheres[tile];
-  for (int f = 0; f < num_frames; ++f) {
+  const int f0 = blockIdx.y * kVisibleFramesPerGroup, f1 = min(num_frames, f0 + kVisibleFramesPerGroup);
+  for (int f = f0; f < f1; ++f) {
     const bool visible = sphere_may_project(in, frames_F + 12 * f, wb);   // (r < 0: never)
     const unsigned long long m = __ballot(visible);
     if (!m) continue;
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&cursors[f], (uint32_t)__popcll(m));
-    if (offsets) {
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (visible) lists[offsets[f] + base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tile;
-    }
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(&cursors[f], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (visible) lists[(size_t)f * tiles + base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tile;
   }
 }
 __global__ void __launch_bounds__(kLcBlock)
@@ -860,10 +862,10 @@ static unsigned sweep_groups(const LifecycleBounds& lb, uint32_t size) {
   return g1((lb.list_count + tail) * 64u);
 }
 void launch_lifecycle_visible_tiles(hipStream_t st, const Intrinsics& in, const float* frames_F, int num_frames, const void* spheres, uint32_t tiles,
-                                    const uint32_t* offsets, uint32_t* cursors, uint32_t* lists) {
+                                    uint32_t* cursors, uint32_t* lists) {
   if (tiles && num_frames)
-    hipLaunchKernelGGL(lifecycle_visible_tiles_kernel, dim3(g1(tiles)), dim3(kLcBlock), 0, st, in, frames_F, num_frames,
-                       static_cast<const WaveBounds*>(spheres), tiles, offsets, cursors, lists);
+    hipLaunchKernelGGL(lifecycle_visible_tiles_kernel, dim3(g1(tiles), (num_frames + kVisibleFramesPerGroup - 1) / kVisibleFramesPerGroup), dim3(kLcBlock), 0, st, in,
+                       frames_F, num_frames, static_cast<const WaveBounds*>(spheres), tiles, cursors, lists);
 }
 void launch_supporting_insert(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SurfelsView& s, const SupportingView& sup,
                               const LifecycleCull& cull, const uint32_t* size_on_device) {
