@@ -192,6 +192,7 @@ SIGNATURES = {
     "bahip_debug_set_launch_shapes": (C.c_int, [C.c_int, C.c_int]),
     "bahip_debug_set_pose_form": (C.c_int, [C.c_int]),
     "bahip_debug_set_append_groups": (C.c_int, [C.c_int]),
+    "bahip_debug_geometry_hybrid_launches": (C.c_int, [C.POINTER(C.c_longlong)]),
     "bahip_debug_set_creation_chain": (C.c_int, [C.c_int]),
     "bahip_debug_creation_chain_batches": (C.c_int, [C.POINTER(C.c_longlong)]),
     "bahip_debug_set_merge_cells": (C.c_int, [C.c_int]),

@@ -135,7 +135,8 @@ void launch_propagate_covisible(hipStream_t stream, KfEntry* frames, int num_kfs
 bool launch_iteration_begin(hipStream_t stream, KfEntry* frames, int num_kfs, int mode, const uint8_t* in_window, const int* offsets, const int* indices,
                             void* work, HbFixed* Hb, void* host_out, const int* stop);
 
-void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes
+void set_tile_waves(int waves);   // 0 = automatic; 1 | 4 wavefronts per surfel tile in the normals / geometry passes; 5 = the hybrid shape of the geometry step
+long long geometry_hybrid_launches();   // launches of the geometry step in the hybrid shape so far (both flavours)
 void set_pose_lds_waves(int waves);        // test hook: wavefronts per workgroup of the LDS form (0: 16)
 void set_pose_lds_parts_shift(int shift);  // test hook: 2^shift wavefronts share a tile's work items in the LDS form (-1: from the grid size)
 void set_pose_lds_items(int items);   // test hook: slices of that many work items per launch of the LDS form (0: as many as the table holds)
@@ -318,6 +319,7 @@ hipError_t launch_compact(hipStream_t st, const SurfelsView& s, uint32_t* invali
   void launch_activation_hits(hipStream_t stream, const Intrinsics& in, const KfEntry* kfs, int num_kfs, const SurfelsView& s,                \
                               uint32_t surfels_size, int kf_rank, int kf_world, uint32_t* hits);                                              \
   void set_tile_waves(int waves);                                                                                                             \
+  long long geometry_hybrid_launches();                                                                                                       \
   /* kernels_pose.hip */                                                                                                                      \
   void launch_pose_accumulate(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* frames,                 \
                               const void* work, int num_work, const SurfelsView& s, HbFixed* Hb, void* tile_bounds, bool stored_bounds,       \

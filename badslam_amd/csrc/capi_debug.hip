@@ -119,12 +119,14 @@ int bahip_debug_set_pose_form(int form) {
 }
 
 int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts) {
-  REQUIRE(tile_waves == 0 || tile_waves == 1 || tile_waves == 4, "tile_waves must be 0 (automatic), 1 or 4");
+  REQUIRE(tile_waves == 0 || tile_waves == 1 || tile_waves == 4 || tile_waves == 5, "tile_waves must be 0 (automatic), 1, 4 or 5 (the geometry step's hybrid shape)");
   REQUIRE(pose_parts == 0 || pose_parts == 1 || pose_parts == 2 || pose_parts == 4 || pose_parts == 8, "pose_parts must be 0, 1, 2, 4 or 8");
   set_tile_waves(tile_waves);
   set_pose_parts(pose_parts);
   return 0;
 }
+
+int bahip_debug_geometry_hybrid_launches(long long* launches_out) { if (launches_out) *launches_out = geometry_hybrid_launches(); return 0; }
 
 int bahip_debug_jacobian(bahip_context* ctx, int kind, const float* in, int n_in, float* out, int n_out) {
   REQUIRE(kind >= 0 && kind <= 4 && n_in > 0 && n_in <= 16 && n_out > 0 && n_out <= 8, "bahip_debug_jacobian: bad arguments");

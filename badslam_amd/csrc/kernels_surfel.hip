@@ -249,13 +249,11 @@ normals_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Surf
 template <bool kUseDepth, bool kUseDesc, int kWaves, bool kActivate, int kPhase>
 __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView& s,
                                               uint32_t activate_count, float* lds, const ClassPartials& cpn, const ClassPartials& cpp,
-                                              const uint32_t* __restrict__ sched) {
+                                              uint32_t tile /* workgroup-uniform (kWaves > 1) or wave-uniform */, unsigned long long* replay_masks) {
   constexpr int kNormalsMode = kPhase == 1 ? kSumsProduce : kPhase == 2 ? kSumsConsume : kSumsFused;
   constexpr int kPositionMode = kPhase == 2 ? kSumsProduce : kPhase == 3 ? kSumsConsume : kSumsFused;
   const int lane = threadIdx.x & 63;
   const bool writer = kWaves == 1 || (threadIdx.x >> 6) == 0;
-  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile); workgroup-uniform
-  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
   const uint32_t i = tile * kSurfelBlock + lane;
   const bool in_range = i < s.size;
   const uint32_t ii = in_range ? i : 0;
@@ -271,8 +269,7 @@ __device__ __forceinline__ void geometry_step(const Intrinsics& in, const KfEntr
   }
   // one wavefront per tile, the whole step in one launch: the position pass replays the candidate masks of the normals pass
   constexpr bool kReplayMasks = kWaves == 1 && kPhase == 0;   // (measured: geometry sweep 0.749 -> 0.731 ms at the bench size, profiles/r5_ab_*.txt)
-  __shared__ unsigned long long candidate_masks[kReplayMasks ? kMaxSumClasses * kMaskChunks : 1];
-  unsigned long long* masks = kReplayMasks ? candidate_masks : nullptr;
+  unsigned long long* masks = kReplayMasks ? replay_masks : nullptr;   // kMaxSumClasses * kMaskChunks words of LDS per wavefront, owned by the kernel
   if (kPhase != 3) normals_pass<kWaves, kActivate, kNormalsMode>(in, kfs, num_kfs, wb, s, ii, &live, decide, gp, &gn, lds, cpn, in_range, masks);
   if (kPhase == 1) return;
 
@@ -410,14 +407,42 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
                 const uint32_t* __restrict__ sched, const int* __restrict__ stop /* device-driven BA loop (capi_ba.hip:
                 bahip_alternating_iterations): a launch queued behind the iteration that ended the loop does nothing; NULL: always runs */) {
   __shared__ float lds[kWaves == 1 ? 1 : kMaxSumClasses * 8 * 64];
+  __shared__ unsigned long long candidate_masks[kWaves == 1 ? kMaxSumClasses * kMaskChunks : 1];
   if (stop && load_global(stop) != 0) return;
 #ifdef BAHIP_RECORD_GEOMETRY_TIMELINE
   const unsigned long long t0 = wall_clock64();
 #endif
-  geometry_step<kUseDepth, kUseDesc, kWaves, kActivate, 0>(in, kfs, num_kfs, s, activate_count, lds, ClassPartials{}, ClassPartials{}, sched);
+  uint32_t tile;   // heavy work first (wave_cull.h: scheduled_tile); workgroup-uniform
+  if (!scheduled_tile(blockIdx.x, gridDim.x - (sched ? kHeavySlots : 0u), sched, &tile)) return;
+  geometry_step<kUseDepth, kUseDesc, kWaves, kActivate, 0>(in, kfs, num_kfs, s, activate_count, lds, ClassPartials{}, ClassPartials{}, tile, candidate_masks);
 #ifdef BAHIP_RECORD_GEOMETRY_TIMELINE
   if (threadIdx.x == 0 && blockIdx.x < 65536) { g_geometry_timeline[blockIdx.x][0] = t0; g_geometry_timeline[blockIdx.x][1] = wall_clock64(); }
 #endif
+}
+
+// The HYBRID shape (round 6), for clouds whose tiles do not fill the chip several times over (a shard of a multi-GPU run): workgroups
+// of four wavefronts; the first kHeavySlots workgroups take one tile of the schedule's heavy list each, a keyframe class per wavefront
+// (the four-wavefront shape), every other workgroup takes FOUR regular tiles, a whole tile per wavefront (the one-wavefront shape with
+// its replayed candidate masks and its two-stage candidate loop).  With four wavefronts on every tile a light tile pays the set-up and
+// the LDS combination four times (93 wavefront-us per tile against 60, profiles/r6_shard_experiments.txt); with one wavefront on every
+// tile the launch lasts as long as its heaviest tile.  Same bits as either shape: the sums are defined per class.
+template <bool kUseDepth, bool kUseDesc, bool kActivate>
+__global__ void __launch_bounds__(256) BAHIP_WAVES_ATTR
+geometry_hybrid_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
+                       const uint32_t* __restrict__ sched /* not NULL */, uint32_t padded_tiles, const int* __restrict__ stop) {
+  __shared__ float lds[kMaxSumClasses * 8 * 64];
+  __shared__ unsigned long long candidate_masks[4][kMaxSumClasses * kMaskChunks];
+  if (stop && load_global(stop) != 0) return;
+  if (blockIdx.x < kHeavySlots) {
+    if (blockIdx.x >= sched[0]) return;
+    geometry_step<kUseDepth, kUseDesc, 4, kActivate, 0>(in, kfs, num_kfs, s, activate_count, lds, ClassPartials{}, ClassPartials{}, sched[8 + blockIdx.x], nullptr);
+  } else {
+    const uint32_t wave = threadIdx.x >> 6, position = (blockIdx.x - kHeavySlots) * 4u + wave;
+    if (position >= padded_tiles) return;
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[kSchedPerm + position]);
+    if (sched[kSchedPerm + padded_tiles + tile] != 0) return;   // on the heavy list
+    geometry_step<kUseDepth, kUseDesc, 1, kActivate, 0>(in, kfs, num_kfs, s, activate_count, nullptr, ClassPartials{}, ClassPartials{}, tile, candidate_masks[wave]);
+  }
 }
 
 // One phase of the keyframe-sharded geometry step (geometry_step: kPhase).
@@ -425,7 +450,7 @@ template <bool kUseDepth, bool kUseDesc, bool kActivate, int kPhase>
 __global__ void __launch_bounds__(64) BAHIP_WAVES_ATTR
 geometry_phase_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
                       ClassPartials cpn, ClassPartials cpp) {
-  geometry_step<kUseDepth, kUseDesc, 1, kActivate, kPhase>(in, kfs, num_kfs, s, activate_count, nullptr, cpn, cpp, nullptr);   // (buffer order)
+  geometry_step<kUseDepth, kUseDesc, 1, kActivate, kPhase>(in, kfs, num_kfs, s, activate_count, nullptr, cpn, cpp, xcd_run_tile(blockIdx.x, gridDim.x), nullptr);   // (buffer order)
 }
 
 // Surfel activation under keyframe sharding: this rank's kActive keyframes only; hits[i] = 1 where one of them sees surfel i
@@ -466,6 +491,8 @@ void launch_activation(hipStream_t stream, const Intrinsics& in, const KfEntry* 
 // fill the chip several times over, else four.  Results do not depend on it; BAHIP_TILE_WAVES=1|4 or
 // bahip_debug_set_launch_shapes force one (tests run both).
 static int g_forced_tile_waves = bahip_env_int("BAHIP_TILE_WAVES", 0);
+static long long g_geometry_hybrid_launches = 0;
+long long geometry_hybrid_launches() { return g_geometry_hybrid_launches; }
 void set_tile_waves(int waves) { g_forced_tile_waves = waves; }
 static int tile_waves(uint32_t surfels) {
   const int forced = g_forced_tile_waves;
@@ -493,13 +520,30 @@ static void launch_geometry_shape(hipStream_t stream, bool use_depth, bool use_d
   else hipLaunchKernelGGL((geometry_kernel<false, true, kWaves, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched, stop);
 }
 
+template <bool kActivate>
+static void launch_geometry_hybrid(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
+                                   int num_kfs, const SurfelsView& s, uint32_t activate_count, const uint32_t* sched, const int* stop) {
+  const uint32_t padded = grid_for(s.size);
+  const dim3 grid(kHeavySlots + (padded + 3u) / 4u), block(256);
+  if (!use_desc) hipLaunchKernelGGL((geometry_hybrid_kernel<true, false, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched, padded, stop);
+  else if (use_depth) hipLaunchKernelGGL((geometry_hybrid_kernel<true, true, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched, padded, stop);
+  else hipLaunchKernelGGL((geometry_hybrid_kernel<false, true, kActivate>), grid, block, 0, stream, in, kfs, num_kfs, s, activate_count, sched, padded, stop);
+}
+
 // activate_count < 0: the activation flags are taken as they are; >= 0: surfels [0, activate_count) are (re)activated first.
 // `sched`: the schedule of a grid of grid_for(s.size) tiles (wave_cull.h: scheduled_tile), or NULL.
 void launch_geometry(hipStream_t stream, bool use_depth, bool use_desc, const Intrinsics& in, const KfEntry* kfs,
                      int num_kfs, const SurfelsView& s, long long activate_count, const uint32_t* sched, const int* stop) {
   if (s.size == 0) return;
   const uint32_t n = activate_count < 0 ? 0u : (uint32_t)activate_count;
-  if (tile_waves(s.size) == 1) {
+  // few tiles and a schedule (its heavy list): the hybrid shape; BAHIP_TILE_WAVES / bahip_debug_set_launch_shapes: 5 forces it (where a
+  // schedule exists), 1 / 4 the uniform shapes
+  const bool hybrid = sched != nullptr && (g_forced_tile_waves == 5 || (g_forced_tile_waves == 0 && grid_for(s.size) < 8192));
+  if (hybrid) {
+    ++g_geometry_hybrid_launches;
+    if (activate_count < 0) launch_geometry_hybrid<false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
+    else launch_geometry_hybrid<true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
+  } else if (tile_waves(s.size) == 1) {
     if (activate_count < 0) launch_geometry_shape<1, false>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
     else launch_geometry_shape<1, true>(stream, use_depth, use_desc, in, kfs, num_kfs, s, n, sched, stop);
   } else {
@@ -650,6 +694,7 @@ void launch_activation_hits(hipStream_t stream, const Intrinsics& in, const KfEn
   BAHIP_PICK(in, launch_activation_hits(stream, in, kfs, num_kfs, s, surfels_size, kf_rank, kf_world, hits));
 }
 void set_tile_waves(int waves) { exact::set_tile_waves(waves); fast::set_tile_waves(waves); }
+long long geometry_hybrid_launches() { return exact::geometry_hybrid_launches() + fast::geometry_hybrid_launches(); }
 }  // namespace bahip
 
 // ---- diagnostics: how much work does a sweep over all keyframes contain? ----------------------------

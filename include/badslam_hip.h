@@ -510,8 +510,12 @@ int bahip_debug_exact_sum(bahip_context* ctx, const float* values, size_t count,
 /* Launch shapes of the surfel sweeps, process-wide; 0 = chosen from the surfel count (default).  tile_waves (1 | 4):
  * wavefronts per 64-surfel tile in the normals / geometry passes - results are bit-identical for both (the per-surfel
  * sums are defined as four interleaved partial sums).  pose_parts (1 | 2 | 4 | 8): wavefronts sharing a
- * tile's keyframes in the pose kernel (sums merged by float atomics in any case). */
+ * tile's keyframes in the pose kernel (sums merged by float atomics in any case).
+ * tile_waves = 5: the geometry step's HYBRID shape (round 6; the default below 8192 tiles once the sweeps have a run order with its
+ * heavy list): the heavy tiles take four wavefronts (a keyframe class each), every other tile one -- in one launch; same bits.
+ * bahip_debug_geometry_hybrid_launches: how many geometry steps have run in that shape so far. */
 int bahip_debug_set_launch_shapes(int tile_waves, int pose_parts);
+int bahip_debug_geometry_hybrid_launches(long long* launches_out);
 /* Form of the pose sweep, process-wide; results are bit-identical for all of them.  0 = chosen from the sizes (default);
  * 1 = one wavefront per surfel tile, tile totals added to the normal equations with global 64-bit integer atomics (the only form
  * for shards and for more work items than fit the table); 2 = persistent workgroups, one per compute unit, that keep the normal

@@ -88,3 +88,33 @@ def test_the_default_configuration_takes_the_device_driven_loop():
     assert proc.returncode == 0, proc.stderr[-3000:]
     out = json.loads([l for l in proc.stdout.splitlines() if l.strip()][-1])
     assert out["loop"]["timed_calls_driven_by_the_device"] == 1 and out["loop"]["timed_calls_driven_by_the_host"] == 0, out["loop"]
+
+
+def test_the_hybrid_shape_of_the_geometry_step_is_the_other_shapes():
+    """kernels_surfel.hip: geometry_hybrid_kernel -- on a cloud of few tiles the heavy tiles of the sweeps' run order take four
+    wavefronts (a keyframe class each), every other tile one, in one launch.  The per-surfel sums are defined per class, so the same
+    BundleAdjustment call must end with the same bits whether every tile takes one wavefront, every tile four, or the hybrid shape
+    is used -- which this small scene takes by default from the second iteration on (the run order comes out of the first pose
+    phase's census); the route is asserted."""
+    import ctypes as C
+    lib = capi.load()
+    scene = common.small_scene(num_keyframes=6, seed=33)
+    rng = np.random.Generator(np.random.PCG64(4))
+    perturbed = [synthetic.perturb_pose(rng, T) for T in scene.poses_gt]
+    runs, surfels = {}, None
+    try:
+        for shape in (1, 4, 5, 0):
+            capi.check(lib.bahip_debug_set_launch_shapes(shape, 0))
+            before = C.c_longlong()
+            capi.check(lib.bahip_debug_geometry_hybrid_launches(C.byref(before)))
+            runs[shape], surfels = _run(scene, perturbed, surfels, device_loop=True, rounds_ahead=0, fused_begin=False, min_iterations=5, max_iterations=5)
+            after = C.c_longlong()
+            capi.check(lib.bahip_debug_geometry_hybrid_launches(C.byref(after)))
+            hybrid = after.value - before.value
+            assert (hybrid >= 3) if shape in (5, 0) else (hybrid == 0), (shape, hybrid)
+    finally:
+        capi.check(lib.bahip_debug_set_launch_shapes(0, 0))
+    for shape in (4, 5, 0):
+        assert runs[shape]["done"] == runs[1]["done"] == 5
+        assert np.array_equal(runs[shape]["poses"].view(np.uint32), runs[1]["poses"].view(np.uint32)), shape
+        assert np.array_equal(runs[shape]["surfels"].view(np.uint32), runs[1]["surfels"].view(np.uint32)), shape
