@@ -234,7 +234,9 @@ int bahip_set_intrinsics(bahip_context* ctx, const bahip_camera* color_camera, c
 /* Maintenance, like compaction: reorders surfels [0, surfels_size) along a Morton curve over a world grid of
  * `grid_cell_size` metres (stable; deleted surfels last).  Moves the 8 data rows and the active flags.  Surfels that
  * one image region shows become neighbours in the buffer, which is what the sweeps' L2 behaviour wants;
- * no result depends on the order.  Not part of the reference: call it when convenient (after keyframes were added). */
+ * no result depends on the order.  Not part of the reference: call it when convenient (after keyframes were added).
+ * Round 6: ordered on the context's stream like a kernel launch -- no allocation and no host wait (a scratch block of the context
+ * holds keys, indices and a dense copy of the rows; it grows when the cloud does). */
 int bahip_sort_surfels_spatially(bahip_context* ctx, const bahip_surfels* surfels, float grid_cell_size);
 
 /* BA planes of one frame: create for the given image sizes, refresh from the frame's images (on the context
