@@ -505,7 +505,7 @@ int bahip_create_surfels_for_keyframes(bahip_context* ctx, const int* keyframe_i
     const size_t columns = n * cells, scan_temp_bytes = known ? create_batch_scan_temp_bytes(n * px) : 0;
     const size_t need = align(occupancy_bytes) + align(candidates_bytes) + align(sizeof(uint32_t) * n * px) + align(sizeof(uint32_t) * columns) +
                         align(sizeof(float) * columns * kSurfelAccum0) + align(sizeof(CreateBatchItem) * n) + align(sizeof(uint32_t) * (n + 1)) + align(scan_temp_bytes);
-    if (known && need <= ((size_t)16 << 30) && sizeof(float) * columns < ((size_t)1 << 32)) {
+    if (known && need <= ((size_t)16 << 30) && sizeof(float) * columns < ((size_t)1 << 32) && n * px < ((size_t)1 << 31)) {   // (the scan counts in int)
       if (need > ctx->create_batch_bytes) {
         HIP_TRY(hipStreamSynchronize(st));
         hipFree(ctx->dev_create_batch); ctx->dev_create_batch = nullptr; ctx->create_batch_bytes = 0;
