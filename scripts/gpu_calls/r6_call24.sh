@@ -2,7 +2,7 @@
 # round 6, call 24: artifact set r6_b -- full GPU suite, the default bench line, counter evidence of the three legs, emulated shares
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp BADSLAM_RENDER_WORKERS=32
-TAG=${TAG:-r6_b}
+TAG=${TAG:-r6_c}
 O=$GRAFT_REPO_ROOT/gpurun_out/${CALL:-r6_call24}; mkdir -p $O
 timeout -k 5 1500 python -m pytest tests -q -m gpu --durations=5 2>&1 | tail -40 > $O/gpu_tests.log
 tail -3 $O/gpu_tests.log | cut -c1-300
