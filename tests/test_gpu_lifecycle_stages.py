@@ -300,3 +300,45 @@ def test_delete_and_update_radii_then_compact_bit_exact(world):
         m = orc.surfels_size
         assert g.surfels_size == m == n - deleted
         assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :m]))
+
+
+@pytest.mark.parametrize("seed,width,height,cell,keyframes", [(41, 320, 240, 2, 9), (42, 200, 152, 3, 8), (43, 320, 240, 1, 6), (44, 168, 120, 4, 10)])
+def test_lifecycle_batches_on_other_scenes(seed, width, height, cell, keyframes):
+    """The round-6 forms of both lifecycle batches -- creation as a chain, merging by cell lists -- on scenes of other sizes, sparse-cell
+    sizes (also ones that do not divide the image) and batch lengths, through three rounds of [creation batch, merge batch] with
+    perturbed poses (surfels appear, overlap and merge), against the oracle's keyframe-by-keyframe calls: the same surfels at the same
+    indices, the same deletions, after every batch."""
+    lib = capi.load()
+    scene = common.small_scene(num_keyframes=keyframes, width=width, height=height, seed=seed, cell=cell)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    poses = [T if k % 3 == 0 else synthetic.perturb_pose(rng, T, 0.02, 0.008) for k, T in enumerate(scene.poses_gt)]
+    capacity = 2 * keyframes * (width // cell + 1) * (height // cell + 1)
+    orc = common.build_oracle(scene, capacity, poses=poses, create_from=[], min_observation_count=2)
+    g = common.build_gpu(scene, capacity, poses=poses, create_from=[])
+    everyone = list(range(keyframes))
+    assert orc.create_surfels_for_keyframe(0, filter_new_surfels=False) == g.create_surfels_for_keyframe(0, filter_new_surfels=False) > 0
+    chains, cells = _chain_batches(), C.c_longlong()
+    capi.check(lib.bahip_debug_merge_cells_batches(C.byref(cells)))
+    for round_ in range(3):
+        order = everyone[round_:] + everyone[:round_]
+        plan = [(k, [c for c in everyone if c != k and (c + k + round_) % 4 != 0]) for k in order]
+        n_ref = sum(orc.create_surfels_for_keyframe(k, filter_new_surfels=True, covis=covis) for k, covis in plan)
+        with g.lifecycle_batch(keyframes=order):
+            n_got = g.create_surfels_for_keyframes(plan, filter_new_surfels=True, min_observation_count=2)
+        assert n_got == n_ref and g.surfels_size == orc.surfels_size, (round_, n_got, n_ref)
+        assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :orc.surfels_size])), round_
+        Fs = [np.array(list(orc.keyframes[k].frame_T_global), np.float32) for k in order]
+        before = int(orc.surfels.surfel_count)
+        with g.lifecycle_batch(frames=Fs):
+            _, merged = g.merge_surfels_for_keyframes(order, Fs, merge_dist_factor=orc.merge_factor)
+        for k in order:
+            orc.determine_supporting_surfels(k, merge=True)
+        assert merged == before - int(orc.surfels.surfel_count), round_
+        assert np.array_equal(_rows(g.surfel_buf.download()[:, :orc.surfels_size]), _rows(orc.surfel_data[:, :orc.surfels_size])), round_
+        g.compact_surfels(with_active=True)
+        orc.compact_surfels()
+        assert g.surfels_size == orc.surfels_size
+        assert np.array_equal(_rows(g.download_surfels()), _rows(orc.surfel_data[:, :orc.surfels_size])), round_
+    after = C.c_longlong()
+    capi.check(lib.bahip_debug_merge_cells_batches(C.byref(after)))
+    assert _chain_batches() - chains == 3 and after.value - cells.value == 3
