@@ -235,7 +235,7 @@ int bahip_context_create(bahip_context** out, void* hip_stream) {
   ctx->stream = static_cast<hipStream_t>(hip_stream);
   if (const char* e = getenv("BAHIP_ARITHMETIC")) ctx->arithmetic = (strcmp(e, "fast") == 0 || strcmp(e, "1") == 0) ? BAHIP_ARITHMETIC_FAST : BAHIP_ARITHMETIC_EXACT;
   ctx->in.fast_math = ctx->arithmetic;
-  if (const char* e = getenv("BAHIP_INTR_SLICES")) ctx->intr_slices_forced = std::min(std::max(atoi(e), 0), 8);   // experiments: slices of the intrinsics sweep
+  if (const char* e = getenv("BAHIP_INTR_SLICES")) ctx->intr_slices_forced = std::min(std::max(atoi(e), 0), kIntrMaxSlices);   // experiments: slices of the intrinsics sweep
   const bool ok = hipMalloc(&ctx->dev_counter, 16 * sizeof(int)) == hipSuccess && hipMemset(ctx->dev_counter, 0, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_i, 16 * sizeof(int)) == hipSuccess &&
                   hipHostMalloc(&ctx->pinned_f, 128 * sizeof(float)) == hipSuccess &&

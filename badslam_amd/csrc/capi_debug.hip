@@ -230,7 +230,7 @@ int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_
   return 0;
 }
 int bahip_debug_set_intrinsics_slices(bahip_context* ctx, int slices) {
-  ctx->intr_slices_forced = slices > 0 ? std::min(slices, 8) : 0;
+  ctx->intr_slices_forced = slices > 0 ? std::min(slices, kIntrMaxSlices) : 0;
   return 0;
 }
 int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out) {

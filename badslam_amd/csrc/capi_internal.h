@@ -83,6 +83,7 @@ int stage_upload(UploadStage* stage, void* dev_dst, const void* src, size_t byte
                  const void* src2 = nullptr, size_t bytes2 = 0, void* dev_dst2 = nullptr);
 void stage_free(UploadStage* stage);
 
+constexpr int kIntrMaxSlices = 16;   // slices of the intrinsics sweep (capi_solvers.hip): automatic up to 8, forced up to 16 (half the record memory again)
 struct bahip_context {
   UploadStage stage_kfs, stage_covis, stage_window;
   hipStream_t stream = nullptr;

@@ -8,7 +8,7 @@ using namespace bahip_capi;
 // the creation chain (create_chain_kernel): on unless BAHIP_CREATION_CHAIN=0 / bahip_debug_set_creation_chain(0); how many batches took it
 static int g_creation_chain_enabled = bahip_env_int("BAHIP_CREATION_CHAIN", 1);
 static long long g_creation_chain_batches = 0;
-// a merge batch by cell lists (merge_cells_kernel): on unless BAHIP_MERGE_CELLS=0 / bahip_debug_set_merge_cells(0)
+// a merge batch by cell lists (merge_pairs_kernel): on unless BAHIP_MERGE_CELLS=0 / bahip_debug_set_merge_cells(0)
 static int g_merge_cells_enabled = bahip_env_int("BAHIP_MERGE_CELLS", 1);
 static long long g_merge_cells_batches = 0;
 
@@ -117,9 +117,9 @@ int bahip_merge_surfels_for_keyframes(bahip_context* ctx, float merge_dist_facto
   REQUIRE(supporting_view(supporting, supporting_pitch, &sup[0]) == 0, "supporting-surfel planes missing");
   if (merged_count_out) *merged_count_out = 0;
   hipStream_t st = ctx->stream;
-  // By cell lists (round 6; kernels_lifecycle.hip: merge_cells_kernel): when the open lifecycle batch knows every frame of this call and
-  // every frame brings its BA planes (the association sweep reads all of them at once), the members of every (frame, cell) are listed
-  // up front and each frame costs ONE launch of one thread per cell.
+  // By cell lists (round 6; kernels_lifecycle.hip: merge_pairs_kernel): when the open lifecycle batch knows every frame of this call and
+  // the frames' BA planes can all be held at once (the association sweep reads them together), the associated (surfel, frame) pairs are
+  // grouped by (frame, cell) up front and each frame costs ONE launch of one thread per pair.
   bool by_cells = false;
   if (g_merge_cells_enabled && num_frames > 0 && surfels->surfels_size > 0) {
     const bool bounds_valid = ctx->lifecycle_bounds_tiles != 0 && ctx->lifecycle_bounds_data == surfels->data &&

@@ -56,7 +56,7 @@ int bahip_optimize_intrinsics(bahip_context* ctx, int optimize_depth, int optimi
       ctx->intr_bin_cursors = nullptr; ctx->intr_bin_counts_host = nullptr; ctx->intr_bin_records = nullptr;
       ctx->intr_bin_capacity = 0; ctx->intr_bin_wanted = 0;
       HIP_TRY(hipMalloc(&ctx->intr_bin_cursors, sizeof(uint32_t) * (size_t)num_bins * 2));
-      HIP_TRY(hipHostMalloc(&ctx->intr_bin_counts_host, sizeof(uint32_t) * (size_t)num_bins * 8));   // one row of counts per slice
+      HIP_TRY(hipHostMalloc(&ctx->intr_bin_counts_host, sizeof(uint32_t) * (size_t)num_bins * kIntrMaxSlices));   // one row of counts per slice
       ctx->intr_bin_count = num_bins;
       ctx->intr_bin_sets = sets;
     }

@@ -539,7 +539,7 @@ int bahip_debug_read_tile_schedule(bahip_context* ctx, uint32_t* padded_tiles_ou
 int bahip_debug_set_intrinsics_bin_capacity(bahip_context* ctx, int records_per_block);
 int bahip_debug_intrinsics_bin_stats(bahip_context* ctx, uint32_t* capacity_out, uint32_t* most_out, uint64_t* total_out);
 /* The intrinsics step's sweep runs in slices of its schedule when the cloud is large (the per-pair records of a slice are reduced on a
- * second stream while the next slice sweeps; two buffer sets of one slice's records each): 1 .. 8 fixes the number of slices (tests on
+ * second stream while the next slice sweeps; two buffer sets of one slice's records each): 1 .. 16 fixes the number of slices (tests on
  * small scenes), 0 = by the size of the sweep (default).  The sums do not depend on it. */
 int bahip_debug_set_intrinsics_slices(bahip_context* ctx, int slices);
 /* The creation batch's scan + append launch (bahip_create_surfels_for_keyframes) runs a grid handshake and therefore never launches more

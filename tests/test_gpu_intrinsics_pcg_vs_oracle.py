@@ -115,7 +115,7 @@ def test_depth_intrinsics_step_whatever_the_record_buffers_hold(scene, capacity,
         assert most.value <= cap.value
 
 
-@pytest.mark.parametrize("slices", [2, 3, 8])
+@pytest.mark.parametrize("slices", [2, 3, 8, 16])
 def test_depth_intrinsics_step_in_slices(scene, slices):
     """Round 5: on a large cloud the sweep runs in slices of its schedule, the records of a slice being added up on a second stream while
     the next slice sweeps into the other buffer set (capi_solvers.hip: bahip_optimize_intrinsics).  Forced on the small scene: the
