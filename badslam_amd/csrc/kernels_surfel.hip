@@ -426,8 +426,12 @@ geometry_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, Sur
 // its replayed candidate masks and its two-stage candidate loop).  With four wavefronts on every tile a light tile pays the set-up and
 // the LDS combination four times (93 wavefront-us per tile against 60, profiles/r6_shard_experiments.txt); with one wavefront on every
 // tile the launch lasts as long as its heaviest tile.  Same bits as either shape: the sums are defined per class.
+#ifndef BAHIP_HYBRID_WAVES
+#define BAHIP_HYBRID_WAVES 4   // both shapes in one kernel: 128 VGPRs + 17 spilled (60 bytes of scratch per lane); 3 = no spills but three wavefronts
+                               // per SIMD: geometry stage of the emulated 8-rank share 0.145 / 0.144 / 0.148 ms against 0.155 / 0.155 / 0.156 (call 28)
+#endif
 template <bool kUseDepth, bool kUseDesc, bool kActivate>
-__global__ void __launch_bounds__(256) BAHIP_WAVES_ATTR
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BAHIP_HYBRID_WAVES)))
 geometry_hybrid_kernel(Intrinsics in, const KfEntry* __restrict__ kfs, int num_kfs, SurfelsView s, uint32_t activate_count,
                        const uint32_t* __restrict__ sched /* not NULL */, uint32_t padded_tiles, const int* __restrict__ stop) {
   __shared__ float lds[kMaxSumClasses * 8 * 64];
