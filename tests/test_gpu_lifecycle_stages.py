@@ -342,3 +342,35 @@ def test_lifecycle_batches_on_other_scenes(seed, width, height, cell, keyframes)
     after = C.c_longlong()
     capi.check(lib.bahip_debug_merge_cells_batches(C.byref(after)))
     assert _chain_batches() - chains == 3 and after.value - cells.value == 3
+
+
+def test_merge_by_cell_lists_with_crowded_cells(world):
+    """Cells with more members than merge_pairs_kernel requests at once (eight): a few hundred surfels of the cloud are repeated fourteen
+    times each, a fraction of a millimetre apart and with slightly different normals and radii, so that their cells hold 15 and more
+    associated surfels of which some merge and some do not -- the batch by cell lists against the oracle's keyframe-by-keyframe merges,
+    twice over the keyframes (the second round finds the first round's deletions)."""
+    scene, orc, g = world
+    lib = capi.load()
+    data, _ = common.oracle_surfels(orc)
+    n = data.shape[1]
+    rng = np.random.Generator(np.random.PCG64(17))
+    pick = np.sort(rng.choice(n, 300, replace=False))
+    crowd = np.repeat(data[:, pick], 14, axis=1).copy()
+    crowd[:3] += rng.normal(0, 0.0004, (3, crowd.shape[1])).astype(np.float32)
+    crowd[4] *= rng.uniform(0.2, 3.0, crowd.shape[1]).astype(np.float32)     # radius squared: the merge distance scales with the smaller one
+    both = np.concatenate([data, crowd], axis=1)
+    _sync(orc, g, both)
+    order = (0, 1, 2, 3, 1, 0)
+    Fs = [np.array(list(orc.keyframes[k].frame_T_global), np.float32) for k in order]
+    before_cells = C.c_longlong()
+    capi.check(lib.bahip_debug_merge_cells_batches(C.byref(before_cells)))
+    before = int(orc.surfels.surfel_count)
+    with g.lifecycle_batch(frames=Fs):
+        _, merged = g.merge_surfels_for_keyframes(order, Fs, merge_dist_factor=orc.merge_factor)
+    for k in order:
+        orc.determine_supporting_surfels(k, merge=True)
+    after_cells = C.c_longlong()
+    capi.check(lib.bahip_debug_merge_cells_batches(C.byref(after_cells)))
+    assert after_cells.value - before_cells.value == 1
+    assert merged == before - int(orc.surfels.surfel_count) and merged > 1000, merged
+    assert np.array_equal(_rows(g.surfel_buf.download()[:, :both.shape[1]]), _rows(orc.surfel_data[:, :both.shape[1]]))
