@@ -259,8 +259,8 @@ hipError_t launch_merge_batch_lists(hipStream_t st, const Intrinsics& in, const 
                                     uint32_t* members, void* member_cell, uint32_t* frame_first /* [num_frames + 1] */, void* scan_temp, size_t scan_temp_bytes);
 size_t merge_batch_scan_temp_bytes(size_t entries);
 void launch_merge_pairs(hipStream_t st, const SurfelsView& s, const uint32_t* members, const void* member_cell, uint32_t first_pair,
-                        uint32_t end_pair, uint32_t step, uint32_t* deleted_at, float cell_merge_dist_sq, float cos_thr, uint32_t* deleted_count);
-void launch_merge_batch_apply(hipStream_t st, const SurfelsView& s, const uint32_t* deleted_at);
+                        uint32_t end_pair, uint32_t step, uint32_t* deleted_at, float cell_merge_dist_sq, float cos_thr);
+void launch_merge_batch_apply(hipStream_t st, const SurfelsView& s, const uint32_t* deleted_at, uint32_t* deleted_count);   // writes the markers, adds their number
 // a creation batch: scan + append at *size_in + the new size into *size_out (or *capacity_exceeded raised and nothing appended) in one
 // launch; group_words: create_append_groups() words, cleared before tag 1 and whenever a tag (1 .. 255) would repeat
 int create_append_groups();

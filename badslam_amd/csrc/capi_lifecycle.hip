@@ -187,10 +187,10 @@ int bahip_merge_surfels_for_keyframes(bahip_context* ctx, float merge_dist_facto
       uint32_t* counter = reinterpret_cast<uint32_t*>(ctx->dev_counter) + 3;   // the deferred count of bahip_take_merged_count
       for (int j = 0; j < num_frames; ++j) {
         launch_merge_pairs(st, s, members, member_cell, first[(size_t)j], first[(size_t)j + 1], (uint32_t)j, deleted_at, cell_merge_dist_sq,
-                           kCosNormalCompat, counter);
+                           kCosNormalCompat);
         CHECK_LAUNCH();
       }
-      launch_merge_batch_apply(st, s, deleted_at);
+      launch_merge_batch_apply(st, s, deleted_at, counter);
       CHECK_LAUNCH();
       // (the planes are not used; the batch's contract is that they end empty)
       if (ctx->supporting_planes_empty != sup[0].b[0]) launch_supporting_fill(st, sup[0], ctx->in.cf_width, ctx->in.cf_height);

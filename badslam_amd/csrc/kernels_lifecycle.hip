@@ -274,7 +274,7 @@ __device__ __forceinline__ bool merge_test_rows(const MergeRows& a, const MergeR
 __global__ void __launch_bounds__(kLcBlock)
 merge_pairs_kernel(SurfelsView s, const uint32_t* __restrict__ members, const uint2* __restrict__ member_cell,
                    uint32_t first, uint32_t end /* the pairs of this frame */, uint32_t step,
-                   uint32_t* __restrict__ deleted_at, float cell_merge_dist_sq, float cos_thr, uint32_t* __restrict__ deleted_count) {
+                   uint32_t* __restrict__ deleted_at, float cell_merge_dist_sq, float cos_thr) {
   for (uint32_t pos = first + blockIdx.x * kLcBlock + threadIdx.x; pos < end; pos += gridDim.x * kLcBlock) {
     const uint2 c = member_cell[pos];
     const uint32_t i = members[pos];
@@ -311,9 +311,9 @@ merge_pairs_kernel(SurfelsView s, const uint32_t* __restrict__ members, const ui
       else del = merge_test_rows(ri, r0, cos_thr, cell_merge_dist_sq) || (!d1 && merge_test_rows(ri, r1, cos_thr, cell_merge_dist_sq)) ||
                  (!d2 && merge_test_rows(ri, r2, cos_thr, cell_merge_dist_sq));
     }
+    // (counted by merge_batch_apply_kernel: an atomic per wavefront on ONE counter here -- ~2000 per launch, served one after the other --
+    // cost 3.4 of the launch's 16 us)
     if (del) deleted_at[i] = step;
-    const unsigned long long b = __ballot(del);
-    if (b && (threadIdx.x & 63) == __ffsll((long long)b) - 1) atomicAdd(deleted_count, (uint32_t)__popcll(b));
   }
 }
 // frame_first[j] = the first pair of frame j (offsets[j * cells]); [n] = all pairs
@@ -322,10 +322,22 @@ merge_batch_frame_first_kernel(const uint32_t* __restrict__ offsets, uint32_t ce
   const uint32_t j = blockIdx.x * kLcBlock + threadIdx.x;
   if (j <= num_frames) frame_first[j] = offsets[(size_t)j * cells];
 }
+// ... and counts them: one atomic per workgroup of a fixed grid
 __global__ void __launch_bounds__(kLcBlock)
-merge_batch_apply_kernel(SurfelsView s, const uint32_t* __restrict__ deleted_at) {
-  const uint32_t i = blockIdx.x * kLcBlock + threadIdx.x;
-  if (i < s.size && deleted_at[i] != kInvalidIndex) s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits);
+merge_batch_apply_kernel(SurfelsView s, const uint32_t* __restrict__ deleted_at, uint32_t* __restrict__ deleted_count) {
+  __shared__ uint32_t wave_counts[kLcBlock / 64];
+  uint32_t mine = 0;
+  for (uint32_t i = blockIdx.x * kLcBlock + threadIdx.x; i < s.size; i += gridDim.x * kLcBlock) {
+    if (deleted_at[i] != kInvalidIndex) { s.row(kSurfelX)[i] = __uint_as_float(kDeletedSurfelBits); ++mine; }
+  }
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+  if ((threadIdx.x & 63) == 0) wave_counts[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < kLcBlock / 64; ++w) total += wave_counts[w];
+    if (total) atomicAdd(deleted_count, total);
+  }
 }
 
 // ---- creation ---------------------------------------------------------------------------------------
@@ -930,13 +942,13 @@ size_t merge_batch_scan_temp_bytes(size_t entries) {
   return bytes;
 }
 void launch_merge_pairs(hipStream_t st, const SurfelsView& s, const uint32_t* members, const void* member_cell, uint32_t first_pair,
-                        uint32_t end_pair, uint32_t step, uint32_t* deleted_at, float cell_merge_dist_sq, float cos_thr, uint32_t* deleted_count) {
+                        uint32_t end_pair, uint32_t step, uint32_t* deleted_at, float cell_merge_dist_sq, float cos_thr) {
   if (end_pair <= first_pair) return;
   hipLaunchKernelGGL(merge_pairs_kernel, dim3(g1(end_pair - first_pair)), dim3(kLcBlock), 0, st, s, members, static_cast<const uint2*>(member_cell),
-                     first_pair, end_pair, step, deleted_at, cell_merge_dist_sq, cos_thr, deleted_count);
+                     first_pair, end_pair, step, deleted_at, cell_merge_dist_sq, cos_thr);
 }
-void launch_merge_batch_apply(hipStream_t st, const SurfelsView& s, const uint32_t* deleted_at) {
-  if (s.size) hipLaunchKernelGGL(merge_batch_apply_kernel, dim3(g1(s.size)), dim3(kLcBlock), 0, st, s, deleted_at);
+void launch_merge_batch_apply(hipStream_t st, const SurfelsView& s, const uint32_t* deleted_at, uint32_t* deleted_count) {
+  if (s.size) hipLaunchKernelGGL(merge_batch_apply_kernel, dim3(std::min<unsigned>(g1(s.size), 512u)), dim3(kLcBlock), 0, st, s, deleted_at, deleted_count);
 }
 void launch_create_flag(hipStream_t st, const Intrinsics& in, const KfEntry& frame, const SupportingView& sup, uint8_t* flags, bool leave_planes_empty) {
   hipLaunchKernelGGL(create_flag_kernel, dim3(g1(in.cf_width * in.cf_height)), dim3(kLcBlock), 0, st, in, frame, sup, flags, leave_planes_empty ? 1 : 0);
