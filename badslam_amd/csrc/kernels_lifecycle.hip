@@ -76,14 +76,26 @@ lifecycle_visible_tiles_kernel(Intrinsics in, const float* __restrict__ frames_F
   wb.cx = wb.cy = wb.cz = 0.f; wb.r = -1.f;
   if (tile < tiles) wb = spheres[tile];
   const int f0 = blockIdx.y * kVisibleFramesPerGroup, f1 = min(num_frames, f0 + kVisibleFramesPerGroup);
+  // one reservation per workgroup and frame: returning atomics on ONE cursor are served one after the other (a reservation per wavefront
+  // was 536 of them per frame)
+  __shared__ uint32_t wave_count[kLcBlock / 64];
+  __shared__ uint32_t group_base;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int f = f0; f < f1; ++f) {
     const bool visible = sphere_may_project(in, frames_F + 12 * f, wb);   // (r < 0: never)
     const unsigned long long m = __ballot(visible);
-    if (!m) continue;
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(&cursors[f], (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (visible) lists[(size_t)f * tiles + base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tile;
+    if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (int w = 0; w < kLcBlock / 64; ++w) total += wave_count[w];
+      group_base = total ? atomicAdd(&cursors[f], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t before = group_base;
+    for (int w = 0; w < wave; ++w) before += wave_count[w];
+    if (visible) lists[(size_t)f * tiles + before + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tile;
+    __syncthreads();   // (wave_count and group_base are reused by the next frame)
   }
 }
 __global__ void __launch_bounds__(kLcBlock)
