@@ -125,8 +125,12 @@ def build_scene(args, log):
             poses_gt.append(se3.mul(T0, se3.mul(se3.exp(np.concatenate([xi[:3], np.zeros(3)])), se3.exp(np.concatenate([np.zeros(3), xi[3:]])))))
     # rendered on a pool of host processes (the same frames in the same order whatever the pool size), preprocessed on the GPU
     workers = None if args.keyframes * args.width * args.height >= 64 * 640 * 480 else 1
+    keep_frames = [] if os.environ.get("BENCH_KEEP_FRAMES") else None   # (tests that build further instances of the same scene)
     for T, (raw, rgb) in zip(poses_gt, synthetic.render_many(poses_gt, planes, cam, args.width, args.height, 1.0 / 5000, workers)):
         ba.AddKeyframe(raw, rgb, T)
+        if keep_frames is not None:
+            keep_frames.append((raw, rgb))
+    build_scene.frames = keep_frames
     log(f"rendered + preprocessed {args.keyframes} keyframes in {time.time() - t0:.1f}s")
     t1 = time.time()
     # surfels from the keyframes (unfiltered creation, reference B/direct_ba.cc:340-405)

@@ -26,6 +26,7 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("BENCH_KEEP_FRAMES", "1")   # bench.build_scene keeps the rendered frames: test_c3_eight_surfel_shards_... builds the ranks' instances from them
 
 
 def _shapes(lib, tile_waves, pose_parts):
@@ -561,3 +562,109 @@ def test_c5_resolution_slice_with_intrinsics_matches_oracle():
     assert np.array_equal(np.asarray(cc, np.float32).view(np.uint32), ref_cc.view(np.uint32)), (cc, ref_cc)
     assert np.float32(a).view(np.uint32) == np.float32(orc.dp.a).view(np.uint32)
     assert np.array_equal(ba.cfactor().view(np.uint32), np.asarray(orc.cfactor, np.float32).view(np.uint32))
+
+
+def test_c3_eight_surfel_shards_are_the_unsharded_run(c3):
+    """BASELINE configs[2] sharded by surfels over EIGHT ranks -- what `bench.py --gpus 8` runs, on one GPU: eight vis::DirectBA
+    instances (host threads) hold the 200 keyframes and every eighth chunk of 4096 of the 3 M surfels each and run
+    BundleAdjustment(3 iterations) in lockstep; the all-reduce hook of the C ABI is served by an in-process loopback that sums the
+    ranks' device buffers in a fixed order (RCCL refuses eight ranks on one device; the exchange is an integer sum either way).  Every
+    rank must end with the poses of the unsharded call, bit for bit, and the union of the shards with its surfels.  At an eighth of the
+    cloud (5 860 tiles) the ranks' geometry steps take the HYBRID launch shape and the pose sweeps share every tile among four
+    wavefronts, neither of which the one-GPU run does: the sums' definitions (classes, fixed tree, fixed point) carry the identity."""
+    import threading
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from badslam_amd import multigpu
+    from badslam_amd.directba import DirectBA
+    ba, data, poses_gt, args = c3
+    frames = bench.build_scene.frames
+    assert frames is not None and len(frames) == args.keyframes
+    K, N, WORLD, ITERATIONS = args.keyframes, data.shape[1], 8, 3
+    lib = capi.load()
+    start_poses = [ba.keyframe_pose(k) for k in range(K)]
+    call = dict(do_surfel_updates=False, optimize_poses=True, optimize_geometry=True, min_iterations=ITERATIONS, max_iterations=ITERATIONS,
+                increase_ba_iteration_count=False)
+    # the unsharded call (device-driven loop)
+    ba.upload_surfels(data)
+    ba.set_ba_iteration_counts(1, 1)       # no end tasks: the surfel set and its order stay
+    assert ba.BundleAdjustment(**call)[0] == ITERATIONS
+    ref_poses = np.asarray([ba.keyframe_pose(k) for k in range(K)], np.float32)
+    ref_surfels = ba.download_surfels(8)
+    for k, T in enumerate(start_poses):     # leave the shared fixture as it was
+        ba.set_keyframe_pose(k, T)
+    ba.upload_surfels(data)
+
+    cam = synthetic.test_camera(args.width, args.height)
+    shards = [multigpu.shard_chunks(N, r, WORLD, 4096) for r in range(WORLD)]
+    ranks = []
+    for r in range(WORLD):
+        rb = DirectBA(int(shards[r].size) + 4096, 1.0 / 5000, 40.0, args.cell, args.width, args.height, cam, cam)
+        for (raw, rgb), T in zip(frames, poses_gt):
+            rb.AddKeyframe(raw, rgb, T)
+        for k, T in enumerate(start_poses):
+            rb.set_keyframe_pose(k, T)
+        rb.upload_surfels(np.ascontiguousarray(data[:, shards[r]]))
+        rb.set_ba_iteration_counts(1, 1)
+        ranks.append(rb)
+
+    barrier, slots, errors, calls = threading.Barrier(WORLD), [None] * WORLD, [], [0]
+
+    def hook_for(rank):
+        def _hook(device_ptr, count, dtype, _stream, _user):
+            try:
+                torch.cuda.synchronize()
+                slots[rank] = (device_ptr, count, dtype)
+                barrier.wait(timeout=120)
+                if rank == 0:
+                    views = [torch.as_tensor(multigpu._DevicePtrView(p, n, d), device="cuda") for p, n, d in slots]
+                    total = views[0].clone()
+                    for v in views[1:]:
+                        total += v
+                    for v in views:
+                        v.copy_(total)
+                    torch.cuda.synchronize()
+                    calls[0] += 1
+                barrier.wait(timeout=120)
+                return 0
+            except Exception as e:   # noqa: BLE001 -- surfaces as a bahip error in the calling thread
+                print("loopback all-reduce failed:", e, flush=True)
+                barrier.abort()
+                return 1
+        return capi.ALLREDUCE_FN(_hook)
+
+    hooks = [hook_for(r) for r in range(WORLD)]
+    results = [None] * WORLD
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            rb = ranks[rank]
+            capi.check(lib.bahip_context_set_allreduce(rb.backend_context().handle, hooks[rank], None))
+            done, _ = rb.BundleAdjustment(**call)
+            results[rank] = dict(done=done, poses=np.asarray([rb.keyframe_pose(k) for k in range(K)], np.float32), surfels=rb.download_surfels(8))
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+            barrier.abort()
+
+    hybrid_before = C.c_longlong()
+    capi.check(lib.bahip_debug_geometry_hybrid_launches(C.byref(hybrid_before)))
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(r is not None and r["done"] == ITERATIONS for r in results)
+    hybrid_after = C.c_longlong()
+    capi.check(lib.bahip_debug_geometry_hybrid_launches(C.byref(hybrid_after)))
+    assert hybrid_after.value - hybrid_before.value >= WORLD * (ITERATIONS - 1)     # every rank, from its second iteration on
+    assert calls[0] >= ITERATIONS                                                    # at least one exchange per pose phase
+    merged = np.zeros_like(ref_surfels)
+    for r in range(WORLD):
+        assert np.array_equal(results[r]["poses"].view(np.uint32), ref_poses.view(np.uint32)), r
+        merged[:, shards[r]] = results[r]["surfels"]
+    assert np.array_equal(merged.view(np.uint32), ref_surfels.view(np.uint32))
+    for rb in ranks:
+        rb.close()
