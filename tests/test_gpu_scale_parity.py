@@ -282,6 +282,7 @@ def _bench_scene(**overrides):
     for k, v in overrides.items():
         setattr(args, k, v)
     ba, data, poses_gt = bench.build_scene(args, lambda m: None)
+    args.frames = bench.build_scene.frames   # (the rendered frames of THIS scene: the next call of build_scene replaces the attribute)
     return ba, data, poses_gt, args
 
 
@@ -574,12 +575,10 @@ def test_c3_eight_surfel_shards_are_the_unsharded_run(c3):
     wavefronts, neither of which the one-GPU run does: the sums' definitions (classes, fixed tree, fixed point) carry the identity."""
     import threading
     import torch
-    sys.path.insert(0, ROOT)
-    import bench
     from badslam_amd import multigpu
     from badslam_amd.directba import DirectBA
     ba, data, poses_gt, args = c3
-    frames = bench.build_scene.frames
+    frames = args.frames
     assert frames is not None and len(frames) == args.keyframes
     K, N, WORLD, ITERATIONS = args.keyframes, data.shape[1], 8, 3
     lib = capi.load()
