@@ -110,6 +110,10 @@ struct PoseLoopControl {
   int min_iterations = 0;
   int* round_log = nullptr;    // mapped host memory: [log_slot] = work items that iterated in this round (for the stage timers)
   int log_slot = 0;
+  // 0: this launch writes nothing to the host copies (counters, control words, sequence number) and needs no system-scope fence -- the
+  // launches of a queued loop that the host does not wait for (round 6: every solve launch used to publish, ~5 us of posted PCIe writes
+  // and two system-scope fences each, 2.7 launches per iteration); the launch whose sequence number the host polls publishes for all
+  int publish = 1;
   // >= 0 (with phase_end, at most 1024 work items): when the phase is complete and the loop goes on, this launch also runs the top
   // of the next iteration -- mode 1: activation window + propagation, 2: propagation -- and sets up its work items
   // (kernels_pose.hip: iteration_begin_body); the caller then queues no launch_iteration_begin for that iteration

@@ -501,6 +501,7 @@ int bahip_alternating_iterations(bahip_context* ctx, const bahip_alternating_opt
         PoseLoopControl loop;
         loop.ctl = ctx->dev_loop_ctl; loop.host_ctl = ctx->host_loop_ctl;
         loop.phase_end = r == phase_rounds - 1 ? 1 : 0;
+        loop.publish = (i == opt->max_iterations - 1 && r == phase_rounds - 1) ? 1 : 0;   // the launch the host waits for (below) publishes for all
         loop.iteration = i; loop.min_iterations = opt->min_iterations;
         loop.round_log = log_slot < kLoopLogSlots ? ctx->host_loop_ctl + kLoopWords : nullptr;
         loop.log_slot = log_slot++;

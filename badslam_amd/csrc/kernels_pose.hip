@@ -912,7 +912,8 @@ __device__ __forceinline__ void pose_solve_body(PoseWork* __restrict__ work, int
     atomicAdd(&loop.ctl[kLoopSteps], steps_here);
     atomicAdd(&counters[kPoseCounterWorked], steps_here);
   }
-  __threadfence_system();
+  const bool publish = loop.publish != 0;
+  if (publish) __threadfence_system(); else __threadfence();
   __syncthreads();
   __shared__ int is_last, begins_next;
   if (threadIdx.x == 0) { is_last = atomicAdd(&counters[kPoseCounterTicket], 1) == (int)gridDim.x - 1; begins_next = 0; }
@@ -939,14 +940,14 @@ __device__ __forceinline__ void pose_solve_body(PoseWork* __restrict__ work, int
             begins_next = 1;
         }
       }
-      for (int c = 0; c < kLoopWords; ++c) loop.host_ctl[c] = __hip_atomic_load(&loop.ctl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (publish) for (int c = 0; c < kLoopWords; ++c) loop.host_ctl[c] = __hip_atomic_load(&loop.ctl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     int* host_counters = reinterpret_cast<int*>(host_out + num_work);
     const int c = threadIdx.x;
-    if (c < kPoseTailRecords * 32 && c != kPoseCounterTicket && c != kPoseCounterSequence)
+    if (publish && c < kPoseTailRecords * 32 && c != kPoseCounterTicket && c != kPoseCounterSequence)
       host_counters[c] = __hip_atomic_load(&counters[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    if (publish) __threadfence_system(); else __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) counters[kPoseCounterTicket] = 0;
     if (kBeginsNext) {
@@ -954,11 +955,11 @@ __device__ __forceinline__ void pose_solve_body(PoseWork* __restrict__ work, int
       // before the sequence number says that this launch is complete
       if (begins_next) {   // workgroup-uniform (read after the barrier above)
         iteration_begin_body(frames, num_work, loop.next_mode, loop.in_window, loop.covis_offsets, loop.covis_indices, work, Hb, host_out);
-        __threadfence_system();
+        if (publish) __threadfence_system(); else __threadfence();
         __syncthreads();
       }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&host_counters[kPoseCounterSequence], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (publish && threadIdx.x == 0) __hip_atomic_store(&host_counters[kPoseCounterSequence], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
