@@ -814,9 +814,11 @@ __device__ __forceinline__ void iteration_begin_body(KfEntry* __restrict__ frame
     pw.moved = 0;
     for (int c = 0; c < 7; ++c) { pw.T[c] = frames[k].global_T_frame[c]; pw.T0[c] = frames[k].global_T_frame[c]; }
     for (int c = 0; c < 12; ++c) pw.F[c] = frames[k].pose.F[c];
-    for (int c = 0; c < kHbStride; ++c) Hb[(size_t)k * kHbStride + c] = 0;
     if (pw.done) host_out[k] = pw;
   }
+  // the normal equations of the phase start at zero: consecutive threads clear consecutive words (a thread per work item clearing its own
+  // 448 bytes issued 56 stores of 64 lines each)
+  for (int e = threadIdx.x; e < num_kfs * kHbStride; e += blockDim.x) Hb[e] = 0;
   int* counters = reinterpret_cast<int*>(work + num_kfs);
   const int num_inactive = __syncthreads_count(inactive ? 1 : 0);
   if (threadIdx.x < kPoseTailRecords * 32) counters[threadIdx.x] = (threadIdx.x == kPoseCounterConverged) ? num_inactive : 0;
